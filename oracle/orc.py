@@ -1,0 +1,394 @@
+"""ORACLE -- test infrastructure only.
+
+ctypes binding of ``oracle/liborc.so`` (the CPU restatement of the reference backend).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package ``svin_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BLOCK_POSE, BLOCK_SPEEDBIAS, BLOCK_HPOINT = 0, 1, 2
+DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT, DIST_RADTAN8 = 0, 1, 2, 3
+LOSS_NONE, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+
+u64, u32, f64, i32 = C.c_uint64, C.c_uint32, C.c_double, C.c_int
+pd = C.POINTER(C.c_double)
+pu64 = C.POINTER(C.c_uint64)
+pu32 = C.POINTER(C.c_uint32)
+pi32 = C.POINTER(C.c_int)
+
+
+def build(force=False, native=False, out=None):
+    """Compile the restatement (g++).  ``native`` builds with -march=native into ``out``."""
+    target = out or os.path.join(_HERE, "liborc.so")
+    if native:
+        srcs = [os.path.join(_HERE, f) for f in ("orc_math.cpp orc_errors.cpp orc_map.cpp orc_marg.cpp "
+                                                 "orc_estimator.cpp orc_capi.cpp").split()]
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-shared", "-o", target] + srcs)
+        return target
+    if force or not os.path.exists(target):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return target
+
+
+def lib(path=None):
+    global _LIB
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _LIB is None:
+        _LIB = _bind(C.CDLL(build()))
+    return _LIB
+
+
+def _bind(L):
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+    vp = C.c_void_p
+    sig("orc_create", vp)
+    sig("orc_destroy", None, vp)
+    sig("orc_new_id", u64, vp)
+    sig("orc_estimator_map", vp, vp)
+    sig("orc_add_camera", i32, vp, i32, pd, pd, i32, i32, pd)
+    sig("orc_add_imu", i32, vp, pd)
+    sig("orc_set_sonar_extrinsics", None, vp, pd)
+    sig("orc_add_states", i32, vp, u64, u32, u32, u64, i32, pd, i32, pu32, pd, i32, i32, pd, i32, pd, f64)
+    sig("orc_add_landmark", i32, vp, u64, pd)
+    sig("orc_add_observation", u64, vp, u64, u64, u64, u64, pd, f64)
+    sig("orc_remove_observation", i32, vp, u64, u64, u64, u64)
+    sig("orc_remove_observation_by_id", i32, vp, u64)
+    sig("orc_optimize", None, vp, u64, u64, i32)
+    sig("orc_set_time_limit", i32, vp, f64, i32)
+    sig("orc_apply_marginalization", i32, vp, u64, u64, pu64, i32, pi32)
+    sig("orc_get_T_WS", i32, vp, u64, pd)
+    sig("orc_get_speed_and_bias", i32, vp, u64, u64, pd)
+    sig("orc_get_camera_sensor_states", i32, vp, u64, u64, pd)
+    sig("orc_get_landmark", i32, vp, u64, pd, pd, pd, pi32)
+    sig("orc_set_T_WS", i32, vp, u64, pd)
+    sig("orc_set_speed_and_bias", i32, vp, u64, u64, pd)
+    sig("orc_set_landmark", i32, vp, u64, pd)
+    sig("orc_num_frames", u64, vp)
+    sig("orc_num_landmarks", u64, vp)
+    sig("orc_current_keyframe_id", u64, vp)
+    sig("orc_current_frame_id", u64, vp)
+    sig("orc_frame_id_by_age", u64, vp, u64)
+    sig("orc_is_keyframe", i32, vp, u64)
+    sig("orc_is_in_imu_window", i32, vp, u64)
+    sig("orc_frame_ids", i32, vp, pu64, i32)
+    sig("orc_landmark_ids", i32, vp, pu64, i32)
+    sig("orc_summary", None, vp, pd)
+    sig("orc_cost_history", i32, vp, pd, i32)
+    sig("orc_set_solver_options", None, vp, f64, f64, f64, i32)
+    sig("orc_marg_size", i32, vp)
+    sig("orc_marg_get", i32, vp, pd, pd, pd, pd)
+    sig("orc_marg_blocks", i32, vp, pu64, pi32, pi32, pd, i32)
+    sig("orc_describe_block", i32, vp, u64, pu64, pi32, pi32)
+    sig("orc_map_create", vp)
+    sig("orc_map_destroy", None, vp)
+    sig("orc_map_add_param", i32, vp, u64, i32, pd)
+    sig("orc_map_set_constant", i32, vp, u64, i32)
+    sig("orc_map_get_param", i32, vp, u64, pd)
+    sig("orc_map_set_param", i32, vp, u64, pd)
+    sig("orc_map_add_reproj", u64, vp, i32, pd, pd, pd, pd, i32, u64, u64, u64)
+    sig("orc_map_add_imu", u64, vp, i32, pu32, pd, pd, u32, u32, u32, u32, pu64)
+    sig("orc_map_add_pose_error", u64, vp, pd, pd, u64)
+    sig("orc_map_add_pose_error_var", u64, vp, pd, f64, f64, u64)
+    sig("orc_map_add_speedbias_error", u64, vp, pd, f64, f64, f64, u64)
+    sig("orc_map_add_relpose_error", u64, vp, f64, f64, u64, u64)
+    sig("orc_map_add_sonar_error", u64, vp, pd, f64, f64, f64, i32, pd, u64)
+    sig("orc_map_add_depth_error", u64, vp, f64, f64, f64, u64)
+    sig("orc_map_add_hpoint_error", u64, vp, pd, f64, u64)
+    sig("orc_map_remove_residual", i32, vp, u64)
+    sig("orc_map_residual_dims", i32, vp, u64, pi32, i32)
+    sig("orc_map_eval", i32, vp, u64, pd, pd, pd)
+    sig("orc_map_is_jacobian_correct", i32, vp, u64, f64, pd)
+    sig("orc_map_get_lhs", i32, vp, u64, pd)
+    sig("orc_map_solve", None, vp, i32, i32, pd)
+    sig("orc_map_set_tolerances", None, vp, f64, f64, f64)
+    sig("orc_map_linearize", i32, vp, f64, pi32, pi32, pi32, pd)
+    sig("orc_map_linearize_get", None, pu64, pi32, pd, pd, pd, pd, pu64, pd, pd)
+    sig("orc_project", i32, i32, pd, pd, i32, i32, pd, pd, pd)
+    sig("orc_project_homogeneous", i32, i32, pd, pd, i32, i32, pd, pd, pd)
+    sig("orc_distort", i32, i32, pd, pd, pd, pd)
+    sig("orc_manifold_plus", None, i32, pd, pd, pd)
+    sig("orc_manifold_minus", None, i32, pd, pd, pd)
+    sig("orc_manifold_plus_jacobian", None, i32, pd, pd)
+    sig("orc_manifold_lift_jacobian", None, i32, pd, pd)
+    sig("orc_pose_minus_jacobian", None, pd, pd)
+    sig("orc_sym_eig", None, pd, i32, pd, pd)
+    sig("orc_right_jacobian", None, pd, pd)
+    sig("orc_transformation_inverse", None, pd, pd)
+    sig("orc_transformation_compose", None, pd, pd, pd)
+    sig("orc_init_pose_from_imu", i32, i32, pu32, pd, pd)
+    sig("orc_imu_propagation", i32, i32, pu32, pd, pd, pd, pd, u32, u32, u32, u32, pd, pd)
+    sig("orc_map_imu_state", i32, vp, u64, pd)
+    return L
+
+
+# ----------------------------------------------------------------------------- helpers
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(pd)
+
+
+def arr(x, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(x, dtype=dtype))
+
+
+def u32ptr(a):
+    return a.ctypes.data_as(pu32)
+
+
+def u64ptr(a):
+    return a.ctypes.data_as(pu64)
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(pi32)
+
+
+def imu_params_vector(p):
+    """dict -> 13-vector [a_max g_max sigma_g_c sigma_a_c sigma_bg sigma_ba sigma_gw_c sigma_aw_c tau g a0(3)]"""
+    return arr([p["a_max"], p["g_max"], p["sigma_g_c"], p["sigma_a_c"], p["sigma_bg"], p["sigma_ba"],
+                p["sigma_gw_c"], p["sigma_aw_c"], p["tau"], p["g"]] + list(p.get("a0", [0, 0, 0])))
+
+
+class OracleMap:
+    """Thin object wrapper over the raw map API (owns the map unless ``handle`` is given)."""
+
+    def __init__(self, handle=None, L=None):
+        self.L = L or lib()
+        self.own = handle is None
+        self.h = C.c_void_p(self.L.orc_map_create()) if handle is None else C.c_void_p(handle)
+
+    def __del__(self):
+        if getattr(self, "own", False) and self.h:
+            self.L.orc_map_destroy(self.h)
+            self.h = None
+
+    def add_param(self, pid, btype, x):
+        x = arr(x)
+        assert self.L.orc_map_add_param(self.h, pid, btype, dptr(x))
+
+    def get_param(self, pid):
+        x = np.zeros(9)
+        n = self.L.orc_map_get_param(self.h, pid, dptr(x))
+        return x[:n].copy()
+
+    def set_param(self, pid, x):
+        x = arr(x)
+        assert self.L.orc_map_set_param(self.h, pid, dptr(x))
+
+    def set_constant(self, pid, c=True):
+        assert self.L.orc_map_set_constant(self.h, pid, 1 if c else 0)
+
+    def add_reproj(self, model, intr, dist, uv, info, loss, pose, lm, ext):
+        intr, dist8, uv, info = arr(intr), np.zeros(8), arr(uv), arr(info).reshape(-1)
+        dist8[:len(dist)] = dist
+        return self.L.orc_map_add_reproj(self.h, model, dptr(intr), dptr(dist8), dptr(uv), dptr(info), loss, pose, lm, ext)
+
+    def add_imu(self, t, meas, par, t0, t1, ids):
+        t = arr(t, np.uint32).reshape(-1, 2)
+        meas = arr(meas).reshape(-1, 6)
+        par, ids = arr(par), arr(ids, np.uint64)
+        return self.L.orc_map_add_imu(self.h, len(t), u32ptr(t), dptr(meas), dptr(par), t0[0], t0[1], t1[0], t1[1], u64ptr(ids))
+
+    def dims(self, rid):
+        d = np.zeros(64, np.int32)
+        n = self.L.orc_map_residual_dims(self.h, rid, i32ptr(d), 64)
+        assert n >= 2
+        m, nb = int(d[0]), int(d[1])
+        return m, [(int(d[2 + 2 * i]), int(d[3 + 2 * i])) for i in range(nb)]
+
+    def eval(self, rid, jac=True):
+        m, blocks = self.dims(rid)
+        r = np.zeros(m)
+        if not jac:
+            assert self.L.orc_map_eval(self.h, rid, dptr(r), None, None)
+            return r
+        J = np.zeros(sum(m * b[0] for b in blocks))
+        Jm = np.zeros(sum(m * b[1] for b in blocks))
+        assert self.L.orc_map_eval(self.h, rid, dptr(r), dptr(J), dptr(Jm))
+        Js, Jms, o, om = [], [], 0, 0
+        for dim, mdim in blocks:
+            Js.append(J[o:o + m * dim].reshape(m, dim).copy()); o += m * dim
+            Jms.append(Jm[om:om + m * mdim].reshape(m, mdim).copy()); om += m * mdim
+        return r, Js, Jms
+
+    def is_jacobian_correct(self, rid, rel_tol=1e-6):
+        w = np.zeros(1)
+        ok = self.L.orc_map_is_jacobian_correct(self.h, rid, rel_tol, dptr(w))
+        return bool(ok), float(w[0])
+
+    def get_lhs(self, pid, mdim):
+        H = np.zeros((mdim, mdim))
+        self.L.orc_map_get_lhs(self.h, pid, dptr(H))
+        return H
+
+    def solve(self, max_iter=50, verbose=False):
+        s = np.zeros(6)
+        self.L.orc_map_solve(self.h, max_iter, 1 if verbose else 0, dptr(s))
+        return dict(initial_cost=s[0], final_cost=s[1], iterations=int(s[2]), successful=int(s[3]),
+                    termination=int(s[4]), time=s[5])
+
+    def linearize(self, mu=0.0):
+        d, nc, nl = C.c_int(), C.c_int(), C.c_int()
+        cost = np.zeros(1)
+        self.L.orc_map_linearize(self.h, mu, C.byref(d), C.byref(nc), C.byref(nl), dptr(cost))
+        d, nc, nl = d.value, nc.value, nl.value
+        camIds, camOff = np.zeros(nc, np.uint64), np.zeros(nc, np.int32)
+        S, g, A, b = np.zeros((d, d)), np.zeros(d), np.zeros((d, d)), np.zeros(d)
+        lmIds, V, bl = np.zeros(nl, np.uint64), np.zeros((nl, 3, 3)), np.zeros((nl, 3))
+        self.L.orc_map_linearize_get(u64ptr(camIds), i32ptr(camOff), dptr(S), dptr(g), dptr(A), dptr(b), u64ptr(lmIds),
+                                     dptr(V), dptr(bl))
+        return dict(d=d, cam_ids=camIds, cam_off=camOff, S=S, g=g, A=A, b=b, lm_ids=lmIds, V=V, bl=bl, cost=float(cost[0]))
+
+
+class OracleEstimator:
+    """Object wrapper mirroring okvis::Estimator over the C API."""
+
+    def __init__(self, L=None):
+        self.L = L or lib()
+        self.h = C.c_void_p(self.L.orc_create())
+        self.n_cam = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def new_id(self):
+        return int(self.L.orc_new_id(self.h))
+
+    def map(self):
+        return OracleMap(handle=self.L.orc_estimator_map(self.h), L=self.L)
+
+    def add_camera(self, model, intr, dist, w, h, sigmas):
+        intr, d8, sig = arr(intr), np.zeros(8), arr(sigmas)
+        d8[:len(dist)] = dist
+        self.n_cam += 1
+        return self.L.orc_add_camera(self.h, model, dptr(intr), dptr(d8), w, h, dptr(sig))
+
+    def add_imu(self, params):
+        p = imu_params_vector(params)
+        return self.L.orc_add_imu(self.h, dptr(p))
+
+    def set_sonar_extrinsics(self, T):
+        T = arr(T)
+        self.L.orc_set_sonar_extrinsics(self.h, dptr(T))
+
+    def add_states(self, fid, stamp, num_keypoints, T_SC, imu_t, imu_m, as_keyframe, sonar=None, depth=None, first_depth=0.0):
+        T_SC = arr(T_SC).reshape(-1, 7)
+        imu_t = arr(imu_t, np.uint32).reshape(-1, 2)
+        imu_m = arr(imu_m).reshape(-1, 6)
+        sonar = arr(sonar if sonar is not None else np.zeros((0, 2))).reshape(-1, 2)
+        depth = arr(depth if depth is not None else np.zeros(0)).reshape(-1)
+        return bool(self.L.orc_add_states(self.h, fid, stamp[0], stamp[1], num_keypoints, len(T_SC), dptr(T_SC), len(imu_t),
+                                          u32ptr(imu_t), dptr(imu_m), 1 if as_keyframe else 0, len(sonar), dptr(sonar),
+                                          len(depth), dptr(depth), first_depth))
+
+    def add_landmark(self, lid, hp):
+        hp = arr(hp)
+        return bool(self.L.orc_add_landmark(self.h, lid, dptr(hp)))
+
+    def add_observation(self, lid, pose, cam, kp, uv, size):
+        uv = arr(uv)
+        return int(self.L.orc_add_observation(self.h, lid, pose, cam, kp, dptr(uv), size))
+
+    def remove_observation(self, lid, pose, cam, kp):
+        return bool(self.L.orc_remove_observation(self.h, lid, pose, cam, kp))
+
+    def optimize(self, num_iter, num_threads=1, verbose=False):
+        self.L.orc_optimize(self.h, num_iter, num_threads, 1 if verbose else 0)
+
+    def set_time_limit(self, tl, min_iter):
+        return bool(self.L.orc_set_time_limit(self.h, tl, min_iter))
+
+    def apply_marginalization(self, num_kf, num_imu):
+        ids = np.zeros(1 << 16, np.uint64)
+        n = C.c_int()
+        ok = self.L.orc_apply_marginalization(self.h, num_kf, num_imu, u64ptr(ids), len(ids), C.byref(n))
+        return bool(ok), ids[:n.value].copy()
+
+    def get_T_WS(self, fid):
+        T = np.zeros(7)
+        return T if self.L.orc_get_T_WS(self.h, fid, dptr(T)) else None
+
+    def get_speed_and_bias(self, fid, imu=0):
+        sb = np.zeros(9)
+        return sb if self.L.orc_get_speed_and_bias(self.h, fid, imu, dptr(sb)) else None
+
+    def get_camera_sensor_states(self, fid, cam):
+        T = np.zeros(7)
+        return T if self.L.orc_get_camera_sensor_states(self.h, fid, cam, dptr(T)) else None
+
+    def get_landmark(self, lid):
+        hp, q, d, n = np.zeros(4), np.zeros(1), np.zeros(1), C.c_int()
+        if not self.L.orc_get_landmark(self.h, lid, dptr(hp), dptr(q), dptr(d), C.byref(n)):
+            return None
+        return dict(point=hp, quality=float(q[0]), distance=float(d[0]), n_obs=n.value)
+
+    def set_T_WS(self, fid, T):
+        T = arr(T)
+        return bool(self.L.orc_set_T_WS(self.h, fid, dptr(T)))
+
+    def set_speed_and_bias(self, fid, sb, imu=0):
+        sb = arr(sb)
+        return bool(self.L.orc_set_speed_and_bias(self.h, fid, imu, dptr(sb)))
+
+    def set_landmark(self, lid, hp):
+        hp = arr(hp)
+        return bool(self.L.orc_set_landmark(self.h, lid, dptr(hp)))
+
+    def frame_ids(self):
+        ids = np.zeros(4096, np.uint64)
+        n = self.L.orc_frame_ids(self.h, u64ptr(ids), len(ids))
+        return [int(i) for i in ids[:n]]
+
+    def landmark_ids(self):
+        n = int(self.L.orc_num_landmarks(self.h))
+        ids = np.zeros(max(n, 1), np.uint64)
+        self.L.orc_landmark_ids(self.h, u64ptr(ids), len(ids))
+        return [int(i) for i in ids[:n]]
+
+    def num_frames(self):
+        return int(self.L.orc_num_frames(self.h))
+
+    def num_landmarks(self):
+        return int(self.L.orc_num_landmarks(self.h))
+
+    def summary(self):
+        s = np.zeros(6)
+        self.L.orc_summary(self.h, dptr(s))
+        return dict(initial_cost=s[0], final_cost=s[1], iterations=int(s[2]), successful=int(s[3]),
+                    termination=int(s[4]), time=s[5])
+
+    def cost_history(self):
+        out = np.zeros(256)
+        n = self.L.orc_cost_history(self.h, dptr(out), 256)
+        return out[:n].copy()
+
+    def set_solver_options(self, function_tol=1e-6, gradient_tol=1e-10, parameter_tol=1e-8, jacobi_scaling=True):
+        self.L.orc_set_solver_options(self.h, function_tol, gradient_tol, parameter_tol, 1 if jacobi_scaling else 0)
+
+    def marg(self):
+        n = self.L.orc_marg_size(self.h)
+        if n == 0:
+            return None
+        H, b0, J, e0 = np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n)
+        self.L.orc_marg_get(self.h, dptr(H), dptr(b0), dptr(J), dptr(e0))
+        ids, ordr, md, lin = np.zeros(512, np.uint64), np.zeros(512, np.int32), np.zeros(512, np.int32), np.zeros((512, 9))
+        nb = self.L.orc_marg_blocks(self.h, u64ptr(ids), i32ptr(ordr), i32ptr(md), dptr(lin), 512)
+        blocks = []
+        for i in range(nb):
+            f, k, ix = C.c_uint64(), C.c_int(), C.c_int()
+            ok = self.L.orc_describe_block(self.h, int(ids[i]), C.byref(f), C.byref(k), C.byref(ix))
+            blocks.append(dict(id=int(ids[i]), ordering=int(ordr[i]), mdim=int(md[i]), lin=lin[i].copy(),
+                               frame=int(f.value) if ok else None, kind=int(k.value) if ok else None,
+                               index=int(ix.value) if ok else None))
+        return dict(n=n, H=H, b0=b0, J=J, e0=e0, blocks=blocks)

@@ -1,0 +1,59 @@
+// ORACLE -- test infrastructure only (never linked into the product library).
+// Restatement of okvis::ceres::MarginalizationError
+// (okvis_ceres/src/MarginalizationError.cpp, include/okvis/ceres/implementation/MarginalizationError.hpp).
+#pragma once
+#include "orc_map.hpp"
+
+namespace orc {
+
+class MarginalizationError : public ErrorTerm {
+ public:
+  struct Info {  // MarginalizationError.hpp:296-345
+    uint64_t id = 0;
+    int type = 0;
+    int orderingIdx = 0, dim = 0, mdim = 0;
+    bool isLandmark = false;
+    double lin[9] = {0};
+  };
+  explicit MarginalizationError(Map* map) : map_(map) {}
+  // M1: MarginalizationError.cpp:126-397
+  bool addResidualBlock(uint64_t resId, bool keep = false);
+  // M2: :463-721
+  bool marginalizeOut(const std::vector<uint64_t>& ids);
+  // M3: :725-758
+  void updateErrorComputation();
+  bool isParameterBlockConnected(uint64_t id) const { return id2idx_.count(id) != 0; }
+  std::vector<uint64_t> parameterBlockIds() const { std::vector<uint64_t> v; for (auto& i : infos_) v.push_back(i.id); return v; }
+
+  // ErrorTerm (M4: :798-844)
+  Kind kind() const override { return MARGINALIZATION; }
+  int residualDim() const override { return n_; }
+  int numBlocks() const override { return (int)infos_.size(); }
+  int blockType(int i) const override { return infos_[i].type; }
+  bool evaluate(double const* const* params, double* residuals, double** J, double** Jmin) const override;
+
+  // inspection
+  int size() const { return n_; }
+  const std::vector<double>& H() const { return H_; }
+  const std::vector<double>& b0() const { return b0_; }
+  const std::vector<double>& Jmat() const { return J_; }
+  const std::vector<double>& e0() const { return e0_; }
+  const std::vector<Info>& infos() const { return infos_; }
+
+ private:
+  void insertZeros(int pos, int k);  // grow H_/b0_ by k rows+cols at index pos
+  Map* map_;
+  int n_ = 0;
+  std::vector<double> H_, b0_;
+  std::vector<Info> infos_;
+  std::map<uint64_t, size_t> id2idx_;
+  size_t denseIndices_ = 0;
+  bool valid_ = false;
+  std::vector<double> J_, e0_;
+};
+
+// helpers shared with tests: pseudo-inverse square root of a symmetric PSD matrix
+// (implementation/MarginalizationError.hpp:187-220): result = U * diag(sqrt(1/lambda_i | 0))
+void pseudoInverseSymmSqrt(const double* A, int n, double* result);
+
+}  // namespace orc
