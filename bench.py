@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gauss-Newton iterations/s of the sliding-window BA backend + Jacobian-eval roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic stereo+IMU window, 10 keyframes / 2 000 landmarks /
+20 000 reprojection residuals / 9 IMU factors, seed 20250629, FP64.  One *step* = one
+`Estimator::optimize(10)` trust-region solve from the seeded perturbed initial state with the inputs
+already resident in HBM (upload and download are excluded and reported separately); `value` =
+Gauss-Newton iterations completed / wall time of the K solves (device-synchronised, max over ranks).
+For N > 1 each rank solves its own replica window (config #2 is far below the size where sharding
+one window pays): weak scaling, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def snapshot_init(est, fids, lids, spec):
+    return dict(T=[spec.T_WS_init[k] for k in range(len(fids))], sb=[spec.sb_init[k] for k in range(len(fids))],
+                lm=[spec.lm_init[l] for l in range(len(lids))],
+                T0=est.get_T_WS(fids[0]).copy())
+
+
+def reset_state(est, fids, lids, snap):
+    est.set_T_WS(fids[0], snap["T0"])
+    for k, f in enumerate(fids):
+        if k > 0:
+            est.set_T_WS(f, snap["T"][k])
+        est.set_speed_and_bias(f, snap["sb"][k])
+    for l, lid in enumerate(lids):
+        est.set_landmark(lid, snap["lm"][l])
+    if hasattr(est, "invalidate_preintegration"):
+        est.invalidate_preintegration()
+
+
+def cpu_baseline(spec, budget_s=15.0):
+    """Oracle (CPU restatement, 1 thread) timed on the same window: optimize(10) from the same start."""
+    from oracle import orc
+    from svin_amd import synthetic as syn
+    lib = None
+    try:
+        path = orc.build(native=True, out="/tmp/liborc_native.so")
+        lib = orc.lib(path)
+    except Exception:
+        lib = orc.lib()
+    iters, total, runs = 0, 0.0, 0
+    while total < budget_s and runs < 200:
+        est = orc.OracleEstimator(L=lib)
+        syn.feed(est, spec)
+        t0 = time.perf_counter()
+        est.optimize(10, 1, False)
+        total += time.perf_counter() - t0
+        iters += est.summary()["iterations"]
+        runs += 1
+    return dict(value=iters / total, unit="GN iterations/s", cores=1, kind="port",
+                sample="%d x optimize(10) on the full config-#2 window (%d iterations, %.1f s), oracle/ C++ restatement, "
+                       "g++ -O3 -march=native, 1 thread" % (runs, iters, total))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--copies", type=int, default=256, help="window replicas for the HBM-resident Jacobian-eval roofline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+
+    from svin_amd import synthetic as syn
+    from svin_amd.estimator import Estimator
+
+    spec = syn.make_window(seed=20250629 + rank)  # config #2 (each rank: its own seeded replica)
+    est = Estimator(local_rank)
+    fids, lids = syn.feed(est, spec)
+    snap = snapshot_init(est, fids, lids, spec)
+
+    def one_step():
+        reset_state(est, fids, lids, snap)
+        est.prepare()                       # pack + upload (untimed: inputs resident in HBM)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        est.solve_prepared(10)              # returns device-synchronised
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        s = est.summary()
+        est.finish()
+        return dt, s["iterations"], s
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    total_t, total_it, last = 0.0, 0, None
+    for _ in range(args.steps):
+        dt, it, last = one_step()
+        total_t += dt
+        total_it += it
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([total_t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ti = torch.tensor([float(total_it)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+        total_t, total_it = float(tt.item()), int(ti.item())
+
+    out = None
+    if rank == 0:
+        value = total_it / total_t
+        out = {
+            "metric": "Gauss-Newton iterations/sec on 10-KF/2k-landmark window; Jacobian-eval HBM GB/s",
+            "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * total_t / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic stereo+IMU 10 KF / 2000 landmarks / 20000 reprojection residuals "
+                                   "/ 9 IMU factors, seed 20250629, optimize(10) per step",
+                       "iterations_per_step": total_it / (args.steps * world), "final_cost": last["final_cost"],
+                       "initial_cost": last["initial_cost"], "upload_ms": 1e3 * last["upload_time"],
+                       "download_ms": 1e3 * last["download_time"], "parallelism": "replicas x%d" % world},
+        }
+        # roofline of the dominant streaming kernel (K1 reprojection residual + Jacobian evaluation) on an
+        # HBM-resident batch of replicas; HIP events on the kernel's own stream
+        ms, nbytes = est.bench_jacobian_eval(args.copies, 20)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        ms1, nbytes1 = est.bench_jacobian_eval(1, 50)
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "k_eval_reproj", "launch_ms": ms, "bytes_per_launch": nbytes,
+                           "replicas": args.copies,
+                           "single_window_cache_resident": {"launch_ms": ms1, "GBps": nbytes1 / (ms1 * 1e-3) / 1e9}}
+        ev, bu, so = est.bench_kernel_times(20)
+        out["kernel_ms"] = {"eval_reproj": ev, "build_normal_equations": bu, "chol_solve_backsub": so}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(syn.make_window(seed=20250629))
+            out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

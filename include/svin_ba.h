@@ -1,0 +1,178 @@
+/* svin_ba.h -- C ABI of the MI355X-native sliding-window bundle-adjustment backend.
+ *
+ * Drop-in boundary for the hot path of AutonomousFieldRoboticsLab/SVIn: every entry point
+ * replaces one member of okvis::Estimator / okvis::ceres::Map (paths below are relative to
+ * /root/reference/okvis_ros/okvis/okvis_ceres/).  The header-only C++ shim that re-declares
+ * okvis::Estimator on top of this ABI is described in INTEGRATION.md.
+ *
+ * Conventions
+ *   - opaque handle, externally synchronised (one caller at a time, like the reference under
+ *     ThreadedKFVio::estimator_mutex_, okvis_multisensor_processing/src/ThreadedKFVio.cpp:1083)
+ *   - poses are 7 doubles [x y z qx qy qz qw] (src/PoseParameterBlock.cpp:64-74), speed/bias 9
+ *     doubles [v bg ba], homogeneous landmarks 4 doubles
+ *   - timestamps are (sec, nsec) uint32 pairs (okvis_time/include/okvis/Time.hpp:128)
+ *   - return: 1 = true / ok, 0 = the reference's benign `false`, <0 = error (SVIN_ERR_*); nothing throws
+ *   - all compute runs on the GPU selected at creation; there is no CPU fallback: without a
+ *     usable HIP device svin_ba_create() returns NULL and svin_ba_last_error() says why.
+ */
+#ifndef SVIN_BA_H_
+#define SVIN_BA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svin_ba svin_ba;
+
+#define SVIN_ERR_INVALID_ARG (-1)
+#define SVIN_ERR_NOT_FOUND (-2)
+#define SVIN_ERR_DEVICE (-3)
+#define SVIN_ERR_UNSUPPORTED (-4)
+
+/* distortion models (okvis_cv/include/okvis/cameras/*Distortion.hpp) */
+#define SVIN_DIST_NONE 0
+#define SVIN_DIST_RADTAN 1
+#define SVIN_DIST_EQUIDISTANT 2
+#define SVIN_DIST_RADTAN8 3
+
+/* okvis::ImuParameters (okvis_common/include/okvis/Parameters.hpp) */
+typedef struct svin_imu_params {
+  double a_max, g_max, sigma_g_c, sigma_a_c, sigma_bg, sigma_ba, sigma_gw_c, sigma_aw_c, tau, g;
+  double a0[3];
+} svin_imu_params;
+
+/* one IMU sample: okvis::ImuMeasurement */
+typedef struct svin_imu_sample {
+  uint32_t sec, nsec;
+  double gyr[3], acc[3];
+} svin_imu_sample;
+
+/* okvis::MapPoint (okvis_common/include/okvis/FrameTypedefs.hpp) without the observation map */
+typedef struct svin_landmark_info {
+  double point[4];
+  double quality;
+  double distance;
+  int32_t num_observations;
+  int32_t initialized;
+} svin_landmark_info;
+
+/* ::ceres::Solver::Summary subset filled by optimize() (Map.hpp:344) */
+typedef struct svin_summary {
+  double initial_cost, final_cost;
+  int32_t iterations, num_successful_steps;
+  int32_t termination; /* 0 convergence, 1 max iterations, 2 time limit (callback), 3 failure */
+  double total_time_s;
+  double upload_time_s, solve_time_s, download_time_s;
+} svin_summary;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+svin_ba* svin_ba_create(int device);            /* Estimator::Estimator()  src/Estimator.cpp:67-73 */
+void svin_ba_destroy(svin_ba* h);
+const char* svin_ba_last_error(void);
+uint64_t svin_ba_new_id(svin_ba* h);            /* IdProvider::instance().newId()  src/IdProvider.cpp */
+
+/* ---- sensors (Estimator.cpp:77-96) -------------------------------------------------------- */
+/* intr = fu fv cu cv; dist = up to 8 coefficients (radtan k1 k2 p1 p2; equidistant k1..k4;
+ * radtan8 k1 k2 p1 p2 k3 k4 k5 k6); sigmas = sigma_absolute_translation, sigma_absolute_orientation,
+ * sigma_c_relative_translation, sigma_c_relative_orientation (ExtrinsicsEstimationParameters) */
+int svin_ba_add_camera(svin_ba* h, int distortion_model, const double intr[4], const double* dist, int n_dist,
+                       int width, int height, const double sigmas[4]);
+int svin_ba_add_imu(svin_ba* h, const svin_imu_params* p);
+int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]); /* Estimator.hpp:617 sonarParameters_ */
+
+/* ---- window construction ------------------------------------------------------------------ */
+/* Estimator::addStates  src/Estimator.cpp:98-411.  T_SC: n_cam x 7 (multiFrame->T_SC(i));
+ * sonar: n_sonar x {range, heading}; depth: n_depth values. */
+int svin_ba_add_states(svin_ba* h, uint64_t frame_id, uint32_t sec, uint32_t nsec, uint64_t num_keypoints,
+                       const double* T_SC, int n_cam, const svin_imu_sample* imu, int n_imu, int as_keyframe,
+                       const double* sonar, int n_sonar, const double* depth, int n_depth, double first_depth);
+int svin_ba_add_landmark(svin_ba* h, uint64_t landmark_id, const double hp[4]);       /* :414-429 */
+/* Estimator::addObservation<GEOMETRY>  include/okvis/implementation/Estimator.hpp:47-87.
+ * Returns the residual id (non-zero) or 0 for a duplicate (the reference returns NULL). */
+uint64_t svin_ba_add_observation(svin_ba* h, uint64_t landmark_id, uint64_t pose_id, uint64_t cam_idx,
+                                 uint64_t keypoint_idx, const double uv[2], double keypoint_size);
+int svin_ba_remove_observation(svin_ba* h, uint64_t landmark_id, uint64_t pose_id, uint64_t cam_idx,
+                               uint64_t keypoint_idx);                                 /* :452-474 */
+int svin_ba_remove_observation_by_id(svin_ba* h, uint64_t residual_id);               /* :432-449 */
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+int svin_ba_optimize(svin_ba* h, uint64_t num_iter, uint64_t num_threads_ignored, int verbose); /* :876-929 */
+int svin_ba_set_optimization_time_limit(svin_ba* h, double time_limit, int min_iterations);    /* :932-951 */
+/* Estimator::applyMarginalizationStrategy :495-814; removed landmark ids are written to
+ * removed_ids (capacity cap), *n_removed receives the full count. */
+int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t num_keyframes, uint64_t num_imu_frames,
+                                           uint64_t* removed_ids, int cap, int* n_removed);
+/* optimize() split in three for measurement with HBM-resident inputs: prepare = pack + upload the window,
+ * solve_prepared = the trust-region iterations only (device-synchronised on return), finish = download
+ * states + landmark quality.  optimize() == prepare; solve_prepared; finish. */
+int svin_ba_prepare(svin_ba* h);
+int svin_ba_solve_prepared(svin_ba* h, uint64_t num_iter, int verbose);
+int svin_ba_finish(svin_ba* h);
+/* forces every IMU factor to re-preintegrate at its next evaluation (ImuError::redo_ = true) */
+int svin_ba_invalidate_preintegration(svin_ba* h);
+int svin_ba_get_summary(svin_ba* h, svin_summary* out);
+/* solver tolerances (::ceres::Solver::Options defaults: 1e-6, 1e-10, 1e-8) */
+int svin_ba_set_solver_tolerances(svin_ba* h, double function_tol, double gradient_tol, double parameter_tol);
+
+/* ---- getters / setters (Estimator.cpp:955-1316) -------------------------------------------- */
+int svin_ba_get_T_WS(svin_ba* h, uint64_t pose_id, double T[7]);
+int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, double sb[9]);
+int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, double T[7]);
+int svin_ba_get_landmark(svin_ba* h, uint64_t landmark_id, svin_landmark_info* out);
+int svin_ba_is_landmark_added(svin_ba* h, uint64_t landmark_id);
+int svin_ba_set_T_WS(svin_ba* h, uint64_t pose_id, const double T[7]);
+int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, const double sb[9]);
+int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, const double T[7]);
+int svin_ba_set_landmark(svin_ba* h, uint64_t landmark_id, const double hp[4]);
+uint64_t svin_ba_num_frames(svin_ba* h);
+uint64_t svin_ba_num_landmarks(svin_ba* h);
+uint64_t svin_ba_current_keyframe_id(svin_ba* h);
+uint64_t svin_ba_current_frame_id(svin_ba* h);
+uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age);
+int svin_ba_is_keyframe(svin_ba* h, uint64_t frame_id);
+int svin_ba_is_in_imu_window(svin_ba* h, uint64_t frame_id);
+int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap);      /* returns the number of frames */
+int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap);   /* returns the number of landmarks */
+
+/* ---- CPU-callable prediction kept for the frontend (ImuError::propagation, ImuError.cpp:266-476):
+ * runs on the GPU like everything else; T (7) and sb (9) are in/out; cov / jac are 15x15 or NULL. */
+int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],
+                            double sb[9], uint32_t sec0, uint32_t nsec0, uint32_t sec1, uint32_t nsec1, double* cov,
+                            double* jac);
+
+/* ---- inspection / parity hooks (ErrorInterface::EvaluateWithMinimalJacobians, Map::getLhs) ---- */
+/* Evaluates every reprojection residual of the window on the GPU at the current estimates.
+ * Outputs are per observation in the order given by svin_ba_observation_ids(); any may be NULL.
+ *   r: n x 2, Jpose: n x 12 (2x6 row-major), Jlm: n x 6 (2x3), Jext: n x 12; robust != 0 applies the
+ *   Cauchy corrector exactly as the solver sees it. Returns n. */
+int svin_ba_eval_reprojection(svin_ba* h, int robust, double* r, double* Jpose, double* Jlm, double* Jext, int cap);
+int svin_ba_observation_ids(svin_ba* h, uint64_t* residual_ids, uint64_t* landmark_ids, uint64_t* pose_ids,
+                            int32_t* cam_idx, int cap);
+/* small factors (IMU, priors, relative pose, sonar, depth): kind, residual dim, residual, stacked
+ * minimal Jacobian (m x ncols, row-major), block ids.  Returns the number of factors. */
+int svin_ba_eval_factors(svin_ba* h, int32_t* kind, int32_t* m, int32_t* ncols, double* r15, double* J15x30,
+                         uint64_t* block_ids4, uint64_t* residual_ids, int cap);
+/* reduced (Schur) system at the current estimates with damping mu: S (d x d), g (d); block_ids / offsets
+ * describe the ordering. Returns d. */
+int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* block_ids, int32_t* block_offsets,
+                      int32_t* n_blocks, int cap_d, double* cost);
+/* marginalisation prior: returns its dimension m; H (m x m), b0 (m), J (m x m), e0 (m) may be NULL */
+int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* block_ids,
+                      int32_t* block_ordering, int32_t* block_mdim, int32_t* n_blocks, int cap_m);
+/* semantic description of an internal parameter-block id: kind 0 pose / 1 extrinsics / 2 speed-bias */
+int svin_ba_describe_block(svin_ba* h, uint64_t block_id, uint64_t* frame_id, int32_t* kind, int32_t* index);
+
+/* ---- measurement hook: the Jacobian-evaluation kernel on `copies` replicas of the current window's
+ * observation set (HBM-resident working set). Runs `iters` launches, returns the mean kernel time in
+ * milliseconds measured with HIP events on the handle's stream; *bytes_per_launch receives the
+ * algorithmic byte count of one launch. */
+int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes_per_launch);
+/* mean wall time (ms) of one reprojection-evaluation launch on the plain window (cache-resident) */
+int svin_ba_bench_kernel_times(svin_ba* h, int iters, double* eval_ms, double* build_ms, double* solve_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVIN_BA_H_ */

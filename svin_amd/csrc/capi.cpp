@@ -1,0 +1,266 @@
+// svin_amd C ABI (include/svin_ba.h).  Plain pointers and sizes only; nothing throws across the boundary.
+#include "../../include/svin_ba.h"
+#include "window.hpp"
+#include <vector>
+
+using namespace svin;
+
+struct svin_ba {
+  Window w;
+  explicit svin_ba(int device) : w(device) {}
+};
+
+#define GUARD_BEGIN try {
+#define GUARD_END(errval)                     \
+  }                                           \
+  catch (const std::exception& e) {           \
+    lastError() = e.what();                   \
+    return errval;                            \
+  }                                           \
+  catch (...) {                               \
+    lastError() = "unknown error";            \
+    return errval;                            \
+  }
+
+static void splitSamples(const svin_imu_sample* imu, int n, std::vector<uint32_t>& t, std::vector<double>& m) {
+  t.resize(2 * (size_t)n);
+  m.resize(6 * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    t[2 * i] = imu[i].sec; t[2 * i + 1] = imu[i].nsec;
+    for (int k = 0; k < 3; ++k) { m[6 * i + k] = imu[i].gyr[k]; m[6 * i + 3 + k] = imu[i].acc[k]; }
+  }
+}
+static ImuParams toParams(const svin_imu_params* p) {
+  ImuParams q;
+  q.a_max = p->a_max; q.g_max = p->g_max; q.sigma_g_c = p->sigma_g_c; q.sigma_a_c = p->sigma_a_c;
+  q.sigma_bg = p->sigma_bg; q.sigma_ba = p->sigma_ba; q.sigma_gw_c = p->sigma_gw_c; q.sigma_aw_c = p->sigma_aw_c;
+  q.tau = p->tau; q.g = p->g;
+  q.a0[0] = p->a0[0]; q.a0[1] = p->a0[1]; q.a0[2] = p->a0[2];
+  return q;
+}
+
+extern "C" {
+
+svin_ba* svin_ba_create(int device) {
+  try {
+    return new svin_ba(device);
+  } catch (const std::exception& e) {
+    lastError() = e.what();
+    return nullptr;
+  } catch (...) {
+    lastError() = "unknown error";
+    return nullptr;
+  }
+}
+void svin_ba_destroy(svin_ba* h) { delete h; }
+const char* svin_ba_last_error(void) { return lastError().c_str(); }
+uint64_t svin_ba_new_id(svin_ba* h) { return h ? h->w.newId() : 0; }
+
+int svin_ba_add_camera(svin_ba* h, int model, const double intr[4], const double* dist, int n_dist, int width, int height,
+                       const double sigmas[4]) {
+  if (!h || !intr || !sigmas) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.addCamera(model, intr, dist, n_dist, width, height, sigmas);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_add_imu(svin_ba* h, const svin_imu_params* p) {
+  if (!h || !p) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.addImu(toParams(p));
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]) {
+  if (!h || !T_SSo) return SVIN_ERR_INVALID_ARG;
+  h->w.setSonarExtrinsics(T_SSo);
+  return 1;
+}
+int svin_ba_add_states(svin_ba* h, uint64_t frame_id, uint32_t sec, uint32_t nsec, uint64_t num_keypoints,
+                       const double* T_SC, int n_cam, const svin_imu_sample* imu, int n_imu, int as_keyframe,
+                       const double* sonar, int n_sonar, const double* depth, int n_depth, double first_depth) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint32_t> t;
+  std::vector<double> m;
+  splitSamples(imu, n_imu, t, m);
+  TimeStamp ts; ts.sec = sec; ts.nsec = nsec;
+  return h->w.addStates(frame_id, ts, num_keypoints, T_SC, n_cam, t.data(), m.data(), n_imu, as_keyframe != 0, sonar,
+                        n_sonar, depth, n_depth, first_depth);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_add_landmark(svin_ba* h, uint64_t id, const double hp[4]) {
+  if (!h || !hp) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.addLandmark(id, hp);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+uint64_t svin_ba_add_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp, const double uv[2],
+                                 double size) {
+  if (!h || !uv) return 0;
+  GUARD_BEGIN return h->w.addObservation(lm, pose, cam, kp, uv, size);
+  GUARD_END(0)
+}
+int svin_ba_remove_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.removeObservation(lm, pose, cam, kp);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_remove_observation_by_id(svin_ba* h, uint64_t rid) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.removeObservationById(rid);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_optimize(svin_ba* h, uint64_t num_iter, uint64_t, int verbose) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.optimize(num_iter, verbose != 0);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_prepare(svin_ba* h) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.prepare();
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_solve_prepared(svin_ba* h, uint64_t num_iter, int verbose) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.solvePrepared(num_iter, verbose != 0);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_finish(svin_ba* h) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.finish();
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_invalidate_preintegration(svin_ba* h) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  h->w.invalidatePreintegration();
+  return 1;
+}
+int svin_ba_set_optimization_time_limit(svin_ba* h, double tl, int min_iter) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  return h->w.setOptimizationTimeLimit(tl, min_iter);
+}
+int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t nkf, uint64_t nimu, uint64_t* removed, int cap,
+                                           int* n_removed) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint64_t> rem;
+  const int r = h->w.applyMarginalizationStrategy(nkf, nimu, rem);
+  if (n_removed) *n_removed = (int)rem.size();
+  for (int i = 0; i < (int)rem.size() && i < cap; ++i) removed[i] = rem[i];
+  return r;
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_get_summary(svin_ba* h, svin_summary* out) {
+  if (!h || !out) return SVIN_ERR_INVALID_ARG;
+  const Summary& s = h->w.summary();
+  out->initial_cost = s.initial_cost; out->final_cost = s.final_cost; out->iterations = s.iterations;
+  out->num_successful_steps = s.num_successful_steps; out->termination = s.termination;
+  out->total_time_s = s.total_time; out->upload_time_s = s.upload_time; out->solve_time_s = s.solve_time;
+  out->download_time_s = s.download_time;
+  return 1;
+}
+int svin_ba_set_solver_tolerances(svin_ba* h, double f, double g, double p) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  h->w.setTolerances(f, g, p);
+  return 1;
+}
+int svin_ba_get_T_WS(svin_ba* h, uint64_t id, double T[7]) { return h ? h->w.get_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
+int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, double sb[9]) {
+  return h ? h->w.getSpeedAndBias(id, imu, sb) : SVIN_ERR_INVALID_ARG;
+}
+int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, double T[7]) {
+  return h ? h->w.getCameraSensorStates(id, cam, T) : SVIN_ERR_INVALID_ARG;
+}
+int svin_ba_get_landmark(svin_ba* h, uint64_t id, svin_landmark_info* out) {
+  if (!h || !out) return SVIN_ERR_INVALID_ARG;
+  const Landmark* lm = h->w.landmark(id);
+  if (!lm) return 0;
+  for (int k = 0; k < 4; ++k) out->point[k] = lm->hp[k];
+  out->quality = lm->quality; out->distance = lm->distance;
+  out->num_observations = (int32_t)lm->obs.size();
+  out->initialized = 1;
+  return 1;
+}
+int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) { return h && h->w.landmark(id) ? 1 : 0; }
+int svin_ba_set_T_WS(svin_ba* h, uint64_t id, const double T[7]) { return h ? h->w.set_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
+int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, const double sb[9]) {
+  return h ? h->w.setSpeedAndBias(id, imu, sb) : SVIN_ERR_INVALID_ARG;
+}
+int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, const double T[7]) {
+  return h ? h->w.setCameraSensorStates(id, cam, T) : SVIN_ERR_INVALID_ARG;
+}
+int svin_ba_set_landmark(svin_ba* h, uint64_t id, const double hp[4]) { return h ? h->w.setLandmark(id, hp) : SVIN_ERR_INVALID_ARG; }
+uint64_t svin_ba_num_frames(svin_ba* h) { return h ? h->w.states().size() : 0; }
+uint64_t svin_ba_num_landmarks(svin_ba* h) { return h ? h->w.landmarks().size() : 0; }
+uint64_t svin_ba_current_keyframe_id(svin_ba* h) { return h ? h->w.currentKeyframeId() : 0; }
+uint64_t svin_ba_current_frame_id(svin_ba* h) { return (h && !h->w.states().empty()) ? h->w.states().rbegin()->first : 0; }
+uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age) { return h ? h->w.frameIdByAge(age) : 0; }
+int svin_ba_is_keyframe(svin_ba* h, uint64_t id) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  auto it = h->w.states().find(id);
+  return it == h->w.states().end() ? SVIN_ERR_NOT_FOUND : (it->second.isKeyframe ? 1 : 0);
+}
+int svin_ba_is_in_imu_window(svin_ba* h, uint64_t id) { return h ? (h->w.isInImuWindow(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; }
+int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  int n = 0;
+  for (auto& kv : h->w.states()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
+  return n;
+}
+int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  int n = 0;
+  for (auto& kv : h->w.landmarks()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
+  return n;
+}
+int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],
+                            double sb[9], uint32_t s0, uint32_t ns0, uint32_t s1, uint32_t ns1, double* cov, double* jac) {
+  if (!h || !imu || !p) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint32_t> t;
+  std::vector<double> m;
+  splitSamples(imu, n_imu, t, m);
+  TimeStamp a, b; a.sec = s0; a.nsec = ns0; b.sec = s1; b.nsec = ns1;
+  return h->w.imuPropagation(t.data(), m.data(), n_imu, toParams(p), T, sb, a, b, cov, jac);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_eval_reprojection(svin_ba* h, int robust, double* r, double* Jp, double* Jl, double* Je, int cap) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.evalReprojection(robust != 0, r, Jp, Jl, Je, cap);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_observation_ids(svin_ba* h, uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t* cam, int cap) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.observationIds(rid, lm, pose, cam, cap);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_eval_factors(svin_ba* h, int32_t* kind, int32_t* m, int32_t* ncols, double* r, double* J, uint64_t* blocks,
+                         uint64_t* rids, int cap) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.evalFactors(kind, m, ncols, r, J, blocks, rids, cap);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* ids, int32_t* off, int32_t* nb, int cap_d,
+                      double* cost) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.linearize(mu, S, g, ids, off, nb, cap_d, cost);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord,
+                      int32_t* mdim, int32_t* nb, int cap_m) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.getPrior(H, b0, J, e0, ids, ord, mdim, nb, cap_m);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_describe_block(svin_ba* h, uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  return h->w.describeBlock(id, frame, kind, index);
+}
+int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_bench_kernel_times(svin_ba* h, int iters, double* e, double* b, double* s) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.benchKernelTimes(iters, e, b, s);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+
+}  // extern "C"

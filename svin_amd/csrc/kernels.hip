@@ -1,0 +1,1704 @@
+// svin_amd HIP kernels for gfx950 (CDNA4, wave64).  No CUDA shims, no CPU fallbacks.
+//
+// K1  k_eval_reproj      reprojection residual + minimal Jacobians + Cauchy corrector (fused K4)
+// K2  k_eval_factors     IMU (incl. conditional re-preintegration) and the small unary/binary factors
+// K3  k_prior_*          marginalisation prior in H-space
+// K5  k_schur            per-landmark V/b, wave-reduced; pairwise Schur blocks accumulated in LDS-private
+//                        copies of the reduced camera matrix, flushed as slabs and reduced deterministically
+// K6  k_chol_solve       blocked Cholesky of the reduced system, trailing update on v_mfma_f64_16x16x4_f64
+// K7  k_backsub / k_dogleg_step / k_retract
+// K8  cost reductions    per-block partials + single-block final reduce (deterministic)
+// K9  k_landmark_quality
+// Reference arithmetic: see dmath.hpp and the per-kernel comments.
+#include "kernels.hpp"
+
+namespace svin {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double waveMax(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum; result valid in thread 0.  `red` must hold blockDim/64 doubles.
+__device__ __forceinline__ double blockSum(double v, double* red) {
+  v = waveSum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ void waveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// partial-sum slots in p.partial (each slot holds up to kMaxPartials doubles)
+constexpr int kMaxPartials = 4096;
+enum PartialSlot : int {
+  PS_COST_REPROJ = 0, PS_COST_FACTORS = 1, PS_JV_SQ = 2, PS_JV_DOT = 3, PS_STEP = 4, PS_XNORM = 5,
+  PS_GHAT = 6, PS_GNHAT = 7, PS_GDOTGN = 8, PS_GRADMAX = 9, PS_JV_SQ_F = 10, PS_JV_DOT_F = 11, PS_COUNT = 12
+};
+
+// ================================================================ K1: reprojection evaluation
+template <bool ROBUST, bool WITH_EXT>
+__global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
+                                                     const double* __restrict__ ext, const double* __restrict__ lm,
+                                                     const CameraModel* __restrict__ cams,
+                                                     const double* __restrict__ obsUv, const double* __restrict__ obsW,
+                                                     const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
+                                                     double* __restrict__ r, double* __restrict__ Jp,
+                                                     double* __restrict__ Jl, double* __restrict__ Je,
+                                                     double* __restrict__ costPartial, size_t stride) {
+  extern __shared__ double smem[];
+  double* sPose = smem;                      // nPose*7
+  double* sExt = sPose + nPose * 7;          // nExt*7
+  CameraModel* sCam = reinterpret_cast<CameraModel*>(sExt + nExt * 7);  // nCam
+  __shared__ double red[2];
+  for (int i = threadIdx.x; i < nPose * 7; i += blockDim.x) sPose[i] = pose[i];
+  for (int i = threadIdx.x; i < nExt * 7; i += blockDim.x) sExt[i] = ext[i];
+  {
+    const double* src = reinterpret_cast<const double*>(cams);
+    double* dst = reinterpret_cast<double*>(sCam);
+    for (int i = threadIdx.x; i < nCam * (int)(sizeof(CameraModel) / 8); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0;
+  if (i < N) {
+    const uint32_t idx = obsIdx[i];
+    const int ps = idx & 0xfff, es = (idx >> 12) & 0xfff, cs = (idx >> 24) & 0xf;
+    const double2 uv = reinterpret_cast<const double2*>(obsUv)[i];
+    const double w = obsW[i];
+    const double4 hp = reinterpret_cast<const double4*>(lm)[obsLm[i]];
+    const double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
+    double rr[2], jp[12], jl[6], je[12];
+    reprojEval(sCam[cs], sPose + ps * 7, hpw, sExt + es * 7, uv.x, uv.y, w, rr, jp, jl, je);
+    const double s = rr[0] * rr[0] + rr[1] * rr[1];
+    if (ROBUST) {
+      // Ceres Corrector for CauchyLoss(1): rho'' < 0 always -> residual and Jacobian scale by sqrt(rho')
+      double rho0, rho1, rho2;
+      cauchyLoss(s, rho0, rho1, rho2);
+      cost = 0.5 * rho0;
+      const double sc = sqrt(rho1);
+      rr[0] *= sc; rr[1] *= sc;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) jp[k] *= sc;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jl[k] *= sc;
+      if (WITH_EXT) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) je[k] *= sc;
+      }
+    } else {
+      cost = 0.5 * s;
+    }
+    r[i] = rr[0];
+    r[stride + i] = rr[1];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Jp[k * stride + i] = jp[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jl[k * stride + i] = jl[k];
+    if (WITH_EXT) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Je[k * stride + i] = je[k];
+    }
+  }
+  if (costPartial) {
+    const double bs = blockSum(cost, red);
+    if (threadIdx.x == 0) costPartial[blockIdx.x] = bs;
+  }
+}
+
+static int evalGrid(int N) { return (N + 127) / 128; }
+
+void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_t s) {
+  if (p.N == 0) return;
+  const size_t smem = (size_t)(p.nPose * 7 + p.nExt * 7) * 8 + (size_t)p.nCam * sizeof(CameraModel);
+  const int grid = evalGrid(p.N);
+  const double* pose = cand ? p.poseC : p.pose;
+  const double* ext = cand ? p.extC : p.ext;
+  const double* lm = cand ? p.lmC : p.lm;
+  double* r = cand ? p.rCand : p.rCur;
+  double* Jp = cand ? p.JpCand : p.JpCur;
+  double* Jl = cand ? p.JlCand : p.JlCur;
+  double* Je = cand ? p.JeCand : p.JeCur;
+  double* cp = p.partial + (size_t)PS_COST_REPROJ * kMaxPartials;
+#define LAUNCH(R, E)                                                                                              \
+  hipLaunchKernelGGL((k_eval_reproj<R, E>), dim3(grid), dim3(128), smem, s, p.N, p.nPose, p.nExt, p.nCam, pose, ext, \
+                     lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, r, Jp, Jl, Je, cp, (size_t)p.N)
+  if (robust) { if (p.anyExtVariable) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (p.anyExtVariable) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+}
+
+// Jacobian-evaluation roofline kernel on `copies` independent replicas of the window (HBM-resident
+// working set): identical arithmetic, outputs offset per replica.
+void launchEvalReprojBatched(const DeviceProblem& p, int copies, double* rOut, double* JpOut, double* JlOut,
+                             double* JeOut, hipStream_t s) {
+  // a replica = the same N observations; the SoA stride is the full batch so every replica owns
+  // distinct output lines.  Inputs are replicated by the caller (obs arrays of size copies*N).
+  const size_t smem = (size_t)(p.nPose * 7 + p.nExt * 7) * 8 + (size_t)p.nCam * sizeof(CameraModel);
+  const int NB = p.N * copies;
+  const int grid = evalGrid(NB);
+  if (p.anyExtVariable)
+    hipLaunchKernelGGL((k_eval_reproj<true, true>), dim3(grid), dim3(128), smem, s, NB, p.nPose, p.nExt, p.nCam, p.pose,
+                       p.ext, p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, rOut, JpOut, JlOut, JeOut,
+                       (double*)nullptr, (size_t)NB);
+  else
+    hipLaunchKernelGGL((k_eval_reproj<true, false>), dim3(grid), dim3(128), smem, s, NB, p.nPose, p.nExt, p.nCam,
+                       p.pose, p.ext, p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, rOut, JpOut, JlOut, JeOut,
+                       (double*)nullptr, (size_t)NB);
+}
+
+// ================================================================ K2: small factors (one workgroup each)
+__device__ __forceinline__ double dtSecDev(const uint32_t* a, const uint32_t* b) {
+  long long s = (long long)a[0] - (long long)b[0];
+  long long ns = (long long)a[1] - (long long)b[1];
+  while (ns < 0) { ns += 1000000000LL; s -= 1; }
+  while (ns >= 1000000000LL) { ns -= 1000000000LL; s += 1; }
+  return (double)s + 1e-9 * (double)ns;
+}
+__device__ __forceinline__ bool timeLess(const uint32_t* a, const uint32_t* b) {
+  return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]);
+}
+__device__ __forceinline__ void mm3(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void crossMxDev(double x, double y, double z, double* C) {
+  C[0] = 0; C[1] = -z; C[2] = y; C[3] = z; C[4] = 0; C[5] = -x; C[6] = -y; C[7] = x; C[8] = 0;
+}
+__device__ __forceinline__ void rightJacobianDev(double x, double y, double z, double* J) {
+  const double Phi = sqrt(x * x + y * y + z * z);
+  double X[9], X2[9];
+  crossMxDev(x, y, z, X);
+  mm3(X, X, X2);
+  double a, b;
+  if (Phi < 1.0e-4) { a = -0.5; b = 1.0 / 6.0; }
+  else {
+    const double Phi2 = Phi * Phi, Phi3 = Phi2 * Phi;
+    a = -(1.0 - cos(Phi)) / Phi2;
+    b = (Phi - sin(Phi)) / Phi3;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] = a * X[i] + b * X2[i];
+  J[0] += 1; J[4] += 1; J[8] += 1;
+}
+__device__ __forceinline__ void quatPlusMat3(const Quat& q, double* Q) {  // top-left 3x3 of plus(q)
+  Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.z; Q[4] = q.w; Q[5] = -q.x; Q[6] = -q.y; Q[7] = q.x; Q[8] = q.w;
+}
+__device__ __forceinline__ void quatOplusMat3(const Quat& q, double* Q) {  // top-left 3x3 of oplus(q)
+  Q[0] = q.w; Q[1] = q.z; Q[2] = -q.y; Q[3] = -q.z; Q[4] = q.w; Q[5] = q.x; Q[6] = q.y; Q[7] = -q.x; Q[8] = q.w;
+}
+__device__ __forceinline__ void quatPlusMat4(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.x;
+  Q[4] = q.z; Q[5] = q.w; Q[6] = -q.x; Q[7] = q.y;
+  Q[8] = -q.y; Q[9] = q.x; Q[10] = q.w; Q[11] = q.z;
+  Q[12] = -q.x; Q[13] = -q.y; Q[14] = -q.z; Q[15] = q.w;
+}
+__device__ __forceinline__ void quatOplusMat4(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = q.z; Q[2] = -q.y; Q[3] = q.x;
+  Q[4] = -q.z; Q[5] = q.w; Q[6] = q.x; Q[7] = q.y;
+  Q[8] = q.y; Q[9] = -q.x; Q[10] = q.w; Q[11] = q.z;
+  Q[12] = -q.x; Q[13] = -q.y; Q[14] = -q.z; Q[15] = q.w;
+}
+__device__ __forceinline__ void mm4(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+      C[i * 4 + j] = s;
+    }
+}
+
+// LDS layout of the factor kernel
+struct FactorShared {
+  double W[225];      // sqrtInfo (m x m)
+  double F[15 * 30];  // un-weighted Jacobian blocks (m x ncols)
+  double e[15];       // un-weighted error
+  double P[225], T[225], Fd[225];  // IMU covariance propagation
+  int flag;
+};
+
+// 15x15 helpers on LDS matrices, executed by the whole workgroup (blockDim >= 225)
+__device__ void chol15(double* A, int* failFlag) {  // in-place lower Cholesky (strict upper left untouched)
+  const int t = threadIdx.x, i = t / 15, j = t % 15;
+  for (int k = 0; k < 15; ++k) {
+    __syncthreads();
+    if (t == 0) {
+      const double x = A[k * 15 + k];
+      if (x <= 0) { *failFlag = 1; A[k * 15 + k] = 1.0; }
+      else A[k * 15 + k] = sqrt(x);
+    }
+    __syncthreads();
+    if (t < 225 && j == k && i > k) A[i * 15 + k] /= A[k * 15 + k];
+    __syncthreads();
+    if (t < 225 && j > k && i >= j) A[i * 15 + j] -= A[i * 15 + k] * A[j * 15 + k];
+  }
+  __syncthreads();
+}
+
+// normalised pose -> Transformation(r, q) semantics (q normalised, C from normalised q)
+struct TF { double r[3]; Quat q; Mat3 C; };
+__device__ __forceinline__ TF makeTF(const double* x) {
+  TF t;
+  t.r[0] = x[0]; t.r[1] = x[1]; t.r[2] = x[2];
+  t.q = qnormalized(Quat{x[3], x[4], x[5], x[6]});
+  t.C = quatToR(t.q);
+  return t;
+}
+
+// IMU integration loop shared by redoPreintegration (ImuError.cpp:76-263, REDO=true) and
+// propagation (:266-476, REDO=false), executed by the whole workgroup: every thread carries the small
+// 3x3 state redundantly in registers; the 15x15 covariance lives in LDS (sh.P), one entry per thread.
+// The two flavours differ exactly where the reference does: dalpha_db_g accumulates
+// C_1*rightJacobian*dt (:189) vs dt*C_1 (:384); sigma2_v = dt*sigma_a_c^2 (:215) vs
+// dt*sigma_a_c*par.sigma_a_c (:412).
+struct ImuState {
+  Quat Dq;
+  double Ci[9], Cdi[9], ai[3], adi[3], dal[9], dv[9], dp[9], Delta_t;
+  int used;
+};
+template <bool REDO>
+__device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, const double* __restrict__ M,
+                             const double* sb, FactorShared& sh, ImuState& st) {
+  const int t = threadIdx.x;
+  Quat Dq = {0, 0, 0, 1};
+  double Ci[9] = {0}, Cdi[9] = {0}, ai[3] = {0}, adi[3] = {0}, cross[9] = {0}, dal[9] = {0}, dv[9] = {0}, dp[9] = {0};
+  if (t < 225) sh.P[t] = 0;
+  __syncthreads();
+  uint32_t time[2] = {im.t0[0], im.t0[1]};
+  const uint32_t end[2] = {im.t1[0], im.t1[1]};
+  double Delta_t = 0;
+  bool hasStarted = false;
+  const int n = im.sampleCount;
+  int used = 0;
+  for (int it = 0; it < n; ++it) {
+    double w0[3] = {M[6 * it], M[6 * it + 1], M[6 * it + 2]};
+    double a0[3] = {M[6 * it + 3], M[6 * it + 4], M[6 * it + 5]};
+    const bool last = (it + 1 == n);
+    const int nx = last ? it : it + 1;
+    double w1[3] = {M[6 * nx], M[6 * nx + 1], M[6 * nx + 2]};
+    double a1[3] = {M[6 * nx + 3], M[6 * nx + 4], M[6 * nx + 5]};
+    uint32_t nexttime[2] = {last ? end[0] : T[2 * nx], last ? end[1] : T[2 * nx + 1]};
+    double dt = dtSecDev(nexttime, time);
+    if (timeLess(end, nexttime)) {
+      const double interval = dtSecDev(nexttime, T + 2 * it);
+      nexttime[0] = end[0]; nexttime[1] = end[1];
+      dt = dtSecDev(nexttime, time);
+      const double rr = dt / interval;
+      for (int k = 0; k < 3; ++k) { w1[k] = (1.0 - rr) * w0[k] + rr * w1[k]; a1[k] = (1.0 - rr) * a0[k] + rr * a1[k]; }
+    }
+    if (dt <= 0.0) continue;
+    Delta_t += dt;
+    if (!hasStarted) {
+      hasStarted = true;
+      const double rr = dt / dtSecDev(nexttime, T + 2 * it);
+      for (int k = 0; k < 3; ++k) { w0[k] = rr * w0[k] + (1.0 - rr) * w1[k]; a0[k] = rr * a0[k] + (1.0 - rr) * a1[k]; }
+    }
+    double sigma_g_c = im.par.sigma_g_c, sigma_a_c = im.par.sigma_a_c;
+    bool gs = false, as = false;
+    for (int k = 0; k < 3; ++k) {
+      gs = gs || fabs(w0[k]) > im.par.g_max || fabs(w1[k]) > im.par.g_max;
+      as = as || fabs(a0[k]) > im.par.a_max || fabs(a1[k]) > im.par.a_max;
+    }
+    if (gs) sigma_g_c *= 100;
+    if (as) sigma_a_c *= 100;
+    const double wt[3] = {0.5 * (w0[0] + w1[0]) - sb[3], 0.5 * (w0[1] + w1[1]) - sb[4], 0.5 * (w0[2] + w1[2]) - sb[5]};
+    const double at[3] = {0.5 * (a0[0] + a1[0]) - sb[6], 0.5 * (a0[1] + a1[1]) - sb[7], 0.5 * (a0[2] + a1[2]) - sb[8]};
+    const double theta_half = sqrt(wt[0] * wt[0] + wt[1] * wt[1] + wt[2] * wt[2]) * 0.5 * dt;
+    const double sc = sinc(theta_half);
+    const Quat dq = {sc * wt[0] * 0.5 * dt, sc * wt[1] * 0.5 * dt, sc * wt[2] * 0.5 * dt, cos(theta_half)};
+    const Quat Dq1 = qmul(Dq, dq);
+    const Mat3 C = quatToR(Dq), C1 = quatToR(Dq1);
+    double Cs[9];
+    for (int k = 0; k < 9; ++k) Cs[k] = C.m[k] + C1.m[k];
+    const double Csa[3] = {Cs[0] * at[0] + Cs[1] * at[1] + Cs[2] * at[2], Cs[3] * at[0] + Cs[4] * at[1] + Cs[5] * at[2],
+                           Cs[6] * at[0] + Cs[7] * at[1] + Cs[8] * at[2]};
+    double Ci1[9], ai1[3], pterm[3];
+    for (int k = 0; k < 9; ++k) Ci1[k] = Ci[k] + 0.5 * Cs[k] * dt;
+    for (int k = 0; k < 3; ++k) ai1[k] = ai[k] + 0.5 * Csa[k] * dt;
+    double B012[9];
+    for (int k = 0; k < 9; ++k) B012[k] = -Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
+    for (int k = 0; k < 9; ++k) Cdi[k] += Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
+    for (int k = 0; k < 3; ++k) pterm[k] = ai[k] * dt + 0.25 * Csa[k] * dt * dt;
+    for (int k = 0; k < 3; ++k) adi[k] += pterm[k];
+    double RJ[9], t9[9];
+    rightJacobianDev(wt[0] * dt, wt[1] * dt, wt[2] * dt, RJ);
+    if (REDO) {
+      mm3(C1.m, RJ, t9);
+      for (int k = 0; k < 9; ++k) dal[k] += t9[k] * dt;
+    } else {
+      for (int k = 0; k < 9; ++k) dal[k] += dt * C1.m[k];
+    }
+    const Mat3 Rdqi = quatToR(qinv(dq));
+    double cross1[9];
+    mm3(Rdqi.m, cross, cross1);
+    for (int k = 0; k < 9; ++k) cross1[k] += RJ[k] * dt;
+    double ax[9], t1[9], t2[9], Mm[9];
+    crossMxDev(at[0], at[1], at[2], ax);
+    mm3(C.m, ax, t1);
+    mm3(t1, cross, Mm);
+    mm3(C1.m, ax, t1);
+    mm3(t1, cross1, t2);
+    for (int k = 0; k < 9; ++k) Mm[k] += t2[k];
+    double dv1[9], F09[9];
+    for (int k = 0; k < 9; ++k) dv1[k] = dv[k] + 0.5 * dt * Mm[k];
+    for (int k = 0; k < 9; ++k) F09[k] = dt * dv[k] + 0.25 * dt * dt * Mm[k];
+    for (int k = 0; k < 9; ++k) dp[k] += F09[k];
+    // covariance propagation P = F P F^T + Q (:197-230)
+    __syncthreads();
+    if (t < 225) sh.Fd[t] = (t / 15 == t % 15) ? 1.0 : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      double X[9];
+      crossMxDev(pterm[0], pterm[1], pterm[2], X);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          sh.Fd[(0 + a) * 15 + 3 + b] = -X[a * 3 + b];
+          sh.Fd[(0 + a) * 15 + 6 + b] = (a == b) ? dt : 0.0;
+          sh.Fd[(0 + a) * 15 + 9 + b] = F09[a * 3 + b];
+          sh.Fd[(0 + a) * 15 + 12 + b] = B012[a * 3 + b];
+          sh.Fd[(3 + a) * 15 + 9 + b] = -dt * C1.m[a * 3 + b];
+          sh.Fd[(6 + a) * 15 + 9 + b] = 0.5 * dt * Mm[a * 3 + b];
+          sh.Fd[(6 + a) * 15 + 12 + b] = -0.5 * Cs[a * 3 + b] * dt;
+        }
+      crossMxDev(0.5 * Csa[0] * dt, 0.5 * Csa[1] * dt, 0.5 * Csa[2] * dt, X);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) sh.Fd[(6 + a) * 15 + 3 + b] = -X[a * 3 + b];
+    }
+    __syncthreads();
+    if (t < 225) {
+      const int a = t / 15, b = t % 15;
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += sh.Fd[a * 15 + k] * sh.P[k * 15 + b];
+      sh.T[t] = s;
+    }
+    __syncthreads();
+    if (t < 225) {
+      const int a = t / 15, b = t % 15;
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += sh.T[a * 15 + k] * sh.Fd[b * 15 + k];
+      if (a == b) {
+        const double s2v = REDO ? dt * sigma_a_c * sigma_a_c : dt * sigma_a_c * im.par.sigma_a_c;
+        if (a < 3) s += 0.5 * dt * dt * s2v;
+        else if (a < 6) s += dt * sigma_g_c * sigma_g_c;
+        else if (a < 9) s += s2v;
+        else if (a < 12) s += dt * im.par.sigma_gw_c * im.par.sigma_gw_c;
+        else s += dt * im.par.sigma_aw_c * im.par.sigma_aw_c;
+      }
+      sh.P[t] = s;
+    }
+    __syncthreads();
+    // memory shift
+    Dq = Dq1;
+    for (int k = 0; k < 9; ++k) { Ci[k] = Ci1[k]; cross[k] = cross1[k]; dv[k] = dv1[k]; }
+    for (int k = 0; k < 3; ++k) ai[k] = ai1[k];
+    time[0] = nexttime[0]; time[1] = nexttime[1];
+    ++used;
+    if (nexttime[0] == end[0] && nexttime[1] == end[1]) break;
+  }
+  st.Dq = Dq;
+  for (int k = 0; k < 9; ++k) { st.Ci[k] = Ci[k]; st.Cdi[k] = Cdi[k]; st.dal[k] = dal[k]; st.dv[k] = dv[k]; st.dp[k] = dp[k]; }
+  for (int k = 0; k < 3; ++k) { st.ai[k] = ai[k]; st.adi[k] = adi[k]; }
+  st.Delta_t = Delta_t;
+  st.used = used;
+}
+
+__device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ imuT, const double* __restrict__ imuM,
+                                      const double* sb, FactorShared& sh) {
+  const int t = threadIdx.x;
+  ImuState st;
+  imuIntegrate<true>(im, imuT + 2 * (size_t)im.sampleStart, imuM + 6 * (size_t)im.sampleStart, sb, sh, st);
+  // store the state (thread 0) -- every thread holds identical values
+  if (t == 0) {
+    im.Delta_q[0] = st.Dq.x; im.Delta_q[1] = st.Dq.y; im.Delta_q[2] = st.Dq.z; im.Delta_q[3] = st.Dq.w;
+    for (int k = 0; k < 9; ++k) { im.C_integral[k] = st.Ci[k]; im.C_doubleintegral[k] = st.Cdi[k]; im.dalpha_db_g[k] = st.dal[k]; im.dv_db_g[k] = st.dv[k]; im.dp_db_g[k] = st.dp[k]; }
+    for (int k = 0; k < 3; ++k) { im.acc_integral[k] = st.ai[k]; im.acc_doubleintegral[k] = st.adi[k]; }
+    for (int k = 0; k < 9; ++k) im.sb_ref[k] = sb[k];
+    im.Delta_t = st.Delta_t;
+  }
+  // symmetrise P, information = P^-1 (via Cholesky), symmetrise, sqrtInfo = chol(information)^T  (:246-258)
+  __syncthreads();
+  if (t < 225) sh.T[t] = 0.5 * sh.P[t] + 0.5 * sh.P[(t % 15) * 15 + t / 15];
+  __syncthreads();
+  if (t < 225) { sh.P[t] = sh.T[t]; im.P_delta[t] = sh.T[t]; }
+  __syncthreads();
+  chol15(sh.P, &sh.flag);  // P = L L^T (lower in sh.P)
+  __syncthreads();
+  if (t < 225) sh.T[t] = 0.0;
+  __syncthreads();
+  // Linv (lower) by forward substitution, one column per thread
+  if (t < 15) {
+    const int c = t;
+    for (int i = c; i < 15; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= sh.P[i * 15 + k] * sh.T[k * 15 + c];
+      sh.T[i * 15 + c] = s / sh.P[i * 15 + i];
+    }
+  }
+  __syncthreads();
+  if (t < 225) {  // information = Linv^T Linv
+    const int a = t / 15, b = t % 15;
+    double s = 0;
+    for (int k = (a > b ? a : b); k < 15; ++k) s += sh.T[k * 15 + a] * sh.T[k * 15 + b];
+    sh.Fd[t] = s;
+  }
+  __syncthreads();
+  if (t < 225) { sh.P[t] = 0.5 * sh.Fd[t] + 0.5 * sh.Fd[(t % 15) * 15 + t / 15]; }
+  __syncthreads();
+  if (t < 225) im.information[t] = sh.P[t];
+  __syncthreads();
+  chol15(sh.P, &sh.flag);
+  if (t < 225) {
+    const int a = t / 15, b = t % 15;
+    im.sqrtInfo[t] = (b >= a) ? sh.P[b * 15 + a] : 0.0;  // L^T
+  }
+  __syncthreads();
+}
+
+// ImuError::propagation (ImuError.cpp:266-476): io[0..6] T_WS, io[7..15] speed/bias (in/out);
+// out[0] = number of integration steps (or -1), optional 15x15 jacobian / covariance.
+__global__ __launch_bounds__(256) void k_imu_propagation(const DevImu* imPtr, const uint32_t* __restrict__ T,
+                                                         const double* __restrict__ M, double* io, double* jac,
+                                                         double* cov, int* used) {
+  __shared__ FactorShared sh;
+  const int t = threadIdx.x;
+  const DevImu& im = *imPtr;
+  // sanity (:279): the last measurement must not be older than t_end
+  if (im.sampleCount <= 0 || timeLess(T + 2 * (im.sampleCount - 1), im.t1)) {
+    if (t == 0) *used = -1;
+    return;
+  }
+  double sb[9];
+  for (int k = 0; k < 9; ++k) sb[k] = io[7 + k];
+  ImuState st;
+  imuIntegrate<false>(im, T, M, sb, sh, st);
+  const TF T0 = makeTF(io);
+  const double gz = im.par.g * (6371009.0 / sqrt(6371009.0 * 6371009.0));
+  const double gW[3] = {im.par.g * 0.0, im.par.g * 0.0, gz};
+  const double Dt = st.Delta_t;
+  const Vec3 c2 = rotate(T0.C, Vec3{st.adi[0], st.adi[1], st.adi[2]});
+  const Vec3 c1 = rotate(T0.C, Vec3{st.ai[0], st.ai[1], st.ai[2]});
+  const double C2[3] = {c2.x, c2.y, c2.z}, C1v[3] = {c1.x, c1.y, c1.z};
+  __syncthreads();
+  if (t == 0) {
+    *used = st.used;
+    for (int k = 0; k < 3; ++k) io[k] = T0.r[k] + sb[k] * Dt + C2[k] - 0.5 * gW[k] * Dt * Dt;
+    const Quat qn = qnormalized(qmul(T0.q, st.Dq));
+    io[3] = qn.x; io[4] = qn.y; io[5] = qn.z; io[6] = qn.w;
+    for (int k = 0; k < 3; ++k) io[7 + k] = sb[k] + C1v[k] - gW[k] * Dt;
+    if (jac) {
+      for (int k = 0; k < 225; ++k) jac[k] = (k / 15 == k % 15) ? 1.0 : 0.0;
+      auto setB = [&](int r0, int c0, const double* B, double s) {
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) jac[(r0 + a) * 15 + c0 + b] = s * B[a * 3 + b];
+      };
+      double X[9], T9[9];
+      const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      crossMxDev(C2[0], C2[1], C2[2], X); setB(0, 3, X, -1.0);
+      setB(0, 6, I3, Dt);
+      mm3(T0.C.m, st.dp, T9); setB(0, 9, T9, 1.0);
+      mm3(T0.C.m, st.Cdi, T9); setB(0, 12, T9, -1.0);
+      mm3(T0.C.m, st.dal, T9); setB(3, 9, T9, -1.0);
+      crossMxDev(C1v[0], C1v[1], C1v[2], X); setB(6, 3, X, -1.0);
+      mm3(T0.C.m, st.dv, T9); setB(6, 9, T9, 1.0);
+      mm3(T0.C.m, st.Ci, T9); setB(6, 12, T9, -1.0);
+    }
+  }
+  if (cov) {
+    // P = T P_delta T^T with T = blockdiag(C, C, C, I, I)
+    __syncthreads();
+    if (t < 225) {
+      const int a = t / 15, b = t % 15;
+      sh.Fd[t] = (a < 9 && b < 9 && a / 3 == b / 3) ? T0.C.m[(a % 3) * 3 + (b % 3)] : ((a == b) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (t < 225) {
+      const int a = t / 15, b = t % 15;
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += sh.Fd[a * 15 + k] * sh.P[k * 15 + b];
+      sh.T[t] = s;
+    }
+    __syncthreads();
+    if (t < 225) {
+      const int a = t / 15, b = t % 15;
+      double s = 0;
+      for (int k = 0; k < 15; ++k) s += sh.T[a * 15 + k] * sh.Fd[b * 15 + k];
+      cov[t] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ const double* blockPtr(const DeviceProblem& p, bool cand, int kind, int slot) {
+  if (kind == B_POSE) return (cand ? p.poseC : p.pose) + (size_t)slot * 7;
+  if (kind == B_EXT) return (cand ? p.extC : p.ext) + (size_t)slot * 7;
+  return (cand ? p.sbC : p.sb) + (size_t)slot * 9;
+}
+__device__ __forceinline__ int blockOff(const DeviceProblem& p, int kind, int slot) {
+  if (kind == B_POSE) return p.poseOff[slot];
+  if (kind == B_EXT) return p.extOff[slot];
+  return p.sbOff[slot];
+}
+
+__global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand) {
+  __shared__ FactorShared sh;
+  const int f = blockIdx.x, t = threadIdx.x;
+  const DevFactor& fac = p.factors[f];
+  FactorLin& lin = (cand ? p.linCand : p.linCur)[f];
+  const int m = fac.m;
+  if (t == 0) sh.flag = 0;
+  for (int i = t; i < 15 * 30; i += blockDim.x) sh.F[i] = 0;
+  __syncthreads();
+  int ncols = 0;
+  for (int b = 0; b < fac.nblk; ++b) ncols += (fac.blkKind[b] == B_SB) ? 9 : 6;
+
+  if (fac.kind == F_IMU) {
+    DevImu& im = p.imus[fac.imuIndex];
+    const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
+    const double* s0 = blockPtr(p, cand, fac.blkKind[1], fac.blkSlot[1]);
+    const double* x1 = blockPtr(p, cand, fac.blkKind[2], fac.blkSlot[2]);
+    const double* s1 = blockPtr(p, cand, fac.blkKind[3], fac.blkSlot[3]);
+    const double Delta_t = dtSecDev(im.t1, im.t0);
+    double Db[6];
+    for (int k = 0; k < 6; ++k) Db[k] = s0[3 + k] - im.sb_ref[3 + k];
+    // ImuError.cpp:739: redo_ || |Delta_b_g| * Delta_t > 1e-4   (uniform across the workgroup)
+    const bool redo = im.redo || (sqrt(Db[0] * Db[0] + Db[1] * Db[1] + Db[2] * Db[2]) * Delta_t > 0.0001);
+    __syncthreads();
+    if (redo) {
+      double sbl[9];
+      for (int k = 0; k < 9; ++k) sbl[k] = s0[k];
+      imuRedoPreintegration(im, p.imuT, p.imuMeas, sbl, sh);
+      if (t == 0) { im.redo = 0; im.redoCounter++; }
+      for (int k = 0; k < 6; ++k) Db[k] = 0;
+      __syncthreads();
+    }
+    if (t < 225) sh.W[t] = im.sqrtInfo[t];
+    if (t == 0) {
+      // ImuError.cpp:751-791
+      const TF T0 = makeTF(x0), T1 = makeTF(x1);
+      const double gz = im.par.g * (6371009.0 / sqrt(6371009.0 * 6371009.0));
+      const double gW[3] = {im.par.g * 0.0, im.par.g * 0.0, gz};
+      double dpv[3], dvv[3];
+      for (int k = 0; k < 3; ++k) {
+        dpv[k] = T0.r[k] - T1.r[k] + s0[k] * Delta_t - 0.5 * gW[k] * Delta_t * Delta_t;
+        dvv[k] = s0[k] - s1[k] - gW[k] * Delta_t;
+      }
+      double F0[225], F1[225];
+      for (int k = 0; k < 225; ++k) { F0[k] = 0; F1[k] = 0; }
+      for (int k = 0; k < 15; ++k) { F0[k * 16] = 1.0; F1[k * 16] = -1.0; }
+      // C_S0_W = C_WS_0^T
+      double Ct[9];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Ct[a * 3 + b] = T0.C.m[b * 3 + a];
+      const double a3[3] = {-(im.dalpha_db_g[0] * Db[0] + im.dalpha_db_g[1] * Db[1] + im.dalpha_db_g[2] * Db[2]),
+                            -(im.dalpha_db_g[3] * Db[0] + im.dalpha_db_g[4] * Db[1] + im.dalpha_db_g[5] * Db[2]),
+                            -(im.dalpha_db_g[6] * Db[0] + im.dalpha_db_g[7] * Db[1] + im.dalpha_db_g[8] * Db[2])};
+      const Quat Dq = qmul(deltaQ(a3[0], a3[1], a3[2]), Quat{im.Delta_q[0], im.Delta_q[1], im.Delta_q[2], im.Delta_q[3]});
+      auto setB = [](double* F, int r0, int c0, const double* B, double s) {
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) F[(r0 + a) * 15 + c0 + b] = s * B[a * 3 + b];
+      };
+      double X[9], T9[9];
+      setB(F0, 0, 0, Ct, 1.0);
+      crossMxDev(dpv[0], dpv[1], dpv[2], X); mm3(Ct, X, T9); setB(F0, 0, 3, T9, 1.0);
+      setB(F0, 0, 6, Ct, Delta_t);
+      setB(F0, 0, 9, im.dp_db_g, 1.0);
+      setB(F0, 0, 12, im.C_doubleintegral, -1.0);
+      const Quat q1inv = qinv(T1.q);
+      double Qp[16], Qo[16], Q44[16];
+      quatPlusMat4(qmul(Dq, q1inv), Qp);
+      quatOplusMat4(T0.q, Qo);
+      mm4(Qp, Qo, Q44);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) F0[(3 + a) * 15 + 3 + b] = Q44[a * 4 + b];
+      double Qo1[16], Qo2[16];
+      quatOplusMat4(qmul(q1inv, T0.q), Qo1);
+      quatOplusMat4(Dq, Qo2);
+      mm4(Qo1, Qo2, Q44);
+      double TL[9], nd[9];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) { TL[a * 3 + b] = Q44[a * 4 + b]; nd[a * 3 + b] = -im.dalpha_db_g[a * 3 + b]; }
+      mm3(TL, nd, T9);
+      setB(F0, 3, 9, T9, 1.0);
+      crossMxDev(dvv[0], dvv[1], dvv[2], X); mm3(Ct, X, T9); setB(F0, 6, 3, T9, 1.0);
+      setB(F0, 6, 6, Ct, 1.0);
+      setB(F0, 6, 9, im.dv_db_g, 1.0);
+      setB(F0, 6, 12, im.C_integral, -1.0);
+      setB(F1, 0, 0, Ct, -1.0);
+      double Qp2[16], Qp3[16], Qt[16];
+      quatPlusMat4(Dq, Qp2);
+      quatPlusMat4(q1inv, Qp3);
+      mm4(Qp2, Qo, Qt);
+      mm4(Qt, Qp3, Q44);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) F1[(3 + a) * 15 + 3 + b] = -Q44[a * 4 + b];
+      setB(F1, 6, 6, Ct, -1.0);
+      // error
+      const Vec3 v1 = rotate(Mat3{{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}}, Vec3{dpv[0], dpv[1], dpv[2]});
+      const Vec3 v2 = rotate(Mat3{{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}}, Vec3{dvv[0], dvv[1], dvv[2]});
+      const double v1a[3] = {v1.x, v1.y, v1.z}, v2a[3] = {v2.x, v2.y, v2.z};
+      for (int a = 0; a < 3; ++a) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < 6; ++k) { s1 += F0[a * 15 + 9 + k] * Db[k]; s2 += F0[(6 + a) * 15 + 9 + k] * Db[k]; }
+        sh.e[a] = v1a[a] + im.acc_doubleintegral[a] + s1;
+        sh.e[6 + a] = v2a[a] + im.acc_integral[a] + s2;
+      }
+      const Quat qd = qmul(Dq, qmul(q1inv, T0.q));
+      sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
+      for (int k = 0; k < 6; ++k) sh.e[9 + k] = s0[3 + k] - s1[3 + k];
+      // F = [F0 | F1] (15 x 30): columns pose0(6) sb0(9) pose1(6) sb1(9)
+      for (int a = 0; a < 15; ++a)
+        for (int c = 0; c < 15; ++c) { sh.F[a * 30 + c] = F0[a * 15 + c]; sh.F[a * 30 + 15 + c] = F1[a * 15 + c]; }
+    }
+  } else if (t == 0) {
+    for (int k = 0; k < m * m; ++k) sh.W[k] = fac.sqrtInfo[k];
+    const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
+    if (fac.kind == F_POSE_PRIOR) {  // PoseError.cpp:87-132
+      const TF Tm = makeTF(fac.meas), Tx = makeTF(x0);
+      const Quat dq = qnormalized(qmul(Tm.q, qnormalized(qinv(Tx.q))));
+      for (int k = 0; k < 3; ++k) sh.e[k] = Tm.r[k] - Tx.r[k];
+      sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
+      double Q[9];
+      quatPlusMat3(dq, Q);
+      for (int a = 0; a < 3; ++a) {
+        sh.F[a * 6 + a] = -1.0;
+        for (int b = 0; b < 3; ++b) sh.F[(3 + a) * 6 + 3 + b] = -Q[a * 3 + b];
+      }
+    } else if (fac.kind == F_SB_PRIOR) {  // SpeedAndBiasError.cpp:83-113
+      for (int k = 0; k < 9; ++k) { sh.e[k] = fac.meas[k] - x0[k]; sh.F[k * 9 + k] = -1.0; }
+    } else if (fac.kind == F_RELPOSE) {  // RelativePoseError.cpp:79-147
+      const double* x1 = blockPtr(p, cand, fac.blkKind[1], fac.blkSlot[1]);
+      const TF T0 = makeTF(x0), T1 = makeTF(x1);
+      const Quat dq = qnormalized(qmul(T1.q, qnormalized(qinv(T0.q))));
+      for (int k = 0; k < 3; ++k) sh.e[k] = T1.r[k] - T0.r[k];
+      sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
+      double Q[9], Qo[9];
+      quatPlusMat3(dq, Q);
+      quatOplusMat3(dq, Qo);
+      for (int a = 0; a < 3; ++a) {
+        sh.F[a * 12 + a] = -1.0;
+        sh.F[a * 12 + 6 + a] = 1.0;
+        for (int b = 0; b < 3; ++b) {
+          sh.F[(3 + a) * 12 + 3 + b] = -Q[a * 3 + b];
+          sh.F[(3 + a) * 12 + 6 + 3 + b] = Qo[a * 3 + b];
+        }
+      }
+    } else if (fac.kind == F_SONAR) {  // SonarError.cpp:118-183 (reference sign/anchor quirks kept)
+      const TF Tx = makeTF(x0);
+      const double range = fac.meas[0], heading = fac.meas[1];
+      const double d[3] = {Tx.r[0] - fac.meas[2], Tx.r[1] - fac.meas[3], Tx.r[2] - fac.meas[4]};
+      sh.e[0] = range - sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const TF Tso = makeTF(fac.aux);
+      // T_WSo = T_WS * T_SSo ; point = T_WSo * (range cos h, range sin h, 0)
+      const Vec3 rso = rotate(Tx.C, Vec3{Tso.r[0], Tso.r[1], Tso.r[2]});
+      const Quat qwso = qnormalized(qmul(Tx.q, Tso.q));
+      const Mat3 Cwso = quatToR(qwso);
+      const Vec3 pp = rotate(Cwso, Vec3{range * cos(heading), range * sin(heading), 0.0});
+      const double sp[3] = {pp.x + rso.x + Tx.r[0], pp.y + rso.y + Tx.r[1], pp.z + rso.z + Tx.r[2]};
+      for (int a = 0; a < 3; ++a) sh.F[a] = (Tx.r[a] - sp[a]) / range;
+    } else if (fac.kind == F_DEPTH) {  // DepthError.cpp:75-139
+      sh.e[0] = x0[2] - (-1 * fac.meas[0] + fac.meas[1]);
+      sh.F[2] = 1.0;
+    }
+  }
+  __syncthreads();
+  // r = W e ; J = W F
+  for (int a = t; a < m; a += blockDim.x) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += sh.W[a * m + k] * sh.e[k];
+    lin.r[a] = s;
+  }
+  for (int idx = t; idx < m * ncols; idx += blockDim.x) {
+    const int a = idx / ncols, c = idx % ncols;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += sh.W[a * m + k] * sh.F[k * ncols + c];
+    lin.J[a * ncols + c] = s;
+  }
+  if (t == 0) {
+    lin.m = m; lin.ncols = ncols;
+    for (int b = 0; b < 4; ++b) {
+      if (b < fac.nblk) { lin.off[b] = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); lin.dim[b] = (fac.blkKind[b] == B_SB) ? 9 : 6; }
+      else { lin.off[b] = -1; lin.dim[b] = 0; }
+    }
+  }
+  __syncthreads();
+  // cost partial: 0.5 |r|^2
+  if (t == 0) {
+    double c = 0;
+    for (int a = 0; a < m; ++a) c += lin.r[a] * lin.r[a];
+    p.partial[(size_t)PS_COST_FACTORS * kMaxPartials + f] = 0.5 * c;
+  }
+}
+
+void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
+                          int* used, hipStream_t s) {
+  hipLaunchKernelGGL(k_imu_propagation, dim3(1), dim3(256), 0, s, im, T, M, io, jac, cov, used);
+}
+
+void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s) {
+  if (p.F == 0) return;
+  hipLaunchKernelGGL(k_eval_factors, dim3(p.F), dim3(256), 0, s, p, cand ? 1 : 0);
+}
+
+// ================================================================ K3: marginalisation prior (H-space)
+// cost = 0.5 c0 + bp^T dchi + 0.5 dchi^T Ht dchi ;  grad (lin space) = bp + Ht dchi
+// Ceres multiplies the ambient Jacobian (J_min * lift(x_lin)) by PlusJacobian(x): for a pose block the
+// effective tangent map is M = blockdiag(I3, oplus(q_cur * q_lin^-1)[0:3,0:3]) (MarginalizationError.cpp:798-844).
+__global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
+  __shared__ double red[4];
+  const int t = threadIdx.x, m = p.priorM;
+  for (int b = t; b < p.priorBlocks; b += blockDim.x) {
+    const PriorBlock& pb = p.priorBlk[b];
+    double* M3 = p.priorM3 + 9 * b;
+    for (int k = 0; k < 9; ++k) M3[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (pb.mdim == 0) continue;
+    const double* x = blockPtr(p, cand != 0, pb.kind, pb.slot);
+    if (pb.kind == B_SB) {
+      for (int k = 0; k < 9; ++k) p.priorDchi[pb.ord + k] = x[k] - pb.lin[k];
+    } else {
+      double d[6];
+      poseMinus(x, pb.lin, d);
+      for (int k = 0; k < 6; ++k) p.priorDchi[pb.ord + k] = d[k];
+      // PlusJacobian normalises q (Transformation ctor); lift uses the raw linearisation quaternion
+      const Quat qc = qnormalized(Quat{x[3], x[4], x[5], x[6]});
+      const Quat ql = Quat{-pb.lin[3], -pb.lin[4], -pb.lin[5], pb.lin[6]};
+      // 2*oplus(q_lin^-1)[0:3,:] * 0.5*oplus(q_cur)[:,0:3]
+      double A[16], B[16], C[16];
+      quatOplusMat4(ql, A);
+      quatOplusMat4(qc, B);
+      mm4(A, B, C);
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) M3[a * 3 + c] = C[a * 4 + c];
+    }
+  }
+  __syncthreads();
+  // grad = bp + Ht dchi (thread per row), cost
+  double c = 0;
+  for (int i = t; i < m; i += blockDim.x) {
+    double s = 0;
+    const double* row = p.priorH + (size_t)i * m;
+    for (int k = 0; k < m; ++k) s += row[k] * p.priorDchi[k];
+    p.priorGrad[i] = p.priorBp[i] + s;
+    c += p.priorDchi[i] * (p.priorBp[i] + 0.5 * s);
+  }
+  const double tot = blockSum(c, red);
+  if (t == 0) p.scal->costPrior = 0.5 * p.priorC0 + tot;
+}
+
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s) {
+  if (p.priorM == 0) return;
+  hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0);
+}
+
+// row i of the prior -> (reduced-system row, or -1) with the 3x3 rotation map applied on the fly
+__device__ __forceinline__ int priorFindBlock(const DeviceProblem& p, int row) {
+  int b = 0;
+  for (int k = 0; k < p.priorBlocks; ++k)
+    if (p.priorBlk[k].mdim > 0 && row >= p.priorBlk[k].ord && row < p.priorBlk[k].ord + p.priorBlk[k].mdim) b = k;
+  return b;
+}
+// (M^T X M)(i,j) for prior rows i,j: rows/cols 3..5 of pose blocks mix through M3
+__device__ __forceinline__ double priorHeff(const DeviceProblem& p, int i, int j) {
+  const int m = p.priorM;
+  const int bi = priorFindBlock(p, i), bj = priorFindBlock(p, j);
+  const PriorBlock& Bi = p.priorBlk[bi];
+  const PriorBlock& Bj = p.priorBlk[bj];
+  const int li = i - Bi.ord, lj = j - Bj.ord;
+  const bool ri = (Bi.kind != B_SB) && li >= 3, rj = (Bj.kind != B_SB) && lj >= 3;
+  double s = 0;
+  const int i0 = ri ? Bi.ord + 3 : i, ni = ri ? 3 : 1;
+  const int j0 = rj ? Bj.ord + 3 : j, nj = rj ? 3 : 1;
+  for (int a = 0; a < ni; ++a) {
+    const double wa = ri ? p.priorM3[9 * bi + a * 3 + (li - 3)] : 1.0;  // M[a][li-3] -> (M^T)[li-3][a]
+    for (int b = 0; b < nj; ++b) {
+      const double wb = rj ? p.priorM3[9 * bj + b * 3 + (lj - 3)] : 1.0;
+      s += wa * p.priorH[(size_t)(i0 + a) * m + j0 + b] * wb;
+    }
+  }
+  return s;
+}
+__device__ __forceinline__ int priorRowToReduced(const DeviceProblem& p, int row) {
+  const PriorBlock& B = p.priorBlk[priorFindBlock(p, row)];
+  const int off = blockOff(p, B.kind, B.slot);
+  return off < 0 ? -1 : off + (row - B.ord);
+}
+__global__ void k_prior_accumulate(DeviceProblem p) {
+  const int m = p.priorM;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * m) return;
+  const int i = idx / m, j = idx % m;
+  const int ri = priorRowToReduced(p, i), rj = priorRowToReduced(p, j);
+  if (ri < 0 || rj < 0) return;
+  const double h = priorHeff(p, i, j);
+  atomicAdd(&p.S[(size_t)ri * p.d + rj], h);
+  if (i == j) {
+    atomicAdd(&p.hC[ri], h);
+    // gradient: (M^T grad)(i)
+    const int bi = priorFindBlock(p, i);
+    const PriorBlock& Bi = p.priorBlk[bi];
+    const int li = i - Bi.ord;
+    double g;
+    if (Bi.kind != B_SB && li >= 3) {
+      g = 0;
+      for (int a = 0; a < 3; ++a) g += p.priorM3[9 * bi + a * 3 + (li - 3)] * p.priorGrad[Bi.ord + 3 + a];
+    } else {
+      g = p.priorGrad[i];
+    }
+    atomicAdd(&p.gRed[ri], g);
+    atomicAdd(&p.gFull[ri], g);
+  }
+}
+// |J_eff v|^2 = (Mv)^T Ht (Mv) ; (J_eff v).r = (Mv)^T grad
+__global__ __launch_bounds__(256) void k_prior_jv(DeviceProblem p, const double* __restrict__ vC) {
+  __shared__ double red[4];
+  const int t = threadIdx.x, m = p.priorM;
+  for (int i = t; i < m; i += blockDim.x) {
+    const int bi = priorFindBlock(p, i);
+    const PriorBlock& B = p.priorBlk[bi];
+    const int off = blockOff(p, B.kind, B.slot);
+    const int li = i - B.ord;
+    double v = 0;
+    if (off >= 0) {
+      if (B.kind != B_SB && li >= 3) {
+        for (int c = 0; c < 3; ++c) v += p.priorM3[9 * bi + (li - 3) * 3 + c] * vC[off + 3 + c];
+      } else {
+        v = vC[off + li];
+      }
+    }
+    p.priorMv[i] = v;
+  }
+  __syncthreads();
+  double sq = 0, dot = 0;
+  for (int i = t; i < m; i += blockDim.x) {
+    double s = 0;
+    const double* row = p.priorH + (size_t)i * m;
+    for (int k = 0; k < m; ++k) s += row[k] * p.priorMv[k];
+    sq += p.priorMv[i] * s;
+    dot += p.priorMv[i] * p.priorGrad[i];
+  }
+  const double a = blockSum(sq, red);
+  const double b = blockSum(dot, red);
+  if (t == 0) {
+    p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + kMaxPartials - 1] = a;
+    p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + kMaxPartials - 1] = b;
+  }
+}
+
+// ================================================================ K5: normal equations + landmark Schur complement
+constexpr int kStage = 34;  // doubles staged per observation: Jl 6, Jp 12, Je 12, offP, offE (as double), pad
+
+template <bool USE_LDS, bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int initScale) {
+  extern __shared__ double smem[];
+  const int dC = p.dC;
+  const int ld = USE_LDS ? dC : dC;  // slab leading dimension
+  double* accS;
+  double* accV;  // gRed | gFull | hC (3*dC)
+  double* stage;
+  if (USE_LDS) {
+    accS = smem;
+    accV = smem + (size_t)dC * dC;
+    stage = accV + 3 * dC;
+    for (int i = threadIdx.x; i < dC * dC + 3 * dC; i += blockDim.x) smem[i] = 0;
+    __syncthreads();
+  } else {
+    accS = p.slabs;                       // single global slab, atomics
+    accV = p.slabs + (size_t)dC * dC;
+    stage = smem;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* stg = stage + (size_t)wave * 64 * kStage;
+  const size_t N = (size_t)p.N;
+  const double* r = p.rCur;
+  const double* Jp = p.JpCur;
+  const double* Jl = p.JlCur;
+  const double* Je = p.JeCur;
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  for (int l = gw; l < p.L; l += nw) {
+    const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+    // ---- pass 1: V = sum Jl^T Jl, bl = sum Jl^T r (wave reduction)
+    double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int i = lane; i < n; i += 64) {
+      const size_t o = start + i;
+      const double r0 = r[o], r1 = r[N + o];
+      const double a0 = Jl[o], a1 = Jl[N + o], a2 = Jl[2 * N + o], c0 = Jl[3 * N + o], c1 = Jl[4 * N + o], c2 = Jl[5 * N + o];
+      v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
+      v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
+      b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
+    }
+    v00 = waveSum(v00); v01 = waveSum(v01); v02 = waveSum(v02); v11 = waveSum(v11); v12 = waveSum(v12);
+    v22 = waveSum(v22); b0 = waveSum(b0); b1 = waveSum(b1); b2 = waveSum(b2);
+    // trust-region metric for the landmark columns (Jacobi scaling fixed at iteration 0)
+    double sc0, sc1, sc2;
+    if (initScale) {
+      sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
+      if (lane == 0) { p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2; }
+    } else {
+      sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2];
+    }
+    const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
+    const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
+    const double ht2 = fmin(fmax(v22 * sc2 * sc2, 1e-6), 1e32) / (sc2 * sc2);
+    // (V + mu*htil)^-1 through its Cholesky factor
+    const double d00 = v00 + mu * ht0, d11 = v11 + mu * ht1, d22 = v22 + mu * ht2;
+    bool bad = !(d00 > 0);
+    const double l00 = sqrt(d00);
+    const double l10 = v01 / l00, l20 = v02 / l00;
+    const double t11 = d11 - l10 * l10;
+    bad = bad || !(t11 > 0);
+    const double l11 = sqrt(t11);
+    const double l21 = (v12 - l20 * l10) / l11;
+    const double t22 = d22 - l20 * l20 - l21 * l21;
+    bad = bad || !(t22 > 0);
+    const double l22 = sqrt(t22);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    // Vinv = Linv^T Linv
+    const double w00 = i00 * i00 + i10 * i10 + i20 * i20, w01 = i10 * i11 + i20 * i21, w02 = i20 * i22;
+    const double w11 = i11 * i11 + i21 * i21, w12 = i21 * i22, w22 = i22 * i22;
+    if (lane == 0) {
+      if (bad) atomicOr(&p.scal->cholFail, 1);
+      double* vi = p.Vinv + 6 * (size_t)l;
+      vi[0] = w00; vi[1] = w01; vi[2] = w02; vi[3] = w11; vi[4] = w12; vi[5] = w22;
+      p.bl[3 * l] = b0; p.bl[3 * l + 1] = b1; p.bl[3 * l + 2] = b2;
+      p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
+    }
+    const double vb0 = w00 * b0 + w01 * b1 + w02 * b2, vb1 = w01 * b0 + w11 * b1 + w12 * b2, vb2 = w02 * b0 + w12 * b1 + w22 * b2;
+    // ---- pass 2: pairwise blocks  Jc_i^T (delta_ij I - Jl_i Vinv Jl_j^T) Jc_j
+    for (int ci = 0; ci < n; ci += 64) {
+      const int i = ci + lane;
+      const bool act = i < n;
+      const size_t o = start + (act ? i : 0);
+      double jp[12], je[12], jl[6], ri[2];
+      int offP = -1, offE = -1;
+      if (act) {
+        const uint32_t idx = p.obsIdx[o];
+        offP = p.poseOff[idx & 0xfff];
+        if (WITH_EXT) offE = p.extOff[(idx >> 12) & 0xfff];
+        ri[0] = r[o]; ri[1] = r[N + o];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) jl[k] = Jl[k * N + o];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) jp[k] = Jp[k * N + o];
+        if (WITH_EXT) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) je[k] = Je[k * N + o];
+        }
+      }
+      // Y = Jl Vinv (2x3), z = r - Jl Vinv bl
+      double Y[6], z[2];
+      if (act) {
+        for (int a = 0; a < 2; ++a) {
+          Y[a * 3 + 0] = jl[a * 3] * w00 + jl[a * 3 + 1] * w01 + jl[a * 3 + 2] * w02;
+          Y[a * 3 + 1] = jl[a * 3] * w01 + jl[a * 3 + 1] * w11 + jl[a * 3 + 2] * w12;
+          Y[a * 3 + 2] = jl[a * 3] * w02 + jl[a * 3 + 1] * w12 + jl[a * 3 + 2] * w22;
+          z[a] = ri[a] - (jl[a * 3] * vb0 + jl[a * 3 + 1] * vb1 + jl[a * 3 + 2] * vb2);
+        }
+        if (offP >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            atomicAdd(&accV[offP + a], jp[a] * z[0] + jp[6 + a] * z[1]);
+            atomicAdd(&accV[dC + offP + a], jp[a] * ri[0] + jp[6 + a] * ri[1]);
+            atomicAdd(&accV[2 * dC + offP + a], jp[a] * jp[a] + jp[6 + a] * jp[6 + a]);
+          }
+        }
+        if (WITH_EXT && offE >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            atomicAdd(&accV[offE + a], je[a] * z[0] + je[6 + a] * z[1]);
+            atomicAdd(&accV[dC + offE + a], je[a] * ri[0] + je[6 + a] * ri[1]);
+            atomicAdd(&accV[2 * dC + offE + a], je[a] * je[a] + je[6 + a] * je[6 + a]);
+          }
+        }
+      }
+      for (int cj = 0; cj < n; cj += 64) {
+        // stage chunk cj (this wave only)
+        waveSync();
+        {
+          const int j = cj + lane;
+          if (j < n) {
+            const size_t oj = start + j;
+            double* sj = stg + (size_t)lane * kStage;
+            if (cj == ci) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) sj[k] = jl[k];
+#pragma unroll
+              for (int k = 0; k < 12; ++k) sj[6 + k] = jp[k];
+              if (WITH_EXT) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) sj[18 + k] = je[k];
+              }
+              sj[30] = (double)offP; sj[31] = (double)offE;
+            } else {
+              const uint32_t idx = p.obsIdx[oj];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) sj[k] = Jl[k * N + oj];
+#pragma unroll
+              for (int k = 0; k < 12; ++k) sj[6 + k] = Jp[k * N + oj];
+              if (WITH_EXT) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) sj[18 + k] = Je[k * N + oj];
+              }
+              sj[30] = (double)p.poseOff[idx & 0xfff];
+              sj[31] = WITH_EXT ? (double)p.extOff[(idx >> 12) & 0xfff] : -1.0;
+            }
+          }
+        }
+        waveSync();
+        const int nj = min(64, n - cj);
+        for (int jj = 0; jj < nj; ++jj) {
+          const double* sj = stg + (size_t)jj * kStage;
+          const int offPj = (int)sj[30], offEj = (int)sj[31];
+          if (!act) continue;
+          // K = delta - Y Jl_j^T
+          const double e = (cj + jj == i) ? 1.0 : 0.0;
+          const double K00 = e - (Y[0] * sj[0] + Y[1] * sj[1] + Y[2] * sj[2]);
+          const double K01 = -(Y[0] * sj[3] + Y[1] * sj[4] + Y[2] * sj[5]);
+          const double K10 = -(Y[3] * sj[0] + Y[4] * sj[1] + Y[5] * sj[2]);
+          const double K11 = e - (Y[3] * sj[3] + Y[4] * sj[4] + Y[5] * sj[5]);
+          // camera-side blocks of observation j: pose (sj+6), ext (sj+18)
+          auto addBlock = [&](const double* ji, int offA, const double* jj_, int offB) {
+            double t0[6], t1[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              t0[b] = K00 * jj_[b] + K01 * jj_[6 + b];
+              t1[b] = K10 * jj_[b] + K11 * jj_[6 + b];
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int b = 0; b < 6; ++b) atomicAdd(&accS[(size_t)(offA + a) * ld + offB + b], ji[a] * t0[b] + ji[6 + a] * t1[b]);
+          };
+          if (offP >= 0 && offPj >= 0 && offP <= offPj) addBlock(jp, offP, sj + 6, offPj);
+          if (WITH_EXT) {
+            if (offP >= 0 && offEj >= 0) addBlock(jp, offP, sj + 18, offEj);          // poses precede extrinsics
+            if (offE >= 0 && offEj >= 0 && offE <= offEj) addBlock(je, offE, sj + 18, offEj);
+          }
+        }
+      }
+    }
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    double* slab = p.slabs + (size_t)blockIdx.x * ((size_t)dC * dC + 3 * dC);
+    for (int i = threadIdx.x; i < dC * dC + 3 * dC; i += blockDim.x) slab[i] = smem[i];
+  }
+}
+
+// generic small factors: J^T J into S (both triangles), J^T r into gRed/gFull, column norms into hC
+__global__ __launch_bounds__(256) void k_factors_accumulate(DeviceProblem p) {
+  const FactorLin& lin = p.linCur[blockIdx.x];
+  const int m = lin.m, nc = lin.ncols;
+  // column -> reduced row map
+  __shared__ int colRow[30];
+  if (threadIdx.x < 30) {
+    int c = threadIdx.x, row = -1, base = 0;
+    for (int b = 0; b < 4; ++b) {
+      if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
+      base += lin.dim[b];
+    }
+    colRow[threadIdx.x] = (c < nc) ? row : -1;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
+    const int a = idx / nc, b = idx % nc;
+    const int ra = colRow[a], rb = colRow[b];
+    if (ra < 0 || rb < 0) continue;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
+    atomicAdd(&p.S[(size_t)ra * p.d + rb], s);
+    if (a == b) {
+      atomicAdd(&p.hC[ra], s);
+      double g = 0;
+      for (int k = 0; k < m; ++k) g += lin.J[k * nc + a] * lin.r[k];
+      atomicAdd(&p.gRed[ra], g);
+      atomicAdd(&p.gFull[ra], g);
+    }
+  }
+}
+
+// S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
+__global__ void k_reduce_slabs(DeviceProblem p) {
+  const int dC = p.dC;
+  const size_t slabSize = (size_t)dC * dC + 3 * dC;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < dC * dC) {
+    const int rr = idx / dC, cc = idx % dC;
+    const bool upper = (rr / 6) <= (cc / 6);
+    const size_t src = upper ? (size_t)rr * dC + cc : (size_t)cc * dC + rr;
+    double s = 0;
+    for (int k = 0; k < p.nSlabs; ++k) s += p.slabs[k * slabSize + src];
+    p.S[(size_t)rr * p.d + cc] += s;
+  } else if (idx < dC * dC + 3 * dC) {
+    const int v = idx - dC * dC;
+    double s = 0;
+    for (int k = 0; k < p.nSlabs; ++k) s += p.slabs[k * slabSize + (size_t)dC * dC + v];
+    if (v < dC) p.gRed[v] += s;
+    else if (v < 2 * dC) p.gFull[v - dC] += s;
+    else p.hC[v - 2 * dC] += s;
+  }
+}
+// camera-column metric, damping on the diagonal of S, gradient max-norm (cam part)
+__global__ void k_finalize_diag(DeviceProblem p, double mu, int initScale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.d) return;
+  double sc;
+  if (initScale) { sc = 1.0 / (1.0 + sqrt(p.hC[i])); p.scaleC[i] = sc; }
+  else sc = p.scaleC[i];
+  const double ht = fmin(fmax(p.hC[i] * sc * sc, 1e-6), 1e32) / (sc * sc);
+  p.htilC[i] = ht;
+  p.S[(size_t)i * p.d + i] += mu * ht;
+}
+
+void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
+  const int d = p.d, dC = p.dC;
+  hipMemsetAsync(p.S, 0, sizeof(double) * (size_t)d * d, s);
+  hipMemsetAsync(p.gRed, 0, sizeof(double) * d, s);
+  hipMemsetAsync(p.gFull, 0, sizeof(double) * d, s);
+  hipMemsetAsync(p.hC, 0, sizeof(double) * d, s);
+  hipMemsetAsync(&p.scal->cholFail, 0, sizeof(int), s);
+  if (p.L > 0 && p.N > 0 && dC > 0) {
+    const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
+    const size_t stageBytes = (size_t)4 * 64 * kStage * 8;
+    const bool useLds = accBytes + stageBytes <= 150 * 1024;
+    if (useLds) {
+      const int grid = p.nSlabs;
+#define LAUNCH(E)                                                                                                   \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)k_schur<true, E>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                              (int)(accBytes + stageBytes));                                                        \
+    hipLaunchKernelGGL((k_schur<true, E>), dim3(grid), dim3(256), accBytes + stageBytes, s, p, mu, initScale ? 1 : 0); \
+  } while (0)
+      if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
+#undef LAUNCH
+    } else {
+      hipMemsetAsync(p.slabs, 0, accBytes, s);
+      const int grid = min((p.L + 3) / 4, 2048);
+      DeviceProblem q = p;
+#define LAUNCH(E)                                                                                                   \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)k_schur<false, E>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                              (int)stageBytes);                                                                     \
+    hipLaunchKernelGGL((k_schur<false, E>), dim3(grid), dim3(256), stageBytes, s, q, mu, initScale ? 1 : 0);        \
+  } while (0)
+      if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
+#undef LAUNCH
+    }
+  }
+  if (p.F > 0) hipLaunchKernelGGL(k_factors_accumulate, dim3(p.F), dim3(256), 0, s, p);
+  if (p.priorM > 0) {
+    const int n = p.priorM * p.priorM;
+    hipLaunchKernelGGL(k_prior_accumulate, dim3((n + 255) / 256), dim3(256), 0, s, p);
+  }
+  if (p.L > 0 && p.N > 0 && dC > 0) {
+    const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
+    const bool useLds = accBytes + (size_t)4 * 64 * kStage * 8 <= 150 * 1024;
+    DeviceProblem q = p;
+    if (!useLds) q.nSlabs = 1;
+    const int n = dC * dC + 3 * dC;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, q);
+  }
+  hipLaunchKernelGGL(k_finalize_diag, dim3((d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
+}
+
+// ================================================================ K6: reduced system solve
+// Single workgroup, 1024 threads (16 waves).  Right-looking blocked Cholesky with 16-wide panels; the
+// symmetric rank-16 trailing update runs on v_mfma_f64_16x16x4_f64 (A/B: one f64 per lane,
+// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)+4*reg).  The matrix is padded to a
+// multiple of 16 with an identity tail so that every tile is full.
+constexpr int kPanelLd = 17;
+__global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) {
+  extern __shared__ double smem[];
+  double* sD = smem;                    // 16 x 17 diagonal block
+  double* sP = smem + 16 * kPanelLd;    // panel rows x 17
+  const int t = threadIdx.x, d = p.d;
+  double* Lm = p.cholL;                 // dpad x dpad, row-major
+  // copy lower triangle of S, identity padding
+  for (int idx = t; idx < dpad * dpad; idx += blockDim.x) {
+    const int i = idx / dpad, j = idx % dpad;
+    double v = 0;
+    if (i < d && j < d) v = (j <= i) ? p.S[(size_t)i * d + j] : 0.0;
+    else if (i == j) v = 1.0;
+    Lm[idx] = v;
+  }
+  __syncthreads();
+  const int nT = dpad / 16;
+  const int wave = t >> 6, lane = t & 63;
+  for (int kb = 0; kb < nT; ++kb) {
+    const int k0 = kb * 16;
+    // 1. diagonal block -> LDS, factor
+    if (t < 256) sD[(t / 16) * kPanelLd + (t % 16)] = Lm[(size_t)(k0 + t / 16) * dpad + k0 + (t % 16)];
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+      if (t == 0) {
+        const double x = sD[k * kPanelLd + k];
+        if (!(x > 0)) { atomicOr(&p.scal->cholFail, 2); sD[k * kPanelLd + k] = 1.0; }
+        else sD[k * kPanelLd + k] = sqrt(x);
+      }
+      __syncthreads();
+      if (t < 16 && t > k) sD[t * kPanelLd + k] /= sD[k * kPanelLd + k];
+      __syncthreads();
+      if (t < 256) {
+        const int i = t / 16, j = t % 16;
+        if (j > k && i >= j) sD[i * kPanelLd + j] -= sD[i * kPanelLd + k] * sD[j * kPanelLd + k];
+      }
+      __syncthreads();
+    }
+    if (t < 256) {
+      const int i = t / 16, j = t % 16;
+      Lm[(size_t)(k0 + i) * dpad + k0 + j] = (j <= i) ? sD[i * kPanelLd + j] : 0.0;
+    }
+    // 2. panel: rows below, forward substitution against the diagonal block
+    const int rows = dpad - k0 - 16;
+    for (int rI = t; rI < rows; rI += blockDim.x) {
+      double x[16];
+      double* row = Lm + (size_t)(k0 + 16 + rI) * dpad + k0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = row[k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        double s = x[k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < k) s -= x[j] * sD[k * kPanelLd + j];
+        x[k] = s / sD[k * kPanelLd + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { row[k] = x[k]; sP[(size_t)rI * kPanelLd + k] = x[k]; }
+    }
+    __syncthreads();
+    // 3. trailing update with MFMA: tile (I,J), I >= J, in units of 16 rows of the panel
+    const int nR = rows / 16;
+    const int nTiles = nR * (nR + 1) / 2;
+    for (int tile = wave; tile < nTiles; tile += 16) {
+      // unrank tile -> (I,J), I >= J
+      int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+      while (I * (I + 1) / 2 > tile) --I;
+      while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+      const int J = tile - I * (I + 1) / 2;
+      d4_t acc;
+      double* Cb = Lm + (size_t)(k0 + 16 + I * 16) * dpad + (k0 + 16 + J * 16);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = -sP[(size_t)(I * 16 + (lane & 15)) * kPanelLd + 4 * q + (lane >> 4)];
+        const double b = sP[(size_t)(J * 16 + (lane & 15)) * kPanelLd + 4 * q + (lane >> 4)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Cb[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)] = acc[rg];
+    }
+    __syncthreads();
+  }
+  // ---- solve L y' = gRed ; L^T y = y'   (y in p.yC), serial over 16-blocks, parallel inside
+  double* y = p.yC;
+  for (int i = t; i < dpad; i += blockDim.x) sP[i] = (i < d) ? p.gRed[i] : 0.0;
+  __syncthreads();
+  for (int kb = 0; kb < nT; ++kb) {
+    const int k0 = kb * 16;
+    if (t == 0) {
+      for (int k = 0; k < 16; ++k) {
+        double s = sP[k0 + k];
+        for (int j = 0; j < k; ++j) s -= Lm[(size_t)(k0 + k) * dpad + k0 + j] * sP[k0 + j];
+        sP[k0 + k] = s / Lm[(size_t)(k0 + k) * dpad + k0 + k];
+      }
+    }
+    __syncthreads();
+    for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
+      double s = 0;
+      const double* row = Lm + (size_t)i * dpad + k0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += row[k] * sP[k0 + k];
+      sP[i] -= s;
+    }
+    __syncthreads();
+  }
+  for (int kb = nT - 1; kb >= 0; --kb) {
+    const int k0 = kb * 16;
+    if (t == 0) {
+      for (int k = 15; k >= 0; --k) {
+        double s = sP[k0 + k];
+        for (int j = k + 1; j < 16; ++j) s -= Lm[(size_t)(k0 + j) * dpad + k0 + k] * sP[k0 + j];
+        sP[k0 + k] = s / Lm[(size_t)(k0 + k) * dpad + k0 + k];
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < k0; i += blockDim.x) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += Lm[(size_t)(k0 + k) * dpad + i] * sP[k0 + k];
+      sP[i] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < d; i += blockDim.x) y[i] = sP[i];
+}
+
+// landmarks: y_l = Vinv (bl - sum_i Jl_i^T (Jc_i y_c))
+template <bool WITH_EXT>
+__global__ void k_backsub(DeviceProblem p) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= p.L) return;
+  const size_t N = (size_t)p.N;
+  double t0 = p.bl[3 * l], t1 = p.bl[3 * l + 1], t2 = p.bl[3 * l + 2];
+  for (int o = p.lmPtr[l]; o < p.lmPtr[l + 1]; ++o) {
+    const uint32_t idx = p.obsIdx[o];
+    const int offP = p.poseOff[idx & 0xfff];
+    double u0 = 0, u1 = 0;
+    if (offP >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { u0 += p.JpCur[a * N + o] * p.yC[offP + a]; u1 += p.JpCur[(6 + a) * N + o] * p.yC[offP + a]; }
+    }
+    if (WITH_EXT) {
+      const int offE = p.extOff[(idx >> 12) & 0xfff];
+      if (offE >= 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { u0 += p.JeCur[a * N + o] * p.yC[offE + a]; u1 += p.JeCur[(6 + a) * N + o] * p.yC[offE + a]; }
+      }
+    }
+    t0 -= p.JlCur[o] * u0 + p.JlCur[3 * N + o] * u1;
+    t1 -= p.JlCur[N + o] * u0 + p.JlCur[4 * N + o] * u1;
+    t2 -= p.JlCur[2 * N + o] * u0 + p.JlCur[5 * N + o] * u1;
+  }
+  const double* w = p.Vinv + 6 * (size_t)l;
+  p.yL[3 * l] = w[0] * t0 + w[1] * t1 + w[2] * t2;
+  p.yL[3 * l + 1] = w[1] * t0 + w[3] * t1 + w[4] * t2;
+  p.yL[3 * l + 2] = w[2] * t0 + w[4] * t1 + w[5] * t2;
+}
+
+void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
+  const int dpad = ((p.d + 15) / 16) * 16;
+  const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
+  (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad);
+  if (p.L > 0) {
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_backsub<true>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);
+    else hipLaunchKernelGGL(k_backsub<false>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);
+  }
+}
+
+// ================================================================ J * v passes and dogleg
+// v = [vC (d) ; vL (3L)].  Accumulates sum |Jv|^2 and sum (Jv).r over reprojection residuals.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_jv_reproj(DeviceProblem p, const double* __restrict__ vC,
+                                                   const double* __restrict__ vL) {
+  __shared__ double red[4];
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t N = (size_t)p.N;
+  double sq = 0, dot = 0;
+  if (o < p.N) {
+    const uint32_t idx = p.obsIdx[o];
+    const int offP = p.poseOff[idx & 0xfff];
+    const int l = p.obsLm[o];
+    double u0 = p.JlCur[o] * vL[3 * l] + p.JlCur[N + o] * vL[3 * l + 1] + p.JlCur[2 * N + o] * vL[3 * l + 2];
+    double u1 = p.JlCur[3 * N + o] * vL[3 * l] + p.JlCur[4 * N + o] * vL[3 * l + 1] + p.JlCur[5 * N + o] * vL[3 * l + 2];
+    if (offP >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { u0 += p.JpCur[a * N + o] * vC[offP + a]; u1 += p.JpCur[(6 + a) * N + o] * vC[offP + a]; }
+    }
+    if (WITH_EXT) {
+      const int offE = p.extOff[(idx >> 12) & 0xfff];
+      if (offE >= 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { u0 += p.JeCur[a * N + o] * vC[offE + a]; u1 += p.JeCur[(6 + a) * N + o] * vC[offE + a]; }
+      }
+    }
+    sq = u0 * u0 + u1 * u1;
+    dot = u0 * p.rCur[o] + u1 * p.rCur[N + o];
+  }
+  const double a = blockSum(sq, red);
+  const double b = blockSum(dot, red);
+  if (threadIdx.x == 0) {
+    p.partial[(size_t)PS_JV_SQ * kMaxPartials + blockIdx.x] = a;
+    p.partial[(size_t)PS_JV_DOT * kMaxPartials + blockIdx.x] = b;
+  }
+}
+__global__ __launch_bounds__(64) void k_jv_factors(DeviceProblem p, const double* __restrict__ vC) {
+  const FactorLin& lin = p.linCur[blockIdx.x];
+  const int lane = threadIdx.x;
+  double sq = 0, dot = 0;
+  if (lane < lin.m) {
+    double u = 0;
+    int base = 0;
+    for (int b = 0; b < 4; ++b) {
+      if (lin.off[b] >= 0)
+        for (int c = 0; c < lin.dim[b]; ++c) u += lin.J[lane * lin.ncols + base + c] * vC[lin.off[b] + c];
+      base += lin.dim[b];
+    }
+    sq = u * u;
+    dot = u * lin.r[lane];
+  }
+  sq = waveSum(sq);
+  dot = waveSum(dot);
+  if (lane == 0) {
+    p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + blockIdx.x] = sq;
+    p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + blockIdx.x] = dot;
+  }
+}
+
+static int jvGrid(int N) { return (N + 255) / 256; }
+
+static void launchJv(const DeviceProblem& p, const double* vC, const double* vL, hipStream_t s) {
+  // clear the factor/prior partial slots that may stay unused
+  hipMemsetAsync(p.partial + (size_t)PS_JV_SQ_F * kMaxPartials, 0, sizeof(double) * 2 * kMaxPartials, s);
+  if (p.N > 0) {
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_jv_reproj<true>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
+    else hipLaunchKernelGGL(k_jv_reproj<false>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
+  }
+  if (p.F > 0) hipLaunchKernelGGL(k_jv_factors, dim3(p.F), dim3(64), 0, s, p, vC);
+  if (p.priorM > 0) hipLaunchKernelGGL(k_prior_jv, dim3(1), dim3(256), 0, s, p, vC);
+}
+
+// v = g / htil ; partial sums of g^2/htil, htil*y^2, -g*y, max|g|
+__global__ __launch_bounds__(256) void k_dogleg_vectors(DeviceProblem p) {
+  __shared__ double red[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = p.d + 3 * p.L;
+  double gh = 0, gn = 0, gd = 0, gm = 0;
+  if (i < n) {
+    double g, ht, y;
+    if (i < p.d) { g = p.gFull[i]; ht = p.htilC[i]; y = p.yC[i]; p.vC[i] = g / ht; }
+    else { const int k = i - p.d; g = p.bl[k]; ht = p.hL[k]; y = p.yL[k]; p.vL[k] = g / ht; }
+    gh = g * g / ht;
+    gn = ht * y * y;
+    gd = -g * y;
+    gm = fabs(g);
+  }
+  const double a = blockSum(gh, red);
+  const double b = blockSum(gn, red);
+  const double c = blockSum(gd, red);
+  gm = waveMax(gm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0;
+    for (int k = 0; k < (int)blockDim.x / 64; ++k) mx = fmax(mx, red[k]);
+    p.partial[(size_t)PS_GHAT * kMaxPartials + blockIdx.x] = a;
+    p.partial[(size_t)PS_GNHAT * kMaxPartials + blockIdx.x] = b;
+    p.partial[(size_t)PS_GDOTGN * kMaxPartials + blockIdx.x] = c;
+    p.partial[(size_t)PS_GRADMAX * kMaxPartials + blockIdx.x] = mx;
+  }
+}
+
+// final single-block reductions of the partial slots into SolverScalars
+__global__ __launch_bounds__(256) void k_reduce_scalars(DeviceProblem p, int what, int nA, int nB) {
+  __shared__ double red[4];
+  const int t = threadIdx.x;
+  auto sumSlot = [&](int slot, int n) {
+    double s = 0;
+    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
+    return blockSum(s, red);
+  };
+  if (what == 0) {  // cost: reproj (nA blocks) + factors (nB)
+    const double a = sumSlot(PS_COST_REPROJ, nA);
+    const double b = sumSlot(PS_COST_FACTORS, nB);
+    if (t == 0) {
+      p.scal->costReproj = a; p.scal->costFactors = b;
+      p.scal->cost = a + b + (p.priorM > 0 ? p.scal->costPrior : 0.0);
+    }
+  } else if (what == 1) {  // dogleg vectors (nA blocks)
+    const double a = sumSlot(PS_GHAT, nA), b = sumSlot(PS_GNHAT, nA), c = sumSlot(PS_GDOTGN, nA);
+    double mx = 0;
+    for (int i = t; i < nA; i += blockDim.x) mx = fmax(mx, p.partial[(size_t)PS_GRADMAX * kMaxPartials + i]);
+    mx = waveMax(mx);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+      double m2 = 0;
+      for (int k = 0; k < 4; ++k) m2 = fmax(m2, red[k]);
+      p.scal->gHatSq = a; p.scal->gnHatSq = b; p.scal->gDotGn = c; p.scal->gradMax = m2;
+    }
+  } else if (what == 2 || what == 3) {  // J*v: reproj (nA) + factors/prior (full slot)
+    const double a = sumSlot(PS_JV_SQ, nA) , b = sumSlot(PS_JV_DOT, nA);
+    const double c = sumSlot(PS_JV_SQ_F, kMaxPartials), e = sumSlot(PS_JV_DOT_F, kMaxPartials);
+    if (t == 0) {
+      if (what == 2) p.scal->jgSq = a + c;
+      else { p.scal->jdSq = a + c; p.scal->jdDotR = b + e; }
+    }
+  } else if (what == 4) {  // step / x norms
+    const double a = sumSlot(PS_STEP, nA), b = sumSlot(PS_XNORM, nA);
+    if (t == 0) { p.scal->stepNormSq = a; p.scal->xNormSq = b; }
+  }
+}
+
+static int vecGrid(const DeviceProblem& p) { return (p.d + 3 * p.L + 255) / 256; }
+
+void launchCost(const DeviceProblem& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 0, p.N > 0 ? evalGrid(p.N) : 0, p.F);
+}
+
+void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_dogleg_vectors, dim3(vecGrid(p)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 1, vecGrid(p), 0);
+  launchJv(p, p.vC, p.vL, s);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 2, p.N > 0 ? jvGrid(p.N) : 0, 0);
+}
+
+// traditional dogleg (ceres dogleg_strategy.cc) expressed on the un-scaled vectors:
+//   delta_i = cg * g_i/htil_i + cn * (-y_i)
+__global__ __launch_bounds__(256) void k_dogleg_step(DeviceProblem p, double radius) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = p.d + 3 * p.L;
+  const SolverScalars& sc = *p.scal;
+  const double gnorm = sqrt(sc.gHatSq), gnnorm = sqrt(sc.gnHatSq);
+  const double alpha = sc.gHatSq / sc.jgSq;
+  double cg, cn, stepNorm;
+  if (gnnorm <= radius) { cg = 0; cn = 1; stepNorm = gnnorm; }
+  else if (gnorm * alpha >= radius) { cg = -(radius / gnorm); cn = 0; stepNorm = radius; }
+  else {
+    const double b_dot_a = -alpha * sc.gDotGn;
+    const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+    const double b_minus_a_sq = a_sq - 2 * b_dot_a + gnnorm * gnnorm;
+    const double c = b_dot_a - a_sq;
+    const double dd = sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
+    const double beta = (c <= 0) ? (dd - c) / b_minus_a_sq : (radius * radius - a_sq) / (dd + c);
+    cg = -alpha * (1.0 - beta);
+    cn = beta;
+    stepNorm = sqrt(fmax(cg * cg * sc.gHatSq + 2 * cg * cn * sc.gDotGn + cn * cn * sc.gnHatSq, 0.0));
+  }
+  if (i == 0) p.scal->doglegStepNorm = stepNorm;
+  if (i < n) {
+    if (i < p.d) { const double v = cg * p.vC[i] - cn * p.yC[i]; p.deltaC[i] = v; }
+    else { const int k = i - p.d; const double v = cg * p.vL[k] - cn * p.yL[k]; p.deltaL[k] = v; }
+  }
+}
+
+// candidate = x [+] delta ; partial sums of |x - x_cand|^2 and |x|^2 over all variable blocks
+__global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
+  __shared__ double red[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nBlk = p.nPose + p.nExt + p.nSb;
+  double st = 0, xn = 0;
+  if (i < nBlk) {
+    if (i < p.nPose + p.nExt) {
+      const bool isPose = i < p.nPose;
+      const int slot = isPose ? i : i - p.nPose;
+      const double* x = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
+      double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
+      const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
+      if (off >= 0) {
+        double xo[7];
+        poseOplus(x, p.deltaC + off, xo);
+        for (int k = 0; k < 7; ++k) { xc[k] = xo[k]; st += (x[k] - xo[k]) * (x[k] - xo[k]); xn += x[k] * x[k]; }
+      } else {
+        for (int k = 0; k < 7; ++k) xc[k] = x[k];
+      }
+    } else {
+      const int slot = i - p.nPose - p.nExt;
+      const double* x = p.sb + (size_t)slot * 9;
+      double* xc = p.sbC + (size_t)slot * 9;
+      const int off = p.sbOff[slot];
+      for (int k = 0; k < 9; ++k) {
+        const double xo = off >= 0 ? x[k] + p.deltaC[off + k] : x[k];
+        xc[k] = xo;
+        if (off >= 0) { st += (x[k] - xo) * (x[k] - xo); xn += x[k] * x[k]; }
+      }
+    }
+  } else if (i < nBlk + p.L) {
+    const int l = i - nBlk;
+    const double* x = p.lm + 4 * (size_t)l;
+    double* xc = p.lmC + 4 * (size_t)l;
+    for (int k = 0; k < 3; ++k) {
+      const double xo = x[k] + p.deltaL[3 * l + k];
+      xc[k] = xo;
+      st += (x[k] - xo) * (x[k] - xo);
+      xn += x[k] * x[k];
+    }
+    xc[3] = x[3] + 0.0;
+    xn += x[3] * x[3];
+  }
+  const double a = blockSum(st, red);
+  const double b = blockSum(xn, red);
+  if (threadIdx.x == 0) {
+    p.partial[(size_t)PS_STEP * kMaxPartials + blockIdx.x] = a;
+    p.partial[(size_t)PS_XNORM * kMaxPartials + blockIdx.x] = b;
+  }
+}
+
+void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s) {
+  hipLaunchKernelGGL(k_dogleg_step, dim3(vecGrid(p)), dim3(256), 0, s, p, radius);
+  launchJv(p, p.deltaC, p.deltaL, s);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 3, p.N > 0 ? jvGrid(p.N) : 0, 0);
+  const int nB = (p.nPose + p.nExt + p.nSb + p.L + 255) / 256;
+  hipLaunchKernelGGL(k_retract, dim3(nB), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 4, nB, 0);
+}
+
+// ================================================================ K9: landmark quality (Estimator.cpp:902-923)
+// H = sum J_lm^T J_lm over all observations WITHOUT loss correction (Map::getLhs), symmetric 3x3
+// eigenvalues by cyclic Jacobi, quality = sqrt(lmin)/sqrt(lmax) (0 if lmin < 1e-12).
+__global__ void k_landmark_quality(DeviceProblem p, double* __restrict__ quality) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= p.L) return;
+  double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+  const double* hp = p.lm + 4 * (size_t)l;
+  const double hpw[4] = {hp[0], hp[1], hp[2], hp[3]};
+  for (int o = p.lmPtr[l]; o < p.lmPtr[l + 1]; ++o) {
+    const uint32_t idx = p.obsIdx[o];
+    double rr[2], jp[12], jl[6], je[12];
+    reprojEval(p.cams[(idx >> 24) & 0xf], p.pose + (size_t)(idx & 0xfff) * 7, hpw, p.ext + (size_t)((idx >> 12) & 0xfff) * 7,
+               p.obsUv[2 * (size_t)o], p.obsUv[2 * (size_t)o + 1], p.obsW[o], rr, jp, jl, je);
+    a00 += jl[0] * jl[0] + jl[3] * jl[3]; a01 += jl[0] * jl[1] + jl[3] * jl[4]; a02 += jl[0] * jl[2] + jl[3] * jl[5];
+    a11 += jl[1] * jl[1] + jl[4] * jl[4]; a12 += jl[1] * jl[2] + jl[4] * jl[5]; a22 += jl[2] * jl[2] + jl[5] * jl[5];
+  }
+  // cyclic Jacobi on the symmetric 3x3
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(a01) + fabs(a02) + fabs(a12);
+    if (off == 0.0) break;
+    // rotate (0,1)
+    if (a01 != 0.0) {
+      const double th = (a11 - a00) / (2.0 * a01);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n00 = a00 - tt * a01, n11 = a11 + tt * a01;
+      const double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
+      a00 = n00; a11 = n11; a01 = 0; a02 = n02; a12 = n12;
+    }
+    if (a02 != 0.0) {
+      const double th = (a22 - a00) / (2.0 * a02);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n00 = a00 - tt * a02, n22 = a22 + tt * a02;
+      const double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
+      a00 = n00; a22 = n22; a02 = 0; a01 = n01; a12 = n12;
+    }
+    if (a12 != 0.0) {
+      const double th = (a22 - a11) / (2.0 * a12);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n11 = a11 - tt * a12, n22 = a22 + tt * a12;
+      const double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
+      a11 = n11; a22 = n22; a12 = 0; a01 = n01; a02 = n02;
+    }
+  }
+  const double smallest = fmin(a00, fmin(a11, a22)), largest = fmax(a00, fmax(a11, a22));
+  quality[l] = (smallest < 1.0e-12) ? 0.0 : sqrt(smallest) / sqrt(largest);
+}
+
+void launchLandmarkQuality(const DeviceProblem& p, double* quality, hipStream_t s) {
+  if (p.L == 0) return;
+  hipLaunchKernelGGL(k_landmark_quality, dim3((p.L + 127) / 128), dim3(128), 0, s, p, quality);
+}
+
+}  // namespace svin

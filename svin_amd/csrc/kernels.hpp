@@ -1,0 +1,141 @@
+// svin_amd: device data layout and kernel launch interface (host side sees plain structs).
+//
+// HBM layout (all FP64 unless noted; SoA so that lane i of a wave touches element i):
+//   parameter tables   pose[nPose][7]  ext[nExt][7]  sb[nSb][9]  lm[L][4]   (+ candidate copies)
+//   reduced-system map poseOff/extOff/sbOff: first row of the block in the reduced system or -1 (fixed)
+//                      order: [poses | variable extrinsics | speed-biases]  -> the leading dC rows are
+//                      the only ones reprojection factors touch
+//   observations       landmark-major CSR: lmPtr[L+1]; per observation uv(2) w(1) packed index (u32)
+//                      and landmark index (i32)
+//   linearisation      r[2][N] Jp[12][N] Jl[6][N] Je[12][N]  (component-major: a wave writes/reads
+//                      512 contiguous bytes per component) -- two sets (current / candidate)
+//   small factors      DevFactor[F] + FactorLin[F] (r[15], J[15x30]) ; DevImu[nImu] pre-integration state
+//   prior              H-space form of the marginalisation prior (Ht m x m, bp m, c0) + block table
+//   normal equations   S[d][d], gRed[d], gFull[d], hC[d], per-landmark Vinv[6] bl[3] hL[3] scaleL[3]
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+#include "dmath.hpp"
+
+namespace svin {
+
+constexpr int kMaxCams = 8;
+
+// packed per-observation index: pose slot (12 bit) | ext slot (12 bit) | camera (4 bit)
+inline __host__ __device__ uint32_t packObs(int pose, int ext, int cam) {
+  return (uint32_t)pose | ((uint32_t)ext << 12) | ((uint32_t)cam << 24);
+}
+
+struct ImuParams {
+  double a_max, g_max, sigma_g_c, sigma_a_c, sigma_bg, sigma_ba, sigma_gw_c, sigma_aw_c, tau, g;
+  double a0[3];
+};
+
+struct DevImu {
+  int sampleStart, sampleCount;  // into the imu sample pool
+  uint32_t t0[2], t1[2];
+  ImuParams par;
+  int redo, redoCounter;
+  double Delta_t;
+  double Delta_q[4], C_integral[9], C_doubleintegral[9], acc_integral[3], acc_doubleintegral[3];
+  double dalpha_db_g[9], dv_db_g[9], dp_db_g[9];
+  double P_delta[225], information[225], sqrtInfo[225];
+  double sb_ref[9];
+};
+
+enum FactorKind : int { F_IMU = 0, F_POSE_PRIOR = 1, F_SB_PRIOR = 2, F_RELPOSE = 3, F_SONAR = 4, F_DEPTH = 5 };
+enum BlockKind : int { B_POSE = 0, B_EXT = 1, B_SB = 2, B_LM = 3 };
+
+struct DevFactor {
+  int kind, nblk, m, imuIndex;
+  int blkKind[4], blkSlot[4];
+  double meas[9];       // pose prior: T(7); sb prior: 9; sonar: range, heading, mean(3); depth: depth, firstDepth
+  double aux[8];        // sonar: T_SSo(7)
+  double sqrtInfo[81];  // row-major m x m (upper-triangular L^T)
+};
+struct FactorLin {
+  double r[15];
+  double J[15 * 30];  // row-major m x ncols, blocks concatenated in order
+  int off[4], dim[4], m, ncols;
+};
+
+struct PriorBlock {
+  int kind, slot;  // BlockKind / table slot (B_LM unsupported in the solver: priors never keep landmarks)
+  int ord, mdim;   // first row in the prior, minimal dimension (0 when the block was fixed)
+  double lin[9];   // linearisation point
+};
+
+// scalar results of one iteration, read back by the host once per iteration
+struct SolverScalars {
+  double cost;            // cost at the evaluated point (current or candidate)
+  double costReproj, costFactors, costPrior;
+  double gradMax;         // max |g_full|
+  double gHatSq;          // |g_hat|^2
+  double jgSq;            // |J (g / htil)|^2          (Cauchy point)
+  double gnHatSq;         // |gn_hat|^2
+  double gDotGn;          // g_hat . gn_hat
+  double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
+  double stepNormSq, xNormSq;
+  double doglegStepNorm;
+  int cholFail;           // != 0 when S or a landmark block is not positive definite
+  int pad;
+};
+
+struct DeviceProblem {
+  // sizes
+  int nPose, nExt, nSb, L, N, F, nImu, d, dC, priorM, priorBlocks, nCam;
+  int anyExtVariable;
+  // tables
+  double *pose, *ext, *sb, *lm;
+  double *poseC, *extC, *sbC, *lmC;
+  int *poseOff, *extOff, *sbOff;
+  CameraModel* cams;
+  // observations
+  int* lmPtr;
+  double *obsUv, *obsW;
+  uint32_t* obsIdx;
+  int* obsLm;
+  // linearisation buffers (cur = accepted point, cand = candidate)
+  double *rCur, *JpCur, *JlCur, *JeCur;
+  double *rCand, *JpCand, *JlCand, *JeCand;
+  // factors
+  DevFactor* factors;
+  FactorLin *linCur, *linCand;
+  DevImu* imus;
+  uint32_t* imuT;    // [M][2]
+  double* imuMeas;   // [M][6]
+  // prior (H-space)
+  double *priorH, *priorBp;
+  double priorC0;
+  PriorBlock* priorBlk;
+  double *priorDchi, *priorGrad, *priorMv;   // scratch m
+  double* priorM3;                           // per block 3x3 rotation map (row-major 9), identity for non-pose
+  // normal equations
+  double *S, *gRed, *gFull, *hC, *htilC, *scaleC;
+  double *Vinv, *bl, *hL, *scaleL;           // per landmark 6 / 3 / 3 / 3
+  double *slabs; int nSlabs;                 // per-workgroup private copies of the leading dC x dC block (+2 dC vectors)
+  double *yC, *yL;                           // Gauss-Newton solution (cam d, landmarks 3L)
+  double *deltaC, *deltaL;                   // trust-region step
+  double *vC, *vL;                           // generic vector for J*v passes
+  double *cholL;                             // factor of S
+  SolverScalars* scal;
+  double* partial;                           // reduction scratch
+};
+
+// ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.
+void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_t s);
+void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s);
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s);
+void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
+void launchSolveReduced(const DeviceProblem& p, hipStream_t s);          // Cholesky + GN step (cam + landmarks)
+void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s);         // g_hat norms, Cauchy J*v pass, gn norms
+void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms
+void launchCost(const DeviceProblem& p, hipStream_t s);                  // sums partial costs into scal->cost
+void launchImuPropagation(const DevImu* im /*device*/, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
+                          int* used, hipStream_t s);
+void launchLandmarkQuality(const DeviceProblem& p, double* quality, hipStream_t s);
+// Jacobian-evaluation micro-benchmark entry: B independent copies of the observation set
+void launchEvalReprojBatched(const DeviceProblem& p, int copies, double* rOut, double* JpOut, double* JlOut,
+                             double* JeOut, hipStream_t s);
+
+}  // namespace svin

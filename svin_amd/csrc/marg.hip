@@ -1,0 +1,804 @@
+// svin_amd marginalisation (K10): Estimator::applyMarginalizationStrategy policy on the host,
+// MarginalizationError algebra on the device.
+//
+// Reference (relative to /root/reference/okvis_ros/okvis/okvis_ceres/):
+//   policy  src/Estimator.cpp:495-814
+//   M1      src/MarginalizationError.cpp:126-397  (linearise at first-estimate points, H += J^T J, b0 -= J^T r)
+//   M2      :463-721 + include/okvis/ceres/implementation/MarginalizationError.hpp:48-220
+//   M3      :725-758
+// Device layout of one marginalisation job: dense part U (m x m) / ba (m), landmark coupling W (m x 3Lm),
+// landmark blocks V (Lm x 9) / bb (3Lm).  The reference's Jacobi preconditioner only influences the
+// rank-revealing thresholds of the eliminated blocks; it is applied to exactly those blocks here
+// (U - W V^+ W^T with V^+ = D^-1 (D^-1 V D^-1)^+ D^-1), which is the same matrix in exact arithmetic.
+#include "window.hpp"
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace svin {
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+__device__ __forceinline__ double waveSumM(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- M1 accumulation
+struct MargDev {
+  int m, Lm, N, F;
+  double *U, *ba, *W, *V, *bb;  // U m x m, W m x 3Lm (row-major), V Lm x 9, bb 3Lm
+};
+
+template <bool WITH_EXT>
+__global__ void k_marg_accum_reproj(DeviceProblem p, MargDev md) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= p.N) return;
+  const size_t N = (size_t)p.N;
+  const uint32_t idx = p.obsIdx[o];
+  const int offP = p.poseOff[idx & 0xfff];
+  const int offE = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
+  const int l = p.obsLm[o];
+  double r0 = p.rCur[o], r1 = p.rCur[N + o];
+  double jl[6], jp[12], je[12];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) jl[k] = p.JlCur[k * N + o];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) jp[k] = p.JpCur[k * N + o];
+  if (WITH_EXT) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) je[k] = p.JeCur[k * N + o];
+  }
+  const int m = md.m, wld = 3 * md.Lm;
+  // landmark block
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) atomicAdd(&md.V[9 * (size_t)l + a * 3 + b], jl[a] * jl[b] + jl[3 + a] * jl[3 + b]);
+    atomicAdd(&md.bb[3 * l + a], -(jl[a] * r0 + jl[3 + a] * r1));
+  }
+  auto cam = [&](const double* jc, int off) {
+    if (off < 0) return;
+    for (int a = 0; a < 6; ++a) {
+      atomicAdd(&md.ba[off + a], -(jc[a] * r0 + jc[6 + a] * r1));
+      for (int b = 0; b < 6; ++b) atomicAdd(&md.U[(size_t)(off + a) * m + off + b], jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
+      for (int b = 0; b < 3; ++b) atomicAdd(&md.W[(size_t)(off + a) * wld + 3 * l + b], jc[a] * jl[b] + jc[6 + a] * jl[3 + b]);
+    }
+  };
+  cam(jp, offP);
+  if (WITH_EXT) {
+    cam(je, offE);
+    if (offP >= 0 && offE >= 0)
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          const double v = jp[a] * je[b] + jp[6 + a] * je[6 + b];
+          atomicAdd(&md.U[(size_t)(offP + a) * m + offE + b], v);
+          atomicAdd(&md.U[(size_t)(offE + b) * m + offP + a], v);
+        }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_marg_accum_factors(DeviceProblem p, MargDev md) {
+  const FactorLin& lin = p.linCur[blockIdx.x];
+  const int mm = lin.m, nc = lin.ncols;
+  __shared__ int colRow[30];
+  if (threadIdx.x < 30) {
+    int c = threadIdx.x, row = -1, base = 0;
+    for (int b = 0; b < 4; ++b) {
+      if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
+      base += lin.dim[b];
+    }
+    colRow[threadIdx.x] = (c < nc) ? row : -1;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
+    const int a = idx / nc, b = idx % nc;
+    const int ra = colRow[a], rb = colRow[b];
+    if (ra < 0 || rb < 0) continue;
+    double s = 0;
+    for (int k = 0; k < mm; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
+    atomicAdd(&md.U[(size_t)ra * md.m + rb], s);
+    if (a == b) {
+      double g = 0;
+      for (int k = 0; k < mm; ++k) g += lin.J[k * nc + a] * lin.r[k];
+      atomicAdd(&md.ba[ra], -g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small symmetric eigen-solvers
+// 3x3: cyclic Jacobi with eigenvectors (columns of Q, row-major 3x3)
+__device__ void symEig3(const double* A9, double* ev, double* Q) {
+  double a00 = A9[0], a01 = 0.5 * (A9[1] + A9[3]), a02 = 0.5 * (A9[2] + A9[6]), a11 = A9[4], a12 = 0.5 * (A9[5] + A9[7]),
+         a22 = A9[8];
+  for (int k = 0; k < 9; ++k) Q[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  auto rotQ = [&](int p, int q, double c, double s) {
+    for (int r = 0; r < 3; ++r) {
+      const double qp = Q[r * 3 + p], qq = Q[r * 3 + q];
+      Q[r * 3 + p] = c * qp - s * qq;
+      Q[r * 3 + q] = s * qp + c * qq;
+    }
+  };
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    if (fabs(a01) + fabs(a02) + fabs(a12) == 0.0) break;
+    if (a01 != 0.0) {
+      const double th = (a11 - a00) / (2.0 * a01);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n00 = a00 - tt * a01, n11 = a11 + tt * a01, n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
+      a00 = n00; a11 = n11; a01 = 0; a02 = n02; a12 = n12;
+      rotQ(0, 1, c, s);
+    }
+    if (a02 != 0.0) {
+      const double th = (a22 - a00) / (2.0 * a02);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n00 = a00 - tt * a02, n22 = a22 + tt * a02, n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
+      a00 = n00; a22 = n22; a02 = 0; a01 = n01; a12 = n12;
+      rotQ(0, 2, c, s);
+    }
+    if (a12 != 0.0) {
+      const double th = (a22 - a11) / (2.0 * a12);
+      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+      const double n11 = a11 - tt * a12, n22 = a22 + tt * a12, n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
+      a11 = n11; a22 = n22; a12 = 0; a01 = n01; a02 = n02;
+      rotQ(1, 2, c, s);
+    }
+  }
+  ev[0] = a00; ev[1] = a11; ev[2] = a22;
+}
+
+// n x n symmetric eigendecomposition by one-sided (Hestenes) Jacobi, executed by one workgroup.
+// G (row j = column j of A on entry) is overwritten by the columns of A*Q; Q (row j = eigenvector j)
+// must hold the identity on entry.  Eigenvalue j = Q_j . G_j.  Rounds follow the round-robin
+// tournament so that the n/2 rotations of one round touch disjoint columns.
+__device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
+  if (n <= 1) return;
+  const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    for (int round = 0; round < np - 1; ++round) {
+      for (int k = wave; k < np / 2; k += nWaves) {
+        int a, b;
+        if (k == 0) { a = np - 1; b = round; }
+        else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
+        if (a >= n || b >= n) continue;
+        const int pI = a < b ? a : b, qI = a < b ? b : a;
+        double* gp = G + (size_t)pI * ld;
+        double* gq = G + (size_t)qI * ld;
+        double al = 0, be = 0, ga = 0;
+        for (int i = lane; i < n; i += 64) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
+        al = waveSumM(al); be = waveSumM(be); ga = waveSumM(ga);
+        if (fabs(ga) <= 1e-15 * sqrt(al * be) || al == 0.0 || be == 0.0) continue;
+        if (lane == 0) *flag = 1;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+        double* vp = Q + (size_t)pI * ld;
+        double* vq = Q + (size_t)qI * ld;
+        for (int i = lane; i < n; i += 64) {
+          const double x = gp[i], y = gq[i];
+          gp[i] = c * x - s * y; gq[i] = s * x + c * y;
+          const double u = vp[i], w = vq[i];
+          vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+        }
+      }
+      __syncthreads();
+    }
+    if (*flag == 0) break;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- M2: landmark part (:557-619)
+// per landmark: p_b from diag(V), V' = V/(p_b p_b^T), (V')^+ by 3x3 eigendecomposition with tolerance
+// eps*3*lmax, N = D_b^-1 U_e diag(sqrt(1/l)|0);  Mu = W_l N (m x 3) overwrites W_l; vb = N N^T bb_l.
+__global__ void k_marg_lm_prepare(MargDev md, double* vb) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= md.Lm) return;
+  const double* V = md.V + 9 * (size_t)l;
+  double pb[3];
+  for (int a = 0; a < 3; ++a) pb[a] = (V[a * 4] > 1.0e-9) ? sqrt(V[a * 4]) : 1.0e-3;
+  double Vs[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) Vs[a * 3 + b] = V[a * 3 + b] / (pb[a] * pb[b]);
+  double ev[3], Q[9];
+  symEig3(Vs, ev, Q);
+  const double mx = fmax(ev[0], fmax(ev[1], ev[2]));
+  const double tol = 2.220446049250313e-16 * 3 * mx;
+  double Nm[9];
+  for (int j = 0; j < 3; ++j) {
+    const double sc = (ev[j] > tol) ? sqrt(1.0 / ev[j]) : 0.0;
+    for (int a = 0; a < 3; ++a) Nm[a * 3 + j] = Q[a * 3 + j] * sc / pb[a];
+  }
+  // vb = N N^T bb
+  const double* bb = md.bb + 3 * l;
+  double t[3];
+  for (int j = 0; j < 3; ++j) t[j] = Nm[j] * bb[0] + Nm[3 + j] * bb[1] + Nm[6 + j] * bb[2];
+  for (int a = 0; a < 3; ++a) vb[3 * l + a] = Nm[a * 3] * t[0] + Nm[a * 3 + 1] * t[1] + Nm[a * 3 + 2] * t[2];
+  // store N in V (no longer needed)
+  double* Vw = md.V + 9 * (size_t)l;
+  for (int k = 0; k < 9; ++k) Vw[k] = Nm[k];
+}
+// ba -= W vb (uses the original W) ; then W_l <- W_l N_l
+__global__ void k_marg_lm_apply(MargDev md, const double* vb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= md.m) return;
+  double* Wr = md.W + (size_t)i * 3 * md.Lm;
+  double s = 0;
+  for (int l = 0; l < md.Lm; ++l) {
+    const double w0 = Wr[3 * l], w1 = Wr[3 * l + 1], w2 = Wr[3 * l + 2];
+    s += w0 * vb[3 * l] + w1 * vb[3 * l + 1] + w2 * vb[3 * l + 2];
+    const double* Nm = md.V + 9 * (size_t)l;
+    Wr[3 * l] = w0 * Nm[0] + w1 * Nm[3] + w2 * Nm[6];
+    Wr[3 * l + 1] = w0 * Nm[1] + w1 * Nm[4] + w2 * Nm[7];
+    Wr[3 * l + 2] = w0 * Nm[2] + w1 * Nm[5] + w2 * Nm[8];
+  }
+  md.ba[i] -= s;
+}
+// U -= Mu Mu^T
+__global__ void k_marg_lm_update(MargDev md) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= md.m * md.m) return;
+  const int i = idx / md.m, j = idx % md.m;
+  const double* a = md.W + (size_t)i * 3 * md.Lm;
+  const double* b = md.W + (size_t)j * 3 * md.Lm;
+  double s = 0;
+  for (int k = 0; k < 3 * md.Lm; ++k) s += a[k] * b[k];
+  md.U[(size_t)i * md.m + j] -= s;
+}
+
+// ---------------------------------------------------------------- M2 dense part (:622-667) + M3 (:725-758)
+// Single workgroup.  keep/marg index lists select rows of U (m x m).  Outputs the reduced Hk (nk x nk), bk.
+struct DenseArgs {
+  int m, nk, nm;
+  const int* keep; const int* marg;
+  const double* U; const double* ba;
+  double *Hk, *bk;          // outputs
+  double *Vm, *Qm, *tmp;    // scratch: nm x nm, nm x nm, nk x nm + 2 nm
+  int* flag;
+};
+__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a) {
+  const int t = threadIdx.x, nt = blockDim.x, nm = a.nm, nk = a.nk, m = a.m;
+  double* pm = a.tmp;                 // nm
+  double* tv = a.tmp + nm;            // nm
+  double* Mu = a.tmp + 2 * nm;        // nk x nm
+  for (int i = t; i < nm; i += nt) {
+    const double hd = a.U[(size_t)a.marg[i] * m + a.marg[i]];
+    pm[i] = (hd > 1.0e-9) ? sqrt(hd) : 1.0e-3;
+  }
+  __syncthreads();
+  // V' = 0.5 (V + V^T) scaled ; Q = I
+  for (int idx = t; idx < nm * nm; idx += nt) {
+    const int i = idx / nm, j = idx % nm;
+    const double v = 0.5 * (a.U[(size_t)a.marg[i] * m + a.marg[j]] + a.U[(size_t)a.marg[j] * m + a.marg[i]]);
+    a.Vm[idx] = v / (pm[i] * pm[j]);
+    a.Qm[idx] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  jacobiEigBlock(a.Vm, a.Qm, nm, nm, a.flag);
+  // eigenvalues, tolerance, N = D^-1 Q diag(sqrt(1/l)|0)  (column j of N = eigenvector j scaled)
+  __shared__ double smax;
+  for (int j = t; j < nm; j += nt) {
+    double s = 0;
+    for (int i = 0; i < nm; ++i) s += a.Qm[(size_t)j * nm + i] * a.Vm[(size_t)j * nm + i];
+    tv[j] = s;
+  }
+  __syncthreads();
+  if (t == 0) { double mx = tv[0]; for (int j = 1; j < nm; ++j) mx = fmax(mx, tv[j]); smax = mx; }
+  __syncthreads();
+  const double tol = 2.220446049250313e-16 * nm * smax;
+  // overwrite Q rows: N^T row j = sqrt(1/l_j) * q_j / pm
+  for (int idx = t; idx < nm * nm; idx += nt) {
+    const int j = idx / nm, i = idx % nm;
+    const double sc = (tv[j] > tol) ? sqrt(1.0 / tv[j]) : 0.0;
+    a.Qm[idx] = a.Qm[idx] * sc / pm[i];
+  }
+  __syncthreads();
+  // Mu = W N  (W = U[keep, marg]) : Mu[r][j] = sum_i W[r][i] N[i][j] = sum_i W[r][i] Qm[j][i]
+  for (int idx = t; idx < nk * nm; idx += nt) {
+    const int r = idx / nm, j = idx % nm;
+    double s = 0;
+    for (int i = 0; i < nm; ++i) s += a.U[(size_t)a.keep[r] * m + a.marg[i]] * a.Qm[(size_t)j * nm + i];
+    Mu[idx] = s;
+  }
+  // tv2 = N^T b_m
+  __syncthreads();
+  for (int j = t; j < nm; j += nt) {
+    double s = 0;
+    for (int i = 0; i < nm; ++i) s += a.Qm[(size_t)j * nm + i] * a.ba[a.marg[i]];
+    pm[j] = s;  // pm reused
+  }
+  __syncthreads();
+  for (int idx = t; idx < nk * nk; idx += nt) {
+    const int r = idx / nk, c = idx % nk;
+    double s = 0;
+    for (int j = 0; j < nm; ++j) s += Mu[(size_t)r * nm + j] * Mu[(size_t)c * nm + j];
+    a.Hk[idx] = a.U[(size_t)a.keep[r] * m + a.keep[c]] - s;
+  }
+  for (int r = t; r < nk; r += nt) {
+    double s = 0;
+    for (int j = 0; j < nm; ++j) s += Mu[(size_t)r * nm + j] * pm[j];
+    a.bk[r] = a.ba[a.keep[r]] - s;
+  }
+}
+
+// M3: H = U S U^T of the Jacobi-preconditioned H; J = (p U sqrt(S))^T, e0 = -(sqrt(S)^+ U^T p^-1) b0;
+// plus the H-space form used by the solver: Ht = J^T J, bp = J^T e0, c0 = e0.e0 (out[0]).
+struct FinalArgs {
+  int n;
+  const double* H; const double* b0;
+  double *G, *Q, *J, *e0, *Ht, *bp, *scal, *tmp;
+  int* flag;
+};
+__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a) {
+  const int t = threadIdx.x, nt = blockDim.x, n = a.n;
+  double* p = a.tmp;        // n
+  double* ev = a.tmp + n;   // n
+  for (int i = t; i < n; i += nt) {
+    const double hd = a.H[(size_t)i * n + i];
+    p[i] = (hd > 1.0e-9) ? sqrt(hd) : 1.0e-3;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx % n;
+    a.G[idx] = 0.5 * (a.H[idx] + a.H[(size_t)j * n + i]) / (p[i] * p[j]);
+    a.Q[idx] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  jacobiEigBlock(a.G, a.Q, n, n, a.flag);
+  __shared__ double smax;
+  for (int j = t; j < n; j += nt) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += a.Q[(size_t)j * n + i] * a.G[(size_t)j * n + i];
+    ev[j] = s;
+  }
+  __syncthreads();
+  if (t == 0) { double mx = ev[0]; for (int j = 1; j < n; ++j) mx = fmax(mx, ev[j]); smax = mx; }
+  __syncthreads();
+  const double tol = 2.220446049250313e-16 * n * smax;
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx % n;  // row i of J = eigen-direction i
+    const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
+    a.J[idx] = p[j] * a.Q[(size_t)i * n + j] * s;
+  }
+  for (int i = t; i < n; i += nt) {
+    const double si = ev[i] > tol ? sqrt(1.0 / ev[i]) : 0.0;
+    double e = 0;
+    for (int j = 0; j < n; ++j) e += si * a.Q[(size_t)i * n + j] * a.b0[j] / p[j];
+    a.e0[i] = -e;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx % n;
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.J[(size_t)k * n + j];
+    a.Ht[idx] = s;
+  }
+  for (int i = t; i < n; i += nt) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.e0[k];
+    a.bp[i] = s;
+  }
+  if (t == 0) {
+    double c = 0;
+    for (int k = 0; k < n; ++k) c += a.e0[k] * a.e0[k];
+    a.scal[0] = c;
+  }
+}
+
+// ================================================================ host: policy + job assembly
+namespace {
+template <class T>
+bool contains(const std::vector<T>& v, const T& q) {
+  for (const T& e : v) if (e == q) return true;
+  return false;
+}
+}  // namespace
+
+int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed) {
+  // ---- policy (Estimator.cpp:495-770), operating on the host graph only
+  auto rit = states_.rbegin();
+  for (size_t k = 0; k < numImuFrames; k++) {
+    rit++;
+    if (rit == states_.rend()) return 1;
+  }
+  // :509-514 the old prior leaves the graph; its content is re-used below
+  const bool hadPrior = hasPrior_;
+  if (hadPrior) {
+    for (const PriorBlockHost& pb : priorBlocks_)
+      if (Block* b = findBlock(pb.id)) {
+        for (size_t i = 0; i < b->residuals.size(); ++i)
+          if (b->residuals[i] == priorResId_) { b->residuals.erase(b->residuals.begin() + i); break; }
+      }
+    priorResId_ = 0;
+  }
+  std::vector<uint64_t> removeFrames, removeAllButPose, allLinearizedFrames;
+  size_t countedKeyframes = 0;
+  while (rit != states_.rend()) {
+    if (!rit->second.isKeyframe || countedKeyframes >= numKeyframes) removeFrames.push_back(rit->second.id);
+    else countedKeyframes++;
+    removeAllButPose.push_back(rit->second.id);
+    allLinearizedFrames.push_back(rit->second.id);
+    ++rit;
+  }
+  // the job: residuals to linearise (copied out of the graph as they are removed) and blocks to marginalise
+  struct JobObs { Observation o; uint64_t lmId; };
+  std::vector<Factor> jobFactors;
+  std::vector<JobObs> jobObs;
+  std::vector<uint64_t> toMarginalize;
+  // connected dense blocks in insertion order (after the blocks of the old prior) and landmarks
+  std::vector<PriorBlockHost> dense = priorBlocks_;
+  std::vector<uint64_t> lmOrder;
+  std::unordered_map<uint64_t, std::vector<double>> lmLin;  // linearisation points of marginalised landmarks
+  auto connectDense = [&](uint64_t id) {
+    for (const PriorBlockHost& pb : dense) if (pb.id == id) return;
+    const Block& b = blocks_.at(id);
+    PriorBlockHost pb;
+    pb.id = id; pb.kind = b.kind; pb.dim = (b.kind == B_SB) ? 9 : 7;
+    pb.mdim = b.fixed ? 0 : ((b.kind == B_SB) ? 9 : 6);
+    std::memcpy(pb.lin, b.x, sizeof(double) * pb.dim);
+    dense.push_back(pb);
+  };
+  auto addFactorToJob = [&](uint64_t rid) {
+    auto it = factors_.find(rid);
+    if (it == factors_.end()) return;
+    for (int b = 0; b < it->second.nblk; ++b) connectDense(it->second.blocks[b]);
+    jobFactors.push_back(it->second);
+    removeFactor(rid);
+  };
+  auto isReproj = [&](uint64_t rid) { return obsRes2Lm_.count(rid) != 0; };
+  auto isPrior = [&](uint64_t rid) { return rid != 0 && !isReproj(rid) && !factors_.count(rid); };
+
+  for (uint64_t fid : removeAllButPose) {  // :541-605
+    auto it = states_.find(fid);
+    for (size_t j = 0; j < it->second.sb.size(); ++j) {
+      StateInfo& si = it->second.sb[j];
+      if (!si.exists) continue;
+      if (blocks_.at(si.id).fixed) continue;
+      auto checkit = it;
+      checkit++;
+      if (checkit != states_.end() && checkit->second.sb.size() > j && checkit->second.sb[j].exists &&
+          checkit->second.sb[j].id == si.id) continue;
+      si.exists = false;
+      toMarginalize.push_back(si.id);
+      const std::vector<uint64_t> res = blocks_.at(si.id).residuals;
+      for (uint64_t rid : res)
+        if (!isReproj(rid) && !isPrior(rid)) addFactorToJob(rid);
+    }
+  }
+  bool reDoFixation = false;
+  for (uint64_t fid : removeFrames) {  // :607-770
+    auto it = states_.find(fid);
+    it->second.pose.exists = false;
+    toMarginalize.push_back(it->second.pose.id);
+    {
+      const std::vector<uint64_t> res = blocks_.at(it->second.pose.id).residuals;
+      for (uint64_t rid : res) {
+        auto fit = factors_.find(rid);
+        if (fit != factors_.end() && fit->second.kind == F_POSE_PRIOR) {  // :624-629
+          removeFactor(rid);
+          reDoFixation = true;
+          continue;
+        }
+        if (!isReproj(rid) && fit != factors_.end()) addFactorToJob(rid);
+      }
+    }
+    for (size_t j = 0; j < it->second.ext.size(); ++j) {  // :638-664
+      StateInfo& si = it->second.ext[j];
+      if (!si.exists) continue;
+      if (blocks_.at(si.id).fixed) continue;
+      auto checkit = it;
+      checkit++;
+      if (checkit != states_.end() && checkit->second.ext[j].exists && checkit->second.ext[j].id == si.id) continue;
+      si.exists = false;
+      toMarginalize.push_back(si.id);
+      const std::vector<uint64_t> res = blocks_.at(si.id).residuals;
+      for (uint64_t rid : res)
+        if (!isReproj(rid) && factors_.count(rid)) addFactorToJob(rid);
+    }
+    const uint64_t currentKfId = allLinearizedFrames.at(0);
+    for (auto pit = landmarks_.begin(); pit != landmarks_.end();) {  // :671-766
+      Landmark& lm = pit->second;
+      std::vector<uint64_t> residuals;
+      for (const Observation& o : lm.obs) residuals.push_back(o.resId);
+      bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
+      size_t obsCount = 0;
+      auto poseOf = [&](uint64_t rid) {
+        for (const Observation& o : lm.obs) if (o.resId == rid) return o.poseId;
+        return (uint64_t)0;
+      };
+      for (uint64_t rid : residuals) {
+        const uint64_t poseId = poseOf(rid);
+        if (contains(removeFrames, poseId)) skipLandmark = false;
+        if (poseId >= currentKfId) { marginalize = false; hasNewObservations = true; }
+        if (contains(allLinearizedFrames, poseId)) obsCount++;
+      }
+      if (residuals.empty()) {
+        removed.push_back(pit->first);
+        pit = landmarks_.erase(pit);
+        continue;
+      }
+      if (skipLandmark) { pit++; continue; }
+      for (size_t r = 0; r < residuals.size(); ++r) {
+        const uint64_t rid = residuals[r];
+        const uint64_t poseId = poseOf(rid);
+        if ((contains(removeFrames, poseId) && hasNewObservations) ||
+            (!contains(allLinearizedFrames, poseId) && marginalize)) {
+          removeObservationById(rid);
+          residuals.erase(residuals.begin() + r);
+          r--;
+        } else if (marginalize && contains(allLinearizedFrames, poseId)) {
+          if (obsCount < 2) {
+            removeObservationById(rid);
+            residuals.erase(residuals.begin() + r);
+            r--;
+          } else {
+            errorTermAdded = true;
+            for (size_t i = 0; i < lm.obs.size(); ++i)
+              if (lm.obs[i].resId == rid) {
+                connectDense(lm.obs[i].poseId);
+                connectDense(lm.obs[i].extId);
+                if (!contains(lmOrder, lm.id)) { lmOrder.push_back(lm.id); lmLin[lm.id].assign(lm.hp, lm.hp + 4); }
+                jobObs.push_back({lm.obs[i], lm.id});
+                removeObsRecord(lm, i);
+                break;
+              }
+          }
+        }
+        if (residuals.size() == 0) { justDelete = true; marginalize = false; }
+      }
+      if (justDelete) {
+        removed.push_back(pit->first);
+        pit = landmarks_.erase(pit);
+        continue;
+      }
+      if (marginalize && errorTermAdded) {
+        toMarginalize.push_back(pit->first);
+        removed.push_back(pit->first);
+        pit = landmarks_.erase(pit);
+        continue;
+      }
+      pit++;
+    }
+    states_.erase(it->second.id);
+  }
+
+  // ---- device job (M1-M3)
+  std::sort(toMarginalize.begin(), toMarginalize.end());
+  toMarginalize.erase(std::unique(toMarginalize.begin(), toMarginalize.end()), toMarginalize.end());
+  bool anyWork = !toMarginalize.empty();
+  // ordering of the dense part
+  int m = 0;
+  for (PriorBlockHost& pb : dense) { pb.ord = m; m += pb.mdim; }
+  const int Lm = (int)lmOrder.size();
+  std::vector<double> Hk, bk;
+  std::vector<PriorBlockHost> kept;
+  if (m > 0 || Lm > 0) {
+    hipStream_t s = stream_;
+    // sub-problem tables at the linearisation points
+    std::vector<uint64_t> jPose, jExt, jSb;
+    std::unordered_map<uint64_t, int> sPose, sExt, sSb, sLm;
+    std::vector<double> hPose, hExt, hSb, hLm;
+    std::vector<int> oPose, oExt, oSb;
+    for (const PriorBlockHost& pb : dense) {
+      const int off = pb.mdim > 0 ? pb.ord : -1;
+      if (pb.kind == B_POSE) { sPose[pb.id] = (int)jPose.size(); jPose.push_back(pb.id); hPose.insert(hPose.end(), pb.lin, pb.lin + 7); oPose.push_back(off); }
+      else if (pb.kind == B_EXT) { sExt[pb.id] = (int)jExt.size(); jExt.push_back(pb.id); hExt.insert(hExt.end(), pb.lin, pb.lin + 7); oExt.push_back(off); }
+      else { sSb[pb.id] = (int)jSb.size(); jSb.push_back(pb.id); hSb.insert(hSb.end(), pb.lin, pb.lin + 9); oSb.push_back(off); }
+    }
+    if (hExt.empty()) { hExt.assign(7, 0.0); hExt[6] = 1.0; oExt.push_back(-1); }
+    if (hPose.empty()) { hPose.assign(7, 0.0); hPose[6] = 1.0; oPose.push_back(-1); }
+    for (int l = 0; l < Lm; ++l) {
+      sLm[lmOrder[l]] = l;
+      const std::vector<double>& hp = lmLin.at(lmOrder[l]);
+      hLm.insert(hLm.end(), hp.begin(), hp.end());
+    }
+    // observations sorted landmark-major
+    std::stable_sort(jobObs.begin(), jobObs.end(), [&](const JobObs& a, const JobObs& b) { return sLm.at(a.lmId) < sLm.at(b.lmId); });
+    const int N = (int)jobObs.size();
+    std::vector<double> hUv, hW;
+    std::vector<uint32_t> hIdx;
+    std::vector<int> hObsLm, hLmPtr(Lm + 1, 0);
+    bool anyExtVar = false;
+    for (const JobObs& jo : jobObs) {
+      hUv.push_back(jo.o.uv[0]); hUv.push_back(jo.o.uv[1]);
+      hW.push_back(std::sqrt(64.0 / (jo.o.size * jo.o.size)));
+      const int es = sExt.count(jo.o.extId) ? sExt.at(jo.o.extId) : 0;
+      hIdx.push_back(packObs(sPose.at(jo.o.poseId), es, jo.o.cam));
+      hObsLm.push_back(sLm.at(jo.lmId));
+      hLmPtr[sLm.at(jo.lmId) + 1]++;
+    }
+    for (int l = 0; l < Lm; ++l) hLmPtr[l + 1] += hLmPtr[l];
+    for (int o : oExt) if (o >= 0) anyExtVar = true;
+    // factors
+    std::vector<DevFactor> hFac;
+    std::vector<DevImu> hImu;
+    std::vector<uint32_t> hImuT;
+    std::vector<double> hImuM;
+    for (Factor& f : jobFactors) {
+      DevFactor df;
+      std::memset(&df, 0, sizeof(df));
+      df.kind = f.kind; df.nblk = f.nblk; df.m = f.m; df.imuIndex = -1;
+      for (int b = 0; b < f.nblk; ++b) {
+        const uint64_t id = f.blocks[b];
+        if (sPose.count(id)) { df.blkKind[b] = B_POSE; df.blkSlot[b] = sPose.at(id); }
+        else if (sExt.count(id)) { df.blkKind[b] = B_EXT; df.blkSlot[b] = sExt.at(id); }
+        else { df.blkKind[b] = B_SB; df.blkSlot[b] = sSb.at(id); }
+      }
+      std::memcpy(df.meas, f.meas, sizeof(df.meas));
+      std::memcpy(df.aux, f.aux, sizeof(df.aux));
+      std::memcpy(df.sqrtInfo, f.sqrtInfo, sizeof(df.sqrtInfo));
+      if (f.kind == F_IMU) {
+        df.imuIndex = (int)hImu.size();
+        f.imu.sampleStart = (int)(hImuT.size() / 2);
+        f.imu.sampleCount = (int)(f.imuT.size() / 2);
+        hImu.push_back(f.imu);
+        hImuT.insert(hImuT.end(), f.imuT.begin(), f.imuT.end());
+        hImuM.insert(hImuM.end(), f.imuMeas.begin(), f.imuMeas.end());
+      }
+      hFac.push_back(df);
+    }
+    const int F = (int)hFac.size();
+    auto up = [&](auto& buf, const auto& host) {
+      buf.reserve(std::max<size_t>(host.size(), 1));
+      if (!host.empty()) HIP_OK(hipMemcpyAsync(buf.p, host.data(), sizeof(host[0]) * host.size(), hipMemcpyHostToDevice, s));
+    };
+    DevBuf<double> bPose, bExt, bSb, bLm, bUv, bW, bLin, bU, bW2, bV, bVec, bScratch;
+    DevBuf<int> bOP, bOE, bOS, bLmPtr, bObsLm, bIdxList, bFlag;
+    DevBuf<uint32_t> bIdx, bImuT;
+    DevBuf<DevFactor> bFac;
+    DevBuf<FactorLin> bFacLin;
+    DevBuf<DevImu> bImu;
+    DevBuf<double> bImuM, bPartial;
+    DevBuf<SolverScalars> bScal;
+    up(bPose, hPose); up(bExt, hExt); up(bSb, hSb); up(bLm, hLm); up(bUv, hUv); up(bW, hW);
+    up(bOP, oPose); up(bOE, oExt); up(bOS, oSb); up(bLmPtr, hLmPtr); up(bObsLm, hObsLm); up(bIdx, hIdx);
+    up(bFac, hFac); up(bImu, hImu); up(bImuT, hImuT); up(bImuM, hImuM);
+    up(dCams_, cameras_);
+    bLin.reserve(std::max<size_t>((size_t)32 * N, 1));
+    bFacLin.reserve(std::max(F, 1));
+    bPartial.reserve((size_t)16 * 4096);
+    bScal.reserve(1);
+    bFlag.reserve(4);
+    const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
+    bU.reserve(mm * mm); bW2.reserve(mm * L3); bV.reserve((size_t)9 * std::max(Lm, 1)); bVec.reserve(mm + 2 * L3 + 16);
+    HIP_OK(hipMemsetAsync(bU.p, 0, sizeof(double) * mm * mm, s));
+    HIP_OK(hipMemsetAsync(bW2.p, 0, sizeof(double) * mm * L3, s));
+    HIP_OK(hipMemsetAsync(bV.p, 0, sizeof(double) * 9 * std::max(Lm, 1), s));
+    HIP_OK(hipMemsetAsync(bVec.p, 0, sizeof(double) * (mm + 2 * L3 + 16), s));
+    // old prior content (H_, b0_) occupies the leading block
+    if (hadPrior && priorM_ > 0) {
+      HIP_OK(hipMemcpy2DAsync(bU.p, sizeof(double) * m, priorH_.data(), sizeof(double) * priorM_, sizeof(double) * priorM_,
+                              priorM_, hipMemcpyHostToDevice, s));
+      HIP_OK(hipMemcpyAsync(bVec.p, priorB0_.data(), sizeof(double) * priorM_, hipMemcpyHostToDevice, s));
+    }
+    DeviceProblem q;
+    std::memset(&q, 0, sizeof(q));
+    q.nPose = (int)(hPose.size() / 7); q.nExt = (int)(hExt.size() / 7); q.nSb = (int)jSb.size();
+    q.L = Lm; q.N = N; q.F = F; q.nImu = (int)hImu.size(); q.d = m; q.dC = 0; q.nCam = (int)cameras_.size();
+    q.anyExtVariable = anyExtVar ? 1 : 0;
+    q.pose = bPose.p; q.ext = bExt.p; q.sb = bSb.p; q.lm = bLm.p;
+    q.poseC = bPose.p; q.extC = bExt.p; q.sbC = bSb.p; q.lmC = bLm.p;
+    q.poseOff = bOP.p; q.extOff = bOE.p; q.sbOff = bOS.p;
+    q.cams = dCams_.p;
+    q.lmPtr = bLmPtr.p; q.obsUv = bUv.p; q.obsW = bW.p; q.obsIdx = bIdx.p; q.obsLm = bObsLm.p;
+    q.rCur = bLin.p; q.JpCur = bLin.p + (size_t)2 * N; q.JlCur = bLin.p + (size_t)14 * N; q.JeCur = bLin.p + (size_t)20 * N;
+    q.factors = bFac.p; q.linCur = bFacLin.p; q.linCand = bFacLin.p;
+    q.imus = bImu.p; q.imuT = bImuT.p; q.imuMeas = bImuM.p;
+    q.scal = bScal.p; q.partial = bPartial.p;
+    MargDev md;
+    md.m = m; md.Lm = Lm; md.N = N; md.F = F;
+    md.U = bU.p; md.ba = bVec.p; md.W = bW2.p; md.V = bV.p; md.bb = bVec.p + mm;
+    double* vb = bVec.p + mm + L3;
+    // M1: evaluate at the linearisation points (Cauchy corrector as in :283-330) and accumulate
+    if (N > 0) {
+      launchEvalReproj(q, false, true, s);
+      if (anyExtVar) hipLaunchKernelGGL(k_marg_accum_reproj<true>, dim3((N + 127) / 128), dim3(128), 0, s, q, md);
+      else hipLaunchKernelGGL(k_marg_accum_reproj<false>, dim3((N + 127) / 128), dim3(128), 0, s, q, md);
+    }
+    if (F > 0) {
+      launchEvalFactors(q, false, s);
+      hipLaunchKernelGGL(k_marg_accum_factors, dim3(F), dim3(256), 0, s, q, md);
+    }
+    // M2 landmark part
+    if (Lm > 0 && m > 0) {
+      hipLaunchKernelGGL(k_marg_lm_prepare, dim3((Lm + 127) / 128), dim3(128), 0, s, md, vb);
+      hipLaunchKernelGGL(k_marg_lm_apply, dim3((m + 127) / 128), dim3(128), 0, s, md, (const double*)vb);
+      hipLaunchKernelGGL(k_marg_lm_update, dim3((m * m + 255) / 256), dim3(256), 0, s, md);
+    }
+    // M2 dense part
+    std::vector<int> keepIdx, margIdx;
+    for (const PriorBlockHost& pb : dense) {
+      const bool marg = std::binary_search(toMarginalize.begin(), toMarginalize.end(), pb.id);
+      for (int k = 0; k < pb.mdim; ++k) (marg ? margIdx : keepIdx).push_back(pb.ord + k);
+      if (!marg) kept.push_back(pb);
+    }
+    const int nk = (int)keepIdx.size(), nm = (int)margIdx.size();
+    int ordk = 0;
+    for (PriorBlockHost& pb : kept) { pb.ord = ordk; ordk += pb.mdim; }
+    Hk.assign((size_t)nk * nk, 0.0);
+    bk.assign(nk, 0.0);
+    DevBuf<double> bHk, bOut;
+    bHk.reserve(std::max<size_t>((size_t)nk * nk + nk, 1));
+    if (nk > 0) {
+      if (nm > 0) {
+        std::vector<int> lists(keepIdx);
+        lists.insert(lists.end(), margIdx.begin(), margIdx.end());
+        up(bIdxList, lists);
+        bScratch.reserve((size_t)2 * nm * nm + (size_t)nk * nm + 2 * nm + 16);
+        DenseArgs da;
+        da.m = m; da.nk = nk; da.nm = nm;
+        da.keep = bIdxList.p; da.marg = bIdxList.p + nk;
+        da.U = bU.p; da.ba = bVec.p;
+        da.Hk = bHk.p; da.bk = bHk.p + (size_t)nk * nk;
+        da.Vm = bScratch.p; da.Qm = bScratch.p + (size_t)nm * nm; da.tmp = bScratch.p + (size_t)2 * nm * nm;
+        da.flag = bFlag.p;
+        hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), 0, s, da);
+      } else {
+        HIP_OK(hipMemcpyAsync(bHk.p, bU.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(bHk.p + (size_t)m * m, bVec.p, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+      }
+      // M3
+      const size_t n2 = (size_t)nk * nk;
+      bOut.reserve(5 * n2 + 4 * nk + 16);
+      FinalArgs fa;
+      fa.n = nk; fa.H = bHk.p; fa.b0 = bHk.p + n2;
+      fa.G = bOut.p; fa.Q = bOut.p + n2; fa.J = bOut.p + 2 * n2; fa.Ht = bOut.p + 3 * n2;
+      fa.e0 = bOut.p + 4 * n2; fa.bp = bOut.p + 4 * n2 + nk; fa.scal = bOut.p + 4 * n2 + 2 * nk;
+      fa.tmp = bOut.p + 4 * n2 + 2 * nk + 8;
+      fa.flag = bFlag.p;
+      hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), 0, s, fa);
+      priorH_.assign(n2, 0.0); priorB0_.assign(nk, 0.0); priorJ_.assign(n2, 0.0); priorE0_.assign(nk, 0.0);
+      priorHt_.assign(n2, 0.0); priorBp_.assign(nk, 0.0);
+      HIP_OK(hipMemcpyAsync(priorH_.data(), bHk.p, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(priorB0_.data(), bHk.p + n2, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(priorJ_.data(), fa.J, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(priorHt_.data(), fa.Ht, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(priorE0_.data(), fa.e0, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(priorBp_.data(), fa.bp, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipMemcpyAsync(&priorC0_, fa.scal, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_OK(hipStreamSynchronize(s));
+    (void)anyWork;
+  }
+  // ---- graph update (:710-716, :788-811)
+  for (uint64_t id : toMarginalize)
+    if (!lmLin.count(id)) removeBlock(id);
+  int nk = 0;
+  for (const PriorBlockHost& pb : kept) nk += pb.mdim;
+  if (nk > 0) {
+    hasPrior_ = true;
+    priorBlocks_ = kept;
+    priorM_ = nk;
+    priorResId_ = nextResId_++;
+    for (const PriorBlockHost& pb : priorBlocks_) blocks_.at(pb.id).residuals.push_back(priorResId_);
+  } else {
+    hasPrior_ = false;
+    priorBlocks_.clear();
+    priorM_ = 0;
+  }
+  if (reDoFixation && !states_.empty()) {
+    const uint64_t firstId = states_.begin()->first;
+    double information[36] = {0};
+    information[35] = 1.0e14; information[0] = 1.0e14; information[7] = 1.0e14; information[14] = 1.0e14;
+    Factor f;
+    f.kind = F_POSE_PRIOR; f.nblk = 1; f.blocks[0] = firstId; f.m = 6;
+    std::memcpy(f.meas, blocks_.at(firstId).x, 7 * sizeof(double));
+    // Eigen LLT early-exit semantics
+    for (int i = 0; i < 36; ++i) f.sqrtInfo[i] = 0;
+    f.sqrtInfo[0] = f.sqrtInfo[7] = f.sqrtInfo[14] = std::sqrt(1.0e14);
+    f.sqrtInfo[35] = 1.0e14;
+    addFactor(std::move(f));
+  }
+  return 1;
+}
+
+}  // namespace svin

@@ -1,0 +1,1057 @@
+// svin_amd host core (see window.hpp).  Reference line numbers cite
+// /root/reference/okvis_ros/okvis/okvis_ceres/src/Estimator.cpp unless another file is named.
+#include "window.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <stdexcept>
+
+namespace svin {
+
+std::string& lastError() {
+  static thread_local std::string e;
+  return e;
+}
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+static double nowSec() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static double dtSecHost(TimeStamp a, TimeStamp b) {  // okvis Duration normalisation + toSec (Time.hpp:146)
+  long long s = (long long)a.sec - (long long)b.sec;
+  long long ns = (long long)a.nsec - (long long)b.nsec;
+  while (ns < 0) { ns += 1000000000LL; s -= 1; }
+  while (ns >= 1000000000LL) { ns -= 1000000000LL; s += 1; }
+  return (double)s + 1e-9 * (double)ns;
+}
+
+// Cholesky-based square-root information with Eigen's "return at the first non-positive pivot and
+// leave the remainder in place" semantics (PoseError.cpp:70-76).  This is
+// constant data preparation at factor construction, not part of the per-iteration arithmetic.
+static void sqrtInformationUpper(const double* info, int n, double* out) {
+  std::vector<double> A(info, info + n * n);
+  for (int k = 0; k < n; ++k) {
+    double x = A[k * n + k];
+    for (int j = 0; j < k; ++j) x -= A[k * n + j] * A[k * n + j];
+    if (x <= 0) break;
+    x = std::sqrt(x);
+    A[k * n + k] = x;
+    for (int i = k + 1; i < n; ++i) {
+      double s = A[i * n + k];
+      for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j];
+      A[i * n + k] = s / x;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? A[j * n + i] : 0.0;
+}
+
+Window::Window(int device) : device_(device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    throw std::runtime_error("svin_ba: no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= count) throw std::runtime_error("svin_ba: invalid device index");
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipStreamCreate(&stream_));
+  std::memset(&prob_, 0, sizeof(prob_));
+}
+Window::~Window() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ------------------------------------------------------------------------------------------ sensors
+int Window::addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig) {
+  if ((int)cameras_.size() >= 15) return -1;
+  CameraModel c;
+  std::memset(&c, 0, sizeof(c));
+  c.fu = intr[0]; c.fv = intr[1]; c.cu = intr[2]; c.cv = intr[3];
+  for (int i = 0; i < 8; ++i) c.k[i] = (dist && i < nDist) ? dist[i] : 0.0;
+  c.model = model; c.width = w; c.height = h;
+  cameras_.push_back(c);
+  ExtrinsicsSigmas e;
+  e.abs_t = sig[0]; e.abs_r = sig[1]; e.rel_t = sig[2]; e.rel_r = sig[3];
+  extrinsics_.push_back(e);
+  return (int)cameras_.size() - 1;
+}
+int Window::addImu(const ImuParams& p) {  // :83-90
+  if (imus_.size() > 1) return -1;
+  imus_.push_back(p);
+  return (int)imus_.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------ graph helpers
+Block& Window::addBlock(uint64_t id, int kind, const double* x) {
+  Block b;
+  b.id = id; b.kind = kind;
+  std::memcpy(b.x, x, sizeof(double) * (kind == B_SB ? 9 : 7));
+  return blocks_[id] = b;
+}
+Block* Window::findBlock(uint64_t id) {
+  auto it = blocks_.find(id);
+  return it == blocks_.end() ? nullptr : &it->second;
+}
+const Block* Window::findBlock(uint64_t id) const {
+  auto it = blocks_.find(id);
+  return it == blocks_.end() ? nullptr : &it->second;
+}
+static void eraseOne(std::vector<uint64_t>& v, uint64_t x) {
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == x) { v.erase(v.begin() + i); return; }
+}
+uint64_t Window::addFactor(Factor&& f) {
+  f.id = nextResId_++;
+  for (int b = 0; b < f.nblk; ++b) blocks_.at(f.blocks[b]).residuals.push_back(f.id);
+  const uint64_t id = f.id;
+  factors_[id] = std::move(f);
+  return id;
+}
+void Window::removeFactor(uint64_t id) {
+  auto it = factors_.find(id);
+  if (it == factors_.end()) return;
+  for (int b = 0; b < it->second.nblk; ++b) {
+    Block* blk = findBlock(it->second.blocks[b]);
+    if (blk) eraseOne(blk->residuals, id);
+  }
+  factors_.erase(it);
+}
+void Window::removeObsRecord(Landmark& lm, size_t idx) {
+  const Observation o = lm.obs[idx];
+  if (Block* b = findBlock(o.poseId)) eraseOne(b->residuals, o.resId);
+  if (Block* b = findBlock(o.extId)) eraseOne(b->residuals, o.resId);
+  obsRes2Lm_.erase(o.resId);
+  lm.obs.erase(lm.obs.begin() + idx);
+}
+void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (Map.cpp:322-333)
+  Block* b = findBlock(id);
+  if (!b) return;
+  const std::vector<uint64_t> res = b->residuals;
+  for (uint64_t rid : res) {
+    auto it = obsRes2Lm_.find(rid);
+    if (it != obsRes2Lm_.end()) {
+      Landmark& lm = landmarks_.at(it->second);
+      for (size_t i = 0; i < lm.obs.size(); ++i)
+        if (lm.obs[i].resId == rid) { removeObsRecord(lm, i); break; }
+    } else if (factors_.count(rid)) {
+      removeFactor(rid);
+    }
+  }
+  blocks_.erase(id);
+}
+
+// ------------------------------------------------------------------------------------------ IMU prediction
+int Window::imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
+                           TimeStamp t0, TimeStamp t1, double* cov, double* jac) {
+  if (n <= 0) return -1;
+  DevImu im;
+  std::memset(&im, 0, sizeof(im));
+  im.sampleStart = 0; im.sampleCount = n;
+  im.t0[0] = t0.sec; im.t0[1] = t0.nsec; im.t1[0] = t1.sec; im.t1[1] = t1.nsec;
+  im.par = par;
+  DevBuf<DevImu> dIm; dIm.reserve(1);
+  DevBuf<uint32_t> dT; dT.reserve(2 * (size_t)n);
+  DevBuf<double> dM; dM.reserve(6 * (size_t)n);
+  DevBuf<double> dIo; dIo.reserve(16 + 450);
+  DevBuf<int> dUsed; dUsed.reserve(1);
+  double io[16];
+  std::memcpy(io, T, 7 * sizeof(double));
+  std::memcpy(io + 7, sb, 9 * sizeof(double));
+  HIP_OK(hipMemcpyAsync(dIm.p, &im, sizeof(im), hipMemcpyHostToDevice, stream_));
+  HIP_OK(hipMemcpyAsync(dT.p, imuT, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice, stream_));
+  HIP_OK(hipMemcpyAsync(dM.p, imuM, sizeof(double) * 6 * n, hipMemcpyHostToDevice, stream_));
+  HIP_OK(hipMemcpyAsync(dIo.p, io, sizeof(io), hipMemcpyHostToDevice, stream_));
+  launchImuPropagation(dIm.p, dT.p, dM.p, dIo.p, jac ? dIo.p + 16 : nullptr, cov ? dIo.p + 16 + 225 : nullptr, dUsed.p,
+                       stream_);
+  int used = -1;
+  HIP_OK(hipMemcpyAsync(io, dIo.p, sizeof(io), hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipMemcpyAsync(&used, dUsed.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  if (jac) HIP_OK(hipMemcpyAsync(jac, dIo.p + 16, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (cov) HIP_OK(hipMemcpyAsync(cov, dIo.p + 16 + 225, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  if (used >= 0) {
+    std::memcpy(T, io, 7 * sizeof(double));
+    std::memcpy(sb, io + 7, 9 * sizeof(double));
+  }
+  return used;
+}
+
+// initPoseFromImu (:848-873): gravity alignment of the very first pose.  A handful of scalar operations
+// on the mean accelerometer reading, done once per session at construction time.
+static bool initPoseFromImu(const double* imuM, int n, double* T) {
+  T[0] = T[1] = T[2] = 0; T[3] = T[4] = T[5] = 0; T[6] = 1;
+  if (n == 0) return false;
+  double acc[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) { acc[0] += imuM[6 * i + 3]; acc[1] += imuM[6 * i + 4]; acc[2] += imuM[6 * i + 5]; }
+  acc[0] /= (double)n; acc[1] /= (double)n; acc[2] /= (double)n;
+  const double an = std::sqrt(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2]);
+  const double e[3] = {acc[0] / an, acc[1] / an, acc[2] / an};
+  double c[3] = {0.0 * e[2] - 1.0 * e[1], 1.0 * e[0] - 0.0 * e[2], 0.0};
+  const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  if (cn > 0) { c[0] /= cn; c[1] /= cn; c[2] /= cn; }
+  const double angle = std::acos(e[2]);
+  const double delta[6] = {0, 0, 0, -c[0] * angle, -c[1] * angle, -c[2] * angle};
+  double To[7];
+  poseOplus(T, delta, To);
+  std::memcpy(T, To, sizeof(To));
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------ addStates (:98-411)
+int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, const double* T_SC, int nCam,
+                      const uint32_t* imuT, const double* imuM, int nImu, bool asKeyframe, const double* sonar,
+                      int nSonar, const double* depth, int nDepth, double firstDepth) {
+  if (nCam != (int)cameras_.size()) { lastError() = "addStates: T_SC count != number of cameras"; return -1; }
+  if (imus_.empty()) { lastError() = "addStates: no IMU added"; return -1; }
+  double T_WS[7], sb[9];
+  const bool first = states_.empty();
+  if (first) {
+    if (!initPoseFromImu(imuM, nImu, T_WS)) return 0;  // :110-113
+    if (!(numKeypoints > 10)) return 0;                 // :116-122
+    for (double& v : sb) v = 0;
+    for (int k = 0; k < 3; ++k) sb[6 + k] = imus_[0].a0[k];
+  } else {
+    const State& last = states_.rbegin()->second;
+    std::memcpy(T_WS, blocks_.at(last.pose.id).x, sizeof(T_WS));
+    std::memcpy(sb, blocks_.at(last.sb.at(0).id).x, sizeof(sb));
+    const int used = imuPropagation(imuT, imuM, nImu, imus_[0], T_WS, sb, last.stamp, stamp, nullptr, nullptr);
+    if (used < 1) return 0;  // :159-162
+  }
+  if (states_.count(frameId) || blocks_.count(frameId)) return 0;
+  State st;
+  st.id = frameId; st.stamp = stamp; st.isKeyframe = asKeyframe;
+  st.pose.id = frameId; st.pose.exists = true;
+  addBlock(frameId, B_POSE, T_WS);
+  const State* prev = first ? nullptr : &states_.rbegin()->second;
+  for (size_t i = 0; i < cameras_.size(); ++i) {  // :203-229
+    StateInfo info;
+    info.exists = true;
+    if ((extrinsics_[i].rel_t < 1e-12 || extrinsics_[i].rel_r < 1e-12) && !first) {
+      info.id = prev->ext.at(i).id;
+    } else {
+      info.id = newId();
+      addBlock(info.id, B_EXT, T_SC + 7 * i);
+    }
+    st.ext.push_back(info);
+  }
+  for (size_t i = 0; i < imus_.size(); ++i) {  // :232-246
+    StateInfo info;
+    info.exists = true;
+    info.id = newId();
+    addBlock(info.id, B_SB, sb);
+    st.sb.push_back(info);
+  }
+  if (nDepth > 0) {  // :248-262
+    double mean_depth = 0.0;
+    for (int i = 0; i < nDepth; ++i) mean_depth += depth[i];
+    mean_depth = mean_depth / nDepth;
+    Factor f;
+    f.kind = F_DEPTH; f.nblk = 1; f.blocks[0] = frameId; f.m = 1;
+    f.meas[0] = mean_depth; f.meas[1] = firstDepth;
+    f.sqrtInfo[0] = std::sqrt(5.0);
+    addFactor(std::move(f));
+  }
+  if (nSonar > 0) {  // :265-316
+    const double range = sonar[2 * (nSonar - 1)], heading = sonar[2 * (nSonar - 1) + 1];
+    // sonar point in the world frame: T_WS * T_SSo * [range cos h, range sin h, 0] -- the same composition the
+    // device factor uses; evaluated here only to select the visual patch (a scan over cached landmark positions)
+    const Quat qws = qnormalized(Quat{T_WS[3], T_WS[4], T_WS[5], T_WS[6]});
+    const Mat3 Cws = quatToR(qws);
+    const Quat qso = qnormalized(Quat{T_SSo_[3], T_SSo_[4], T_SSo_[5], T_SSo_[6]});
+    const Vec3 rso = rotate(Cws, Vec3{T_SSo_[0], T_SSo_[1], T_SSo_[2]});
+    const Mat3 Cwso = quatToR(qnormalized(qmul(qws, qso)));
+    const Vec3 pp = rotate(Cwso, Vec3{range * std::cos(heading), range * std::sin(heading), 0.0});
+    const double sl[3] = {pp.x + rso.x + T_WS[0], pp.y + rso.y + T_WS[1], pp.z + rso.z + T_WS[2]};
+    double mean[3] = {0, 0, 0};
+    size_t cnt = 0;
+    double vl[3] = {0, 0, 0};
+    for (auto rit = landmarks_.rbegin(); rit != landmarks_.rend(); ++rit) {
+      const double* pt = rit->second.hp;
+      if (std::fabs(pt[3]) > 1.0e-8) { vl[0] = pt[0] / pt[3]; vl[1] = pt[1] / pt[3]; vl[2] = pt[2] / pt[3]; }
+      if (std::fabs(sl[0] - vl[0]) < 0.1 && std::fabs(sl[1] - vl[1]) < 0.1 && std::fabs(sl[2] - vl[2]) < 0.1) {
+        mean[0] += vl[0]; mean[1] += vl[1]; mean[2] += vl[2];
+        ++cnt;
+      }
+    }
+    if (cnt > 0) {
+      Factor f;
+      f.kind = F_SONAR; f.nblk = 1; f.blocks[0] = frameId; f.m = 1;
+      f.meas[0] = range; f.meas[1] = heading;
+      f.meas[2] = mean[0] / cnt; f.meas[3] = mean[1] / cnt; f.meas[4] = mean[2] / cnt;
+      std::memcpy(f.aux, T_SSo_, sizeof(T_SSo_));
+      f.sqrtInfo[0] = std::sqrt(1.0);
+      addFactor(std::move(f));
+    }
+  }
+  if (first) {
+    {  // pose prior (:319-327)
+      double information[36] = {0};
+      information[35] = 1.0e8; information[0] = 1.0e8; information[7] = 1.0e8; information[14] = 1.0e8;
+      Factor f;
+      f.kind = F_POSE_PRIOR; f.nblk = 1; f.blocks[0] = frameId; f.m = 6;
+      std::memcpy(f.meas, T_WS, 7 * sizeof(double));
+      sqrtInformationUpper(information, 6, f.sqrtInfo);
+      addFactor(std::move(f));
+    }
+    for (size_t i = 0; i < cameras_.size(); ++i) {  // :330-350
+      const double tv = extrinsics_[i].abs_t * extrinsics_[i].abs_t, rv = extrinsics_[i].abs_r * extrinsics_[i].abs_r;
+      if (tv > 1.0e-16 && rv > 1.0e-16) {
+        double information[36] = {0};
+        for (int k = 0; k < 3; ++k) { information[k * 7] = 1.0 * 1.0 / tv; information[(k + 3) * 7] = 1.0 * 1.0 / rv; }
+        Factor f;
+        f.kind = F_POSE_PRIOR; f.nblk = 1; f.blocks[0] = st.ext[i].id; f.m = 6;
+        std::memcpy(f.meas, T_SC + 7 * i, 7 * sizeof(double));
+        sqrtInformationUpper(information, 6, f.sqrtInfo);
+        addFactor(std::move(f));
+      } else {
+        blocks_.at(st.ext[i].id).fixed = true;
+      }
+    }
+    for (size_t i = 0; i < imus_.size(); ++i) {  // :351-364
+      const double sbg = imus_[0].sigma_bg, sba = imus_[0].sigma_ba;
+      double information[81] = {0};
+      for (int k = 0; k < 3; ++k) {
+        information[k * 10] = 1.0 * 1.0 / 1.0;
+        information[(k + 3) * 10] = 1.0 * 1.0 / (sbg * sbg);
+        information[(k + 6) * 10] = 1.0 * 1.0 / (sba * sba);
+      }
+      Factor f;
+      f.kind = F_SB_PRIOR; f.nblk = 1; f.blocks[0] = st.sb[i].id; f.m = 9;
+      std::memcpy(f.meas, sb, sizeof(sb));
+      sqrtInformationUpper(information, 9, f.sqrtInfo);
+      addFactor(std::move(f));
+    }
+  } else {
+    for (size_t i = 0; i < imus_.size(); ++i) {  // :368-382
+      Factor f;
+      f.kind = F_IMU; f.nblk = 4; f.m = 15;
+      f.blocks[0] = prev->id; f.blocks[1] = prev->sb.at(i).id; f.blocks[2] = st.id; f.blocks[3] = st.sb[i].id;
+      f.imuT.assign(imuT, imuT + 2 * (size_t)nImu);
+      f.imuMeas.assign(imuM, imuM + 6 * (size_t)nImu);
+      std::memset(&f.imu, 0, sizeof(f.imu));
+      f.imu.sampleCount = nImu;
+      f.imu.t0[0] = prev->stamp.sec; f.imu.t0[1] = prev->stamp.nsec;
+      f.imu.t1[0] = stamp.sec; f.imu.t1[1] = stamp.nsec;
+      f.imu.par = imus_[i];
+      f.imu.redo = 1;
+      f.imu.Delta_q[3] = 1.0;
+      addFactor(std::move(f));
+    }
+    for (size_t i = 0; i < cameras_.size(); ++i) {  // :385-404
+      if (prev->ext.at(i).id != st.ext[i].id) {
+        const double dt = dtSecHost(stamp, prev->stamp);
+        const double tv = extrinsics_[i].rel_t * extrinsics_[i].rel_t * dt;
+        const double rv = extrinsics_[i].rel_r * extrinsics_[i].rel_r * dt;
+        double information[36] = {0};
+        for (int k = 0; k < 3; ++k) { information[k * 7] = 1.0 * 1.0 / tv; information[(k + 3) * 7] = 1.0 * 1.0 / rv; }
+        Factor f;
+        f.kind = F_RELPOSE; f.nblk = 2; f.blocks[0] = prev->ext.at(i).id; f.blocks[1] = st.ext[i].id; f.m = 6;
+        sqrtInformationUpper(information, 6, f.sqrtInfo);
+        addFactor(std::move(f));
+      }
+    }
+  }
+  states_[frameId] = st;
+  return 1;
+}
+
+int Window::addLandmark(uint64_t id, const double* hp) {  // :414-429
+  if (landmarks_.count(id) || blocks_.count(id)) return 0;
+  Landmark lm;
+  lm.id = id;
+  std::memcpy(lm.hp, hp, sizeof(lm.hp));
+  lm.quality = 0.0;
+  double dist = std::numeric_limits<double>::max();
+  if (std::fabs(hp[3]) > 1.0e-8) {
+    const double e[3] = {hp[0] / hp[3], hp[1] / hp[3], hp[2] / hp[3]};
+    dist = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  }
+  lm.distance = dist;
+  landmarks_[id] = lm;
+  return 1;
+}
+
+uint64_t Window::addObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint64_t kp, const double* uv,
+                                double size) {  // implementation/Estimator.hpp:47-87
+  auto lit = landmarks_.find(lmId);
+  auto sit = states_.find(poseId);
+  if (lit == landmarks_.end() || sit == states_.end() || cam >= cameras_.size()) return 0;
+  for (const Observation& o : lit->second.obs)
+    if (o.poseId == poseId && (uint64_t)o.cam == cam && o.kp == kp) return 0;  // duplicate -> NULL
+  Observation o;
+  o.resId = nextResId_++;
+  o.poseId = poseId;
+  o.extId = sit->second.ext.at(cam).id;
+  o.cam = (int)cam;
+  o.kp = kp;
+  o.uv[0] = uv[0]; o.uv[1] = uv[1];
+  o.size = size;
+  lit->second.obs.push_back(o);
+  blocks_.at(o.poseId).residuals.push_back(o.resId);
+  blocks_.at(o.extId).residuals.push_back(o.resId);
+  obsRes2Lm_[o.resId] = lmId;
+  return o.resId;
+}
+int Window::removeObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint64_t kp) {  // :452-474
+  auto lit = landmarks_.find(lmId);
+  if (lit == landmarks_.end()) return 0;
+  for (size_t i = 0; i < lit->second.obs.size(); ++i) {
+    const Observation& o = lit->second.obs[i];
+    if (o.poseId == poseId && (uint64_t)o.cam == cam && o.kp == kp) { removeObsRecord(lit->second, i); return 1; }
+  }
+  return 0;
+}
+int Window::removeObservationById(uint64_t resId) {  // :432-449
+  auto it = obsRes2Lm_.find(resId);
+  if (it == obsRes2Lm_.end()) return 0;
+  Landmark& lm = landmarks_.at(it->second);
+  for (size_t i = 0; i < lm.obs.size(); ++i)
+    if (lm.obs[i].resId == resId) { removeObsRecord(lm, i); return 1; }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ getters / setters
+int Window::get_T_WS(uint64_t id, double* T) const {
+  auto it = states_.find(id);
+  if (it == states_.end() || !it->second.pose.exists) return 0;
+  std::memcpy(T, blocks_.at(it->second.pose.id).x, 7 * sizeof(double));
+  return 1;
+}
+int Window::getSpeedAndBias(uint64_t id, size_t imu, double* sb) const {
+  auto it = states_.find(id);
+  if (it == states_.end() || imu >= it->second.sb.size() || !it->second.sb[imu].exists) return 0;
+  std::memcpy(sb, blocks_.at(it->second.sb[imu].id).x, 9 * sizeof(double));
+  return 1;
+}
+int Window::getCameraSensorStates(uint64_t id, size_t cam, double* T) const {
+  auto it = states_.find(id);
+  if (it == states_.end() || cam >= it->second.ext.size() || !it->second.ext[cam].exists) return 0;
+  std::memcpy(T, blocks_.at(it->second.ext[cam].id).x, 7 * sizeof(double));
+  return 1;
+}
+const Landmark* Window::landmark(uint64_t id) const {
+  auto it = landmarks_.find(id);
+  return it == landmarks_.end() ? nullptr : &it->second;
+}
+static void normalisedPose(const double* T, double* out) {  // PoseParameterBlock::setEstimate keeps a Transformation
+  const Quat q = qnormalized(Quat{T[3], T[4], T[5], T[6]});
+  out[0] = T[0]; out[1] = T[1]; out[2] = T[2];
+  out[3] = q.x; out[4] = q.y; out[5] = q.z; out[6] = q.w;
+}
+int Window::set_T_WS(uint64_t id, const double* T) {
+  auto it = states_.find(id);
+  if (it == states_.end() || !it->second.pose.exists) return 0;
+  normalisedPose(T, blocks_.at(it->second.pose.id).x);
+  return 1;
+}
+int Window::setSpeedAndBias(uint64_t id, size_t imu, const double* sb) {
+  auto it = states_.find(id);
+  if (it == states_.end() || imu >= it->second.sb.size() || !it->second.sb[imu].exists) return 0;
+  std::memcpy(blocks_.at(it->second.sb[imu].id).x, sb, 9 * sizeof(double));
+  return 1;
+}
+int Window::setCameraSensorStates(uint64_t id, size_t cam, const double* T) {
+  auto it = states_.find(id);
+  if (it == states_.end() || cam >= it->second.ext.size() || !it->second.ext[cam].exists) return 0;
+  normalisedPose(T, blocks_.at(it->second.ext[cam].id).x);
+  return 1;
+}
+int Window::setLandmark(uint64_t id, const double* hp) {
+  auto it = landmarks_.find(id);
+  if (it == landmarks_.end()) return 0;
+  std::memcpy(it->second.hp, hp, 4 * sizeof(double));
+  return 1;
+}
+uint64_t Window::currentKeyframeId() const {
+  for (auto rit = states_.rbegin(); rit != states_.rend(); ++rit)
+    if (rit->second.isKeyframe) return rit->first;
+  return 0;
+}
+uint64_t Window::frameIdByAge(size_t age) const {
+  auto rit = states_.rbegin();
+  for (size_t i = 0; i < age; ++i) { ++rit; if (rit == states_.rend()) return 0; }
+  return rit == states_.rend() ? 0 : rit->first;
+}
+bool Window::isInImuWindow(uint64_t id) const {
+  auto it = states_.find(id);
+  if (it == states_.end() || it->second.sb.empty()) return false;
+  return it->second.sb[0].exists;
+}
+int Window::describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) const {
+  for (const auto& kv : states_) {
+    const State& s = kv.second;
+    if (s.pose.id == id) { *frame = s.id; *kind = 0; *index = 0; return 1; }
+    for (size_t i = 0; i < s.ext.size(); ++i) if (s.ext[i].id == id) { *frame = s.id; *kind = 1; *index = (int)i; return 1; }
+    for (size_t i = 0; i < s.sb.size(); ++i) if (s.sb[i].id == id) { *frame = s.id; *kind = 2; *index = (int)i; return 1; }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ pack: host graph -> HBM
+template <class T>
+static void upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
+  buf.reserve(std::max<size_t>(host.size(), 1));
+  if (!host.empty()) HIP_OK(hipMemcpyAsync(buf.p, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice, s));
+}
+
+void Window::pack() {
+  poseIds_.clear(); extIds_.clear(); sbIds_.clear(); lmIds_.clear(); factorIds_.clear();
+  poseSlot_.clear(); extSlot_.clear(); sbSlot_.clear(); lmSlot_.clear();
+  for (const auto& kv : states_) {
+    const State& s = kv.second;
+    if (s.pose.exists) { poseSlot_[s.pose.id] = (int)poseIds_.size(); poseIds_.push_back(s.pose.id); }
+    for (const StateInfo& e : s.ext)
+      if (e.exists && !extSlot_.count(e.id)) { extSlot_[e.id] = (int)extIds_.size(); extIds_.push_back(e.id); }
+    for (const StateInfo& b : s.sb)
+      if (b.exists) { sbSlot_[b.id] = (int)sbIds_.size(); sbIds_.push_back(b.id); }
+  }
+  if (poseIds_.size() > 4095 || extIds_.size() > 4095) throw std::runtime_error("window too wide for the packed index");
+  std::vector<double> hPose(poseIds_.size() * 7), hExt(std::max<size_t>(extIds_.size(), 1) * 7), hSb(sbIds_.size() * 9);
+  std::vector<int> hPoseOff(poseIds_.size()), hExtOff(std::max<size_t>(extIds_.size(), 1), -1), hSbOff(sbIds_.size());
+  redBlockIds_.clear(); redBlockOff_.clear();
+  int d = 0;
+  bool anyExtVar = false;
+  for (size_t i = 0; i < poseIds_.size(); ++i) {
+    const Block& b = blocks_.at(poseIds_[i]);
+    std::memcpy(&hPose[7 * i], b.x, 7 * sizeof(double));
+    if (b.fixed) hPoseOff[i] = -1;
+    else { hPoseOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 6; }
+  }
+  for (size_t i = 0; i < extIds_.size(); ++i) {
+    const Block& b = blocks_.at(extIds_[i]);
+    std::memcpy(&hExt[7 * i], b.x, 7 * sizeof(double));
+    if (b.fixed) hExtOff[i] = -1;
+    else { hExtOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 6; anyExtVar = true; }
+  }
+  const int dC = d;
+  for (size_t i = 0; i < sbIds_.size(); ++i) {
+    const Block& b = blocks_.at(sbIds_[i]);
+    std::memcpy(&hSb[9 * i], b.x, 9 * sizeof(double));
+    if (b.fixed) hSbOff[i] = -1;
+    else { hSbOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 9; }
+  }
+  // landmarks + observations (landmark-major)
+  std::vector<double> hLm, hUv, hW;
+  std::vector<int> hLmPtr, hObsLm;
+  std::vector<uint32_t> hIdx;
+  obsResIds_.clear(); obsLmIds_.clear(); obsPoseIds_.clear(); obsCam_.clear();
+  hLmPtr.push_back(0);
+  for (const auto& kv : landmarks_) {
+    const Landmark& lm = kv.second;
+    if (lm.obs.empty()) continue;
+    const int slot = (int)lmIds_.size();
+    lmSlot_[lm.id] = slot;
+    lmIds_.push_back(lm.id);
+    hLm.insert(hLm.end(), lm.hp, lm.hp + 4);
+    for (const Observation& o : lm.obs) {
+      hUv.push_back(o.uv[0]); hUv.push_back(o.uv[1]);
+      // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
+      hW.push_back(std::sqrt(64.0 / (o.size * o.size)));
+      hIdx.push_back(packObs(poseSlot_.at(o.poseId), extSlot_.at(o.extId), o.cam));
+      hObsLm.push_back(slot);
+      obsResIds_.push_back(o.resId); obsLmIds_.push_back(lm.id); obsPoseIds_.push_back(o.poseId); obsCam_.push_back(o.cam);
+    }
+    hLmPtr.push_back((int)hObsLm.size());
+  }
+  const int L = (int)lmIds_.size(), N = (int)hObsLm.size();
+  // factors
+  std::vector<DevFactor> hFac;
+  std::vector<DevImu> hImu;
+  std::vector<uint32_t> hImuT;
+  std::vector<double> hImuM;
+  auto blkKindSlot = [&](uint64_t id, int& kind, int& slot) {
+    const Block& b = blocks_.at(id);
+    kind = b.kind;
+    slot = (b.kind == B_POSE) ? poseSlot_.at(id) : (b.kind == B_EXT ? extSlot_.at(id) : sbSlot_.at(id));
+  };
+  for (auto& kv : factors_) {
+    Factor& f = kv.second;
+    DevFactor df;
+    std::memset(&df, 0, sizeof(df));
+    df.kind = f.kind; df.nblk = f.nblk; df.m = f.m; df.imuIndex = -1;
+    for (int b = 0; b < f.nblk; ++b) blkKindSlot(f.blocks[b], df.blkKind[b], df.blkSlot[b]);
+    std::memcpy(df.meas, f.meas, sizeof(df.meas));
+    std::memcpy(df.aux, f.aux, sizeof(df.aux));
+    std::memcpy(df.sqrtInfo, f.sqrtInfo, sizeof(df.sqrtInfo));
+    if (f.kind == F_IMU) {
+      df.imuIndex = (int)hImu.size();
+      f.imu.sampleStart = (int)(hImuT.size() / 2);
+      f.imu.sampleCount = (int)(f.imuT.size() / 2);
+      hImu.push_back(f.imu);
+      hImuT.insert(hImuT.end(), f.imuT.begin(), f.imuT.end());
+      hImuM.insert(hImuM.end(), f.imuMeas.begin(), f.imuMeas.end());
+    }
+    factorIds_.push_back(f.id);
+    hFac.push_back(df);
+  }
+  const int F = (int)hFac.size();
+  // prior
+  std::vector<PriorBlock> hPb;
+  int priorM = 0;
+  if (hasPrior_) {
+    priorM = priorM_;
+    for (const PriorBlockHost& pb : priorBlocks_) {
+      PriorBlock q;
+      std::memset(&q, 0, sizeof(q));
+      q.kind = pb.kind;
+      q.slot = (pb.kind == B_POSE) ? poseSlot_.at(pb.id) : (pb.kind == B_EXT ? extSlot_.at(pb.id) : sbSlot_.at(pb.id));
+      q.ord = pb.ord; q.mdim = pb.mdim;
+      std::memcpy(q.lin, pb.lin, sizeof(q.lin));
+      hPb.push_back(q);
+    }
+  }
+  // ---- device allocation + upload
+  hipStream_t s = stream_;
+  upload(dPose_, hPose, s); upload(dExt_, hExt, s); upload(dSb_, hSb, s); upload(dLm_, hLm, s);
+  dPoseC_.reserve(std::max<size_t>(hPose.size(), 1)); dExtC_.reserve(std::max<size_t>(hExt.size(), 1));
+  dSbC_.reserve(std::max<size_t>(hSb.size(), 1)); dLmC_.reserve(std::max<size_t>(hLm.size(), 1));
+  upload(dPoseOff_, hPoseOff, s); upload(dExtOff_, hExtOff, s); upload(dSbOff_, hSbOff, s);
+  upload(dCams_, cameras_, s);
+  upload(dLmPtr_, hLmPtr, s); upload(dObsLm_, hObsLm, s); upload(dObsUv_, hUv, s); upload(dObsW_, hW, s);
+  upload(dObsIdx_, hIdx, s);
+  for (int k = 0; k < 2; ++k) { dLin_[k].reserve(std::max<size_t>((size_t)32 * N, 1)); dFacLin_[k].reserve(std::max(F, 1)); }
+  upload(dFactors_, hFac, s); upload(dImus_, hImu, s); upload(dImuT_, hImuT, s); upload(dImuM_, hImuM, s);
+  if (hasPrior_) {
+    upload(dPriorH_, priorHt_, s); upload(dPriorBp_, priorBp_, s); upload(dPriorBlk_, hPb, s);
+    dPriorScratch_.reserve((size_t)3 * priorM + 9 * hPb.size() + 16);
+  }
+  const int dpad = ((d + 15) / 16) * 16;
+  dS_.reserve(std::max<size_t>((size_t)d * d, 1));
+  dVec_.reserve((size_t)12 * std::max(d, 1) + 64);
+  dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
+  dChol_.reserve(std::max<size_t>((size_t)dpad * dpad, 1));
+  dPartial_.reserve((size_t)16 * 4096);
+  dScal_.reserve(1);
+  dQuality_.reserve(std::max(L, 1));
+  const size_t slabSize = (size_t)dC * dC + 3 * dC;
+  const bool useLds = slabSize * 8 + (size_t)4 * 64 * 34 * 8 <= 150 * 1024;
+  int nSlabs = 1;
+  if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
+  dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
+
+  DeviceProblem& p = prob_;
+  std::memset(&p, 0, sizeof(p));
+  p.nPose = (int)poseIds_.size(); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
+  p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
+  p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
+  p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
+  p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
+  p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
+  p.cams = dCams_.p;
+  p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
+  curSet_ = 0;
+  auto setLin = [&](int set, double*& r, double*& Jp, double*& Jl, double*& Je) {
+    double* base = dLin_[set].p;
+    r = base; Jp = base + (size_t)2 * N; Jl = base + (size_t)14 * N; Je = base + (size_t)20 * N;
+  };
+  setLin(0, p.rCur, p.JpCur, p.JlCur, p.JeCur);
+  setLin(1, p.rCand, p.JpCand, p.JlCand, p.JeCand);
+  p.factors = dFactors_.p; p.linCur = dFacLin_[0].p; p.linCand = dFacLin_[1].p;
+  p.imus = dImus_.p; p.imuT = dImuT_.p; p.imuMeas = dImuM_.p;
+  if (hasPrior_) {
+    p.priorH = dPriorH_.p; p.priorBp = dPriorBp_.p; p.priorC0 = priorC0_; p.priorBlk = dPriorBlk_.p;
+    p.priorDchi = dPriorScratch_.p; p.priorGrad = dPriorScratch_.p + priorM; p.priorMv = dPriorScratch_.p + 2 * priorM;
+    p.priorM3 = dPriorScratch_.p + 3 * priorM;
+    HIP_OK(hipMemsetAsync(dPriorScratch_.p, 0, sizeof(double) * (3 * (size_t)priorM + 9 * hPb.size()), s));
+  }
+  const int dd = std::max(d, 1);
+  p.S = dS_.p;
+  p.gRed = dVec_.p; p.gFull = dVec_.p + dd; p.hC = dVec_.p + 2 * dd; p.htilC = dVec_.p + 3 * dd;
+  p.scaleC = dVec_.p + 4 * dd; p.yC = dVec_.p + 5 * dd; p.deltaC = dVec_.p + 6 * dd; p.vC = dVec_.p + 7 * dd;
+  const size_t LL = std::max(L, 1);
+  p.Vinv = dLmVec_.p; p.bl = dLmVec_.p + 6 * LL; p.hL = dLmVec_.p + 9 * LL; p.scaleL = dLmVec_.p + 12 * LL;
+  p.yL = dLmVec_.p + 15 * LL; p.deltaL = dLmVec_.p + 18 * LL; p.vL = dLmVec_.p + 21 * LL;
+  p.slabs = dSlabs_.p; p.nSlabs = nSlabs;
+  p.cholL = dChol_.p;
+  p.scal = dScal_.p;
+  p.partial = dPartial_.p;
+  HIP_OK(hipMemsetAsync(dScal_.p, 0, sizeof(SolverScalars), s));
+  HIP_OK(hipMemsetAsync(dPartial_.p, 0, sizeof(double) * 16 * 4096, s));
+}
+
+void Window::downloadStates() {
+  hipStream_t s = stream_;
+  const DeviceProblem& p = prob_;
+  std::vector<double> hPose(poseIds_.size() * 7), hExt(std::max<size_t>(extIds_.size(), 1) * 7), hSb(sbIds_.size() * 9),
+      hLm((size_t)p.L * 4), hQ(p.L);
+  std::vector<DevImu> hImu(p.nImu);
+  if (p.L > 0) launchLandmarkQuality(p, dQuality_.p, s);
+  if (!hPose.empty()) HIP_OK(hipMemcpyAsync(hPose.data(), p.pose, sizeof(double) * hPose.size(), hipMemcpyDeviceToHost, s));
+  if (!extIds_.empty()) HIP_OK(hipMemcpyAsync(hExt.data(), p.ext, sizeof(double) * extIds_.size() * 7, hipMemcpyDeviceToHost, s));
+  if (!hSb.empty()) HIP_OK(hipMemcpyAsync(hSb.data(), p.sb, sizeof(double) * hSb.size(), hipMemcpyDeviceToHost, s));
+  if (p.L > 0) {
+    HIP_OK(hipMemcpyAsync(hLm.data(), p.lm, sizeof(double) * hLm.size(), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(hQ.data(), dQuality_.p, sizeof(double) * p.L, hipMemcpyDeviceToHost, s));
+  }
+  if (p.nImu > 0) HIP_OK(hipMemcpyAsync(hImu.data(), p.imus, sizeof(DevImu) * p.nImu, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < poseIds_.size(); ++i) std::memcpy(blocks_.at(poseIds_[i]).x, &hPose[7 * i], 7 * sizeof(double));
+  for (size_t i = 0; i < extIds_.size(); ++i) std::memcpy(blocks_.at(extIds_[i]).x, &hExt[7 * i], 7 * sizeof(double));
+  for (size_t i = 0; i < sbIds_.size(); ++i) std::memcpy(blocks_.at(sbIds_[i]).x, &hSb[9 * i], 9 * sizeof(double));
+  for (size_t i = 0; i < lmIds_.size(); ++i) {
+    Landmark& lm = landmarks_.at(lmIds_[i]);
+    std::memcpy(lm.hp, &hLm[4 * i], 4 * sizeof(double));
+    lm.quality = hQ[i];
+  }
+  // Estimator::optimize also sets quality of unobserved landmarks: getLhs yields H = 0 -> quality 0 (:910-913)
+  for (auto& kv : landmarks_)
+    if (kv.second.obs.empty()) kv.second.quality = 0.0;
+  int k = 0;
+  for (auto& kv : factors_)
+    if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+}
+
+void Window::evaluateAll(bool cand, hipStream_t s) {
+  launchEvalReproj(prob_, cand, true, s);
+  launchEvalFactors(prob_, cand, s);
+  launchEvalPrior(prob_, cand, s);
+  launchCost(prob_, s);
+}
+
+SolverScalars Window::readScalars() {
+  SolverScalars sc;
+  HIP_OK(hipMemcpyAsync(&sc, prob_.scal, sizeof(sc), hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  return sc;
+}
+
+// ------------------------------------------------------------------------------------------ trust-region loop
+// Ceres 2.2 TrustRegionMinimizer + DoglegStrategy(TRADITIONAL_DOGLEG) semantics with the options
+// Estimator::optimize sets (:878-890): Jacobi scaling, monotonic steps, min_relative_decrease 1e-3,
+// initial radius 1e4.  All linear algebra and all residual evaluation run on the device; the host only
+// takes the accept/reject decision from one SolverScalars read-back per iteration.
+void Window::solve(size_t numIter, bool verbose) {
+  const double tStart = nowSec();
+  DeviceProblem& p = prob_;
+  hipStream_t s = stream_;
+  summary_.iterations = 0; summary_.num_successful_steps = 0; summary_.termination = 1;
+  if (p.d + 3 * p.L == 0) { summary_.termination = 0; summary_.initial_cost = summary_.final_cost = 0; return; }
+  const int dpad = ((p.d + 15) / 16) * 16;
+  if ((size_t)(16 * 17 + (size_t)std::max(dpad, 16) * 17) * 8 > 160 * 1024)
+    throw std::runtime_error("reduced system too large for the single-workgroup solver (d > ~1100)");
+  evaluateAll(false, s);
+  SolverScalars sc = readScalars();
+  double x_cost = sc.cost;
+  summary_.initial_cost = x_cost;
+  double radius = 1e4;
+  const double min_mu = 1e-8, max_mu = 1.0, mu_increase = 10.0;
+  double mu = min_mu;
+  bool reuse = false, initScale = true;
+  int invalid = 0;
+  int iteration = 0;
+  double lastIterTime = 0;
+  auto swapSets = [&]() {
+    std::swap(p.pose, p.poseC); std::swap(p.ext, p.extC); std::swap(p.sb, p.sbC); std::swap(p.lm, p.lmC);
+    std::swap(p.rCur, p.rCand); std::swap(p.JpCur, p.JpCand); std::swap(p.JlCur, p.JlCand); std::swap(p.JeCur, p.JeCand);
+    std::swap(p.linCur, p.linCand);
+  };
+  auto finish = [&](int term) {
+    summary_.termination = term;
+    summary_.final_cost = x_cost;
+    summary_.iterations = iteration;
+  };
+  while (true) {
+    if (timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) { finish(2); break; }
+    if (iteration >= (int)numIter) { finish(1); break; }
+    if (radius <= 1e-32) { finish(0); break; }
+    const double tIter = nowSec();
+    ++iteration;
+    bool stepOk = true;
+    while (true) {
+      if (!reuse) {
+        launchBuildNormalEquations(p, mu, initScale, s);
+        launchSolveReduced(p, s);
+        launchDoglegPrepare(p, s);
+      }
+      launchDoglegStep(p, radius, s);
+      evaluateAll(true, s);
+      sc = readScalars();
+      if (!reuse && sc.cholFail) {
+        mu *= mu_increase;
+        if (mu < max_mu) continue;
+        stepOk = false;
+      }
+      break;
+    }
+    if (!reuse) { initScale = false; reuse = true; }
+    if (sc.gradMax <= gTol_) { --iteration; finish(0); break; }
+    const double model_cost_change = -(sc.jdDotR + 0.5 * sc.jdSq);
+    if (!stepOk || !(model_cost_change > 0.0)) {
+      if (++invalid >= 5) { finish(3); break; }
+      mu *= mu_increase;
+      reuse = false;
+      lastIterTime = nowSec() - tIter;
+      continue;
+    }
+    invalid = 0;
+    const double step_norm = std::sqrt(sc.stepNormSq), x_norm = std::sqrt(sc.xNormSq);
+    if (step_norm <= pTol_ * (x_norm + pTol_)) { finish(0); break; }
+    const double candidate_cost = sc.cost;
+    const double cost_change = x_cost - candidate_cost;
+    if (std::fabs(cost_change) <= fTol_ * x_cost) { finish(0); break; }
+    const double relative_decrease = cost_change / model_cost_change;
+    if (relative_decrease > 1e-3) {
+      swapSets();
+      x_cost = candidate_cost;
+      summary_.num_successful_steps++;
+      if (relative_decrease < 0.25) radius *= 0.5;
+      if (relative_decrease > 0.75) radius = std::max(radius, 3.0 * sc.doglegStepNorm);
+      radius = std::min(radius, 1e16);
+      mu = std::max(min_mu, 2.0 * mu / mu_increase);
+      reuse = false;
+    } else {
+      radius *= 0.5;
+      reuse = true;
+    }
+    if (verbose)
+      std::printf("[svin_ba] it %d cost %.9e rel_dec %.3e radius %.3e step %.3e\n", iteration, x_cost, relative_decrease,
+                  radius, step_norm);
+    lastIterTime = nowSec() - tIter;
+  }
+  summary_.total_time = nowSec() - tStart;
+}
+
+int Window::prepare() {
+  const double t0 = nowSec();
+  pack();
+  HIP_OK(hipStreamSynchronize(stream_));
+  summary_.upload_time = nowSec() - t0;
+  return 1;
+}
+int Window::solvePrepared(size_t numIter, bool verbose) {
+  maxIterationsOption_ = numIter;
+  const double t1 = nowSec();
+  solve(numIter, verbose);
+  HIP_OK(hipStreamSynchronize(stream_));
+  summary_.solve_time = nowSec() - t1;
+  return 1;
+}
+int Window::finish() {
+  const double t2 = nowSec();
+  downloadStates();
+  summary_.download_time = nowSec() - t2;
+  return 1;
+}
+int Window::optimize(size_t numIter, bool verbose) {
+  prepare();
+  solvePrepared(numIter, verbose);
+  return finish();
+}
+
+int Window::setOptimizationTimeLimit(double timeLimit, int minIter) {  // :932-951
+  if (hasCallback_) {
+    if (timeLimit < 0.0) { minIterations_ = (int)maxIterationsOption_; return 1; }
+    timeLimit_ = timeLimit; minIterations_ = minIter;
+    return 1;
+  } else if (timeLimit >= 0.0) {
+    hasCallback_ = true;
+    timeLimit_ = timeLimit; minIterations_ = minIter;
+    return 1;
+  }
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------ inspection hooks
+int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t* cam, int cap) {
+  pack();
+  HIP_OK(hipStreamSynchronize(stream_));
+  const int n = (int)obsResIds_.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (rid) rid[i] = obsResIds_[i];
+    if (lm) lm[i] = obsLmIds_[i];
+    if (pose) pose[i] = obsPoseIds_[i];
+    if (cam) cam[i] = obsCam_[i];
+  }
+  return n;
+}
+int Window::evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap) {
+  pack();
+  const DeviceProblem& p = prob_;
+  const int N = p.N;
+  if (N == 0) return 0;
+  // always materialise the extrinsics Jacobian for inspection
+  DeviceProblem q = p;
+  q.anyExtVariable = 1;
+  launchEvalReproj(q, false, robust, stream_);
+  std::vector<double> h((size_t)32 * N);
+  HIP_OK(hipMemcpyAsync(h.data(), dLin_[0].p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  const int n = std::min(N, cap);
+  for (int i = 0; i < n; ++i) {
+    if (r) { r[2 * i] = h[i]; r[2 * i + 1] = h[(size_t)N + i]; }
+    if (Jp) for (int k = 0; k < 12; ++k) Jp[12 * i + k] = h[(size_t)(2 + k) * N + i];
+    if (Jl) for (int k = 0; k < 6; ++k) Jl[6 * i + k] = h[(size_t)(14 + k) * N + i];
+    if (Je) for (int k = 0; k < 12; ++k) Je[12 * i + k] = h[(size_t)(20 + k) * N + i];
+  }
+  return N;
+}
+int Window::evalFactors(int32_t* kind, int32_t* m, int32_t* ncols, double* r, double* J, uint64_t* blocks,
+                        uint64_t* rids, int cap) {
+  pack();
+  const DeviceProblem& p = prob_;
+  if (p.F == 0) return 0;
+  launchEvalFactors(p, false, stream_);
+  std::vector<FactorLin> h(p.F);
+  std::vector<DevImu> hImu(p.nImu);
+  HIP_OK(hipMemcpyAsync(h.data(), p.linCur, sizeof(FactorLin) * p.F, hipMemcpyDeviceToHost, stream_));
+  if (p.nImu > 0) HIP_OK(hipMemcpyAsync(hImu.data(), p.imus, sizeof(DevImu) * p.nImu, hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  // evaluation may re-preintegrate: keep the state, exactly like ImuError's mutable members
+  int k = 0;
+  for (auto& kv : factors_)
+    if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+  int i = 0;
+  for (auto& kv : factors_) {
+    if (i >= cap) break;
+    const Factor& f = kv.second;
+    if (kind) kind[i] = f.kind;
+    if (rids) rids[i] = f.id;
+    if (m) m[i] = h[i].m;
+    if (ncols) ncols[i] = h[i].ncols;
+    if (r) std::memcpy(r + 15 * i, h[i].r, 15 * sizeof(double));
+    if (J) std::memcpy(J + 450 * i, h[i].J, 450 * sizeof(double));
+    if (blocks) for (int b = 0; b < 4; ++b) blocks[4 * i + b] = b < f.nblk ? f.blocks[b] : 0;
+    ++i;
+  }
+  return p.F;
+}
+int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks,
+                      int capD, double* cost) {
+  pack();
+  DeviceProblem& p = prob_;
+  if (p.d > capD) return -p.d;
+  evaluateAll(false, stream_);
+  launchBuildNormalEquations(p, mu, true, stream_);
+  SolverScalars sc = readScalars();
+  if (cost) *cost = sc.cost;
+  if (S) HIP_OK(hipMemcpy(S, p.S, sizeof(double) * (size_t)p.d * p.d, hipMemcpyDeviceToHost));
+  if (g) HIP_OK(hipMemcpy(g, p.gRed, sizeof(double) * p.d, hipMemcpyDeviceToHost));
+  if (nBlocks) *nBlocks = (int)redBlockIds_.size();
+  for (size_t i = 0; i < redBlockIds_.size(); ++i) {
+    if (blockIds) blockIds[i] = redBlockIds_[i];
+    if (blockOff) blockOff[i] = redBlockOff_[i];
+  }
+  // evaluation may have re-preintegrated IMU factors
+  std::vector<DevImu> hImu(p.nImu);
+  if (p.nImu > 0) {
+    HIP_OK(hipMemcpy(hImu.data(), p.imus, sizeof(DevImu) * p.nImu, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (auto& kv : factors_)
+      if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+  }
+  return p.d;
+}
+int Window::getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
+                     int32_t* nBlocks, int capM) {
+  if (!hasPrior_) return 0;
+  const int m = priorM_;
+  if (m > capM) return -m;
+  if (H) std::memcpy(H, priorH_.data(), sizeof(double) * m * m);
+  if (b0) std::memcpy(b0, priorB0_.data(), sizeof(double) * m);
+  if (J) std::memcpy(J, priorJ_.data(), sizeof(double) * m * m);
+  if (e0) std::memcpy(e0, priorE0_.data(), sizeof(double) * m);
+  if (nBlocks) *nBlocks = (int)priorBlocks_.size();
+  for (size_t i = 0; i < priorBlocks_.size(); ++i) {
+    if (ids) ids[i] = priorBlocks_[i].id;
+    if (ord) ord[i] = priorBlocks_[i].ord;
+    if (mdim) mdim[i] = priorBlocks_[i].mdim;
+  }
+  return m;
+}
+
+// ------------------------------------------------------------------------------------------ measurement hooks
+int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* bytes) {
+  pack();
+  const DeviceProblem& p = prob_;
+  const size_t N = (size_t)p.N, NB = N * copies;
+  if (N == 0) return 0;
+  // replicate the observation arrays; every replica reads its own copy and writes its own output lines
+  std::vector<double> hUv(2 * N), hW(N);
+  std::vector<uint32_t> hIdx(N);
+  std::vector<int> hLm(N);
+  HIP_OK(hipMemcpy(hUv.data(), p.obsUv, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(hW.data(), p.obsW, sizeof(double) * N, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(hIdx.data(), p.obsIdx, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(hLm.data(), p.obsLm, sizeof(int) * N, hipMemcpyDeviceToHost));
+  std::vector<double> hLmTab((size_t)4 * p.L);
+  HIP_OK(hipMemcpy(hLmTab.data(), p.lm, sizeof(double) * 4 * p.L, hipMemcpyDeviceToHost));
+  DevBuf<double> bUv, bW, bLm, bOut;
+  DevBuf<uint32_t> bIdx;
+  DevBuf<int> bObsLm;
+  bUv.reserve(2 * NB); bW.reserve(NB); bIdx.reserve(NB); bObsLm.reserve(NB); bLm.reserve((size_t)4 * p.L * copies);
+  const int rows = p.anyExtVariable ? 32 : 20;
+  bOut.reserve((size_t)rows * NB);
+  for (int c = 0; c < copies; ++c) {
+    std::vector<int> lmShift(N);
+    for (size_t i = 0; i < N; ++i) lmShift[i] = hLm[i] + c * p.L;
+    HIP_OK(hipMemcpy(bUv.p + 2 * N * c, hUv.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bW.p + N * c, hW.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bIdx.p + N * c, hIdx.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bObsLm.p + N * c, lmShift.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bLm.p + (size_t)4 * p.L * c, hLmTab.data(), sizeof(double) * 4 * p.L, hipMemcpyHostToDevice));
+  }
+  DeviceProblem q = p;
+  q.obsUv = bUv.p; q.obsW = bW.p; q.obsIdx = bIdx.p; q.obsLm = bObsLm.p; q.lm = bLm.p;
+  double* r = bOut.p;
+  double* Jp = r + 2 * NB;
+  double* Jl = Jp + 12 * NB;
+  double* Je = p.anyExtVariable ? Jl + 6 * NB : nullptr;
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) launchEvalReprojBatched(q, copies, r, Jp, Jl, Je, stream_);
+  HIP_OK(hipStreamSynchronize(stream_));
+  double total = 0;
+  for (int it = 0; it < iters; ++it) {
+    HIP_OK(hipEventRecord(e0, stream_));
+    launchEvalReprojBatched(q, copies, r, Jp, Jl, Je, stream_);
+    HIP_OK(hipEventRecord(e1, stream_));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    total += ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (meanMs) *meanMs = total / iters;
+  // algorithmic bytes per residual: read uv 16 + w 8 + packed index 4 + landmark index 4
+  // + landmark 32/obs-per-landmark; write r 16 + Jp 96 + Jl 48 (+ Je 96 when extrinsics are variable)
+  const double perRes = 16 + 8 + 4 + 4 + 32.0 * p.L / (double)N + 16 + 96 + 48 + (p.anyExtVariable ? 96 : 0);
+  if (bytes) *bytes = perRes * (double)NB;
+  return 1;
+}
+
+int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs) {
+  pack();
+  DeviceProblem& p = prob_;
+  hipStream_t s = stream_;
+  evaluateAll(false, s);
+  launchBuildNormalEquations(p, 1e-8, true, s);
+  launchSolveReduced(p, s);
+  HIP_OK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  auto timeIt = [&](auto fn) {
+    double tot = 0;
+    for (int i = 0; i < iters; ++i) {
+      HIP_OK(hipEventRecord(e0, s));
+      fn();
+      HIP_OK(hipEventRecord(e1, s));
+      HIP_OK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      tot += ms;
+    }
+    return tot / iters;
+  };
+  if (evalMs) *evalMs = timeIt([&]() { launchEvalReproj(p, false, true, s); });
+  if (buildMs) *buildMs = timeIt([&]() { launchBuildNormalEquations(p, 1e-8, false, s); });
+  if (solveMs) *solveMs = timeIt([&]() { launchSolveReduced(p, s); });
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 1;
+}
+
+}  // namespace svin

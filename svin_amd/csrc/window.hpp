@@ -1,0 +1,249 @@
+// svin_amd host core: the okvis::Estimator / okvis::ceres::Map mirror behind the C ABI.
+//
+// The host keeps the *graph* (states, landmark-major observation lists, small factors, the
+// marginalisation prior's bookkeeping) and the policy code; every floating-point operation of
+// the hot path (residuals, Jacobians, normal equations, Schur complement, solves, retraction,
+// landmark quality, IMU prediction, marginalisation algebra) runs in HIP kernels on the device
+// buffers described in kernels.hpp.  There is no CPU arithmetic fallback.
+//
+// Reference (relative to /root/reference/okvis_ros/okvis/okvis_ceres/): src/Estimator.cpp,
+// include/okvis/implementation/Estimator.hpp, src/Map.cpp, src/MarginalizationError.cpp.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+#include "kernels.hpp"
+
+namespace svin {
+
+struct TimeStamp {
+  uint32_t sec = 0, nsec = 0;
+};
+
+struct ExtrinsicsSigmas {
+  double abs_t = 0, abs_r = 0, rel_t = 0, rel_r = 0;
+};
+
+// a parameter block that is not a landmark
+struct Block {
+  uint64_t id = 0;
+  int kind = B_POSE;  // B_POSE / B_EXT / B_SB
+  bool fixed = false;
+  double x[9] = {0};
+  std::vector<uint64_t> residuals;  // ids of residual blocks touching it (insertion order)
+};
+
+struct Observation {
+  uint64_t resId = 0, poseId = 0, extId = 0;
+  int cam = 0;
+  uint64_t kp = 0;
+  double uv[2] = {0, 0};
+  double size = 1.0;
+};
+
+struct Landmark {
+  uint64_t id = 0;
+  double hp[4] = {0, 0, 0, 1};
+  double quality = 0, distance = 0;
+  std::vector<Observation> obs;  // insertion order
+};
+
+struct Factor {
+  uint64_t id = 0;
+  int kind = F_IMU;
+  int nblk = 0;
+  uint64_t blocks[4] = {0, 0, 0, 0};
+  int m = 0;
+  double meas[9] = {0};
+  double aux[8] = {0};
+  double sqrtInfo[81] = {0};
+  // IMU
+  std::vector<uint32_t> imuT;   // 2 per sample
+  std::vector<double> imuMeas;  // 6 per sample
+  DevImu imu;                   // persistent pre-integration state (synced back after each solve)
+};
+
+struct StateInfo { uint64_t id = 0; bool exists = false; };
+struct State {
+  uint64_t id = 0;
+  TimeStamp stamp;
+  bool isKeyframe = false;
+  StateInfo pose;
+  std::vector<StateInfo> ext;  // per camera
+  std::vector<StateInfo> sb;   // per imu
+};
+
+struct PriorBlockHost {
+  uint64_t id = 0;
+  int kind = B_POSE;
+  int ord = 0, mdim = 0, dim = 0;
+  double lin[9] = {0};
+};
+
+struct Summary {
+  double initial_cost = 0, final_cost = 0;
+  int iterations = 0, num_successful_steps = 0, termination = 0;
+  double total_time = 0, upload_time = 0, solve_time = 0, download_time = 0;
+};
+
+// growable device buffer
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipFree(p);
+    size_t c = cap ? cap : 64;
+    while (c < n) c *= 2;
+    if (hipMalloc(&p, c * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; throw std::runtime_error("hipMalloc failed"); }
+    cap = c;
+  }
+};
+
+class Window {
+ public:
+  explicit Window(int device);
+  ~Window();
+
+  uint64_t newId() { return ++idCounter_; }
+  int addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig);
+  int addImu(const ImuParams& p);
+  void setSonarExtrinsics(const double* T) { std::memcpy(T_SSo_, T, sizeof(T_SSo_)); }
+
+  int addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, const double* T_SC, int nCam,
+                const uint32_t* imuT, const double* imuM, int nImu, bool asKeyframe, const double* sonar, int nSonar,
+                const double* depth, int nDepth, double firstDepth);
+  int addLandmark(uint64_t id, const double* hp);
+  uint64_t addObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
+  int removeObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp);
+  int removeObservationById(uint64_t resId);
+  int optimize(size_t numIter, bool verbose);
+  int prepare();
+  int solvePrepared(size_t numIter, bool verbose);
+  int finish();
+  void invalidatePreintegration() { for (auto& kv : factors_) if (kv.second.kind == F_IMU) kv.second.imu.redo = 1; }
+  int setOptimizationTimeLimit(double timeLimit, int minIter);
+  int applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed);
+  int imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
+                     TimeStamp t0, TimeStamp t1, double* cov, double* jac);
+
+  // getters / setters
+  int get_T_WS(uint64_t id, double* T) const;
+  int getSpeedAndBias(uint64_t id, size_t imu, double* sb) const;
+  int getCameraSensorStates(uint64_t id, size_t cam, double* T) const;
+  const Landmark* landmark(uint64_t id) const;
+  int set_T_WS(uint64_t id, const double* T);
+  int setSpeedAndBias(uint64_t id, size_t imu, const double* sb);
+  int setCameraSensorStates(uint64_t id, size_t cam, const double* T);
+  int setLandmark(uint64_t id, const double* hp);
+  const std::map<uint64_t, State>& states() const { return states_; }
+  const std::map<uint64_t, Landmark>& landmarks() const { return landmarks_; }
+  uint64_t currentKeyframeId() const;
+  uint64_t frameIdByAge(size_t age) const;
+  bool isInImuWindow(uint64_t id) const;
+  const Summary& summary() const { return summary_; }
+  void setTolerances(double f, double g, double p) { fTol_ = f; gTol_ = g; pTol_ = p; }
+
+  // inspection hooks
+  int evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap);
+  int observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t* cam, int cap);
+  int evalFactors(int32_t* kind, int32_t* m, int32_t* ncols, double* r, double* J, uint64_t* blocks, uint64_t* rids,
+                  int cap);
+  int linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks, int capD,
+                double* cost);
+  int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
+               int32_t* nBlocks, int capM);
+  int describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) const;
+  int benchJacobianEval(int copies, int iters, double* meanMs, double* bytes);
+  int benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs);
+
+ private:
+  // graph helpers
+  Block& addBlock(uint64_t id, int kind, const double* x);
+  void removeBlock(uint64_t id);
+  uint64_t addFactor(Factor&& f);
+  void removeFactor(uint64_t id);
+  void removeObsRecord(Landmark& lm, size_t idx);
+  Block* findBlock(uint64_t id);
+  const Block* findBlock(uint64_t id) const;
+
+  // device side
+  void pack();                 // host graph -> device arrays (sets prob_)
+  void downloadStates();       // device tables -> host blocks / landmarks / imu states
+  void evaluateAll(bool cand, hipStream_t s);
+  void solve(size_t numIter, bool verbose);
+  SolverScalars readScalars();
+
+  // marginalisation (device algebra in marg.hip)
+  friend class Marginalizer;
+
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  uint64_t idCounter_ = 0;
+  std::vector<CameraModel> cameras_;
+  std::vector<ExtrinsicsSigmas> extrinsics_;
+  std::vector<ImuParams> imus_;
+  double T_SSo_[7] = {0, 0, 0, 0, 0, 0, 1};
+
+  std::map<uint64_t, State> states_;
+  std::map<uint64_t, Landmark> landmarks_;
+  std::unordered_map<uint64_t, Block> blocks_;
+  std::map<uint64_t, Factor> factors_;
+  std::unordered_map<uint64_t, uint64_t> obsRes2Lm_;  // reprojection residual id -> landmark id
+  uint64_t nextResId_ = 1;
+
+  // marginalisation prior (host bookkeeping + device matrices mirrored on the host for the C API)
+  bool hasPrior_ = false;
+  uint64_t priorResId_ = 0;
+  std::vector<PriorBlockHost> priorBlocks_;
+  std::vector<double> priorH_, priorB0_, priorJ_, priorE0_;  // H/b0 as marginalised; J,e0 from M3
+  std::vector<double> priorHt_, priorBp_;                    // H-space form used by the solver
+  double priorC0_ = 0;
+  int priorM_ = 0;
+
+  // solver options
+  double fTol_ = 1e-6, gTol_ = 1e-10, pTol_ = 1e-8;
+  double timeLimit_ = -1.0;
+  int minIterations_ = 0;
+  bool hasCallback_ = false;
+  size_t maxIterationsOption_ = 50;
+  Summary summary_;
+
+  // packing maps (valid after pack())
+  std::vector<uint64_t> poseIds_, extIds_, sbIds_, lmIds_, factorIds_;
+  std::unordered_map<uint64_t, int> poseSlot_, extSlot_, sbSlot_, lmSlot_;
+  std::vector<uint64_t> obsResIds_, obsLmIds_, obsPoseIds_;
+  std::vector<int32_t> obsCam_;
+  std::vector<uint64_t> redBlockIds_;
+  std::vector<int32_t> redBlockOff_;
+  DeviceProblem prob_;
+
+  // device buffers
+  DevBuf<double> dPose_, dExt_, dSb_, dLm_, dPoseC_, dExtC_, dSbC_, dLmC_;
+  DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_;
+  DevBuf<CameraModel> dCams_;
+  DevBuf<double> dObsUv_, dObsW_;
+  DevBuf<uint32_t> dObsIdx_;
+  DevBuf<double> dLin_[2];  // r(2N) Jp(12N) Jl(6N) Je(12N) each
+  DevBuf<DevFactor> dFactors_;
+  DevBuf<FactorLin> dFacLin_[2];
+  DevBuf<DevImu> dImus_;
+  DevBuf<uint32_t> dImuT_;
+  DevBuf<double> dImuM_;
+  DevBuf<double> dPriorH_, dPriorBp_, dPriorScratch_;
+  DevBuf<PriorBlock> dPriorBlk_;
+  DevBuf<double> dS_, dVec_, dLmVec_, dSlabs_, dChol_, dPartial_, dQuality_;
+  DevBuf<SolverScalars> dScal_;
+  int curSet_ = 0;
+};
+
+std::string& lastError();
+
+}  // namespace svin

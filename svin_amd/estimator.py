@@ -1,0 +1,386 @@
+"""Python mirror of ``okvis::Estimator`` over the C ABI of ``libsvin_ba.so``.
+
+Method names / argument meaning follow the reference interface
+(okvis_ceres/include/okvis/Estimator.hpp:81): ``addStates`` -> :meth:`add_states`,
+``addLandmark`` -> :meth:`add_landmark`, ``addObservation`` -> :meth:`add_observation`,
+``optimize``, ``applyMarginalizationStrategy`` -> :meth:`apply_marginalization`, getters/setters.
+Everything numerical happens inside the HIP library; this module only marshals arguments.
+The library is required: importing without it (or creating an estimator without a GPU) raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u64, u32, f64, i32 = C.c_uint64, C.c_uint32, C.c_double, C.c_int
+pd = C.POINTER(C.c_double)
+pu64 = C.POINTER(C.c_uint64)
+pi32 = C.POINTER(C.c_int32)
+
+
+class ImuParams(C.Structure):
+    _fields_ = [(n, f64) for n in ("a_max", "g_max", "sigma_g_c", "sigma_a_c", "sigma_bg", "sigma_ba", "sigma_gw_c",
+                                   "sigma_aw_c", "tau", "g")] + [("a0", f64 * 3)]
+
+
+class ImuSample(C.Structure):
+    _fields_ = [("sec", u32), ("nsec", u32), ("gyr", f64 * 3), ("acc", f64 * 3)]
+
+
+class LandmarkInfo(C.Structure):
+    _fields_ = [("point", f64 * 4), ("quality", f64), ("distance", f64), ("num_observations", C.c_int32),
+                ("initialized", C.c_int32)]
+
+
+class SummaryStruct(C.Structure):
+    _fields_ = [("initial_cost", f64), ("final_cost", f64), ("iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("termination", C.c_int32), ("total_time_s", f64), ("upload_time_s", f64), ("solve_time_s", f64),
+                ("download_time_s", f64)]
+
+
+IMU_SAMPLE_DTYPE = np.dtype([("sec", np.uint32), ("nsec", np.uint32), ("gyr", np.float64, 3), ("acc", np.float64, 3)],
+                            align=True)
+
+EXPORTS = [
+    "svin_ba_create", "svin_ba_destroy", "svin_ba_last_error", "svin_ba_new_id", "svin_ba_add_camera", "svin_ba_add_imu",
+    "svin_ba_set_sonar_extrinsics", "svin_ba_add_states", "svin_ba_add_landmark", "svin_ba_add_observation",
+    "svin_ba_remove_observation", "svin_ba_remove_observation_by_id", "svin_ba_optimize", "svin_ba_prepare",
+    "svin_ba_solve_prepared", "svin_ba_finish", "svin_ba_invalidate_preintegration",
+    "svin_ba_set_optimization_time_limit", "svin_ba_apply_marginalization_strategy", "svin_ba_get_summary",
+    "svin_ba_set_solver_tolerances", "svin_ba_get_T_WS", "svin_ba_get_speed_and_bias", "svin_ba_get_camera_sensor_states",
+    "svin_ba_get_landmark", "svin_ba_is_landmark_added", "svin_ba_set_T_WS", "svin_ba_set_speed_and_bias",
+    "svin_ba_set_camera_sensor_states", "svin_ba_set_landmark", "svin_ba_num_frames", "svin_ba_num_landmarks",
+    "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
+    "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
+    "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
+    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_kernel_times",
+]
+
+
+def library_path():
+    return os.path.join(_HERE, "libsvin_ba.so")
+
+
+def load_library():
+    """Load ``libsvin_ba.so`` (built in-tree by ``__graft_entry__.build()``); raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libsvin_ba.so is missing: run __graft_entry__.build() (there is no fallback path)")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(path)
+    vp = C.c_void_p
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+    sig("svin_ba_create", vp, i32)
+    sig("svin_ba_destroy", None, vp)
+    sig("svin_ba_last_error", C.c_char_p)
+    sig("svin_ba_new_id", u64, vp)
+    sig("svin_ba_add_camera", i32, vp, i32, pd, pd, i32, i32, i32, pd)
+    sig("svin_ba_add_imu", i32, vp, C.POINTER(ImuParams))
+    sig("svin_ba_set_sonar_extrinsics", i32, vp, pd)
+    sig("svin_ba_add_states", i32, vp, u64, u32, u32, u64, pd, i32, C.c_void_p, i32, i32, pd, i32, pd, i32, f64)
+    sig("svin_ba_add_landmark", i32, vp, u64, pd)
+    sig("svin_ba_add_observation", u64, vp, u64, u64, u64, u64, pd, f64)
+    sig("svin_ba_remove_observation", i32, vp, u64, u64, u64, u64)
+    sig("svin_ba_remove_observation_by_id", i32, vp, u64)
+    sig("svin_ba_optimize", i32, vp, u64, u64, i32)
+    sig("svin_ba_prepare", i32, vp)
+    sig("svin_ba_solve_prepared", i32, vp, u64, i32)
+    sig("svin_ba_finish", i32, vp)
+    sig("svin_ba_invalidate_preintegration", i32, vp)
+    sig("svin_ba_set_optimization_time_limit", i32, vp, f64, i32)
+    sig("svin_ba_apply_marginalization_strategy", i32, vp, u64, u64, pu64, i32, C.POINTER(C.c_int))
+    sig("svin_ba_get_summary", i32, vp, C.POINTER(SummaryStruct))
+    sig("svin_ba_set_solver_tolerances", i32, vp, f64, f64, f64)
+    sig("svin_ba_get_T_WS", i32, vp, u64, pd)
+    sig("svin_ba_get_speed_and_bias", i32, vp, u64, u64, pd)
+    sig("svin_ba_get_camera_sensor_states", i32, vp, u64, u64, pd)
+    sig("svin_ba_get_landmark", i32, vp, u64, C.POINTER(LandmarkInfo))
+    sig("svin_ba_is_landmark_added", i32, vp, u64)
+    sig("svin_ba_set_T_WS", i32, vp, u64, pd)
+    sig("svin_ba_set_speed_and_bias", i32, vp, u64, u64, pd)
+    sig("svin_ba_set_camera_sensor_states", i32, vp, u64, u64, pd)
+    sig("svin_ba_set_landmark", i32, vp, u64, pd)
+    sig("svin_ba_num_frames", u64, vp)
+    sig("svin_ba_num_landmarks", u64, vp)
+    sig("svin_ba_current_keyframe_id", u64, vp)
+    sig("svin_ba_current_frame_id", u64, vp)
+    sig("svin_ba_frame_id_by_age", u64, vp, u64)
+    sig("svin_ba_is_keyframe", i32, vp, u64)
+    sig("svin_ba_is_in_imu_window", i32, vp, u64)
+    sig("svin_ba_frame_ids", i32, vp, pu64, i32)
+    sig("svin_ba_landmark_ids", i32, vp, pu64, i32)
+    sig("svin_ba_imu_propagation", i32, vp, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd)
+    sig("svin_ba_eval_reprojection", i32, vp, i32, pd, pd, pd, pd, i32)
+    sig("svin_ba_observation_ids", i32, vp, pu64, pu64, pu64, pi32, i32)
+    sig("svin_ba_eval_factors", i32, vp, pi32, pi32, pi32, pd, pd, pu64, pu64, i32)
+    sig("svin_ba_linearize", i32, vp, f64, pd, pd, pu64, pi32, pi32, i32, pd)
+    sig("svin_ba_get_prior", i32, vp, pd, pd, pd, pd, pu64, pi32, pi32, pi32, i32)
+    sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
+    sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
+    sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
+    _LIB = L
+    return L
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(pd)
+
+
+def _arr(x, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(x, dtype=dtype))
+
+
+def pack_imu(imu_t, imu_m):
+    imu_t = _arr(imu_t, np.uint32).reshape(-1, 2)
+    imu_m = _arr(imu_m).reshape(-1, 6)
+    s = np.zeros(len(imu_t), IMU_SAMPLE_DTYPE)
+    s["sec"], s["nsec"] = imu_t[:, 0], imu_t[:, 1]
+    s["gyr"], s["acc"] = imu_m[:, :3], imu_m[:, 3:]
+    assert s.itemsize == C.sizeof(ImuSample)
+    return s
+
+
+def make_imu_params(p):
+    q = ImuParams()
+    for k in ("a_max", "g_max", "sigma_g_c", "sigma_a_c", "sigma_bg", "sigma_ba", "sigma_gw_c", "sigma_aw_c", "tau", "g"):
+        setattr(q, k, float(p[k]))
+    a0 = p.get("a0", [0.0, 0.0, 0.0])
+    q.a0[0], q.a0[1], q.a0[2] = float(a0[0]), float(a0[1]), float(a0[2])
+    return q
+
+
+class Estimator:
+    """MI355X-native drop-in for ``okvis::Estimator`` (hot path only)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = self.L.svin_ba_create(device)
+        if not h:
+            raise RuntimeError("svin_ba_create failed: " + self.L.svin_ba_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.svin_ba_destroy(self.h)
+            self.h = None
+
+    def _check(self, r, what):
+        if r < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, r, self.L.svin_ba_last_error().decode()))
+        return r
+
+    # -- construction ---------------------------------------------------------------------------
+    def new_id(self):
+        return int(self.L.svin_ba_new_id(self.h))
+
+    def add_camera(self, model, intr, dist, w, h, sigmas):
+        intr, dist, sig = _arr(intr), _arr(dist), _arr(sigmas)
+        return self._check(self.L.svin_ba_add_camera(self.h, model, _d(intr), _d(dist) if len(dist) else None, len(dist), w, h,
+                                                     _d(sig)), "add_camera")
+
+    def add_imu(self, params):
+        q = make_imu_params(params)
+        return self._check(self.L.svin_ba_add_imu(self.h, C.byref(q)), "add_imu")
+
+    def set_sonar_extrinsics(self, T):
+        T = _arr(T)
+        return self._check(self.L.svin_ba_set_sonar_extrinsics(self.h, _d(T)), "set_sonar_extrinsics")
+
+    def add_states(self, fid, stamp, num_keypoints, T_SC, imu_t, imu_m, as_keyframe, sonar=None, depth=None, first_depth=0.0):
+        T_SC = _arr(T_SC).reshape(-1, 7)
+        s = pack_imu(imu_t, imu_m)
+        sonar = _arr(sonar if sonar is not None else np.zeros((0, 2))).reshape(-1, 2)
+        depth = _arr(depth if depth is not None else np.zeros(0)).reshape(-1)
+        r = self.L.svin_ba_add_states(self.h, fid, stamp[0], stamp[1], num_keypoints, _d(T_SC), len(T_SC),
+                                      s.ctypes.data_as(C.c_void_p), len(s), 1 if as_keyframe else 0,
+                                      _d(sonar) if len(sonar) else None, len(sonar), _d(depth) if len(depth) else None,
+                                      len(depth), first_depth)
+        return bool(self._check(r, "add_states"))
+
+    def add_landmark(self, lid, hp):
+        hp = _arr(hp)
+        return bool(self._check(self.L.svin_ba_add_landmark(self.h, lid, _d(hp)), "add_landmark"))
+
+    def add_observation(self, lid, pose, cam, kp, uv, size):
+        uv = _arr(uv)
+        return int(self.L.svin_ba_add_observation(self.h, lid, pose, cam, kp, _d(uv), size))
+
+    def remove_observation(self, lid, pose, cam, kp):
+        return bool(self._check(self.L.svin_ba_remove_observation(self.h, lid, pose, cam, kp), "remove_observation"))
+
+    # -- hot path ---------------------------------------------------------------------------------
+    def optimize(self, num_iter, num_threads=1, verbose=False):
+        self._check(self.L.svin_ba_optimize(self.h, num_iter, num_threads, 1 if verbose else 0), "optimize")
+
+    def prepare(self):
+        self._check(self.L.svin_ba_prepare(self.h), "prepare")
+
+    def solve_prepared(self, num_iter, verbose=False):
+        self._check(self.L.svin_ba_solve_prepared(self.h, num_iter, 1 if verbose else 0), "solve_prepared")
+
+    def finish(self):
+        self._check(self.L.svin_ba_finish(self.h), "finish")
+
+    def invalidate_preintegration(self):
+        self.L.svin_ba_invalidate_preintegration(self.h)
+
+    def set_time_limit(self, tl, min_iter):
+        return bool(self.L.svin_ba_set_optimization_time_limit(self.h, tl, min_iter))
+
+    def apply_marginalization(self, num_kf, num_imu):
+        ids = np.zeros(1 << 16, np.uint64)
+        n = C.c_int()
+        r = self._check(self.L.svin_ba_apply_marginalization_strategy(self.h, num_kf, num_imu, ids.ctypes.data_as(pu64),
+                                                                      len(ids), C.byref(n)), "apply_marginalization")
+        return bool(r), ids[:n.value].copy()
+
+    def summary(self):
+        s = SummaryStruct()
+        self.L.svin_ba_get_summary(self.h, C.byref(s))
+        return dict(initial_cost=s.initial_cost, final_cost=s.final_cost, iterations=s.iterations,
+                    successful=s.num_successful_steps, termination=s.termination, time=s.total_time_s,
+                    upload_time=s.upload_time_s, solve_time=s.solve_time_s, download_time=s.download_time_s)
+
+    def set_solver_options(self, function_tol=1e-6, gradient_tol=1e-10, parameter_tol=1e-8, jacobi_scaling=True):
+        assert jacobi_scaling, "the device solver always applies Ceres' default Jacobi scaling"
+        self.L.svin_ba_set_solver_tolerances(self.h, function_tol, gradient_tol, parameter_tol)
+
+    # -- getters / setters --------------------------------------------------------------------------
+    def get_T_WS(self, fid):
+        T = np.zeros(7)
+        return T if self.L.svin_ba_get_T_WS(self.h, fid, _d(T)) == 1 else None
+
+    def get_speed_and_bias(self, fid, imu=0):
+        sb = np.zeros(9)
+        return sb if self.L.svin_ba_get_speed_and_bias(self.h, fid, imu, _d(sb)) == 1 else None
+
+    def get_camera_sensor_states(self, fid, cam):
+        T = np.zeros(7)
+        return T if self.L.svin_ba_get_camera_sensor_states(self.h, fid, cam, _d(T)) == 1 else None
+
+    def get_landmark(self, lid):
+        info = LandmarkInfo()
+        if self.L.svin_ba_get_landmark(self.h, lid, C.byref(info)) != 1:
+            return None
+        return dict(point=np.array(info.point[:]), quality=info.quality, distance=info.distance,
+                    n_obs=info.num_observations)
+
+    def set_T_WS(self, fid, T):
+        T = _arr(T)
+        return self.L.svin_ba_set_T_WS(self.h, fid, _d(T)) == 1
+
+    def set_speed_and_bias(self, fid, sb, imu=0):
+        sb = _arr(sb)
+        return self.L.svin_ba_set_speed_and_bias(self.h, fid, imu, _d(sb)) == 1
+
+    def set_landmark(self, lid, hp):
+        hp = _arr(hp)
+        return self.L.svin_ba_set_landmark(self.h, lid, _d(hp)) == 1
+
+    def frame_ids(self):
+        ids = np.zeros(4096, np.uint64)
+        n = self.L.svin_ba_frame_ids(self.h, ids.ctypes.data_as(pu64), len(ids))
+        return [int(i) for i in ids[:n]]
+
+    def landmark_ids(self):
+        n = int(self.L.svin_ba_num_landmarks(self.h))
+        ids = np.zeros(max(n, 1), np.uint64)
+        self.L.svin_ba_landmark_ids(self.h, ids.ctypes.data_as(pu64), len(ids))
+        return [int(i) for i in ids[:n]]
+
+    def num_frames(self):
+        return int(self.L.svin_ba_num_frames(self.h))
+
+    def num_landmarks(self):
+        return int(self.L.svin_ba_num_landmarks(self.h))
+
+    def imu_propagation(self, imu_t, imu_m, params, T, sb, t0, t1, want_cov=False, want_jac=False):
+        s = pack_imu(imu_t, imu_m)
+        q = make_imu_params(params)
+        T, sb = _arr(T).copy(), _arr(sb).copy()
+        cov = np.zeros((15, 15)) if want_cov else None
+        jac = np.zeros((15, 15)) if want_jac else None
+        n = self._check(self.L.svin_ba_imu_propagation(self.h, s.ctypes.data_as(C.c_void_p), len(s), C.byref(q), _d(T), _d(sb),
+                                                       t0[0], t0[1], t1[0], t1[1], _d(cov), _d(jac)) + 1, "imu_propagation") - 1
+        return n, T, sb, cov, jac
+
+    # -- inspection hooks -----------------------------------------------------------------------------
+    def eval_reprojection(self, robust=False):
+        n = self._check(self.L.svin_ba_eval_reprojection(self.h, 1 if robust else 0, None, None, None, None, 0), "eval")
+        r, Jp, Jl, Je = np.zeros((n, 2)), np.zeros((n, 2, 6)), np.zeros((n, 2, 3)), np.zeros((n, 2, 6))
+        rid, lm, pose, cam = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.int32)
+        if n:
+            self.L.svin_ba_eval_reprojection(self.h, 1 if robust else 0, _d(r), _d(Jp), _d(Jl), _d(Je), n)
+            self.L.svin_ba_observation_ids(self.h, rid.ctypes.data_as(pu64), lm.ctypes.data_as(pu64),
+                                           pose.ctypes.data_as(pu64), cam.ctypes.data_as(pi32), n)
+        return dict(r=r, Jp=Jp, Jl=Jl, Je=Je, res_id=rid, lm_id=lm, pose_id=pose, cam=cam)
+
+    def eval_factors(self):
+        n = self._check(self.L.svin_ba_eval_factors(self.h, None, None, None, None, None, None, None, 0), "eval_factors")
+        kind, m, nc = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        r, J, blk, rid = np.zeros((n, 15)), np.zeros((n, 450)), np.zeros((n, 4), np.uint64), np.zeros(n, np.uint64)
+        if n:
+            self.L.svin_ba_eval_factors(self.h, kind.ctypes.data_as(pi32), m.ctypes.data_as(pi32), nc.ctypes.data_as(pi32),
+                                        _d(r), _d(J), blk.ctypes.data_as(pu64), rid.ctypes.data_as(pu64), n)
+        out = []
+        for i in range(n):
+            out.append(dict(kind=int(kind[i]), m=int(m[i]), res_id=int(rid[i]), r=r[i, :m[i]].copy(),
+                            J=J[i, :m[i] * nc[i]].reshape(m[i], nc[i]).copy(), blocks=[int(b) for b in blk[i] if b]))
+        return out
+
+    def linearize(self, mu=0.0, cap=4096):
+        S, g = np.zeros((cap, cap)), np.zeros(cap)
+        ids, off, nb, cost = np.zeros(cap, np.uint64), np.zeros(cap, np.int32), C.c_int32(), np.zeros(1)
+        # first query the size
+        d = self.L.svin_ba_linearize(self.h, mu, None, None, ids.ctypes.data_as(pu64), off.ctypes.data_as(pi32), C.byref(nb),
+                                     cap, _d(cost))
+        d = self._check(d, "linearize")
+        S, g = np.zeros((d, d)), np.zeros(d)
+        self.L.svin_ba_linearize(self.h, mu, _d(S), _d(g), ids.ctypes.data_as(pu64), off.ctypes.data_as(pi32), C.byref(nb), d,
+                                 _d(cost))
+        return dict(d=d, S=S, g=g, block_ids=ids[:nb.value].copy(), block_off=off[:nb.value].copy(), cost=float(cost[0]))
+
+    def describe_block(self, bid):
+        f, k, ix = C.c_uint64(), C.c_int32(), C.c_int32()
+        if self.L.svin_ba_describe_block(self.h, int(bid), C.byref(f), C.byref(k), C.byref(ix)) != 1:
+            return None
+        return int(f.value), int(k.value), int(ix.value)
+
+    def marg(self, cap=2048):
+        ids, ordr, md, nb = np.zeros(512, np.uint64), np.zeros(512, np.int32), np.zeros(512, np.int32), C.c_int32()
+        n = self.L.svin_ba_get_prior(self.h, None, None, None, None, ids.ctypes.data_as(pu64), ordr.ctypes.data_as(pi32),
+                                     md.ctypes.data_as(pi32), C.byref(nb), cap)
+        if n <= 0:
+            return None
+        H, b0, J, e0 = np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n)
+        self.L.svin_ba_get_prior(self.h, _d(H), _d(b0), _d(J), _d(e0), ids.ctypes.data_as(pu64), ordr.ctypes.data_as(pi32),
+                                 md.ctypes.data_as(pi32), C.byref(nb), n)
+        blocks = []
+        for i in range(nb.value):
+            d = self.describe_block(ids[i])
+            blocks.append(dict(id=int(ids[i]), ordering=int(ordr[i]), mdim=int(md[i]), frame=d[0] if d else None,
+                               kind=d[1] if d else None, index=d[2] if d else None))
+        return dict(n=n, H=H, b0=b0, J=J, e0=e0, blocks=blocks)
+
+    # -- measurement hooks -------------------------------------------------------------------------------
+    def bench_jacobian_eval(self, copies, iters):
+        ms, by = np.zeros(1), np.zeros(1)
+        self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
+        return float(ms[0]), float(by[0])
+
+    def bench_kernel_times(self, iters):
+        a, b, c = np.zeros(1), np.zeros(1), np.zeros(1)
+        self._check(self.L.svin_ba_bench_kernel_times(self.h, iters, _d(a), _d(b), _d(c)), "bench_kernel_times")
+        return float(a[0]), float(b[0]), float(c[0])
