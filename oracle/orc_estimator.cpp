@@ -178,6 +178,8 @@ bool Estimator::addLandmark(uint64_t id, const double* hp) {  // :414-429
 uint64_t Estimator::addObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx,
                                    const double* uv, double size) {  // implementation/Estimator.hpp:47-87
   auto kid = std::make_tuple(poseId, camIdx, keypointIdx);
+  // the reference asserts (debug only) that landmark and pose exist; a missing one is reported as 0 here
+  if (!landmarksMap_.count(landmarkId) || !statesMap_.count(poseId) || camIdx >= cameras_.size()) return 0;
   MapPoint& mp = landmarksMap_.at(landmarkId);
   if (mp.observations.count(kid)) return 0;
   double information[4] = {1, 0, 0, 1};

@@ -220,20 +220,16 @@ SVIN_HD void reprojEval(const CameraModel& cam, const double* T_WS, const double
   // weighted projection Jacobian (2x3), the homogeneous column of Jh is zero
   double Jw[6];
   for (int i = 0; i < 6; ++i) Jw[i] = w * J3[i];
-  // A = Jw * C_CS  (2x3),  C_CS = C_SC^T
+  // A = Jw * C_CS  (2x3),  C_CS = C_SC^T  ->  A[i][j] = sum_k Jw[i][k] C_SC[j][k]
   double A[6];
-  for (int i = 0; i < 2; ++i) {
-    A[i * 3 + 0] = Jw[i * 3] * C_SC.m[0] + Jw[i * 3 + 1] * C_SC.m[3] + Jw[i * 3 + 2] * C_SC.m[6];
-    A[i * 3 + 1] = Jw[i * 3] * C_SC.m[1] + Jw[i * 3 + 1] * C_SC.m[4] + Jw[i * 3 + 2] * C_SC.m[7];
-    A[i * 3 + 2] = Jw[i * 3] * C_SC.m[2] + Jw[i * 3 + 1] * C_SC.m[5] + Jw[i * 3 + 2] * C_SC.m[8];
-  }
-  // B = A * C_SW (2x3), C_SW = C_WS^T
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j)
+      A[i * 3 + j] = Jw[i * 3] * C_SC.m[j * 3] + Jw[i * 3 + 1] * C_SC.m[j * 3 + 1] + Jw[i * 3 + 2] * C_SC.m[j * 3 + 2];
+  // B = A * C_SW (2x3), C_SW = C_WS^T  ->  B[i][j] = sum_k A[i][k] C_WS[j][k]
   double B[6];
-  for (int i = 0; i < 2; ++i) {
-    B[i * 3 + 0] = A[i * 3] * C_WS.m[0] + A[i * 3 + 1] * C_WS.m[3] + A[i * 3 + 2] * C_WS.m[6];
-    B[i * 3 + 1] = A[i * 3] * C_WS.m[1] + A[i * 3 + 1] * C_WS.m[4] + A[i * 3 + 2] * C_WS.m[7];
-    B[i * 3 + 2] = A[i * 3] * C_WS.m[2] + A[i * 3 + 1] * C_WS.m[5] + A[i * 3 + 2] * C_WS.m[8];
-  }
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j)
+      B[i * 3 + j] = A[i * 3] * C_WS.m[j * 3] + A[i * 3 + 1] * C_WS.m[j * 3 + 1] + A[i * 3 + 2] * C_WS.m[j * 3 + 2];
   // pose: J = Jw T_CS [C_SW*hw | -C_SW [p]x],  p = hp_W.head - t_WS*hw = dW   (:153-162)
   for (int i = 0; i < 2; ++i) {
     const double b0 = B[i * 3], b1 = B[i * 3 + 1], b2 = B[i * 3 + 2];
