@@ -204,7 +204,7 @@ def run_sequence(est, spec, num_kf, num_imu, iters):
     return f, l, removed_all
 
 
-@pytest.mark.parametrize("rig", ["euroc", "test3"])
+@pytest.mark.parametrize("rig", ["euroc", "test4"])
 def test_marginalization_sequence_parity(gpu_lib, rig):
     """E6 / M1-M4: optimise + applyMarginalizationStrategy every frame, compare priors and states."""
     from svin_amd.estimator import Estimator
@@ -264,8 +264,11 @@ def test_config2_full_size_properties(gpu_lib):
     log("config2 pose difference vs oracle", worst, "max position error vs truth", err)
     assert worst < 1e-4
     assert err < 0.05
-    # idempotence: a second optimize from the converged point does not move the states
+    # idempotence: once converged, another optimize() does not move the states
+    gpu.set_solver_options(1e-10, 1e-12, 1e-10)
+    gpu.optimize(200)
+    assert gpu.summary()["termination"] == 0
     T_before = np.stack([gpu.get_T_WS(a) for a in fg])
-    gpu.optimize(3)
+    gpu.optimize(5)
     T_after = np.stack([gpu.get_T_WS(a) for a in fg])
-    assert np.max(np.abs(T_before - T_after)) < 1e-4
+    assert np.max(np.abs(T_before - T_after)) < 1e-6
