@@ -599,9 +599,11 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
         dpv[k] = T0.r[k] - T1.r[k] + s0[k] * Delta_t - 0.5 * gW[k] * Delta_t * Delta_t;
         dvv[k] = s0[k] - s1[k] - gW[k] * Delta_t;
       }
-      double F0[225], F1[225];
-      for (int k = 0; k < 225; ++k) { F0[k] = 0; F1[k] = 0; }
-      for (int k = 0; k < 15; ++k) { F0[k * 16] = 1.0; F1[k * 16] = -1.0; }
+      // F = [F0 | F1] (15 x 30, columns pose0(6) sb0(9) pose1(6) sb1(9)) is written straight into LDS
+      // (sh.F was zeroed by the whole workgroup above); F0 / F1 are views with leading dimension 30
+      double* F0 = sh.F;
+      double* F1 = sh.F + 15;
+      for (int k = 0; k < 15; ++k) { F0[k * 31] = 1.0; F1[k * 31] = -1.0; }
       // C_S0_W = C_WS_0^T
       double Ct[9];
       for (int a = 0; a < 3; ++a)
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       const Quat Dq = qmul(deltaQ(a3[0], a3[1], a3[2]), Quat{im.Delta_q[0], im.Delta_q[1], im.Delta_q[2], im.Delta_q[3]});
       auto setB = [](double* F, int r0, int c0, const double* B, double s) {
         for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) F[(r0 + a) * 15 + c0 + b] = s * B[a * 3 + b];
+          for (int b = 0; b < 3; ++b) F[(r0 + a) * 30 + c0 + b] = s * B[a * 3 + b];
       };
       double X[9], T9[9];
       setB(F0, 0, 0, Ct, 1.0);
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       quatOplusMat4(T0.q, Qo);
       mm4(Qp, Qo, Q44);
       for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) F0[(3 + a) * 15 + 3 + b] = Q44[a * 4 + b];
+        for (int b = 0; b < 3; ++b) F0[(3 + a) * 30 + 3 + b] = Q44[a * 4 + b];
       double Qo1[16], Qo2[16];
       quatOplusMat4(qmul(q1inv, T0.q), Qo1);
       quatOplusMat4(Dq, Qo2);
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       mm4(Qp2, Qo, Qt);
       mm4(Qt, Qp3, Q44);
       for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) F1[(3 + a) * 15 + 3 + b] = -Q44[a * 4 + b];
+        for (int b = 0; b < 3; ++b) F1[(3 + a) * 30 + 3 + b] = -Q44[a * 4 + b];
       setB(F1, 6, 6, Ct, -1.0);
       // error
       const Vec3 v1 = rotate(Mat3{{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}}, Vec3{dpv[0], dpv[1], dpv[2]});
@@ -655,16 +657,13 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       const double v1a[3] = {v1.x, v1.y, v1.z}, v2a[3] = {v2.x, v2.y, v2.z};
       for (int a = 0; a < 3; ++a) {
         double s1 = 0, s2 = 0;
-        for (int k = 0; k < 6; ++k) { s1 += F0[a * 15 + 9 + k] * Db[k]; s2 += F0[(6 + a) * 15 + 9 + k] * Db[k]; }
+        for (int k = 0; k < 6; ++k) { s1 += F0[a * 30 + 9 + k] * Db[k]; s2 += F0[(6 + a) * 30 + 9 + k] * Db[k]; }
         sh.e[a] = v1a[a] + im.acc_doubleintegral[a] + s1;
         sh.e[6 + a] = v2a[a] + im.acc_integral[a] + s2;
       }
       const Quat qd = qmul(Dq, qmul(q1inv, T0.q));
       sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
       for (int k = 0; k < 6; ++k) sh.e[9 + k] = s0[3 + k] - s1[3 + k];
-      // F = [F0 | F1] (15 x 30): columns pose0(6) sb0(9) pose1(6) sb1(9)
-      for (int a = 0; a < 15; ++a)
-        for (int c = 0; c < 15; ++c) { sh.F[a * 30 + c] = F0[a * 15 + c]; sh.F[a * 30 + 15 + c] = F1[a * 15 + c]; }
     }
   } else if (t == 0) {
     for (int k = 0; k < m * m; ++k) sh.W[k] = fac.sqrtInfo[k];
@@ -1136,24 +1135,47 @@ __global__ __launch_bounds__(256) void k_factors_accumulate(DeviceProblem p) {
 }
 
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
-__global__ void k_reduce_slabs(DeviceProblem p) {
+// 64 entries x 4 slab-quarters per 256-thread block; fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
+  __shared__ double part[256];
   const int dC = p.dC;
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const int total = dC * dC + 3 * dC;
+  size_t src = 0;
+  int rr = 0, cc = 0;
   if (idx < dC * dC) {
-    const int rr = idx / dC, cc = idx % dC;
+    rr = idx / dC; cc = idx % dC;
     const bool upper = (rr / 6) <= (cc / 6);
-    const size_t src = upper ? (size_t)rr * dC + cc : (size_t)cc * dC + rr;
-    double s = 0;
-    for (int k = 0; k < p.nSlabs; ++k) s += p.slabs[k * slabSize + src];
-    p.S[(size_t)rr * p.d + cc] += s;
-  } else if (idx < dC * dC + 3 * dC) {
-    const int v = idx - dC * dC;
-    double s = 0;
-    for (int k = 0; k < p.nSlabs; ++k) s += p.slabs[k * slabSize + (size_t)dC * dC + v];
-    if (v < dC) p.gRed[v] += s;
-    else if (v < 2 * dC) p.gFull[v - dC] += s;
-    else p.hC[v - 2 * dC] += s;
+    src = upper ? (size_t)rr * dC + cc : (size_t)cc * dC + rr;
+  } else if (idx < total) {
+    src = (size_t)idx;
+  }
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (idx < total) {
+    const int per = (p.nSlabs + 3) / 4;
+    const int k0 = q * per, k1 = min(p.nSlabs, k0 + per);
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      s0 += p.slabs[(size_t)k * slabSize + src];
+      s1 += p.slabs[(size_t)(k + 1) * slabSize + src];
+      s2 += p.slabs[(size_t)(k + 2) * slabSize + src];
+      s3 += p.slabs[(size_t)(k + 3) * slabSize + src];
+    }
+    for (; k < k1; ++k) s0 += p.slabs[(size_t)k * slabSize + src];
+  }
+  part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && idx < total) {
+    const double s = (part[e] + part[64 + e]) + (part[128 + e] + part[192 + e]);
+    if (idx < dC * dC) p.S[(size_t)rr * p.d + cc] += s;
+    else {
+      const int v = idx - dC * dC;
+      if (v < dC) p.gRed[v] += s;
+      else if (v < 2 * dC) p.gFull[v - dC] += s;
+      else p.hC[v - 2 * dC] += s;
+    }
   }
 }
 // camera-column metric, damping on the diagonal of S, gradient max-norm (cam part)
@@ -1168,13 +1190,17 @@ __global__ void k_finalize_diag(DeviceProblem p, double mu, int initScale) {
   p.S[(size_t)i * p.d + i] += mu * ht;
 }
 
+__global__ void k_zero_build(DeviceProblem p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = p.d;
+  if (i < d * d) p.S[i] = 0.0;
+  if (i < d) { p.gRed[i] = 0.0; p.gFull[i] = 0.0; p.hC[i] = 0.0; }
+  if (i == 0) p.scal->cholFail = 0;
+}
+
 void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
   const int d = p.d, dC = p.dC;
-  hipMemsetAsync(p.S, 0, sizeof(double) * (size_t)d * d, s);
-  hipMemsetAsync(p.gRed, 0, sizeof(double) * d, s);
-  hipMemsetAsync(p.gFull, 0, sizeof(double) * d, s);
-  hipMemsetAsync(p.hC, 0, sizeof(double) * d, s);
-  hipMemsetAsync(&p.scal->cholFail, 0, sizeof(int), s);
+  hipLaunchKernelGGL(k_zero_build, dim3((d * d + 255) / 256), dim3(256), 0, s, p);
   if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;
@@ -1214,7 +1240,7 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
     DeviceProblem q = p;
     if (!useLds) q.nSlabs = 1;
     const int n = dC * dC + 3 * dC;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 63) / 64), dim3(256), 0, s, q);
   }
   hipLaunchKernelGGL(k_finalize_diag, dim3((d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
 }
@@ -1225,10 +1251,34 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
 // A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)+4*reg).  The matrix is padded to a
 // multiple of 16 with an identity tail so that every tile is full.
 constexpr int kPanelLd = 17;
+
+// 16x16 in-LDS Cholesky executed by ONE wave (lanes 0..63), wave-level synchronisation only.
+__device__ __forceinline__ void cholDiag16(double* sD, int lane, int* failFlag) {
+  for (int k = 0; k < 16; ++k) {
+    waveSync();
+    const double x = sD[k * kPanelLd + k];
+    const bool ok = x > 0;
+    const double dk = ok ? sqrt(x) : 1.0;
+    if (!ok && lane == 0) atomicOr(failFlag, 2);
+    waveSync();
+    // column scale (lanes k..15 own rows) and diagonal
+    if (lane == k) sD[k * kPanelLd + k] = dk;
+    if (lane > k && lane < 16) sD[lane * kPanelLd + k] /= dk;
+    waveSync();
+    // trailing rank-1 update: 256 entries over 64 lanes
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
+      if (j > k && i >= j) sD[i * kPanelLd + j] -= sD[i * kPanelLd + k] * sD[j * kPanelLd + k];
+    }
+  }
+  waveSync();
+}
+
 __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) {
   extern __shared__ double smem[];
   double* sD = smem;                    // 16 x 17 diagonal block
-  double* sP = smem + 16 * kPanelLd;    // panel rows x 17
+  double* sP = smem + 16 * kPanelLd;    // panel rows x 17 (later: rhs vector)
   const int t = threadIdx.x, d = p.d;
   double* Lm = p.cholL;                 // dpad x dpad, row-major
   // copy lower triangle of S, identity padding
@@ -1244,26 +1294,13 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
   const int wave = t >> 6, lane = t & 63;
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
-    // 1. diagonal block -> LDS, factor
-    if (t < 256) sD[(t / 16) * kPanelLd + (t % 16)] = Lm[(size_t)(k0 + t / 16) * dpad + k0 + (t % 16)];
+    // 1. diagonal block -> LDS, factor it with wave 0 alone
+    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
     __syncthreads();
-    for (int k = 0; k < 16; ++k) {
-      if (t == 0) {
-        const double x = sD[k * kPanelLd + k];
-        if (!(x > 0)) { atomicOr(&p.scal->cholFail, 2); sD[k * kPanelLd + k] = 1.0; }
-        else sD[k * kPanelLd + k] = sqrt(x);
-      }
-      __syncthreads();
-      if (t < 16 && t > k) sD[t * kPanelLd + k] /= sD[k * kPanelLd + k];
-      __syncthreads();
-      if (t < 256) {
-        const int i = t / 16, j = t % 16;
-        if (j > k && i >= j) sD[i * kPanelLd + j] -= sD[i * kPanelLd + k] * sD[j * kPanelLd + k];
-      }
-      __syncthreads();
-    }
+    if (wave == 0) cholDiag16(sD, lane, &p.scal->cholFail);
+    __syncthreads();
     if (t < 256) {
-      const int i = t / 16, j = t % 16;
+      const int i = t >> 4, j = t & 15;
       Lm[(size_t)(k0 + i) * dpad + k0 + j] = (j <= i) ? sD[i * kPanelLd + j] : 0.0;
     }
     // 2. panel: rows below, forward substitution against the diagonal block
@@ -1289,7 +1326,6 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
     const int nR = rows / 16;
     const int nTiles = nR * (nR + 1) / 2;
     for (int tile = wave; tile < nTiles; tile += 16) {
-      // unrank tile -> (I,J), I >= J
       int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
       while (I * (I + 1) / 2 > tile) --I;
       while ((I + 1) * (I + 2) / 2 <= tile) ++I;
@@ -1309,18 +1345,24 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
     }
     __syncthreads();
   }
-  // ---- solve L y' = gRed ; L^T y = y'   (y in p.yC), serial over 16-blocks, parallel inside
+  // ---- solve L y' = gRed ; L^T y = y'.  rhs in LDS (sP), diagonal blocks staged in sD, the 16-wide
+  // substitution runs in wave 0 with one lane per unknown.
   double* y = p.yC;
   for (int i = t; i < dpad; i += blockDim.x) sP[i] = (i < d) ? p.gRed[i] : 0.0;
   __syncthreads();
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
-    if (t == 0) {
+    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
+    __syncthreads();
+    if (wave == 0) {
       for (int k = 0; k < 16; ++k) {
-        double s = sP[k0 + k];
-        for (int j = 0; j < k; ++j) s -= Lm[(size_t)(k0 + k) * dpad + k0 + j] * sP[k0 + j];
-        sP[k0 + k] = s / Lm[(size_t)(k0 + k) * dpad + k0 + k];
+        waveSync();
+        const double xk = sP[k0 + k] / sD[k * kPanelLd + k];
+        waveSync();
+        if (lane == k) sP[k0 + k] = xk;
+        if (lane > k && lane < 16) sP[k0 + lane] -= sD[lane * kPanelLd + k] * xk;
       }
+      waveSync();
     }
     __syncthreads();
     for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
@@ -1334,12 +1376,17 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
   }
   for (int kb = nT - 1; kb >= 0; --kb) {
     const int k0 = kb * 16;
-    if (t == 0) {
+    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
+    __syncthreads();
+    if (wave == 0) {
       for (int k = 15; k >= 0; --k) {
-        double s = sP[k0 + k];
-        for (int j = k + 1; j < 16; ++j) s -= Lm[(size_t)(k0 + j) * dpad + k0 + k] * sP[k0 + j];
-        sP[k0 + k] = s / Lm[(size_t)(k0 + k) * dpad + k0 + k];
+        waveSync();
+        const double xk = sP[k0 + k] / sD[k * kPanelLd + k];
+        waveSync();
+        if (lane == k) sP[k0 + k] = xk;
+        if (lane < k) sP[k0 + lane] -= sD[k * kPanelLd + lane] * xk;   // L^T: column k of the block row k
       }
+      waveSync();
     }
     __syncthreads();
     for (int i = t; i < k0; i += blockDim.x) {
@@ -1458,8 +1505,6 @@ __global__ __launch_bounds__(64) void k_jv_factors(DeviceProblem p, const double
 static int jvGrid(int N) { return (N + 255) / 256; }
 
 static void launchJv(const DeviceProblem& p, const double* vC, const double* vL, hipStream_t s) {
-  // clear the factor/prior partial slots that may stay unused
-  hipMemsetAsync(p.partial + (size_t)PS_JV_SQ_F * kMaxPartials, 0, sizeof(double) * 2 * kMaxPartials, s);
   if (p.N > 0) {
     if (p.anyExtVariable) hipLaunchKernelGGL(k_jv_reproj<true>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
     else hipLaunchKernelGGL(k_jv_reproj<false>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
@@ -1531,7 +1576,11 @@ __global__ __launch_bounds__(256) void k_reduce_scalars(DeviceProblem p, int wha
     }
   } else if (what == 2 || what == 3) {  // J*v: reproj (nA) + factors/prior (full slot)
     const double a = sumSlot(PS_JV_SQ, nA) , b = sumSlot(PS_JV_DOT, nA);
-    const double c = sumSlot(PS_JV_SQ_F, kMaxPartials), e = sumSlot(PS_JV_DOT_F, kMaxPartials);
+    double c = sumSlot(PS_JV_SQ_F, nB), e = sumSlot(PS_JV_DOT_F, nB);
+    if (t == 0 && p.priorM > 0) {
+      c += p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + kMaxPartials - 1];
+      e += p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + kMaxPartials - 1];
+    }
     if (t == 0) {
       if (what == 2) p.scal->jgSq = a + c;
       else { p.scal->jdSq = a + c; p.scal->jdDotR = b + e; }
@@ -1552,7 +1601,7 @@ void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s) {
   hipLaunchKernelGGL(k_dogleg_vectors, dim3(vecGrid(p)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 1, vecGrid(p), 0);
   launchJv(p, p.vC, p.vL, s);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 2, p.N > 0 ? jvGrid(p.N) : 0, 0);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 2, p.N > 0 ? jvGrid(p.N) : 0, p.F);
 }
 
 // traditional dogleg (ceres dogleg_strategy.cc) expressed on the un-scaled vectors:
@@ -1639,7 +1688,7 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s) {
   hipLaunchKernelGGL(k_dogleg_step, dim3(vecGrid(p)), dim3(256), 0, s, p, radius);
   launchJv(p, p.deltaC, p.deltaL, s);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 3, p.N > 0 ? jvGrid(p.N) : 0, 0);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 3, p.N > 0 ? jvGrid(p.N) : 0, p.F);
   const int nB = (p.nPose + p.nExt + p.nSb + p.L + 255) / 256;
   hipLaunchKernelGGL(k_retract, dim3(nB), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 4, nB, 0);
