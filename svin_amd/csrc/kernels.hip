@@ -232,6 +232,9 @@ struct FactorShared {
   double F[15 * 30];  // un-weighted Jacobian blocks (m x ncols)
   double e[15];       // un-weighted error
   double P[225], T[225], Fd[225];  // IMU covariance propagation
+  double st[72];      // staged IMU pre-integration state (Delta_t .. dp_db_g, 56 doubles)
+  double xs[32];      // staged parameter blocks x0(7) s0(9) x1(7) s1(9)
+  double rw[15];      // weighted residual
   int flag;
 };
 
@@ -589,8 +592,27 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       __syncthreads();
     }
     if (t < 225) sh.W[t] = im.sqrtInfo[t];
+    // stage the small state + parameters through LDS: one round trip instead of ~100 dependent loads in thread 0
+    if (t < 56) sh.st[t] = (&im.Delta_t)[t];
+    if (t >= 64 && t < 71) sh.xs[t - 64] = x0[t - 64];
+    if (t >= 71 && t < 80) sh.xs[7 + t - 71] = s0[t - 71];
+    if (t >= 80 && t < 87) sh.xs[16 + t - 80] = x1[t - 80];
+    if (t >= 87 && t < 96) sh.xs[23 + t - 87] = s1[t - 87];
+    __syncthreads();
     if (t == 0) {
       // ImuError.cpp:751-791
+      const double* x0 = sh.xs;
+      const double* s0 = sh.xs + 7;
+      const double* x1 = sh.xs + 16;
+      const double* s1 = sh.xs + 23;
+      const double* imDelta_q = sh.st + 1;
+      const double* imC_integral = sh.st + 5;
+      const double* imC_doubleintegral = sh.st + 14;
+      const double* imacc_integral = sh.st + 23;
+      const double* imacc_doubleintegral = sh.st + 26;
+      const double* imdalpha_db_g = sh.st + 29;
+      const double* imdv_db_g = sh.st + 38;
+      const double* imdp_db_g = sh.st + 47;
       const TF T0 = makeTF(x0), T1 = makeTF(x1);
       const double gz = im.par.g * (6371009.0 / sqrt(6371009.0 * 6371009.0));
       const double gW[3] = {im.par.g * 0.0, im.par.g * 0.0, gz};
@@ -608,10 +630,10 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       double Ct[9];
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) Ct[a * 3 + b] = T0.C.m[b * 3 + a];
-      const double a3[3] = {-(im.dalpha_db_g[0] * Db[0] + im.dalpha_db_g[1] * Db[1] + im.dalpha_db_g[2] * Db[2]),
-                            -(im.dalpha_db_g[3] * Db[0] + im.dalpha_db_g[4] * Db[1] + im.dalpha_db_g[5] * Db[2]),
-                            -(im.dalpha_db_g[6] * Db[0] + im.dalpha_db_g[7] * Db[1] + im.dalpha_db_g[8] * Db[2])};
-      const Quat Dq = qmul(deltaQ(a3[0], a3[1], a3[2]), Quat{im.Delta_q[0], im.Delta_q[1], im.Delta_q[2], im.Delta_q[3]});
+      const double a3[3] = {-(imdalpha_db_g[0] * Db[0] + imdalpha_db_g[1] * Db[1] + imdalpha_db_g[2] * Db[2]),
+                            -(imdalpha_db_g[3] * Db[0] + imdalpha_db_g[4] * Db[1] + imdalpha_db_g[5] * Db[2]),
+                            -(imdalpha_db_g[6] * Db[0] + imdalpha_db_g[7] * Db[1] + imdalpha_db_g[8] * Db[2])};
+      const Quat Dq = qmul(deltaQ(a3[0], a3[1], a3[2]), Quat{imDelta_q[0], imDelta_q[1], imDelta_q[2], imDelta_q[3]});
       auto setB = [](double* F, int r0, int c0, const double* B, double s) {
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) F[(r0 + a) * 30 + c0 + b] = s * B[a * 3 + b];
@@ -620,8 +642,8 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       setB(F0, 0, 0, Ct, 1.0);
       crossMxDev(dpv[0], dpv[1], dpv[2], X); mm3(Ct, X, T9); setB(F0, 0, 3, T9, 1.0);
       setB(F0, 0, 6, Ct, Delta_t);
-      setB(F0, 0, 9, im.dp_db_g, 1.0);
-      setB(F0, 0, 12, im.C_doubleintegral, -1.0);
+      setB(F0, 0, 9, imdp_db_g, 1.0);
+      setB(F0, 0, 12, imC_doubleintegral, -1.0);
       const Quat q1inv = qinv(T1.q);
       double Qp[16], Qo[16], Q44[16];
       quatPlusMat4(qmul(Dq, q1inv), Qp);
@@ -635,13 +657,13 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       mm4(Qo1, Qo2, Q44);
       double TL[9], nd[9];
       for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) { TL[a * 3 + b] = Q44[a * 4 + b]; nd[a * 3 + b] = -im.dalpha_db_g[a * 3 + b]; }
+        for (int b = 0; b < 3; ++b) { TL[a * 3 + b] = Q44[a * 4 + b]; nd[a * 3 + b] = -imdalpha_db_g[a * 3 + b]; }
       mm3(TL, nd, T9);
       setB(F0, 3, 9, T9, 1.0);
       crossMxDev(dvv[0], dvv[1], dvv[2], X); mm3(Ct, X, T9); setB(F0, 6, 3, T9, 1.0);
       setB(F0, 6, 6, Ct, 1.0);
-      setB(F0, 6, 9, im.dv_db_g, 1.0);
-      setB(F0, 6, 12, im.C_integral, -1.0);
+      setB(F0, 6, 9, imdv_db_g, 1.0);
+      setB(F0, 6, 12, imC_integral, -1.0);
       setB(F1, 0, 0, Ct, -1.0);
       double Qp2[16], Qp3[16], Qt[16];
       quatPlusMat4(Dq, Qp2);
@@ -658,8 +680,8 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
       for (int a = 0; a < 3; ++a) {
         double s1 = 0, s2 = 0;
         for (int k = 0; k < 6; ++k) { s1 += F0[a * 30 + 9 + k] * Db[k]; s2 += F0[(6 + a) * 30 + 9 + k] * Db[k]; }
-        sh.e[a] = v1a[a] + im.acc_doubleintegral[a] + s1;
-        sh.e[6 + a] = v2a[a] + im.acc_integral[a] + s2;
+        sh.e[a] = v1a[a] + imacc_doubleintegral[a] + s1;
+        sh.e[6 + a] = v2a[a] + imacc_integral[a] + s2;
       }
       const Quat qd = qmul(Dq, qmul(q1inv, T0.q));
       sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
@@ -722,6 +744,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
     double s = 0;
     for (int k = 0; k < m; ++k) s += sh.W[a * m + k] * sh.e[k];
     lin.r[a] = s;
+    sh.rw[a] = s;
   }
   for (int idx = t; idx < m * ncols; idx += blockDim.x) {
     const int a = idx / ncols, c = idx % ncols;
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
   // cost partial: 0.5 |r|^2
   if (t == 0) {
     double c = 0;
-    for (int a = 0; a < m; ++a) c += lin.r[a] * lin.r[a];
+    for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
     p.partial[(size_t)PS_COST_FACTORS * kMaxPartials + f] = 0.5 * c;
   }
 }
@@ -1400,6 +1423,132 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
   for (int i = t; i < d; i += blockDim.x) y[i] = sP[i];
 }
 
+// LDS-resident variant for dpad <= 176: the lower triangle lives in LDS as 16x17 tiles (tile (I,J), I>=J at
+// index I(I+1)/2+J), so the whole factorisation and both triangular solves run at LDS latency.
+constexpr int kTile = 16 * kPanelLd;  // doubles per tile
+__device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
+
+__global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dpad) {
+  extern __shared__ double smem[];
+  const int t = threadIdx.x, d = p.d, nT = dpad / 16;
+  const int wave = t >> 6, lane = t & 63;
+  const int nTilesAll = nT * (nT + 1) / 2;
+  double* tiles = smem;
+  double* rhs = smem + (size_t)nTilesAll * kTile;  // dpad
+  // load lower triangle (identity padding)
+  for (int idx = t; idx < nTilesAll * 256; idx += blockDim.x) {
+    const int tl = idx >> 8, e = idx & 255, r = e >> 4, c = e & 15;
+    int I = (int)((sqrt(8.0 * tl + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > tl) --I;
+    while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+    const int J = tl - I * (I + 1) / 2;
+    const int gi = I * 16 + r, gj = J * 16 + c;
+    double v = 0;
+    if (gi < d && gj < d) v = (gj <= gi) ? p.S[(size_t)gi * d + gj] : 0.0;
+    else if (gi == gj) v = 1.0;
+    tiles[(size_t)tl * kTile + r * kPanelLd + c] = v;
+  }
+  for (int i = t; i < dpad; i += blockDim.x) rhs[i] = (i < d) ? p.gRed[i] : 0.0;
+  __syncthreads();
+  for (int kb = 0; kb < nT; ++kb) {
+    double* D = tileAt(tiles, kb, kb);
+    if (wave == 0) cholDiag16(D, lane, &p.scal->cholFail);
+    __syncthreads();
+    // TRSM: X L^T = A for every tile below the diagonal; one row per thread
+    const int rows = (nT - kb - 1) * 16;
+    for (int rI = t; rI < rows; rI += blockDim.x) {
+      double* row = tileAt(tiles, kb + 1 + (rI >> 4), kb) + (rI & 15) * kPanelLd;
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = row[k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        double s = x[k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < k) s -= x[j] * D[k * kPanelLd + j];
+        x[k] = s / D[k * kPanelLd + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) row[k] = x[k];
+    }
+    __syncthreads();
+    // trailing update on MFMA: C(I,J) -= L(I,kb) L(J,kb)^T
+    const int nR = nT - kb - 1;
+    const int nUp = nR * (nR + 1) / 2;
+    for (int tile = wave; tile < nUp; tile += 16) {
+      int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+      while (I * (I + 1) / 2 > tile) --I;
+      while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+      const int J = tile - I * (I + 1) / 2;
+      double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
+      const double* A = tileAt(tiles, kb + 1 + I, kb);
+      const double* B = tileAt(tiles, kb + 1 + J, kb);
+      d4_t acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+        const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+    }
+    __syncthreads();
+  }
+  // forward substitution L y' = g
+  for (int kb = 0; kb < nT; ++kb) {
+    const int k0 = kb * 16;
+    const double* D = tileAt(tiles, kb, kb);
+    if (wave == 0) {
+      for (int k = 0; k < 16; ++k) {
+        waveSync();
+        const double xk = rhs[k0 + k] / D[k * kPanelLd + k];
+        waveSync();
+        if (lane == k) rhs[k0 + k] = xk;
+        if (lane > k && lane < 16) rhs[k0 + lane] -= D[lane * kPanelLd + k] * xk;
+      }
+      waveSync();
+    }
+    __syncthreads();
+    for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
+      const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += row[k] * rhs[k0 + k];
+      rhs[i] -= s;
+    }
+    __syncthreads();
+  }
+  // backward substitution L^T y = y'
+  for (int kb = nT - 1; kb >= 0; --kb) {
+    const int k0 = kb * 16;
+    const double* D = tileAt(tiles, kb, kb);
+    if (wave == 0) {
+      for (int k = 15; k >= 0; --k) {
+        waveSync();
+        const double xk = rhs[k0 + k] / D[k * kPanelLd + k];
+        waveSync();
+        if (lane == k) rhs[k0 + k] = xk;
+        if (lane < k) rhs[k0 + lane] -= D[k * kPanelLd + lane] * xk;
+      }
+      waveSync();
+    }
+    __syncthreads();
+    for (int i = t; i < k0; i += blockDim.x) {
+      const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += col[k * kPanelLd] * rhs[k0 + k];
+      rhs[i] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < d; i += blockDim.x) p.yC[i] = rhs[i];
+}
+
 // landmarks: y_l = Vinv (bl - sum_i Jl_i^T (Jc_i y_c))
 template <bool WITH_EXT>
 __global__ void k_backsub(DeviceProblem p) {
@@ -1434,9 +1583,16 @@ __global__ void k_backsub(DeviceProblem p) {
 
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
   const int dpad = ((p.d + 15) / 16) * 16;
-  const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
-  (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad);
+  const int nT = dpad / 16;
+  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + dpad) * 8;
+  if (ldsBytes <= 156 * 1024) {
+    (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(1024), ldsBytes, s, p, dpad);
+  } else {
+    const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
+    (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad);
+  }
   if (p.L > 0) {
     if (p.anyExtVariable) hipLaunchKernelGGL(k_backsub<true>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);
     else hipLaunchKernelGGL(k_backsub<false>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);

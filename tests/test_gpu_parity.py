@@ -149,9 +149,10 @@ def test_reduced_system_parity(gpu_lib, rig):
     assert rel(gn, gc) < 1e-9
 
 
-@pytest.mark.parametrize("rig,kw", [("euroc", {}), ("rig_v2", dict(sonar=True, depth=True))])
-def test_optimize_matches_oracle(gpu_lib, rig, kw):
-    spec = syn.make_window(P=6, L=300, n_obs=3000, seed=33, rig=rig, **kw)
+@pytest.mark.parametrize("rig,P,kw", [("euroc", 6, {}), ("rig_v2", 6, dict(sonar=True, depth=True)),
+                                      ("rig_v2", 9, dict(depth=True))])  # d = 90 / 162 / 243 (LDS and global Cholesky)
+def test_optimize_matches_oracle(gpu_lib, rig, P, kw):
+    spec = syn.make_window(P=P, L=300, n_obs=3000, seed=33, rig=rig, **kw)
     gpu, cpu, fg, fc, lg, lc = make_pair(spec)
     for e in (gpu, cpu):
         e.set_solver_options(1e-12, 1e-12, 1e-12)
