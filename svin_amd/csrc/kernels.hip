@@ -1423,6 +1423,56 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
   for (int i = t; i < d; i += blockDim.x) y[i] = sP[i];
 }
 
+// ---- 16x16 diagonal block in registers (wave 0, lane i = row i), cross-lane traffic through v_readlane.
+__device__ __forceinline__ double readlaneD(double v, int srcLane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+// Factorises the tile D (16 x kPanelLd in LDS) in place: lower triangle <- L, strict upper triangle <-
+// transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); diag(L^-1) = 1/L_ii.
+__device__ __forceinline__ void cholDiag16Reg(double* D, int lane, int* failFlag) {
+  double a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = (lane < 16) ? D[lane * kPanelLd + j] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double akk = readlaneD(a[k], k);
+    const bool ok = akk > 0;
+    bad = bad || !ok;
+    const double dk = ok ? sqrt(akk) : 1.0;
+    const double lk = (lane == k) ? dk : a[k] / dk;
+    a[k] = lk;
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) {
+      const double ljk = readlaneD(lk, j);
+      a[j] -= lk * ljk;
+    }
+  }
+  if (bad && lane == 0) atomicOr(failFlag, 2);
+  // inverse: lane j builds column j of X = L^-1 (x[i] = X[i][j], i >= j)
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const double lii = readlaneD(a[i], i);
+    double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) {
+      const double lik = readlaneD(a[k], i);
+      if (k >= lane) sacc -= lik * x[k];
+    }
+    x[i] = (i >= lane) ? sacc / lii : 0.0;
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j <= lane) D[lane * kPanelLd + j] = a[j];      // L[lane][j]
+      if (j > lane) D[lane * kPanelLd + j] = x[j];       // D[c=lane][r=j] = Linv[j][lane]
+    }
+  }
+}
+
 // LDS-resident variant for dpad <= 176: the lower triangle lives in LDS as 16x17 tiles (tile (I,J), I>=J at
 // index I(I+1)/2+J), so the whole factorisation and both triangular solves run at LDS latency.
 constexpr int kTile = 16 * kPanelLd;  // doubles per tile
@@ -1452,7 +1502,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
   __syncthreads();
   for (int kb = 0; kb < nT; ++kb) {
     double* D = tileAt(tiles, kb, kb);
-    if (wave == 0) cholDiag16(D, lane, &p.scal->cholFail);
+    if (wave == 0) cholDiag16Reg(D, lane, &p.scal->cholFail);
     __syncthreads();
     // TRSM: X L^T = A for every tile below the diagonal; one row per thread
     const int rows = (nT - kb - 1) * 16;
@@ -1498,51 +1548,44 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
     }
     __syncthreads();
   }
-  // forward substitution L y' = g
+  // forward substitution L y' = g : y_blk = Linv * rhs_blk (one lane per unknown), then update the rest
+  double* ytmp = rhs + dpad;  // 16 scratch doubles
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
     const double* D = tileAt(tiles, kb, kb);
-    if (wave == 0) {
-      for (int k = 0; k < 16; ++k) {
-        waveSync();
-        const double xk = rhs[k0 + k] / D[k * kPanelLd + k];
-        waveSync();
-        if (lane == k) rhs[k0 + k] = xk;
-        if (lane > k && lane < 16) rhs[k0 + lane] -= D[lane * kPanelLd + k] * xk;
-      }
-      waveSync();
+    if (t < 16) {
+      double sacc = rhs[k0 + t] / D[t * kPanelLd + t];
+      for (int c = 0; c < t; ++c) sacc += D[c * kPanelLd + t] * rhs[k0 + c];
+      ytmp[t] = sacc;
     }
     __syncthreads();
+    if (t < 16) rhs[k0 + t] = ytmp[t];
     for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
       const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
-      double s = 0;
+      double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += row[k] * rhs[k0 + k];
-      rhs[i] -= s;
+      for (int k = 0; k < 16; ++k) sacc += row[k] * ytmp[k];
+      rhs[i] -= sacc;
     }
     __syncthreads();
   }
-  // backward substitution L^T y = y'
+  // backward substitution L^T y = y' : y_blk = Linv^T * rhs_blk
   for (int kb = nT - 1; kb >= 0; --kb) {
     const int k0 = kb * 16;
     const double* D = tileAt(tiles, kb, kb);
-    if (wave == 0) {
-      for (int k = 15; k >= 0; --k) {
-        waveSync();
-        const double xk = rhs[k0 + k] / D[k * kPanelLd + k];
-        waveSync();
-        if (lane == k) rhs[k0 + k] = xk;
-        if (lane < k) rhs[k0 + lane] -= D[k * kPanelLd + lane] * xk;
-      }
-      waveSync();
+    if (t < 16) {
+      double sacc = rhs[k0 + t] / D[t * kPanelLd + t];
+      for (int r = t + 1; r < 16; ++r) sacc += D[t * kPanelLd + r] * rhs[k0 + r];
+      ytmp[t] = sacc;
     }
     __syncthreads();
+    if (t < 16) rhs[k0 + t] = ytmp[t];
     for (int i = t; i < k0; i += blockDim.x) {
       const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
-      double s = 0;
+      double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += col[k * kPanelLd] * rhs[k0 + k];
-      rhs[i] -= s;
+      for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * ytmp[k];
+      rhs[i] -= sacc;
     }
     __syncthreads();
   }
@@ -1584,7 +1627,7 @@ __global__ void k_backsub(DeviceProblem p) {
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
-  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + dpad) * 8;
+  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + dpad + 16) * 8;
   if (ldsBytes <= 156 * 1024) {
     (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(1024), ldsBytes, s, p, dpad);
