@@ -2,7 +2,7 @@
 # Builds libsvin_ba.so for gfx950 in-tree (the .so is git-ignored but travels to the GPU box).
 set -e
 cd "$(dirname "$0")"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $SVIN_EXTRA_FLAGS"
 mkdir -p obj
 for f in kernels.hip marg.hip; do
   if [ ! -f obj/$f.o ] || [ $f -nt obj/$f.o ] || [ kernels.hpp -nt obj/$f.o ] || [ dmath.hpp -nt obj/$f.o ] || [ window.hpp -nt obj/$f.o ]; then

@@ -1430,9 +1430,10 @@ __device__ __forceinline__ double readlaneD(double v, int srcLane) {
   return __hiloint2double(hi, lo);
 }
 // Factorises the tile D (16 x kPanelLd in LDS) in place: lower triangle <- L, strict upper triangle <-
-// transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); diag(L^-1) = 1/L_ii.
-__device__ __forceinline__ void cholDiag16Reg(double* D, int lane, int* failFlag) {
-  double a[16];
+// transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii = diag(L^-1).
+// Divisions and square roots are replaced by one rsqrt per pivot (the serial chain is latency-bound).
+__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane, int* failFlag) {
+  double a[16], rinv[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) a[j] = (lane < 16) ? D[lane * kPanelLd + j] : 0.0;
   bool bad = false;
@@ -1441,8 +1442,9 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, int lane, int* failFlag
     const double akk = readlaneD(a[k], k);
     const bool ok = akk > 0;
     bad = bad || !ok;
-    const double dk = ok ? sqrt(akk) : 1.0;
-    const double lk = (lane == k) ? dk : a[k] / dk;
+    const double r = ok ? rsqrt(akk) : 1.0;   // 1/L_kk
+    rinv[k] = r;
+    const double lk = (lane == k) ? akk * r : a[k] * r;
     a[k] = lk;
 #pragma unroll
     for (int j = k + 1; j < 16; ++j) {
@@ -1455,20 +1457,20 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, int lane, int* failFlag
   double x[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const double lii = readlaneD(a[i], i);
     double sacc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < i; ++k) {
       const double lik = readlaneD(a[k], i);
       if (k >= lane) sacc -= lik * x[k];
     }
-    x[i] = (i >= lane) ? sacc / lii : 0.0;
+    x[i] = (i >= lane) ? sacc * rinv[i] : 0.0;
   }
   if (lane < 16) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j <= lane) D[lane * kPanelLd + j] = a[j];      // L[lane][j]
       if (j > lane) D[lane * kPanelLd + j] = x[j];       // D[c=lane][r=j] = Linv[j][lane]
+      if (j == lane) dinv[j] = rinv[j];
     }
   }
 }
@@ -1485,110 +1487,108 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
   const int nTilesAll = nT * (nT + 1) / 2;
   double* tiles = smem;
   double* rhs = smem + (size_t)nTilesAll * kTile;  // dpad
-  // load lower triangle (identity padding)
-  for (int idx = t; idx < nTilesAll * 256; idx += blockDim.x) {
-    const int tl = idx >> 8, e = idx & 255, r = e >> 4, c = e & 15;
-    int I = (int)((sqrt(8.0 * tl + 1.0) - 1.0) * 0.5);
-    while (I * (I + 1) / 2 > tl) --I;
-    while ((I + 1) * (I + 2) / 2 <= tl) ++I;
-    const int J = tl - I * (I + 1) / 2;
-    const int gi = I * 16 + r, gj = J * 16 + c;
+  double* dinv = rhs + dpad;                       // dpad
+  // load the lower triangle of S (identity padding); coalesced over the rows of S
+  for (int idx = t; idx < dpad * dpad; idx += blockDim.x) {
+    const int gi = idx / dpad, gj = idx - gi * dpad;
+    const int I = gi >> 4, J = gj >> 4;
+    if (J > I) continue;
     double v = 0;
     if (gi < d && gj < d) v = (gj <= gi) ? p.S[(size_t)gi * d + gj] : 0.0;
     else if (gi == gj) v = 1.0;
-    tiles[(size_t)tl * kTile + r * kPanelLd + c] = v;
+    tileAt(tiles, I, J)[(gi & 15) * kPanelLd + (gj & 15)] = v;
   }
   for (int i = t; i < dpad; i += blockDim.x) rhs[i] = (i < d) ? p.gRed[i] : 0.0;
   __syncthreads();
   for (int kb = 0; kb < nT; ++kb) {
+    const int k0 = kb * 16;
     double* D = tileAt(tiles, kb, kb);
-    if (wave == 0) cholDiag16Reg(D, lane, &p.scal->cholFail);
+    if (wave == 0) cholDiag16Reg(D, dinv + k0, lane, &p.scal->cholFail);
     __syncthreads();
-    // TRSM: X L^T = A for every tile below the diagonal; one row per thread
-    const int rows = (nT - kb - 1) * 16;
-    for (int rI = t; rI < rows; rI += blockDim.x) {
-      double* row = tileAt(tiles, kb + 1 + (rI >> 4), kb) + (rI & 15) * kPanelLd;
-      double x[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = row[k];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        double s = x[k];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j < k) s -= x[j] * D[k * kPanelLd + j];
-        x[k] = s / D[k * kPanelLd + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) row[k] = x[k];
-    }
-    __syncthreads();
-    // trailing update on MFMA: C(I,J) -= L(I,kb) L(J,kb)^T
     const int nR = nT - kb - 1;
-    const int nUp = nR * (nR + 1) / 2;
-    for (int tile = wave; tile < nUp; tile += 16) {
-      int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-      while (I * (I + 1) / 2 > tile) --I;
-      while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-      const int J = tile - I * (I + 1) / 2;
-      double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
-      const double* A = tileAt(tiles, kb + 1 + I, kb);
-      const double* B = tileAt(tiles, kb + 1 + J, kb);
-      d4_t acc;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+    // phase B: panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile);
+    // the last wave also advances the forward substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb
+    for (int ti = wave; ti < nR; ti += 16) {
+      double* A = tileAt(tiles, kb + 1 + ti, kb);
+      d4_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
-        const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+        const int kk = 4 * q + (lane >> 4), jj = lane & 15;
+        const double a = A[(lane & 15) * kPanelLd + kk];
+        const double b = (jj > kk) ? D[kk * kPanelLd + jj] : ((jj == kk) ? dinv[k0 + kk] : 0.0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+      for (int rg = 0; rg < 4; ++rg) A[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+    }
+    if (wave == 15) {
+      double yv = 0;
+      if (lane < 16) {
+        yv = rhs[k0 + lane] * dinv[k0 + lane];
+        for (int c = 0; c < lane; ++c) yv += D[c * kPanelLd + lane] * rhs[k0 + c];
+      }
+      waveSync();
+      if (lane < 16) rhs[k0 + lane] = yv;
     }
     __syncthreads();
-  }
-  // forward substitution L y' = g : y_blk = Linv * rhs_blk (one lane per unknown), then update the rest
-  double* ytmp = rhs + dpad;  // 16 scratch doubles
-  for (int kb = 0; kb < nT; ++kb) {
-    const int k0 = kb * 16;
-    const double* D = tileAt(tiles, kb, kb);
-    if (t < 16) {
-      double sacc = rhs[k0 + t] / D[t * kPanelLd + t];
-      for (int c = 0; c < t; ++c) sacc += D[c * kPanelLd + t] * rhs[k0 + c];
-      ytmp[t] = sacc;
-    }
-    __syncthreads();
-    if (t < 16) rhs[k0 + t] = ytmp[t];
-    for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
-      const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
-      double sacc = 0;
+    // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA; wave 15 first updates the rhs tail
+    if (wave == 15) {
+      for (int i = k0 + 16 + lane; i < dpad; i += 64) {
+        const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
+        double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sacc += row[k] * ytmp[k];
-      rhs[i] -= sacc;
+        for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
+        rhs[i] -= sacc;
+      }
     }
-    __syncthreads();
-  }
-  // backward substitution L^T y = y' : y_blk = Linv^T * rhs_blk
-  for (int kb = nT - 1; kb >= 0; --kb) {
-    const int k0 = kb * 16;
-    const double* D = tileAt(tiles, kb, kb);
-    if (t < 16) {
-      double sacc = rhs[k0 + t] / D[t * kPanelLd + t];
-      for (int r = t + 1; r < 16; ++r) sacc += D[t * kPanelLd + r] * rhs[k0 + r];
-      ytmp[t] = sacc;
-    }
-    __syncthreads();
-    if (t < 16) rhs[k0 + t] = ytmp[t];
-    for (int i = t; i < k0; i += blockDim.x) {
-      const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
-      double sacc = 0;
+    const int nUp = nR * (nR + 1) / 2;
+    int I = 0, J = 0, cnt = 0;  // walk the lower-triangular tile list without square roots
+    for (int tile = 0; tile < nUp; ++tile) {
+      if ((tile & 15) == wave) {
+        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
+        const double* A = tileAt(tiles, kb + 1 + I, kb);
+        const double* B = tileAt(tiles, kb + 1 + J, kb);
+        d4_t acc;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * ytmp[k];
-      rhs[i] -= sacc;
+        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+          const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+      }
+      if (++J > I) { ++I; J = 0; }
+      (void)cnt;
     }
     __syncthreads();
   }
+  // backward substitution L^T y = y' in wave 0 alone (wave-level synchronisation only)
+  if (wave == 0) {
+    for (int kb = nT - 1; kb >= 0; --kb) {
+      const int k0 = kb * 16;
+      const double* D = tileAt(tiles, kb, kb);
+      double yv = 0;
+      if (lane < 16) {
+        yv = rhs[k0 + lane] * dinv[k0 + lane];
+        for (int r = lane + 1; r < 16; ++r) yv += D[lane * kPanelLd + r] * rhs[k0 + r];
+      }
+      waveSync();
+      if (lane < 16) rhs[k0 + lane] = yv;
+      waveSync();
+      for (int i = lane; i < k0; i += 64) {
+        const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + k];
+        rhs[i] -= sacc;
+      }
+      waveSync();
+    }
+  }
+  __syncthreads();
   for (int i = t; i < d; i += blockDim.x) p.yC[i] = rhs[i];
 }
 
@@ -1627,7 +1627,7 @@ __global__ void k_backsub(DeviceProblem p) {
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
-  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + dpad + 16) * 8;
+  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 2 * dpad) * 8;
   if (ldsBytes <= 156 * 1024) {
     (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(1024), ldsBytes, s, p, dpad);
