@@ -1503,8 +1503,19 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
     double* D = tileAt(tiles, kb, kb);
+#ifdef SVIN_CHOL_TIMING
+    long long q0 = __builtin_readcyclecounter();
+#endif
     if (wave == 0) cholDiag16Reg(D, dinv + k0, lane, &p.scal->cholFail);
+#ifdef SVIN_CHOL_TIMING
+    long long q1 = __builtin_readcyclecounter();
+    if (t == 0) p.partial[(size_t)15 * 4096 + 0] += (double)(q1 - q0);
+#endif
     __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+    long long q2 = __builtin_readcyclecounter();
+    if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(q2 - q1);
+#endif
     const int nR = nT - kb - 1;
     // phase B: panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile);
     // the last wave also advances the forward substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb
@@ -1531,6 +1542,10 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
       if (lane < 16) rhs[k0 + lane] = yv;
     }
     __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+    long long q3 = __builtin_readcyclecounter();
+    if (t == 0) p.partial[(size_t)15 * 4096 + 2] += (double)(q3 - q2);
+#endif
     // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA; wave 15 first updates the rhs tail
     if (wave == 15) {
       for (int i = k0 + 16 + lane; i < dpad; i += 64) {
@@ -1564,7 +1579,14 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
       (void)cnt;
     }
     __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+    long long q4 = __builtin_readcyclecounter();
+    if (t == 0) p.partial[(size_t)15 * 4096 + 3] += (double)(q4 - q3);
+#endif
   }
+#ifdef SVIN_CHOL_TIMING
+  long long q5 = __builtin_readcyclecounter();
+#endif
   // backward substitution L^T y = y' in wave 0 alone (wave-level synchronisation only)
   if (wave == 0) {
     for (int kb = nT - 1; kb >= 0; --kb) {
@@ -1589,6 +1611,9 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
     }
   }
   __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+  if (t == 0) p.partial[(size_t)15 * 4096 + 4] += (double)(__builtin_readcyclecounter() - q5);
+#endif
   for (int i = t; i < d; i += blockDim.x) p.yC[i] = rhs[i];
 }
 

@@ -1049,7 +1049,14 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
   };
   if (evalMs) *evalMs = timeIt([&]() { launchEvalReproj(p, false, true, s); });
   if (buildMs) *buildMs = timeIt([&]() { launchBuildNormalEquations(p, 1e-8, false, s); });
+  if (getenv("SVIN_CHOL_TIMING")) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64));
   if (solveMs) *solveMs = timeIt([&]() { launchSolveReduced(p, s); });
+  if (getenv("SVIN_CHOL_TIMING")) {
+    double dbg[5];
+    HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096, sizeof(dbg), hipMemcpyDeviceToHost));
+    std::printf("[chol cycles per launch] diag %.0f sync %.0f trsm %.0f mfma %.0f back %.0f\n", dbg[0] / iters, dbg[1] / iters,
+                dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 1;
 }
