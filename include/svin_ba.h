@@ -113,6 +113,13 @@ int svin_ba_finish(svin_ba* h);
 /* forces every IMU factor to re-preintegrate at its next evaluation (ImuError::redo_ = true) */
 int svin_ba_invalidate_preintegration(svin_ba* h);
 int svin_ba_get_summary(svin_ba* h, svin_summary* out);
+/* Landmark-sharded multi-GPU solve (one process per GPU; BASELINE config "64 KF / 50 000 landmarks").  Every
+ * rank adds ALL states (add_states on every rank) and only ITS landmarks + observations; the reduced camera
+ * system and a handful of scalars are summed over ranks through `fn`, which must all-reduce `count` doubles at
+ * the DEVICE address `ptr` in place (op 0 = sum, 1 = max) and return 0 -- e.g. RCCL via torch.distributed.
+ * The reference has no counterpart (single process, Ceres threads: Estimator.cpp:889). */
+typedef int (*svin_allreduce_fn)(void* ptr, uint64_t count, int op, void* user);
+int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user);
 /* solver tolerances (::ceres::Solver::Options defaults: 1e-6, 1e-10, 1e-8) */
 int svin_ba_set_solver_tolerances(svin_ba* h, double function_tol, double gradient_tol, double parameter_tol);
 

@@ -105,6 +105,8 @@ def _bind(L):
     sig("orc_map_add_depth_error", u64, vp, f64, f64, f64, u64)
     sig("orc_map_add_hpoint_error", u64, vp, pd, f64, u64)
     sig("orc_map_remove_residual", i32, vp, u64)
+    sig("orc_map_residual_kind", i32, vp, u64)
+    sig("orc_map_residual_ids", i32, vp, pu64, i32)
     sig("orc_map_residual_dims", i32, vp, u64, pi32, i32)
     sig("orc_map_eval", i32, vp, u64, pd, pd, pd)
     sig("orc_map_is_jacobian_correct", i32, vp, u64, f64, pd)
@@ -197,6 +199,18 @@ class OracleMap:
         meas = arr(meas).reshape(-1, 6)
         par, ids = arr(par), arr(ids, np.uint64)
         return self.L.orc_map_add_imu(self.h, len(t), u32ptr(t), dptr(meas), dptr(par), t0[0], t0[1], t1[0], t1[1], u64ptr(ids))
+
+    def residual_ids(self):
+        n = self.L.orc_map_residual_ids(self.h, None, 0)
+        ids = np.zeros(max(n, 1), np.uint64)
+        self.L.orc_map_residual_ids(self.h, u64ptr(ids), n)
+        return [int(i) for i in ids[:n]]
+
+    def residual_kind(self, rid):
+        return int(self.L.orc_map_residual_kind(self.h, rid))
+
+    def remove_residual(self, rid):
+        return bool(self.L.orc_map_remove_residual(self.h, rid))
 
     def dims(self, rid):
         d = np.zeros(64, np.int32)

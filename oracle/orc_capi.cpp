@@ -223,6 +223,17 @@ uint64_t orc_map_add_depth_error(void* m, double depth, double info, double firs
 uint64_t orc_map_add_hpoint_error(void* m, const double* meas, double variance, uint64_t id) {
   return static_cast<Map*>(m)->addResidualBlock(std::make_shared<HomogeneousPointError>(meas, variance), LOSS_NONE, {id});
 }
+// ErrorTerm::Kind of a residual block (0 = reprojection), -1 if it does not exist
+int orc_map_residual_kind(void* m, uint64_t rid) {
+  Map* mp = static_cast<Map*>(m);
+  if (!mp->residualExists(rid)) return -1;
+  return (int)mp->residual(rid).err->kind();
+}
+int orc_map_residual_ids(void* m, uint64_t* ids, int cap) {
+  int n = 0;
+  for (auto& kv : static_cast<Map*>(m)->residualMap()) { if (n < cap) ids[n] = kv.first; ++n; }
+  return n;
+}
 int orc_map_remove_residual(void* m, uint64_t rid) { return static_cast<Map*>(m)->removeResidualBlock(rid) ? 1 : 0; }
 // dims: m, nb, then per block dim / mdim
 int orc_map_residual_dims(void* m, uint64_t rid, int* dims, int cap) {

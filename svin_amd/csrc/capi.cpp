@@ -155,6 +155,11 @@ int svin_ba_get_summary(svin_ba* h, svin_summary* out) {
   out->download_time_s = s.download_time;
   return 1;
 }
+int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user) {
+  if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SVIN_ERR_INVALID_ARG;
+  h->w.setDistributed(rank, world, fn, user);
+  return 1;
+}
 int svin_ba_set_solver_tolerances(svin_ba* h, double f, double g, double p) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.setTolerances(f, g, p);

@@ -774,7 +774,7 @@ void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, 
 }
 
 void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s) {
-  if (p.F == 0) return;
+  if (p.F == 0 || !p.ownsCamera) return;
   hipLaunchKernelGGL(k_eval_factors, dim3(p.F), dim3(256), 0, s, p, cand ? 1 : 0);
 }
 
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
 }
 
 void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s) {
-  if (p.priorM == 0) return;
+  if (p.priorM == 0 || !p.ownsCamera) return;
   hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0);
 }
 
@@ -1222,6 +1222,13 @@ __global__ void k_zero_build(DeviceProblem p) {
 }
 
 void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
+  launchAccumulateNormalEquations(p, mu, initScale, s);
+  launchFinalizeNormalEquations(p, mu, initScale, s);
+}
+void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_diag, dim3((p.d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
+}
+void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
   const int d = p.d, dC = p.dC;
   hipLaunchKernelGGL(k_zero_build, dim3((d * d + 255) / 256), dim3(256), 0, s, p);
   if (p.L > 0 && p.N > 0 && dC > 0) {
@@ -1252,8 +1259,8 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
 #undef LAUNCH
     }
   }
-  if (p.F > 0) hipLaunchKernelGGL(k_factors_accumulate, dim3(p.F), dim3(256), 0, s, p);
-  if (p.priorM > 0) {
+  if (p.F > 0 && p.ownsCamera) hipLaunchKernelGGL(k_factors_accumulate, dim3(p.F), dim3(256), 0, s, p);
+  if (p.priorM > 0 && p.ownsCamera) {
     const int n = p.priorM * p.priorM;
     hipLaunchKernelGGL(k_prior_accumulate, dim3((n + 255) / 256), dim3(256), 0, s, p);
   }
@@ -1265,7 +1272,6 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
     const int n = dC * dC + 3 * dC;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 63) / 64), dim3(256), 0, s, q);
   }
-  hipLaunchKernelGGL(k_finalize_diag, dim3((d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
 }
 
 // ================================================================ K6: reduced system solve
@@ -1733,8 +1739,8 @@ static void launchJv(const DeviceProblem& p, const double* vC, const double* vL,
     if (p.anyExtVariable) hipLaunchKernelGGL(k_jv_reproj<true>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
     else hipLaunchKernelGGL(k_jv_reproj<false>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
   }
-  if (p.F > 0) hipLaunchKernelGGL(k_jv_factors, dim3(p.F), dim3(64), 0, s, p, vC);
-  if (p.priorM > 0) hipLaunchKernelGGL(k_prior_jv, dim3(1), dim3(256), 0, s, p, vC);
+  if (p.F > 0 && p.ownsCamera) hipLaunchKernelGGL(k_jv_factors, dim3(p.F), dim3(64), 0, s, p, vC);
+  if (p.priorM > 0 && p.ownsCamera) hipLaunchKernelGGL(k_prior_jv, dim3(1), dim3(256), 0, s, p, vC);
 }
 
 // v = g / htil ; partial sums of g^2/htil, htil*y^2, -g*y, max|g|
@@ -1745,12 +1751,15 @@ __global__ __launch_bounds__(256) void k_dogleg_vectors(DeviceProblem p) {
   double gh = 0, gn = 0, gd = 0, gm = 0;
   if (i < n) {
     double g, ht, y;
-    if (i < p.d) { g = p.gFull[i]; ht = p.htilC[i]; y = p.yC[i]; p.vC[i] = g / ht; }
+    bool count = true;
+    if (i < p.d) { g = p.gFull[i]; ht = p.htilC[i]; y = p.yC[i]; p.vC[i] = g / ht; count = p.ownsCamera != 0; }
     else { const int k = i - p.d; g = p.bl[k]; ht = p.hL[k]; y = p.yL[k]; p.vL[k] = g / ht; }
-    gh = g * g / ht;
-    gn = ht * y * y;
-    gd = -g * y;
-    gm = fabs(g);
+    if (count) {
+      gh = g * g / ht;
+      gn = ht * y * y;
+      gd = -g * y;
+      gm = fabs(g);
+    }
   }
   const double a = blockSum(gh, red);
   const double b = blockSum(gn, red);
@@ -1782,8 +1791,10 @@ __global__ __launch_bounds__(256) void k_reduce_scalars(DeviceProblem p, int wha
     const double a = sumSlot(PS_COST_REPROJ, nA);
     const double b = sumSlot(PS_COST_FACTORS, nB);
     if (t == 0) {
-      p.scal->costReproj = a; p.scal->costFactors = b;
-      p.scal->cost = a + b + (p.priorM > 0 ? p.scal->costPrior : 0.0);
+      const double bf = p.ownsCamera ? b : 0.0;
+      const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
+      p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
+      p.scal->cost = a + bf + pr;
     }
   } else if (what == 1) {  // dogleg vectors (nA blocks)
     const double a = sumSlot(PS_GHAT, nA), b = sumSlot(PS_GNHAT, nA), c = sumSlot(PS_GDOTGN, nA);
@@ -1797,11 +1808,12 @@ __global__ __launch_bounds__(256) void k_reduce_scalars(DeviceProblem p, int wha
       double m2 = 0;
       for (int k = 0; k < 4; ++k) m2 = fmax(m2, red[k]);
       p.scal->gHatSq = a; p.scal->gnHatSq = b; p.scal->gDotGn = c; p.scal->gradMax = m2;
+      p.scal->failMax = (double)p.scal->cholFail;
     }
   } else if (what == 2 || what == 3) {  // J*v: reproj (nA) + factors/prior (full slot)
     const double a = sumSlot(PS_JV_SQ, nA) , b = sumSlot(PS_JV_DOT, nA);
-    double c = sumSlot(PS_JV_SQ_F, nB), e = sumSlot(PS_JV_DOT_F, nB);
-    if (t == 0 && p.priorM > 0) {
+    double c = sumSlot(PS_JV_SQ_F, p.ownsCamera ? nB : 0), e = sumSlot(PS_JV_DOT_F, p.ownsCamera ? nB : 0);
+    if (t == 0 && p.priorM > 0 && p.ownsCamera) {
       c += p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + kMaxPartials - 1];
       e += p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + kMaxPartials - 1];
     }
@@ -1873,7 +1885,10 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
       if (off >= 0) {
         double xo[7];
         poseOplus(x, p.deltaC + off, xo);
-        for (int k = 0; k < 7; ++k) { xc[k] = xo[k]; st += (x[k] - xo[k]) * (x[k] - xo[k]); xn += x[k] * x[k]; }
+        for (int k = 0; k < 7; ++k) {
+          xc[k] = xo[k];
+          if (p.ownsCamera) { st += (x[k] - xo[k]) * (x[k] - xo[k]); xn += x[k] * x[k]; }
+        }
       } else {
         for (int k = 0; k < 7; ++k) xc[k] = x[k];
       }
@@ -1885,7 +1900,7 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
       for (int k = 0; k < 9; ++k) {
         const double xo = off >= 0 ? x[k] + p.deltaC[off + k] : x[k];
         xc[k] = xo;
-        if (off >= 0) { st += (x[k] - xo) * (x[k] - xo); xn += x[k] * x[k]; }
+        if (off >= 0 && p.ownsCamera) { st += (x[k] - xo) * (x[k] - xo); xn += x[k] * x[k]; }
       }
     }
   } else if (i < nBlk + p.L) {

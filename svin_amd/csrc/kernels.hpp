@@ -67,24 +67,31 @@ struct PriorBlock {
 
 // scalar results of one iteration, read back by the host once per iteration
 struct SolverScalars {
+  // --- 12 summable scalars (contiguous: one all-reduce(sum) in landmark-sharded mode)
+  // group A (8): produced by the step + candidate evaluation
   double cost;            // cost at the evaluated point (current or candidate)
   double costReproj, costFactors, costPrior;
-  double gradMax;         // max |g_full|
+  double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
+  double stepNormSq, xNormSq;
+  // group B (4): produced by the dogleg preparation
   double gHatSq;          // |g_hat|^2
   double jgSq;            // |J (g / htil)|^2          (Cauchy point)
   double gnHatSq;         // |gn_hat|^2
   double gDotGn;          // g_hat . gn_hat
-  double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
-  double stepNormSq, xNormSq;
+  // --- 2 max-reduced scalars
+  double gradMax;         // max |g_full|
+  double failMax;         // (double)cholFail, for the max all-reduce
   double doglegStepNorm;
   int cholFail;           // != 0 when S or a landmark block is not positive definite
   int pad;
 };
+constexpr int kNumSumScalars = 12, kNumMaxScalars = 2;
 
 struct DeviceProblem {
   // sizes
   int nPose, nExt, nSb, L, N, F, nImu, d, dC, priorM, priorBlocks, nCam;
   int anyExtVariable;
+  int ownsCamera;   // landmark-sharded mode: only one rank accumulates the non-landmark factors / camera-side norms
   // tables
   double *pose, *ext, *sb, *lm;
   double *poseC, *extC, *sbC, *lmC;
@@ -127,6 +134,9 @@ void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_
 void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s);
 void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s);
 void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
+// the same in two halves, so that a landmark-sharded solve can all-reduce [S | gRed | gFull | hC] in between
+void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
+void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s);          // Cholesky + GN step (cam + landmarks)
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s);         // g_hat norms, Cauchy J*v pass, gn norms
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms

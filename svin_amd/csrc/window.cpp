@@ -621,8 +621,8 @@ void Window::pack() {
     dPriorScratch_.reserve((size_t)3 * priorM + 9 * hPb.size() + 16);
   }
   const int dpad = ((d + 15) / 16) * 16;
-  dS_.reserve(std::max<size_t>((size_t)d * d, 1));
-  dVec_.reserve((size_t)12 * std::max(d, 1) + 64);
+  // S and the camera-side vectors share one allocation: [S | gRed | gFull | hC | ...] is all-reduced as one message
+  dS_.reserve((size_t)d * d + (size_t)12 * std::max(d, 1) + 64);
   dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
   dChol_.reserve(std::max<size_t>((size_t)dpad * dpad, 1));
   dPartial_.reserve((size_t)16 * 4096);
@@ -639,6 +639,7 @@ void Window::pack() {
   p.nPose = (int)poseIds_.size(); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
+  p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
@@ -661,8 +662,9 @@ void Window::pack() {
   }
   const int dd = std::max(d, 1);
   p.S = dS_.p;
-  p.gRed = dVec_.p; p.gFull = dVec_.p + dd; p.hC = dVec_.p + 2 * dd; p.htilC = dVec_.p + 3 * dd;
-  p.scaleC = dVec_.p + 4 * dd; p.yC = dVec_.p + 5 * dd; p.deltaC = dVec_.p + 6 * dd; p.vC = dVec_.p + 7 * dd;
+  double* vecBase = dS_.p + (size_t)d * d;
+  p.gRed = vecBase; p.gFull = vecBase + dd; p.hC = vecBase + 2 * dd; p.htilC = vecBase + 3 * dd;
+  p.scaleC = vecBase + 4 * dd; p.yC = vecBase + 5 * dd; p.deltaC = vecBase + 6 * dd; p.vC = vecBase + 7 * dd;
   const size_t LL = std::max(L, 1);
   p.Vinv = dLmVec_.p; p.bl = dLmVec_.p + 6 * LL; p.hL = dLmVec_.p + 9 * LL; p.scaleL = dLmVec_.p + 12 * LL;
   p.yL = dLmVec_.p + 15 * LL; p.deltaL = dLmVec_.p + 18 * LL; p.vL = dLmVec_.p + 21 * LL;
@@ -734,7 +736,15 @@ void Window::solve(size_t numIter, bool verbose) {
   const int dpad = ((p.d + 15) / 16) * 16;
   if ((size_t)(16 * 17 + (size_t)std::max(dpad, 16) * 17) * 8 > 160 * 1024)
     throw std::runtime_error("reduced system too large for the single-workgroup solver (d > ~1100)");
+  // landmark-sharded mode: partial sums are all-reduced at three points per iteration
+  auto AR = [&](void* ptr, size_t n, int op) {
+    if (world_ <= 1) return;
+    HIP_OK(hipStreamSynchronize(s));
+    if (!allreduce_ || allreduce_(ptr, (uint64_t)n, op, allreduceUser_) != 0) throw std::runtime_error("all-reduce callback failed");
+  };
+  double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..11] group B, [12..13] max group
   evaluateAll(false, s);
+  AR(scalD, 4, 0);
   SolverScalars sc = readScalars();
   double x_cost = sc.cost;
   summary_.initial_cost = x_cost;
@@ -764,13 +774,19 @@ void Window::solve(size_t numIter, bool verbose) {
     bool stepOk = true;
     while (true) {
       if (!reuse) {
-        launchBuildNormalEquations(p, mu, initScale, s);
+        launchAccumulateNormalEquations(p, mu, initScale, s);
+        AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
+        launchFinalizeNormalEquations(p, mu, initScale, s);
         launchSolveReduced(p, s);
         launchDoglegPrepare(p, s);
+        AR(scalD + 8, 4, 0);
+        AR(scalD + 12, 2, 1);
       }
       launchDoglegStep(p, radius, s);
       evaluateAll(true, s);
+      AR(scalD, 8, 0);
       sc = readScalars();
+      if (world_ > 1) sc.cholFail = sc.failMax != 0.0 ? 1 : 0;
       if (!reuse && sc.cholFail) {
         mu *= mu_increase;
         if (mu < max_mu) continue;

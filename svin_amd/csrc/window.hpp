@@ -150,6 +150,10 @@ class Window {
   bool isInImuWindow(uint64_t id) const;
   const Summary& summary() const { return summary_; }
   void setTolerances(double f, double g, double p) { fTol_ = f; gTol_ = g; pTol_ = p; }
+  // landmark-sharded multi-GPU mode: every rank holds all states and the factors between them, plus its own
+  // range of landmarks; `fn` all-reduces `count` doubles at device address `ptr` in place (op 0 = sum, 1 = max).
+  typedef int (*AllReduceFn)(void* ptr, uint64_t count, int op, void* user);
+  void setDistributed(int rank, int world, AllReduceFn fn, void* user) { rank_ = rank; world_ = world; allreduce_ = fn; allreduceUser_ = user; }
 
   // inspection hooks
   int evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap);
@@ -185,6 +189,9 @@ class Window {
   friend class Marginalizer;
 
   int device_ = 0;
+  int rank_ = 0, world_ = 1;
+  AllReduceFn allreduce_ = nullptr;
+  void* allreduceUser_ = nullptr;
   hipStream_t stream_ = nullptr;
   uint64_t idCounter_ = 0;
   std::vector<CameraModel> cameras_;

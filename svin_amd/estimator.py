@@ -49,7 +49,7 @@ EXPORTS = [
     "svin_ba_remove_observation", "svin_ba_remove_observation_by_id", "svin_ba_optimize", "svin_ba_prepare",
     "svin_ba_solve_prepared", "svin_ba_finish", "svin_ba_invalidate_preintegration",
     "svin_ba_set_optimization_time_limit", "svin_ba_apply_marginalization_strategy", "svin_ba_get_summary",
-    "svin_ba_set_solver_tolerances", "svin_ba_get_T_WS", "svin_ba_get_speed_and_bias", "svin_ba_get_camera_sensor_states",
+    "svin_ba_set_solver_tolerances", "svin_ba_set_distributed", "svin_ba_get_T_WS", "svin_ba_get_speed_and_bias", "svin_ba_get_camera_sensor_states",
     "svin_ba_get_landmark", "svin_ba_is_landmark_added", "svin_ba_set_T_WS", "svin_ba_set_speed_and_bias",
     "svin_ba_set_camera_sensor_states", "svin_ba_set_landmark", "svin_ba_num_frames", "svin_ba_num_landmarks",
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
@@ -103,6 +103,7 @@ def load_library():
     sig("svin_ba_apply_marginalization_strategy", i32, vp, u64, u64, pu64, i32, C.POINTER(C.c_int))
     sig("svin_ba_get_summary", i32, vp, C.POINTER(SummaryStruct))
     sig("svin_ba_set_solver_tolerances", i32, vp, f64, f64, f64)
+    sig("svin_ba_set_distributed", i32, vp, i32, i32, C.c_void_p, C.c_void_p)
     sig("svin_ba_get_T_WS", i32, vp, u64, pd)
     sig("svin_ba_get_speed_and_bias", i32, vp, u64, u64, pd)
     sig("svin_ba_get_camera_sensor_states", i32, vp, u64, u64, pd)
@@ -235,6 +236,12 @@ class Estimator:
 
     def invalidate_preintegration(self):
         self.L.svin_ba_invalidate_preintegration(self.h)
+
+    def set_distributed(self, rank, world, allreduce_cb):
+        """landmark-sharded mode; `allreduce_cb` is a distributed.ALLREDUCE_FN instance (kept alive here)"""
+        self._allreduce_cb = allreduce_cb
+        self._check(self.L.svin_ba_set_distributed(self.h, rank, world, C.cast(allreduce_cb, C.c_void_p), None),
+                    "set_distributed")
 
     def set_time_limit(self, tl, min_iter):
         return bool(self.L.svin_ba_set_optimization_time_limit(self.h, tl, min_iter))

@@ -273,3 +273,59 @@ def test_config2_full_size_properties(gpu_lib):
     gpu.optimize(5)
     T_after = np.stack([gpu.get_T_WS(a) for a in fg])
     assert np.max(np.abs(T_before - T_after)) < 1e-6
+
+
+def test_wide_window_global_paths(gpu_lib):
+    """16 keyframes: dC = 96 (global-atomic Schur accumulation) and d = 240 (global-memory Cholesky)."""
+    spec = syn.make_window(P=16, L=600, n_obs=9000, seed=61, frame_dt=0.25)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    gpu.optimize(8)
+    cpu.optimize(8)
+    sg, sc = gpu.summary(), cpu.summary()
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    log("wide window gpu", sg, "cpu", sc, "pose diff", worst)
+    assert sg["iterations"] == sc["iterations"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    assert worst < 1e-4
+
+
+def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
+    """the landmark-sharded solve (2 ranks emulated by 2 threads on one GPU, all-reduce through a
+    barrier) must reproduce the single-GPU solve."""
+    import threading
+    from svin_amd.estimator import Estimator
+    from svin_amd import distributed as sd
+    spec = syn.make_window(P=6, L=300, n_obs=3000, seed=71)
+    ref = Estimator(0)
+    f_ref, l_ref = syn.feed(ref, spec)
+    ref.optimize(10)
+    world = 2
+    ar = sd.ThreadAllReduce(world)
+    ests, frames, errs = [], [], []
+    for r in range(world):
+        e = Estimator(0)
+        f, l = syn.feed(e, sd.shard_spec(spec, r, world))
+        e.set_distributed(r, world, ar.callback(r))
+        ests.append(e)
+        frames.append(f)
+
+    def run(r):
+        try:
+            ests[r].optimize(10)
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+            ar.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    s_ref = ref.summary()
+    for r in range(world):
+        s = ests[r].summary()
+        worst = max(pose_diff(ests[r].get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(frames[r], f_ref))
+        log("sharded rank", r, "summary", s, "pose diff vs single-GPU", worst)
+        assert s["iterations"] == s_ref["iterations"]
+        assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+        assert worst < 1e-9
