@@ -685,6 +685,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     q.nPose = (int)(hPose.size() / 7); q.nExt = (int)(hExt.size() / 7); q.nSb = (int)jSb.size();
     q.L = Lm; q.N = N; q.F = F; q.nImu = (int)hImu.size(); q.d = m; q.dC = 0; q.nCam = (int)cameras_.size();
     q.anyExtVariable = anyExtVar ? 1 : 0;
+    q.ownsCamera = 1;
     q.pose = bPose.p; q.ext = bExt.p; q.sb = bSb.p; q.lm = bLm.p;
     q.poseC = bPose.p; q.extC = bExt.p; q.sbC = bSb.p; q.lmC = bLm.p;
     q.poseOff = bOP.p; q.extOff = bOE.p; q.sbOff = bOS.p;

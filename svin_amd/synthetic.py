@@ -258,8 +258,11 @@ def stamp_of(t0_sec, t):
 
 def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=0.5, pixel_noise=1.0, kp_size=8.0,
                 imu_noise=True, pose_noise=(0.05, 0.01), lm_noise=0.1, depth_range=(2.0, 15.0), sonar=False, depth=False,
-                keyframe_every=1, t0_sec=1000):
-    """Build one seeded synthetic window (config #2 defaults: 10 KF / 2 000 landmarks / 20 000 residuals)."""
+                keyframe_every=1, t0_sec=1000, traj=None):
+    """Build one seeded synthetic window (config #2 defaults: 10 KF / 2 000 landmarks / 20 000 residuals).
+
+    imu_noise: True = discrete white noise sigma/sqrt(dt); "testestimator" = the reference test's model
+    (uniform[-1,1] * sigma * sqrt(dt), TestEstimator.cpp:90-96); False = none.  traj: Trajectory kwargs."""
     rng = np.random.Generator(np.random.PCG64(seed))
     if rig == "euroc":
         cams, imu_params, sig = euroc_rig()
@@ -269,7 +272,7 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
         cams, imu_params, sig = test_rig(int(rig[4:] or 0))
     else:
         raise ValueError(rig)
-    traj = Trajectory(imu_params["g"])
+    traj = Trajectory(imu_params["g"], **(traj or {}))
     rate = imu_params["rate"]
     times = np.arange(P) * frame_dt
     # IMU stream covering [ -2/rate, T + 2/rate ]
@@ -279,7 +282,10 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
     dt = 1.0 / rate
     for i, t in enumerate(imu_times):
         w, a = traj.imu(t)
-        if imu_noise:
+        if imu_noise == "testestimator":
+            w = w + rng.uniform(-1, 1, 3) * imu_params["sigma_g_c"] * np.sqrt(dt)
+            a = a + rng.uniform(-1, 1, 3) * imu_params["sigma_a_c"] * np.sqrt(dt)
+        elif imu_noise:
             w = w + rng.normal(size=3) * imu_params["sigma_g_c"] / np.sqrt(dt)
             a = a + rng.normal(size=3) * imu_params["sigma_a_c"] / np.sqrt(dt)
         imu_meas[i, :3], imu_meas[i, 3:] = w, a
