@@ -235,7 +235,13 @@ struct FactorShared {
   double st[72];      // staged IMU pre-integration state (Delta_t .. dp_db_g, 56 doubles)
   double xs[32];      // staged parameter blocks x0(7) s0(9) x1(7) s1(9)
   double rw[15];      // weighted residual
-  int flag;
+  // re-preintegration pipeline (imuIntegrate): per-step inputs that do not depend on the recurrence (phase 0),
+  // per-step F_delta blocks produced by the state recurrence (phase 1) and consumed by the covariance
+  // recurrence (phase 2); N is the dense 9x15 expansion of (F_delta - I) for the step in flight
+  double pre[128][32];
+  double fb[128][56];
+  double N[9 * 15];
+  int flag, used;
 };
 
 // 15x15 helpers on LDS matrices, executed by the whole workgroup (blockDim >= 225)
@@ -277,144 +283,215 @@ struct ImuState {
   double Ci[9], Cdi[9], ai[3], adi[3], dal[9], dv[9], dp[9], Delta_t;
   int used;
 };
+constexpr int kImuSuper = 128;  // steps staged in LDS at a time
+constexpr int kImuChunk = 32;   // pipeline granularity between the state wave and the covariance wave
+
+// crossMx(v)[i][j]
+__device__ __forceinline__ double crossElem(double x, double y, double z, int i, int j) {
+  if (i == j) return 0.0;
+  if (i == 0) return j == 1 ? -z : y;
+  if (i == 1) return j == 0 ? z : -x;
+  return j == 0 ? -y : x;
+}
+
+// Re-preintegration as a three-phase pipeline inside one workgroup (>= 128 threads):
+//   phase 0  all threads, one integration step each: time bookkeeping, interpolation at the interval ends,
+//            saturation test, omega/acc minus bias, dq, R(dq^-1), rightJacobian*dt   -> sh.pre
+//   phase 1  wave 0: the serial recurrence on the 3x3 state (Delta_q, C integrals, cross, bias Jacobians);
+//            emits the blocks of F_delta per step                                      -> sh.fb
+//   phase 2  wave 1: covariance recurrence P = F P F^T + Q on sh.P (one chunk behind wave 0), exploiting the
+//            block structure of F_delta - I (rows 0-8 only), wave-level synchronisation only.
+// Arithmetic restated from ImuError.cpp:118-243 (redo) / :309-452 (propagation); see imuRedoPreintegration.
 template <bool REDO>
 __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, const double* __restrict__ M,
                              const double* sb, FactorShared& sh, ImuState& st) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int n = im.sampleCount;
+  const uint32_t t0[2] = {im.t0[0], im.t0[1]}, end[2] = {im.t1[0], im.t1[1]};
+  // recurrence state (meaningful in wave 0 only)
   Quat Dq = {0, 0, 0, 1};
+  Mat3 C = quatToR(Dq);
   double Ci[9] = {0}, Cdi[9] = {0}, ai[3] = {0}, adi[3] = {0}, cross[9] = {0}, dal[9] = {0}, dv[9] = {0}, dp[9] = {0};
+  double Delta_t = 0;
+  int used = 0;
   if (t < 225) sh.P[t] = 0;
   __syncthreads();
-  uint32_t time[2] = {im.t0[0], im.t0[1]};
-  const uint32_t end[2] = {im.t1[0], im.t1[1]};
-  double Delta_t = 0;
-  bool hasStarted = false;
-  const int n = im.sampleCount;
-  int used = 0;
-  for (int it = 0; it < n; ++it) {
-    double w0[3] = {M[6 * it], M[6 * it + 1], M[6 * it + 2]};
-    double a0[3] = {M[6 * it + 3], M[6 * it + 4], M[6 * it + 5]};
-    const bool last = (it + 1 == n);
-    const int nx = last ? it : it + 1;
-    double w1[3] = {M[6 * nx], M[6 * nx + 1], M[6 * nx + 2]};
-    double a1[3] = {M[6 * nx + 3], M[6 * nx + 4], M[6 * nx + 5]};
-    uint32_t nexttime[2] = {last ? end[0] : T[2 * nx], last ? end[1] : T[2 * nx + 1]};
-    double dt = dtSecDev(nexttime, time);
-    if (timeLess(end, nexttime)) {
-      const double interval = dtSecDev(nexttime, T + 2 * it);
-      nexttime[0] = end[0]; nexttime[1] = end[1];
-      dt = dtSecDev(nexttime, time);
-      const double rr = dt / interval;
-      for (int k = 0; k < 3; ++k) { w1[k] = (1.0 - rr) * w0[k] + rr * w1[k]; a1[k] = (1.0 - rr) * a0[k] + rr * a1[k]; }
-    }
-    if (dt <= 0.0) continue;
-    Delta_t += dt;
-    if (!hasStarted) {
-      hasStarted = true;
-      const double rr = dt / dtSecDev(nexttime, T + 2 * it);
-      for (int k = 0; k < 3; ++k) { w0[k] = rr * w0[k] + (1.0 - rr) * w1[k]; a0[k] = rr * a0[k] + (1.0 - rr) * a1[k]; }
-    }
-    double sigma_g_c = im.par.sigma_g_c, sigma_a_c = im.par.sigma_a_c;
-    bool gs = false, as = false;
-    for (int k = 0; k < 3; ++k) {
-      gs = gs || fabs(w0[k]) > im.par.g_max || fabs(w1[k]) > im.par.g_max;
-      as = as || fabs(a0[k]) > im.par.a_max || fabs(a1[k]) > im.par.a_max;
-    }
-    if (gs) sigma_g_c *= 100;
-    if (as) sigma_a_c *= 100;
-    const double wt[3] = {0.5 * (w0[0] + w1[0]) - sb[3], 0.5 * (w0[1] + w1[1]) - sb[4], 0.5 * (w0[2] + w1[2]) - sb[5]};
-    const double at[3] = {0.5 * (a0[0] + a1[0]) - sb[6], 0.5 * (a0[1] + a1[1]) - sb[7], 0.5 * (a0[2] + a1[2]) - sb[8]};
-    const double theta_half = sqrt(wt[0] * wt[0] + wt[1] * wt[1] + wt[2] * wt[2]) * 0.5 * dt;
-    const double sc = sinc(theta_half);
-    const Quat dq = {sc * wt[0] * 0.5 * dt, sc * wt[1] * 0.5 * dt, sc * wt[2] * 0.5 * dt, cos(theta_half)};
-    const Quat Dq1 = qmul(Dq, dq);
-    const Mat3 C = quatToR(Dq), C1 = quatToR(Dq1);
-    double Cs[9];
-    for (int k = 0; k < 9; ++k) Cs[k] = C.m[k] + C1.m[k];
-    const double Csa[3] = {Cs[0] * at[0] + Cs[1] * at[1] + Cs[2] * at[2], Cs[3] * at[0] + Cs[4] * at[1] + Cs[5] * at[2],
-                           Cs[6] * at[0] + Cs[7] * at[1] + Cs[8] * at[2]};
-    double Ci1[9], ai1[3], pterm[3];
-    for (int k = 0; k < 9; ++k) Ci1[k] = Ci[k] + 0.5 * Cs[k] * dt;
-    for (int k = 0; k < 3; ++k) ai1[k] = ai[k] + 0.5 * Csa[k] * dt;
-    double B012[9];
-    for (int k = 0; k < 9; ++k) B012[k] = -Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
-    for (int k = 0; k < 9; ++k) Cdi[k] += Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
-    for (int k = 0; k < 3; ++k) pterm[k] = ai[k] * dt + 0.25 * Csa[k] * dt * dt;
-    for (int k = 0; k < 3; ++k) adi[k] += pterm[k];
-    double RJ[9], t9[9];
-    rightJacobianDev(wt[0] * dt, wt[1] * dt, wt[2] * dt, RJ);
-    if (REDO) {
-      mm3(C1.m, RJ, t9);
-      for (int k = 0; k < 9; ++k) dal[k] += t9[k] * dt;
-    } else {
-      for (int k = 0; k < 9; ++k) dal[k] += dt * C1.m[k];
-    }
-    const Mat3 Rdqi = quatToR(qinv(dq));
-    double cross1[9];
-    mm3(Rdqi.m, cross, cross1);
-    for (int k = 0; k < 9; ++k) cross1[k] += RJ[k] * dt;
-    double ax[9], t1[9], t2[9], Mm[9];
-    crossMxDev(at[0], at[1], at[2], ax);
-    mm3(C.m, ax, t1);
-    mm3(t1, cross, Mm);
-    mm3(C1.m, ax, t1);
-    mm3(t1, cross1, t2);
-    for (int k = 0; k < 9; ++k) Mm[k] += t2[k];
-    double dv1[9], F09[9];
-    for (int k = 0; k < 9; ++k) dv1[k] = dv[k] + 0.5 * dt * Mm[k];
-    for (int k = 0; k < 9; ++k) F09[k] = dt * dv[k] + 0.25 * dt * dt * Mm[k];
-    for (int k = 0; k < 9; ++k) dp[k] += F09[k];
-    // covariance propagation P = F P F^T + Q (:197-230)
-    __syncthreads();
-    if (t < 225) sh.Fd[t] = (t / 15 == t % 15) ? 1.0 : 0.0;
-    __syncthreads();
-    if (t == 0) {
-      double X[9];
-      crossMxDev(pterm[0], pterm[1], pterm[2], X);
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-          sh.Fd[(0 + a) * 15 + 3 + b] = -X[a * 3 + b];
-          sh.Fd[(0 + a) * 15 + 6 + b] = (a == b) ? dt : 0.0;
-          sh.Fd[(0 + a) * 15 + 9 + b] = F09[a * 3 + b];
-          sh.Fd[(0 + a) * 15 + 12 + b] = B012[a * 3 + b];
-          sh.Fd[(3 + a) * 15 + 9 + b] = -dt * C1.m[a * 3 + b];
-          sh.Fd[(6 + a) * 15 + 9 + b] = 0.5 * dt * Mm[a * 3 + b];
-          sh.Fd[(6 + a) * 15 + 12 + b] = -0.5 * Cs[a * 3 + b] * dt;
-        }
-      crossMxDev(0.5 * Csa[0] * dt, 0.5 * Csa[1] * dt, 0.5 * Csa[2] * dt, X);
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) sh.Fd[(6 + a) * 15 + 3 + b] = -X[a * 3 + b];
-    }
-    __syncthreads();
-    if (t < 225) {
-      const int a = t / 15, b = t % 15;
-      double s = 0;
-      for (int k = 0; k < 15; ++k) s += sh.Fd[a * 15 + k] * sh.P[k * 15 + b];
-      sh.T[t] = s;
-    }
-    __syncthreads();
-    if (t < 225) {
-      const int a = t / 15, b = t % 15;
-      double s = 0;
-      for (int k = 0; k < 15; ++k) s += sh.T[a * 15 + k] * sh.Fd[b * 15 + k];
-      if (a == b) {
-        const double s2v = REDO ? dt * sigma_a_c * sigma_a_c : dt * sigma_a_c * im.par.sigma_a_c;
-        if (a < 3) s += 0.5 * dt * dt * s2v;
-        else if (a < 6) s += dt * sigma_g_c * sigma_g_c;
-        else if (a < 9) s += s2v;
-        else if (a < 12) s += dt * im.par.sigma_gw_c * im.par.sigma_gw_c;
-        else s += dt * im.par.sigma_aw_c * im.par.sigma_aw_c;
+  for (int s0 = 0; s0 < n; s0 += kImuSuper) {
+    const int ns = min(kImuSuper, n - s0);
+    // ---------------- phase 0
+    if (t < ns) {
+      const int it = s0 + t;
+      double w0[3] = {M[6 * it], M[6 * it + 1], M[6 * it + 2]};
+      double a0[3] = {M[6 * it + 3], M[6 * it + 4], M[6 * it + 5]};
+      const bool last = (it + 1 == n);
+      const int nx = last ? it : it + 1;
+      double w1[3] = {M[6 * nx], M[6 * nx + 1], M[6 * nx + 2]};
+      double a1[3] = {M[6 * nx + 3], M[6 * nx + 4], M[6 * nx + 5]};
+      const uint32_t tIt[2] = {T[2 * it], T[2 * it + 1]};
+      // `time` of the reference loop: t0 until the first executed step, the sample time afterwards
+      const bool prevStarted = (it > 0) && timeLess(t0, tIt);
+      const uint32_t time[2] = {prevStarted ? tIt[0] : t0[0], prevStarted ? tIt[1] : t0[1]};
+      uint32_t nexttime[2] = {last ? end[0] : T[2 * nx], last ? end[1] : T[2 * nx + 1]};
+      double dt = dtSecDev(nexttime, time);
+      if (timeLess(end, nexttime)) {
+        const double interval = dtSecDev(nexttime, tIt);
+        nexttime[0] = end[0]; nexttime[1] = end[1];
+        dt = dtSecDev(nexttime, time);
+        const double rr = dt / interval;
+        for (int k = 0; k < 3; ++k) { w1[k] = (1.0 - rr) * w0[k] + rr * w1[k]; a1[k] = (1.0 - rr) * a0[k] + rr * a1[k]; }
       }
-      sh.P[t] = s;
+      const bool exec = (dt > 0.0) && timeLess(time, end);
+      if (exec && !prevStarted) {
+        const double rr = dt / dtSecDev(nexttime, tIt);
+        for (int k = 0; k < 3; ++k) { w0[k] = rr * w0[k] + (1.0 - rr) * w1[k]; a0[k] = rr * a0[k] + (1.0 - rr) * a1[k]; }
+      }
+      double sigma_g_c = im.par.sigma_g_c, sigma_a_c = im.par.sigma_a_c;
+      bool gs = false, as = false;
+      for (int k = 0; k < 3; ++k) {
+        gs = gs || fabs(w0[k]) > im.par.g_max || fabs(w1[k]) > im.par.g_max;
+        as = as || fabs(a0[k]) > im.par.a_max || fabs(a1[k]) > im.par.a_max;
+      }
+      if (gs) sigma_g_c *= 100;
+      if (as) sigma_a_c *= 100;
+      const double wt[3] = {0.5 * (w0[0] + w1[0]) - sb[3], 0.5 * (w0[1] + w1[1]) - sb[4], 0.5 * (w0[2] + w1[2]) - sb[5]};
+      const double at[3] = {0.5 * (a0[0] + a1[0]) - sb[6], 0.5 * (a0[1] + a1[1]) - sb[7], 0.5 * (a0[2] + a1[2]) - sb[8]};
+      const double theta_half = sqrt(wt[0] * wt[0] + wt[1] * wt[1] + wt[2] * wt[2]) * 0.5 * dt;
+      const double sc = sinc(theta_half);
+      const Quat dq = {sc * wt[0] * 0.5 * dt, sc * wt[1] * 0.5 * dt, sc * wt[2] * 0.5 * dt, cos(theta_half)};
+      const Mat3 Rdqi = quatToR(qinv(dq));
+      double RJ[9];
+      rightJacobianDev(wt[0] * dt, wt[1] * dt, wt[2] * dt, RJ);
+      double* pr = sh.pre[t];
+      pr[0] = dt; pr[1] = at[0]; pr[2] = at[1]; pr[3] = at[2];
+      pr[4] = dq.x; pr[5] = dq.y; pr[6] = dq.z; pr[7] = dq.w;
+      for (int k = 0; k < 9; ++k) { pr[8 + k] = Rdqi.m[k]; pr[17 + k] = RJ[k] * dt; }
+      pr[26] = dt * sigma_g_c * sigma_g_c;
+      pr[27] = REDO ? dt * sigma_a_c * sigma_a_c : dt * sigma_a_c * im.par.sigma_a_c;
+      pr[28] = exec ? 1.0 : 0.0;
     }
     __syncthreads();
-    // memory shift
-    Dq = Dq1;
-    for (int k = 0; k < 9; ++k) { Ci[k] = Ci1[k]; cross[k] = cross1[k]; dv[k] = dv1[k]; }
-    for (int k = 0; k < 3; ++k) ai[k] = ai1[k];
-    time[0] = nexttime[0]; time[1] = nexttime[1];
-    ++used;
-    if (nexttime[0] == end[0] && nexttime[1] == end[1]) break;
+    // ---------------- phases 1 and 2, pipelined by chunks
+    const int nChunks = (ns + kImuChunk - 1) / kImuChunk;
+    for (int c = 0; c <= nChunks; ++c) {
+      if (wave == 0 && c < nChunks) {
+        const int hi = min(ns, (c + 1) * kImuChunk);
+        for (int i = c * kImuChunk; i < hi; ++i) {
+          const double* pr = sh.pre[i];
+          double* fb = sh.fb[i];
+          const bool exec = pr[28] != 0.0;
+          if (lane == 0) fb[54] = pr[28];
+          if (!exec) continue;
+          const double dt = pr[0];
+          const double at[3] = {pr[1], pr[2], pr[3]};
+          const Quat dq = {pr[4], pr[5], pr[6], pr[7]};
+          Delta_t += dt;
+          ++used;
+          const Quat Dq1 = qmul(Dq, dq);
+          const Mat3 C1 = quatToR(Dq1);
+          double Cs[9];
+          for (int k = 0; k < 9; ++k) Cs[k] = C.m[k] + C1.m[k];
+          const double Csa[3] = {Cs[0] * at[0] + Cs[1] * at[1] + Cs[2] * at[2], Cs[3] * at[0] + Cs[4] * at[1] + Cs[5] * at[2],
+                                 Cs[6] * at[0] + Cs[7] * at[1] + Cs[8] * at[2]};
+          double pterm[3], B012[9];
+          for (int k = 0; k < 9; ++k) B012[k] = -Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
+          for (int k = 0; k < 9; ++k) Cdi[k] += Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
+          for (int k = 0; k < 3; ++k) pterm[k] = ai[k] * dt + 0.25 * Csa[k] * dt * dt;
+          for (int k = 0; k < 3; ++k) adi[k] += pterm[k];
+          for (int k = 0; k < 9; ++k) Ci[k] += 0.5 * Cs[k] * dt;
+          for (int k = 0; k < 3; ++k) ai[k] += 0.5 * Csa[k] * dt;
+          if (REDO) {
+            double t9[9];
+            mm3(C1.m, pr + 17, t9);  // C_1 * rightJacobian * dt
+            for (int k = 0; k < 9; ++k) dal[k] += t9[k];
+          } else {
+            for (int k = 0; k < 9; ++k) dal[k] += dt * C1.m[k];
+          }
+          double cross1[9];
+          mm3(pr + 8, cross, cross1);
+          for (int k = 0; k < 9; ++k) cross1[k] += pr[17 + k];
+          double ax[9], t1[9], t2[9], Mm[9];
+          crossMxDev(at[0], at[1], at[2], ax);
+          mm3(C.m, ax, t1);
+          mm3(t1, cross, Mm);
+          mm3(C1.m, ax, t1);
+          mm3(t1, cross1, t2);
+          for (int k = 0; k < 9; ++k) Mm[k] += t2[k];
+          double F09[9];
+          for (int k = 0; k < 9; ++k) F09[k] = dt * dv[k] + 0.25 * dt * dt * Mm[k];
+          for (int k = 0; k < 9; ++k) dp[k] += F09[k];
+          for (int k = 0; k < 9; ++k) dv[k] += 0.5 * dt * Mm[k];
+          if (lane == 0) {
+            fb[0] = pterm[0]; fb[1] = pterm[1]; fb[2] = pterm[2]; fb[3] = dt;
+            for (int k = 0; k < 9; ++k) {
+              fb[4 + k] = F09[k]; fb[13 + k] = B012[k]; fb[22 + k] = -dt * C1.m[k];
+              fb[34 + k] = 0.5 * dt * Mm[k]; fb[43 + k] = -0.5 * Cs[k] * dt;
+            }
+            fb[31] = 0.5 * Csa[0] * dt; fb[32] = 0.5 * Csa[1] * dt; fb[33] = 0.5 * Csa[2] * dt;
+            fb[52] = pr[26]; fb[53] = pr[27];
+          }
+          Dq = Dq1;
+          C = C1;
+          for (int k = 0; k < 9; ++k) cross[k] = cross1[k];
+        }
+      }
+      if (wave == 1 && c > 0) {
+        const int hi = min(ns, c * kImuChunk);
+        for (int i = (c - 1) * kImuChunk; i < hi; ++i) {
+          const double* fb = sh.fb[i];
+          if (fb[54] == 0.0) continue;
+          // expand N = F_delta - I (rows 0..8)
+          for (int e = lane; e < 135; e += 64) {
+            const int a = e / 15, cc = e % 15, br = a / 3, ii = a % 3, bc = cc / 3, jj = cc % 3;
+            double v = 0.0;
+            if (br == 0) {
+              if (bc == 1) v = -crossElem(fb[0], fb[1], fb[2], ii, jj);
+              else if (bc == 2) v = (ii == jj) ? fb[3] : 0.0;
+              else if (bc == 3) v = fb[4 + ii * 3 + jj];
+              else if (bc == 4) v = fb[13 + ii * 3 + jj];
+            } else if (br == 1) {
+              if (bc == 3) v = fb[22 + ii * 3 + jj];
+            } else {
+              if (bc == 1) v = -crossElem(fb[31], fb[32], fb[33], ii, jj);
+              else if (bc == 3) v = fb[34 + ii * 3 + jj];
+              else if (bc == 4) v = fb[43 + ii * 3 + jj];
+            }
+            sh.N[e] = v;
+          }
+          waveSync();
+          // T = F P : rows 0..8 change, rows 9..14 are copies
+          for (int e = lane; e < 225; e += 64) {
+            const int a = e / 15, b = e % 15;
+            double sacc = sh.P[e];
+            if (a < 9) {
+#pragma unroll
+              for (int k = 3; k < 15; ++k) sacc += sh.N[a * 15 + k] * sh.P[k * 15 + b];
+            }
+            sh.T[e] = sacc;
+          }
+          waveSync();
+          // P = T F^T + Q
+          const double dt = fb[3], sg2 = fb[52], sa2 = fb[53];
+          for (int e = lane; e < 225; e += 64) {
+            const int a = e / 15, b = e % 15;
+            double sacc = sh.T[e];
+            if (b < 9) {
+#pragma unroll
+              for (int k = 3; k < 15; ++k) sacc += sh.T[a * 15 + k] * sh.N[b * 15 + k];
+            }
+            if (a == b) {
+              if (a < 3) sacc += 0.5 * dt * dt * sa2;
+              else if (a < 6) sacc += sg2;
+              else if (a < 9) sacc += sa2;
+              else if (a < 12) sacc += dt * im.par.sigma_gw_c * im.par.sigma_gw_c;
+              else sacc += dt * im.par.sigma_aw_c * im.par.sigma_aw_c;
+            }
+            sh.P[e] = sacc;
+          }
+          waveSync();
+        }
+      }
+      __syncthreads();
+    }
   }
   st.Dq = Dq;
   for (int k = 0; k < 9; ++k) { st.Ci[k] = Ci[k]; st.Cdi[k] = Cdi[k]; st.dal[k] = dal[k]; st.dv[k] = dv[k]; st.dp[k] = dp[k]; }
