@@ -235,12 +235,12 @@ struct FactorShared {
   double st[72];      // staged IMU pre-integration state (Delta_t .. dp_db_g, 56 doubles)
   double xs[32];      // staged parameter blocks x0(7) s0(9) x1(7) s1(9)
   double rw[15];      // weighted residual
-  // re-preintegration pipeline (imuIntegrate): per-step inputs that do not depend on the recurrence (phase 0),
-  // per-step F_delta blocks produced by the state recurrence (phase 1) and consumed by the covariance
-  // recurrence (phase 2); N is the dense 9x15 expansion of (F_delta - I) for the step in flight
-  double pre[128][32];
-  double fb[128][56];
-  double N[9 * 15];
+  // re-preintegration (imuIntegrate): per-step inputs (P0), the two serial chains (P1), the blocks of F_delta
+  // per step (P2/P3, double buffered for the covariance wave) and the published integrals
+  double pre[64 * 33];
+  double fb[2][64 * 87];
+  double seq[65 * 13];
+  double tot[64];
   int flag, used;
 };
 
@@ -283,42 +283,147 @@ struct ImuState {
   double Ci[9], Cdi[9], ai[3], adi[3], dal[9], dv[9], dp[9], Delta_t;
   int used;
 };
-constexpr int kImuSuper = 128;  // steps staged in LDS at a time
-constexpr int kImuChunk = 32;   // pipeline granularity between the state wave and the covariance wave
+constexpr int kImuSuper = 64;  // integration steps staged in LDS per round
+constexpr int kPreLd = 33;     // odd row strides keep the one-thread-per-step phases off the same LDS banks
+constexpr int kFbLd = 87;
+constexpr int kSeqLd = 13;
 
-// crossMx(v)[i][j]
-__device__ __forceinline__ double crossElem(double x, double y, double z, int i, int j) {
-  if (i == j) return 0.0;
-  if (i == 0) return j == 1 ? -z : y;
-  if (i == 1) return j == 0 ? z : -x;
-  return j == 0 ? -y : x;
+// -crossMx(v)[i][j] = sign * v[comp]  (sign 0 on the diagonal)
+__device__ __forceinline__ void negCrossDesc(int i, int j, int& comp, double& sign) {
+  comp = 0; sign = 0.0;
+  if (i == j) return;
+  comp = 3 - i - j;
+  sign = ((j - i + 3) % 3 == 1) ? 1.0 : -1.0;
 }
 
-// Re-preintegration as a three-phase pipeline inside one workgroup (>= 128 threads):
-//   phase 0  all threads, one integration step each: time bookkeeping, interpolation at the interval ends,
-//            saturation test, omega/acc minus bias, dq, R(dq^-1), rightJacobian*dt   -> sh.pre
-//   phase 1  wave 0: the serial recurrence on the 3x3 state (Delta_q, C integrals, cross, bias Jacobians);
-//            emits the blocks of F_delta per step                                      -> sh.fb
-//   phase 2  wave 1: covariance recurrence P = F P F^T + Q on sh.P (one chunk behind wave 0), exploiting the
-//            block structure of F_delta - I (rows 0-8 only), wave-level synchronisation only.
-// Arithmetic restated from ImuError.cpp:118-243 (redo) / :309-452 (propagation); see imuRedoPreintegration.
+#ifdef SVIN_IMU_TIMING
+__device__ double g_imuDbg[8];
+#define IMU_TICK(var) long long var = __builtin_readcyclecounter()
+#define IMU_ACC(slot, a, b, cond) if (cond) atomicAdd(&g_imuDbg[slot], (double)((b) - (a)))
+#else
+#define IMU_TICK(var)
+#define IMU_ACC(slot, a, b, cond)
+#endif
+
+// Re-preintegration (ImuError.cpp:118-243 redo / :309-452 propagation) restructured so that only the two
+// genuinely serial chains stay serial, every round handling kImuSuper integration steps:
+//   P0  one thread per step : time bookkeeping, interpolation at the interval ends, saturation test,
+//                             omega/acc minus bias, dq, R(dq^-1), rightJacobian*dt                -> sh.pre
+//   P1  wave 0 / wave 1     : Delta_q_{k+1} = Delta_q_k (x) dq_k  /  cross_{k+1} = R(dq^-1) cross_k + rJ dt
+//                             (the only recurrences that are not plain sums)                       -> sh.seq
+//   P2  one thread per step : C, C_1, the per-step increments of every integral and the blocks of F_delta
+//                             that do not involve running sums                                      -> sh.fb
+//   P3  wave 0, one lane per scalar component: the running sums C_integral, acc_integral, dv_db_g (in step
+//                             order, like the reference) and the F_delta blocks built from them    -> sh.fb
+//   P4  wave 3              : P <- F P F^T + Q as 2 x 4 v_mfma_f64_16x16x4_f64 per step with P held in the
+//                             MFMA accumulator layout; runs one round behind P0-P3 (sh.fb is double buffered)
 template <bool REDO>
 __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, const double* __restrict__ M,
                              const double* sb, FactorShared& sh, ImuState& st) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int n = im.sampleCount;
   const uint32_t t0[2] = {im.t0[0], im.t0[1]}, end[2] = {im.t1[0], im.t1[1]};
-  // recurrence state (meaningful in wave 0 only)
-  Quat Dq = {0, 0, 0, 1};
-  Mat3 C = quatToR(Dq);
-  double Ci[9] = {0}, Cdi[9] = {0}, ai[3] = {0}, adi[3] = {0}, cross[9] = {0}, dal[9] = {0}, dv[9] = {0}, dp[9] = {0};
-  double Delta_t = 0;
-  int used = 0;
-  if (t < 225) sh.P[t] = 0;
-  __syncthreads();
-  for (int s0 = 0; s0 < n; s0 += kImuSuper) {
-    const int ns = min(kImuSuper, n - s0);
-    // ---------------- phase 0
+  const int nRounds = (n + kImuSuper - 1) / kImuSuper;
+  const double sgw2 = im.par.sigma_gw_c * im.par.sigma_gw_c, saw2 = im.par.sigma_aw_c * im.par.sigma_aw_c;
+  IMU_TICK(qStart);
+
+  Quat Dq = {0, 0, 0, 1};  // wave 0
+  double cross[9] = {0};   // wave 1
+  // wave 0, P3: lane c owns one scalar component: run1 (first sum) and run2 (second sum)
+  //   c 0..8 C_integral/C_doubleintegral, 9..11 acc_integral/acc_doubleintegral, 12..20 dv_db_g/dp_db_g,
+  //   21..29 dalpha_db_g, 30 Delta_t, 31 number of executed steps
+  double run1 = 0, run2 = 0;
+  int iInc = 86, iQ = 86, iOut = 85, tot1 = 60, tot2 = 61;
+  double incSign = 1.0, outSign = 1.0;
+  if (lane < 9) { iInc = 43 + lane; incSign = -1.0; iQ = 55 + lane; iOut = 13 + lane; outSign = -1.0; tot1 = 4 + lane; tot2 = 13 + lane; }
+  else if (lane < 12) { const int k = lane - 9; iInc = 31 + k; iQ = 64 + k; iOut = k; tot1 = 22 + k; tot2 = 25 + k; }
+  else if (lane < 21) { const int k = lane - 12; iInc = 34 + k; iQ = 67 + k; iOut = 4 + k; tot1 = 37 + k; tot2 = 46 + k; }
+  else if (lane < 30) { const int k = lane - 21; iInc = 76 + k; tot1 = 28 + k; }
+  else if (lane == 30) { iInc = 3; tot1 = 55; }
+  else if (lane == 31) { iInc = 54; tot1 = 56; }
+  // wave 3, P4: X = P (even number of executed steps) or P^T (odd) in the accumulator layout
+  // X[(lane>>4)+4r][lane&15]; F_delta entries F[lane&15][(lane>>4)+4q] = fC0 + fS * fb[fIdx]
+  d4_t X = {0, 0, 0, 0};
+  int parity = 0;
+  int fIdx[4], qDiag = -1, dKind = 0;
+  double fS[4], fC0[4];
+  for (int q = 0; q < 4; ++q) {
+    const int i = lane & 15, c = (lane >> 4) + 4 * q;
+    fIdx[q] = 86; fS[q] = 0.0; fC0[q] = (i == c && i < 15) ? 1.0 : 0.0;
+    if (i == c && i < 15) { qDiag = q; dKind = i / 3 + 1; }
+    if (i < 9 && c < 15) {
+      const int br = i / 3, ii = i % 3, bc = c / 3, jj = c % 3;
+      int comp; double sg;
+      if (br == 0) {
+        if (bc == 1) { negCrossDesc(ii, jj, comp, sg); fIdx[q] = comp; fS[q] = sg; }
+        else if (bc == 2) { if (ii == jj) { fIdx[q] = 3; fS[q] = 1.0; } }
+        else if (bc == 3) { fIdx[q] = 4 + ii * 3 + jj; fS[q] = 1.0; }
+        else if (bc == 4) { fIdx[q] = 13 + ii * 3 + jj; fS[q] = 1.0; }
+      } else if (br == 1) {
+        if (bc == 3) { fIdx[q] = 22 + ii * 3 + jj; fS[q] = 1.0; }
+      } else {
+        if (bc == 1) { negCrossDesc(ii, jj, comp, sg); fIdx[q] = 31 + comp; fS[q] = sg; }
+        else if (bc == 3) { fIdx[q] = 34 + ii * 3 + jj; fS[q] = 1.0; }
+        else if (bc == 4) { fIdx[q] = 43 + ii * 3 + jj; fS[q] = 1.0; }
+      }
+    }
+  }
+  // (qDiag, dKind): accumulator register q holds row (lane>>4)+4q, column lane&15 -- the F descriptor's pairing
+  // with rows and columns swapped; the diagonal test is symmetric, so one loop serves both.
+
+  for (int r = 0; r <= nRounds; ++r) {
+    const int s0 = r * kImuSuper;
+    const int ns = r < nRounds ? min(kImuSuper, n - s0) : 0;
+    double* fbw = sh.fb[r & 1];
+    const double* fbr = sh.fb[(r + 1) & 1];
+    const int nsPrev = r > 0 ? min(kImuSuper, n - (s0 - kImuSuper)) : 0;
+    // one quarter of the previous round's covariance steps (wave 3), called between the barriers of P0..P3
+    auto covSegment = [&](int seg) {
+      if (wave != 3) return;
+      IMU_TICK(qc0);
+      const int lo = nsPrev * seg / 4, hi = nsPrev * (seg + 1) / 4;
+      if (lo >= hi) return;
+      // inputs of step i+1 are gathered from LDS while the MFMAs of step i run
+      const double* row = fbr + lo * kFbLd;
+      double g[4], dt = row[3], sg2 = row[52], sa2 = row[53], ex = row[54];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = row[fIdx[q]];
+      for (int i = lo; i < hi; ++i) {
+        const double* rn = fbr + min(i + 1, hi - 1) * kFbLd;
+        double gn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gn[q] = rn[fIdx[q]];
+        const double dtn = rn[3], sg2n = rn[52], sa2n = rn[53], exn = rn[54];
+        if (ex != 0.0) {
+          double f[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f[q] = fC0[q] + fS[q] * g[q];
+          d4_t V = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) V = __builtin_amdgcn_mfma_f64_16x16x4f64(X[q], f[q], V, 0, 0, 0);   // X^T F^T
+          d4_t Y = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], V[q], Y, 0, 0, 0);   // F (X^T F^T)
+          // Q_delta on the diagonal: every lane owns at most one diagonal entry (accumulator register qDiag)
+          double add = dt * saw2;
+          add = (dKind == 4) ? dt * sgw2 : add;
+          add = (dKind == 3) ? sa2 : add;
+          add = (dKind == 2) ? sg2 : add;
+          add = (dKind == 1) ? 0.5 * dt * dt * sa2 : add;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) X[q] = Y[q] + ((q == qDiag) ? add : 0.0);
+          parity ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = gn[q];
+        dt = dtn; sg2 = sg2n; sa2 = sa2n; ex = exn;
+      }
+      IMU_TICK(qc1);
+      IMU_ACC(2, qc0, qc1, t == 192);
+    };
+
+    // ---------------- P0
+    IMU_TICK(qp0);
     if (t < ns) {
       const int it = s0 + t;
       double w0[3] = {M[6 * it], M[6 * it + 1], M[6 * it + 2]};
@@ -361,7 +466,7 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       const Mat3 Rdqi = quatToR(qinv(dq));
       double RJ[9];
       rightJacobianDev(wt[0] * dt, wt[1] * dt, wt[2] * dt, RJ);
-      double* pr = sh.pre[t];
+      double* pr = sh.pre + t * kPreLd;
       pr[0] = dt; pr[1] = at[0]; pr[2] = at[1]; pr[3] = at[2];
       pr[4] = dq.x; pr[5] = dq.y; pr[6] = dq.z; pr[7] = dq.w;
       for (int k = 0; k < 9; ++k) { pr[8 + k] = Rdqi.m[k]; pr[17 + k] = RJ[k] * dt; }
@@ -369,135 +474,156 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       pr[27] = REDO ? dt * sigma_a_c * sigma_a_c : dt * sigma_a_c * im.par.sigma_a_c;
       pr[28] = exec ? 1.0 : 0.0;
     }
+    IMU_TICK(qp1);
+    IMU_ACC(0, qp0, qp1, t == 0);
+    covSegment(0);
     __syncthreads();
-    // ---------------- phases 1 and 2, pipelined by chunks
-    const int nChunks = (ns + kImuChunk - 1) / kImuChunk;
-    for (int c = 0; c <= nChunks; ++c) {
-      if (wave == 0 && c < nChunks) {
-        const int hi = min(ns, (c + 1) * kImuChunk);
-        for (int i = c * kImuChunk; i < hi; ++i) {
-          const double* pr = sh.pre[i];
-          double* fb = sh.fb[i];
-          const bool exec = pr[28] != 0.0;
-          if (lane == 0) fb[54] = pr[28];
-          if (!exec) continue;
-          const double dt = pr[0];
-          const double at[3] = {pr[1], pr[2], pr[3]};
-          const Quat dq = {pr[4], pr[5], pr[6], pr[7]};
-          Delta_t += dt;
-          ++used;
-          const Quat Dq1 = qmul(Dq, dq);
-          const Mat3 C1 = quatToR(Dq1);
-          double Cs[9];
-          for (int k = 0; k < 9; ++k) Cs[k] = C.m[k] + C1.m[k];
-          const double Csa[3] = {Cs[0] * at[0] + Cs[1] * at[1] + Cs[2] * at[2], Cs[3] * at[0] + Cs[4] * at[1] + Cs[5] * at[2],
-                                 Cs[6] * at[0] + Cs[7] * at[1] + Cs[8] * at[2]};
-          double pterm[3], B012[9];
-          for (int k = 0; k < 9; ++k) B012[k] = -Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
-          for (int k = 0; k < 9; ++k) Cdi[k] += Ci[k] * dt + 0.25 * Cs[k] * dt * dt;
-          for (int k = 0; k < 3; ++k) pterm[k] = ai[k] * dt + 0.25 * Csa[k] * dt * dt;
-          for (int k = 0; k < 3; ++k) adi[k] += pterm[k];
-          for (int k = 0; k < 9; ++k) Ci[k] += 0.5 * Cs[k] * dt;
-          for (int k = 0; k < 3; ++k) ai[k] += 0.5 * Csa[k] * dt;
-          if (REDO) {
-            double t9[9];
-            mm3(C1.m, pr + 17, t9);  // C_1 * rightJacobian * dt
-            for (int k = 0; k < 9; ++k) dal[k] += t9[k];
-          } else {
-            for (int k = 0; k < 9; ++k) dal[k] += dt * C1.m[k];
+    IMU_TICK(qp2);
+    // ---------------- P1: the two serial chains, side by side
+    if (wave == 0 && ns > 0) {
+      // Delta_q chain; the inputs of step i+1 are fetched from LDS while step i computes
+      const double* pr = sh.pre;
+      double d0 = pr[4], d1 = pr[5], d2 = pr[6], d3 = pr[7], ex = pr[28];
+      for (int i = 0; i < ns; ++i) {
+        const double* pn = sh.pre + min(i + 1, ns - 1) * kPreLd;
+        const double n0 = pn[4], n1 = pn[5], n2 = pn[6], n3 = pn[7], nex = pn[28];
+        if (lane == 0) { double* sq = sh.seq + i * kSeqLd; sq[0] = Dq.x; sq[1] = Dq.y; sq[2] = Dq.z; sq[3] = Dq.w; }
+        const Quat Dq1 = qmul(Dq, Quat{d0, d1, d2, d3});
+        if (ex != 0.0) Dq = Dq1;
+        d0 = n0; d1 = n1; d2 = n2; d3 = n3; ex = nex;
+      }
+      if (lane == 0) { double* sq = sh.seq + ns * kSeqLd; sq[0] = Dq.x; sq[1] = Dq.y; sq[2] = Dq.z; sq[3] = Dq.w; }
+    }
+    if (wave == 1 && ns > 0) {
+      // cross chain: the three columns are independent, lane c (mod 3) carries column c in cross[0..2]
+      const int c = lane % 3;
+      const double* pr = sh.pre;
+      double R[9], b[3], ex = pr[28];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = pr[8 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) b[k] = pr[17 + 3 * k + c];
+      for (int i = 0; i < ns; ++i) {
+        const double* pn = sh.pre + min(i + 1, ns - 1) * kPreLd;
+        double Rn[9], bn[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rn[k] = pn[8 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bn[k] = pn[17 + 3 * k + c];
+        const double nex = pn[28];
+        if (lane < 3) { double* sq = sh.seq + i * kSeqLd + 4 + c; sq[0] = cross[0]; sq[3] = cross[1]; sq[6] = cross[2]; }
+        double y[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) y[k] = (R[3 * k] * cross[0] + R[3 * k + 1] * cross[1] + R[3 * k + 2] * cross[2]) + b[k];
+        if (ex != 0.0) { cross[0] = y[0]; cross[1] = y[1]; cross[2] = y[2]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b[k] = bn[k];
+        ex = nex;
+      }
+      if (lane < 3) { double* sq = sh.seq + ns * kSeqLd + 4 + c; sq[0] = cross[0]; sq[3] = cross[1]; sq[6] = cross[2]; }
+    }
+    IMU_TICK(qp3);
+    IMU_ACC(1, qp2, qp3, t == 0);
+    IMU_ACC(6, qp2, qp3, t == 64);
+    covSegment(1);
+    __syncthreads();
+    IMU_TICK(qp4);
+    // ---------------- P2
+    if (t < ns) {
+      const double* pr = sh.pre + t * kPreLd;
+      const double* sq = sh.seq + t * kSeqLd;
+      double* fb = fbw + t * kFbLd;
+      if (pr[28] == 0.0) {
+        for (int k = 0; k < kFbLd; ++k) fb[k] = 0.0;
+      } else {
+        const double dt = pr[0];
+        const double at[3] = {pr[1], pr[2], pr[3]};
+        const Mat3 C = quatToR(Quat{sq[0], sq[1], sq[2], sq[3]});
+        const Mat3 C1 = quatToR(Quat{sq[kSeqLd], sq[kSeqLd + 1], sq[kSeqLd + 2], sq[kSeqLd + 3]});
+        double Cs[9];
+        for (int k = 0; k < 9; ++k) Cs[k] = C.m[k] + C1.m[k];
+        const double Csa[3] = {Cs[0] * at[0] + Cs[1] * at[1] + Cs[2] * at[2], Cs[3] * at[0] + Cs[4] * at[1] + Cs[5] * at[2],
+                               Cs[6] * at[0] + Cs[7] * at[1] + Cs[8] * at[2]};
+        double dalInc[9];
+        if (REDO) mm3(C1.m, pr + 17, dalInc);  // C_1 * rightJacobian * dt
+        else for (int k = 0; k < 9; ++k) dalInc[k] = dt * C1.m[k];
+        double ax[9], t1[9], t2[9], Mm[9];
+        crossMxDev(at[0], at[1], at[2], ax);
+        mm3(C.m, ax, t1);
+        mm3(t1, sq + 4, Mm);
+        mm3(C1.m, ax, t1);
+        mm3(t1, sq + kSeqLd + 4, t2);
+        for (int k = 0; k < 9; ++k) Mm[k] += t2[k];
+        fb[0] = fb[1] = fb[2] = 0.0;
+        fb[3] = dt;
+        for (int k = 0; k < 9; ++k) {
+          fb[4 + k] = 0.0; fb[13 + k] = 0.0;
+          fb[22 + k] = -dt * C1.m[k];
+          fb[34 + k] = 0.5 * dt * Mm[k];
+          fb[43 + k] = -0.5 * Cs[k] * dt;
+          fb[55 + k] = 0.25 * Cs[k] * dt * dt;
+          fb[67 + k] = 0.25 * dt * dt * Mm[k];
+          fb[76 + k] = dalInc[k];
+        }
+        for (int k = 0; k < 3; ++k) { fb[31 + k] = 0.5 * Csa[k] * dt; fb[64 + k] = 0.25 * Csa[k] * dt * dt; }
+        fb[52] = pr[26]; fb[53] = pr[27]; fb[54] = 1.0;
+        fb[85] = 0.0; fb[86] = 0.0;
+      }
+    }
+    IMU_TICK(qp5);
+    IMU_ACC(7, qp4, qp5, t == 0);
+    covSegment(2);
+    __syncthreads();
+    IMU_TICK(qp6);
+    // ---------------- P3: running sums in step order; B012 / pterm / F09 need the sums *before* the step
+    if (wave == 0 && ns > 0) {
+      for (int i0 = 0; i0 < ns; i0 += 4) {
+        double dtv[4], inc[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* row = fbw + min(i0 + u, ns - 1) * kFbLd;
+          dtv[u] = row[3]; inc[u] = row[iInc]; qv[u] = row[iQ];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < ns) {
+            const double a = run1 * dtv[u];
+            fbw[(i0 + u) * kFbLd + iOut] = outSign * a + qv[u];
+            run2 += a + qv[u];
+            run1 += incSign * inc[u];
           }
-          double cross1[9];
-          mm3(pr + 8, cross, cross1);
-          for (int k = 0; k < 9; ++k) cross1[k] += pr[17 + k];
-          double ax[9], t1[9], t2[9], Mm[9];
-          crossMxDev(at[0], at[1], at[2], ax);
-          mm3(C.m, ax, t1);
-          mm3(t1, cross, Mm);
-          mm3(C1.m, ax, t1);
-          mm3(t1, cross1, t2);
-          for (int k = 0; k < 9; ++k) Mm[k] += t2[k];
-          double F09[9];
-          for (int k = 0; k < 9; ++k) F09[k] = dt * dv[k] + 0.25 * dt * dt * Mm[k];
-          for (int k = 0; k < 9; ++k) dp[k] += F09[k];
-          for (int k = 0; k < 9; ++k) dv[k] += 0.5 * dt * Mm[k];
-          if (lane == 0) {
-            fb[0] = pterm[0]; fb[1] = pterm[1]; fb[2] = pterm[2]; fb[3] = dt;
-            for (int k = 0; k < 9; ++k) {
-              fb[4 + k] = F09[k]; fb[13 + k] = B012[k]; fb[22 + k] = -dt * C1.m[k];
-              fb[34 + k] = 0.5 * dt * Mm[k]; fb[43 + k] = -0.5 * Cs[k] * dt;
-            }
-            fb[31] = 0.5 * Csa[0] * dt; fb[32] = 0.5 * Csa[1] * dt; fb[33] = 0.5 * Csa[2] * dt;
-            fb[52] = pr[26]; fb[53] = pr[27];
-          }
-          Dq = Dq1;
-          C = C1;
-          for (int k = 0; k < 9; ++k) cross[k] = cross1[k];
         }
       }
-      if (wave == 1 && c > 0) {
-        const int hi = min(ns, c * kImuChunk);
-        for (int i = (c - 1) * kImuChunk; i < hi; ++i) {
-          const double* fb = sh.fb[i];
-          if (fb[54] == 0.0) continue;
-          // expand N = F_delta - I (rows 0..8)
-          for (int e = lane; e < 135; e += 64) {
-            const int a = e / 15, cc = e % 15, br = a / 3, ii = a % 3, bc = cc / 3, jj = cc % 3;
-            double v = 0.0;
-            if (br == 0) {
-              if (bc == 1) v = -crossElem(fb[0], fb[1], fb[2], ii, jj);
-              else if (bc == 2) v = (ii == jj) ? fb[3] : 0.0;
-              else if (bc == 3) v = fb[4 + ii * 3 + jj];
-              else if (bc == 4) v = fb[13 + ii * 3 + jj];
-            } else if (br == 1) {
-              if (bc == 3) v = fb[22 + ii * 3 + jj];
-            } else {
-              if (bc == 1) v = -crossElem(fb[31], fb[32], fb[33], ii, jj);
-              else if (bc == 3) v = fb[34 + ii * 3 + jj];
-              else if (bc == 4) v = fb[43 + ii * 3 + jj];
-            }
-            sh.N[e] = v;
-          }
-          waveSync();
-          // T = F P : rows 0..8 change, rows 9..14 are copies
-          for (int e = lane; e < 225; e += 64) {
-            const int a = e / 15, b = e % 15;
-            double sacc = sh.P[e];
-            if (a < 9) {
+    }
+    IMU_TICK(qp7);
+    IMU_ACC(5, qp6, qp7, t == 0);
+    covSegment(3);
+    __syncthreads();
+  }
+  // publish: covariance (wave 3) and the integrals (wave 0)
+  if (wave == 3) {
 #pragma unroll
-              for (int k = 3; k < 15; ++k) sacc += sh.N[a * 15 + k] * sh.P[k * 15 + b];
-            }
-            sh.T[e] = sacc;
-          }
-          waveSync();
-          // P = T F^T + Q
-          const double dt = fb[3], sg2 = fb[52], sa2 = fb[53];
-          for (int e = lane; e < 225; e += 64) {
-            const int a = e / 15, b = e % 15;
-            double sacc = sh.T[e];
-            if (b < 9) {
-#pragma unroll
-              for (int k = 3; k < 15; ++k) sacc += sh.T[a * 15 + k] * sh.N[b * 15 + k];
-            }
-            if (a == b) {
-              if (a < 3) sacc += 0.5 * dt * dt * sa2;
-              else if (a < 6) sacc += sg2;
-              else if (a < 9) sacc += sa2;
-              else if (a < 12) sacc += dt * im.par.sigma_gw_c * im.par.sigma_gw_c;
-              else sacc += dt * im.par.sigma_aw_c * im.par.sigma_aw_c;
-            }
-            sh.P[e] = sacc;
-          }
-          waveSync();
-        }
-      }
-      __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+      const int row = (lane >> 4) + 4 * q, col = lane & 15;
+      if (row < 15 && col < 15) sh.P[parity ? col * 15 + row : row * 15 + col] = X[q];
     }
   }
-  st.Dq = Dq;
-  for (int k = 0; k < 9; ++k) { st.Ci[k] = Ci[k]; st.Cdi[k] = Cdi[k]; st.dal[k] = dal[k]; st.dv[k] = dv[k]; st.dp[k] = dp[k]; }
-  for (int k = 0; k < 3; ++k) { st.ai[k] = ai[k]; st.adi[k] = adi[k]; }
-  st.Delta_t = Delta_t;
-  st.used = used;
+  if (wave == 0) {
+    if (lane < 32) { sh.tot[tot1] = run1; if (lane < 21) sh.tot[tot2] = run2; }
+    if (lane == 32) { sh.tot[0] = Dq.x; sh.tot[1] = Dq.y; sh.tot[2] = Dq.z; sh.tot[3] = Dq.w; }
+  }
+  __syncthreads();
+  st.Dq = Quat{sh.tot[0], sh.tot[1], sh.tot[2], sh.tot[3]};
+  for (int k = 0; k < 9; ++k) {
+    st.Ci[k] = sh.tot[4 + k]; st.Cdi[k] = sh.tot[13 + k]; st.dal[k] = sh.tot[28 + k]; st.dv[k] = sh.tot[37 + k]; st.dp[k] = sh.tot[46 + k];
+  }
+  for (int k = 0; k < 3; ++k) { st.ai[k] = sh.tot[22 + k]; st.adi[k] = sh.tot[25 + k]; }
+  st.Delta_t = sh.tot[55];
+  st.used = (int)sh.tot[56];
+  IMU_TICK(qEnd);
+  IMU_ACC(3, qStart, qEnd, t == 0);
 }
 
 __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ imuT, const double* __restrict__ imuM,
@@ -515,6 +641,7 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   }
   // symmetrise P, information = P^-1 (via Cholesky), symmetrise, sqrtInfo = chol(information)^T  (:246-258)
   __syncthreads();
+  IMU_TICK(qPost0);
   if (t < 225) sh.T[t] = 0.5 * sh.P[t] + 0.5 * sh.P[(t % 15) * 15 + t / 15];
   __syncthreads();
   if (t < 225) { sh.P[t] = sh.T[t]; im.P_delta[t] = sh.T[t]; }
@@ -550,7 +677,15 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
     im.sqrtInfo[t] = (b >= a) ? sh.P[b * 15 + a] : 0.0;  // L^T
   }
   __syncthreads();
+  IMU_TICK(qPost1);
+  IMU_ACC(4, qPost0, qPost1, t == 0);
 }
+#ifdef SVIN_IMU_TIMING
+void debugImuTiming(double* out, bool reset) {
+  if (reset) { double z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_imuDbg), z, sizeof(z)); return; }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_imuDbg), 64);
+}
+#endif
 
 // ImuError::propagation (ImuError.cpp:266-476): io[0..6] T_WS, io[7..15] speed/bias (in/out);
 // out[0] = number of integration steps (or -1), optional 15x15 jacobian / covariance.

@@ -1040,8 +1040,28 @@ int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* byt
   return 1;
 }
 
+#ifdef SVIN_IMU_TIMING
+void debugImuTiming(double* out, bool reset);
+#endif
 int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs) {
   pack();
+#ifdef SVIN_IMU_TIMING
+  {
+    debugImuTiming(nullptr, true);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) {
+      invalidatePreintegration();
+      pack();
+      launchEvalFactors(prob_, false, stream_);
+      HIP_OK(hipStreamSynchronize(stream_));
+    }
+    double dbg[8];
+    debugImuTiming(dbg, false);
+    const double n = 9.0 * reps;
+    std::printf("[imu redo cycles] P0 %.0f P1dq %.0f P1cross %.0f P2 %.0f P3 %.0f cov %.0f integrate %.0f post %.0f\n", dbg[0] / n,
+                dbg[1] / n, dbg[6] / n, dbg[7] / n, dbg[5] / n, dbg[2] / n, dbg[3] / n, dbg[4] / n);
+  }
+#endif
   DeviceProblem& p = prob_;
   hipStream_t s = stream_;
   evaluateAll(false, s);
