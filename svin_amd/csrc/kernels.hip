@@ -1647,50 +1647,89 @@ __device__ __forceinline__ double readlaneD(double v, int srcLane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
   return __hiloint2double(hi, lo);
 }
-// Factorises the tile D (16 x kPanelLd in LDS) in place: lower triangle <- L, strict upper triangle <-
-// transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii = diag(L^-1).
-// Divisions and square roots are replaced by one rsqrt per pivot (the serial chain is latency-bound).
-__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane, int* failFlag) {
-  double a[16], rinv[16];
+#ifdef SVIN_CHOL_TIMING
+__device__ double g_cholDbg[4];
+void debugCholTiming(double* out, bool reset) {
+  if (reset) { double z[4] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cholDbg), z, sizeof(z)); return; }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cholDbg), 32);
+}
+#endif
+// 1/x to about one ulp without the IEEE division sequence: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double rcpNewton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+// 1/sqrt(x) for normal positive x: v_rsq_f64 and two Newton steps (the pivots of S are far from the denormals)
+__device__ __forceinline__ double rsqrtNewton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = __builtin_fma(-h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+// Factorises the tile D (16 x kPanelLd in LDS, full symmetric block) in place: lower triangle <- L, strict upper
+// triangle <- transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii.
+// Lane i carries the full symmetric row i, so the pivot row k (= column k) is one lane's registers and is
+// broadcast with v_readlane; the square-root-free elimination a_ij -= a_ik a_kj / a_kk (A = Lt D Lt^T, Lt unit
+// lower) keeps sqrt off the serial chain.  The same broadcast values drive a fused forward substitution: lane j
+// carries column j of Lt^-1 and applies xt_i -= Lt_ik xt_k as soon as column k is known, so the inverse needs
+// no second pass and no LDS traffic.  One rsqrt per lane at the end scales both factors: L = Lt D^1/2,
+// L^-1 = D^-1/2 Lt^-1.
+__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneIn, int* failFlag) {
+  // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks and constants of this
+  // routine out of the caller's block-column loop (that costs ~100 registers across the whole kernel -> scratch)
+  int lane = laneIn;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 15;
+#ifdef SVIN_CHOL_TIMING
+  const long long qd0 = __builtin_readcyclecounter();
+#endif
+  double a[16], x[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = (lane < 16) ? D[lane * kPanelLd + j] : 0.0;
+  for (int j = 0; j < 16; ++j) { a[j] = D[li * kPanelLd + j]; x[j] = (j == li) ? 1.0 : 0.0; }
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const double akk = readlaneD(a[k], k);
-    const bool ok = akk > 0;
+    double pr[16];
+#pragma unroll
+    for (int j = k; j < 16; ++j) pr[j] = readlaneD(a[j], k);
+    const bool ok = pr[k] > 0;
     bad = bad || !ok;
-    const double r = ok ? rsqrt(akk) : 1.0;   // 1/L_kk
-    rinv[k] = r;
-    const double lk = (lane == k) ? akk * r : a[k] * r;
-    a[k] = lk;
+    const double rk = rcpNewton(ok ? pr[k] : 1.0);  // branch-free: 1 for a failed pivot
+    const double m = a[k] * rk, mx = x[k] * rk;
 #pragma unroll
-    for (int j = k + 1; j < 16; ++j) {
-      const double ljk = readlaneD(lk, j);
-      a[j] -= lk * ljk;
-    }
+    for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-m, pr[j], a[j]);
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) x[j] = __builtin_fma(-mx, pr[j], x[j]);
+    __builtin_amdgcn_sched_barrier(0);  // keep each column's updates next to its broadcasts (SGPR lifetime)
   }
-  if (bad && lane == 0) atomicOr(failFlag, 2);
-  // inverse: lane j builds column j of X = L^-1 (x[i] = X[i][j], i >= j)
-  double x[16];
+#ifdef SVIN_CHOL_TIMING
+  const long long qd1 = __builtin_readcyclecounter();
+#endif
+  double dk = a[0];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double sacc = (i == lane) ? 1.0 : 0.0;
+  for (int k = 1; k < 16; ++k) dk = (li == k) ? a[k] : dk;
+  const double rs = rsqrtNewton(dk > 0 ? dk : 1.0);  // 1/L_kk in lane k (1 for a failed pivot), branch-free
 #pragma unroll
-    for (int k = 0; k < i; ++k) {
-      const double lik = readlaneD(a[k], i);
-      if (k >= lane) sacc -= lik * x[k];
-    }
-    x[i] = (i >= lane) ? sacc * rinv[i] : 0.0;
+  for (int k = 0; k < 16; ++k) {
+    const double rsk = readlaneD(rs, k);
+    a[k] *= rsk;  // L[li][k] for k <= li
+    x[k] *= rsk;  // Linv[k][li] for k >= li
   }
-  if (lane < 16) {
+  // lanes 16..63 replicate lanes 0..15 (same values to the same addresses): storing from all of them keeps the
+  // compiler from sinking the x recurrence into a divergent block (which spills every broadcast value)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j <= lane) D[lane * kPanelLd + j] = a[j];      // L[lane][j]
-      if (j > lane) D[lane * kPanelLd + j] = x[j];       // D[c=lane][r=j] = Linv[j][lane]
-      if (j == lane) dinv[j] = rinv[j];
-    }
-  }
+  for (int j = 0; j < 16; ++j) D[li * kPanelLd + j] = (j > li) ? x[j] : a[j];  // D[c=li][r=j] = Linv[j][li]
+  dinv[li] = rs;
+  if (bad && lane == 0) atomicOr(failFlag, 2);  // after the stores: no block boundary inside the register pipeline
+#ifdef SVIN_CHOL_TIMING
+  const long long qd2 = __builtin_readcyclecounter();
+  if (lane == 0) { g_cholDbg[0] += (double)(qd1 - qd0); g_cholDbg[1] += (double)(qd2 - qd1); }
+#endif
 }
 
 // LDS-resident variant for dpad <= 176: the lower triangle lives in LDS as 16x17 tiles (tile (I,J), I>=J at
@@ -1698,46 +1737,70 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane,
 constexpr int kTile = 16 * kPanelLd;  // doubles per tile
 __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
 
-__global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dpad) {
+constexpr int kCholLdsThreads = 512;  // 8 waves: 256 VGPRs per lane keep the 16x16 diagonal factorisation out of scratch
+__global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, d = p.d, nT = dpad / 16;
-  const int wave = t >> 6, lane = t & 63;
+  const int wave = t >> 6, lane = t & 63, nW = kCholLdsThreads / 64;
   const int nTilesAll = nT * (nT + 1) / 2;
   double* tiles = smem;
   double* rhs = smem + (size_t)nTilesAll * kTile;  // dpad
   double* dinv = rhs + dpad;                       // dpad
-  // load the lower triangle of S (identity padding); coalesced over the rows of S
-  for (int idx = t; idx < dpad * dpad; idx += blockDim.x) {
-    const int gi = idx / dpad, gj = idx - gi * dpad;
-    const int I = gi >> 4, J = gj >> 4;
-    if (J > I) continue;
-    double v = 0;
-    if (gi < d && gj < d) v = (gj <= gi) ? p.S[(size_t)gi * d + gj] : 0.0;
-    else if (gi == gj) v = 1.0;
-    tileAt(tiles, I, J)[(gi & 15) * kPanelLd + (gj & 15)] = v;
+#ifdef SVIN_CHOL_TIMING
+  const long long ql0 = __builtin_readcyclecounter();
+#endif
+  // load the lower triangle of S tile by tile (identity padding): every wave first issues the loads of all its
+  // tiles (independent, <= kMaxTilesPerWave x 4 values per lane in flight), then writes them to LDS -- the copy
+  // is bound by one global-memory latency instead of one per element
+  {
+    constexpr int kMaxTilesPerWave = 9;  // nT <= 11 -> 66 tiles over 8 waves
+    double v[kMaxTilesPerWave][4];
+#pragma unroll
+    for (int it = 0; it < kMaxTilesPerWave; ++it) {
+      const int tl = wave + it * nW;
+      int I = 0;
+      while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+      const int J = tl - I * (I + 1) / 2;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
+        double x = (gi == gj) ? 1.0 : 0.0;
+        // diagonal tiles are kept fully symmetric (the MFMA trailing update preserves that)
+        if (tl < nTilesAll && gi < d && gj < d) x = (gj <= gi) ? p.S[(size_t)gi * d + gj] : p.S[(size_t)gj * d + gi];
+        v[it][rg] = x;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kMaxTilesPerWave; ++it) {
+      const int tl = wave + it * nW;
+      if (tl < nTilesAll) {
+        double* dst = tiles + (size_t)tl * kTile;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) dst[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = v[it][rg];
+      }
+    }
   }
   for (int i = t; i < dpad; i += blockDim.x) rhs[i] = (i < d) ? p.gRed[i] : 0.0;
   __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+  long long qq0 = __builtin_readcyclecounter();
+  if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(qq0 - ql0);
+#endif
+  if (wave == 0) cholDiag16Reg(tileAt(tiles, 0, 0), dinv, lane, &p.scal->cholFail);
+  __syncthreads();
+#ifdef SVIN_CHOL_TIMING
+  if (t == 0) p.partial[(size_t)15 * 4096 + 0] += (double)(__builtin_readcyclecounter() - qq0);
+#endif
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
-    double* D = tileAt(tiles, kb, kb);
-#ifdef SVIN_CHOL_TIMING
-    long long q0 = __builtin_readcyclecounter();
-#endif
-    if (wave == 0) cholDiag16Reg(D, dinv + k0, lane, &p.scal->cholFail);
-#ifdef SVIN_CHOL_TIMING
-    long long q1 = __builtin_readcyclecounter();
-    if (t == 0) p.partial[(size_t)15 * 4096 + 0] += (double)(q1 - q0);
-#endif
-    __syncthreads();
+    double* D = tileAt(tiles, kb, kb);  // already factorised (prologue / look-ahead of the previous step)
 #ifdef SVIN_CHOL_TIMING
     long long q2 = __builtin_readcyclecounter();
-    if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(q2 - q1);
 #endif
     const int nR = nT - kb - 1;
     // phase B: panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile);
     // the last wave also advances the forward substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb
-    for (int ti = wave; ti < nR; ti += 16) {
+    for (int ti = wave; ti < nR; ti += nW) {
       double* A = tileAt(tiles, kb + 1 + ti, kb);
       d4_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1750,11 +1813,13 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) A[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
     }
-    if (wave == 15) {
-      double yv = 0;
-      if (lane < 16) {
-        yv = rhs[k0 + lane] * dinv[k0 + lane];
-        for (int c = 0; c < lane; ++c) yv += D[c * kPanelLd + lane] * rhs[k0 + c];
+    if (wave == nW - 1) {
+      const int li = lane & 15;
+      double yv = rhs[k0 + li] * dinv[k0 + li];
+#pragma unroll
+      for (int c = 0; c < 15; ++c) {
+        const double term = D[c * kPanelLd + li] * rhs[k0 + c];
+        yv += (c < li) ? term : 0.0;
       }
       waveSync();
       if (lane < 16) rhs[k0 + lane] = yv;
@@ -1764,8 +1829,10 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
     long long q3 = __builtin_readcyclecounter();
     if (t == 0) p.partial[(size_t)15 * 4096 + 2] += (double)(q3 - q2);
 #endif
-    // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA; wave 15 first updates the rhs tail
-    if (wave == 15) {
+    // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA.  Look-ahead: wave 0 updates the next diagonal
+    // tile first and factorises it right away while waves 1.. work through the other tiles; the last wave first
+    // updates the tail of the right-hand side.
+    if (wave == nW - 1) {
       for (int i = k0 + 16 + lane; i < dpad; i += 64) {
         const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
         double sacc = 0;
@@ -1775,9 +1842,10 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
       }
     }
     const int nUp = nR * (nR + 1) / 2;
-    int I = 0, J = 0, cnt = 0;  // walk the lower-triangular tile list without square roots
+    int I = 0, J = 0;  // walk the lower-triangular tile list without square roots
     for (int tile = 0; tile < nUp; ++tile) {
-      if ((tile & 15) == wave) {
+      const int owner = (tile == 0) ? 0 : 1 + (tile - 1) % (nW - 1);
+      if (owner == wave) {
         double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
         const double* A = tileAt(tiles, kb + 1 + I, kb);
         const double* B = tileAt(tiles, kb + 1 + J, kb);
@@ -1792,9 +1860,12 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+        if (tile == 0) {
+          waveSync();
+          cholDiag16Reg(Cb, dinv + k0 + 16, lane, &p.scal->cholFail);
+        }
       }
       if (++J > I) { ++I; J = 0; }
-      (void)cnt;
     }
     __syncthreads();
 #ifdef SVIN_CHOL_TIMING
@@ -1805,30 +1876,32 @@ __global__ __launch_bounds__(1024) void k_chol_solve_lds(DeviceProblem p, int dp
 #ifdef SVIN_CHOL_TIMING
   long long q5 = __builtin_readcyclecounter();
 #endif
-  // backward substitution L^T y = y' in wave 0 alone (wave-level synchronisation only)
-  if (wave == 0) {
-    for (int kb = nT - 1; kb >= 0; --kb) {
-      const int k0 = kb * 16;
-      const double* D = tileAt(tiles, kb, kb);
-      double yv = 0;
-      if (lane < 16) {
-        yv = rhs[k0 + lane] * dinv[k0 + lane];
-        for (int r = lane + 1; r < 16; ++r) yv += D[lane * kPanelLd + r] * rhs[k0 + r];
+  // backward substitution L^T y = y': wave 0 solves the 16x16 diagonal system with L^-T, then every thread
+  // removes that block's contribution from one earlier row
+  for (int kb = nT - 1; kb >= 0; --kb) {
+    const int k0 = kb * 16;
+    const double* D = tileAt(tiles, kb, kb);
+    if (wave == 0) {
+      const int li = lane & 15;
+      double yv = rhs[k0 + li] * dinv[k0 + li];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) {
+        const double term = D[li * kPanelLd + r] * rhs[k0 + r];
+        yv += (r > li) ? term : 0.0;
       }
       waveSync();
       if (lane < 16) rhs[k0 + lane] = yv;
-      waveSync();
-      for (int i = lane; i < k0; i += 64) {
-        const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
-        double sacc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + k];
-        rhs[i] -= sacc;
-      }
-      waveSync();
     }
+    __syncthreads();
+    for (int i = t; i < k0; i += blockDim.x) {
+      const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
+      double sacc = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + k];
+      rhs[i] -= sacc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 #ifdef SVIN_CHOL_TIMING
   if (t == 0) p.partial[(size_t)15 * 4096 + 4] += (double)(__builtin_readcyclecounter() - q5);
 #endif
@@ -1873,7 +1946,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
   const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 2 * dpad) * 8;
   if (ldsBytes <= 156 * 1024) {
     (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(1024), ldsBytes, s, p, dpad);
+    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad);
   } else {
     const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
     (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

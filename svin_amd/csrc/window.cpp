@@ -1043,6 +1043,9 @@ int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* byt
 #ifdef SVIN_IMU_TIMING
 void debugImuTiming(double* out, bool reset);
 #endif
+#ifdef SVIN_CHOL_TIMING
+void debugCholTiming(double* out, bool reset);
+#endif
 int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs) {
   pack();
 #ifdef SVIN_IMU_TIMING
@@ -1086,12 +1089,20 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
   if (evalMs) *evalMs = timeIt([&]() { launchEvalReproj(p, false, true, s); });
   if (buildMs) *buildMs = timeIt([&]() { launchBuildNormalEquations(p, 1e-8, false, s); });
   if (getenv("SVIN_CHOL_TIMING")) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64));
+#ifdef SVIN_CHOL_TIMING
+  debugCholTiming(nullptr, true);
+#endif
   if (solveMs) *solveMs = timeIt([&]() { launchSolveReduced(p, s); });
   if (getenv("SVIN_CHOL_TIMING")) {
     double dbg[5];
     HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096, sizeof(dbg), hipMemcpyDeviceToHost));
-    std::printf("[chol cycles per launch] diag %.0f sync %.0f trsm %.0f mfma %.0f back %.0f\n", dbg[0] / iters, dbg[1] / iters,
+    std::printf("[chol cycles per launch] diag0 %.0f load %.0f trsm %.0f mfma %.0f back %.0f\n", dbg[0] / iters, dbg[1] / iters,
                 dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
+#ifdef SVIN_CHOL_TIMING
+    double dd[4];
+    debugCholTiming(dd, false);
+    std::printf("[diag block cycles per launch] eliminate %.0f scale+store %.0f inverse %.0f\n", dd[0] / iters, dd[1] / iters, dd[2] / iters);
+#endif
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 1;
