@@ -49,7 +49,7 @@ __device__ __forceinline__ void waveSync() {
 constexpr int kMaxPartials = 4096;
 enum PartialSlot : int {
   PS_COST_REPROJ = 0, PS_COST_FACTORS = 1, PS_JV_SQ = 2, PS_JV_DOT = 3, PS_STEP = 4, PS_XNORM = 5,
-  PS_GHAT = 6, PS_GNHAT = 7, PS_GDOTGN = 8, PS_GRADMAX = 9, PS_JV_SQ_F = 10, PS_JV_DOT_F = 11, PS_COUNT = 12
+  PS_GHAT = 6, PS_GNHAT = 7, PS_GDOTGN = 8, PS_GRADMAX = 9, PS_JY_SQ = 10, PS_JVJY = 11, PS_JY_DOT = 12, PS_COUNT = 13
 };
 
 // ================================================================ K1: reprojection evaluation
@@ -997,18 +997,20 @@ void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
   __shared__ double red[4];
   const int t = threadIdx.x, m = p.priorM;
+  double* priorDchi = cand ? p.priorDchiC : p.priorDchi;
+  double* priorGrad = cand ? p.priorGradC : p.priorGrad;
   for (int b = t; b < p.priorBlocks; b += blockDim.x) {
     const PriorBlock& pb = p.priorBlk[b];
-    double* M3 = p.priorM3 + 9 * b;
+    double* M3 = (cand ? p.priorM3C : p.priorM3) + 9 * b;
     for (int k = 0; k < 9; ++k) M3[k] = (k % 4 == 0) ? 1.0 : 0.0;
     if (pb.mdim == 0) continue;
     const double* x = blockPtr(p, cand != 0, pb.kind, pb.slot);
     if (pb.kind == B_SB) {
-      for (int k = 0; k < 9; ++k) p.priorDchi[pb.ord + k] = x[k] - pb.lin[k];
+      for (int k = 0; k < 9; ++k) priorDchi[pb.ord + k] = x[k] - pb.lin[k];
     } else {
       double d[6];
       poseMinus(x, pb.lin, d);
-      for (int k = 0; k < 6; ++k) p.priorDchi[pb.ord + k] = d[k];
+      for (int k = 0; k < 6; ++k) priorDchi[pb.ord + k] = d[k];
       // PlusJacobian normalises q (Transformation ctor); lift uses the raw linearisation quaternion
       const Quat qc = qnormalized(Quat{x[3], x[4], x[5], x[6]});
       const Quat ql = Quat{-pb.lin[3], -pb.lin[4], -pb.lin[5], pb.lin[6]};
@@ -1027,9 +1029,9 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
   for (int i = t; i < m; i += blockDim.x) {
     double s = 0;
     const double* row = p.priorH + (size_t)i * m;
-    for (int k = 0; k < m; ++k) s += row[k] * p.priorDchi[k];
-    p.priorGrad[i] = p.priorBp[i] + s;
-    c += p.priorDchi[i] * (p.priorBp[i] + 0.5 * s);
+    for (int k = 0; k < m; ++k) s += row[k] * priorDchi[k];
+    priorGrad[i] = p.priorBp[i] + s;
+    c += priorDchi[i] * (p.priorBp[i] + 0.5 * s);
   }
   const double tot = blockSum(c, red);
   if (t == 0) p.scal->costPrior = 0.5 * p.priorC0 + tot;
@@ -1098,42 +1100,6 @@ __global__ void k_prior_accumulate(DeviceProblem p) {
     atomicAdd(&p.gFull[ri], g);
   }
 }
-// |J_eff v|^2 = (Mv)^T Ht (Mv) ; (J_eff v).r = (Mv)^T grad
-__global__ __launch_bounds__(256) void k_prior_jv(DeviceProblem p, const double* __restrict__ vC) {
-  __shared__ double red[4];
-  const int t = threadIdx.x, m = p.priorM;
-  for (int i = t; i < m; i += blockDim.x) {
-    const int bi = priorFindBlock(p, i);
-    const PriorBlock& B = p.priorBlk[bi];
-    const int off = blockOff(p, B.kind, B.slot);
-    const int li = i - B.ord;
-    double v = 0;
-    if (off >= 0) {
-      if (B.kind != B_SB && li >= 3) {
-        for (int c = 0; c < 3; ++c) v += p.priorM3[9 * bi + (li - 3) * 3 + c] * vC[off + 3 + c];
-      } else {
-        v = vC[off + li];
-      }
-    }
-    p.priorMv[i] = v;
-  }
-  __syncthreads();
-  double sq = 0, dot = 0;
-  for (int i = t; i < m; i += blockDim.x) {
-    double s = 0;
-    const double* row = p.priorH + (size_t)i * m;
-    for (int k = 0; k < m; ++k) s += row[k] * p.priorMv[k];
-    sq += p.priorMv[i] * s;
-    dot += p.priorMv[i] * p.priorGrad[i];
-  }
-  const double a = blockSum(sq, red);
-  const double b = blockSum(dot, red);
-  if (t == 0) {
-    p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + kMaxPartials - 1] = a;
-    p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + kMaxPartials - 1] = b;
-  }
-}
-
 // ================================================================ K5: normal equations + landmark Schur complement
 constexpr int kStage = 34;  // doubles staged per observation: Jl 6, Jp 12, Je 12, offP, offE (as double), pad
 
@@ -1638,7 +1604,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
     }
     __syncthreads();
   }
-  for (int i = t; i < d; i += blockDim.x) y[i] = sP[i];
+  for (int i = t; i < d; i += blockDim.x) { y[i] = sP[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
 }
 
 // ---- 16x16 diagonal block in registers (wave 0, lane i = row i), cross-lane traffic through v_readlane.
@@ -1905,39 +1871,7 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 #ifdef SVIN_CHOL_TIMING
   if (t == 0) p.partial[(size_t)15 * 4096 + 4] += (double)(__builtin_readcyclecounter() - q5);
 #endif
-  for (int i = t; i < d; i += blockDim.x) p.yC[i] = rhs[i];
-}
-
-// landmarks: y_l = Vinv (bl - sum_i Jl_i^T (Jc_i y_c))
-template <bool WITH_EXT>
-__global__ void k_backsub(DeviceProblem p) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= p.L) return;
-  const size_t N = (size_t)p.N;
-  double t0 = p.bl[3 * l], t1 = p.bl[3 * l + 1], t2 = p.bl[3 * l + 2];
-  for (int o = p.lmPtr[l]; o < p.lmPtr[l + 1]; ++o) {
-    const uint32_t idx = p.obsIdx[o];
-    const int offP = p.poseOff[idx & 0xfff];
-    double u0 = 0, u1 = 0;
-    if (offP >= 0) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a) { u0 += p.JpCur[a * N + o] * p.yC[offP + a]; u1 += p.JpCur[(6 + a) * N + o] * p.yC[offP + a]; }
-    }
-    if (WITH_EXT) {
-      const int offE = p.extOff[(idx >> 12) & 0xfff];
-      if (offE >= 0) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { u0 += p.JeCur[a * N + o] * p.yC[offE + a]; u1 += p.JeCur[(6 + a) * N + o] * p.yC[offE + a]; }
-      }
-    }
-    t0 -= p.JlCur[o] * u0 + p.JlCur[3 * N + o] * u1;
-    t1 -= p.JlCur[N + o] * u0 + p.JlCur[4 * N + o] * u1;
-    t2 -= p.JlCur[2 * N + o] * u0 + p.JlCur[5 * N + o] * u1;
-  }
-  const double* w = p.Vinv + 6 * (size_t)l;
-  p.yL[3 * l] = w[0] * t0 + w[1] * t1 + w[2] * t2;
-  p.yL[3 * l + 1] = w[1] * t0 + w[3] * t1 + w[4] * t2;
-  p.yL[3 * l + 2] = w[2] * t0 + w[4] * t1 + w[5] * t2;
+  for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
 }
 
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
@@ -1952,184 +1886,248 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad);
   }
-  if (p.L > 0) {
-    if (p.anyExtVariable) hipLaunchKernelGGL(k_backsub<true>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);
-    else hipLaunchKernelGGL(k_backsub<false>, dim3((p.L + 127) / 128), dim3(128), 0, s, p);
-  }
 }
 
-// ================================================================ J * v passes and dogleg
-// v = [vC (d) ; vL (3L)].  Accumulates sum |Jv|^2 and sum (Jv).r over reprojection residuals.
-template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_jv_reproj(DeviceProblem p, const double* __restrict__ vC,
-                                                   const double* __restrict__ vL) {
-  __shared__ double red[4];
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t N = (size_t)p.N;
-  double sq = 0, dot = 0;
-  if (o < p.N) {
-    const uint32_t idx = p.obsIdx[o];
-    const int offP = p.poseOff[idx & 0xfff];
-    const int l = p.obsLm[o];
-    double u0 = p.JlCur[o] * vL[3 * l] + p.JlCur[N + o] * vL[3 * l + 1] + p.JlCur[2 * N + o] * vL[3 * l + 2];
-    double u1 = p.JlCur[3 * N + o] * vL[3 * l] + p.JlCur[4 * N + o] * vL[3 * l + 1] + p.JlCur[5 * N + o] * vL[3 * l + 2];
-    if (offP >= 0) {
+// ================================================================ post-solve pass and dogleg step
+// Block-wide reduction of K values at once: out[k] valid in threads 0..K-1 (as `mine`), `red` holds 4*K doubles.
+template <int K>
+__device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, int kMaxIndex) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nW = (blockDim.x + 63) >> 6;
+  __syncthreads();
 #pragma unroll
-      for (int a = 0; a < 6; ++a) { u0 += p.JpCur[a * N + o] * vC[offP + a]; u1 += p.JpCur[(6 + a) * N + o] * vC[offP + a]; }
+  for (int k = 0; k < K; ++k) {
+    const double s = (k == kMaxIndex) ? waveMax(v[k]) : waveSum(v[k]);
+    if (lane == 0) red[w * K + k] = s;
+  }
+  __syncthreads();
+  double mine = 0;
+  if ((int)threadIdx.x < K) {
+    for (int i = 0; i < nW; ++i) {
+      const double x = red[i * K + threadIdx.x];
+      mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
     }
-    if (WITH_EXT) {
-      const int offE = p.extOff[(idx >> 12) & 0xfff];
-      if (offE >= 0) {
+  }
+  return mine;
+}
+
+enum Ticket : int { TK_POST = 0, TK_STEP = 1 };
+// last-block-done: returns true in every thread of the block that finishes last (its loads see all other
+// blocks' partials); the summation order over the partial slots is fixed, so the result is deterministic
+__device__ __forceinline__ bool lastBlockDone(unsigned int* ticket, int* flagLds) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int tk = atomicAdd(ticket, 1u);
+    *flagLds = (tk == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool last = *flagLds != 0;
+  if (last) __threadfence();
+  return last;
+}
+
+// partial slots of the post-solve pass
+constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
+__device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};
+
+// One pass over the whole linearisation right after the reduced solve (y_C, and v_C = g/htil from the solver):
+//  landmark blocks (16 lanes per landmark): back-substitution y_l = Vinv (b_l - sum_i Jl_i^T Jc_i y_C), v_l = g_l/htil_l,
+//      then per observation u_v = J v and u_y = J y and the five sums that price every dogleg step of this
+//      linearisation (J*delta = cg*u_v - cn*u_y), plus the landmark part of the scaled-gradient norms;
+//  factor blocks (one wave per factor): the same five sums over the rows of the small factors;
+//  last block: camera part of the norms and the marginalisation prior (H-space);
+//  whichever block finishes last reduces all partials into SolverScalars group B.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks) {
+  __shared__ double red[4 * kPostK];
+  __shared__ int lastFlag;
+  const int t = threadIdx.x, b = blockIdx.x;
+  double acc[kPostK];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { u0 += p.JeCur[a * N + o] * vC[offE + a]; u1 += p.JeCur[(6 + a) * N + o] * vC[offE + a]; }
+  for (int k = 0; k < kPostK; ++k) acc[k] = 0;
+  if (b < nLmBlocks) {
+    const int grp = t >> 4, gl = t & 15;
+    const size_t N = (size_t)p.N;
+    // u_y = Jc y_C, u_v = Jc v_C, Jl and r of observation o
+    auto loadObs = [&](size_t o, double* jl, double* uy, double* uv, double* rr) {
+      const uint32_t idx = p.obsIdx[o];
+      const int offP = p.poseOff[idx & 0xfff];
+      uy[0] = uy[1] = uv[0] = uv[1] = 0;
+      if (offP >= 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double j0 = p.JpCur[a * N + o], j1 = p.JpCur[(6 + a) * N + o], y = p.yC[offP + a], v = p.vC[offP + a];
+          uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
+        }
+      }
+      if (WITH_EXT) {
+        const int offE = p.extOff[(idx >> 12) & 0xfff];
+        if (offE >= 0) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double j0 = p.JeCur[a * N + o], j1 = p.JeCur[(6 + a) * N + o], y = p.yC[offE + a], v = p.vC[offE + a];
+            uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jl[k] = p.JlCur[k * N + o];
+      rr[0] = p.rCur[o]; rr[1] = p.rCur[N + o];
+    };
+    for (int l = b * 16 + grp; l < p.L; l += nLmBlocks * 16) {
+      const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      double t0 = 0, t1 = 0, t2 = 0;
+      double cjl[6], cuy[2], cuv[2], crr[2];  // first observation of this lane stays in registers
+      for (int i = gl; i < n; i += 16) {
+        double jl[6], uy[2], uv[2], rr[2];
+        loadObs((size_t)start + i, jl, uy, uv, rr);
+        t0 += jl[0] * uy[0] + jl[3] * uy[1];
+        t1 += jl[1] * uy[0] + jl[4] * uy[1];
+        t2 += jl[2] * uy[0] + jl[5] * uy[1];
+        if (i == gl) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) cjl[k] = jl[k];
+          cuy[0] = uy[0]; cuy[1] = uy[1]; cuv[0] = uv[0]; cuv[1] = uv[1]; crr[0] = rr[0]; crr[1] = rr[1];
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { t0 += __shfl_xor(t0, o, 16); t1 += __shfl_xor(t1, o, 16); t2 += __shfl_xor(t2, o, 16); }
+      const double g0 = p.bl[3 * l], g1 = p.bl[3 * l + 1], g2 = p.bl[3 * l + 2];
+      const double* vi = p.Vinv + 6 * (size_t)l;
+      const double q0 = g0 - t0, q1 = g1 - t1, q2 = g2 - t2;
+      const double y0 = vi[0] * q0 + vi[1] * q1 + vi[2] * q2;
+      const double y1 = vi[1] * q0 + vi[3] * q1 + vi[4] * q2;
+      const double y2 = vi[2] * q0 + vi[4] * q1 + vi[5] * q2;
+      const double h0 = p.hL[3 * l], h1 = p.hL[3 * l + 1], h2 = p.hL[3 * l + 2];
+      const double v0 = g0 / h0, v1 = g1 / h1, v2 = g2 / h2;
+      if (gl == 0) {
+        p.yL[3 * l] = y0; p.yL[3 * l + 1] = y1; p.yL[3 * l + 2] = y2;
+        p.vL[3 * l] = v0; p.vL[3 * l + 1] = v1; p.vL[3 * l + 2] = v2;
+        acc[5] += g0 * g0 / h0 + g1 * g1 / h1 + g2 * g2 / h2;
+        acc[6] += h0 * y0 * y0 + h1 * y1 * y1 + h2 * y2 * y2;
+        acc[7] += -(g0 * y0 + g1 * y1 + g2 * y2);
+        acc[8] = fmax(acc[8], fmax(fabs(g0), fmax(fabs(g1), fabs(g2))));
+      }
+      for (int i = gl; i < n; i += 16) {
+        double jl[6], uy[2], uv[2], rr[2];
+        if (i == gl) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) jl[k] = cjl[k];
+          uy[0] = cuy[0]; uy[1] = cuy[1]; uv[0] = cuv[0]; uv[1] = cuv[1]; rr[0] = crr[0]; rr[1] = crr[1];
+        } else {
+          loadObs((size_t)start + i, jl, uy, uv, rr);
+        }
+        const double jv0 = uv[0] + jl[0] * v0 + jl[1] * v1 + jl[2] * v2, jv1 = uv[1] + jl[3] * v0 + jl[4] * v1 + jl[5] * v2;
+        const double jy0 = uy[0] + jl[0] * y0 + jl[1] * y1 + jl[2] * y2, jy1 = uy[1] + jl[3] * y0 + jl[4] * y1 + jl[5] * y2;
+        acc[0] += jv0 * jv0 + jv1 * jv1;
+        acc[1] += jy0 * jy0 + jy1 * jy1;
+        acc[2] += jv0 * jy0 + jv1 * jy1;
+        acc[3] += jv0 * rr[0] + jv1 * rr[1];
+        acc[4] += jy0 * rr[0] + jy1 * rr[1];
       }
     }
-    sq = u0 * u0 + u1 * u1;
-    dot = u0 * p.rCur[o] + u1 * p.rCur[N + o];
-  }
-  const double a = blockSum(sq, red);
-  const double b = blockSum(dot, red);
-  if (threadIdx.x == 0) {
-    p.partial[(size_t)PS_JV_SQ * kMaxPartials + blockIdx.x] = a;
-    p.partial[(size_t)PS_JV_DOT * kMaxPartials + blockIdx.x] = b;
-  }
-}
-__global__ __launch_bounds__(64) void k_jv_factors(DeviceProblem p, const double* __restrict__ vC) {
-  const FactorLin& lin = p.linCur[blockIdx.x];
-  const int lane = threadIdx.x;
-  double sq = 0, dot = 0;
-  if (lane < lin.m) {
-    double u = 0;
-    int base = 0;
-    for (int b = 0; b < 4; ++b) {
-      if (lin.off[b] >= 0)
-        for (int c = 0; c < lin.dim[b]; ++c) u += lin.J[lane * lin.ncols + base + c] * vC[lin.off[b] + c];
-      base += lin.dim[b];
+  } else if (b < nLmBlocks + nFacBlocks) {
+    if (p.ownsCamera) {
+      const int wave = t >> 6, lane = t & 63;
+      for (int f = (b - nLmBlocks) * 4 + wave; f < p.F; f += nFacBlocks * 4) {
+        const FactorLin& lin = p.linCur[f];
+        if (lane < lin.m) {
+          double uv = 0, uy = 0;
+          int base = 0;
+          for (int bb = 0; bb < 4; ++bb) {
+            if (lin.off[bb] >= 0)
+              for (int c = 0; c < lin.dim[bb]; ++c) {
+                const double j = lin.J[lane * lin.ncols + base + c];
+                uv += j * p.vC[lin.off[bb] + c];
+                uy += j * p.yC[lin.off[bb] + c];
+              }
+            base += lin.dim[bb];
+          }
+          const double r = lin.r[lane];
+          acc[0] += uv * uv; acc[1] += uy * uy; acc[2] += uv * uy; acc[3] += uv * r; acc[4] += uy * r;
+        }
+      }
     }
-    sq = u * u;
-    dot = u * lin.r[lane];
-  }
-  sq = waveSum(sq);
-  dot = waveSum(dot);
-  if (lane == 0) {
-    p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + blockIdx.x] = sq;
-    p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + blockIdx.x] = dot;
-  }
-}
-
-static int jvGrid(int N) { return (N + 255) / 256; }
-
-static void launchJv(const DeviceProblem& p, const double* vC, const double* vL, hipStream_t s) {
-  if (p.N > 0) {
-    if (p.anyExtVariable) hipLaunchKernelGGL(k_jv_reproj<true>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
-    else hipLaunchKernelGGL(k_jv_reproj<false>, dim3(jvGrid(p.N)), dim3(256), 0, s, p, vC, vL);
-  }
-  if (p.F > 0 && p.ownsCamera) hipLaunchKernelGGL(k_jv_factors, dim3(p.F), dim3(64), 0, s, p, vC);
-  if (p.priorM > 0 && p.ownsCamera) hipLaunchKernelGGL(k_prior_jv, dim3(1), dim3(256), 0, s, p, vC);
-}
-
-// v = g / htil ; partial sums of g^2/htil, htil*y^2, -g*y, max|g|
-__global__ __launch_bounds__(256) void k_dogleg_vectors(DeviceProblem p) {
-  __shared__ double red[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = p.d + 3 * p.L;
-  double gh = 0, gn = 0, gd = 0, gm = 0;
-  if (i < n) {
-    double g, ht, y;
-    bool count = true;
-    if (i < p.d) { g = p.gFull[i]; ht = p.htilC[i]; y = p.yC[i]; p.vC[i] = g / ht; count = p.ownsCamera != 0; }
-    else { const int k = i - p.d; g = p.bl[k]; ht = p.hL[k]; y = p.yL[k]; p.vL[k] = g / ht; }
-    if (count) {
-      gh = g * g / ht;
-      gn = ht * y * y;
-      gd = -g * y;
-      gm = fabs(g);
+  } else if (p.ownsCamera) {
+    // camera part of the scaled-gradient norms
+    for (int i = t; i < p.d; i += blockDim.x) {
+      const double g = p.gFull[i], ht = p.htilC[i], y = p.yC[i];
+      acc[5] += g * g / ht;
+      acc[6] += ht * y * y;
+      acc[7] += -g * y;
+      acc[8] = fmax(acc[8], fabs(g));
+    }
+    // marginalisation prior: |J_eff v|^2 = (Mv)^T Ht (Mv), (J_eff v).r = (Mv)^T grad  (same with y)
+    const int m = p.priorM;
+    if (m > 0) {
+      for (int i = t; i < m; i += blockDim.x) {
+        const int bi = priorFindBlock(p, i);
+        const PriorBlock& B = p.priorBlk[bi];
+        const int off = blockOff(p, B.kind, B.slot);
+        const int li = i - B.ord;
+        double v = 0, y = 0;
+        if (off >= 0) {
+          if (B.kind != B_SB && li >= 3) {
+            for (int c = 0; c < 3; ++c) {
+              const double w = p.priorM3[9 * bi + (li - 3) * 3 + c];
+              v += w * p.vC[off + 3 + c];
+              y += w * p.yC[off + 3 + c];
+            }
+          } else {
+            v = p.vC[off + li];
+            y = p.yC[off + li];
+          }
+        }
+        p.priorMv[i] = v;
+        p.priorMy[i] = y;
+      }
+      __syncthreads();
+      for (int i = t; i < m; i += blockDim.x) {
+        double sv = 0, sy = 0;
+        const double* row = p.priorH + (size_t)i * m;
+        for (int k = 0; k < m; ++k) { sv += row[k] * p.priorMv[k]; sy += row[k] * p.priorMy[k]; }
+        const double mv = p.priorMv[i], my = p.priorMy[i], gr = p.priorGrad[i];
+        acc[0] += mv * sv; acc[1] += my * sy; acc[2] += mv * sy; acc[3] += mv * gr; acc[4] += my * gr;
+      }
     }
   }
-  const double a = blockSum(gh, red);
-  const double b = blockSum(gn, red);
-  const double c = blockSum(gd, red);
-  gm = waveMax(gm);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double mx = 0;
-    for (int k = 0; k < (int)blockDim.x / 64; ++k) mx = fmax(mx, red[k]);
-    p.partial[(size_t)PS_GHAT * kMaxPartials + blockIdx.x] = a;
-    p.partial[(size_t)PS_GNHAT * kMaxPartials + blockIdx.x] = b;
-    p.partial[(size_t)PS_GDOTGN * kMaxPartials + blockIdx.x] = c;
-    p.partial[(size_t)PS_GRADMAX * kMaxPartials + blockIdx.x] = mx;
-  }
-}
-
-// final single-block reductions of the partial slots into SolverScalars
-__global__ __launch_bounds__(256) void k_reduce_scalars(DeviceProblem p, int what, int nA, int nB) {
-  __shared__ double red[4];
-  const int t = threadIdx.x;
-  auto sumSlot = [&](int slot, int n) {
+  const double mine = blockSumK<kPostK>(acc, red, 8);
+  if (t < kPostK) p.partial[(size_t)kPostSlot[t] * kMaxPartials + b] = mine;
+  if (!lastBlockDone(&p.tickets[TK_POST], &lastFlag)) return;
+  // final reduction over the blocks, fixed order: thread k-strided per slot
+#pragma unroll
+  for (int k = 0; k < kPostK; ++k) {
     double s = 0;
-    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
-    return blockSum(s, red);
-  };
-  if (what == 0) {  // cost: reproj (nA blocks) + factors (nB)
-    const double a = sumSlot(PS_COST_REPROJ, nA);
-    const double b = sumSlot(PS_COST_FACTORS, nB);
-    if (t == 0) {
-      const double bf = p.ownsCamera ? b : 0.0;
-      const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
-      p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
-      p.scal->cost = a + bf + pr;
-    }
-  } else if (what == 1) {  // dogleg vectors (nA blocks)
-    const double a = sumSlot(PS_GHAT, nA), b = sumSlot(PS_GNHAT, nA), c = sumSlot(PS_GDOTGN, nA);
-    double mx = 0;
-    for (int i = t; i < nA; i += blockDim.x) mx = fmax(mx, p.partial[(size_t)PS_GRADMAX * kMaxPartials + i]);
-    mx = waveMax(mx);
-    __syncthreads();
-    if ((t & 63) == 0) red[t >> 6] = mx;
-    __syncthreads();
-    if (t == 0) {
-      double m2 = 0;
-      for (int k = 0; k < 4; ++k) m2 = fmax(m2, red[k]);
-      p.scal->gHatSq = a; p.scal->gnHatSq = b; p.scal->gDotGn = c; p.scal->gradMax = m2;
-      p.scal->failMax = (double)p.scal->cholFail;
-    }
-  } else if (what == 2 || what == 3) {  // J*v: reproj (nA) + factors/prior (full slot)
-    const double a = sumSlot(PS_JV_SQ, nA) , b = sumSlot(PS_JV_DOT, nA);
-    double c = sumSlot(PS_JV_SQ_F, p.ownsCamera ? nB : 0), e = sumSlot(PS_JV_DOT_F, p.ownsCamera ? nB : 0);
-    if (t == 0 && p.priorM > 0 && p.ownsCamera) {
-      c += p.partial[(size_t)PS_JV_SQ_F * kMaxPartials + kMaxPartials - 1];
-      e += p.partial[(size_t)PS_JV_DOT_F * kMaxPartials + kMaxPartials - 1];
-    }
-    if (t == 0) {
-      if (what == 2) p.scal->jgSq = a + c;
-      else { p.scal->jdSq = a + c; p.scal->jdDotR = b + e; }
-    }
-  } else if (what == 4) {  // step / x norms
-    const double a = sumSlot(PS_STEP, nA), b = sumSlot(PS_XNORM, nA);
-    if (t == 0) { p.scal->stepNormSq = a; p.scal->xNormSq = b; }
+    const double* src = p.partial + (size_t)kPostSlot[k] * kMaxPartials;
+    for (int i = t; i < (int)gridDim.x; i += blockDim.x) s = (k == 8) ? fmax(s, src[i]) : s + src[i];
+    acc[k] = s;
   }
-}
-
-static int vecGrid(const DeviceProblem& p) { return (p.d + 3 * p.L + 255) / 256; }
-
-void launchCost(const DeviceProblem& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 0, p.N > 0 ? evalGrid(p.N) : 0, p.F);
+  const double tot = blockSumK<kPostK>(acc, red, 8);
+  if (t < kPostK) {
+    double* dst = &p.scal->gHatSq;
+    //                     A  B  C  D  E  gHat gnHat gDotGn
+    const int field[8] = {1, 4, 5, 6, 7, 0, 2, 3};
+    if (t < 8) dst[field[t]] = tot;
+    else { p.scal->gradMax = tot; p.scal->failMax = (double)p.scal->cholFail; }
+  }
+  if (t == 0) p.tickets[TK_POST] = 0;
 }
 
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_dogleg_vectors, dim3(vecGrid(p)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 1, vecGrid(p), 0);
-  launchJv(p, p.vC, p.vL, s);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 2, p.N > 0 ? jvGrid(p.N) : 0, p.F);
+  const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 2048) : 0;
+  const int nFac = p.F > 0 ? min((p.F + 3) / 4, 1024) : 0;
+  if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac);
+  else hipLaunchKernelGGL(k_post_solve<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac);
 }
 
 // traditional dogleg (ceres dogleg_strategy.cc) expressed on the un-scaled vectors:
 //   delta_i = cg * g_i/htil_i + cn * (-y_i)
-__global__ __launch_bounds__(256) void k_dogleg_step(DeviceProblem p, double radius) {
+// followed by candidate = x [+] delta and the partial sums of |x - x_cand|^2 and |x|^2 over all variable blocks;
+// the last block reduces them.  J*delta is never formed: |J delta|^2 and (J delta).r follow from group B.
+__global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) {
+  __shared__ double red[4 * 2];
+  __shared__ int lastFlag;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = p.d + 3 * p.L;
   const SolverScalars& sc = *p.scal;
   const double gnorm = sqrt(sc.gHatSq), gnnorm = sqrt(sc.gnHatSq);
   const double alpha = sc.gHatSq / sc.jgSq;
@@ -2147,19 +2145,13 @@ __global__ __launch_bounds__(256) void k_dogleg_step(DeviceProblem p, double rad
     cn = beta;
     stepNorm = sqrt(fmax(cg * cg * sc.gHatSq + 2 * cg * cn * sc.gDotGn + cn * cn * sc.gnHatSq, 0.0));
   }
-  if (i == 0) p.scal->doglegStepNorm = stepNorm;
-  if (i < n) {
-    if (i < p.d) { const double v = cg * p.vC[i] - cn * p.yC[i]; p.deltaC[i] = v; }
-    else { const int k = i - p.d; const double v = cg * p.vL[k] - cn * p.yL[k]; p.deltaL[k] = v; }
+  if (i == 0) {
+    p.scal->doglegStepNorm = stepNorm;
+    p.scal->jdSq = cg * cg * sc.jgSq - 2.0 * cg * cn * sc.jvDotJy + cn * cn * sc.jySq;
+    p.scal->jdDotR = cg * sc.jvDotR - cn * sc.jyDotR;
   }
-}
-
-// candidate = x [+] delta ; partial sums of |x - x_cand|^2 and |x|^2 over all variable blocks
-__global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
-  __shared__ double red[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nBlk = p.nPose + p.nExt + p.nSb;
-  double st = 0, xn = 0;
+  double acc[2] = {0, 0};  // |x - x_cand|^2, |x|^2
   if (i < nBlk) {
     if (i < p.nPose + p.nExt) {
       const bool isPose = i < p.nPose;
@@ -2168,11 +2160,12 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
       double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
       const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
       if (off >= 0) {
-        double xo[7];
-        poseOplus(x, p.deltaC + off, xo);
+        double dl[6], xo[7];
+        for (int k = 0; k < 6; ++k) dl[k] = cg * p.vC[off + k] - cn * p.yC[off + k];
+        poseOplus(x, dl, xo);
         for (int k = 0; k < 7; ++k) {
           xc[k] = xo[k];
-          if (p.ownsCamera) { st += (x[k] - xo[k]) * (x[k] - xo[k]); xn += x[k] * x[k]; }
+          if (p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
         }
       } else {
         for (int k = 0; k < 7; ++k) xc[k] = x[k];
@@ -2183,9 +2176,9 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
       double* xc = p.sbC + (size_t)slot * 9;
       const int off = p.sbOff[slot];
       for (int k = 0; k < 9; ++k) {
-        const double xo = off >= 0 ? x[k] + p.deltaC[off + k] : x[k];
+        const double xo = off >= 0 ? x[k] + (cg * p.vC[off + k] - cn * p.yC[off + k]) : x[k];
         xc[k] = xo;
-        if (off >= 0 && p.ownsCamera) { st += (x[k] - xo) * (x[k] - xo); xn += x[k] * x[k]; }
+        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo) * (x[k] - xo); acc[1] += x[k] * x[k]; }
       }
     }
   } else if (i < nBlk + p.L) {
@@ -2193,29 +2186,55 @@ __global__ __launch_bounds__(256) void k_retract(DeviceProblem p) {
     const double* x = p.lm + 4 * (size_t)l;
     double* xc = p.lmC + 4 * (size_t)l;
     for (int k = 0; k < 3; ++k) {
-      const double xo = x[k] + p.deltaL[3 * l + k];
+      const double xo = x[k] + (cg * p.vL[3 * l + k] - cn * p.yL[3 * l + k]);
       xc[k] = xo;
-      st += (x[k] - xo) * (x[k] - xo);
-      xn += x[k] * x[k];
+      acc[0] += (x[k] - xo) * (x[k] - xo);
+      acc[1] += x[k] * x[k];
     }
     xc[3] = x[3] + 0.0;
-    xn += x[3] * x[3];
+    acc[1] += x[3] * x[3];
   }
-  const double a = blockSum(st, red);
-  const double b = blockSum(xn, red);
-  if (threadIdx.x == 0) {
-    p.partial[(size_t)PS_STEP * kMaxPartials + blockIdx.x] = a;
-    p.partial[(size_t)PS_XNORM * kMaxPartials + blockIdx.x] = b;
+  const double mine = blockSumK<2>(acc, red, -1);
+  if (threadIdx.x < 2) p.partial[(size_t)(threadIdx.x == 0 ? PS_STEP : PS_XNORM) * kMaxPartials + blockIdx.x] = mine;
+  if (!lastBlockDone(&p.tickets[TK_STEP], &lastFlag)) return;
+  for (int k = 0; k < 2; ++k) {
+    double s = 0;
+    const double* src = p.partial + (size_t)(k == 0 ? PS_STEP : PS_XNORM) * kMaxPartials;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) s += src[j];
+    acc[k] = s;
+  }
+  const double tot = blockSumK<2>(acc, red, -1);
+  if (threadIdx.x == 0) p.scal->stepNormSq = tot;
+  if (threadIdx.x == 1) p.scal->xNormSq = tot;
+  if (threadIdx.x == 0) p.tickets[TK_STEP] = 0;
+}
+
+// final single-block reduction of the cost partials into SolverScalars
+__global__ __launch_bounds__(256) void k_reduce_cost(DeviceProblem p, int nA, int nB) {
+  __shared__ double red[4];
+  const int t = threadIdx.x;
+  auto sumSlot = [&](int slot, int n) {
+    double s = 0;
+    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
+    return blockSum(s, red);
+  };
+  const double a = sumSlot(PS_COST_REPROJ, nA);
+  const double b = sumSlot(PS_COST_FACTORS, nB);
+  if (t == 0) {
+    const double bf = p.ownsCamera ? b : 0.0;
+    const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
+    p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
+    p.scal->cost = a + bf + pr;
   }
 }
 
+void launchCost(const DeviceProblem& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_cost, dim3(1), dim3(256), 0, s, p, p.N > 0 ? evalGrid(p.N) : 0, p.F);
+}
+
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s) {
-  hipLaunchKernelGGL(k_dogleg_step, dim3(vecGrid(p)), dim3(256), 0, s, p, radius);
-  launchJv(p, p.deltaC, p.deltaL, s);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 3, p.N > 0 ? jvGrid(p.N) : 0, p.F);
   const int nB = (p.nPose + p.nExt + p.nSb + p.L + 255) / 256;
-  hipLaunchKernelGGL(k_retract, dim3(nB), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, p, 4, nB, 0);
+  hipLaunchKernelGGL(k_step_retract, dim3(nB), dim3(256), 0, s, p, radius);
 }
 
 // ================================================================ K9: landmark quality (Estimator.cpp:902-923)

@@ -67,25 +67,32 @@ struct PriorBlock {
 
 // scalar results of one iteration, read back by the host once per iteration
 struct SolverScalars {
-  // --- 12 summable scalars (contiguous: one all-reduce(sum) in landmark-sharded mode)
-  // group A (8): produced by the step + candidate evaluation
+  // --- group A (8 summable scalars): produced by the step (retraction) and the candidate evaluation
   double cost;            // cost at the evaluated point (current or candidate)
   double costReproj, costFactors, costPrior;
-  double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
   double stepNormSq, xNormSq;
-  // group B (4): produced by the dogleg preparation
+  double spareA0, spareA1;
+  // --- group B (8 summable scalars): produced once per linearisation by the post-solve pass.  With
+  // v = g / htil (steepest descent) and y = Gauss-Newton solution, J*delta is linear in the dogleg
+  // coefficients, so the five J sums below price ANY dogleg step of this linearisation.
   double gHatSq;          // |g_hat|^2
-  double jgSq;            // |J (g / htil)|^2          (Cauchy point)
+  double jgSq;            // |J v|^2                    (Cauchy point)
   double gnHatSq;         // |gn_hat|^2
   double gDotGn;          // g_hat . gn_hat
+  double jySq;            // |J y|^2
+  double jvDotJy;         // (J v).(J y)
+  double jvDotR;          // (J v).r
+  double jyDotR;          // (J y).r
   // --- 2 max-reduced scalars
   double gradMax;         // max |g_full|
   double failMax;         // (double)cholFail, for the max all-reduce
+  // --- derived on the device from the (all-reduced) sums and the trust-region radius
+  double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
   double doglegStepNorm;
   int cholFail;           // != 0 when S or a landmark block is not positive definite
   int pad;
 };
-constexpr int kNumSumScalars = 12, kNumMaxScalars = 2;
+constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGroupMax = 16;  // offsets (doubles) of the all-reduced groups
 
 struct DeviceProblem {
   // sizes
@@ -115,8 +122,9 @@ struct DeviceProblem {
   double *priorH, *priorBp;
   double priorC0;
   PriorBlock* priorBlk;
-  double *priorDchi, *priorGrad, *priorMv;   // scratch m
-  double* priorM3;                           // per block 3x3 rotation map (row-major 9), identity for non-pose
+  double *priorDchi, *priorGrad, *priorM3;      // linearisation of the prior at the accepted point: m, m, 9 per block
+  double *priorDchiC, *priorGradC, *priorM3C;   // ... at the candidate (swapped on acceptance)
+  double *priorMv, *priorMy;                    // scratch m
   // normal equations
   double *S, *gRed, *gFull, *hC, *htilC, *scaleC;
   double *Vinv, *bl, *hL, *scaleL;           // per landmark 6 / 3 / 3 / 3
@@ -127,6 +135,7 @@ struct DeviceProblem {
   double *cholL;                             // factor of S
   SolverScalars* scal;
   double* partial;                           // reduction scratch
+  unsigned int* tickets;                     // last-block-done counters of the fused reductions
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

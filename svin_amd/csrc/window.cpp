@@ -618,7 +618,7 @@ void Window::pack() {
   upload(dFactors_, hFac, s); upload(dImus_, hImu, s); upload(dImuT_, hImuT, s); upload(dImuM_, hImuM, s);
   if (hasPrior_) {
     upload(dPriorH_, priorHt_, s); upload(dPriorBp_, priorBp_, s); upload(dPriorBlk_, hPb, s);
-    dPriorScratch_.reserve((size_t)3 * priorM + 9 * hPb.size() + 16);
+    dPriorScratch_.reserve((size_t)6 * priorM + 18 * hPb.size() + 16);
   }
   const int dpad = ((d + 15) / 16) * 16;
   // S and the camera-side vectors share one allocation: [S | gRed | gFull | hC | ...] is all-reduced as one message
@@ -656,9 +656,11 @@ void Window::pack() {
   p.imus = dImus_.p; p.imuT = dImuT_.p; p.imuMeas = dImuM_.p;
   if (hasPrior_) {
     p.priorH = dPriorH_.p; p.priorBp = dPriorBp_.p; p.priorC0 = priorC0_; p.priorBlk = dPriorBlk_.p;
-    p.priorDchi = dPriorScratch_.p; p.priorGrad = dPriorScratch_.p + priorM; p.priorMv = dPriorScratch_.p + 2 * priorM;
-    p.priorM3 = dPriorScratch_.p + 3 * priorM;
-    HIP_OK(hipMemsetAsync(dPriorScratch_.p, 0, sizeof(double) * (3 * (size_t)priorM + 9 * hPb.size()), s));
+    double* ps = dPriorScratch_.p;
+    p.priorDchi = ps; p.priorGrad = ps + priorM; p.priorDchiC = ps + 2 * priorM; p.priorGradC = ps + 3 * priorM;
+    p.priorMv = ps + 4 * priorM; p.priorMy = ps + 5 * priorM;
+    p.priorM3 = ps + 6 * priorM; p.priorM3C = p.priorM3 + 9 * hPb.size();
+    HIP_OK(hipMemsetAsync(ps, 0, sizeof(double) * (6 * (size_t)priorM + 18 * hPb.size()), s));
   }
   const int dd = std::max(d, 1);
   p.S = dS_.p;
@@ -672,6 +674,7 @@ void Window::pack() {
   p.cholL = dChol_.p;
   p.scal = dScal_.p;
   p.partial = dPartial_.p;
+  p.tickets = reinterpret_cast<unsigned int*>(dPartial_.p + (size_t)14 * 4096);  // zeroed with the partials
   HIP_OK(hipMemsetAsync(dScal_.p, 0, sizeof(SolverScalars), s));
   HIP_OK(hipMemsetAsync(dPartial_.p, 0, sizeof(double) * 16 * 4096, s));
 }
@@ -742,7 +745,7 @@ void Window::solve(size_t numIter, bool verbose) {
     HIP_OK(hipStreamSynchronize(s));
     if (!allreduce_ || allreduce_(ptr, (uint64_t)n, op, allreduceUser_) != 0) throw std::runtime_error("all-reduce callback failed");
   };
-  double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..11] group B, [12..13] max group
+  double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..17] max group
   evaluateAll(false, s);
   AR(scalD, 4, 0);
   SolverScalars sc = readScalars();
@@ -759,6 +762,7 @@ void Window::solve(size_t numIter, bool verbose) {
     std::swap(p.pose, p.poseC); std::swap(p.ext, p.extC); std::swap(p.sb, p.sbC); std::swap(p.lm, p.lmC);
     std::swap(p.rCur, p.rCand); std::swap(p.JpCur, p.JpCand); std::swap(p.JlCur, p.JlCand); std::swap(p.JeCur, p.JeCand);
     std::swap(p.linCur, p.linCand);
+    std::swap(p.priorDchi, p.priorDchiC); std::swap(p.priorGrad, p.priorGradC); std::swap(p.priorM3, p.priorM3C);
   };
   auto finish = [&](int term) {
     summary_.termination = term;
@@ -779,8 +783,8 @@ void Window::solve(size_t numIter, bool verbose) {
         launchFinalizeNormalEquations(p, mu, initScale, s);
         launchSolveReduced(p, s);
         launchDoglegPrepare(p, s);
-        AR(scalD + 8, 4, 0);
-        AR(scalD + 12, 2, 1);
+        AR(scalD + kScalGroupB, 8, 0);
+        AR(scalD + kScalGroupMax, 2, 1);
       }
       launchDoglegStep(p, radius, s);
       evaluateAll(true, s);
