@@ -52,6 +52,40 @@ enum PartialSlot : int {
   PS_GHAT = 6, PS_GNHAT = 7, PS_GDOTGN = 8, PS_GRADMAX = 9, PS_JY_SQ = 10, PS_JVJY = 11, PS_JY_DOT = 12, PS_COUNT = 13
 };
 
+enum Ticket : int { TK_POST = 0, TK_STEP = 1, TK_EVAL = 2 };
+// last-block-done: returns true in every thread of the block that finishes last (its loads see all other
+// blocks' partials); the summation order over the partial slots is fixed, so the result is deterministic
+__device__ __forceinline__ bool lastBlockDone(unsigned int* ticket, int* flagLds) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int tk = atomicAdd(ticket, 1u);
+    *flagLds = (tk == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool last = *flagLds != 0;
+  if (last) __threadfence();
+  return last;
+}
+
+// total cost = reprojection partials (nA blocks) + factor partials (nB) + prior, into SolverScalars (whole block)
+__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) {
+  const int t = threadIdx.x;
+  auto sumSlot = [&](int slot, int n) {
+    double s = 0;
+    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
+    return blockSum(s, red);
+  };
+  const double a = sumSlot(PS_COST_REPROJ, nA);
+  const double b = sumSlot(PS_COST_FACTORS, nB);
+  if (t == 0) {
+    const double bf = p.ownsCamera ? b : 0.0;
+    const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
+    p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
+    p.scal->cost = a + bf + pr;
+  }
+}
+
 // ================================================================ K1: reprojection evaluation
 template <bool ROBUST, bool WITH_EXT>
 __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
@@ -771,7 +805,7 @@ __device__ __forceinline__ int blockOff(const DeviceProblem& p, int kind, int sl
   return p.sbOff[slot];
 }
 
-__global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand) {
+__global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand, int costBlocksA) {
   __shared__ FactorShared sh;
   const int f = blockIdx.x, t = threadIdx.x;
   const DevFactor& fac = p.factors[f];
@@ -978,6 +1012,15 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand)
     for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
     p.partial[(size_t)PS_COST_FACTORS * kMaxPartials + f] = 0.5 * c;
   }
+  // the factor block that finishes last also sums the cost (reprojection partials were written by the previous
+  // kernel of the stream) -- saves the separate reduction launch
+  if (costBlocksA >= 0) {
+    __shared__ int lastFlag;
+    if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
+      reduceCost(p, costBlocksA, (int)gridDim.x, sh.rw);
+      if (t == 0) p.tickets[TK_EVAL] = 0;
+    }
+  }
 }
 
 void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
@@ -985,16 +1028,23 @@ void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, 
   hipLaunchKernelGGL(k_imu_propagation, dim3(1), dim3(256), 0, s, im, T, M, io, jac, cov, used);
 }
 
-void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s) {
+void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost) {
   if (p.F == 0 || !p.ownsCamera) return;
-  hipLaunchKernelGGL(k_eval_factors, dim3(p.F), dim3(256), 0, s, p, cand ? 1 : 0);
+  hipLaunchKernelGGL(k_eval_factors, dim3(p.F), dim3(256), 0, s, p, cand ? 1 : 0,
+                     sumCost ? (p.N > 0 ? evalGrid(p.N) : 0) : -1);
+}
+// which kernel of evaluateAll sums the cost: 2 = prior evaluation, 1 = factor evaluation, 0 = separate launch
+int costSummedBy(const DeviceProblem& p) {
+  if (!p.ownsCamera) return 0;
+  if (p.priorM > 0) return 2;
+  return p.F > 0 ? 1 : 0;
 }
 
 // ================================================================ K3: marginalisation prior (H-space)
 // cost = 0.5 c0 + bp^T dchi + 0.5 dchi^T Ht dchi ;  grad (lin space) = bp + Ht dchi
 // Ceres multiplies the ambient Jacobian (J_min * lift(x_lin)) by PlusJacobian(x): for a pose block the
 // effective tangent map is M = blockdiag(I3, oplus(q_cur * q_lin^-1)[0:3,0:3]) (MarginalizationError.cpp:798-844).
-__global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
+__global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
   __shared__ double red[4];
   const int t = threadIdx.x, m = p.priorM;
   double* priorDchi = cand ? p.priorDchiC : p.priorDchi;
@@ -1035,11 +1085,15 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand) {
   }
   const double tot = blockSum(c, red);
   if (t == 0) p.scal->costPrior = 0.5 * p.priorC0 + tot;
+  if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
+    __syncthreads();
+    reduceCost(p, costBlocksA, p.F, red);
+  }
 }
 
-void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s) {
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost) {
   if (p.priorM == 0 || !p.ownsCamera) return;
-  hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0);
+  hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0, sumCost ? (p.N > 0 ? evalGrid(p.N) : 0) : -1);
 }
 
 // row i of the prior -> (reduced-system row, or -1) with the 3x3 rotation map applied on the fly
@@ -1101,11 +1155,48 @@ __global__ void k_prior_accumulate(DeviceProblem p) {
   }
 }
 // ================================================================ K5: normal equations + landmark Schur complement
+// generic small factors: J^T J into S (both triangles), J^T r into gRed/gFull, column norms into hC
+__device__ void factorsAccumulate(const DeviceProblem& p, int f, int* colRow) {
+  const FactorLin& lin = p.linCur[f];
+  const int m = lin.m, nc = lin.ncols;
+  // column -> reduced row map (colRow: 30 ints of LDS)
+  if (threadIdx.x < 30) {
+    int c = threadIdx.x, row = -1, base = 0;
+    for (int b = 0; b < 4; ++b) {
+      if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
+      base += lin.dim[b];
+    }
+    colRow[threadIdx.x] = (c < nc) ? row : -1;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
+    const int a = idx / nc, b = idx % nc;
+    const int ra = colRow[a], rb = colRow[b];
+    if (ra < 0 || rb < 0) continue;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
+    atomicAdd(&p.S[(size_t)ra * p.d + rb], s);
+    if (a == b) {
+      atomicAdd(&p.hC[ra], s);
+      double g = 0;
+      for (int k = 0; k < m; ++k) g += lin.J[k * nc + a] * lin.r[k];
+      atomicAdd(&p.gRed[ra], g);
+      atomicAdd(&p.gFull[ra], g);
+    }
+  }
+}
+
 constexpr int kStage = 34;  // doubles staged per observation: Jl 6, Jp 12, Je 12, offP, offE (as double), pad
 
+// Blocks [0, nSchurBlocks) run the landmark Schur complement; blocks beyond that accumulate one small factor each
+// (J^T J straight into S with atomics) so that the two independent parts of the build share one launch.
 template <bool USE_LDS, bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int initScale) {
+__global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int initScale, int nSchurBlocks) {
   extern __shared__ double smem[];
+  if ((int)blockIdx.x >= nSchurBlocks) {
+    factorsAccumulate(p, blockIdx.x - nSchurBlocks, reinterpret_cast<int*>(smem));
+    return;
+  }
   const int dC = p.dC;
   const int ld = USE_LDS ? dC : dC;  // slab leading dimension
   double* accS;
@@ -1129,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
   const double* Jp = p.JpCur;
   const double* Jl = p.JlCur;
   const double* Je = p.JeCur;
-  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  const int gw = blockIdx.x * 4 + wave, nw = nSchurBlocks * 4;
   for (int l = gw; l < p.L; l += nw) {
     const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
     // ---- pass 1: V = sum Jl^T Jl, bl = sum Jl^T r (wave reduction)
@@ -1303,46 +1394,15 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
   }
 }
 
-// generic small factors: J^T J into S (both triangles), J^T r into gRed/gFull, column norms into hC
-__global__ __launch_bounds__(256) void k_factors_accumulate(DeviceProblem p) {
-  const FactorLin& lin = p.linCur[blockIdx.x];
-  const int m = lin.m, nc = lin.ncols;
-  // column -> reduced row map
-  __shared__ int colRow[30];
-  if (threadIdx.x < 30) {
-    int c = threadIdx.x, row = -1, base = 0;
-    for (int b = 0; b < 4; ++b) {
-      if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
-      base += lin.dim[b];
-    }
-    colRow[threadIdx.x] = (c < nc) ? row : -1;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
-    const int a = idx / nc, b = idx % nc;
-    const int ra = colRow[a], rb = colRow[b];
-    if (ra < 0 || rb < 0) continue;
-    double s = 0;
-    for (int k = 0; k < m; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
-    atomicAdd(&p.S[(size_t)ra * p.d + rb], s);
-    if (a == b) {
-      atomicAdd(&p.hC[ra], s);
-      double g = 0;
-      for (int k = 0; k < m; ++k) g += lin.J[k * nc + a] * lin.r[k];
-      atomicAdd(&p.gRed[ra], g);
-      atomicAdd(&p.gFull[ra], g);
-    }
-  }
-}
-
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
-// 64 entries x 4 slab-quarters per 256-thread block; fixed summation order -> deterministic
+// 16 entries x 16 slab-partitions per 256-thread block; fixed summation order -> deterministic
+constexpr int kSlabParts = 16;
 __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   __shared__ double part[256];
   const int dC = p.dC;
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + e;
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + e;
   const int total = dC * dC + 3 * dC;
   size_t src = 0;
   int rr = 0, cc = 0;
@@ -1355,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   }
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   if (idx < total) {
-    const int per = (p.nSlabs + 3) / 4;
+    const int per = (p.nSlabs + kSlabParts - 1) / kSlabParts;
     const int k0 = q * per, k1 = min(p.nSlabs, k0 + per);
     int k = k0;
     for (; k + 3 < k1; k += 4) {
@@ -1369,7 +1429,9 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   part[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (q == 0 && idx < total) {
-    const double s = (part[e] + part[64 + e]) + (part[128 + e] + part[192 + e]);
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < kSlabParts; ++k) s += part[16 * k + e];
     if (idx < dC * dC) p.S[(size_t)rr * p.d + cc] += s;
     else {
       const int v = idx - dC * dC;
@@ -1379,16 +1441,20 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
     }
   }
 }
-// camera-column metric, damping on the diagonal of S, gradient max-norm (cam part)
-__global__ void k_finalize_diag(DeviceProblem p, double mu, int initScale) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.d) return;
+// camera-column metric (Jacobi scaling fixed at iteration 0): returns the damping mu*htil for row i
+__device__ __forceinline__ double finalizeRow(const DeviceProblem& p, int i, double mu, int initScale) {
   double sc;
   if (initScale) { sc = 1.0 / (1.0 + sqrt(p.hC[i])); p.scaleC[i] = sc; }
   else sc = p.scaleC[i];
   const double ht = fmin(fmax(p.hC[i] * sc * sc, 1e-6), 1e32) / (sc * sc);
   p.htilC[i] = ht;
-  p.S[(size_t)i * p.d + i] += mu * ht;
+  return mu * ht;
+}
+// stand-alone version for the inspection hooks (the trust-region loop fuses this into the solver's load)
+__global__ void k_finalize_diag(DeviceProblem p, double mu, int initScale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.d) return;
+  p.S[(size_t)i * p.d + i] += finalizeRow(p, i, mu, initScale);
 }
 
 __global__ void k_zero_build(DeviceProblem p) {
@@ -1406,9 +1472,19 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize_diag, dim3((p.d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
 }
-void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
-  const int d = p.d, dC = p.dC;
-  hipLaunchKernelGGL(k_zero_build, dim3((d * d + 255) / 256), dim3(256), 0, s, p);
+__global__ __launch_bounds__(256) void k_factors_only(DeviceProblem p) {
+  __shared__ int colRow[30];
+  factorsAccumulate(p, blockIdx.x, colRow);
+}
+void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_zero_build, dim3((p.d * p.d + 255) / 256), dim3(256), 0, s, p);
+}
+// zeroFirst = false: the accumulators are already clear (pack() clears them, and k_post_solve clears them again
+// for the next linearisation of the trust-region loop)
+void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst) {
+  const int dC = p.dC;
+  if (zeroFirst) launchZeroBuild(p, s);
+  const int nFac = (p.F > 0 && p.ownsCamera) ? p.F : 0;
   if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;
@@ -1419,7 +1495,8 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_schur<true, E>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                               (int)(accBytes + stageBytes));                                                        \
-    hipLaunchKernelGGL((k_schur<true, E>), dim3(grid), dim3(256), accBytes + stageBytes, s, p, mu, initScale ? 1 : 0); \
+    hipLaunchKernelGGL((k_schur<true, E>), dim3(grid + nFac), dim3(256), accBytes + stageBytes, s, p, mu,          \
+                       initScale ? 1 : 0, grid);                                                                    \
   } while (0)
       if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
@@ -1431,13 +1508,15 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_schur<false, E>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                               (int)stageBytes);                                                                     \
-    hipLaunchKernelGGL((k_schur<false, E>), dim3(grid), dim3(256), stageBytes, s, q, mu, initScale ? 1 : 0);        \
+    hipLaunchKernelGGL((k_schur<false, E>), dim3(grid + nFac), dim3(256), stageBytes, s, q, mu, initScale ? 1 : 0, \
+                       grid);                                                                                       \
   } while (0)
       if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
     }
+  } else if (nFac > 0) {
+    hipLaunchKernelGGL(k_factors_only, dim3(nFac), dim3(256), 0, s, p);
   }
-  if (p.F > 0 && p.ownsCamera) hipLaunchKernelGGL(k_factors_accumulate, dim3(p.F), dim3(256), 0, s, p);
   if (p.priorM > 0 && p.ownsCamera) {
     const int n = p.priorM * p.priorM;
     hipLaunchKernelGGL(k_prior_accumulate, dim3((n + 255) / 256), dim3(256), 0, s, p);
@@ -1448,7 +1527,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     DeviceProblem q = p;
     if (!useLds) q.nSlabs = 1;
     const int n = dC * dC + 3 * dC;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 63) / 64), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 15) / 16), dim3(256), 0, s, q);
   }
 }
 
@@ -1482,7 +1561,7 @@ __device__ __forceinline__ void cholDiag16(double* sD, int lane, int* failFlag) 
   waveSync();
 }
 
-__global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) {
+__global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize) {
   extern __shared__ double smem[];
   double* sD = smem;                    // 16 x 17 diagonal block
   double* sP = smem + 16 * kPanelLd;    // panel rows x 17 (later: rhs vector)
@@ -1496,6 +1575,9 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad) 
     else if (i == j) v = 1.0;
     Lm[idx] = v;
   }
+  __syncthreads();
+  if (fuseFinalize)
+    for (int i = t; i < d; i += blockDim.x) Lm[(size_t)i * dpad + i] += finalizeRow(p, i, mu, initScale);
   __syncthreads();
   const int nT = dpad / 16;
   const int wave = t >> 6, lane = t & 63;
@@ -1704,7 +1786,8 @@ constexpr int kTile = 16 * kPanelLd;  // doubles per tile
 __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
 
 constexpr int kCholLdsThreads = 512;  // 8 waves: 256 VGPRs per lane keep the 16x16 diagonal factorisation out of scratch
-__global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad) {
+__global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
+                                                                    int fuseFinalize) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, d = p.d, nT = dpad / 16;
   const int wave = t >> 6, lane = t & 63, nW = kCholLdsThreads / 64;
@@ -1748,6 +1831,10 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
   }
   for (int i = t; i < dpad; i += blockDim.x) rhs[i] = (i < d) ? p.gRed[i] : 0.0;
   __syncthreads();
+  if (fuseFinalize) {  // metric + damping on the diagonal (k_finalize_diag) applied to the LDS copy
+    for (int i = t; i < d; i += blockDim.x) tileAt(tiles, i >> 4, i >> 4)[(i & 15) * kPanelLd + (i & 15)] += finalizeRow(p, i, mu, initScale);
+    __syncthreads();
+  }
 #ifdef SVIN_CHOL_TIMING
   long long qq0 = __builtin_readcyclecounter();
   if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(qq0 - ql0);
@@ -1874,17 +1961,18 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
   for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
 }
 
-void launchSolveReduced(const DeviceProblem& p, hipStream_t s) {
+void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
   const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 2 * dpad) * 8;
   if (ldsBytes <= 156 * 1024) {
     (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad);
+    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0);
   } else {
     const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
     (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad);
+    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
   }
 }
 
@@ -1910,22 +1998,6 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
   return mine;
 }
 
-enum Ticket : int { TK_POST = 0, TK_STEP = 1 };
-// last-block-done: returns true in every thread of the block that finishes last (its loads see all other
-// blocks' partials); the summation order over the partial slots is fixed, so the result is deterministic
-__device__ __forceinline__ bool lastBlockDone(unsigned int* ticket, int* flagLds) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int tk = atomicAdd(ticket, 1u);
-    *flagLds = (tk == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  const bool last = *flagLds != 0;
-  if (last) __threadfence();
-  return last;
-}
-
 // partial slots of the post-solve pass
 constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
 __device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};
@@ -1945,6 +2017,10 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   double acc[kPostK];
 #pragma unroll
   for (int k = 0; k < kPostK; ++k) acc[k] = 0;
+  // clear the accumulators of the next linearisation (nothing reads S / gRed / hC after the solve; gFull is
+  // still needed by the last block below and is cleared there)
+  for (int i = b * blockDim.x + t; i < p.d * p.d; i += gridDim.x * blockDim.x) p.S[i] = 0.0;
+  for (int i = b * blockDim.x + t; i < p.d; i += gridDim.x * blockDim.x) { p.gRed[i] = 0.0; p.hC[i] = 0.0; }
   if (b < nLmBlocks) {
     const int grp = t >> 4, gl = t & 15;
     const size_t N = (size_t)p.N;
@@ -2108,8 +2184,9 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     //                     A  B  C  D  E  gHat gnHat gDotGn
     const int field[8] = {1, 4, 5, 6, 7, 0, 2, 3};
     if (t < 8) dst[field[t]] = tot;
-    else { p.scal->gradMax = tot; p.scal->failMax = (double)p.scal->cholFail; }
+    else { p.scal->gradMax = tot; p.scal->failMax = (double)p.scal->cholFail; p.scal->cholFail = 0; }
   }
+  for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
   if (t == 0) p.tickets[TK_POST] = 0;
 }
 
@@ -2209,23 +2286,11 @@ __global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double ra
   if (threadIdx.x == 0) p.tickets[TK_STEP] = 0;
 }
 
-// final single-block reduction of the cost partials into SolverScalars
+// final single-block reduction of the cost partials into SolverScalars (used when no later evaluation kernel
+// can take it over, see evaluateAll)
 __global__ __launch_bounds__(256) void k_reduce_cost(DeviceProblem p, int nA, int nB) {
   __shared__ double red[4];
-  const int t = threadIdx.x;
-  auto sumSlot = [&](int slot, int n) {
-    double s = 0;
-    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
-    return blockSum(s, red);
-  };
-  const double a = sumSlot(PS_COST_REPROJ, nA);
-  const double b = sumSlot(PS_COST_FACTORS, nB);
-  if (t == 0) {
-    const double bf = p.ownsCamera ? b : 0.0;
-    const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
-    p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
-    p.scal->cost = a + bf + pr;
-  }
+  reduceCost(p, nA, nB, red);
 }
 
 void launchCost(const DeviceProblem& p, hipStream_t s) {

@@ -140,13 +140,16 @@ struct DeviceProblem {
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.
 void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_t s);
-void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s);
-void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s);
+void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false);
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false);
+int costSummedBy(const DeviceProblem& p);  // 2 = prior evaluation, 1 = factor evaluation, 0 = separate launchCost
 void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // the same in two halves, so that a landmark-sharded solve can all-reduce [S | gRed | gFull | hC] in between
-void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
+void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst = true);
+void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
-void launchSolveReduced(const DeviceProblem& p, hipStream_t s);          // Cholesky + GN step (cam + landmarks)
+// Cholesky + GN step of the reduced system; fuseFinalize applies k_finalize_diag (metric + damping) while loading S
+void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s);         // g_hat norms, Cauchy J*v pass, gn norms
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms
 void launchCost(const DeviceProblem& p, hipStream_t s);                  // sums partial costs into scal->cost

@@ -663,6 +663,8 @@ void Window::pack() {
     HIP_OK(hipMemsetAsync(ps, 0, sizeof(double) * (6 * (size_t)priorM + 18 * hPb.size()), s));
   }
   const int dd = std::max(d, 1);
+  // accumulators start clear: the trust-region loop never launches k_zero_build (k_post_solve re-clears them)
+  HIP_OK(hipMemsetAsync(dS_.p, 0, sizeof(double) * ((size_t)d * d + (size_t)12 * dd), s));
   p.S = dS_.p;
   double* vecBase = dS_.p + (size_t)d * d;
   p.gRed = vecBase; p.gFull = vecBase + dd; p.hC = vecBase + 2 * dd; p.htilC = vecBase + 3 * dd;
@@ -713,9 +715,10 @@ void Window::downloadStates() {
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
   launchEvalReproj(prob_, cand, true, s);
-  launchEvalFactors(prob_, cand, s);
-  launchEvalPrior(prob_, cand, s);
-  launchCost(prob_, s);
+  const int who = costSummedBy(prob_);
+  launchEvalFactors(prob_, cand, s, who == 1);
+  launchEvalPrior(prob_, cand, s, who == 2);
+  if (who == 0) launchCost(prob_, s);
 }
 
 SolverScalars Window::readScalars() {
@@ -778,10 +781,9 @@ void Window::solve(size_t numIter, bool verbose) {
     bool stepOk = true;
     while (true) {
       if (!reuse) {
-        launchAccumulateNormalEquations(p, mu, initScale, s);
+        launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/false);  // pack() / k_post_solve cleared them
         AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
-        launchFinalizeNormalEquations(p, mu, initScale, s);
-        launchSolveReduced(p, s);
+        launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
         launchDoglegPrepare(p, s);
         AR(scalD + kScalGroupB, 8, 0);
         AR(scalD + kScalGroupMax, 2, 1);
@@ -790,7 +792,7 @@ void Window::solve(size_t numIter, bool verbose) {
       evaluateAll(true, s);
       AR(scalD, 8, 0);
       sc = readScalars();
-      if (world_ > 1) sc.cholFail = sc.failMax != 0.0 ? 1 : 0;
+      sc.cholFail = sc.failMax != 0.0 ? 1 : 0;  // the device flag itself is re-armed by k_post_solve
       if (!reuse && sc.cholFail) {
         mu *= mu_increase;
         if (mu < max_mu) continue;
