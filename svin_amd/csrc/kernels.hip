@@ -1197,6 +1197,10 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
     factorsAccumulate(p, blockIdx.x - nSchurBlocks, reinterpret_cast<int*>(smem));
     return;
   }
+#ifdef SVIN_SCHUR_TIMING
+  const long long qs0 = __builtin_readcyclecounter();
+  long long qPass1 = 0, qVinv = 0, qPass2 = 0;
+#endif
   const int dC = p.dC;
   const int ld = USE_LDS ? dC : dC;  // slab leading dimension
   double* accS;
@@ -1220,9 +1224,15 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
   const double* Jp = p.JpCur;
   const double* Jl = p.JlCur;
   const double* Je = p.JeCur;
+#ifdef SVIN_SCHUR_TIMING
+  const long long qs1 = __builtin_readcyclecounter();
+#endif
   const int gw = blockIdx.x * 4 + wave, nw = nSchurBlocks * 4;
   for (int l = gw; l < p.L; l += nw) {
     const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+#ifdef SVIN_SCHUR_TIMING
+    const long long qa = __builtin_readcyclecounter();
+#endif
     // ---- pass 1: V = sum Jl^T Jl, bl = sum Jl^T r (wave reduction)
     double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (int i = lane; i < n; i += 64) {
@@ -1235,6 +1245,10 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
     }
     v00 = waveSum(v00); v01 = waveSum(v01); v02 = waveSum(v02); v11 = waveSum(v11); v12 = waveSum(v12);
     v22 = waveSum(v22); b0 = waveSum(b0); b1 = waveSum(b1); b2 = waveSum(b2);
+#ifdef SVIN_SCHUR_TIMING
+    const long long qb = __builtin_readcyclecounter();
+    qPass1 += qb - qa;
+#endif
     // trust-region metric for the landmark columns (Jacobi scaling fixed at iteration 0)
     double sc0, sc1, sc2;
     if (initScale) {
@@ -1273,6 +1287,10 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
       p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
     }
     const double vb0 = w00 * b0 + w01 * b1 + w02 * b2, vb1 = w01 * b0 + w11 * b1 + w12 * b2, vb2 = w02 * b0 + w12 * b1 + w22 * b2;
+#ifdef SVIN_SCHUR_TIMING
+    const long long qc = __builtin_readcyclecounter();
+    qVinv += qc - qb;
+#endif
     // ---- pass 2: pairwise blocks  Jc_i^T (delta_ij I - Jl_i Vinv Jl_j^T) Jc_j
     for (int ci = 0; ci < n; ci += 64) {
       const int i = ci + lane;
@@ -1387,11 +1405,21 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
       }
     }
   }
+#ifdef SVIN_SCHUR_TIMING
+  const long long qs2 = __builtin_readcyclecounter();
+#endif
   if (USE_LDS) {
     __syncthreads();
     double* slab = p.slabs + (size_t)blockIdx.x * ((size_t)dC * dC + 3 * dC);
     for (int i = threadIdx.x; i < dC * dC + 3 * dC; i += blockDim.x) slab[i] = smem[i];
   }
+#ifdef SVIN_SCHUR_TIMING
+  const long long qs3 = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double* dbg = p.partial + (size_t)15 * 4096 + 16;
+    dbg[0] += (double)(qs1 - qs0); dbg[1] += (double)qPass1; dbg[2] += (double)qVinv; dbg[3] += (double)(qs2 - qs1); dbg[4] += (double)(qs3 - qs2);
+  }
+#endif
 }
 
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
@@ -1785,7 +1813,7 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneI
 constexpr int kTile = 16 * kPanelLd;  // doubles per tile
 __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
 
-constexpr int kCholLdsThreads = 512;  // 8 waves: 256 VGPRs per lane keep the 16x16 diagonal factorisation out of scratch
+constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: barrier + LDS pressure, the diagonal block is the critical path)
 __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
                                                                     int fuseFinalize) {
   extern __shared__ double smem[];
@@ -1798,6 +1826,10 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 #ifdef SVIN_CHOL_TIMING
   const long long ql0 = __builtin_readcyclecounter();
 #endif
+  // right-hand side and diagonal damping (one element per thread, d <= 176 < blockDim): their global loads
+  // are in flight together with the tile loads below
+  const double rhsMine = (t < d) ? p.gRed[t] : 0.0;
+  double dampMine = 0.0;
   // load the lower triangle of S tile by tile (identity padding): every wave first issues the loads of all its
   // tiles (independent, <= kMaxTilesPerWave x 4 values per lane in flight), then writes them to LDS -- the copy
   // is bound by one global-memory latency instead of one per element
@@ -1813,12 +1845,14 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
-        double x = (gi == gj) ? 1.0 : 0.0;
-        // diagonal tiles are kept fully symmetric (the MFMA trailing update preserves that)
-        if (tl < nTilesAll && gi < d && gj < d) x = (gj <= gi) ? p.S[(size_t)gi * d + gj] : p.S[(size_t)gj * d + gi];
-        v[it][rg] = x;
+        // branch-free: always read a valid element of the lower triangle, select afterwards.  Diagonal tiles are
+        // kept fully symmetric (the MFMA trailing update preserves that).
+        const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
+        const double x = p.S[(size_t)ci * d + cj];
+        v[it][rg] = (gi < d && gj < d) ? x : ((gi == gj) ? 1.0 : 0.0);
       }
     }
+    if (fuseFinalize && t < d) dampMine = finalizeRow(p, t, mu, initScale);
 #pragma unroll
     for (int it = 0; it < kMaxTilesPerWave; ++it) {
       const int tl = wave + it * nW;
@@ -1829,10 +1863,10 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
       }
     }
   }
-  for (int i = t; i < dpad; i += blockDim.x) rhs[i] = (i < d) ? p.gRed[i] : 0.0;
+  if (t < dpad) rhs[t] = rhsMine;
   __syncthreads();
   if (fuseFinalize) {  // metric + damping on the diagonal (k_finalize_diag) applied to the LDS copy
-    for (int i = t; i < d; i += blockDim.x) tileAt(tiles, i >> 4, i >> 4)[(i & 15) * kPanelLd + (i & 15)] += finalizeRow(p, i, mu, initScale);
+    if (t < d) tileAt(tiles, t >> 4, t >> 4)[(t & 15) * kPanelLd + (t & 15)] += dampMine;
     __syncthreads();
   }
 #ifdef SVIN_CHOL_TIMING
@@ -1883,9 +1917,36 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
     if (t == 0) p.partial[(size_t)15 * 4096 + 2] += (double)(q3 - q2);
 #endif
     // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA.  Look-ahead: wave 0 updates the next diagonal
-    // tile first and factorises it right away while waves 1.. work through the other tiles; the last wave first
-    // updates the tail of the right-hand side.
-    if (wave == nW - 1) {
+    // tile first and factorises it right away.  That routine is VALU-issue bound, so the wave sharing its SIMD
+    // (wave nW/2 for 2 waves per SIMD) stays off the matrix pipe and only updates the tail of the right-hand side;
+    // the other waves take the remaining tiles, software-pipelined (operands of the next tile are fetched before
+    // the current one is written back).
+    const int nUp = nR * (nR + 1) / 2;
+    const int quiet = nW / 2;  // shares SIMD 0 with wave 0
+    auto updateTile = [&](int I, int J) {
+      double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
+      const double* A = tileAt(tiles, kb + 1 + I, kb);
+      const double* B = tileAt(tiles, kb + 1 + J, kb);
+      d4_t acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+        const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+      return Cb;
+    };
+    if (wave == 0) {
+      if (nUp > 0) {
+        double* Cb = updateTile(0, 0);
+        waveSync();
+        cholDiag16Reg(Cb, dinv + k0 + 16, lane, &p.scal->cholFail);
+      }
+    } else if (wave == quiet) {
       for (int i = k0 + 16 + lane; i < dpad; i += 64) {
         const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
         double sacc = 0;
@@ -1893,33 +1954,63 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
         for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
         rhs[i] -= sacc;
       }
-    }
-    const int nUp = nR * (nR + 1) / 2;
-    int I = 0, J = 0;  // walk the lower-triangular tile list without square roots
-    for (int tile = 0; tile < nUp; ++tile) {
-      const int owner = (tile == 0) ? 0 : 1 + (tile - 1) % (nW - 1);
-      if (owner == wave) {
-        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
-        const double* A = tileAt(tiles, kb + 1 + I, kb);
-        const double* B = tileAt(tiles, kb + 1 + J, kb);
+    } else {
+      const int widx = wave - 1 - (wave > quiet ? 1 : 0), nWork = nW - 2;
+      // tile index -> (I, J) of the lower-triangular list (row-major, diagonal included)
+      auto decode = [&](int tile, int& I, int& J) {
+        I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        if ((I + 1) * (I + 2) / 2 <= tile) ++I;
+        if (I * (I + 1) / 2 > tile) --I;
+        J = tile - I * (I + 1) / 2;
+      };
+      int tile = 1 + widx;
+      if (tile < nUp) {
+        int I, J;
+        decode(tile, I, J);
+        double a[4], bq[4];
         d4_t acc;
+        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
+        {
+          const double* A = tileAt(tiles, kb + 1 + I, kb);
+          const double* B = tileAt(tiles, kb + 1 + J, kb);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+          for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
-          const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) { a[q] = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; bq[q] = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; }
         }
+        while (true) {
+          const int next = tile + nWork;
+          const bool more = next < nUp;
+          double an[4], bn[4];
+          d4_t accn = {0, 0, 0, 0};
+          double* Cn = Cb;
+          if (more) {
+            int In, Jn;
+            decode(next, In, Jn);
+            Cn = tileAt(tiles, kb + 1 + In, kb + 1 + Jn);
+            const double* A = tileAt(tiles, kb + 1 + In, kb);
+            const double* B = tileAt(tiles, kb + 1 + Jn, kb);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
-        if (tile == 0) {
-          waveSync();
-          cholDiag16Reg(Cb, dinv + k0 + 16, lane, &p.scal->cholFail);
+            for (int rg = 0; rg < 4; ++rg) accn[rg] = Cn[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { an[q] = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; bn[q] = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
+          if (!more) break;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { a[q] = an[q]; bq[q] = bn[q]; }
+          acc = accn;
+          Cb = Cn;
+          tile = next;
         }
       }
-      if (++J > I) { ++I; J = 0; }
     }
+#ifdef SVIN_CHOL_TIMING
+    if (lane == 0 && kb < 3) p.partial[(size_t)15 * 4096 + 32 + kb * 8 + wave] += (double)(__builtin_readcyclecounter() - q3);
+#endif
     __syncthreads();
 #ifdef SVIN_CHOL_TIMING
     long long q4 = __builtin_readcyclecounter();

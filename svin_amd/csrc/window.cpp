@@ -1093,8 +1093,19 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
     return tot / iters;
   };
   if (evalMs) *evalMs = timeIt([&]() { launchEvalReproj(p, false, true, s); });
+#ifdef SVIN_SCHUR_TIMING
+  HIP_OK(hipMemset(p.partial + (size_t)15 * 4096 + 16, 0, 64));
+#endif
   if (buildMs) *buildMs = timeIt([&]() { launchBuildNormalEquations(p, 1e-8, false, s); });
-  if (getenv("SVIN_CHOL_TIMING")) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64));
+#ifdef SVIN_SCHUR_TIMING
+  {
+    double dbg[5];
+    HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096 + 16, sizeof(dbg), hipMemcpyDeviceToHost));
+    std::printf("[schur cycles per launch, block 0 wave 0] zero %.0f pass1 %.0f vinv %.0f loop-total %.0f slab-store %.0f\n", dbg[0] / iters,
+                dbg[1] / iters, dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
+  }
+#endif
+  if (getenv("SVIN_CHOL_TIMING")) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64 * 8));
 #ifdef SVIN_CHOL_TIMING
   debugCholTiming(nullptr, true);
 #endif
@@ -1105,6 +1116,15 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
     std::printf("[chol cycles per launch] diag0 %.0f load %.0f trsm %.0f mfma %.0f back %.0f\n", dbg[0] / iters, dbg[1] / iters,
                 dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
 #ifdef SVIN_CHOL_TIMING
+    {
+      double w[24];
+      HIP_OK(hipMemcpy(w, p.partial + (size_t)15 * 4096 + 32, sizeof(w), hipMemcpyDeviceToHost));
+      for (int kb = 0; kb < 3; ++kb) {
+        std::printf("[phase C busy cycles kb=%d]", kb);
+        for (int k = 0; k < 8; ++k) std::printf(" w%d %.0f", k, w[kb * 8 + k] / iters);
+        std::printf("\n");
+      }
+    }
     double dd[4];
     debugCholTiming(dd, false);
     std::printf("[diag block cycles per launch] eliminate %.0f scale+store %.0f inverse %.0f\n", dd[0] / iters, dd[1] / iters, dd[2] / iters);
