@@ -86,6 +86,44 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) 
   }
 }
 
+// Block-wide reduction of K values at once: out[k] valid in threads 0..K-1 (as `mine`), `red` holds 4*K doubles.
+template <int K>
+__device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, int kMaxIndex) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nW = (blockDim.x + 63) >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double s = (k == kMaxIndex) ? waveMax(v[k]) : waveSum(v[k]);
+    if (lane == 0) red[w * K + k] = s;
+  }
+  __syncthreads();
+  double mine = 0;
+  if ((int)threadIdx.x < K) {
+    for (int i = 0; i < nW; ++i) {
+      const double x = red[i * K + threadIdx.x];
+      mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
+    }
+  }
+  return mine;
+}
+
+// 1/x to about one ulp without the IEEE division sequence: v_rcp_f64 and two Newton steps
+__device__ __forceinline__ double rcpNewton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+// 1/sqrt(x) for normal positive x: v_rsq_f64 and two Newton steps (the pivots of S are far from the denormals)
+__device__ __forceinline__ double rsqrtNewton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = __builtin_fma(-h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
 // ================================================================ K1: reprojection evaluation
 template <bool ROBUST, bool WITH_EXT>
 __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
@@ -1422,6 +1460,205 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int i
 #endif
 }
 
+// ---------------------------------------------------------------- dense Schur complement for narrow windows
+// For windows of up to ~20 poses nearly every landmark couples most poses, and the landmark elimination is a
+// Gram matrix:
+//     S_cam = A - G G^T,   A = blockdiag_p( sum_{o in p} Jp_o^T Jp_o ),   G = [G_1 .. G_L],
+//     G_l = (sum_{i in l} Jp_i^T Jl_i) L_l^-T  (dC x 3),   (V_l + mu*htil) = L_l L_l^T.
+// Two augmented rows carry the gradients through the same product:
+//     row dC   : sum Jp^T r  -  G c,  c_l = L_l^-1 b_l   = reduced gradient
+//     row dC+1 : sum Jp^T r                              = full camera gradient
+// Chunk blocks take 16 landmarks at a time, 16 lanes per landmark: V, b, L^-1, the columns of G into an LDS tile
+// and the 6x6 pose blocks of A (plus Jp^T r) into per-wave LDS copies; then every wave adds the A blocks of the
+// chunk into the accumulator tiles it owns and subtracts G G^T with v_mfma_f64_16x16x4_f64.  A and G G^T of the
+// same 16 landmarks meet in the accumulator back to back, so their cancellation happens at the scale of one
+// chunk (the rounding behaviour of the pairwise kernel).  Tiles stay in registers across chunks; one private slab
+// per block, summed by k_reduce_slabs -- no atomics on S.  Extra blocks of the launch accumulate the small factors.
+constexpr int kDenseLm = 16;              // landmarks per chunk
+constexpr int kDenseK = 3 * kDenseLm;     // columns of G per chunk
+constexpr int kDenseLd = kDenseK + 1;     // odd leading dimension keeps the MFMA operand reads off the same banks
+constexpr int kPoseAcc = 28;              // per pose: 21 (upper 6x6) + 6 (Jp^T r) + pad
+
+// index of (a, c), a <= c, in the packed upper triangle of a 6x6 block
+__device__ __forceinline__ int sym6(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
+
+__global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks) {
+  extern __shared__ double smem[];
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (b >= nChunkBlocks) {
+    factorsAccumulate(p, b - nChunkBlocks, reinterpret_cast<int*>(smem));
+    return;
+  }
+  const size_t N = (size_t)p.N;
+  const int dC = p.dC, nP = dC / 6;          // reduced pose blocks (fixed extrinsics on this path)
+  const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
+  double* Gt = smem;                          // rows x kDenseLd
+  double* Aw = smem + (size_t)rows * kDenseLd;  // 4 waves x nP x kPoseAcc
+  const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
+  double* Amine = Aw + (size_t)wave * nP * kPoseAcc;
+  // accumulator tiles (I >= J) owned by this wave: tile index tl = wave, wave + 4, ...
+  constexpr int kMaxTiles = 9;                // nTr <= 8 -> 36 tiles over 4 waves
+  d4_t acc[kMaxTiles];
+#pragma unroll
+  for (int k = 0; k < kMaxTiles; ++k) acc[k] = d4_t{0, 0, 0, 0};
+  const int nTiles = nTr * (nTr + 1) / 2;
+  double hcAcc = 0;                           // thread c < dC: column norm hC[c]
+  for (int i = t; i < rows * kDenseLd + 4 * nP * kPoseAcc; i += blockDim.x) smem[i] = 0.0;
+  __syncthreads();
+  for (int chunk = b; chunk * kDenseLm < p.L; chunk += nChunkBlocks) {
+    const int l = chunk * kDenseLm + grp;
+    if (l < p.L) {
+      const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      // V = sum Jl^T Jl, b = sum Jl^T r over the landmark's observations (16 lanes)
+      double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
+      for (int i = gl; i < n; i += 16) {
+        const size_t o = (size_t)start + i;
+        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
+        v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
+        b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        v00 += __shfl_xor(v00, o, 16); v01 += __shfl_xor(v01, o, 16); v02 += __shfl_xor(v02, o, 16);
+        v11 += __shfl_xor(v11, o, 16); v12 += __shfl_xor(v12, o, 16); v22 += __shfl_xor(v22, o, 16);
+        b0 += __shfl_xor(b0, o, 16); b1 += __shfl_xor(b1, o, 16); b2 += __shfl_xor(b2, o, 16);
+      }
+      // trust-region metric for the landmark columns (Jacobi scaling fixed at iteration 0)
+      double sc0, sc1, sc2;
+      if (initScale) {
+        sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
+        if (gl == 0) { p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2; }
+      } else {
+        sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2];
+      }
+      const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
+      const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
+      const double ht2 = fmin(fmax(v22 * sc2 * sc2, 1e-6), 1e32) / (sc2 * sc2);
+      // (V + mu*htil) = L L^T; only L^-1 is needed, so the factor runs on reciprocal square roots
+      const double d00 = v00 + mu * ht0, d11 = v11 + mu * ht1, d22 = v22 + mu * ht2;
+      bool bad = !(d00 > 0);
+      const double i00 = rsqrtNewton(bad ? 1.0 : d00);          // 1/l00
+      const double l10 = v01 * i00, l20 = v02 * i00;
+      const double t11 = d11 - l10 * l10;
+      bad = bad || !(t11 > 0);
+      const double i11 = rsqrtNewton(t11 > 0 ? t11 : 1.0);
+      const double l21 = (v12 - l20 * l10) * i11;
+      const double t22 = d22 - l20 * l20 - l21 * l21;
+      bad = bad || !(t22 > 0);
+      const double i22 = rsqrtNewton(t22 > 0 ? t22 : 1.0);
+      const double i10 = -l10 * i00 * i11;
+      const double i21 = -l21 * i11 * i22;
+      const double i20 = -(l20 * i00 + l21 * i10) * i22;
+      if (gl == 0) {
+        if (bad) atomicOr(&p.scal->cholFail, 1);
+        double* vi = p.Vinv + 6 * (size_t)l;  // Vinv = Linv^T Linv
+        vi[0] = i00 * i00 + i10 * i10 + i20 * i20; vi[1] = i10 * i11 + i20 * i21; vi[2] = i20 * i22;
+        vi[3] = i11 * i11 + i21 * i21; vi[4] = i21 * i22; vi[5] = i22 * i22;
+        p.bl[3 * l] = b0; p.bl[3 * l + 1] = b1; p.bl[3 * l + 2] = b2;
+        p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
+        // augmented row dC: c = Linv b  (row dC+1 stays zero under G)
+        double* cr = Gt + (size_t)dC * kDenseLd + 3 * grp;
+        cr[0] = i00 * b0; cr[1] = i10 * b0 + i11 * b1; cr[2] = i20 * b0 + i21 * b1 + i22 * b2;
+      }
+      // per observation: columns of G = (Jp^T Jl) Linv^T at the pose's rows (two cameras of one pose meet
+      // there), and the pose block of A with Jp^T r into this wave's copy
+      for (int i = gl; i < n; i += 16) {
+        const size_t o = (size_t)start + i;
+        const int offP = p.poseOff[p.obsIdx[o] & 0xfff];
+        if (offP < 0) continue;
+        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+        double jp[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) jp[k] = p.JpCur[k * N + o];
+        double* ap = Amine + (size_t)(offP / 6) * kPoseAcc;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double j0 = jp[a], j1 = jp[6 + a];
+          const double e0 = j0 * a0 + j1 * c0, e1 = j0 * a1 + j1 * c1, e2 = j0 * a2 + j1 * c2;
+          double* g = Gt + (size_t)(offP + a) * kDenseLd + 3 * grp;
+          atomicAdd(&g[0], e0 * i00);
+          atomicAdd(&g[1], e0 * i10 + e1 * i11);
+          atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
+#pragma unroll
+          for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jp[c] + j1 * jp[6 + c]);
+          atomicAdd(&ap[21 + a], j0 * r0 + j1 * r1);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- acc(I,J) += A_chunk (pose-diagonal blocks, gradient rows), then acc(I,J) -= G_I G_J^T (12 k-steps)
+    if (t < dC) {
+      const int ps = t / 6, a = t % 6;
+      double s = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + sym6(a, a)];
+      hcAcc += s;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
+      const int tl = wave + 4 * k;
+      if (tl < nTiles) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+        const int J = tl - I * (I + 1) / 2;
+        d4_t c = acc[k];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * I + (lane >> 4) + 4 * rg, cc = 16 * J + (lane & 15);
+          int idx = -1, ps = 0;
+          if (cc < dC) {
+            ps = cc / 6;
+            if (r < dC) { if (r / 6 == ps) { const int a = r % 6, e = cc % 6; idx = sym6(min(a, e), max(a, e)); } }
+            else if (r <= dC + 1) idx = 21 + cc % 6;
+          }
+          if (idx >= 0) {
+            double s = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + idx];
+            c[rg] += s;
+          }
+        }
+        const double* A = Gt + (size_t)(16 * I + (lane & 15)) * kDenseLd + (lane >> 4);
+        const double* B = Gt + (size_t)(16 * J + (lane & 15)) * kDenseLd + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
+        acc[k] = c;
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < rows * kDenseLd + 4 * nP * kPoseAcc; i += blockDim.x) smem[i] = 0.0;
+    __syncthreads();
+  }
+  // ---- private slab: [S (dC x dC) | gRed | gFull | hC]
+  double* slab = p.slabs + (size_t)b * ((size_t)dC * dC + 3 * dC);
+  if (t < dC) slab[(size_t)dC * dC + 2 * dC + t] = hcAcc;
+#pragma unroll
+  for (int k = 0; k < kMaxTiles; ++k) {
+    const int tl = wave + 4 * k;
+    if (tl < nTiles) {
+      int I = 0;
+      while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+      const int J = tl - I * (I + 1) / 2;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 16 * I + (lane >> 4) + 4 * rg, c = 16 * J + (lane & 15);
+        const double v = acc[k][rg];
+        if (r < dC && c < dC) {
+          slab[(size_t)r * dC + c] = v;
+          if (I != J) slab[(size_t)c * dC + r] = v;
+        } else if ((r == dC || r == dC + 1) && c < dC) {
+          slab[(size_t)dC * dC + (r - dC) * dC + c] = v;  // reduced gradient / full camera gradient
+        }
+      }
+    }
+  }
+}
+
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
 // 16 entries x 16 slab-partitions per 256-thread block; fixed summation order -> deterministic
 constexpr int kSlabParts = 16;
@@ -1513,7 +1750,12 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   const int dC = p.dC;
   if (zeroFirst) launchZeroBuild(p, s);
   const int nFac = (p.F > 0 && p.ownsCamera) ? p.F : 0;
-  if (p.L > 0 && p.N > 0 && dC > 0) {
+  if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
+    const int rows = 16 * ((dC + 2 + 15) / 16);
+    const size_t ldsBytes = ((size_t)rows * kDenseLd + (size_t)4 * (dC / 6) * kPoseAcc) * 8;
+    (void)hipFuncSetAttribute((const void*)k_schur_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL(k_schur_dense, dim3(p.nSlabs + nFac), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs);
+  } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;
     const bool useLds = accBytes + stageBytes <= 150 * 1024;
@@ -1553,7 +1795,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const bool useLds = accBytes + (size_t)4 * 64 * kStage * 8 <= 150 * 1024;
     DeviceProblem q = p;
-    if (!useLds) q.nSlabs = 1;
+    if (!useLds && !p.schurDense) q.nSlabs = 1;
     const int n = dC * dC + 3 * dC;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 15) / 16), dim3(256), 0, s, q);
   }
@@ -1730,23 +1972,6 @@ void debugCholTiming(double* out, bool reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cholDbg), 32);
 }
 #endif
-// 1/x to about one ulp without the IEEE division sequence: v_rcp_f64 and two Newton steps
-__device__ __forceinline__ double rcpNewton(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
-// 1/sqrt(x) for normal positive x: v_rsq_f64 and two Newton steps (the pivots of S are far from the denormals)
-__device__ __forceinline__ double rsqrtNewton(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  double e = __builtin_fma(-h * y, y, 0.5);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-h * y, y, 0.5);
-  return __builtin_fma(y, e, y);
-}
 // Factorises the tile D (16 x kPanelLd in LDS, full symmetric block) in place: lower triangle <- L, strict upper
 // triangle <- transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii.
 // Lane i carries the full symmetric row i, so the pivot row k (= column k) is one lane's registers and is
@@ -2068,27 +2293,6 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
 }
 
 // ================================================================ post-solve pass and dogleg step
-// Block-wide reduction of K values at once: out[k] valid in threads 0..K-1 (as `mine`), `red` holds 4*K doubles.
-template <int K>
-__device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, int kMaxIndex) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nW = (blockDim.x + 63) >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const double s = (k == kMaxIndex) ? waveMax(v[k]) : waveSum(v[k]);
-    if (lane == 0) red[w * K + k] = s;
-  }
-  __syncthreads();
-  double mine = 0;
-  if ((int)threadIdx.x < K) {
-    for (int i = 0; i < nW; ++i) {
-      const double x = red[i * K + threadIdx.x];
-      mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
-    }
-  }
-  return mine;
-}
-
 // partial slots of the post-solve pass
 constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
 __device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};

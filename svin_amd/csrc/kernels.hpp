@@ -106,6 +106,7 @@ struct DeviceProblem {
   CameraModel* cams;
   // observations
   int* lmPtr;
+  int schurDense;                            // narrow window: Schur complement as a Gram matrix on MFMA
   double *obsUv, *obsW;
   uint32_t* obsIdx;
   int* obsLm;

@@ -631,7 +631,10 @@ void Window::pack() {
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
   const bool useLds = slabSize * 8 + (size_t)4 * 64 * 34 * 8 <= 150 * 1024;
   int nSlabs = 1;
-  if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
+  // narrow windows (<= ~20 poses, fixed extrinsics): dense Gram-matrix Schur complement on MFMA
+  const bool schurDense = !anyExtVar && dC > 0 && dC + 2 <= 128 && !getenv("SVIN_SCHUR_PAIRWISE");
+  if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
+  else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
   dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
 
   DeviceProblem& p = prob_;
@@ -644,6 +647,7 @@ void Window::pack() {
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;
+  p.schurDense = schurDense ? 1 : 0;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
   curSet_ = 0;
   auto setLin = [&](int set, double*& r, double*& Jp, double*& Jl, double*& Je) {

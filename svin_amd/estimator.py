@@ -60,7 +60,8 @@ EXPORTS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libsvin_ba.so")
+    # SVIN_BA_LIB: developer override (A/B runs of two builds of the same ABI); there is still no non-HIP path
+    return os.environ.get("SVIN_BA_LIB") or os.path.join(_HERE, "libsvin_ba.so")
 
 
 def load_library():
