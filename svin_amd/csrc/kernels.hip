@@ -125,6 +125,10 @@ __device__ __forceinline__ double rsqrtNewton(double x) {
   return __builtin_fma(y, e, y);
 }
 // ================================================================ K1: reprojection evaluation
+// The linearisation buffers are write-once streams (160-256 B per observation, nothing of them is re-read by this
+// kernel): non-temporal stores keep them from thrashing L2 on their way to HBM -- measured 4.3 -> 6.4 TB/s on the
+// HBM-resident batch, neutral for the single cache-resident window of the solver (profiles/r01_k1_variants.txt).
+#define K1_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
 template <bool ROBUST, bool WITH_EXT>
 __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
                                                      const double* __restrict__ ext, const double* __restrict__ lm,
@@ -177,15 +181,15 @@ __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt,
     } else {
       cost = 0.5 * s;
     }
-    r[i] = rr[0];
-    r[stride + i] = rr[1];
+    K1_STORE(&r[i], rr[0]);
+    K1_STORE(&r[stride + i], rr[1]);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) Jp[k * stride + i] = jp[k];
+    for (int k = 0; k < 12; ++k) K1_STORE(&Jp[k * stride + i], jp[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Jl[k * stride + i] = jl[k];
+    for (int k = 0; k < 6; ++k) K1_STORE(&Jl[k * stride + i], jl[k]);
     if (WITH_EXT) {
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Je[k * stride + i] = je[k];
+      for (int k = 0; k < 12; ++k) K1_STORE(&Je[k * stride + i], je[k]);
     }
   }
   if (costPartial) {
