@@ -145,8 +145,20 @@ def main():
         ms, nbytes = est.bench_jacobian_eval(args.copies, 20)
         ach = nbytes / (ms * 1e-3) / 1e9
         ms1, nbytes1 = est.bench_jacobian_eval(1, 50)
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
+        # tools/k1_bench.py, gfx950 FETCH_SIZE x2 correction; committed summary profiles/r01_k1_pmc.txt).  Counters
+        # cannot be read from inside this process, so the committed measurement is quoted when it describes the same
+        # launch (same replica count and algorithmic bytes); otherwise null.
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k1_pmc.json")) as fh:
+                pmc = json.load(fh)
+            if abs(pmc["algorithmic_bytes_per_launch"] - nbytes) < 1e-6 * nbytes:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_eval_reproj", "launch_ms": ms, "bytes_per_launch": nbytes,
+                           "traffic": traffic, "kernel": "k_eval_reproj", "launch_ms": ms, "bytes_per_launch": nbytes,
                            "replicas": args.copies,
                            "single_window_cache_resident": {"launch_ms": ms1, "GBps": nbytes1 / (ms1 * 1e-3) / 1e9}}
         ev, bu, so = est.bench_kernel_times(20)

@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0,'.')
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from svin_amd import synthetic as syn
 from svin_amd.estimator import Estimator
 spec=syn.make_window(); est=Estimator(0); syn.feed(est,spec)
