@@ -124,6 +124,81 @@ __device__ __forceinline__ double rsqrtNewton(double x) {
   e = __builtin_fma(-h * y, y, 0.5);
   return __builtin_fma(y, e, y);
 }
+constexpr int kPanelLd = 17;  // leading dimension of the 16x16 LDS tiles of the dense solvers
+// ---- 16x16 diagonal block in registers (wave 0, lane i = row i), cross-lane traffic through v_readlane.
+__device__ __forceinline__ double readlaneD(double v, int srcLane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+#ifdef SVIN_CHOL_TIMING
+__device__ double g_cholDbg[4];
+void debugCholTiming(double* out, bool reset) {
+  if (reset) { double z[4] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cholDbg), z, sizeof(z)); return; }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cholDbg), 32);
+}
+#endif
+// Factorises the tile D (16 x kPanelLd in LDS, full symmetric block) in place: lower triangle <- L, strict upper
+// triangle <- transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii.
+// Lane i carries the full symmetric row i, so the pivot row k (= column k) is one lane's registers and is
+// broadcast with v_readlane; the square-root-free elimination a_ij -= a_ik a_kj / a_kk (A = Lt D Lt^T, Lt unit
+// lower) keeps sqrt off the serial chain.  The same broadcast values drive a fused forward substitution: lane j
+// carries column j of Lt^-1 and applies xt_i -= Lt_ik xt_k as soon as column k is known, so the inverse needs
+// no second pass and no LDS traffic.  One rsqrt per lane at the end scales both factors: L = Lt D^1/2,
+// L^-1 = D^-1/2 Lt^-1.
+__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneIn, int* failFlag) {
+  // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks and constants of this
+  // routine out of the caller's block-column loop (that costs ~100 registers across the whole kernel -> scratch)
+  int lane = laneIn;
+  asm volatile("" : "+v"(lane));
+  const int li = lane & 15;
+#ifdef SVIN_CHOL_TIMING
+  const long long qd0 = __builtin_readcyclecounter();
+#endif
+  double a[16], x[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a[j] = D[li * kPanelLd + j]; x[j] = (j == li) ? 1.0 : 0.0; }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double pr[16];
+#pragma unroll
+    for (int j = k; j < 16; ++j) pr[j] = readlaneD(a[j], k);
+    const bool ok = pr[k] > 0;
+    bad = bad || !ok;
+    const double rk = rcpNewton(ok ? pr[k] : 1.0);  // branch-free: 1 for a failed pivot
+    const double m = a[k] * rk, mx = x[k] * rk;
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-m, pr[j], a[j]);
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) x[j] = __builtin_fma(-mx, pr[j], x[j]);
+    __builtin_amdgcn_sched_barrier(0);  // keep each column's updates next to its broadcasts (SGPR lifetime)
+  }
+#ifdef SVIN_CHOL_TIMING
+  const long long qd1 = __builtin_readcyclecounter();
+#endif
+  double dk = a[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) dk = (li == k) ? a[k] : dk;
+  const double rs = rsqrtNewton(dk > 0 ? dk : 1.0);  // 1/L_kk in lane k (1 for a failed pivot), branch-free
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double rsk = readlaneD(rs, k);
+    a[k] *= rsk;  // L[li][k] for k <= li
+    x[k] *= rsk;  // Linv[k][li] for k >= li
+  }
+  // lanes 16..63 replicate lanes 0..15 (same values to the same addresses): storing from all of them keeps the
+  // compiler from sinking the x recurrence into a divergent block (which spills every broadcast value)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) D[li * kPanelLd + j] = (j > li) ? x[j] : a[j];  // D[c=li][r=j] = Linv[j][li]
+  dinv[li] = rs;
+  if (bad && lane == 0) atomicOr(failFlag, 2);  // after the stores: no block boundary inside the register pipeline
+#ifdef SVIN_CHOL_TIMING
+  const long long qd2 = __builtin_readcyclecounter();
+  if (lane == 0) { g_cholDbg[0] += (double)(qd1 - qd0); g_cholDbg[1] += (double)(qd2 - qd1); }
+#endif
+}
+
 // ================================================================ K1: reprojection evaluation
 // The linearisation buffers are write-once streams (160-256 B per observation, nothing of them is re-read by this
 // kernel): non-temporal stores keep them from thrashing L2 on their way to HBM -- measured 4.3 -> 6.4 TB/s on the
@@ -314,29 +389,13 @@ struct FactorShared {
   // re-preintegration (imuIntegrate): per-step inputs (P0), the two serial chains (P1), the blocks of F_delta
   // per step (P2/P3, double buffered for the covariance wave) and the published integrals
   double pre[64 * 33];
-  double fb[2][64 * 87];
+  double fb[128 * 87];
   double seq[65 * 13];
   double tot[64];
+  double tile[16 * kPanelLd];  // 15x15 covariance / information padded to the 16x16 wave-level factorisation
+  double dinv[16];
   int flag, used;
 };
-
-// 15x15 helpers on LDS matrices, executed by the whole workgroup (blockDim >= 225)
-__device__ void chol15(double* A, int* failFlag) {  // in-place lower Cholesky (strict upper left untouched)
-  const int t = threadIdx.x, i = t / 15, j = t % 15;
-  for (int k = 0; k < 15; ++k) {
-    __syncthreads();
-    if (t == 0) {
-      const double x = A[k * 15 + k];
-      if (x <= 0) { *failFlag = 1; A[k * 15 + k] = 1.0; }
-      else A[k * 15 + k] = sqrt(x);
-    }
-    __syncthreads();
-    if (t < 225 && j == k && i > k) A[i * 15 + k] /= A[k * 15 + k];
-    __syncthreads();
-    if (t < 225 && j > k && i >= j) A[i * 15 + j] -= A[i * 15 + k] * A[j * 15 + k];
-  }
-  __syncthreads();
-}
 
 // normalised pose -> Transformation(r, q) semantics (q normalised, C from normalised q)
 struct TF { double r[3]; Quat q; Mat3 C; };
@@ -359,7 +418,8 @@ struct ImuState {
   double Ci[9], Cdi[9], ai[3], adi[3], dal[9], dv[9], dp[9], Delta_t;
   int used;
 };
-constexpr int kImuSuper = 64;  // integration steps staged in LDS per round
+constexpr int kImuSuper = 64;  // integration steps per round of the per-step phases P0..P3
+constexpr int kImuBlock = 128;  // integration steps per block of the covariance stage (sh.fb)
 constexpr int kPreLd = 33;     // odd row strides keep the one-thread-per-step phases off the same LDS banks
 constexpr int kFbLd = 87;
 constexpr int kSeqLd = 13;
@@ -391,15 +451,15 @@ __device__ double g_imuDbg[8];
 //                             that do not involve running sums                                      -> sh.fb
 //   P3  wave 0, one lane per scalar component: the running sums C_integral, acc_integral, dv_db_g (in step
 //                             order, like the reference) and the F_delta blocks built from them    -> sh.fb
-//   P4  wave 3              : P <- F P F^T + Q as 2 x 4 v_mfma_f64_16x16x4_f64 per step with P held in the
-//                             MFMA accumulator layout; runs one round behind P0-P3 (sh.fb is double buffered)
+//   P4  all four waves      : P <- F P F^T + Q as v_mfma_f64_16x16x4_f64 products with P held in the MFMA accumulator
+//                             layout; the steps of a block are split into four segments (one per SIMD), each wave
+//                             carries its segment's covariance and transition product, wave 0 chains the segments
 template <bool REDO>
 __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, const double* __restrict__ M,
                              const double* sb, FactorShared& sh, ImuState& st) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int n = im.sampleCount;
   const uint32_t t0[2] = {im.t0[0], im.t0[1]}, end[2] = {im.t1[0], im.t1[1]};
-  const int nRounds = (n + kImuSuper - 1) / kImuSuper;
   const double sgw2 = im.par.sigma_gw_c * im.par.sigma_gw_c, saw2 = im.par.sigma_aw_c * im.par.sigma_aw_c;
   IMU_TICK(qStart);
 
@@ -417,7 +477,7 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
   else if (lane < 30) { const int k = lane - 21; iInc = 76 + k; tot1 = 28 + k; }
   else if (lane == 30) { iInc = 3; tot1 = 55; }
   else if (lane == 31) { iInc = 54; tot1 = 56; }
-  // wave 3, P4: X = P (even number of executed steps) or P^T (odd) in the accumulator layout
+  // wave 0, P4: X = P (parity 0) or P^T (parity 1) in the accumulator layout
   // X[(lane>>4)+4r][lane&15]; F_delta entries F[lane&15][(lane>>4)+4q] = fC0 + fS * fb[fIdx]
   d4_t X = {0, 0, 0, 0};
   int parity = 0;
@@ -447,57 +507,11 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
   // (qDiag, dKind): accumulator register q holds row (lane>>4)+4q, column lane&15 -- the F descriptor's pairing
   // with rows and columns swapped; the diagonal test is symmetric, so one loop serves both.
 
-  for (int r = 0; r <= nRounds; ++r) {
-    const int s0 = r * kImuSuper;
-    const int ns = r < nRounds ? min(kImuSuper, n - s0) : 0;
-    double* fbw = sh.fb[r & 1];
-    const double* fbr = sh.fb[(r + 1) & 1];
-    const int nsPrev = r > 0 ? min(kImuSuper, n - (s0 - kImuSuper)) : 0;
-    // one quarter of the previous round's covariance steps (wave 3), called between the barriers of P0..P3
-    auto covSegment = [&](int seg) {
-      if (wave != 3) return;
-      IMU_TICK(qc0);
-      const int lo = nsPrev * seg / 4, hi = nsPrev * (seg + 1) / 4;
-      if (lo >= hi) return;
-      // inputs of step i+1 are gathered from LDS while the MFMAs of step i run
-      const double* row = fbr + lo * kFbLd;
-      double g[4], dt = row[3], sg2 = row[52], sa2 = row[53], ex = row[54];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) g[q] = row[fIdx[q]];
-      for (int i = lo; i < hi; ++i) {
-        const double* rn = fbr + min(i + 1, hi - 1) * kFbLd;
-        double gn[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gn[q] = rn[fIdx[q]];
-        const double dtn = rn[3], sg2n = rn[52], sa2n = rn[53], exn = rn[54];
-        if (ex != 0.0) {
-          double f[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) f[q] = fC0[q] + fS[q] * g[q];
-          d4_t V = {0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) V = __builtin_amdgcn_mfma_f64_16x16x4f64(X[q], f[q], V, 0, 0, 0);   // X^T F^T
-          d4_t Y = {0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], V[q], Y, 0, 0, 0);   // F (X^T F^T)
-          // Q_delta on the diagonal: every lane owns at most one diagonal entry (accumulator register qDiag)
-          double add = dt * saw2;
-          add = (dKind == 4) ? dt * sgw2 : add;
-          add = (dKind == 3) ? sa2 : add;
-          add = (dKind == 2) ? sg2 : add;
-          add = (dKind == 1) ? 0.5 * dt * dt * sa2 : add;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) X[q] = Y[q] + ((q == qDiag) ? add : 0.0);
-          parity ^= 1;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = gn[q];
-        dt = dtn; sg2 = sg2n; sa2 = sa2n; ex = exn;
-      }
-      IMU_TICK(qc1);
-      IMU_ACC(2, qc0, qc1, t == 192);
-    };
-
+  for (int blk0 = 0; blk0 < n; blk0 += kImuBlock) {
+   const int nb = min(kImuBlock, n - blk0);
+   for (int s0 = blk0; s0 < blk0 + nb; s0 += kImuSuper) {
+    const int ns = min(kImuSuper, blk0 + nb - s0);
+    double* fbw = sh.fb + (size_t)(s0 - blk0) * kFbLd;
     // ---------------- P0
     IMU_TICK(qp0);
     if (t < ns) {
@@ -552,7 +566,6 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     }
     IMU_TICK(qp1);
     IMU_ACC(0, qp0, qp1, t == 0);
-    covSegment(0);
     __syncthreads();
     IMU_TICK(qp2);
     // ---------------- P1: the two serial chains, side by side
@@ -603,7 +616,6 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     IMU_TICK(qp3);
     IMU_ACC(1, qp2, qp3, t == 0);
     IMU_ACC(6, qp2, qp3, t == 64);
-    covSegment(1);
     __syncthreads();
     IMU_TICK(qp4);
     // ---------------- P2
@@ -650,7 +662,6 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     }
     IMU_TICK(qp5);
     IMU_ACC(7, qp4, qp5, t == 0);
-    covSegment(2);
     __syncthreads();
     IMU_TICK(qp6);
     // ---------------- P3: running sums in step order; B012 / pterm / F09 need the sums *before* the step
@@ -675,11 +686,100 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     }
     IMU_TICK(qp7);
     IMU_ACC(5, qp6, qp7, t == 0);
-    covSegment(3);
     __syncthreads();
+   }
+   // ---------------- P4: covariance of the block.  The recurrence P <- F P F^T + Q is split into four segments,
+   // one per wave (= per SIMD, each with its own matrix pipe): segment w integrates its own covariance P_w from
+   // zero together with its transition product Phi_w = F...F; wave 0 then chains the segments:
+   // P <- Phi_w P Phi_w^T + P_w.  (Exact in exact arithmetic; the additions associate differently from the
+   // step-by-step recurrence, i.e. rounding-level differences only.)
+   {
+    IMU_TICK(qc0);
+    const int seg = (nb + 3) / 4;
+    const int lo = min(nb, wave * seg), hi = min(nb, lo + seg);
+    d4_t Xs = {0, 0, 0, 0}, Ph;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q, col = lane & 15; Ph[q] = (row == col && row < 15) ? 1.0 : 0.0; }
+    int par = 0;
+    if (lo < hi) {
+      // inputs of step i+1 are gathered from LDS while the MFMAs of step i run
+      const double* row = sh.fb + (size_t)lo * kFbLd;
+      double g[4], dt = row[3], sg2 = row[52], sa2 = row[53], ex = row[54];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = row[fIdx[q]];
+      for (int i = lo; i < hi; ++i) {
+        const double* rn = sh.fb + (size_t)min(i + 1, hi - 1) * kFbLd;
+        double gn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gn[q] = rn[fIdx[q]];
+        const double dtn = rn[3], sg2n = rn[52], sa2n = rn[53], exn = rn[54];
+        if (ex != 0.0) {
+          double f[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f[q] = fC0[q] + fS[q] * g[q];
+          d4_t V = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) V = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[q], f[q], V, 0, 0, 0);   // X^T F^T
+          d4_t Pn = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], Ph[q], Pn, 0, 0, 0);  // F Phi
+          d4_t Y = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], V[q], Y, 0, 0, 0);   // F (X^T F^T)
+          // Q_delta on the diagonal: every lane owns at most one diagonal entry (accumulator register qDiag)
+          double add = dt * saw2;
+          add = (dKind == 4) ? dt * sgw2 : add;
+          add = (dKind == 3) ? sa2 : add;
+          add = (dKind == 2) ? sg2 : add;
+          add = (dKind == 1) ? 0.5 * dt * dt * sa2 : add;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Xs[q] = Y[q] + ((q == qDiag) ? add : 0.0);
+          Ph = Pn;
+          par ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = gn[q];
+        dt = dtn; sg2 = sg2n; sa2 = sa2n; ex = exn;
+      }
+    }
+    // publish Phi_w and P_w (true orientation) as 16x16 tiles; sh.pre is free between the rounds
+    double* phiT = sh.pre + wave * 512;
+    double* pT = phiT + 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = (lane >> 4) + 4 * q, col = lane & 15;
+      phiT[row * 16 + col] = Ph[q];
+      pT[par ? col * 16 + row : row * 16 + col] = Xs[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 0; w < 4; ++w) {
+        const double* ph = sh.pre + w * 512;
+        const double* pw = ph + 256;
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = ph[(lane & 15) * 16 + (lane >> 4) + 4 * q];
+        d4_t V = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) V = __builtin_amdgcn_mfma_f64_16x16x4f64(X[q], a[q], V, 0, 0, 0);   // X^T Phi^T
+        d4_t Y = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], V[q], Y, 0, 0, 0);   // Phi X^T Phi^T
+        parity ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (lane >> 4) + 4 * q, col = lane & 15;
+          X[q] = Y[q] + pw[parity ? col * 16 + row : row * 16 + col];
+        }
+      }
+    }
+    __syncthreads();  // sh.pre is written again by the next block's P0
+    IMU_TICK(qc1);
+    IMU_ACC(2, qc0, qc1, t == 0);
+   }
   }
-  // publish: covariance (wave 3) and the integrals (wave 0)
-  if (wave == 3) {
+  // publish: covariance and integrals (wave 0)
+  if (wave == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = (lane >> 4) + 4 * q, col = lane & 15;
@@ -715,42 +815,46 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
     for (int k = 0; k < 9; ++k) im.sb_ref[k] = sb[k];
     im.Delta_t = st.Delta_t;
   }
-  // symmetrise P, information = P^-1 (via Cholesky), symmetrise, sqrtInfo = chol(information)^T  (:246-258)
+  // symmetrise P, information = P^-1 (via Cholesky), symmetrise, sqrtInfo = chol(information)^T  (:246-258).
+  // Both factorisations run on the register-resident 16x16 routine of the reduced solver (one wave, identity
+  // padding): it returns L and L^-1 together, so information = L^-T L^-1 needs no triangular solves.
   __syncthreads();
   IMU_TICK(qPost0);
+  const int wave = t >> 6, lane = t & 63;
   if (t < 225) sh.T[t] = 0.5 * sh.P[t] + 0.5 * sh.P[(t % 15) * 15 + t / 15];
   __syncthreads();
-  if (t < 225) { sh.P[t] = sh.T[t]; im.P_delta[t] = sh.T[t]; }
-  __syncthreads();
-  chol15(sh.P, &sh.flag);  // P = L L^T (lower in sh.P)
-  __syncthreads();
-  if (t < 225) sh.T[t] = 0.0;
-  __syncthreads();
-  // Linv (lower) by forward substitution, one column per thread
-  if (t < 15) {
-    const int c = t;
-    for (int i = c; i < 15; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) s -= sh.P[i * 15 + k] * sh.T[k * 15 + c];
-      sh.T[i * 15 + c] = s / sh.P[i * 15 + i];
-    }
+  if (t < 225) im.P_delta[t] = sh.T[t];
+  {
+    const int r = t >> 4, c = t & 15;
+    sh.tile[r * kPanelLd + c] = (r < 15 && c < 15) ? sh.T[r * 15 + c] : ((r == c) ? 1.0 : 0.0);
   }
   __syncthreads();
-  if (t < 225) {  // information = Linv^T Linv
-    const int a = t / 15, b = t % 15;
+  if (wave == 0) cholDiag16Reg(sh.tile, sh.dinv, lane, &sh.flag);
+  __syncthreads();
+  if (t < 225) {  // information = Linv^T Linv; Linv[k][a] sits at tile[a][k] for k > a, dinv[a] on the diagonal
+    const int a = t / 15, b = t % 15, k0 = a > b ? a : b;
     double s = 0;
-    for (int k = (a > b ? a : b); k < 15; ++k) s += sh.T[k * 15 + a] * sh.T[k * 15 + b];
+    for (int k = k0; k < 15; ++k) {
+      const double xa = (k > a) ? sh.tile[a * kPanelLd + k] : sh.dinv[a];
+      const double xb = (k > b) ? sh.tile[b * kPanelLd + k] : sh.dinv[b];
+      s += xa * xb;
+    }
     sh.Fd[t] = s;
   }
   __syncthreads();
   if (t < 225) { sh.P[t] = 0.5 * sh.Fd[t] + 0.5 * sh.Fd[(t % 15) * 15 + t / 15]; }
   __syncthreads();
   if (t < 225) im.information[t] = sh.P[t];
+  {
+    const int r = t >> 4, c = t & 15;
+    sh.tile[r * kPanelLd + c] = (r < 15 && c < 15) ? sh.P[r * 15 + c] : ((r == c) ? 1.0 : 0.0);
+  }
   __syncthreads();
-  chol15(sh.P, &sh.flag);
+  if (wave == 0) cholDiag16Reg(sh.tile, sh.dinv, lane, &sh.flag);
+  __syncthreads();
   if (t < 225) {
     const int a = t / 15, b = t % 15;
-    im.sqrtInfo[t] = (b >= a) ? sh.P[b * 15 + a] : 0.0;  // L^T
+    im.sqrtInfo[t] = (b >= a) ? sh.tile[b * kPanelLd + a] : 0.0;  // L^T
   }
   __syncthreads();
   IMU_TICK(qPost1);
@@ -1810,7 +1914,6 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
 // symmetric rank-16 trailing update runs on v_mfma_f64_16x16x4_f64 (A/B: one f64 per lane,
 // A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)+4*reg).  The matrix is padded to a
 // multiple of 16 with an identity tail so that every tile is full.
-constexpr int kPanelLd = 17;
 
 // 16x16 in-LDS Cholesky executed by ONE wave (lanes 0..63), wave-level synchronisation only.
 __device__ __forceinline__ void cholDiag16(double* sD, int lane, int* failFlag) {
@@ -1961,80 +2064,6 @@ __global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad, 
     __syncthreads();
   }
   for (int i = t; i < d; i += blockDim.x) { y[i] = sP[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
-}
-
-// ---- 16x16 diagonal block in registers (wave 0, lane i = row i), cross-lane traffic through v_readlane.
-__device__ __forceinline__ double readlaneD(double v, int srcLane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
-  return __hiloint2double(hi, lo);
-}
-#ifdef SVIN_CHOL_TIMING
-__device__ double g_cholDbg[4];
-void debugCholTiming(double* out, bool reset) {
-  if (reset) { double z[4] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cholDbg), z, sizeof(z)); return; }
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cholDbg), 32);
-}
-#endif
-// Factorises the tile D (16 x kPanelLd in LDS, full symmetric block) in place: lower triangle <- L, strict upper
-// triangle <- transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii.
-// Lane i carries the full symmetric row i, so the pivot row k (= column k) is one lane's registers and is
-// broadcast with v_readlane; the square-root-free elimination a_ij -= a_ik a_kj / a_kk (A = Lt D Lt^T, Lt unit
-// lower) keeps sqrt off the serial chain.  The same broadcast values drive a fused forward substitution: lane j
-// carries column j of Lt^-1 and applies xt_i -= Lt_ik xt_k as soon as column k is known, so the inverse needs
-// no second pass and no LDS traffic.  One rsqrt per lane at the end scales both factors: L = Lt D^1/2,
-// L^-1 = D^-1/2 Lt^-1.
-__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneIn, int* failFlag) {
-  // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks and constants of this
-  // routine out of the caller's block-column loop (that costs ~100 registers across the whole kernel -> scratch)
-  int lane = laneIn;
-  asm volatile("" : "+v"(lane));
-  const int li = lane & 15;
-#ifdef SVIN_CHOL_TIMING
-  const long long qd0 = __builtin_readcyclecounter();
-#endif
-  double a[16], x[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { a[j] = D[li * kPanelLd + j]; x[j] = (j == li) ? 1.0 : 0.0; }
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    double pr[16];
-#pragma unroll
-    for (int j = k; j < 16; ++j) pr[j] = readlaneD(a[j], k);
-    const bool ok = pr[k] > 0;
-    bad = bad || !ok;
-    const double rk = rcpNewton(ok ? pr[k] : 1.0);  // branch-free: 1 for a failed pivot
-    const double m = a[k] * rk, mx = x[k] * rk;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-m, pr[j], a[j]);
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) x[j] = __builtin_fma(-mx, pr[j], x[j]);
-    __builtin_amdgcn_sched_barrier(0);  // keep each column's updates next to its broadcasts (SGPR lifetime)
-  }
-#ifdef SVIN_CHOL_TIMING
-  const long long qd1 = __builtin_readcyclecounter();
-#endif
-  double dk = a[0];
-#pragma unroll
-  for (int k = 1; k < 16; ++k) dk = (li == k) ? a[k] : dk;
-  const double rs = rsqrtNewton(dk > 0 ? dk : 1.0);  // 1/L_kk in lane k (1 for a failed pivot), branch-free
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double rsk = readlaneD(rs, k);
-    a[k] *= rsk;  // L[li][k] for k <= li
-    x[k] *= rsk;  // Linv[k][li] for k >= li
-  }
-  // lanes 16..63 replicate lanes 0..15 (same values to the same addresses): storing from all of them keeps the
-  // compiler from sinking the x recurrence into a divergent block (which spills every broadcast value)
-#pragma unroll
-  for (int j = 0; j < 16; ++j) D[li * kPanelLd + j] = (j > li) ? x[j] : a[j];  // D[c=li][r=j] = Linv[j][li]
-  dinv[li] = rs;
-  if (bad && lane == 0) atomicOr(failFlag, 2);  // after the stores: no block boundary inside the register pipeline
-#ifdef SVIN_CHOL_TIMING
-  const long long qd2 = __builtin_readcyclecounter();
-  if (lane == 0) { g_cholDbg[0] += (double)(qd1 - qd0); g_cholDbg[1] += (double)(qd2 - qd1); }
-#endif
 }
 
 // LDS-resident variant for dpad <= 176: the lower triangle lives in LDS as 16x17 tiles (tile (I,J), I>=J at
