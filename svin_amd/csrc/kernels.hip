@@ -2326,6 +2326,106 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
 }
 
 // ================================================================ post-solve pass and dogleg step
+// traditional dogleg (ceres dogleg_strategy.cc) expressed on the un-scaled vectors:
+//   delta_i = cg * g_i/htil_i + cn * (-y_i)
+// J*delta is never formed: |J delta|^2 and (J delta).r follow from group B by linearity.
+struct DoglegCoeff { double cg, cn, stepNorm, jdSq, jdDotR; };
+__device__ __forceinline__ DoglegCoeff doglegCoefficients(double gHatSq, double jgSq, double gnHatSq, double gDotGn,
+                                                          double jySq, double jvDotJy, double jvDotR, double jyDotR,
+                                                          double radius) {
+  const double gnorm = sqrt(gHatSq), gnnorm = sqrt(gnHatSq);
+  const double alpha = gHatSq / jgSq;
+  DoglegCoeff c;
+  if (gnnorm <= radius) { c.cg = 0; c.cn = 1; c.stepNorm = gnnorm; }
+  else if (gnorm * alpha >= radius) { c.cg = -(radius / gnorm); c.cn = 0; c.stepNorm = radius; }
+  else {
+    const double b_dot_a = -alpha * gDotGn;
+    const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+    const double b_minus_a_sq = a_sq - 2 * b_dot_a + gnnorm * gnnorm;
+    const double cc = b_dot_a - a_sq;
+    const double dd = sqrt(cc * cc + b_minus_a_sq * (radius * radius - a_sq));
+    const double beta = (cc <= 0) ? (dd - cc) / b_minus_a_sq : (radius * radius - a_sq) / (dd + cc);
+    c.cg = -alpha * (1.0 - beta);
+    c.cn = beta;
+    c.stepNorm = sqrt(fmax(c.cg * c.cg * gHatSq + 2 * c.cg * c.cn * gDotGn + c.cn * c.cn * gnHatSq, 0.0));
+  }
+  c.jdSq = c.cg * c.cg * jgSq - 2.0 * c.cg * c.cn * jvDotJy + c.cn * c.cn * jySq;
+  c.jdDotR = c.cg * jvDotR - c.cn * jyDotR;
+  return c;
+}
+// candidate = x [+] delta for item i (variable blocks first, then landmarks); acc += |x - x_cand|^2, |x|^2
+__device__ __forceinline__ void retractItem(const DeviceProblem& p, int i, double cg, double cn, double* acc) {
+  const int nBlk = p.nPose + p.nExt + p.nSb;
+  if (i < nBlk) {
+    if (i < p.nPose + p.nExt) {
+      const bool isPose = i < p.nPose;
+      const int slot = isPose ? i : i - p.nPose;
+      const double* x = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
+      double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
+      const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
+      if (off >= 0) {
+        double dl[6], xo[7];
+        for (int k = 0; k < 6; ++k) dl[k] = cg * p.vC[off + k] - cn * p.yC[off + k];
+        poseOplus(x, dl, xo);
+        for (int k = 0; k < 7; ++k) {
+          xc[k] = xo[k];
+          if (p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
+        }
+      } else {
+        for (int k = 0; k < 7; ++k) xc[k] = x[k];
+      }
+    } else {
+      const int slot = i - p.nPose - p.nExt;
+      const double* x = p.sb + (size_t)slot * 9;
+      double* xc = p.sbC + (size_t)slot * 9;
+      const int off = p.sbOff[slot];
+      for (int k = 0; k < 9; ++k) {
+        const double xo = off >= 0 ? x[k] + (cg * p.vC[off + k] - cn * p.yC[off + k]) : x[k];
+        xc[k] = xo;
+        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo) * (x[k] - xo); acc[1] += x[k] * x[k]; }
+      }
+    }
+  } else if (i < nBlk + p.L) {
+    const int l = i - nBlk;
+    const double* x = p.lm + 4 * (size_t)l;
+    double* xc = p.lmC + 4 * (size_t)l;
+    for (int k = 0; k < 3; ++k) {
+      const double xo = x[k] + (cg * p.vL[3 * l + k] - cn * p.yL[3 * l + k]);
+      xc[k] = xo;
+      acc[0] += (x[k] - xo) * (x[k] - xo);
+      acc[1] += x[k] * x[k];
+    }
+    xc[3] = x[3] + 0.0;
+    acc[1] += x[3] * x[3];
+  }
+}
+
+// stand-alone dogleg step + retraction (re-used linearisation after a rejected step, multi-GPU mode, wide windows);
+// the last block reduces the norms
+__global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) {
+  __shared__ double red[4 * 2];
+  __shared__ int lastFlag;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const SolverScalars& sc = *p.scal;
+  const DoglegCoeff c = doglegCoefficients(sc.gHatSq, sc.jgSq, sc.gnHatSq, sc.gDotGn, sc.jySq, sc.jvDotJy, sc.jvDotR, sc.jyDotR, radius);
+  if (i == 0) { p.scal->doglegStepNorm = c.stepNorm; p.scal->jdSq = c.jdSq; p.scal->jdDotR = c.jdDotR; }
+  double acc[2] = {0, 0};  // |x - x_cand|^2, |x|^2
+  retractItem(p, i, c.cg, c.cn, acc);
+  const double mine = blockSumK<2>(acc, red, -1);
+  if (threadIdx.x < 2) p.partial[(size_t)(threadIdx.x == 0 ? PS_STEP : PS_XNORM) * kMaxPartials + blockIdx.x] = mine;
+  if (!lastBlockDone(&p.tickets[TK_STEP], &lastFlag)) return;
+  for (int k = 0; k < 2; ++k) {
+    double s = 0;
+    const double* src = p.partial + (size_t)(k == 0 ? PS_STEP : PS_XNORM) * kMaxPartials;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) s += src[j];
+    acc[k] = s;
+  }
+  const double tot = blockSumK<2>(acc, red, -1);
+  if (threadIdx.x == 0) p.scal->stepNormSq = tot;
+  if (threadIdx.x == 1) p.scal->xNormSq = tot;
+  if (threadIdx.x == 0) p.tickets[TK_STEP] = 0;
+}
+
 // partial slots of the post-solve pass
 constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
 __device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};
@@ -2338,7 +2438,7 @@ __device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS
 //  last block: camera part of the norms and the marginalisation prior (H-space);
 //  whichever block finishes last reduces all partials into SolverScalars group B.
 template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks) {
+__global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) {
   __shared__ double red[4 * kPostK];
   __shared__ int lastFlag;
   const int t = threadIdx.x, b = blockIdx.x;
@@ -2507,111 +2607,65 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     acc[k] = s;
   }
   const double tot = blockSumK<kPostK>(acc, red, 8);
+  __shared__ double grpB[8];
   if (t < kPostK) {
     double* dst = &p.scal->gHatSq;
     //                     A  B  C  D  E  gHat gnHat gDotGn
     const int field[8] = {1, 4, 5, 6, 7, 0, 2, 3};
-    if (t < 8) dst[field[t]] = tot;
+    if (t < 8) { dst[field[t]] = tot; grpB[field[t]] = tot; }
     else { p.scal->gradMax = tot; p.scal->failMax = (double)p.scal->cholFail; p.scal->cholFail = 0; }
   }
   for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
   if (t == 0) p.tickets[TK_POST] = 0;
+  if (fuseRadius > 0.0) {
+    // single-GPU narrow windows: this block also takes the dogleg step and retracts (k_step_retract's work) --
+    // one launch less on the critical path of every accepted iteration
+    __syncthreads();
+    const DoglegCoeff c = doglegCoefficients(grpB[0], grpB[1], grpB[2], grpB[3], grpB[4], grpB[5], grpB[6], grpB[7], fuseRadius);
+    if (t == 0) { p.scal->doglegStepNorm = c.stepNorm; p.scal->jdSq = c.jdSq; p.scal->jdDotR = c.jdDotR; }
+    double a2[2] = {0, 0};
+    const int nBlkItems = p.nPose + p.nExt + p.nSb;
+    for (int i = t; i < nBlkItems; i += blockDim.x) retractItem(p, i, c.cg, c.cn, a2);
+    // landmarks: four per thread per round with all loads issued before the first store (one memory latency per
+    // round instead of one per landmark)
+    for (int l0 = 0; l0 < p.L; l0 += 4 * (int)blockDim.x) {
+      double x[4][4], v[4][3], y[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + u * (int)blockDim.x + t, p.L - 1);
+        const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
+        x[u][0] = xx.x; x[u][1] = xx.y; x[u][2] = xx.z; x[u][3] = xx.w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[u][k] = p.vL[3 * l + k]; y[u][k] = p.yL[3 * l + k]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = l0 + u * (int)blockDim.x + t;
+        if (l < p.L) {
+          double xo[4];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            xo[k] = x[u][k] + (c.cg * v[u][k] - c.cn * y[u][k]);
+            a2[0] += (x[u][k] - xo[k]) * (x[u][k] - xo[k]);
+            a2[1] += x[u][k] * x[u][k];
+          }
+          xo[3] = x[u][3] + 0.0;
+          a2[1] += x[u][3] * x[u][3];
+          reinterpret_cast<double4*>(p.lmC)[l] = double4{xo[0], xo[1], xo[2], xo[3]};
+        }
+      }
+    }
+    const double tt = blockSumK<2>(a2, red, -1);
+    if (t == 0) p.scal->stepNormSq = tt;
+    if (t == 1) p.scal->xNormSq = tt;
+  }
 }
 
-void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s) {
+void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius) {
   const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 2048) : 0;
   const int nFac = p.F > 0 ? min((p.F + 3) / 4, 1024) : 0;
-  if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac);
-  else hipLaunchKernelGGL(k_post_solve<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac);
-}
-
-// traditional dogleg (ceres dogleg_strategy.cc) expressed on the un-scaled vectors:
-//   delta_i = cg * g_i/htil_i + cn * (-y_i)
-// followed by candidate = x [+] delta and the partial sums of |x - x_cand|^2 and |x|^2 over all variable blocks;
-// the last block reduces them.  J*delta is never formed: |J delta|^2 and (J delta).r follow from group B.
-__global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) {
-  __shared__ double red[4 * 2];
-  __shared__ int lastFlag;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const SolverScalars& sc = *p.scal;
-  const double gnorm = sqrt(sc.gHatSq), gnnorm = sqrt(sc.gnHatSq);
-  const double alpha = sc.gHatSq / sc.jgSq;
-  double cg, cn, stepNorm;
-  if (gnnorm <= radius) { cg = 0; cn = 1; stepNorm = gnnorm; }
-  else if (gnorm * alpha >= radius) { cg = -(radius / gnorm); cn = 0; stepNorm = radius; }
-  else {
-    const double b_dot_a = -alpha * sc.gDotGn;
-    const double a_sq = (alpha * gnorm) * (alpha * gnorm);
-    const double b_minus_a_sq = a_sq - 2 * b_dot_a + gnnorm * gnnorm;
-    const double c = b_dot_a - a_sq;
-    const double dd = sqrt(c * c + b_minus_a_sq * (radius * radius - a_sq));
-    const double beta = (c <= 0) ? (dd - c) / b_minus_a_sq : (radius * radius - a_sq) / (dd + c);
-    cg = -alpha * (1.0 - beta);
-    cn = beta;
-    stepNorm = sqrt(fmax(cg * cg * sc.gHatSq + 2 * cg * cn * sc.gDotGn + cn * cn * sc.gnHatSq, 0.0));
-  }
-  if (i == 0) {
-    p.scal->doglegStepNorm = stepNorm;
-    p.scal->jdSq = cg * cg * sc.jgSq - 2.0 * cg * cn * sc.jvDotJy + cn * cn * sc.jySq;
-    p.scal->jdDotR = cg * sc.jvDotR - cn * sc.jyDotR;
-  }
-  const int nBlk = p.nPose + p.nExt + p.nSb;
-  double acc[2] = {0, 0};  // |x - x_cand|^2, |x|^2
-  if (i < nBlk) {
-    if (i < p.nPose + p.nExt) {
-      const bool isPose = i < p.nPose;
-      const int slot = isPose ? i : i - p.nPose;
-      const double* x = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
-      double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
-      const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
-      if (off >= 0) {
-        double dl[6], xo[7];
-        for (int k = 0; k < 6; ++k) dl[k] = cg * p.vC[off + k] - cn * p.yC[off + k];
-        poseOplus(x, dl, xo);
-        for (int k = 0; k < 7; ++k) {
-          xc[k] = xo[k];
-          if (p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
-        }
-      } else {
-        for (int k = 0; k < 7; ++k) xc[k] = x[k];
-      }
-    } else {
-      const int slot = i - p.nPose - p.nExt;
-      const double* x = p.sb + (size_t)slot * 9;
-      double* xc = p.sbC + (size_t)slot * 9;
-      const int off = p.sbOff[slot];
-      for (int k = 0; k < 9; ++k) {
-        const double xo = off >= 0 ? x[k] + (cg * p.vC[off + k] - cn * p.yC[off + k]) : x[k];
-        xc[k] = xo;
-        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo) * (x[k] - xo); acc[1] += x[k] * x[k]; }
-      }
-    }
-  } else if (i < nBlk + p.L) {
-    const int l = i - nBlk;
-    const double* x = p.lm + 4 * (size_t)l;
-    double* xc = p.lmC + 4 * (size_t)l;
-    for (int k = 0; k < 3; ++k) {
-      const double xo = x[k] + (cg * p.vL[3 * l + k] - cn * p.yL[3 * l + k]);
-      xc[k] = xo;
-      acc[0] += (x[k] - xo) * (x[k] - xo);
-      acc[1] += x[k] * x[k];
-    }
-    xc[3] = x[3] + 0.0;
-    acc[1] += x[3] * x[3];
-  }
-  const double mine = blockSumK<2>(acc, red, -1);
-  if (threadIdx.x < 2) p.partial[(size_t)(threadIdx.x == 0 ? PS_STEP : PS_XNORM) * kMaxPartials + blockIdx.x] = mine;
-  if (!lastBlockDone(&p.tickets[TK_STEP], &lastFlag)) return;
-  for (int k = 0; k < 2; ++k) {
-    double s = 0;
-    const double* src = p.partial + (size_t)(k == 0 ? PS_STEP : PS_XNORM) * kMaxPartials;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) s += src[j];
-    acc[k] = s;
-  }
-  const double tot = blockSumK<2>(acc, red, -1);
-  if (threadIdx.x == 0) p.scal->stepNormSq = tot;
-  if (threadIdx.x == 1) p.scal->xNormSq = tot;
-  if (threadIdx.x == 0) p.tickets[TK_STEP] = 0;
+  if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
+  else hipLaunchKernelGGL(k_post_solve<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
 }
 
 // final single-block reduction of the cost partials into SolverScalars (used when no later evaluation kernel

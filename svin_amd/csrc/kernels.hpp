@@ -151,7 +151,9 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // Cholesky + GN step of the reduced system; fuseFinalize applies k_finalize_diag (metric + damping) while loading S
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);
-void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s);         // g_hat norms, Cauchy J*v pass, gn norms
+// post-solve pass (back-substitution, J*v / J*y sums, norms); fuseRadius > 0: its last block also takes the dogleg
+// step with that radius and retracts (single GPU, narrow windows) -- launchDoglegStep is then not needed
+void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius = -1.0);
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms
 void launchCost(const DeviceProblem& p, hipStream_t s);                  // sums partial costs into scal->cost
 void launchImuPropagation(const DevImu* im /*device*/, const uint32_t* T, const double* M, double* io, double* jac, double* cov,

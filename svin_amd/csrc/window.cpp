@@ -753,6 +753,9 @@ void Window::solve(size_t numIter, bool verbose) {
     if (!allreduce_ || allreduce_(ptr, (uint64_t)n, op, allreduceUser_) != 0) throw std::runtime_error("all-reduce callback failed");
   };
   double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..17] max group
+  // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
+  // retracts the whole window quickly enough
+  const bool fuseStep = world_ <= 1 && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
   evaluateAll(false, s);
   AR(scalD, 4, 0);
   SolverScalars sc = readScalars();
@@ -788,11 +791,11 @@ void Window::solve(size_t numIter, bool verbose) {
         launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/false);  // pack() / k_post_solve cleared them
         AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
         launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
-        launchDoglegPrepare(p, s);
+        launchDoglegPrepare(p, s, fuseStep ? radius : -1.0);
         AR(scalD + kScalGroupB, 8, 0);
         AR(scalD + kScalGroupMax, 2, 1);
       }
-      launchDoglegStep(p, radius, s);
+      if (reuse || !fuseStep) launchDoglegStep(p, radius, s);
       evaluateAll(true, s);
       AR(scalD, 8, 0);
       sc = readScalars();
