@@ -83,6 +83,15 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) 
     const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
     p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
     p.scal->cost = a + bf + pr;
+    if (p.mailbox) {
+      // publish everything the host needs for its accept/reject decision; the sequence number goes last
+      const double* src = reinterpret_cast<const double*>(p.scal);
+      volatile double* dst = reinterpret_cast<volatile double*>(&p.mailbox->scal);
+      for (int k = 0; k < (int)(sizeof(SolverScalars) / sizeof(double)); ++k) dst[k] = src[k];
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
+      __threadfence_system();
+    }
   }
 }
 

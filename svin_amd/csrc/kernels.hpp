@@ -92,6 +92,11 @@ struct SolverScalars {
   int cholFail;           // != 0 when S or a landmark block is not positive definite
   int pad;
 };
+// pinned-host mailbox: the kernel that sums the cost publishes all scalars + the sequence number of that evaluation
+struct ScalarMailbox {
+  SolverScalars scal;
+  unsigned long long seq;
+};
 constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGroupMax = 16;  // offsets (doubles) of the all-reduced groups
 
 struct DeviceProblem {
@@ -137,6 +142,8 @@ struct DeviceProblem {
   SolverScalars* scal;
   double* partial;                           // reduction scratch
   unsigned int* tickets;                     // last-block-done counters of the fused reductions
+  ScalarMailbox* mailbox;                    // host-visible copy of the scalars (nullptr: disabled)
+  unsigned long long mailboxSeq;             // sequence number to publish with this evaluation
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

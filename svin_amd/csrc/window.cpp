@@ -1,6 +1,7 @@
 // svin_amd host core (see window.hpp).  Reference line numbers cite
 // /root/reference/okvis_ros/okvis/okvis_ceres/src/Estimator.cpp unless another file is named.
 #include "window.hpp"
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -61,8 +62,22 @@ Window::Window(int device) : device_(device) {
   HIP_OK(hipSetDevice(device));
   HIP_OK(hipStreamCreate(&stream_));
   std::memset(&prob_, 0, sizeof(prob_));
+  // zero-copy mailbox for the per-iteration scalars: the last evaluation kernel stores SolverScalars and a sequence
+  // number straight into pinned host memory, the host polls it -- no copy kernel, no stream synchronisation on the
+  // critical path of an iteration (SVIN_NO_MAILBOX=1 falls back to memcpy + synchronize)
+  if (!getenv("SVIN_NO_MAILBOX") &&
+      hipHostMalloc(reinterpret_cast<void**>(&mailbox_), sizeof(ScalarMailbox), hipHostMallocMapped) == hipSuccess) {
+    std::memset(mailbox_, 0, sizeof(ScalarMailbox));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&mailboxDev_), mailbox_, 0) != hipSuccess) {
+      (void)hipHostFree(mailbox_);
+      mailbox_ = nullptr; mailboxDev_ = nullptr;
+    }
+  } else {
+    mailbox_ = nullptr;
+  }
 }
 Window::~Window() {
+  if (mailbox_) (void)hipHostFree(mailbox_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -718,6 +733,8 @@ void Window::downloadStates() {
 }
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
+  prob_.mailbox = mailboxDev_;
+  prob_.mailboxSeq = ++mailboxSeq_;
   launchEvalReproj(prob_, cand, true, s);
   const int who = costSummedBy(prob_);
   launchEvalFactors(prob_, cand, s, who == 1);
@@ -727,6 +744,21 @@ void Window::evaluateAll(bool cand, hipStream_t s) {
 
 SolverScalars Window::readScalars() {
   SolverScalars sc;
+  if (mailbox_ && world_ <= 1) {
+    // wait for the sequence number of the last evaluateAll(); bounded spin, then fall back to a real synchronise
+    volatile unsigned long long* seq = &mailbox_->seq;
+    const double tSpin = nowSec();
+    bool ok = false;
+    for (unsigned long long spins = 0;; ++spins) {
+      if (*seq == mailboxSeq_) { ok = true; break; }
+      if ((spins & 1023) == 1023 && nowSec() - tSpin > 2.0) break;
+    }
+    if (ok) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      std::memcpy(&sc, const_cast<SolverScalars*>(&mailbox_->scal), sizeof(sc));
+      return sc;
+    }
+  }
   HIP_OK(hipMemcpyAsync(&sc, prob_.scal, sizeof(sc), hipMemcpyDeviceToHost, stream_));
   HIP_OK(hipStreamSynchronize(stream_));
   return sc;

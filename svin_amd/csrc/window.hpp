@@ -248,6 +248,9 @@ class Window {
   DevBuf<PriorBlock> dPriorBlk_;
   DevBuf<double> dS_, dVec_, dLmVec_, dSlabs_, dChol_, dPartial_, dQuality_;
   DevBuf<SolverScalars> dScal_;
+  ScalarMailbox* mailbox_ = nullptr;      // pinned host memory, written by the device
+  ScalarMailbox* mailboxDev_ = nullptr;   // its device-side address
+  unsigned long long mailboxSeq_ = 0;
   int curSet_ = 0;
 };
 

@@ -149,6 +149,54 @@ def test_reduced_system_parity(gpu_lib, rig):
     assert rel(gn, gc) < 1e-9
 
 
+@pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400)])
+def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
+    """The two landmark-elimination kernels (Gram-matrix form on MFMA for narrow windows, pairwise blocks for wide
+    ones) must produce the same reduced system and the same optimisation result on a window both can handle."""
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=P, L=L, n_obs=n_obs, seed=5, rig="euroc")
+    out = {}
+    for mode in ("dense", "pairwise"):
+        if mode == "pairwise":
+            monkeypatch.setenv("SVIN_SCHUR_PAIRWISE", "1")
+        else:
+            monkeypatch.delenv("SVIN_SCHUR_PAIRWISE", raising=False)
+        est = Estimator(0)
+        f, l = syn.feed(est, spec)
+        lin = est.linearize(1e-8)
+        est.set_solver_options(1e-12, 1e-12, 1e-12)
+        est.optimize(30)
+        out[mode] = (lin, [est.get_T_WS(i) for i in f], est.summary())
+    (la, Ta, sa), (lb, Tb, sb) = out["dense"], out["pairwise"]
+    sd = np.sqrt(np.abs(np.diag(lb["S"])))
+    dS = rel(la["S"] / np.outer(sd, sd), lb["S"] / np.outer(sd, sd))
+    dg = rel(la["g"] / sd, lb["g"] / sd)
+    worst = max(pose_diff(a, b) for a, b in zip(Ta, Tb))
+    log("dense vs pairwise P", P, "dS", dS, "dg", dg, "pose", worst, "iterations", sa["iterations"], sb["iterations"])
+    assert dS < 1e-10 and dg < 1e-10
+    assert sa["iterations"] == sb["iterations"]
+    assert worst < 1e-8
+
+
+def test_mailbox_and_memcpy_scalar_paths_agree(gpu_lib, monkeypatch):
+    """Per-iteration scalars through the pinned-host mailbox or through memcpy + synchronise: identical runs."""
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=6, L=300, n_obs=3000, seed=9, rig="euroc")
+    res = []
+    for no_mailbox in (False, True):
+        if no_mailbox:
+            monkeypatch.setenv("SVIN_NO_MAILBOX", "1")
+        else:
+            monkeypatch.delenv("SVIN_NO_MAILBOX", raising=False)
+        est = Estimator(0)
+        f, l = syn.feed(est, spec)
+        est.optimize(15)
+        res.append((est.summary(), [est.get_T_WS(i) for i in f]))
+    assert res[0][0]["iterations"] == res[1][0]["iterations"]
+    assert res[0][0]["final_cost"] == res[1][0]["final_cost"]
+    assert max(np.max(np.abs(a - b)) for a, b in zip(res[0][1], res[1][1])) == 0.0
+
+
 @pytest.mark.parametrize("rig,P,kw", [("euroc", 6, {}), ("rig_v2", 6, dict(sonar=True, depth=True)),
                                       ("rig_v2", 9, dict(depth=True))])  # d = 90 / 162 / 243 (LDS and global Cholesky)
 def test_optimize_matches_oracle(gpu_lib, rig, P, kw):
