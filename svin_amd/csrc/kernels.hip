@@ -213,20 +213,20 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneI
 // kernel): non-temporal stores keep them from thrashing L2 on their way to HBM -- measured 4.3 -> 6.4 TB/s on the
 // HBM-resident batch, neutral for the single cache-resident window of the solver (profiles/r01_k1_variants.txt).
 #define K1_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+// One block of the reprojection evaluation: `block` is the block index within the evaluation (not necessarily
+// blockIdx.x: the fused evaluation kernel runs these next to the small-factor blocks), `smem` holds
+// (nPose + nExt) * 7 doubles + nCam camera models, `red` 4 doubles.
 template <bool ROBUST, bool WITH_EXT>
-__global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
-                                                     const double* __restrict__ ext, const double* __restrict__ lm,
-                                                     const CameraModel* __restrict__ cams,
-                                                     const double* __restrict__ obsUv, const double* __restrict__ obsW,
-                                                     const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
-                                                     double* __restrict__ r, double* __restrict__ Jp,
-                                                     double* __restrict__ Jl, double* __restrict__ Je,
-                                                     double* __restrict__ costPartial, size_t stride) {
-  extern __shared__ double smem[];
+__device__ __forceinline__ void evalReprojBlock(int block, double* smem, double* red, int N, int nPose, int nExt, int nCam,
+                                                const double* __restrict__ pose, const double* __restrict__ ext,
+                                                const double* __restrict__ lm, const CameraModel* __restrict__ cams,
+                                                const double* __restrict__ obsUv, const double* __restrict__ obsW,
+                                                const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
+                                                double* __restrict__ r, double* __restrict__ Jp, double* __restrict__ Jl,
+                                                double* __restrict__ Je, double* __restrict__ costPartial, size_t stride) {
   double* sPose = smem;                      // nPose*7
   double* sExt = sPose + nPose * 7;          // nExt*7
   CameraModel* sCam = reinterpret_cast<CameraModel*>(sExt + nExt * 7);  // nCam
-  __shared__ double red[2];
   for (int i = threadIdx.x; i < nPose * 7; i += blockDim.x) sPose[i] = pose[i];
   for (int i = threadIdx.x; i < nExt * 7; i += blockDim.x) sExt[i] = ext[i];
   {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt,
     for (int i = threadIdx.x; i < nCam * (int)(sizeof(CameraModel) / 8); i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = block * blockDim.x + threadIdx.x;
   double cost = 0;
   if (i < N) {
     const uint32_t idx = obsIdx[i];
@@ -278,8 +278,23 @@ __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt,
   }
   if (costPartial) {
     const double bs = blockSum(cost, red);
-    if (threadIdx.x == 0) costPartial[blockIdx.x] = bs;
+    if (threadIdx.x == 0) costPartial[block] = bs;
   }
+}
+
+template <bool ROBUST, bool WITH_EXT>
+__global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt, int nCam, const double* __restrict__ pose,
+                                                     const double* __restrict__ ext, const double* __restrict__ lm,
+                                                     const CameraModel* __restrict__ cams,
+                                                     const double* __restrict__ obsUv, const double* __restrict__ obsW,
+                                                     const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
+                                                     double* __restrict__ r, double* __restrict__ Jp,
+                                                     double* __restrict__ Jl, double* __restrict__ Je,
+                                                     double* __restrict__ costPartial, size_t stride) {
+  extern __shared__ double smem[];
+  __shared__ double red[4];
+  evalReprojBlock<ROBUST, WITH_EXT>(blockIdx.x, smem, red, N, nPose, nExt, nCam, pose, ext, lm, cams, obsUv, obsW, obsIdx,
+                                    obsLm, r, Jp, Jl, Je, costPartial, stride);
 }
 
 static int evalGrid(int N) { return (N + 127) / 128; }
@@ -960,9 +975,8 @@ __device__ __forceinline__ int blockOff(const DeviceProblem& p, int kind, int sl
   return p.sbOff[slot];
 }
 
-__global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand, int costBlocksA) {
-  __shared__ FactorShared sh;
-  const int f = blockIdx.x, t = threadIdx.x;
+__device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorShared& sh) {
+  const int t = threadIdx.x;
   const DevFactor& fac = p.factors[f];
   FactorLin& lin = (cand ? p.linCand : p.linCur)[f];
   const int m = fac.m;
@@ -1167,15 +1181,57 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand,
     for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
     p.partial[(size_t)PS_COST_FACTORS * kMaxPartials + f] = 0.5 * c;
   }
+}
+
+__global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand, int costBlocksA) {
+  __shared__ FactorShared sh;
+  evalFactorBlock(p, cand, blockIdx.x, sh);
   // the factor block that finishes last also sums the cost (reprojection partials were written by the previous
   // kernel of the stream) -- saves the separate reduction launch
   if (costBlocksA >= 0) {
     __shared__ int lastFlag;
     if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
       reduceCost(p, costBlocksA, (int)gridDim.x, sh.rw);
-      if (t == 0) p.tickets[TK_EVAL] = 0;
+      if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
     }
   }
+}
+
+// Fused evaluation for the trust-region loop: blocks [0, F) evaluate the small factors (IMU re-preintegration can
+// take tens of microseconds), blocks [F, F + nR) the reprojection residuals with 256 observations each, side by side
+// in one launch; the block that finishes last sums the cost (sumCost) and publishes the scalars.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost) {
+  __shared__ FactorShared sh;
+  const int F = (int)gridDim.x - nR;
+  if ((int)blockIdx.x < F) {
+    evalFactorBlock(p, cand, blockIdx.x, sh);
+  } else {
+    double* smem = reinterpret_cast<double*>(&sh);  // poses / extrinsics / cameras staged in the same LDS
+    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 8, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
+                                    cand ? p.extC : p.ext, cand ? p.lmC : p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
+                                    cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
+                                    cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N);
+  }
+  if (sumCost) {
+    __shared__ int lastFlag;
+    __shared__ double red4[4];
+    if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
+      reduceCost(p, nR, F, red4);
+      if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
+    }
+  }
+}
+
+// fused evaluation possible: factors and observations present, camera-owning rank, staging area fits
+bool canFuseEvaluation(const DeviceProblem& p) {
+  const size_t stage = (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
+  return p.F > 0 && p.N > 0 && p.ownsCamera && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
+}
+void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s) {
+  const int nR = (p.N + 255) / 256;
+  if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_all<true>, dim3(p.F + nR), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0);
+  else hipLaunchKernelGGL(k_eval_all<false>, dim3(p.F + nR), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0);
 }
 
 void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
@@ -1246,9 +1302,11 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, i
   }
 }
 
-void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost) {
+// reprojBlocks: number of reprojection cost partials to sum (-1: the stand-alone evaluation's grid)
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost, int reprojBlocks) {
   if (p.priorM == 0 || !p.ownsCamera) return;
-  hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0, sumCost ? (p.N > 0 ? evalGrid(p.N) : 0) : -1);
+  const int nA = reprojBlocks >= 0 ? reprojBlocks : (p.N > 0 ? evalGrid(p.N) : 0);
+  hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0, sumCost ? nA : -1);
 }
 
 // row i of the prior -> (reduced-system row, or -1) with the 3x3 rotation map applied on the fly

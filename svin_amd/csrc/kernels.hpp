@@ -149,7 +149,10 @@ struct DeviceProblem {
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.
 void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_t s);
 void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false);
-void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false);
+void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false, int reprojBlocks = -1);
+// fused evaluation (small factors + reprojection residuals in one launch, 256 observations per block)
+bool canFuseEvaluation(const DeviceProblem& p);
+void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s);
 int costSummedBy(const DeviceProblem& p);  // 2 = prior evaluation, 1 = factor evaluation, 0 = separate launchCost
 void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // the same in two halves, so that a landmark-sharded solve can all-reduce [S | gRed | gFull | hC] in between

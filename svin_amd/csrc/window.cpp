@@ -735,8 +735,14 @@ void Window::downloadStates() {
 void Window::evaluateAll(bool cand, hipStream_t s) {
   prob_.mailbox = mailboxDev_;
   prob_.mailboxSeq = ++mailboxSeq_;
-  launchEvalReproj(prob_, cand, true, s);
   const int who = costSummedBy(prob_);
+  if (canFuseEvaluation(prob_) && !getenv("SVIN_SPLIT_EVAL")) {
+    // one launch: the reprojection blocks run next to the (much longer) IMU factor blocks
+    launchEvalAll(prob_, cand, who == 1, s);
+    launchEvalPrior(prob_, cand, s, who == 2, (prob_.N + 255) / 256);
+    return;
+  }
+  launchEvalReproj(prob_, cand, true, s);
   launchEvalFactors(prob_, cand, s, who == 1);
   launchEvalPrior(prob_, cand, s, who == 2);
   if (who == 0) launchCost(prob_, s);
