@@ -515,6 +515,7 @@ static void upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
 }
 
 void Window::pack() {
+  const double tPack0 = nowSec();
   poseIds_.clear(); extIds_.clear(); sbIds_.clear(); lmIds_.clear(); factorIds_.clear();
   poseSlot_.clear(); extSlot_.clear(); sbSlot_.clear(); lmSlot_.clear();
   for (const auto& kv : states_) {
@@ -621,6 +622,7 @@ void Window::pack() {
     }
   }
   // ---- device allocation + upload
+  const double tPack1 = nowSec();
   hipStream_t s = stream_;
   upload(dPose_, hPose, s); upload(dExt_, hExt, s); upload(dSb_, hSb, s); upload(dLm_, hLm, s);
   dPoseC_.reserve(std::max<size_t>(hPose.size(), 1)); dExtC_.reserve(std::max<size_t>(hExt.size(), 1));
@@ -698,6 +700,12 @@ void Window::pack() {
   p.tickets = reinterpret_cast<unsigned int*>(dPartial_.p + (size_t)14 * 4096);  // zeroed with the partials
   HIP_OK(hipMemsetAsync(dScal_.p, 0, sizeof(SolverScalars), s));
   HIP_OK(hipMemsetAsync(dPartial_.p, 0, sizeof(double) * 16 * 4096, s));
+  if (getenv("SVIN_PACK_TIMING")) {
+    const double tPack2 = nowSec();
+    HIP_OK(hipStreamSynchronize(s));
+    std::printf("[pack] host graph -> arrays %.1f us, allocation + enqueue %.1f us, drain %.1f us\n", 1e6 * (tPack1 - tPack0),
+                1e6 * (tPack2 - tPack1), 1e6 * (nowSec() - tPack2));
+  }
 }
 
 void Window::downloadStates() {
