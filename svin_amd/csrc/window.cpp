@@ -517,7 +517,7 @@ static void upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
 void Window::pack() {
   const double tPack0 = nowSec();
   poseIds_.clear(); extIds_.clear(); sbIds_.clear(); lmIds_.clear(); factorIds_.clear();
-  poseSlot_.clear(); extSlot_.clear(); sbSlot_.clear(); lmSlot_.clear();
+  poseSlot_.clear(); extSlot_.clear(); sbSlot_.clear();
   for (const auto& kv : states_) {
     const State& s = kv.second;
     if (s.pose.exists) { poseSlot_[s.pose.id] = (int)poseIds_.size(); poseIds_.push_back(s.pose.id); }
@@ -551,28 +551,48 @@ void Window::pack() {
     if (b.fixed) hSbOff[i] = -1;
     else { hSbOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 9; }
   }
-  // landmarks + observations (landmark-major)
-  std::vector<double> hLm, hUv, hW;
-  std::vector<int> hLmPtr, hObsLm;
-  std::vector<uint32_t> hIdx;
-  obsResIds_.clear(); obsLmIds_.clear(); obsPoseIds_.clear(); obsCam_.clear();
-  hLmPtr.push_back(0);
-  for (const auto& kv : landmarks_) {
-    const Landmark& lm = kv.second;
-    if (lm.obs.empty()) continue;
-    const int slot = (int)lmIds_.size();
-    lmSlot_[lm.id] = slot;
-    lmIds_.push_back(lm.id);
-    hLm.insert(hLm.end(), lm.hp, lm.hp + 4);
-    for (const Observation& o : lm.obs) {
-      hUv.push_back(o.uv[0]); hUv.push_back(o.uv[1]);
-      // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
-      hW.push_back(std::sqrt(64.0 / (o.size * o.size)));
-      hIdx.push_back(packObs(poseSlot_.at(o.poseId), extSlot_.at(o.extId), o.cam));
-      hObsLm.push_back(slot);
-      obsResIds_.push_back(o.resId); obsLmIds_.push_back(lm.id); obsPoseIds_.push_back(o.poseId); obsCam_.push_back(o.cam);
+  // landmarks + observations (landmark-major).  Sized in a first pass and filled by index; pose / extrinsics slots
+  // come from a small linear table (a window holds a few dozen states) instead of one hash lookup per observation.
+  size_t nLmObs = 0, nObs = 0;
+  for (const auto& kv : landmarks_)
+    if (!kv.second.obs.empty()) { ++nLmObs; nObs += kv.second.obs.size(); }
+  std::vector<double> hLm(4 * nLmObs), hUv(2 * nObs), hW(nObs);
+  std::vector<int> hLmPtr(nLmObs + 1), hObsLm(nObs);
+  std::vector<uint32_t> hIdx(nObs);
+  lmIds_.resize(nLmObs);
+  struct SlotCache {
+    const std::unordered_map<uint64_t, int>& map;
+    std::vector<uint64_t> ids;
+    std::vector<int> slots;
+    explicit SlotCache(const std::unordered_map<uint64_t, int>& m) : map(m) {
+      if (m.size() <= 64)
+        for (const auto& kv : m) { ids.push_back(kv.first); slots.push_back(kv.second); }
     }
-    hLmPtr.push_back((int)hObsLm.size());
+    int at(uint64_t id) const {
+      for (size_t i = 0; i < ids.size(); ++i)
+        if (ids[i] == id) return slots[i];
+      return map.at(id);
+    }
+  };
+  const SlotCache poseCache(poseSlot_), extCache(extSlot_);
+  {
+    size_t slot = 0, o = 0;
+    hLmPtr[0] = 0;
+    for (const auto& kv : landmarks_) {
+      const Landmark& lm = kv.second;
+      if (lm.obs.empty()) continue;
+      lmIds_[slot] = lm.id;
+      std::memcpy(&hLm[4 * slot], lm.hp, 4 * sizeof(double));
+      for (const Observation& ob : lm.obs) {
+        hUv[2 * o] = ob.uv[0]; hUv[2 * o + 1] = ob.uv[1];
+        // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
+        hW[o] = std::sqrt(64.0 / (ob.size * ob.size));
+        hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(ob.extId), ob.cam);
+        hObsLm[o] = (int)slot;
+        ++o;
+      }
+      hLmPtr[++slot] = (int)o;
+    }
   }
   const int L = (int)lmIds_.size(), N = (int)hObsLm.size();
   // factors
@@ -935,13 +955,18 @@ int Window::setOptimizationTimeLimit(double timeLimit, int minIter) {  // :932-9
 int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t* cam, int cap) {
   pack();
   HIP_OK(hipStreamSynchronize(stream_));
-  const int n = (int)obsResIds_.size();
-  for (int i = 0; i < n && i < cap; ++i) {
-    if (rid) rid[i] = obsResIds_[i];
-    if (lm) lm[i] = obsLmIds_[i];
-    if (pose) pose[i] = obsPoseIds_[i];
-    if (cam) cam[i] = obsCam_[i];
-  }
+  // same order as pack(): landmarks with observations in id order, observations in insertion order
+  int n = 0;
+  for (const auto& kv : landmarks_)
+    for (const Observation& o : kv.second.obs) {
+      if (n < cap) {
+        if (rid) rid[n] = o.resId;
+        if (lm) lm[n] = kv.second.id;
+        if (pose) pose[n] = o.poseId;
+        if (cam) cam[n] = o.cam;
+      }
+      ++n;
+    }
   return n;
 }
 int Window::evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap) {

@@ -225,9 +225,7 @@ class Window {
 
   // packing maps (valid after pack())
   std::vector<uint64_t> poseIds_, extIds_, sbIds_, lmIds_, factorIds_;
-  std::unordered_map<uint64_t, int> poseSlot_, extSlot_, sbSlot_, lmSlot_;
-  std::vector<uint64_t> obsResIds_, obsLmIds_, obsPoseIds_;
-  std::vector<int32_t> obsCam_;
+  std::unordered_map<uint64_t, int> poseSlot_, extSlot_, sbSlot_;
   std::vector<uint64_t> redBlockIds_;
   std::vector<int32_t> redBlockOff_;
   DeviceProblem prob_;
