@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, i
     c += priorDchi[i] * (p.priorBp[i] + 0.5 * s);
   }
   const double tot = blockSum(c, red);
-  if (t == 0) p.scal->costPrior = 0.5 * p.priorC0 + tot;
+  if (t == 0) p.scal->costPrior = 0.5 * (*p.priorC0) + tot;
   if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
     __syncthreads();
     reduceCost(p, costBlocksA, p.F, red);

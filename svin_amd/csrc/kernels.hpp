@@ -126,7 +126,7 @@ struct DeviceProblem {
   double* imuMeas;   // [M][6]
   // prior (H-space)
   double *priorH, *priorBp;
-  double priorC0;
+  const double* priorC0;                     // e0.e0 of the prior (device scalar)
   PriorBlock* priorBlk;
   double *priorDchi, *priorGrad, *priorM3;      // linearisation of the prior at the accepted point: m, m, 9 per block
   double *priorDchiC, *priorGradC, *priorM3C;   // ... at the candidate (swapped on acceptance)

@@ -11,6 +11,9 @@
 // rank-revealing thresholds of the eliminated blocks; it is applied to exactly those blocks here
 // (U - W V^+ W^T with V^+ = D^-1 (D^-1 V D^-1)^+ D^-1), which is the same matrix in exact arithmetic.
 #include "window.hpp"
+#include <chrono>
+#include <memory>
+#include <type_traits>
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -156,16 +159,39 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // G (row j = column j of A on entry) is overwritten by the columns of A*Q; Q (row j = eigenvector j)
 // must hold the identity on entry.  Eigenvalue j = Q_j . G_j.  Rounds follow the round-robin
 // tournament so that the n/2 rotations of one round touch disjoint columns.
+// columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
+// dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
+constexpr double kJacobiOrthTol = 2.0e-14;
 __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
   if (n <= 1) return;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
+  // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
+  // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
+  // to keep the solver busy for all 40 sweeps).  Pairs with at least one significant column are still rotated.
+  __shared__ double nullTol2;
   for (int sweep = 0; sweep < 40; ++sweep) {
     __syncthreads();
-    if (threadIdx.x == 0) *flag = 0;
+    if (threadIdx.x == 0) { *flag = 0; nullTol2 = 0.0; }
     __syncthreads();
+    {
+      double mx = 0;
+      for (int j = wave; j < n; j += nWaves) {
+        double a2 = 0;
+        for (int i = lane; i < n; i += 64) { const double x = G[(size_t)j * ld + i]; a2 += x * x; }
+        a2 = waveSumM(a2);
+        mx = fmax(mx, a2);
+      }
+      // non-negative doubles order like their bit patterns
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(&nullTol2), (unsigned long long)__double_as_longlong(mx));
+    }
+    __syncthreads();
+    const double eps_n = 2.220446049250313e-16 * n;
+    const double tol2 = nullTol2 * eps_n * eps_n;
+    // 16 lanes per pair (DPP-sized groups): the n/2 disjoint pairs of a round run side by side, four per wave
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
     for (int round = 0; round < np - 1; ++round) {
-      for (int k = wave; k < np / 2; k += nWaves) {
+      for (int k = grp; k < np / 2; k += nGroups) {
         int a, b;
         if (k == 0) { a = np - 1; b = round; }
         else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
@@ -174,16 +200,18 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
         double* gp = G + (size_t)pI * ld;
         double* gq = G + (size_t)qI * ld;
         double al = 0, be = 0, ga = 0;
-        for (int i = lane; i < n; i += 64) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
-        al = waveSumM(al); be = waveSumM(be); ga = waveSumM(ga);
-        if (fabs(ga) <= 1e-15 * sqrt(al * be) || al == 0.0 || be == 0.0) continue;
-        if (lane == 0) *flag = 1;
+        for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { al += __shfl_xor(al, o, 16); be += __shfl_xor(be, o, 16); ga += __shfl_xor(ga, o, 16); }
+        if (fabs(ga) <= kJacobiOrthTol * sqrt(al * be) || al == 0.0 || be == 0.0) continue;
+        if (al <= tol2 && be <= tol2) continue;
+        if (gl == 0) *flag = 1;
         const double zeta = (be - al) / (2.0 * ga);
         const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
         double* vp = Q + (size_t)pI * ld;
         double* vq = Q + (size_t)qI * ld;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = gl; i < n; i += 16) {
           const double x = gp[i], y = gq[i];
           gp[i] = c * x - s * y; gq[i] = s * x + c * y;
           const double u = vp[i], w = vq[i];
@@ -192,9 +220,38 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
       }
       __syncthreads();
     }
+    if (threadIdx.x == 0) flag[1] = sweep + 1;
     if (*flag == 0) break;
   }
   __syncthreads();
+}
+
+// Same, with G and Q staged through LDS when the kernel was launched with 2*n*(n|1) doubles of dynamic shared
+// memory (lds != nullptr): every round of the tournament is one LDS round trip instead of a global-memory one
+// (12 sweeps x 50 rounds at n = 51: 1.9 ms -> 0.2 ms).
+__device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
+  if (!lds) { jacobiEigBlock(G, Q, n, n, flag); return; }
+  const int ld = n | 1;
+  double* sG = lds;
+  double* sQ = lds + (size_t)n * ld;
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    sG[i * ld + j] = G[idx];
+    sQ[i * ld + j] = Q[idx];
+  }
+  __syncthreads();
+  jacobiEigBlock(sG, sQ, n, ld, flag);
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    G[idx] = sG[i * ld + j];
+    Q[idx] = sQ[i * ld + j];
+  }
+  __syncthreads();
+}
+constexpr size_t kJacobiLdsLimit = 150 * 1024;
+static size_t jacobiLdsBytes(int n) {
+  const size_t b = (size_t)2 * n * (n | 1) * sizeof(double);
+  return b <= kJacobiLdsLimit ? b : 0;
 }
 
 // ---------------------------------------------------------------- M2: landmark part (:557-619)
@@ -265,7 +322,8 @@ struct DenseArgs {
   double *Vm, *Qm, *tmp;    // scratch: nm x nm, nm x nm, nk x nm + 2 nm
   int* flag;
 };
-__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a) {
+__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds) {
+  extern __shared__ double jacobiLds[];
   const int t = threadIdx.x, nt = blockDim.x, nm = a.nm, nk = a.nk, m = a.m;
   double* pm = a.tmp;                 // nm
   double* tv = a.tmp + nm;            // nm
@@ -283,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a) {
     a.Qm[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  jacobiEigBlock(a.Vm, a.Qm, nm, nm, a.flag);
+  jacobiEig(a.Vm, a.Qm, nm, a.flag, useLds ? jacobiLds : nullptr);
   // eigenvalues, tolerance, N = D^-1 Q diag(sqrt(1/l)|0)  (column j of N = eigenvector j scaled)
   __shared__ double smax;
   for (int j = t; j < nm; j += nt) {
@@ -338,7 +396,8 @@ struct FinalArgs {
   double *G, *Q, *J, *e0, *Ht, *bp, *scal, *tmp;
   int* flag;
 };
-__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a) {
+__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
+  extern __shared__ double jacobiLds[];
   const int t = threadIdx.x, nt = blockDim.x, n = a.n;
   double* p = a.tmp;        // n
   double* ev = a.tmp + n;   // n
@@ -353,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a) {
     a.Q[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  jacobiEigBlock(a.G, a.Q, n, n, a.flag);
+  jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
   __shared__ double smax;
   for (int j = t; j < n; j += nt) {
     double s = 0;
@@ -364,6 +423,7 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a) {
   if (t == 0) { double mx = ev[0]; for (int j = 1; j < n; ++j) mx = fmax(mx, ev[j]); smax = mx; }
   __syncthreads();
   const double tol = 2.220446049250313e-16 * n * smax;
+  if (t == 0) { int c = 0; double mn = ev[0]; for (int j = 0; j < n; ++j) { c += ev[j] <= tol; mn = fmin(mn, ev[j]); } a.flag[2] = c; a.scal[1] = mn; a.scal[2] = smax; }
   for (int idx = t; idx < n * n; idx += nt) {
     const int i = idx / n, j = idx % n;  // row i of J = eigen-direction i
     const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
@@ -403,7 +463,14 @@ bool contains(const std::vector<T>& v, const T& q) {
 }
 }  // namespace
 
+static double nowSec() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed) {
+  const bool timing = getenv("SVIN_MARG_TIMING") != nullptr;
+  const double tm0 = nowSec();
+  double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
   // ---- policy (Estimator.cpp:495-770), operating on the host graph only
   auto rit = states_.rbegin();
   for (size_t k = 0; k < numImuFrames; k++) {
@@ -572,6 +639,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
   }
 
   // ---- device job (M1-M3)
+  tm1 = nowSec();
   std::sort(toMarginalize.begin(), toMarginalize.end());
   toMarginalize.erase(std::unique(toMarginalize.begin(), toMarginalize.end()), toMarginalize.end());
   bool anyWork = !toMarginalize.empty();
@@ -647,18 +715,32 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       hFac.push_back(df);
     }
     const int F = (int)hFac.size();
+    // The job is asynchronous (nothing below waits for the device): the staging copies of the uploaded arrays are
+    // kept in margHold_ until the next job has synchronised with the stream.
+    HIP_OK(hipStreamSynchronize(s));
+    margHold_.clear();
     auto up = [&](auto& buf, const auto& host) {
-      buf.reserve(std::max<size_t>(host.size(), 1));
-      if (!host.empty()) HIP_OK(hipMemcpyAsync(buf.p, host.data(), sizeof(host[0]) * host.size(), hipMemcpyHostToDevice, s));
+      using V = std::decay_t<decltype(host)>;
+      auto keep = std::make_shared<V>(host);
+      margHold_.push_back(keep);
+      buf.reserve(std::max<size_t>(keep->size(), 1));
+      if (!keep->empty())
+        HIP_OK(hipMemcpyAsync(buf.p, keep->data(), sizeof((*keep)[0]) * keep->size(), hipMemcpyHostToDevice, s));
     };
-    DevBuf<double> bPose, bExt, bSb, bLm, bUv, bW, bLin, bU, bW2, bV, bVec, bScratch;
-    DevBuf<int> bOP, bOE, bOS, bLmPtr, bObsLm, bIdxList, bFlag;
-    DevBuf<uint32_t> bIdx, bImuT;
-    DevBuf<DevFactor> bFac;
-    DevBuf<FactorLin> bFacLin;
-    DevBuf<DevImu> bImu;
-    DevBuf<double> bImuM, bPartial;
-    DevBuf<SolverScalars> bScal;
+    tm2 = nowSec();
+    double* dbgScal = nullptr;
+    // persistent job buffers (grow-only): hipMalloc / hipFree per call used to cost more than the algebra
+    MargBuffers& mb = margBuf_;
+    auto &bPose = mb.bPose, &bExt = mb.bExt, &bSb = mb.bSb, &bLm = mb.bLm, &bUv = mb.bUv, &bW = mb.bW, &bLin = mb.bLin,
+         &bU = mb.bU, &bW2 = mb.bW2, &bV = mb.bV, &bVec = mb.bVec, &bScratch = mb.bScratch;
+    auto &bOP = mb.bOP, &bOE = mb.bOE, &bOS = mb.bOS, &bLmPtr = mb.bLmPtr, &bObsLm = mb.bObsLm, &bIdxList = mb.bIdxList,
+         &bFlag = mb.bFlag;
+    auto &bIdx = mb.bIdx, &bImuT = mb.bImuT;
+    auto& bFac = mb.bFac;
+    auto& bFacLin = mb.bFacLin;
+    auto& bImu = mb.bImu;
+    auto &bImuM = mb.bImuM, &bPartial = mb.bPartial;
+    auto& bScal = mb.bScal;
     up(bPose, hPose); up(bExt, hExt); up(bSb, hSb); up(bLm, hLm); up(bUv, hUv); up(bW, hW);
     up(bOP, oPose); up(bOE, oExt); up(bOS, oSb); up(bLmPtr, hLmPtr); up(bObsLm, hObsLm); up(bIdx, hIdx);
     up(bFac, hFac); up(bImu, hImu); up(bImuT, hImuT); up(bImuM, hImuM);
@@ -676,9 +758,10 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     HIP_OK(hipMemsetAsync(bVec.p, 0, sizeof(double) * (mm + 2 * L3 + 16), s));
     // old prior content (H_, b0_) occupies the leading block
     if (hadPrior && priorM_ > 0) {
-      HIP_OK(hipMemcpy2DAsync(bU.p, sizeof(double) * m, priorH_.data(), sizeof(double) * priorM_, sizeof(double) * priorM_,
-                              priorM_, hipMemcpyHostToDevice, s));
-      HIP_OK(hipMemcpyAsync(bVec.p, priorB0_.data(), sizeof(double) * priorM_, hipMemcpyHostToDevice, s));
+      // the previous prior (H | b0) is still on the device, exactly where k_marg_dense left it
+      HIP_OK(hipMemcpy2DAsync(bU.p, sizeof(double) * m, mb.bHk.p, sizeof(double) * priorM_, sizeof(double) * priorM_,
+                              priorM_, hipMemcpyDeviceToDevice, s));
+      HIP_OK(hipMemcpyAsync(bVec.p, mb.bHk.p + (size_t)priorM_ * priorM_, sizeof(double) * priorM_, hipMemcpyDeviceToDevice, s));
     }
     DeviceProblem q;
     std::memset(&q, 0, sizeof(q));
@@ -727,7 +810,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     for (PriorBlockHost& pb : kept) { pb.ord = ordk; ordk += pb.mdim; }
     Hk.assign((size_t)nk * nk, 0.0);
     bk.assign(nk, 0.0);
-    DevBuf<double> bHk, bOut;
+    auto &bHk = mb.bHk, &bOut = mb.bOut;
     bHk.reserve(std::max<size_t>((size_t)nk * nk + nk, 1));
     if (nk > 0) {
       if (nm > 0) {
@@ -742,7 +825,11 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         da.Hk = bHk.p; da.bk = bHk.p + (size_t)nk * nk;
         da.Vm = bScratch.p; da.Qm = bScratch.p + (size_t)nm * nm; da.tmp = bScratch.p + (size_t)2 * nm * nm;
         da.flag = bFlag.p;
-        hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), 0, s, da);
+        {
+          const size_t lds = jacobiLdsBytes(nm);
+          if (lds) (void)hipFuncSetAttribute((const void*)k_marg_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, lds ? 1 : 0);
+        }
       } else {
         HIP_OK(hipMemcpyAsync(bHk.p, bU.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, s));
         HIP_OK(hipMemcpyAsync(bHk.p + (size_t)m * m, bVec.p, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
@@ -756,20 +843,27 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       fa.e0 = bOut.p + 4 * n2; fa.bp = bOut.p + 4 * n2 + nk; fa.scal = bOut.p + 4 * n2 + 2 * nk;
       fa.tmp = bOut.p + 4 * n2 + 2 * nk + 8;
       fa.flag = bFlag.p;
-      hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), 0, s, fa);
-      priorH_.assign(n2, 0.0); priorB0_.assign(nk, 0.0); priorJ_.assign(n2, 0.0); priorE0_.assign(nk, 0.0);
-      priorHt_.assign(n2, 0.0); priorBp_.assign(nk, 0.0);
-      HIP_OK(hipMemcpyAsync(priorH_.data(), bHk.p, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(priorB0_.data(), bHk.p + n2, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(priorJ_.data(), fa.J, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(priorHt_.data(), fa.Ht, sizeof(double) * n2, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(priorE0_.data(), fa.e0, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(priorBp_.data(), fa.bp, sizeof(double) * nk, hipMemcpyDeviceToHost, s));
-      HIP_OK(hipMemcpyAsync(&priorC0_, fa.scal, sizeof(double), hipMemcpyDeviceToHost, s));
+      dbgScal = fa.scal;
+      {
+        const size_t lds = jacobiLdsBytes(nk);
+        if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, lds ? 1 : 0);
+      }
+      priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     }
-    HIP_OK(hipStreamSynchronize(s));
+    tm3 = nowSec();
+    if (timing) {
+      HIP_OK(hipStreamSynchronize(s));
+      int fl[4] = {0, 0, 0, 0};
+      HIP_OK(hipMemcpy(fl, bFlag.p, sizeof(fl), hipMemcpyDeviceToHost));
+      double sc3[3] = {0, 0, 0};
+      if (mb.bOut.p) HIP_OK(hipMemcpy(sc3, dbgScal, sizeof(sc3), hipMemcpyDeviceToHost));
+      std::printf("[marg] m %d Lm %d; Jacobi sweeps of the last eigen-solve: %d; eigenvalues <= tol: %d (min %.3e max %.3e)\n", m, Lm,
+                  fl[1], fl[2], sc3[1], sc3[2]);
+    }
     (void)anyWork;
   }
+  tm4 = nowSec();
   // ---- graph update (:710-716, :788-811)
   for (uint64_t id : toMarginalize)
     if (!lmLin.count(id)) removeBlock(id);
@@ -799,6 +893,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     f.sqrtInfo[35] = 1.0e14;
     addFactor(std::move(f));
   }
+  if (timing)
+    std::printf("[marg] policy %.0f us, job assembly %.0f us, upload+enqueue %.0f us, device wait %.0f us, graph update %.0f us\n",
+                1e6 * (tm1 - tm0), 1e6 * (tm2 - tm1), 1e6 * (tm3 - tm2), 1e6 * (tm4 - tm3), 1e6 * (nowSec() - tm4));
   return 1;
 }
 

@@ -654,7 +654,7 @@ void Window::pack() {
   for (int k = 0; k < 2; ++k) { dLin_[k].reserve(std::max<size_t>((size_t)32 * N, 1)); dFacLin_[k].reserve(std::max(F, 1)); }
   upload(dFactors_, hFac, s); upload(dImus_, hImu, s); upload(dImuT_, hImuT, s); upload(dImuM_, hImuM, s);
   if (hasPrior_) {
-    upload(dPriorH_, priorHt_, s); upload(dPriorBp_, priorBp_, s); upload(dPriorBlk_, hPb, s);
+    upload(dPriorBlk_, hPb, s);  // Ht / bp / c0 stay where the marginalisation kernels left them (margBuf_.bOut)
     dPriorScratch_.reserve((size_t)6 * priorM + 18 * hPb.size() + 16);
   }
   const int dpad = ((d + 15) / 16) * 16;
@@ -696,7 +696,12 @@ void Window::pack() {
   p.factors = dFactors_.p; p.linCur = dFacLin_[0].p; p.linCand = dFacLin_[1].p;
   p.imus = dImus_.p; p.imuT = dImuT_.p; p.imuMeas = dImuM_.p;
   if (hasPrior_) {
-    p.priorH = dPriorH_.p; p.priorBp = dPriorBp_.p; p.priorC0 = priorC0_; p.priorBlk = dPriorBlk_.p;
+    {
+      const size_t n2 = (size_t)priorM * priorM;
+      const double* out = margBuf_.bOut.p;  // k_marg_final: G | Q | J | Ht | e0 | bp | scal
+      p.priorH = const_cast<double*>(out) + 3 * n2; p.priorBp = const_cast<double*>(out) + 4 * n2 + priorM;
+      p.priorC0 = out + 4 * n2 + 2 * priorM; p.priorBlk = dPriorBlk_.p;
+    }
     double* ps = dPriorScratch_.p;
     p.priorDchi = ps; p.priorGrad = ps + priorM; p.priorDchiC = ps + 2 * priorM; p.priorGradC = ps + 3 * priorM;
     p.priorMv = ps + 4 * priorM; p.priorMy = ps + 5 * priorM;
@@ -1051,6 +1056,16 @@ int Window::getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids
   if (!hasPrior_) return 0;
   const int m = priorM_;
   if (m > capM) return -m;
+  if (!priorHostValid_) {  // the prior lives on the device; fetch the inspection copies on demand
+    const size_t n2 = (size_t)m * m;
+    priorH_.assign(n2, 0.0); priorB0_.assign(m, 0.0); priorJ_.assign(n2, 0.0); priorE0_.assign(m, 0.0);
+    HIP_OK(hipMemcpyAsync(priorH_.data(), margBuf_.bHk.p, sizeof(double) * n2, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(priorB0_.data(), margBuf_.bHk.p + n2, sizeof(double) * m, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(priorJ_.data(), margBuf_.bOut.p + 2 * n2, sizeof(double) * n2, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(priorE0_.data(), margBuf_.bOut.p + 4 * n2, sizeof(double) * m, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    priorHostValid_ = true;
+  }
   if (H) std::memcpy(H, priorH_.data(), sizeof(double) * m * m);
   if (b0) std::memcpy(b0, priorB0_.data(), sizeof(double) * m);
   if (J) std::memcpy(J, priorJ_.data(), sizeof(double) * m * m);

@@ -107,6 +107,17 @@ struct DevBuf {
   }
 };
 
+// device buffers of the marginalisation job (marg.hip), kept across calls
+struct MargBuffers {
+  DevBuf<double> bPose, bExt, bSb, bLm, bUv, bW, bLin, bU, bW2, bV, bVec, bScratch, bImuM, bPartial, bHk, bOut;
+  DevBuf<int> bOP, bOE, bOS, bLmPtr, bObsLm, bIdxList, bFlag;
+  DevBuf<uint32_t> bIdx, bImuT;
+  DevBuf<DevFactor> bFac;
+  DevBuf<FactorLin> bFacLin;
+  DevBuf<DevImu> bImu;
+  DevBuf<SolverScalars> bScal;
+};
+
 class Window {
  public:
   explicit Window(int device);
@@ -211,8 +222,8 @@ class Window {
   uint64_t priorResId_ = 0;
   std::vector<PriorBlockHost> priorBlocks_;
   std::vector<double> priorH_, priorB0_, priorJ_, priorE0_;  // H/b0 as marginalised; J,e0 from M3
-  std::vector<double> priorHt_, priorBp_;                    // H-space form used by the solver
-  double priorC0_ = 0;
+  bool priorHostValid_ = false;                              // host copies above fetched from the device (getPrior)
+  std::vector<std::shared_ptr<void>> margHold_;              // host staging of the last (asynchronous) marginalisation job
   int priorM_ = 0;
 
   // solver options
@@ -246,6 +257,7 @@ class Window {
   DevBuf<PriorBlock> dPriorBlk_;
   DevBuf<double> dS_, dVec_, dLmVec_, dSlabs_, dChol_, dPartial_, dQuality_;
   DevBuf<SolverScalars> dScal_;
+  MargBuffers margBuf_;
   ScalarMailbox* mailbox_ = nullptr;      // pinned host memory, written by the device
   ScalarMailbox* mailboxDev_ = nullptr;   // its device-side address
   unsigned long long mailboxSeq_ = 0;
