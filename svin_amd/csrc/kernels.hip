@@ -1197,43 +1197,6 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand,
   }
 }
 
-// Fused evaluation for the trust-region loop: blocks [0, F) evaluate the small factors (IMU re-preintegration can
-// take tens of microseconds), blocks [F, F + nR) the reprojection residuals with 256 observations each, side by side
-// in one launch; the block that finishes last sums the cost (sumCost) and publishes the scalars.
-template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost) {
-  __shared__ FactorShared sh;
-  const int F = (int)gridDim.x - nR;
-  if ((int)blockIdx.x < F) {
-    evalFactorBlock(p, cand, blockIdx.x, sh);
-  } else {
-    double* smem = reinterpret_cast<double*>(&sh);  // poses / extrinsics / cameras staged in the same LDS
-    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 8, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
-                                    cand ? p.extC : p.ext, cand ? p.lmC : p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
-                                    cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
-                                    cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N);
-  }
-  if (sumCost) {
-    __shared__ int lastFlag;
-    __shared__ double red4[4];
-    if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
-      reduceCost(p, nR, F, red4);
-      if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
-    }
-  }
-}
-
-// fused evaluation possible: factors and observations present, camera-owning rank, staging area fits
-bool canFuseEvaluation(const DeviceProblem& p) {
-  const size_t stage = (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
-  return p.F > 0 && p.N > 0 && p.ownsCamera && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
-}
-void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s) {
-  const int nR = (p.N + 255) / 256;
-  if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_all<true>, dim3(p.F + nR), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0);
-  else hipLaunchKernelGGL(k_eval_all<false>, dim3(p.F + nR), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0);
-}
-
 void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
                           int* used, hipStream_t s) {
   hipLaunchKernelGGL(k_imu_propagation, dim3(1), dim3(256), 0, s, im, T, M, io, jac, cov, used);
@@ -1255,8 +1218,7 @@ int costSummedBy(const DeviceProblem& p) {
 // cost = 0.5 c0 + bp^T dchi + 0.5 dchi^T Ht dchi ;  grad (lin space) = bp + Ht dchi
 // Ceres multiplies the ambient Jacobian (J_min * lift(x_lin)) by PlusJacobian(x): for a pose block the
 // effective tangent map is M = blockdiag(I3, oplus(q_cur * q_lin^-1)[0:3,0:3]) (MarginalizationError.cpp:798-844).
-__global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
-  __shared__ double red[4];
+__device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
   const int t = threadIdx.x, m = p.priorM;
   double* priorDchi = cand ? p.priorDchiC : p.priorDchi;
   double* priorGrad = cand ? p.priorGradC : p.priorGrad;
@@ -1296,6 +1258,10 @@ __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, i
   }
   const double tot = blockSum(c, red);
   if (t == 0) p.scal->costPrior = 0.5 * (*p.priorC0) + tot;
+}
+__global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
+  __shared__ double red[4];
+  priorEvalBlock(p, cand, red);
   if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
     __syncthreads();
     reduceCost(p, costBlocksA, p.F, red);
@@ -1307,6 +1273,48 @@ void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumC
   if (p.priorM == 0 || !p.ownsCamera) return;
   const int nA = reprojBlocks >= 0 ? reprojBlocks : (p.N > 0 ? evalGrid(p.N) : 0);
   hipLaunchKernelGGL(k_prior_eval, dim3(1), dim3(256), 0, s, p, cand ? 1 : 0, sumCost ? nA : -1);
+}
+
+// Fused evaluation for the trust-region loop: blocks [0, F) evaluate the small factors (IMU re-preintegration can
+// take tens of microseconds), blocks [F, F + nR) the reprojection residuals with 256 observations each, side by side
+// in one launch, plus one block for the marginalisation prior (hasPrior); the block that finishes last sums the cost
+// (sumCost) and publishes the scalars.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost, int hasPrior) {
+  __shared__ FactorShared sh;
+  const int F = (int)gridDim.x - nR - hasPrior;
+  if ((int)blockIdx.x < F) {
+    evalFactorBlock(p, cand, blockIdx.x, sh);
+  } else if ((int)blockIdx.x == F + nR) {
+    priorEvalBlock(p, cand, reinterpret_cast<double*>(&sh));
+  } else {
+    double* smem = reinterpret_cast<double*>(&sh);  // poses / extrinsics / cameras staged in the same LDS
+    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 8, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
+                                    cand ? p.extC : p.ext, cand ? p.lmC : p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
+                                    cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
+                                    cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N);
+  }
+  if (sumCost) {
+    __shared__ int lastFlag;
+    __shared__ double red4[4];
+    if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
+      reduceCost(p, nR, F, red4);
+      if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
+    }
+  }
+}
+
+// fused evaluation possible: factors and observations present, camera-owning rank, staging area fits
+bool canFuseEvaluation(const DeviceProblem& p) {
+  const size_t stage = (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
+  return p.F > 0 && p.N > 0 && p.ownsCamera && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
+}
+void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s) {
+  const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
+  if (p.anyExtVariable)
+    hipLaunchKernelGGL(k_eval_all<true>, dim3(p.F + nR + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0, pri);
+  else
+    hipLaunchKernelGGL(k_eval_all<false>, dim3(p.F + nR + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0, pri);
 }
 
 // row i of the prior -> (reduced-system row, or -1) with the 3x3 rotation map applied on the fly
@@ -1341,9 +1349,9 @@ __device__ __forceinline__ int priorRowToReduced(const DeviceProblem& p, int row
   const int off = blockOff(p, B.kind, B.slot);
   return off < 0 ? -1 : off + (row - B.ord);
 }
-__global__ void k_prior_accumulate(DeviceProblem p) {
+__device__ void priorAccumulateBlock(const DeviceProblem& p, int block) {
   const int m = p.priorM;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = block * blockDim.x + threadIdx.x;
   if (idx >= m * m) return;
   const int i = idx / m, j = idx % m;
   const int ri = priorRowToReduced(p, i), rj = priorRowToReduced(p, j);
@@ -1367,6 +1375,8 @@ __global__ void k_prior_accumulate(DeviceProblem p) {
     atomicAdd(&p.gFull[ri], g);
   }
 }
+__global__ __launch_bounds__(256) void k_prior_accumulate(DeviceProblem p) { priorAccumulateBlock(p, blockIdx.x); }
+static int priorAccBlocks(const DeviceProblem& p) { return (p.priorM > 0 && p.ownsCamera) ? (p.priorM * p.priorM + 255) / 256 : 0; }
 // ================================================================ K5: normal equations + landmark Schur complement
 // generic small factors: J^T J into S (both triangles), J^T r into gRed/gFull, column norms into hC
 __device__ void factorsAccumulate(const DeviceProblem& p, int f, int* colRow) {
@@ -1401,13 +1411,16 @@ __device__ void factorsAccumulate(const DeviceProblem& p, int f, int* colRow) {
 
 constexpr int kStage = 34;  // doubles staged per observation: Jl 6, Jp 12, Je 12, offP, offE (as double), pad
 
-// Blocks [0, nSchurBlocks) run the landmark Schur complement; blocks beyond that accumulate one small factor each
-// (J^T J straight into S with atomics) so that the two independent parts of the build share one launch.
+// Blocks [0, nSchurBlocks) run the landmark Schur complement; the next nFacBlocks accumulate one small factor each
+// (J^T J straight into S with atomics), the rest the marginalisation prior (256 entries of M^T Ht M each), so that the
+// independent parts of the build share one launch.
 template <bool USE_LDS, bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int initScale, int nSchurBlocks) {
+__global__ __launch_bounds__(256) void k_schur(DeviceProblem p, double mu, int initScale, int nSchurBlocks, int nFacBlocks) {
   extern __shared__ double smem[];
   if ((int)blockIdx.x >= nSchurBlocks) {
-    factorsAccumulate(p, blockIdx.x - nSchurBlocks, reinterpret_cast<int*>(smem));
+    const int e = blockIdx.x - nSchurBlocks;
+    if (e < nFacBlocks) factorsAccumulate(p, e, reinterpret_cast<int*>(smem));
+    else priorAccumulateBlock(p, e - nFacBlocks);
     return;
   }
 #ifdef SVIN_SCHUR_TIMING
@@ -1657,11 +1670,13 @@ constexpr int kPoseAcc = 28;              // per pose: 21 (upper 6x6) + 6 (Jp^T 
 // index of (a, c), a <= c, in the packed upper triangle of a 6x6 block
 __device__ __forceinline__ int sym6(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
 
-__global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks) {
+__global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
   if (b >= nChunkBlocks) {
-    factorsAccumulate(p, b - nChunkBlocks, reinterpret_cast<int*>(smem));
+    const int e = b - nChunkBlocks;
+    if (e < nFacBlocks) factorsAccumulate(p, e, reinterpret_cast<int*>(smem));
+    else priorAccumulateBlock(p, e - nFacBlocks);
     return;
   }
   const size_t N = (size_t)p.N;
@@ -1912,9 +1927,10 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize_diag, dim3((p.d + 255) / 256), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
 }
-__global__ __launch_bounds__(256) void k_factors_only(DeviceProblem p) {
+__global__ __launch_bounds__(256) void k_factors_only(DeviceProblem p, int nFacBlocks) {
   __shared__ int colRow[30];
-  factorsAccumulate(p, blockIdx.x, colRow);
+  if ((int)blockIdx.x < nFacBlocks) factorsAccumulate(p, blockIdx.x, colRow);
+  else priorAccumulateBlock(p, blockIdx.x - nFacBlocks);
 }
 void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_build, dim3((p.d * p.d + 255) / 256), dim3(256), 0, s, p);
@@ -1925,11 +1941,12 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   const int dC = p.dC;
   if (zeroFirst) launchZeroBuild(p, s);
   const int nFac = (p.F > 0 && p.ownsCamera) ? p.F : 0;
+  const int nPri = priorAccBlocks(p);  // the prior rides along as extra blocks of the same launch
   if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
     const int rows = 16 * ((dC + 2 + 15) / 16);
     const size_t ldsBytes = ((size_t)rows * kDenseLd + (size_t)4 * (dC / 6) * kPoseAcc) * 8;
     (void)hipFuncSetAttribute((const void*)k_schur_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    hipLaunchKernelGGL(k_schur_dense, dim3(p.nSlabs + nFac), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs);
+    hipLaunchKernelGGL(k_schur_dense, dim3(p.nSlabs + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs, nFac);
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;
@@ -1940,8 +1957,8 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_schur<true, E>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                               (int)(accBytes + stageBytes));                                                        \
-    hipLaunchKernelGGL((k_schur<true, E>), dim3(grid + nFac), dim3(256), accBytes + stageBytes, s, p, mu,          \
-                       initScale ? 1 : 0, grid);                                                                    \
+    hipLaunchKernelGGL((k_schur<true, E>), dim3(grid + nFac + nPri), dim3(256), accBytes + stageBytes, s, p, mu,   \
+                       initScale ? 1 : 0, grid, nFac);                                                              \
   } while (0)
       if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
@@ -1953,18 +1970,14 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_schur<false, E>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                               (int)stageBytes);                                                                     \
-    hipLaunchKernelGGL((k_schur<false, E>), dim3(grid + nFac), dim3(256), stageBytes, s, q, mu, initScale ? 1 : 0, \
-                       grid);                                                                                       \
+    hipLaunchKernelGGL((k_schur<false, E>), dim3(grid + nFac + nPri), dim3(256), stageBytes, s, q, mu,             \
+                       initScale ? 1 : 0, grid, nFac);                                                              \
   } while (0)
       if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
     }
-  } else if (nFac > 0) {
-    hipLaunchKernelGGL(k_factors_only, dim3(nFac), dim3(256), 0, s, p);
-  }
-  if (p.priorM > 0 && p.ownsCamera) {
-    const int n = p.priorM * p.priorM;
-    hipLaunchKernelGGL(k_prior_accumulate, dim3((n + 255) / 256), dim3(256), 0, s, p);
+  } else if (nFac + nPri > 0) {
+    hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
   }
   if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;

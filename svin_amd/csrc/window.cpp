@@ -770,9 +770,8 @@ void Window::evaluateAll(bool cand, hipStream_t s) {
   prob_.mailboxSeq = ++mailboxSeq_;
   const int who = costSummedBy(prob_);
   if (canFuseEvaluation(prob_) && !getenv("SVIN_SPLIT_EVAL")) {
-    // one launch: the reprojection blocks run next to the (much longer) IMU factor blocks
-    launchEvalAll(prob_, cand, who == 1, s);
-    launchEvalPrior(prob_, cand, s, who == 2, (prob_.N + 255) / 256);
+    // one launch: the reprojection blocks and the prior run next to the (much longer) IMU factor blocks
+    launchEvalAll(prob_, cand, true, s);  // factor, reprojection and prior blocks; the last one sums the cost
     return;
   }
   launchEvalReproj(prob_, cand, true, s);
