@@ -574,26 +574,28 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     const uint64_t currentKfId = allLinearizedFrames.at(0);
     for (auto pit = landmarks_.begin(); pit != landmarks_.end();) {  // :671-766
       Landmark& lm = pit->second;
-      std::vector<uint64_t> residuals;
-      for (const Observation& o : lm.obs) residuals.push_back(o.resId);
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
       size_t obsCount = 0;
-      auto poseOf = [&](uint64_t rid) {
-        for (const Observation& o : lm.obs) if (o.resId == rid) return o.poseId;
-        return (uint64_t)0;
-      };
-      for (uint64_t rid : residuals) {
-        const uint64_t poseId = poseOf(rid);
+      // first pass straight over the observation list (no copies): most landmarks are skipped here
+      for (const Observation& o : lm.obs) {
+        const uint64_t poseId = o.poseId;
         if (contains(removeFrames, poseId)) skipLandmark = false;
         if (poseId >= currentKfId) { marginalize = false; hasNewObservations = true; }
         if (contains(allLinearizedFrames, poseId)) obsCount++;
       }
-      if (residuals.empty()) {
+      if (lm.obs.empty()) {
         removed.push_back(pit->first);
         pit = landmarks_.erase(pit);
         continue;
       }
       if (skipLandmark) { pit++; continue; }
+      std::vector<uint64_t> residuals;
+      residuals.reserve(lm.obs.size());
+      for (const Observation& o : lm.obs) residuals.push_back(o.resId);
+      auto poseOf = [&](uint64_t rid) {
+        for (const Observation& o : lm.obs) if (o.resId == rid) return o.poseId;
+        return (uint64_t)0;
+      };
       for (size_t r = 0; r < residuals.size(); ++r) {
         const uint64_t rid = residuals[r];
         const uint64_t poseId = poseOf(rid);

@@ -149,7 +149,7 @@ def test_reduced_system_parity(gpu_lib, rig):
     assert rel(gn, gc) < 1e-9
 
 
-@pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400)])
+@pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400), (12, 60, 1400), (3, 40, 200)])
 def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
     """The two landmark-elimination kernels (Gram-matrix form on MFMA for narrow windows, pairwise blocks for wide
     ones) must produce the same reduced system and the same optimisation result on a window both can handle."""
