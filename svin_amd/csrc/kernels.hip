@@ -1670,6 +1670,13 @@ constexpr int kPoseAcc = 28;              // per pose: 21 (upper 6x6) + 6 (Jp^T 
 // index of (a, c), a <= c, in the packed upper triangle of a 6x6 block
 __device__ __forceinline__ int sym6(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
 
+// MAXT: accumulator tiles per wave (9: up to 8 tile rows, dC <= 126; 34: up to 16 tile rows, dC <= 254).
+// A_MFMA: the A part goes through the same MFMA path as G (U = [.. Jc_o^T ..] in batches of obsBatch observations, two
+// columns each, U U^T added to the tiles; the augmented rows carry r) instead of per-wave block copies.  Required with
+// variable extrinsics (their Jacobians add rows to G, and A gets pose-extrinsics cross blocks) and used for the
+// 34-tile variant (the block-copy merge does not fit the register file next to 34 accumulator tiles).
+__host__ __device__ constexpr int denseObsBatch(int rows) { return rows <= 128 ? 32 : (rows <= 192 ? 16 : 8); }
+template <int MAXT, bool A_MFMA>
 __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
@@ -1680,22 +1687,82 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     return;
   }
   const size_t N = (size_t)p.N;
-  const int dC = p.dC, nP = dC / 6;          // reduced pose blocks (fixed extrinsics on this path)
+  const bool WITH_EXT = A_MFMA && p.anyExtVariable != 0;
+  const int dC = p.dC, nP = dC / 6;          // reduced 6-blocks (poses, then variable extrinsics)
   const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
+  const int obsBatch = denseObsBatch(rows), ldU = 2 * obsBatch + 1;
   double* Gt = smem;                          // rows x kDenseLd
-  double* Aw = smem + (size_t)rows * kDenseLd;  // 4 waves x nP x kPoseAcc
+  double* Aw = smem + (size_t)rows * kDenseLd;  // !A_MFMA: 4 waves x nP x kPoseAcc;  A_MFMA: U tile, rows x ldU
+  double* Ut = Aw;
+  const size_t extraLds = A_MFMA ? (size_t)rows * ldU : (size_t)4 * nP * kPoseAcc;
   const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
   double* Amine = Aw + (size_t)wave * nP * kPoseAcc;
   // accumulator tiles (I >= J) owned by this wave: tile index tl = wave, wave + 4, ...
-  constexpr int kMaxTiles = 9;                // nTr <= 8 -> 36 tiles over 4 waves
+  constexpr int kMaxTiles = MAXT;
   d4_t acc[kMaxTiles];
 #pragma unroll
   for (int k = 0; k < kMaxTiles; ++k) acc[k] = d4_t{0, 0, 0, 0};
   const int nTiles = nTr * (nTr + 1) / 2;
   double hcAcc = 0;                           // thread c < dC: column norm hC[c]
-  for (int i = t; i < rows * kDenseLd + 4 * nP * kPoseAcc; i += blockDim.x) smem[i] = 0.0;
+  for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
+  // acc(I,J) += sign * T_I T_J^T over nK4 steps of 4 columns of the LDS tile T (leading dimension ld)
+  auto rankUpdate = [&](const double* T, int ld, int nK4, double sign) {
+#pragma unroll
+    for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
+      const int tl = wave + 4 * k;
+      if (tl < nTiles) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+        const int J = tl - I * (I + 1) / 2;
+        const double* A = T + (size_t)(16 * I + (lane & 15)) * ld + (lane >> 4);
+        const double* B = T + (size_t)(16 * J + (lane & 15)) * ld + (lane >> 4);
+        d4_t c = acc[k];
+        for (int q = 0; q < nK4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * A[4 * q], B[4 * q], c, 0, 0, 0);
+        acc[k] = c;
+      }
+    }
+  };
   for (int chunk = b; chunk * kDenseLm < p.L; chunk += nChunkBlocks) {
+    if (A_MFMA) {
+      // ---- A part on MFMA: the chunk's observations are contiguous (landmark-major CSR); batches of obsBatch
+      const int l0 = chunk * kDenseLm, l1 = min(p.L, l0 + kDenseLm);
+      const int oBeg = p.lmPtr[l0], oEnd = p.lmPtr[l1];
+      for (int ob = oBeg; ob < oEnd; ob += obsBatch) {
+        const int nb = min(obsBatch, oEnd - ob);
+        // entry e = k * nb + j: component k (0..11 Jp, 12..23 Je, 24..25 r) of observation ob + j
+        auto forEntries = [&](bool clear) {
+          for (int e = t; e < 26 * nb; e += blockDim.x) {
+            const int k = e / nb, j = e - k * nb;
+            const size_t o = (size_t)ob + j;
+            const uint32_t idx = p.obsIdx[o];
+            if (k < 24) {
+              const bool isP = k < 12;
+              if (!isP && !WITH_EXT) continue;
+              const int kk = isP ? k : k - 12;
+              const int off = isP ? p.poseOff[idx & 0xfff] : p.extOff[(idx >> 12) & 0xfff];
+              if (off >= 0)
+                Ut[(size_t)(off + (kk % 6)) * ldU + 2 * j + kk / 6] = clear ? 0.0 : (isP ? p.JpCur : p.JeCur)[kk * N + o];
+            } else {
+              const double r = clear ? 0.0 : p.rCur[(k - 24) * N + o];
+              Ut[(size_t)dC * ldU + 2 * j + (k - 24)] = r;
+              Ut[(size_t)(dC + 1) * ldU + 2 * j + (k - 24)] = r;
+            }
+          }
+        };
+        forEntries(false);
+        __syncthreads();
+        if (t < dC) {  // column norms hC = diag(U U^T)
+          double s2 = 0;
+          for (int c = 0; c < 2 * nb; ++c) { const double u = Ut[(size_t)t * ldU + c]; s2 += u * u; }
+          hcAcc += s2;
+        }
+        rankUpdate(Ut, ldU, (2 * nb + 3) / 4, 1.0);
+        __syncthreads();
+        forEntries(true);  // clear exactly what was written
+        __syncthreads();
+      }
+    }
     const int l = chunk * kDenseLm + grp;
     if (l < p.L) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
@@ -1757,32 +1824,41 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       // there), and the pose block of A with Jp^T r into this wave's copy
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const int offP = p.poseOff[p.obsIdx[o] & 0xfff];
-        if (offP < 0) continue;
+        const uint32_t idx = p.obsIdx[o];
+        const int offP = p.poseOff[idx & 0xfff];
+        const int offE = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
+        if (offP < 0 && offE < 0) continue;
         const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
         const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
-        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
-        double jp[12];
+        // one 6-block of camera-side Jacobian: rows of G (and, with fixed extrinsics, the block of A + Jc^T r)
+        auto addBlock = [&](const double* J, int off) {
+          double jc[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) jp[k] = p.JpCur[k * N + o];
-        double* ap = Amine + (size_t)(offP / 6) * kPoseAcc;
+          for (int k = 0; k < 12; ++k) jc[k] = J[k * N + o];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double j0 = jp[a], j1 = jp[6 + a];
-          const double e0 = j0 * a0 + j1 * c0, e1 = j0 * a1 + j1 * c1, e2 = j0 * a2 + j1 * c2;
-          double* g = Gt + (size_t)(offP + a) * kDenseLd + 3 * grp;
-          atomicAdd(&g[0], e0 * i00);
-          atomicAdd(&g[1], e0 * i10 + e1 * i11);
-          atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
+          for (int a = 0; a < 6; ++a) {
+            const double j0 = jc[a], j1 = jc[6 + a];
+            const double e0 = j0 * a0 + j1 * c0, e1 = j0 * a1 + j1 * c1, e2 = j0 * a2 + j1 * c2;
+            double* g = Gt + (size_t)(off + a) * kDenseLd + 3 * grp;
+            atomicAdd(&g[0], e0 * i00);
+            atomicAdd(&g[1], e0 * i10 + e1 * i11);
+            atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
+            if (!A_MFMA) {
+              const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+              double* ap = Amine + (size_t)(off / 6) * kPoseAcc;
 #pragma unroll
-          for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jp[c] + j1 * jp[6 + c]);
-          atomicAdd(&ap[21 + a], j0 * r0 + j1 * r1);
-        }
+              for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jc[c] + j1 * jc[6 + c]);
+              atomicAdd(&ap[21 + a], j0 * r0 + j1 * r1);
+            }
+          }
+        };
+        if (offP >= 0) addBlock(p.JpCur, offP);
+        if (WITH_EXT && offE >= 0) addBlock(p.JeCur, offE);
       }
     }
     __syncthreads();
     // ---- acc(I,J) += A_chunk (pose-diagonal blocks, gradient rows), then acc(I,J) -= G_I G_J^T (12 k-steps)
-    if (t < dC) {
+    if (!A_MFMA && t < dC) {
       const int ps = t / 6, a = t % 6;
       double s = 0;
 #pragma unroll
@@ -1806,7 +1882,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
             if (r < dC) { if (r / 6 == ps) { const int a = r % 6, e = cc % 6; idx = sym6(min(a, e), max(a, e)); } }
             else if (r <= dC + 1) idx = 21 + cc % 6;
           }
-          if (idx >= 0) {
+          if (!A_MFMA && idx >= 0) {
             double s = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + idx];
@@ -1821,7 +1897,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       }
     }
     __syncthreads();
-    for (int i = t; i < rows * kDenseLd + 4 * nP * kPoseAcc; i += blockDim.x) smem[i] = 0.0;
+    for (int i = t; i < rows * kDenseLd + (A_MFMA ? 0 : 4 * nP * kPoseAcc); i += blockDim.x) smem[i] = 0.0;
     __syncthreads();
   }
   // ---- private slab: [S (dC x dC) | gRed | gFull | hC]
@@ -1943,10 +2019,22 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   const int nFac = (p.F > 0 && p.ownsCamera) ? p.F : 0;
   const int nPri = priorAccBlocks(p);  // the prior rides along as extra blocks of the same launch
   if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
-    const int rows = 16 * ((dC + 2 + 15) / 16);
-    const size_t ldsBytes = ((size_t)rows * kDenseLd + (size_t)4 * (dC / 6) * kPoseAcc) * 8;
-    (void)hipFuncSetAttribute((const void*)k_schur_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-    hipLaunchKernelGGL(k_schur_dense, dim3(p.nSlabs + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs, nFac);
+    const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
+    const bool aMfma = p.anyExtVariable || nTr > 8;
+    const size_t extra = aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc;
+    const size_t ldsBytes = ((size_t)rows * kDenseLd + extra) * 8;
+    const dim3 grid(p.nSlabs + nFac + nPri);
+#define LAUNCH(MAXT, E)                                                                                             \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)k_schur_dense<MAXT, E>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)ldsBytes);                                                                       \
+    hipLaunchKernelGGL((k_schur_dense<MAXT, E>), grid, dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs, \
+                       nFac);                                                                                       \
+  } while (0)
+    if (nTr > 8) LAUNCH(34, true);
+    else if (aMfma) LAUNCH(9, true);
+    else LAUNCH(9, false);
+#undef LAUNCH
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;

@@ -668,8 +668,9 @@ void Window::pack() {
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
   const bool useLds = slabSize * 8 + (size_t)4 * 64 * 34 * 8 <= 150 * 1024;
   int nSlabs = 1;
-  // narrow windows (<= ~20 poses, fixed extrinsics): dense Gram-matrix Schur complement on MFMA
-  const bool schurDense = !anyExtVar && dC > 0 && dC + 2 <= 128 && !getenv("SVIN_SCHUR_PAIRWISE");
+  // windows whose camera block fits 16 x 16 MFMA tiles (dC <= 254, e.g. 42 poses or 10 poses with per-frame extrinsics):
+  // dense Gram-matrix Schur complement on MFMA
+  const bool schurDense = dC > 0 && dC + 2 <= 256 && !getenv("SVIN_SCHUR_PAIRWISE");
   if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
   dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
