@@ -1925,6 +1925,224 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   }
 }
 
+// ---------------------------------------------------------------- Gram-matrix Schur complement for WIDE windows
+// dC > 254 rows do not fit one block's accumulator tiles, so the camera matrix is cut into panels of kPanelRows = 96
+// rows (16 pose blocks, 6 MFMA tile rows) and every workgroup owns one panel pair (I >= J) for a list of landmark
+// chunks whose observations touch both panels (host-built work list: in a sliding window a landmark is seen from a
+// few consecutive frames, so most chunks touch one or two panels).  Per chunk the block rebuilds V, b, L^-1 (cheap),
+// writes the rows of G that fall into panel I and panel J into two LDS tiles and subtracts G_I G_J^T on MFMA; diagonal
+// pairs also add the 6x6 pose blocks of A (per-wave LDS copies) and collect the gradient / column-norm vectors.  One
+// slab (96 x 96 + 3 x 96) per workgroup, summed per pair by k_reduce_panel_slabs.  Fixed extrinsics only (wide
+// windows with variable extrinsics keep the pairwise kernel).
+constexpr int kPanelRows = 96;
+constexpr int kPanelSlab = kPanelRows * kPanelRows + 3 * kPanelRows;
+constexpr int kPanelChunksPerBlock = 8;
+
+__global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu, int initScale, int nWorkBlocks, int nFacBlocks) {
+  extern __shared__ double smem[];
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (b >= nWorkBlocks) {
+    const int e = b - nWorkBlocks;
+    if (e < nFacBlocks) factorsAccumulate(p, e, reinterpret_cast<int*>(smem));
+    else priorAccumulateBlock(p, e - nFacBlocks);
+    return;
+  }
+  const int4 work = p.panelWork[b];  // x = I, y = J, z = first entry of panelChunks, w = number of chunks
+  const int pI = work.x, pJ = work.y;
+  const bool diag = pI == pJ;
+  const int r0I = kPanelRows * pI, r0J = kPanelRows * pJ;
+  const size_t N = (size_t)p.N;
+  constexpr int nPB = kPanelRows / 6;              // pose blocks per panel
+  double* GtI = smem;                               // kPanelRows x kDenseLd
+  double* GtJ = diag ? GtI : smem + (size_t)kPanelRows * kDenseLd;
+  double* Aw = smem + (size_t)2 * kPanelRows * kDenseLd;   // 4 waves x nPB x kPoseAcc (diagonal pairs)
+  double* cvec = Aw + (size_t)4 * nPB * kPoseAcc;           // kDenseK: c_l = L_l^-1 b_l of the chunk's landmarks
+  const int ldsDoubles = 2 * kPanelRows * kDenseLd + 4 * nPB * kPoseAcc + kDenseK;
+  const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
+  double* Amine = Aw + (size_t)wave * nPB * kPoseAcc;
+  constexpr int kMaxTiles = 9;                      // 6 x 6 tiles over 4 waves
+  d4_t acc[kMaxTiles];
+#pragma unroll
+  for (int k = 0; k < kMaxTiles; ++k) acc[k] = d4_t{0, 0, 0, 0};
+  double gRedAcc = 0, gFullAcc = 0, hcAcc = 0;      // thread r < kPanelRows (diagonal pairs)
+  for (int i = t; i < ldsDoubles; i += blockDim.x) smem[i] = 0.0;
+  __syncthreads();
+  for (int ci = 0; ci < work.w; ++ci) {
+    const int chunk = p.panelChunks[work.z + ci];
+    const int l = chunk * kDenseLm + grp;
+    if (l < p.L) {
+      const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
+      for (int i = gl; i < n; i += 16) {
+        const size_t o = (size_t)start + i;
+        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
+        v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
+        b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        v00 += __shfl_xor(v00, o, 16); v01 += __shfl_xor(v01, o, 16); v02 += __shfl_xor(v02, o, 16);
+        v11 += __shfl_xor(v11, o, 16); v12 += __shfl_xor(v12, o, 16); v22 += __shfl_xor(v22, o, 16);
+        b0 += __shfl_xor(b0, o, 16); b1 += __shfl_xor(b1, o, 16); b2 += __shfl_xor(b2, o, 16);
+      }
+      double sc0, sc1, sc2;
+      if (initScale) {
+        sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
+        if (gl == 0) { p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2; }
+      } else {
+        sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2];
+      }
+      const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
+      const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
+      const double ht2 = fmin(fmax(v22 * sc2 * sc2, 1e-6), 1e32) / (sc2 * sc2);
+      const double d00 = v00 + mu * ht0, d11 = v11 + mu * ht1, d22 = v22 + mu * ht2;
+      bool bad = !(d00 > 0);
+      const double i00 = rsqrtNewton(bad ? 1.0 : d00);
+      const double l10 = v01 * i00, l20 = v02 * i00;
+      const double t11 = d11 - l10 * l10;
+      bad = bad || !(t11 > 0);
+      const double i11 = rsqrtNewton(t11 > 0 ? t11 : 1.0);
+      const double l21 = (v12 - l20 * l10) * i11;
+      const double t22 = d22 - l20 * l20 - l21 * l21;
+      bad = bad || !(t22 > 0);
+      const double i22 = rsqrtNewton(t22 > 0 ? t22 : 1.0);
+      const double i10 = -l10 * i00 * i11;
+      const double i21 = -l21 * i11 * i22;
+      const double i20 = -(l20 * i00 + l21 * i10) * i22;
+      if (gl == 0) {
+        // every pair that sees this chunk computes the same per-landmark quantities; all of them store (same values)
+        if (bad) atomicOr(&p.scal->cholFail, 1);
+        double* vi = p.Vinv + 6 * (size_t)l;
+        vi[0] = i00 * i00 + i10 * i10 + i20 * i20; vi[1] = i10 * i11 + i20 * i21; vi[2] = i20 * i22;
+        vi[3] = i11 * i11 + i21 * i21; vi[4] = i21 * i22; vi[5] = i22 * i22;
+        p.bl[3 * l] = b0; p.bl[3 * l + 1] = b1; p.bl[3 * l + 2] = b2;
+        p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
+        double* cr = cvec + 3 * grp;
+        cr[0] = i00 * b0; cr[1] = i10 * b0 + i11 * b1; cr[2] = i20 * b0 + i21 * b1 + i22 * b2;
+      }
+      for (int i = gl; i < n; i += 16) {
+        const size_t o = (size_t)start + i;
+        const int offP = p.poseOff[p.obsIdx[o] & 0xfff];
+        if (offP < 0) continue;
+        const bool inI = offP >= r0I && offP < r0I + kPanelRows;
+        const bool inJ = !diag && offP >= r0J && offP < r0J + kPanelRows;
+        if (!inI && !inJ) continue;
+        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        double jc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) jc[k] = p.JpCur[k * N + o];
+        double* Gt = inI ? GtI : GtJ;
+        const int rl = offP - (inI ? r0I : r0J);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double j0 = jc[a], j1 = jc[6 + a];
+          const double e0 = j0 * a0 + j1 * c0, e1 = j0 * a1 + j1 * c1, e2 = j0 * a2 + j1 * c2;
+          double* g = Gt + (size_t)(rl + a) * kDenseLd + 3 * grp;
+          atomicAdd(&g[0], e0 * i00);
+          atomicAdd(&g[1], e0 * i10 + e1 * i11);
+          atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
+          if (diag) {
+            const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+            double* ap = Amine + (size_t)(rl / 6) * kPoseAcc;
+#pragma unroll
+            for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jc[c] + j1 * jc[6 + c]);
+            atomicAdd(&ap[21 + a], j0 * r0 + j1 * r1);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (diag && t < kPanelRows) {  // gradient and column norms of this panel's rows
+      const int ps = t / 6, a = t % 6;
+      double hc = 0, gf = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        hc += Aw[((size_t)w * nPB + ps) * kPoseAcc + sym6(a, a)];
+        gf += Aw[((size_t)w * nPB + ps) * kPoseAcc + 21 + a];
+      }
+      double gc = 0;
+      for (int k = 0; k < kDenseK; ++k) gc += GtI[(size_t)t * kDenseLd + k] * cvec[k];
+      hcAcc += hc; gFullAcc += gf; gRedAcc += gf - gc;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxTiles; ++k) {
+      const int tl = wave + 4 * k;           // 36 tiles: tile row ti (panel I), tile column tj (panel J)
+      const int ti = tl / 6, tj = tl % 6;
+      d4_t c = acc[k];
+      if (diag) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * ti + (lane >> 4) + 4 * rg, cc = 16 * tj + (lane & 15);
+          if (r / 6 == cc / 6) {
+            const int a = r % 6, e = cc % 6, idx = sym6(min(a, e), max(a, e)), ps = cc / 6;
+            double s = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nPB + ps) * kPoseAcc + idx];
+            c[rg] += s;
+          }
+        }
+      }
+      const double* A = GtI + (size_t)(16 * ti + (lane & 15)) * kDenseLd + (lane >> 4);
+      const double* B = GtJ + (size_t)(16 * tj + (lane & 15)) * kDenseLd + (lane >> 4);
+#pragma unroll
+      for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
+      acc[k] = c;
+    }
+    __syncthreads();
+    for (int i = t; i < ldsDoubles; i += blockDim.x) smem[i] = 0.0;
+    __syncthreads();
+  }
+  double* slab = p.slabs + (size_t)b * kPanelSlab;
+#pragma unroll
+  for (int k = 0; k < kMaxTiles; ++k) {
+    const int tl = wave + 4 * k, ti = tl / 6, tj = tl % 6;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) slab[(size_t)(16 * ti + (lane >> 4) + 4 * rg) * kPanelRows + 16 * tj + (lane & 15)] = acc[k][rg];
+  }
+  if (t < kPanelRows) {
+    double* v = slab + kPanelRows * kPanelRows;
+    v[t] = gRedAcc; v[kPanelRows + t] = gFullAcc; v[2 * kPanelRows + t] = hcAcc;
+  }
+}
+
+// sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors
+__global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
+  const int pair = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kPanelSlab) return;
+  const int b0 = p.panelPairPtr[pair], b1 = p.panelPairPtr[pair + 1];
+  if (b0 == b1) return;
+  const int pI = p.panelWork[b0].x, pJ = p.panelWork[b0].y;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = b0;
+  for (; k + 3 < b1; k += 4) {
+    s0 += p.slabs[(size_t)k * kPanelSlab + e];
+    s1 += p.slabs[(size_t)(k + 1) * kPanelSlab + e];
+    s2 += p.slabs[(size_t)(k + 2) * kPanelSlab + e];
+    s3 += p.slabs[(size_t)(k + 3) * kPanelSlab + e];
+  }
+  for (; k < b1; ++k) s0 += p.slabs[(size_t)k * kPanelSlab + e];
+  const double s = (s0 + s1) + (s2 + s3);
+  if (e < kPanelRows * kPanelRows) {
+    const int r = kPanelRows * pI + e / kPanelRows, c = kPanelRows * pJ + e % kPanelRows;
+    if (r < p.dC && c < p.dC) {
+      p.S[(size_t)r * p.d + c] += s;
+      if (pI != pJ) p.S[(size_t)c * p.d + r] += s;
+    }
+  } else if (pI == pJ) {
+    const int v = e - kPanelRows * kPanelRows, which = v / kPanelRows, r = kPanelRows * pI + v % kPanelRows;
+    if (r < p.dC) {
+      if (which == 0) p.gRed[r] += s;
+      else if (which == 1) p.gFull[r] += s;
+      else p.hC[r] += s;
+    }
+  }
+}
+
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
 // 16 entries x 16 slab-partitions per 256-thread block; fixed summation order -> deterministic
 constexpr int kSlabParts = 16;
@@ -2035,6 +2253,13 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     else if (aMfma) LAUNCH(9, true);
     else LAUNCH(9, false);
 #undef LAUNCH
+  } else if (p.L > 0 && p.N > 0 && dC > 0 && p.schurPanels) {
+    const size_t ldsBytes = ((size_t)2 * kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc + kDenseK) * 8;
+    (void)hipFuncSetAttribute((const void*)k_schur_panels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipLaunchKernelGGL(k_schur_panels, dim3(p.nPanelBlocks + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0,
+                       p.nPanelBlocks, nFac);
+    hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 255) / 256, p.nPanelPairs), dim3(256), 0, s, p);
+    return;
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
     const size_t stageBytes = (size_t)4 * 64 * kStage * 8;

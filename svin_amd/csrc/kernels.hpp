@@ -112,6 +112,10 @@ struct DeviceProblem {
   // observations
   int* lmPtr;
   int schurDense;                            // narrow window: Schur complement as a Gram matrix on MFMA
+  int schurPanels, nPanelBlocks, nPanelPairs;  // wide window: the same per 96-row panel pair (k_schur_panels)
+  const int4* panelWork;                     // per workgroup: panel I, panel J, first chunk entry, chunk count
+  const int* panelChunks;                    // chunk ids (16 landmarks each) of the work list
+  const int* panelPairPtr;                   // per panel pair: first workgroup (nPanelPairs + 1 entries)
   double *obsUv, *obsW;
   uint32_t* obsIdx;
   int* obsLm;

@@ -2,6 +2,7 @@
 // /root/reference/okvis_ros/okvis/okvis_ceres/src/Estimator.cpp unless another file is named.
 #include "window.hpp"
 #include <atomic>
+#include <cstdint>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -575,12 +576,28 @@ void Window::pack() {
     }
   };
   const SlotCache poseCache(poseSlot_), extCache(extSlot_);
+  // landmark order of the CSR: id order; for wide windows sorted by the first pose that observes the landmark, so that
+  // a chunk of 16 consecutive landmarks touches few 96-row panels of the camera matrix (k_schur_panels work list)
+  std::vector<const Landmark*> lmOrder;
+  lmOrder.reserve(nLmObs);
+  for (const auto& kv : landmarks_)
+    if (!kv.second.obs.empty()) lmOrder.push_back(&kv.second);
+  if (poseIds_.size() > 42) {
+    std::vector<std::pair<int, const Landmark*>> keyed;
+    keyed.reserve(lmOrder.size());
+    for (const Landmark* lm : lmOrder) {
+      int first = INT32_MAX;
+      for (const Observation& ob : lm->obs) first = std::min(first, poseCache.at(ob.poseId));
+      keyed.emplace_back(first, lm);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t i = 0; i < keyed.size(); ++i) lmOrder[i] = keyed[i].second;
+  }
   {
     size_t slot = 0, o = 0;
     hLmPtr[0] = 0;
-    for (const auto& kv : landmarks_) {
-      const Landmark& lm = kv.second;
-      if (lm.obs.empty()) continue;
+    for (const Landmark* lmp : lmOrder) {
+      const Landmark& lm = *lmp;
       lmIds_[slot] = lm.id;
       std::memcpy(&hLm[4 * slot], lm.hp, 4 * sizeof(double));
       for (const Observation& ob : lm.obs) {
@@ -673,7 +690,47 @@ void Window::pack() {
   const bool schurDense = dC > 0 && dC + 2 <= 256 && !getenv("SVIN_SCHUR_PAIRWISE");
   if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
-  dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
+  // wide windows with fixed extrinsics: Gram-matrix Schur complement per pair of 96-row panels (k_schur_panels).
+  // Work list: every chunk of 16 landmarks goes to all panel pairs (I >= J) inside the row range its observations touch.
+  const bool schurPanels = !schurDense && !anyExtVar && dC > 0 && L > 0 && !getenv("SVIN_SCHUR_PAIRWISE");
+  std::vector<int> hPanelWork, hPanelChunks, hPanelPairPtr;
+  int nPanelBlocks = 0, nPanelPairs = 0;
+  if (schurPanels) {
+    constexpr int kRows = 96, kChunk = 16, kPerBlock = 8;
+    const int nPan = (dC + kRows - 1) / kRows;
+    nPanelPairs = nPan * (nPan + 1) / 2;
+    std::vector<std::vector<int>> lists(nPanelPairs);
+    const int nChunks = (L + kChunk - 1) / kChunk;
+    for (int c = 0; c < nChunks; ++c) {
+      int lo = INT32_MAX, hi = -1;
+      const int o0 = hLmPtr[c * kChunk], o1 = hLmPtr[std::min(L, (c + 1) * kChunk)];
+      for (int o = o0; o < o1; ++o) {
+        const int off = hPoseOff[hIdx[o] & 0xfff];
+        if (off < 0) continue;
+        lo = std::min(lo, off); hi = std::max(hi, off);
+      }
+      // a chunk without variable poses still has to produce V^-1, b, htil for its landmarks: give it to pair (0, 0)
+      const int pLo = hi < 0 ? 0 : lo / kRows, pHi = hi < 0 ? 0 : hi / kRows;
+      for (int I = pLo; I <= pHi; ++I)
+        for (int J = pLo; J <= I; ++J) lists[I * (I + 1) / 2 + J].push_back(c);
+    }
+    hPanelPairPtr.push_back(0);
+    for (int I = 0; I < nPan; ++I)
+      for (int J = 0; J <= I; ++J) {
+        const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
+        for (size_t k = 0; k < li.size(); k += kPerBlock) {
+          const int cnt = (int)std::min<size_t>(kPerBlock, li.size() - k);
+          hPanelWork.insert(hPanelWork.end(), {I, J, (int)hPanelChunks.size(), cnt});
+          hPanelChunks.insert(hPanelChunks.end(), li.begin() + k, li.begin() + k + cnt);
+          ++nPanelBlocks;
+        }
+        hPanelPairPtr.push_back(nPanelBlocks);
+      }
+    upload(dPanelWork_, hPanelWork, s); upload(dPanelChunks_, hPanelChunks, s); upload(dPanelPairPtr_, hPanelPairPtr, s);
+    dSlabs_.reserve(std::max<size_t>((size_t)nPanelBlocks * (kRows * kRows + 3 * kRows), 1));
+  } else {
+    dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
+  }
 
   DeviceProblem& p = prob_;
   std::memset(&p, 0, sizeof(p));
@@ -686,6 +743,8 @@ void Window::pack() {
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;
   p.schurDense = schurDense ? 1 : 0;
+  p.schurPanels = schurPanels ? 1 : 0; p.nPanelBlocks = nPanelBlocks; p.nPanelPairs = nPanelPairs;
+  p.panelWork = reinterpret_cast<const int4*>(dPanelWork_.p); p.panelChunks = dPanelChunks_.p; p.panelPairPtr = dPanelPairPtr_.p;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
   curSet_ = 0;
   auto setLin = [&](int set, double*& r, double*& Jp, double*& Jl, double*& Je) {
@@ -960,18 +1019,20 @@ int Window::setOptimizationTimeLimit(double timeLimit, int minIter) {  // :932-9
 int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t* cam, int cap) {
   pack();
   HIP_OK(hipStreamSynchronize(stream_));
-  // same order as pack(): landmarks with observations in id order, observations in insertion order
+  // same order as pack(): landmarks in CSR order (lmIds_), observations in insertion order
   int n = 0;
-  for (const auto& kv : landmarks_)
-    for (const Observation& o : kv.second.obs) {
+  for (uint64_t id : lmIds_) {
+    const Landmark& l = landmarks_.at(id);
+    for (const Observation& o : l.obs) {
       if (n < cap) {
         if (rid) rid[n] = o.resId;
-        if (lm) lm[n] = kv.second.id;
+        if (lm) lm[n] = l.id;
         if (pose) pose[n] = o.poseId;
         if (cam) cam[n] = o.cam;
       }
       ++n;
     }
+  }
   return n;
 }
 int Window::evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap) {

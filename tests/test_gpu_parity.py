@@ -149,10 +149,12 @@ def test_reduced_system_parity(gpu_lib, rig):
     assert rel(gn, gc) < 1e-9
 
 
-@pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400), (12, 60, 1400), (3, 40, 200)])
+@pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400), (12, 60, 1400), (3, 40, 200),
+                                        (48, 900, 9000), (70, 1500, 12000)])  # last two: panel-pair kernel (dC = 288 / 420)
 def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
-    """The two landmark-elimination kernels (Gram-matrix form on MFMA for narrow windows, pairwise blocks for wide
-    ones) must produce the same reduced system and the same optimisation result on a window both can handle."""
+    """The landmark-elimination kernels (Gram-matrix form on MFMA: one block for narrow windows, 96-row panel pairs for
+    wide ones; pairwise blocks as the general fallback) must produce the same reduced system and the same optimisation
+    result on a window both can handle."""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=P, L=L, n_obs=n_obs, seed=5, rig="euroc")
     out = {}
