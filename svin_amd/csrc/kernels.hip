@@ -2703,6 +2703,249 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
   for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
 }
 
+// ================================================================ K6': reduced systems beyond the LDS-resident solver
+// Blocked right-looking Cholesky with 64-wide panels over several workgroups (d > 176, e.g. per-frame extrinsics or
+// wide windows).  The right-hand side rides along as one extra row block below the matrix, so the forward
+// substitution falls out of the panel solves; per panel two launches:
+//   k_big_panel  every workgroup factorises the 64x64 diagonal block redundantly in LDS (4x4 tiles, the register
+//                routine on the diagonal tiles, MFMA for the rest) and solves its own 64-row slab of the panel
+//                X = A L^-T with MFMA (block forward substitution over the four tile columns);
+//   k_big_syrk   one workgroup per 64x64 block of the trailing matrix: C -= X_I X_J^T on MFMA.
+// k_big_back finishes with the backward substitution in one workgroup.
+constexpr int kNB = 64;
+constexpr int kBigTileLd = kPanelLd;                 // 16 x 17 LDS tiles
+constexpr int kBigBlockLds = 16 * 16 * kBigTileLd;   // a 64x64 block as 4x4 tiles
+
+// global (row-major, leading dimension ld) 64x64 block -> 4x4 LDS tiles and back; 256 threads
+__device__ __forceinline__ void loadBlock64(const double* g, int ld, double* tiles) {
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)] = g[(size_t)r * ld + c];
+  }
+}
+__device__ __forceinline__ void storeBlock64(double* g, int ld, const double* tiles) {
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    g[(size_t)r * ld + c] = tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)];
+  }
+}
+// in-LDS factorisation of a 64x64 SPD block (4x4 tiles, diagonal tiles fully symmetric) by 4 waves:
+// lower tiles <- L, strict upper triangle of the diagonal tiles <- L_tt^-T, dinv <- 1/L_ii
+__device__ void factor64(double* T, double* dinv, int* failFlag) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto tile = [&](int I, int J) { return T + (I * 4 + J) * (16 * kBigTileLd); };
+  for (int kb = 0; kb < 4; ++kb) {
+    if (wave == 0) cholDiag16Reg(tile(kb, kb), dinv + 16 * kb, lane, failFlag);
+    __syncthreads();
+    const double* D = tile(kb, kb);
+    {  // panel: X = A L^-T for the tiles below (one per wave)
+      const int ti = kb + 1 + wave;
+      if (ti < 4) {
+        double* A = tile(ti, kb);
+        d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = 4 * q + (lane >> 4), jj = lane & 15;
+          const double a = A[(lane & 15) * kBigTileLd + kk];
+          const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * kb + kk] : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) A[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
+      }
+    }
+    __syncthreads();
+    // trailing tiles (I, J), kb < J <= I < 4 (both triangles of the diagonal tiles: MFMA computes the full tile)
+    int cnt = 0;
+    for (int I = kb + 1; I < 4; ++I)
+      for (int J = kb + 1; J <= I; ++J, ++cnt) {
+        if ((cnt & 3) != wave) continue;
+        double* Cb = tile(I, J);
+        const double* A = tile(I, kb);
+        const double* B = tile(J, kb);
+        d4_t acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                     B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
+      }
+    __syncthreads();
+  }
+}
+
+// M = p.cholL: (dpad + kNB) x dpad row-major; rows [dpad, dpad + kNB) hold the right-hand side in their first row
+__global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize) {
+  const int d = p.d;
+  const size_t total = (size_t)(dpad + kNB) * dpad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx / dpad), gj = (int)(idx - (size_t)gi * dpad);
+    double x = 0.0;
+    if (gi < dpad) {
+      x = (gi == gj) ? 1.0 : 0.0;
+      if (gi < d && gj < d) {
+        x = p.S[(size_t)max(gi, gj) * d + min(gi, gj)];
+        if (gi == gj && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
+      }
+    } else if (gi == dpad && gj < d) {
+      x = p.gRed[gj];
+    }
+    p.cholL[idx] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_big_panel(DeviceProblem p, int dpad, int k0, double* dinvG, double* diagF) {
+  extern __shared__ double smem[];
+  double* Dt = smem;                         // diagonal block, 16 tiles
+  double* At = smem + kBigBlockLds;          // this workgroup's slab, 16 tiles
+  double* dinv = At + kBigBlockLds;          // 64
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* M = p.cholL;
+  loadBlock64(M + (size_t)k0 * dpad + k0, dpad, Dt);
+  const int r0 = k0 + kNB + kNB * (int)blockIdx.x;   // first row of the slab
+  const bool hasSlab = r0 < dpad + kNB;
+  if (hasSlab) loadBlock64(M + (size_t)r0 * dpad + k0, dpad, At);
+  __syncthreads();
+  factor64(Dt, dinv, &p.scal->cholFail);
+  if (blockIdx.x == 0) {   // the factor itself: L below / L_tt^-T above the diagonal of the diagonal tiles, 1/L_ii.
+    // It goes to its own buffer: the other workgroups may still be loading the unfactorised block from M.
+    storeBlock64(diagF + (size_t)k0 * kNB, kNB, Dt);
+    if (threadIdx.x < kNB) dinvG[k0 + threadIdx.x] = dinv[threadIdx.x];
+  }
+  if (!hasSlab) return;
+  // X = A L^-T: wave w owns row tile w; block forward substitution over the tile columns j
+  auto dt = [&](int I, int J) { return Dt + (I * 4 + J) * (16 * kBigTileLd); };
+  auto at = [&](int I, int J) { return At + (I * 4 + J) * (16 * kBigTileLd); };
+  for (int j = 0; j < 4; ++j) {
+    double* X = at(wave, j);
+    d4_t acc;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[rg] = X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
+    for (int i = 0; i < j; ++i) {
+      const double* Xi = at(wave, i);
+      const double* Lji = dt(j, i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                   Lji[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
+    waveSync();
+    const double* D = dt(j, j);
+    d4_t out = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 4 * q + (lane >> 4), jj = lane & 15;
+      const double a = X[(lane & 15) * kBigTileLd + kk];
+      const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * j + kk] : 0.0);
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, out, 0, 0, 0);
+    }
+    waveSync();
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = out[rg];
+    waveSync();
+  }
+  __syncthreads();
+  storeBlock64(M + (size_t)r0 * dpad + k0, dpad, At);
+}
+
+// trailing update: block (bi, bj), bi >= bj, of the rows / columns behind panel k0 (the right-hand-side row block is
+// the last bi; it has no columns of its own)
+__global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int k0) {
+  extern __shared__ double smem[];
+  double* Xi = smem;
+  double* Xj = smem + kBigBlockLds;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nCol = (dpad - k0 - kNB) / kNB;          // column blocks behind the panel
+  // blockIdx.x -> (bi, bj): bj < nCol, bj <= bi <= nCol (bi == nCol is the rhs row block)
+  int bj = 0, rem = blockIdx.x;
+  while (rem >= nCol + 1 - bj) { rem -= nCol + 1 - bj; ++bj; }
+  const int bi = bj + rem;
+  double* M = p.cholL;
+  const int ri = k0 + kNB + kNB * bi, rj = k0 + kNB + kNB * bj;
+  loadBlock64(M + (size_t)ri * dpad + k0, dpad, Xi);
+  if (bi != bj) loadBlock64(M + (size_t)rj * dpad + k0, dpad, Xj);
+  __syncthreads();
+  const double* XJ = (bi == bj) ? Xi : Xj;
+  for (int tj = 0; tj < 4; ++tj) {   // wave owns row tile `wave` of the 64x64 output block
+    double* C = M + (size_t)(ri + 16 * wave) * dpad + rj + 16 * tj;
+    d4_t acc;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[rg] = C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const double* A = Xi + (wave * 4 + kt) * (16 * kBigTileLd);
+      const double* B = XJ + (tj * 4 + kt) * (16 * kBigTileLd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                   B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)] = acc[rg];
+  }
+}
+
+// backward substitution L^T y = y' (y' = first row of the right-hand-side block), one workgroup
+__global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, const double* dinvG, const double* diagF) {
+  extern __shared__ double smem[];
+  double* y = smem;                 // dpad
+  double* part = smem + dpad;       // 8 x 64 partial sums
+  const int t = threadIdx.x, d = p.d;
+  const double* M = p.cholL;
+  for (int i = t; i < dpad; i += blockDim.x) y[i] = M[(size_t)dpad * dpad + i];
+  __syncthreads();
+  for (int k0 = dpad - kNB; k0 >= 0; k0 -= kNB) {
+    // s_c = sum_{i >= k0 + 64} L[i][k0 + c] y[i]: 8 row stripes x 64 columns
+    {
+      const int c = t & 63, stripe = t >> 6;
+      double s = 0;
+      for (int i = k0 + kNB + stripe; i < dpad; i += 8) s += M[(size_t)i * dpad + k0 + c] * y[i];
+      part[stripe * 64 + c] = s;
+    }
+    __syncthreads();
+    if (t < kNB) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += part[k * 64 + t];
+      y[k0 + t] -= s;
+    }
+    __syncthreads();
+    // 64x64 triangular solve L_kk^T y_k = rhs with the stored tile inverses, tile by tile from the last
+    if (t < 64) {
+      const int lane = t;
+      for (int tt = 3; tt >= 0; --tt) {
+        const int b0 = k0 + 16 * tt;
+        const int li = lane & 15;
+        // y_t = L_tt^-T rhs_t : (L^-T)[li][r] = Linv[r][li], stored at tile(tt,tt)[li][r] for r > li
+        double yv = y[b0 + li] * dinvG[b0 + li];
+        const double* F = diagF + (size_t)k0 * kNB;   // this panel's 64x64 factor block, row-major
+        for (int r = 1; r < 16; ++r) {
+          const double term = F[(size_t)(16 * tt + li) * kNB + 16 * tt + r] * y[b0 + r];
+          yv += (r > li) ? term : 0.0;
+        }
+        waveSync();
+        if (lane < 16) y[b0 + lane] = yv;
+        waveSync();
+        // remove this tile's contribution from the earlier tiles of the panel: rhs_u -= L[b0 + k][u] y[b0 + k]
+        for (int u = lane; u < 16 * tt; u += 64) {
+          double s = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) s += F[(size_t)(16 * tt + k) * kNB + u] * y[b0 + k];
+          y[k0 + u] -= s;
+        }
+        waveSync();
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < d; i += blockDim.x) { p.yC[i] = y[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }
+}
+
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
@@ -2712,9 +2955,27 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
                        fuseFinalize ? 1 : 0);
   } else {
-    const size_t smem = (size_t)(16 * kPanelLd + (size_t)max(dpad, 16) * kPanelLd) * 8;
-    (void)hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), smem, s, p, dpad, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
+    // multi-workgroup blocked factorisation, 64-wide panels; p.cholL holds (dpad64 + 64) x dpad64 doubles, its tail
+    // the 1/L_ii vector
+    const int dp = ((p.d + kNB - 1) / kNB) * kNB;
+    double* dinvG = p.cholL + (size_t)(dp + kNB) * dp;
+    double* diagF = dinvG + dp;   // per panel the factorised 64x64 diagonal block (dp x 64)
+    const size_t ldsPanel = ((size_t)2 * kBigBlockLds + kNB) * 8, ldsSyrk = (size_t)2 * kBigBlockLds * 8;
+    (void)hipFuncSetAttribute((const void*)k_big_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsPanel);
+    (void)hipFuncSetAttribute((const void*)k_big_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSyrk);
+    hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
+    for (int k0 = 0; k0 < dp; k0 += kNB) {
+      const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included
+      hipLaunchKernelGGL(k_big_panel, dim3(nRowBlocks), dim3(256), ldsPanel, s, p, dp, k0, dinvG, diagF);
+      const int nCol = (dp - k0 - kNB) / kNB;
+      if (nCol > 0) {
+        const int nBlocks = nCol * (nCol + 1) / 2 + nCol;   // lower-triangular blocks + the rhs row block
+        hipLaunchKernelGGL(k_big_syrk, dim3(nBlocks), dim3(256), ldsSyrk, s, p, dp, k0);
+      }
+    }
+    const size_t ldsBack = ((size_t)dp + 8 * 64) * 8;
+    (void)hipFuncSetAttribute((const void*)k_big_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
+    hipLaunchKernelGGL(k_big_back, dim3(1), dim3(512), ldsBack, s, p, dp, (const double*)dinvG, (const double*)diagF);
   }
 }
 

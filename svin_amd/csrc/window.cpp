@@ -678,7 +678,10 @@ void Window::pack() {
   // S and the camera-side vectors share one allocation: [S | gRed | gFull | hC | ...] is all-reduced as one message
   dS_.reserve((size_t)d * d + (size_t)12 * std::max(d, 1) + 64);
   dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
-  dChol_.reserve(std::max<size_t>((size_t)dpad * dpad, 1));
+  {
+    const size_t dp64 = ((size_t)d + 63) / 64 * 64;  // multi-workgroup solver: (dp64 + 64) x dp64 matrix + 1/L_ii + diagonal factors
+    dChol_.reserve(std::max<size_t>(std::max((size_t)dpad * dpad, (dp64 + 64) * dp64 + dp64 + dp64 * 64), 1));
+  }
   dPartial_.reserve((size_t)16 * 4096);
   dScal_.reserve(1);
   dQuality_.reserve(std::max(L, 1));
