@@ -65,20 +65,7 @@ def _bind(L):
     sig("orc_pg_cost", C.c_double, vp)
     sig("orc_pg_linearize", None, vp, pd, pd)
     sig("orc_pg_ypr", None, pd, pd)
-    # pose graph (orc_posegraph.cpp)
-    sig("orc_pg_create", vp, i32, i32)
-    sig("orc_pg_destroy", None, vp)
-    sig("orc_pg_set_envelope", None, vp, i32)
-    sig("orc_pg_add_keyframe", None, vp, i32, i32, pd, pd, i32, pd, pd, C.c_double)
-    sig("orc_pg_optimize", i32, vp, i32, i32, pd)
-    sig("orc_pg_num_keyframes", i32, vp)
-    sig("orc_pg_get_pose", None, vp, i32, pd, pd)
-    sig("orc_pg_build", i32, vp, i32, i32, pi32, pi32)
-    sig("orc_pg_eval_edge", None, vp, i32, pi32, pi32, pi32, pd, pd, pd)
-    sig("orc_pg_perturb_node", None, vp, i32, pd)
-    sig("orc_pg_cost", C.c_double, vp)
-    sig("orc_pg_linearize", None, vp, pd, pd)
-    sig("orc_pg_ypr", None, pd, pd)
+    sig("orc_pg_get_drift", None, vp, pd, pd, pd)
     sig("orc_create", vp)
     sig("orc_destroy", None, vp)
     sig("orc_new_id", u64, vp)
@@ -474,69 +461,11 @@ class OraclePoseGraph:
             self.L.orc_pg_get_pose(self.h, k, dptr(T[k]), dptr(Q[k]))
         return T, Q
 
-    # ---- inspection hooks for the Jacobian tests
-    def build(self, earliest_loop_index, cur_index):
-        nt, ne = C.c_int(), C.c_int()
-        nodes = self.L.orc_pg_build(self.h, earliest_loop_index, cur_index, C.byref(nt), C.byref(ne))
-        return nodes, nt.value, ne.value
-
-    def eval_edge(self, e):
-        d = 6 if self.six else 4
-        a, b, lp = C.c_int(), C.c_int(), C.c_int()
-        r, Ja, Jb = np.zeros(d), np.zeros((d, d)), np.zeros((d, d))
-        self.L.orc_pg_eval_edge(self.h, e, C.byref(a), C.byref(b), C.byref(lp), dptr(r), dptr(Ja), dptr(Jb))
-        return a.value, b.value, bool(lp.value), r, Ja, Jb
-
-    def perturb_node(self, k, d):
-        d = arr(d)
-        self.L.orc_pg_perturb_node(self.h, k, dptr(d))
-
-    def cost(self):
-        return self.L.orc_pg_cost(self.h)
-
-    def linearize(self, m, n):
-        r, J = np.zeros(m), np.zeros((m, n))
-        self.L.orc_pg_linearize(self.h, dptr(r), dptr(J))
-        return r, J
-
-
-class OraclePoseGraph:
-    """ctypes view of the pose-graph restatement (PoseGraph::optimize4DoFPoseGraph / optimize6DoFPoseGraph)."""
-
-    def __init__(self, six_dof=False, max_iterations=0, envelope=False, L=None):
-        self.L = L or lib()
-        self.six = bool(six_dof)
-        self.h = self.L.orc_pg_create(1 if six_dof else 0, max_iterations)
-        if envelope:
-            self.L.orc_pg_set_envelope(self.h, 1)
-
-    def __del__(self):
-        if getattr(self, "h", None):
-            self.L.orc_pg_destroy(self.h)
-            self.h = None
-
-    def add_keyframe(self, index, sequence, t, q, loop=None):
-        """loop = (loop_index, rel_t[3], rel_q[4] xyzw, rel_yaw_deg) or None"""
-        t, q = arr(t), arr(q)
-        if loop is None:
-            z3, z4 = np.zeros(3), np.array([0.0, 0, 0, 1])
-            self.L.orc_pg_add_keyframe(self.h, index, sequence, dptr(t), dptr(q), -1, dptr(z3), dptr(z4), 0.0)
-        else:
-            li, rt, rq, ry = loop
-            rt, rq = arr(rt), arr(rq)
-            self.L.orc_pg_add_keyframe(self.h, index, sequence, dptr(t), dptr(q), int(li), dptr(rt), dptr(rq), float(ry))
-
-    def optimize(self, earliest_loop_index, cur_index):
-        s = np.zeros(5)
-        self.L.orc_pg_optimize(self.h, earliest_loop_index, cur_index, dptr(s))
-        return dict(initial_cost=s[0], final_cost=s[1], iterations=int(s[2]), termination=int(s[3]), successful=int(s[4]))
-
-    def poses(self):
-        n = self.L.orc_pg_num_keyframes(self.h)
-        T, Q = np.zeros((n, 3)), np.zeros((n, 4))
-        for k in range(n):
-            self.L.orc_pg_get_pose(self.h, k, dptr(T[k]), dptr(Q[k]))
-        return T, Q
+    def drift(self):
+        """(yaw_drift degrees, r_drift 3x3, t_drift) of PoseGraph.cpp:356-363 / :521-526"""
+        y, r, t = np.zeros(1), np.zeros((3, 3)), np.zeros(3)
+        self.L.orc_pg_get_drift(self.h, dptr(y), dptr(r), dptr(t))
+        return float(y[0]), r, t
 
     # ---- inspection hooks for the Jacobian tests
     def build(self, earliest_loop_index, cur_index):

@@ -64,7 +64,9 @@ inline void ypr2R(double yaw, double pitch, double roll, double* R, double* dR_d
 struct Keyframe {
   int index = 0, sequence = 0;
   double t[3] = {0, 0, 0};
-  double q[4] = {0, 0, 0, 1};        // [x y z w]
+  double q[4] = {0, 0, 0, 1};        // [x y z w]   (t, q) = Keyframe::getSVInPose, never modified by the optimisation
+  double P[3] = {0, 0, 0};           // Keyframe::getPose: the drift-corrected / optimised pose (updatePose)
+  double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   bool hasLoop = false;
   int loopIndex = -1;
   double loopT[3] = {0, 0, 0}, loopQ[4] = {0, 0, 0, 1}, loopYaw = 0;
@@ -568,22 +570,57 @@ class Graph {
     }
   }
 
-  // PoseGraph.cpp:338-350 / :505-515: write the optimised poses back (4-DoF: ypr2R(yaw, pitch, roll))
+  // drift of the odometry frame against the optimised map (PoseGraph.cpp:356-363 / :521-526)
+  double yawDrift = 0, rDrift[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tDrift[3] = {0, 0, 0};
+  // addKeyframe's pose update (PoseGraph.cpp:127-132): pose = drift * SVIn pose
+  void applyDrift(Keyframe& kf) const {
+    double R[9];
+    q2R(kf.q, R);
+    mat3_vec(rDrift, kf.t, kf.P);
+    for (int c = 0; c < 3; ++c) kf.P[c] += tDrift[c];
+    matmul<3, 3, 3>(rDrift, R, kf.Rp);
+  }
+  // PoseGraph.cpp:340-375 / :504-534: write the optimised poses back (4-DoF: ypr2R(yaw, pitch, roll)), update the
+  // drift from the current keyframe and move the keyframes after it
   void writeBack(int earliestLoopIndex, int curIndex) {
     int i = 0;
-    for (Keyframe& kf : kfs) {
+    size_t k = 0;
+    Keyframe* cur = nullptr;
+    for (; k < kfs.size(); ++k) {
+      Keyframe& kf = kfs[k];
       if (kf.index < earliestLoopIndex) continue;
-      for (int c = 0; c < 3; ++c) kf.t[c] = t[3 * i + c];
+      for (int c = 0; c < 3; ++c) kf.P[c] = t[3 * i + c];
       if (!sixDof) {
-        double R[9];
+        double R[9], qq[4];
         ypr2R(yaw[i], pitch[i], roll[i], R);
-        r2q(R, kf.q);
+        r2q(R, qq);      // tmp_q = ypr2R(...); tmp_r = tmp_q.toRotationMatrix()
+        q2R(qq, kf.Rp);
       } else {
-        std::memcpy(kf.q, &q[4 * i], sizeof(kf.q));
+        q2R(&q[4 * i], kf.Rp);
       }
-      if (kf.index == curIndex) break;
+      if (kf.index == curIndex) { cur = &kf; break; }
       ++i;
     }
+    if (!cur) return;
+    double Rs[9];
+    q2R(cur->q, Rs);
+    if (!sixDof) {
+      double a[3], b[3];
+      r2ypr(cur->Rp, a);
+      r2ypr(Rs, b);
+      yawDrift = a[0] - b[0];
+      ypr2R(yawDrift, 0, 0, rDrift);
+    } else {
+      double Rt[9], a[3];
+      transpose<3, 3>(cur->Rp, Rt);
+      matmul<3, 3, 3>(Rt, Rs, rDrift);   // r_drift = cur_r.transpose() * svin_r (PoseGraph.cpp:523)
+      r2ypr(rDrift, a);
+      yawDrift = a[0];
+    }
+    double rs[3];
+    mat3_vec(rDrift, cur->t, rs);
+    for (int c = 0; c < 3; ++c) tDrift[c] = cur->P[c] - rs[c];
+    for (++k; k < kfs.size(); ++k) applyDrift(kfs[k]);
   }
   // Eigen Quaterniond(Matrix3d) (Shepperd)
   static void r2q(const double* R, double* qo) {
@@ -638,6 +675,7 @@ void orc_pg_add_keyframe(void* h, int index, int sequence, const double* t, cons
     std::memcpy(kf.loopQ, rel_q, sizeof(kf.loopQ));
     kf.loopYaw = rel_yaw;
   }
+  static_cast<Graph*>(h)->applyDrift(kf);
   static_cast<Graph*>(h)->kfs.push_back(kf);
 }
 // returns the number of iterations; summary5 = initial_cost, final_cost, iterations, termination, successful steps
@@ -655,8 +693,15 @@ int orc_pg_optimize(void* h, int earliest_loop_index, int cur_index, double* sum
 int orc_pg_num_keyframes(void* h) { return (int)static_cast<Graph*>(h)->kfs.size(); }
 void orc_pg_get_pose(void* h, int k, double* t, double* q) {
   const Keyframe& kf = static_cast<Graph*>(h)->kfs.at(k);
-  std::memcpy(t, kf.t, sizeof(kf.t));
-  std::memcpy(q, kf.q, sizeof(kf.q));
+  std::memcpy(t, kf.P, sizeof(kf.P));
+  Graph::r2q(kf.Rp, q);
+}
+// yaw_drift (degrees), r_drift (3x3 row-major), t_drift
+void orc_pg_get_drift(void* h, double* yaw, double* r, double* t) {
+  const Graph* g = static_cast<Graph*>(h);
+  if (yaw) *yaw = g->yawDrift;
+  if (r) std::memcpy(r, g->rDrift, sizeof(g->rDrift));
+  if (t) std::memcpy(t, g->tDrift, sizeof(g->tDrift));
 }
 // inspection: builds the local problem and returns sizes; then edge-level evaluation for the Jacobian checks
 int orc_pg_build(void* h, int earliest_loop_index, int cur_index, int* n_tangent, int* n_edges) {

@@ -4,8 +4,8 @@ set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $SVIN_EXTRA_FLAGS"
 mkdir -p obj
-for f in kernels.hip marg.hip; do
-  if [ ! -f obj/$f.o ] || [ $f -nt obj/$f.o ] || [ kernels.hpp -nt obj/$f.o ] || [ dmath.hpp -nt obj/$f.o ] || [ window.hpp -nt obj/$f.o ]; then
+for f in kernels.hip marg.hip posegraph.hip; do
+  if [ ! -f obj/$f.o ] || [ $f -nt obj/$f.o ] || [ ../../include/svin_pg.h -nt obj/$f.o ] || [ kernels.hpp -nt obj/$f.o ] || [ dmath.hpp -nt obj/$f.o ] || [ window.hpp -nt obj/$f.o ]; then
     hipcc $FLAGS -c $f -o obj/$f.o
   fi
 done
@@ -14,5 +14,5 @@ for f in window.cpp capi.cpp; do
     hipcc $FLAGS -x hip -c $f -o obj/$f.o
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvin_ba.so obj/kernels.hip.o obj/marg.hip.o obj/window.cpp.o obj/capi.cpp.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvin_ba.so obj/kernels.hip.o obj/marg.hip.o obj/posegraph.hip.o obj/window.cpp.o obj/capi.cpp.o
 echo "built $(cd .. && pwd)/libsvin_ba.so"

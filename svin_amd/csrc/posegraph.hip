@@ -1,0 +1,762 @@
+// svin_amd global pose-graph optimisation: the numerical core of pose_graph's optimisation thread
+// (/root/reference/pose_graph/src/pose_graph/PoseGraph.cpp:226-543) on gfx950 behind include/svin_pg.h.
+//
+//   host    keyframe list -> local problem exactly like the reference (sequential edges to the 2 / 4 predecessors of
+//           the same sequence, loop edges, constant first keyframe), Levenberg-Marquardt control flow of Ceres 2.2
+//           (TrustRegionMinimizer + LevenbergMarquardtStrategy, default options), one scalar read-back per iteration
+//   device  k_pg_eval     one thread per edge: FourDOFError / FourDOFWeightError / PoseGraph3dErrorTerm residual,
+//                         analytic minimal Jacobians (the reference uses AutoDiff: same derivatives), HuberLoss(0.1)
+//                         corrector on loop edges, cost partials
+//           k_pg_node     one thread per free keyframe: gradient, column norms, Jacobi scaling, diagonal block of
+//                         the damped normal equations (incident edges in fixed order: deterministic)
+//           k_pg_offdiag  one thread per edge: the off-diagonal block J_b^T J_a
+//           solve         the dense reduced-system solver of the BA backend (LDS-resident or multi-workgroup
+//                         blocked Cholesky on v_mfma_f64_16x16x4_f64, kernels.hip launchSolveReduced)
+//           k_pg_model / k_pg_plus / k_pg_reduce   model cost change, candidate = Plus(x, delta), norms
+// Stage 2a (this file): every free keyframe is an unknown of one dense system (graphs up to a few thousand unknowns);
+// the segment / separator elimination for config-#5-sized graphs builds on the same kernels.
+#include "kernels.hpp"
+#include "dmath.hpp"
+#include "../../include/svin_pg.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace svin {
+namespace pg {
+
+#define PG_HIP_OK(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+constexpr double kPgPi = 3.14159265358979323846;
+
+struct PgDev {
+  int nn, ne, n, m, six, D, R;
+  double *yaw, *pitch, *roll, *t, *q;   // current point (yaw in degrees; q = [x y z w])
+  double *yawC, *tC, *qC;               // candidate
+  int* off;                             // tangent offset per node, -1 = constant
+  int *ea, *eb, *eloop;
+  double *et, *eyaw, *epitch, *eroll, *eq, *esq;
+  double *res, *Ja, *Jb;                // robustified residuals and Jacobian blocks (R x D per edge and side)
+  int *nodePtr, *nodeEdge;              // incident edges per node: edge * 2 + side (0 = a, 1 = b)
+  double *H, *rhs, *scale, *g, *colsq, *y, *delta;
+  double *partial, *scal;
+};
+enum PgScal : int { PG_COST = 0, PG_GRADMAX = 1, PG_MODEL = 2, PG_STEP2 = 3, PG_X2 = 4, PG_NSCAL = 8 };
+constexpr int kPgMaxPartials = 4096;
+
+__device__ __forceinline__ double pgNormalizeAngle(double deg) {  // PoseGraph.h:85-93
+  if (deg > 180.0) return deg - 360.0;
+  if (deg < -180.0) return deg + 360.0;
+  return deg;
+}
+// PoseGraph.h:110-127 (Rz Ry Rx, degrees) and its derivative with respect to the yaw angle (degrees)
+__device__ __forceinline__ void pgYpr2R(double yaw, double pitch, double roll, double* R, double* dR) {
+  const double y = yaw / 180.0 * kPgPi, p = pitch / 180.0 * kPgPi, r = roll / 180.0 * kPgPi;
+  const double cy = cos(y), sy = sin(y), cp = cos(p), sp = sin(p), cr = cos(r), sr = sin(r);
+  R[0] = cy * cp; R[1] = -sy * cr + cy * sp * sr; R[2] = sy * sr + cy * sp * cr;
+  R[3] = sy * cp; R[4] = cy * cr + sy * sp * sr;  R[5] = -cy * sr + sy * sp * cr;
+  R[6] = -sp;     R[7] = cp * sr;                 R[8] = cp * cr;
+  const double k = kPgPi / 180.0;
+  dR[0] = -sy * cp * k; dR[1] = (-cy * cr - sy * sp * sr) * k; dR[2] = (cy * sr - sy * sp * cr) * k;
+  dR[3] = cy * cp * k;  dR[4] = (-sy * cr + cy * sp * sr) * k; dR[5] = (sy * sr + cy * sp * cr) * k;
+  dR[6] = 0; dR[7] = 0; dR[8] = 0;
+}
+// q_a * x = plus(q_a) x ; x * q_b = oplus(q_b) x  (rows / columns in [x y z w] order)
+__device__ __forceinline__ void pgPlusMat(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.x;
+  Q[4] = q.z; Q[5] = q.w; Q[6] = -q.x; Q[7] = q.y;
+  Q[8] = -q.y; Q[9] = q.x; Q[10] = q.w; Q[11] = q.z;
+  Q[12] = -q.x; Q[13] = -q.y; Q[14] = -q.z; Q[15] = q.w;
+}
+__device__ __forceinline__ void pgOplusMat(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = q.z; Q[2] = -q.y; Q[3] = q.x;
+  Q[4] = -q.z; Q[5] = q.w; Q[6] = q.x; Q[7] = q.y;
+  Q[8] = q.y; Q[9] = -q.x; Q[10] = q.w; Q[11] = q.z;
+  Q[12] = -q.x; Q[13] = -q.y; Q[14] = -q.z; Q[15] = q.w;
+}
+__device__ __forceinline__ double pgBlockSum(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ double pgBlockMax(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) s = fmax(s, red[i]);
+  return s;
+}
+
+// residual and minimal Jacobians of one edge (tangent order 4-DoF: [yaw, t]; 6-DoF: [t, dq], q <- [sin|d| d/|d|, cos|d|] q)
+__device__ void pgEdge(const PgDev& p, int e, bool cand, double* r, double* Ja, double* Jb) {
+  const int a = p.ea[e], b = p.eb[e];
+  const double* T = cand ? p.tC : p.t;
+  const double d[3] = {T[3 * b] - T[3 * a], T[3 * b + 1] - T[3 * a + 1], T[3 * b + 2] - T[3 * a + 2]};
+  if (!p.six) {
+    const double* Y = cand ? p.yawC : p.yaw;
+    double R[9], dR[9];
+    pgYpr2R(Y[a], p.epitch[e], p.eroll[e], R, dR);
+    const bool loop = p.eloop[e] != 0;
+    const double wt = 1.0, wy = loop ? 0.1 : 1.0;  // FourDOFWeightError: weight 1, yaw / 10 (PoseGraph.h:182, :206)
+    for (int k = 0; k < 3; ++k) {
+      const double ti = R[k] * d[0] + R[3 + k] * d[1] + R[6 + k] * d[2];    // (R^T d)[k]
+      const double dti = dR[k] * d[0] + dR[3 + k] * d[1] + dR[6 + k] * d[2];
+      r[k] = (ti - p.et[3 * e + k]) * wt;
+      Ja[k * 4 + 0] = dti * wt;
+      Jb[k * 4 + 0] = 0.0;
+      for (int c = 0; c < 3; ++c) { Ja[k * 4 + 1 + c] = -R[c * 3 + k] * wt; Jb[k * 4 + 1 + c] = R[c * 3 + k] * wt; }
+    }
+    r[3] = pgNormalizeAngle(Y[b] - Y[a] - p.eyaw[e]) * wy;
+    Ja[12] = -wy; Ja[13] = Ja[14] = Ja[15] = 0.0;
+    Jb[12] = wy;  Jb[13] = Jb[14] = Jb[15] = 0.0;
+  } else {
+    const double* Qn = cand ? p.qC : p.q;
+    const Quat qa{Qn[4 * a], Qn[4 * a + 1], Qn[4 * a + 2], Qn[4 * a + 3]}, qb{Qn[4 * b], Qn[4 * b + 1], Qn[4 * b + 2], Qn[4 * b + 3]};
+    const Quat qm{p.eq[4 * e], p.eq[4 * e + 1], p.eq[4 * e + 2], p.eq[4 * e + 3]};
+    const double* si = p.esq + 6 * e;
+    const Mat3 Ra = quatToR(qa);
+    double pab[3];
+    for (int k = 0; k < 3; ++k) pab[k] = Ra.m[k] * d[0] + Ra.m[3 + k] * d[1] + Ra.m[6 + k] * d[2];
+    const Quat qac{-qa.x, -qa.y, -qa.z, qa.w}, qbc{-qb.x, -qb.y, -qb.z, qb.w};
+    const Quat qab = qmul(qac, qb);
+    const Quat dq = qmul(qm, Quat{-qab.x, -qab.y, -qab.z, qab.w});
+    const double u[6] = {pab[0] - p.et[3 * e], pab[1] - p.et[3 * e + 1], pab[2] - p.et[3 * e + 2], 2 * dq.x, 2 * dq.y, 2 * dq.z};
+    for (int k = 0; k < 6; ++k) r[k] = si[k] * u[k];
+    for (int k = 0; k < 36; ++k) { Ja[k] = 0.0; Jb[k] = 0.0; }
+    // d(R_a^T d)/d(delta_a) = 2 R_a^T [d]x
+    const double dx[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) {
+        const double rt = Ra.m[c * 3 + k];   // (R^T)[k][c]
+        Ja[k * 6 + c] = -rt * si[k];
+        Jb[k * 6 + c] = rt * si[k];
+        double s = 0;
+        for (int j = 0; j < 3; ++j) s += Ra.m[j * 3 + k] * dx[j * 3 + c];
+        Ja[k * 6 + 3 + c] = 2.0 * s * si[k];
+      }
+    double PA[16], OB[16];
+    pgPlusMat(qmul(qm, qbc), PA);
+    pgOplusMat(qa, OB);
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) {
+        double s = 0;
+        for (int j = 0; j < 4; ++j) s += PA[k * 4 + j] * OB[j * 4 + c];
+        Ja[(3 + k) * 6 + 3 + c] = 2.0 * s * si[3 + k];
+        Jb[(3 + k) * 6 + 3 + c] = -2.0 * s * si[3 + k];
+      }
+  }
+}
+
+__global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac) {
+  __shared__ double red[2];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0;
+  if (e < p.ne) {
+    double r[6], Ja[36], Jb[36];
+    pgEdge(p, e, cand != 0, r, Ja, Jb);
+    double s = 0;
+    for (int k = 0; k < p.R; ++k) s += r[k] * r[k];
+    double sc = 1.0;
+    if (p.eloop[e]) {  // HuberLoss(0.1) + Corrector (rho'' <= 0: plain sqrt(rho') scaling)
+      const double a = 0.1, b = a * a;
+      if (s > b) {
+        const double rt = sqrt(s);
+        cost = 0.5 * (2.0 * a * rt - b);
+        sc = sqrt(fmax(2.2250738585072014e-308, a / rt));
+      } else {
+        cost = 0.5 * s;
+      }
+    } else {
+      cost = 0.5 * s;
+    }
+    if (withJac) {
+      const int RD = p.R * p.D;
+      for (int k = 0; k < p.R; ++k) p.res[(size_t)e * p.R + k] = sc * r[k];
+      for (int k = 0; k < RD; ++k) { p.Ja[(size_t)e * RD + k] = sc * Ja[k]; p.Jb[(size_t)e * RD + k] = sc * Jb[k]; }
+    }
+  }
+  const double bs = pgBlockSum(cost, red);
+  if (threadIdx.x == 0) p.partial[PG_COST * kPgMaxPartials + blockIdx.x] = bs;
+}
+
+// one thread per node: gradient, column norms, (first iteration) Jacobi scaling, damped diagonal block, rhs
+__global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale, double radius) {
+  __shared__ double red[2];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double gmax = 0;
+  if (k < p.nn && p.off[k] >= 0) {
+    const int D = p.D, R = p.R, o = p.off[k];
+    double g[6] = {0, 0, 0, 0, 0, 0}, blk[36];
+    for (int i = 0; i < 36; ++i) blk[i] = 0;
+    for (int it = p.nodePtr[k]; it < p.nodePtr[k + 1]; ++it) {
+      const int e = p.nodeEdge[it] >> 1, side = p.nodeEdge[it] & 1;
+      const double* J = (side ? p.Jb : p.Ja) + (size_t)e * R * D;
+      const double* r = p.res + (size_t)e * R;
+      for (int c1 = 0; c1 < D; ++c1) {
+        double gs = 0;
+        for (int q = 0; q < R; ++q) gs += J[q * D + c1] * r[q];
+        g[c1] += gs;
+        for (int c2 = 0; c2 < D; ++c2) {
+          double s = 0;
+          for (int q = 0; q < R; ++q) s += J[q * D + c1] * J[q * D + c2];
+          blk[c1 * D + c2] += s;
+        }
+      }
+    }
+    double sc[6];
+    for (int c = 0; c < D; ++c) {
+      if (initScale) { sc[c] = 1.0 / (1.0 + sqrt(blk[c * D + c])); p.scale[o + c] = sc[c]; }
+      else sc[c] = p.scale[o + c];
+      p.g[o + c] = g[c];
+      p.colsq[o + c] = blk[c * D + c];
+      p.rhs[o + c] = g[c] * sc[c];
+      gmax = fmax(gmax, fabs(g[c]));
+    }
+    for (int c1 = 0; c1 < D; ++c1)
+      for (int c2 = 0; c2 < D; ++c2) {
+        double v = blk[c1 * D + c2] * sc[c1] * sc[c2];
+        if (c1 == c2) v += fmin(fmax(blk[c1 * D + c1] * sc[c1] * sc[c1], 1e-6), 1e32) / radius;  // LM diagonal
+        p.H[(size_t)(o + c1) * p.n + o + c2] = v;
+      }
+  }
+  const double bm = pgBlockMax(gmax, red);
+  if (threadIdx.x == 0) p.partial[PG_GRADMAX * kPgMaxPartials + blockIdx.x] = bm;
+}
+
+// one thread per edge: off-diagonal block (rows of b, columns of a) = J_b^T J_a, and its transpose
+__global__ void k_pg_offdiag(PgDev p) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.ne) return;
+  const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
+  if (oa < 0 || ob < 0) return;
+  const int D = p.D, R = p.R;
+  const double* Ja = p.Ja + (size_t)e * R * D;
+  const double* Jb = p.Jb + (size_t)e * R * D;
+  for (int c1 = 0; c1 < D; ++c1)
+    for (int c2 = 0; c2 < D; ++c2) {
+      double s = 0;
+      for (int q = 0; q < R; ++q) s += Jb[q * D + c1] * Ja[q * D + c2];
+      s *= p.scale[ob + c1] * p.scale[oa + c2];
+      p.H[(size_t)(ob + c1) * p.n + oa + c2] = s;
+      p.H[(size_t)(oa + c2) * p.n + ob + c1] = s;
+    }
+}
+
+__global__ void k_pg_step(PgDev p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.n) p.delta[i] = -p.y[i] * p.scale[i];
+}
+
+// model cost change = -(J delta).(r + J delta / 2) over the edges
+__global__ __launch_bounds__(128) void k_pg_model(PgDev p) {
+  __shared__ double red[2];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0;
+  if (e < p.ne) {
+    const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]], D = p.D, R = p.R;
+    for (int q = 0; q < R; ++q) {
+      double mr = 0;
+      if (oa >= 0) for (int c = 0; c < D; ++c) mr += p.Ja[((size_t)e * R + q) * D + c] * p.delta[oa + c];
+      if (ob >= 0) for (int c = 0; c < D; ++c) mr += p.Jb[((size_t)e * R + q) * D + c] * p.delta[ob + c];
+      acc += mr * (p.res[(size_t)e * R + q] + 0.5 * mr);
+    }
+  }
+  const double bs = pgBlockSum(acc, red);
+  if (threadIdx.x == 0) p.partial[PG_MODEL * kPgMaxPartials + blockIdx.x] = bs;
+}
+
+// candidate = Plus(x, delta) (YawAngleFunctor PoseGraph.h:95-108 / EigenQuaternionManifold::Plus); |x_c - x|^2, |x|^2
+__global__ __launch_bounds__(128) void k_pg_plus(PgDev p) {
+  __shared__ double red[2];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double st = 0, xn = 0;
+  if (k < p.nn) {
+    const int o = p.off[k];
+    if (!p.six) {
+      const double y0 = p.yaw[k];
+      const double y1 = o >= 0 ? pgNormalizeAngle(y0 + p.delta[o]) : y0;
+      p.yawC[k] = y1;
+      if (o >= 0) { st += (y1 - y0) * (y1 - y0); xn += y0 * y0; }
+      for (int c = 0; c < 3; ++c) {
+        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + p.delta[o + 1 + c] : x0;
+        p.tC[3 * k + c] = x1;
+        if (o >= 0) { st += (x1 - x0) * (x1 - x0); xn += x0 * x0; }
+      }
+    } else {
+      for (int c = 0; c < 3; ++c) {
+        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + p.delta[o + c] : x0;
+        p.tC[3 * k + c] = x1;
+        if (o >= 0) { st += (x1 - x0) * (x1 - x0); xn += x0 * x0; }
+      }
+      const Quat q0{p.q[4 * k], p.q[4 * k + 1], p.q[4 * k + 2], p.q[4 * k + 3]};
+      Quat q1 = q0;
+      if (o >= 0) {
+        const double dx = p.delta[o + 3], dy = p.delta[o + 4], dz = p.delta[o + 5];
+        const double nd = sqrt(dx * dx + dy * dy + dz * dz);
+        if (nd > 0.0) {
+          const double s = sin(nd) / nd;
+          q1 = qmul(Quat{s * dx, s * dy, s * dz, cos(nd)}, q0);
+        }
+        st += (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) + (q1.z - q0.z) * (q1.z - q0.z) + (q1.w - q0.w) * (q1.w - q0.w);
+        xn += q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w;
+      }
+      p.qC[4 * k] = q1.x; p.qC[4 * k + 1] = q1.y; p.qC[4 * k + 2] = q1.z; p.qC[4 * k + 3] = q1.w;
+    }
+  }
+  const double a = pgBlockSum(st, red);
+  const double b = pgBlockSum(xn, red);
+  if (threadIdx.x == 0) { p.partial[PG_STEP2 * kPgMaxPartials + blockIdx.x] = a; p.partial[PG_X2 * kPgMaxPartials + blockIdx.x] = b; }
+}
+
+// single-block final reductions (fixed order): slot -> scal[slot]; isMax selects max instead of sum
+__global__ __launch_bounds__(256) void k_pg_reduce(PgDev p, int slot, int n, int isMax) {
+  __shared__ double red[4];
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double x = p.partial[slot * kPgMaxPartials + i];
+    v = isMax ? fmax(v, x) : v + x;
+  }
+  const double s = isMax ? pgBlockMax(v, red) : pgBlockSum(v, red);
+  if (threadIdx.x == 0) p.scal[slot] = s;
+}
+
+// ---------------------------------------------------------------- host
+struct Keyframe {
+  int index = 0, sequence = 0;
+  double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};   // Keyframe::getSVInPose: the optimisation's input, never modified
+  double P[3] = {0, 0, 0}, Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // Keyframe::getPose (updatePose)
+  bool hasLoop = false;
+  int loopIndex = -1;
+  double loopT[3] = {0, 0, 0}, loopQ[4] = {0, 0, 0, 1}, loopYaw = 0;
+};
+
+template <class T>
+struct Buf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~Buf() { if (p) (void)hipFree(p); }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipFree(p);
+    size_t c = cap ? cap : 64;
+    while (c < n) c *= 2;
+    if (hipMalloc(&p, c * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; throw std::runtime_error("hipMalloc failed"); }
+    cap = c;
+  }
+  void upload(const std::vector<T>& h, hipStream_t s) {
+    reserve(std::max<size_t>(h.size(), 1));
+    if (!h.empty()) PG_HIP_OK(hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
+  }
+};
+
+static void hostR2ypr(const double* q, double* ypr) {  // Utils.h:71-86 on Quaterniond::toRotationMatrix()
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  const double yw = std::atan2(R[3], R[0]);
+  const double p = std::atan2(-R[6], R[0] * std::cos(yw) + R[3] * std::sin(yw));
+  const double r = std::atan2(R[2] * std::sin(yw) - R[5] * std::cos(yw), -R[1] * std::sin(yw) + R[4] * std::cos(yw));
+  ypr[0] = yw / kPgPi * 180.0; ypr[1] = p / kPgPi * 180.0; ypr[2] = r / kPgPi * 180.0;
+}
+static double hostYawOfR(const double* R) { return std::atan2(R[3], R[0]) / kPgPi * 180.0; }
+static void hostQmul(const double* a, const double* b, double* o) {
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+static void hostQ2R(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void hostYpr2R(double yaw, double pitch, double roll, double* R) {
+  const double y = yaw / 180.0 * kPgPi, p = pitch / 180.0 * kPgPi, r = roll / 180.0 * kPgPi;
+  const double cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
+  R[0] = cy * cp; R[1] = -sy * cr + cy * sp * sr; R[2] = sy * sr + cy * sp * cr;
+  R[3] = sy * cp; R[4] = cy * cr + sy * sp * sr;  R[5] = -cy * sr + sy * sp * cr;
+  R[6] = -sp;     R[7] = cp * sr;                 R[8] = cp * cr;
+}
+static void hostR2q(const double* R, double* qo) {  // Eigen::Quaterniond(Matrix3d)
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0);
+    qo[3] = 0.5 * s; s = 0.5 / s;
+    qo[0] = (R[7] - R[5]) * s; qo[1] = (R[2] - R[6]) * s; qo[2] = (R[3] - R[1]) * s;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    qo[i] = 0.5 * s; s = 0.5 / s;
+    qo[3] = (R[k * 3 + j] - R[j * 3 + k]) * s;
+    qo[j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
+    qo[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+  }
+}
+
+class PoseGraph {
+ public:
+  PoseGraph(int device, bool six, int maxIter) : six_(six), maxIter_(maxIter > 0 ? maxIter : (six ? 5 : 10)) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      throw std::runtime_error("svin_pg: no HIP device available (this backend has no CPU fallback)");
+    if (device < 0 || device >= count) throw std::runtime_error("svin_pg: invalid device index");
+    PG_HIP_OK(hipSetDevice(device));
+    PG_HIP_OK(hipStreamCreate(&s_));
+  }
+  ~PoseGraph() { if (s_) (void)hipStreamDestroy(s_); }
+
+  std::vector<Keyframe> kfs;
+  double summary[6] = {0, 0, 0, 1, 0, 0};
+  // drift of the odometry frame against the optimised map (PoseGraph.cpp:356-363 / :521-526)
+  double yawDrift = 0, rDrift[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tDrift[3] = {0, 0, 0};
+
+  // addKeyframe's pose update (PoseGraph.cpp:127-132): pose = drift * SVIn pose
+  void applyDrift(Keyframe& kf) const {
+    double R[9];
+    hostQ2R(kf.q, R);
+    for (int r = 0; r < 3; ++r) {
+      kf.P[r] = rDrift[3 * r] * kf.t[0] + rDrift[3 * r + 1] * kf.t[1] + rDrift[3 * r + 2] * kf.t[2] + tDrift[r];
+      for (int c = 0; c < 3; ++c) kf.Rp[3 * r + c] = rDrift[3 * r] * R[c] + rDrift[3 * r + 1] * R[3 + c] + rDrift[3 * r + 2] * R[6 + c];
+    }
+  }
+
+  int optimize(int earliest, int cur) {
+    // ---- local problem (PoseGraph.cpp:262-332 / :436-489)
+    std::vector<double> yaw, pitch, roll, t, q;
+    std::vector<int> off, ea, eb, eloop, seq, localOf(kfs.size(), -1), kfOfLocal;
+    std::vector<char> fixed;
+    std::vector<double> et, eyaw, epitch, eroll, eq, esq;
+    int i = 0;
+    for (size_t k = 0; k < kfs.size(); ++k) {
+      const Keyframe& kf = kfs[k];
+      if (kf.index < earliest) continue;
+      localOf[k] = i;
+      kfOfLocal.push_back((int)k);
+      double ypr[3];
+      hostR2ypr(kf.q, ypr);
+      yaw.push_back(ypr[0]); pitch.push_back(ypr[1]); roll.push_back(ypr[2]);
+      t.insert(t.end(), kf.t, kf.t + 3);
+      q.insert(q.end(), kf.q, kf.q + 4);
+      seq.push_back(kf.sequence);
+      fixed.push_back(six_ ? (kf.index == earliest || kf.sequence == 0) : (kf.index <= earliest));
+      const int nSeq = six_ ? 4 : 2;
+      for (int j = 1; j <= nSeq; ++j) {
+        if (i - j >= 0 && seq[i] == seq[i - j]) {
+          const double* qa = &q[4 * (i - j)];
+          double Ra[9];
+          hostQ2R(qa, Ra);
+          const double d[3] = {t[3 * i] - t[3 * (i - j)], t[3 * i + 1] - t[3 * (i - j) + 1], t[3 * i + 2] - t[3 * (i - j) + 2]};
+          for (int c = 0; c < 3; ++c) et.push_back(Ra[c] * d[0] + Ra[3 + c] * d[1] + Ra[6 + c] * d[2]);
+          ea.push_back(i - j); eb.push_back(i); eloop.push_back(0);
+          eyaw.push_back(yaw[i] - yaw[i - j]); epitch.push_back(pitch[i - j]); eroll.push_back(roll[i - j]);
+          const double n2 = qa[0] * qa[0] + qa[1] * qa[1] + qa[2] * qa[2] + qa[3] * qa[3];
+          const double qai[4] = {-qa[0] / n2, -qa[1] / n2, -qa[2] / n2, qa[3] / n2};
+          double rq[4];
+          hostQmul(qai, &q[4 * i], rq);
+          eq.insert(eq.end(), rq, rq + 4);
+          const double si[6] = {20, 20, 20, 100, 100, 57.3};
+          esq.insert(esq.end(), si, si + 6);
+        }
+      }
+      if (kf.hasLoop) {
+        int ci = -1;
+        for (size_t kk = 0; kk < kfs.size(); ++kk)
+          if (kfs[kk].index == kf.loopIndex) ci = localOf[kk];
+        if (ci >= 0) {
+          ea.push_back(ci); eb.push_back(i); eloop.push_back(1);
+          et.insert(et.end(), kf.loopT, kf.loopT + 3);
+          eyaw.push_back(kf.loopYaw); epitch.push_back(pitch[ci]); eroll.push_back(roll[ci]);
+          eq.insert(eq.end(), kf.loopQ, kf.loopQ + 4);
+          const double si[6] = {20, 20, 20, 100, 100, 100};
+          esq.insert(esq.end(), si, si + 6);
+        }
+      }
+      if (kf.index == cur) { ++i; break; }
+      ++i;
+    }
+    const int nn = (int)fixed.size(), ne = (int)ea.size(), D = six_ ? 6 : 4, R = D;
+    off.assign(nn, -1);
+    int n = 0;
+    for (int k = 0; k < nn; ++k)
+      if (!fixed[k]) { off[k] = n; n += D; }
+    summary[0] = summary[1] = 0; summary[2] = 0; summary[3] = 0; summary[4] = 0; summary[5] = 0;
+    if (n == 0 || ne == 0) {  // nothing to optimise: the poses are still written back and the drift updated
+      writeBack(yaw, pitch, roll, t, q, kfOfLocal, cur);
+      return 1;
+    }
+    // incident edges per node (edge order = insertion order: deterministic accumulation)
+    std::vector<int> nodePtr(nn + 1, 0), nodeEdge(2 * (size_t)ne);
+    for (int e = 0; e < ne; ++e) { nodePtr[ea[e] + 1]++; nodePtr[eb[e] + 1]++; }
+    for (int k = 0; k < nn; ++k) nodePtr[k + 1] += nodePtr[k];
+    {
+      std::vector<int> curp(nodePtr.begin(), nodePtr.end() - 1);
+      for (int e = 0; e < ne; ++e) { nodeEdge[curp[ea[e]]++] = 2 * e; nodeEdge[curp[eb[e]]++] = 2 * e + 1; }
+    }
+    // ---- upload
+    dYaw_.upload(yaw, s_); dPitch_.upload(pitch, s_); dRoll_.upload(roll, s_); dT_.upload(t, s_); dQ_.upload(q, s_);
+    dYawC_.reserve(nn); dTC_.reserve(3 * (size_t)nn); dQC_.reserve(4 * (size_t)nn);
+    dOff_.upload(off, s_); dEa_.upload(ea, s_); dEb_.upload(eb, s_); dEloop_.upload(eloop, s_);
+    dEt_.upload(et, s_); dEyaw_.upload(eyaw, s_); dEpitch_.upload(epitch, s_); dEroll_.upload(eroll, s_);
+    dEq_.upload(eq, s_); dEsq_.upload(esq, s_);
+    dNodePtr_.upload(nodePtr, s_); dNodeEdge_.upload(nodeEdge, s_);
+    const size_t RD = (size_t)R * D;
+    dRes_.reserve((size_t)ne * R); dJa_.reserve(ne * RD); dJb_.reserve(ne * RD);
+    const int dpad = ((n + 15) / 16) * 16;
+    const size_t dp64 = ((size_t)n + 63) / 64 * 64;
+    dH_.reserve((size_t)n * n); dVec_.reserve((size_t)8 * n + 64);
+    dChol_.reserve(std::max((size_t)dpad * dpad, (dp64 + 64) * dp64 + dp64 + dp64 * 64));
+    dPartial_.reserve((size_t)8 * kPgMaxPartials); dScal_.reserve(PG_NSCAL); dSolScal_.reserve(1);
+    PgDev p;
+    std::memset(&p, 0, sizeof(p));
+    p.nn = nn; p.ne = ne; p.n = n; p.m = ne * R; p.six = six_ ? 1 : 0; p.D = D; p.R = R;
+    p.yaw = dYaw_.p; p.pitch = dPitch_.p; p.roll = dRoll_.p; p.t = dT_.p; p.q = dQ_.p;
+    p.yawC = dYawC_.p; p.tC = dTC_.p; p.qC = dQC_.p;
+    p.off = dOff_.p; p.ea = dEa_.p; p.eb = dEb_.p; p.eloop = dEloop_.p;
+    p.et = dEt_.p; p.eyaw = dEyaw_.p; p.epitch = dEpitch_.p; p.eroll = dEroll_.p; p.eq = dEq_.p; p.esq = dEsq_.p;
+    p.res = dRes_.p; p.Ja = dJa_.p; p.Jb = dJb_.p; p.nodePtr = dNodePtr_.p; p.nodeEdge = dNodeEdge_.p;
+    p.H = dH_.p;
+    p.rhs = dVec_.p; p.scale = dVec_.p + n; p.g = dVec_.p + 2 * (size_t)n; p.colsq = dVec_.p + 3 * (size_t)n;
+    p.y = dVec_.p + 4 * (size_t)n; p.delta = dVec_.p + 5 * (size_t)n;
+    double* ones = dVec_.p + 6 * (size_t)n;    // htilC stand-in for the solver's v_C output
+    double* vdump = dVec_.p + 7 * (size_t)n;
+    p.partial = dPartial_.p; p.scal = dScal_.p;
+    {
+      std::vector<double> one(n, 1.0);
+      PG_HIP_OK(hipMemcpyAsync(ones, one.data(), sizeof(double) * n, hipMemcpyHostToDevice, s_));
+      PG_HIP_OK(hipStreamSynchronize(s_));
+    }
+    // the dense solver of the BA backend sees the system through a DeviceProblem view
+    DeviceProblem dp;
+    std::memset(&dp, 0, sizeof(dp));
+    dp.d = n; dp.S = p.H; dp.gRed = p.rhs; dp.gFull = p.rhs; dp.htilC = ones; dp.yC = p.y; dp.vC = vdump;
+    dp.cholL = dChol_.p; dp.scal = dSolScal_.p;
+    const int gE = (ne + 127) / 128, gN = (nn + 127) / 128;
+    if (gE > kPgMaxPartials || gN > kPgMaxPartials) throw std::runtime_error("svin_pg: graph too large for the reduction scratch");
+    auto readScal = [&](double* out) {
+      PG_HIP_OK(hipMemcpyAsync(out, p.scal, sizeof(double) * PG_NSCAL, hipMemcpyDeviceToHost, s_));
+      PG_HIP_OK(hipStreamSynchronize(s_));
+    };
+    auto evalCost = [&](bool cand, bool withJac) {
+      hipLaunchKernelGGL(k_pg_eval, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
+      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    // ---- Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy, default options
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
+    double radius = 1e4, decrease_factor = 2.0;
+    double sc[PG_NSCAL];
+    evalCost(false, true);
+    readScal(sc);
+    double x_cost = sc[PG_COST];
+    summary[0] = x_cost;
+    bool needLinearize = true, initScale = true;
+    int iteration = 0, invalid = 0, successful = 0, termination = 1;
+    double gradMax = 0;
+    while (true) {
+      if (needLinearize) {  // gradient / column norms of the current linearisation (also the gradient check)
+        hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0, radius);
+        hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_GRADMAX, gN, 1);
+        readScal(sc);
+        gradMax = sc[PG_GRADMAX];
+        initScale = false;
+      }
+      if (iteration >= maxIter_) { termination = 1; break; }
+      if (gradMax <= gradient_tolerance) { termination = 0; break; }
+      if (radius <= min_radius) { termination = 0; break; }
+      ++iteration;
+      // normal equations with the current radius (k_pg_node rewrites the diagonal blocks)
+      PG_HIP_OK(hipMemsetAsync(p.H, 0, sizeof(double) * (size_t)n * n, s_));
+      PG_HIP_OK(hipMemsetAsync(dSolScal_.p, 0, sizeof(SolverScalars), s_));
+      hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, 0, radius);
+      hipLaunchKernelGGL(k_pg_offdiag, dim3((ne + 127) / 128), dim3(128), 0, s_, p);
+      launchSolveReduced(dp, s_, 0.0, false, false);
+      hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
+      hipLaunchKernelGGL(k_pg_model, dim3(gE), dim3(128), 0, s_, p);
+      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_MODEL, gE, 0);
+      hipLaunchKernelGGL(k_pg_plus, dim3(gN), dim3(128), 0, s_, p);
+      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_STEP2, gN, 0);
+      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_X2, gN, 0);
+      evalCost(true, false);
+      readScal(sc);
+      SolverScalars ss;
+      PG_HIP_OK(hipMemcpy(&ss, dSolScal_.p, sizeof(ss), hipMemcpyDeviceToHost));
+      const double model_cost_change = -sc[PG_MODEL];
+      needLinearize = false;
+      if (ss.cholFail != 0 || !(model_cost_change > 0.0) || !std::isfinite(sc[PG_STEP2])) {  // HandleInvalidStep
+        if (++invalid >= 5) { termination = 3; break; }
+        radius /= decrease_factor; decrease_factor *= 2.0;
+        continue;
+      }
+      invalid = 0;
+      const double step_norm = std::sqrt(sc[PG_STEP2]), x_norm = std::sqrt(sc[PG_X2]);
+      if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = 0; break; }
+      const double cand_cost = sc[PG_COST];
+      const double cost_change = x_cost - cand_cost;
+      if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = 0; break; }
+      const double rel = cost_change / model_cost_change;
+      if (rel > min_relative_decrease) {
+        std::swap(p.yaw, p.yawC); std::swap(p.t, p.tC); std::swap(p.q, p.qC);
+        evalCost(false, true);   // residuals + Jacobians at the accepted point (HandleSuccessfulStep)
+        x_cost = cand_cost;
+        radius = std::min(max_radius, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+        decrease_factor = 2.0;
+        needLinearize = true;
+        ++successful;
+      } else {
+        radius /= decrease_factor; decrease_factor *= 2.0;
+      }
+    }
+    PG_HIP_OK(hipStreamSynchronize(s_));
+    summary[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    summary[1] = x_cost; summary[2] = iteration; summary[3] = termination; summary[4] = successful;
+    // ---- write back, drift update, keyframes after cur (PoseGraph.cpp:340-375 / :504-534)
+    std::vector<double> hy(nn), ht(3 * (size_t)nn), hq(4 * (size_t)nn);
+    PG_HIP_OK(hipMemcpy(hy.data(), p.yaw, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    PG_HIP_OK(hipMemcpy(ht.data(), p.t, sizeof(double) * 3 * nn, hipMemcpyDeviceToHost));
+    PG_HIP_OK(hipMemcpy(hq.data(), p.q, sizeof(double) * 4 * nn, hipMemcpyDeviceToHost));
+    writeBack(hy, pitch, roll, ht, hq, kfOfLocal, cur);
+    return 1;
+  }
+
+  void writeBack(const std::vector<double>& hy, const std::vector<double>& pitch, const std::vector<double>& roll,
+                 const std::vector<double>& ht, const std::vector<double>& hq, const std::vector<int>& kfOfLocal, int cur) {
+    const int nn = (int)kfOfLocal.size();
+    for (int k = 0; k < nn; ++k) {
+      Keyframe& kf = kfs[kfOfLocal[k]];
+      for (int c = 0; c < 3; ++c) kf.P[c] = ht[3 * k + c];
+      if (!six_) {
+        double Rm[9], qq[4];
+        hostYpr2R(hy[k], pitch[k], roll[k], Rm);
+        hostR2q(Rm, qq);   // tmp_q = ypr2R(...); tmp_r = tmp_q.toRotationMatrix()
+        hostQ2R(qq, kf.Rp);
+      } else {
+        hostQ2R(&hq[4 * k], kf.Rp);
+      }
+    }
+    if (nn == 0 || kfs[kfOfLocal[nn - 1]].index != cur) return;
+    const Keyframe& ck = kfs[kfOfLocal[nn - 1]];
+    double Rs[9];
+    hostQ2R(ck.q, Rs);
+    if (!six_) {
+      yawDrift = hostYawOfR(ck.Rp) - hostYawOfR(Rs);
+      hostYpr2R(yawDrift, 0, 0, rDrift);
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) rDrift[3 * r + c] = ck.Rp[r] * Rs[c] + ck.Rp[3 + r] * Rs[3 + c] + ck.Rp[6 + r] * Rs[6 + c];
+      yawDrift = hostYawOfR(rDrift);
+    }
+    for (int r = 0; r < 3; ++r)
+      tDrift[r] = ck.P[r] - (rDrift[3 * r] * ck.t[0] + rDrift[3 * r + 1] * ck.t[1] + rDrift[3 * r + 2] * ck.t[2]);
+    for (size_t k = (size_t)kfOfLocal[nn - 1] + 1; k < kfs.size(); ++k) applyDrift(kfs[k]);
+  }
+
+ private:
+  bool six_;
+  int maxIter_;
+  hipStream_t s_ = nullptr;
+  Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
+  Buf<double> dRes_, dJa_, dJb_, dH_, dVec_, dChol_, dPartial_, dScal_;
+  Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_;
+  Buf<SolverScalars> dSolScal_;
+};
+
+}  // namespace pg
+}  // namespace svin
+
+// ---------------------------------------------------------------- C ABI
+struct svin_pg {
+  svin::pg::PoseGraph g;
+  svin_pg(int device, bool six, int it) : g(device, six, it) {}
+};
+static thread_local std::string g_pgError;
+extern "C" {
+svin_pg* svin_pg_create(int device, int six_dof, int max_iterations) {
+  try {
+    return new svin_pg(device, six_dof != 0, max_iterations);
+  } catch (const std::exception& e) {
+    g_pgError = e.what();
+    return nullptr;
+  }
+}
+void svin_pg_destroy(svin_pg* h) { delete h; }
+const char* svin_pg_last_error(void) { return g_pgError.c_str(); }
+int svin_pg_add_keyframe(svin_pg* h, int index, int sequence, const double* t, const double* q, int loop_index,
+                         const double* loop_rel_t, const double* loop_rel_q, double loop_rel_yaw_deg) {
+  if (!h || !t || !q) return -1;
+  svin::pg::Keyframe kf;
+  kf.index = index; kf.sequence = sequence;
+  std::memcpy(kf.t, t, sizeof(kf.t));
+  std::memcpy(kf.q, q, sizeof(kf.q));
+  if (loop_index >= 0) {
+    if (!loop_rel_t || !loop_rel_q) return -1;
+    kf.hasLoop = true; kf.loopIndex = loop_index;
+    std::memcpy(kf.loopT, loop_rel_t, sizeof(kf.loopT));
+    std::memcpy(kf.loopQ, loop_rel_q, sizeof(kf.loopQ));
+    kf.loopYaw = loop_rel_yaw_deg;
+  }
+  h->g.applyDrift(kf);
+  h->g.kfs.push_back(kf);
+  return 1;
+}
+int svin_pg_num_keyframes(const svin_pg* h) { return h ? (int)h->g.kfs.size() : -1; }
+int svin_pg_optimize(svin_pg* h, int earliest_loop_index, int cur_index) {
+  if (!h) return -1;
+  try {
+    return h->g.optimize(earliest_loop_index, cur_index);
+  } catch (const std::exception& e) {
+    g_pgError = e.what();
+    return -3;
+  }
+}
+int svin_pg_get_pose(const svin_pg* h, int k, double* t, double* q) {
+  if (!h || k < 0 || k >= (int)h->g.kfs.size()) return -2;
+  if (t) std::memcpy(t, h->g.kfs[k].P, sizeof(double) * 3);
+  if (q) svin::pg::hostR2q(h->g.kfs[k].Rp, q);
+  return 1;
+}
+int svin_pg_get_poses(const svin_pg* h, int n, double* t, double* q) {
+  if (!h || n < 0 || n > (int)h->g.kfs.size()) return -2;
+  for (int k = 0; k < n; ++k) {
+    if (t) std::memcpy(t + 3 * (size_t)k, h->g.kfs[k].P, sizeof(double) * 3);
+    if (q) svin::pg::hostR2q(h->g.kfs[k].Rp, q + 4 * (size_t)k);
+  }
+  return 1;
+}
+int svin_pg_get_drift(const svin_pg* h, double* yaw_drift_deg, double* r_drift, double* t_drift) {
+  if (!h) return -1;
+  if (yaw_drift_deg) *yaw_drift_deg = h->g.yawDrift;
+  if (r_drift) std::memcpy(r_drift, h->g.rDrift, sizeof(double) * 9);
+  if (t_drift) std::memcpy(t_drift, h->g.tDrift, sizeof(double) * 3);
+  return 1;
+}
+int svin_pg_summary(const svin_pg* h, double* out6) {
+  if (!h || !out6) return -1;
+  std::memcpy(out6, h->g.summary, sizeof(double) * 6);
+  return 1;
+}
+}

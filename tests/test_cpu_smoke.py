@@ -17,6 +17,31 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(estimator.EXPORTS)
 
 
+def test_library_exports_every_pose_graph_symbol():
+    from svin_amd import estimator, posegraph
+    lib = estimator.load_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "svin_pg.h")).read()
+    declared = sorted(set(re.findall(r"\b(svin_pg_[a-zA-Z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 10
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(declared) == set(posegraph.PG_EXPORTS)
+
+
+def test_pose_graph_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    from svin_amd import posegraph
+    try:
+        posegraph.PoseGraph(0)
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e) or "HIP" in str(e)
+    else:
+        raise AssertionError("creating a pose graph without a GPU must fail")
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

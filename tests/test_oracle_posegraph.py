@@ -79,3 +79,28 @@ def test_reference_iteration_limits_and_fixed_first_keyframe():
         T, Q = pg.poses()
         assert np.allclose(T[earliest], spec.t_svin[earliest])  # constant block (PoseGraph.cpp:286-289 / :449-452)
         assert np.allclose(T[:earliest], spec.t_svin[:earliest])  # keyframes before the earliest loop are untouched
+
+
+@pytest.mark.parametrize("six", [False, True])
+def test_drift_moves_later_keyframes_and_reoptimisation_starts_from_svin_poses(six):
+    """PoseGraph.cpp:127-132 (addKeyframe applies the drift), :262-275 (the problem is built from getSVInPose),
+    :356-375 (drift from the current keyframe, applied to the keyframes after it)"""
+    spec = spg.make_pose_graph(n=200, laps=2, loop_every=20, seed=4)
+    pg = orc.OraclePoseGraph(six_dof=six)
+    for k in range(150):
+        pg.add_keyframe(k, 1, spec.t_svin[k], spec.q_svin[k], spec.loops.get(k))
+    earliest = min(v[0] for k, v in spec.loops.items() if k <= 120)
+    s1 = pg.optimize(earliest, 120)
+    T1, Q1 = pg.poses()
+    yaw, r, t = pg.drift()
+    cur_svin = spec.t_svin[120]
+    assert np.allclose(T1[120], r @ cur_svin + t, atol=1e-12)          # t_drift's definition
+    assert np.allclose(T1[121:150], spec.t_svin[121:150] @ r.T + t, atol=1e-12)
+    assert np.allclose(T1[:earliest], spec.t_svin[:earliest])           # before the earliest loop: untouched
+    for k in range(150, 200):                                             # new keyframes arrive drift-corrected
+        pg.add_keyframe(k, 1, spec.t_svin[k], spec.q_svin[k], spec.loops.get(k))
+    T2, _ = pg.poses()
+    assert np.allclose(T2[150:], spec.t_svin[150:] @ r.T + t, atol=1e-12)
+    # a second pass over the same range starts from the SVIn poses again: identical summary
+    s2 = pg.optimize(earliest, 120)
+    assert s2["initial_cost"] == s1["initial_cost"] and s2["final_cost"] == s1["final_cost"]
