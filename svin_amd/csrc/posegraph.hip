@@ -3,18 +3,26 @@
 //
 //   host    keyframe list -> local problem exactly like the reference (sequential edges to the 2 / 4 predecessors of
 //           the same sequence, loop edges, constant first keyframe), Levenberg-Marquardt control flow of Ceres 2.2
-//           (TrustRegionMinimizer + LevenbergMarquardtStrategy, default options), one scalar read-back per iteration
-//   device  k_pg_eval     one thread per edge: FourDOFError / FourDOFWeightError / PoseGraph3dErrorTerm residual,
-//                         analytic minimal Jacobians (the reference uses AutoDiff: same derivatives), HuberLoss(0.1)
-//                         corrector on loop edges, cost partials
-//           k_pg_node     one thread per free keyframe: gradient, column norms, Jacobi scaling, diagonal block of
-//                         the damped normal equations (incident edges in fixed order: deterministic)
-//           k_pg_offdiag  one thread per edge: the off-diagonal block J_b^T J_a
-//           solve         the dense reduced-system solver of the BA backend (LDS-resident or multi-workgroup
-//                         blocked Cholesky on v_mfma_f64_16x16x4_f64, kernels.hip launchSolveReduced)
+//           (TrustRegionMinimizer + LevenbergMarquardtStrategy, default options), one scalar read-back per iteration;
+//           symbolic step once per call: the keyframe chain is cut into pieces (<= 64 keyframes) by separators =
+//           w consecutive keyframes every piece (w = 2 / 4, the reach of the sequential edges) + a vertex cover of
+//           the long (loop) edges, so that every piece's interior only talks to itself and to separators
+//   device  k_pg_eval            one thread per edge: FourDOFError / FourDOFWeightError / PoseGraph3dErrorTerm
+//                                residual, analytic minimal Jacobians (the reference uses AutoDiff: same derivatives),
+//                                HuberLoss(0.1) corrector on loop edges, cost partials
+//           k_pg_node            one thread per free keyframe: gradient, column norms, Jacobi scaling, J^T J block
+//                                (incident edges in fixed order: deterministic)
+//           k_pg_assemble_*      damped normal equations scattered into: the dense separator system, the pieces'
+//                                banded interior blocks, the pieces' interior x separator coupling columns
+//           k_pg_piece_factor    one workgroup per piece: banded Cholesky in LDS, forward substitution of the coupling
+//                                and right-hand-side columns (one column per thread): Y = L^-1 [C | r]
+//           k_pg_piece_schur     Y^T Y per piece (16x16 tiles), k_pg_sep_gather subtracts them from the separator
+//                                system in a fixed order (deterministic)
+//           solve                the dense reduced-system solver of the BA backend on the separator system (LDS-
+//                                resident or multi-workgroup blocked Cholesky on v_mfma_f64_16x16x4_f64, kernels.hip)
+//           k_pg_piece_back      interior unknowns: x_I = L^-T (y_r - Y_C x_S)
 //           k_pg_model / k_pg_plus / k_pg_reduce   model cost change, candidate = Plus(x, delta), norms
-// Stage 2a (this file): every free keyframe is an unknown of one dense system (graphs up to a few thousand unknowns);
-// the segment / separator elimination for config-#5-sized graphs builds on the same kernels.
+// Graphs with <= 128 free keyframes skip the pieces (every keyframe is a separator: one dense solve).
 #include "kernels.hpp"
 #include "dmath.hpp"
 #include "../../include/svin_pg.h"
@@ -38,8 +46,14 @@ namespace pg {
 
 constexpr double kPgPi = 3.14159265358979323846;
 
+struct PgPiece {
+  int rows, cols, ld, colPtr;          // interior unknowns, coupling columns + 1 (rhs last), row stride of Y / S_p
+  int rowPtr, pad;
+  long long bandOff, yOff, sOff;       // offsets (doubles) into band / Y / Sp
+};
 struct PgDev {
   int nn, ne, n, m, six, D, R;
+  int BW, nS, nPieces, maxRows;         // band half-width (elements), separator unknowns, pieces, max interior rows
   double *yaw, *pitch, *roll, *t, *q;   // current point (yaw in degrees; q = [x y z w])
   double *yawC, *tC, *qC;               // candidate
   int* off;                             // tangent offset per node, -1 = constant
@@ -47,8 +61,19 @@ struct PgDev {
   double *et, *eyaw, *epitch, *eroll, *eq, *esq;
   double *res, *Ja, *Jb;                // robustified residuals and Jacobian blocks (R x D per edge and side)
   int *nodePtr, *nodeEdge;              // incident edges per node: edge * 2 + side (0 = a, 1 = b)
-  double *H, *rhs, *scale, *g, *colsq, *y, *delta;
+  double *scale, *g, *colsq, *nodeBlk, *y, *delta;
   double *partial, *scal;
+  // partition
+  int* sepOff;                          // per node: offset in the separator system, -1 = interior / constant
+  int *nodePiece, *nodeRow;             // per node: piece and first interior row, -1 = not interior
+  const PgPiece* pieces;
+  int4* edgeDst;                        // {kind | rowIsB << 4, piece, rowOff, colOff}; kind 0 none, 1 sep-sep, 2 band, 3 coupling
+  int *colSep, *rowTan;                 // per piece column -> separator offset; per piece row -> tangent index
+  int4* tileWork;                       // {piece, ti, tj, 0}
+  int *gPtr; int2* gDst; int4* gSrc;    // separator block <- sum of piece Schur blocks {piece, rowOff, colOff, 0}
+  int *rPtr; int2* rSrc;                // separator node rhs <- {piece, colOff}
+  double *band, *Y, *Sp, *HS, *rhsS, *yS;
+  int* fail;
 };
 enum PgScal : int { PG_COST = 0, PG_GRADMAX = 1, PG_MODEL = 2, PG_STEP2 = 3, PG_X2 = 4, PG_NSCAL = 8 };
 constexpr int kPgMaxPartials = 4096;
@@ -198,8 +223,8 @@ __global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac)
   if (threadIdx.x == 0) p.partial[PG_COST * kPgMaxPartials + blockIdx.x] = bs;
 }
 
-// one thread per node: gradient, column norms, (first iteration) Jacobi scaling, damped diagonal block, rhs
-__global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale, double radius) {
+// one thread per node: gradient, column norms, (first iteration) Jacobi scaling, raw J^T J block
+__global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale) {
   __shared__ double red[2];
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double gmax = 0;
@@ -222,43 +247,218 @@ __global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale, double 
         }
       }
     }
-    double sc[6];
     for (int c = 0; c < D; ++c) {
-      if (initScale) { sc[c] = 1.0 / (1.0 + sqrt(blk[c * D + c])); p.scale[o + c] = sc[c]; }
-      else sc[c] = p.scale[o + c];
+      if (initScale) p.scale[o + c] = 1.0 / (1.0 + sqrt(blk[c * D + c]));
       p.g[o + c] = g[c];
       p.colsq[o + c] = blk[c * D + c];
-      p.rhs[o + c] = g[c] * sc[c];
       gmax = fmax(gmax, fabs(g[c]));
     }
-    for (int c1 = 0; c1 < D; ++c1)
-      for (int c2 = 0; c2 < D; ++c2) {
-        double v = blk[c1 * D + c2] * sc[c1] * sc[c2];
-        if (c1 == c2) v += fmin(fmax(blk[c1 * D + c1] * sc[c1] * sc[c1], 1e-6), 1e32) / radius;  // LM diagonal
-        p.H[(size_t)(o + c1) * p.n + o + c2] = v;
-      }
+    for (int i = 0; i < D * D; ++i) p.nodeBlk[(size_t)k * 36 + i] = blk[i];
   }
   const double bm = pgBlockMax(gmax, red);
   if (threadIdx.x == 0) p.partial[PG_GRADMAX * kPgMaxPartials + blockIdx.x] = bm;
 }
 
-// one thread per edge: off-diagonal block (rows of b, columns of a) = J_b^T J_a, and its transpose
-__global__ void k_pg_offdiag(PgDev p) {
+// damped, scaled diagonal block and right-hand side of one free node -> separator system or its piece
+__global__ void k_pg_assemble_nodes(PgDev p, double radius) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.nn || p.off[k] < 0) return;
+  const int D = p.D, o = p.off[k], so = p.sepOff[k];
+  const double* blk = p.nodeBlk + (size_t)k * 36;
+  double sc[6];
+  for (int c = 0; c < D; ++c) sc[c] = p.scale[o + c];
+  const PgPiece pc = so < 0 ? p.pieces[p.nodePiece[k]] : PgPiece{};
+  const int row = so < 0 ? p.nodeRow[k] : 0, LDB = p.BW + 1;
+  for (int c1 = 0; c1 < D; ++c1) {
+    for (int c2 = 0; c2 <= c1; ++c2) {
+      double v = blk[c1 * D + c2] * sc[c1] * sc[c2];
+      if (c1 == c2) v += fmin(fmax(blk[c1 * D + c1] * sc[c1] * sc[c1], 1e-6), 1e32) / radius;  // LM diagonal
+      if (so >= 0) p.HS[(size_t)(so + c1) * p.nS + so + c2] = v;
+      else p.band[pc.bandOff + (size_t)(row + c1) * LDB + (c2 - c1 + p.BW)] = v;
+    }
+    const double r = p.g[o + c1] * sc[c1];
+    if (so >= 0) p.rhsS[so + c1] = r;
+    else p.Y[pc.yOff + (size_t)(row + c1) * pc.ld + pc.cols - 1] = r;
+  }
+}
+
+// one thread per edge between two free nodes: the off-diagonal block J_b^T J_a (rows of b, columns of a), scaled,
+// added to its destination.  At most two edges share a destination block (a sequential and a loop edge between the
+// same pair), so the atomic adds commute exactly.
+__global__ void k_pg_assemble_edges(PgDev p) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.ne) return;
+  const int4 dst = p.edgeDst[e];
+  const int kind = dst.x & 15, rowIsB = (dst.x >> 4) & 1;
+  if (kind == 0) return;
   const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
-  if (oa < 0 || ob < 0) return;
   const int D = p.D, R = p.R;
   const double* Ja = p.Ja + (size_t)e * R * D;
   const double* Jb = p.Jb + (size_t)e * R * D;
+  double* base;
+  size_t ld;
+  if (kind == 1) { base = p.HS + (size_t)dst.z * p.nS + dst.w; ld = p.nS; }
+  else {
+    const PgPiece pc = p.pieces[dst.y];
+    if (kind == 2) { base = p.band + pc.bandOff + (size_t)dst.z * (p.BW + 1) + (dst.w - dst.z + p.BW); ld = p.BW; }  // (r, c) -> r * LDB + c - r + BW
+    else { base = p.Y + pc.yOff + (size_t)dst.z * pc.ld + dst.w; ld = pc.ld; }
+  }
   for (int c1 = 0; c1 < D; ++c1)
     for (int c2 = 0; c2 < D; ++c2) {
       double s = 0;
       for (int q = 0; q < R; ++q) s += Jb[q * D + c1] * Ja[q * D + c2];
       s *= p.scale[ob + c1] * p.scale[oa + c2];
-      p.H[(size_t)(ob + c1) * p.n + oa + c2] = s;
-      p.H[(size_t)(oa + c2) * p.n + ob + c1] = s;
+      const int r = rowIsB ? c1 : c2, c = rowIsB ? c2 : c1;
+      atomicAdd(base + (size_t)r * ld + c, s);
     }
+}
+
+// ---------------------------------------------------------------- pieces
+constexpr int kPgRing = 32;          // rows of forward-substitution history kept in LDS (> BW)
+constexpr int kPgPieceThreads = 256; // = max coupling columns + 1 of a piece
+
+// banded Cholesky of the piece's interior block (band storage, row r holds columns r-BW..r) and Y = L^-1 [C | r]
+__global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
+  extern __shared__ double sm[];
+  const PgPiece pc = p.pieces[blockIdx.x];
+  const int n = pc.rows, BW = p.BW, LDB = BW + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* Lb = sm;
+  double* dinv = Lb + (size_t)p.maxRows * LDB;
+  double* ring = dinv + p.maxRows;
+  unsigned short* tab = reinterpret_cast<unsigned short*>(ring + (size_t)kPgRing * kPgPieceThreads);
+  double* band = p.band + pc.bandOff;
+  for (int i = tid; i < n * LDB; i += kPgPieceThreads) Lb[i] = band[i];
+  const int nPairs = BW * (BW + 1) / 2;
+  for (int i = tid; i < nPairs; i += kPgPieceThreads) {   // (s, t), 1 <= t <= s <= BW
+    int s_ = 1, rem = i;
+    while (rem >= s_) { rem -= s_; ++s_; }
+    tab[i] = (unsigned short)(s_ | ((rem + 1) << 8));
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int bad = 0;
+    for (int j = 0; j < n; ++j) {
+      const double ajj = Lb[j * LDB + BW];
+      const bool ok = ajj > 0.0;
+      bad |= ok ? 0 : 1;
+      const double d = sqrt(ok ? ajj : 1.0), di = 1.0 / d;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { Lb[j * LDB + BW] = d; dinv[j] = di; }
+      else if (lane <= BW && j + lane < n) Lb[(j + lane) * LDB + BW - lane] *= di;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int pi = lane; pi < nPairs; pi += 64) {
+        const int s_ = tab[pi] & 255, t_ = tab[pi] >> 8;
+        if (j + s_ < n) Lb[(j + s_) * LDB + BW - (s_ - t_)] -= Lb[(j + s_) * LDB + BW - s_] * Lb[(j + t_) * LDB + BW - t_];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (bad && lane == 0) atomicOr(p.fail, 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < n * LDB; i += kPgPieceThreads) band[i] = Lb[i];
+  if (tid < pc.cols) {
+    double* Yc = p.Y + pc.yOff + tid;
+    double* rg = ring + tid;
+    for (int r0 = 0; r0 < n; r0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r0 + u < n ? Yc[(size_t)(r0 + u) * pc.ld] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r < n) {
+          double x = v[u];
+          const int k0 = r > BW ? r - BW : 0;
+          for (int k = k0; k < r; ++k) x -= Lb[r * LDB + (k - r + BW)] * rg[(k & (kPgRing - 1)) * kPgPieceThreads];
+          x *= dinv[r];
+          rg[(r & (kPgRing - 1)) * kPgPieceThreads] = x;
+          Yc[(size_t)r * pc.ld] = x;
+        }
+      }
+    }
+  }
+}
+
+// S_p = Y^T Y, one 16x16 tile per workgroup (lower tiles only; the rhs column is the last row of S_p)
+__global__ __launch_bounds__(256) void k_pg_piece_schur(PgDev p) {
+  const int4 wk = p.tileWork[blockIdx.x];
+  const PgPiece pc = p.pieces[wk.x];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const double* Ya = p.Y + pc.yOff + 16 * wk.y + ty;
+  const double* Yb = p.Y + pc.yOff + 16 * wk.z + tx;
+  double acc = 0;
+#pragma unroll 8
+  for (int r = 0; r < pc.rows; ++r) acc += Ya[(size_t)r * pc.ld] * Yb[(size_t)r * pc.ld];
+  p.Sp[pc.sOff + (size_t)(16 * wk.y + ty) * pc.ld + 16 * wk.z + tx] = acc;
+}
+
+// separator system -= sum over pieces of their Schur blocks, contributions in the host's fixed order
+__global__ void k_pg_sep_gather(PgDev p, int nDest) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, DD = p.D * p.D;
+  if (idx >= nDest * DD) return;
+  const int b = idx / DD, e = idx - b * DD, r = e / p.D, c = e - r * p.D;
+  const int2 dst = p.gDst[b];
+  if (dst.x == dst.y && c > r) return;
+  double acc = 0;
+  for (int i = p.gPtr[b]; i < p.gPtr[b + 1]; ++i) {
+    const int4 src = p.gSrc[i];
+    const PgPiece pc = p.pieces[src.x];
+    acc += p.Sp[pc.sOff + (size_t)(src.y + r) * pc.ld + src.z + c];
+  }
+  p.HS[(size_t)(dst.x + r) * p.nS + dst.y + c] -= acc;
+}
+__global__ void k_pg_sep_gather_rhs(PgDev p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.nS) return;
+  const int sn = idx / p.D, c = idx - sn * p.D;
+  double acc = 0;
+  for (int i = p.rPtr[sn]; i < p.rPtr[sn + 1]; ++i) {
+    const int2 src = p.rSrc[i];
+    const PgPiece pc = p.pieces[src.x];
+    acc += p.Sp[pc.sOff + (size_t)(pc.cols - 1) * pc.ld + src.y + c];
+  }
+  p.rhsS[idx] -= acc;
+}
+
+// interior unknowns of one piece: x_I = L^-T (y_r - Y_C x_S)
+__global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_back(PgDev p) {
+  extern __shared__ double sm[];
+  const PgPiece pc = p.pieces[blockIdx.x];
+  const int n = pc.rows, BW = p.BW, LDB = BW + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* Lb = sm;
+  double* z = Lb + (size_t)p.maxRows * LDB;
+  double* xA = z + p.maxRows;
+  const double* band = p.band + pc.bandOff;
+  for (int i = tid; i < n * LDB; i += kPgPieceThreads) Lb[i] = band[i];
+  for (int c = tid; c < pc.cols - 1; c += kPgPieceThreads) xA[c] = p.yS[p.colSep[pc.colPtr + c]];
+  __syncthreads();
+  const double* Y = p.Y + pc.yOff;
+  for (int r = wave; r < n; r += kPgPieceThreads / 64) {   // one wave per row: coalesced dot product
+    double acc = 0;
+    for (int c = lane; c < pc.cols - 1; c += 64) acc += Y[(size_t)r * pc.ld + c] * xA[c];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) z[r] = Y[(size_t)r * pc.ld + pc.cols - 1] - acc;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int r = n - 1; r >= 0; --r) {
+      const double x = z[r] / Lb[r * LDB + BW];
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) z[r] = x;
+      else if (lane <= BW && r - lane >= 0) z[r - lane] -= Lb[r * LDB + BW - lane] * x;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < n; r += kPgPieceThreads) p.y[p.rowTan[pc.rowPtr + r]] = z[r];
+}
+__global__ void k_pg_scatter_sep(PgDev p) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.nn || p.off[k] < 0 || p.sepOff[k] < 0) return;
+  for (int c = 0; c < p.D; ++c) p.y[p.off[k] + c] = p.yS[p.sepOff[k] + c];
 }
 
 __global__ void k_pg_step(PgDev p) {
@@ -430,7 +630,9 @@ class PoseGraph {
   ~PoseGraph() { if (s_) (void)hipStreamDestroy(s_); }
 
   std::vector<Keyframe> kfs;
-  double summary[6] = {0, 0, 0, 1, 0, 0};
+  double summary[8] = {0, 0, 0, 1, 0, 0, 0, 0};   // [6] = seconds of the symbolic step (host)
+  int partition[5] = {0, 0, 0, 0, 0};             // free keyframes, separator keyframes, pieces, max piece rows, Schur tiles
+  int pieceLen_ = 64, denseNodes_ = 128;
   // drift of the odometry frame against the optimised map (PoseGraph.cpp:356-363 / :521-526)
   double yawDrift = 0, rDrift[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tDrift[3] = {0, 0, 0};
 
@@ -516,6 +718,166 @@ class PoseGraph {
       std::vector<int> curp(nodePtr.begin(), nodePtr.end() - 1);
       for (int e = 0; e < ne; ++e) { nodeEdge[curp[ea[e]]++] = 2 * e; nodeEdge[curp[eb[e]]++] = 2 * e + 1; }
     }
+    const auto tSym0 = std::chrono::steady_clock::now();
+    // ---- symbolic step: separators (cuts of w keyframes + a vertex cover of the long edges) and pieces
+    const int w = six_ ? 4 : 2, BW = w * D + D - 1;
+    const int pieceLen = std::max(8, std::min(pieceLen_, 256 / D));           // interior keyframes per piece
+    const int maxAdj = (kPgPieceThreads - 1) / D;                              // separator keyframes a piece may touch
+    std::vector<int> freeNodes, pos(nn, -1);
+    for (int k = 0; k < nn; ++k)
+      if (!fixed[k]) { pos[k] = (int)freeNodes.size(); freeNodes.push_back(k); }
+    const int F = (int)freeNodes.size();
+    std::vector<char> isSep(nn, 0);
+    std::vector<int> pieceOf(nn, -1);
+    int nPieces = 0;
+    if (F <= denseNodes_) {
+      for (int k : freeNodes) isSep[k] = 1;
+    } else {
+      std::vector<int> longDeg(nn, 0);
+      auto isLong = [&](int e) { return pos[ea[e]] >= 0 && pos[eb[e]] >= 0 && std::abs(pos[ea[e]] - pos[eb[e]]) > w; };
+      for (int e = 0; e < ne; ++e)
+        if (isLong(e)) { longDeg[ea[e]]++; longDeg[eb[e]]++; }
+      for (int e = 0; e < ne; ++e)
+        if (isLong(e) && !isSep[ea[e]] && !isSep[eb[e]]) isSep[longDeg[ea[e]] >= longDeg[eb[e]] ? ea[e] : eb[e]] = 1;
+      // walk the chain: close a piece after pieceLen interior keyframes (or when it touches too many separators)
+      std::vector<int> stamp(nn, -1);
+      int cnt = 0, adj = 2 * w;
+      for (int i = 0; i < F; ++i) {
+        const int k = freeNodes[i];
+        if (isSep[k]) {
+          if (stamp[k] != nPieces) { stamp[k] = nPieces; ++adj; }   // (conservative: counted even if not adjacent)
+          continue;
+        }
+        pieceOf[k] = nPieces;
+        ++cnt;
+        for (int it = nodePtr[k]; it < nodePtr[k + 1]; ++it) {
+          const int e = nodeEdge[it] >> 1, o = (nodeEdge[it] & 1) ? ea[e] : eb[e];
+          if (pos[o] >= 0 && isSep[o] && stamp[o] != nPieces) { stamp[o] = nPieces; ++adj; }
+        }
+        if ((cnt >= pieceLen || adj + 1 >= maxAdj) && i + w < F - 1) {
+          for (int j = 1; j <= w; ++j) isSep[freeNodes[i + j]] = 1;
+          i += w;
+          ++nPieces; cnt = 0; adj = 2 * w;
+        }
+      }
+      if (cnt > 0) ++nPieces;
+      else {  // the walk ended right after a cut (or on separators): the last piece id may be unused
+        bool used = false;
+        for (int k : freeNodes) used |= pieceOf[k] == nPieces;
+        if (used) ++nPieces;
+      }
+    }
+    std::vector<int> sepOff(nn, -1), nodePiece(nn, -1), nodeRow(nn, -1);
+    int nS = 0;
+    for (int k : freeNodes)
+      if (isSep[k]) { sepOff[k] = nS; nS += D; }
+    std::vector<PgPiece> pieces(nPieces);
+    std::vector<std::vector<int>> pieceAdj(nPieces);
+    std::vector<int> rowTan, colSep;
+    {
+      std::vector<int> rows(nPieces, 0);
+      for (int k : freeNodes)
+        if (!isSep[k]) { nodePiece[k] = pieceOf[k]; nodeRow[k] = rows[pieceOf[k]]; rows[pieceOf[k]] += D; }
+      for (int e = 0; e < ne; ++e) {
+        const int a = ea[e], b = eb[e];
+        if (pos[a] < 0 || pos[b] < 0) continue;
+        if (!isSep[a] && !isSep[b] && pieceOf[a] != pieceOf[b]) throw std::runtime_error("svin_pg: partition left an edge between two pieces");
+        if (!isSep[a] && isSep[b]) pieceAdj[pieceOf[a]].push_back(sepOff[b]);
+        if (!isSep[b] && isSep[a]) pieceAdj[pieceOf[b]].push_back(sepOff[a]);
+      }
+      long long bandOff = 0, yOff = 0, sOff = 0;
+      for (int pi = 0; pi < nPieces; ++pi) {
+        auto& A = pieceAdj[pi];
+        std::sort(A.begin(), A.end());
+        A.erase(std::unique(A.begin(), A.end()), A.end());
+        PgPiece& pc = pieces[pi];
+        pc.rows = rows[pi];
+        pc.cols = (int)A.size() * D + 1;
+        if (pc.cols > kPgPieceThreads) throw std::runtime_error("svin_pg: a piece touches too many separators");
+        pc.ld = (pc.cols + 15) / 16 * 16;
+        pc.colPtr = (int)colSep.size();
+        pc.rowPtr = (int)rowTan.size();
+        pc.pad = 0;
+        pc.bandOff = bandOff; pc.yOff = yOff; pc.sOff = sOff;
+        bandOff += (long long)pc.rows * (BW + 1);
+        yOff += (long long)pc.rows * pc.ld;
+        sOff += (long long)pc.ld * pc.ld;
+        for (int so : A)
+          for (int c = 0; c < D; ++c) colSep.push_back(so + c);
+        rowTan.resize(rowTan.size() + pc.rows);
+      }
+      for (int k : freeNodes)
+        if (!isSep[k])
+          for (int c = 0; c < D; ++c) rowTan[pieces[pieceOf[k]].rowPtr + nodeRow[k] + c] = off[k] + c;
+    }
+    auto colOf = [&](int pi, int so) {
+      const auto& A = pieceAdj[pi];
+      return (int)(std::lower_bound(A.begin(), A.end(), so) - A.begin()) * D;
+    };
+    std::vector<int4> edgeDst(ne);
+    for (int e = 0; e < ne; ++e) {
+      const int a = ea[e], b = eb[e];
+      int4 d4 = make_int4(0, 0, 0, 0);
+      if (pos[a] >= 0 && pos[b] >= 0) {
+        if (isSep[a] && isSep[b]) {
+          const bool rowB = sepOff[b] > sepOff[a];
+          d4 = make_int4(1 | (rowB ? 16 : 0), 0, rowB ? sepOff[b] : sepOff[a], rowB ? sepOff[a] : sepOff[b]);
+        } else if (!isSep[a] && !isSep[b]) {
+          const bool rowB = nodeRow[b] > nodeRow[a];
+          d4 = make_int4(2 | (rowB ? 16 : 0), pieceOf[a], rowB ? nodeRow[b] : nodeRow[a], rowB ? nodeRow[a] : nodeRow[b]);
+        } else {
+          const bool rowB = !isSep[b];   // the interior node owns the rows
+          const int in = rowB ? b : a, sp = rowB ? a : b;
+          d4 = make_int4(3 | (rowB ? 16 : 0), pieceOf[in], nodeRow[in], colOf(pieceOf[in], sepOff[sp]));
+        }
+      }
+      edgeDst[e] = d4;
+    }
+    // work lists: Schur tiles, and per separator block / separator keyframe the pieces that contribute to it
+    std::vector<int4> tileWork, gSrc;
+    std::vector<int2> gDst, rSrc;
+    std::vector<int> gPtr(1, 0), rPtr(nS / D + 1, 0);
+    {
+      struct Contrib { long long key; int piece, ro, co; };
+      std::vector<Contrib> cs;
+      std::vector<std::vector<int2>> rl(nS / D);
+      for (int pi = 0; pi < nPieces; ++pi) {
+        const PgPiece& pc = pieces[pi];
+        const int nt = pc.ld / 16;
+        for (int ti = 0; ti < nt; ++ti)
+          for (int tj = 0; tj <= ti; ++tj) tileWork.push_back(make_int4(pi, ti, tj, 0));
+        const auto& A = pieceAdj[pi];
+        for (size_t i = 0; i < A.size(); ++i) {
+          rl[A[i] / D].push_back(make_int2(pi, (int)i * D));
+          for (size_t j = 0; j <= i; ++j)
+            cs.push_back({(long long)A[i] * nS + A[j], pi, (int)i * D, (int)j * D});
+        }
+      }
+      std::stable_sort(cs.begin(), cs.end(), [](const Contrib& x, const Contrib& y) { return x.key < y.key; });
+      for (size_t i = 0; i < cs.size(); ++i) {
+        if (i == 0 || cs[i].key != cs[i - 1].key) {
+          if (i) gPtr.push_back((int)gSrc.size());
+          gDst.push_back(make_int2((int)(cs[i].key / nS), (int)(cs[i].key % nS)));
+        }
+        gSrc.push_back(make_int4(cs[i].piece, cs[i].ro, cs[i].co, 0));
+      }
+      if (!cs.empty()) gPtr.push_back((int)gSrc.size());
+      for (int sn = 0; sn < nS / D; ++sn) {
+        rPtr[sn + 1] = rPtr[sn] + (int)rl[sn].size();
+        rSrc.insert(rSrc.end(), rl[sn].begin(), rl[sn].end());
+      }
+    }
+    const int nDest = (int)gDst.size();
+    int maxRows = 0;
+    size_t bandTot = 1, yTot = 1, spTot = 1;
+    for (const PgPiece& pc : pieces) {
+      maxRows = std::max(maxRows, pc.rows);
+      bandTot = (size_t)(pc.bandOff + (long long)pc.rows * (BW + 1));
+      yTot = (size_t)(pc.yOff + (long long)pc.rows * pc.ld);
+      spTot = (size_t)(pc.sOff + (long long)pc.ld * pc.ld);
+    }
+    partition[0] = F; partition[1] = nS / D; partition[2] = nPieces; partition[3] = maxRows; partition[4] = (int)tileWork.size();
+    summary[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tSym0).count();
     // ---- upload
     dYaw_.upload(yaw, s_); dPitch_.upload(pitch, s_); dRoll_.upload(roll, s_); dT_.upload(t, s_); dQ_.upload(q, s_);
     dYawC_.reserve(nn); dTC_.reserve(3 * (size_t)nn); dQC_.reserve(4 * (size_t)nn);
@@ -523,39 +885,57 @@ class PoseGraph {
     dEt_.upload(et, s_); dEyaw_.upload(eyaw, s_); dEpitch_.upload(epitch, s_); dEroll_.upload(eroll, s_);
     dEq_.upload(eq, s_); dEsq_.upload(esq, s_);
     dNodePtr_.upload(nodePtr, s_); dNodeEdge_.upload(nodeEdge, s_);
+    dSepOff_.upload(sepOff, s_); dNodePiece_.upload(nodePiece, s_); dNodeRow_.upload(nodeRow, s_);
+    dPieces_.upload(pieces, s_); dEdgeDst_.upload(edgeDst, s_); dColSep_.upload(colSep, s_); dRowTan_.upload(rowTan, s_);
+    dTileWork_.upload(tileWork, s_); dGPtr_.upload(gPtr, s_); dGDst_.upload(gDst, s_); dGSrc_.upload(gSrc, s_);
+    dRPtr_.upload(rPtr, s_); dRSrc_.upload(rSrc, s_);
     const size_t RD = (size_t)R * D;
     dRes_.reserve((size_t)ne * R); dJa_.reserve(ne * RD); dJb_.reserve(ne * RD);
-    const int dpad = ((n + 15) / 16) * 16;
-    const size_t dp64 = ((size_t)n + 63) / 64 * 64;
-    dH_.reserve((size_t)n * n); dVec_.reserve((size_t)8 * n + 64);
+    const int dpad = ((nS + 15) / 16) * 16;
+    const size_t dp64 = ((size_t)nS + 63) / 64 * 64;
+    dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
+    dBand_.reserve(bandTot); dY_.reserve(yTot); dSp_.reserve(spTot);
     dChol_.reserve(std::max((size_t)dpad * dpad, (dp64 + 64) * dp64 + dp64 + dp64 * 64));
     dPartial_.reserve((size_t)8 * kPgMaxPartials); dScal_.reserve(PG_NSCAL); dSolScal_.reserve(1);
     PgDev p;
     std::memset(&p, 0, sizeof(p));
     p.nn = nn; p.ne = ne; p.n = n; p.m = ne * R; p.six = six_ ? 1 : 0; p.D = D; p.R = R;
+    p.BW = BW; p.nS = nS; p.nPieces = nPieces; p.maxRows = maxRows;
     p.yaw = dYaw_.p; p.pitch = dPitch_.p; p.roll = dRoll_.p; p.t = dT_.p; p.q = dQ_.p;
     p.yawC = dYawC_.p; p.tC = dTC_.p; p.qC = dQC_.p;
     p.off = dOff_.p; p.ea = dEa_.p; p.eb = dEb_.p; p.eloop = dEloop_.p;
     p.et = dEt_.p; p.eyaw = dEyaw_.p; p.epitch = dEpitch_.p; p.eroll = dEroll_.p; p.eq = dEq_.p; p.esq = dEsq_.p;
     p.res = dRes_.p; p.Ja = dJa_.p; p.Jb = dJb_.p; p.nodePtr = dNodePtr_.p; p.nodeEdge = dNodeEdge_.p;
-    p.H = dH_.p;
-    p.rhs = dVec_.p; p.scale = dVec_.p + n; p.g = dVec_.p + 2 * (size_t)n; p.colsq = dVec_.p + 3 * (size_t)n;
-    p.y = dVec_.p + 4 * (size_t)n; p.delta = dVec_.p + 5 * (size_t)n;
-    double* ones = dVec_.p + 6 * (size_t)n;    // htilC stand-in for the solver's v_C output
-    double* vdump = dVec_.p + 7 * (size_t)n;
+    p.scale = dVec_.p; p.g = dVec_.p + n; p.colsq = dVec_.p + 2 * (size_t)n; p.y = dVec_.p + 3 * (size_t)n;
+    p.delta = dVec_.p + 4 * (size_t)n;
+    p.rhsS = dVec_.p + 5 * (size_t)n; p.yS = p.rhsS + nS;
+    double* ones = p.yS + nS;    // htilC stand-in for the solver's v_C output
+    double* vdump = ones + nS;
+    p.nodeBlk = dNodeBlk_.p;
     p.partial = dPartial_.p; p.scal = dScal_.p;
+    p.sepOff = dSepOff_.p; p.nodePiece = dNodePiece_.p; p.nodeRow = dNodeRow_.p; p.pieces = dPieces_.p;
+    p.edgeDst = dEdgeDst_.p; p.colSep = dColSep_.p; p.rowTan = dRowTan_.p; p.tileWork = dTileWork_.p;
+    p.gPtr = dGPtr_.p; p.gDst = dGDst_.p; p.gSrc = dGSrc_.p; p.rPtr = dRPtr_.p; p.rSrc = dRSrc_.p;
+    p.band = dBand_.p; p.Y = dY_.p; p.Sp = dSp_.p; p.HS = dHS_.p;
+    p.fail = &dSolScal_.p->cholFail;
     {
-      std::vector<double> one(n, 1.0);
-      PG_HIP_OK(hipMemcpyAsync(ones, one.data(), sizeof(double) * n, hipMemcpyHostToDevice, s_));
+      std::vector<double> one(nS, 1.0);
+      PG_HIP_OK(hipMemcpyAsync(ones, one.data(), sizeof(double) * nS, hipMemcpyHostToDevice, s_));
       PG_HIP_OK(hipStreamSynchronize(s_));
     }
-    // the dense solver of the BA backend sees the system through a DeviceProblem view
+    // the dense solver of the BA backend sees the separator system through a DeviceProblem view
     DeviceProblem dp;
     std::memset(&dp, 0, sizeof(dp));
-    dp.d = n; dp.S = p.H; dp.gRed = p.rhs; dp.gFull = p.rhs; dp.htilC = ones; dp.yC = p.y; dp.vC = vdump;
+    dp.d = nS; dp.S = p.HS; dp.gRed = p.rhsS; dp.gFull = p.rhsS; dp.htilC = ones; dp.yC = p.yS; dp.vC = vdump;
     dp.cholL = dChol_.p; dp.scal = dSolScal_.p;
     const int gE = (ne + 127) / 128, gN = (nn + 127) / 128;
     if (gE > kPgMaxPartials || gN > kPgMaxPartials) throw std::runtime_error("svin_pg: graph too large for the reduction scratch");
+    const size_t ldsFactor = ((size_t)maxRows * (BW + 2) + (size_t)kPgRing * kPgPieceThreads) * 8 + (size_t)BW * (BW + 1);
+    const size_t ldsBack = ((size_t)maxRows * (BW + 2) + kPgPieceThreads) * 8;
+    if (nPieces > 0) {
+      (void)hipFuncSetAttribute((const void*)k_pg_piece_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFactor);
+      (void)hipFuncSetAttribute((const void*)k_pg_piece_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
+    }
     auto readScal = [&](double* out) {
       PG_HIP_OK(hipMemcpyAsync(out, p.scal, sizeof(double) * PG_NSCAL, hipMemcpyDeviceToHost, s_));
       PG_HIP_OK(hipStreamSynchronize(s_));
@@ -563,6 +943,26 @@ class PoseGraph {
     auto evalCost = [&](bool cand, bool withJac) {
       hipLaunchKernelGGL(k_pg_eval, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
+    };
+    // damped normal equations at the current linearisation -> y (tangent order, scaled space)
+    auto solveNormalEquations = [&](double radius) {
+      PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * (size_t)nS * nS, s_));
+      PG_HIP_OK(hipMemsetAsync(dSolScal_.p, 0, sizeof(SolverScalars), s_));
+      if (nPieces > 0) {
+        PG_HIP_OK(hipMemsetAsync(p.band, 0, sizeof(double) * bandTot, s_));
+        PG_HIP_OK(hipMemsetAsync(p.Y, 0, sizeof(double) * yTot, s_));
+      }
+      hipLaunchKernelGGL(k_pg_assemble_nodes, dim3(gN), dim3(128), 0, s_, p, radius);
+      hipLaunchKernelGGL(k_pg_assemble_edges, dim3(gE), dim3(128), 0, s_, p);
+      if (nPieces > 0) {
+        hipLaunchKernelGGL(k_pg_piece_factor, dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
+        hipLaunchKernelGGL(k_pg_piece_schur, dim3((unsigned)tileWork.size()), dim3(256), 0, s_, p);
+        hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256), dim3(256), 0, s_, p, nDest);
+        hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
+      }
+      launchSolveReduced(dp, s_, 0.0, false, false);
+      if (nPieces > 0) hipLaunchKernelGGL(k_pg_piece_back, dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
+      hipLaunchKernelGGL(k_pg_scatter_sep, dim3(gN), dim3(128), 0, s_, p);
     };
     const auto t0 = std::chrono::steady_clock::now();
     // ---- Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy, default options
@@ -579,7 +979,7 @@ class PoseGraph {
     double gradMax = 0;
     while (true) {
       if (needLinearize) {  // gradient / column norms of the current linearisation (also the gradient check)
-        hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0, radius);
+        hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
         hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_GRADMAX, gN, 1);
         readScal(sc);
         gradMax = sc[PG_GRADMAX];
@@ -589,12 +989,7 @@ class PoseGraph {
       if (gradMax <= gradient_tolerance) { termination = 0; break; }
       if (radius <= min_radius) { termination = 0; break; }
       ++iteration;
-      // normal equations with the current radius (k_pg_node rewrites the diagonal blocks)
-      PG_HIP_OK(hipMemsetAsync(p.H, 0, sizeof(double) * (size_t)n * n, s_));
-      PG_HIP_OK(hipMemsetAsync(dSolScal_.p, 0, sizeof(SolverScalars), s_));
-      hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, 0, radius);
-      hipLaunchKernelGGL(k_pg_offdiag, dim3((ne + 127) / 128), dim3(128), 0, s_, p);
-      launchSolveReduced(dp, s_, 0.0, false, false);
+      solveNormalEquations(radius);
       hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
       hipLaunchKernelGGL(k_pg_model, dim3(gE), dim3(128), 0, s_, p);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_MODEL, gE, 0);
@@ -680,8 +1075,11 @@ class PoseGraph {
   int maxIter_;
   hipStream_t s_ = nullptr;
   Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
-  Buf<double> dRes_, dJa_, dJb_, dH_, dVec_, dChol_, dPartial_, dScal_;
-  Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_;
+  Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dY_, dSp_;
+  Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_, dSepOff_, dNodePiece_, dNodeRow_, dColSep_, dRowTan_, dGPtr_, dRPtr_;
+  Buf<PgPiece> dPieces_;
+  Buf<int4> dEdgeDst_, dTileWork_, dGSrc_;
+  Buf<int2> dGDst_, dRSrc_;
   Buf<SolverScalars> dSolScal_;
 };
 
@@ -752,6 +1150,18 @@ int svin_pg_get_drift(const svin_pg* h, double* yaw_drift_deg, double* r_drift, 
   if (yaw_drift_deg) *yaw_drift_deg = h->g.yawDrift;
   if (r_drift) std::memcpy(r_drift, h->g.rDrift, sizeof(double) * 9);
   if (t_drift) std::memcpy(t_drift, h->g.tDrift, sizeof(double) * 3);
+  return 1;
+}
+int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes) {
+  if (!h || piece_keyframes < 0 || dense_keyframes < 0) return -1;
+  if (piece_keyframes > 0) h->g.pieceLen_ = piece_keyframes;
+  h->g.denseNodes_ = dense_keyframes;
+  return 1;
+}
+int svin_pg_get_partition(const svin_pg* h, double* out6) {
+  if (!h || !out6) return -1;
+  for (int i = 0; i < 5; ++i) out6[i] = h->g.partition[i];
+  out6[5] = h->g.summary[6];
   return 1;
 }
 int svin_pg_summary(const svin_pg* h, double* out6) {

@@ -13,6 +13,7 @@ from . import estimator
 PG_EXPORTS = [
     "svin_pg_create", "svin_pg_destroy", "svin_pg_last_error", "svin_pg_add_keyframe", "svin_pg_num_keyframes",
     "svin_pg_optimize", "svin_pg_get_pose", "svin_pg_get_poses", "svin_pg_get_drift", "svin_pg_summary",
+    "svin_pg_set_partition", "svin_pg_get_partition",
 ]
 
 _BOUND = False
@@ -38,6 +39,8 @@ def _lib():
         sig("svin_pg_get_poses", i32, vp, i32, pd, pd)
         sig("svin_pg_get_drift", i32, vp, pd, pd, pd)
         sig("svin_pg_summary", i32, vp, pd)
+        sig("svin_pg_set_partition", i32, vp, i32, i32)
+        sig("svin_pg_get_partition", i32, vp, pd)
         _BOUND = True
     return L
 
@@ -99,3 +102,12 @@ class PoseGraph:
         y, r, t = np.zeros(1), np.zeros((3, 3)), np.zeros(3)
         self._check(self.L.svin_pg_get_drift(self.h, _p(y), _p(r), _p(t)), "get_drift")
         return float(y[0]), r, t
+
+    def set_partition(self, piece_keyframes=0, dense_keyframes=128):
+        self._check(self.L.svin_pg_set_partition(self.h, piece_keyframes, dense_keyframes), "set_partition")
+
+    def partition(self):
+        s = np.zeros(6)
+        self._check(self.L.svin_pg_get_partition(self.h, _p(s)), "get_partition")
+        return dict(free=int(s[0]), separators=int(s[1]), pieces=int(s[2]), max_rows=int(s[3]), tiles=int(s[4]),
+                    symbolic_seconds=s[5])

@@ -104,3 +104,32 @@ def test_no_loop_is_a_no_op():
     compare(g, c, sg, sc)
     Tg, _ = g.poses()
     assert np.max(np.abs(Tg - spec.t_svin)) < 1e-9
+
+
+@pytest.mark.parametrize("six", [False, True])
+@pytest.mark.parametrize("n,laps,loop_every,piece", [(160, 4, 8, 8), (400, 4, 25, 16), (400, 4, 10, 64), (1200, 6, 20, 64)])
+def test_piece_elimination_matches_oracle(six, n, laps, loop_every, piece):
+    """the separator / piece solver (chain cut into pieces, banded Cholesky per piece, dense separator system) against
+    the oracle's plain Cholesky of the same normal equations"""
+    spec = spg.make_pose_graph(n=n, laps=laps, loop_every=loop_every, seed=5 + n)
+    g, c, earliest, cur = pair(six, spec)
+    g.set_partition(piece, 0)
+    sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
+    part = g.partition()
+    print(part)
+    assert part["pieces"] >= 2 and part["separators"] < part["free"]
+    compare(g, c, sg, sc)
+
+
+@pytest.mark.parametrize("six", [False, True])
+def test_config5_graph_matches_oracle(six):
+    """BASELINE config #5 size: 5,000 keyframes, 190 loop closures (oracle: envelope Cholesky)"""
+    from oracle import orc
+    from svin_amd.posegraph import PoseGraph
+    spec = spg.make_pose_graph(n=5000, laps=20, loop_every=25, seed=7)
+    g, c = PoseGraph(0, six_dof=six), orc.OraclePoseGraph(six_dof=six, envelope=True)
+    earliest, cur = spg.feed(g, spec)
+    spg.feed(c, spec)
+    sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
+    print(g.partition())
+    compare(g, c, sg, sc, tol_pose=1e-6)
