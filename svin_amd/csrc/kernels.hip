@@ -2890,21 +2890,49 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
   }
 }
 
-// backward substitution L^T y = y' (y' = first row of the right-hand-side block), one workgroup
-__global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, const double* dinvG, const double* diagF) {
-  extern __shared__ double smem[];
-  double* y = smem;                 // dpad
-  double* part = smem + dpad;       // 8 x 64 partial sums
-  const int t = threadIdx.x, d = p.d;
-  const double* M = p.cholL;
-  for (int i = t; i < dpad; i += blockDim.x) y[i] = M[(size_t)dpad * dpad + i];
+// backward substitution L^T y = y' (y' = first row of the right-hand-side block) in super-panels of kBackSpan columns,
+// from the last to the first.  For the columns [c0, c1) of a super-panel the rows below it (i >= c1, already solved)
+// are a plain matrix-vector product spread over many workgroups (k_big_back_gemv: partial sums per 512-row chunk,
+// kept in the unused rows 1.. of the right-hand-side block, summed in fixed order); the triangle inside the
+// super-panel is one workgroup (k_big_back).
+constexpr int kBackSpan = 512;
+__global__ __launch_bounds__(512) void k_big_back_gemv(DeviceProblem p, int dpad, int c0, int c1) {
+  __shared__ double part[8 * 64];
+  double* M = p.cholL;
+  const double* y = M + (size_t)dpad * dpad;
+  const int t = threadIdx.x, c = t & 63, stripe = t >> 6;
+  const int col = c0 + 64 * blockIdx.x + c;
+  const int i0 = c1 + kBackSpan * blockIdx.y, i1 = min(dpad, i0 + kBackSpan);
+  double s = 0;
+  for (int i = i0 + stripe; i < i1; i += 8) s += M[(size_t)i * dpad + col] * y[i];
+  part[stripe * 64 + c] = s;
   __syncthreads();
-  for (int k0 = dpad - kNB; k0 >= 0; k0 -= kNB) {
-    // s_c = sum_{i >= k0 + 64} L[i][k0 + c] y[i]: 8 row stripes x 64 columns
+  if (t < 64) {
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += part[k * 64 + t];
+    M[(size_t)(dpad + 1 + blockIdx.y) * dpad + col] = acc;
+  }
+}
+__global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int c0, int c1, int nChunks, const double* dinvG,
+                                                  const double* diagF) {
+  extern __shared__ double smem[];
+  double* y = smem - c0;            // y[c0 .. c1) lives in smem[0 .. c1 - c0)
+  double* part = smem + (c1 - c0);  // 8 x 64 partial sums
+  const int t = threadIdx.x, d = p.d;
+  double* M = p.cholL;
+  for (int i = c0 + t; i < c1; i += blockDim.x) {
+    double v = M[(size_t)dpad * dpad + i];
+    for (int k = 0; k < nChunks; ++k) v -= M[(size_t)(dpad + 1 + k) * dpad + i];
+    y[i] = v;
+  }
+  __syncthreads();
+  for (int k0 = c1 - kNB; k0 >= c0; k0 -= kNB) {
+    // s_c = sum_{k0 + 64 <= i < c1} L[i][k0 + c] y[i]: 8 row stripes x 64 columns
     {
       const int c = t & 63, stripe = t >> 6;
       double s = 0;
-      for (int i = k0 + kNB + stripe; i < dpad; i += 8) s += M[(size_t)i * dpad + k0 + c] * y[i];
+      for (int i = k0 + kNB + stripe; i < c1; i += 8) s += M[(size_t)i * dpad + k0 + c] * y[i];
       part[stripe * 64 + c] = s;
     }
     __syncthreads();
@@ -2943,7 +2971,10 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, con
     }
     __syncthreads();
   }
-  for (int i = t; i < d; i += blockDim.x) { p.yC[i] = y[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }
+  for (int i = c0 + t; i < c1; i += blockDim.x) {
+    M[(size_t)dpad * dpad + i] = y[i];   // the solved part of y, read by the super-panels before this one
+    if (i < d) { p.yC[i] = y[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
+  }
 }
 
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
@@ -2973,9 +3004,14 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
         hipLaunchKernelGGL(k_big_syrk, dim3(nBlocks), dim3(256), ldsSyrk, s, p, dp, k0);
       }
     }
-    const size_t ldsBack = ((size_t)dp + 8 * 64) * 8;
-    (void)hipFuncSetAttribute((const void*)k_big_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
-    hipLaunchKernelGGL(k_big_back, dim3(1), dim3(512), ldsBack, s, p, dp, (const double*)dinvG, (const double*)diagF);
+    const size_t ldsBack = ((size_t)kBackSpan + 8 * 64) * 8;
+    for (int c1 = dp; c1 > 0; c1 -= kBackSpan) {
+      const int c0 = std::max(0, c1 - kBackSpan);
+      const int nChunks = (dp - c1 + kBackSpan - 1) / kBackSpan;   // <= 63: the spare rows of the rhs block
+      if (nChunks > 0) hipLaunchKernelGGL(k_big_back_gemv, dim3((c1 - c0) / kNB, nChunks), dim3(512), 0, s, p, dp, c0, c1);
+      hipLaunchKernelGGL(k_big_back, dim3(1), dim3(512), ldsBack, s, p, dp, c0, c1, nChunks, (const double*)dinvG,
+                         (const double*)diagF);
+    }
   }
 }
 

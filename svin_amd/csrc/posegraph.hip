@@ -132,11 +132,12 @@ __device__ __forceinline__ double pgBlockMax(double v, double* red) {
 }
 
 // residual and minimal Jacobians of one edge (tangent order 4-DoF: [yaw, t]; 6-DoF: [t, dq], q <- [sin|d| d/|d|, cos|d|] q)
-__device__ void pgEdge(const PgDev& p, int e, bool cand, double* r, double* Ja, double* Jb) {
+template <bool SIX>
+__device__ __forceinline__ void pgEdge(const PgDev& p, int e, bool cand, double* r, double* Ja, double* Jb) {
   const int a = p.ea[e], b = p.eb[e];
   const double* T = cand ? p.tC : p.t;
   const double d[3] = {T[3 * b] - T[3 * a], T[3 * b + 1] - T[3 * a + 1], T[3 * b + 2] - T[3 * a + 2]};
-  if (!p.six) {
+  if constexpr (!SIX) {
     const double* Y = cand ? p.yawC : p.yaw;
     double R[9], dR[9];
     pgYpr2R(Y[a], p.epitch[e], p.eroll[e], R, dR);
@@ -191,15 +192,18 @@ __device__ void pgEdge(const PgDev& p, int e, bool cand, double* r, double* Ja, 
   }
 }
 
+template <bool SIX>
 __global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac) {
+  constexpr int D = SIX ? 6 : 4, R = D, RD = R * D;
   __shared__ double red[2];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0;
   if (e < p.ne) {
-    double r[6], Ja[36], Jb[36];
-    pgEdge(p, e, cand != 0, r, Ja, Jb);
+    double r[R], Ja[RD], Jb[RD];
+    pgEdge<SIX>(p, e, cand != 0, r, Ja, Jb);
     double s = 0;
-    for (int k = 0; k < p.R; ++k) s += r[k] * r[k];
+#pragma unroll
+    for (int k = 0; k < R; ++k) s += r[k] * r[k];
     double sc = 1.0;
     if (p.eloop[e]) {  // HuberLoss(0.1) + Corrector (rho'' <= 0: plain sqrt(rho') scaling)
       const double a = 0.1, b = a * a;
@@ -214,8 +218,9 @@ __global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac)
       cost = 0.5 * s;
     }
     if (withJac) {
-      const int RD = p.R * p.D;
-      for (int k = 0; k < p.R; ++k) p.res[(size_t)e * p.R + k] = sc * r[k];
+#pragma unroll
+      for (int k = 0; k < R; ++k) p.res[(size_t)e * R + k] = sc * r[k];
+#pragma unroll
       for (int k = 0; k < RD; ++k) { p.Ja[(size_t)e * RD + k] = sc * Ja[k]; p.Jb[(size_t)e * RD + k] = sc * Jb[k]; }
     }
   }
@@ -224,36 +229,54 @@ __global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac)
 }
 
 // one thread per node: gradient, column norms, (first iteration) Jacobi scaling, raw J^T J block
+template <int D>
 __global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale) {
+  constexpr int R = D;
   __shared__ double red[2];
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double gmax = 0;
   if (k < p.nn && p.off[k] >= 0) {
-    const int D = p.D, R = p.R, o = p.off[k];
-    double g[6] = {0, 0, 0, 0, 0, 0}, blk[36];
-    for (int i = 0; i < 36; ++i) blk[i] = 0;
+    const int o = p.off[k];
+    double g[D], blk[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) blk[i] = 0;
     for (int it = p.nodePtr[k]; it < p.nodePtr[k + 1]; ++it) {
       const int e = p.nodeEdge[it] >> 1, side = p.nodeEdge[it] & 1;
-      const double* J = (side ? p.Jb : p.Ja) + (size_t)e * R * D;
-      const double* r = p.res + (size_t)e * R;
+      const double* Jg = (side ? p.Jb : p.Ja) + (size_t)e * R * D;
+      const double* rg = p.res + (size_t)e * R;
+      double J[R * D], r[R];
+#pragma unroll
+      for (int i = 0; i < R * D; ++i) J[i] = Jg[i];
+#pragma unroll
+      for (int i = 0; i < R; ++i) r[i] = rg[i];
+#pragma unroll
       for (int c1 = 0; c1 < D; ++c1) {
         double gs = 0;
+#pragma unroll
         for (int q = 0; q < R; ++q) gs += J[q * D + c1] * r[q];
         g[c1] += gs;
-        for (int c2 = 0; c2 < D; ++c2) {
+#pragma unroll
+        for (int c2 = 0; c2 <= c1; ++c2) {
           double s = 0;
+#pragma unroll
           for (int q = 0; q < R; ++q) s += J[q * D + c1] * J[q * D + c2];
           blk[c1 * D + c2] += s;
         }
       }
     }
+#pragma unroll
     for (int c = 0; c < D; ++c) {
       if (initScale) p.scale[o + c] = 1.0 / (1.0 + sqrt(blk[c * D + c]));
       p.g[o + c] = g[c];
       p.colsq[o + c] = blk[c * D + c];
       gmax = fmax(gmax, fabs(g[c]));
     }
-    for (int i = 0; i < D * D; ++i) p.nodeBlk[(size_t)k * 36 + i] = blk[i];
+#pragma unroll
+    for (int c1 = 0; c1 < D; ++c1)
+#pragma unroll
+      for (int c2 = 0; c2 <= c1; ++c2) p.nodeBlk[(size_t)k * 36 + c1 * D + c2] = blk[c1 * D + c2];   // lower triangle
   }
   const double bm = pgBlockMax(gmax, red);
   if (threadIdx.x == 0) p.partial[PG_GRADMAX * kPgMaxPartials + blockIdx.x] = bm;
@@ -285,16 +308,20 @@ __global__ void k_pg_assemble_nodes(PgDev p, double radius) {
 // one thread per edge between two free nodes: the off-diagonal block J_b^T J_a (rows of b, columns of a), scaled,
 // added to its destination.  At most two edges share a destination block (a sequential and a loop edge between the
 // same pair), so the atomic adds commute exactly.
-__global__ void k_pg_assemble_edges(PgDev p) {
+template <int D>
+__global__ __launch_bounds__(128) void k_pg_assemble_edges(PgDev p) {
+  constexpr int R = D;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.ne) return;
   const int4 dst = p.edgeDst[e];
   const int kind = dst.x & 15, rowIsB = (dst.x >> 4) & 1;
   if (kind == 0) return;
   const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
-  const int D = p.D, R = p.R;
-  const double* Ja = p.Ja + (size_t)e * R * D;
-  const double* Jb = p.Jb + (size_t)e * R * D;
+  double Ja[R * D], Jb[R * D], sa[D], sb[D];
+#pragma unroll
+  for (int i = 0; i < R * D; ++i) { Ja[i] = p.Ja[(size_t)e * R * D + i]; Jb[i] = p.Jb[(size_t)e * R * D + i]; }
+#pragma unroll
+  for (int i = 0; i < D; ++i) { sa[i] = p.scale[oa + i]; sb[i] = p.scale[ob + i]; }
   double* base;
   size_t ld;
   if (kind == 1) { base = p.HS + (size_t)dst.z * p.nS + dst.w; ld = p.nS; }
@@ -303,77 +330,156 @@ __global__ void k_pg_assemble_edges(PgDev p) {
     if (kind == 2) { base = p.band + pc.bandOff + (size_t)dst.z * (p.BW + 1) + (dst.w - dst.z + p.BW); ld = p.BW; }  // (r, c) -> r * LDB + c - r + BW
     else { base = p.Y + pc.yOff + (size_t)dst.z * pc.ld + dst.w; ld = pc.ld; }
   }
+#pragma unroll
   for (int c1 = 0; c1 < D; ++c1)
+#pragma unroll
     for (int c2 = 0; c2 < D; ++c2) {
       double s = 0;
+#pragma unroll
       for (int q = 0; q < R; ++q) s += Jb[q * D + c1] * Ja[q * D + c2];
-      s *= p.scale[ob + c1] * p.scale[oa + c2];
+      s *= sb[c1] * sa[c2];
       const int r = rowIsB ? c1 : c2, c = rowIsB ? c2 : c1;
       atomicAdd(base + (size_t)r * ld + c, s);
     }
 }
 
 // ---------------------------------------------------------------- pieces
-constexpr int kPgRing = 32;          // rows of forward-substitution history kept in LDS (> BW)
 constexpr int kPgPieceThreads = 256; // = max coupling columns + 1 of a piece
+__device__ __forceinline__ double pgRsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = __builtin_fma(-h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ void pgWaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// band geometry of a chain whose keyframes (D unknowns) talk to their W predecessors: row r keeps columns r-BW..r
+template <int D, int W>
+struct PgBand {
+  static constexpr int BW = W * D + D - 1, LDB = BW + 1, P = W * D, NPAIR = P * (P + 1) / 2;
+};
 
-// banded Cholesky of the piece's interior block (band storage, row r holds columns r-BW..r) and Y = L^-1 [C | r]
+// Block-banded Cholesky of the piece's interior (one keyframe = D columns at a time: the D x D diagonal block in
+// registers, the W*D rows below it one per lane, the trailing update one (row, column) pair per lane), then
+// Y = L^-1 [C | r]: one column per thread, the last BW values of its column in registers.
+template <int D, int W>
 __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
+  using G = PgBand<D, W>;
+  constexpr int BW = G::BW, LDB = G::LDB, P = G::P, NPAIR = G::NPAIR;
+  constexpr bool kAllWaves = NPAIR > 64;   // the trailing update of a 6-DoF keyframe has 300 pairs: use the workgroup
   extern __shared__ double sm[];
   const PgPiece pc = p.pieces[blockIdx.x];
-  const int n = pc.rows, BW = p.BW, LDB = BW + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = pc.rows, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* Lb = sm;
   double* dinv = Lb + (size_t)p.maxRows * LDB;
-  double* ring = dinv + p.maxRows;
-  unsigned short* tab = reinterpret_cast<unsigned short*>(ring + (size_t)kPgRing * kPgPieceThreads);
+  unsigned short* tab = reinterpret_cast<unsigned short*>(dinv + p.maxRows);
   double* band = p.band + pc.bandOff;
   for (int i = tid; i < n * LDB; i += kPgPieceThreads) Lb[i] = band[i];
-  const int nPairs = BW * (BW + 1) / 2;
-  for (int i = tid; i < nPairs; i += kPgPieceThreads) {   // (s, t), 1 <= t <= s <= BW
-    int s_ = 1, rem = i;
-    while (rem >= s_) { rem -= s_; ++s_; }
-    tab[i] = (unsigned short)(s_ | ((rem + 1) << 8));
+  for (int i = tid; i < NPAIR; i += kPgPieceThreads) {   // (s, t), 0 <= t <= s < P
+    int s_ = 0, rem = i;
+    while (rem > s_) { rem -= s_ + 1; ++s_; }
+    tab[i] = (unsigned short)(s_ | (rem << 8));
   }
   __syncthreads();
-  if (wave == 0) {
-    int bad = 0;
-    for (int j = 0; j < n; ++j) {
-      const double ajj = Lb[j * LDB + BW];
-      const bool ok = ajj > 0.0;
-      bad |= ok ? 0 : 1;
-      const double d = sqrt(ok ? ajj : 1.0), di = 1.0 / d;
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { Lb[j * LDB + BW] = d; dinv[j] = di; }
-      else if (lane <= BW && j + lane < n) Lb[(j + lane) * LDB + BW - lane] *= di;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int pi = lane; pi < nPairs; pi += 64) {
-        const int s_ = tab[pi] & 255, t_ = tab[pi] >> 8;
-        if (j + s_ < n) Lb[(j + s_) * LDB + BW - (s_ - t_)] -= Lb[(j + s_) * LDB + BW - s_] * Lb[(j + t_) * LDB + BW - t_];
+  int bad = 0;
+  if (kAllWaves || wave == 0) {
+    for (int j0 = 0; j0 < n; j0 += D) {
+      if (wave == 0) {
+        // the D x D diagonal block, factorised redundantly by every lane (broadcast LDS reads)
+        double a[D][D], di[D];
+#pragma unroll
+        for (int x = 0; x < D; ++x)
+#pragma unroll
+          for (int y = 0; y <= x; ++y) a[x][y] = Lb[(j0 + x) * LDB + BW - (x - y)];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          double sdiag = a[k][k];
+#pragma unroll
+          for (int m = 0; m < k; ++m) sdiag -= a[k][m] * a[k][m];
+          const bool ok = sdiag > 0.0;
+          bad |= ok ? 0 : 1;
+          di[k] = pgRsqrt(ok ? sdiag : 1.0);
+          a[k][k] = sdiag * di[k];
+#pragma unroll
+          for (int x = k + 1; x < D; ++x) {
+            double v = a[x][k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) v -= a[x][m] * a[k][m];
+            a[x][k] = v * di[k];
+          }
+        }
+        if (lane < D) {
+#pragma unroll
+          for (int x = 0; x < D; ++x)
+            if (lane == x) {
+#pragma unroll
+              for (int y = 0; y <= x; ++y) Lb[(j0 + x) * LDB + BW - (x - y)] = a[x][y];
+              dinv[j0 + x] = di[x];
+            }
+        }
+        // the rows below: X = A L_jj^-T, one row per lane
+        const int r = j0 + D + lane;
+        if (lane < P && r < n) {
+          double* row = Lb + r * LDB + BW - D - lane;   // columns j0 .. j0 + D - 1 of row r
+          double x[D];
+#pragma unroll
+          for (int b = 0; b < D; ++b) {
+            double v = row[b];
+#pragma unroll
+            for (int k = 0; k < b; ++k) v -= x[k] * a[b][k];
+            x[b] = v * di[b];
+          }
+#pragma unroll
+          for (int b = 0; b < D; ++b) row[b] = x[b];
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      if (kAllWaves) __syncthreads(); else pgWaveSync();
+      // trailing update: A[j0+D+s][j0+D+t] -= X_s . X_t
+      for (int pi = kAllWaves ? tid : lane; pi < NPAIR; pi += kAllWaves ? kPgPieceThreads : 64) {
+        const int s_ = tab[pi] & 255, t_ = tab[pi] >> 8;
+        const int rs = j0 + D + s_;
+        if (rs < n) {
+          const double* xs = Lb + rs * LDB + BW - D - s_;
+          const double* xt = Lb + (j0 + D + t_) * LDB + BW - D - t_;
+          double acc = 0;
+#pragma unroll
+          for (int b = 0; b < D; ++b) acc += xs[b] * xt[b];
+          Lb[rs * LDB + BW - (s_ - t_)] -= acc;
+        }
+      }
+      if (kAllWaves) __syncthreads(); else pgWaveSync();
     }
-    if (bad && lane == 0) atomicOr(p.fail, 1);
+    if (bad && tid == 0) atomicOr(p.fail, 1);
   }
   __syncthreads();
   for (int i = tid; i < n * LDB; i += kPgPieceThreads) band[i] = Lb[i];
   if (tid < pc.cols) {
     double* Yc = p.Y + pc.yOff + tid;
-    double* rg = ring + tid;
-    for (int r0 = 0; r0 < n; r0 += 8) {
-      double v[8];
+    double yh[LDB];   // yh[r % LDB] = y_r for the last BW rows (rows < 0: zero)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = r0 + u < n ? Yc[(size_t)(r0 + u) * pc.ld] : 0.0;
+    for (int u = 0; u < LDB; ++u) yh[u] = 0.0;
+    for (int rb = 0; rb < n; rb += LDB) {
+      double v[LDB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + u;
+      for (int u = 0; u < LDB; ++u) v[u] = rb + u < n ? Yc[(size_t)(rb + u) * pc.ld] : 0.0;
+#pragma unroll
+      for (int u = 0; u < LDB; ++u) {
+        const int r = rb + u;
         if (r < n) {
-          double x = v[u];
-          const int k0 = r > BW ? r - BW : 0;
-          for (int k = k0; k < r; ++k) x -= Lb[r * LDB + (k - r + BW)] * rg[(k & (kPgRing - 1)) * kPgPieceThreads];
-          x *= dinv[r];
-          rg[(r & (kPgRing - 1)) * kPgPieceThreads] = x;
+          const double* row = Lb + r * LDB;
+          double x0 = v[u], x1 = 0.0;
+#pragma unroll
+          for (int t = 1; t <= BW; ++t) {
+            const double term = row[BW - t] * yh[(u - t + 2 * LDB) % LDB];
+            if (t & 1) x0 -= term; else x1 -= term;
+          }
+          const double x = (x0 + x1) * dinv[r];
+          yh[u] = x;
           Yc[(size_t)r * pc.ld] = x;
         }
       }
@@ -423,16 +529,20 @@ __global__ void k_pg_sep_gather_rhs(PgDev p) {
 }
 
 // interior unknowns of one piece: x_I = L^-T (y_r - Y_C x_S)
+template <int D, int W>
 __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_back(PgDev p) {
+  using G = PgBand<D, W>;
+  constexpr int BW = G::BW, LDB = G::LDB, P = G::P;
   extern __shared__ double sm[];
   const PgPiece pc = p.pieces[blockIdx.x];
-  const int n = pc.rows, BW = p.BW, LDB = BW + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = pc.rows, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* Lb = sm;
-  double* z = Lb + (size_t)p.maxRows * LDB;
-  double* xA = z + p.maxRows;
+  double* z = Lb + (size_t)p.maxRows * LDB;   // P zeros of padding behind the last row
+  double* xA = z + p.maxRows + P;
   const double* band = p.band + pc.bandOff;
   for (int i = tid; i < n * LDB; i += kPgPieceThreads) Lb[i] = band[i];
   for (int c = tid; c < pc.cols - 1; c += kPgPieceThreads) xA[c] = p.yS[p.colSep[pc.colPtr + c]];
+  if (tid < P) z[n + tid] = 0.0;
   __syncthreads();
   const double* Y = p.Y + pc.yOff;
   for (int r = wave; r < n; r += kPgPieceThreads / 64) {   // one wave per row: coalesced dot product
@@ -443,13 +553,35 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_back(PgDev p) {
   }
   __syncthreads();
   if (wave == 0) {
-    for (int r = n - 1; r >= 0; --r) {
-      const double x = z[r] / Lb[r * LDB + BW];
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) z[r] = x;
-      else if (lane <= BW && r - lane >= 0) z[r - lane] -= Lb[r * LDB + BW - lane] * x;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+    // keyframe by keyframe from the last: lane b < D gathers row j0 + b of L^T x over the W keyframes behind it,
+    // then every lane solves the D x D triangle redundantly
+    for (int j0 = n - D; j0 >= 0; j0 -= D) {
+      if (lane < D) {
+        double a0 = z[j0 + lane], a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const int r = j0 + D + k;
+          const double l = r < n ? Lb[r * LDB + BW - D - k + lane] : 0.0;   // L[r][j0 + lane]
+          if (k & 1) a1 -= l * z[r]; else a0 -= l * z[r];
+        }
+        z[j0 + lane] = a0 + a1;
+      }
+      pgWaveSync();
+      double x[D];
+#pragma unroll
+      for (int b = D - 1; b >= 0; --b) {
+        double v = z[j0 + b];
+#pragma unroll
+        for (int k = b + 1; k < D; ++k) v -= Lb[(j0 + k) * LDB + BW - (k - b)] * x[k];
+        x[b] = v / Lb[(j0 + b) * LDB + BW];
+      }
+      pgWaveSync();
+      if (lane < D) {
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+          if (lane == b) z[j0 + b] = x[b];
+      }
+      pgWaveSync();
     }
   }
   __syncthreads();
@@ -467,16 +599,22 @@ __global__ void k_pg_step(PgDev p) {
 }
 
 // model cost change = -(J delta).(r + J delta / 2) over the edges
+template <int D>
 __global__ __launch_bounds__(128) void k_pg_model(PgDev p) {
+  constexpr int R = D;
   __shared__ double red[2];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   double acc = 0;
   if (e < p.ne) {
-    const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]], D = p.D, R = p.R;
+    const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
+    double da[D], db[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { da[c] = oa >= 0 ? p.delta[oa + c] : 0.0; db[c] = ob >= 0 ? p.delta[ob + c] : 0.0; }
+#pragma unroll
     for (int q = 0; q < R; ++q) {
       double mr = 0;
-      if (oa >= 0) for (int c = 0; c < D; ++c) mr += p.Ja[((size_t)e * R + q) * D + c] * p.delta[oa + c];
-      if (ob >= 0) for (int c = 0; c < D; ++c) mr += p.Jb[((size_t)e * R + q) * D + c] * p.delta[ob + c];
+#pragma unroll
+      for (int c = 0; c < D; ++c) mr += p.Ja[((size_t)e * R + q) * D + c] * da[c] + p.Jb[((size_t)e * R + q) * D + c] * db[c];
       acc += mr * (p.res[(size_t)e * R + q] + 0.5 * mr);
     }
   }
@@ -930,18 +1068,21 @@ class PoseGraph {
     dp.cholL = dChol_.p; dp.scal = dSolScal_.p;
     const int gE = (ne + 127) / 128, gN = (nn + 127) / 128;
     if (gE > kPgMaxPartials || gN > kPgMaxPartials) throw std::runtime_error("svin_pg: graph too large for the reduction scratch");
-    const size_t ldsFactor = ((size_t)maxRows * (BW + 2) + (size_t)kPgRing * kPgPieceThreads) * 8 + (size_t)BW * (BW + 1);
-    const size_t ldsBack = ((size_t)maxRows * (BW + 2) + kPgPieceThreads) * 8;
+    const size_t ldsFactor = (size_t)maxRows * (BW + 2) * 8 + 2 * 512;
+    const size_t ldsBack = ((size_t)maxRows * (BW + 2) + w * D + kPgPieceThreads) * 8;
     if (nPieces > 0) {
-      (void)hipFuncSetAttribute((const void*)k_pg_piece_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFactor);
-      (void)hipFuncSetAttribute((const void*)k_pg_piece_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
+      (void)hipFuncSetAttribute(six_ ? (const void*)k_pg_piece_factor<6, 4> : (const void*)k_pg_piece_factor<4, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFactor);
+      (void)hipFuncSetAttribute(six_ ? (const void*)k_pg_piece_back<6, 4> : (const void*)k_pg_piece_back<4, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
     }
     auto readScal = [&](double* out) {
       PG_HIP_OK(hipMemcpyAsync(out, p.scal, sizeof(double) * PG_NSCAL, hipMemcpyDeviceToHost, s_));
       PG_HIP_OK(hipStreamSynchronize(s_));
     };
     auto evalCost = [&](bool cand, bool withJac) {
-      hipLaunchKernelGGL(k_pg_eval, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
+      if (six_) hipLaunchKernelGGL(k_pg_eval<true>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
+      else hipLaunchKernelGGL(k_pg_eval<false>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
     };
     // damped normal equations at the current linearisation -> y (tangent order, scaled space)
@@ -953,15 +1094,20 @@ class PoseGraph {
         PG_HIP_OK(hipMemsetAsync(p.Y, 0, sizeof(double) * yTot, s_));
       }
       hipLaunchKernelGGL(k_pg_assemble_nodes, dim3(gN), dim3(128), 0, s_, p, radius);
-      hipLaunchKernelGGL(k_pg_assemble_edges, dim3(gE), dim3(128), 0, s_, p);
+      if (six_) hipLaunchKernelGGL(k_pg_assemble_edges<6>, dim3(gE), dim3(128), 0, s_, p);
+      else hipLaunchKernelGGL(k_pg_assemble_edges<4>, dim3(gE), dim3(128), 0, s_, p);
       if (nPieces > 0) {
-        hipLaunchKernelGGL(k_pg_piece_factor, dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
+        if (six_) hipLaunchKernelGGL((k_pg_piece_factor<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
+        else hipLaunchKernelGGL((k_pg_piece_factor<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
         hipLaunchKernelGGL(k_pg_piece_schur, dim3((unsigned)tileWork.size()), dim3(256), 0, s_, p);
         hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256), dim3(256), 0, s_, p, nDest);
         hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
       }
       launchSolveReduced(dp, s_, 0.0, false, false);
-      if (nPieces > 0) hipLaunchKernelGGL(k_pg_piece_back, dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
+      if (nPieces > 0) {
+        if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
+        else hipLaunchKernelGGL((k_pg_piece_back<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
+      }
       hipLaunchKernelGGL(k_pg_scatter_sep, dim3(gN), dim3(128), 0, s_, p);
     };
     const auto t0 = std::chrono::steady_clock::now();
@@ -979,7 +1125,8 @@ class PoseGraph {
     double gradMax = 0;
     while (true) {
       if (needLinearize) {  // gradient / column norms of the current linearisation (also the gradient check)
-        hipLaunchKernelGGL(k_pg_node, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
+        if (six_) hipLaunchKernelGGL(k_pg_node<6>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
+        else hipLaunchKernelGGL(k_pg_node<4>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
         hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_GRADMAX, gN, 1);
         readScal(sc);
         gradMax = sc[PG_GRADMAX];
@@ -991,7 +1138,8 @@ class PoseGraph {
       ++iteration;
       solveNormalEquations(radius);
       hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
-      hipLaunchKernelGGL(k_pg_model, dim3(gE), dim3(128), 0, s_, p);
+      if (six_) hipLaunchKernelGGL(k_pg_model<6>, dim3(gE), dim3(128), 0, s_, p);
+      else hipLaunchKernelGGL(k_pg_model<4>, dim3(gE), dim3(128), 0, s_, p);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_MODEL, gE, 0);
       hipLaunchKernelGGL(k_pg_plus, dim3(gN), dim3(128), 0, s_, p);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_STEP2, gN, 0);

@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 def pair(six, spec, upto=None, max_iterations=0):
     from oracle import orc
     from svin_amd.posegraph import PoseGraph
-    g, c = PoseGraph(0, six_dof=six, max_iterations=max_iterations), orc.OraclePoseGraph(six_dof=six, max_iterations=max_iterations)
+    # the oracle's envelope Cholesky is the same arithmetic as its dense one restricted to the profile; it keeps the
+    # larger graphs in seconds (tests/test_oracle_posegraph.py checks the two against each other)
+    g = PoseGraph(0, six_dof=six, max_iterations=max_iterations)
+    c = orc.OraclePoseGraph(six_dof=six, max_iterations=max_iterations, envelope=spec.n > 300)
     eg = spg.feed(g, spec, upto)
     ec = spg.feed(c, spec, upto)
     assert eg == ec
