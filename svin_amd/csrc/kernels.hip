@@ -12,6 +12,8 @@
 // Reference arithmetic: see dmath.hpp and the per-kernel comments.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace svin {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -2777,9 +2779,49 @@ __device__ void factor64(double* T, double* dinv, int* failFlag) {
   }
 }
 
+// X = A L^-T for a 64x64 slab in LDS tiles (At, in place) against a factorised diagonal block (Dt, dinv) from
+// factor64: wave w owns row tile w; block forward substitution over the tile columns j
+__device__ __forceinline__ void slabSolve64(const double* Dt, double* At, const double* dinv) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto dt = [&](int I, int J) { return Dt + (I * 4 + J) * (16 * kBigTileLd); };
+  auto at = [&](int I, int J) { return At + (I * 4 + J) * (16 * kBigTileLd); };
+  for (int j = 0; j < 4; ++j) {
+    double* X = at(wave, j);
+    d4_t acc;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) acc[rg] = X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
+    for (int i = 0; i < j; ++i) {
+      const double* Xi = at(wave, i);
+      const double* Lji = dt(j, i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                   Lji[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
+    waveSync();
+    const double* D = dt(j, j);
+    d4_t out = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 4 * q + (lane >> 4), jj = lane & 15;
+      const double a = X[(lane & 15) * kBigTileLd + kk];
+      const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * j + kk] : 0.0);
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, out, 0, 0, 0);
+    }
+    waveSync();
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = out[rg];
+    waveSync();
+  }
+}
+
 // M = p.cholL: (dpad + kNB) x dpad row-major; rows [dpad, dpad + kNB) hold the right-hand side in their first row
-__global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize) {
+__global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize, int* ready,
+                                                  int nReady) {
   const int d = p.d;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nReady; i += gridDim.x * blockDim.x) ready[i] = 0;
   const size_t total = (size_t)(dpad + kNB) * dpad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int gi = (int)(idx / dpad), gj = (int)(idx - (size_t)gi * dpad);
@@ -2816,39 +2858,7 @@ __global__ __launch_bounds__(256) void k_big_panel(DeviceProblem p, int dpad, in
     if (threadIdx.x < kNB) dinvG[k0 + threadIdx.x] = dinv[threadIdx.x];
   }
   if (!hasSlab) return;
-  // X = A L^-T: wave w owns row tile w; block forward substitution over the tile columns j
-  auto dt = [&](int I, int J) { return Dt + (I * 4 + J) * (16 * kBigTileLd); };
-  auto at = [&](int I, int J) { return At + (I * 4 + J) * (16 * kBigTileLd); };
-  for (int j = 0; j < 4; ++j) {
-    double* X = at(wave, j);
-    d4_t acc;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[rg] = X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
-    for (int i = 0; i < j; ++i) {
-      const double* Xi = at(wave, i);
-      const double* Lji = dt(j, i);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
-                                                   Lji[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
-    waveSync();
-    const double* D = dt(j, j);
-    d4_t out = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int kk = 4 * q + (lane >> 4), jj = lane & 15;
-      const double a = X[(lane & 15) * kBigTileLd + kk];
-      const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * j + kk] : 0.0);
-      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, out, 0, 0, 0);
-    }
-    waveSync();
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = out[rg];
-    waveSync();
-  }
+  slabSolve64(Dt, At, dinv);
   __syncthreads();
   storeBlock64(M + (size_t)r0 * dpad + k0, dpad, At);
 }
@@ -2887,6 +2897,120 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)] = acc[rg];
+  }
+}
+
+// ---------------------------------------------------------------- one-launch tile Cholesky (d > 176)
+// Left-looking over 64x64 blocks in ONE launch: task (I, J), I >= J (I = nb is the right-hand-side row block), owns
+// block (I, J): C = A(I,J) - sum_{k<J} X(I,k) X(J,k)^T on MFMA (C in registers), then potrf (I == J, factor64) or
+// X = C L_JJ^-T (slabSolve64).  Tasks are numbered column by column and dealt round-robin to <= 256 co-resident
+// workgroups, each working through its tasks in increasing order; a task only depends on tasks with a smaller
+// number, which are either finished, running elsewhere or earlier in the same workgroup, so the waits cannot cycle.
+// Finished blocks are published with a release store of ready[I][J] and consumed after an acquire load (agent scope:
+// the blocks cross XCD L2s).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
+// The per-panel launch pair (k_big_panel + k_big_syrk) stays as the fallback (SVIN_BIG_CHOL_LAUNCHES=1).
+constexpr int kSpinMax = 1 << 20;
+constexpr int kPersistMaxGrid = 256;
+__device__ __forceinline__ bool pollReady(const int* f) {
+  for (int it = 0; it < kSpinMax; ++it) {
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return false;
+}
+__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
+  extern __shared__ double smem[];
+  double* Xi = smem;                       // X(I, k) / the slab during the solve
+  double* Xj = smem + kBigBlockLds;        // X(J, k)
+  double* Dt = smem + 2 * kBigBlockLds;    // diagonal block
+  double* dinv = Dt + kBigBlockLds;        // 64
+  int* seen = reinterpret_cast<int*>(dinv + kNB);   // [0] = all dependencies of the first sweep present, [1] = wait ok
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nb = dpad / kNB;
+  double* M = p.cholL;
+  const int nTasks = nb * (nb + 1) / 2 + nb;
+  bool gaveUp = false;                     // (thread 0) a wait ran into its bound: stop waiting, the result is flagged bad
+  int J = 0, colStart = 0;                 // tasks of column J: colStart .. colStart + (nb - J), I = J + (t - colStart)
+  for (int task = blockIdx.x; task < nTasks; task += gridDim.x) {
+    while (task >= colStart + (nb - J + 1)) { colStart += nb - J + 1; ++J; }
+    const int I = J + (task - colStart);
+    // C <- A(I, J), row tile `wave`, 4 column tiles
+    d4_t acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      const double* C = M + (size_t)(kNB * I + 16 * wave) * dpad + kNB * J + 16 * tj;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[tj][rg] = C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
+    }
+    // one parallel look at all dependencies: usually everything but the last columns is already there
+    if (tid == 0) seen[0] = J;
+    __syncthreads();
+    int firstMissing = J;
+    for (int k = tid; k < J; k += blockDim.x) {
+      const bool ok = __hip_atomic_load(ready + I * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                      __hip_atomic_load(ready + J * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (!ok) firstMissing = min(firstMissing, k);
+    }
+    if (firstMissing < J) atomicMin(seen, firstMissing);
+    __syncthreads();
+    const int kSafe = seen[0];   // dependencies k < kSafe are present
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    for (int k = 0; k < J; ++k) {
+      if (k >= kSafe) {
+        if (tid == 0 && !gaveUp) {
+          const bool ok = pollReady(ready + I * nb + k) && pollReady(ready + J * nb + k);
+          if (!ok) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      loadBlock64(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
+      if (I != J) loadBlock64(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
+      __syncthreads();
+      const double* XJ = (I == J) ? Xi : Xj;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const double* A = Xi + (wave * 4 + kt) * (16 * kBigTileLd);
+          const double* B = XJ + (tj * 4 + kt) * (16 * kBigTileLd);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                           B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc[tj], 0, 0, 0);
+        }
+      __syncthreads();
+    }
+    if (I == J) {
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          Dt[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
+      __syncthreads();
+      factor64(Dt, dinv, &p.scal->cholFail);
+      storeBlock64(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
+      if (tid < kNB) dinvG[kNB * J + tid] = dinv[tid];
+    } else {
+      if (tid == 0 && !gaveUp && !pollReady(ready + J * nb + J)) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      loadBlock64(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
+      if (tid < kNB) dinv[tid] = dinvG[kNB * J + tid];
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          Xi[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
+      __syncthreads();
+      slabSolve64(Dt, Xi, dinv);
+      __syncthreads();
+      storeBlock64(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, Xi);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ready + I * nb + J, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -2994,14 +3118,26 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     const size_t ldsPanel = ((size_t)2 * kBigBlockLds + kNB) * 8, ldsSyrk = (size_t)2 * kBigBlockLds * 8;
     (void)hipFuncSetAttribute((const void*)k_big_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsPanel);
     (void)hipFuncSetAttribute((const void*)k_big_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSyrk);
-    hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
-    for (int k0 = 0; k0 < dp; k0 += kNB) {
-      const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included
-      hipLaunchKernelGGL(k_big_panel, dim3(nRowBlocks), dim3(256), ldsPanel, s, p, dp, k0, dinvG, diagF);
-      const int nCol = (dp - k0 - kNB) / kNB;
-      if (nCol > 0) {
-        const int nBlocks = nCol * (nCol + 1) / 2 + nCol;   // lower-triangular blocks + the rhs row block
-        hipLaunchKernelGGL(k_big_syrk, dim3(nBlocks), dim3(256), ldsSyrk, s, p, dp, k0);
+    const int nb = dp / kNB;
+    int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 1) x nb block flags
+    static const bool perPanelLaunches = std::getenv("SVIN_BIG_CHOL_LAUNCHES") != nullptr;
+    hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
+                       (nb + 1) * nb);
+    if (!perPanelLaunches) {
+      const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
+      (void)hipFuncSetAttribute((const void*)k_big_chol_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
+      const int nTasks = nb * (nb + 1) / 2 + nb;
+      hipLaunchKernelGGL(k_big_chol_tasks, dim3(std::min(nTasks, kPersistMaxGrid)), dim3(256), ldsTasks, s, p, dp, dinvG, diagF,
+                         ready);
+    } else {
+      for (int k0 = 0; k0 < dp; k0 += kNB) {
+        const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included
+        hipLaunchKernelGGL(k_big_panel, dim3(nRowBlocks), dim3(256), ldsPanel, s, p, dp, k0, dinvG, diagF);
+        const int nCol = (dp - k0 - kNB) / kNB;
+        if (nCol > 0) {
+          const int nBlocks = nCol * (nCol + 1) / 2 + nCol;   // lower-triangular blocks + the rhs row block
+          hipLaunchKernelGGL(k_big_syrk, dim3(nBlocks), dim3(256), ldsSyrk, s, p, dp, k0);
+        }
       }
     }
     const size_t ldsBack = ((size_t)kBackSpan + 8 * 64) * 8;

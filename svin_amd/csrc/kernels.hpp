@@ -165,6 +165,13 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // Cholesky + GN step of the reduced system; fuseFinalize applies k_finalize_diag (metric + damping) while loading S
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);
+// doubles DeviceProblem::cholL must hold for a reduced system of d unknowns: the LDS-resident solver's spill copy, or
+// the blocked solver's (d64 + 64) x d64 matrix + 1/L_ii + factorised diagonal blocks + block-ready flags
+inline size_t solveReducedScratchDoubles(int d) {
+  const size_t dpad = ((size_t)d + 15) / 16 * 16, d64 = ((size_t)d + 63) / 64 * 64, nb = d64 / 64;
+  const size_t big = (d64 + 64) * d64 + d64 + d64 * 64 + ((nb + 1) * nb + 1) / 2 + 2;
+  return dpad * dpad > big ? dpad * dpad : big;
+}
 // post-solve pass (back-substitution, J*v / J*y sums, norms); fuseRadius > 0: its last block also takes the dogleg
 // step with that radius and retracts (single GPU, narrow windows) -- launchDoglegStep is then not needed
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius = -1.0);

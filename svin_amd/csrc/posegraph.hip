@@ -1033,7 +1033,7 @@ class PoseGraph {
     const size_t dp64 = ((size_t)nS + 63) / 64 * 64;
     dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
     dBand_.reserve(bandTot); dY_.reserve(yTot); dSp_.reserve(spTot);
-    dChol_.reserve(std::max((size_t)dpad * dpad, (dp64 + 64) * dp64 + dp64 + dp64 * 64));
+    dChol_.reserve(solveReducedScratchDoubles(nS));
     dPartial_.reserve((size_t)8 * kPgMaxPartials); dScal_.reserve(PG_NSCAL); dSolScal_.reserve(1);
     PgDev p;
     std::memset(&p, 0, sizeof(p));

@@ -680,7 +680,7 @@ void Window::pack() {
   dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
   {
     const size_t dp64 = ((size_t)d + 63) / 64 * 64;  // multi-workgroup solver: (dp64 + 64) x dp64 matrix + 1/L_ii + diagonal factors
-    dChol_.reserve(std::max<size_t>(std::max((size_t)dpad * dpad, (dp64 + 64) * dp64 + dp64 + dp64 * 64), 1));
+    dChol_.reserve(std::max<size_t>(solveReducedScratchDoubles(d), 1));
   }
   dPartial_.reserve((size_t)16 * 4096);
   dScal_.reserve(1);
