@@ -54,9 +54,10 @@ int svin_pg_get_drift(const svin_pg* h, double* yaw_drift_deg, double* r_drift, 
 /* solver layout (no reference counterpart; Ceres picks its own ordering): keyframes per piece (0 = keep, default
  * 64, at most 256 / tangent size) and the free-keyframe count up to which the whole graph is solved as one dense
  * system (default 128).  svin_pg_get_partition: free keyframes, separator keyframes, pieces, largest piece (rows),
- * Schur tiles, seconds of the host-side symbolic step of the last svin_pg_optimize */
+ * Schur tiles, seconds of the host-side symbolic step, separator unknowns, number of dense separator solves and their
+ * total seconds (HIP events on the solver's stream) of the last svin_pg_optimize */
 int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes);
-int svin_pg_get_partition(const svin_pg* h, double* out6);
+int svin_pg_get_partition(const svin_pg* h, double* out9);
 
 /* ceres::Solver::Summary of the last solve: initial_cost, final_cost, iterations, termination (0 convergence,
  * 1 no convergence, 3 failure), successful steps, solve seconds (device work, inputs resident) */

@@ -2278,7 +2278,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       if (p.anyExtVariable) LAUNCH(true); else LAUNCH(false);
 #undef LAUNCH
     } else {
-      hipMemsetAsync(p.slabs, 0, accBytes, s);
+      (void)hipMemsetAsync(p.slabs, 0, accBytes, s);
       const int grid = min((p.L + 3) / 4, 2048);
       DeviceProblem q = p;
 #define LAUNCH(E)                                                                                                   \

@@ -764,12 +764,17 @@ class PoseGraph {
     if (device < 0 || device >= count) throw std::runtime_error("svin_pg: invalid device index");
     PG_HIP_OK(hipSetDevice(device));
     PG_HIP_OK(hipStreamCreate(&s_));
+    for (int i = 0; i < kPgMaxTimed; ++i) { PG_HIP_OK(hipEventCreate(&evA_[i])); PG_HIP_OK(hipEventCreate(&evB_[i])); }
   }
-  ~PoseGraph() { if (s_) (void)hipStreamDestroy(s_); }
+  ~PoseGraph() {
+    for (int i = 0; i < kPgMaxTimed; ++i) { if (evA_[i]) (void)hipEventDestroy(evA_[i]); if (evB_[i]) (void)hipEventDestroy(evB_[i]); }
+    if (s_) (void)hipStreamDestroy(s_);
+  }
 
   std::vector<Keyframe> kfs;
   double summary[8] = {0, 0, 0, 1, 0, 0, 0, 0};   // [6] = seconds of the symbolic step (host)
-  int partition[5] = {0, 0, 0, 0, 0};             // free keyframes, separator keyframes, pieces, max piece rows, Schur tiles
+  int partition[7] = {0, 0, 0, 0, 0, 0, 0};       // free keyframes, separator keyframes, pieces, max piece rows, Schur tiles,
+                                                  // separator unknowns, timed dense solves ([7] of summary = their seconds)
   int pieceLen_ = 64, denseNodes_ = 128;
   // drift of the odometry frame against the optimised map (PoseGraph.cpp:356-363 / :521-526)
   double yawDrift = 0, rDrift[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tDrift[3] = {0, 0, 0};
@@ -1086,7 +1091,7 @@ class PoseGraph {
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
     };
     // damped normal equations at the current linearisation -> y (tangent order, scaled space)
-    auto solveNormalEquations = [&](double radius) {
+    auto solveNormalEquations = [&](double radius, int& nSolves) {
       PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * (size_t)nS * nS, s_));
       PG_HIP_OK(hipMemsetAsync(dSolScal_.p, 0, sizeof(SolverScalars), s_));
       if (nPieces > 0) {
@@ -1103,13 +1108,17 @@ class PoseGraph {
         hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256), dim3(256), 0, s_, p, nDest);
         hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
       }
+      PG_HIP_OK(hipEventRecord(evA_[nSolves % kPgMaxTimed], s_));
       launchSolveReduced(dp, s_, 0.0, false, false);
+      PG_HIP_OK(hipEventRecord(evB_[nSolves % kPgMaxTimed], s_));
+      ++nSolves;
       if (nPieces > 0) {
         if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
         else hipLaunchKernelGGL((k_pg_piece_back<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
       }
       hipLaunchKernelGGL(k_pg_scatter_sep, dim3(gN), dim3(128), 0, s_, p);
     };
+    int nSolves = 0;
     const auto t0 = std::chrono::steady_clock::now();
     // ---- Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy, default options
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
@@ -1136,7 +1145,7 @@ class PoseGraph {
       if (gradMax <= gradient_tolerance) { termination = 0; break; }
       if (radius <= min_radius) { termination = 0; break; }
       ++iteration;
-      solveNormalEquations(radius);
+      solveNormalEquations(radius, nSolves);
       hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
       if (six_) hipLaunchKernelGGL(k_pg_model<6>, dim3(gE), dim3(128), 0, s_, p);
       else hipLaunchKernelGGL(k_pg_model<4>, dim3(gE), dim3(128), 0, s_, p);
@@ -1177,6 +1186,13 @@ class PoseGraph {
     PG_HIP_OK(hipStreamSynchronize(s_));
     summary[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     summary[1] = x_cost; summary[2] = iteration; summary[3] = termination; summary[4] = successful;
+    summary[7] = 0;
+    for (int i = 0; i < std::min(nSolves, kPgMaxTimed); ++i) {   // HIP events on the solve's own stream
+      float ms = 0;
+      PG_HIP_OK(hipEventElapsedTime(&ms, evA_[i], evB_[i]));
+      summary[7] += 1e-3 * ms;
+    }
+    partition[5] = nS; partition[6] = std::min(nSolves, kPgMaxTimed);
     // ---- write back, drift update, keyframes after cur (PoseGraph.cpp:340-375 / :504-534)
     std::vector<double> hy(nn), ht(3 * (size_t)nn), hq(4 * (size_t)nn);
     PG_HIP_OK(hipMemcpy(hy.data(), p.yaw, sizeof(double) * nn, hipMemcpyDeviceToHost));
@@ -1222,6 +1238,8 @@ class PoseGraph {
   bool six_;
   int maxIter_;
   hipStream_t s_ = nullptr;
+  static constexpr int kPgMaxTimed = 64;
+  hipEvent_t evA_[kPgMaxTimed] = {}, evB_[kPgMaxTimed] = {};
   Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
   Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dY_, dSp_;
   Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_, dSepOff_, dNodePiece_, dNodeRow_, dColSep_, dRowTan_, dGPtr_, dRPtr_;
@@ -1306,10 +1324,13 @@ int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes) 
   h->g.denseNodes_ = dense_keyframes;
   return 1;
 }
-int svin_pg_get_partition(const svin_pg* h, double* out6) {
-  if (!h || !out6) return -1;
-  for (int i = 0; i < 5; ++i) out6[i] = h->g.partition[i];
-  out6[5] = h->g.summary[6];
+int svin_pg_get_partition(const svin_pg* h, double* out9) {
+  if (!h || !out9) return -1;
+  for (int i = 0; i < 5; ++i) out9[i] = h->g.partition[i];
+  out9[5] = h->g.summary[6];
+  out9[6] = h->g.partition[5];
+  out9[7] = h->g.partition[6];
+  out9[8] = h->g.summary[7];
   return 1;
 }
 int svin_pg_summary(const svin_pg* h, double* out6) {

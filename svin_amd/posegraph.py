@@ -107,7 +107,8 @@ class PoseGraph:
         self._check(self.L.svin_pg_set_partition(self.h, piece_keyframes, dense_keyframes), "set_partition")
 
     def partition(self):
-        s = np.zeros(6)
+        s = np.zeros(9)
         self._check(self.L.svin_pg_get_partition(self.h, _p(s)), "get_partition")
         return dict(free=int(s[0]), separators=int(s[1]), pieces=int(s[2]), max_rows=int(s[3]), tiles=int(s[4]),
-                    symbolic_seconds=s[5])
+                    symbolic_seconds=float(s[5]), separator_unknowns=int(s[6]), dense_solves=int(s[7]),
+                    dense_solve_seconds=float(s[8]))
