@@ -596,17 +596,21 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         for (const Observation& o : lm.obs) if (o.resId == rid) return o.poseId;
         return (uint64_t)0;
       };
+      auto dropObservation = [&](uint64_t rid) {   // Estimator::removeObservation(rid) on this landmark
+        for (size_t i = 0; i < lm.obs.size(); ++i)
+          if (lm.obs[i].resId == rid) { removeObsRecord(lm, i); return; }
+      };
       for (size_t r = 0; r < residuals.size(); ++r) {
         const uint64_t rid = residuals[r];
         const uint64_t poseId = poseOf(rid);
         if ((contains(removeFrames, poseId) && hasNewObservations) ||
             (!contains(allLinearizedFrames, poseId) && marginalize)) {
-          removeObservationById(rid);
+          dropObservation(rid);
           residuals.erase(residuals.begin() + r);
           r--;
         } else if (marginalize && contains(allLinearizedFrames, poseId)) {
           if (obsCount < 2) {
-            removeObservationById(rid);
+            dropObservation(rid);
             residuals.erase(residuals.begin() + r);
             r--;
           } else {

@@ -139,8 +139,8 @@ void Window::removeFactor(uint64_t id) {
 }
 void Window::removeObsRecord(Landmark& lm, size_t idx) {
   const Observation o = lm.obs[idx];
-  if (Block* b = findBlock(o.poseId)) eraseOne(b->residuals, o.resId);
-  if (Block* b = findBlock(o.extId)) eraseOne(b->residuals, o.resId);
+  if (Block* b = findBlock(o.poseId)) b->nObs--;
+  if (Block* b = findBlock(o.extId)) b->nObs--;
   obsRes2Lm_.erase(o.resId);
   lm.obs.erase(lm.obs.begin() + idx);
 }
@@ -148,14 +148,14 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
   Block* b = findBlock(id);
   if (!b) return;
   const std::vector<uint64_t> res = b->residuals;
-  for (uint64_t rid : res) {
-    auto it = obsRes2Lm_.find(rid);
-    if (it != obsRes2Lm_.end()) {
-      Landmark& lm = landmarks_.at(it->second);
-      for (size_t i = 0; i < lm.obs.size(); ++i)
-        if (lm.obs[i].resId == rid) { removeObsRecord(lm, i); break; }
-    } else if (factors_.count(rid)) {
-      removeFactor(rid);
+  for (uint64_t rid : res)
+    if (factors_.count(rid)) removeFactor(rid);
+  if (b->nObs > 0) {  // reprojection residuals are only listed per landmark: the (rare) cascade scans for them
+    for (auto& kv : landmarks_) {
+      Landmark& lm = kv.second;
+      for (size_t i = 0; i < lm.obs.size();)
+        if (lm.obs[i].poseId == id || lm.obs[i].extId == id) removeObsRecord(lm, i);
+        else ++i;
     }
   }
   blocks_.erase(id);
@@ -408,8 +408,8 @@ uint64_t Window::addObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, ui
   o.uv[0] = uv[0]; o.uv[1] = uv[1];
   o.size = size;
   lit->second.obs.push_back(o);
-  blocks_.at(o.poseId).residuals.push_back(o.resId);
-  blocks_.at(o.extId).residuals.push_back(o.resId);
+  blocks_.at(o.poseId).nObs++;
+  blocks_.at(o.extId).nObs++;
   obsRes2Lm_[o.resId] = lmId;
   return o.resId;
 }

@@ -35,7 +35,8 @@ struct Block {
   int kind = B_POSE;  // B_POSE / B_EXT / B_SB
   bool fixed = false;
   double x[9] = {0};
-  std::vector<uint64_t> residuals;  // ids of residual blocks touching it (insertion order)
+  std::vector<uint64_t> residuals;  // ids of the factors / the prior touching it (insertion order)
+  int nObs = 0;                     // reprojection residuals touching it (they live in Landmark::obs only)
 };
 
 struct Observation {
