@@ -93,6 +93,12 @@ int svin_ba_add_landmark(svin_ba* h, uint64_t landmark_id, const double hp[4]); 
  * Returns the residual id (non-zero) or 0 for a duplicate (the reference returns NULL). */
 uint64_t svin_ba_add_observation(svin_ba* h, uint64_t landmark_id, uint64_t pose_id, uint64_t cam_idx,
                                  uint64_t keypoint_idx, const double uv[2], double keypoint_size);
+/* the same call for n matches held as arrays (uv = n x 2); out_ids (optional) receives the residual ids, 0 for
+ * duplicates; returns the number of observations added.  The reference adds matches one by one from
+ * VioKeyframeWindowMatchingAlgorithm::setBestMatch; a host that has them as arrays saves n - 1 boundary crossings. */
+int svin_ba_add_observations(svin_ba* h, int n, const uint64_t* landmark_ids, const uint64_t* pose_ids,
+                             const uint64_t* cam_idx, const uint64_t* keypoint_idx, const double* uv,
+                             const double* keypoint_sizes, uint64_t* out_ids);
 int svin_ba_remove_observation(svin_ba* h, uint64_t landmark_id, uint64_t pose_id, uint64_t cam_idx,
                                uint64_t keypoint_idx);                                 /* :452-474 */
 int svin_ba_remove_observation_by_id(svin_ba* h, uint64_t residual_id);               /* :432-449 */

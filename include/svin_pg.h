@@ -57,7 +57,11 @@ int svin_pg_get_drift(const svin_pg* h, double* yaw_drift_deg, double* r_drift, 
  * Schur tiles, seconds of the host-side symbolic step, separator unknowns, number of dense separator solves and their
  * total seconds (HIP events on the solver's stream) of the last svin_pg_optimize */
 int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes);
-int svin_pg_get_partition(const svin_pg* h, double* out9);
+/* 1 = eliminate the pieces only; 2 (default) = also eliminate the cut keyframes in level-2 pieces (of
+ * level2_piece_keyframes cut keyframes, 0 = keep, default 32) so that the dense root only holds the loop cover */
+int svin_pg_set_levels(svin_pg* h, int levels, int level2_piece_keyframes);
+/* out10: ... as above, [6] = unknowns of the dense root solve, [9] = level-2 pieces */
+int svin_pg_get_partition(const svin_pg* h, double* out10);
 
 /* ceres::Solver::Summary of the last solve: initial_cost, final_cost, iterations, termination (0 convergence,
  * 1 no convergence, 3 failure), successful steps, solve seconds (device work, inputs resident) */

@@ -96,6 +96,19 @@ uint64_t svin_ba_add_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_
   GUARD_BEGIN return h->w.addObservation(lm, pose, cam, kp, uv, size);
   GUARD_END(0)
 }
+int svin_ba_add_observations(svin_ba* h, int n, const uint64_t* lm, const uint64_t* pose, const uint64_t* cam, const uint64_t* kp,
+                             const double* uv, const double* size, uint64_t* out_ids) {
+  if (!h || n < 0 || (n > 0 && (!lm || !pose || !cam || !kp || !uv || !size))) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  int added = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t id = h->w.addObservation(lm[i], pose[i], cam[i], kp[i], uv + 2 * (size_t)i, size[i]);
+    if (out_ids) out_ids[i] = id;
+    added += id != 0;
+  }
+  return added;
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_remove_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.removeObservation(lm, pose, cam, kp);

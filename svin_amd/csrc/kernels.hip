@@ -2501,7 +2501,7 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
         // branch-free: always read a valid element of the lower triangle, select afterwards.  Diagonal tiles are
         // kept fully symmetric (the MFMA trailing update preserves that).
         const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
-        const double x = p.S[(size_t)ci * d + cj];
+        const double x = p.S[(size_t)ci * (p.ldS ? p.ldS : d) + cj];
         v[it][rg] = (gi < d && gj < d) ? x : ((gi == gj) ? 1.0 : 0.0);
       }
     }
@@ -2731,6 +2731,22 @@ __device__ __forceinline__ void storeBlock64(double* g, int ld, const double* ti
     g[(size_t)r * ld + c] = tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)];
   }
 }
+// the same through agent-scope relaxed atomics (sc1: the access itself is coherent across the XCDs' L2s), for blocks
+// handed between workgroups of one launch without an L2 write-back / invalidate
+__device__ __forceinline__ void loadBlock64Coherent(const double* g, int ld, double* tiles) {
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)] =
+        __hip_atomic_load(g + (size_t)r * ld + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void storeBlock64Coherent(double* g, int ld, const double* tiles) {
+  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
+    const int r = e >> 6, c = e & 63;
+    __hip_atomic_store(g + (size_t)r * ld + c, tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 // in-LDS factorisation of a 64x64 SPD block (4x4 tiles, diagonal tiles fully symmetric) by 4 waves:
 // lower tiles <- L, strict upper triangle of the diagonal tiles <- L_tt^-T, dinv <- 1/L_ii
 __device__ void factor64(double* T, double* dinv, int* failFlag) {
@@ -2829,7 +2845,7 @@ __global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, dou
     if (gi < dpad) {
       x = (gi == gj) ? 1.0 : 0.0;
       if (gi < d && gj < d) {
-        x = p.S[(size_t)max(gi, gj) * d + min(gi, gj)];
+        x = p.S[(size_t)max(gi, gj) * (p.ldS ? p.ldS : d) + min(gi, gj)];
         if (gi == gj && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
       }
     } else if (gi == dpad && gj < d) {
@@ -2906,8 +2922,9 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
 // X = C L_JJ^-T (slabSolve64).  Tasks are numbered column by column and dealt round-robin to <= 256 co-resident
 // workgroups, each working through its tasks in increasing order; a task only depends on tasks with a smaller
 // number, which are either finished, running elsewhere or earlier in the same workgroup, so the waits cannot cycle.
-// Finished blocks are published with a release store of ready[I][J] and consumed after an acquire load (agent scope:
-// the blocks cross XCD L2s).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
+// Finished blocks cross XCD L2s: they are written and read with agent-scope relaxed atomics (sc1 accesses, coherent by
+// themselves), the writer waits for its stores to complete before ready[I][J] is set, the reader polls ready[I][J]
+// before it loads -- no L2 write-back / invalidate (buffer_wbl2 / buffer_inv cost ~10 us per hand-over here).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
 // The per-panel launch pair (k_big_panel + k_big_syrk) stays as the fallback (SVIN_BIG_CHOL_LAUNCHES=1).
 constexpr int kSpinMax = 1 << 20;
 constexpr int kPersistMaxGrid = 256;
@@ -2918,7 +2935,8 @@ __device__ __forceinline__ bool pollReady(const int* f) {
   }
   return false;
 }
-__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
+__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready,
+                                                        int dbgSkip) {
   extern __shared__ double smem[];
   double* Xi = smem;                       // X(I, k) / the slab during the solve
   double* Xj = smem + kBigBlockLds;        // X(J, k)
@@ -2954,7 +2972,7 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
     if (firstMissing < J) atomicMin(seen, firstMissing);
     __syncthreads();
     const int kSafe = seen[0];   // dependencies k < kSafe are present
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __syncthreads();
     for (int k = 0; k < J; ++k) {
       if (k >= kSafe) {
@@ -2963,12 +2981,13 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
           if (!ok) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
-      loadBlock64(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
-      if (I != J) loadBlock64(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
+      if (!(dbgSkip & 8)) loadBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
+      if (I != J && !(dbgSkip & 8)) loadBlock64Coherent(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
       __syncthreads();
       const double* XJ = (I == J) ? Xi : Xj;
+      if (!(dbgSkip & 4))
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -2989,28 +3008,28 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
         for (int rg = 0; rg < 4; ++rg)
           Dt[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
       __syncthreads();
-      factor64(Dt, dinv, &p.scal->cholFail);
-      storeBlock64(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
-      if (tid < kNB) dinvG[kNB * J + tid] = dinv[tid];
+      if (!(dbgSkip & 1)) factor64(Dt, dinv, &p.scal->cholFail);
+      storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
+      if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (tid == 0 && !gaveUp && !pollReady(ready + J * nb + J)) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
       __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      loadBlock64(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
-      if (tid < kNB) dinv[tid] = dinvG[kNB * J + tid];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      loadBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
+      if (tid < kNB) dinv[tid] = __hip_atomic_load(dinvG + kNB * J + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           Xi[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
       __syncthreads();
-      slabSolve64(Dt, Xi, dinv);
+      if (!(dbgSkip & 2)) slabSolve64(Dt, Xi, dinv);
       __syncthreads();
-      storeBlock64(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, Xi);
+      storeBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, Xi);
     }
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's coherent stores have completed (vmcnt 0)
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ready + I * nb + J, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(ready + I * nb + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -3127,8 +3146,9 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
       (void)hipFuncSetAttribute((const void*)k_big_chol_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
       const int nTasks = nb * (nb + 1) / 2 + nb;
+      static const int dbgSkip = std::getenv("SVIN_TASK_SKIP") ? std::atoi(std::getenv("SVIN_TASK_SKIP")) : 0;
       hipLaunchKernelGGL(k_big_chol_tasks, dim3(std::min(nTasks, kPersistMaxGrid)), dim3(256), ldsTasks, s, p, dp, dinvG, diagF,
-                         ready);
+                         ready, dbgSkip);
     } else {
       for (int k0 = 0; k0 < dp; k0 += kNB) {
         const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included

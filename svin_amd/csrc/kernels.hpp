@@ -137,6 +137,7 @@ struct DeviceProblem {
   double *priorMv, *priorMy;                    // scratch m
   // normal equations
   double *S, *gRed, *gFull, *hC, *htilC, *scaleC;
+  int ldS;   // leading dimension of S as seen by launchSolveReduced (0 = d); lets a caller solve a trailing principal block in place
   double *Vinv, *bl, *hL, *scaleL;           // per landmark 6 / 3 / 3 / 3
   double *slabs; int nSlabs;                 // per-workgroup private copies of the leading dC x dC block (+2 dC vectors)
   double *yC, *yL;                           // Gauss-Newton solution (cam d, landmarks 3L)

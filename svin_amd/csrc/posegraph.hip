@@ -464,15 +464,17 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
 #pragma unroll
     for (int u = 0; u < LDB; ++u) yh[u] = 0.0;
     for (int rb = 0; rb < n; rb += LDB) {
-      double v[LDB];
-#pragma unroll
-      for (int u = 0; u < LDB; ++u) v[u] = rb + u < n ? Yc[(size_t)(rb + u) * pc.ld] : 0.0;
+      double v[8];
 #pragma unroll
       for (int u = 0; u < LDB; ++u) {
+        if ((u & 7) == 0) {   // the next 8 right-hand-side values of this column, loads in flight together
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = (u + q < LDB && rb + u + q < n) ? Yc[(size_t)(rb + u + q) * pc.ld] : 0.0;
+        }
         const int r = rb + u;
         if (r < n) {
           const double* row = Lb + r * LDB;
-          double x0 = v[u], x1 = 0.0;
+          double x0 = v[u & 7], x1 = 0.0;
 #pragma unroll
           for (int t = 1; t <= BW; ++t) {
             const double term = row[BW - t] * yh[(u - t + 2 * LDB) % LDB];
@@ -526,6 +528,25 @@ __global__ void k_pg_sep_gather_rhs(PgDev p) {
     acc += p.Sp[pc.sOff + (size_t)(pc.cols - 1) * pc.ld + src.y + c];
   }
   p.rhsS[idx] -= acc;
+}
+
+// level 2: the blocks of a level-2 piece (band, coupling columns, right-hand side) copied out of the separator system
+__global__ void k_pg_l2_extract(PgDev p, const int4* xDst, const int2* xSrc, int nX) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, DD = p.D * p.D;
+  if (idx >= nX * DD) return;
+  const int b = idx / DD, e = idx - b * DD, r = e / p.D, c = e - r * p.D;
+  const int4 dst = xDst[b];
+  const int2 src = xSrc[b];
+  const int kind = dst.x & 15;
+  const PgPiece pc = p.pieces[dst.y];
+  if (kind == 2) {        // band block (rows of the later keyframe); the diagonal block only has its lower triangle
+    if (dst.z == dst.w && c > r) return;
+    p.band[pc.bandOff + (size_t)(dst.z + r) * (p.BW + 1) + (dst.w + c - dst.z - r + p.BW)] = p.HS[(size_t)(src.x + r) * p.nS + src.y + c];
+  } else if (kind == 3) { // coupling to a root separator: stored transposed in the lower triangle of the system
+    p.Y[pc.yOff + (size_t)(dst.z + r) * pc.ld + dst.w + c] = p.HS[(size_t)(src.x + c) * p.nS + src.y + r];
+  } else if (c == 0) {    // right-hand side column
+    p.Y[pc.yOff + (size_t)(dst.z + r) * pc.ld + dst.w] = p.rhsS[src.x + r];
+  }
 }
 
 // interior unknowns of one piece: x_I = L^-T (y_r - Y_C x_S)
@@ -773,9 +794,10 @@ class PoseGraph {
 
   std::vector<Keyframe> kfs;
   double summary[8] = {0, 0, 0, 1, 0, 0, 0, 0};   // [6] = seconds of the symbolic step (host)
-  int partition[7] = {0, 0, 0, 0, 0, 0, 0};       // free keyframes, separator keyframes, pieces, max piece rows, Schur tiles,
+  int partition[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // [7] level-2 pieces, [8] root unknowns; [5] = unknowns of the dense solve       // free keyframes, separator keyframes, pieces, max piece rows, Schur tiles,
                                                   // separator unknowns, timed dense solves ([7] of summary = their seconds)
-  int pieceLen_ = 64, denseNodes_ = 128;
+  int pieceLen_ = 64, denseNodes_ = 128, l2Len_ = 32;
+  bool level2_ = true;
   // drift of the odometry frame against the optimised map (PoseGraph.cpp:356-363 / :521-526)
   double yawDrift = 0, rDrift[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tDrift[3] = {0, 0, 0};
 
@@ -870,7 +892,7 @@ class PoseGraph {
     for (int k = 0; k < nn; ++k)
       if (!fixed[k]) { pos[k] = (int)freeNodes.size(); freeNodes.push_back(k); }
     const int F = (int)freeNodes.size();
-    std::vector<char> isSep(nn, 0);
+    std::vector<char> isSep(nn, 0), isCover(nn, 0);
     std::vector<int> pieceOf(nn, -1);
     int nPieces = 0;
     if (F <= denseNodes_) {
@@ -881,7 +903,10 @@ class PoseGraph {
       for (int e = 0; e < ne; ++e)
         if (isLong(e)) { longDeg[ea[e]]++; longDeg[eb[e]]++; }
       for (int e = 0; e < ne; ++e)
-        if (isLong(e) && !isSep[ea[e]] && !isSep[eb[e]]) isSep[longDeg[ea[e]] >= longDeg[eb[e]] ? ea[e] : eb[e]] = 1;
+        if (isLong(e) && !isSep[ea[e]] && !isSep[eb[e]]) {
+          const int c = longDeg[ea[e]] >= longDeg[eb[e]] ? ea[e] : eb[e];
+          isSep[c] = 1; isCover[c] = 1;
+        }
       // walk the chain: close a piece after pieceLen interior keyframes (or when it touches too many separators)
       std::vector<int> stamp(nn, -1);
       int cnt = 0, adj = 2 * w;
@@ -910,53 +935,177 @@ class PoseGraph {
         if (used) ++nPieces;
       }
     }
+    // ---- level 2 (optional): the cut keyframes form a chain of their own (a cut group only talks to the next one
+    // through the piece between them: reach W2 = 2w - 1 cut keyframes); they are eliminated the same way, so the
+    // dense root only holds the loop cover and a few level-2 cuts
+    const int W2 = 2 * w - 1, BW2 = W2 * D + D - 1;
+    std::vector<std::vector<int>> pieceAdjNodes(nPieces);
+    for (int e = 0; e < ne; ++e) {
+      const int a = ea[e], b = eb[e];
+      if (pos[a] < 0 || pos[b] < 0) continue;
+      if (!isSep[a] && !isSep[b] && pieceOf[a] != pieceOf[b]) throw std::runtime_error("svin_pg: partition left an edge between two pieces");
+      if (!isSep[a] && isSep[b]) pieceAdjNodes[pieceOf[a]].push_back(b);
+      if (!isSep[b] && isSep[a]) pieceAdjNodes[pieceOf[b]].push_back(a);
+    }
+    for (auto& A : pieceAdjNodes) { std::sort(A.begin(), A.end()); A.erase(std::unique(A.begin(), A.end()), A.end()); }
+    std::vector<std::vector<int>> sepAdj(nn);   // structure of the separator system after level 1 (node ids)
+    std::vector<int> l2PieceOf(nn, -1);
+    std::vector<char> isRoot(nn, 0);            // separators that stay in the dense root
+    int nPieces2 = 0;
+    {
+      std::vector<int> cutList;
+      for (int k : freeNodes)
+        if (isSep[k] && !isCover[k]) cutList.push_back(k);
+      bool useL2 = level2_ && nPieces >= 8 && (int)cutList.size() >= 3 * l2Len_;
+      if (useL2) {
+        for (const auto& A : pieceAdjNodes)
+          for (int x : A)
+            for (int y : A)
+              if (x != y) sepAdj[x].push_back(y);
+        for (int e = 0; e < ne; ++e) {
+          const int a = ea[e], b = eb[e];
+          if (pos[a] >= 0 && pos[b] >= 0 && isSep[a] && isSep[b]) { sepAdj[a].push_back(b); sepAdj[b].push_back(a); }
+        }
+        for (int k : freeNodes)
+          if (isSep[k]) { auto& A = sepAdj[k]; std::sort(A.begin(), A.end()); A.erase(std::unique(A.begin(), A.end()), A.end()); }
+        const int maxAdj2 = (kPgPieceThreads - 1) / D;
+        std::vector<int> stamp(nn, -1);
+        std::vector<char> isL2Cut(nn, 0);
+        int cnt = 0, adj = 2 * W2;
+        const int C = (int)cutList.size();
+        for (int i = 0; i < C; ++i) {
+          const int k = cutList[i];
+          l2PieceOf[k] = nPieces2;
+          ++cnt;
+          for (int o : sepAdj[k])
+            if (isCover[o] && stamp[o] != nPieces2) { stamp[o] = nPieces2; ++adj; }
+          if ((cnt >= l2Len_ || adj + 12 >= maxAdj2) && i + W2 < C - 1) {
+            for (int j = 1; j <= W2; ++j) isL2Cut[cutList[i + j]] = 1;
+            i += W2;
+            ++nPieces2; cnt = 0; adj = 2 * W2;
+          }
+        }
+        if (cnt > 0) ++nPieces2;
+        for (int k : freeNodes)
+          if (isSep[k] && (isCover[k] || isL2Cut[k])) { isRoot[k] = 1; l2PieceOf[k] = -1; }
+        // validate: interior cut keyframes only talk to their own level-2 piece (within W2) or to root separators,
+        // and no piece exceeds the column budget; otherwise fall back to one level
+        std::vector<int> rank(nn, -1);
+        for (int i = 0, r = 0; i < C; ++i)
+          if (!isRoot[cutList[i]]) rank[cutList[i]] = r++;
+        std::vector<std::vector<int>> a2(nPieces2);
+        for (int k : cutList) {
+          if (isRoot[k]) continue;
+          for (int o : sepAdj[k]) {
+            if (isRoot[o]) a2[l2PieceOf[k]].push_back(o);
+            else if (l2PieceOf[o] != l2PieceOf[k] || std::abs(rank[o] - rank[k]) > W2) useL2 = false;
+          }
+        }
+        for (auto& A : a2) {
+          std::sort(A.begin(), A.end());
+          A.erase(std::unique(A.begin(), A.end()), A.end());
+          if ((int)A.size() * D + 1 > kPgPieceThreads) useL2 = false;
+        }
+        if (nPieces2 < 2) useL2 = false;
+      }
+      if (!useL2) {
+        nPieces2 = 0;
+        for (int k : freeNodes) { l2PieceOf[k] = -1; isRoot[k] = isSep[k]; }
+      }
+    }
     std::vector<int> sepOff(nn, -1), nodePiece(nn, -1), nodeRow(nn, -1);
     int nS = 0;
     for (int k : freeNodes)
-      if (isSep[k]) { sepOff[k] = nS; nS += D; }
-    std::vector<PgPiece> pieces(nPieces);
-    std::vector<std::vector<int>> pieceAdj(nPieces);
-    std::vector<int> rowTan, colSep;
-    {
-      std::vector<int> rows(nPieces, 0);
-      for (int k : freeNodes)
-        if (!isSep[k]) { nodePiece[k] = pieceOf[k]; nodeRow[k] = rows[pieceOf[k]]; rows[pieceOf[k]] += D; }
-      for (int e = 0; e < ne; ++e) {
-        const int a = ea[e], b = eb[e];
-        if (pos[a] < 0 || pos[b] < 0) continue;
-        if (!isSep[a] && !isSep[b] && pieceOf[a] != pieceOf[b]) throw std::runtime_error("svin_pg: partition left an edge between two pieces");
-        if (!isSep[a] && isSep[b]) pieceAdj[pieceOf[a]].push_back(sepOff[b]);
-        if (!isSep[b] && isSep[a]) pieceAdj[pieceOf[b]].push_back(sepOff[a]);
-      }
+      if (isSep[k] && !isRoot[k]) { sepOff[k] = nS; nS += D; }
+    const int offR = nS;   // the root = trailing block of the separator system
+    for (int k : freeNodes)
+      if (isSep[k] && isRoot[k]) { sepOff[k] = nS; nS += D; }
+    const int nR = nS - offR;
+    // piece descriptors of one level from the per-piece row counts and adjacent separator offsets
+    struct LevelHost {
+      std::vector<PgPiece> pieces;
+      std::vector<std::vector<int>> adj;   // per piece: sorted offsets of the separators it touches
+      std::vector<int> rowMap, colSep, gPtr, rPtr;
+      std::vector<int4> tileWork, gSrc;
+      std::vector<int2> gDst, rSrc;
+      int maxRows = 0, nDest = 0;
+      size_t bandTot = 1, yTot = 1, spTot = 1;
+    };
+    auto finishLevel = [&](LevelHost& Lh, const std::vector<int>& rows, int bw) {
+      const int np = (int)rows.size();
+      Lh.pieces.resize(np);
       long long bandOff = 0, yOff = 0, sOff = 0;
-      for (int pi = 0; pi < nPieces; ++pi) {
-        auto& A = pieceAdj[pi];
+      for (int pi = 0; pi < np; ++pi) {
+        auto& A = Lh.adj[pi];
         std::sort(A.begin(), A.end());
         A.erase(std::unique(A.begin(), A.end()), A.end());
-        PgPiece& pc = pieces[pi];
+        PgPiece& pc = Lh.pieces[pi];
         pc.rows = rows[pi];
         pc.cols = (int)A.size() * D + 1;
         if (pc.cols > kPgPieceThreads) throw std::runtime_error("svin_pg: a piece touches too many separators");
         pc.ld = (pc.cols + 15) / 16 * 16;
-        pc.colPtr = (int)colSep.size();
-        pc.rowPtr = (int)rowTan.size();
+        pc.colPtr = (int)Lh.colSep.size();
+        pc.rowPtr = (int)Lh.rowMap.size();
         pc.pad = 0;
         pc.bandOff = bandOff; pc.yOff = yOff; pc.sOff = sOff;
-        bandOff += (long long)pc.rows * (BW + 1);
+        bandOff += (long long)pc.rows * (bw + 1);
         yOff += (long long)pc.rows * pc.ld;
         sOff += (long long)pc.ld * pc.ld;
         for (int so : A)
-          for (int c = 0; c < D; ++c) colSep.push_back(so + c);
-        rowTan.resize(rowTan.size() + pc.rows);
+          for (int c = 0; c < D; ++c) Lh.colSep.push_back(so + c);
+        Lh.rowMap.resize(Lh.rowMap.size() + pc.rows);
+        Lh.maxRows = std::max(Lh.maxRows, pc.rows);
       }
+      Lh.bandTot = (size_t)std::max<long long>(bandOff, 1); Lh.yTot = (size_t)std::max<long long>(yOff, 1);
+      Lh.spTot = (size_t)std::max<long long>(sOff, 1);
+      // work lists: Schur tiles, and per separator block / separator keyframe the pieces that contribute to it
+      struct Contrib { long long key; int piece, ro, co; };
+      std::vector<Contrib> cs;
+      std::vector<std::vector<int2>> rl(nS / D);
+      for (int pi = 0; pi < np; ++pi) {
+        const PgPiece& pc = Lh.pieces[pi];
+        const int nt = pc.ld / 16;
+        for (int ti = 0; ti < nt; ++ti)
+          for (int tj = 0; tj <= ti; ++tj) Lh.tileWork.push_back(make_int4(pi, ti, tj, 0));
+        const auto& A = Lh.adj[pi];
+        for (size_t i = 0; i < A.size(); ++i) {
+          rl[A[i] / D].push_back(make_int2(pi, (int)i * D));
+          for (size_t j = 0; j <= i; ++j)
+            cs.push_back({(long long)A[i] * nS + A[j], pi, (int)i * D, (int)j * D});
+        }
+      }
+      std::stable_sort(cs.begin(), cs.end(), [](const Contrib& x, const Contrib& y) { return x.key < y.key; });
+      Lh.gPtr.assign(1, 0);
+      for (size_t i = 0; i < cs.size(); ++i) {
+        if (i == 0 || cs[i].key != cs[i - 1].key) {
+          if (i) Lh.gPtr.push_back((int)Lh.gSrc.size());
+          Lh.gDst.push_back(make_int2((int)(cs[i].key / nS), (int)(cs[i].key % nS)));
+        }
+        Lh.gSrc.push_back(make_int4(cs[i].piece, cs[i].ro, cs[i].co, 0));
+      }
+      if (!cs.empty()) Lh.gPtr.push_back((int)Lh.gSrc.size());
+      Lh.rPtr.assign(nS / D + 1, 0);
+      for (int sn = 0; sn < nS / D; ++sn) {
+        Lh.rPtr[sn + 1] = Lh.rPtr[sn] + (int)rl[sn].size();
+        Lh.rSrc.insert(Lh.rSrc.end(), rl[sn].begin(), rl[sn].end());
+      }
+      Lh.nDest = (int)Lh.gDst.size();
+    };
+    auto colIn = [&](const std::vector<int>& A, int so) { return (int)(std::lower_bound(A.begin(), A.end(), so) - A.begin()) * D; };
+    // level 1
+    LevelHost L1;
+    {
+      std::vector<int> rows(nPieces, 0);
+      for (int k : freeNodes)
+        if (!isSep[k]) { nodePiece[k] = pieceOf[k]; nodeRow[k] = rows[pieceOf[k]]; rows[pieceOf[k]] += D; }
+      L1.adj.resize(nPieces);
+      for (int pi = 0; pi < nPieces; ++pi)
+        for (int o : pieceAdjNodes[pi]) L1.adj[pi].push_back(sepOff[o]);
+      finishLevel(L1, rows, BW);
       for (int k : freeNodes)
         if (!isSep[k])
-          for (int c = 0; c < D; ++c) rowTan[pieces[pieceOf[k]].rowPtr + nodeRow[k] + c] = off[k] + c;
+          for (int c = 0; c < D; ++c) L1.rowMap[L1.pieces[pieceOf[k]].rowPtr + nodeRow[k] + c] = off[k] + c;
     }
-    auto colOf = [&](int pi, int so) {
-      const auto& A = pieceAdj[pi];
-      return (int)(std::lower_bound(A.begin(), A.end(), so) - A.begin()) * D;
-    };
     std::vector<int4> edgeDst(ne);
     for (int e = 0; e < ne; ++e) {
       const int a = ea[e], b = eb[e];
@@ -971,54 +1120,48 @@ class PoseGraph {
         } else {
           const bool rowB = !isSep[b];   // the interior node owns the rows
           const int in = rowB ? b : a, sp = rowB ? a : b;
-          d4 = make_int4(3 | (rowB ? 16 : 0), pieceOf[in], nodeRow[in], colOf(pieceOf[in], sepOff[sp]));
+          d4 = make_int4(3 | (rowB ? 16 : 0), pieceOf[in], nodeRow[in], colIn(L1.adj[pieceOf[in]], sepOff[sp]));
         }
       }
       edgeDst[e] = d4;
     }
-    // work lists: Schur tiles, and per separator block / separator keyframe the pieces that contribute to it
-    std::vector<int4> tileWork, gSrc;
-    std::vector<int2> gDst, rSrc;
-    std::vector<int> gPtr(1, 0), rPtr(nS / D + 1, 0);
-    {
-      struct Contrib { long long key; int piece, ro, co; };
-      std::vector<Contrib> cs;
-      std::vector<std::vector<int2>> rl(nS / D);
-      for (int pi = 0; pi < nPieces; ++pi) {
-        const PgPiece& pc = pieces[pi];
-        const int nt = pc.ld / 16;
-        for (int ti = 0; ti < nt; ++ti)
-          for (int tj = 0; tj <= ti; ++tj) tileWork.push_back(make_int4(pi, ti, tj, 0));
-        const auto& A = pieceAdj[pi];
-        for (size_t i = 0; i < A.size(); ++i) {
-          rl[A[i] / D].push_back(make_int2(pi, (int)i * D));
-          for (size_t j = 0; j <= i; ++j)
-            cs.push_back({(long long)A[i] * nS + A[j], pi, (int)i * D, (int)j * D});
+    // level 2: pieces of cut keyframes; their blocks are copied out of the level-1 separator system
+    LevelHost L2;
+    std::vector<int4> xDst;   // {kind | transposed << 4, piece, dstRow, dstCol}: 2 band, 3 coupling, 4 right-hand side
+    std::vector<int2> xSrc;   // {row, col} offsets in the separator system
+    if (nPieces2 > 0) {
+      std::vector<int> rows(nPieces2, 0), l2Row(nn, -1);
+      for (int k : freeNodes)
+        if (l2PieceOf[k] >= 0) { l2Row[k] = rows[l2PieceOf[k]]; rows[l2PieceOf[k]] += D; }
+      L2.adj.resize(nPieces2);
+      for (int k : freeNodes)
+        if (l2PieceOf[k] >= 0)
+          for (int o : sepAdj[k])
+            if (isRoot[o]) L2.adj[l2PieceOf[k]].push_back(sepOff[o]);
+      finishLevel(L2, rows, BW2);
+      for (int k : freeNodes) {
+        if (l2PieceOf[k] < 0) continue;
+        const int pi = l2PieceOf[k];
+        for (int c = 0; c < D; ++c) L2.rowMap[L2.pieces[pi].rowPtr + l2Row[k] + c] = sepOff[k] + c;
+        xDst.push_back(make_int4(2, pi, l2Row[k], l2Row[k]));   // diagonal block
+        xSrc.push_back(make_int2(sepOff[k], sepOff[k]));
+        xDst.push_back(make_int4(4, pi, l2Row[k], L2.pieces[pi].cols - 1));
+        xSrc.push_back(make_int2(sepOff[k], 0));
+        for (int o : sepAdj[k]) {
+          if (isRoot[o]) {
+            xDst.push_back(make_int4(3 | 16, pi, l2Row[k], colIn(L2.adj[pi], sepOff[o])));
+            xSrc.push_back(make_int2(sepOff[o], sepOff[k]));
+          } else if (l2Row[o] < l2Row[k]) {
+            xDst.push_back(make_int4(2, pi, l2Row[k], l2Row[o]));
+            xSrc.push_back(make_int2(sepOff[k], sepOff[o]));
+          }
         }
       }
-      std::stable_sort(cs.begin(), cs.end(), [](const Contrib& x, const Contrib& y) { return x.key < y.key; });
-      for (size_t i = 0; i < cs.size(); ++i) {
-        if (i == 0 || cs[i].key != cs[i - 1].key) {
-          if (i) gPtr.push_back((int)gSrc.size());
-          gDst.push_back(make_int2((int)(cs[i].key / nS), (int)(cs[i].key % nS)));
-        }
-        gSrc.push_back(make_int4(cs[i].piece, cs[i].ro, cs[i].co, 0));
-      }
-      if (!cs.empty()) gPtr.push_back((int)gSrc.size());
-      for (int sn = 0; sn < nS / D; ++sn) {
-        rPtr[sn + 1] = rPtr[sn] + (int)rl[sn].size();
-        rSrc.insert(rSrc.end(), rl[sn].begin(), rl[sn].end());
-      }
     }
-    const int nDest = (int)gDst.size();
-    int maxRows = 0;
-    size_t bandTot = 1, yTot = 1, spTot = 1;
-    for (const PgPiece& pc : pieces) {
-      maxRows = std::max(maxRows, pc.rows);
-      bandTot = (size_t)(pc.bandOff + (long long)pc.rows * (BW + 1));
-      yTot = (size_t)(pc.yOff + (long long)pc.rows * pc.ld);
-      spTot = (size_t)(pc.sOff + (long long)pc.ld * pc.ld);
-    }
+    const std::vector<int4>& tileWork = L1.tileWork;
+    const int nDest = L1.nDest, maxRows = L1.maxRows;
+    const size_t bandTot = L1.bandTot, yTot = L1.yTot, spTot = L1.spTot;
+    partition[7] = nPieces2; partition[8] = nR;
     partition[0] = F; partition[1] = nS / D; partition[2] = nPieces; partition[3] = maxRows; partition[4] = (int)tileWork.size();
     summary[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tSym0).count();
     // ---- upload
@@ -1029,16 +1172,22 @@ class PoseGraph {
     dEq_.upload(eq, s_); dEsq_.upload(esq, s_);
     dNodePtr_.upload(nodePtr, s_); dNodeEdge_.upload(nodeEdge, s_);
     dSepOff_.upload(sepOff, s_); dNodePiece_.upload(nodePiece, s_); dNodeRow_.upload(nodeRow, s_);
-    dPieces_.upload(pieces, s_); dEdgeDst_.upload(edgeDst, s_); dColSep_.upload(colSep, s_); dRowTan_.upload(rowTan, s_);
-    dTileWork_.upload(tileWork, s_); dGPtr_.upload(gPtr, s_); dGDst_.upload(gDst, s_); dGSrc_.upload(gSrc, s_);
-    dRPtr_.upload(rPtr, s_); dRSrc_.upload(rSrc, s_);
+    dPieces_.upload(L1.pieces, s_); dEdgeDst_.upload(edgeDst, s_); dColSep_.upload(L1.colSep, s_); dRowTan_.upload(L1.rowMap, s_);
+    dTileWork_.upload(L1.tileWork, s_); dGPtr_.upload(L1.gPtr, s_); dGDst_.upload(L1.gDst, s_); dGSrc_.upload(L1.gSrc, s_);
+    dRPtr_.upload(L1.rPtr, s_); dRSrc_.upload(L1.rSrc, s_);
+    if (nPieces2 > 0) {
+      dPieces2_.upload(L2.pieces, s_); dColSep2_.upload(L2.colSep, s_); dRowMap2_.upload(L2.rowMap, s_);
+      dTileWork2_.upload(L2.tileWork, s_); dGPtr2_.upload(L2.gPtr, s_); dGDst2_.upload(L2.gDst, s_); dGSrc2_.upload(L2.gSrc, s_);
+      dRPtr2_.upload(L2.rPtr, s_); dRSrc2_.upload(L2.rSrc, s_); dXDst_.upload(xDst, s_); dXSrc_.upload(xSrc, s_);
+      dBand2_.reserve(L2.bandTot); dY2_.reserve(L2.yTot); dSp2_.reserve(L2.spTot);
+    }
     const size_t RD = (size_t)R * D;
     dRes_.reserve((size_t)ne * R); dJa_.reserve(ne * RD); dJb_.reserve(ne * RD);
     const int dpad = ((nS + 15) / 16) * 16;
     const size_t dp64 = ((size_t)nS + 63) / 64 * 64;
     dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
     dBand_.reserve(bandTot); dY_.reserve(yTot); dSp_.reserve(spTot);
-    dChol_.reserve(solveReducedScratchDoubles(nS));
+    dChol_.reserve(solveReducedScratchDoubles(nR));
     dPartial_.reserve((size_t)8 * kPgMaxPartials); dScal_.reserve(PG_NSCAL); dSolScal_.reserve(1);
     PgDev p;
     std::memset(&p, 0, sizeof(p));
@@ -1069,8 +1218,26 @@ class PoseGraph {
     // the dense solver of the BA backend sees the separator system through a DeviceProblem view
     DeviceProblem dp;
     std::memset(&dp, 0, sizeof(dp));
-    dp.d = nS; dp.S = p.HS; dp.gRed = p.rhsS; dp.gFull = p.rhsS; dp.htilC = ones; dp.yC = p.yS; dp.vC = vdump;
+    dp.d = nR; dp.S = p.HS + (size_t)offR * nS + offR; dp.ldS = nS;   // the root: trailing block, solved in place
+    dp.gRed = p.rhsS + offR; dp.gFull = p.rhsS + offR; dp.htilC = ones; dp.yC = p.yS + offR; dp.vC = vdump;
     dp.cholL = dChol_.p; dp.scal = dSolScal_.p;
+    // level 2 runs the same piece kernels on a second view: its pieces' rows are separator unknowns (y = yS)
+    PgDev p2 = p;
+    const int nX = (int)xDst.size();
+    if (nPieces2 > 0) {
+      p2.BW = BW2; p2.nPieces = nPieces2; p2.maxRows = L2.maxRows;
+      p2.pieces = dPieces2_.p; p2.colSep = dColSep2_.p; p2.rowTan = dRowMap2_.p; p2.tileWork = dTileWork2_.p;
+      p2.gPtr = dGPtr2_.p; p2.gDst = dGDst2_.p; p2.gSrc = dGSrc2_.p; p2.rPtr = dRPtr2_.p; p2.rSrc = dRSrc2_.p;
+      p2.band = dBand2_.p; p2.Y = dY2_.p; p2.Sp = dSp2_.p; p2.y = p.yS;
+    }
+    const size_t ldsFactor2 = (size_t)L2.maxRows * (BW2 + 2) * 8 + 2 * 1024;
+    const size_t ldsBack2 = ((size_t)L2.maxRows * (BW2 + 2) + W2 * D + kPgPieceThreads) * 8;
+    if (nPieces2 > 0) {
+      (void)hipFuncSetAttribute(six_ ? (const void*)k_pg_piece_factor<6, 7> : (const void*)k_pg_piece_factor<4, 3>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFactor2);
+      (void)hipFuncSetAttribute(six_ ? (const void*)k_pg_piece_back<6, 7> : (const void*)k_pg_piece_back<4, 3>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack2);
+    }
     const int gE = (ne + 127) / 128, gN = (nn + 127) / 128;
     if (gE > kPgMaxPartials || gN > kPgMaxPartials) throw std::runtime_error("svin_pg: graph too large for the reduction scratch");
     const size_t ldsFactor = (size_t)maxRows * (BW + 2) * 8 + 2 * 512;
@@ -1108,10 +1275,25 @@ class PoseGraph {
         hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256), dim3(256), 0, s_, p, nDest);
         hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
       }
+      if (nPieces2 > 0) {
+        PG_HIP_OK(hipMemsetAsync(p2.band, 0, sizeof(double) * L2.bandTot, s_));
+        PG_HIP_OK(hipMemsetAsync(p2.Y, 0, sizeof(double) * L2.yTot, s_));
+        hipLaunchKernelGGL(k_pg_l2_extract, dim3((nX * D * D + 255) / 256), dim3(256), 0, s_, p2, (const int4*)dXDst_.p,
+                           (const int2*)dXSrc_.p, nX);
+        if (six_) hipLaunchKernelGGL((k_pg_piece_factor<6, 7>), dim3(nPieces2), dim3(kPgPieceThreads), ldsFactor2, s_, p2);
+        else hipLaunchKernelGGL((k_pg_piece_factor<4, 3>), dim3(nPieces2), dim3(kPgPieceThreads), ldsFactor2, s_, p2);
+        hipLaunchKernelGGL(k_pg_piece_schur, dim3((unsigned)L2.tileWork.size()), dim3(256), 0, s_, p2);
+        hipLaunchKernelGGL(k_pg_sep_gather, dim3((L2.nDest * D * D + 255) / 256), dim3(256), 0, s_, p2, L2.nDest);
+        hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p2);
+      }
       PG_HIP_OK(hipEventRecord(evA_[nSolves % kPgMaxTimed], s_));
       launchSolveReduced(dp, s_, 0.0, false, false);
       PG_HIP_OK(hipEventRecord(evB_[nSolves % kPgMaxTimed], s_));
       ++nSolves;
+      if (nPieces2 > 0) {
+        if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 7>), dim3(nPieces2), dim3(kPgPieceThreads), ldsBack2, s_, p2);
+        else hipLaunchKernelGGL((k_pg_piece_back<4, 3>), dim3(nPieces2), dim3(kPgPieceThreads), ldsBack2, s_, p2);
+      }
       if (nPieces > 0) {
         if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
         else hipLaunchKernelGGL((k_pg_piece_back<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
@@ -1192,7 +1374,7 @@ class PoseGraph {
       PG_HIP_OK(hipEventElapsedTime(&ms, evA_[i], evB_[i]));
       summary[7] += 1e-3 * ms;
     }
-    partition[5] = nS; partition[6] = std::min(nSolves, kPgMaxTimed);
+    partition[5] = nR; partition[6] = std::min(nSolves, kPgMaxTimed);
     // ---- write back, drift update, keyframes after cur (PoseGraph.cpp:340-375 / :504-534)
     std::vector<double> hy(nn), ht(3 * (size_t)nn), hq(4 * (size_t)nn);
     PG_HIP_OK(hipMemcpy(hy.data(), p.yaw, sizeof(double) * nn, hipMemcpyDeviceToHost));
@@ -1243,9 +1425,11 @@ class PoseGraph {
   Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
   Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dY_, dSp_;
   Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_, dSepOff_, dNodePiece_, dNodeRow_, dColSep_, dRowTan_, dGPtr_, dRPtr_;
-  Buf<PgPiece> dPieces_;
-  Buf<int4> dEdgeDst_, dTileWork_, dGSrc_;
-  Buf<int2> dGDst_, dRSrc_;
+  Buf<PgPiece> dPieces_, dPieces2_;
+  Buf<int4> dEdgeDst_, dTileWork_, dGSrc_, dTileWork2_, dGSrc2_, dXDst_;
+  Buf<int2> dGDst_, dRSrc_, dGDst2_, dRSrc2_, dXSrc_;
+  Buf<int> dColSep2_, dRowMap2_, dGPtr2_, dRPtr2_;
+  Buf<double> dBand2_, dY2_, dSp2_;
   Buf<SolverScalars> dSolScal_;
 };
 
@@ -1324,13 +1508,20 @@ int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes) 
   h->g.denseNodes_ = dense_keyframes;
   return 1;
 }
-int svin_pg_get_partition(const svin_pg* h, double* out9) {
-  if (!h || !out9) return -1;
-  for (int i = 0; i < 5; ++i) out9[i] = h->g.partition[i];
-  out9[5] = h->g.summary[6];
-  out9[6] = h->g.partition[5];
-  out9[7] = h->g.partition[6];
-  out9[8] = h->g.summary[7];
+int svin_pg_set_levels(svin_pg* h, int levels, int level2_piece_keyframes) {
+  if (!h || levels < 1 || levels > 2 || level2_piece_keyframes < 0) return -1;
+  h->g.level2_ = levels == 2;
+  if (level2_piece_keyframes > 0) h->g.l2Len_ = level2_piece_keyframes;
+  return 1;
+}
+int svin_pg_get_partition(const svin_pg* h, double* out10) {
+  if (!h || !out10) return -1;
+  for (int i = 0; i < 5; ++i) out10[i] = h->g.partition[i];
+  out10[5] = h->g.summary[6];
+  out10[6] = h->g.partition[5];
+  out10[7] = h->g.partition[6];
+  out10[8] = h->g.summary[7];
+  out10[9] = h->g.partition[7];
   return 1;
 }
 int svin_pg_summary(const svin_pg* h, double* out6) {

@@ -46,6 +46,7 @@ IMU_SAMPLE_DTYPE = np.dtype([("sec", np.uint32), ("nsec", np.uint32), ("gyr", np
 EXPORTS = [
     "svin_ba_create", "svin_ba_destroy", "svin_ba_last_error", "svin_ba_new_id", "svin_ba_add_camera", "svin_ba_add_imu",
     "svin_ba_set_sonar_extrinsics", "svin_ba_add_states", "svin_ba_add_landmark", "svin_ba_add_observation",
+    "svin_ba_add_observations",
     "svin_ba_remove_observation", "svin_ba_remove_observation_by_id", "svin_ba_optimize", "svin_ba_prepare",
     "svin_ba_solve_prepared", "svin_ba_finish", "svin_ba_invalidate_preintegration",
     "svin_ba_set_optimization_time_limit", "svin_ba_apply_marginalization_strategy", "svin_ba_get_summary",
@@ -93,6 +94,8 @@ def load_library():
     sig("svin_ba_add_states", i32, vp, u64, u32, u32, u64, pd, i32, C.c_void_p, i32, i32, pd, i32, pd, i32, f64)
     sig("svin_ba_add_landmark", i32, vp, u64, pd)
     sig("svin_ba_add_observation", u64, vp, u64, u64, u64, u64, pd, f64)
+    sig("svin_ba_add_observations", i32, vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), pd, pd,
+        C.POINTER(u64))
     sig("svin_ba_remove_observation", i32, vp, u64, u64, u64, u64)
     sig("svin_ba_remove_observation_by_id", i32, vp, u64)
     sig("svin_ba_optimize", i32, vp, u64, u64, i32)
@@ -218,6 +221,18 @@ class Estimator:
     def add_observation(self, lid, pose, cam, kp, uv, size):
         uv = _arr(uv)
         return int(self.L.svin_ba_add_observation(self.h, lid, pose, cam, kp, _d(uv), size))
+
+    def add_observations(self, lids, poses, cams, kps, uvs, sizes):
+        """batched add_observation (svin_ba_add_observations); returns the residual ids (0 = duplicate)"""
+        n = len(lids)
+        a = [np.ascontiguousarray(x, np.uint64) for x in (lids, poses, cams, kps)]
+        uvs = np.ascontiguousarray(uvs, np.float64).reshape(n, 2)
+        sizes = np.ascontiguousarray(sizes, np.float64)
+        out = np.zeros(n, np.uint64)
+        p64 = C.POINTER(C.c_uint64)
+        self._check(self.L.svin_ba_add_observations(self.h, n, *[x.ctypes.data_as(p64) for x in a], _d(uvs), _d(sizes),
+                                                    out.ctypes.data_as(p64)), "add_observations")
+        return out
 
     def remove_observation(self, lid, pose, cam, kp):
         return bool(self._check(self.L.svin_ba_remove_observation(self.h, lid, pose, cam, kp), "remove_observation"))

@@ -13,7 +13,7 @@ from . import estimator
 PG_EXPORTS = [
     "svin_pg_create", "svin_pg_destroy", "svin_pg_last_error", "svin_pg_add_keyframe", "svin_pg_num_keyframes",
     "svin_pg_optimize", "svin_pg_get_pose", "svin_pg_get_poses", "svin_pg_get_drift", "svin_pg_summary",
-    "svin_pg_set_partition", "svin_pg_get_partition",
+    "svin_pg_set_partition", "svin_pg_get_partition", "svin_pg_set_levels",
 ]
 
 _BOUND = False
@@ -41,6 +41,7 @@ def _lib():
         sig("svin_pg_summary", i32, vp, pd)
         sig("svin_pg_set_partition", i32, vp, i32, i32)
         sig("svin_pg_get_partition", i32, vp, pd)
+        sig("svin_pg_set_levels", i32, vp, i32, i32)
         _BOUND = True
     return L
 
@@ -107,8 +108,11 @@ class PoseGraph:
         self._check(self.L.svin_pg_set_partition(self.h, piece_keyframes, dense_keyframes), "set_partition")
 
     def partition(self):
-        s = np.zeros(9)
+        s = np.zeros(10)
         self._check(self.L.svin_pg_get_partition(self.h, _p(s)), "get_partition")
         return dict(free=int(s[0]), separators=int(s[1]), pieces=int(s[2]), max_rows=int(s[3]), tiles=int(s[4]),
                     symbolic_seconds=float(s[5]), separator_unknowns=int(s[6]), dense_solves=int(s[7]),
-                    dense_solve_seconds=float(s[8]))
+                    dense_solve_seconds=float(s[8]), level2_pieces=int(s[9]))
+
+    def set_levels(self, levels=2, level2_piece_keyframes=0):
+        self._check(self.L.svin_pg_set_levels(self.h, levels, level2_piece_keyframes), "set_levels")

@@ -7,6 +7,8 @@ landmarks in the union of the frusta and their noisy projections.  The same `Win
 drives the oracle, the product and the benchmark through `feed()`.
 """
 from dataclasses import dataclass, field
+import time
+
 import numpy as np
 
 DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT, DIST_RADTAN8 = 0, 1, 2, 3
@@ -367,7 +369,7 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
     return spec
 
 
-def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None):
+def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, timing=None):
     """Drive an estimator-like object (oracle or product) with a WindowSpec.
 
     The estimator API is the okvis::Estimator mirror: new_id / add_camera / add_imu / add_states /
@@ -409,11 +411,25 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None):
             if k > 0:
                 est.set_T_WS(fid, spec.T_WS_true[k])
             est.set_speed_and_bias(fid, spec.sb_true[k])
-        for i in by_frame[k]:
-            c = int(spec.obs_cam[i])
-            kp = kp_counter.get((k, c), 0)
-            kp_counter[(k, c)] = kp + 1
-            est.add_observation(lm_ids[int(spec.obs_lm[i])], fid, c, kp, spec.obs_uv[i], float(spec.obs_size[i]))
+        if hasattr(est, "add_observations") and len(by_frame[k]):   # the product's batched form of the same calls
+            idx = by_frame[k]
+            cams = spec.obs_cam[idx].astype(np.uint64)
+            kps = np.zeros(len(idx), np.uint64)
+            for c in np.unique(cams):
+                m = cams == c
+                kps[m] = np.arange(int(m.sum()), dtype=np.uint64)
+            lids = np.array([lm_ids[int(j)] for j in spec.obs_lm[idx]], np.uint64)
+            t0 = time.perf_counter()
+            est.add_observations(lids, np.full(len(idx), fid, np.uint64), cams, kps, spec.obs_uv[idx], spec.obs_size[idx])
+            if timing is not None:
+                timing.setdefault("add_observations_s", []).append(time.perf_counter() - t0)
+                timing.setdefault("add_observations_n", []).append(len(idx))
+        else:
+            for i in by_frame[k]:
+                c = int(spec.obs_cam[i])
+                kp = kp_counter.get((k, c), 0)
+                kp_counter[(k, c)] = kp + 1
+                est.add_observation(lm_ids[int(spec.obs_lm[i])], fid, c, kp, spec.obs_uv[i], float(spec.obs_size[i]))
         if optimize_each:
             est.optimize(optimize_each, 1, False)
         if on_frame is not None:

@@ -110,17 +110,22 @@ def test_no_loop_is_a_no_op():
 
 
 @pytest.mark.parametrize("six", [False, True])
-@pytest.mark.parametrize("n,laps,loop_every,piece", [(160, 4, 8, 8), (400, 4, 25, 16), (400, 4, 10, 64), (1200, 6, 20, 64)])
-def test_piece_elimination_matches_oracle(six, n, laps, loop_every, piece):
+@pytest.mark.parametrize("levels", [1, 2])
+@pytest.mark.parametrize("n,laps,loop_every,piece", [(160, 4, 8, 8), (400, 4, 25, 16), (400, 4, 10, 64), (1200, 6, 20, 64),
+                                                     (1200, 6, 40, 8)])
+def test_piece_elimination_matches_oracle(six, levels, n, laps, loop_every, piece):
     """the separator / piece solver (chain cut into pieces, banded Cholesky per piece, dense separator system) against
     the oracle's plain Cholesky of the same normal equations"""
     spec = spg.make_pose_graph(n=n, laps=laps, loop_every=loop_every, seed=5 + n)
     g, c, earliest, cur = pair(six, spec)
     g.set_partition(piece, 0)
+    g.set_levels(levels, 8)   # level 2: the cut keyframes are eliminated too (pieces of 8), the root keeps the loop cover
     sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
     part = g.partition()
     print(part)
     assert part["pieces"] >= 2 and part["separators"] < part["free"]
+    if levels == 1:
+        assert part["level2_pieces"] == 0 and part["separator_unknowns"] == part["separators"] * (6 if six else 4)
     compare(g, c, sg, sc)
 
 

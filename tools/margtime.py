@@ -13,8 +13,11 @@ def run(est, spec, iters, label):
         ok, removed = est.apply_marginalization(5, 3); t2 = time.perf_counter()
         t_opt.append(t1 - t0); t_marg.append(t2 - t1); nrem.append(len(removed))
     t0 = time.perf_counter()
-    syn.feed(est, spec, on_frame=on_frame)
+    timing = {}
+    syn.feed(est, spec, on_frame=on_frame, timing=timing)
     tot = time.perf_counter() - t0
+    if timing:
+        print("%s: add_observations %.3f ms per frame (%d observations, %.0f ns each)" % (label, 1e3 * np.median(timing['add_observations_s']), int(np.median(timing['add_observations_n'])), 1e9 * sum(timing['add_observations_s']) / sum(timing['add_observations_n'])))
     print("%s: frames %d  optimize(%d) median %.3f ms  marginalise median %.3f ms (max %.3f)  whole feed %.1f ms  landmarks removed/frame %s" %
           (label, len(t_opt), iters, 1e3 * np.median(t_opt[3:]), 1e3 * np.median(t_marg[3:]), 1e3 * max(t_marg[3:]), 1e3 * tot, nrem[-4:]))
 
