@@ -460,31 +460,35 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
   for (int i = tid; i < n * LDB; i += kPgPieceThreads) band[i] = Lb[i];
   if (tid < pc.cols) {
     double* Yc = p.Y + pc.yOff + tid;
-    double yh[LDB];   // yh[r % LDB] = y_r for the last BW rows (rows < 0: zero)
+    // keyframe by keyframe: hist = y of the W keyframes before (oldest first, zero before the first row), shifted by
+    // one keyframe per step so that every register index is static
+    double hist[P], cur[D], v[D];
 #pragma unroll
-    for (int u = 0; u < LDB; ++u) yh[u] = 0.0;
-    for (int rb = 0; rb < n; rb += LDB) {
-      double v[8];
+    for (int k = 0; k < P; ++k) hist[k] = 0.0;
 #pragma unroll
-      for (int u = 0; u < LDB; ++u) {
-        if ((u & 7) == 0) {   // the next 8 right-hand-side values of this column, loads in flight together
+    for (int b = 0; b < D; ++b) v[b] = Yc[(size_t)b * pc.ld];
+    for (int j0 = 0; j0 < n; j0 += D) {
+      double vn[D];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = (u + q < LDB && rb + u + q < n) ? Yc[(size_t)(rb + u + q) * pc.ld] : 0.0;
+      for (int b = 0; b < D; ++b) vn[b] = j0 + D + b < n ? Yc[(size_t)(j0 + D + b) * pc.ld] : 0.0;   // next keyframe's, in flight
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        const double* row = Lb + (j0 + b) * LDB;
+        double x0 = v[b], x1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {   // L[r][j0 - P + k] sits at row[D - 1 - b + k]
+          const double term = row[D - 1 - b + k] * hist[k];
+          if (k & 1) x1 -= term; else x0 -= term;
         }
-        const int r = rb + u;
-        if (r < n) {
-          const double* row = Lb + r * LDB;
-          double x0 = v[u & 7], x1 = 0.0;
 #pragma unroll
-          for (int t = 1; t <= BW; ++t) {
-            const double term = row[BW - t] * yh[(u - t + 2 * LDB) % LDB];
-            if (t & 1) x0 -= term; else x1 -= term;
-          }
-          const double x = (x0 + x1) * dinv[r];
-          yh[u] = x;
-          Yc[(size_t)r * pc.ld] = x;
-        }
+        for (int k = 0; k < b; ++k) x0 -= row[BW - b + k] * cur[k];
+        cur[b] = (x0 + x1) * dinv[j0 + b];
+        Yc[(size_t)(j0 + b) * pc.ld] = cur[b];
       }
+#pragma unroll
+      for (int k = 0; k < P - D; ++k) hist[k] = hist[k + D];
+#pragma unroll
+      for (int b = 0; b < D; ++b) { hist[P - D + b] = cur[b]; v[b] = vn[b]; }
     }
   }
 }
@@ -566,11 +570,25 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_back(PgDev p) {
   if (tid < P) z[n + tid] = 0.0;
   __syncthreads();
   const double* Y = p.Y + pc.yOff;
-  for (int r = wave; r < n; r += kPgPieceThreads / 64) {   // one wave per row: coalesced dot product
-    double acc = 0;
-    for (int c = lane; c < pc.cols - 1; c += 64) acc += Y[(size_t)r * pc.ld + c] * xA[c];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) z[r] = Y[(size_t)r * pc.ld + pc.cols - 1] - acc;
+  constexpr int kRowsInFlight = 8;   // one wave per row (coalesced dot product), 8 rows' loads in flight together
+  for (int r0 = wave * kRowsInFlight; r0 < n; r0 += kRowsInFlight * (kPgPieceThreads / 64)) {
+    double acc[kRowsInFlight], rhs[kRowsInFlight];
+#pragma unroll
+    for (int q = 0; q < kRowsInFlight; ++q) { acc[q] = 0; rhs[q] = (lane == 0 && r0 + q < n) ? Y[(size_t)(r0 + q) * pc.ld + pc.cols - 1] : 0.0; }
+    for (int c = lane; c < pc.cols - 1; c += 64) {
+      const double x = xA[c];
+      double yv[kRowsInFlight];
+#pragma unroll
+      for (int q = 0; q < kRowsInFlight; ++q) yv[q] = r0 + q < n ? Y[(size_t)(r0 + q) * pc.ld + c] : 0.0;
+#pragma unroll
+      for (int q = 0; q < kRowsInFlight; ++q) acc[q] += yv[q] * x;
+    }
+#pragma unroll
+    for (int q = 0; q < kRowsInFlight; ++q) {
+      double a = acc[q];
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (lane == 0 && r0 + q < n) z[r0 + q] = rhs[q] - a;
+    }
   }
   __syncthreads();
   if (wave == 0) {
