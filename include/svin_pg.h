@@ -52,13 +52,13 @@ int svin_pg_get_poses(const svin_pg* h, int n, double* t, double* q);
 int svin_pg_get_drift(const svin_pg* h, double* yaw_drift_deg, double* r_drift, double* t_drift);
 
 /* solver layout (no reference counterpart; Ceres picks its own ordering): keyframes per piece (0 = keep, default
- * 64, at most 256 / tangent size) and the free-keyframe count up to which the whole graph is solved as one dense
+ * 32 for 4-DoF / 64 for 6-DoF, at most 256 / tangent size) and the free-keyframe count up to which the whole graph is solved as one dense
  * system (default 128).  svin_pg_get_partition: free keyframes, separator keyframes, pieces, largest piece (rows),
  * Schur tiles, seconds of the host-side symbolic step, separator unknowns, number of dense separator solves and their
  * total seconds (HIP events on the solver's stream) of the last svin_pg_optimize */
 int svin_pg_set_partition(svin_pg* h, int piece_keyframes, int dense_keyframes);
 /* 1 = eliminate the pieces only; 2 (default) = also eliminate the cut keyframes in level-2 pieces (of
- * level2_piece_keyframes cut keyframes, 0 = keep, default 32) so that the dense root only holds the loop cover */
+ * level2_piece_keyframes cut keyframes, 0 = keep, default 16 / 32) so that the dense root only holds the loop cover */
 int svin_pg_set_levels(svin_pg* h, int levels, int level2_piece_keyframes);
 /* out10: ... as above, [6] = unknowns of the dense root solve, [9] = level-2 pieces */
 int svin_pg_get_partition(const svin_pg* h, double* out10);

@@ -797,6 +797,10 @@ static void hostR2q(const double* R, double* qo) {  // Eigen::Quaterniond(Matrix
 class PoseGraph {
  public:
   PoseGraph(int device, bool six, int maxIter) : six_(six), maxIter_(maxIter > 0 ? maxIter : (six ? 5 : 10)) {
+    // measured on the config-#5 graph (tools/pgtime.py sweeps): short level-1 pieces pay off once the cuts are
+    // eliminated at level 2; the 6-DoF band is wider, so its pieces stay at the 256-row limit
+    pieceLen_ = six ? 64 : 32;
+    l2Len_ = six ? 32 : 16;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
       throw std::runtime_error("svin_pg: no HIP device available (this backend has no CPU fallback)");
@@ -1206,7 +1210,9 @@ class PoseGraph {
     dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
     dBand_.reserve(bandTot); dY_.reserve(yTot); dSp_.reserve(spTot);
     dChol_.reserve(solveReducedScratchDoubles(nR));
-    dPartial_.reserve((size_t)8 * kPgMaxPartials); dScal_.reserve(PG_NSCAL); dSolScal_.reserve(1);
+    dPartial_.reserve((size_t)8 * kPgMaxPartials);
+    dScal_.reserve(PG_NSCAL + sizeof(SolverScalars) / sizeof(double) + 1);   // LM scalars, then the dense solver's: one read-back
+    SolverScalars* const dSol = reinterpret_cast<SolverScalars*>(dScal_.p + PG_NSCAL);
     PgDev p;
     std::memset(&p, 0, sizeof(p));
     p.nn = nn; p.ne = ne; p.n = n; p.m = ne * R; p.six = six_ ? 1 : 0; p.D = D; p.R = R;
@@ -1227,7 +1233,7 @@ class PoseGraph {
     p.edgeDst = dEdgeDst_.p; p.colSep = dColSep_.p; p.rowTan = dRowTan_.p; p.tileWork = dTileWork_.p;
     p.gPtr = dGPtr_.p; p.gDst = dGDst_.p; p.gSrc = dGSrc_.p; p.rPtr = dRPtr_.p; p.rSrc = dRSrc_.p;
     p.band = dBand_.p; p.Y = dY_.p; p.Sp = dSp_.p; p.HS = dHS_.p;
-    p.fail = &dSolScal_.p->cholFail;
+    p.fail = &dSol->cholFail;
     {
       std::vector<double> one(nS, 1.0);
       PG_HIP_OK(hipMemcpyAsync(ones, one.data(), sizeof(double) * nS, hipMemcpyHostToDevice, s_));
@@ -1238,7 +1244,7 @@ class PoseGraph {
     std::memset(&dp, 0, sizeof(dp));
     dp.d = nR; dp.S = p.HS + (size_t)offR * nS + offR; dp.ldS = nS;   // the root: trailing block, solved in place
     dp.gRed = p.rhsS + offR; dp.gFull = p.rhsS + offR; dp.htilC = ones; dp.yC = p.yS + offR; dp.vC = vdump;
-    dp.cholL = dChol_.p; dp.scal = dSolScal_.p;
+    dp.cholL = dChol_.p; dp.scal = dSol;
     // level 2 runs the same piece kernels on a second view: its pieces' rows are separator unknowns (y = yS)
     PgDev p2 = p;
     const int nX = (int)xDst.size();
@@ -1266,8 +1272,11 @@ class PoseGraph {
       (void)hipFuncSetAttribute(six_ ? (const void*)k_pg_piece_back<6, 4> : (const void*)k_pg_piece_back<4, 2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBack);
     }
-    auto readScal = [&](double* out) {
-      PG_HIP_OK(hipMemcpyAsync(out, p.scal, sizeof(double) * PG_NSCAL, hipMemcpyDeviceToHost, s_));
+    struct HostScal { double sc[PG_NSCAL]; SolverScalars sol; } hs;
+    static_assert(sizeof(SolverScalars) % sizeof(double) == 0, "SolverScalars must pack behind the LM scalars");
+    double* const sc = hs.sc;
+    auto readScal = [&]() {   // the one blocking read-back of an iteration
+      PG_HIP_OK(hipMemcpyAsync(&hs, p.scal, sizeof(double) * PG_NSCAL + sizeof(SolverScalars), hipMemcpyDeviceToHost, s_));
       PG_HIP_OK(hipStreamSynchronize(s_));
     };
     auto evalCost = [&](bool cand, bool withJac) {
@@ -1278,7 +1287,7 @@ class PoseGraph {
     // damped normal equations at the current linearisation -> y (tangent order, scaled space)
     auto solveNormalEquations = [&](double radius, int& nSolves) {
       PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * (size_t)nS * nS, s_));
-      PG_HIP_OK(hipMemsetAsync(dSolScal_.p, 0, sizeof(SolverScalars), s_));
+      PG_HIP_OK(hipMemsetAsync(dSol, 0, sizeof(SolverScalars), s_));
       if (nPieces > 0) {
         PG_HIP_OK(hipMemsetAsync(p.band, 0, sizeof(double) * bandTot, s_));
         PG_HIP_OK(hipMemsetAsync(p.Y, 0, sizeof(double) * yTot, s_));
@@ -1324,27 +1333,24 @@ class PoseGraph {
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const double min_relative_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
-    double sc[PG_NSCAL];
     evalCost(false, true);
-    readScal(sc);
+    readScal();
     double x_cost = sc[PG_COST];
     summary[0] = x_cost;
     bool needLinearize = true, initScale = true;
     int iteration = 0, invalid = 0, successful = 0, termination = 1;
-    double gradMax = 0;
     while (true) {
-      if (needLinearize) {  // gradient / column norms of the current linearisation (also the gradient check)
+      const bool freshLinearization = needLinearize;
+      if (needLinearize) {  // gradient / column norms / J^T J blocks of the current linearisation
         if (six_) hipLaunchKernelGGL(k_pg_node<6>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
         else hipLaunchKernelGGL(k_pg_node<4>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
         hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_GRADMAX, gN, 1);
-        readScal(sc);
-        gradMax = sc[PG_GRADMAX];
         initScale = false;
       }
       if (iteration >= maxIter_) { termination = 1; break; }
-      if (gradMax <= gradient_tolerance) { termination = 0; break; }
       if (radius <= min_radius) { termination = 0; break; }
-      ++iteration;
+      // The step is enqueued before the gradient check's scalar is back (one read-back per iteration instead of
+      // three); when the gradient test fires the step is simply not used -- Ceres would not have computed it.
       solveNormalEquations(radius, nSolves);
       hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
       if (six_) hipLaunchKernelGGL(k_pg_model<6>, dim3(gE), dim3(128), 0, s_, p);
@@ -1354,12 +1360,12 @@ class PoseGraph {
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_STEP2, gN, 0);
       hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_X2, gN, 0);
       evalCost(true, false);
-      readScal(sc);
-      SolverScalars ss;
-      PG_HIP_OK(hipMemcpy(&ss, dSolScal_.p, sizeof(ss), hipMemcpyDeviceToHost));
+      readScal();
+      if (freshLinearization && sc[PG_GRADMAX] <= gradient_tolerance) { termination = 0; break; }
+      ++iteration;
       const double model_cost_change = -sc[PG_MODEL];
       needLinearize = false;
-      if (ss.cholFail != 0 || !(model_cost_change > 0.0) || !std::isfinite(sc[PG_STEP2])) {  // HandleInvalidStep
+      if (hs.sol.cholFail != 0 || !(model_cost_change > 0.0) || !std::isfinite(sc[PG_STEP2])) {  // HandleInvalidStep
         if (++invalid >= 5) { termination = 3; break; }
         radius /= decrease_factor; decrease_factor *= 2.0;
         continue;
@@ -1448,7 +1454,6 @@ class PoseGraph {
   Buf<int2> dGDst_, dRSrc_, dGDst2_, dRSrc2_, dXSrc_;
   Buf<int> dColSep2_, dRowMap2_, dGPtr2_, dRPtr2_;
   Buf<double> dBand2_, dY2_, dSp2_;
-  Buf<SolverScalars> dSolScal_;
 };
 
 }  // namespace pg

@@ -16,11 +16,13 @@ t0 = time.time()
 spec = spg.make_pose_graph(n=n, laps=laps, loop_every=loop_every, seed=7)
 print("graph: %d keyframes, %d loops (%.1fs to generate)" % (n, len(spec.loops), time.time() - t0), flush=True)
 for six in (False, True):
-    for piece in ([int(os.environ["PG_PIECE"])] if "PG_PIECE" in os.environ else [64]):
+    for piece in ([int(os.environ["PG_PIECE"])] if "PG_PIECE" in os.environ else [0]):
         best = None
         for rep in range(reps):
             g = PoseGraph(0, six_dof=six)
             g.set_partition(piece, 128)
+            if "PG_L2" in os.environ:
+                g.set_levels(2 if int(os.environ["PG_L2"]) > 0 else 1, max(int(os.environ["PG_L2"]), 0))
             earliest, cur = spg.feed(g, spec)
             t1 = time.time()
             s = g.optimize(earliest, cur)
