@@ -2925,7 +2925,8 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
 // Finished blocks cross XCD L2s: they are written and read with agent-scope relaxed atomics (sc1 accesses, coherent by
 // themselves), the writer waits for its stores to complete before ready[I][J] is set, the reader polls ready[I][J]
 // before it loads -- no L2 write-back / invalidate (buffer_wbl2 / buffer_inv cost ~10 us per hand-over here).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
-// The per-panel launch pair (k_big_panel + k_big_syrk) stays as the fallback (SVIN_BIG_CHOL_LAUNCHES=1).
+// Superseded by k_big_chol_chain below (kept for A/B runs: SVIN_BIG_CHOL_TASKS=1); the per-panel launch pair
+// (k_big_panel + k_big_syrk) stays as the launch-based fallback (SVIN_BIG_CHOL_LAUNCHES=1).
 constexpr int kSpinMax = 1 << 20;
 constexpr int kPersistMaxGrid = 256;
 __device__ __forceinline__ bool pollReady(const int* f) {
@@ -2935,8 +2936,7 @@ __device__ __forceinline__ bool pollReady(const int* f) {
   }
   return false;
 }
-__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready,
-                                                        int dbgSkip) {
+__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
   extern __shared__ double smem[];
   double* Xi = smem;                       // X(I, k) / the slab during the solve
   double* Xj = smem + kBigBlockLds;        // X(J, k)
@@ -2983,11 +2983,10 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
-      if (!(dbgSkip & 8)) loadBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
-      if (I != J && !(dbgSkip & 8)) loadBlock64Coherent(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
+      loadBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
+      if (I != J) loadBlock64Coherent(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
       __syncthreads();
       const double* XJ = (I == J) ? Xi : Xj;
-      if (!(dbgSkip & 4))
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -3008,7 +3007,7 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
         for (int rg = 0; rg < 4; ++rg)
           Dt[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
       __syncthreads();
-      if (!(dbgSkip & 1)) factor64(Dt, dinv, &p.scal->cholFail);
+      factor64(Dt, dinv, &p.scal->cholFail);
       storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
       if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -3023,13 +3022,180 @@ __global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpa
         for (int rg = 0; rg < 4; ++rg)
           Xi[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
       __syncthreads();
-      if (!(dbgSkip & 2)) slabSolve64(Dt, Xi, dinv);
+      slabSolve64(Dt, Xi, dinv);
       __syncthreads();
       storeBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, Xi);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's coherent stores have completed (vmcnt 0)
     __syncthreads();
     if (tid == 0) __hip_atomic_store(ready + I * nb + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------- tile Cholesky with a critical-path workgroup
+// Same left-looking block tasks, but the two blocks per column that sit on the critical path -- the diagonal block
+// (J, J) and the block below it (J+1, J) -- belong to ONE workgroup (the chain) that keeps L_JJ and X(J+1, J) in LDS
+// from one column to the next: no hand-over on the critical path (a hand-over of a 32 KB block costs ~5 us,
+// tools/ubench/handoff.hip).  The helpers do everything else:
+//   H(I, J), I >= J + 2   the full block task of k_big_chol_tasks
+//   PD(J), PS(J), J >= 2  blocks (J, J) and (J+1, J) minus the updates k <= J - 2, stored back in place and flagged,
+//                         so that the chain only applies the last update (k = J - 1) itself
+// Helper tasks are numbered stage by stage (stage s: H(., s), then PD(s+2), PS(s+2)) and dealt round-robin; chain
+// step J needs helper stages <= J - 1, helper stage s needs chain steps <= s: no cycles, bounded waits as before.
+struct TileLds { double *A, *B, *Dt, *dinv; int* seen; };
+__device__ __forceinline__ void tileAccLoad(d4_t acc[4], const double* blk, int ld, bool coherent) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const double* q = blk + (size_t)(16 * wave + (lane >> 4) + 4 * rg) * ld + 16 * tj + (lane & 15);
+      acc[tj][rg] = coherent ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
+}
+__device__ __forceinline__ void tileAccToLds(const d4_t acc[4], double* tiles) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      tiles[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
+}
+// acc -= X_a(row tile of this wave) X_b^T, both 64x64 blocks as LDS tiles
+__device__ __forceinline__ void tileMfmaSub(d4_t acc[4], const double* Xa, const double* Xb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const double* A = Xa + (wave * 4 + kt) * (16 * kBigTileLd);
+      const double* B = Xb + (tj * 4 + kt) * (16 * kBigTileLd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
+                                                       B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc[tj], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tileWait(const int* flag, bool& gaveUp, int* fail) {
+  if (threadIdx.x == 0 && !gaveUp && !pollReady(flag)) { atomicOr(fail, 2); gaveUp = true; }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void tilePublish(int* flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's coherent stores have completed (vmcnt 0)
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// acc -= sum_{k < kEnd} X(I,k) X(J,k)^T, blocks taken as they become ready
+__device__ __forceinline__ void tileAccumulate(d4_t acc[4], const TileLds& L, double* M, int dpad, const int* ready, int nb,
+                                               int I, int J, int kEnd, bool& gaveUp, int* fail) {
+  const int tid = threadIdx.x;
+  if (tid == 0) L.seen[0] = kEnd;
+  __syncthreads();
+  int firstMissing = kEnd;
+  for (int k = tid; k < kEnd; k += blockDim.x) {   // one parallel look: usually all but the last columns are there
+    const bool ok = __hip_atomic_load(ready + I * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                    __hip_atomic_load(ready + J * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (!ok) firstMissing = min(firstMissing, k);
+  }
+  if (firstMissing < kEnd) atomicMin(L.seen, firstMissing);
+  __syncthreads();
+  const int kSafe = L.seen[0];
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __syncthreads();
+  for (int k = 0; k < kEnd; ++k) {
+    if (k >= kSafe) {
+      if (tid == 0 && !gaveUp) {
+        const bool ok = pollReady(ready + I * nb + k) && pollReady(ready + J * nb + k);
+        if (!ok) { atomicOr(fail, 2); gaveUp = true; }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    loadBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, L.A);
+    if (I != J) loadBlock64Coherent(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, L.B);
+    __syncthreads();
+    tileMfmaSub(acc, L.A, (I == J) ? L.A : L.B);
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
+  extern __shared__ double smem[];
+  TileLds L;
+  L.A = smem; L.B = smem + kBigBlockLds; L.Dt = smem + 2 * kBigBlockLds; L.dinv = L.Dt + kBigBlockLds;
+  L.seen = reinterpret_cast<int*>(L.dinv + kNB);
+  const int tid = threadIdx.x;
+  const int nb = dpad / kNB;
+  double* M = p.cholL;
+  int* pd = ready + (nb + 1) * nb;   // PD(J) / PS(J) done
+  int* ps = pd + nb;
+  int* fail = &p.scal->cholFail;
+  bool gaveUp = false;
+  d4_t acc[4];
+  if (blockIdx.x == 0) {
+    double* S = L.B;    // X(J, J-1) from the previous column
+    double* W = L.A;    // work block
+    for (int J = 0; J < nb; ++J) {
+      // diagonal block
+      if (J >= 2) tileWait(pd + J, gaveUp, fail);
+      tileAccLoad(acc, M + (size_t)(kNB * J) * dpad + kNB * J, dpad, true);
+      if (J >= 1) tileMfmaSub(acc, S, S);
+      tileAccToLds(acc, L.Dt);
+      __syncthreads();
+      factor64(L.Dt, L.dinv, fail);
+      storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, L.Dt);
+      if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, L.dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tilePublish(ready + J * nb + J);
+      // the block below it (row block J + 1 <= nb: the last one is the right-hand side)
+      if (J >= 2) tileWait(ps + J, gaveUp, fail);
+      tileAccLoad(acc, M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, true);
+      if (J >= 1) {
+        tileWait(ready + (J + 1) * nb + (J - 1), gaveUp, fail);
+        loadBlock64Coherent(M + (size_t)(kNB * (J + 1)) * dpad + kNB * (J - 1), dpad, W);
+        __syncthreads();
+        tileMfmaSub(acc, W, S);
+        __syncthreads();
+      }
+      tileAccToLds(acc, W);
+      __syncthreads();
+      slabSolve64(L.Dt, W, L.dinv);
+      __syncthreads();
+      storeBlock64Coherent(M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, W);
+      tilePublish(ready + (J + 1) * nb + J);
+      double* t = S; S = W; W = t;
+    }
+    return;
+  }
+  // helpers
+  int s = 0, stageStart = 0;
+  auto stageCount = [&](int st) { return max(nb - st - 1, 0) + ((st + 2 <= nb - 1) ? 2 : 0); };
+  int nTasks = 0;
+  for (int st = 0; st < nb; ++st) nTasks += stageCount(st);
+  for (int task = blockIdx.x - 1; task < nTasks; task += gridDim.x - 1) {
+    while (task >= stageStart + stageCount(s)) { stageStart += stageCount(s); ++s; }
+    const int li = task - stageStart, nH = max(nb - s - 1, 0);
+    if (li < nH) {   // H(I, s)
+      const int I = s + 2 + li, J = s;
+      tileAccLoad(acc, M + (size_t)(kNB * I) * dpad + kNB * J, dpad, false);
+      tileAccumulate(acc, L, M, dpad, ready, nb, I, J, J, gaveUp, fail);
+      tileWait(ready + J * nb + J, gaveUp, fail);
+      loadBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, L.Dt);
+      if (tid < kNB) L.dinv[tid] = __hip_atomic_load(dinvG + kNB * J + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tileAccToLds(acc, L.A);
+      __syncthreads();
+      slabSolve64(L.Dt, L.A, L.dinv);
+      __syncthreads();
+      storeBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, L.A);
+      tilePublish(ready + I * nb + J);
+    } else {         // PD(J) / PS(J): everything but the last update, back in place
+      const int J = s + 2, I = J + (li - nH);
+      tileAccLoad(acc, M + (size_t)(kNB * I) * dpad + kNB * J, dpad, false);
+      tileAccumulate(acc, L, M, dpad, ready, nb, I, J, J - 1, gaveUp, fail);
+      tileAccToLds(acc, L.A);
+      __syncthreads();
+      storeBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, L.A);
+      tilePublish((li - nH == 0 ? pd : ps) + J);
+    }
   }
 }
 
@@ -3141,14 +3307,21 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 1) x nb block flags
     static const bool perPanelLaunches = std::getenv("SVIN_BIG_CHOL_LAUNCHES") != nullptr;
     hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
-                       (nb + 1) * nb);
-    if (!perPanelLaunches) {
+                       (nb + 3) * nb);
+    static const bool plainTasks = std::getenv("SVIN_BIG_CHOL_TASKS") != nullptr;
+    if (!perPanelLaunches && !plainTasks) {
+      const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
+      (void)hipFuncSetAttribute((const void*)k_big_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
+      int nHelperTasks = 0;
+      for (int st = 0; st < nb; ++st) nHelperTasks += std::max(nb - st - 1, 0) + ((st + 2 <= nb - 1) ? 2 : 0);
+      hipLaunchKernelGGL(k_big_chol_chain, dim3(1 + std::max(1, std::min(nHelperTasks, kPersistMaxGrid - 1))), dim3(256), ldsTasks, s, p, dp,
+                         dinvG, diagF, ready);
+    } else if (!perPanelLaunches) {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
       (void)hipFuncSetAttribute((const void*)k_big_chol_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
       const int nTasks = nb * (nb + 1) / 2 + nb;
-      static const int dbgSkip = std::getenv("SVIN_TASK_SKIP") ? std::atoi(std::getenv("SVIN_TASK_SKIP")) : 0;
       hipLaunchKernelGGL(k_big_chol_tasks, dim3(std::min(nTasks, kPersistMaxGrid)), dim3(256), ldsTasks, s, p, dp, dinvG, diagF,
-                         ready, dbgSkip);
+                         ready);
     } else {
       for (int k0 = 0; k0 < dp; k0 += kNB) {
         const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included

@@ -170,7 +170,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, 
 // the blocked solver's (d64 + 64) x d64 matrix + 1/L_ii + factorised diagonal blocks + block-ready flags
 inline size_t solveReducedScratchDoubles(int d) {
   const size_t dpad = ((size_t)d + 15) / 16 * 16, d64 = ((size_t)d + 63) / 64 * 64, nb = d64 / 64;
-  const size_t big = (d64 + 64) * d64 + d64 + d64 * 64 + ((nb + 1) * nb + 1) / 2 + 2;
+  const size_t big = (d64 + 64) * d64 + d64 + d64 * 64 + ((nb + 3) * nb + 1) / 2 + 2;
   return dpad * dpad > big ? dpad * dpad : big;
 }
 // post-solve pass (back-substitution, J*v / J*y sums, norms); fuseRadius > 0: its last block also takes the dogleg
