@@ -133,10 +133,10 @@ def main_posegraph(args):
                        "iterations_per_step": total_it / (args.steps * world), "initial_cost": last["initial_cost"],
                        "final_cost": last["final_cost"], "partition": part, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_big_chol_tasks + k_big_back",
+                         "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_big_chol_chain + k_big_back",
                          "launch_ms": 1e3 * dense_t / max(dense_n, 1), "flops_per_launch": flops,
-                         "note": "dense separator system of %d unknowns: latency-bound (serial 16-column pivots), not "
-                                 "throughput-bound; see DESIGN.md 9" % d},
+                         "note": "dense root of %d unknowns (loop cover + level-2 cuts): latency-bound (serial 16-column "
+                                 "pivots), not throughput-bound; see DESIGN.md 9" % d},
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc

@@ -141,3 +141,19 @@ def test_config5_graph_matches_oracle(six):
     sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
     print(g.partition())
     compare(g, c, sg, sc, tol_pose=1e-6)
+
+
+@pytest.mark.parametrize("six", [False, True])
+def test_outlier_loops_in_the_huber_region(six):
+    """a few grossly wrong loop measurements: their residuals sit far outside HuberLoss(0.1)'s quadratic region, so the
+    corrector scaling sqrt(rho') is active on both sides (loss_function.cc / corrector.cc restated in the oracle)"""
+    spec = spg.make_pose_graph(n=600, laps=4, loop_every=15, seed=17)
+    rng = np.random.default_rng(1)
+    bad = rng.choice(sorted(spec.loops), size=5, replace=False)
+    for k in bad:
+        li, rt, rq, ry = spec.loops[int(k)]
+        spec.loops[int(k)] = (li, rt + rng.normal(0, 1.5, 3), rq, ry + 25.0)
+    g, c, earliest, cur = pair(six, spec)
+    sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
+    compare(g, c, sg, sc)
+    assert g.partition()["pieces"] >= 2
