@@ -3228,6 +3228,9 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
   extern __shared__ double smem[];
   double* y = smem - c0;            // y[c0 .. c1) lives in smem[0 .. c1 - c0)
   double* part = smem + (c1 - c0);  // 8 x 64 partial sums
+  double* Fl = part + 8 * 64;       // this panel's factorised diagonal block (64 x 65: conflict-free columns) + 1/L_ii
+  double* dl = Fl + kNB * (kNB + 1);
+  constexpr int kFld = kNB + 1;
   const int t = threadIdx.x, d = p.d;
   double* M = p.cholL;
   for (int i = c0 + t; i < c1; i += blockDim.x) {
@@ -3237,12 +3240,20 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
   }
   __syncthreads();
   for (int k0 = c1 - kNB; k0 >= c0; k0 -= kNB) {
+    // the panel's diagonal factor goes to LDS while the sums below run (it is read 4 x 2 times, serially, afterwards)
+    for (int e = t; e < kNB * kNB; e += blockDim.x) Fl[(e >> 6) * kFld + (e & 63)] = diagF[(size_t)k0 * kNB + e];
+    if (t < kNB) dl[t] = dinvG[k0 + t];
     // s_c = sum_{k0 + 64 <= i < c1} L[i][k0 + c] y[i]: 8 row stripes x 64 columns
     {
       const int c = t & 63, stripe = t >> 6;
-      double s = 0;
-      for (int i = k0 + kNB + stripe; i < c1; i += 8) s += M[(size_t)i * dpad + k0 + c] * y[i];
-      part[stripe * 64 + c] = s;
+      double s0 = 0, s1 = 0;
+      int i = k0 + kNB + stripe;
+      for (; i + 8 < c1; i += 16) {
+        s0 += M[(size_t)i * dpad + k0 + c] * y[i];
+        s1 += M[(size_t)(i + 8) * dpad + k0 + c] * y[i + 8];
+      }
+      if (i < c1) s0 += M[(size_t)i * dpad + k0 + c] * y[i];
+      part[stripe * 64 + c] = s0 + s1;
     }
     __syncthreads();
     if (t < kNB) {
@@ -3259,10 +3270,10 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
         const int b0 = k0 + 16 * tt;
         const int li = lane & 15;
         // y_t = L_tt^-T rhs_t : (L^-T)[li][r] = Linv[r][li], stored at tile(tt,tt)[li][r] for r > li
-        double yv = y[b0 + li] * dinvG[b0 + li];
-        const double* F = diagF + (size_t)k0 * kNB;   // this panel's 64x64 factor block, row-major
+        double yv = y[b0 + li] * dl[16 * tt + li];
+#pragma unroll
         for (int r = 1; r < 16; ++r) {
-          const double term = F[(size_t)(16 * tt + li) * kNB + 16 * tt + r] * y[b0 + r];
+          const double term = Fl[(16 * tt + li) * kFld + 16 * tt + r] * y[b0 + r];
           yv += (r > li) ? term : 0.0;
         }
         waveSync();
@@ -3272,7 +3283,7 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
         for (int u = lane; u < 16 * tt; u += 64) {
           double s = 0;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) s += F[(size_t)(16 * tt + k) * kNB + u] * y[b0 + k];
+          for (int k = 0; k < 16; ++k) s += Fl[(16 * tt + k) * kFld + u] * y[b0 + k];
           y[k0 + u] -= s;
         }
         waveSync();
@@ -3333,7 +3344,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
         }
       }
     }
-    const size_t ldsBack = ((size_t)kBackSpan + 8 * 64) * 8;
+    const size_t ldsBack = ((size_t)kBackSpan + 8 * 64 + kNB * (kNB + 1) + kNB) * 8;
     for (int c1 = dp; c1 > 0; c1 -= kBackSpan) {
       const int c0 = std::max(0, c1 - kBackSpan);
       const int nChunks = (dp - c1 + kBackSpan - 1) / kBackSpan;   // <= 63: the spare rows of the rhs block

@@ -632,10 +632,8 @@ __global__ void k_pg_scatter_sep(PgDev p) {
   for (int c = 0; c < p.D; ++c) p.y[p.off[k] + c] = p.yS[p.sepOff[k] + c];
 }
 
-__global__ void k_pg_step(PgDev p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < p.n) p.delta[i] = -p.y[i] * p.scale[i];
-}
+// the step in the tangent space: delta = -y * scale (y solves the scaled, damped normal equations)
+__device__ __forceinline__ double pgDelta(const PgDev& p, int i) { return -p.y[i] * p.scale[i]; }
 
 // model cost change = -(J delta).(r + J delta / 2) over the edges
 template <int D>
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(128) void k_pg_model(PgDev p) {
     const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
     double da[D], db[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) { da[c] = oa >= 0 ? p.delta[oa + c] : 0.0; db[c] = ob >= 0 ? p.delta[ob + c] : 0.0; }
+    for (int c = 0; c < D; ++c) { da[c] = oa >= 0 ? pgDelta(p, oa + c) : 0.0; db[c] = ob >= 0 ? pgDelta(p, ob + c) : 0.0; }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       double mr = 0;
@@ -670,24 +668,24 @@ __global__ __launch_bounds__(128) void k_pg_plus(PgDev p) {
     const int o = p.off[k];
     if (!p.six) {
       const double y0 = p.yaw[k];
-      const double y1 = o >= 0 ? pgNormalizeAngle(y0 + p.delta[o]) : y0;
+      const double y1 = o >= 0 ? pgNormalizeAngle(y0 + pgDelta(p, o)) : y0;
       p.yawC[k] = y1;
       if (o >= 0) { st += (y1 - y0) * (y1 - y0); xn += y0 * y0; }
       for (int c = 0; c < 3; ++c) {
-        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + p.delta[o + 1 + c] : x0;
+        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + pgDelta(p, o + 1 + c) : x0;
         p.tC[3 * k + c] = x1;
         if (o >= 0) { st += (x1 - x0) * (x1 - x0); xn += x0 * x0; }
       }
     } else {
       for (int c = 0; c < 3; ++c) {
-        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + p.delta[o + c] : x0;
+        const double x0 = p.t[3 * k + c], x1 = o >= 0 ? x0 + pgDelta(p, o + c) : x0;
         p.tC[3 * k + c] = x1;
         if (o >= 0) { st += (x1 - x0) * (x1 - x0); xn += x0 * x0; }
       }
       const Quat q0{p.q[4 * k], p.q[4 * k + 1], p.q[4 * k + 2], p.q[4 * k + 3]};
       Quat q1 = q0;
       if (o >= 0) {
-        const double dx = p.delta[o + 3], dy = p.delta[o + 4], dz = p.delta[o + 5];
+        const double dx = pgDelta(p, o + 3), dy = pgDelta(p, o + 4), dz = pgDelta(p, o + 5);
         const double nd = sqrt(dx * dx + dy * dy + dz * dz);
         if (nd > 0.0) {
           const double s = sin(nd) / nd;
@@ -704,6 +702,16 @@ __global__ __launch_bounds__(128) void k_pg_plus(PgDev p) {
   if (threadIdx.x == 0) { p.partial[PG_STEP2 * kPgMaxPartials + blockIdx.x] = a; p.partial[PG_X2 * kPgMaxPartials + blockIdx.x] = b; }
 }
 
+// the iteration's four sums in one launch: block b reduces slot b's partials (model, step^2, x^2 over nodes; cost over edges)
+__global__ __launch_bounds__(256) void k_pg_reduce_step(PgDev p, int nEdgeBlocks, int nNodeBlocks) {
+  __shared__ double red[4];
+  const int slots[4] = {PG_MODEL, PG_STEP2, PG_X2, PG_COST};
+  const int slot = slots[blockIdx.x], n = (slot == PG_MODEL || slot == PG_COST) ? nEdgeBlocks : nNodeBlocks;
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += p.partial[slot * kPgMaxPartials + i];
+  const double s = pgBlockSum(v, red);
+  if (threadIdx.x == 0) p.scal[slot] = s;
+}
 // single-block final reductions (fixed order): slot -> scal[slot]; isMax selects max instead of sum
 __global__ __launch_bounds__(256) void k_pg_reduce(PgDev p, int slot, int n, int isMax) {
   __shared__ double red[4];
@@ -1201,14 +1209,16 @@ class PoseGraph {
       dPieces2_.upload(L2.pieces, s_); dColSep2_.upload(L2.colSep, s_); dRowMap2_.upload(L2.rowMap, s_);
       dTileWork2_.upload(L2.tileWork, s_); dGPtr2_.upload(L2.gPtr, s_); dGDst2_.upload(L2.gDst, s_); dGSrc2_.upload(L2.gSrc, s_);
       dRPtr2_.upload(L2.rPtr, s_); dRSrc2_.upload(L2.rSrc, s_); dXDst_.upload(xDst, s_); dXSrc_.upload(xSrc, s_);
-      dBand2_.reserve(L2.bandTot); dY2_.reserve(L2.yTot); dSp2_.reserve(L2.spTot);
+      dSp2_.reserve(L2.spTot);
     }
     const size_t RD = (size_t)R * D;
     dRes_.reserve((size_t)ne * R); dJa_.reserve(ne * RD); dJb_.reserve(ne * RD);
     const int dpad = ((nS + 15) / 16) * 16;
     const size_t dp64 = ((size_t)nS + 63) / 64 * 64;
     dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
-    dBand_.reserve(bandTot); dY_.reserve(yTot); dSp_.reserve(spTot);
+    // band | Y of both levels share one allocation: one memset per iteration
+    const size_t workTot = bandTot + yTot + (nPieces2 > 0 ? L2.bandTot + L2.yTot : 0);
+    dBand_.reserve(workTot); dSp_.reserve(spTot);
     dChol_.reserve(solveReducedScratchDoubles(nR));
     dPartial_.reserve((size_t)8 * kPgMaxPartials);
     dScal_.reserve(PG_NSCAL + sizeof(SolverScalars) / sizeof(double) + 1);   // LM scalars, then the dense solver's: one read-back
@@ -1232,7 +1242,7 @@ class PoseGraph {
     p.sepOff = dSepOff_.p; p.nodePiece = dNodePiece_.p; p.nodeRow = dNodeRow_.p; p.pieces = dPieces_.p;
     p.edgeDst = dEdgeDst_.p; p.colSep = dColSep_.p; p.rowTan = dRowTan_.p; p.tileWork = dTileWork_.p;
     p.gPtr = dGPtr_.p; p.gDst = dGDst_.p; p.gSrc = dGSrc_.p; p.rPtr = dRPtr_.p; p.rSrc = dRSrc_.p;
-    p.band = dBand_.p; p.Y = dY_.p; p.Sp = dSp_.p; p.HS = dHS_.p;
+    p.band = dBand_.p; p.Y = dBand_.p + bandTot; p.Sp = dSp_.p; p.HS = dHS_.p;
     p.fail = &dSol->cholFail;
     {
       std::vector<double> one(nS, 1.0);
@@ -1252,7 +1262,7 @@ class PoseGraph {
       p2.BW = BW2; p2.nPieces = nPieces2; p2.maxRows = L2.maxRows;
       p2.pieces = dPieces2_.p; p2.colSep = dColSep2_.p; p2.rowTan = dRowMap2_.p; p2.tileWork = dTileWork2_.p;
       p2.gPtr = dGPtr2_.p; p2.gDst = dGDst2_.p; p2.gSrc = dGSrc2_.p; p2.rPtr = dRPtr2_.p; p2.rSrc = dRSrc2_.p;
-      p2.band = dBand2_.p; p2.Y = dY2_.p; p2.Sp = dSp2_.p; p2.y = p.yS;
+      p2.band = dBand_.p + bandTot + yTot; p2.Y = p2.band + L2.bandTot; p2.Sp = dSp2_.p; p2.y = p.yS;
     }
     const size_t ldsFactor2 = (size_t)L2.maxRows * (BW2 + 2) * 8 + 2 * 1024;
     const size_t ldsBack2 = ((size_t)L2.maxRows * (BW2 + 2) + W2 * D + kPgPieceThreads) * 8;
@@ -1288,10 +1298,7 @@ class PoseGraph {
     auto solveNormalEquations = [&](double radius, int& nSolves) {
       PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * (size_t)nS * nS, s_));
       PG_HIP_OK(hipMemsetAsync(dSol, 0, sizeof(SolverScalars), s_));
-      if (nPieces > 0) {
-        PG_HIP_OK(hipMemsetAsync(p.band, 0, sizeof(double) * bandTot, s_));
-        PG_HIP_OK(hipMemsetAsync(p.Y, 0, sizeof(double) * yTot, s_));
-      }
+      if (nPieces > 0) PG_HIP_OK(hipMemsetAsync(p.band, 0, sizeof(double) * workTot, s_));
       hipLaunchKernelGGL(k_pg_assemble_nodes, dim3(gN), dim3(128), 0, s_, p, radius);
       if (six_) hipLaunchKernelGGL(k_pg_assemble_edges<6>, dim3(gE), dim3(128), 0, s_, p);
       else hipLaunchKernelGGL(k_pg_assemble_edges<4>, dim3(gE), dim3(128), 0, s_, p);
@@ -1303,8 +1310,6 @@ class PoseGraph {
         hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
       }
       if (nPieces2 > 0) {
-        PG_HIP_OK(hipMemsetAsync(p2.band, 0, sizeof(double) * L2.bandTot, s_));
-        PG_HIP_OK(hipMemsetAsync(p2.Y, 0, sizeof(double) * L2.yTot, s_));
         hipLaunchKernelGGL(k_pg_l2_extract, dim3((nX * D * D + 255) / 256), dim3(256), 0, s_, p2, (const int4*)dXDst_.p,
                            (const int2*)dXSrc_.p, nX);
         if (six_) hipLaunchKernelGGL((k_pg_piece_factor<6, 7>), dim3(nPieces2), dim3(kPgPieceThreads), ldsFactor2, s_, p2);
@@ -1352,14 +1357,12 @@ class PoseGraph {
       // The step is enqueued before the gradient check's scalar is back (one read-back per iteration instead of
       // three); when the gradient test fires the step is simply not used -- Ceres would not have computed it.
       solveNormalEquations(radius, nSolves);
-      hipLaunchKernelGGL(k_pg_step, dim3((n + 255) / 256), dim3(256), 0, s_, p);
       if (six_) hipLaunchKernelGGL(k_pg_model<6>, dim3(gE), dim3(128), 0, s_, p);
       else hipLaunchKernelGGL(k_pg_model<4>, dim3(gE), dim3(128), 0, s_, p);
-      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_MODEL, gE, 0);
       hipLaunchKernelGGL(k_pg_plus, dim3(gN), dim3(128), 0, s_, p);
-      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_STEP2, gN, 0);
-      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_X2, gN, 0);
-      evalCost(true, false);
+      if (six_) hipLaunchKernelGGL(k_pg_eval<true>, dim3(gE), dim3(128), 0, s_, p, 1, 0);
+      else hipLaunchKernelGGL(k_pg_eval<false>, dim3(gE), dim3(128), 0, s_, p, 1, 0);
+      hipLaunchKernelGGL(k_pg_reduce_step, dim3(4), dim3(256), 0, s_, p, gE, gN);
       readScal();
       if (freshLinearization && sc[PG_GRADMAX] <= gradient_tolerance) { termination = 0; break; }
       ++iteration;
@@ -1447,13 +1450,13 @@ class PoseGraph {
   static constexpr int kPgMaxTimed = 64;
   hipEvent_t evA_[kPgMaxTimed] = {}, evB_[kPgMaxTimed] = {};
   Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
-  Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dY_, dSp_;
+  Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dSp_;
   Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_, dSepOff_, dNodePiece_, dNodeRow_, dColSep_, dRowTan_, dGPtr_, dRPtr_;
   Buf<PgPiece> dPieces_, dPieces2_;
   Buf<int4> dEdgeDst_, dTileWork_, dGSrc_, dTileWork2_, dGSrc2_, dXDst_;
   Buf<int2> dGDst_, dRSrc_, dGDst2_, dRSrc2_, dXSrc_;
   Buf<int> dColSep2_, dRowMap2_, dGPtr2_, dRPtr2_;
-  Buf<double> dBand2_, dY2_, dSp2_;
+  Buf<double> dSp2_;
 };
 
 }  // namespace pg
