@@ -149,6 +149,17 @@ int svin_ba_is_in_imu_window(svin_ba* h, uint64_t frame_id);
 int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap);      /* returns the number of frames */
 int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap);   /* returns the number of landmarks */
 
+/* ---- keyframe hand-off to pose_graph: the estimator-side content of the keyframe message that
+ * ThreadedKFVio::optimizationLoop assembles (okvis_multisensor_processing/src/ThreadedKFVio.cpp:1147-1240).  For every
+ * landmark whose first observation in `frame_id` (MapPoint::observations order: frame, camera, keypoint) is in camera
+ * `cam_idx` (:1167, :1183): landmark id, Euclidean point (:1171-1176), keypoint index and quality (:1196-1199), and the
+ * frame ids of all its other observations (:1210-1226; the caller maps them to keyframe indices with kf_f_map_ and
+ * adds the cv::KeyPoint fields it owns).  obs_ptr has cap_points + 1 entries (CSR into obs_frame_ids).  Returns the
+ * number of points (it may exceed cap_points: call again with larger buffers); *n_obs_total the number of list entries. */
+int svin_ba_keyframe_points(svin_ba* h, uint64_t frame_id, uint64_t cam_idx, int cap_points, uint64_t* landmark_ids,
+                            double* xyz, uint64_t* keypoint_idx, double* quality, int32_t* obs_ptr, int cap_obs,
+                            uint64_t* obs_frame_ids, int32_t* n_obs_total);
+
 /* ---- CPU-callable prediction kept for the frontend (ImuError::propagation, ImuError.cpp:266-476):
  * runs on the GPU like everything else; T (7) and sb (9) are in/out; cov / jac are 15x15 or NULL. */
 int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],

@@ -66,6 +66,7 @@ def _bind(L):
     sig("orc_pg_linearize", None, vp, pd, pd)
     sig("orc_pg_ypr", None, pd, pd)
     sig("orc_pg_get_drift", None, vp, pd, pd, pd)
+    sig("orc_keyframe_points", i32, vp, u64, u64, i32, C.POINTER(u64), pd, C.POINTER(u64), pd, pi32, i32, C.POINTER(u64), pi32)
     sig("orc_create", vp)
     sig("orc_destroy", None, vp)
     sig("orc_new_id", u64, vp)
@@ -421,6 +422,18 @@ class OracleEstimator:
                                frame=int(f.value) if ok else None, kind=int(k.value) if ok else None,
                                index=int(ix.value) if ok else None))
         return dict(n=n, H=H, b0=b0, J=J, e0=e0, blocks=blocks)
+
+
+    def keyframe_points(self, frame_id, cam=0):
+        p64 = C.POINTER(C.c_uint64)
+        nt = C.c_int(0)
+        n = self.L.orc_keyframe_points(self.h, frame_id, cam, 0, None, None, None, None, None, 0, None, C.byref(nt))
+        ids, kps = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        xyz, q = np.zeros((n, 3)), np.zeros(n)
+        ptr, fr = np.zeros(n + 1, np.int32), np.zeros(max(nt.value, 1), np.uint64)
+        self.L.orc_keyframe_points(self.h, frame_id, cam, n, ids.ctypes.data_as(p64), dptr(xyz), kps.ctypes.data_as(p64), dptr(q),
+                                   i32ptr(ptr), nt.value, fr.ctypes.data_as(p64), C.byref(nt))
+        return ids, xyz, kps, q, [fr[ptr[i]:ptr[i + 1]].copy() for i in range(n)]
 
 
 class OraclePoseGraph:

@@ -111,6 +111,35 @@ int orc_landmark_ids(void* h, uint64_t* ids, int cap) {
   for (auto& kv : static_cast<Estimator*>(h)->landmarks()) { if (n < cap) ids[n] = kv.first; ++n; }
   return n;
 }
+// keyframe message content for pose_graph (ThreadedKFVio.cpp:1147-1240), same contract as svin_ba_keyframe_points
+int orc_keyframe_points(void* h, uint64_t frame_id, uint64_t cam_idx, int cap_points, uint64_t* lm_ids, double* xyz,
+                        uint64_t* kp_idx, double* quality, int* obs_ptr, int cap_obs, uint64_t* obs_frame_ids, int* n_obs_total) {
+  int n = 0, no = 0;
+  for (auto& kv : static_cast<Estimator*>(h)->landmarks()) {
+    const MapPoint& mp = kv.second;
+    for (auto mit = mp.observations.begin(); mit != mp.observations.end(); ++mit) {
+      if (std::get<0>(mit->first) != frame_id) continue;
+      if (std::get<1>(mit->first) != cam_idx) break;   // :1183 `continue` on the first match, then :1229 never reached: next landmark
+      if (n < cap_points) {
+        if (lm_ids) lm_ids[n] = kv.first;
+        if (xyz) for (int k = 0; k < 3; ++k) xyz[3 * n + k] = mp.point[k] / mp.point[3];
+        if (kp_idx) kp_idx[n] = std::get<2>(mit->first);
+        if (quality) quality[n] = mp.quality;
+        if (obs_ptr) obs_ptr[n] = no;
+      }
+      for (auto oit = mp.observations.begin(); oit != mp.observations.end(); ++oit) {
+        if (std::get<0>(oit->first) == frame_id) continue;
+        if (no < cap_obs && obs_frame_ids) obs_frame_ids[no] = std::get<0>(oit->first);
+        ++no;
+      }
+      ++n;
+      break;
+    }
+  }
+  if (obs_ptr && n <= cap_points) obs_ptr[n] = no;
+  if (n_obs_total) *n_obs_total = no;
+  return n;
+}
 // [initial_cost, final_cost, iterations, successful_steps, termination, total_time]
 void orc_summary(void* h, double* out) {
   const SolverSummary& s = static_cast<Estimator*>(h)->map().summary;

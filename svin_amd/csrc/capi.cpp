@@ -1,5 +1,7 @@
 // svin_amd C ABI (include/svin_ba.h).  Plain pointers and sizes only; nothing throws across the boundary.
 #include "../../include/svin_ba.h"
+
+#include <algorithm>
 #include "window.hpp"
 #include <vector>
 
@@ -226,6 +228,46 @@ int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) {
   int n = 0;
   for (auto& kv : h->w.landmarks()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
   return n;
+}
+int svin_ba_keyframe_points(svin_ba* h, uint64_t frame_id, uint64_t cam_idx, int cap_points, uint64_t* lm_ids, double* xyz,
+                            uint64_t* kp_idx, double* quality, int32_t* obs_ptr, int cap_obs, uint64_t* obs_frame_ids,
+                            int32_t* n_obs_total) {
+  if (!h || cap_points < 0 || cap_obs < 0) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  int n = 0, no = 0;
+  std::vector<const svin::Observation*> sorted;
+  for (const auto& kv : h->w.landmarks()) {   // PointMap order (std::map by landmark id)
+    const svin::Landmark& lm = kv.second;
+    // MapPoint::observations is ordered by (frame, camera, keypoint); the publisher takes the first entry of the frame
+    sorted.clear();
+    for (const svin::Observation& o : lm.obs) sorted.push_back(&o);
+    std::sort(sorted.begin(), sorted.end(), [](const svin::Observation* a, const svin::Observation* b) {
+      if (a->poseId != b->poseId) return a->poseId < b->poseId;
+      if (a->cam != b->cam) return a->cam < b->cam;
+      return a->kp < b->kp;
+    });
+    const svin::Observation* first = nullptr;
+    for (const svin::Observation* o : sorted)
+      if (o->poseId == frame_id) { first = o; break; }
+    if (!first || (uint64_t)first->cam != cam_idx) continue;   // ThreadedKFVio.cpp:1167, :1183
+    if (n < cap_points) {
+      if (lm_ids) lm_ids[n] = lm.id;
+      if (xyz) for (int k = 0; k < 3; ++k) xyz[3 * n + k] = lm.hp[k] / lm.hp[3];
+      if (kp_idx) kp_idx[n] = first->kp;
+      if (quality) quality[n] = lm.quality;
+      if (obs_ptr) obs_ptr[n] = no;
+    }
+    for (const svin::Observation* o : sorted) {
+      if (o->poseId == frame_id) continue;   // :1213
+      if (no < cap_obs && obs_frame_ids) obs_frame_ids[no] = o->poseId;
+      ++no;
+    }
+    ++n;
+  }
+  if (obs_ptr && n <= cap_points) obs_ptr[n] = no;
+  if (n_obs_total) *n_obs_total = no;
+  return n;
+  GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],
                             double sb[9], uint32_t s0, uint32_t ns0, uint32_t s1, uint32_t ns1, double* cov, double* jac) {

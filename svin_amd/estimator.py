@@ -46,7 +46,7 @@ IMU_SAMPLE_DTYPE = np.dtype([("sec", np.uint32), ("nsec", np.uint32), ("gyr", np
 EXPORTS = [
     "svin_ba_create", "svin_ba_destroy", "svin_ba_last_error", "svin_ba_new_id", "svin_ba_add_camera", "svin_ba_add_imu",
     "svin_ba_set_sonar_extrinsics", "svin_ba_add_states", "svin_ba_add_landmark", "svin_ba_add_observation",
-    "svin_ba_add_observations",
+    "svin_ba_add_observations", "svin_ba_keyframe_points",
     "svin_ba_remove_observation", "svin_ba_remove_observation_by_id", "svin_ba_optimize", "svin_ba_prepare",
     "svin_ba_solve_prepared", "svin_ba_finish", "svin_ba_invalidate_preintegration",
     "svin_ba_set_optimization_time_limit", "svin_ba_apply_marginalization_strategy", "svin_ba_get_summary",
@@ -96,6 +96,8 @@ def load_library():
     sig("svin_ba_add_observation", u64, vp, u64, u64, u64, u64, pd, f64)
     sig("svin_ba_add_observations", i32, vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), pd, pd,
         C.POINTER(u64))
+    sig("svin_ba_keyframe_points", i32, vp, u64, u64, i32, C.POINTER(u64), pd, C.POINTER(u64), pd, C.POINTER(i32), i32,
+        C.POINTER(u64), C.POINTER(i32))
     sig("svin_ba_remove_observation", i32, vp, u64, u64, u64, u64)
     sig("svin_ba_remove_observation_by_id", i32, vp, u64)
     sig("svin_ba_optimize", i32, vp, u64, u64, i32)
@@ -233,6 +235,21 @@ class Estimator:
         self._check(self.L.svin_ba_add_observations(self.h, n, *[x.ctypes.data_as(p64) for x in a], _d(uvs), _d(sizes),
                                                     out.ctypes.data_as(p64)), "add_observations")
         return out
+
+    def keyframe_points(self, frame_id, cam=0):
+        """estimator-side content of the keyframe message for pose_graph (ThreadedKFVio.cpp:1147-1240): landmark ids,
+        Euclidean points, keypoint indices, qualities and per point the frame ids of its other observations"""
+        p64, p32 = C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+        nt = C.c_int32(0)
+        n = self._check(self.L.svin_ba_keyframe_points(self.h, frame_id, cam, 0, None, None, None, None, None, 0, None,
+                                                       C.byref(nt)), "keyframe_points")
+        ids, kps = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        xyz, q = np.zeros((n, 3)), np.zeros(n)
+        ptr, fr = np.zeros(n + 1, np.int32), np.zeros(max(nt.value, 1), np.uint64)
+        self._check(self.L.svin_ba_keyframe_points(self.h, frame_id, cam, n, ids.ctypes.data_as(p64), _d(xyz),
+                                                   kps.ctypes.data_as(p64), _d(q), ptr.ctypes.data_as(p32), nt.value,
+                                                   fr.ctypes.data_as(p64), C.byref(nt)), "keyframe_points")
+        return ids, xyz, kps, q, [fr[ptr[i]:ptr[i + 1]].copy() for i in range(n)]
 
     def remove_observation(self, lid, pose, cam, kp):
         return bool(self._check(self.L.svin_ba_remove_observation(self.h, lid, pose, cam, kp), "remove_observation"))

@@ -385,3 +385,34 @@ def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
         assert s["iterations"] == s_ref["iterations"]
         assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
         assert worst < 1e-9
+
+
+def test_keyframe_hand_off_matches_oracle():
+    """the estimator-side content of the keyframe message for pose_graph (ThreadedKFVio.cpp:1147-1240),
+    on a window that has been optimised and marginalised (landmarks and observations come and go)"""
+    spec = syn.make_window(P=12, L=300, n_obs=3000, seed=19, keyframe_every=2)
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    gpu, cpu = Estimator(0), orc.OracleEstimator()
+    checked, worst = [0], [0.0, 0.0]
+
+    def per_frame(est):
+        def cb(k, fid):
+            est.optimize(10, 1, False)
+            if k >= 6:
+                est.apply_marginalization(4, 2)
+        return cb
+    fg, _ = syn.feed(gpu, spec, on_frame=per_frame(gpu))
+    fc, _ = syn.feed(cpu, spec, on_frame=per_frame(cpu))
+    assert fg == fc
+    for fid in fg[-6:]:
+        for cam in (0, 1):
+            a, b = gpu.keyframe_points(fid, cam), cpu.keyframe_points(fid, cam)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+            assert len(a[4]) == len(b[4]) and all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+            if len(a[0]):   # the payload are solver outputs: same tolerance as the marginalisation-sequence tests
+                worst[0] = max(worst[0], rel(a[1], b[1]))
+                worst[1] = max(worst[1], float(np.max(np.abs(a[3] - b[3]))))
+            checked[0] += len(a[0])
+    log("keyframe hand-off: %d points compared, worst relative point difference %.2e, quality %.2e" % (checked[0], worst[0], worst[1]))
+    assert checked[0] > 100 and worst[0] < 1e-3 and worst[1] < 1e-2
