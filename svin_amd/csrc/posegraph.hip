@@ -371,7 +371,10 @@ template <int D, int W>
 __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
   using G = PgBand<D, W>;
   constexpr int BW = G::BW, LDB = G::LDB, P = G::P, NPAIR = G::NPAIR;
-  constexpr bool kAllWaves = NPAIR > 64;   // the trailing update of a 6-DoF keyframe has 300 pairs: use the workgroup
+  constexpr bool kAllWaves = NPAIR > 128;  // the trailing update of a 6-DoF keyframe has 300 pairs: use the workgroup
+  // With one factorising wave (4-DoF) the other waves run the forward substitution BEHIND it: keyframe j's rows are
+  // final once wave 0 has finished steps A and B of keyframe j (`progress`), long before the whole band is done.
+  __shared__ int progress;
   extern __shared__ double sm[];
   const PgPiece pc = p.pieces[blockIdx.x];
   const int n = pc.rows, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,8 +388,17 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
     while (rem > s_) { rem -= s_ + 1; ++s_; }
     tab[i] = (unsigned short)(s_ | (rem << 8));
   }
+  if (tid == 0) progress = 0;
   __syncthreads();
   int bad = 0;
+  constexpr int kStride = kAllWaves ? kPgPieceThreads : 64, kRounds = (NPAIR + kStride - 1) / kStride;
+  int pairS[kRounds], pairT[kRounds];
+#pragma unroll
+  for (int rd = 0; rd < kRounds; ++rd) {
+    const int pi = (kAllWaves ? tid : lane) + rd * kStride;
+    pairS[rd] = pi < NPAIR ? (tab[pi] & 255) : -1;
+    pairT[rd] = pi < NPAIR ? (tab[pi] >> 8) : 0;
+  }
   if (kAllWaves || wave == 0) {
     for (int j0 = 0; j0 < n; j0 += D) {
       if (wave == 0) {
@@ -438,12 +450,17 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
           for (int b = 0; b < D; ++b) row[b] = x[b];
         }
       }
-      if (kAllWaves) __syncthreads(); else pgWaveSync();
+      if (kAllWaves) __syncthreads();
+      else {
+        pgWaveSync();
+        if (lane == 0) __hip_atomic_store(&progress, j0 / D + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       // trailing update: A[j0+D+s][j0+D+t] -= X_s . X_t
-      for (int pi = kAllWaves ? tid : lane; pi < NPAIR; pi += kAllWaves ? kPgPieceThreads : 64) {
-        const int s_ = tab[pi] & 255, t_ = tab[pi] >> 8;
+#pragma unroll
+      for (int rd = 0; rd < kRounds; ++rd) {
+        const int s_ = pairS[rd], t_ = pairT[rd];   // (this thread's pairs never change: decoded once, before the loop)
         const int rs = j0 + D + s_;
-        if (rs < n) {
+        if (s_ >= 0 && rs < n) {
           const double* xs = Lb + rs * LDB + BW - D - s_;
           const double* xt = Lb + (j0 + D + t_) * LDB + BW - D - t_;
           double acc = 0;
@@ -456,10 +473,11 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
     }
     if (bad && tid == 0) atomicOr(p.fail, 1);
   }
-  __syncthreads();
-  for (int i = tid; i < n * LDB; i += kPgPieceThreads) band[i] = Lb[i];
-  if (tid < pc.cols) {
-    double* Yc = p.Y + pc.yOff + tid;
+  if (kAllWaves) __syncthreads();
+  // column -> thread: waves 1..3 take the first 192 columns (they are free while wave 0 factorises), wave 0 the rest
+  const int col = kAllWaves ? tid : (tid + kPgPieceThreads - 64) % kPgPieceThreads;
+  if (col < pc.cols) {
+    double* Yc = p.Y + pc.yOff + col;
     // keyframe by keyframe: hist = y of the W keyframes before (oldest first, zero before the first row), shifted by
     // one keyframe per step so that every register index is static
     double hist[P], cur[D], v[D];
@@ -471,6 +489,9 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
       double vn[D];
 #pragma unroll
       for (int b = 0; b < D; ++b) vn[b] = j0 + D + b < n ? Yc[(size_t)(j0 + D + b) * pc.ld] : 0.0;   // next keyframe's, in flight
+      if (!kAllWaves && wave != 0) {   // (wave 0 only gets here after its own loop)
+        while (__hip_atomic_load(&progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < j0 / D + 1) __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int b = 0; b < D; ++b) {
         const double* row = Lb + (j0 + b) * LDB;
@@ -491,6 +512,8 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_factor(PgDev p) {
       for (int b = 0; b < D; ++b) { hist[P - D + b] = cur[b]; v[b] = vn[b]; }
     }
   }
+  __syncthreads();
+  for (int i = tid; i < n * LDB; i += kPgPieceThreads) band[i] = Lb[i];
 }
 
 // S_p = Y^T Y, one 16x16 tile per workgroup (lower tiles only; the rhs column is the last row of S_p)
