@@ -2928,7 +2928,11 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
 // Superseded by k_big_chol_chain below (kept for A/B runs: SVIN_BIG_CHOL_TASKS=1); the per-panel launch pair
 // (k_big_panel + k_big_syrk) stays as the launch-based fallback (SVIN_BIG_CHOL_LAUNCHES=1).
 constexpr int kSpinMax = 1 << 20;
-constexpr int kPersistMaxGrid = 256;
+// Workgroups of one solve: all must be co-resident (1 per CU: 104 KB of LDS each).  120 leaves room for a second
+// solve of another handle / stream on the same GPU (2 x 120 <= 256 CUs); roots with more than kPersistWideTasks
+// block tasks (> ~2000 unknowns) take the whole chip.  Beyond that the bounded waits turn a would-be deadlock into
+// a flagged failure.
+constexpr int kPersistMaxGrid = 120, kPersistWideGrid = 256, kPersistWideTasks = 512;
 __device__ __forceinline__ bool pollReady(const int* f) {
   for (int it = 0; it < kSpinMax; ++it) {
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
@@ -3325,7 +3329,9 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
       (void)hipFuncSetAttribute((const void*)k_big_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
       int nHelperTasks = 0;
       for (int st = 0; st < nb; ++st) nHelperTasks += std::max(nb - st - 1, 0) + ((st + 2 <= nb - 1) ? 2 : 0);
-      hipLaunchKernelGGL(k_big_chol_chain, dim3(1 + std::max(1, std::min(nHelperTasks, kPersistMaxGrid - 1))), dim3(256), ldsTasks, s, p, dp,
+      hipLaunchKernelGGL(k_big_chol_chain,
+                         dim3(1 + std::max(1, std::min(nHelperTasks, (nHelperTasks > kPersistWideTasks ? kPersistWideGrid : kPersistMaxGrid) - 1))),
+                         dim3(256), ldsTasks, s, p, dp,
                          dinvG, diagF, ready);
     } else if (!perPanelLaunches) {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;

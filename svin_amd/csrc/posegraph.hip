@@ -73,7 +73,7 @@ struct PgDev {
   int *gPtr; int2* gDst; int4* gSrc;    // separator block <- sum of piece Schur blocks {piece, rowOff, colOff, 0}
   int *rPtr; int2* rSrc;                // separator node rhs <- {piece, colOff}
   double *band, *Y, *Sp, *HS, *rhsS, *yS;
-  int* fail;
+  int *fail, *ticket;
 };
 enum PgScal : int { PG_COST = 0, PG_GRADMAX = 1, PG_MODEL = 2, PG_STEP2 = 3, PG_X2 = 4, PG_NSCAL = 8 };
 constexpr int kPgMaxPartials = 4096;
@@ -192,8 +192,23 @@ __device__ __forceinline__ void pgEdge(const PgDev& p, int e, bool cand, double*
   }
 }
 
+// the iteration's sums (and the linearisation's gradient max) from the block partials, fixed order; one block
+__device__ void pgFinalReduce(const PgDev& p, int nEdgeBlocks, int nNodeBlocks, double* red) {
+  const int slots[5] = {PG_MODEL, PG_STEP2, PG_X2, PG_COST, PG_GRADMAX};
+  for (int k = 0; k < 5; ++k) {
+    const int slot = slots[k], n = (slot == PG_MODEL || slot == PG_COST) ? nEdgeBlocks : nNodeBlocks;
+    const bool isMax = slot == PG_GRADMAX;
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const double x = p.partial[slot * kPgMaxPartials + i];
+      v = isMax ? fmax(v, x) : v + x;
+    }
+    const double s = isMax ? pgBlockMax(v, red) : pgBlockSum(v, red);
+    if (threadIdx.x == 0) p.scal[slot] = s;
+  }
+}
 template <bool SIX>
-__global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac) {
+__global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac, int finalReduceNodeBlocks) {
   constexpr int D = SIX ? 6 : 4, R = D, RD = R * D;
   __shared__ double red[2];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,6 +241,18 @@ __global__ __launch_bounds__(128) void k_pg_eval(PgDev p, int cand, int withJac)
   }
   const double bs = pgBlockSum(cost, red);
   if (threadIdx.x == 0) p.partial[PG_COST * kPgMaxPartials + blockIdx.x] = bs;
+  if (finalReduceNodeBlocks <= 0) return;
+  // candidate evaluation = last kernel of an iteration: whichever block finishes last reduces every scalar of the
+  // iteration (one launch less per iteration)
+  __shared__ int isLast;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) isLast = atomicAdd(p.ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!isLast) return;
+  __threadfence();
+  pgFinalReduce(p, gridDim.x, finalReduceNodeBlocks, red);
+  if (threadIdx.x == 0) *p.ticket = 0;
 }
 
 // one thread per node: gradient, column norms, (first iteration) Jacobi scaling, raw J^T J block
@@ -283,8 +310,8 @@ __global__ __launch_bounds__(128) void k_pg_node(PgDev p, int initScale) {
 }
 
 // damped, scaled diagonal block and right-hand side of one free node -> separator system or its piece
-__global__ void k_pg_assemble_nodes(PgDev p, double radius) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pgAssembleNode(const PgDev& p, double radius, int vb) {
+  const int k = vb * blockDim.x + threadIdx.x;
   if (k >= p.nn || p.off[k] < 0) return;
   const int D = p.D, o = p.off[k], so = p.sepOff[k];
   const double* blk = p.nodeBlk + (size_t)k * 36;
@@ -309,9 +336,9 @@ __global__ void k_pg_assemble_nodes(PgDev p, double radius) {
 // added to its destination.  At most two edges share a destination block (a sequential and a loop edge between the
 // same pair), so the atomic adds commute exactly.
 template <int D>
-__global__ __launch_bounds__(128) void k_pg_assemble_edges(PgDev p) {
+__device__ __forceinline__ void pgAssembleEdge(const PgDev& p, int vb) {
   constexpr int R = D;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = vb * blockDim.x + threadIdx.x;
   if (e >= p.ne) return;
   const int4 dst = p.edgeDst[e];
   const int kind = dst.x & 15, rowIsB = (dst.x >> 4) & 1;
@@ -341,6 +368,13 @@ __global__ __launch_bounds__(128) void k_pg_assemble_edges(PgDev p) {
       const int r = rowIsB ? c1 : c2, c = rowIsB ? c2 : c1;
       atomicAdd(base + (size_t)r * ld + c, s);
     }
+}
+// the damped normal equations of one linearisation in one launch: node blocks first, then edge blocks
+template <int D>
+__global__ __launch_bounds__(128) void k_pg_assemble(PgDev p, double radius, int nNodeBlocks) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.fail = 0;   // (read back after the solve; set by the piece / dense factorisations)
+  if ((int)blockIdx.x < nNodeBlocks) pgAssembleNode(p, radius, blockIdx.x);
+  else pgAssembleEdge<D>(p, blockIdx.x - nNodeBlocks);
 }
 
 // ---------------------------------------------------------------- pieces
@@ -530,8 +564,8 @@ __global__ __launch_bounds__(256) void k_pg_piece_schur(PgDev p) {
 }
 
 // separator system -= sum over pieces of their Schur blocks, contributions in the host's fixed order
-__global__ void k_pg_sep_gather(PgDev p, int nDest) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x, DD = p.D * p.D;
+__device__ __forceinline__ void pgSepGather(const PgDev& p, int nDest, int vb) {
+  const int idx = vb * blockDim.x + threadIdx.x, DD = p.D * p.D;
   if (idx >= nDest * DD) return;
   const int b = idx / DD, e = idx - b * DD, r = e / p.D, c = e - r * p.D;
   const int2 dst = p.gDst[b];
@@ -544,8 +578,8 @@ __global__ void k_pg_sep_gather(PgDev p, int nDest) {
   }
   p.HS[(size_t)(dst.x + r) * p.nS + dst.y + c] -= acc;
 }
-__global__ void k_pg_sep_gather_rhs(PgDev p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pgSepGatherRhs(const PgDev& p, int vb) {
+  const int idx = vb * blockDim.x + threadIdx.x;
   if (idx >= p.nS) return;
   const int sn = idx / p.D, c = idx - sn * p.D;
   double acc = 0;
@@ -555,6 +589,10 @@ __global__ void k_pg_sep_gather_rhs(PgDev p) {
     acc += p.Sp[pc.sOff + (size_t)(pc.cols - 1) * pc.ld + src.y + c];
   }
   p.rhsS[idx] -= acc;
+}
+__global__ __launch_bounds__(256) void k_pg_sep_gather(PgDev p, int nDest, int nDestBlocks) {
+  if ((int)blockIdx.x < nDestBlocks) pgSepGather(p, nDest, blockIdx.x);
+  else pgSepGatherRhs(p, blockIdx.x - nDestBlocks);
 }
 
 // level 2: the blocks of a level-2 piece (band, coupling columns, right-hand side) copied out of the separator system
@@ -582,6 +620,12 @@ __global__ __launch_bounds__(kPgPieceThreads) void k_pg_piece_back(PgDev p) {
   using G = PgBand<D, W>;
   constexpr int BW = G::BW, LDB = G::LDB, P = G::P;
   extern __shared__ double sm[];
+  if ((int)blockIdx.x >= p.nPieces) {   // level 1 only: extra blocks copy the separators' solution to tangent order
+    const int k = ((int)blockIdx.x - p.nPieces) * blockDim.x + threadIdx.x;
+    if (k < p.nn && p.off[k] >= 0 && p.sepOff[k] >= 0)
+      for (int c = 0; c < p.D; ++c) p.y[p.off[k] + c] = p.yS[p.sepOff[k] + c];
+    return;
+  }
   const PgPiece pc = p.pieces[blockIdx.x];
   const int n = pc.rows, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* Lb = sm;
@@ -660,10 +704,9 @@ __device__ __forceinline__ double pgDelta(const PgDev& p, int i) { return -p.y[i
 
 // model cost change = -(J delta).(r + J delta / 2) over the edges
 template <int D>
-__global__ __launch_bounds__(128) void k_pg_model(PgDev p) {
+__device__ __forceinline__ void pgModel(const PgDev& p, int vb, double* red) {
   constexpr int R = D;
-  __shared__ double red[2];
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = vb * blockDim.x + threadIdx.x;
   double acc = 0;
   if (e < p.ne) {
     const int oa = p.off[p.ea[e]], ob = p.off[p.eb[e]];
@@ -679,13 +722,12 @@ __global__ __launch_bounds__(128) void k_pg_model(PgDev p) {
     }
   }
   const double bs = pgBlockSum(acc, red);
-  if (threadIdx.x == 0) p.partial[PG_MODEL * kPgMaxPartials + blockIdx.x] = bs;
+  if (threadIdx.x == 0) p.partial[PG_MODEL * kPgMaxPartials + vb] = bs;
 }
 
 // candidate = Plus(x, delta) (YawAngleFunctor PoseGraph.h:95-108 / EigenQuaternionManifold::Plus); |x_c - x|^2, |x|^2
-__global__ __launch_bounds__(128) void k_pg_plus(PgDev p) {
-  __shared__ double red[2];
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pgPlus(const PgDev& p, int vb, double* red) {
+  const int k = vb * blockDim.x + threadIdx.x;
   double st = 0, xn = 0;
   if (k < p.nn) {
     const int o = p.off[k];
@@ -722,19 +764,16 @@ __global__ __launch_bounds__(128) void k_pg_plus(PgDev p) {
   }
   const double a = pgBlockSum(st, red);
   const double b = pgBlockSum(xn, red);
-  if (threadIdx.x == 0) { p.partial[PG_STEP2 * kPgMaxPartials + blockIdx.x] = a; p.partial[PG_X2 * kPgMaxPartials + blockIdx.x] = b; }
+  if (threadIdx.x == 0) { p.partial[PG_STEP2 * kPgMaxPartials + vb] = a; p.partial[PG_X2 * kPgMaxPartials + vb] = b; }
+}
+// model cost change (edge blocks) and candidate (node blocks) in one launch
+template <int D>
+__global__ __launch_bounds__(128) void k_pg_model_plus(PgDev p, int nEdgeBlocks) {
+  __shared__ double red[2];
+  if ((int)blockIdx.x < nEdgeBlocks) pgModel<D>(p, blockIdx.x, red);
+  else pgPlus(p, blockIdx.x - nEdgeBlocks, red);
 }
 
-// the iteration's four sums in one launch: block b reduces slot b's partials (model, step^2, x^2 over nodes; cost over edges)
-__global__ __launch_bounds__(256) void k_pg_reduce_step(PgDev p, int nEdgeBlocks, int nNodeBlocks) {
-  __shared__ double red[4];
-  const int slots[4] = {PG_MODEL, PG_STEP2, PG_X2, PG_COST};
-  const int slot = slots[blockIdx.x], n = (slot == PG_MODEL || slot == PG_COST) ? nEdgeBlocks : nNodeBlocks;
-  double v = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += p.partial[slot * kPgMaxPartials + i];
-  const double s = pgBlockSum(v, red);
-  if (threadIdx.x == 0) p.scal[slot] = s;
-}
 // single-block final reductions (fixed order): slot -> scal[slot]; isMax selects max instead of sum
 __global__ __launch_bounds__(256) void k_pg_reduce(PgDev p, int slot, int n, int isMax) {
   __shared__ double red[4];
@@ -1236,15 +1275,13 @@ class PoseGraph {
     }
     const size_t RD = (size_t)R * D;
     dRes_.reserve((size_t)ne * R); dJa_.reserve(ne * RD); dJb_.reserve(ne * RD);
-    const int dpad = ((nS + 15) / 16) * 16;
-    const size_t dp64 = ((size_t)nS + 63) / 64 * 64;
-    dHS_.reserve((size_t)nS * nS); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
-    // band | Y of both levels share one allocation: one memset per iteration
+    // the separator system and band | Y of both levels share one allocation: one memset per iteration
     const size_t workTot = bandTot + yTot + (nPieces2 > 0 ? L2.bandTot + L2.yTot : 0);
-    dBand_.reserve(workTot); dSp_.reserve(spTot);
+    dHS_.reserve((size_t)nS * nS + workTot); dVec_.reserve((size_t)5 * n + 4 * (size_t)nS + 64); dNodeBlk_.reserve((size_t)nn * 36);
+    dSp_.reserve(spTot);
     dChol_.reserve(solveReducedScratchDoubles(nR));
     dPartial_.reserve((size_t)8 * kPgMaxPartials);
-    dScal_.reserve(PG_NSCAL + sizeof(SolverScalars) / sizeof(double) + 1);   // LM scalars, then the dense solver's: one read-back
+    dScal_.reserve(PG_NSCAL + sizeof(SolverScalars) / sizeof(double) + 3);   // LM scalars, then the dense solver's: one read-back
     SolverScalars* const dSol = reinterpret_cast<SolverScalars*>(dScal_.p + PG_NSCAL);
     PgDev p;
     std::memset(&p, 0, sizeof(p));
@@ -1265,8 +1302,10 @@ class PoseGraph {
     p.sepOff = dSepOff_.p; p.nodePiece = dNodePiece_.p; p.nodeRow = dNodeRow_.p; p.pieces = dPieces_.p;
     p.edgeDst = dEdgeDst_.p; p.colSep = dColSep_.p; p.rowTan = dRowTan_.p; p.tileWork = dTileWork_.p;
     p.gPtr = dGPtr_.p; p.gDst = dGDst_.p; p.gSrc = dGSrc_.p; p.rPtr = dRPtr_.p; p.rSrc = dRSrc_.p;
-    p.band = dBand_.p; p.Y = dBand_.p + bandTot; p.Sp = dSp_.p; p.HS = dHS_.p;
+    p.HS = dHS_.p; p.band = dHS_.p + (size_t)nS * nS; p.Y = p.band + bandTot; p.Sp = dSp_.p;
     p.fail = &dSol->cholFail;
+    p.ticket = reinterpret_cast<int*>(dSol + 1);
+    PG_HIP_OK(hipMemsetAsync(dSol, 0, sizeof(SolverScalars) + 2 * sizeof(double), s_));
     {
       std::vector<double> one(nS, 1.0);
       PG_HIP_OK(hipMemcpyAsync(ones, one.data(), sizeof(double) * nS, hipMemcpyHostToDevice, s_));
@@ -1285,7 +1324,7 @@ class PoseGraph {
       p2.BW = BW2; p2.nPieces = nPieces2; p2.maxRows = L2.maxRows;
       p2.pieces = dPieces2_.p; p2.colSep = dColSep2_.p; p2.rowTan = dRowMap2_.p; p2.tileWork = dTileWork2_.p;
       p2.gPtr = dGPtr2_.p; p2.gDst = dGDst2_.p; p2.gSrc = dGSrc2_.p; p2.rPtr = dRPtr2_.p; p2.rSrc = dRSrc2_.p;
-      p2.band = dBand_.p + bandTot + yTot; p2.Y = p2.band + L2.bandTot; p2.Sp = dSp2_.p; p2.y = p.yS;
+      p2.band = p.band + bandTot + yTot; p2.Y = p2.band + L2.bandTot; p2.Sp = dSp2_.p; p2.y = p.yS;
     }
     const size_t ldsFactor2 = (size_t)L2.maxRows * (BW2 + 2) * 8 + 2 * 1024;
     const size_t ldsBack2 = ((size_t)L2.maxRows * (BW2 + 2) + W2 * D + kPgPieceThreads) * 8;
@@ -1312,25 +1351,22 @@ class PoseGraph {
       PG_HIP_OK(hipMemcpyAsync(&hs, p.scal, sizeof(double) * PG_NSCAL + sizeof(SolverScalars), hipMemcpyDeviceToHost, s_));
       PG_HIP_OK(hipStreamSynchronize(s_));
     };
-    auto evalCost = [&](bool cand, bool withJac) {
-      if (six_) hipLaunchKernelGGL(k_pg_eval<true>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
-      else hipLaunchKernelGGL(k_pg_eval<false>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0);
-      hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
+    // residuals (+ Jacobians) at the current point or the candidate; finalReduce: the launch also sums the iteration's scalars
+    auto evaluate = [&](bool cand, bool withJac, bool finalReduce) {
+      if (six_) hipLaunchKernelGGL(k_pg_eval<true>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0, finalReduce ? gN : 0);
+      else hipLaunchKernelGGL(k_pg_eval<false>, dim3(gE), dim3(128), 0, s_, p, cand ? 1 : 0, withJac ? 1 : 0, finalReduce ? gN : 0);
     };
     // damped normal equations at the current linearisation -> y (tangent order, scaled space)
     auto solveNormalEquations = [&](double radius, int& nSolves) {
-      PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * (size_t)nS * nS, s_));
-      PG_HIP_OK(hipMemsetAsync(dSol, 0, sizeof(SolverScalars), s_));
-      if (nPieces > 0) PG_HIP_OK(hipMemsetAsync(p.band, 0, sizeof(double) * workTot, s_));
-      hipLaunchKernelGGL(k_pg_assemble_nodes, dim3(gN), dim3(128), 0, s_, p, radius);
-      if (six_) hipLaunchKernelGGL(k_pg_assemble_edges<6>, dim3(gE), dim3(128), 0, s_, p);
-      else hipLaunchKernelGGL(k_pg_assemble_edges<4>, dim3(gE), dim3(128), 0, s_, p);
+      PG_HIP_OK(hipMemsetAsync(p.HS, 0, sizeof(double) * ((size_t)nS * nS + (nPieces > 0 ? workTot : 0)), s_));   // H_S | band | Y (| level 2)
+      if (six_) hipLaunchKernelGGL(k_pg_assemble<6>, dim3(gN + gE), dim3(128), 0, s_, p, radius, gN);
+      else hipLaunchKernelGGL(k_pg_assemble<4>, dim3(gN + gE), dim3(128), 0, s_, p, radius, gN);
       if (nPieces > 0) {
         if (six_) hipLaunchKernelGGL((k_pg_piece_factor<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
         else hipLaunchKernelGGL((k_pg_piece_factor<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsFactor, s_, p);
         hipLaunchKernelGGL(k_pg_piece_schur, dim3((unsigned)tileWork.size()), dim3(256), 0, s_, p);
-        hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256), dim3(256), 0, s_, p, nDest);
-        hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p);
+        hipLaunchKernelGGL(k_pg_sep_gather, dim3((nDest * D * D + 255) / 256 + (nS + 255) / 256), dim3(256), 0, s_, p, nDest,
+                           (nDest * D * D + 255) / 256);
       }
       if (nPieces2 > 0) {
         hipLaunchKernelGGL(k_pg_l2_extract, dim3((nX * D * D + 255) / 256), dim3(256), 0, s_, p2, (const int4*)dXDst_.p,
@@ -1338,8 +1374,8 @@ class PoseGraph {
         if (six_) hipLaunchKernelGGL((k_pg_piece_factor<6, 7>), dim3(nPieces2), dim3(kPgPieceThreads), ldsFactor2, s_, p2);
         else hipLaunchKernelGGL((k_pg_piece_factor<4, 3>), dim3(nPieces2), dim3(kPgPieceThreads), ldsFactor2, s_, p2);
         hipLaunchKernelGGL(k_pg_piece_schur, dim3((unsigned)L2.tileWork.size()), dim3(256), 0, s_, p2);
-        hipLaunchKernelGGL(k_pg_sep_gather, dim3((L2.nDest * D * D + 255) / 256), dim3(256), 0, s_, p2, L2.nDest);
-        hipLaunchKernelGGL(k_pg_sep_gather_rhs, dim3((nS + 255) / 256), dim3(256), 0, s_, p2);
+        hipLaunchKernelGGL(k_pg_sep_gather, dim3((L2.nDest * D * D + 255) / 256 + (nS + 255) / 256), dim3(256), 0, s_, p2, L2.nDest,
+                           (L2.nDest * D * D + 255) / 256);
       }
       PG_HIP_OK(hipEventRecord(evA_[nSolves % kPgMaxTimed], s_));
       launchSolveReduced(dp, s_, 0.0, false, false);
@@ -1350,10 +1386,12 @@ class PoseGraph {
         else hipLaunchKernelGGL((k_pg_piece_back<4, 3>), dim3(nPieces2), dim3(kPgPieceThreads), ldsBack2, s_, p2);
       }
       if (nPieces > 0) {
-        if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 4>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
-        else hipLaunchKernelGGL((k_pg_piece_back<4, 2>), dim3(nPieces), dim3(kPgPieceThreads), ldsBack, s_, p);
+        const int nScatter = (nn + kPgPieceThreads - 1) / kPgPieceThreads;
+        if (six_) hipLaunchKernelGGL((k_pg_piece_back<6, 4>), dim3(nPieces + nScatter), dim3(kPgPieceThreads), ldsBack, s_, p);
+        else hipLaunchKernelGGL((k_pg_piece_back<4, 2>), dim3(nPieces + nScatter), dim3(kPgPieceThreads), ldsBack, s_, p);
+      } else {
+        hipLaunchKernelGGL(k_pg_scatter_sep, dim3(gN), dim3(128), 0, s_, p);
       }
-      hipLaunchKernelGGL(k_pg_scatter_sep, dim3(gN), dim3(128), 0, s_, p);
     };
     int nSolves = 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1361,7 +1399,8 @@ class PoseGraph {
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const double min_relative_decrease = 1e-3, max_radius = 1e16, min_radius = 1e-32;
     double radius = 1e4, decrease_factor = 2.0;
-    evalCost(false, true);
+    evaluate(false, true, false);
+    hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_COST, gE, 0);
     readScal();
     double x_cost = sc[PG_COST];
     summary[0] = x_cost;
@@ -1372,7 +1411,6 @@ class PoseGraph {
       if (needLinearize) {  // gradient / column norms / J^T J blocks of the current linearisation
         if (six_) hipLaunchKernelGGL(k_pg_node<6>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
         else hipLaunchKernelGGL(k_pg_node<4>, dim3(gN), dim3(128), 0, s_, p, initScale ? 1 : 0);
-        hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, s_, p, (int)PG_GRADMAX, gN, 1);
         initScale = false;
       }
       if (iteration >= maxIter_) { termination = 1; break; }
@@ -1380,12 +1418,9 @@ class PoseGraph {
       // The step is enqueued before the gradient check's scalar is back (one read-back per iteration instead of
       // three); when the gradient test fires the step is simply not used -- Ceres would not have computed it.
       solveNormalEquations(radius, nSolves);
-      if (six_) hipLaunchKernelGGL(k_pg_model<6>, dim3(gE), dim3(128), 0, s_, p);
-      else hipLaunchKernelGGL(k_pg_model<4>, dim3(gE), dim3(128), 0, s_, p);
-      hipLaunchKernelGGL(k_pg_plus, dim3(gN), dim3(128), 0, s_, p);
-      if (six_) hipLaunchKernelGGL(k_pg_eval<true>, dim3(gE), dim3(128), 0, s_, p, 1, 0);
-      else hipLaunchKernelGGL(k_pg_eval<false>, dim3(gE), dim3(128), 0, s_, p, 1, 0);
-      hipLaunchKernelGGL(k_pg_reduce_step, dim3(4), dim3(256), 0, s_, p, gE, gN);
+      if (six_) hipLaunchKernelGGL(k_pg_model_plus<6>, dim3(gE + gN), dim3(128), 0, s_, p, gE);
+      else hipLaunchKernelGGL(k_pg_model_plus<4>, dim3(gE + gN), dim3(128), 0, s_, p, gE);
+      evaluate(true, false, true);   // + the iteration's scalars (and the gradient max of this linearisation)
       readScal();
       if (freshLinearization && sc[PG_GRADMAX] <= gradient_tolerance) { termination = 0; break; }
       ++iteration;
@@ -1405,7 +1440,7 @@ class PoseGraph {
       const double rel = cost_change / model_cost_change;
       if (rel > min_relative_decrease) {
         std::swap(p.yaw, p.yawC); std::swap(p.t, p.tC); std::swap(p.q, p.qC);
-        evalCost(false, true);   // residuals + Jacobians at the accepted point (HandleSuccessfulStep)
+        evaluate(false, true, false);   // residuals + Jacobians at the accepted point (HandleSuccessfulStep)
         x_cost = cand_cost;
         radius = std::min(max_radius, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
         decrease_factor = 2.0;
@@ -1473,7 +1508,7 @@ class PoseGraph {
   static constexpr int kPgMaxTimed = 64;
   hipEvent_t evA_[kPgMaxTimed] = {}, evB_[kPgMaxTimed] = {};
   Buf<double> dYaw_, dPitch_, dRoll_, dT_, dQ_, dYawC_, dTC_, dQC_, dEt_, dEyaw_, dEpitch_, dEroll_, dEq_, dEsq_;
-  Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dBand_, dSp_;
+  Buf<double> dRes_, dJa_, dJb_, dHS_, dVec_, dChol_, dPartial_, dScal_, dNodeBlk_, dSp_;
   Buf<int> dOff_, dEa_, dEb_, dEloop_, dNodePtr_, dNodeEdge_, dSepOff_, dNodePiece_, dNodeRow_, dColSep_, dRowTan_, dGPtr_, dRPtr_;
   Buf<PgPiece> dPieces_, dPieces2_;
   Buf<int4> dEdgeDst_, dTileWork_, dGSrc_, dTileWork2_, dGSrc2_, dXDst_;
