@@ -10,8 +10,9 @@
 //   /root/reference/pose_graph/src/pose_graph/Keyframe.cpp:495-500, :576-582  loop-edge measurements
 // PARITY UNPINNED against a running reference: pose_graph has no unit tests, golden vectors or fixtures in the
 // reference, and neither pose_graph nor Ceres can be built here (Ceres / Eigen / OpenCV / ROS absent).  What pins this
-// file: central differences of the error terms through the same manifold Plus, convergence on loop-closure graphs,
-// dense vs envelope solver agreement (tests/test_oracle_posegraph.py).
+// file: central differences of the error terms through the same manifold Plus, an independent numpy restatement of
+// the problem construction + error terms + Huber (costs equal to 1e-10), scipy least_squares landing on the same
+// minimum, convergence on loop-closure graphs, dense vs envelope solver agreement (tests/test_oracle_posegraph.py).
 // The reference differentiates its error functors with ceres::AutoDiffCostFunction (exact derivatives); the
 // Jacobians below are the analytic equivalents (checked against central differences in the tests).
 // Third-party arithmetic restated from its published algorithm (Ceres Solver 2.2.0, not vendored):

@@ -104,3 +104,103 @@ def test_drift_moves_later_keyframes_and_reoptimisation_starts_from_svin_poses(s
     # a second pass over the same range starts from the SVIn poses again: identical summary
     s2 = pg.optimize(earliest, 120)
     assert s2["initial_cost"] == s1["initial_cost"] and s2["final_cost"] == s1["final_cost"]
+
+
+def _numpy_residuals(spec, upto, six, T, Q_or_yaw, earliest):
+    """Independent numpy restatement of the three error terms straight from the reference's functors
+    (FourDOFError / FourDOFWeightError PoseGraph.h:134-231, PoseGraph3dErrorTerm Pose3DError.h:103-147) and of the
+    problem construction (PoseGraph.cpp:262-332 / :436-489); loop blocks carry Huber(0.1) as sqrt(rho(s)) r / |r|."""
+    ypr0 = np.array([spg.R2ypr(spg.q2R(q)) for q in spec.q_svin[:upto]])
+    blocks = []
+
+    def huber(r):
+        s = float(r @ r)
+        if s <= 0.01:
+            return r
+        return r * np.sqrt(2 * 0.1 * np.sqrt(s) - 0.01) / np.sqrt(s)
+
+    def qmul(a, b):
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+    def conj(q):
+        return np.array([-q[0], -q[1], -q[2], q[3]])
+
+    for i in range(earliest, upto):
+        nseq = 4 if six else 2
+        for j in range(1, nseq + 1):
+            a = i - j
+            if a < earliest or spec.sequence[a] != spec.sequence[i]:
+                continue
+            Ra0 = spg.q2R(spec.q_svin[a])
+            t_meas = Ra0.T @ (spec.t_svin[i] - spec.t_svin[a])
+            if not six:
+                Ra = spg.ypr2R([Q_or_yaw[a], ypr0[a, 1], ypr0[a, 2]])
+                r = np.zeros(4)
+                r[:3] = Ra.T @ (T[i] - T[a]) - t_meas
+                d = Q_or_yaw[i] - Q_or_yaw[a] - (ypr0[i, 0] - ypr0[a, 0])
+                r[3] = d - 360 if d > 180 else (d + 360 if d < -180 else d)
+                blocks.append(r)
+            else:
+                q_meas = qmul(conj(spec.q_svin[a]), spec.q_svin[i])
+                qa, qb = Q_or_yaw[a], Q_or_yaw[i]
+                p_ab = spg.q2R(qa).T @ (T[i] - T[a])
+                dq = qmul(q_meas, conj(qmul(conj(qa), qb)))
+                r = np.concatenate([p_ab - t_meas, 2 * dq[:3]]) * np.array([20, 20, 20, 100, 100, 57.3])
+                blocks.append(r)
+        if i in spec.loops and spec.loops[i][0] >= earliest:
+            a, rt, rq, ryaw = spec.loops[i]
+            if not six:
+                Ra = spg.ypr2R([Q_or_yaw[a], ypr0[a, 1], ypr0[a, 2]])
+                r = np.zeros(4)
+                r[:3] = Ra.T @ (T[i] - T[a]) - rt
+                d = Q_or_yaw[i] - Q_or_yaw[a] - ryaw
+                r[3] = (d - 360 if d > 180 else (d + 360 if d < -180 else d)) / 10.0
+            else:
+                qa, qb = Q_or_yaw[a], Q_or_yaw[i]
+                p_ab = spg.q2R(qa).T @ (T[i] - T[a])
+                dq = qmul(rq, conj(qmul(conj(qa), qb)))
+                r = np.concatenate([p_ab - rt, 2 * dq[:3]]) * np.array([20, 20, 20, 100, 100, 100.0])
+            blocks.append(huber(r))
+    return np.concatenate(blocks)
+
+
+@pytest.mark.parametrize("six", [False, True])
+def test_cost_matches_an_independent_numpy_restatement(six):
+    spec = spg.make_pose_graph(n=80, laps=2, loop_every=8, seed=23)
+    pg = orc.OraclePoseGraph(six_dof=six)
+    earliest, cur = spg.feed(pg, spec)
+    pg.build(earliest, cur)
+    yaw0 = np.array([spg.R2ypr(spg.q2R(q))[0] for q in spec.q_svin])
+    f = _numpy_residuals(spec, spec.n, six, spec.t_svin, spec.q_svin if six else yaw0, earliest)
+    assert abs(0.5 * f @ f - pg.cost()) <= 1e-10 * max(1.0, pg.cost())
+
+
+def test_converged_4dof_solution_is_the_minimum_scipy_finds():
+    """fixed-point parity of the Levenberg-Marquardt restatement: run to convergence, it must land on the minimum an
+    independent solver (scipy least_squares on the numpy restatement above) finds from the same start"""
+    from scipy.optimize import least_squares
+    spec = spg.make_pose_graph(n=60, laps=2, loop_every=6, seed=29)
+    pg = orc.OraclePoseGraph(six_dof=False, max_iterations=200)
+    earliest, cur = spg.feed(pg, spec)
+    s = pg.optimize(earliest, cur)
+    T, _ = pg.poses()
+    n = spec.n
+    yaw0 = np.array([spg.R2ypr(spg.q2R(q))[0] for q in spec.q_svin])
+    free = np.arange(earliest + 1, n)
+
+    def fun(x):
+        yaw, t = yaw0.copy(), spec.t_svin.copy()
+        yaw[free] = x[:len(free)]
+        t[free] = x[len(free):].reshape(-1, 3)
+        return _numpy_residuals(spec, n, False, t, yaw, earliest)
+
+    x0 = np.concatenate([yaw0[free], spec.t_svin[free].ravel()])
+    sol = least_squares(fun, x0, method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=400)
+    print("oracle final cost", s["final_cost"], "iterations", s["iterations"], "scipy cost", sol.cost)
+    assert abs(s["final_cost"] - sol.cost) <= 2e-5 * max(sol.cost, 1e-12)
+    t_scipy = spec.t_svin.copy()
+    t_scipy[free] = sol.x[len(free):].reshape(-1, 3)
+    assert np.max(np.abs(T - t_scipy)) < 2e-3
