@@ -27,12 +27,15 @@ for six in (False, True):
             t1 = time.time()
             s = g.optimize(earliest, cur)
             wall = time.time() - t1
+            t1 = time.time()
+            g.optimize(earliest, cur)   # same object again: buffers are allocated, the problem is rebuilt from the SVIn poses
+            wall2 = time.time() - t1
             if best is None or s["solve_seconds"] < best[0]["solve_seconds"]:
-                best = (s, wall, g.partition())
-        s, wall, part = best
-        print("%s piece %d: %d iterations, device %.3f ms (%.3f ms / iteration), call wall %.3f ms, cost %.4g -> %.4g, %s"
+                best = (s, wall, g.partition(), wall2)
+        s, wall, part, wall2 = best
+        print("%s piece %d: %d iterations, device %.3f ms (%.3f ms / iteration), call wall %.3f ms (repeat call on the same handle %.3f ms), cost %.4g -> %.4g, %s"
               % ("6dof" if six else "4dof", piece, s["iterations"], 1e3 * s["solve_seconds"],
-                 1e3 * s["solve_seconds"] / max(1, s["iterations"]), 1e3 * wall, s["initial_cost"], s["final_cost"], part), flush=True)
+                 1e3 * s["solve_seconds"] / max(1, s["iterations"]), 1e3 * wall, 1e3 * wall2, s["initial_cost"], s["final_cost"], part), flush=True)
     if "--no-oracle" not in sys.argv:
         from oracle import orc
         c = orc.OraclePoseGraph(six_dof=six, envelope=True)
