@@ -30,9 +30,12 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace svin {
@@ -791,6 +794,7 @@ struct Keyframe {
   int index = 0, sequence = 0;
   double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1};   // Keyframe::getSVInPose: the optimisation's input, never modified
   double P[3] = {0, 0, 0}, Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // Keyframe::getPose (updatePose)
+  double ypr[3] = {0, 0, 0}, Rs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // R2ypr / rotation matrix of the SVIn pose (cached at add time)
   bool hasLoop = false;
   int loopIndex = -1;
   double loopT[3] = {0, 0, 0}, loopQ[4] = {0, 0, 0, 1}, loopYaw = 0;
@@ -895,8 +899,7 @@ class PoseGraph {
 
   // addKeyframe's pose update (PoseGraph.cpp:127-132): pose = drift * SVIn pose
   void applyDrift(Keyframe& kf) const {
-    double R[9];
-    hostQ2R(kf.q, R);
+    const double* R = kf.Rs;
     for (int r = 0; r < 3; ++r) {
       kf.P[r] = rDrift[3 * r] * kf.t[0] + rDrift[3 * r + 1] * kf.t[1] + rDrift[3 * r + 2] * kf.t[2] + tDrift[r];
       for (int c = 0; c < 3; ++c) kf.Rp[3 * r + c] = rDrift[3 * r] * R[c] + rDrift[3 * r + 1] * R[3 + c] + rDrift[3 * r + 2] * R[6 + c];
@@ -904,19 +907,22 @@ class PoseGraph {
   }
 
   int optimize(int earliest, int cur) {
+    const auto tCall0 = std::chrono::steady_clock::now();
     // ---- local problem (PoseGraph.cpp:262-332 / :436-489)
     std::vector<double> yaw, pitch, roll, t, q;
     std::vector<int> off, ea, eb, eloop, seq, localOf(kfs.size(), -1), kfOfLocal;
     std::vector<char> fixed;
     std::vector<double> et, eyaw, epitch, eroll, eq, esq;
+    std::unordered_map<int, size_t> posOfIndex;
+    posOfIndex.reserve(kfs.size() * 2);
+    for (size_t k = 0; k < kfs.size(); ++k) posOfIndex[kfs[k].index] = k;
     int i = 0;
     for (size_t k = 0; k < kfs.size(); ++k) {
       const Keyframe& kf = kfs[k];
       if (kf.index < earliest) continue;
       localOf[k] = i;
       kfOfLocal.push_back((int)k);
-      double ypr[3];
-      hostR2ypr(kf.q, ypr);
+      const double* ypr = kf.ypr;
       yaw.push_back(ypr[0]); pitch.push_back(ypr[1]); roll.push_back(ypr[2]);
       t.insert(t.end(), kf.t, kf.t + 3);
       q.insert(q.end(), kf.q, kf.q + 4);
@@ -926,8 +932,7 @@ class PoseGraph {
       for (int j = 1; j <= nSeq; ++j) {
         if (i - j >= 0 && seq[i] == seq[i - j]) {
           const double* qa = &q[4 * (i - j)];
-          double Ra[9];
-          hostQ2R(qa, Ra);
+          const double* Ra = kfs[kfOfLocal[i - j]].Rs;
           const double d[3] = {t[3 * i] - t[3 * (i - j)], t[3 * i + 1] - t[3 * (i - j) + 1], t[3 * i + 2] - t[3 * (i - j) + 2]};
           for (int c = 0; c < 3; ++c) et.push_back(Ra[c] * d[0] + Ra[3 + c] * d[1] + Ra[6 + c] * d[2]);
           ea.push_back(i - j); eb.push_back(i); eloop.push_back(0);
@@ -942,9 +947,9 @@ class PoseGraph {
         }
       }
       if (kf.hasLoop) {
-        int ci = -1;
-        for (size_t kk = 0; kk < kfs.size(); ++kk)
-          if (kfs[kk].index == kf.loopIndex) ci = localOf[kk];
+        int ci = -1;   // getKeyframe(loop_index)->local_index: the last keyframe of the list with that index
+        const auto lit = posOfIndex.find(kf.loopIndex);
+        if (lit != posOfIndex.end()) ci = localOf[lit->second];
         if (ci >= 0) {
           ea.push_back(ci); eb.push_back(i); eloop.push_back(1);
           et.insert(et.end(), kf.loopT, kf.loopT + 3);
@@ -1465,7 +1470,14 @@ class PoseGraph {
     PG_HIP_OK(hipMemcpy(hy.data(), p.yaw, sizeof(double) * nn, hipMemcpyDeviceToHost));
     PG_HIP_OK(hipMemcpy(ht.data(), p.t, sizeof(double) * 3 * nn, hipMemcpyDeviceToHost));
     PG_HIP_OK(hipMemcpy(hq.data(), p.q, sizeof(double) * 4 * nn, hipMemcpyDeviceToHost));
+    const auto tWb0 = std::chrono::steady_clock::now();
     writeBack(hy, pitch, roll, ht, hq, kfOfLocal, cur);
+    if (std::getenv("SVIN_PG_TIMING")) {
+      auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return 1e3 * std::chrono::duration<double>(b - a).count(); };
+      const auto tEnd = std::chrono::steady_clock::now();
+      std::printf("[pg] problem construction %.3f ms, symbolic %.3f ms, upload + setup %.3f ms, LM loop %.3f ms, download %.3f ms, write back %.3f ms\n",
+                  sec(tCall0, tSym0), 1e3 * summary[6], sec(tSym0, t0) - 1e3 * summary[6], 1e3 * summary[5], sec(t0, tWb0) - 1e3 * summary[5], sec(tWb0, tEnd));
+    }
     return 1;
   }
 
@@ -1486,8 +1498,7 @@ class PoseGraph {
     }
     if (nn == 0 || kfs[kfOfLocal[nn - 1]].index != cur) return;
     const Keyframe& ck = kfs[kfOfLocal[nn - 1]];
-    double Rs[9];
-    hostQ2R(ck.q, Rs);
+    const double* Rs = ck.Rs;
     if (!six_) {
       yawDrift = hostYawOfR(ck.Rp) - hostYawOfR(Rs);
       hostYpr2R(yawDrift, 0, 0, rDrift);
@@ -1551,6 +1562,8 @@ int svin_pg_add_keyframe(svin_pg* h, int index, int sequence, const double* t, c
     std::memcpy(kf.loopQ, loop_rel_q, sizeof(kf.loopQ));
     kf.loopYaw = loop_rel_yaw_deg;
   }
+  svin::pg::hostR2ypr(kf.q, kf.ypr);
+  svin::pg::hostQ2R(kf.q, kf.Rs);
   h->g.applyDrift(kf);
   h->g.kfs.push_back(kf);
   return 1;
