@@ -70,30 +70,52 @@ __device__ __forceinline__ bool lastBlockDone(unsigned int* ticket, int* flagLds
   return last;
 }
 
+// The same ticket without the L2 write-back: for kernels whose blocks hand ONLY values written with cstore() (agent-
+// scope relaxed atomics: sc1, coherent by themselves) to the last block, which reads them with cload().  A plain
+// __threadfence() makes every block write back its XCD's dirty L2 lines -- megabytes of Jacobians right after K1.
+__device__ __forceinline__ void cstore(double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double cload(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool lastBlockDoneLight(unsigned int* ticket, int* flagLds) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's cstore()s have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int tk = atomicAdd(ticket, 1u);
+    *flagLds = (tk == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  return *flagLds != 0;
+}
+
 // total cost = reprojection partials (nA blocks) + factor partials (nB) + prior, into SolverScalars (whole block)
 __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) {
   const int t = threadIdx.x;
   auto sumSlot = [&](int slot, int n) {
     double s = 0;
-    for (int i = t; i < n; i += blockDim.x) s += p.partial[(size_t)slot * kMaxPartials + i];
+    for (int i = t; i < n; i += blockDim.x) s += cload(p.partial + (size_t)slot * kMaxPartials + i);
     return blockSum(s, red);
   };
   const double a = sumSlot(PS_COST_REPROJ, nA);
   const double b = sumSlot(PS_COST_FACTORS, nB);
   if (t == 0) {
     const double bf = p.ownsCamera ? b : 0.0;
-    const double pr = (p.ownsCamera && p.priorM > 0) ? p.scal->costPrior : 0.0;
+    const double pr = (p.ownsCamera && p.priorM > 0) ? cload(&p.scal->costPrior) : 0.0;
     p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
     p.scal->cost = a + bf + pr;
-    if (p.mailbox) {
-      // publish everything the host needs for its accept/reject decision; the sequence number goes last
-      const double* src = reinterpret_cast<const double*>(p.scal);
-      volatile double* dst = reinterpret_cast<volatile double*>(&p.mailbox->scal);
-      for (int k = 0; k < (int)(sizeof(SolverScalars) / sizeof(double)); ++k) dst[k] = src[k];
-      __threadfence_system();
-      *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
-      __threadfence_system();
+  }
+  if (p.mailbox) {
+    // publish everything the host needs for its accept/reject decision: the scalars as ONE wave-wide store to the
+    // pinned host page (25 serial stores + two system fences cost ~18 us of every iteration), then the sequence number
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // thread 0's stores above are in L2 (this block re-reads them with sc1 loads)
+    __syncthreads();
+    constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
+    static_assert(nD <= 64, "SolverScalars must fit one wave-wide store");
+    if (t < nD) {
+      const double v = __hip_atomic_load(reinterpret_cast<const double*>(p.scal) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      reinterpret_cast<volatile double*>(&p.mailbox->scal)[t] = v;
     }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
   }
 }
 
@@ -280,7 +302,7 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
   }
   if (costPartial) {
     const double bs = blockSum(cost, red);
-    if (threadIdx.x == 0) costPartial[block] = bs;
+    if (threadIdx.x == 0) cstore(costPartial + block, bs);
   }
 }
 
@@ -459,7 +481,7 @@ __device__ __forceinline__ void negCrossDesc(int i, int j, int& comp, double& si
 }
 
 #ifdef SVIN_IMU_TIMING
-__device__ double g_imuDbg[8];
+__device__ double g_imuDbg[16];
 #define IMU_TICK(var) long long var = __builtin_readcyclecounter()
 #define IMU_ACC(slot, a, b, cond) if (cond) atomicAdd(&g_imuDbg[slot], (double)((b) - (a)))
 #else
@@ -888,8 +910,8 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
 }
 #ifdef SVIN_IMU_TIMING
 void debugImuTiming(double* out, bool reset) {
-  if (reset) { double z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_imuDbg), z, sizeof(z)); return; }
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_imuDbg), 64);
+  if (reset) { double z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_imuDbg), z, sizeof(z)); return; }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_imuDbg), 128);
 }
 #endif
 
@@ -988,6 +1010,7 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
   int ncols = 0;
   for (int b = 0; b < fac.nblk; ++b) ncols += (fac.blkKind[b] == B_SB) ? 9 : 6;
 
+  IMU_TICK(qe0);
   if (fac.kind == F_IMU) {
     DevImu& im = p.imus[fac.imuIndex];
     const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
@@ -1016,6 +1039,8 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
     if (t >= 80 && t < 87) sh.xs[16 + t - 80] = x1[t - 80];
     if (t >= 87 && t < 96) sh.xs[23 + t - 87] = s1[t - 87];
     __syncthreads();
+    IMU_TICK(qe1);
+    IMU_ACC(8, qe0, qe1, t == 0 && !redo);
     if (t == 0) {
       // ImuError.cpp:751-791
       const double* x0 = sh.xs;
@@ -1103,6 +1128,9 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
       const Quat qd = qmul(Dq, qmul(q1inv, T0.q));
       sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
       for (int k = 0; k < 6; ++k) sh.e[9 + k] = s0[3 + k] - s1[3 + k];
+      IMU_TICK(qe2);
+      IMU_ACC(9, qe1, qe2, !redo);
+      IMU_ACC(11, qe1, qe1 + 1, !redo);
     }
   } else if (t == 0) {
     for (int k = 0; k < m * m; ++k) sh.W[k] = fac.sqrtInfo[k];
@@ -1181,8 +1209,10 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
   if (t == 0) {
     double c = 0;
     for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
-    p.partial[(size_t)PS_COST_FACTORS * kMaxPartials + f] = 0.5 * c;
+    cstore(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + f, 0.5 * c);
   }
+  IMU_TICK(qe3);
+  IMU_ACC(10, qe0, qe3, t == 0 && fac.kind == F_IMU);
 }
 
 __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand, int costBlocksA) {
@@ -1259,7 +1289,7 @@ __device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
     c += priorDchi[i] * (p.priorBp[i] + 0.5 * s);
   }
   const double tot = blockSum(c, red);
-  if (t == 0) p.scal->costPrior = 0.5 * (*p.priorC0) + tot;
+  if (t == 0) cstore(&p.scal->costPrior, 0.5 * (*p.priorC0) + tot);
 }
 __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
   __shared__ double red[4];
@@ -1299,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
   if (sumCost) {
     __shared__ int lastFlag;
     __shared__ double red4[4];
-    if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
+    if (lastBlockDoneLight(&p.tickets[TK_EVAL], &lastFlag)) {   // (cost partials and costPrior are cstore()d)
       reduceCost(p, nR, F, red4);
       if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
     }

@@ -1221,9 +1221,34 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
       launchEvalFactors(prob_, false, stream_);
       HIP_OK(hipStreamSynchronize(stream_));
     }
-    double dbg[8];
+    double dbg[16];
     debugImuTiming(dbg, false);
     const double n = 9.0 * reps;
+    {  // the evaluation without re-integration (most iterations)
+      debugImuTiming(nullptr, true);
+      for (int i = 0; i < reps; ++i) { launchEvalFactors(prob_, false, stream_); HIP_OK(hipStreamSynchronize(stream_)); }
+      double d2[16];
+      debugImuTiming(d2, false);
+      std::printf("[imu eval cycles, no redo] factors counted %.0f: staging %.0f, serial F/e block %.0f, whole block %.0f\n", d2[11],
+                  d2[8] / d2[11], d2[9] / d2[11], d2[10] / d2[11]);
+      hipEvent_t a, b;
+      HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+      for (int variant = 0; variant < 3; ++variant) {
+        float tot = 0;
+        for (int i = 0; i < 20; ++i) {
+          HIP_OK(hipEventRecord(a, stream_));
+          if (variant == 0) evaluateAll(false, stream_);
+          else if (variant == 1) launchEvalFactors(prob_, false, stream_);
+          else launchEvalAll(prob_, false, false, stream_);
+          HIP_OK(hipEventRecord(b, stream_));
+          HIP_OK(hipEventSynchronize(b));
+          float ms = 0;
+          HIP_OK(hipEventElapsedTime(&ms, a, b));
+          tot += ms;
+        }
+        std::printf("[eval timing, no redo] %s: %.2f us\n", variant == 0 ? "evaluateAll (fused, cost summed)" : variant == 1 ? "factors only" : "fused, no cost sum", 1e3 * tot / 20);
+      }
+    }
     std::printf("[imu redo cycles] P0 %.0f P1dq %.0f P1cross %.0f P2 %.0f P3 %.0f cov %.0f integrate %.0f post %.0f\n", dbg[0] / n,
                 dbg[1] / n, dbg[6] / n, dbg[7] / n, dbg[5] / n, dbg[2] / n, dbg[3] / n, dbg[4] / n);
   }
