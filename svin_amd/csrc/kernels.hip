@@ -3478,12 +3478,12 @@ __global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double ra
   double acc[2] = {0, 0};  // |x - x_cand|^2, |x|^2
   retractItem(p, i, c.cg, c.cn, acc);
   const double mine = blockSumK<2>(acc, red, -1);
-  if (threadIdx.x < 2) p.partial[(size_t)(threadIdx.x == 0 ? PS_STEP : PS_XNORM) * kMaxPartials + blockIdx.x] = mine;
-  if (!lastBlockDone(&p.tickets[TK_STEP], &lastFlag)) return;
+  if (threadIdx.x < 2) cstore(p.partial + (size_t)(threadIdx.x == 0 ? PS_STEP : PS_XNORM) * kMaxPartials + blockIdx.x, mine);
+  if (!lastBlockDoneLight(&p.tickets[TK_STEP], &lastFlag)) return;
   for (int k = 0; k < 2; ++k) {
     double s = 0;
     const double* src = p.partial + (size_t)(k == 0 ? PS_STEP : PS_XNORM) * kMaxPartials;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) s += src[j];
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += blockDim.x) s += cload(src + j);
     acc[k] = s;
   }
   const double tot = blockSumK<2>(acc, red, -1);
@@ -3571,8 +3571,8 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
       const double h0 = p.hL[3 * l], h1 = p.hL[3 * l + 1], h2 = p.hL[3 * l + 2];
       const double v0 = g0 / h0, v1 = g1 / h1, v2 = g2 / h2;
       if (gl == 0) {
-        p.yL[3 * l] = y0; p.yL[3 * l + 1] = y1; p.yL[3 * l + 2] = y2;
-        p.vL[3 * l] = v0; p.vL[3 * l + 1] = v1; p.vL[3 * l + 2] = v2;
+        cstore(p.yL + 3 * l, y0); cstore(p.yL + 3 * l + 1, y1); cstore(p.yL + 3 * l + 2, y2);   // read by the last block's fused step
+        cstore(p.vL + 3 * l, v0); cstore(p.vL + 3 * l + 1, v1); cstore(p.vL + 3 * l + 2, v2);
         acc[5] += g0 * g0 / h0 + g1 * g1 / h1 + g2 * g2 / h2;
         acc[6] += h0 * y0 * y0 + h1 * y1 * y1 + h2 * y2 * y2;
         acc[7] += -(g0 * y0 + g1 * y1 + g2 * y2);
@@ -3662,14 +3662,14 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     }
   }
   const double mine = blockSumK<kPostK>(acc, red, 8);
-  if (t < kPostK) p.partial[(size_t)kPostSlot[t] * kMaxPartials + b] = mine;
-  if (!lastBlockDone(&p.tickets[TK_POST], &lastFlag)) return;
+  if (t < kPostK) cstore(p.partial + (size_t)kPostSlot[t] * kMaxPartials + b, mine);
+  if (!lastBlockDoneLight(&p.tickets[TK_POST], &lastFlag)) return;   // partials, y_l and v_l are cstore()d
   // final reduction over the blocks, fixed order: thread k-strided per slot
 #pragma unroll
   for (int k = 0; k < kPostK; ++k) {
     double s = 0;
     const double* src = p.partial + (size_t)kPostSlot[k] * kMaxPartials;
-    for (int i = t; i < (int)gridDim.x; i += blockDim.x) s = (k == 8) ? fmax(s, src[i]) : s + src[i];
+    for (int i = t; i < (int)gridDim.x; i += blockDim.x) { const double x = cload(src + i); s = (k == 8) ? fmax(s, x) : s + x; }
     acc[k] = s;
   }
   const double tot = blockSumK<kPostK>(acc, red, 8);
@@ -3702,7 +3702,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
         x[u][0] = xx.x; x[u][1] = xx.y; x[u][2] = xx.z; x[u][3] = xx.w;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v[u][k] = p.vL[3 * l + k]; y[u][k] = p.yL[3 * l + k]; }
+        for (int k = 0; k < 3; ++k) { v[u][k] = cload(p.vL + 3 * l + k); y[u][k] = cload(p.yL + 3 * l + k); }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
