@@ -3692,12 +3692,13 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     double a2[2] = {0, 0};
     const int nBlkItems = p.nPose + p.nExt + p.nSb;
     for (int i = t; i < nBlkItems; i += blockDim.x) retractItem(p, i, c.cg, c.cn, a2);
-    // landmarks: four per thread per round with all loads issued before the first store (one memory latency per
+    // landmarks: eight per thread per round with all loads issued before the first store (one memory latency per
     // round instead of one per landmark)
-    for (int l0 = 0; l0 < p.L; l0 += 4 * (int)blockDim.x) {
-      double x[4][4], v[4][3], y[4][3];
+    constexpr int kPer = 8;
+    for (int l0 = 0; l0 < p.L; l0 += kPer * (int)blockDim.x) {
+      double x[kPer][4], v[kPer][3], y[kPer][3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kPer; ++u) {
         const int l = min(l0 + u * (int)blockDim.x + t, p.L - 1);
         const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
         x[u][0] = xx.x; x[u][1] = xx.y; x[u][2] = xx.z; x[u][3] = xx.w;
@@ -3705,7 +3706,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         for (int k = 0; k < 3; ++k) { v[u][k] = cload(p.vL + 3 * l + k); y[u][k] = cload(p.yL + 3 * l + k); }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kPer; ++u) {
         const int l = l0 + u * (int)blockDim.x + t;
         if (l < p.L) {
           double xo[4];

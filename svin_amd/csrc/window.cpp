@@ -888,7 +888,8 @@ void Window::solve(size_t numIter, bool verbose) {
   double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..17] max group
   // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
   // retracts the whole window quickly enough
-  const bool fuseStep = world_ <= 1 && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
+  static const bool noFuseStep = getenv("SVIN_NO_FUSE_STEP") != nullptr;   // A/B switch for profiling
+  const bool fuseStep = !noFuseStep && world_ <= 1 && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
   evaluateAll(false, s);
   AR(scalD, 4, 0);
   SolverScalars sc = readScalars();
