@@ -913,6 +913,15 @@ void Window::solve(size_t numIter, bool verbose) {
     summary_.final_cost = x_cost;
     summary_.iterations = iteration;
   };
+  // Speculative build (single GPU): most steps are accepted, and the host needs ~7 us from the mailbox to the first
+  // launch of the next iteration.  Right behind the candidate evaluation the normal equations of the NEXT iteration
+  // are enqueued on the candidate's linearisation (the sets an accepted step swaps in) with the damping an accepted
+  // step gets; on acceptance they are simply kept, otherwise the accumulators are re-zeroed before the next build.
+  static const bool noSpeculation = getenv("SVIN_NO_SPECULATION") != nullptr;
+  const bool speculate = !noSpeculation && world_ <= 1;
+  bool accumulatorsClean = true;   // S / gRed / hC zero (pack() or k_post_solve), nothing speculative in them
+  bool specValid = false;          // the accumulators hold the build of the candidate with damping specMu
+  double specMu = 0;
   while (true) {
     if (timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) { finish(2); break; }
     if (iteration >= (int)numIter) { finish(1); break; }
@@ -922,19 +931,34 @@ void Window::solve(size_t numIter, bool verbose) {
     bool stepOk = true;
     while (true) {
       if (!reuse) {
-        launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/false);  // pack() / k_post_solve cleared them
+        if (!(specValid && specMu == mu && !initScale))
+          launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/!accumulatorsClean);  // pack() / k_post_solve cleared them
+        specValid = false;
         AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
         launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
         launchDoglegPrepare(p, s, fuseStep ? radius : -1.0);
+        accumulatorsClean = true;
         AR(scalD + kScalGroupB, 8, 0);
         AR(scalD + kScalGroupMax, 2, 1);
       }
       if (reuse || !fuseStep) launchDoglegStep(p, radius, s);
       evaluateAll(true, s);
+      if (speculate && accumulatorsClean && iteration < (int)numIter) {
+        DeviceProblem q = p;   // the problem as it looks after an accepted step
+        std::swap(q.pose, q.poseC); std::swap(q.ext, q.extC); std::swap(q.sb, q.sbC); std::swap(q.lm, q.lmC);
+        std::swap(q.rCur, q.rCand); std::swap(q.JpCur, q.JpCand); std::swap(q.JlCur, q.JlCand); std::swap(q.JeCur, q.JeCand);
+        std::swap(q.linCur, q.linCand);
+        std::swap(q.priorDchi, q.priorDchiC); std::swap(q.priorGrad, q.priorGradC); std::swap(q.priorM3, q.priorM3C);
+        specMu = std::max(min_mu, 2.0 * mu / mu_increase);
+        launchAccumulateNormalEquations(q, specMu, false, s, /*zeroFirst=*/false);
+        accumulatorsClean = false;
+        specValid = true;
+      }
       AR(scalD, 8, 0);
       sc = readScalars();
       sc.cholFail = sc.failMax != 0.0 ? 1 : 0;  // the device flag itself is re-armed by k_post_solve
       if (!reuse && sc.cholFail) {
+        specValid = false;   // (its damping assumed an accepted step)
         mu *= mu_increase;
         if (mu < max_mu) continue;
         stepOk = false;
@@ -948,6 +972,7 @@ void Window::solve(size_t numIter, bool verbose) {
       if (++invalid >= 5) { finish(3); break; }
       mu *= mu_increase;
       reuse = false;
+      specValid = false;
       lastIterTime = nowSec() - tIter;
       continue;
     }
@@ -970,6 +995,7 @@ void Window::solve(size_t numIter, bool verbose) {
     } else {
       radius *= 0.5;
       reuse = true;
+      specValid = false;   // rejected: the speculative build is discarded (accumulators are re-zeroed before the next one)
     }
     if (verbose)
       std::printf("[svin_ba] it %d cost %.9e rel_dec %.3e radius %.3e step %.3e\n", iteration, x_cost, relative_decrease,
