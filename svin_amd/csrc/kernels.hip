@@ -13,8 +13,24 @@
 #include "kernels.hpp"
 
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace svin {
+
+// hipFuncSetAttribute once per kernel and size (it is a driver call: ~2 us on the host path of every launch otherwise)
+static void ensureDynamicLds(const void* fn, size_t bytes) {
+  static std::mutex mtx;
+  static std::unordered_map<unsigned long long, size_t> granted;   // (device, kernel) -> bytes
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(fn) * 64ull + (unsigned long long)dev;
+  std::lock_guard<std::mutex> lock(mtx);
+  auto it = granted.find(key);
+  if (it != granted.end() && it->second >= bytes) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  granted[key] = bytes;
+}
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
@@ -2276,8 +2292,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     const dim3 grid(p.nSlabs + nFac + nPri);
 #define LAUNCH(MAXT, E)                                                                                             \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_schur_dense<MAXT, E>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                              (int)ldsBytes);                                                                       \
+    ensureDynamicLds((const void*)k_schur_dense<MAXT, E>, ldsBytes); \
     hipLaunchKernelGGL((k_schur_dense<MAXT, E>), grid, dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs, \
                        nFac);                                                                                       \
   } while (0)
@@ -2287,7 +2302,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
 #undef LAUNCH
   } else if (p.L > 0 && p.N > 0 && dC > 0 && p.schurPanels) {
     const size_t ldsBytes = ((size_t)2 * kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc + kDenseK) * 8;
-    (void)hipFuncSetAttribute((const void*)k_schur_panels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    ensureDynamicLds((const void*)k_schur_panels, ldsBytes);
     hipLaunchKernelGGL(k_schur_panels, dim3(p.nPanelBlocks + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0,
                        p.nPanelBlocks, nFac);
     hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 255) / 256, p.nPanelPairs), dim3(256), 0, s, p);
@@ -2300,8 +2315,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       const int grid = p.nSlabs;
 #define LAUNCH(E)                                                                                                   \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_schur<true, E>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
-                              (int)(accBytes + stageBytes));                                                        \
+    ensureDynamicLds((const void*)k_schur<true, E>, accBytes + stageBytes);                                        \
     hipLaunchKernelGGL((k_schur<true, E>), dim3(grid + nFac + nPri), dim3(256), accBytes + stageBytes, s, p, mu,   \
                        initScale ? 1 : 0, grid, nFac);                                                              \
   } while (0)
@@ -2313,8 +2327,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       DeviceProblem q = p;
 #define LAUNCH(E)                                                                                                   \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)k_schur<false, E>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                              (int)stageBytes);                                                                     \
+    ensureDynamicLds((const void*)k_schur<false, E>, stageBytes); \
     hipLaunchKernelGGL((k_schur<false, E>), dim3(grid + nFac + nPri), dim3(256), stageBytes, s, q, mu,             \
                        initScale ? 1 : 0, grid, nFac);                                                              \
   } while (0)
@@ -3336,7 +3349,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
   const int nT = dpad / 16;
   const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 2 * dpad) * 8;
   if (ldsBytes <= 156 * 1024) {
-    (void)hipFuncSetAttribute((const void*)k_chol_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
                        fuseFinalize ? 1 : 0);
   } else {
@@ -3346,8 +3359,8 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     double* dinvG = p.cholL + (size_t)(dp + kNB) * dp;
     double* diagF = dinvG + dp;   // per panel the factorised 64x64 diagonal block (dp x 64)
     const size_t ldsPanel = ((size_t)2 * kBigBlockLds + kNB) * 8, ldsSyrk = (size_t)2 * kBigBlockLds * 8;
-    (void)hipFuncSetAttribute((const void*)k_big_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsPanel);
-    (void)hipFuncSetAttribute((const void*)k_big_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSyrk);
+    ensureDynamicLds((const void*)k_big_panel, ldsPanel);
+    ensureDynamicLds((const void*)k_big_syrk, ldsSyrk);
     const int nb = dp / kNB;
     int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 1) x nb block flags
     static const bool perPanelLaunches = std::getenv("SVIN_BIG_CHOL_LAUNCHES") != nullptr;
@@ -3356,7 +3369,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     static const bool plainTasks = std::getenv("SVIN_BIG_CHOL_TASKS") != nullptr;
     if (!perPanelLaunches && !plainTasks) {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
-      (void)hipFuncSetAttribute((const void*)k_big_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
+      ensureDynamicLds((const void*)k_big_chol_chain, ldsTasks);
       int nHelperTasks = 0;
       for (int st = 0; st < nb; ++st) nHelperTasks += std::max(nb - st - 1, 0) + ((st + 2 <= nb - 1) ? 2 : 0);
       hipLaunchKernelGGL(k_big_chol_chain,
@@ -3365,7 +3378,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
                          dinvG, diagF, ready);
     } else if (!perPanelLaunches) {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
-      (void)hipFuncSetAttribute((const void*)k_big_chol_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTasks);
+      ensureDynamicLds((const void*)k_big_chol_tasks, ldsTasks);
       const int nTasks = nb * (nb + 1) / 2 + nb;
       hipLaunchKernelGGL(k_big_chol_tasks, dim3(std::min(nTasks, kPersistMaxGrid)), dim3(256), ldsTasks, s, p, dp, dinvG, diagF,
                          ready);
