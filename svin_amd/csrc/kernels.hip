@@ -5,7 +5,8 @@
 // K3  k_prior_*          marginalisation prior in H-space
 // K5  k_schur            per-landmark V/b, wave-reduced; pairwise Schur blocks accumulated in LDS-private
 //                        copies of the reduced camera matrix, flushed as slabs and reduced deterministically
-// K6  k_chol_solve       blocked Cholesky of the reduced system, trailing update on v_mfma_f64_16x16x4_f64
+// K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS, trailing update on v_mfma_f64_16x16x4_f64
+//     k_big_chol_chain   (d > 176) one-launch tile Cholesky over many workgroups + super-panel backward substitution
 // K7  k_backsub / k_dogleg_step / k_retract
 // K8  cost reductions    per-block partials + single-block final reduce (deterministic)
 // K9  k_landmark_quality
@@ -2348,162 +2349,8 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
 }
 
 // ================================================================ K6: reduced system solve
-// Single workgroup, 1024 threads (16 waves).  Right-looking blocked Cholesky with 16-wide panels; the
-// symmetric rank-16 trailing update runs on v_mfma_f64_16x16x4_f64 (A/B: one f64 per lane,
-// A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)+4*reg).  The matrix is padded to a
-// multiple of 16 with an identity tail so that every tile is full.
-
-// 16x16 in-LDS Cholesky executed by ONE wave (lanes 0..63), wave-level synchronisation only.
-__device__ __forceinline__ void cholDiag16(double* sD, int lane, int* failFlag) {
-  for (int k = 0; k < 16; ++k) {
-    waveSync();
-    const double x = sD[k * kPanelLd + k];
-    const bool ok = x > 0;
-    const double dk = ok ? sqrt(x) : 1.0;
-    if (!ok && lane == 0) atomicOr(failFlag, 2);
-    waveSync();
-    // column scale (lanes k..15 own rows) and diagonal
-    if (lane == k) sD[k * kPanelLd + k] = dk;
-    if (lane > k && lane < 16) sD[lane * kPanelLd + k] /= dk;
-    waveSync();
-    // trailing rank-1 update: 256 entries over 64 lanes
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = lane + 64 * e, i = idx >> 4, j = idx & 15;
-      if (j > k && i >= j) sD[i * kPanelLd + j] -= sD[i * kPanelLd + k] * sD[j * kPanelLd + k];
-    }
-  }
-  waveSync();
-}
-
-__global__ __launch_bounds__(1024) void k_chol_solve(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize) {
-  extern __shared__ double smem[];
-  double* sD = smem;                    // 16 x 17 diagonal block
-  double* sP = smem + 16 * kPanelLd;    // panel rows x 17 (later: rhs vector)
-  const int t = threadIdx.x, d = p.d;
-  double* Lm = p.cholL;                 // dpad x dpad, row-major
-  // copy lower triangle of S, identity padding
-  for (int idx = t; idx < dpad * dpad; idx += blockDim.x) {
-    const int i = idx / dpad, j = idx % dpad;
-    double v = 0;
-    if (i < d && j < d) v = (j <= i) ? p.S[(size_t)i * d + j] : 0.0;
-    else if (i == j) v = 1.0;
-    Lm[idx] = v;
-  }
-  __syncthreads();
-  if (fuseFinalize)
-    for (int i = t; i < d; i += blockDim.x) Lm[(size_t)i * dpad + i] += finalizeRow(p, i, mu, initScale);
-  __syncthreads();
-  const int nT = dpad / 16;
-  const int wave = t >> 6, lane = t & 63;
-  for (int kb = 0; kb < nT; ++kb) {
-    const int k0 = kb * 16;
-    // 1. diagonal block -> LDS, factor it with wave 0 alone
-    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
-    __syncthreads();
-    if (wave == 0) cholDiag16(sD, lane, &p.scal->cholFail);
-    __syncthreads();
-    if (t < 256) {
-      const int i = t >> 4, j = t & 15;
-      Lm[(size_t)(k0 + i) * dpad + k0 + j] = (j <= i) ? sD[i * kPanelLd + j] : 0.0;
-    }
-    // 2. panel: rows below, forward substitution against the diagonal block
-    const int rows = dpad - k0 - 16;
-    for (int rI = t; rI < rows; rI += blockDim.x) {
-      double x[16];
-      double* row = Lm + (size_t)(k0 + 16 + rI) * dpad + k0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = row[k];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        double s = x[k];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j < k) s -= x[j] * sD[k * kPanelLd + j];
-        x[k] = s / sD[k * kPanelLd + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { row[k] = x[k]; sP[(size_t)rI * kPanelLd + k] = x[k]; }
-    }
-    __syncthreads();
-    // 3. trailing update with MFMA: tile (I,J), I >= J, in units of 16 rows of the panel
-    const int nR = rows / 16;
-    const int nTiles = nR * (nR + 1) / 2;
-    for (int tile = wave; tile < nTiles; tile += 16) {
-      int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-      while (I * (I + 1) / 2 > tile) --I;
-      while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-      const int J = tile - I * (I + 1) / 2;
-      d4_t acc;
-      double* Cb = Lm + (size_t)(k0 + 16 + I * 16) * dpad + (k0 + 16 + J * 16);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double a = -sP[(size_t)(I * 16 + (lane & 15)) * kPanelLd + 4 * q + (lane >> 4)];
-        const double b = sP[(size_t)(J * 16 + (lane & 15)) * kPanelLd + 4 * q + (lane >> 4)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) Cb[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)] = acc[rg];
-    }
-    __syncthreads();
-  }
-  // ---- solve L y' = gRed ; L^T y = y'.  rhs in LDS (sP), diagonal blocks staged in sD, the 16-wide
-  // substitution runs in wave 0 with one lane per unknown.
-  double* y = p.yC;
-  for (int i = t; i < dpad; i += blockDim.x) sP[i] = (i < d) ? p.gRed[i] : 0.0;
-  __syncthreads();
-  for (int kb = 0; kb < nT; ++kb) {
-    const int k0 = kb * 16;
-    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
-    __syncthreads();
-    if (wave == 0) {
-      for (int k = 0; k < 16; ++k) {
-        waveSync();
-        const double xk = sP[k0 + k] / sD[k * kPanelLd + k];
-        waveSync();
-        if (lane == k) sP[k0 + k] = xk;
-        if (lane > k && lane < 16) sP[k0 + lane] -= sD[lane * kPanelLd + k] * xk;
-      }
-      waveSync();
-    }
-    __syncthreads();
-    for (int i = k0 + 16 + t; i < dpad; i += blockDim.x) {
-      double s = 0;
-      const double* row = Lm + (size_t)i * dpad + k0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) s += row[k] * sP[k0 + k];
-      sP[i] -= s;
-    }
-    __syncthreads();
-  }
-  for (int kb = nT - 1; kb >= 0; --kb) {
-    const int k0 = kb * 16;
-    if (t < 256) sD[(t >> 4) * kPanelLd + (t & 15)] = Lm[(size_t)(k0 + (t >> 4)) * dpad + k0 + (t & 15)];
-    __syncthreads();
-    if (wave == 0) {
-      for (int k = 15; k >= 0; --k) {
-        waveSync();
-        const double xk = sP[k0 + k] / sD[k * kPanelLd + k];
-        waveSync();
-        if (lane == k) sP[k0 + k] = xk;
-        if (lane < k) sP[k0 + lane] -= sD[k * kPanelLd + lane] * xk;   // L^T: column k of the block row k
-      }
-      waveSync();
-    }
-    __syncthreads();
-    for (int i = t; i < k0; i += blockDim.x) {
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) s += Lm[(size_t)(k0 + k) * dpad + i] * sP[k0 + k];
-      sP[i] -= s;
-    }
-    __syncthreads();
-  }
-  for (int i = t; i < d; i += blockDim.x) { y[i] = sP[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
-}
-
+// v_mfma_f64_16x16x4_f64 operand layout used throughout: A/B one f64 per lane, A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// C/D: col=l&15, row=(l>>4)+4*reg.  The matrix is padded to a multiple of 16 with an identity tail so that every tile is full.
 // LDS-resident variant for dpad <= 176: the lower triangle lives in LDS as 16x17 tiles (tile (I,J), I>=J at
 // index I(I+1)/2+J), so the whole factorisation and both triangular solves run at LDS latency.
 constexpr int kTile = 16 * kPanelLd;  // doubles per tile

@@ -64,7 +64,7 @@ struct PgDev {
   double *et, *eyaw, *epitch, *eroll, *eq, *esq;
   double *res, *Ja, *Jb;                // robustified residuals and Jacobian blocks (R x D per edge and side)
   int *nodePtr, *nodeEdge;              // incident edges per node: edge * 2 + side (0 = a, 1 = b)
-  double *scale, *g, *colsq, *nodeBlk, *y, *delta;
+  double *scale, *g, *colsq, *nodeBlk, *y;
   double *partial, *scal;
   // partition
   int* sepOff;                          // per node: offset in the separator system, -1 = interior / constant
@@ -1298,7 +1298,6 @@ class PoseGraph {
     p.et = dEt_.p; p.eyaw = dEyaw_.p; p.epitch = dEpitch_.p; p.eroll = dEroll_.p; p.eq = dEq_.p; p.esq = dEsq_.p;
     p.res = dRes_.p; p.Ja = dJa_.p; p.Jb = dJb_.p; p.nodePtr = dNodePtr_.p; p.nodeEdge = dNodeEdge_.p;
     p.scale = dVec_.p; p.g = dVec_.p + n; p.colsq = dVec_.p + 2 * (size_t)n; p.y = dVec_.p + 3 * (size_t)n;
-    p.delta = dVec_.p + 4 * (size_t)n;
     p.rhsS = dVec_.p + 5 * (size_t)n; p.yS = p.rhsS + nS;
     double* ones = p.yS + nS;    // htilC stand-in for the solver's v_C output
     double* vdump = ones + nS;
