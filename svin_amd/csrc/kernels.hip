@@ -2204,15 +2204,19 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   const int total = dC * dC + 3 * dC;
   size_t src = 0;
   int rr = 0, cc = 0;
+  bool work = false;
   if (idx < dC * dC) {
+    // the slabs hold the upper block triangle (6x6 blocks, diagonal blocks full): only those entries are read --
+    // row-wise, coalesced -- and mirrored into the lower triangle on the way out
     rr = idx / dC; cc = idx % dC;
-    const bool upper = (rr / 6) <= (cc / 6);
-    src = upper ? (size_t)rr * dC + cc : (size_t)cc * dC + rr;
+    work = (rr / 6) <= (cc / 6);
+    src = (size_t)rr * dC + cc;
   } else if (idx < total) {
+    work = true;
     src = (size_t)idx;
   }
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  if (idx < total) {
+  if (work) {
     const int per = (p.nSlabs + kSlabParts - 1) / kSlabParts;
     const int k0 = q * per, k1 = min(p.nSlabs, k0 + per);
     int k = k0;
@@ -2226,12 +2230,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   }
   part[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (q == 0 && idx < total) {
+  if (q == 0 && work) {
     double s = 0;
 #pragma unroll
     for (int k = 0; k < kSlabParts; ++k) s += part[16 * k + e];
-    if (idx < dC * dC) p.S[(size_t)rr * p.d + cc] += s;
-    else {
+    if (idx < dC * dC) {
+      p.S[(size_t)rr * p.d + cc] += s;
+      if ((rr / 6) < (cc / 6)) p.S[(size_t)cc * p.d + rr] += s;
+    } else {
       const int v = idx - dC * dC;
       if (v < dC) p.gRed[v] += s;
       else if (v < 2 * dC) p.gFull[v - dC] += s;
