@@ -635,48 +635,73 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     IMU_TICK(qp2);
     // ---------------- P1: the two serial chains, side by side
     if (wave == 0 && ns > 0) {
-      // Delta_q chain; the inputs of step i+1 are fetched from LDS while step i computes
-      const double* pr = sh.pre;
-      double d0 = pr[4], d1 = pr[5], d2 = pr[6], d3 = pr[7], ex = pr[28];
-      for (int i = 0; i < ns; ++i) {
-        const double* pn = sh.pre + min(i + 1, ns - 1) * kPreLd;
-        const double n0 = pn[4], n1 = pn[5], n2 = pn[6], n3 = pn[7], nex = pn[28];
-        if (lane == 0) { double* sq = sh.seq + i * kSeqLd; sq[0] = Dq.x; sq[1] = Dq.y; sq[2] = Dq.z; sq[3] = Dq.w; }
-        const Quat Dq1 = qmul(Dq, Quat{d0, d1, d2, d3});
-        if (ex != 0.0) Dq = Dq1;
-        d0 = n0; d1 = n1; d2 = n2; d3 = n3; ex = nex;
+      // Delta_q chain as a wave-wide inclusive scan (quaternion products are associative): lane i carries dq_i
+      // (identity for a step that is not executed), six combine levels instead of ns serial products
+      const double* pr = sh.pre + min(lane, ns - 1) * kPreLd;
+      const bool act = lane < ns && pr[28] != 0.0;
+      Quat q = act ? Quat{pr[4], pr[5], pr[6], pr[7]} : Quat{0, 0, 0, 1};
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const Quat lo = {__shfl_up(q.x, o, 64), __shfl_up(q.y, o, 64), __shfl_up(q.z, o, 64), __shfl_up(q.w, o, 64)};
+        const Quat c = qmul(lo, q);   // earlier steps on the left
+        if (lane >= o) q = c;
       }
+      Quat e = {__shfl_up(q.x, 1, 64), __shfl_up(q.y, 1, 64), __shfl_up(q.z, 1, 64), __shfl_up(q.w, 1, 64)};
+      if (lane == 0) e = Quat{0, 0, 0, 1};
+      const Quat before = qmul(Dq, e);     // Delta_q before step `lane`
+      if (lane < ns) { double* sq = sh.seq + lane * kSeqLd; sq[0] = before.x; sq[1] = before.y; sq[2] = before.z; sq[3] = before.w; }
+      const Quat tot = {__shfl(q.x, ns - 1, 64), __shfl(q.y, ns - 1, 64), __shfl(q.z, ns - 1, 64), __shfl(q.w, ns - 1, 64)};
+      Dq = qmul(Dq, tot);
       if (lane == 0) { double* sq = sh.seq + ns * kSeqLd; sq[0] = Dq.x; sq[1] = Dq.y; sq[2] = Dq.z; sq[3] = Dq.w; }
     }
     if (wave == 1 && ns > 0) {
-      // cross chain: the three columns are independent, lane c (mod 3) carries column c in cross[0..2]
-      const int c = lane % 3;
-      const double* pr = sh.pre;
-      double R[9], b[3], ex = pr[28];
+      // cross chain M <- R_i M + B_i (3x3, B_i = rightJacobian dt): affine maps compose associatively,
+      // (R_l, B_l) after (R_e, B_e) = (R_l R_e, R_l B_e + B_l); same scan, lane i carries step i's map
+      const double* pr = sh.pre + min(lane, ns - 1) * kPreLd;
+      const bool act = lane < ns && pr[28] != 0.0;
+      double R[9], B[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = pr[8 + k];
+      for (int k = 0; k < 9; ++k) { R[k] = act ? pr[8 + k] : ((k % 4 == 0) ? 1.0 : 0.0); B[k] = act ? pr[17 + k] : 0.0; }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) b[k] = pr[17 + 3 * k + c];
-      for (int i = 0; i < ns; ++i) {
-        const double* pn = sh.pre + min(i + 1, ns - 1) * kPreLd;
-        double Rn[9], bn[3];
+      for (int o = 1; o < 64; o <<= 1) {
+        double Re[9], Be[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rn[k] = pn[8 + k];
+        for (int k = 0; k < 9; ++k) { Re[k] = __shfl_up(R[k], o, 64); Be[k] = __shfl_up(B[k], o, 64); }
+        double Rn[9], Bn[9];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bn[k] = pn[17 + 3 * k + c];
-        const double nex = pn[28];
-        if (lane < 3) { double* sq = sh.seq + i * kSeqLd + 4 + c; sq[0] = cross[0]; sq[3] = cross[1]; sq[6] = cross[2]; }
-        double y[3];
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) y[k] = (R[3 * k] * cross[0] + R[3 * k + 1] * cross[1] + R[3 * k + 2] * cross[2]) + b[k];
-        if (ex != 0.0) { cross[0] = y[0]; cross[1] = y[1]; cross[2] = y[2]; }
+          for (int c = 0; c < 3; ++c) {
+            Rn[3 * r + c] = R[3 * r] * Re[c] + R[3 * r + 1] * Re[3 + c] + R[3 * r + 2] * Re[6 + c];
+            Bn[3 * r + c] = (R[3 * r] * Be[c] + R[3 * r + 1] * Be[3 + c] + R[3 * r + 2] * Be[6 + c]) + B[3 * r + c];
+          }
+        if (lane >= o) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) b[k] = bn[k];
-        ex = nex;
+          for (int k = 0; k < 9; ++k) { R[k] = Rn[k]; B[k] = Bn[k]; }
+        }
       }
-      if (lane < 3) { double* sq = sh.seq + ns * kSeqLd + 4 + c; sq[0] = cross[0]; sq[3] = cross[1]; sq[6] = cross[2]; }
+      // exclusive prefix applied to the state at the start of the round; the inclusive one of the last step ends it
+      double Re[9], Be[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { Re[k] = __shfl_up(R[k], 1, 64); Be[k] = __shfl_up(B[k], 1, 64); }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Re[k] = (k % 4 == 0) ? 1.0 : 0.0; Be[k] = 0.0; }
+      }
+      double after[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double bef = (Re[3 * r] * cross[c] + Re[3 * r + 1] * cross[3 + c] + Re[3 * r + 2] * cross[6 + c]) + Be[3 * r + c];
+          after[3 * r + c] = (R[3 * r] * cross[c] + R[3 * r + 1] * cross[3 + c] + R[3 * r + 2] * cross[6 + c]) + B[3 * r + c];
+          if (lane < ns) sh.seq[lane * kSeqLd + 4 + 3 * r + c] = bef;
+        }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cross[k] = __shfl(after[k], ns - 1, 64);
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (lane == k) sh.seq[ns * kSeqLd + 4 + k] = cross[k];
     }
     IMU_TICK(qp3);
     IMU_ACC(1, qp2, qp3, t == 0);
