@@ -3409,6 +3409,17 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   if (b < nLmBlocks) {
     const int grp = t >> 4, gl = t & 15;
     const size_t N = (size_t)p.N;
+    // the camera-side solution vectors are tiny and read by every observation: one staged copy in LDS instead of a
+    // dependent global load per observation (narrow windows; wide ones keep reading them through L2)
+    constexpr int kStageMax = 512;
+    __shared__ double sYV[2 * kStageMax];
+    const bool staged = p.d <= kStageMax;
+    if (staged) {
+      for (int i = t; i < p.d; i += blockDim.x) { sYV[i] = p.yC[i]; sYV[kStageMax + i] = p.vC[i]; }
+      __syncthreads();
+    }
+    const double* yCs = staged ? sYV : p.yC;
+    const double* vCs = staged ? sYV + kStageMax : p.vC;
     // u_y = Jc y_C, u_v = Jc v_C, Jl and r of observation o
     auto loadObs = [&](size_t o, double* jl, double* uy, double* uv, double* rr) {
       const uint32_t idx = p.obsIdx[o];
@@ -3417,7 +3428,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
       if (offP >= 0) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          const double j0 = p.JpCur[a * N + o], j1 = p.JpCur[(6 + a) * N + o], y = p.yC[offP + a], v = p.vC[offP + a];
+          const double j0 = p.JpCur[a * N + o], j1 = p.JpCur[(6 + a) * N + o], y = yCs[offP + a], v = vCs[offP + a];
           uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
         }
       }
@@ -3426,7 +3437,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         if (offE >= 0) {
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
-            const double j0 = p.JeCur[a * N + o], j1 = p.JeCur[(6 + a) * N + o], y = p.yC[offE + a], v = p.vC[offE + a];
+            const double j0 = p.JeCur[a * N + o], j1 = p.JeCur[(6 + a) * N + o], y = yCs[offE + a], v = vCs[offE + a];
             uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
           }
         }
