@@ -2306,6 +2306,21 @@ __global__ __launch_bounds__(256) void k_factors_only(DeviceProblem p, int nFacB
   if ((int)blockIdx.x < nFacBlocks) factorsAccumulate(p, blockIdx.x, colRow);
   else priorAccumulateBlock(p, blockIdx.x - nFacBlocks);
 }
+// one workgroup per (segment, 16 KB slice): 16-byte copies from the staged block to the arrays' own allocations
+__global__ __launch_bounds__(256) void k_scatter_staged(const unsigned char* block, int nSeg) {
+  const StageSegment* segs = reinterpret_cast<const StageSegment*>(block);
+  for (int sIdx = blockIdx.y; sIdx < nSeg; sIdx += gridDim.y) {
+    const StageSegment sg = segs[sIdx];
+    const uint4* src = reinterpret_cast<const uint4*>(block + sg.srcOff);
+    uint4* dst = reinterpret_cast<uint4*>(sg.dst);
+    const size_t n16 = sg.bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+}
+void launchScatterStaged(const void* block, int nSeg, hipStream_t s) {
+  if (nSeg <= 0) return;
+  hipLaunchKernelGGL(k_scatter_staged, dim3(32, std::min(nSeg, 64)), dim3(256), 0, s, reinterpret_cast<const unsigned char*>(block), nSeg);
+}
 void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_build, dim3((p.d * p.d + 255) / 256), dim3(256), 0, s, p);
 }

@@ -163,6 +163,10 @@ void launchBuildNormalEquations(const DeviceProblem& p, double mu, bool initScal
 // the same in two halves, so that a landmark-sharded solve can all-reduce [S | gRed | gFull | hC] in between
 void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst = true);
 void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
+// Staged upload: the host arrays of a window arrive as ONE block (one DMA from pinned memory); the segment table at
+// the head of the block tells this kernel where each array belongs.  Offsets and sizes are multiples of 16 bytes.
+struct StageSegment { unsigned long long srcOff, bytes; void* dst; };
+void launchScatterStaged(const void* block, int nSeg, hipStream_t s);
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // Cholesky + GN step of the reduced system; fuseFinalize applies k_finalize_diag (metric + damping) while loading S
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);

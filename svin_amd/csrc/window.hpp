@@ -205,6 +205,11 @@ class Window {
   AllReduceFn allreduce_ = nullptr;
   void* allreduceUser_ = nullptr;
   hipStream_t stream_ = nullptr;
+  // staged upload of pack(): pinned host block + its device twin (segment table first), see launchScatterStaged
+  unsigned char* stageHost_ = nullptr;
+  size_t stageHostCap_ = 0;
+  DevBuf<unsigned char> stageDev_;
+  hipEvent_t stageEvt_ = nullptr;
   uint64_t idCounter_ = 0;
   std::vector<CameraModel> cameras_;
   std::vector<ExtrinsicsSigmas> extrinsics_;
