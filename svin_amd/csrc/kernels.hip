@@ -2321,6 +2321,18 @@ void launchScatterStaged(const void* block, int nSeg, hipStream_t s) {
   if (nSeg <= 0) return;
   hipLaunchKernelGGL(k_scatter_staged, dim3(32, std::min(nSeg, 64)), dim3(256), 0, s, reinterpret_cast<const unsigned char*>(block), nSeg);
 }
+__global__ __launch_bounds__(256) void k_gather_staged(unsigned char* block, GatherArgs a) {
+  const int sIdx = blockIdx.y;
+  if (sIdx >= a.n) return;
+  const uint4* src = reinterpret_cast<const uint4*>(a.src[sIdx]);
+  uint4* dst = reinterpret_cast<uint4*>(block + a.off[sIdx]);
+  const size_t n16 = a.bytes[sIdx] / 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launchGatherStaged(void* block, const GatherArgs& a, hipStream_t s) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_gather_staged, dim3(16, a.n), dim3(256), 0, s, reinterpret_cast<unsigned char*>(block), a);
+}
 void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_build, dim3((p.d * p.d + 255) / 256), dim3(256), 0, s, p);
 }

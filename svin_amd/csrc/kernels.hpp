@@ -167,6 +167,10 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
 // the head of the block tells this kernel where each array belongs.  Offsets and sizes are multiples of 16 bytes.
 struct StageSegment { unsigned long long srcOff, bytes; void* dst; };
 void launchScatterStaged(const void* block, int nSeg, hipStream_t s);
+// the reverse for the read-back: up to 8 device arrays gathered into one block (offsets / sizes multiples of 16 bytes,
+// sizes rounded up: the sources are over-allocated accordingly)
+struct GatherArgs { const void* src[8]; unsigned long long off[8], bytes[8]; int n; };
+void launchGatherStaged(void* block, const GatherArgs& a, hipStream_t s);
 void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s);
 // Cholesky + GN step of the reduced system; fuseFinalize applies k_finalize_diag (metric + damping) while loading S
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);

@@ -843,15 +843,42 @@ void Window::downloadStates() {
       hLm((size_t)p.L * 4), hQ(p.L);
   std::vector<DevImu> hImu(p.nImu);
   if (p.L > 0) launchLandmarkQuality(p, dQuality_.p, s);
-  if (!hPose.empty()) HIP_OK(hipMemcpyAsync(hPose.data(), p.pose, sizeof(double) * hPose.size(), hipMemcpyDeviceToHost, s));
-  if (!extIds_.empty()) HIP_OK(hipMemcpyAsync(hExt.data(), p.ext, sizeof(double) * extIds_.size() * 7, hipMemcpyDeviceToHost, s));
-  if (!hSb.empty()) HIP_OK(hipMemcpyAsync(hSb.data(), p.sb, sizeof(double) * hSb.size(), hipMemcpyDeviceToHost, s));
-  if (p.L > 0) {
-    HIP_OK(hipMemcpyAsync(hLm.data(), p.lm, sizeof(double) * hLm.size(), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(hQ.data(), dQuality_.p, sizeof(double) * p.L, hipMemcpyDeviceToHost, s));
+  {  // one gather kernel + one DMA into the pinned block instead of six read-backs
+    GatherArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    struct Out { void* dst; size_t bytes; };
+    Out outs[8];
+    size_t off = 0;
+    auto add = [&](const void* src, void* dst, size_t bytes) {
+      if (bytes == 0) return;
+      const size_t b16 = (bytes + 15) / 16 * 16;
+      ga.src[ga.n] = src; ga.off[ga.n] = off; ga.bytes[ga.n] = b16;
+      outs[ga.n] = Out{dst, bytes};
+      ++ga.n;
+      off += b16;
+    };
+    add(p.pose, hPose.data(), sizeof(double) * hPose.size());
+    if (!extIds_.empty()) add(p.ext, hExt.data(), sizeof(double) * extIds_.size() * 7);
+    add(p.sb, hSb.data(), sizeof(double) * hSb.size());
+    if (p.L > 0) {
+      add(p.lm, hLm.data(), sizeof(double) * hLm.size());
+      add(dQuality_.p, hQ.data(), sizeof(double) * p.L);
+    }
+    if (p.nImu > 0) add(p.imus, hImu.data(), sizeof(DevImu) * p.nImu);
+    if (ga.n > 0) {
+      if (stageEvt_) HIP_OK(hipEventSynchronize(stageEvt_));
+      if (off > stageHostCap_) {
+        if (stageHost_) (void)hipHostFree(stageHost_);
+        stageHostCap_ = std::max<size_t>(2 * off, 1 << 20);
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&stageHost_), stageHostCap_, hipHostMallocDefault));
+      }
+      stageDev_.reserve(std::max<size_t>(off, 16));
+      launchGatherStaged(stageDev_.p, ga, s);
+      HIP_OK(hipMemcpyAsync(stageHost_, stageDev_.p, off, hipMemcpyDeviceToHost, s));
+    }
+    HIP_OK(hipStreamSynchronize(s));
+    for (int i = 0; i < ga.n; ++i) std::memcpy(outs[i].dst, stageHost_ + ga.off[i], outs[i].bytes);
   }
-  if (p.nImu > 0) HIP_OK(hipMemcpyAsync(hImu.data(), p.imus, sizeof(DevImu) * p.nImu, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
   for (size_t i = 0; i < poseIds_.size(); ++i) std::memcpy(blocks_.at(poseIds_[i]).x, &hPose[7 * i], 7 * sizeof(double));
   for (size_t i = 0; i < extIds_.size(); ++i) std::memcpy(blocks_.at(extIds_[i]).x, &hExt[7 * i], 7 * sizeof(double));
   for (size_t i = 0; i < sbIds_.size(); ++i) std::memcpy(blocks_.at(sbIds_[i]).x, &hSb[9 * i], 9 * sizeof(double));
