@@ -1781,7 +1781,8 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
   // acc(I,J) += sign * T_I T_J^T over nK4 steps of 4 columns of the LDS tile T (leading dimension ld)
-  auto rankUpdate = [&](const double* T, int ld, int nK4, double sign) {
+  // tileMask: bit I set = tile row I of T holds non-zeros (a product of two tile rows needs both)
+  auto rankUpdate = [&](const double* T, int ld, int nK4, double sign, unsigned tileMask) {
 #pragma unroll
     for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
       const int tl = wave + 4 * k;
@@ -1789,6 +1790,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= tl) ++I;
         const int J = tl - I * (I + 1) / 2;
+        if (!((tileMask >> I) & 1u) || !((tileMask >> J) & 1u)) continue;
         const double* A = T + (size_t)(16 * I + (lane & 15)) * ld + (lane >> 4);
         const double* B = T + (size_t)(16 * J + (lane & 15)) * ld + (lane >> 4);
         d4_t c = acc[k];
@@ -1802,39 +1804,61 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       // ---- A part on MFMA: the chunk's observations are contiguous (landmark-major CSR); batches of obsBatch
       const int l0 = chunk * kDenseLm, l1 = min(p.L, l0 + kDenseLm);
       const int oBeg = p.lmPtr[l0], oEnd = p.lmPtr[l1];
-      for (int ob = oBeg; ob < oEnd; ob += obsBatch) {
-        const int nb = min(obsBatch, oEnd - ob);
-        // entry e = k * nb + j: component k (0..11 Jp, 12..23 Je, 24..25 r) of observation ob + j
-        auto forEntries = [&](bool clear) {
-          for (int e = t; e < 26 * nb; e += blockDim.x) {
-            const int k = e / nb, j = e - k * nb;
-            const size_t o = (size_t)ob + j;
-            const uint32_t idx = p.obsIdx[o];
-            if (k < 24) {
-              const bool isP = k < 12;
-              if (!isP && !WITH_EXT) continue;
-              const int kk = isP ? k : k - 12;
-              const int off = isP ? p.poseOff[idx & 0xfff] : p.extOff[(idx >> 12) & 0xfff];
-              if (off >= 0)
-                Ut[(size_t)(off + (kk % 6)) * ldU + 2 * j + kk / 6] = clear ? 0.0 : (isP ? p.JpCur : p.JeCur)[kk * N + o];
-            } else {
-              const double r = clear ? 0.0 : p.rCur[(k - 24) * N + o];
-              Ut[(size_t)dC * ldU + 2 * j + (k - 24)] = r;
-              Ut[(size_t)(dC + 1) * ldU + 2 * j + (k - 24)] = r;
-            }
-          }
-        };
-        forEntries(false);
-        __syncthreads();
-        if (t < dC) {  // column norms hC = diag(U U^T)
-          double s2 = 0;
-          for (int c = 0; c < 2 * nb; ++c) { const double u = Ut[(size_t)t * ldU + c]; s2 += u * u; }
-          hcAcc += s2;
+      // the chunk's observations are taken pose by pose (p.obsOrder): a batch then touches the rows of one or two
+      // poses and their extrinsics, and only the tiles between touched tile rows are multiplied
+      __shared__ unsigned touched;
+      const unsigned gradBits = (1u << (dC >> 4)) | (1u << ((dC + 1) >> 4));
+      if (t == 0) touched = gradBits;
+      __syncthreads();
+      // observation index and row offsets of up to kMetaCap observations at a time: resolved once (three dependent
+      // loads) instead of in every fill and clear pass of every batch
+      constexpr int kMetaCap = 256;
+      __shared__ int metaO[kMetaCap], metaP[kMetaCap], metaE[kMetaCap];
+      for (int g0 = oBeg; g0 < oEnd; g0 += kMetaCap) {
+        const int gn = min(kMetaCap, oEnd - g0);
+        for (int j = t; j < gn; j += blockDim.x) {
+          const int o = p.obsOrder ? p.obsOrder[g0 + j] : g0 + j;
+          const uint32_t idx = p.obsIdx[o];
+          metaO[j] = o;
+          metaP[j] = p.poseOff[idx & 0xfff];
+          metaE[j] = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
         }
-        rankUpdate(Ut, ldU, (2 * nb + 3) / 4, 1.0);
         __syncthreads();
-        forEntries(true);  // clear exactly what was written
-        __syncthreads();
+        for (int ob = 0; ob < gn; ob += obsBatch) {
+          const int nb = min(obsBatch, gn - ob);
+          // entry e = k * nb + j: component k (0..11 Jp, 12..23 Je, 24..25 r) of observation ob + j of the group
+          auto forEntries = [&](bool clear) {
+            for (int e = t; e < 26 * nb; e += blockDim.x) {
+              const int k = e / nb, j = e - k * nb;
+              const size_t o = (size_t)metaO[ob + j];
+              if (k < 24) {
+                const bool isP = k < 12;
+                if (!isP && !WITH_EXT) continue;
+                const int kk = isP ? k : k - 12;
+                const int off = isP ? metaP[ob + j] : metaE[ob + j];
+                if (off >= 0 && !clear && kk == 0) atomicOr(&touched, (1u << (off >> 4)) | (1u << ((off + 5) >> 4)));
+                if (off >= 0)
+                  Ut[(size_t)(off + (kk % 6)) * ldU + 2 * j + kk / 6] = clear ? 0.0 : (isP ? p.JpCur : p.JeCur)[kk * N + o];
+              } else {
+                const double r = clear ? 0.0 : p.rCur[(k - 24) * N + o];
+                Ut[(size_t)dC * ldU + 2 * j + (k - 24)] = r;
+                Ut[(size_t)(dC + 1) * ldU + 2 * j + (k - 24)] = r;
+              }
+            }
+          };
+          forEntries(false);
+          __syncthreads();
+          if (t < dC) {  // column norms hC = diag(U U^T)
+            double s2 = 0;
+            for (int c = 0; c < 2 * nb; ++c) { const double u = Ut[(size_t)t * ldU + c]; s2 += u * u; }
+            hcAcc += s2;
+          }
+          rankUpdate(Ut, ldU, (2 * nb + 3) / 4, 1.0, touched);
+          __syncthreads();
+          forEntries(true);  // clear exactly what was written
+          if (t == 0) touched = gradBits;
+          __syncthreads();
+        }
       }
     }
     const int l = chunk * kDenseLm + grp;

@@ -704,6 +704,22 @@ void Window::pack() {
   const bool schurDense = dC > 0 && dC + 2 <= 256 && !getenv("SVIN_SCHUR_PAIRWISE");
   if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
+  // dense Schur with the A part on MFMA (variable extrinsics, or more than 8 tile rows): within every chunk of 16
+  // landmarks the observations are visited pose by pose, so that a batch only touches a few tile rows (counting sort)
+  std::vector<int> hObsOrder;
+  const bool orderObs = schurDense && (anyExtVar || (dC + 2 + 15) / 16 > 8) && N > 0;
+  if (orderObs) {
+    hObsOrder.resize(N);
+    std::vector<int> cnt;
+    for (int l0 = 0; l0 < L; l0 += 16) {
+      const int oBeg = hLmPtr[l0], oEnd = hLmPtr[std::min(L, l0 + 16)];
+      cnt.assign(poseIds_.size() + 2, 0);
+      for (int o = oBeg; o < oEnd; ++o) cnt[(hIdx[o] & 0xfff) + 1]++;
+      for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+      for (int o = oBeg; o < oEnd; ++o) hObsOrder[oBeg + cnt[hIdx[o] & 0xfff]++] = o;
+    }
+    upload(dObsOrder_, hObsOrder, s);
+  }
   // wide windows with fixed extrinsics: Gram-matrix Schur complement per pair of 96-row panels (k_schur_panels).
   // Work list: every chunk of 16 landmarks goes to all panel pairs (I >= J) inside the row range its observations touch.
   const bool schurPanels = !schurDense && !anyExtVar && dC > 0 && L > 0 && !getenv("SVIN_SCHUR_PAIRWISE");
@@ -782,6 +798,7 @@ void Window::pack() {
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
   p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
+  p.obsOrder = orderObs ? dObsOrder_.p : nullptr;
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;

@@ -249,7 +249,7 @@ class Window {
 
   // device buffers
   DevBuf<double> dPose_, dExt_, dSb_, dLm_, dPoseC_, dExtC_, dSbC_, dLmC_;
-  DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_, dPanelWork_, dPanelChunks_, dPanelPairPtr_;
+  DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_, dPanelWork_, dPanelChunks_, dPanelPairPtr_, dObsOrder_;
   DevBuf<CameraModel> dCams_;
   DevBuf<double> dObsUv_, dObsW_;
   DevBuf<uint32_t> dObsIdx_;
