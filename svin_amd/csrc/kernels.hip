@@ -1768,7 +1768,14 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   double* Gt = smem;                          // rows x kDenseLd
   double* Aw = smem + (size_t)rows * kDenseLd;  // !A_MFMA: 4 waves x nP x kPoseAcc;  A_MFMA: U tile, rows x ldU
   double* Ut = Aw;
-  const size_t extraLds = A_MFMA ? (size_t)rows * ldU : (size_t)4 * nP * kPoseAcc;
+  // A_MFMA with p.aBlocks: the A part is accumulated block-wise with LDS atomics instead (one shared copy): diagonal
+  // 6x6 blocks + Jc^T r per reduced block (Ash, kPoseAcc each), then the extrinsics x pose cross blocks (36 each)
+  const bool useBlocks = A_MFMA && p.aBlocks != 0;
+  const int nPB = p.dCPose / 6, nEB = nP - nPB;
+  double* Ash = Aw;
+  double* Across = Aw + (size_t)nP * kPoseAcc;
+  const size_t extraLds = useBlocks ? (size_t)nP * kPoseAcc + (size_t)nEB * nPB * 36
+                                    : (A_MFMA ? (size_t)rows * ldU : (size_t)4 * nP * kPoseAcc);
   const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
   double* Amine = Aw + (size_t)wave * nP * kPoseAcc;
   // accumulator tiles (I >= J) owned by this wave: tile index tl = wave, wave + 4, ...
@@ -1778,8 +1785,15 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   for (int k = 0; k < kMaxTiles; ++k) acc[k] = d4_t{0, 0, 0, 0};
   const int nTiles = nTr * (nTr + 1) / 2;
   double hcAcc = 0;                           // thread c < dC: column norm hC[c]
+#ifdef SVIN_SCHUR_TIMING
+  const long long qd0 = __builtin_readcyclecounter();
+  long long qdA = 0, qdL = 0, qdG = 0;
+#endif
   for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
+#ifdef SVIN_SCHUR_TIMING
+  const long long qd1 = __builtin_readcyclecounter();
+#endif
   // acc(I,J) += sign * T_I T_J^T over nK4 steps of 4 columns of the LDS tile T (leading dimension ld)
   // tileMask: bit I set = tile row I of T holds non-zeros (a product of two tile rows needs both)
   auto rankUpdate = [&](const double* T, int ld, int nK4, double sign, unsigned tileMask) {
@@ -1800,7 +1814,10 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     }
   };
   for (int chunk = b; chunk * kDenseLm < p.L; chunk += nChunkBlocks) {
-    if (A_MFMA) {
+#ifdef SVIN_SCHUR_TIMING
+    const long long qc0 = __builtin_readcyclecounter();
+#endif
+    if (A_MFMA && !useBlocks) {
       // ---- A part on MFMA: the chunk's observations are contiguous (landmark-major CSR); batches of obsBatch
       const int l0 = chunk * kDenseLm, l1 = min(p.L, l0 + kDenseLm);
       const int oBeg = p.lmPtr[l0], oEnd = p.lmPtr[l1];
@@ -1861,6 +1878,10 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         }
       }
     }
+#ifdef SVIN_SCHUR_TIMING
+    const long long qc1 = __builtin_readcyclecounter();
+    qdA += qc1 - qc0;
+#endif
     const int l = chunk * kDenseLm + grp;
     if (l < p.L) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
@@ -1952,9 +1973,38 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         };
         if (offP >= 0) addBlock(p.JpCur, offP);
         if (WITH_EXT && offE >= 0) addBlock(p.JeCur, offE);
+        if (useBlocks) {
+          // A = sum Jc^T Jc of this observation: its pose block, its extrinsics block, their cross block, Jc^T r
+          const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+          double jp[12], je[12];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) { jp[k] = offP >= 0 ? p.JpCur[k * N + o] : 0.0; je[k] = offE >= 0 ? p.JeCur[k * N + o] : 0.0; }
+          auto diagBlock = [&](const double* j, int off) {
+            double* ap = Ash + (size_t)(off / 6) * kPoseAcc;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+              for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j[a] * j[c] + j[6 + a] * j[6 + c]);
+              atomicAdd(&ap[21 + a], j[a] * r0 + j[6 + a] * r1);
+            }
+          };
+          if (offP >= 0) diagBlock(jp, offP);
+          if (offE >= 0) diagBlock(je, offE);
+          if (offP >= 0 && offE >= 0) {
+            double* cr = Across + ((size_t)((offE - p.dCPose) / 6) * nPB + offP / 6) * 36;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c = 0; c < 6; ++c) atomicAdd(&cr[a * 6 + c], je[a] * jp[c] + je[6 + a] * jp[6 + c]);
+          }
+        }
       }
     }
     __syncthreads();
+#ifdef SVIN_SCHUR_TIMING
+    const long long qc2 = __builtin_readcyclecounter();
+    qdL += qc2 - qc1;
+#endif
     // ---- acc(I,J) += A_chunk (pose-diagonal blocks, gradient rows), then acc(I,J) -= G_I G_J^T (12 k-steps)
     if (!A_MFMA && t < dC) {
       const int ps = t / 6, a = t % 6;
@@ -1963,6 +2013,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + sym6(a, a)];
       hcAcc += s;
     }
+    if (useBlocks && t < dC) hcAcc += Ash[(size_t)(t / 6) * kPoseAcc + sym6(t % 6, t % 6)];
 #pragma unroll
     for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
       const int tl = wave + 4 * k;
@@ -1986,6 +2037,18 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
             for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + idx];
             c[rg] += s;
           }
+          if (useBlocks) {
+            if (idx >= 0) {   // diagonal block / gradient rows
+              c[rg] += Ash[(size_t)ps * kPoseAcc + idx];
+            } else if (cc < dC && r < dC) {   // extrinsics x pose cross block, stored [extrinsics row][pose column]
+              const bool rExt = r >= p.dCPose, cExt = cc >= p.dCPose;
+              if (rExt != cExt) {
+                const int eb = (rExt ? r : cc) / 6 - nPB, pb = (rExt ? cc : r) / 6;
+                const int ea = (rExt ? r : cc) % 6, pe = (rExt ? cc : r) % 6;
+                c[rg] += Across[((size_t)eb * nPB + pb) * 36 + ea * 6 + pe];
+              }
+            }
+          }
         }
         const double* A = Gt + (size_t)(16 * I + (lane & 15)) * kDenseLd + (lane >> 4);
         const double* B = Gt + (size_t)(16 * J + (lane & 15)) * kDenseLd + (lane >> 4);
@@ -1995,9 +2058,15 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       }
     }
     __syncthreads();
-    for (int i = t; i < rows * kDenseLd + (A_MFMA ? 0 : 4 * nP * kPoseAcc); i += blockDim.x) smem[i] = 0.0;
+    for (int i = t; i < rows * kDenseLd + (A_MFMA ? (useBlocks ? (int)extraLds : 0) : 4 * nP * kPoseAcc); i += blockDim.x) smem[i] = 0.0;
     __syncthreads();
+#ifdef SVIN_SCHUR_TIMING
+    qdG += __builtin_readcyclecounter() - qc2;
+#endif
   }
+#ifdef SVIN_SCHUR_TIMING
+  const long long qd2 = __builtin_readcyclecounter();
+#endif
   // ---- private slab: [S (dC x dC) | gRed | gFull | hC]
   double* slab = p.slabs + (size_t)b * ((size_t)dC * dC + 3 * dC);
   if (t < dC) slab[(size_t)dC * dC + 2 * dC + t] = hcAcc;
@@ -2021,6 +2090,13 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       }
     }
   }
+#ifdef SVIN_SCHUR_TIMING
+  if (b == 0 && t == 0) {
+    double* dbg = p.partial + (size_t)15 * 4096 + 16;
+    dbg[0] += (double)(qd1 - qd0); dbg[1] += (double)qdA; dbg[2] += (double)qdL; dbg[3] += (double)qdG;
+    dbg[4] += (double)(__builtin_readcyclecounter() - qd2);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- Gram-matrix Schur complement for WIDE windows
@@ -2370,13 +2446,21 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
   if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
     const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
     const bool aMfma = p.anyExtVariable || nTr > 8;
-    const size_t extra = aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc;
+    // A on the MFMA path needs a fill / barrier / clear round per batch of observations; when the blocks of A fit LDS
+    // next to G they are accumulated directly (LDS atomics) and merged into the accumulator tiles once per chunk
+    const int nPB = p.dCPose / 6, nEB = dC / 6 - nPB;
+    const size_t blocksExtra = (size_t)(dC / 6) * kPoseAcc + (size_t)nEB * nPB * 36;
+    static const bool forceU = std::getenv("SVIN_SCHUR_A_MFMA") != nullptr;
+    const bool aBlocks = aMfma && !forceU && ((size_t)rows * kDenseLd + blocksExtra) * 8 <= 150 * 1024;
+    const size_t extra = aBlocks ? blocksExtra : (aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc);
     const size_t ldsBytes = ((size_t)rows * kDenseLd + extra) * 8;
     const dim3 grid(p.nSlabs + nFac + nPri);
+    DeviceProblem pb = p;
+    pb.aBlocks = aBlocks ? 1 : 0;
 #define LAUNCH(MAXT, E)                                                                                             \
   do {                                                                                                              \
     ensureDynamicLds((const void*)k_schur_dense<MAXT, E>, ldsBytes); \
-    hipLaunchKernelGGL((k_schur_dense<MAXT, E>), grid, dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nSlabs, \
+    hipLaunchKernelGGL((k_schur_dense<MAXT, E>), grid, dim3(256), ldsBytes, s, pb, mu, initScale ? 1 : 0, p.nSlabs, \
                        nFac);                                                                                       \
   } while (0)
     if (nTr > 8) LAUNCH(34, true);

@@ -118,6 +118,7 @@ struct DeviceProblem {
   const int* panelPairPtr;                   // per panel pair: first workgroup (nPanelPairs + 1 entries)
   double *obsUv, *obsW;
   uint32_t* obsIdx;
+  int dCPose, aBlocks;   // rows of the variable poses in the reduced camera system; dense Schur: A accumulated block-wise in LDS
   const int* obsOrder;   // dense Schur with the A part on MFMA: the observations of every 16-landmark chunk sorted by pose (or null)
   int* obsLm;
   // linearisation buffers (cur = accepted point, cand = candidate)

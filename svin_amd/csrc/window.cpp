@@ -541,6 +541,7 @@ void Window::pack() {
     if (b.fixed) hPoseOff[i] = -1;
     else { hPoseOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 6; }
   }
+  const int dCPose = d;
   for (size_t i = 0; i < extIds_.size(); ++i) {
     const Block& b = blocks_.at(extIds_[i]);
     std::memcpy(&hExt[7 * i], b.x, 7 * sizeof(double));
@@ -799,6 +800,7 @@ void Window::pack() {
   p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
   p.obsOrder = orderObs ? dObsOrder_.p : nullptr;
+  p.dCPose = dCPose;
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;
