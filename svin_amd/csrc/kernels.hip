@@ -2082,7 +2082,8 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         const int r = 16 * I + (lane >> 4) + 4 * rg, c = 16 * J + (lane & 15);
         const double v = acc[k][rg];
         if (r < dC && c < dC) {
-          slab[(size_t)r * dC + c] = v;
+          // k_reduce_slabs only reads the upper block triangle (6x6 blocks, diagonal blocks full)
+          if (r / 6 <= c / 6) slab[(size_t)r * dC + c] = v;
           if (I != J) slab[(size_t)c * dC + r] = v;
         } else if ((r == dC || r == dC + 1) && c < dC) {
           slab[(size_t)dC * dC + (r - dC) * dC + c] = v;  // reduced gradient / full camera gradient
