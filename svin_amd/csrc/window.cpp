@@ -529,6 +529,26 @@ void Window::pack() {
     for (const StateInfo& b : s.sb)
       if (b.exists) { sbSlot_[b.id] = (int)sbIds_.size(); sbIds_.push_back(b.id); }
   }
+  // Fixed blocks are never marginalised (Estimator.cpp:643-645, "we never eliminate fixed blocks"): when their frame
+  // leaves the window they stay in the graph as constants -- e.g. the fixed extrinsics of the first frame, still tied
+  // to the next frame's by a RelativePoseError, or listed (with no columns) in the marginalisation prior.  The
+  // factors and the prior address them by slot like any other block.
+  {
+    std::vector<uint64_t> orphans;
+    for (const auto& kv : blocks_) {
+      const Block& b = kv.second;
+      if (!b.fixed || (b.residuals.empty() && b.nObs == 0)) continue;
+      const bool known = (b.kind == B_POSE) ? poseSlot_.count(b.id) : (b.kind == B_EXT ? extSlot_.count(b.id) : sbSlot_.count(b.id));
+      if (!known) orphans.push_back(b.id);
+    }
+    std::sort(orphans.begin(), orphans.end());
+    for (uint64_t id : orphans) {
+      const Block& b = blocks_.at(id);
+      if (b.kind == B_POSE) { poseSlot_[id] = (int)poseIds_.size(); poseIds_.push_back(id); }
+      else if (b.kind == B_EXT) { extSlot_[id] = (int)extIds_.size(); extIds_.push_back(id); }
+      else { sbSlot_[id] = (int)sbIds_.size(); sbIds_.push_back(id); }
+    }
+  }
   if (poseIds_.size() > 4095 || extIds_.size() > 4095) throw std::runtime_error("window too wide for the packed index");
   std::vector<double> hPose(poseIds_.size() * 7), hExt(std::max<size_t>(extIds_.size(), 1) * 7), hSb(sbIds_.size() * 9);
   std::vector<int> hPoseOff(poseIds_.size()), hExtOff(std::max<size_t>(extIds_.size(), 1), -1), hSbOff(sbIds_.size());

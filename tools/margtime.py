@@ -22,7 +22,8 @@ def run(est, spec, iters, label):
           (label, len(t_opt), iters, 1e3 * np.median(t_opt[3:]), 1e3 * np.median(t_marg[3:]), 1e3 * max(t_marg[3:]), 1e3 * tot, nrem[-4:]))
 
 if __name__ == "__main__":
-    spec = syn.make_window(P=20, L=2000, n_obs=20000, seed=7, rig="euroc", keyframe_every=2, frame_dt=0.25)
+    rig = "rig_v2" if "--rig-v2" in sys.argv else "euroc"   # rig_v2: per-frame extrinsics (sigma_c_relative > 0), sonar + depth off
+    spec = syn.make_window(P=20, L=2000, n_obs=20000, seed=7, rig=rig, keyframe_every=2, frame_dt=0.25)
     run(Estimator(0), spec, 10, "gpu")
     if "--cpu" in sys.argv:
         from oracle import orc
