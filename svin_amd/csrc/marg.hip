@@ -162,7 +162,7 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
-__device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
+__device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, double2* rotLog = nullptr) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
   if (n <= 1) return;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
@@ -195,7 +195,10 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
         int a, b;
         if (k == 0) { a = np - 1; b = round; }
         else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
-        if (a >= n || b >= n) continue;
+        if (a >= n || b >= n) {
+          if (rotLog && gl == 0) rotLog[((size_t)sweep * (np - 1) + round) * (np / 2) + k] = make_double2(1.0, 0.0);
+          continue;
+        }
         const int pI = a < b ? a : b, qI = a < b ? b : a;
         double* gp = G + (size_t)pI * ld;
         double* gq = G + (size_t)qI * ld;
@@ -203,19 +206,30 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag) {
         for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { al += __shfl_xor(al, o, 16); be += __shfl_xor(be, o, 16); ga += __shfl_xor(ga, o, 16); }
-        if (fabs(ga) <= kJacobiOrthTol * sqrt(al * be) || al == 0.0 || be == 0.0) continue;
-        if (al <= tol2 && be <= tol2) continue;
+        double2* slot = rotLog ? rotLog + ((size_t)sweep * (np - 1) + round) * (np / 2) + k : nullptr;
+        if (fabs(ga) <= kJacobiOrthTol * sqrt(al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
+          if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
+          continue;
+        }
         if (gl == 0) *flag = 1;
         const double zeta = (be - al) / (2.0 * ga);
         const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
-        double* vp = Q + (size_t)pI * ld;
-        double* vq = Q + (size_t)qI * ld;
-        for (int i = gl; i < n; i += 16) {
-          const double x = gp[i], y = gq[i];
-          gp[i] = c * x - s * y; gq[i] = s * x + c * y;
-          const double u = vp[i], w = vq[i];
-          vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+        if (slot && gl == 0) *slot = make_double2(c, s);
+        if (Q) {
+          double* vp = Q + (size_t)pI * ld;
+          double* vq = Q + (size_t)qI * ld;
+          for (int i = gl; i < n; i += 16) {
+            const double x = gp[i], y = gq[i];
+            gp[i] = c * x - s * y; gq[i] = s * x + c * y;
+            const double u = vp[i], w = vq[i];
+            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+          }
+        } else {
+          for (int i = gl; i < n; i += 16) {
+            const double x = gp[i], y = gq[i];
+            gp[i] = c * x - s * y; gq[i] = s * x + c * y;
+          }
         }
       }
       __syncthreads();
@@ -248,9 +262,59 @@ __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
   }
   __syncthreads();
 }
+// n too large for G and Q to share LDS (2 n^2 doubles), small enough for one of them (n <= 136): two phases with the
+// same arithmetic as the one-phase solver.  Phase 1 rotates G alone in LDS and logs every rotation (c, s) of every
+// sweep / round / pair in global memory (fire-and-forget stores); phase 2 replays the log on Q = I in the same LDS.
+// (Reading the eigenvectors off G_j = lambda_j q_j instead is NOT good enough: for small eigenvalues the direction of
+// G_j is rounding noise, and e0 = -pinv(J^T) b0 amplifies it by 1 / lambda.)
+__device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double* lds, double2* rotLog) {
+  const int ld = n | 1, np = (n & 1) ? n + 1 : n;
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    lds[i * ld + j] = G[idx];
+  }
+  __syncthreads();
+  jacobiEigBlock(lds, nullptr, n, ld, flag, rotLog);
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    G[idx] = lds[i * ld + j];
+    lds[i * ld + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int nSweeps = flag[1];
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
+  for (int sweep = 0; sweep < nSweeps; ++sweep)
+    for (int round = 0; round < np - 1; ++round) {
+      for (int k = grp; k < np / 2; k += nGroups) {
+        const double2 cs = rotLog[((size_t)sweep * (np - 1) + round) * (np / 2) + k];
+        if (cs.y == 0.0) continue;
+        int a, b;
+        if (k == 0) { a = np - 1; b = round; }
+        else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
+        const int pI = a < b ? a : b, qI = a < b ? b : a;
+        double* vp = lds + (size_t)pI * ld;
+        double* vq = lds + (size_t)qI * ld;
+        for (int i = gl; i < n; i += 16) {
+          const double u = vp[i], w = vq[i];
+          vp[i] = cs.x * u - cs.y * w; vq[i] = cs.y * u + cs.x * w;
+        }
+      }
+      __syncthreads();
+    }
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int i = idx / n, j = idx - i * n;
+    Q[idx] = lds[i * ld + j];
+  }
+  __syncthreads();
+}
 constexpr size_t kJacobiLdsLimit = 150 * 1024;
 static size_t jacobiLdsBytes(int n) {
   const size_t b = (size_t)2 * n * (n | 1) * sizeof(double);
+  return b <= kJacobiLdsLimit ? b : 0;
+}
+static size_t jacobiLdsBytesGOnly(int n) {
+  const size_t b = (size_t)n * (n | 1) * sizeof(double);
   return b <= kJacobiLdsLimit ? b : 0;
 }
 
@@ -395,6 +459,7 @@ struct FinalArgs {
   const double* H; const double* b0;
   double *G, *Q, *J, *e0, *Ht, *bp, *scal, *tmp;
   int* flag;
+  double2* rotLog;   // two-phase eigen-solve (96 < n <= 136): 40 sweeps x (np - 1) rounds x np / 2 pairs
 };
 __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   extern __shared__ double jacobiLds[];
@@ -412,7 +477,8 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
     a.Q[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
+  if (useLds == 2) jacobiEigTwoPhase(a.G, a.Q, n, a.flag, jacobiLds, a.rotLog);
+  else jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
   __shared__ double smax;
   for (int j = t; j < n; j += nt) {
     double s = 0;
@@ -851,9 +917,18 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       fa.flag = bFlag.p;
       dbgScal = fa.scal;
       {
-        const size_t lds = jacobiLdsBytes(nk);
+        size_t lds = jacobiLdsBytes(nk);
+        int mode = lds ? 1 : 0;
+        fa.rotLog = nullptr;
+        static const bool noTwoPhase = getenv("SVIN_MARG_NO_TWOPHASE") != nullptr;   // A/B switch
+        if (!lds && !noTwoPhase && (lds = jacobiLdsBytesGOnly(nk)) != 0) {   // G and Q take turns in LDS
+          mode = 2;
+          const size_t npk = (nk & 1) ? nk + 1 : nk;
+          mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
+          fa.rotLog = reinterpret_cast<double2*>(mb.bRotLog.p);
+        }
         if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, lds ? 1 : 0);
+        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode);
       }
       priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     }
