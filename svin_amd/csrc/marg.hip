@@ -162,17 +162,55 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
+constexpr int kJacobiRegCols = 9;   // a 16-lane group keeps columns of up to 9 x 16 = 144 entries in registers
+
+// one 32-bit half at a time through DPP row_ror:N (ctrl 0x120 + N): lane i of a 16-lane row reads lane (i - N) & 15
+template <int kCtrl>
+__device__ __forceinline__ double dppRowMov(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// sum over the 16 lanes of a DPP row, in every lane; all 16 lanes must be active.  (__shfl_xor(.., 16) compiles to
+// ds_bpermute: 24 LDS round trips per pair for the three inner products.)
+__device__ __forceinline__ double rowSum16(double v) {
+  v += dppRowMov<0x128>(v);
+  v += dppRowMov<0x124>(v);
+  v += dppRowMov<0x122>(v);
+  v += dppRowMov<0x121>(v);
+  return v;
+}
+// pair k of round `round` of the round-robin tournament over np players (np even)
+__device__ __forceinline__ void jacobiPair(int np, int round, int k, int& a, int& b) {
+  if (k == 0) { a = np - 1; b = round; return; }
+  a = round + k; if (a >= np - 1) a -= np - 1;
+  b = round - k; if (b < 0) b += np - 1;
+}
+// Jacobi rotation that orthogonalises two columns with |p|^2 = al, |q|^2 = be, p.q = ga: t = tan(theta) is the smaller
+// root of t^2 + 2 zeta t - 1 = 0, zeta = (be - al) / (2 ga), written with one sqrt, one division and one rsqrt
+__device__ __forceinline__ void jacobiRotation(double al, double be, double ga, double& c, double& s) {
+  const double d = be - al, g2 = 2.0 * ga;
+  const double hyp = sqrt(d * d + g2 * g2);
+  const double tt = g2 / (d + copysign(hyp, d));
+  c = rsqrt(1.0 + tt * tt);
+  s = c * tt;
+}
+
 __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, double2* rotLog = nullptr) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
   if (n <= 1) return;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
+  const bool inRegs = n <= 16 * kJacobiRegCols;
   // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
   // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
   // to keep the solver busy for all 40 sweeps).  Pairs with at least one significant column are still rotated.
   __shared__ double nullTol2;
+  __shared__ int anyRotation;
   for (int sweep = 0; sweep < 40; ++sweep) {
     __syncthreads();
-    if (threadIdx.x == 0) { *flag = 0; nullTol2 = 0.0; }
+    if (threadIdx.x == 0) { anyRotation = 0; nullTol2 = 0.0; }
     __syncthreads();
     {
       double mx = 0;
@@ -188,42 +226,52 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
     __syncthreads();
     const double eps_n = 2.220446049250313e-16 * n;
     const double tol2 = nullTol2 * eps_n * eps_n;
-    // 16 lanes per pair (DPP-sized groups): the n/2 disjoint pairs of a round run side by side, four per wave
+    // 16 lanes per pair (one DPP row): the n/2 disjoint pairs of a round run side by side, four per wave
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
-    for (int round = 0; round < np - 1; ++round) {
+    double2* logRound = rotLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
+    bool rotated = false;
+    for (int round = 0; round < np - 1; ++round, logRound += rotLog ? np / 2 : 0) {
       for (int k = grp; k < np / 2; k += nGroups) {
         int a, b;
-        if (k == 0) { a = np - 1; b = round; }
-        else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
+        jacobiPair(np, round, k, a, b);
+        double2* slot = rotLog ? logRound + k : nullptr;
         if (a >= n || b >= n) {
-          if (rotLog && gl == 0) rotLog[((size_t)sweep * (np - 1) + round) * (np / 2) + k] = make_double2(1.0, 0.0);
-          continue;
-        }
-        const int pI = a < b ? a : b, qI = a < b ? b : a;
-        double* gp = G + (size_t)pI * ld;
-        double* gq = G + (size_t)qI * ld;
-        double al = 0, be = 0, ga = 0;
-        for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { al += __shfl_xor(al, o, 16); be += __shfl_xor(be, o, 16); ga += __shfl_xor(ga, o, 16); }
-        double2* slot = rotLog ? rotLog + ((size_t)sweep * (np - 1) + round) * (np / 2) + k : nullptr;
-        if (fabs(ga) <= kJacobiOrthTol * sqrt(al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
           if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
           continue;
         }
-        if (gl == 0) *flag = 1;
-        const double zeta = (be - al) / (2.0 * ga);
-        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+        const int pI = a < b ? a : b, qI = a < b ? b : a;
+        double* gp = G + pI * ld;
+        double* gq = G + qI * ld;
+        double al = 0, be = 0, ga = 0;
+        double xs[kJacobiRegCols], ys[kJacobiRegCols];
+        if (inRegs) {
+#pragma unroll
+          for (int u = 0; u < kJacobiRegCols; ++u) {
+            if (16 * u >= n) break;
+            const int i = gl + 16 * u;
+            const bool in = i < n;
+            const double x = in ? gp[i] : 0.0, y = in ? gq[i] : 0.0;
+            xs[u] = x; ys[u] = y;
+            al += x * x; be += y * y; ga += x * y;
+          }
+        } else {
+          for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
+        }
+        al = rowSum16(al); be = rowSum16(be); ga = rowSum16(ga);
+        if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
+          if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
+          continue;
+        }
+        rotated = true;
+        double c, s;
+        jacobiRotation(al, be, ga, c, s);
         if (slot && gl == 0) *slot = make_double2(c, s);
-        if (Q) {
-          double* vp = Q + (size_t)pI * ld;
-          double* vq = Q + (size_t)qI * ld;
-          for (int i = gl; i < n; i += 16) {
-            const double x = gp[i], y = gq[i];
-            gp[i] = c * x - s * y; gq[i] = s * x + c * y;
-            const double u = vp[i], w = vq[i];
-            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+        if (inRegs) {
+#pragma unroll
+          for (int u = 0; u < kJacobiRegCols; ++u) {
+            if (16 * u >= n) break;
+            const int i = gl + 16 * u;
+            if (i < n) { gp[i] = c * xs[u] - s * ys[u]; gq[i] = s * xs[u] + c * ys[u]; }
           }
         } else {
           for (int i = gl; i < n; i += 16) {
@@ -231,11 +279,21 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
             gp[i] = c * x - s * y; gq[i] = s * x + c * y;
           }
         }
+        if (Q) {
+          double* vp = Q + pI * ld;
+          double* vq = Q + qI * ld;
+          for (int i = gl; i < n; i += 16) {
+            const double u = vp[i], w = vq[i];
+            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+          }
+        }
       }
       __syncthreads();
     }
+    if (rotated) anyRotation = 1;   // racing stores of the same value
     if (threadIdx.x == 0) flag[1] = sweep + 1;
-    if (*flag == 0) break;
+    __syncthreads();
+    if (anyRotation == 0) break;
   }
   __syncthreads();
 }
@@ -282,26 +340,50 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
   }
   __threadfence_block();
   __syncthreads();
-  const int nSweeps = flag[1];
+  // replay: rotation (c, s) of pair k in round r sits at rotLog[r * half + k]; the log is read four rounds ahead so
+  // that the L2 round trip hides behind the rotations of the rounds in between
+  const int half = np / 2, R = flag[1] * (np - 1);
   const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
-  for (int sweep = 0; sweep < nSweeps; ++sweep)
-    for (int round = 0; round < np - 1; ++round) {
-      for (int k = grp; k < np / 2; k += nGroups) {
-        const double2 cs = rotLog[((size_t)sweep * (np - 1) + round) * (np / 2) + k];
-        if (cs.y == 0.0) continue;
-        int a, b;
-        if (k == 0) { a = np - 1; b = round; }
-        else { a = (round + k) % (np - 1); b = (round - k + (np - 1)) % (np - 1); }
-        const int pI = a < b ? a : b, qI = a < b ? b : a;
-        double* vp = lds + (size_t)pI * ld;
-        double* vq = lds + (size_t)qI * ld;
-        for (int i = gl; i < n; i += 16) {
-          const double u = vp[i], w = vq[i];
-          vp[i] = cs.x * u - cs.y * w; vq[i] = cs.y * u + cs.x * w;
-        }
-      }
-      __syncthreads();
+  const int k0 = grp, k1 = grp + nGroups;   // half <= 2 * nGroups (n <= 136, 64 groups)
+  const bool has0 = k0 < half, has1 = k1 < half;
+  auto fetch = [&](int r, double2& c0, double2& c1) {
+    const double2* row = rotLog + (size_t)r * half;
+    c0 = has0 ? row[k0] : make_double2(1.0, 0.0);
+    c1 = has1 ? row[k1] : make_double2(1.0, 0.0);
+  };
+  auto rotate = [&](int round, int k, const double2 cs) {
+    if (cs.y == 0.0) return;
+    int a, b;
+    jacobiPair(np, round, k, a, b);
+    const int pI = a < b ? a : b, qI = a < b ? b : a;
+    double* vp = lds + pI * ld;
+    double* vq = lds + qI * ld;
+    for (int i = gl; i < n; i += 16) {
+      const double u = vp[i], w = vq[i];
+      vp[i] = cs.x * u - cs.y * w; vq[i] = cs.y * u + cs.x * w;
     }
+  };
+  constexpr int kAhead = 4;
+  double2 ring0[kAhead], ring1[kAhead];
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u) {
+    ring0[u] = ring1[u] = make_double2(1.0, 0.0);
+    if (u < R) fetch(u, ring0[u], ring1[u]);
+  }
+  int round = 0;
+  for (int r0 = 0; r0 < R; r0 += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int r = r0 + u;
+      if (r >= R) break;
+      const double2 c0 = ring0[u], c1 = ring1[u];
+      if (r + kAhead < R) fetch(r + kAhead, ring0[u], ring1[u]);
+      if (has0) rotate(round, k0, c0);
+      if (has1) rotate(round, k1, c1);
+      __syncthreads();
+      if (++round == np - 1) round = 0;
+    }
+  }
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     Q[idx] = lds[i * ld + j];
@@ -466,6 +548,7 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   const int t = threadIdx.x, nt = blockDim.x, n = a.n;
   double* p = a.tmp;        // n
   double* ev = a.tmp + n;   // n
+  const long long tStart = wall_clock64();
   for (int i = t; i < n; i += nt) {
     const double hd = a.H[(size_t)i * n + i];
     p[i] = (hd > 1.0e-9) ? sqrt(hd) : 1.0e-3;
@@ -477,46 +560,84 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
     a.Q[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
+  const long long tPrep = wall_clock64();
   if (useLds == 2) jacobiEigTwoPhase(a.G, a.Q, n, a.flag, jacobiLds, a.rotLog);
   else jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
+  long long tEig = wall_clock64();
   __shared__ double smax;
-  for (int j = t; j < n; j += nt) {
+  const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;   // 16-lane groups (one DPP row each)
+  for (int j = grp; j < n; j += nGroups) {
     double s = 0;
-    for (int i = 0; i < n; ++i) s += a.Q[(size_t)j * n + i] * a.G[(size_t)j * n + i];
-    ev[j] = s;
+    for (int i = gl; i < n; i += 16) s += a.Q[(size_t)j * n + i] * a.G[(size_t)j * n + i];
+    s = rowSum16(s);
+    if (gl == 0) ev[j] = s;
   }
   __syncthreads();
-  if (t == 0) { double mx = ev[0]; for (int j = 1; j < n; ++j) mx = fmax(mx, ev[j]); smax = mx; }
+  if (t < 64) {
+    double mx = -1.0e300, mn = 1.0e300;
+    for (int j = t; j < n; j += 64) { mx = fmax(mx, ev[j]); mn = fmin(mn, ev[j]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); mn = fmin(mn, __shfl_xor(mn, o, 64)); }
+    const double tl = 2.220446049250313e-16 * n * mx;
+    int c = 0;
+    for (int j = t; j < n; j += 64) c += ev[j] <= tl;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (t == 0) { smax = mx; a.flag[2] = c; a.scal[1] = mn; a.scal[2] = mx; }
+  }
   __syncthreads();
   const double tol = 2.220446049250313e-16 * n * smax;
-  if (t == 0) { int c = 0; double mn = ev[0]; for (int j = 0; j < n; ++j) { c += ev[j] <= tol; mn = fmin(mn, ev[j]); } a.flag[2] = c; a.scal[1] = mn; a.scal[2] = smax; }
+  // J = (p U sqrt(S))^T: row i = eigen-direction i; kept in LDS (when the launch has it) for the J^T J below
+  const int ld = n | 1;
+  double* sJ = useLds ? jacobiLds : nullptr;
   for (int idx = t; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx % n;  // row i of J = eigen-direction i
+    const int i = idx / n, j = idx - i * n;
     const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
-    a.J[idx] = p[j] * a.Q[(size_t)i * n + j] * s;
+    const double v = p[j] * a.Q[idx] * s;
+    a.J[idx] = v;
+    if (sJ) sJ[i * ld + j] = v;
   }
-  for (int i = t; i < n; i += nt) {
-    const double si = ev[i] > tol ? sqrt(1.0 / ev[i]) : 0.0;
+  for (int i = grp; i < n; i += nGroups) {
     double e = 0;
-    for (int j = 0; j < n; ++j) e += si * a.Q[(size_t)i * n + j] * a.b0[j] / p[j];
-    a.e0[i] = -e;
+    for (int j = gl; j < n; j += 16) e += a.Q[(size_t)i * n + j] * (a.b0[j] / p[j]);
+    e = rowSum16(e);
+    if (gl == 0) a.e0[i] = ev[i] > tol ? -sqrt(1.0 / ev[i]) * e : 0.0;
   }
   __syncthreads();
-  for (int idx = t; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx % n;
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.J[(size_t)k * n + j];
-    a.Ht[idx] = s;
+  if (sJ) {
+    for (int idx = t; idx < n * n; idx += nt) {
+      const int i = idx / n, j = idx - i * n;
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += sJ[k * ld + i] * sJ[k * ld + j];
+      a.Ht[idx] = s;
+    }
+    for (int i = t; i < n; i += nt) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += sJ[k * ld + i] * a.e0[k];
+      a.bp[i] = s;
+    }
+  } else {
+    for (int idx = t; idx < n * n; idx += nt) {
+      const int i = idx / n, j = idx % n;
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.J[(size_t)k * n + j];
+      a.Ht[idx] = s;
+    }
+    for (int i = t; i < n; i += nt) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.e0[k];
+      a.bp[i] = s;
+    }
   }
-  for (int i = t; i < n; i += nt) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += a.J[(size_t)k * n + i] * a.e0[k];
-    a.bp[i] = s;
-  }
-  if (t == 0) {
+  if (t < 64) {
     double c = 0;
-    for (int k = 0; k < n; ++k) c += a.e0[k] * a.e0[k];
-    a.scal[0] = c;
+    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    c = waveSumM(c);
+    if (t == 0) {
+      a.scal[0] = c;
+      // 100 MHz ticks: prepare, eigen-solve, everything after it (printed under SVIN_MARG_TIMING)
+      a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
+    }
   }
 }
 
@@ -937,10 +1058,12 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       HIP_OK(hipStreamSynchronize(s));
       int fl[4] = {0, 0, 0, 0};
       HIP_OK(hipMemcpy(fl, bFlag.p, sizeof(fl), hipMemcpyDeviceToHost));
-      double sc3[3] = {0, 0, 0};
+      double sc3[6] = {0, 0, 0, 0, 0, 0};
       if (mb.bOut.p) HIP_OK(hipMemcpy(sc3, dbgScal, sizeof(sc3), hipMemcpyDeviceToHost));
       std::printf("[marg] m %d Lm %d; Jacobi sweeps of the last eigen-solve: %d; eigenvalues <= tol: %d (min %.3e max %.3e)\n", m, Lm,
                   fl[1], fl[2], sc3[1], sc3[2]);
+      std::printf("[marg] k_marg_final: prepare %.0f us, eigen-solve %.0f us, J / e0 / J^T J %.0f us\n", sc3[3] / 100.0, sc3[4] / 100.0,
+                  sc3[5] / 100.0);
     }
     (void)anyWork;
   }
