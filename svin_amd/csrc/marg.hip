@@ -162,9 +162,10 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
-constexpr int kJacobiRegCols = 9;   // a 16-lane group keeps columns of up to 9 x 16 = 144 entries in registers
+constexpr int kJacobiRegLen = 144;   // columns up to this (padded) length are held in registers by their lane group
 
-// one 32-bit half at a time through DPP row_ror:N (ctrl 0x120 + N): lane i of a 16-lane row reads lane (i - N) & 15
+// one 32-bit half at a time through DPP; kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane (i - N) & 15),
+// quad_perm = the four 2-bit selectors, row_half_mirror = 0x141 (lane i of an 8-lane half reads lane 7 - i)
 template <int kCtrl>
 __device__ __forceinline__ double dppRowMov(double v) {
   const long long b = __double_as_longlong(v);
@@ -182,6 +183,22 @@ __device__ __forceinline__ double rowSum16(double v) {
   v += dppRowMov<0x121>(v);
   return v;
 }
+// the same over the 8 lanes of half a row: xor 1, xor 2 (quad_perm [1 0 3 2], [2 3 0 1]), then the mirrored half
+__device__ __forceinline__ double halfRowSum8(double v) {
+  v += dppRowMov<0xB1>(v);
+  v += dppRowMov<0x4E>(v);
+  v += dppRowMov<0x141>(v);
+  return v;
+}
+template <int LPG> __device__ __forceinline__ double groupSum(double v);
+template <> __device__ __forceinline__ double groupSum<16>(double v) { return rowSum16(v); }
+template <> __device__ __forceinline__ double groupSum<8>(double v) { return halfRowSum8(v); }
+
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also waits for every outstanding global access
+// (s_waitcnt vmcnt(0)), which turns the fire-and-forget rotation-log stores of phase 1 and the read-ahead of phase 2
+// into one L2 round trip per tournament round.
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // pair k of round `round` of the round-robin tournament over np players (np even)
 __device__ __forceinline__ void jacobiPair(int np, int round, int k, int& a, int& b) {
   if (k == 0) { a = np - 1; b = round; return; }
@@ -197,12 +214,29 @@ __device__ __forceinline__ void jacobiRotation(double al, double be, double ga, 
   c = rsqrt(1.0 + tt * tt);
   s = c * tt;
 }
+// row length of the LDS images: the column length rounded up to the lane-group size (the tail is kept zero, so the
+// register path needs no predication), odd so that the columns of a round start on different banks
+__host__ __device__ inline int jacobiLd(int n) { return ((n + 15) & ~15) | 1; }
+// lanes per column pair: the solver is bound by VALU issue on its one CU (about 450 instructions per wave and round,
+// most of them per-pair overhead that does not depend on the group size), so large problems put eight pairs in a wave
+// instead of four; small ones have too few pairs for that to matter and keep the shorter 16-lane columns
+__device__ __forceinline__ bool jacobiNarrowGroups(int n) { return n > 64; }
 
-__device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, double2* rotLog = nullptr) {
+// Pointers into the LDS images carry their address space: through a generic double* every access is a FLAT
+// instruction (aperture check in the texture addresser, counted on vmcnt and lgkmcnt), several times slower than ds_*.
+using lds_double = __attribute__((address_space(3))) double;
+__device__ __forceinline__ lds_double* toLds(double* p) { return (lds_double*)p; }
+
+// LPG lanes per pair; P = lds_double* (the LDS images: every column has jacobiLd(n) addressable entries with a zero
+// tail) or double* (global memory, leading dimension n).
+template <int LPG, class P>
+__device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLog) {
+  constexpr bool padded = std::is_same<P, lds_double*>::value;
+  constexpr int kRegCols = kJacobiRegLen / LPG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
   if (n <= 1) return;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
-  const bool inRegs = n <= 16 * kJacobiRegCols;
+  const bool inRegs = padded && n <= kJacobiRegLen;
   // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
   // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
   // to keep the solver busy for all 40 sweeps).  Pairs with at least one significant column are still rotated.
@@ -226,8 +260,8 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
     __syncthreads();
     const double eps_n = 2.220446049250313e-16 * n;
     const double tol2 = nullTol2 * eps_n * eps_n;
-    // 16 lanes per pair (one DPP row): the n/2 disjoint pairs of a round run side by side, four per wave
-    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
+    // the n/2 disjoint pairs of a round run side by side, one lane group each
+    const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
     double2* logRound = rotLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
     bool rotated = false;
     for (int round = 0; round < np - 1; ++round, logRound += rotLog ? np / 2 : 0) {
@@ -240,24 +274,22 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
           continue;
         }
         const int pI = a < b ? a : b, qI = a < b ? b : a;
-        double* gp = G + pI * ld;
-        double* gq = G + qI * ld;
+        P gp = G + pI * ld + gl;
+        P gq = G + qI * ld + gl;
         double al = 0, be = 0, ga = 0;
-        double xs[kJacobiRegCols], ys[kJacobiRegCols];
+        double xs[kRegCols], ys[kRegCols];
         if (inRegs) {
 #pragma unroll
-          for (int u = 0; u < kJacobiRegCols; ++u) {
-            if (16 * u >= n) break;
-            const int i = gl + 16 * u;
-            const bool in = i < n;
-            const double x = in ? gp[i] : 0.0, y = in ? gq[i] : 0.0;
+          for (int u = 0; u < kRegCols; ++u) {
+            if (LPG * u >= n) break;
+            const double x = gp[LPG * u], y = gq[LPG * u];
             xs[u] = x; ys[u] = y;
             al += x * x; be += y * y; ga += x * y;
           }
         } else {
-          for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
+          for (int i = gl; i < n; i += LPG) { const double x = gp[i - gl], y = gq[i - gl]; al += x * x; be += y * y; ga += x * y; }
         }
-        al = rowSum16(al); be = rowSum16(be); ga = rowSum16(ga);
+        al = groupSum<LPG>(al); be = groupSum<LPG>(be); ga = groupSum<LPG>(ga);
         if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
           if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
           continue;
@@ -268,27 +300,27 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
         if (slot && gl == 0) *slot = make_double2(c, s);
         if (inRegs) {
 #pragma unroll
-          for (int u = 0; u < kJacobiRegCols; ++u) {
-            if (16 * u >= n) break;
-            const int i = gl + 16 * u;
-            if (i < n) { gp[i] = c * xs[u] - s * ys[u]; gq[i] = s * xs[u] + c * ys[u]; }
+          for (int u = 0; u < kRegCols; ++u) {
+            if (LPG * u >= n) break;
+            gp[LPG * u] = c * xs[u] - s * ys[u];
+            gq[LPG * u] = s * xs[u] + c * ys[u];
           }
         } else {
-          for (int i = gl; i < n; i += 16) {
-            const double x = gp[i], y = gq[i];
-            gp[i] = c * x - s * y; gq[i] = s * x + c * y;
+          for (int i = gl; i < n; i += LPG) {
+            const double x = gp[i - gl], y = gq[i - gl];
+            gp[i - gl] = c * x - s * y; gq[i - gl] = s * x + c * y;
           }
         }
         if (Q) {
-          double* vp = Q + pI * ld;
-          double* vq = Q + qI * ld;
-          for (int i = gl; i < n; i += 16) {
+          P vp = Q + pI * ld;
+          P vq = Q + qI * ld;
+          for (int i = gl; i < n; i += LPG) {
             const double u = vp[i], w = vq[i];
             vp[i] = c * u - s * w; vq[i] = s * u + c * w;
           }
         }
       }
-      __syncthreads();
+      if (padded) ldsBarrier(); else __syncthreads();   // padded = G and Q are LDS images
     }
     if (rotated) anyRotation = 1;   // racing stores of the same value
     if (threadIdx.x == 0) flag[1] = sweep + 1;
@@ -297,22 +329,27 @@ __device__ void jacobiEigBlock(double* G, double* Q, int n, int ld, int* flag, d
   }
   __syncthreads();
 }
+template <class P>
+__device__ void jacobiEigBlockAny(P G, P Q, int n, int ld, int* flag, double2* rotLog) {
+  if (jacobiNarrowGroups(n)) jacobiEigBlock<8, P>(G, Q, n, ld, flag, rotLog);
+  else jacobiEigBlock<16, P>(G, Q, n, ld, flag, rotLog);
+}
 
-// Same, with G and Q staged through LDS when the kernel was launched with 2*n*(n|1) doubles of dynamic shared
+// Same, with G and Q staged through LDS when the kernel was launched with 2*n*jacobiLd(n) doubles of dynamic shared
 // memory (lds != nullptr): every round of the tournament is one LDS round trip instead of a global-memory one
 // (12 sweeps x 50 rounds at n = 51: 1.9 ms -> 0.2 ms).
 __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
-  if (!lds) { jacobiEigBlock(G, Q, n, n, flag); return; }
-  const int ld = n | 1;
-  double* sG = lds;
-  double* sQ = lds + (size_t)n * ld;
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int i = idx / n, j = idx - i * n;
-    sG[i * ld + j] = G[idx];
-    sQ[i * ld + j] = Q[idx];
+  if (!lds) { jacobiEigBlockAny<double*>(G, Q, n, n, flag, nullptr); return; }
+  const int ld = jacobiLd(n);
+  lds_double* sG = toLds(lds);
+  lds_double* sQ = sG + n * ld;
+  for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
+    const int i = idx / ld, j = idx - i * ld;
+    sG[idx] = j < n ? G[i * n + j] : 0.0;
+    sQ[idx] = j < n ? Q[i * n + j] : 0.0;
   }
   __syncthreads();
-  jacobiEigBlock(sG, sQ, n, ld, flag);
+  jacobiEigBlockAny<lds_double*>(sG, sQ, n, ld, flag, nullptr);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     G[idx] = sG[i * ld + j];
@@ -325,26 +362,14 @@ __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
 // sweep / round / pair in global memory (fire-and-forget stores); phase 2 replays the log on Q = I in the same LDS.
 // (Reading the eigenvectors off G_j = lambda_j q_j instead is NOT good enough: for small eigenvalues the direction of
 // G_j is rounding noise, and e0 = -pinv(J^T) b0 amplifies it by 1 / lambda.)
-__device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double* lds, double2* rotLog) {
-  const int ld = n | 1, np = (n & 1) ? n + 1 : n;
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int i = idx / n, j = idx - i * n;
-    lds[i * ld + j] = G[idx];
-  }
-  __syncthreads();
-  jacobiEigBlock(lds, nullptr, n, ld, flag, rotLog);
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int i = idx / n, j = idx - i * n;
-    G[idx] = lds[i * ld + j];
-    lds[i * ld + j] = (i == j) ? 1.0 : 0.0;
-  }
-  __threadfence_block();
-  __syncthreads();
-  // replay: rotation (c, s) of pair k in round r sits at rotLog[r * half + k]; the log is read four rounds ahead so
-  // that the L2 round trip hides behind the rotations of the rounds in between
-  const int half = np / 2, R = flag[1] * (np - 1);
-  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, nGroups = blockDim.x >> 4;
-  const int k0 = grp, k1 = grp + nGroups;   // half <= 2 * nGroups (n <= 136, 64 groups)
+template <int LPG>
+__device__ void jacobiReplay(lds_double* lds, int n, int ld, int nRounds, const double2* rotLog) {
+  // rotation (c, s) of pair k in round r sits at rotLog[r * half + k]; the log is read four rounds ahead so that the
+  // L2 round trip hides behind the rotations of the rounds in between
+  constexpr int kRegCols = kJacobiRegLen / LPG;
+  const int np = (n & 1) ? n + 1 : n, half = np / 2;
+  const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
+  const int k0 = grp, k1 = grp + nGroups;   // half <= 2 * nGroups (n <= 144, at least 64 groups)
   const bool has0 = k0 < half, has1 = k1 < half;
   auto fetch = [&](int r, double2& c0, double2& c1) {
     const double2* row = rotLog + (size_t)r * half;
@@ -356,11 +381,13 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
     int a, b;
     jacobiPair(np, round, k, a, b);
     const int pI = a < b ? a : b, qI = a < b ? b : a;
-    double* vp = lds + pI * ld;
-    double* vq = lds + qI * ld;
-    for (int i = gl; i < n; i += 16) {
-      const double u = vp[i], w = vq[i];
-      vp[i] = cs.x * u - cs.y * w; vq[i] = cs.y * u + cs.x * w;
+    lds_double* vp = lds + pI * ld + gl;
+    lds_double* vq = lds + qI * ld + gl;
+#pragma unroll
+    for (int u = 0; u < kRegCols; ++u) {   // the zero tail of the padded columns stays zero
+      if (LPG * u >= n) break;
+      const double x = vp[LPG * u], w = vq[LPG * u];
+      vp[LPG * u] = cs.x * x - cs.y * w; vq[LPG * u] = cs.y * x + cs.x * w;
     }
   };
   constexpr int kAhead = 4;
@@ -368,36 +395,58 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
 #pragma unroll
   for (int u = 0; u < kAhead; ++u) {
     ring0[u] = ring1[u] = make_double2(1.0, 0.0);
-    if (u < R) fetch(u, ring0[u], ring1[u]);
+    if (u < nRounds) fetch(u, ring0[u], ring1[u]);
   }
   int round = 0;
-  for (int r0 = 0; r0 < R; r0 += kAhead) {
+  for (int r0 = 0; r0 < nRounds; r0 += kAhead) {
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const int r = r0 + u;
-      if (r >= R) break;
+      if (r >= nRounds) break;
       const double2 c0 = ring0[u], c1 = ring1[u];
-      if (r + kAhead < R) fetch(r + kAhead, ring0[u], ring1[u]);
+      if (r + kAhead < nRounds) fetch(r + kAhead, ring0[u], ring1[u]);
       if (has0) rotate(round, k0, c0);
       if (has1) rotate(round, k1, c1);
-      __syncthreads();
+      ldsBarrier();
       if (++round == np - 1) round = 0;
     }
   }
+}
+__device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double* ldsGeneric, double2* rotLog) {
+  lds_double* lds = toLds(ldsGeneric);
+  const int ld = jacobiLd(n), np = (n & 1) ? n + 1 : n;
+  for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
+    const int i = idx / ld, j = idx - i * ld;
+    lds[idx] = j < n ? G[i * n + j] : 0.0;
+  }
+  __syncthreads();
+  const long long tPhase1 = wall_clock64();
+  jacobiEigBlockAny<lds_double*>(lds, nullptr, n, ld, flag, rotLog);
+  if (threadIdx.x == 0) flag[3] = (int)((wall_clock64() - tPhase1) / 100);   // us, printed under SVIN_MARG_TIMING
+  for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
+    const int i = idx / ld, j = idx - i * ld;
+    if (j < n) G[i * n + j] = lds[idx];
+    lds[idx] = (i == j) ? 1.0 : 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int nRounds = flag[1] * (np - 1);
+  if (jacobiNarrowGroups(n)) jacobiReplay<8>(lds, n, ld, nRounds, rotLog);
+  else jacobiReplay<16>(lds, n, ld, nRounds, rotLog);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     Q[idx] = lds[i * ld + j];
   }
   __syncthreads();
 }
-constexpr size_t kJacobiLdsLimit = 150 * 1024;
+constexpr size_t kJacobiLdsLimit = 158 * 1024;   // 160 KB per workgroup less the static __shared__ scalars
 static size_t jacobiLdsBytes(int n) {
-  const size_t b = (size_t)2 * n * (n | 1) * sizeof(double);
+  const size_t b = (size_t)2 * n * jacobiLd(n) * sizeof(double);
   return b <= kJacobiLdsLimit ? b : 0;
 }
 static size_t jacobiLdsBytesGOnly(int n) {
-  const size_t b = (size_t)n * (n | 1) * sizeof(double);
-  return b <= kJacobiLdsLimit ? b : 0;
+  const size_t b = (size_t)n * jacobiLd(n) * sizeof(double);
+  return b <= kJacobiLdsLimit && n <= kJacobiRegLen ? b : 0;
 }
 
 // ---------------------------------------------------------------- M2: landmark part (:557-619)
@@ -560,10 +609,10 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
     a.Q[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const long long tPrep = wall_clock64();
+  const long long tPrep = wall_clock64(), cPrep = clock64();
   if (useLds == 2) jacobiEigTwoPhase(a.G, a.Q, n, a.flag, jacobiLds, a.rotLog);
   else jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
-  long long tEig = wall_clock64();
+  const long long tEig = wall_clock64(), cEig = clock64();
   __shared__ double smax;
   const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;   // 16-lane groups (one DPP row each)
   for (int j = grp; j < n; j += nGroups) {
@@ -588,8 +637,8 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   __syncthreads();
   const double tol = 2.220446049250313e-16 * n * smax;
   // J = (p U sqrt(S))^T: row i = eigen-direction i; kept in LDS (when the launch has it) for the J^T J below
-  const int ld = n | 1;
-  double* sJ = useLds ? jacobiLds : nullptr;
+  const int ld = jacobiLd(n);
+  lds_double* sJ = useLds ? toLds(jacobiLds) : nullptr;
   for (int idx = t; idx < n * n; idx += nt) {
     const int i = idx / n, j = idx - i * n;
     const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
@@ -637,6 +686,8 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
       a.scal[0] = c;
       // 100 MHz ticks: prepare, eigen-solve, everything after it (printed under SVIN_MARG_TIMING)
       a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
+      a.scal[6] = (double)(cEig - cPrep);   // shader clocks of the eigen-solve
+      a.scal[7] = (double)n;
     }
   }
 }
@@ -1058,11 +1109,12 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       HIP_OK(hipStreamSynchronize(s));
       int fl[4] = {0, 0, 0, 0};
       HIP_OK(hipMemcpy(fl, bFlag.p, sizeof(fl), hipMemcpyDeviceToHost));
-      double sc3[6] = {0, 0, 0, 0, 0, 0};
+      double sc3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (mb.bOut.p) HIP_OK(hipMemcpy(sc3, dbgScal, sizeof(sc3), hipMemcpyDeviceToHost));
       std::printf("[marg] m %d Lm %d; Jacobi sweeps of the last eigen-solve: %d; eigenvalues <= tol: %d (min %.3e max %.3e)\n", m, Lm,
                   fl[1], fl[2], sc3[1], sc3[2]);
-      std::printf("[marg] k_marg_final: prepare %.0f us, eigen-solve %.0f us, J / e0 / J^T J %.0f us\n", sc3[3] / 100.0, sc3[4] / 100.0,
+      std::printf("[marg] k_marg_final: n %d, prepare %.0f us, eigen-solve %.0f us (two-phase: phase 1 %d us; %.0f shader clocks per us), "
+                  "J / e0 / J^T J %.0f us\n", (int)sc3[7], sc3[3] / 100.0, sc3[4] / 100.0, fl[3], sc3[6] / std::max(1.0, sc3[4] / 100.0),
                   sc3[5] / 100.0);
     }
     (void)anyWork;
