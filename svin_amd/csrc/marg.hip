@@ -162,6 +162,9 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
+// de Rijk's column sorting (trade the two results when q is the longer column) costs sweeps in the round-robin
+// tournament, where a column's index says nothing about its neighbours: 18 -> 26 sweeps at n = 105.  Kept switchable.
+constexpr bool kJacobiSortColumns = false;
 constexpr int kJacobiRegLen = 144;   // columns up to this (padded) length are held in registers by their lane group
 
 // one 32-bit half at a time through DPP; kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane (i - N) & 15),
@@ -227,6 +230,13 @@ __device__ __forceinline__ bool jacobiNarrowGroups(int n) { return n > 64; }
 using lds_double = __attribute__((address_space(3))) double;
 __device__ __forceinline__ lds_double* toLds(double* p) { return (lds_double*)p; }
 
+// one copy for all instantiations of the solver
+struct JacobiShared {
+  double nullTol2;
+  int anyRotation;
+};
+__shared__ JacobiShared gJacobiShared;
+
 // LPG lanes per pair; P = lds_double* (the LDS images: every column has jacobiLd(n) addressable entries with a zero
 // tail) or double* (global memory, leading dimension n).
 template <int LPG, class P>
@@ -240,8 +250,10 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
   // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
   // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
   // to keep the solver busy for all 40 sweeps).  Pairs with at least one significant column are still rotated.
-  __shared__ double nullTol2;
-  __shared__ int anyRotation;
+  double& nullTol2 = gJacobiShared.nullTol2;
+  int& anyRotation = gJacobiShared.anyRotation;
+  // (Skipping pairs whose columns did not change since they were last found orthogonal buys nothing: the sweeps are
+  // dense, nearly every column still moves a little in every one of the 14 .. 19 sweeps.)
   for (int sweep = 0; sweep < 40; ++sweep) {
     __syncthreads();
     if (threadIdx.x == 0) { anyRotation = 0; nullTol2 = 0.0; }
@@ -297,26 +309,32 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
         rotated = true;
         double c, s;
         jacobiRotation(al, be, ga, c, s);
-        if (slot && gl == 0) *slot = make_double2(c, s);
+        // de Rijk's ordering: the rotation keeps the longer column longer, so when that is q the two results trade
+        // places and the columns drift towards decreasing norm, which saves sweeps on a graded spectrum
+        // (logged as a negative c)
+        const bool trade = kJacobiSortColumns && al < be;
+        if (slot && gl == 0) *slot = make_double2(trade ? -c : c, s);
+        P dp = trade ? gq : gp, dq = trade ? gp : gq;
         if (inRegs) {
 #pragma unroll
           for (int u = 0; u < kRegCols; ++u) {
             if (LPG * u >= n) break;
-            gp[LPG * u] = c * xs[u] - s * ys[u];
-            gq[LPG * u] = s * xs[u] + c * ys[u];
+            dp[LPG * u] = c * xs[u] - s * ys[u];
+            dq[LPG * u] = s * xs[u] + c * ys[u];
           }
         } else {
           for (int i = gl; i < n; i += LPG) {
             const double x = gp[i - gl], y = gq[i - gl];
-            gp[i - gl] = c * x - s * y; gq[i - gl] = s * x + c * y;
+            dp[i - gl] = c * x - s * y; dq[i - gl] = s * x + c * y;
           }
         }
         if (Q) {
           P vp = Q + pI * ld;
           P vq = Q + qI * ld;
+          P wp = trade ? vq : vp, wq = trade ? vp : vq;
           for (int i = gl; i < n; i += LPG) {
             const double u = vp[i], w = vq[i];
-            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
+            wp[i] = c * u - s * w; wq[i] = s * u + c * w;
           }
         }
       }
@@ -383,11 +401,15 @@ __device__ void jacobiReplay(lds_double* lds, int n, int ld, int nRounds, const 
     const int pI = a < b ? a : b, qI = a < b ? b : a;
     lds_double* vp = lds + pI * ld + gl;
     lds_double* vq = lds + qI * ld + gl;
+    const bool trade = cs.x < 0.0;   // the two results trade places (column sorting of phase 1)
+    const double c = fabs(cs.x), s = cs.y;
+    lds_double* wp = trade ? vq : vp;
+    lds_double* wq = trade ? vp : vq;
 #pragma unroll
     for (int u = 0; u < kRegCols; ++u) {   // the zero tail of the padded columns stays zero
       if (LPG * u >= n) break;
       const double x = vp[LPG * u], w = vq[LPG * u];
-      vp[LPG * u] = cs.x * x - cs.y * w; vq[LPG * u] = cs.y * x + cs.x * w;
+      wp[LPG * u] = c * x - s * w; wq[LPG * u] = s * x + c * w;
     }
   };
   constexpr int kAhead = 4;
@@ -439,7 +461,7 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
   }
   __syncthreads();
 }
-constexpr size_t kJacobiLdsLimit = 158 * 1024;   // 160 KB per workgroup less the static __shared__ scalars
+constexpr size_t kJacobiLdsLimit = 158 * 1024 - sizeof(JacobiShared);   // 160 KB per workgroup less the static __shared__ scalars
 static size_t jacobiLdsBytes(int n) {
   const size_t b = (size_t)2 * n * jacobiLd(n) * sizeof(double);
   return b <= kJacobiLdsLimit ? b : 0;
