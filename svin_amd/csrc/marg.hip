@@ -202,6 +202,28 @@ template <> __device__ __forceinline__ double groupSum<8>(double v) { return hal
 // into one L2 round trip per tournament round.
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// agent-scope accesses (sc1: served by L2, the coherence point between the two workgroups of the split solve)
+__device__ __forceinline__ void agentStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int agentLoad(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double2 agentLoad(const double2* p) {
+  const double* q = reinterpret_cast<const double*>(p);
+  return make_double2(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// A rotation-log entry.  Consecutive workgroups land on different XCDs, each with its own L2: what the replaying
+// workgroup is to see while the kernel runs has to be written through (sc1), not left in the writer's L2.
+__device__ __forceinline__ void logStore(double2* slot, double c, double s, bool coherent) {
+  if (coherent) {
+    double* q = reinterpret_cast<double*>(slot);
+    __hip_atomic_store(q, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *slot = make_double2(c, s);
+  }
+}
+__device__ __forceinline__ void waitGlobalStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int kJacobiChunk = 8;   // rounds between two progress reports of the producer (power of two)
+
 // pair k of round `round` of the round-robin tournament over np players (np even)
 __device__ __forceinline__ void jacobiPair(int np, int round, int k, int& a, int& b) {
   if (k == 0) { a = np - 1; b = round; return; }
@@ -234,19 +256,23 @@ __device__ __forceinline__ lds_double* toLds(double* p) { return (lds_double*)p;
 struct JacobiShared {
   double nullTol2;
   int anyRotation;
+  int avail, done;   // consumer side of the two-workgroup solve
 };
 __shared__ JacobiShared gJacobiShared;
 
 // LPG lanes per pair; P = lds_double* (the LDS images: every column has jacobiLd(n) addressable entries with a zero
 // tail) or double* (global memory, leading dimension n).
+// progress (optional): the number of tournament rounds whose rotation-log entries are visible at L2, reported every
+// kJacobiChunk rounds for the workgroup that replays them.  Returns the number of sweeps.
 template <int LPG, class P>
-__device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLog) {
+__device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLog, int* progress) {
   constexpr bool padded = std::is_same<P, lds_double*>::value;
   constexpr int kRegCols = kJacobiRegLen / LPG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
-  if (n <= 1) return;
+  if (n <= 1) return 0;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
   const bool inRegs = padded && n <= kJacobiRegLen;
+  int sweeps = 0;
   // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
   // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
   // to keep the solver busy for all 40 sweeps).  Pairs with at least one significant column are still rotated.
@@ -282,7 +308,7 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
         jacobiPair(np, round, k, a, b);
         double2* slot = rotLog ? logRound + k : nullptr;
         if (a >= n || b >= n) {
-          if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
+          if (slot && gl == 0) logStore(slot, 1.0, 0.0, progress != nullptr);
           continue;
         }
         const int pI = a < b ? a : b, qI = a < b ? b : a;
@@ -303,7 +329,7 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
         }
         al = groupSum<LPG>(al); be = groupSum<LPG>(be); ga = groupSum<LPG>(ga);
         if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
-          if (slot && gl == 0) *slot = make_double2(1.0, 0.0);
+          if (slot && gl == 0) logStore(slot, 1.0, 0.0, progress != nullptr);
           continue;
         }
         rotated = true;
@@ -313,7 +339,7 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
         // places and the columns drift towards decreasing norm, which saves sweeps on a graded spectrum
         // (logged as a negative c)
         const bool trade = kJacobiSortColumns && al < be;
-        if (slot && gl == 0) *slot = make_double2(trade ? -c : c, s);
+        if (slot && gl == 0) logStore(slot, trade ? -c : c, s, progress != nullptr);
         P dp = trade ? gq : gp, dq = trade ? gp : gq;
         if (inRegs) {
 #pragma unroll
@@ -338,19 +364,25 @@ __device__ void jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotL
           }
         }
       }
+      const int roundsDone = sweep * (np - 1) + round + 1;
+      const bool report = progress && (roundsDone & (kJacobiChunk - 1)) == 0;
+      if (report) waitGlobalStores();   // this wave's log entries have reached L2 ...
       if (padded) ldsBarrier(); else __syncthreads();   // padded = G and Q are LDS images
+      if (report && threadIdx.x == 0) agentStore(progress, roundsDone);   // ... and so have everybody else's
     }
     if (rotated) anyRotation = 1;   // racing stores of the same value
     if (threadIdx.x == 0) flag[1] = sweep + 1;
+    sweeps = sweep + 1;
     __syncthreads();
     if (anyRotation == 0) break;
   }
   __syncthreads();
+  return sweeps;
 }
 template <class P>
-__device__ void jacobiEigBlockAny(P G, P Q, int n, int ld, int* flag, double2* rotLog) {
-  if (jacobiNarrowGroups(n)) jacobiEigBlock<8, P>(G, Q, n, ld, flag, rotLog);
-  else jacobiEigBlock<16, P>(G, Q, n, ld, flag, rotLog);
+__device__ int jacobiEigBlockAny(P G, P Q, int n, int ld, int* flag, double2* rotLog, int* progress = nullptr) {
+  if (jacobiNarrowGroups(n)) return jacobiEigBlock<8, P>(G, Q, n, ld, flag, rotLog, progress);
+  return jacobiEigBlock<16, P>(G, Q, n, ld, flag, rotLog, progress);
 }
 
 // Same, with G and Q staged through LDS when the kernel was launched with 2*n*jacobiLd(n) doubles of dynamic shared
@@ -380,8 +412,9 @@ __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
 // sweep / round / pair in global memory (fire-and-forget stores); phase 2 replays the log on Q = I in the same LDS.
 // (Reading the eigenvectors off G_j = lambda_j q_j instead is NOT good enough: for small eigenvalues the direction of
 // G_j is rounding noise, and e0 = -pinv(J^T) b0 amplifies it by 1 / lambda.)
-template <int LPG>
-__device__ void jacobiReplay(lds_double* lds, int n, int ld, int nRounds, const double2* rotLog) {
+// rounds [rBegin, rEnd) of the log; kCoherent: the log is being written by another workgroup (read it at L2)
+template <int LPG, bool kCoherent>
+__device__ void jacobiReplay(lds_double* lds, int n, int ld, int rBegin, int rEnd, const double2* rotLog) {
   // rotation (c, s) of pair k in round r sits at rotLog[r * half + k]; the log is read four rounds ahead so that the
   // L2 round trip hides behind the rotations of the rounds in between
   constexpr int kRegCols = kJacobiRegLen / LPG;
@@ -391,8 +424,13 @@ __device__ void jacobiReplay(lds_double* lds, int n, int ld, int nRounds, const 
   const bool has0 = k0 < half, has1 = k1 < half;
   auto fetch = [&](int r, double2& c0, double2& c1) {
     const double2* row = rotLog + (size_t)r * half;
-    c0 = has0 ? row[k0] : make_double2(1.0, 0.0);
-    c1 = has1 ? row[k1] : make_double2(1.0, 0.0);
+    if (kCoherent) {
+      c0 = has0 ? agentLoad(row + k0) : make_double2(1.0, 0.0);
+      c1 = has1 ? agentLoad(row + k1) : make_double2(1.0, 0.0);
+    } else {
+      c0 = has0 ? row[k0] : make_double2(1.0, 0.0);
+      c1 = has1 ? row[k1] : make_double2(1.0, 0.0);
+    }
   };
   auto rotate = [&](int round, int k, const double2 cs) {
     if (cs.y == 0.0) return;
@@ -417,16 +455,16 @@ __device__ void jacobiReplay(lds_double* lds, int n, int ld, int nRounds, const 
 #pragma unroll
   for (int u = 0; u < kAhead; ++u) {
     ring0[u] = ring1[u] = make_double2(1.0, 0.0);
-    if (u < nRounds) fetch(u, ring0[u], ring1[u]);
+    if (rBegin + u < rEnd) fetch(rBegin + u, ring0[u], ring1[u]);
   }
-  int round = 0;
-  for (int r0 = 0; r0 < nRounds; r0 += kAhead) {
+  int round = rBegin % (np - 1);
+  for (int r0 = rBegin; r0 < rEnd; r0 += kAhead) {
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
       const int r = r0 + u;
-      if (r >= nRounds) break;
+      if (r >= rEnd) break;
       const double2 c0 = ring0[u], c1 = ring1[u];
-      if (r + kAhead < nRounds) fetch(r + kAhead, ring0[u], ring1[u]);
+      if (r + kAhead < rEnd) fetch(r + kAhead, ring0[u], ring1[u]);
       if (has0) rotate(round, k0, c0);
       if (has1) rotate(round, k1, c1);
       ldsBarrier();
@@ -453,8 +491,8 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
   __threadfence_block();
   __syncthreads();
   const int nRounds = flag[1] * (np - 1);
-  if (jacobiNarrowGroups(n)) jacobiReplay<8>(lds, n, ld, nRounds, rotLog);
-  else jacobiReplay<16>(lds, n, ld, nRounds, rotLog);
+  if (jacobiNarrowGroups(n)) jacobiReplay<8, false>(lds, n, ld, 0, nRounds, rotLog);
+  else jacobiReplay<16, false>(lds, n, ld, 0, nRounds, rotLog);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     Q[idx] = lds[i * ld + j];
@@ -614,8 +652,151 @@ struct FinalArgs {
   int* flag;
   double2* rotLog;   // two-phase eigen-solve (96 < n <= 136): 40 sweeps x (np - 1) rounds x np / 2 pairs
 };
+// ---- split solve (mode 3): two workgroups on two CUs.  Workgroup 0 rotates G in its LDS and streams the rotation log;
+// workgroup 1 replays the log on Q = I in its own LDS as the rounds are reported, then builds J, e0, J^T J, J^T e0.
+// flag[4] = rounds whose log entries are visible, flag[5] = number of sweeps once G is final in global memory (both
+// zeroed by the host before the launch).  Only workgroup 1 ever waits, so the pair cannot deadlock whatever order the
+// two are scheduled in; its wait is bounded all the same (flag[0] = 1 on timeout).
+__device__ __forceinline__ double margScale(double hd) { return (hd > 1.0e-9) ? sqrt(hd) : 1.0e-3; }
+
+__device__ void margFinalProducer(const FinalArgs& a, lds_double* lds) {
+  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n), np = (n & 1) ? n + 1 : n;
+  for (int idx = t; idx < n * ld; idx += nt) {
+    const int i = idx / ld, j = idx - i * ld;
+    double v = 0.0;
+    if (j < n) {
+      const double pi = margScale(a.H[(size_t)i * n + i]), pj = margScale(a.H[(size_t)j * n + j]);
+      v = 0.5 * (a.H[(size_t)i * n + j] + a.H[(size_t)j * n + i]) / (pi * pj);
+    }
+    lds[idx] = v;
+  }
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  const int sweeps = jacobiEigBlockAny<lds_double*>(lds, (lds_double*)nullptr, n, ld, a.flag, a.rotLog, a.flag + 4);
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    __hip_atomic_store(a.G + idx, (double)lds[i * ld + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through, see logStore
+  }
+  waitGlobalStores();
+  __syncthreads();
+  if (t == 0) {
+    a.flag[3] = (int)((wall_clock64() - t0) / 100);
+    agentStore(a.flag + 4, sweeps * (np - 1));
+    waitGlobalStores();   // the final round count is in place before the consumer can see `done`
+    agentStore(a.flag + 5, sweeps > 0 ? sweeps : 1);
+  }
+}
+
+__device__ void margFinalConsumer(const FinalArgs& a, lds_double* lds) {
+  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n);
+  const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;
+  double* p = a.tmp;        // n
+  double* ev = a.tmp + n;   // n
+  const long long tStart = wall_clock64();
+  for (int i = t; i < n; i += nt) p[i] = margScale(a.H[(size_t)i * n + i]);
+  for (int idx = t; idx < n * ld; idx += nt) {
+    const int i = idx / ld, j = idx - i * ld;
+    lds[idx] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const long long tPrep = wall_clock64(), cPrep = clock64();
+  int processed = 0;
+  for (;;) {
+    if (t == 0) {
+      int d = 0, av = processed;
+      for (long long spins = 0; spins < (1ll << 21); ++spins) {
+        d = agentLoad(a.flag + 5);
+        if (d != 0) { av = agentLoad(a.flag + 4); break; }   // read after `done` was seen: the final count
+        av = agentLoad(a.flag + 4);
+        if (av > processed) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (d == 0 && av <= processed) { d = -1; a.flag[0] = 1; }   // producer never showed up
+      gJacobiShared.avail = av; gJacobiShared.done = d;
+    }
+    __syncthreads();
+    const int av = gJacobiShared.avail, d = gJacobiShared.done;
+    __syncthreads();
+    if (av > processed) {
+      if (jacobiNarrowGroups(n)) jacobiReplay<8, true>(lds, n, ld, processed, av, a.rotLog);
+      else jacobiReplay<16, true>(lds, n, ld, processed, av, a.rotLog);
+      processed = av;
+    }
+    if (d != 0) break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // G of the producer
+  __syncthreads();
+  const long long tEig = wall_clock64(), cEig = clock64();
+  // rows of the LDS image = eigenvectors; eigenvalue j = Q_j . G_j
+  for (int j = grp; j < n; j += nGroups) {
+    double s = 0;
+    for (int i = gl; i < n; i += 16)
+      s += lds[j * ld + i] * __hip_atomic_load(a.G + (size_t)j * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = rowSum16(s);
+    if (gl == 0) ev[j] = s;
+  }
+  __syncthreads();
+  if (t < 64) {
+    double mx = -1.0e300, mn = 1.0e300;
+    for (int j = t; j < n; j += 64) { mx = fmax(mx, ev[j]); mn = fmin(mn, ev[j]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); mn = fmin(mn, __shfl_xor(mn, o, 64)); }
+    const double tl = 2.220446049250313e-16 * n * mx;
+    int c = 0;
+    for (int j = t; j < n; j += 64) c += ev[j] <= tl;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (t == 0) { gJacobiShared.nullTol2 = mx; a.flag[2] = c; a.scal[1] = mn; a.scal[2] = mx; }
+  }
+  __syncthreads();
+  const double tol = 2.220446049250313e-16 * n * gJacobiShared.nullTol2;
+  for (int i = grp; i < n; i += nGroups) {
+    double e = 0;
+    for (int j = gl; j < n; j += 16) e += lds[i * ld + j] * (a.b0[j] / p[j]);
+    e = rowSum16(e);
+    if (gl == 0) a.e0[i] = ev[i] > tol ? -sqrt(1.0 / ev[i]) * e : 0.0;
+  }
+  __syncthreads();
+  // J = (p U sqrt(S))^T in place of Q
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
+    const double v = p[j] * lds[i * ld + j] * s;
+    a.J[idx] = v;
+    lds[i * ld + j] = v;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * lds[k * ld + j];
+    a.Ht[idx] = s;
+  }
+  for (int i = t; i < n; i += nt) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * a.e0[k];
+    a.bp[i] = s;
+  }
+  if (t < 64) {
+    double c = 0;
+    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    c = waveSumM(c);
+    if (t == 0) {
+      a.scal[0] = c;
+      a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
+      a.scal[6] = (double)(cEig - cPrep);
+      a.scal[7] = (double)n;
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   extern __shared__ double jacobiLds[];
+  if (useLds == 3) {
+    if (blockIdx.x == 0) margFinalProducer(a, toLds(jacobiLds));
+    else margFinalConsumer(a, toLds(jacobiLds));
+    return;
+  }
   const int t = threadIdx.x, nt = blockDim.x, n = a.n;
   double* p = a.tmp;        // n
   double* ev = a.tmp + n;   // n
@@ -1015,7 +1196,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     bFacLin.reserve(std::max(F, 1));
     bPartial.reserve((size_t)16 * 4096);
     bScal.reserve(1);
-    bFlag.reserve(4);
+    bFlag.reserve(8);
     const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
     bU.reserve(mm * mm); bW2.reserve(mm * L3); bV.reserve((size_t)9 * std::max(Lm, 1)); bVec.reserve(mm + 2 * L3 + 16);
     HIP_OK(hipMemsetAsync(bU.p, 0, sizeof(double) * mm * mm, s));
@@ -1116,13 +1297,15 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         fa.rotLog = nullptr;
         static const bool noTwoPhase = getenv("SVIN_MARG_NO_TWOPHASE") != nullptr;   // A/B switch
         if (!lds && !noTwoPhase && (lds = jacobiLdsBytesGOnly(nk)) != 0) {   // G and Q take turns in LDS
-          mode = 2;
+          static const bool noSplit = getenv("SVIN_MARG_NO_SPLIT") != nullptr;   // A/B switch: both phases in one workgroup
+          mode = noSplit ? 2 : 3;
           const size_t npk = (nk & 1) ? nk + 1 : nk;
           mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
           fa.rotLog = reinterpret_cast<double2*>(mb.bRotLog.p);
         }
         if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode);
+        if (mode == 3) HIP_OK(hipMemsetAsync(bFlag.p + 4, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_marg_final, dim3(mode == 3 ? 2 : 1), dim3(1024), lds, s, fa, mode);
       }
       priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     }
