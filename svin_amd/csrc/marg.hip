@@ -230,14 +230,17 @@ __device__ __forceinline__ void jacobiPair(int np, int round, int k, int& a, int
   a = round + k; if (a >= np - 1) a -= np - 1;
   b = round - k; if (b < 0) b += np - 1;
 }
-// Jacobi rotation that orthogonalises two columns with |p|^2 = al, |q|^2 = be, p.q = ga: t = tan(theta) is the smaller
-// root of t^2 + 2 zeta t - 1 = 0, zeta = (be - al) / (2 ga), written with one sqrt, one division and one rsqrt
+// Jacobi rotation that orthogonalises two columns with |p|^2 = al, |q|^2 = be, p.q = ga: the small-angle solution of
+// tan(2 theta) = 2 ga / (be - al).  The rotation sits on the critical path of every tournament round, so it is written
+// with two reciprocal square roots and no division: with h = hypot(be - al, 2 ga), cos(2 theta) = |be - al| / h and
+// x = (1 + cos(2 theta)) / 2 in [1/2, 1]:  c = sqrt(x) = x rsqrt(x),  s = sin(2 theta) / (2 c) = sin(2 theta) rsqrt(x) / 2.
 __device__ __forceinline__ void jacobiRotation(double al, double be, double ga, double& c, double& s) {
   const double d = be - al, g2 = 2.0 * ga;
-  const double hyp = sqrt(d * d + g2 * g2);
-  const double tt = g2 / (d + copysign(hyp, d));
-  c = rsqrt(1.0 + tt * tt);
-  s = c * tt;
+  const double rh = rsqrt(d * d + g2 * g2);
+  const double x = 0.5 + 0.5 * fabs(d) * rh;
+  const double rx = rsqrt(x);
+  c = x * rx;
+  s = copysign(0.5 * g2 * rh * rx, d * g2);
 }
 // row length of the LDS images: the column length rounded up to the lane-group size (the tail is kept zero, so the
 // register path needs no predication), odd so that the columns of a round start on different banks
@@ -1295,9 +1298,13 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         size_t lds = jacobiLdsBytes(nk);
         int mode = lds ? 1 : 0;
         fa.rotLog = nullptr;
-        static const bool noTwoPhase = getenv("SVIN_MARG_NO_TWOPHASE") != nullptr;   // A/B switch
-        if (!lds && !noTwoPhase && (lds = jacobiLdsBytesGOnly(nk)) != 0) {   // G and Q take turns in LDS
-          static const bool noSplit = getenv("SVIN_MARG_NO_SPLIT") != nullptr;   // A/B switch: both phases in one workgroup
+        static const bool noTwoPhase = getenv("SVIN_MARG_NO_TWOPHASE") != nullptr;   // A/B switches
+        static const bool noSplit = getenv("SVIN_MARG_NO_SPLIT") != nullptr;
+        // G and Q in one LDS (mode 1) only for small problems or on request; otherwise one LDS image each: in two
+        // workgroups side by side (mode 3), or taking turns in one (mode 2)
+        const bool separate = !noTwoPhase && jacobiLdsBytesGOnly(nk) != 0 && (!lds || (!noSplit && nk >= 32));
+        if (separate) {
+          lds = jacobiLdsBytesGOnly(nk);
           mode = noSplit ? 2 : 3;
           const size_t npk = (nk & 1) ? nk + 1 : nk;
           mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
