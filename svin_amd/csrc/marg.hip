@@ -245,11 +245,9 @@ __device__ __forceinline__ void jacobiRotation(double al, double be, double ga, 
 // row length of the LDS images: the column length rounded up to the lane-group size (the tail is kept zero, so the
 // register path needs no predication), odd so that the columns of a round start on different banks
 __host__ __device__ inline int jacobiLd(int n) { return ((n + 15) & ~15) | 1; }
-// lanes per column pair: the solver is bound by VALU issue on its one CU (about 450 instructions per wave and round,
-// most of them per-pair overhead that does not depend on the group size), so large problems put eight pairs in a wave
-// instead of four; small ones have too few pairs for that to matter and keep the shorter 16-lane columns
-__device__ __forceinline__ bool jacobiNarrowGroups(int n) { return n > 64; }
-
+// Lanes per column pair: 16 (one DPP row).  A tournament round is one dependent chain per wave (LDS read -> inner
+// products -> reduce -> rotation -> LDS write -> barrier) and what it costs is that chain's instruction count, not VALU
+// throughput: 8 lanes per pair (twice the per-lane column length) measured 11 % slower at n = 105.
 // Pointers into the LDS images carry their address space: through a generic double* every access is a FLAT
 // instruction (aperture check in the texture addresser, counted on vmcnt and lgkmcnt), several times slower than ds_*.
 using lds_double = __attribute__((address_space(3))) double;
@@ -267,14 +265,16 @@ __shared__ JacobiShared gJacobiShared;
 // tail) or double* (global memory, leading dimension n).
 // progress (optional): the number of tournament rounds whose rotation-log entries are visible at L2, reported every
 // kJacobiChunk rounds for the workgroup that replays them.  Returns the number of sweeps.
-template <int LPG, class P>
+// kHasQ: rotate the rows of Q along with G.  kLog: 0 no rotation log, 1 plain stores, 2 written through for a consumer
+// workgroup (with progress reports).  Compile-time so that each use gets a straight-line round.
+template <int LPG, class P, bool kHasQ, int kLog>
 __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLog, int* progress) {
   constexpr bool padded = std::is_same<P, lds_double*>::value;
   constexpr int kRegCols = kJacobiRegLen / LPG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
   if (n <= 1) return 0;
   const int np = (n & 1) ? n + 1 : n;  // phantom player when n is odd
-  const bool inRegs = padded && n <= kJacobiRegLen;
+  constexpr bool inRegs = padded;   // the LDS images exist for n <= 136 < kJacobiRegLen only
   int sweeps = 0;
   // Columns whose norm (= |eigenvalue|) is below eps*n*max-norm belong to the numerical null space: the callers zero
   // those eigenvalues anyway, and rotating two such columns against each other only chases rounding noise (it used
@@ -303,15 +303,15 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
     const double tol2 = nullTol2 * eps_n * eps_n;
     // the n/2 disjoint pairs of a round run side by side, one lane group each
     const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
-    double2* logRound = rotLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
+    double2* logRound = kLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
     bool rotated = false;
-    for (int round = 0; round < np - 1; ++round, logRound += rotLog ? np / 2 : 0) {
+    for (int round = 0; round < np - 1; ++round, logRound += kLog ? np / 2 : 0) {
       for (int k = grp; k < np / 2; k += nGroups) {
         int a, b;
         jacobiPair(np, round, k, a, b);
-        double2* slot = rotLog ? logRound + k : nullptr;
+        double2* slot = kLog ? logRound + k : nullptr;
         if (a >= n || b >= n) {
-          if (slot && gl == 0) logStore(slot, 1.0, 0.0, progress != nullptr);
+          if (kLog && gl == 0) logStore(slot, 1.0, 0.0, kLog == 2);
           continue;
         }
         const int pI = a < b ? a : b, qI = a < b ? b : a;
@@ -332,7 +332,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         }
         al = groupSum<LPG>(al); be = groupSum<LPG>(be); ga = groupSum<LPG>(ga);
         if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
-          if (slot && gl == 0) logStore(slot, 1.0, 0.0, progress != nullptr);
+          if (kLog && gl == 0) logStore(slot, 1.0, 0.0, kLog == 2);
           continue;
         }
         rotated = true;
@@ -342,7 +342,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         // places and the columns drift towards decreasing norm, which saves sweeps on a graded spectrum
         // (logged as a negative c)
         const bool trade = kJacobiSortColumns && al < be;
-        if (slot && gl == 0) logStore(slot, trade ? -c : c, s, progress != nullptr);
+        if (kLog && gl == 0) logStore(slot, trade ? -c : c, s, kLog == 2);
         P dp = trade ? gq : gp, dq = trade ? gp : gq;
         if (inRegs) {
 #pragma unroll
@@ -357,7 +357,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
             dp[i - gl] = c * x - s * y; dq[i - gl] = s * x + c * y;
           }
         }
-        if (Q) {
+        if (kHasQ) {
           P vp = Q + pI * ld;
           P vq = Q + qI * ld;
           P wp = trade ? vq : vp, wq = trade ? vp : vq;
@@ -368,7 +368,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         }
       }
       const int roundsDone = sweep * (np - 1) + round + 1;
-      const bool report = progress && (roundsDone & (kJacobiChunk - 1)) == 0;
+      const bool report = kLog == 2 && (roundsDone & (kJacobiChunk - 1)) == 0;
       if (report) waitGlobalStores();   // this wave's log entries have reached L2 ...
       if (padded) ldsBarrier(); else __syncthreads();   // padded = G and Q are LDS images
       if (report && threadIdx.x == 0) agentStore(progress, roundsDone);   // ... and so have everybody else's
@@ -382,17 +382,13 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
   __syncthreads();
   return sweeps;
 }
-template <class P>
-__device__ int jacobiEigBlockAny(P G, P Q, int n, int ld, int* flag, double2* rotLog, int* progress = nullptr) {
-  if (jacobiNarrowGroups(n)) return jacobiEigBlock<8, P>(G, Q, n, ld, flag, rotLog, progress);
-  return jacobiEigBlock<16, P>(G, Q, n, ld, flag, rotLog, progress);
-}
+constexpr int kJacobiLanes = 16;
 
 // Same, with G and Q staged through LDS when the kernel was launched with 2*n*jacobiLd(n) doubles of dynamic shared
 // memory (lds != nullptr): every round of the tournament is one LDS round trip instead of a global-memory one
 // (12 sweeps x 50 rounds at n = 51: 1.9 ms -> 0.2 ms).
 __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
-  if (!lds) { jacobiEigBlockAny<double*>(G, Q, n, n, flag, nullptr); return; }
+  if (!lds) { jacobiEigBlock<kJacobiLanes, double*, true, 0>(G, Q, n, n, flag, nullptr, nullptr); return; }
   const int ld = jacobiLd(n);
   lds_double* sG = toLds(lds);
   lds_double* sQ = sG + n * ld;
@@ -402,7 +398,7 @@ __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
     sQ[idx] = j < n ? Q[i * n + j] : 0.0;
   }
   __syncthreads();
-  jacobiEigBlockAny<lds_double*>(sG, sQ, n, ld, flag, nullptr);
+  jacobiEigBlock<kJacobiLanes, lds_double*, true, 0>(sG, sQ, n, ld, flag, nullptr, nullptr);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     G[idx] = sG[i * ld + j];
@@ -484,7 +480,7 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
   }
   __syncthreads();
   const long long tPhase1 = wall_clock64();
-  jacobiEigBlockAny<lds_double*>(lds, nullptr, n, ld, flag, rotLog);
+  jacobiEigBlock<kJacobiLanes, lds_double*, false, 1>(lds, (lds_double*)nullptr, n, ld, flag, rotLog, nullptr);
   if (threadIdx.x == 0) flag[3] = (int)((wall_clock64() - tPhase1) / 100);   // us, printed under SVIN_MARG_TIMING
   for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
     const int i = idx / ld, j = idx - i * ld;
@@ -494,8 +490,7 @@ __device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double
   __threadfence_block();
   __syncthreads();
   const int nRounds = flag[1] * (np - 1);
-  if (jacobiNarrowGroups(n)) jacobiReplay<8, false>(lds, n, ld, 0, nRounds, rotLog);
-  else jacobiReplay<16, false>(lds, n, ld, 0, nRounds, rotLog);
+  jacobiReplay<kJacobiLanes, false>(lds, n, ld, 0, nRounds, rotLog);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     Q[idx] = lds[i * ld + j];
@@ -675,7 +670,7 @@ __device__ void margFinalProducer(const FinalArgs& a, lds_double* lds) {
   }
   __syncthreads();
   const long long t0 = wall_clock64();
-  const int sweeps = jacobiEigBlockAny<lds_double*>(lds, (lds_double*)nullptr, n, ld, a.flag, a.rotLog, a.flag + 4);
+  const int sweeps = jacobiEigBlock<kJacobiLanes, lds_double*, false, 2>(lds, (lds_double*)nullptr, n, ld, a.flag, a.rotLog, a.flag + 4);
   for (int idx = t; idx < n * n; idx += nt) {
     const int i = idx / n, j = idx - i * n;
     __hip_atomic_store(a.G + idx, (double)lds[i * ld + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through, see logStore
@@ -721,8 +716,7 @@ __device__ void margFinalConsumer(const FinalArgs& a, lds_double* lds) {
     const int av = gJacobiShared.avail, d = gJacobiShared.done;
     __syncthreads();
     if (av > processed) {
-      if (jacobiNarrowGroups(n)) jacobiReplay<8, true>(lds, n, ld, processed, av, a.rotLog);
-      else jacobiReplay<16, true>(lds, n, ld, processed, av, a.rotLog);
+      jacobiReplay<kJacobiLanes, true>(lds, n, ld, processed, av, a.rotLog);
       processed = av;
     }
     if (d != 0) break;
