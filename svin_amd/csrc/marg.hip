@@ -787,8 +787,128 @@ __device__ void margFinalConsumer(const FinalArgs& a, lds_double* lds) {
   }
 }
 
+// ---- Cholesky-preconditioned solve (mode 4, Veselic / Hari): A + delta I = R^T R, then one-sided Jacobi on the rows of R
+// (the columns of L = R^T).  R V = Sigma U^T with U the eigenvectors of A and sigma_j^2 = lambda_j + delta, so the
+// eigenvectors come out of the rotated rows themselves - no Q, no rotation log, no second workgroup - and because the
+// rows of R carry the square roots of the spectrum (condition 1e6 instead of 1e15 for the columns of A) the tournament
+// converges in 11-12 sweeps instead of 18-19.  delta = 64 n eps (A has a unit diagonal) keeps the factorisation away
+// from the rounding-negative eigenvalues of the numerically semidefinite A and is removed again from sigma^2 exactly
+// (sigma^2 >= delta is computed to relative precision); an eigen-direction is reliable to eps |R| / sigma_j, i.e. 1e-10 for
+// the null space (which is dropped) and better than 1e-12 for everything above 1e-8.  Returns false (uniformly) if a
+// pivot is not positive; the caller then runs the two-phase solve.
+__device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
+  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n);
+  const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
+  const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;
+  double* p = a.tmp;            // n
+  double* ev = a.tmp + n;       // n
+  double* rsig = a.tmp + 2 * n; // n: 1 / sigma_j
+  const double delta = 64.0 * n * 2.220446049250313e-16;
+  const long long tStart = wall_clock64();
+  for (int i = t; i < n; i += nt) p[i] = margScale(a.H[(size_t)i * n + i]);
+  // upper triangle of A + delta I, the rest (lower triangle and the padding) zero
+  for (int idx = t; idx < n * ld; idx += nt) {
+    const int r = idx / ld, c = idx - r * ld;
+    double v = 0.0;
+    if (c >= r && c < n) {
+      const double pr = margScale(a.H[(size_t)r * n + r]), pc = margScale(a.H[(size_t)c * n + c]);
+      v = 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (pr * pc) + (r == c ? delta : 0.0);
+    }
+    lds[idx] = v;
+  }
+  __syncthreads();
+  // right-looking Cholesky on the upper triangle; row k is left unscaled (A[j][i] -= A[k][j] A[k][i] / A[k][k]) so that
+  // a step is one pass and one barrier, and scaled afterwards
+  for (int k = 0; k < n - 1; ++k) {
+    const double pivot = lds[k * ld + k];
+    if (!(pivot > 0.0)) return false;
+    const double rp = 1.0 / pivot;
+    for (int j = k + 1 + wave; j < n; j += nWaves) {
+      const double f = lds[k * ld + j] * rp;
+      for (int i = j + lane; i < n; i += 64) lds[j * ld + i] -= f * lds[k * ld + i];
+    }
+    ldsBarrier();
+  }
+  if (!(lds[(n - 1) * ld + (n - 1)] > 0.0)) return false;
+  for (int k = wave; k < n; k += nWaves) {
+    const double rs = rsqrt(lds[k * ld + k]);
+    for (int i = k + lane; i < n; i += 64) lds[k * ld + i] *= rs;
+  }
+  __syncthreads();
+  const long long tPrep = wall_clock64(), cPrep = clock64();
+  jacobiEigBlock<kJacobiLanes, lds_double*, false, 0>(lds, (lds_double*)nullptr, n, ld, a.flag, nullptr, nullptr);
+  const long long tEig = wall_clock64(), cEig = clock64();
+  // row j = sigma_j u_j
+  for (int j = grp; j < n; j += nGroups) {
+    double s = 0;
+    for (int i = gl; i < n; i += 16) { const double x = lds[j * ld + i]; s += x * x; }
+    s = rowSum16(s);
+    if (gl == 0) { ev[j] = s - delta; rsig[j] = rsqrt(s); }
+  }
+  __syncthreads();
+  if (t < 64) {
+    double mx = -1.0e300, mn = 1.0e300;
+    for (int j = t; j < n; j += 64) { mx = fmax(mx, ev[j]); mn = fmin(mn, ev[j]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); mn = fmin(mn, __shfl_xor(mn, o, 64)); }
+    const double tl = 2.220446049250313e-16 * n * mx;
+    int c = 0;
+    for (int j = t; j < n; j += 64) c += ev[j] <= tl;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (t == 0) { gJacobiShared.nullTol2 = mx; a.flag[2] = c; a.scal[1] = mn; a.scal[2] = mx; }
+  }
+  __syncthreads();
+  const double tol = 2.220446049250313e-16 * n * gJacobiShared.nullTol2;
+  for (int i = grp; i < n; i += nGroups) {
+    double e = 0;
+    for (int j = gl; j < n; j += 16) e += lds[i * ld + j] * (a.b0[j] / p[j]);
+    e = rowSum16(e);
+    if (gl == 0) a.e0[i] = ev[i] > tol ? -sqrt(1.0 / ev[i]) * (e * rsig[i]) : 0.0;
+  }
+  __syncthreads();
+  // J = (p U sqrt(S))^T in place of the rows
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    const double s = ev[i] > tol ? sqrt(ev[i]) * rsig[i] : 0.0;
+    const double v = p[j] * lds[i * ld + j] * s;
+    a.J[idx] = v;
+    lds[i * ld + j] = v;
+  }
+  __syncthreads();
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * lds[k * ld + j];
+    a.Ht[idx] = s;
+  }
+  for (int i = t; i < n; i += nt) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * a.e0[k];
+    a.bp[i] = s;
+  }
+  if (t < 64) {
+    double c = 0;
+    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    c = waveSumM(c);
+    if (t == 0) {
+      a.scal[0] = c;
+      a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
+      a.scal[6] = (double)(cEig - cPrep);
+      a.scal[7] = (double)n;
+      a.flag[3] = -4;   // marks the mode in the SVIN_MARG_TIMING line
+    }
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   extern __shared__ double jacobiLds[];
+  if (useLds == 4) {
+    if (margFinalCholesky(a, toLds(jacobiLds))) return;
+    __syncthreads();
+    useLds = 2;   // a pivot was not positive: G and Q take turns in this workgroup's LDS
+  }
   if (useLds == 3) {
     if (blockIdx.x == 0) margFinalProducer(a, toLds(jacobiLds));
     else margFinalConsumer(a, toLds(jacobiLds));
@@ -1298,8 +1418,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         // workgroups side by side (mode 3), or taking turns in one (mode 2)
         const bool separate = !noTwoPhase && jacobiLdsBytesGOnly(nk) != 0 && (!lds || (!noSplit && nk >= 32));
         if (separate) {
+          static const bool noCholesky = getenv("SVIN_MARG_NO_CHOLESKY") != nullptr;
           lds = jacobiLdsBytesGOnly(nk);
-          mode = noSplit ? 2 : 3;
+          mode = !noCholesky ? 4 : noSplit ? 2 : 3;
           const size_t npk = (nk & 1) ? nk + 1 : nk;
           mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
           fa.rotLog = reinterpret_cast<double2*>(mb.bRotLog.p);
