@@ -904,10 +904,10 @@ __device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
 
 __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   extern __shared__ double jacobiLds[];
-  if (useLds == 4) {
-    if (margFinalCholesky(a, toLds(jacobiLds))) return;
+  if (useLds >= 4) {
+    if (useLds == 4 && margFinalCholesky(a, toLds(jacobiLds))) return;
     __syncthreads();
-    useLds = 2;   // a pivot was not positive: G and Q take turns in this workgroup's LDS
+    useLds = 2;   // a pivot was not positive (or mode 5, the test hook): G and Q take turns in this workgroup's LDS
   }
   if (useLds == 3) {
     if (blockIdx.x == 0) margFinalProducer(a, toLds(jacobiLds));
@@ -1409,21 +1409,31 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       fa.flag = bFlag.p;
       dbgScal = fa.scal;
       {
-        size_t lds = jacobiLdsBytes(nk);
-        int mode = lds ? 1 : 0;
+        // Eigen-solver of the prior (k_marg_final's `useLds`):
+        //   4 "cholesky"  A + delta I = R^T R, one-sided Jacobi on the rows of R in LDS (default when one image fits: n <= 136)
+        //   3 "split"     one-sided Jacobi on A; G in workgroup 0, the eigenvectors replayed from its log in workgroup 1
+        //   2 "twophase"  the same two phases one after the other in one workgroup (also the fall-back of mode 4)
+        //   1 "single"    G and Q side by side in one LDS (n <= 96; default below 32 unknowns)
+        //   0             G and Q in global memory (anything larger)
+        // SVIN_MARG_EIG selects one of the names for A/B runs and for the tests that keep the non-default paths honest;
+        // "cholesky-fail" takes the fall-back branch of mode 4 without attempting the factorisation.
+        const char* want = getenv("SVIN_MARG_EIG");
+        const std::string eig = want ? want : "";
+        const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
+        size_t lds = 0;
+        int mode = 0;
+        if (ldsOne && (eig == "cholesky" || eig == "cholesky-fail" || (eig.empty() && nk >= 32))) mode = eig == "cholesky-fail" ? 5 : 4;
+        else if (ldsOne && eig == "split") mode = 3;
+        else if (ldsOne && (eig == "twophase" || (!ldsBoth && eig != "global"))) mode = 2;
+        else if (ldsBoth && eig != "global") mode = 1;
         fa.rotLog = nullptr;
-        static const bool noTwoPhase = getenv("SVIN_MARG_NO_TWOPHASE") != nullptr;   // A/B switches
-        static const bool noSplit = getenv("SVIN_MARG_NO_SPLIT") != nullptr;
-        // G and Q in one LDS (mode 1) only for small problems or on request; otherwise one LDS image each: in two
-        // workgroups side by side (mode 3), or taking turns in one (mode 2)
-        const bool separate = !noTwoPhase && jacobiLdsBytesGOnly(nk) != 0 && (!lds || (!noSplit && nk >= 32));
-        if (separate) {
-          static const bool noCholesky = getenv("SVIN_MARG_NO_CHOLESKY") != nullptr;
-          lds = jacobiLdsBytesGOnly(nk);
-          mode = !noCholesky ? 4 : noSplit ? 2 : 3;
+        if (mode >= 2) {
+          lds = ldsOne;
           const size_t npk = (nk & 1) ? nk + 1 : nk;
           mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
           fa.rotLog = reinterpret_cast<double2*>(mb.bRotLog.p);
+        } else if (mode == 1) {
+          lds = ldsBoth;
         }
         if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (mode == 3) HIP_OK(hipMemsetAsync(bFlag.p + 4, 0, 2 * sizeof(int), s));
