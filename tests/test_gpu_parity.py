@@ -441,8 +441,8 @@ def test_rejected_steps_follow_the_oracle(gpu_lib):
 
 
 def test_marginalization_large_prior_per_frame_extrinsics(gpu_lib):
-    """rig v2 with the reference's window (5 keyframes + 3 IMU frames): the prior grows past 96 unknowns, where the
-    M3 eigen-solve switches to the G-only LDS rotation (k_marg_final mode 2)"""
+    """rig v2 with the reference's window (5 keyframes + 3 IMU frames): the prior grows past 96 unknowns, where G and
+    Q no longer fit one LDS together (k_marg_final: the Cholesky-preconditioned solve by default, SVIN_MARG_EIG for the others)"""
     from svin_amd.estimator import Estimator
     from oracle import orc
     spec = syn.make_window(P=13, L=250, n_obs=3000, seed=45, rig="rig_v2", keyframe_every=2, frame_dt=0.3)
