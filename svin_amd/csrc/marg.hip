@@ -796,8 +796,12 @@ __device__ void margFinalConsumer(const FinalArgs& a, lds_double* lds) {
 // (sigma^2 >= delta is computed to relative precision); an eigen-direction is reliable to eps |R| / sigma_j, i.e. 1e-10 for
 // the null space (which is dropped) and better than 1e-12 for everything above 1e-8.  Returns false (uniformly) if a
 // pivot is not positive; the caller then runs the two-phase solve.
-__device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
-  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n);
+// P = lds_double* (the image in LDS, n <= 136) or double* (the image in a.G: larger priors; the same arithmetic at
+// global-memory latency, still 2-3x faster than mode 0 for its fewer sweeps and the missing Q).
+template <class P>
+__device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
+  constexpr bool inLds = std::is_same<P, lds_double*>::value;
+  const int t = threadIdx.x, nt = blockDim.x, n = a.n;
   const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
   const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;
   double* p = a.tmp;            // n
@@ -827,7 +831,7 @@ __device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
       const double f = lds[k * ld + j] * rp;
       for (int i = j + lane; i < n; i += 64) lds[j * ld + i] -= f * lds[k * ld + i];
     }
-    ldsBarrier();
+    if (inLds) ldsBarrier(); else __syncthreads();
   }
   if (!(lds[(n - 1) * ld + (n - 1)] > 0.0)) return false;
   for (int k = wave; k < n; k += nWaves) {
@@ -836,7 +840,7 @@ __device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
   }
   __syncthreads();
   const long long tPrep = wall_clock64(), cPrep = clock64();
-  jacobiEigBlock<kJacobiLanes, lds_double*, false, 0>(lds, (lds_double*)nullptr, n, ld, a.flag, nullptr, nullptr);
+  jacobiEigBlock<kJacobiLanes, P, false, 0>(lds, (P) nullptr, n, ld, a.flag, nullptr, nullptr);
   const long long tEig = wall_clock64(), cEig = clock64();
   // row j = sigma_j u_j
   for (int j = grp; j < n; j += nGroups) {
@@ -896,7 +900,7 @@ __device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
       a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
       a.scal[6] = (double)(cEig - cPrep);
       a.scal[7] = (double)n;
-      a.flag[3] = -4;   // marks the mode in the SVIN_MARG_TIMING line
+      a.flag[3] = inLds ? -4 : -6;   // marks the mode in the SVIN_MARG_TIMING line
     }
   }
   return true;
@@ -904,8 +908,13 @@ __device__ bool margFinalCholesky(const FinalArgs& a, lds_double* lds) {
 
 __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   extern __shared__ double jacobiLds[];
+  if (useLds == 6) {
+    if (margFinalCholesky<double*>(a, a.G, a.n)) return;
+    __syncthreads();
+    useLds = 0;
+  }
   if (useLds >= 4) {
-    if (useLds == 4 && margFinalCholesky(a, toLds(jacobiLds))) return;
+    if (useLds == 4 && margFinalCholesky<lds_double*>(a, toLds(jacobiLds), jacobiLd(a.n))) return;
     __syncthreads();
     useLds = 2;   // a pivot was not positive (or mode 5, the test hook): G and Q take turns in this workgroup's LDS
   }
@@ -1414,20 +1423,28 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         //   3 "split"     one-sided Jacobi on A; G in workgroup 0, the eigenvectors replayed from its log in workgroup 1
         //   2 "twophase"  the same two phases one after the other in one workgroup (also the fall-back of mode 4)
         //   1 "single"    G and Q side by side in one LDS (n <= 96; default below 32 unknowns)
-        //   0             G and Q in global memory (anything larger)
+        //   6 "cholesky-global"  mode 4 with the image in global memory (default for anything larger)
+        //   0 "global"    one-sided Jacobi on A with G and Q in global memory (fall-back of mode 6)
         // SVIN_MARG_EIG selects one of the names for A/B runs and for the tests that keep the non-default paths honest;
         // "cholesky-fail" takes the fall-back branch of mode 4 without attempting the factorisation.
         const char* want = getenv("SVIN_MARG_EIG");
         const std::string eig = want ? want : "";
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
         size_t lds = 0;
-        int mode = 0;
-        if (ldsOne && (eig == "cholesky" || eig == "cholesky-fail" || (eig.empty() && nk >= 32))) mode = eig == "cholesky-fail" ? 5 : 4;
-        else if (ldsOne && eig == "split") mode = 3;
-        else if (ldsOne && (eig == "twophase" || (!ldsBoth && eig != "global"))) mode = 2;
-        else if (ldsBoth && eig != "global") mode = 1;
+        const int mode = [&]() -> int {
+          if (eig == "global") return 0;
+          if (eig == "cholesky-global") return 6;
+          if (eig == "cholesky-fail" && ldsOne) return 5;
+          if (eig == "split" && ldsOne) return 3;
+          if (eig == "twophase" && ldsOne) return 2;
+          if (eig == "single" && ldsBoth) return 1;
+          if (eig == "single" && ldsOne) return 2;
+          if (ldsOne && (nk >= 32 || eig == "cholesky")) return 4;   // the default from here on
+          if (ldsBoth) return 1;
+          return 6;
+        }();
         fa.rotLog = nullptr;
-        if (mode >= 2) {
+        if (mode >= 2 && mode <= 5) {
           lds = ldsOne;
           const size_t npk = (nk & 1) ? nk + 1 : nk;
           mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);

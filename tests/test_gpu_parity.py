@@ -490,8 +490,9 @@ def test_marginalization_large_prior_per_frame_extrinsics(gpu_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rig,window,P", [("euroc", (2, 3), 8), ("rig_v2", (5, 3), 13)])
 def test_prior_eigen_solver_variants_agree(gpu_lib, monkeypatch, rig, window, P):
-    """M3 has five eigen-solver paths (SVIN_MARG_EIG, marg.hip): the Cholesky-preconditioned Jacobi that runs by default,
-    its fall-back branch, the two-workgroup solve, the two-phase solve and the one-LDS / global-memory solve.  They must
+    """M3 has six eigen-solver paths (SVIN_MARG_EIG, marg.hip): the Cholesky-preconditioned Jacobi that runs by default,
+    its fall-back branch, the two-workgroup solve, the two-phase solve, the one-LDS / global-memory solve and the
+    Cholesky-preconditioned solve in global memory (priors beyond 136 unknowns).  They must
     hand the optimiser the same prior: J^T J, J^T e0 and the numerical rank of the last prior of a sliding window, and
     the window it leads to.  The rotated-rows eigenvectors of the default differ from the accumulated Q of the others at
     rounding level, the sequences amplify that (see test_marginalization_sequence_parity), hence the tolerances."""
@@ -499,7 +500,7 @@ def test_prior_eigen_solver_variants_agree(gpu_lib, monkeypatch, rig, window, P)
     spec = syn.make_window(P=P, L=250, n_obs=2500 if rig == "euroc" else 3000, seed=44 if rig == "euroc" else 45, rig=rig,
                            keyframe_every=2, frame_dt=0.3)
     out = {}
-    for mode in ("cholesky", "cholesky-fail", "split", "twophase", "single", "global"):
+    for mode in ("cholesky", "cholesky-fail", "split", "twophase", "single", "global", "cholesky-global"):
         monkeypatch.setenv("SVIN_MARG_EIG", mode)
         est = Estimator(0)
         est.set_solver_options(1e-12, 1e-12, 1e-12)
