@@ -1467,6 +1467,15 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       if (mb.bOut.p) HIP_OK(hipMemcpy(sc3, dbgScal, sizeof(sc3), hipMemcpyDeviceToHost));
       std::printf("[marg] m %d Lm %d; Jacobi sweeps of the last eigen-solve: %d; eigenvalues <= tol: %d (min %.3e max %.3e)\n", m, Lm,
                   fl[1], fl[2], sc3[1], sc3[2]);
+      if (mb.bOut.p && sc3[7] > 0) {   // the eigenvalues sit behind p[] in the kernel's scratch
+        const int nn = (int)sc3[7];
+        std::vector<double> evh(nn);
+        HIP_OK(hipMemcpy(evh.data(), dbgScal + 8 + nn, sizeof(double) * nn, hipMemcpyDeviceToHost));
+        std::sort(evh.begin(), evh.end());
+        std::printf("[marg] smallest eigenvalues:");
+        for (int i = 0; i < std::min(nn, 8); ++i) std::printf(" %.3e", evh[i]);
+        std::printf("  (tol %.3e)\n", 2.220446049250313e-16 * nn * sc3[2]);
+      }
       std::printf("[marg] k_marg_final: n %d, prepare %.0f us, eigen-solve %.0f us (two-phase: phase 1 %d us; %.0f shader clocks per us), "
                   "J / e0 / J^T J %.0f us\n", (int)sc3[7], sc3[3] / 100.0, sc3[4] / 100.0, fl[3], sc3[6] / std::max(1.0, sc3[4] / 100.0),
                   sc3[5] / 100.0);
