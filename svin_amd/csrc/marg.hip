@@ -162,13 +162,9 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
-// de Rijk's column sorting (trade the two results when q is the longer column) costs sweeps in the round-robin
-// tournament, where a column's index says nothing about its neighbours: 18 -> 26 sweeps at n = 105.  Kept switchable.
-constexpr bool kJacobiSortColumns = false;
 constexpr int kJacobiRegLen = 144;   // columns up to this (padded) length are held in registers by their lane group
 
-// one 32-bit half at a time through DPP; kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane (i - N) & 15),
-// quad_perm = the four 2-bit selectors, row_half_mirror = 0x141 (lane i of an 8-lane half reads lane 7 - i)
+// one 32-bit half at a time through DPP; kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane (i - N) & 15)
 template <int kCtrl>
 __device__ __forceinline__ double dppRowMov(double v) {
   const long long b = __double_as_longlong(v);
@@ -186,16 +182,6 @@ __device__ __forceinline__ double rowSum16(double v) {
   v += dppRowMov<0x121>(v);
   return v;
 }
-// the same over the 8 lanes of half a row: xor 1, xor 2 (quad_perm [1 0 3 2], [2 3 0 1]), then the mirrored half
-__device__ __forceinline__ double halfRowSum8(double v) {
-  v += dppRowMov<0xB1>(v);
-  v += dppRowMov<0x4E>(v);
-  v += dppRowMov<0x141>(v);
-  return v;
-}
-template <int LPG> __device__ __forceinline__ double groupSum(double v);
-template <> __device__ __forceinline__ double groupSum<16>(double v) { return rowSum16(v); }
-template <> __device__ __forceinline__ double groupSum<8>(double v) { return halfRowSum8(v); }
 
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also waits for every outstanding global access
 // (s_waitcnt vmcnt(0)), which turns the fire-and-forget rotation-log stores of phase 1 and the read-ahead of phase 2
@@ -330,7 +316,8 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         } else {
           for (int i = gl; i < n; i += LPG) { const double x = gp[i - gl], y = gq[i - gl]; al += x * x; be += y * y; ga += x * y; }
         }
-        al = groupSum<LPG>(al); be = groupSum<LPG>(be); ga = groupSum<LPG>(ga);
+        static_assert(LPG == 16, "one DPP row per column pair");
+        al = rowSum16(al); be = rowSum16(be); ga = rowSum16(ga);
         if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
           if (kLog && gl == 0) logStore(slot, 1.0, 0.0, kLog == 2);
           continue;
@@ -338,32 +325,26 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         rotated = true;
         double c, s;
         jacobiRotation(al, be, ga, c, s);
-        // de Rijk's ordering: the rotation keeps the longer column longer, so when that is q the two results trade
-        // places and the columns drift towards decreasing norm, which saves sweeps on a graded spectrum
-        // (logged as a negative c)
-        const bool trade = kJacobiSortColumns && al < be;
-        if (kLog && gl == 0) logStore(slot, trade ? -c : c, s, kLog == 2);
-        P dp = trade ? gq : gp, dq = trade ? gp : gq;
+        if (kLog && gl == 0) logStore(slot, c, s, kLog == 2);
         if (inRegs) {
 #pragma unroll
           for (int u = 0; u < kRegCols; ++u) {
             if (LPG * u >= n) break;
-            dp[LPG * u] = c * xs[u] - s * ys[u];
-            dq[LPG * u] = s * xs[u] + c * ys[u];
+            gp[LPG * u] = c * xs[u] - s * ys[u];
+            gq[LPG * u] = s * xs[u] + c * ys[u];
           }
         } else {
           for (int i = gl; i < n; i += LPG) {
             const double x = gp[i - gl], y = gq[i - gl];
-            dp[i - gl] = c * x - s * y; dq[i - gl] = s * x + c * y;
+            gp[i - gl] = c * x - s * y; gq[i - gl] = s * x + c * y;
           }
         }
         if (kHasQ) {
           P vp = Q + pI * ld;
           P vq = Q + qI * ld;
-          P wp = trade ? vq : vp, wq = trade ? vp : vq;
           for (int i = gl; i < n; i += LPG) {
             const double u = vp[i], w = vq[i];
-            wp[i] = c * u - s * w; wq[i] = s * u + c * w;
+            vp[i] = c * u - s * w; vq[i] = s * u + c * w;
           }
         }
       }
@@ -438,15 +419,12 @@ __device__ void jacobiReplay(lds_double* lds, int n, int ld, int rBegin, int rEn
     const int pI = a < b ? a : b, qI = a < b ? b : a;
     lds_double* vp = lds + pI * ld + gl;
     lds_double* vq = lds + qI * ld + gl;
-    const bool trade = cs.x < 0.0;   // the two results trade places (column sorting of phase 1)
-    const double c = fabs(cs.x), s = cs.y;
-    lds_double* wp = trade ? vq : vp;
-    lds_double* wq = trade ? vp : vq;
+    const double c = cs.x, s = cs.y;
 #pragma unroll
     for (int u = 0; u < kRegCols; ++u) {   // the zero tail of the padded columns stays zero
       if (LPG * u >= n) break;
       const double x = vp[LPG * u], w = vq[LPG * u];
-      wp[LPG * u] = c * x - s * w; wq[LPG * u] = s * x + c * w;
+      vp[LPG * u] = c * x - s * w; vq[LPG * u] = s * x + c * w;
     }
   };
   constexpr int kAhead = 4;
