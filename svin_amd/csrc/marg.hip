@@ -162,6 +162,7 @@ __device__ void symEig3(const double* A9, double* ev, double* Q) {
 // columns count as orthogonal below this relative inner product: a few times the rounding noise eps*sqrt(n) of the
 // dot product itself (1e-15 kept the solver chasing that noise for 5+ extra sweeps)
 constexpr double kJacobiOrthTol = 2.0e-14;
+constexpr double kJacobiFinalCos = 3.0e-9;
 constexpr int kJacobiRegLen = 144;   // columns up to this (padded) length are held in registers by their lane group
 
 // one 32-bit half at a time through DPP; kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane (i - N) & 15)
@@ -242,7 +243,7 @@ __device__ __forceinline__ lds_double* toLds(double* p) { return (lds_double*)p;
 // one copy for all instantiations of the solver
 struct JacobiShared {
   double nullTol2;
-  int anyRotation;
+  int anyRotation, anyLargeRotation;
   int avail, done;   // consumer side of the two-workgroup solve
 };
 __shared__ JacobiShared gJacobiShared;
@@ -271,7 +272,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
   // dense, nearly every column still moves a little in every one of the 14 .. 19 sweeps.)
   for (int sweep = 0; sweep < 40; ++sweep) {
     __syncthreads();
-    if (threadIdx.x == 0) { anyRotation = 0; nullTol2 = 0.0; }
+    if (threadIdx.x == 0) { anyRotation = 0; gJacobiShared.anyLargeRotation = 0; nullTol2 = 0.0; }
     __syncthreads();
     {
       double mx = 0;
@@ -290,7 +291,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
     // the n/2 disjoint pairs of a round run side by side, one lane group each
     const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
     double2* logRound = kLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
-    bool rotated = false;
+    bool rotated = false, large = false;
     for (int round = 0; round < np - 1; ++round, logRound += kLog ? np / 2 : 0) {
       for (int k = grp; k < np / 2; k += nGroups) {
         int a, b;
@@ -323,6 +324,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
           continue;
         }
         rotated = true;
+        large = large || ga * ga >= (kJacobiFinalCos * kJacobiFinalCos) * (al * be);
         double c, s;
         jacobiRotation(al, be, ga, c, s);
         if (kLog && gl == 0) logStore(slot, c, s, kLog == 2);
@@ -355,10 +357,14 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
       if (report && threadIdx.x == 0) agentStore(progress, roundsDone);   // ... and so have everybody else's
     }
     if (rotated) anyRotation = 1;   // racing stores of the same value
+    if (large) gJacobiShared.anyLargeRotation = 1;
     if (threadIdx.x == 0) flag[1] = sweep + 1;
     sweeps = sweep + 1;
     __syncthreads();
-    if (anyRotation == 0) break;
+    // Converged when nothing was rotated - or when every rotation of this sweep was by less than kJacobiFinalCos: the
+    // pairs it left alone were orthogonal to kJacobiOrthTol when visited and have since moved by products of two such
+    // angles at most (n of them: 1e-15), so the sweep that would only confirm it is not run.
+    if (anyRotation == 0 || gJacobiShared.anyLargeRotation == 0) break;
   }
   __syncthreads();
   return sweeps;
