@@ -794,14 +794,13 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   const double delta = 64.0 * n * 2.220446049250313e-16;
   const long long tStart = wall_clock64();
   for (int i = t; i < n; i += nt) p[i] = margScale(a.H[(size_t)i * n + i]);
+  __syncthreads();
   // upper triangle of A + delta I, the rest (lower triangle and the padding) zero
   for (int idx = t; idx < n * ld; idx += nt) {
     const int r = idx / ld, c = idx - r * ld;
     double v = 0.0;
-    if (c >= r && c < n) {
-      const double pr = margScale(a.H[(size_t)r * n + r]), pc = margScale(a.H[(size_t)c * n + c]);
-      v = 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (pr * pc) + (r == c ? delta : 0.0);
-    }
+    if (c >= r && c < n)
+      v = 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (p[r] * p[c]) + (r == c ? delta : 0.0);
     lds[idx] = v;
   }
   __syncthreads();
