@@ -239,3 +239,45 @@ def test_estimator_scenario_thresholds(case):
         JtJ = mg["J"].T @ mg["J"]
         sd = np.sqrt(np.maximum(np.diag(H), 1e-300))
         assert np.max(np.abs(JtJ - H) / np.outer(sd, sd)) < 1e-6
+
+
+@pytest.mark.parametrize("rig,window", [("euroc", (2, 3)), ("rig_v2", (5, 3))])
+def test_cholesky_preconditioned_eigen_solve_reproduces_the_oracle_prior(rig, window):
+    """The product's M3 (svin_amd/csrc/marg.hip, margFinalCholesky) does not diagonalise the Jacobi-scaled prior A the
+    way the reference does (Eigen SelfAdjointEigenSolver, MarginalizationError.cpp:725-758; oracle: tred2 / tql2): it
+    factors A + delta I = R^T R and takes the singular vectors of R, lambda = sigma^2 - delta.  Restated here in numpy
+    on the priors of an oracle sliding window: the same rank against the reference's threshold (eps * n * lambda_max)
+    and the same H-space prior J^T J that the optimiser consumes."""
+    P = 8 if rig == "euroc" else 12
+    spec = syn.make_window(P=P, L=200, n_obs=2000, seed=44, rig=rig, keyframe_every=2, frame_dt=0.3)
+    est = orc.OracleEstimator()
+    checked = []
+
+    def on_frame(k, fid):
+        est.optimize(10)
+        ok, removed = est.apply_marginalization(*window)
+        assert ok
+        m = est.marg()
+        if m is None:
+            return
+        H, n = m["H"], m["n"]
+        hd = np.diag(H)
+        p = np.where(hd > 1.0e-9, np.sqrt(np.maximum(hd, 0.0)), 1.0e-3)
+        A = 0.5 * (H + H.T) / np.outer(p, p)
+        delta = 64.0 * n * np.finfo(float).eps
+        R = np.linalg.cholesky(A + delta * np.eye(n)).T          # fails loudly if a pivot is not positive
+        U, sv, _ = np.linalg.svd(R.T)                             # R^T = U Sigma V^T: U = eigenvectors of A
+        lam = sv * sv - delta
+        tol = np.finfo(float).eps * n * lam.max()
+        keep = lam > tol
+        J = (np.sqrt(np.where(keep, lam, 0.0))[:, None] * U.T) * p[None, :]
+        Jo = m["J"]
+        rank_oracle = int(np.sum(np.any(Jo != 0, axis=1)))
+        # eigenvalues within a factor 4 of the threshold can legitimately fall on either side of it (DESIGN.md 8)
+        borderline = int(np.sum((np.abs(lam) > tol / 4) & (np.abs(lam) < tol * 4)))
+        assert abs(int(keep.sum()) - rank_oracle) <= borderline, (n, int(keep.sum()), rank_oracle, np.sort(lam)[:8], tol)
+        num = np.linalg.norm(J.T @ J - Jo.T @ Jo)
+        assert num <= 1e-10 * np.linalg.norm(Jo.T @ Jo), (n, num)
+        checked.append(n)
+    syn.feed(est, spec, on_frame=on_frame)
+    assert len(checked) >= 4 and max(checked) >= (27 if rig == "euroc" else 90), checked
