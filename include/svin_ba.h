@@ -31,7 +31,7 @@ typedef struct svin_ba svin_ba;
 #define SVIN_ERR_DEVICE (-3)
 #define SVIN_ERR_UNSUPPORTED (-4)
 
-/* distortion models (okvis_cv/include/okvis/cameras/*Distortion.hpp) */
+/* distortion models (okvis_cv/include/okvis/cameras/ ...Distortion.hpp) */
 #define SVIN_DIST_NONE 0
 #define SVIN_DIST_RADTAN 1
 #define SVIN_DIST_EQUIDISTANT 2
@@ -72,6 +72,16 @@ svin_ba* svin_ba_create(int device);            /* Estimator::Estimator()  src/E
 void svin_ba_destroy(svin_ba* h);
 const char* svin_ba_last_error(void);
 uint64_t svin_ba_new_id(svin_ba* h);            /* IdProvider::instance().newId()  src/IdProvider.cpp */
+/* ONE id space.  Upstream, frame ids (FrameSynchronizer.cpp:97), landmark ids (Frontend.cpp:599) and the estimator's
+ * internal extrinsics / speed-bias block ids (src/Estimator.cpp:217,234) all come from the process-wide
+ * okvis::IdProvider.  A host that owns such a provider installs it here (the shim passes a trampoline to
+ * IdProvider::instance().newId()); the core then draws its internal ids -- and svin_ba_new_id() -- from it.
+ * Without a provider the core counts upwards from the largest id svin_ba_reserve_ids() has been told about
+ * (call it with the largest caller-chosen id before add_states).  An internal id that collides with any known
+ * frame / landmark / block id makes add_states fail with SVIN_ERR_INVALID_ARG and leaves the window unchanged. */
+typedef uint64_t (*svin_id_provider_fn)(void* user);
+int svin_ba_set_id_provider(svin_ba* h, svin_id_provider_fn fn, void* user);
+int svin_ba_reserve_ids(svin_ba* h, uint64_t largest_id_seen);
 
 /* ---- sensors (Estimator.cpp:77-96) -------------------------------------------------------- */
 /* intr = fu fv cu cv; dist = up to 8 coefficients (radtan k1 k2 p1 p2; equidistant k1..k4;
@@ -79,7 +89,15 @@ uint64_t svin_ba_new_id(svin_ba* h);            /* IdProvider::instance().newId(
  * sigma_c_relative_translation, sigma_c_relative_orientation (ExtrinsicsEstimationParameters) */
 int svin_ba_add_camera(svin_ba* h, int distortion_model, const double intr[4], const double* dist, int n_dist,
                        int width, int height, const double sigmas[4]);
+/* Estimator::addCamera only registers the extrinsics-estimation parameters (:77-81); the geometry reaches the reference
+ * with every observation (implementation/Estimator.hpp:62-66, multiFrame->geometryAs<GEOMETRY>(camIdx)).  A host in that
+ * position calls svin_ba_add_camera with SVIN_DIST_NONE / zero intrinsics and hands the geometry over once it has the
+ * first multi-frame. */
+int svin_ba_set_camera_geometry(svin_ba* h, uint64_t cam_idx, int distortion_model, const double intr[4],
+                                const double* dist, int n_dist, int width, int height);
 int svin_ba_add_imu(svin_ba* h, const svin_imu_params* p);
+int svin_ba_clear_cameras(svin_ba* h);          /* Estimator::clearCameras :91 */
+int svin_ba_clear_imus(svin_ba* h);             /* Estimator::clearImus    :94 */
 int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]); /* Estimator.hpp:617 sonarParameters_ */
 
 /* ---- window construction ------------------------------------------------------------------ */
@@ -126,6 +144,14 @@ int svin_ba_get_summary(svin_ba* h, svin_summary* out);
  * The reference has no counterpart (single process, Ceres threads: Estimator.cpp:889). */
 typedef int (*svin_allreduce_fn)(void* ptr, uint64_t count, int op, void* user);
 int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user);
+/* The same mode with RCCL called natively: the all-reduces are enqueued on the handle's stream (ncclAllReduce, FP64, in
+ * place), no host synchronisation and no callback inside the iteration.  Rank 0 obtains a 128-byte ncclUniqueId with
+ * svin_ba_rccl_unique_id() and the host hands it to every rank by whatever means it has (torch.distributed broadcast,
+ * MPI, a file); each rank then calls svin_ba_set_distributed_rccl() -- collectively, it blocks until all ranks have
+ * joined (ncclCommInitRank).  One process per GPU.  RCCL (librccl.so.1) is resolved with dlopen at this point, a
+ * single-GPU user never needs it. */
+int svin_ba_rccl_unique_id(unsigned char id_out[128]);
+int svin_ba_set_distributed_rccl(svin_ba* h, int rank, int world, const unsigned char id[128]);
 /* solver tolerances (::ceres::Solver::Options defaults: 1e-6, 1e-10, 1e-8) */
 int svin_ba_set_solver_tolerances(svin_ba* h, double function_tol, double gradient_tol, double parameter_tol);
 
@@ -135,6 +161,13 @@ int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, d
 int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, double T[7]);
 int svin_ba_get_landmark(svin_ba* h, uint64_t landmark_id, svin_landmark_info* out);
 int svin_ba_is_landmark_added(svin_ba* h, uint64_t landmark_id);
+/* Estimator::isLandmarkInitialized :966-969 / setLandmarkInitialized :1126-1129 (HomogeneousPointParameterBlock::
+ * initialized_, true after addLandmark).  is_: 1 / 0, SVIN_ERR_NOT_FOUND for an unknown landmark. */
+int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t landmark_id);
+int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t landmark_id, int initialized);
+/* Estimator::getLandmarks :974-990: all landmarks in PointMap order (ascending id); ids / infos may be NULL;
+ * returns the number of landmarks (numLandmarks()). */
+int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, int cap);
 int svin_ba_set_T_WS(svin_ba* h, uint64_t pose_id, const double T[7]);
 int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, const double sb[9]);
 int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, const double T[7]);
@@ -145,6 +178,18 @@ uint64_t svin_ba_current_keyframe_id(svin_ba* h);
 uint64_t svin_ba_current_frame_id(svin_ba* h);
 uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age);
 int svin_ba_is_keyframe(svin_ba* h, uint64_t frame_id);
+int svin_ba_set_keyframe(svin_ba* h, uint64_t frame_id, int is_keyframe);              /* Estimator.hpp:444 */
+int svin_ba_timestamp(svin_ba* h, uint64_t frame_id, uint32_t* sec, uint32_t* nsec);   /* Estimator.hpp:373 */
+int svin_ba_state_count(svin_ba* h);            /* public member stateCount_, Estimator.hpp:450 (read by Frontend.cpp:269) */
+/* Estimator::getImuPreIntegral :1001-1014 / setImuPreIntegral :1081-1087 (imuIntegralsMap_, filled by addStates :165
+ * from the second ImuError::propagation overload): acc_doubleintegral(3), acc_integral(3), Delta_t */
+int svin_ba_get_imu_preintegral(svin_ba* h, uint64_t pose_id, double acc_doubleintegral[3], double acc_integral[3],
+                                double* delta_t);
+int svin_ba_set_imu_preintegral(svin_ba* h, uint64_t pose_id, const double acc_doubleintegral[3],
+                                const double acc_integral[3], double delta_t);
+/* static Estimator::initPoseFromImu :848-873 (no handle: a few scalar operations on the mean accelerometer reading);
+ * returns 0 for an empty deque like the reference */
+int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_WS[7]);
 int svin_ba_is_in_imu_window(svin_ba* h, uint64_t frame_id);
 int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap);      /* returns the number of frames */
 int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap);   /* returns the number of landmarks */
@@ -165,6 +210,10 @@ int svin_ba_keyframe_points(svin_ba* h, uint64_t frame_id, uint64_t cam_idx, int
 int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],
                             double sb[9], uint32_t sec0, uint32_t nsec0, uint32_t sec1, uint32_t nsec1, double* cov,
                             double* jac);
+/* the second overload (ImuError.cpp:479-697): additionally acc_doubleintegral(3), acc_integral(3), Delta_t in integrals[7] */
+int svin_ba_imu_propagation_integrals(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p,
+                                      double T[7], double sb[9], uint32_t sec0, uint32_t nsec0, uint32_t sec1,
+                                      uint32_t nsec1, double* cov, double* jac, double integrals[7]);
 
 /* ---- inspection / parity hooks (ErrorInterface::EvaluateWithMinimalJacobians, Map::getLhs) ---- */
 /* Evaluates every reprojection residual of the window on the GPU at the current estimates.

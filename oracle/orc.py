@@ -29,7 +29,7 @@ def build(force=False, native=False, out=None):
     if native:
         srcs = [os.path.join(_HERE, f) for f in ("orc_math.cpp orc_errors.cpp orc_map.cpp orc_marg.cpp "
                                                  "orc_estimator.cpp orc_capi.cpp orc_posegraph.cpp").split()]
-        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-shared", "-o", target] + srcs)
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-o", target] + srcs)
         return target
     if force or not os.path.exists(target):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))

@@ -370,8 +370,9 @@ bool Estimator::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuF
 }
 
 // Estimator.cpp:876-929
-void Estimator::optimize(size_t numIter, size_t /*numThreads*/, bool verbose) {
+void Estimator::optimize(size_t numIter, size_t numThreads, bool verbose) {
   map_->options.max_num_iterations = (int)numIter;
+  map_->options.num_threads = (int)std::max<size_t>(1, numThreads);  // :889 options.num_threads = numThreads
   map_->options.verbose = verbose;
   map_->solve();
   for (auto& kv : landmarksMap_) {

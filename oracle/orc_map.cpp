@@ -2,6 +2,7 @@
 // See orc_map.hpp for what is restated from where.
 #include "orc_map.hpp"
 #include <chrono>
+#include <omp.h>
 #include <cstdio>
 #include <cassert>
 
@@ -154,8 +155,17 @@ struct ResInfo {
   std::vector<ParamBlock*> pb;
 };
 
+struct PhaseTimer {   // ORC_TIMING=1: where a solve spends its time (diagnostics for the CPU baseline)
+  double* acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit PhaseTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~PhaseTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct Problem {
   Map& map;
+  mutable double tEvalJ = 0, tEval = 0, tSchur = 0, tChol = 0, tJv = 0, tGrad = 0;
+  int numThreads = 1;
   std::vector<ParamBlock*> cam;
   std::vector<int> camOff;
   int d = 0;
@@ -214,12 +224,18 @@ struct Problem {
 
   // Evaluate all residual blocks at the current parameter values.  With jac: local
   // (tangent-space) Jacobians = ambient Jacobian * PlusJacobian(x), then Ceres' Corrector.
-  double evaluate(bool jac) {
-    double total = 0;
-    std::vector<double> scratch, rtmp;
+  struct EvalScratch {
+    std::vector<double> scratch;
     std::vector<const double*> P;
     std::vector<double*> Jp;
-    for (ResInfo& ri : res) {
+  };
+  // one residual block: residual (+ local Jacobians and Ceres' Corrector with jac); returns its cost term
+  double evalOne(ResInfo& ri, bool jac, EvalScratch& es) {
+    std::vector<double>& scratch = es.scratch;
+    std::vector<const double*>& P = es.P;
+    std::vector<double*>& Jp = es.Jp;
+    double cost = 0;
+    {
       const int m = ri.m;
       P.resize(ri.nb);
       for (int j = 0; j < ri.nb; ++j) P[j] = ri.pb[j]->x;
@@ -259,11 +275,11 @@ struct Problem {
       double sq = 0;
       for (int a = 0; a < m; ++a) sq += rr[a] * rr[a];
       if (ri.rb->loss == LOSS_NONE) {
-        total += 0.5 * sq;
+        cost = 0.5 * sq;
       } else {
         double rho[3];
         lossEvaluate(ri.rb->loss, ri.rb->lossParam, sq, rho);
-        total += 0.5 * rho[0];
+        cost = 0.5 * rho[0];
         if (jac) {
           // ceres/internal/ceres/corrector.cc
           const double sqrt_rho1 = std::sqrt(rho[1]);
@@ -295,11 +311,36 @@ struct Problem {
         }
       }
     }
+    return cost;
+  }
+  double evaluate(bool jac) {
+    PhaseTimer pt(jac ? &tEvalJ : &tEval);
+    if (numThreads > 1) return evaluateParallel(jac);
+    double total = 0;
+    EvalScratch es;
+    for (ResInfo& ri : res) total += evalOne(ri, jac, es);
+    return total;
+  }
+  // the same evaluation on numThreads threads (Ceres: options.num_threads parallelises the residual / Jacobian
+  // evaluation).  The per-block cost terms are summed in block order afterwards, so the result does not depend on the
+  // thread count.
+  double evaluateParallel(bool jac) {
+    const int n = (int)res.size();
+    std::vector<double> costs(n);
+#pragma omp parallel num_threads(numThreads)
+    {
+      EvalScratch es;
+#pragma omp for schedule(static)
+      for (int i = 0; i < n; ++i) costs[i] = evalOne(res[i], jac, es);
+    }
+    double total = 0;
+    for (int i = 0; i < n; ++i) total += costs[i];
     return total;
   }
 
   // full gradient g = J^T r and squared column norms h of the local Jacobian. layout: [cam(d), lm(3L)]
   void gradientAndColumnNorms(std::vector<double>& g, std::vector<double>& h) const {
+    PhaseTimer pt(&tGrad);
     g.assign(nvar(), 0.0);
     h.assign(nvar(), 0.0);
     for (const ResInfo& ri : res) {
@@ -319,6 +360,7 @@ struct Problem {
   }
   // out = J v  (per-residual), returns sum |Jv|^2 and (Jv).r
   void Jtimes(const std::vector<double>& v, double& sqnorm, double& dot_r) const {
+    PhaseTimer pt(&tJv);
     sqnorm = 0; dot_r = 0;
     std::vector<double> jv;
     for (const ResInfo& ri : res) {
@@ -347,6 +389,8 @@ struct Problem {
     std::vector<double> W;                       // 18 or 27 (mdim x 3) per entry, row-major mdim x 3, padded to 27
   };
   bool buildSchur(const std::vector<double>& damp, Schur& s) const {
+    PhaseTimer pt(&tSchur);
+    if (numThreads > 1) return buildSchurParallel(damp, s);
     const int L = (int)lm.size();
     s.A.assign((size_t)d * d, 0.0);
     s.b.assign(d, 0.0);
@@ -488,13 +532,171 @@ struct Problem {
     s.wStart[L] = (int)s.wCam.size();
     return true;
   }
+  // buildSchur on numThreads threads (Ceres' SchurEliminator is threaded by chunks of landmarks as well): every thread
+  // eliminates a contiguous range of landmarks into private copies of the camera matrices, which are summed in thread
+  // order afterwards.  Same arithmetic per landmark as buildSchur; the summation order across landmarks differs, so the
+  // result matches the sequential one to rounding only -- used for the multi-thread CPU baseline, never by the parity tests.
+  bool buildSchurParallel(const std::vector<double>& damp, Schur& s) const {
+    const int L = (int)lm.size();
+    s.A.assign((size_t)d * d, 0.0);
+    s.b.assign(d, 0.0);
+    s.V.assign((size_t)L * 9, 0.0);
+    s.Vinv.assign((size_t)L * 9, 0.0);
+    s.bl.assign((size_t)L * 3, 0.0);
+    s.wStart.assign(L + 1, 0);
+    s.wCam.clear();
+    s.W.clear();
+    auto camPart = [&](const ResInfo& ri, double* A, double* b) {   // J_c^T J_c and J_c^T r of one residual block
+      const double* rr = &r[ri.roff];
+      for (int j = 0; j < ri.nb; ++j) {
+        if (ri.kind[j] != 0) continue;
+        const int mj = ri.mdim[j], oj = camOff[ri.idx[j]];
+        const double* Jj = &Jloc[ri.joff[j]];
+        for (int a = 0; a < mj; ++a) {
+          double sb = 0;
+          for (int k = 0; k < ri.m; ++k) sb += Jj[k * mj + a] * rr[k];
+          b[oj + a] += sb;
+        }
+        for (int i = 0; i < ri.nb; ++i) {
+          if (ri.kind[i] != 0) continue;
+          const int mi = ri.mdim[i], oi = camOff[ri.idx[i]];
+          const double* Ji = &Jloc[ri.joff[i]];
+          for (int a = 0; a < mj; ++a)
+            for (int c = 0; c < mi; ++c) {
+              double sa = 0;
+              for (int k = 0; k < ri.m; ++k) sa += Jj[k * mj + a] * Ji[k * mi + c];
+              A[(size_t)(oj + a) * d + oi + c] += sa;
+            }
+        }
+      }
+    };
+    for (int ridx : camOnlyRes) camPart(res[ridx], s.A.data(), s.b.data());
+    if (!damp.empty())
+      for (int i = 0; i < d; ++i) s.A[(size_t)i * d + i] += damp[i];
+    s.S = s.A;
+    s.gred = s.b;
+    const int nt = numThreads;
+    std::vector<std::vector<double>> tA(nt), tB(nt), tS(nt), tG(nt);
+    std::vector<std::vector<int>> lmCam(L);
+    std::vector<std::vector<double>> lmW(L);
+    int failed = 0;
+#pragma omp parallel num_threads(nt)
+    {
+      const int t = omp_get_thread_num();
+      std::vector<double>& dA = tA[t]; std::vector<double>& dB = tB[t];
+      std::vector<double>& dS = tS[t]; std::vector<double>& dG = tG[t];
+      dA.assign((size_t)d * d, 0.0); dB.assign(d, 0.0); dS.assign((size_t)d * d, 0.0); dG.assign(d, 0.0);
+#pragma omp for schedule(static)
+      for (int l = 0; l < L; ++l) {
+        double V[9] = {0}, bl[3] = {0};
+        std::vector<int>& wc = lmCam[l];
+        std::vector<double>& W = lmW[l];
+        for (int ridx : lmRes[l]) {
+          const ResInfo& ri = res[ridx];
+          const double* rr = &r[ri.roff];
+          int jl = -1;
+          for (int j = 0; j < ri.nb; ++j) if (ri.kind[j] == 1) jl = j;
+          const double* Jl = &Jloc[ri.joff[jl]];
+          for (int a = 0; a < 3; ++a) {
+            for (int c = 0; c < 3; ++c) {
+              double sv = 0;
+              for (int k = 0; k < ri.m; ++k) sv += Jl[k * 3 + a] * Jl[k * 3 + c];
+              V[a * 3 + c] += sv;
+            }
+            double sb = 0;
+            for (int k = 0; k < ri.m; ++k) sb += Jl[k * 3 + a] * rr[k];
+            bl[a] += sb;
+          }
+          camPart(ri, dA.data(), dB.data());
+          for (int j = 0; j < ri.nb; ++j) {
+            if (ri.kind[j] != 0) continue;
+            const int mj = ri.mdim[j];
+            const double* Jj = &Jloc[ri.joff[j]];
+            int wi = -1;
+            for (int w = 0; w < (int)wc.size(); ++w) if (wc[w] == ri.idx[j]) { wi = w; break; }
+            if (wi < 0) { wi = (int)wc.size(); wc.push_back(ri.idx[j]); W.resize(W.size() + 27, 0.0); }
+            double* Ww = &W[(size_t)wi * 27];
+            for (int a = 0; a < mj; ++a)
+              for (int c = 0; c < 3; ++c) {
+                double sw = 0;
+                for (int k = 0; k < ri.m; ++k) sw += Jj[k * mj + a] * Jl[k * 3 + c];
+                Ww[a * 3 + c] += sw;
+              }
+          }
+        }
+        std::memcpy(&s.V[(size_t)l * 9], V, sizeof(V));
+        if (!damp.empty()) { V[0] += damp[d + 3 * l]; V[4] += damp[d + 3 * l + 1]; V[8] += damp[d + 3 * l + 2]; }
+        double Lc[9];
+        std::memcpy(Lc, V, sizeof(V));
+        if (llt_inplace(Lc, 3) >= 0) {
+#pragma omp atomic write
+          failed = 1;
+          continue;
+        }
+        double Linv[9] = {0};
+        Linv[0] = 1 / Lc[0]; Linv[4] = 1 / Lc[4]; Linv[8] = 1 / Lc[8];
+        Linv[3] = -Lc[3] * Linv[0] / Lc[4];
+        Linv[7] = -Lc[7] * Linv[4] / Lc[8];
+        Linv[6] = -(Lc[6] * Linv[0] + Lc[7] * Linv[3]) / Lc[8];
+        double Vi[9];
+        for (int a = 0; a < 3; ++a)
+          for (int c = 0; c < 3; ++c) {
+            double sv = 0;
+            for (int k = 0; k < 3; ++k) sv += Linv[k * 3 + a] * Linv[k * 3 + c];
+            Vi[a * 3 + c] = sv;
+          }
+        std::memcpy(&s.Vinv[(size_t)l * 9], Vi, sizeof(Vi));
+        std::memcpy(&s.bl[(size_t)l * 3], bl, sizeof(bl));
+        double Vibl[3];
+        mat3_vec(Vi, bl, Vibl);
+        const int nw = (int)wc.size();
+        for (int wa = 0; wa < nw; ++wa) {
+          const int ca = wc[wa], ma = cam[ca]->mdim(), oa = camOff[ca];
+          const double* Wa = &W[(size_t)wa * 27];
+          double WVi[27];
+          for (int a = 0; a < ma; ++a)
+            for (int c = 0; c < 3; ++c) WVi[a * 3 + c] = Wa[a * 3] * Vi[c] + Wa[a * 3 + 1] * Vi[3 + c] + Wa[a * 3 + 2] * Vi[6 + c];
+          for (int a = 0; a < ma; ++a) dG[oa + a] -= Wa[a * 3] * Vibl[0] + Wa[a * 3 + 1] * Vibl[1] + Wa[a * 3 + 2] * Vibl[2];
+          for (int wb = 0; wb < nw; ++wb) {
+            const int cb = wc[wb], mb = cam[cb]->mdim(), ob = camOff[cb];
+            const double* Wb = &W[(size_t)wb * 27];
+            for (int a = 0; a < ma; ++a)
+              for (int c = 0; c < mb; ++c)
+                dS[(size_t)(oa + a) * d + ob + c] -= WVi[a * 3] * Wb[c * 3] + WVi[a * 3 + 1] * Wb[c * 3 + 1] + WVi[a * 3 + 2] * Wb[c * 3 + 2];
+          }
+        }
+      }
+      // merge the private copies: rows split over the threads, thread order inside
+#pragma omp for schedule(static)
+      for (int i = 0; i < d; ++i) {
+        for (int tt = 0; tt < nt; ++tt) {
+          const double* a = &tA[tt][(size_t)i * d];
+          const double* sp = &tS[tt][(size_t)i * d];
+          for (int j = 0; j < d; ++j) { s.A[(size_t)i * d + j] += a[j]; s.S[(size_t)i * d + j] += a[j] + sp[j]; }
+          s.b[i] += tB[tt][i];
+          s.gred[i] += tB[tt][i] + tG[tt][i];
+        }
+      }
+    }
+    if (failed) return false;
+    for (int l = 0; l < L; ++l) {
+      s.wStart[l] = (int)s.wCam.size();
+      s.wCam.insert(s.wCam.end(), lmCam[l].begin(), lmCam[l].end());
+      s.W.insert(s.W.end(), lmW[l].begin(), lmW[l].end());
+    }
+    s.wStart[L] = (int)s.wCam.size();
+    return true;
+  }
   // y = (H + damp)^-1 g  via the Schur complement; false on Cholesky failure
   bool solveNormal(const std::vector<double>& damp, std::vector<double>& y, Schur* keep = nullptr) const {
     Schur local;
     Schur& s = keep ? *keep : local;
     if (!buildSchur(damp, s)) return false;
     std::vector<double> Lm(s.S);
-    if (d > 0 && llt_inplace(Lm.data(), d) >= 0) return false;
+    {
+      PhaseTimer pt(&tChol);
+      if (d > 0 && llt_inplace(Lm.data(), d) >= 0) return false;
+    }
     y.assign(nvar(), 0.0);
     // forward / backward
     for (int i = 0; i < d; ++i) {
@@ -572,6 +774,7 @@ void Map::solve() {
   auto elapsed = [&]() { return std::chrono::duration<double>(clock::now() - t_start).count(); };
   summary = SolverSummary();
   Problem p(*this);
+  p.numThreads = std::max(1, options.num_threads);
   const int n = p.nvar();
   if (n == 0) { summary.termination = 0; return; }
 
@@ -608,6 +811,9 @@ void Map::solve() {
     summary.final_cost = x_cost;
     summary.iterations = iteration;
     summary.total_time = elapsed();
+    if (getenv("ORC_TIMING"))
+      std::printf("[orc timing, %d threads] total %.4f s: evaluate+jacobians %.4f, evaluate %.4f, schur %.4f, cholesky %.4f, "
+                  "J*v %.4f, gradient %.4f\n", p.numThreads, summary.total_time, p.tEvalJ, p.tEval, p.tSchur, p.tChol, p.tJv, p.tGrad);
   };
 
   while (true) {

@@ -41,6 +41,7 @@ struct SolverOptions {
   double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
   double min_relative_decrease = 1e-3;
   bool jacobi_scaling = true;
+  int num_threads = 1;          // Estimator::optimize numThreads (Estimator.cpp:889): residual evaluation + Schur elimination
   bool verbose = false;
 };
 struct SolverSummary {

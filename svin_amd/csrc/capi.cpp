@@ -57,6 +57,23 @@ svin_ba* svin_ba_create(int device) {
 void svin_ba_destroy(svin_ba* h) { delete h; }
 const char* svin_ba_last_error(void) { return lastError().c_str(); }
 uint64_t svin_ba_new_id(svin_ba* h) { return h ? h->w.newId() : 0; }
+int svin_ba_set_id_provider(svin_ba* h, svin_id_provider_fn fn, void* user) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  h->w.setIdProvider(fn, user);
+  return 1;
+}
+int svin_ba_reserve_ids(svin_ba* h, uint64_t largest) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  h->w.reserveIds(largest);
+  return 1;
+}
+int svin_ba_set_camera_geometry(svin_ba* h, uint64_t cam, int model, const double intr[4], const double* dist, int n_dist,
+                                int width, int height) {
+  if (!h || !intr || (n_dist > 0 && !dist) || n_dist < 0 || n_dist > 8) return SVIN_ERR_INVALID_ARG;
+  return h->w.setCameraGeometry(cam, model, intr, dist, n_dist, width, height) ? 1 : SVIN_ERR_NOT_FOUND;
+}
+int svin_ba_clear_cameras(svin_ba* h) { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearCameras(); return 1; }
+int svin_ba_clear_imus(svin_ba* h) { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearImus(); return 1; }
 
 int svin_ba_add_camera(svin_ba* h, int model, const double intr[4], const double* dist, int n_dist, int width, int height,
                        const double sigmas[4]) {
@@ -77,7 +94,9 @@ int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]) {
 int svin_ba_add_states(svin_ba* h, uint64_t frame_id, uint32_t sec, uint32_t nsec, uint64_t num_keypoints,
                        const double* T_SC, int n_cam, const svin_imu_sample* imu, int n_imu, int as_keyframe,
                        const double* sonar, int n_sonar, const double* depth, int n_depth, double first_depth) {
-  if (!h) return SVIN_ERR_INVALID_ARG;
+  if (!h || n_imu < 0 || n_cam < 0 || n_sonar < 0 || n_depth < 0 || (n_imu > 0 && !imu) || (n_cam > 0 && !T_SC) ||
+      (n_sonar > 0 && !sonar) || (n_depth > 0 && !depth))
+    return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN
   std::vector<uint32_t> t;
   std::vector<double> m;
@@ -152,7 +171,7 @@ int svin_ba_set_optimization_time_limit(svin_ba* h, double tl, int min_iter) {
 }
 int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t nkf, uint64_t nimu, uint64_t* removed, int cap,
                                            int* n_removed) {
-  if (!h) return SVIN_ERR_INVALID_ARG;
+  if (!h || cap < 0 || (cap > 0 && !removed)) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN
   std::vector<uint64_t> rem;
   const int r = h->w.applyMarginalizationStrategy(nkf, nimu, rem);
@@ -175,6 +194,16 @@ int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn f
   h->w.setDistributed(rank, world, fn, user);
   return 1;
 }
+int svin_ba_rccl_unique_id(unsigned char id_out[128]) {
+  if (!id_out) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return Window::rcclUniqueId(id_out);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_set_distributed_rccl(svin_ba* h, int rank, int world, const unsigned char id[128]) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.setDistributedRccl(rank, world, id);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_set_solver_tolerances(svin_ba* h, double f, double g, double p) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.setTolerances(f, g, p);
@@ -187,15 +216,72 @@ int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, double sb[
 int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, double T[7]) {
   return h ? h->w.getCameraSensorStates(id, cam, T) : SVIN_ERR_INVALID_ARG;
 }
+static void fillInfo(const Landmark& lm, svin_landmark_info* out) {
+  for (int k = 0; k < 4; ++k) out->point[k] = lm.hp[k];
+  out->quality = lm.quality; out->distance = lm.distance;
+  out->num_observations = (int32_t)lm.obs.size();
+  out->initialized = lm.initialized ? 1 : 0;
+}
 int svin_ba_get_landmark(svin_ba* h, uint64_t id, svin_landmark_info* out) {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmark(id);
   if (!lm) return 0;
-  for (int k = 0; k < 4; ++k) out->point[k] = lm->hp[k];
-  out->quality = lm->quality; out->distance = lm->distance;
-  out->num_observations = (int32_t)lm->obs.size();
-  out->initialized = 1;
+  fillInfo(*lm, out);
   return 1;
+}
+int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, int cap) {
+  if (!h || cap < 0) return SVIN_ERR_INVALID_ARG;
+  int n = 0;
+  for (const auto& kv : h->w.landmarks()) {
+    if (n < cap) {
+      if (ids) ids[n] = kv.first;
+      if (infos) fillInfo(kv.second, infos + n);
+    }
+    ++n;
+  }
+  return n;
+}
+int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  const Landmark* lm = h->w.landmark(id);
+  return lm ? (lm->initialized ? 1 : 0) : SVIN_ERR_NOT_FOUND;
+}
+int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t id, int initialized) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  return h->w.setLandmarkInitialized(id, initialized != 0) ? 1 : SVIN_ERR_NOT_FOUND;
+}
+int svin_ba_set_keyframe(svin_ba* h, uint64_t id, int is_kf) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  return h->w.setKeyframe(id, is_kf != 0) ? 1 : SVIN_ERR_NOT_FOUND;
+}
+int svin_ba_timestamp(svin_ba* h, uint64_t id, uint32_t* sec, uint32_t* nsec) {
+  if (!h || !sec || !nsec) return SVIN_ERR_INVALID_ARG;
+  auto it = h->w.states().find(id);
+  if (it == h->w.states().end()) return SVIN_ERR_NOT_FOUND;
+  *sec = it->second.stamp.sec; *nsec = it->second.stamp.nsec;
+  return 1;
+}
+int svin_ba_state_count(svin_ba* h) { return h ? h->w.stateCount() : SVIN_ERR_INVALID_ARG; }
+int svin_ba_get_imu_preintegral(svin_ba* h, uint64_t pose_id, double adi[3], double ai[3], double* dt) {
+  if (!h || !adi || !ai || !dt) return SVIN_ERR_INVALID_ARG;
+  double v[7];
+  if (!h->w.getImuPreIntegral(pose_id, v)) return 0;
+  for (int k = 0; k < 3; ++k) { adi[k] = v[k]; ai[k] = v[3 + k]; }
+  *dt = v[6];
+  return 1;
+}
+int svin_ba_set_imu_preintegral(svin_ba* h, uint64_t pose_id, const double adi[3], const double ai[3], double dt) {
+  if (!h || !adi || !ai) return SVIN_ERR_INVALID_ARG;
+  const double v[7] = {adi[0], adi[1], adi[2], ai[0], ai[1], ai[2], dt};
+  h->w.setImuPreIntegral(pose_id, v);
+  return 1;
+}
+int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_WS[7]) {
+  if (!T_WS || n_imu < 0 || (n_imu > 0 && !imu)) return SVIN_ERR_INVALID_ARG;
+  std::vector<uint32_t> t;
+  std::vector<double> m;
+  splitSamples(imu, n_imu, t, m);
+  return Window::initPoseFromImu(m.data(), n_imu, T_WS) ? 1 : 0;
 }
 int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) { return h && h->w.landmark(id) ? 1 : 0; }
 int svin_ba_set_T_WS(svin_ba* h, uint64_t id, const double T[7]) { return h ? h->w.set_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
@@ -278,6 +364,18 @@ int svin_ba_imu_propagation(svin_ba* h, const svin_imu_sample* imu, int n_imu, c
   splitSamples(imu, n_imu, t, m);
   TimeStamp a, b; a.sec = s0; a.nsec = ns0; b.sec = s1; b.nsec = ns1;
   return h->w.imuPropagation(t.data(), m.data(), n_imu, toParams(p), T, sb, a, b, cov, jac);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_imu_propagation_integrals(svin_ba* h, const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7],
+                                      double sb[9], uint32_t s0, uint32_t ns0, uint32_t s1, uint32_t ns1, double* cov,
+                                      double* jac, double integrals[7]) {
+  if (!h || !imu || !p || !T || !sb || n_imu < 0) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint32_t> t;
+  std::vector<double> m;
+  splitSamples(imu, n_imu, t, m);
+  TimeStamp a, b; a.sec = s0; a.nsec = ns0; b.sec = s1; b.nsec = ns1;
+  return h->w.imuPropagation(t.data(), m.data(), n_imu, toParams(p), T, sb, a, b, cov, jac, integrals);
   GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_eval_reprojection(svin_ba* h, int robust, double* r, double* Jp, double* Jl, double* Je, int cap) {

@@ -136,6 +136,21 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) 
   }
 }
 
+__global__ __launch_bounds__(64) void k_publish_scalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq) {
+  constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
+  const int t = threadIdx.x;
+  if (t < nD) {
+    const double v = __hip_atomic_load(reinterpret_cast<const double*>(scal) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    reinterpret_cast<volatile double*>(&mailbox->scal)[t] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&mailbox->seq) = seq;
+}
+void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, scal, mailbox, seq);
+}
+
 // Block-wide reduction of K values at once: out[k] valid in threads 0..K-1 (as `mine`), `red` holds 4*K doubles.
 template <int K>
 __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, int kMaxIndex) {
@@ -957,7 +972,7 @@ void debugImuTiming(double* out, bool reset) {
 }
 #endif
 
-// ImuError::propagation (ImuError.cpp:266-476): io[0..6] T_WS, io[7..15] speed/bias (in/out);
+// ImuError::propagation (ImuError.cpp:266-476, :479-697): io[0..6] T_WS, io[7..15] speed/bias (in/out), io[16..22] integrals (out);
 // out[0] = number of integration steps (or -1), optional 15x15 jacobian / covariance.
 __global__ __launch_bounds__(256) void k_imu_propagation(const DevImu* imPtr, const uint32_t* __restrict__ T,
                                                          const double* __restrict__ M, double* io, double* jac,
@@ -988,6 +1003,9 @@ __global__ __launch_bounds__(256) void k_imu_propagation(const DevImu* imPtr, co
     const Quat qn = qnormalized(qmul(T0.q, st.Dq));
     io[3] = qn.x; io[4] = qn.y; io[5] = qn.z; io[6] = qn.w;
     for (int k = 0; k < 3; ++k) io[7 + k] = sb[k] + C1v[k] - gW[k] * Dt;
+    // second overload (ImuError.cpp:664-667): acc_doubleintegral, acc_integral, Delta_t for Estimator::imuIntegralsMap_
+    for (int k = 0; k < 3; ++k) { io[16 + k] = st.adi[k]; io[19 + k] = st.ai[k]; }
+    io[22] = Dt;
     if (jac) {
       for (int k = 0; k < 225; ++k) jac[k] = (k / 15 == k % 15) ? 1.0 : 0.0;
       auto setB = [&](int r0, int c0, const double* B, double s) {

@@ -187,6 +187,8 @@ inline size_t solveReducedScratchDoubles(int d) {
 // step with that radius and retracts (single GPU, narrow windows) -- launchDoglegStep is then not needed
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius = -1.0);
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms
+// sharded mode: the (all-reduced) scalars + sequence number into the pinned-host mailbox, as one wave-wide store
+void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq, hipStream_t s);
 void launchCost(const DeviceProblem& p, hipStream_t s);                  // sums partial costs into scal->cost
 void launchImuPropagation(const DevImu* im /*device*/, const uint32_t* T, const double* M, double* io, double* jac, double* cov,
                           int* used, hipStream_t s);

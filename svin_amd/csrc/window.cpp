@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <dlfcn.h>
 #include <limits>
 #include <stdexcept>
 
@@ -55,6 +56,62 @@ static void sqrtInformationUpper(const double* info, int n, double* out) {
     for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? A[j * n + i] : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------ RCCL (resolved at run time)
+// The library is looked up with dlopen when the landmark-sharded mode is switched on: a process that already holds an
+// RCCL (torch.distributed's) gets that one (same SONAME), a single-GPU user never needs it to be installed.
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*getUniqueId)(void*) = nullptr;
+  void* commInitRankRaw = nullptr;   // (ncclComm_t*, int nranks, ncclUniqueId BY VALUE, int rank): cast where it is called
+  int (*allReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*commDestroy)(void*) = nullptr;
+  const char* (*getErrorString)(int) = nullptr;
+};
+struct UniqueId { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.lib) return api;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
+  auto sym = [&](const char* n) {
+    void* f = dlsym(api.lib, n);
+    if (!f) throw std::runtime_error(std::string("RCCL symbol missing: ") + n);
+    return f;
+  };
+  api.getUniqueId = reinterpret_cast<int (*)(void*)>(sym("ncclGetUniqueId"));
+  api.commInitRankRaw = sym("ncclCommInitRank");
+  api.allReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(sym("ncclAllReduce"));
+  api.commDestroy = reinterpret_cast<int (*)(void*)>(sym("ncclCommDestroy"));
+  api.getErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+  return api;
+}
+void rcclCheck(int r, const char* what) {
+  if (r != 0) throw std::runtime_error(std::string(what) + ": " + rccl().getErrorString(r));
+}
+}  // namespace
+
+int Window::rcclUniqueId(unsigned char* out128) {
+  UniqueId id;
+  std::memset(&id, 0, sizeof(id));
+  rcclCheck(rccl().getUniqueId(&id), "ncclGetUniqueId");
+  std::memcpy(out128, id.internal, 128);
+  return 1;
+}
+int Window::setDistributedRccl(int rank, int world, const unsigned char* id128) {
+  HIP_OK(hipSetDevice(device_));
+  UniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  typedef int (*InitFn)(void**, int, UniqueId, int);
+  if (rcclComm_) { (void)rccl().commDestroy(rcclComm_); rcclComm_ = nullptr; }
+  rcclCheck(reinterpret_cast<InitFn>(rccl().commInitRankRaw)(&rcclComm_, world, id, rank), "ncclCommInitRank");
+  rank_ = rank; world_ = world; allreduce_ = nullptr; allreduceUser_ = nullptr;
+  return 1;
+}
+
 Window::Window(int device) : device_(device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -78,6 +135,7 @@ Window::Window(int device) : device_(device) {
   }
 }
 Window::~Window() {
+  if (rcclComm_) (void)rccl().commDestroy(rcclComm_);
   if (stageEvt_) (void)hipEventDestroy(stageEvt_);
   if (stageHost_) (void)hipHostFree(stageHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
@@ -98,6 +156,17 @@ int Window::addCamera(int model, const double* intr, const double* dist, int nDi
   extrinsics_.push_back(e);
   return (int)cameras_.size() - 1;
 }
+int Window::setCameraGeometry(size_t cam, int model, const double* intr, const double* dist, int nDist, int w, int h) {
+  // the reference learns the camera geometry from the multi-frame of each observation (implementation/Estimator.hpp:62-66:
+  // multiFramePtr->geometryAs<GEOMETRY_TYPE>(camIdx)); a shim that registers the extrinsics parameters first
+  // (Estimator::addCamera) hands the geometry over with this call when the first multi-frame arrives
+  if (cam >= cameras_.size()) return 0;
+  CameraModel& c = cameras_[cam];
+  c.fu = intr[0]; c.fv = intr[1]; c.cu = intr[2]; c.cv = intr[3];
+  for (int i = 0; i < 8; ++i) c.k[i] = (dist && i < nDist) ? dist[i] : 0.0;
+  c.model = model; c.width = w; c.height = h;
+  return 1;
+}
 int Window::addImu(const ImuParams& p) {  // :83-90
   if (imus_.size() > 1) return -1;
   imus_.push_back(p);
@@ -105,11 +174,12 @@ int Window::addImu(const ImuParams& p) {  // :83-90
 }
 
 // ------------------------------------------------------------------------------------------ graph helpers
-Block& Window::addBlock(uint64_t id, int kind, const double* x) {
+Block* Window::addBlock(uint64_t id, int kind, const double* x) {  // Map::addParameterBlock refuses a known id (Map.cpp:257-260)
+  if (idInUse(id)) return nullptr;
   Block b;
   b.id = id; b.kind = kind;
   std::memcpy(b.x, x, sizeof(double) * (kind == B_SB ? 9 : 7));
-  return blocks_[id] = b;
+  return &(blocks_[id] = b);
 }
 Block* Window::findBlock(uint64_t id) {
   auto it = blocks_.find(id);
@@ -165,7 +235,7 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
 
 // ------------------------------------------------------------------------------------------ IMU prediction
 int Window::imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
-                           TimeStamp t0, TimeStamp t1, double* cov, double* jac) {
+                           TimeStamp t0, TimeStamp t1, double* cov, double* jac, double* integrals) {
   if (n <= 0) return -1;
   DevImu im;
   std::memset(&im, 0, sizeof(im));
@@ -175,33 +245,35 @@ int Window::imuPropagation(const uint32_t* imuT, const double* imuM, int n, cons
   DevBuf<DevImu> dIm; dIm.reserve(1);
   DevBuf<uint32_t> dT; dT.reserve(2 * (size_t)n);
   DevBuf<double> dM; dM.reserve(6 * (size_t)n);
-  DevBuf<double> dIo; dIo.reserve(16 + 450);
+  constexpr int kIo = 24;   // T(7) sb(9) | acc_doubleintegral(3) acc_integral(3) Delta_t | pad
+  DevBuf<double> dIo; dIo.reserve(kIo + 450);
   DevBuf<int> dUsed; dUsed.reserve(1);
-  double io[16];
+  double io[kIo] = {0};
   std::memcpy(io, T, 7 * sizeof(double));
   std::memcpy(io + 7, sb, 9 * sizeof(double));
   HIP_OK(hipMemcpyAsync(dIm.p, &im, sizeof(im), hipMemcpyHostToDevice, stream_));
   HIP_OK(hipMemcpyAsync(dT.p, imuT, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice, stream_));
   HIP_OK(hipMemcpyAsync(dM.p, imuM, sizeof(double) * 6 * n, hipMemcpyHostToDevice, stream_));
   HIP_OK(hipMemcpyAsync(dIo.p, io, sizeof(io), hipMemcpyHostToDevice, stream_));
-  launchImuPropagation(dIm.p, dT.p, dM.p, dIo.p, jac ? dIo.p + 16 : nullptr, cov ? dIo.p + 16 + 225 : nullptr, dUsed.p,
+  launchImuPropagation(dIm.p, dT.p, dM.p, dIo.p, jac ? dIo.p + kIo : nullptr, cov ? dIo.p + kIo + 225 : nullptr, dUsed.p,
                        stream_);
   int used = -1;
   HIP_OK(hipMemcpyAsync(io, dIo.p, sizeof(io), hipMemcpyDeviceToHost, stream_));
   HIP_OK(hipMemcpyAsync(&used, dUsed.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  if (jac) HIP_OK(hipMemcpyAsync(jac, dIo.p + 16, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  if (cov) HIP_OK(hipMemcpyAsync(cov, dIo.p + 16 + 225, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (jac) HIP_OK(hipMemcpyAsync(jac, dIo.p + kIo, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (cov) HIP_OK(hipMemcpyAsync(cov, dIo.p + kIo + 225, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
   HIP_OK(hipStreamSynchronize(stream_));
   if (used >= 0) {
     std::memcpy(T, io, 7 * sizeof(double));
     std::memcpy(sb, io + 7, 9 * sizeof(double));
+    if (integrals) std::memcpy(integrals, io + 16, 7 * sizeof(double));
   }
   return used;
 }
 
 // initPoseFromImu (:848-873): gravity alignment of the very first pose.  A handful of scalar operations
 // on the mean accelerometer reading, done once per session at construction time.
-static bool initPoseFromImu(const double* imuM, int n, double* T) {
+bool Window::initPoseFromImu(const double* imuM, int n, double* T) {
   T[0] = T[1] = T[2] = 0; T[3] = T[4] = T[5] = 0; T[6] = 1;
   if (n == 0) return false;
   double acc[3] = {0, 0, 0};
@@ -226,7 +298,8 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
                       int nSonar, const double* depth, int nDepth, double firstDepth) {
   if (nCam != (int)cameras_.size()) { lastError() = "addStates: T_SC count != number of cameras"; return -1; }
   if (imus_.empty()) { lastError() = "addStates: no IMU added"; return -1; }
-  double T_WS[7], sb[9];
+  if (imuM == nullptr || imuT == nullptr) nImu = 0;
+  double T_WS[7], sb[9], integrals[7];
   const bool first = states_.empty();
   if (first) {
     if (!initPoseFromImu(imuM, nImu, T_WS)) return 0;  // :110-113
@@ -237,10 +310,35 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
     const State& last = states_.rbegin()->second;
     std::memcpy(T_WS, blocks_.at(last.pose.id).x, sizeof(T_WS));
     std::memcpy(sb, blocks_.at(last.sb.at(0).id).x, sizeof(sb));
-    const int used = imuPropagation(imuT, imuM, nImu, imus_[0], T_WS, sb, last.stamp, stamp, nullptr, nullptr);
+    const int used = imuPropagation(imuT, imuM, nImu, imus_[0], T_WS, sb, last.stamp, stamp, nullptr, nullptr, integrals);
     if (used < 1) return 0;  // :159-162
+    setImuPreIntegral(frameId, integrals);  // :165
   }
-  if (states_.count(frameId) || blocks_.count(frameId)) return 0;
+  ++stateCount_;  // :171 (before the id check, like the reference)
+  if (idInUse(frameId)) return 0;  // Map::addParameterBlock refuses the pose block (:186-193)
+  // internal block ids: drawn up front so that a colliding provider leaves the graph untouched
+  const State* prevState = first ? nullptr : &states_.rbegin()->second;
+  std::vector<uint64_t> extIds(cameras_.size(), 0), sbIds(imus_.size(), 0);
+  {
+    std::vector<uint64_t> drawn{frameId};
+    auto draw = [&]() -> uint64_t {
+      const uint64_t id = newId();
+      if (id == 0 || idInUse(id) || std::find(drawn.begin(), drawn.end(), id) != drawn.end()) return 0;
+      drawn.push_back(id);
+      return id;
+    };
+    bool ok = true;
+    for (size_t i = 0; i < cameras_.size(); ++i) {
+      if ((extrinsics_[i].rel_t < 1e-12 || extrinsics_[i].rel_r < 1e-12) && !first) extIds[i] = prevState->ext.at(i).id;
+      else ok &= (extIds[i] = draw()) != 0;
+    }
+    for (size_t i = 0; i < imus_.size(); ++i) ok &= (sbIds[i] = draw()) != 0;
+    if (!ok) {
+      lastError() = "addStates: the id provider returned an id that is already in use (frames, landmarks and the "
+                    "estimator's internal blocks share ONE id space, see svin_ba_set_id_provider / svin_ba_reserve_ids)";
+      return -1;
+    }
+  }
   State st;
   st.id = frameId; st.stamp = stamp; st.isKeyframe = asKeyframe;
   st.pose.id = frameId; st.pose.exists = true;
@@ -249,18 +347,14 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
   for (size_t i = 0; i < cameras_.size(); ++i) {  // :203-229
     StateInfo info;
     info.exists = true;
-    if ((extrinsics_[i].rel_t < 1e-12 || extrinsics_[i].rel_r < 1e-12) && !first) {
-      info.id = prev->ext.at(i).id;
-    } else {
-      info.id = newId();
-      addBlock(info.id, B_EXT, T_SC + 7 * i);
-    }
+    info.id = extIds[i];
+    if (!((extrinsics_[i].rel_t < 1e-12 || extrinsics_[i].rel_r < 1e-12) && !first)) addBlock(info.id, B_EXT, T_SC + 7 * i);
     st.ext.push_back(info);
   }
   for (size_t i = 0; i < imus_.size(); ++i) {  // :232-246
     StateInfo info;
     info.exists = true;
-    info.id = newId();
+    info.id = sbIds[i];
     addBlock(info.id, B_SB, sb);
     st.sb.push_back(info);
   }
@@ -379,7 +473,7 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
 }
 
 int Window::addLandmark(uint64_t id, const double* hp) {  // :414-429
-  if (landmarks_.count(id) || blocks_.count(id)) return 0;
+  if (idInUse(id)) return 0;
   Landmark lm;
   lm.id = id;
   std::memcpy(lm.hp, hp, sizeof(lm.hp));
@@ -484,6 +578,29 @@ int Window::setLandmark(uint64_t id, const double* hp) {
   if (it == landmarks_.end()) return 0;
   std::memcpy(it->second.hp, hp, 4 * sizeof(double));
   return 1;
+}
+int Window::setLandmarkInitialized(uint64_t id, bool init) {
+  auto it = landmarks_.find(id);
+  if (it == landmarks_.end()) return 0;
+  it->second.initialized = init;
+  return 1;
+}
+int Window::setKeyframe(uint64_t frameId, bool isKf) {
+  auto it = states_.find(frameId);
+  if (it == states_.end()) return 0;
+  it->second.isKeyframe = isKf;
+  return 1;
+}
+int Window::getImuPreIntegral(uint64_t poseId, double* out7) const {
+  auto it = imuIntegrals_.find(poseId);
+  if (it == imuIntegrals_.end()) return 0;
+  std::memcpy(out7, it->second.data(), 7 * sizeof(double));
+  return 1;
+}
+void Window::setImuPreIntegral(uint64_t poseId, const double* in7) {
+  std::array<double, 7> a;
+  std::memcpy(a.data(), in7, sizeof(a));
+  imuIntegrals_.insert(std::make_pair(poseId, a));
 }
 uint64_t Window::currentKeyframeId() const {
   for (auto rit = states_.rbegin(); rit != states_.rend(); ++rit)
@@ -935,7 +1052,7 @@ void Window::downloadStates() {
 }
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
-  prob_.mailbox = mailboxDev_;
+  prob_.mailbox = distNative_ ? nullptr : mailboxDev_;   // sharded: published after the all-reduce (launchPublishScalars)
   prob_.mailboxSeq = ++mailboxSeq_;
   const int who = costSummedBy(prob_);
   if (canFuseEvaluation(prob_) && !getenv("SVIN_SPLIT_EVAL")) {
@@ -951,7 +1068,7 @@ void Window::evaluateAll(bool cand, hipStream_t s) {
 
 SolverScalars Window::readScalars() {
   SolverScalars sc;
-  if (mailbox_ && world_ <= 1) {
+  if (mailbox_ && (world_ <= 1 || distNative_)) {
     // wait for the sequence number of the last evaluateAll(); bounded spin, then fall back to a real synchronise
     volatile unsigned long long* seq = &mailbox_->seq;
     const double tSpin = nowSec();
@@ -982,22 +1099,32 @@ void Window::solve(size_t numIter, bool verbose) {
   hipStream_t s = stream_;
   summary_.iterations = 0; summary_.num_successful_steps = 0; summary_.termination = 1;
   if (p.d + 3 * p.L == 0) { summary_.termination = 0; summary_.initial_cost = summary_.final_cost = 0; return; }
-  const int dpad = ((p.d + 15) / 16) * 16;
-  if ((size_t)(16 * 17 + (size_t)std::max(dpad, 16) * 17) * 8 > 160 * 1024)
-    throw std::runtime_error("reduced system too large for the single-workgroup solver (d > ~1100)");
   // landmark-sharded mode: partial sums are all-reduced at three points per iteration
+  const bool forceDist = getenv("SVIN_FORCE_DISTRIBUTED") != nullptr;   // single-rank RCCL: exercises the sharded code path on one GPU
+  const bool dist = world_ > 1 || (forceDist && rcclComm_);
   auto AR = [&](void* ptr, size_t n, int op) {
-    if (world_ <= 1) return;
+    if (!dist) return;
+    if (rcclComm_) {   // native: enqueued on the solver's stream, in place (ncclDouble = 8, ncclSum = 0, ncclMax = 2)
+      rcclCheck(rccl().allReduce(ptr, ptr, n, 8, op == 0 ? 0 : 2, rcclComm_, s), "ncclAllReduce");
+      return;
+    }
     HIP_OK(hipStreamSynchronize(s));
     if (!allreduce_ || allreduce_(ptr, (uint64_t)n, op, allreduceUser_) != 0) throw std::runtime_error("all-reduce callback failed");
+  };
+  // the scalars reach the host through the mailbox once they are complete: on one GPU the evaluation kernel publishes
+  // them itself; in sharded mode they are complete only after the all-reduce, so a one-wave kernel publishes them then
+  distNative_ = dist && rcclComm_ != nullptr;
+  auto publish = [&]() {
+    if (distNative_ && mailbox_) launchPublishScalars(p.scal, mailboxDev_, mailboxSeq_, s);
   };
   double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..17] max group
   // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
   // retracts the whole window quickly enough
   static const bool noFuseStep = getenv("SVIN_NO_FUSE_STEP") != nullptr;   // A/B switch for profiling
-  const bool fuseStep = !noFuseStep && world_ <= 1 && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
+  const bool fuseStep = !noFuseStep && !dist && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
   evaluateAll(false, s);
   AR(scalD, 4, 0);
+  publish();
   SolverScalars sc = readScalars();
   double x_cost = sc.cost;
   summary_.initial_cost = x_cost;
@@ -1024,7 +1151,7 @@ void Window::solve(size_t numIter, bool verbose) {
   // are enqueued on the candidate's linearisation (the sets an accepted step swaps in) with the damping an accepted
   // step gets; on acceptance they are simply kept, otherwise the accumulators are re-zeroed before the next build.
   static const bool noSpeculation = getenv("SVIN_NO_SPECULATION") != nullptr;
-  const bool speculate = !noSpeculation && world_ <= 1;
+  const bool speculate = !noSpeculation && (!dist || distNative_);
   bool accumulatorsClean = true;   // S / gRed / hC zero (pack() or k_post_solve), nothing speculative in them
   bool specValid = false;          // the accumulators hold the build of the candidate with damping specMu
   double specMu = 0;
@@ -1061,6 +1188,7 @@ void Window::solve(size_t numIter, bool verbose) {
         specValid = true;
       }
       AR(scalD, 8, 0);
+      publish();
       sc = readScalars();
       sc.cholFail = sc.failMax != 0.0 ? 1 : 0;  // the device flag itself is re-armed by k_post_solve
       if (!reuse && sc.cholFail) {
@@ -1109,6 +1237,7 @@ void Window::solve(size_t numIter, bool verbose) {
     lastIterTime = nowSec() - tIter;
   }
   summary_.total_time = nowSec() - tStart;
+  distNative_ = false;
 }
 
 int Window::prepare() {
@@ -1224,6 +1353,7 @@ int Window::evalFactors(int32_t* kind, int32_t* m, int32_t* ncols, double* r, do
 }
 int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks,
                       int capD, double* cost) {
+  distNative_ = false;
   pack();
   DeviceProblem& p = prob_;
   if (p.d > capD) return -p.d;

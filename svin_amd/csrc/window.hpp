@@ -9,6 +9,7 @@
 // Reference (relative to /root/reference/okvis_ros/okvis/okvis_ceres/): src/Estimator.cpp,
 // include/okvis/implementation/Estimator.hpp, src/Map.cpp, src/MarginalizationError.cpp.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -51,6 +52,7 @@ struct Landmark {
   uint64_t id = 0;
   double hp[4] = {0, 0, 0, 1};
   double quality = 0, distance = 0;
+  bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
   std::vector<Observation> obs;  // insertion order
 };
 
@@ -124,9 +126,22 @@ class Window {
   explicit Window(int device);
   ~Window();
 
-  uint64_t newId() { return ++idCounter_; }
+  // Ids.  Upstream every id -- frames, landmarks AND the estimator's internal extrinsics / speed-bias blocks
+  // (Estimator.cpp:217,234) -- comes from ONE process-wide okvis::IdProvider.  The core therefore never invents ids
+  // on its own authority: it asks the provider the host installed (the shim forwards to IdProvider::instance().newId()),
+  // and without one it counts from the largest id it has been shown so far (reserveIds).  A collision is an error.
+  typedef uint64_t (*IdProviderFn)(void* user);
+  void setIdProvider(IdProviderFn fn, void* user) { idProvider_ = fn; idProviderUser_ = user; }
+  void reserveIds(uint64_t maxSeen) { if (maxSeen > idCounter_) idCounter_ = maxSeen; }
+  uint64_t newId() { return idProvider_ ? idProvider_(idProviderUser_) : ++idCounter_; }
+  bool idInUse(uint64_t id) const { return blocks_.count(id) || landmarks_.count(id) || states_.count(id); }
   int addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig);
+  int setCameraGeometry(size_t cam, int model, const double* intr, const double* dist, int nDist, int w, int h);
   int addImu(const ImuParams& p);
+  void clearCameras() { cameras_.clear(); extrinsics_.clear(); }   // Estimator.cpp:91
+  void clearImus() { imus_.clear(); }                                // Estimator.cpp:94
+  size_t numCameras() const { return cameras_.size(); }
+  size_t numImus() const { return imus_.size(); }
   void setSonarExtrinsics(const double* T) { std::memcpy(T_SSo_, T, sizeof(T_SSo_)); }
 
   int addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, const double* T_SC, int nCam,
@@ -143,8 +158,11 @@ class Window {
   void invalidatePreintegration() { for (auto& kv : factors_) if (kv.second.kind == F_IMU) kv.second.imu.redo = 1; }
   int setOptimizationTimeLimit(double timeLimit, int minIter);
   int applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed);
+  // integrals (optional, 7 doubles): acc_doubleintegral(3), acc_integral(3), Delta_t -- the second overload of
+  // ImuError::propagation (ImuError.cpp:479-697)
   int imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
-                     TimeStamp t0, TimeStamp t1, double* cov, double* jac);
+                     TimeStamp t0, TimeStamp t1, double* cov, double* jac, double* integrals = nullptr);
+  static bool initPoseFromImu(const double* imuM, int n, double* T);   // Estimator.cpp:848-873
 
   // getters / setters
   int get_T_WS(uint64_t id, double* T) const;
@@ -155,6 +173,11 @@ class Window {
   int setSpeedAndBias(uint64_t id, size_t imu, const double* sb);
   int setCameraSensorStates(uint64_t id, size_t cam, const double* T);
   int setLandmark(uint64_t id, const double* hp);
+  int setLandmarkInitialized(uint64_t id, bool init);                  // Estimator.cpp:1126-1129
+  int setKeyframe(uint64_t frameId, bool isKf);                        // Estimator.hpp:444
+  int getImuPreIntegral(uint64_t poseId, double* out7) const;          // Estimator.cpp:1001-1014
+  void setImuPreIntegral(uint64_t poseId, const double* in7);          // Estimator.cpp:1081-1087 (std::map::insert: first one wins)
+  int stateCount() const { return stateCount_; }                       // Estimator.hpp:450
   const std::map<uint64_t, State>& states() const { return states_; }
   const std::map<uint64_t, Landmark>& landmarks() const { return landmarks_; }
   uint64_t currentKeyframeId() const;
@@ -166,6 +189,10 @@ class Window {
   // range of landmarks; `fn` all-reduces `count` doubles at device address `ptr` in place (op 0 = sum, 1 = max).
   typedef int (*AllReduceFn)(void* ptr, uint64_t count, int op, void* user);
   void setDistributed(int rank, int world, AllReduceFn fn, void* user) { rank_ = rank; world_ = world; allreduce_ = fn; allreduceUser_ = user; }
+  // the same with RCCL called natively on the handle's stream (no host synchronisation, no callback): `id` is the
+  // 128-byte ncclUniqueId rank 0 obtained from rcclUniqueId() and the host distributed to every rank
+  static int rcclUniqueId(unsigned char* out128);
+  int setDistributedRccl(int rank, int world, const unsigned char* id128);
 
   // inspection hooks
   int evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap);
@@ -182,7 +209,7 @@ class Window {
 
  private:
   // graph helpers
-  Block& addBlock(uint64_t id, int kind, const double* x);
+  Block* addBlock(uint64_t id, int kind, const double* x);   // nullptr when the id is already in use
   void removeBlock(uint64_t id);
   uint64_t addFactor(Factor&& f);
   void removeFactor(uint64_t id);
@@ -204,6 +231,8 @@ class Window {
   int rank_ = 0, world_ = 1;
   AllReduceFn allreduce_ = nullptr;
   void* allreduceUser_ = nullptr;
+  bool distNative_ = false;    // the current solve all-reduces through rcclComm_ (scalars published after the reduction)
+  void* rcclComm_ = nullptr;   // ncclComm_t of the native path (RCCL resolved at run time, see window.cpp)
   hipStream_t stream_ = nullptr;
   // staged upload of pack(): pinned host block + its device twin (segment table first), see launchScatterStaged
   unsigned char* stageHost_ = nullptr;
@@ -211,6 +240,10 @@ class Window {
   DevBuf<unsigned char> stageDev_;
   hipEvent_t stageEvt_ = nullptr;
   uint64_t idCounter_ = 0;
+  IdProviderFn idProvider_ = nullptr;
+  void* idProviderUser_ = nullptr;
+  int stateCount_ = 0;
+  std::map<uint64_t, std::array<double, 7>> imuIntegrals_;   // Estimator::imuIntegralsMap_ (Estimator.hpp:404-408)
   std::vector<CameraModel> cameras_;
   std::vector<ExtrinsicsSigmas> extrinsics_;
   std::vector<ImuParams> imus_;

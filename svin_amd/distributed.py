@@ -39,6 +39,20 @@ def shard_spec(spec, rank, world):
     return out
 
 
+def init_rccl(est, rank, world, group=None, device=None):
+    """Switches `est` to the landmark-sharded mode with native RCCL: rank 0 creates the ncclUniqueId, torch.distributed
+    (any backend; only this 128-byte hand-shake goes through it) broadcasts it, every rank joins the communicator."""
+    import torch
+    import torch.distributed as dist
+    from . import estimator
+    uid = estimator.rccl_unique_id() if rank == 0 else bytes(128)
+    backend = dist.get_backend(group)
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
+    t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0, group=group)
+    est.set_distributed_rccl(rank, world, bytes(t.cpu().tolist()))
+
+
 class _DevArray:
     """exposes a raw device pointer through __cuda_array_interface__ so that torch can alias it"""
 

@@ -57,7 +57,14 @@ EXPORTS = [
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
     "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
     "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_kernel_times",
+    "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
+    "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
+    "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
+    "svin_ba_set_imu_preintegral", "svin_ba_init_pose_from_imu", "svin_ba_imu_propagation_integrals",
+    "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl",
 ]
+
+ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
 
 
 def library_path():
@@ -137,8 +144,35 @@ def load_library():
     sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
+    sig("svin_ba_rccl_unique_id", i32, C.c_char_p)
+    sig("svin_ba_set_distributed_rccl", i32, vp, i32, i32, C.c_char_p)
+    sig("svin_ba_set_id_provider", i32, vp, C.c_void_p, C.c_void_p)
+    sig("svin_ba_reserve_ids", i32, vp, u64)
+    sig("svin_ba_set_camera_geometry", i32, vp, u64, i32, pd, pd, i32, i32, i32)
+    sig("svin_ba_clear_cameras", i32, vp)
+    sig("svin_ba_clear_imus", i32, vp)
+    sig("svin_ba_is_landmark_initialized", i32, vp, u64)
+    sig("svin_ba_set_landmark_initialized", i32, vp, u64, i32)
+    sig("svin_ba_get_landmarks", i32, vp, pu64, C.POINTER(LandmarkInfo), i32)
+    sig("svin_ba_set_keyframe", i32, vp, u64, i32)
+    sig("svin_ba_timestamp", i32, vp, u64, C.POINTER(u32), C.POINTER(u32))
+    sig("svin_ba_state_count", i32, vp)
+    sig("svin_ba_get_imu_preintegral", i32, vp, u64, pd, pd, pd)
+    sig("svin_ba_set_imu_preintegral", i32, vp, u64, pd, pd, f64)
+    sig("svin_ba_init_pose_from_imu", i32, C.c_void_p, i32, pd)
+    sig("svin_ba_imu_propagation_integrals", i32, vp, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd,
+        pd)
     _LIB = L
     return L
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (call on rank 0, hand to every rank)"""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    if L.svin_ba_rccl_unique_id(buf) != 1:
+        raise RuntimeError("svin_ba_rccl_unique_id failed: " + L.svin_ba_last_error().decode())
+    return buf.raw
 
 
 def _d(a):
@@ -191,6 +225,25 @@ class Estimator:
     # -- construction ---------------------------------------------------------------------------
     def new_id(self):
         return int(self.L.svin_ba_new_id(self.h))
+
+    def set_id_provider(self, fn):
+        """fn() -> int: the host's id source (okvis::IdProvider); None restores the internal counter"""
+        self._id_cb = ID_PROVIDER_FN(lambda _u: int(fn())) if fn is not None else None
+        self._check(self.L.svin_ba_set_id_provider(self.h, C.cast(self._id_cb, C.c_void_p) if fn is not None else None, None),
+                    "set_id_provider")
+
+    def reserve_ids(self, largest):
+        self._check(self.L.svin_ba_reserve_ids(self.h, int(largest)), "reserve_ids")
+
+    def set_camera_geometry(self, cam, model, intr, dist, w, h):
+        intr, dist = _arr(intr), _arr(dist)
+        return self.L.svin_ba_set_camera_geometry(self.h, cam, model, _d(intr), _d(dist) if len(dist) else None, len(dist), w, h) == 1
+
+    def clear_cameras(self):
+        self.L.svin_ba_clear_cameras(self.h)
+
+    def clear_imus(self):
+        self.L.svin_ba_clear_imus(self.h)
 
     def add_camera(self, model, intr, dist, w, h, sigmas):
         intr, dist, sig = _arr(intr), _arr(dist), _arr(sigmas)
@@ -254,6 +307,9 @@ class Estimator:
     def remove_observation(self, lid, pose, cam, kp):
         return bool(self._check(self.L.svin_ba_remove_observation(self.h, lid, pose, cam, kp), "remove_observation"))
 
+    def remove_observation_by_id(self, rid):
+        return bool(self._check(self.L.svin_ba_remove_observation_by_id(self.h, rid), "remove_observation_by_id"))
+
     # -- hot path ---------------------------------------------------------------------------------
     def optimize(self, num_iter, num_threads=1, verbose=False):
         self._check(self.L.svin_ba_optimize(self.h, num_iter, num_threads, 1 if verbose else 0), "optimize")
@@ -275,6 +331,12 @@ class Estimator:
         self._allreduce_cb = allreduce_cb
         self._check(self.L.svin_ba_set_distributed(self.h, rank, world, C.cast(allreduce_cb, C.c_void_p), None),
                     "set_distributed")
+
+    def set_distributed_rccl(self, rank, world, unique_id):
+        """landmark-sharded mode with native RCCL on the solver's stream; `unique_id` = 128 bytes from rccl_unique_id()
+        on rank 0, distributed by the caller (svin_amd.distributed.init_rccl does it over torch.distributed)"""
+        assert len(unique_id) == 128
+        self._check(self.L.svin_ba_set_distributed_rccl(self.h, rank, world, bytes(unique_id)), "set_distributed_rccl")
 
     def set_time_limit(self, tl, min_iter):
         return bool(self.L.svin_ba_set_optimization_time_limit(self.h, tl, min_iter))
@@ -315,7 +377,67 @@ class Estimator:
         if self.L.svin_ba_get_landmark(self.h, lid, C.byref(info)) != 1:
             return None
         return dict(point=np.array(info.point[:]), quality=info.quality, distance=info.distance,
-                    n_obs=info.num_observations)
+                    n_obs=info.num_observations, initialized=bool(info.initialized))
+
+    def get_landmarks(self):
+        """Estimator::getLandmarks: {id: dict} in PointMap order"""
+        n = self.L.svin_ba_get_landmarks(self.h, None, None, 0)
+        ids, infos = np.zeros(max(n, 1), np.uint64), (LandmarkInfo * max(n, 1))()
+        self.L.svin_ba_get_landmarks(self.h, ids.ctypes.data_as(pu64), infos, n)
+        return {int(ids[i]): dict(point=np.array(infos[i].point[:]), quality=infos[i].quality, distance=infos[i].distance,
+                                  n_obs=infos[i].num_observations, initialized=bool(infos[i].initialized)) for i in range(n)}
+
+    def is_landmark_added(self, lid):
+        return self.L.svin_ba_is_landmark_added(self.h, lid) == 1
+
+    def is_landmark_initialized(self, lid):
+        return self._check(self.L.svin_ba_is_landmark_initialized(self.h, lid), "is_landmark_initialized") == 1
+
+    def set_landmark_initialized(self, lid, flag):
+        return self.L.svin_ba_set_landmark_initialized(self.h, lid, 1 if flag else 0) == 1
+
+    def set_keyframe(self, fid, flag):
+        return self.L.svin_ba_set_keyframe(self.h, fid, 1 if flag else 0) == 1
+
+    def is_keyframe(self, fid):
+        return self._check(self.L.svin_ba_is_keyframe(self.h, fid), "is_keyframe") == 1
+
+    def timestamp(self, fid):
+        a, b = u32(), u32()
+        return (a.value, b.value) if self.L.svin_ba_timestamp(self.h, fid, C.byref(a), C.byref(b)) == 1 else None
+
+    def state_count(self):
+        return int(self.L.svin_ba_state_count(self.h))
+
+    def get_imu_preintegral(self, fid):
+        a, b, dt = np.zeros(3), np.zeros(3), np.zeros(1)
+        return (a, b, float(dt[0])) if self.L.svin_ba_get_imu_preintegral(self.h, fid, _d(a), _d(b), _d(dt)) == 1 else None
+
+    def set_imu_preintegral(self, fid, adi, ai, dt):
+        adi, ai = _arr(adi), _arr(ai)
+        return self.L.svin_ba_set_imu_preintegral(self.h, fid, _d(adi), _d(ai), float(dt)) == 1
+
+    def init_pose_from_imu(self, imu_t, imu_m):
+        s = pack_imu(imu_t, imu_m)
+        T = np.zeros(7)
+        ok = self.L.svin_ba_init_pose_from_imu(s.ctypes.data_as(C.c_void_p), len(s), _d(T))
+        return ok == 1, T
+
+    def current_keyframe_id(self):
+        return int(self.L.svin_ba_current_keyframe_id(self.h))
+
+    def current_frame_id(self):
+        return int(self.L.svin_ba_current_frame_id(self.h))
+
+    def frame_id_by_age(self, age):
+        return int(self.L.svin_ba_frame_id_by_age(self.h, age))
+
+    def is_in_imu_window(self, fid):
+        return self.L.svin_ba_is_in_imu_window(self.h, fid) == 1
+
+    def set_camera_sensor_states(self, fid, cam, T):
+        T = _arr(T)
+        return self.L.svin_ba_set_camera_sensor_states(self.h, fid, cam, _d(T)) == 1
 
     def set_T_WS(self, fid, T):
         T = _arr(T)
@@ -346,12 +468,18 @@ class Estimator:
     def num_landmarks(self):
         return int(self.L.svin_ba_num_landmarks(self.h))
 
-    def imu_propagation(self, imu_t, imu_m, params, T, sb, t0, t1, want_cov=False, want_jac=False):
+    def imu_propagation(self, imu_t, imu_m, params, T, sb, t0, t1, want_cov=False, want_jac=False, want_integrals=False):
         s = pack_imu(imu_t, imu_m)
         q = make_imu_params(params)
         T, sb = _arr(T).copy(), _arr(sb).copy()
         cov = np.zeros((15, 15)) if want_cov else None
         jac = np.zeros((15, 15)) if want_jac else None
+        if want_integrals:   # second overload: acc_doubleintegral, acc_integral, Delta_t
+            integ = np.zeros(7)
+            n = self._check(self.L.svin_ba_imu_propagation_integrals(self.h, s.ctypes.data_as(C.c_void_p), len(s), C.byref(q),
+                                                                     _d(T), _d(sb), t0[0], t0[1], t1[0], t1[1], _d(cov),
+                                                                     _d(jac), _d(integ)) + 1, "imu_propagation") - 1
+            return n, T, sb, cov, jac, integ
         n = self._check(self.L.svin_ba_imu_propagation(self.h, s.ctypes.data_as(C.c_void_p), len(s), C.byref(q), _d(T), _d(sb),
                                                        t0[0], t0[1], t1[0], t1[1], _d(cov), _d(jac)) + 1, "imu_propagation") - 1
         return n, T, sb, cov, jac

@@ -175,16 +175,17 @@ def test_rig(extr_case=0):
 class Trajectory:
     """p(t): constant velocity plus gentle sinusoids; attitude: level start, sinusoidal roll/pitch/yaw (<= ~0.2 rad)."""
 
-    def __init__(self, g, speed=1.0, rot_amp=0.2, wobble=0.3):
+    def __init__(self, g, speed=1.0, rot_amp=0.2, wobble=0.3, axis=0):
         self.g = g
         self.speed = speed
         self.rot_amp = rot_amp
         self.wobble = wobble
+        self.axis = axis   # world axis of the main motion: 0 = sideways to the cameras, 2 = along the optical axes
 
     def p(self, t):
         w = self.wobble
-        return np.array([self.speed * t + w * np.sin(0.7 * t), w * np.sin(0.9 * t + 0.3) - w * np.sin(0.3),
-                         0.5 * w * np.sin(1.1 * t)])
+        return np.roll(np.array([self.speed * t + w * np.sin(0.7 * t), w * np.sin(0.9 * t + 0.3) - w * np.sin(0.3),
+                                 0.5 * w * np.sin(1.1 * t)]), self.axis)
 
     def R(self, t):
         a = self.rot_amp
@@ -260,7 +261,7 @@ def stamp_of(t0_sec, t):
 
 def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=0.5, pixel_noise=1.0, kp_size=8.0,
                 imu_noise=True, pose_noise=(0.05, 0.01), lm_noise=0.1, depth_range=(2.0, 15.0), sonar=False, depth=False,
-                keyframe_every=1, t0_sec=1000, traj=None):
+                keyframe_every=1, t0_sec=1000, traj=None, sonar_patch=(8, 30)):
     """Build one seeded synthetic window (config #2 defaults: 10 KF / 2 000 landmarks / 20 000 residuals).
 
     imu_noise: True = discrete white noise sigma/sqrt(dt); "testestimator" = the reference test's model
@@ -274,6 +275,8 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
         cams, imu_params, sig = test_rig(int(rig[4:] or 0))
     else:
         raise ValueError(rig)
+    if traj is None and sonar:
+        traj = dict(axis=2)   # along the optical axes: the side-looking sonar sweeps what the cameras saw earlier
     traj = Trajectory(imu_params["g"], **(traj or {}))
     rate = imu_params["rate"]
     times = np.arange(P) * frame_dt
@@ -308,6 +311,24 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
         p_s = quat_to_R(cam["T_SC"][3:]) @ p_c + cam["T_SC"][:3]
         lm[l, :3] = quat_to_R(T_true[k, 3:]) @ p_s + T_true[k, :3]
         lm[l, 3] = 1.0
+    # sonar (config #3): every frame gets one (range, heading) return and a *visual patch* -- a cluster of landmarks
+    # around the sonar point T_WS * T_SSo * [r cos h, r sin h, 0] (Estimator.cpp:265-316 gathers the landmarks inside a
+    # +-0.1 m box around that point, evaluated at the IMU-predicted pose).  The patch landmarks take the place of the
+    # last ones of the table, so L stays what the caller asked for.
+    sonar_meas, patch_slots = [None] * P, np.zeros(0, int)
+    if sonar:
+        n_patch = [int(rng.integers(sonar_patch[0], sonar_patch[1] + 1)) for _ in range(P)]
+        assert sum(n_patch) < L, "not enough landmarks for the sonar patches"
+        slot = L - sum(n_patch)
+        patch_slots = np.arange(slot, L)
+        for k in range(P):
+            rge, hdg = rng.uniform(0.6, 1.6), rng.uniform(-np.pi, np.pi)
+            R_ws = quat_to_R(T_true[k, 3:])
+            p_s = quat_to_R(T_SSO_RIG_V2[3:]) @ np.array([rge * np.cos(hdg), rge * np.sin(hdg), 0.0]) + T_SSO_RIG_V2[:3]
+            p_w = R_ws @ p_s + T_true[k, :3]
+            lm[slot:slot + n_patch[k], :3] = p_w + rng.uniform(-0.03, 0.03, size=(n_patch[k], 3))
+            slot += n_patch[k]
+            sonar_meas[k] = (float(rge + 0.005 * rng.normal()), float(hdg))
     # observations: all successful projections, landmark-major, truncated to n_obs
     obs = []
     for k in range(P):
@@ -318,9 +339,9 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
             p_c = (p_s - cam["T_SC"][:3]) @ Rsc
             uv, vis = project(cam, p_c)
             idx = np.nonzero(vis)[0]
-            for l in idx:
-                obs.append((l, k, c, uv[l, 0], uv[l, 1]))
-    obs = np.array(obs)
+            obs.append(np.stack([idx.astype(float), np.full(len(idx), float(k)), np.full(len(idx), float(c)), uv[idx, 0],
+                                 uv[idx, 1]], 1))
+    obs = np.concatenate(obs)
     order = np.lexsort((obs[:, 2], obs[:, 1], obs[:, 0]))
     obs = obs[order]
     if n_obs is not None and len(obs) > n_obs:
@@ -340,6 +361,8 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
         sb_init[k, :3] += rng.normal(size=3) * 0.02
     lm_init = lm.copy()
     lm_init[:, :3] += lm_noise * rng.normal(size=(L, 3))
+    if len(patch_slots):   # the patch landmarks are close to the vehicle and well triangulated: cm-level error
+        lm_init[patch_slots, :3] = lm[patch_slots, :3] + min(lm_noise, 0.01) * rng.normal(size=(len(patch_slots), 3))
     spec = WindowSpec(cameras=cams, extr_sigmas=sig, imu_params=imu_params, stamps=stamps, T_WS_true=T_true,
                       sb_true=sb_true, T_WS_init=T_init, sb_init=sb_init,
                       keyframe=(np.arange(P) % keyframe_every == 0), imu_t=imu_t, imu_meas=imu_meas, lm_true=lm,
@@ -353,19 +376,7 @@ def make_window(P=10, L=2000, n_obs=20000, seed=20250629, rig="euroc", frame_dt=
         spec.depth = [float(spec.first_depth - T_true[k, 2] + 0.01 * rng.normal()) for k in range(P)]
     if sonar:
         spec.T_SSo = T_SSO_RIG_V2.copy()
-        son = []
-        for k in range(P):
-            # aim the sonar at a landmark near its horizontal plane so that a visual patch exists
-            Two = np.r_[quat_to_R(T_true[k, 3:]) @ spec.T_SSo[:3] + T_true[k, :3],
-                        quat_mul(T_true[k, 3:], spec.T_SSo[3:])]
-            p_so = pose_inverse_apply(Two, lm[:, :3])
-            cand = np.nonzero((np.abs(p_so[:, 2]) < 0.05) & (np.hypot(p_so[:, 0], p_so[:, 1]) > 1.0))[0]
-            if len(cand) == 0:
-                son.append(None)
-                continue
-            l = cand[rng.integers(len(cand))]
-            son.append((float(np.hypot(p_so[l, 0], p_so[l, 1])), float(np.arctan2(p_so[l, 1], p_so[l, 0]))))
-        spec.sonar = son
+        spec.sonar = sonar_meas
     return spec
 
 
@@ -391,6 +402,12 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
     imu_sec = spec.imu_t[:, 0].astype(np.float64) - float(spec.imu_t[0, 0]) + 1e-9 * spec.imu_t[:, 1]
     frm_sec = spec.stamps[:, 0].astype(np.float64) - float(spec.imu_t[0, 0]) + 1e-9 * spec.stamps[:, 1]
     margin = 2.5 / spec.imu_params["rate"]
+    # The sonar patch of a frame is selected inside add_states at the IMU-predicted pose (Estimator.cpp:265-316), i.e.
+    # from the previous frame's *current* estimate.  The reference runs with optimised states at that point; in batch
+    # mode (all frames added, then one optimize) the states therefore stay at the truth while the window is built and
+    # the seeded perturbation is applied once every frame is in.
+    has_sonar = any(x is not None for x in (spec.sonar or []))
+    defer = perturb and has_sonar and on_frame is None and not optimize_each
     for k in range(spec.P if frames is None else frames):
         fid = est.new_id()
         frame_ids.append(fid)
@@ -403,7 +420,7 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
         ok = est.add_states(fid, (int(spec.stamps[k, 0]), int(spec.stamps[k, 1])), 400, T_SC, imu_t_k, imu_m_k,
                             bool(spec.keyframe[k]), son, dep, spec.first_depth)
         assert ok, "add_states failed for frame %d" % k
-        if perturb:
+        if perturb and not defer:
             if k > 0:
                 est.set_T_WS(fid, spec.T_WS_init[k])
             est.set_speed_and_bias(fid, spec.sb_init[k])
@@ -434,4 +451,9 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
             est.optimize(optimize_each, 1, False)
         if on_frame is not None:
             on_frame(k, fid)
+    if defer:
+        for k, fid in enumerate(frame_ids):
+            if k > 0:
+                est.set_T_WS(fid, spec.T_WS_init[k])
+            est.set_speed_and_bias(fid, spec.sb_init[k])
     return frame_ids, lm_ids

@@ -78,27 +78,130 @@ def test_reprojection_residuals_and_jacobians(gpu_lib, model, dist, robust):
     assert worst["r"] < 1e-9 and worst["Jp"] < 1e-10 and worst["Jl"] < 1e-10 and worst["Je"] < 1e-10
 
 
-def test_small_factors_parity(gpu_lib):
-    spec = syn.make_window(P=4, L=100, n_obs=800, seed=5, rig="rig_v2", sonar=True, depth=True)
-    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+def check_small_factors(gpu, cpu, expect_kinds, n_sonar=None):
+    """every non-reprojection factor of the window: residual, stacked minimal Jacobian, J^T J, J^T r against the oracle"""
     m = cpu.map()
     facs = gpu.eval_factors()
     assert len(facs) > 0
-    kinds = set()
+    kinds, count = set(), {}
     for f in facs:
         r, Js, Jm = m.eval(f["res_id"])
         J = np.concatenate(Jm, axis=1)
         kinds.add(f["kind"])
+        count[f["kind"]] = count.get(f["kind"], 0) + 1
         tol = {0: 1e-6, 3: 1e-8}.get(f["kind"], 1e-10)  # IMU: different 15x15 inverse; relpose: 1e8-scale weights
         dr = np.max(np.abs(f["r"] - r)) / max(1.0, np.max(np.abs(r)))
         dJ = np.max(np.abs(f["J"] - J)) / max(1.0, np.max(np.abs(J)))
         # weighting-independent invariants
         dH = rel(f["J"].T @ f["J"], J.T @ J)
-        dg = rel(f["J"].T @ f["r"], J.T @ r) if np.max(np.abs(J.T @ r)) > 1e-9 else 0.0
-        log("factor kind", f["kind"], "m", f["m"], "dr", dr, "dJ", dJ, "dJtJ", dH, "dJtr", dg)
+        # gradient contribution J^T r, compared in units of the parameters' standard deviations (column norms of J):
+        # a relative measure is meaningless where r is rounding noise (the relative-extrinsics factors start at r = 0
+        # exactly, |r| ~ 1e-9 after one normalisation, times 1e8-scale weights), an absolute one is not
+        cn = np.sqrt(np.maximum(np.sum(J * J, axis=0), 1e-300))
+        dg = float(np.max(np.abs(f["J"].T @ f["r"] - J.T @ r) / cn))
+        log("factor kind", f["kind"], "m", f["m"], "dr", dr, "dJ", dJ, "dJtJ", dH, "dJtr/sigma", dg)
         assert dr < tol and dJ < tol, (f["kind"], dr, dJ)
         assert dH < 1e-7
-    assert {0, 1, 2, 3}.issubset(kinds), kinds  # imu, pose prior, speed/bias prior, relative pose
+        assert dg < 1e-8 * max(1.0, float(np.max(np.abs(r)))), (f["kind"], dg)
+    assert expect_kinds.issubset(kinds), kinds
+    if n_sonar is not None:
+        assert count.get(4, 0) == n_sonar, count
+    return count
+
+
+def test_small_factors_parity(gpu_lib):
+    """IMU (0), pose prior (1), speed/bias prior (2), relative extrinsics (3), SONAR (4) and DEPTH (5) factors of a
+    rig-v2 window: every frame carries a sonar return whose visual patch exists (U4, Estimator.cpp:265-316)"""
+    spec = syn.make_window(P=4, L=300, n_obs=2500, seed=5, rig="rig_v2", sonar=True, depth=True)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    count = check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
+    assert count[5] == spec.P
+    # the same factors after the states have moved (the patch stays what it was at construction, SonarError.cpp:66)
+    for e in (gpu, cpu):
+        e.optimize(3)
+    check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
+
+
+def test_config3_full_size_sonar_depth(gpu_lib):
+    """BASELINE config #3 at full size: rig v2 (per-frame extrinsics + relative-pose factors), 10 keyframes, 4 000
+    landmarks, ~40 000 reprojection residuals, one depth and one sonar factor (8-30 point patch) per state"""
+    spec = syn.make_window(P=10, L=4000, n_obs=40000, seed=20250629, rig="rig_v2", sonar=True, depth=True)
+    assert spec.P == 10 and spec.L == 4000 and spec.N == 40000
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    count = check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=10)
+    assert count[5] == 10 and count[0] == 9 and count[3] == 18
+    gpu.optimize(10)
+    cpu.optimize(10)
+    sg, sc = gpu.summary(), cpu.summary()
+    log("config3 gpu", sg, "cpu", sc)
+    assert sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert sg["final_cost"] < sg["initial_cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    worst_e = max(pose_diff(gpu.get_camera_sensor_states(a, c), cpu.get_camera_sensor_states(b, c))
+                  for a, b in zip(fg, fc) for c in (0, 1))
+    err = max(np.linalg.norm(gpu.get_T_WS(a)[:3] - spec.T_WS_true[k, :3]) for k, a in enumerate(fg))
+    log("config3 pose difference vs oracle", worst, "extrinsics", worst_e, "max position error vs truth", err)
+    assert worst < 1e-4 and worst_e < 1e-4
+    assert err < 0.1
+
+
+@pytest.mark.parametrize("model,dist", [(syn.DIST_RADTAN, [-0.28, 0.07, 0.0002, 1.8e-05]), (syn.DIST_EQUIDISTANT, [-0.21, 0.14, 0.0006, 0.0003]),
+                                        (syn.DIST_RADTAN8, [-0.16, 0.15, 0.0003, 0.0002, 0.01, 0.02, -0.01, 0.005]),
+                                        (syn.DIST_NONE, [])])
+def test_reprojection_edge_cases(gpu_lib, model, dist):
+    """points the reference treats specially: closer than 0.2 m / behind the camera (zero Jacobians, residual kept,
+    ReprojectionError.hpp:140-147), on the optical axis (equidistant limit r <= 1e-8, EquidistantDistortion.hpp:176-183),
+    beyond rho = 9 (radtan8 gives up, RadialTangentialDistortion8.hpp:104,125), negative and tiny homogeneous scale"""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    imu = dict(syn.test_rig()[1])
+    rate = 100
+    ns = ((np.arange(8) - 2) * (1_000_000_000 // rate)).astype(np.int64) + 1_000_000_000
+    t = np.stack([50 + ns // 1_000_000_000, ns % 1_000_000_000], 1).astype(np.uint32)
+    m = np.zeros((8, 6))
+    m[:, 5] = imu["g"]                       # level and at rest: the first pose is the identity
+    T_SC = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+    pts = [[0.0, 0.0, 5.0, 1.0],             # exactly on the optical axis
+           [1e-9, -1e-9, 4.0, 1.0],          # inside the equidistant limit
+           [0.3, -0.2, 0.15, 1.0],           # closer than 20 cm: invalid
+           [0.3, 0.2, -2.0, 1.0],            # behind the camera: invalid
+           [12.0, 1.0, 3.0, 1.0],            # rho = 16.1 > 9
+           [2.9 * 2.0, 0.0, 2.0, 1.0],       # rho = 8.41: still accepted
+           [-0.4, 0.6, -6.0, -2.0],          # negative homogeneous scale (the same point as (0.2, -0.3, 3))
+           [0.5, 0.25, 3.0, 1e-9],           # |w| <= 1e-8: no validity test
+           [0.4, -0.1, 2.5, 1.0]]            # an ordinary point
+    ests = []
+    for cls in (Estimator, orc.OracleEstimator):
+        e = cls(0) if cls is Estimator else cls()
+        e.add_camera(model, [350.0, 360.0, 378.0, 238.0], dist, 752, 480, [0.0, 0.0, 0.0, 0.0])
+        e.add_imu(imu)
+        lids = [e.new_id() for _ in pts]
+        for lid, p in zip(lids, pts):
+            assert e.add_landmark(lid, np.array(p))
+        fid = e.new_id()
+        assert e.add_states(fid, (51, 0), 400, T_SC, t, m, True)
+        for k, lid in enumerate(lids):
+            assert e.add_observation(lid, fid, 0, k, [300.0 + 7 * k, 200.0 - 5 * k], 6.0) != 0
+        ests.append(e)
+    gpu, cpu = ests
+    assert np.max(np.abs(gpu.get_T_WS(fid) - cpu.get_T_WS(fid))) == 0.0
+    ev = gpu.eval_reprojection(robust=False)
+    mp_ = cpu.map()
+    for i in range(len(pts)):
+        r, Js, Jm = mp_.eval(int(ev["res_id"][i]))
+        k = int(np.nonzero(np.array(lids) == int(ev["lm_id"][i]))[0][0])
+        for a, b in ((ev["r"][i], r), (ev["Jp"][i], Jm[0]), (ev["Jl"][i], Jm[1]), (ev["Je"][i], Jm[2])):
+            assert np.max(np.abs(a - b)) <= 1e-10 * max(1.0, np.max(np.abs(b))), (k, pts[k], a, b)
+        if k in (2, 3):
+            assert np.all(ev["Jp"][i] == 0) and np.all(ev["Jl"][i] == 0) and np.all(ev["Je"][i] == 0) and np.any(ev["r"][i] != 0)
+        if k == 8:
+            assert np.any(ev["Jp"][i] != 0)
+    # the window still optimises (the invalid observations contribute cost but no curvature) and both sides agree
+    gpu.optimize(5)
+    cpu.optimize(5)
+    assert gpu.summary()["iterations"] == cpu.summary()["iterations"]
+    assert abs(gpu.summary()["final_cost"] - cpu.summary()["final_cost"]) <= 1e-9 * max(1.0, cpu.summary()["final_cost"])
 
 
 def map_blocks(est, ids):
@@ -390,7 +493,116 @@ def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
         assert worst < 1e-9
 
 
-def test_keyframe_hand_off_matches_oracle():
+def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
+    """The sharded solve with RCCL called natively on the solver's stream (ncclAllReduce in place, scalars published to
+    the mailbox after the reduction, speculative build kept).  One GPU cannot hold two RCCL ranks, so the code path is
+    driven with a ONE-rank communicator: every collective really runs (and is the identity), the rest of the path is
+    what 8 ranks execute."""
+    from svin_amd.estimator import Estimator, rccl_unique_id
+    spec = syn.make_window(P=6, L=300, n_obs=3000, seed=71)
+    ref = Estimator(0)
+    f_ref, _ = syn.feed(ref, spec)
+    ref.optimize(10)
+    est = Estimator(0)
+    f, _ = syn.feed(est, spec)
+    est.set_distributed_rccl(0, 1, rccl_unique_id())
+    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    est.optimize(10)
+    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    s, s_ref = est.summary(), ref.summary()
+    worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
+    log("native RCCL, one rank: summary", s, "reference", s_ref, "pose diff", worst)
+    assert s["iterations"] == s_ref["iterations"] and s["successful"] == s_ref["successful"]
+    assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+    assert worst < 1e-9
+    # a wide window through the same path (panel-pair Schur kernel + multi-workgroup Cholesky)
+    spec = syn.make_window(P=48, L=900, n_obs=9000, seed=5)
+    ref = Estimator(0)
+    f_ref, _ = syn.feed(ref, spec)
+    ref.optimize(6)
+    est = Estimator(0)
+    f, _ = syn.feed(est, spec)
+    est.set_distributed_rccl(0, 1, rccl_unique_id())
+    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    est.optimize(6)
+    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
+    assert est.summary()["iterations"] == ref.summary()["iterations"] and worst < 1e-8, worst
+
+
+def test_wide_window_panels_against_oracle(gpu_lib):
+    """config-#4 shape at a size the oracle finishes in seconds: 48 keyframes (dC = 288: three 96-row panels, six panel
+    pairs in k_schur_panels) and d = 720 unknowns through the one-launch tile Cholesky (k_big_chol_chain) -- held
+    against the ORACLE (reduced system and optimised states), not against the product's other kernel"""
+    spec = syn.make_window(P=48, L=1500, n_obs=15000, seed=31, frame_dt=0.25)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    lin_c = cpu.map().linearize(0.0)
+    lin_g = gpu.linearize(0.0)
+    assert lin_g["d"] == lin_c["d"] == 48 * 15
+    perm = reduced_permutation(gpu, cpu, fg, fc, lin_g, lin_c)
+    S, g = lin_g["S"][np.ix_(perm, perm)], lin_g["g"][perm]
+    sd = np.sqrt(np.abs(np.diag(lin_c["S"])))
+    dS, dg = rel(S / np.outer(sd, sd), lin_c["S"] / np.outer(sd, sd)), rel(g / sd, lin_c["g"] / sd)
+    log("wide window (P = 48) reduced system vs oracle: dS", dS, "dg", dg)
+    assert dS < 1e-9 and dg < 1e-9
+    gpu.optimize(6)
+    cpu.optimize(6)
+    sg, sc = gpu.summary(), cpu.summary()
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    log("wide window (P = 48) gpu", sg, "cpu", sc, "pose diff", worst)
+    assert sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    assert worst < 1e-4
+
+
+def test_wide_window_with_per_frame_extrinsics(gpu_lib):
+    """config #4 with online extrinsics calibration: 64 keyframes x (6 pose + 2 x 6 extrinsics + 9 speed/bias) =
+    1 728 unknowns -- beyond the former d ~ 1 100 guard: pairwise Schur accumulation with global atomics,
+    twenty-seven 64-column panels in the tile Cholesky"""
+    spec = syn.make_window(P=64, L=2500, n_obs=25000, seed=37, rig="test4", frame_dt=0.25)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    lin_g = gpu.linearize(0.0)
+    assert lin_g["d"] == 64 * 27 == 1728
+    gpu.optimize(5)
+    cpu.optimize(5, 8)
+    sg, sc = gpu.summary(), cpu.summary()
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    worst_e = max(pose_diff(gpu.get_camera_sensor_states(a, c), cpu.get_camera_sensor_states(b, c))
+                  for a, b in zip(fg, fc) for c in (0, 1))
+    log("64 KF, per-frame extrinsics: d", lin_g["d"], "gpu", sg, "cpu", sc, "pose diff", worst, "extrinsics", worst_e)
+    assert sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    assert worst < 1e-4 and worst_e < 1e-4
+
+
+def test_config4_full_size_single_gpu(gpu_lib):
+    """BASELINE config #4 at full size on ONE GPU (64 keyframes / 50 000 landmarks / 500 000 residuals, d = 960):
+    size-independent properties, and the oracle's first linearisation + one iteration beside it"""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    spec = syn.make_window(P=64, L=50000, n_obs=500000, seed=20250629, frame_dt=0.25)
+    assert spec.P == 64 and spec.L == 50000 and spec.N == 500000
+    gpu, cpu = Estimator(0), orc.OracleEstimator()
+    fg, lg = syn.feed(gpu, spec)
+    fc, lc = syn.feed(cpu, spec)
+    gpu.optimize(2)
+    cpu.optimize(2, 8)        # 8 threads: the summation order differs from one thread at rounding level only
+    sg, sc = gpu.summary(), cpu.summary()
+    log("config4 gpu", sg, "cpu", sc)
+    assert sg["iterations"] == sc["iterations"] == 2
+    assert abs(sg["initial_cost"] - sc["initial_cost"]) <= 1e-9 * sc["initial_cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    log("config4 pose difference vs oracle after 2 iterations", worst)
+    assert worst < 1e-6
+    gpu.optimize(10)
+    s = gpu.summary()
+    err = max(np.linalg.norm(gpu.get_T_WS(a)[:3] - spec.T_WS_true[k, :3]) for k, a in enumerate(fg))
+    log("config4 after 12 iterations", s, "max position error vs truth", err)
+    assert s["final_cost"] <= sg["final_cost"] and err < 0.1
+
+
+def test_keyframe_hand_off_matches_oracle(gpu_lib):
     """the estimator-side content of the keyframe message for pose_graph (ThreadedKFVio.cpp:1147-1240),
     on a window that has been optimised and marginalised (landmarks and observations come and go)"""
     spec = syn.make_window(P=12, L=300, n_obs=3000, seed=19, keyframe_every=2)

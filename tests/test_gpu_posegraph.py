@@ -51,7 +51,7 @@ def compare(g, c, sg, sc, tol_pose=1e-7):
 
 @pytest.mark.parametrize("six", [False, True])
 @pytest.mark.parametrize("n,laps,loop_every", [(40, 2, 5), (160, 4, 8), (400, 4, 25)])
-def test_optimize_matches_oracle(six, n, laps, loop_every):
+def test_optimize_matches_oracle(gpu_lib, six, n, laps, loop_every):
     # d = 4 * 39 = 156 (LDS-resident Cholesky) ... 6 * 399 = 2394 (multi-workgroup blocked Cholesky)
     spec = spg.make_pose_graph(n=n, laps=laps, loop_every=loop_every, seed=11 + n)
     g, c, earliest, cur = pair(six, spec)
@@ -61,7 +61,7 @@ def test_optimize_matches_oracle(six, n, laps, loop_every):
 
 
 @pytest.mark.parametrize("six", [False, True])
-def test_incremental_optimisation_and_drift(six):
+def test_incremental_optimisation_and_drift(gpu_lib, six):
     """the optimisation thread's life: optimise at a loop, keyframes keep arriving (drift-corrected on arrival),
     optimise again from the SVIn poses (PoseGraph.cpp:127-132, :262-275, :356-375)"""
     spec = spg.make_pose_graph(n=300, laps=3, loop_every=20, seed=21)
@@ -84,7 +84,7 @@ def test_incremental_optimisation_and_drift(six):
     assert np.max(np.abs(Tg[281:] - spec.t_svin[281:])) > 1e-3
 
 
-def test_multiple_sequences_and_constant_first_sequence():
+def test_multiple_sequences_and_constant_first_sequence(gpu_lib):
     """6-DoF: keyframes of sequence 0 stay constant (PoseGraph.cpp:449-452); sequential edges only inside a sequence"""
     spec = spg.make_pose_graph(n=200, laps=4, loop_every=10, seed=31)
     spec.sequence[:60] = 0
@@ -99,7 +99,7 @@ def test_multiple_sequences_and_constant_first_sequence():
             assert np.max(np.abs(Tg[lo:60] - spec.t_svin[lo:60])) == 0.0
 
 
-def test_no_loop_is_a_no_op():
+def test_no_loop_is_a_no_op(gpu_lib):
     spec = spg.make_pose_graph(n=50, laps=1, loop_every=1000, seed=2)
     assert not spec.loops
     g, c, earliest, cur = pair(False, spec)
@@ -113,7 +113,7 @@ def test_no_loop_is_a_no_op():
 @pytest.mark.parametrize("levels", [1, 2])
 @pytest.mark.parametrize("n,laps,loop_every,piece", [(160, 4, 8, 8), (400, 4, 25, 16), (400, 4, 10, 64), (1200, 6, 20, 64),
                                                      (1200, 6, 40, 8)])
-def test_piece_elimination_matches_oracle(six, levels, n, laps, loop_every, piece):
+def test_piece_elimination_matches_oracle(gpu_lib, six, levels, n, laps, loop_every, piece):
     """the separator / piece solver (chain cut into pieces, banded Cholesky per piece, dense separator system) against
     the oracle's plain Cholesky of the same normal equations"""
     spec = spg.make_pose_graph(n=n, laps=laps, loop_every=loop_every, seed=5 + n)
@@ -130,7 +130,7 @@ def test_piece_elimination_matches_oracle(six, levels, n, laps, loop_every, piec
 
 
 @pytest.mark.parametrize("six", [False, True])
-def test_config5_graph_matches_oracle(six):
+def test_config5_graph_matches_oracle(gpu_lib, six):
     """BASELINE config #5 size: 5,000 keyframes, 190 loop closures (oracle: envelope Cholesky)"""
     from oracle import orc
     from svin_amd.posegraph import PoseGraph
@@ -144,7 +144,7 @@ def test_config5_graph_matches_oracle(six):
 
 
 @pytest.mark.parametrize("six", [False, True])
-def test_outlier_loops_in_the_huber_region(six):
+def test_outlier_loops_in_the_huber_region(gpu_lib, six):
     """a few grossly wrong loop measurements: their residuals sit far outside HuberLoss(0.1)'s quadratic region, so the
     corrector scaling sqrt(rho') is active on both sides (loss_function.cc / corrector.cc restated in the oracle)"""
     spec = spg.make_pose_graph(n=600, laps=4, loop_every=15, seed=17)

@@ -102,3 +102,27 @@ def test_tiny_window_fixed_point_matches_independent_minimiser():
     assert np.linalg.norm(T1[:3] - g["T1_opt"][:3]) < 2e-3
     assert min(np.linalg.norm(T1[3:] - g["T1_opt"][3:]), np.linalg.norm(T1[3:] + g["T1_opt"][3:])) < 1e-3
     assert np.max(np.abs(lm - g["lm_opt"])) < 3e-2
+
+
+def test_sonar_and_depth_errors_match_independent_derivation():
+    """SonarError (incl. the reference's Jacobian, which is not the derivative of its residual) and DepthError against
+    tests/golden/sonar_depth.npz (mpmath restatement of the definitions, tests/golden/make_golden_r2.py)"""
+    g = np.load(os.path.join(GOLD, "sonar_depth.npz"))
+    m = orc.OracleMap()
+    L = orc.lib()
+    for i in range(len(g["range"])):
+        k = int(g["npatch"][i])
+        patch = orc.arr(g["patch"][i][:k])
+        m.add_param(300 + i, orc.BLOCK_POSE, g["T_eval"][i])
+        rid = L.orc_map_add_sonar_error(m.h, orc.dptr(orc.arr(g["T_SSo"])), float(g["range"][i]), float(g["heading"][i]), 1.0, k,
+                                        orc.dptr(patch), 300 + i)
+        r, Js, Jm = m.eval(rid)
+        assert abs(r[0] - g["r"][i]) < 1e-13
+        assert np.max(np.abs(Jm[0][0] - g["J_ref"][i])) < 1e-13
+        assert np.max(np.abs(Js[0][0][:3] - g["J_ref"][i][:3])) < 1e-13 and np.all(Js[0][0][3:] == 0)
+        rid = L.orc_map_add_depth_error(m.h, float(g["depth"][i]), 5.0, float(g["first_depth"][i]), 300 + i)
+        r, Js, Jm = m.eval(rid)
+        assert abs(r[0] - g["depth_r"][i]) < 1e-13
+        assert np.max(np.abs(Jm[0][0] - g["depth_J"][i])) < 1e-15
+    # the reference's sonar Jacobian has (nearly) the opposite sign of the residual's true derivative: recorded, not fixed
+    assert np.max(np.abs(g["J_ref"] - g["J_true"])) > 1.0
