@@ -8,13 +8,23 @@ Workload (BASELINE.json configs[1]): synthetic stereo+IMU window, 10 keyframes /
 `Estimator::optimize(10)` trust-region solve from the seeded perturbed initial state with the inputs
 already resident in HBM (upload and download are excluded and reported separately); `value` =
 Gauss-Newton iterations completed / wall time of the K solves (device-synchronised, max over ranks).
-For N > 1 each rank solves its own replica window (config #2 is far below the size where sharding
-one window pays): weak scaling, no data-path collective.
+
+N > 1: `--gpus N` launches N ranks itself (torch.distributed.run, one process per GPU) unless it already runs under
+such a launcher, in which case WORLD_SIZE must equal N.  The headline stays config #2 with one replica window per rank
+(the window is far below the size where sharding pays, SURVEY.md 8(e): weak scaling, no data-path collective); the
+line additionally carries `sharded_config4`: ONE 64-keyframe / 50 000-landmark window whose landmarks are split over
+the ranks, the reduced camera system all-reduced by RCCL on the solver's stream every iteration.
+
+Sub-records in the same JSON line (rank 0, measured after the headline region): `config3` (sonar + depth + per-frame
+extrinsics), `config4_single_gpu`, `config5` (pose graph), `cpu_baseline` at 1 / 2 / all host threads.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,13 +32,14 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0   # measured copy ceiling quoted by the same guide (report both fractions)
+F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64, tools/ubench) x 2.4 GHz
 
 
 def snapshot_init(est, fids, lids, spec):
     return dict(T=[spec.T_WS_init[k] for k in range(len(fids))], sb=[spec.sb_init[k] for k in range(len(fids))],
-                lm=[spec.lm_init[l] for l in range(len(lids))],
-                T0=est.get_T_WS(fids[0]).copy())
+                lm=[spec.lm_init[l] for l in range(len(lids))], T0=est.get_T_WS(fids[0]).copy())
 
 
 def reset_state(est, fids, lids, snap):
@@ -43,31 +54,99 @@ def reset_state(est, fids, lids, snap):
         est.invalidate_preintegration()
 
 
-def cpu_baseline(spec, budget_s=15.0):
-    """Oracle (CPU restatement, 1 thread) timed on the same window: optimize(10) from the same start."""
+def timed_solves(est, fids, lids, snap, steps, warmup, iters, sync):
+    """`steps` solves from the same start; returns (per-step seconds, per-step iterations, last summary)"""
+    times, its, last = [], [], None
+    for k in range(warmup + steps):
+        reset_state(est, fids, lids, snap)
+        est.prepare()                       # pack + upload (untimed: inputs resident in HBM)
+        sync()
+        t0 = time.perf_counter()
+        est.solve_prepared(iters)           # returns device-synchronised
+        sync()
+        dt = time.perf_counter() - t0
+        last = est.summary()
+        est.finish()
+        if k >= warmup:
+            times.append(dt)
+            its.append(last["iterations"])
+    return times, its, last
+
+
+def cpu_baseline(spec, budget_s=6.0):
+    """Oracle (CPU restatement of the reference's Ceres path) on the same window: optimize(10) from the same start, at
+    1 thread, 2 threads (what the pipeline uses, ThreadedKFVio.cpp:1086) and all host cores."""
     from oracle import orc
     from svin_amd import synthetic as syn
-    lib = None
     try:
-        path = orc.build(native=True, out="/tmp/liborc_native.so")
-        lib = orc.lib(path)
+        lib = orc.lib(orc.build(native=True, out="/tmp/liborc_native.so"))
     except Exception:
         lib = orc.lib()
-    iters, total, runs = 0, 0.0, 0
-    while total < budget_s and runs < 200:
-        est = orc.OracleEstimator(L=lib)
-        syn.feed(est, spec)
-        t0 = time.perf_counter()
-        est.optimize(10, 1, False)
-        total += time.perf_counter() - t0
-        iters += est.summary()["iterations"]
-        runs += 1
-    return dict(value=iters / total, unit="GN iterations/s", cores=1, kind="port",
-                sample="%d x optimize(10) on the full config-#2 window (%d iterations, %.1f s), oracle/ C++ restatement, "
-                       "g++ -O3 -march=native, 1 thread" % (runs, iters, total))
+    nproc = os.cpu_count() or 1
+    rows = {}
+    for nt in sorted({1, 2, nproc}):
+        iters, total, runs = 0, 0.0, 0
+        while total < budget_s and runs < 200:
+            est = orc.OracleEstimator(L=lib)
+            syn.feed(est, spec)
+            t0 = time.perf_counter()
+            est.optimize(10, nt, False)
+            total += time.perf_counter() - t0
+            iters += est.summary()["iterations"]
+            runs += 1
+        rows[nt] = dict(value=iters / total, runs=runs, iterations=iters, seconds=total)
+    one = rows[1]
+    return dict(value=one["value"], unit="GN iterations/s", cores=1, kind="port", nproc=nproc,
+                threads={str(nt): r["value"] for nt, r in rows.items()},
+                sample="%d x optimize(10) on the full config-#2 window (%d iterations, %.1f s) per thread count; oracle/ C++ "
+                       "restatement of the reference's Ceres path (analytic Jacobians, landmark Schur, dense Cholesky), g++ -O3 "
+                       "-march=native; threads = residual evaluation + Schur elimination like ceres num_threads; host has %d "
+                       "logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
 
 
-F64_MFMA_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 2048 flop / 64 cycles (v_mfma_f64_16x16x4_f64, tools/ubench) x 2.4 GHz
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) and pass their output through"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def init_distributed(args):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or let bench.py spawn the "
+                         "ranks itself)" % (args.gpus, world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank, dist
+
+
+def reduce_time_and_count(dist, total_t, total_it):
+    import torch
+    if dist is None:
+        return total_t, total_it
+    tt = torch.tensor([total_t], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ti = torch.tensor([float(total_it)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+    return float(tt.item()), int(ti.item())
 
 
 def main_posegraph(args):
@@ -76,15 +155,17 @@ def main_posegraph(args):
     iterations (relinearise + solve + candidate evaluation) per second of device time, inputs resident in HBM.  The
     path does not shard: N > 1 runs replicas."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    rank, world, local_rank, dist = init_distributed(args)
+    out = posegraph_record(args, rank, world, local_rank, dist, args.steps, args.warmup, cpu=not args.no_cpu_baseline and world == 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+def posegraph_record(args, rank, world, local_rank, dist, steps, warmup, cpu):
+    import torch
     from svin_amd import synthetic_pg as spg
     from svin_amd.posegraph import PoseGraph
     spec = spg.make_pose_graph(n=5000, laps=20, loop_every=25, seed=7 + rank)
@@ -97,13 +178,13 @@ def main_posegraph(args):
         g.close()
         return s, part
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     total_t, total_it, dense_t, dense_n, last, part = 0.0, 0, 0.0, 0, None, None
-    for _ in range(args.steps):
+    for _ in range(steps):
         last, part = one_step()
         total_t += last["solve_seconds"]
         total_it += last["iterations"]
@@ -112,49 +193,97 @@ def main_posegraph(args):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-        tt = torch.tensor([total_t], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ti = torch.tensor([float(total_it)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-        total_t, total_it = float(tt.item()), int(ti.item())
-    out = None
-    if rank == 0:
-        value = total_it / total_t
-        d = part["separator_unknowns"]
-        flops = d ** 3 / 3.0 + 2.0 * d * d     # Cholesky + the two triangular solves of the separator system
-        ach = flops / (dense_t / max(dense_n, 1)) / 1e12
-        out = {
-            "metric": "pose-graph Levenberg-Marquardt iterations/sec on a 5,000-keyframe loop-closure graph",
-            "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * total_t / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[4]: pose_graph loop closure, 5000 keyframes / %d loop edges, %s, seed 7, one "
-                                   "optimize pass per step" % (len(spec.loops), "6-DoF" if args.six_dof else "4-DoF"),
-                       "iterations_per_step": total_it / (args.steps * world), "initial_cost": last["initial_cost"],
-                       "final_cost": last["final_cost"], "partition": part, "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_big_chol_chain + k_big_back",
-                         "launch_ms": 1e3 * dense_t / max(dense_n, 1), "flops_per_launch": flops,
-                         "note": "dense root of %d unknowns (loop cover + level-2 cuts): latency-bound (serial 16-column "
-                                 "pivots), not throughput-bound; see DESIGN.md 9" % d},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import orc
-            c = orc.OraclePoseGraph(six_dof=args.six_dof, envelope=True)
-            earliest, cur = spg.feed(c, spec)
-            t0 = time.perf_counter()
-            sc = c.optimize(earliest, cur)
-            dt = time.perf_counter() - t0
-            out["cpu_baseline"] = dict(value=sc["iterations"] / dt, unit="LM iterations/s", cores=1, kind="port",
-                                       sample="one optimize pass of the same graph (%d iterations, %.1f s), oracle/ C++ "
-                                              "restatement with an envelope Cholesky in natural order -- NOT Ceres' "
-                                              "supernodal SuiteSparse factorisation, which would be markedly faster"
-                                              % (sc["iterations"], dt))
-            out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    total_t, total_it = reduce_time_and_count(dist, total_t, total_it)
+    if rank != 0:
+        return None
+    value = total_it / total_t
+    d = part["separator_unknowns"]
+    flops = d ** 3 / 3.0 + 2.0 * d * d     # Cholesky + the two triangular solves of the separator system
+    ach = flops / (dense_t / max(dense_n, 1)) / 1e12
+    out = {
+        "metric": "pose-graph Levenberg-Marquardt iterations/sec on a 5,000-keyframe loop-closure graph",
+        "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * total_t / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[4]: pose_graph loop closure, 5000 keyframes / %d loop edges, %s, seed 7, one "
+                               "optimize pass per step" % (len(spec.loops), "6-DoF" if args.six_dof else "4-DoF"),
+                   "iterations_per_step": total_it / (steps * world), "initial_cost": last["initial_cost"],
+                   "final_cost": last["final_cost"], "partition": part, "parallelism": "replicas x%d" % world},
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_big_chol_chain + k_big_back",
+                     "launch_ms": 1e3 * dense_t / max(dense_n, 1), "flops_per_launch": flops,
+                     "note": "dense root of %d unknowns (loop cover + level-2 cuts): latency-bound (serial 16-column "
+                             "pivots), not throughput-bound; see DESIGN.md 9" % d},
+    }
+    if cpu:
+        from oracle import orc
+        c = orc.OraclePoseGraph(six_dof=args.six_dof, envelope=True)
+        earliest, cur = spg.feed(c, spec)
+        t0 = time.perf_counter()
+        sc = c.optimize(earliest, cur)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=sc["iterations"] / dt, unit="LM iterations/s", cores=1, kind="port",
+                                   sample="one optimize pass of the same graph (%d iterations, %.1f s), oracle/ C++ "
+                                          "restatement with an envelope Cholesky in natural order -- NOT Ceres' "
+                                          "supernodal SuiteSparse factorisation, which would be markedly faster"
+                                          % (sc["iterations"], dt))
+        out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     return out
+
+
+def window_record(name, spec, device, steps, warmup, iters):
+    """one single-GPU sub-record: `steps` x optimize(iters) of a synthetic window, inputs resident"""
+    import torch
+    from svin_amd import synthetic as syn
+    from svin_amd.estimator import Estimator
+    est = Estimator(device)
+    fids, lids = syn.feed(est, spec)
+    snap = snapshot_init(est, fids, lids, spec)
+    times, its, last = timed_solves(est, fids, lids, snap, steps, warmup, iters, torch.cuda.synchronize)
+    facs = est.eval_factors() if spec.P <= 16 else []
+    kinds = {}
+    for f in facs:
+        kinds[str(f["kind"])] = kinds.get(str(f["kind"]), 0) + 1
+    rec = dict(workload=name, value=sum(its) / sum(times), unit="GN iterations/s", steps=steps,
+               ms_per_iteration=1e3 * sum(times) / max(sum(its), 1), median_ms_per_step=1e3 * float(np.median(times)),
+               iterations_per_step=sum(its) / steps, initial_cost=last["initial_cost"], final_cost=last["final_cost"],
+               upload_ms=1e3 * last["upload_time"], P=spec.P, L=spec.L, N=spec.N)
+    if kinds:
+        rec["factor_kinds"] = kinds   # 0 imu 1 pose prior 2 speed/bias prior 3 relative extrinsics 4 sonar 5 depth
+    return rec, est
+
+
+def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
+    """ONE config-#4 window (64 KF / 50 000 landmarks / 500 000 residuals) with its landmarks split over the ranks: every
+    rank holds all states and its landmark range; per iteration one RCCL all-reduce of [S | g | h] (d^2 + 3d doubles) and
+    three small ones of trust-region scalars, all enqueued on the solver's stream (svin_ba_set_distributed_rccl)."""
+    import torch
+    from svin_amd import synthetic as syn
+    from svin_amd import distributed as sd
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=64, L=50000, n_obs=500000, seed=20250629, frame_dt=0.25)
+    mine = sd.shard_spec(spec, rank, world)
+    est = Estimator(local_rank)
+    fids, lids = syn.feed(est, mine)
+    sd.init_rccl(est, rank, world)
+    snap = snapshot_init(est, fids, lids, mine)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+    times, its, last = timed_solves(est, fids, lids, snap, steps, warmup, iters, sync)
+    t = torch.tensor(times, dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per step: the slowest rank
+    times = [float(v) for v in t.cpu()]
+    d = 64 * 15
+    return dict(workload="configs[3]: ONE window, 64 KF / 50000 landmarks / 500000 residuals, landmarks sharded over %d GPUs, "
+                         "optimize(%d) per step" % (world, iters),
+                value=sum(its) / sum(times), unit="GN iterations/s", n_gpus=world, steps=steps, scaling="strong",
+                ms_per_iteration=1e3 * sum(times) / max(sum(its), 1), median_ms_per_step=1e3 * float(np.median(times)),
+                iterations_per_step=sum(its) / steps, final_cost=last["final_cost"], initial_cost=last["initial_cost"],
+                landmarks_per_rank=mine.L, residuals_per_rank=mine.N,
+                allreduce_bytes_per_iteration=8 * (d * d + 3 * d) + 8 * (8 + 2 + 8),
+                collective="ncclAllReduce (RCCL), FP64 sum, in place, on the solver's HIP stream")
 
 
 def main():
@@ -164,24 +293,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--copies", type=int, default=256, help="window replicas for the HBM-resident Jacobian-eval roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config3 / config4 / config5 / sharded sub-records")
     ap.add_argument("--workload", default="window", choices=["window", "posegraph"],
                     help="window = BASELINE configs[1] (the north-star metric, default); posegraph = configs[4], the "
                          "global pose-graph optimisation (SURVEY 8(f) N1), reported as its own line")
     ap.add_argument("--six-dof", action="store_true", help="posegraph: optimize6DoFPoseGraph instead of the 4-DoF one")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.workload == "posegraph":
         return main_posegraph(args)
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    rank, world, local_rank, dist = init_distributed(args)
 
     from svin_amd import synthetic as syn
     from svin_amd.estimator import Estimator
@@ -191,40 +315,22 @@ def main():
     fids, lids = syn.feed(est, spec)
     snap = snapshot_init(est, fids, lids, spec)
 
-    def one_step():
-        reset_state(est, fids, lids, snap)
-        est.prepare()                       # pack + upload (untimed: inputs resident in HBM)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        est.solve_prepared(10)              # returns device-synchronised
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        s = est.summary()
-        est.finish()
-        return dt, s["iterations"], s
-
-    for _ in range(args.warmup):
-        one_step()
+    timed_solves(est, fids, lids, snap, 0, args.warmup, 10, torch.cuda.synchronize)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    total_t, total_it, last = 0.0, 0, None
-    for _ in range(args.steps):
-        dt, it, last = one_step()
-        total_t += dt
-        total_it += it
+    t_region = time.perf_counter()
+    times, its, last = timed_solves(est, fids, lids, snap, args.steps, 0, 10, torch.cuda.synchronize)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-        tt = torch.tensor([total_t], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ti = torch.tensor([float(total_it)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-        total_t, total_it = float(tt.item()), int(ti.item())
+    t_region = time.perf_counter() - t_region
+    total_t, total_it = reduce_time_and_count(dist, sum(times), sum(its))
 
     out = None
     if rank == 0:
         value = total_it / total_t
+        med = float(np.median(times))
         out = {
             "metric": "Gauss-Newton iterations/sec on 10-KF/2k-landmark window; Jacobian-eval HBM GB/s",
             "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,7 +340,11 @@ def main():
                                    "/ 9 IMU factors, seed 20250629, optimize(10) per step",
                        "iterations_per_step": total_it / (args.steps * world), "final_cost": last["final_cost"],
                        "initial_cost": last["initial_cost"], "upload_ms": 1e3 * last["upload_time"],
-                       "download_ms": 1e3 * last["download_time"], "parallelism": "replicas x%d" % world},
+                       "download_ms": 1e3 * last["download_time"], "parallelism": "replicas x%d" % world,
+                       # median of >= 30 runs; `value` itself is total iterations / total time of the K steps
+                       "median_ms_per_step": 1e3 * med, "value_at_median": (its[0] / med) * world,
+                       "min_ms_per_step": 1e3 * min(times), "max_ms_per_step": 1e3 * max(times),
+                       "timed_region_s_incl_untimed_upload": t_region},
         }
         # roofline of the dominant streaming kernel (K1 reprojection residual + Jacobian evaluation) on an
         # HBM-resident batch of replicas; HIP events on the kernel's own stream
@@ -242,28 +352,87 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         ms1, nbytes1 = est.bench_jacobian_eval(1, 50)
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
-        # tools/k1_bench.py, gfx950 FETCH_SIZE x2 correction; committed summary profiles/r01_k1_pmc.txt).  Counters
+        # tools/k1_bench.py, gfx950 FETCH_SIZE x2 correction; committed summary profiles/*_k1_pmc.json).  Counters
         # cannot be read from inside this process, so the committed measurement is quoted when it describes the same
         # launch (same replica count and algorithmic bytes); otherwise null.
         traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k1_pmc.json")) as fh:
-                pmc = json.load(fh)
-            if abs(pmc["algorithmic_bytes_per_launch"] - nbytes) < 1e-6 * nbytes:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r02_k1_pmc.json", "r01_k1_pmc.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh)
+                if abs(pmc["algorithmic_bytes_per_launch"] - nbytes) < 1e-6 * nbytes:
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        n_res = spec.N * args.copies
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "k_eval_reproj", "launch_ms": ms, "bytes_per_launch": nbytes,
                            "replicas": args.copies,
+                           "frac_of_copy_ceiling": ach / HBM_COPY_CEILING_GBS,
+                           # SURVEY 8(d) prices a residual at 191.2 B (fixed extrinsics); this layout stores the landmark
+                           # index explicitly (+4 B) and `achieved` counts it -- the figure without it:
+                           "achieved_survey_bytes": 191.2 * n_res / (ms * 1e-3) / 1e9,
+                           "frac_survey_bytes": 191.2 * n_res / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "single_window_cache_resident": {"launch_ms": ms1, "GBps": nbytes1 / (ms1 * 1e-3) / 1e9}}
         ev, bu, so = est.bench_kernel_times(20)
         out["kernel_ms"] = {"eval_reproj": ev, "build_normal_equations": bu, "chol_solve_backsub": so}
+        d = 150
+        out["solver"] = {"kernel": "k_chol_solve_lds", "d": d, "launch_ms": so, "flops": d ** 3 / 3.0 + 2.0 * d * d,
+                         "achieved_tflops": (d ** 3 / 3.0 + 2.0 * d * d) / (so * 1e-3) / 1e12, "peak_tflops": F64_MFMA_PEAK_TFLOPS,
+                         "note": "latency-bound pivot chain at d = 150, see DESIGN.md"}
+    del est
+    if not args.no_extras:
+        extras = {}
+        if world > 1 and not os.environ.get("SVIN_BENCH_NO_SHARDED"):
+            # watchdog: a collective that never returns must not cost the headline line
+            done = threading.Event()
+
+            def watchdog():
+                if not done.wait(float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "240"))):
+                    if rank == 0:
+                        out["sharded_config4"] = {"error": "timed out (watchdog)"}
+                        out.update(extras)
+                        print(json.dumps(out), flush=True)
+                    os._exit(0)
+            threading.Thread(target=watchdog, daemon=True).start()
+            try:
+                rec = sharded_config4(rank, world, local_rank, dist, 5, 1)
+            except Exception as ex:
+                rec = {"error": repr(ex)}
+            done.set()
+            if rank == 0:
+                extras["sharded_config4"] = rec
+        if rank == 0:
+            try:
+                spec3 = syn.make_window(P=10, L=4000, n_obs=40000, seed=20250629, rig="rig_v2", sonar=True, depth=True)
+                extras["config3"], e3 = window_record("configs[2]: rig v2 stereo+IMU+sonar+depth, per-frame extrinsics, 10 KF / 4000 "
+                                                      "landmarks / 40000 residuals, optimize(10) per step", spec3, local_rank, 10, 2, 10)
+                del e3
+                spec4 = syn.make_window(P=64, L=50000, n_obs=500000, seed=20250629, frame_dt=0.25)
+                extras["config4_single_gpu"], e4 = window_record("configs[3] on ONE GPU: 64 KF / 50000 landmarks / 500000 residuals "
+                                                                 "(d = 960), optimize(5) per step", spec4, local_rank, 5, 1, 5)
+                del e4, spec4
+                if "value" in extras.get("sharded_config4", {}):
+                    extras["sharded_config4"]["speedup_vs_one_gpu"] = extras["sharded_config4"]["value"] / extras["config4_single_gpu"]["value"]
+            except Exception as ex:   # a sub-record must never take the headline line down
+                extras["error"] = repr(ex)
+        if rank == 0:
+            try:
+                pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=False)
+                extras["config5"] = {k: pg[k] for k in ("value", "unit", "ms_per_step")}
+                extras["config5"].update(workload=pg["config"]["workload"], iterations_per_step=pg["config"]["iterations_per_step"],
+                                         ms_per_iteration=pg["ms_per_step"] / pg["config"]["iterations_per_step"])
+            except Exception as ex:
+                extras["config5"] = {"error": repr(ex)}
+            out.update(extras)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(syn.make_window(seed=20250629))
-            out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+            out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     return out
 

