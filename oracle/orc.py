@@ -88,6 +88,7 @@ def _bind(L):
     sig("orc_get_landmark", i32, vp, u64, pd, pd, pd, pi32)
     sig("orc_set_T_WS", i32, vp, u64, pd)
     sig("orc_set_speed_and_bias", i32, vp, u64, u64, pd)
+    sig("orc_set_camera_sensor_states", i32, vp, u64, u64, pd)
     sig("orc_set_landmark", i32, vp, u64, pd)
     sig("orc_num_frames", u64, vp)
     sig("orc_num_landmarks", u64, vp)
@@ -104,6 +105,7 @@ def _bind(L):
     sig("orc_marg_size", i32, vp)
     sig("orc_marg_get", i32, vp, pd, pd, pd, pd)
     sig("orc_marg_blocks", i32, vp, pu64, pi32, pi32, pd, i32)
+    sig("orc_marg_pre", i32, vp, pd, pd, pi32, pi32, pi32, i32)
     sig("orc_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("orc_map_create", vp)
     sig("orc_map_destroy", None, vp)
@@ -371,6 +373,10 @@ class OracleEstimator:
         sb = arr(sb)
         return bool(self.L.orc_set_speed_and_bias(self.h, fid, imu, dptr(sb)))
 
+    def set_camera_sensor_states(self, fid, cam, T):
+        T = arr(T)
+        return bool(self.L.orc_set_camera_sensor_states(self.h, fid, cam, dptr(T)))
+
     def set_landmark(self, lid, hp):
         hp = arr(hp)
         return bool(self.L.orc_set_landmark(self.h, lid, dptr(hp)))
@@ -423,6 +429,19 @@ class OracleEstimator:
                                index=int(ix.value) if ok else None))
         return dict(n=n, H=H, b0=b0, J=J, e0=e0, blocks=blocks)
 
+
+    def marg_pre(self):
+        """the system of the last marginalisation after M1 / before M2 (test hook): H, b0, landmark and dense ranges"""
+        nl, nd = C.c_int(), C.c_int()
+        n = self.L.orc_marg_pre(self.h, None, None, C.byref(nl), C.byref(nd), None, 0)
+        if n == 0:
+            return None
+        H, b0 = np.zeros((n, n)), np.zeros(n)
+        rg = np.zeros(2 * (nl.value + nd.value), np.int32)
+        self.L.orc_marg_pre(self.h, dptr(H), dptr(b0), C.byref(nl), C.byref(nd), i32ptr(rg), len(rg))
+        rg = rg.reshape(-1, 2)
+        return dict(n=n, H=H, b0=b0, lm=[tuple(int(v) for v in r) for r in rg[:nl.value]],
+                    dense=[tuple(int(v) for v in r) for r in rg[nl.value:]])
 
     def keyframe_points(self, frame_id, cam=0):
         p64 = C.POINTER(C.c_uint64)

@@ -92,6 +92,7 @@ int orc_get_landmark(void* h, uint64_t id, double* hp, double* quality, double* 
   return 1;
 }
 int orc_set_T_WS(void* h, uint64_t id, const double* T) { return static_cast<Estimator*>(h)->set_T_WS(id, T) ? 1 : 0; }
+int orc_set_camera_sensor_states(void* h, uint64_t id, uint64_t cam, const double* T) { return static_cast<Estimator*>(h)->setCameraSensorStates(id, cam, T) ? 1 : 0; }
 int orc_set_speed_and_bias(void* h, uint64_t id, uint64_t imu, const double* sb) { return static_cast<Estimator*>(h)->setSpeedAndBias(id, imu, sb) ? 1 : 0; }
 int orc_set_landmark(void* h, uint64_t id, const double* hp) { return static_cast<Estimator*>(h)->setLandmark(id, hp) ? 1 : 0; }
 uint64_t orc_num_frames(void* h) { return static_cast<Estimator*>(h)->numFrames(); }
@@ -170,6 +171,22 @@ int orc_marg_get(void* h, double* H, double* b0, double* J, double* e0) {
   if (J && (int)m->Jmat().size() == n * n) std::memcpy(J, m->Jmat().data(), sizeof(double) * n * n);
   if (e0 && (int)m->e0().size() == n) std::memcpy(e0, m->e0().data(), sizeof(double) * n);
   return n;
+}
+// test hook (orc_marg.hpp PreMarg): returns n; H (n x n), b0 (n); ranges = {first, size} pairs, landmark part then dense part
+int orc_marg_pre(void* h, double* H, double* b0, int* nLm, int* nDense, int* ranges, int cap) {
+  auto m = static_cast<Estimator*>(h)->marginalizationError();
+  if (!m) return 0;
+  const auto& p = m->preMarg();
+  if (H) std::memcpy(H, p.H.data(), sizeof(double) * p.H.size());
+  if (b0) std::memcpy(b0, p.b0.data(), sizeof(double) * p.b0.size());
+  if (nLm) *nLm = (int)p.lm.size();
+  if (nDense) *nDense = (int)p.dense.size();
+  int k = 0;
+  if (ranges) {
+    for (auto& pr : p.lm) if (k + 2 <= cap) { ranges[k++] = pr.first; ranges[k++] = pr.second; }
+    for (auto& pr : p.dense) if (k + 2 <= cap) { ranges[k++] = pr.first; ranges[k++] = pr.second; }
+  }
+  return p.n;
 }
 // per connected block: id, orderingIdx, mdim ; returns number of blocks
 int orc_marg_blocks(void* h, uint64_t* ids, int* ordering, int* mdim, double* lin9, int cap) {

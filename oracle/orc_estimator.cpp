@@ -433,6 +433,13 @@ bool Estimator::set_T_WS(uint64_t poseId, const double* T) {
   std::memcpy(map_->param(it->second.T_WS.id).x, t.p, 7 * sizeof(double));
   return true;
 }
+bool Estimator::setCameraSensorStates(uint64_t poseId, size_t camIdx, const double* T) {  // Estimator.cpp:1102-1106
+  auto it = statesMap_.find(poseId);
+  if (it == statesMap_.end() || camIdx >= it->second.T_SC.size() || !it->second.T_SC[camIdx].exists) return false;
+  const Transformation t(T);
+  std::memcpy(map_->param(it->second.T_SC[camIdx].id).x, t.p, 7 * sizeof(double));
+  return true;
+}
 bool Estimator::setSpeedAndBias(uint64_t poseId, size_t imuIdx, const double* sb) {
   auto it = statesMap_.find(poseId);
   if (it == statesMap_.end() || imuIdx >= it->second.speedAndBias.size() || !it->second.speedAndBias[imuIdx].exists)

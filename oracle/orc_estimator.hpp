@@ -64,6 +64,7 @@ class Estimator {
   bool isLandmarkAdded(uint64_t id) const { return landmarksMap_.count(id) != 0; }
   bool set_T_WS(uint64_t poseId, const double* T);
   bool setSpeedAndBias(uint64_t poseId, size_t imuIdx, const double* sb);
+  bool setCameraSensorStates(uint64_t poseId, size_t camIdx, const double* T);
   bool setLandmark(uint64_t id, const double* hp);
   size_t numFrames() const { return statesMap_.size(); }
   size_t numLandmarks() const { return landmarksMap_.size(); }

@@ -162,6 +162,7 @@ bool MarginalizationError::marginalizeOut(const std::vector<uint64_t>& idsIn) {
   std::sort(pairsLm.begin(), pairsLm.end(), byFirst);
   std::sort(pairsDense.begin(), pairsDense.end(), byFirst);
   valid_ = false;
+  pre_.n = n_; pre_.H = H_; pre_.b0 = b0_; pre_.lm = pairsLm; pre_.dense = pairsDense;   // test hook, see orc_marg.hpp
 
   // ---- landmark part (:557-619)
   if (!pairsLm.empty()) {

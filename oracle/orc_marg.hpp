@@ -39,6 +39,15 @@ class MarginalizationError : public ErrorTerm {
   const std::vector<double>& Jmat() const { return J_; }
   const std::vector<double>& e0() const { return e0_; }
   const std::vector<Info>& infos() const { return infos_; }
+  // test hook: the system as it stood when the last marginalizeOut() began (after M1, before M2), the marginalised index
+  // ranges (first row, size) of the landmark and of the dense part, both in THAT ordering -- lets an independent
+  // high-precision restatement of M2 / M3 arbitrate between two double-precision implementations
+  struct PreMarg {
+    int n = 0;
+    std::vector<double> H, b0;
+    std::vector<std::pair<int, int>> lm, dense;
+  };
+  const PreMarg& preMarg() const { return pre_; }
 
  private:
   void insertZeros(int pos, int k);  // grow H_/b0_ by k rows+cols at index pos
@@ -50,6 +59,7 @@ class MarginalizationError : public ErrorTerm {
   size_t denseIndices_ = 0;
   bool valid_ = false;
   std::vector<double> J_, e0_;
+  PreMarg pre_;
 };
 
 // helpers shared with tests: pseudo-inverse square root of a symmetric PSD matrix

@@ -38,76 +38,136 @@ struct MargDev {
   double *U, *ba, *W, *V, *bb;  // U m x m, W m x 3Lm (row-major), V Lm x 9, bb 3Lm
 };
 
+// M1 is accumulated in a FIXED order (no atomics): the prior feeds a sequence of optimisations that amplifies rounding
+// differences, so two runs of the same window must produce the same bits.
+//   k_marg_accum_lm    one thread per marginalised landmark: V_l, bb_l and the three columns of W it owns, over its
+//                      observations in CSR order
+//   k_marg_accum_cam   one wave per (camera-side block, part): lane i sums the observations i, i + 64, ... that touch
+//                      the block, then a fixed butterfly over the lanes; part 0 = diagonal block + right-hand side,
+//                      part 1 + c = the pose x extrinsics cross block of camera c (written with its transpose)
+//   k_marg_accum_factors  one workgroup, the small factors one after the other
 template <bool WITH_EXT>
-__global__ void k_marg_accum_reproj(DeviceProblem p, MargDev md) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= p.N) return;
+__global__ void k_marg_accum_lm(DeviceProblem p, MargDev md) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= md.Lm) return;
   const size_t N = (size_t)p.N;
-  const uint32_t idx = p.obsIdx[o];
-  const int offP = p.poseOff[idx & 0xfff];
-  const int offE = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
-  const int l = p.obsLm[o];
-  double r0 = p.rCur[o], r1 = p.rCur[N + o];
-  double jl[6], jp[12], je[12];
+  const int wld = 3 * md.Lm;
+  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+  for (int o = p.lmPtr[l]; o < p.lmPtr[l + 1]; ++o) {
+    const uint32_t idx = p.obsIdx[o];
+    const int offP = p.poseOff[idx & 0xfff];
+    const int offE = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
+    const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+    double jl[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) jl[k] = p.JlCur[k * N + o];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) jp[k] = p.JpCur[k * N + o];
-  if (WITH_EXT) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) je[k] = p.JeCur[k * N + o];
-  }
-  const int m = md.m, wld = 3 * md.Lm;
-  // landmark block
-  for (int a = 0; a < 3; ++a) {
-    for (int b = 0; b < 3; ++b) atomicAdd(&md.V[9 * (size_t)l + a * 3 + b], jl[a] * jl[b] + jl[3 + a] * jl[3 + b]);
-    atomicAdd(&md.bb[3 * l + a], -(jl[a] * r0 + jl[3 + a] * r1));
-  }
-  auto cam = [&](const double* jc, int off) {
-    if (off < 0) return;
-    for (int a = 0; a < 6; ++a) {
-      atomicAdd(&md.ba[off + a], -(jc[a] * r0 + jc[6 + a] * r1));
-      for (int b = 0; b < 6; ++b) atomicAdd(&md.U[(size_t)(off + a) * m + off + b], jc[a] * jc[b] + jc[6 + a] * jc[6 + b]);
-      for (int b = 0; b < 3; ++b) atomicAdd(&md.W[(size_t)(off + a) * wld + 3 * l + b], jc[a] * jl[b] + jc[6 + a] * jl[3 + b]);
+    for (int k = 0; k < 6; ++k) jl[k] = p.JlCur[k * N + o];
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) V[a * 3 + b] += jl[a] * jl[b] + jl[3 + a] * jl[3 + b];
+      bb[a] += -(jl[a] * r0 + jl[3 + a] * r1);
     }
-  };
-  cam(jp, offP);
-  if (WITH_EXT) {
-    cam(je, offE);
-    if (offP >= 0 && offE >= 0)
+    auto cam = [&](const double* J, int off) {
+      if (off < 0) return;
+      for (int a = 0; a < 6; ++a) {
+        const double j0 = J[(size_t)a * N + o], j1 = J[(size_t)(6 + a) * N + o];
+        double* w = md.W + (size_t)(off + a) * wld + 3 * l;   // columns 3l .. 3l+2 belong to this thread
+        for (int b = 0; b < 3; ++b) w[b] += j0 * jl[b] + j1 * jl[3 + b];
+      }
+    };
+    cam(p.JpCur, offP);
+    if (WITH_EXT) cam(p.JeCur, offE);
+  }
+  for (int k = 0; k < 9; ++k) md.V[9 * (size_t)l + k] = V[k];
+  for (int a = 0; a < 3; ++a) md.bb[3 * l + a] = bb[a];
+}
+
+template <bool WITH_EXT>
+__global__ __launch_bounds__(64) void k_marg_accum_cam(DeviceProblem p, MargDev md) {
+  const int target = blockIdx.x, part = blockIdx.y, lane = threadIdx.x;
+  const bool isPose = target < p.nPose;
+  const int slot = isPose ? target : target - p.nPose;
+  const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
+  if (off < 0) return;
+  if (part > 0 && !isPose) return;                 // cross blocks are written by the pose side
+  const size_t N = (size_t)p.N;
+  const int m = md.m;
+  double acc[42];
+#pragma unroll
+  for (int k = 0; k < 42; ++k) acc[k] = 0.0;
+  int partner = -1;                                // extrinsics slot of the cross block (unique per pose and camera)
+  for (int o = lane; o < p.N; o += 64) {
+    const uint32_t idx = p.obsIdx[o];
+    const int ps = idx & 0xfff, es = (idx >> 12) & 0xfff, cam = (idx >> 24) & 0xf;
+    if (isPose ? ps != slot : es != slot) continue;
+    const double* J = isPose ? p.JpCur : p.JeCur;
+    double ja[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ja[k] = J[(size_t)k * N + o];
+    if (part == 0) {
+      const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a * 6 + b] += ja[a] * ja[b] + ja[6 + a] * ja[6 + b];
+        acc[36 + a] += -(ja[a] * r0 + ja[6 + a] * r1);
+      }
+    } else if (WITH_EXT) {
+      if (cam != part - 1 || p.extOff[es] < 0) continue;
+      partner = es;
+      double je[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) je[k] = p.JeCur[(size_t)k * N + o];
+#pragma unroll
       for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 6; ++b) {
-          const double v = jp[a] * je[b] + jp[6 + a] * je[6 + b];
-          atomicAdd(&md.U[(size_t)(offP + a) * m + offE + b], v);
-          atomicAdd(&md.U[(size_t)(offE + b) * m + offP + a], v);
-        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a * 6 + b] += ja[a] * je[b] + ja[6 + a] * je[6 + b];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 42; ++k) acc[k] = waveSumM(acc[k]);   // xor butterfly: the same order on every run
+  for (int o = 32; o > 0; o >>= 1) partner = max(partner, __shfl_xor(partner, o, 64));
+  if (lane != 0) return;
+  if (part == 0) {
+    for (int a = 0; a < 6; ++a) {
+      for (int b = 0; b < 6; ++b) md.U[(size_t)(off + a) * m + off + b] += acc[a * 6 + b];
+      md.ba[off + a] += acc[36 + a];
+    }
+  } else if (partner >= 0) {
+    const int offE = p.extOff[partner];
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        md.U[(size_t)(off + a) * m + offE + b] += acc[a * 6 + b];
+        md.U[(size_t)(offE + b) * m + off + a] += acc[a * 6 + b];
+      }
   }
 }
 
 __global__ __launch_bounds__(256) void k_marg_accum_factors(DeviceProblem p, MargDev md) {
-  const FactorLin& lin = p.linCur[blockIdx.x];
-  const int mm = lin.m, nc = lin.ncols;
   __shared__ int colRow[30];
-  if (threadIdx.x < 30) {
-    int c = threadIdx.x, row = -1, base = 0;
-    for (int b = 0; b < 4; ++b) {
-      if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
-      base += lin.dim[b];
+  for (int f = 0; f < md.F; ++f) {
+    const FactorLin& lin = p.linCur[f];
+    const int mm = lin.m, nc = lin.ncols;
+    __syncthreads();
+    if (threadIdx.x < 30) {
+      int c = threadIdx.x, row = -1, base = 0;
+      for (int b = 0; b < 4; ++b) {
+        if (c >= base && c < base + lin.dim[b]) row = lin.off[b] < 0 ? -1 : lin.off[b] + (c - base);
+        base += lin.dim[b];
+      }
+      colRow[threadIdx.x] = (c < nc) ? row : -1;
     }
-    colRow[threadIdx.x] = (c < nc) ? row : -1;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
-    const int a = idx / nc, b = idx % nc;
-    const int ra = colRow[a], rb = colRow[b];
-    if (ra < 0 || rb < 0) continue;
-    double s = 0;
-    for (int k = 0; k < mm; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
-    atomicAdd(&md.U[(size_t)ra * md.m + rb], s);
-    if (a == b) {
-      double g = 0;
-      for (int k = 0; k < mm; ++k) g += lin.J[k * nc + a] * lin.r[k];
-      atomicAdd(&md.ba[ra], -g);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nc * nc; idx += blockDim.x) {
+      const int a = idx / nc, b = idx % nc;
+      const int ra = colRow[a], rb = colRow[b];
+      if (ra < 0 || rb < 0) continue;
+      double s = 0;
+      for (int k = 0; k < mm; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
+      md.U[(size_t)ra * md.m + rb] += s;             // distinct columns of one factor are distinct rows of U
+      if (a == b) {
+        double g = 0;
+        for (int k = 0; k < mm; ++k) g += lin.J[k * nc + a] * lin.r[k];
+        md.ba[ra] -= g;
+      }
     }
   }
 }
@@ -184,32 +244,8 @@ __device__ __forceinline__ double rowSum16(double v) {
   return v;
 }
 
-// Workgroup barrier that only orders LDS traffic.  __syncthreads() also waits for every outstanding global access
-// (s_waitcnt vmcnt(0)), which turns the fire-and-forget rotation-log stores of phase 1 and the read-ahead of phase 2
-// into one L2 round trip per tournament round.
+// Workgroup barrier that only orders LDS traffic (__syncthreads() also waits for every outstanding global access).
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// agent-scope accesses (sc1: served by L2, the coherence point between the two workgroups of the split solve)
-__device__ __forceinline__ void agentStore(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int agentLoad(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double2 agentLoad(const double2* p) {
-  const double* q = reinterpret_cast<const double*>(p);
-  return make_double2(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                      __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// A rotation-log entry.  Consecutive workgroups land on different XCDs, each with its own L2: what the replaying
-// workgroup is to see while the kernel runs has to be written through (sc1), not left in the writer's L2.
-__device__ __forceinline__ void logStore(double2* slot, double c, double s, bool coherent) {
-  if (coherent) {
-    double* q = reinterpret_cast<double*>(slot);
-    __hip_atomic_store(q, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    *slot = make_double2(c, s);
-  }
-}
-__device__ __forceinline__ void waitGlobalStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-constexpr int kJacobiChunk = 8;   // rounds between two progress reports of the producer (power of two)
 
 // pair k of round `round` of the round-robin tournament over np players (np even)
 __device__ __forceinline__ void jacobiPair(int np, int round, int k, int& a, int& b) {
@@ -244,18 +280,14 @@ __device__ __forceinline__ lds_double* toLds(double* p) { return (lds_double*)p;
 struct JacobiShared {
   double nullTol2;
   int anyRotation, anyLargeRotation;
-  int avail, done;   // consumer side of the two-workgroup solve
 };
 __shared__ JacobiShared gJacobiShared;
 
 // LPG lanes per pair; P = lds_double* (the LDS images: every column has jacobiLd(n) addressable entries with a zero
 // tail) or double* (global memory, leading dimension n).
-// progress (optional): the number of tournament rounds whose rotation-log entries are visible at L2, reported every
-// kJacobiChunk rounds for the workgroup that replays them.  Returns the number of sweeps.
-// kHasQ: rotate the rows of Q along with G.  kLog: 0 no rotation log, 1 plain stores, 2 written through for a consumer
-// workgroup (with progress reports).  Compile-time so that each use gets a straight-line round.
-template <int LPG, class P, bool kHasQ, int kLog>
-__device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLog, int* progress) {
+// Returns the number of sweeps.  kHasQ: rotate the rows of Q along with G (compile-time: each use gets a straight-line round).
+template <int LPG, class P, bool kHasQ>
+__device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag) {
   constexpr bool padded = std::is_same<P, lds_double*>::value;
   constexpr int kRegCols = kJacobiRegLen / LPG;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nWaves = blockDim.x >> 6;
@@ -290,17 +322,12 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
     const double tol2 = nullTol2 * eps_n * eps_n;
     // the n/2 disjoint pairs of a round run side by side, one lane group each
     const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
-    double2* logRound = kLog ? rotLog + (size_t)sweep * (np - 1) * (np / 2) : nullptr;
     bool rotated = false, large = false;
-    for (int round = 0; round < np - 1; ++round, logRound += kLog ? np / 2 : 0) {
+    for (int round = 0; round < np - 1; ++round) {
       for (int k = grp; k < np / 2; k += nGroups) {
         int a, b;
         jacobiPair(np, round, k, a, b);
-        double2* slot = kLog ? logRound + k : nullptr;
-        if (a >= n || b >= n) {
-          if (kLog && gl == 0) logStore(slot, 1.0, 0.0, kLog == 2);
-          continue;
-        }
+        if (a >= n || b >= n) continue;
         const int pI = a < b ? a : b, qI = a < b ? b : a;
         P gp = G + pI * ld + gl;
         P gq = G + qI * ld + gl;
@@ -319,15 +346,12 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
         }
         static_assert(LPG == 16, "one DPP row per column pair");
         al = rowSum16(al); be = rowSum16(be); ga = rowSum16(ga);
-        if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2)) {
-          if (kLog && gl == 0) logStore(slot, 1.0, 0.0, kLog == 2);
+        if (ga * ga <= (kJacobiOrthTol * kJacobiOrthTol) * (al * be) || al == 0.0 || be == 0.0 || (al <= tol2 && be <= tol2))
           continue;
-        }
         rotated = true;
         large = large || ga * ga >= (kJacobiFinalCos * kJacobiFinalCos) * (al * be);
         double c, s;
         jacobiRotation(al, be, ga, c, s);
-        if (kLog && gl == 0) logStore(slot, c, s, kLog == 2);
         if (inRegs) {
 #pragma unroll
           for (int u = 0; u < kRegCols; ++u) {
@@ -350,11 +374,7 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag, double2* rotLo
           }
         }
       }
-      const int roundsDone = sweep * (np - 1) + round + 1;
-      const bool report = kLog == 2 && (roundsDone & (kJacobiChunk - 1)) == 0;
-      if (report) waitGlobalStores();   // this wave's log entries have reached L2 ...
       if (padded) ldsBarrier(); else __syncthreads();   // padded = G and Q are LDS images
-      if (report && threadIdx.x == 0) agentStore(progress, roundsDone);   // ... and so have everybody else's
     }
     if (rotated) anyRotation = 1;   // racing stores of the same value
     if (large) gJacobiShared.anyLargeRotation = 1;
@@ -375,7 +395,7 @@ constexpr int kJacobiLanes = 16;
 // memory (lds != nullptr): every round of the tournament is one LDS round trip instead of a global-memory one
 // (12 sweeps x 50 rounds at n = 51: 1.9 ms -> 0.2 ms).
 __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
-  if (!lds) { jacobiEigBlock<kJacobiLanes, double*, true, 0>(G, Q, n, n, flag, nullptr, nullptr); return; }
+  if (!lds) { jacobiEigBlock<kJacobiLanes, double*, true>(G, Q, n, n, flag); return; }
   const int ld = jacobiLd(n);
   lds_double* sG = toLds(lds);
   lds_double* sQ = sG + n * ld;
@@ -385,99 +405,11 @@ __device__ void jacobiEig(double* G, double* Q, int n, int* flag, double* lds) {
     sQ[idx] = j < n ? Q[i * n + j] : 0.0;
   }
   __syncthreads();
-  jacobiEigBlock<kJacobiLanes, lds_double*, true, 0>(sG, sQ, n, ld, flag, nullptr, nullptr);
+  jacobiEigBlock<kJacobiLanes, lds_double*, true>(sG, sQ, n, ld, flag);
   for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
     const int i = idx / n, j = idx - i * n;
     G[idx] = sG[i * ld + j];
     Q[idx] = sQ[i * ld + j];
-  }
-  __syncthreads();
-}
-// n too large for G and Q to share LDS (2 n^2 doubles), small enough for one of them (n <= 136): two phases with the
-// same arithmetic as the one-phase solver.  Phase 1 rotates G alone in LDS and logs every rotation (c, s) of every
-// sweep / round / pair in global memory (fire-and-forget stores); phase 2 replays the log on Q = I in the same LDS.
-// (Reading the eigenvectors off G_j = lambda_j q_j instead is NOT good enough: for small eigenvalues the direction of
-// G_j is rounding noise, and e0 = -pinv(J^T) b0 amplifies it by 1 / lambda.)
-// rounds [rBegin, rEnd) of the log; kCoherent: the log is being written by another workgroup (read it at L2)
-template <int LPG, bool kCoherent>
-__device__ void jacobiReplay(lds_double* lds, int n, int ld, int rBegin, int rEnd, const double2* rotLog) {
-  // rotation (c, s) of pair k in round r sits at rotLog[r * half + k]; the log is read four rounds ahead so that the
-  // L2 round trip hides behind the rotations of the rounds in between
-  constexpr int kRegCols = kJacobiRegLen / LPG;
-  const int np = (n & 1) ? n + 1 : n, half = np / 2;
-  const int grp = threadIdx.x / LPG, gl = threadIdx.x % LPG, nGroups = blockDim.x / LPG;
-  const int k0 = grp, k1 = grp + nGroups;   // half <= 2 * nGroups (n <= 144, at least 64 groups)
-  const bool has0 = k0 < half, has1 = k1 < half;
-  auto fetch = [&](int r, double2& c0, double2& c1) {
-    const double2* row = rotLog + (size_t)r * half;
-    if (kCoherent) {
-      c0 = has0 ? agentLoad(row + k0) : make_double2(1.0, 0.0);
-      c1 = has1 ? agentLoad(row + k1) : make_double2(1.0, 0.0);
-    } else {
-      c0 = has0 ? row[k0] : make_double2(1.0, 0.0);
-      c1 = has1 ? row[k1] : make_double2(1.0, 0.0);
-    }
-  };
-  auto rotate = [&](int round, int k, const double2 cs) {
-    if (cs.y == 0.0) return;
-    int a, b;
-    jacobiPair(np, round, k, a, b);
-    const int pI = a < b ? a : b, qI = a < b ? b : a;
-    lds_double* vp = lds + pI * ld + gl;
-    lds_double* vq = lds + qI * ld + gl;
-    const double c = cs.x, s = cs.y;
-#pragma unroll
-    for (int u = 0; u < kRegCols; ++u) {   // the zero tail of the padded columns stays zero
-      if (LPG * u >= n) break;
-      const double x = vp[LPG * u], w = vq[LPG * u];
-      vp[LPG * u] = c * x - s * w; vq[LPG * u] = s * x + c * w;
-    }
-  };
-  constexpr int kAhead = 4;
-  double2 ring0[kAhead], ring1[kAhead];
-#pragma unroll
-  for (int u = 0; u < kAhead; ++u) {
-    ring0[u] = ring1[u] = make_double2(1.0, 0.0);
-    if (rBegin + u < rEnd) fetch(rBegin + u, ring0[u], ring1[u]);
-  }
-  int round = rBegin % (np - 1);
-  for (int r0 = rBegin; r0 < rEnd; r0 += kAhead) {
-#pragma unroll
-    for (int u = 0; u < kAhead; ++u) {
-      const int r = r0 + u;
-      if (r >= rEnd) break;
-      const double2 c0 = ring0[u], c1 = ring1[u];
-      if (r + kAhead < rEnd) fetch(r + kAhead, ring0[u], ring1[u]);
-      if (has0) rotate(round, k0, c0);
-      if (has1) rotate(round, k1, c1);
-      ldsBarrier();
-      if (++round == np - 1) round = 0;
-    }
-  }
-}
-__device__ void jacobiEigTwoPhase(double* G, double* Q, int n, int* flag, double* ldsGeneric, double2* rotLog) {
-  lds_double* lds = toLds(ldsGeneric);
-  const int ld = jacobiLd(n), np = (n & 1) ? n + 1 : n;
-  for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
-    const int i = idx / ld, j = idx - i * ld;
-    lds[idx] = j < n ? G[i * n + j] : 0.0;
-  }
-  __syncthreads();
-  const long long tPhase1 = wall_clock64();
-  jacobiEigBlock<kJacobiLanes, lds_double*, false, 1>(lds, (lds_double*)nullptr, n, ld, flag, rotLog, nullptr);
-  if (threadIdx.x == 0) flag[3] = (int)((wall_clock64() - tPhase1) / 100);   // us, printed under SVIN_MARG_TIMING
-  for (int idx = threadIdx.x; idx < n * ld; idx += blockDim.x) {
-    const int i = idx / ld, j = idx - i * ld;
-    if (j < n) G[i * n + j] = lds[idx];
-    lds[idx] = (i == j) ? 1.0 : 0.0;
-  }
-  __threadfence_block();
-  __syncthreads();
-  const int nRounds = flag[1] * (np - 1);
-  jacobiReplay<kJacobiLanes, false>(lds, n, ld, 0, nRounds, rotLog);
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int i = idx / n, j = idx - i * n;
-    Q[idx] = lds[i * ld + j];
   }
   __syncthreads();
 }
@@ -632,144 +564,8 @@ struct FinalArgs {
   const double* H; const double* b0;
   double *G, *Q, *J, *e0, *Ht, *bp, *scal, *tmp;
   int* flag;
-  double2* rotLog;   // two-phase eigen-solve (96 < n <= 136): 40 sweeps x (np - 1) rounds x np / 2 pairs
 };
-// ---- split solve (mode 3): two workgroups on two CUs.  Workgroup 0 rotates G in its LDS and streams the rotation log;
-// workgroup 1 replays the log on Q = I in its own LDS as the rounds are reported, then builds J, e0, J^T J, J^T e0.
-// flag[4] = rounds whose log entries are visible, flag[5] = number of sweeps once G is final in global memory (both
-// zeroed by the host before the launch).  Only workgroup 1 ever waits, so the pair cannot deadlock whatever order the
-// two are scheduled in; its wait is bounded all the same (flag[0] = 1 on timeout).
 __device__ __forceinline__ double margScale(double hd) { return (hd > 1.0e-9) ? sqrt(hd) : 1.0e-3; }
-
-__device__ void margFinalProducer(const FinalArgs& a, lds_double* lds) {
-  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n), np = (n & 1) ? n + 1 : n;
-  for (int idx = t; idx < n * ld; idx += nt) {
-    const int i = idx / ld, j = idx - i * ld;
-    double v = 0.0;
-    if (j < n) {
-      const double pi = margScale(a.H[(size_t)i * n + i]), pj = margScale(a.H[(size_t)j * n + j]);
-      v = 0.5 * (a.H[(size_t)i * n + j] + a.H[(size_t)j * n + i]) / (pi * pj);
-    }
-    lds[idx] = v;
-  }
-  __syncthreads();
-  const long long t0 = wall_clock64();
-  const int sweeps = jacobiEigBlock<kJacobiLanes, lds_double*, false, 2>(lds, (lds_double*)nullptr, n, ld, a.flag, a.rotLog, a.flag + 4);
-  for (int idx = t; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx - i * n;
-    __hip_atomic_store(a.G + idx, (double)lds[i * ld + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through, see logStore
-  }
-  waitGlobalStores();
-  __syncthreads();
-  if (t == 0) {
-    a.flag[3] = (int)((wall_clock64() - t0) / 100);
-    agentStore(a.flag + 4, sweeps * (np - 1));
-    waitGlobalStores();   // the final round count is in place before the consumer can see `done`
-    agentStore(a.flag + 5, sweeps > 0 ? sweeps : 1);
-  }
-}
-
-__device__ void margFinalConsumer(const FinalArgs& a, lds_double* lds) {
-  const int t = threadIdx.x, nt = blockDim.x, n = a.n, ld = jacobiLd(n);
-  const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;
-  double* p = a.tmp;        // n
-  double* ev = a.tmp + n;   // n
-  const long long tStart = wall_clock64();
-  for (int i = t; i < n; i += nt) p[i] = margScale(a.H[(size_t)i * n + i]);
-  for (int idx = t; idx < n * ld; idx += nt) {
-    const int i = idx / ld, j = idx - i * ld;
-    lds[idx] = (i == j) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  const long long tPrep = wall_clock64(), cPrep = clock64();
-  int processed = 0;
-  for (;;) {
-    if (t == 0) {
-      int d = 0, av = processed;
-      for (long long spins = 0; spins < (1ll << 21); ++spins) {
-        d = agentLoad(a.flag + 5);
-        if (d != 0) { av = agentLoad(a.flag + 4); break; }   // read after `done` was seen: the final count
-        av = agentLoad(a.flag + 4);
-        if (av > processed) break;
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (d == 0 && av <= processed) { d = -1; a.flag[0] = 1; }   // producer never showed up
-      gJacobiShared.avail = av; gJacobiShared.done = d;
-    }
-    __syncthreads();
-    const int av = gJacobiShared.avail, d = gJacobiShared.done;
-    __syncthreads();
-    if (av > processed) {
-      jacobiReplay<kJacobiLanes, true>(lds, n, ld, processed, av, a.rotLog);
-      processed = av;
-    }
-    if (d != 0) break;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // G of the producer
-  __syncthreads();
-  const long long tEig = wall_clock64(), cEig = clock64();
-  // rows of the LDS image = eigenvectors; eigenvalue j = Q_j . G_j
-  for (int j = grp; j < n; j += nGroups) {
-    double s = 0;
-    for (int i = gl; i < n; i += 16)
-      s += lds[j * ld + i] * __hip_atomic_load(a.G + (size_t)j * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s = rowSum16(s);
-    if (gl == 0) ev[j] = s;
-  }
-  __syncthreads();
-  if (t < 64) {
-    double mx = -1.0e300, mn = 1.0e300;
-    for (int j = t; j < n; j += 64) { mx = fmax(mx, ev[j]); mn = fmin(mn, ev[j]); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o, 64)); mn = fmin(mn, __shfl_xor(mn, o, 64)); }
-    const double tl = 2.220446049250313e-16 * n * mx;
-    int c = 0;
-    for (int j = t; j < n; j += 64) c += ev[j] <= tl;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (t == 0) { gJacobiShared.nullTol2 = mx; a.flag[2] = c; a.scal[1] = mn; a.scal[2] = mx; }
-  }
-  __syncthreads();
-  const double tol = 2.220446049250313e-16 * n * gJacobiShared.nullTol2;
-  for (int i = grp; i < n; i += nGroups) {
-    double e = 0;
-    for (int j = gl; j < n; j += 16) e += lds[i * ld + j] * (a.b0[j] / p[j]);
-    e = rowSum16(e);
-    if (gl == 0) a.e0[i] = ev[i] > tol ? -sqrt(1.0 / ev[i]) * e : 0.0;
-  }
-  __syncthreads();
-  // J = (p U sqrt(S))^T in place of Q
-  for (int idx = t; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx - i * n;
-    const double s = ev[i] > tol ? sqrt(ev[i]) : 0.0;
-    const double v = p[j] * lds[i * ld + j] * s;
-    a.J[idx] = v;
-    lds[i * ld + j] = v;
-  }
-  __syncthreads();
-  for (int idx = t; idx < n * n; idx += nt) {
-    const int i = idx / n, j = idx - i * n;
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * lds[k * ld + j];
-    a.Ht[idx] = s;
-  }
-  for (int i = t; i < n; i += nt) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += lds[k * ld + i] * a.e0[k];
-    a.bp[i] = s;
-  }
-  if (t < 64) {
-    double c = 0;
-    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
-    c = waveSumM(c);
-    if (t == 0) {
-      a.scal[0] = c;
-      a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
-      a.scal[6] = (double)(cEig - cPrep);
-      a.scal[7] = (double)n;
-    }
-  }
-}
 
 // ---- Cholesky-preconditioned solve (mode 4, Veselic / Hari): A + delta I = R^T R, then one-sided Jacobi on the rows of R
 // (the columns of L = R^T).  R V = Sigma U^T with U the eigenvectors of A and sigma_j^2 = lambda_j + delta, so the
@@ -823,7 +619,7 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   }
   __syncthreads();
   const long long tPrep = wall_clock64(), cPrep = clock64();
-  jacobiEigBlock<kJacobiLanes, P, false, 0>(lds, (P) nullptr, n, ld, a.flag, nullptr, nullptr);
+  jacobiEigBlock<kJacobiLanes, P, false>(lds, (P) nullptr, n, ld, a.flag);
   const long long tEig = wall_clock64(), cEig = clock64();
   // row j = sigma_j u_j
   for (int j = grp; j < n; j += nGroups) {
@@ -889,22 +685,19 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   return true;
 }
 
-__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
+__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds, int fallbackLds) {
   extern __shared__ double jacobiLds[];
+  // modes: 4 = Cholesky-preconditioned Jacobi, image in LDS; 6 = the same with the image in global memory (priors too
+  // large for LDS); 1 / 0 = the fall-back, one-sided Jacobi on A itself with G and Q in LDS / in global memory
+  // (also what runs when a pivot of the factorisation is not positive: `fallbackLds` says whether G and Q both fit)
   if (useLds == 6) {
     if (margFinalCholesky<double*>(a, a.G, a.n)) return;
     __syncthreads();
     useLds = 0;
-  }
-  if (useLds >= 4) {
-    if (useLds == 4 && margFinalCholesky<lds_double*>(a, toLds(jacobiLds), jacobiLd(a.n))) return;
+  } else if (useLds == 4) {
+    if (margFinalCholesky<lds_double*>(a, toLds(jacobiLds), jacobiLd(a.n))) return;
     __syncthreads();
-    useLds = 2;   // a pivot was not positive (or mode 5, the test hook): G and Q take turns in this workgroup's LDS
-  }
-  if (useLds == 3) {
-    if (blockIdx.x == 0) margFinalProducer(a, toLds(jacobiLds));
-    else margFinalConsumer(a, toLds(jacobiLds));
-    return;
+    useLds = fallbackLds ? 1 : 0;
   }
   const int t = threadIdx.x, nt = blockDim.x, n = a.n;
   double* p = a.tmp;        // n
@@ -922,8 +715,7 @@ __global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds) {
   }
   __syncthreads();
   const long long tPrep = wall_clock64(), cPrep = clock64();
-  if (useLds == 2) jacobiEigTwoPhase(a.G, a.Q, n, a.flag, jacobiLds, a.rotLog);
-  else jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
+  jacobiEig(a.G, a.Q, n, a.flag, useLds ? jacobiLds : nullptr);
   const long long tEig = wall_clock64(), cEig = clock64();
   __shared__ double smax;
   const int grp = t >> 4, gl = t & 15, nGroups = nt >> 4;   // 16-lane groups (one DPP row each)
@@ -1341,12 +1133,18 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     // M1: evaluate at the linearisation points (Cauchy corrector as in :283-330) and accumulate
     if (N > 0) {
       launchEvalReproj(q, false, true, s);
-      if (anyExtVar) hipLaunchKernelGGL(k_marg_accum_reproj<true>, dim3((N + 127) / 128), dim3(128), 0, s, q, md);
-      else hipLaunchKernelGGL(k_marg_accum_reproj<false>, dim3((N + 127) / 128), dim3(128), 0, s, q, md);
+      const dim3 camGrid(q.nPose + q.nExt, anyExtVar ? 1 + q.nCam : 1);
+      if (anyExtVar) {
+        hipLaunchKernelGGL(k_marg_accum_lm<true>, dim3((Lm + 63) / 64), dim3(64), 0, s, q, md);
+        hipLaunchKernelGGL(k_marg_accum_cam<true>, camGrid, dim3(64), 0, s, q, md);
+      } else {
+        hipLaunchKernelGGL(k_marg_accum_lm<false>, dim3((Lm + 63) / 64), dim3(64), 0, s, q, md);
+        hipLaunchKernelGGL(k_marg_accum_cam<false>, camGrid, dim3(64), 0, s, q, md);
+      }
     }
     if (F > 0) {
       launchEvalFactors(q, false, s);
-      hipLaunchKernelGGL(k_marg_accum_factors, dim3(F), dim3(256), 0, s, q, md);
+      hipLaunchKernelGGL(k_marg_accum_factors, dim3(1), dim3(256), 0, s, q, md);
     }
     // M2 landmark part
     if (Lm > 0 && m > 0) {
@@ -1402,42 +1200,18 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       dbgScal = fa.scal;
       {
         // Eigen-solver of the prior (k_marg_final's `useLds`):
-        //   4 "cholesky"  A + delta I = R^T R, one-sided Jacobi on the rows of R in LDS (default when one image fits: n <= 136)
-        //   3 "split"     one-sided Jacobi on A; G in workgroup 0, the eigenvectors replayed from its log in workgroup 1
-        //   2 "twophase"  the same two phases one after the other in one workgroup (also the fall-back of mode 4)
-        //   1 "single"    G and Q side by side in one LDS (n <= 96; default below 32 unknowns)
-        //   6 "cholesky-global"  mode 4 with the image in global memory (default for anything larger)
-        //   0 "global"    one-sided Jacobi on A with G and Q in global memory (fall-back of mode 6)
-        // SVIN_MARG_EIG selects one of the names for A/B runs and for the tests that keep the non-default paths honest;
-        // "cholesky-fail" takes the fall-back branch of mode 4 without attempting the factorisation.
+        //   4  A + delta I = R^T R, one-sided Jacobi on the rows of R, image in LDS (default: n <= 136)
+        //   6  the same with the image in global memory (larger priors)
+        //   1 / 0  the ONE fall-back: one-sided Jacobi on A itself with G and Q in LDS (n <= 96) / in global memory; taken
+        //          inside the kernel when a pivot of the factorisation is not positive, or with SVIN_MARG_EIG=jacobi
+        //          (the test that keeps the fall-back honest)
         const char* want = getenv("SVIN_MARG_EIG");
-        const std::string eig = want ? want : "";
+        const bool forceFallback = want && std::string(want) == "jacobi";
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
-        size_t lds = 0;
-        const int mode = [&]() -> int {
-          if (eig == "global") return 0;
-          if (eig == "cholesky-global") return 6;
-          if (eig == "cholesky-fail" && ldsOne) return 5;
-          if (eig == "split" && ldsOne) return 3;
-          if (eig == "twophase" && ldsOne) return 2;
-          if (eig == "single" && ldsBoth) return 1;
-          if (eig == "single" && ldsOne) return 2;
-          if (ldsOne && (nk >= 32 || eig == "cholesky")) return 4;   // the default from here on
-          if (ldsBoth) return 1;
-          return 6;
-        }();
-        fa.rotLog = nullptr;
-        if (mode >= 2 && mode <= 5) {
-          lds = ldsOne;
-          const size_t npk = (nk & 1) ? nk + 1 : nk;
-          mb.bRotLog.reserve((size_t)40 * (npk - 1) * (npk / 2) * 2 + 2);
-          fa.rotLog = reinterpret_cast<double2*>(mb.bRotLog.p);
-        } else if (mode == 1) {
-          lds = ldsBoth;
-        }
+        const int mode = forceFallback ? (ldsBoth ? 1 : 0) : (ldsOne ? 4 : 6);
+        const size_t lds = (mode == 4) ? std::max(ldsOne, ldsBoth) : (mode == 1 ? ldsBoth : 0);
         if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (mode == 3) HIP_OK(hipMemsetAsync(bFlag.p + 4, 0, 2 * sizeof(int), s));
-        hipLaunchKernelGGL(k_marg_final, dim3(mode == 3 ? 2 : 1), dim3(1024), lds, s, fa, mode);
+        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0);
       }
       priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     }

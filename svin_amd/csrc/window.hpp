@@ -112,7 +112,7 @@ struct DevBuf {
 
 // device buffers of the marginalisation job (marg.hip), kept across calls
 struct MargBuffers {
-  DevBuf<double> bPose, bExt, bSb, bLm, bUv, bW, bLin, bU, bW2, bV, bVec, bScratch, bImuM, bPartial, bHk, bOut, bRotLog;
+  DevBuf<double> bPose, bExt, bSb, bLm, bUv, bW, bLin, bU, bW2, bV, bVec, bScratch, bImuM, bPartial, bHk, bOut;
   DevBuf<int> bOP, bOE, bOS, bLmPtr, bObsLm, bIdxList, bFlag;
   DevBuf<uint32_t> bIdx, bImuT;
   DevBuf<DevFactor> bFac;
