@@ -168,6 +168,10 @@ int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t landmark_id, int initi
 /* Estimator::getLandmarks :974-990: all landmarks in PointMap order (ascending id); ids / infos may be NULL;
  * returns the number of landmarks (numLandmarks()). */
 int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, int cap);
+/* MapPoint::observations of one landmark (okvis_common FrameTypedefs.hpp: map KeypointIdentifier -> residual id), in
+ * KeypointIdentifier order (frame, camera, keypoint); any output may be NULL; returns the number of observations */
+int svin_ba_get_landmark_observations(svin_ba* h, uint64_t landmark_id, uint64_t* frame_ids, uint64_t* cam_idx,
+                                      uint64_t* keypoint_idx, uint64_t* residual_ids, int cap);
 int svin_ba_set_T_WS(svin_ba* h, uint64_t pose_id, const double T[7]);
 int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, const double sb[9]);
 int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, const double T[7]);
@@ -193,6 +197,22 @@ int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_W
 int svin_ba_is_in_imu_window(svin_ba* h, uint64_t frame_id);
 int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap);      /* returns the number of frames */
 int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap);   /* returns the number of landmarks */
+
+/* ---- okvis::ceres::Map surface that survives (Map.hpp:65-420): the graph queries Estimator / callers use,
+ * answered from the core's own graph.  Block ids: frame id (pose block), the ids add_states drew (extrinsics,
+ * speed/bias: svin_ba_describe_block tells which), landmark ids.  Residual ids: what add_observation returned, the
+ * ids of the non-reprojection factors (svin_ba_eval_factors lists them) and of the marginalisation prior. */
+int svin_ba_parameter_block_exists(svin_ba* h, uint64_t block_id);                    /* Map::parameterBlockExists */
+/* Map::setParameterBlockConstant / Variable (src/Map.cpp:495-510); landmarks: SVIN_ERR_UNSUPPORTED, unknown id: 0 */
+int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t block_id, int constant);
+int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t block_id);               /* ParameterBlock::fixed() */
+/* Map::residuals(id) (src/Map.cpp:576-587): ids of every residual touching the block, in insertion order; returns the
+ * count (may exceed cap), SVIN_ERR_NOT_FOUND for an unknown block */
+int svin_ba_residuals_of(svin_ba* h, uint64_t block_id, uint64_t* residual_ids, int cap);
+/* Map::parameters(residual) (src/Map.cpp:602-620): block ids in the cost function's parameter order (reprojection:
+ * pose, landmark, extrinsics); *kind receives 100 reprojection / 101 marginalisation prior / the factor kind
+ * (0 imu, 1 pose prior, 2 speed-bias prior, 3 relative pose, 4 sonar, 5 depth); returns the count */
+int svin_ba_parameters_of(svin_ba* h, uint64_t residual_id, uint64_t* block_ids, int cap, int32_t* kind);
 
 /* ---- keyframe hand-off to pose_graph: the estimator-side content of the keyframe message that
  * ThreadedKFVio::optimizationLoop assembles (okvis_multisensor_processing/src/ThreadedKFVio.cpp:1147-1240).  For every

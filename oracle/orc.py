@@ -123,6 +123,9 @@ def _bind(L):
     sig("orc_map_add_depth_error", u64, vp, f64, f64, f64, u64)
     sig("orc_map_add_hpoint_error", u64, vp, pd, f64, u64)
     sig("orc_map_remove_residual", i32, vp, u64)
+    sig("orc_map_residuals_of", i32, vp, u64, pu64, i32)
+    sig("orc_map_parameters_of", i32, vp, u64, pu64, i32)
+    sig("orc_map_is_constant", i32, vp, u64)
     sig("orc_map_residual_kind", i32, vp, u64)
     sig("orc_map_residual_ids", i32, vp, pu64, i32)
     sig("orc_map_residual_dims", i32, vp, u64, pi32, i32)
@@ -223,6 +226,19 @@ class OracleMap:
         ids = np.zeros(max(n, 1), np.uint64)
         self.L.orc_map_residual_ids(self.h, u64ptr(ids), n)
         return [int(i) for i in ids[:n]]
+
+    def residuals_of(self, pid):
+        out = np.zeros(1 << 16, np.uint64)
+        n = self.L.orc_map_residuals_of(self.h, pid, u64ptr(out), len(out))
+        return [int(v) for v in out[:n]]
+
+    def parameters_of(self, rid):
+        out = np.zeros(64, np.uint64)
+        n = self.L.orc_map_parameters_of(self.h, rid, u64ptr(out), 64)
+        return [int(v) for v in out[:max(n, 0)]]
+
+    def is_constant(self, pid):
+        return bool(self.L.orc_map_is_constant(self.h, pid))
 
     def residual_kind(self, rid):
         return int(self.L.orc_map_residual_kind(self.h, rid))

@@ -280,6 +280,20 @@ int orc_map_residual_ids(void* m, uint64_t* ids, int cap) {
   for (auto& kv : static_cast<Map*>(m)->residualMap()) { if (n < cap) ids[n] = kv.first; ++n; }
   return n;
 }
+// Map::residuals(paramId) / Map::parameters(resId) (Map.cpp:576-620)
+int orc_map_residuals_of(void* m, uint64_t pid, uint64_t* ids, int cap) {
+  const std::vector<uint64_t> v = static_cast<Map*>(m)->residuals(pid);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
+  return (int)v.size();
+}
+int orc_map_parameters_of(void* m, uint64_t rid, uint64_t* ids, int cap) {
+  Map* mp = static_cast<Map*>(m);
+  if (!mp->residualExists(rid)) return -1;
+  const ResidualBlock& rb = mp->residual(rid);
+  for (int i = 0; i < (int)rb.params.size() && i < cap; ++i) ids[i] = rb.params[i];
+  return (int)rb.params.size();
+}
+int orc_map_is_constant(void* m, uint64_t pid) { return static_cast<Map*>(m)->param(pid).fixed ? 1 : 0; }
 int orc_map_remove_residual(void* m, uint64_t rid) { return static_cast<Map*>(m)->removeResidualBlock(rid) ? 1 : 0; }
 // dims: m, nb, then per block dim / mdim
 int orc_map_residual_dims(void* m, uint64_t rid, int* dims, int cap) {

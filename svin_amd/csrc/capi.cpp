@@ -241,6 +241,26 @@ int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, 
   }
   return n;
 }
+int svin_ba_get_landmark_observations(svin_ba* h, uint64_t id, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids,
+                                      int cap) {
+  if (!h || cap < 0) return SVIN_ERR_INVALID_ARG;
+  const Landmark* lm = h->w.landmark(id);
+  if (!lm) return SVIN_ERR_NOT_FOUND;
+  std::vector<const svin::Observation*> sorted;
+  for (const svin::Observation& o : lm->obs) sorted.push_back(&o);
+  std::sort(sorted.begin(), sorted.end(), [](const svin::Observation* a, const svin::Observation* b) {
+    if (a->poseId != b->poseId) return a->poseId < b->poseId;
+    if (a->cam != b->cam) return a->cam < b->cam;
+    return a->kp < b->kp;
+  });
+  for (int i = 0; i < (int)sorted.size() && i < cap; ++i) {
+    if (frames) frames[i] = sorted[i]->poseId;
+    if (cams) cams[i] = (uint64_t)sorted[i]->cam;
+    if (kps) kps[i] = sorted[i]->kp;
+    if (rids) rids[i] = sorted[i]->resId;
+  }
+  return (int)sorted.size();
+}
 int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmark(id);
@@ -314,6 +334,30 @@ int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) {
   int n = 0;
   for (auto& kv : h->w.landmarks()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
   return n;
+}
+int svin_ba_parameter_block_exists(svin_ba* h, uint64_t id) { return h ? (h->w.parameterBlockExists(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; }
+int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t id, int constant) {
+  return h ? h->w.setParameterBlockConstant(id, constant != 0) : SVIN_ERR_INVALID_ARG;
+}
+int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t id) { return h ? h->w.isParameterBlockConstant(id) : SVIN_ERR_INVALID_ARG; }
+int svin_ba_residuals_of(svin_ba* h, uint64_t id, uint64_t* out, int cap) {
+  if (!h || cap < 0 || (cap > 0 && !out)) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint64_t> v;
+  if (!h->w.residualsOf(id, v)) return SVIN_ERR_NOT_FOUND;
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_parameters_of(svin_ba* h, uint64_t rid, uint64_t* out, int cap, int32_t* kind) {
+  if (!h || cap < 0 || (cap > 0 && !out)) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+  std::vector<uint64_t> v;
+  if (!h->w.parametersOf(rid, v)) return SVIN_ERR_NOT_FOUND;
+  if (kind) *kind = h->w.residualKind(rid);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+  GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_keyframe_points(svin_ba* h, uint64_t frame_id, uint64_t cam_idx, int cap_points, uint64_t* lm_ids, double* xyz,
                             uint64_t* kp_idx, double* quality, int32_t* obs_ptr, int cap_obs, uint64_t* obs_frame_ids,

@@ -602,6 +602,58 @@ void Window::setImuPreIntegral(uint64_t poseId, const double* in7) {
   std::memcpy(a.data(), in7, sizeof(a));
   imuIntegrals_.insert(std::make_pair(poseId, a));
 }
+int Window::setParameterBlockConstant(uint64_t id, bool constant) {
+  Block* b = findBlock(id);
+  if (!b) return landmarks_.count(id) ? -4 : 0;   // the landmark-elimination kernels have no "fixed landmark" path
+  b->fixed = constant;
+  return 1;
+}
+int Window::isParameterBlockConstant(uint64_t id) const {
+  const Block* b = findBlock(id);
+  if (!b) return landmarks_.count(id) ? 0 : -2;
+  return b->fixed ? 1 : 0;
+}
+int Window::residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const {
+  out.clear();
+  auto lit = landmarks_.find(blockId);
+  if (lit != landmarks_.end()) {
+    for (const Observation& o : lit->second.obs) out.push_back(o.resId);
+    return 1;
+  }
+  const Block* b = findBlock(blockId);
+  if (!b) return 0;
+  out = b->residuals;   // small factors and the prior, in insertion order
+  if (b->nObs > 0)      // reprojection residuals live in their landmark's list only
+    for (const auto& kv : landmarks_)
+      for (const Observation& o : kv.second.obs)
+        if (o.poseId == blockId || o.extId == blockId) out.push_back(o.resId);
+  std::sort(out.begin(), out.end());   // ids grow with insertion: this IS insertion order across both kinds
+  return 1;
+}
+int Window::residualKind(uint64_t resId) const {
+  if (obsRes2Lm_.count(resId)) return 100;
+  if (hasPrior_ && resId == priorResId_) return 101;
+  auto it = factors_.find(resId);
+  return it == factors_.end() ? -1 : it->second.kind;
+}
+int Window::parametersOf(uint64_t resId, std::vector<uint64_t>& out) const {
+  out.clear();
+  auto ot = obsRes2Lm_.find(resId);
+  if (ot != obsRes2Lm_.end()) {   // ReprojectionError: pose, landmark, extrinsics (ReprojectionErrorBase.hpp:50-54)
+    const Landmark& lm = landmarks_.at(ot->second);
+    for (const Observation& o : lm.obs)
+      if (o.resId == resId) { out = {o.poseId, lm.id, o.extId}; return 1; }
+    return 0;
+  }
+  if (hasPrior_ && resId == priorResId_) {
+    for (const PriorBlockHost& pb : priorBlocks_) out.push_back(pb.id);
+    return 1;
+  }
+  auto it = factors_.find(resId);
+  if (it == factors_.end()) return 0;
+  for (int b = 0; b < it->second.nblk; ++b) out.push_back(it->second.blocks[b]);
+  return 1;
+}
 uint64_t Window::currentKeyframeId() const {
   for (auto rit = states_.rbegin(); rit != states_.rend(); ++rit)
     if (rit->second.isKeyframe) return rit->first;

@@ -178,6 +178,15 @@ class Window {
   int getImuPreIntegral(uint64_t poseId, double* out7) const;          // Estimator.cpp:1001-1014
   void setImuPreIntegral(uint64_t poseId, const double* in7);          // Estimator.cpp:1081-1087 (std::map::insert: first one wins)
   int stateCount() const { return stateCount_; }                       // Estimator.hpp:450
+  // okvis::ceres::Map graph queries answered from the core's own graph (Map.cpp:495-620).  Residual ids are the ids
+  // addObservation / the factors / the prior were given; block ids are frame ids (pose), internal ids (extrinsics,
+  // speed/bias) and landmark ids.
+  bool parameterBlockExists(uint64_t id) const { return blocks_.count(id) || landmarks_.count(id); }   // Map.cpp:77-80
+  int setParameterBlockConstant(uint64_t id, bool constant);     // Map.cpp:495-510 (landmarks: SVIN_ERR_UNSUPPORTED)
+  int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
+  int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
+  int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
+  int residualKind(uint64_t resId) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, else FactorKind
   const std::map<uint64_t, State>& states() const { return states_; }
   const std::map<uint64_t, Landmark>& landmarks() const { return landmarks_; }
   uint64_t currentKeyframeId() const;

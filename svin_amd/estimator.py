@@ -62,6 +62,8 @@ EXPORTS = [
     "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
     "svin_ba_set_imu_preintegral", "svin_ba_init_pose_from_imu", "svin_ba_imu_propagation_integrals",
     "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl",
+    "svin_ba_parameter_block_exists", "svin_ba_set_parameter_block_constant", "svin_ba_is_parameter_block_constant",
+    "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -144,6 +146,12 @@ def load_library():
     sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
+    sig("svin_ba_get_landmark_observations", i32, vp, u64, pu64, pu64, pu64, pu64, i32)
+    sig("svin_ba_parameter_block_exists", i32, vp, u64)
+    sig("svin_ba_set_parameter_block_constant", i32, vp, u64, i32)
+    sig("svin_ba_is_parameter_block_constant", i32, vp, u64)
+    sig("svin_ba_residuals_of", i32, vp, u64, pu64, i32)
+    sig("svin_ba_parameters_of", i32, vp, u64, pu64, i32, pi32)
     sig("svin_ba_rccl_unique_id", i32, C.c_char_p)
     sig("svin_ba_set_distributed_rccl", i32, vp, i32, i32, C.c_char_p)
     sig("svin_ba_set_id_provider", i32, vp, C.c_void_p, C.c_void_p)
@@ -387,6 +395,13 @@ class Estimator:
         return {int(ids[i]): dict(point=np.array(infos[i].point[:]), quality=infos[i].quality, distance=infos[i].distance,
                                   n_obs=infos[i].num_observations, initialized=bool(infos[i].initialized)) for i in range(n)}
 
+    def landmark_observations(self, lid):
+        """MapPoint::observations: [(frame id, camera, keypoint, residual id)] in KeypointIdentifier order"""
+        n = self._check(self.L.svin_ba_get_landmark_observations(self.h, lid, None, None, None, None, 0), "landmark_observations")
+        a = [np.zeros(max(n, 1), np.uint64) for _ in range(4)]
+        self.L.svin_ba_get_landmark_observations(self.h, lid, *[x.ctypes.data_as(pu64) for x in a], n)
+        return [tuple(int(x[i]) for x in a) for i in range(n)]
+
     def is_landmark_added(self, lid):
         return self.L.svin_ba_is_landmark_added(self.h, lid) == 1
 
@@ -422,6 +437,27 @@ class Estimator:
         T = np.zeros(7)
         ok = self.L.svin_ba_init_pose_from_imu(s.ctypes.data_as(C.c_void_p), len(s), _d(T))
         return ok == 1, T
+
+    # -- okvis::ceres::Map graph queries ------------------------------------------------------------
+    def parameter_block_exists(self, bid):
+        return self.L.svin_ba_parameter_block_exists(self.h, bid) == 1
+
+    def set_parameter_block_constant(self, bid, constant=True):
+        return self._check(self.L.svin_ba_set_parameter_block_constant(self.h, bid, 1 if constant else 0), "set_parameter_block_constant") == 1
+
+    def is_parameter_block_constant(self, bid):
+        return self._check(self.L.svin_ba_is_parameter_block_constant(self.h, bid), "is_parameter_block_constant") == 1
+
+    def residuals_of(self, bid):
+        n = self._check(self.L.svin_ba_residuals_of(self.h, bid, None, 0), "residuals_of")
+        out = np.zeros(max(n, 1), np.uint64)
+        self.L.svin_ba_residuals_of(self.h, bid, out.ctypes.data_as(pu64), n)
+        return [int(v) for v in out[:n]]
+
+    def parameters_of(self, rid):
+        out, kind = np.zeros(64, np.uint64), C.c_int32()
+        n = self._check(self.L.svin_ba_parameters_of(self.h, rid, out.ctypes.data_as(pu64), 64, C.byref(kind)), "parameters_of")
+        return [int(v) for v in out[:n]], int(kind.value)
 
     def current_keyframe_id(self):
         return int(self.L.svin_ba_current_keyframe_id(self.h))

@@ -335,3 +335,66 @@ def test_add_states_false_returns_and_null_arguments(gpu_lib):
         assert a != 0 and e.add_observation(7, 100, 0, 3, [100.0, 120.0], 8.0) == 0
         assert e.add_observation(7, 100, 1, 3, [100.0, 120.0], 8.0) != 0      # another camera is another observation
         assert e.add_observation(8, 100, 0, 4, [100.0, 120.0], 8.0) == 0      # unknown landmark
+
+
+def test_map_graph_queries_match_oracle(gpu_lib):
+    """okvis::ceres::Map surface (SURVEY 8(a) G1, 8(b)): parameterBlockExists, residuals(id), parameters(residual),
+    ParameterBlock::fixed(), setParameterBlockConstant / Variable (Map.cpp:495-620) -- answered from the core's graph,
+    compared with the oracle's Map entry by entry, before and after a marginalisation."""
+    spec = syn.make_window(P=6, L=300, n_obs=2500, seed=14, rig="rig_v2", sonar=True, depth=True, keyframe_every=2)
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    gpu, cpu = Estimator(0), orc.OracleEstimator()
+
+    def cb(est):
+        def f(k, fid):
+            if k == 5:
+                est.optimize(5)
+                est.apply_marginalization(2, 2)
+        return f
+    fg, lg = syn.feed(gpu, spec, on_frame=cb(gpu))
+    fc, lc = syn.feed(cpu, spec, on_frame=cb(cpu))
+    assert fg == fc and lg == lc
+    m = cpu.map()
+    kinds_seen = set()
+    n_res = 0
+    blocks = set()
+    for fid in gpu.frame_ids():
+        ids = [fid]
+        # the extrinsics / speed-bias block ids of the frame, found through the factors that touch the pose
+        for rid in gpu.residuals_of(fid):
+            ps, kind = gpu.parameters_of(rid)
+            kinds_seen.add(kind)
+            assert ps == m.parameters_of(rid), (rid, kind, ps, m.parameters_of(rid))
+            ids.extend(ps)
+            n_res += 1
+        for bid in set(ids):
+            for rid in gpu.residuals_of(bid):      # relative-extrinsics factors only touch extrinsics blocks
+                kinds_seen.add(gpu.parameters_of(rid)[1])
+            blocks.add(bid)
+            assert gpu.parameter_block_exists(bid)
+            assert gpu.residuals_of(bid) == sorted(m.residuals_of(bid)), bid
+            assert gpu.is_parameter_block_constant(bid) == m.is_constant(bid), bid
+    assert {0, 3, 4, 5, 100, 101}.issubset(kinds_seen), kinds_seen      # imu, relative pose, sonar, depth, reprojection, prior
+    assert n_res > 500 and len(blocks) > 100
+    assert not gpu.parameter_block_exists(987654321)
+    with pytest.raises(RuntimeError):
+        gpu.residuals_of(987654321)
+    lid = gpu.landmark_ids()[3]
+    assert gpu.residuals_of(lid) == sorted(m.residuals_of(lid)) and len(gpu.residuals_of(lid)) == gpu.get_landmark(lid)["n_obs"]
+    with pytest.raises(RuntimeError):
+        gpu.set_parameter_block_constant(lid, True)       # no fixed-landmark path in the elimination kernels
+    # hold one pose constant on both sides: it must not move, everything else follows the oracle
+    hold = gpu.frame_ids()[-2]
+    assert gpu.set_parameter_block_constant(hold, True) and gpu.is_parameter_block_constant(hold)
+    assert cpu.L.orc_map_set_constant(m.h, hold, 1)
+    before, before_c = gpu.get_T_WS(hold).copy(), cpu.get_T_WS(hold).copy()
+    for e in (gpu, cpu):
+        e.optimize(6)
+    assert np.array_equal(gpu.get_T_WS(hold), before) and np.array_equal(cpu.get_T_WS(hold), before_c)
+    assert gpu.summary()["iterations"] == cpu.summary()["iterations"]
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(a)) for a in gpu.frame_ids())
+    assert worst < 1e-4, worst
+    assert gpu.set_parameter_block_constant(hold, False) and not gpu.is_parameter_block_constant(hold)
+    gpu.optimize(2)
+    assert not np.array_equal(gpu.get_T_WS(hold), before)
