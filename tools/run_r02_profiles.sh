@@ -1,0 +1,22 @@
+# round-2 profile set (run on the GPU box through gpurun from the repo root); outputs under gpurun_out/r02prof
+set -x
+OUT=$PWD/gpurun_out/r02prof; mkdir -p $OUT
+REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace of the headline command (the bench line that goes with it is written next to it)
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o b -- python $REPO/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+python $REPO/tools/prof_summary.py $OUT/trace/b_results.db > $OUT/bench_kernel_stats.txt 2>&1
+# 2. counter passes (PMC only with --kernel-trace; each pass within the SQ slot budget)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $OUT/pmc1 -o b -- python $REPO/tools/solver_kernels.py > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS --kernel-trace -d $OUT/pmc2 -o b -- python $REPO/tools/solver_kernels.py > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA --kernel-trace -d $OUT/pmc3 -o b -- python $REPO/tools/solver_kernels.py > $OUT/pmc3.log 2>&1
+for p in pmc1 pmc2 pmc3; do python $REPO/tools/pmc_summary.py $OUT/$p/b_results.db > $OUT/$p.txt 2>&1; done
+# 3. HBM traffic of the Jacobian-evaluation kernel on the HBM-resident batch (separate passes: FETCH_SIZE 3 slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/k1f -o b -- python $REPO/tools/k1_bench.py > $OUT/k1f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/k1w -o b -- python $REPO/tools/k1_bench.py > $OUT/k1w.log 2>&1
+python $REPO/tools/pmc_summary.py $OUT/k1f/b_results.db k_eval_reproj > $OUT/k1_fetch.txt 2>&1
+python $REPO/tools/pmc_summary.py $OUT/k1w/b_results.db k_eval_reproj > $OUT/k1_write.txt 2>&1
+cd $REPO
+# keep the databases out of the merge (size)
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/k1f $OUT/k1w
+ls -la $OUT
