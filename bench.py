@@ -104,6 +104,29 @@ def cpu_baseline(spec, budget_s=6.0):
                        "logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (flushed at exit, i.e. after
+    anything Python printed), and other libraries may do the like: from here on file descriptor 1 is stderr for everybody,
+    and emit() writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -131,10 +154,15 @@ def init_distributed(args):
                          "ranks itself)" % (args.gpus, world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dist = None
-    if world > 1:
+    if world > 1 or getattr(args, "force_sharded", False):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     return rank, world, local_rank, dist
 
 
@@ -158,7 +186,7 @@ def main_posegraph(args):
     rank, world, local_rank, dist = init_distributed(args)
     out = posegraph_record(args, rank, world, local_rank, dist, args.steps, args.warmup, cpu=not args.no_cpu_baseline and world == 1)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
     return out
@@ -298,9 +326,13 @@ def main():
                     help="window = BASELINE configs[1] (the north-star metric, default); posegraph = configs[4], the "
                          "global pose-graph optimisation (SURVEY 8(f) N1), reported as its own line")
     ap.add_argument("--six-dof", action="store_true", help="posegraph: optimize6DoFPoseGraph instead of the 4-DoF one")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the sharded config-#4 sub-record even with one rank (one-rank RCCL communicator: every collective "
+                         "really runs): the only way to exercise that code path on a 1-GPU box")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    protect_stdout()
     if args.workload == "posegraph":
         return main_posegraph(args)
 
@@ -384,7 +416,9 @@ def main():
     del est
     if not args.no_extras:
         extras = {}
-        if world > 1 and not os.environ.get("SVIN_BENCH_NO_SHARDED"):
+        if (world > 1 or args.force_sharded) and not os.environ.get("SVIN_BENCH_NO_SHARDED"):
+            if world == 1:
+                os.environ["SVIN_FORCE_DISTRIBUTED"] = "1"   # a one-rank communicator still takes the sharded code path
             # watchdog: a collective that never returns must not cost the headline line
             done = threading.Event()
 
@@ -393,7 +427,7 @@ def main():
                     if rank == 0:
                         out["sharded_config4"] = {"error": "timed out (watchdog)"}
                         out.update(extras)
-                        print(json.dumps(out), flush=True)
+                        emit(out)
                     os._exit(0)
             threading.Thread(target=watchdog, daemon=True).start()
             try:
@@ -430,7 +464,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(syn.make_window(seed=20250629))
             out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
