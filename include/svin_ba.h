@@ -235,6 +235,23 @@ int svin_ba_imu_propagation_integrals(svin_ba* h, const svin_imu_sample* imu, in
                                       double T[7], double sb[9], uint32_t sec0, uint32_t nsec0, uint32_t sec1,
                                       uint32_t nsec1, double* cov, double* jac, double integrals[7]);
 
+/* ---- host-side twins for the callers that stay on the CPU.  No handle, no GPU, no allocation: these are
+ * NOT a fall-back of the window solve (it has none).
+ * svin_host_imu_propagation: ImuError::propagation, both overloads (src/ImuError.cpp:266-476, :479-697) -- the call
+ * ThreadedKFVio::imuConsumerLoop makes per IMU sample (ThreadedKFVio.cpp:808-819) and :599 / Frontend.cpp:258 per frame.
+ * Same arguments and return value as svin_ba_imu_propagation_integrals; cov / jac / integrals may be NULL. */
+int svin_host_imu_propagation(const svin_imu_sample* imu, int n_imu, const svin_imu_params* p, double T[7], double sb[9],
+                              uint32_t sec0, uint32_t nsec0, uint32_t sec1, uint32_t nsec1, double* cov, double* jac,
+                              double* integrals);
+/* svin_host_reprojection_error: ONE ReprojectionError<GEOMETRY>::EvaluateWithMinimalJacobians
+ * (include/okvis/ceres/implementation/ReprojectionError.hpp:85-229) as ProbabilisticStereoTriangulator.cpp:266-300 uses it.
+ * information = 2x2 (row-major), its Cholesky factor weights the error (ReprojectionErrorBase setInformation).
+ * Outputs (any Jacobian pointer may be NULL): residual[2]; minimal 2x6 / 2x3 / 2x6; ambient 2x7 / 2x4 / 2x7. */
+int svin_host_reprojection_error(int distortion_model, const double intr[4], const double* dist, int n_dist,
+                                 const double T_WS[7], const double hp_W[4], const double T_SC[7], const double uv[2],
+                                 const double information[4], double residual[2], double* J_pose_min, double* J_lm_min,
+                                 double* J_ext_min, double* J_pose, double* J_lm, double* J_ext);
+
 /* ---- inspection / parity hooks (ErrorInterface::EvaluateWithMinimalJacobians, Map::getLhs) ---- */
 /* Evaluates every reprojection residual of the window on the GPU at the current estimates.
  * Outputs are per observation in the order given by svin_ba_observation_ids(); any may be NULL.

@@ -9,10 +9,10 @@ for f in kernels.hip marg.hip posegraph.hip; do
     hipcc $FLAGS -c $f -o obj/$f.o
   fi
 done
-for f in window.cpp capi.cpp; do
+for f in window.cpp capi.cpp host_eval.cpp; do
   if [ ! -f obj/$f.o ] || [ $f -nt obj/$f.o ] || [ kernels.hpp -nt obj/$f.o ] || [ dmath.hpp -nt obj/$f.o ] || [ window.hpp -nt obj/$f.o ] || [ ../../include/svin_ba.h -nt obj/$f.o ]; then
     hipcc $FLAGS -x hip -c $f -o obj/$f.o
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvin_ba.so obj/kernels.hip.o obj/marg.hip.o obj/posegraph.hip.o obj/window.cpp.o obj/capi.cpp.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsvin_ba.so obj/kernels.hip.o obj/marg.hip.o obj/posegraph.hip.o obj/window.cpp.o obj/capi.cpp.o obj/host_eval.cpp.o
 echo "built $(cd .. && pwd)/libsvin_ba.so"

@@ -64,6 +64,7 @@ EXPORTS = [
     "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl",
     "svin_ba_parameter_block_exists", "svin_ba_set_parameter_block_constant", "svin_ba_is_parameter_block_constant",
     "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
+    "svin_host_imu_propagation", "svin_host_reprojection_error",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -146,6 +147,8 @@ def load_library():
     sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
+    sig("svin_host_imu_propagation", i32, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd, pd)
+    sig("svin_host_reprojection_error", i32, i32, pd, pd, i32, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd)
     sig("svin_ba_get_landmark_observations", i32, vp, u64, pu64, pu64, pu64, pu64, i32)
     sig("svin_ba_parameter_block_exists", i32, vp, u64)
     sig("svin_ba_set_parameter_block_constant", i32, vp, u64, i32)
@@ -185,6 +188,33 @@ def rccl_unique_id():
 
 def _d(a):
     return None if a is None else a.ctypes.data_as(pd)
+
+
+def host_imu_propagation(imu_t, imu_m, params, T, sb, t0, t1, want_cov=False, want_jac=False):
+    """CPU twin of ImuError::propagation (svin_host_imu_propagation): returns (n, T, sb, cov, jac, integrals)"""
+    L = load_library()
+    s = pack_imu(imu_t, imu_m)
+    q = make_imu_params(params)
+    T, sb = _arr(T).copy(), _arr(sb).copy()
+    cov = np.zeros((15, 15)) if want_cov else None
+    jac = np.zeros((15, 15)) if want_jac else None
+    integ = np.zeros(7)
+    n = L.svin_host_imu_propagation(s.ctypes.data_as(C.c_void_p), len(s), C.byref(q), _d(T), _d(sb), t0[0], t0[1], t1[0], t1[1],
+                                    _d(cov), _d(jac), _d(integ))
+    return n, T, sb, cov, jac, integ
+
+
+def host_reprojection_error(model, intr, dist, T_WS, hp, T_SC, uv, information):
+    """CPU twin of one ReprojectionError::EvaluateWithMinimalJacobians (svin_host_reprojection_error)"""
+    L = load_library()
+    intr, dist, T_WS, hp, T_SC, uv, info = (_arr(x) for x in (intr, dist, T_WS, hp, T_SC, uv, information))
+    r, Jp, Jl, Je = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 3)), np.zeros((2, 6))
+    Ap, Al, Ae = np.zeros((2, 7)), np.zeros((2, 4)), np.zeros((2, 7))
+    rc = L.svin_host_reprojection_error(model, _d(intr), _d(dist) if len(dist) else None, len(dist), _d(T_WS), _d(hp), _d(T_SC), _d(uv),
+                                        _d(info.reshape(-1)), _d(r), _d(Jp), _d(Jl), _d(Je), _d(Ap), _d(Al), _d(Ae))
+    if rc != 1:
+        raise RuntimeError("svin_host_reprojection_error failed (%d)" % rc)
+    return dict(r=r, Jp=Jp, Jl=Jl, Je=Je, J_pose=Ap, J_lm=Al, J_ext=Ae)
 
 
 def _arr(x, dtype=np.float64):

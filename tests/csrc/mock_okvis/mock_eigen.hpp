@@ -18,6 +18,8 @@ struct Matrix {
   Matrix(S a, S b, S c, S d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
   S& operator[](int i) { return v[i]; }
   const S& operator[](int i) const { return v[i]; }
+  S& operator()(int i, int j) { return v[j * R + i]; }               // column-major like Eigen's default
+  const S& operator()(int i, int j) const { return v[j * R + i]; }
   S* data() { return v; }
   const S* data() const { return v; }
 };

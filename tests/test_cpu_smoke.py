@@ -10,7 +10,7 @@ def test_library_exports_every_declared_symbol():
     lib = estimator.load_library()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "svin_ba.h")).read()
-    declared = sorted(set(re.findall(r"\b(svin_ba_[a-zA-Z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(svin_(?:ba|host)_[a-zA-Z0-9_]+)\s*\(", header)))
     assert len(declared) > 40
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing

@@ -398,3 +398,36 @@ def test_map_graph_queries_match_oracle(gpu_lib):
     assert gpu.set_parameter_block_constant(hold, False) and not gpu.is_parameter_block_constant(hold)
     gpu.optimize(2)
     assert not np.array_equal(gpu.get_T_WS(hold), before)
+
+
+def test_host_evaluators_match_device(gpu_lib):
+    """the CPU twins the shim's ImuError / ReprojectionError classes forward to, against the device
+    versions of the same arithmetic (k_imu_propagation, k_eval_reproj)"""
+    from svin_amd import estimator
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=4, L=150, n_obs=1200, seed=13)
+    gpu = Estimator(0)
+    fg, lg = syn.feed(gpu, spec)
+    T0, sb0 = spec.T_WS_true[0].copy(), spec.sb_true[0].copy()
+    sb0[3:] = [0.01, -0.02, 0.005, 0.05, -0.03, 0.02]
+    t0, t1 = tuple(int(v) for v in spec.stamps[0]), tuple(int(v) for v in spec.stamps[2])
+    n, T, sb, cov, jac, integ = gpu.imu_propagation(spec.imu_t, spec.imu_meas, spec.imu_params, T0, sb0, t0, t1, True, True, want_integrals=True)
+    nh, Th, sbh, covh, jach, integh = estimator.host_imu_propagation(spec.imu_t, spec.imu_meas, spec.imu_params, T0, sb0, t0, t1, True, True)
+    assert n == nh
+    assert np.max(np.abs(T - Th)) < 1e-11 and np.max(np.abs(sb - sbh)) < 1e-11 and np.max(np.abs(integ - integh)) < 1e-11
+    assert np.max(np.abs(cov - covh)) <= 1e-9 * np.max(np.abs(covh)) and np.max(np.abs(jac - jach)) <= 1e-10 * np.max(np.abs(jach))
+    ev = gpu.eval_reprojection(robust=False)
+    ids = {fid: k for k, fid in enumerate(fg)}
+    worst = 0.0
+    for i in range(0, len(ev["r"]), 7):
+        k, c = ids[int(ev["pose_id"][i])], int(ev["cam"][i])
+        cam = spec.cameras[c]
+        hp = gpu.get_landmark(int(ev["lm_id"][i]))["point"]
+        size = 8.0
+        # the uv of this observation: found through its residual id order = insertion order per frame
+        o = estimator.host_reprojection_error(cam["model"], cam["intr"], cam["dist"], gpu.get_T_WS(fg[k]), hp, gpu.get_camera_sensor_states(fg[k], c),
+                                              [0.0, 0.0], np.eye(2) * 64.0 / size ** 2)
+        # measurement-independent parts: the Jacobians; the residual differs by w * uv
+        for key in ("Jp", "Jl", "Je"):
+            worst = max(worst, float(np.max(np.abs(o[key] - ev[key][i])) / max(1.0, np.max(np.abs(ev[key][i])))))
+    assert worst < 1e-12, worst
