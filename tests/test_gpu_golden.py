@@ -124,3 +124,47 @@ def test_sonar_and_depth_match_mpmath_fixture(gpu_lib):
     fid = est.new_id()
     assert est.add_states(fid, stamp(0.0), 400, T_SC, t, m, True, sonar=[(float(g["range"][0]), float(g["heading"][0]))])
     assert [f for f in est.eval_factors() if f["kind"] == 4] == []
+
+
+def test_imu_propagation_and_factor_match_mpmath_fixture(gpu_lib):
+    """I1-I3 on the device against tests/golden/imu.npz (50-digit mpmath, make_golden_imu.py): k_imu_propagation's
+    prediction / covariance / integrals, and the IMU factor's chi^2 = e^T P^-1 e in a two-frame window whose states are
+    set to the fixture's (frame stamps = the fixture's t0 / t1, so first and last sample are interpolated; case 2 has a
+    saturated gyroscope sample)"""
+    from svin_amd.estimator import Estimator
+    g = np.load(os.path.join(GOLD, "imu.npz"))
+    names = ("a_max", "g_max", "sigma_g_c", "sigma_a_c", "sigma_bg", "sigma_ba", "sigma_gw_c", "sigma_aw_c", "tau", "g")
+    par = dict(zip(names, [float(v) for v in g["params"]]))
+    par["a0"] = [0.0, 0.0, 0.0]
+    worst = dict(p=0.0, q=0.0, v=0.0, cov=0.0, integ=0.0, chi2=0.0, e=0.0)
+    for i in range(len(g["imu_n"])):
+        n = int(g["imu_n"][i])
+        it, im = g["imu_t"][i][:n], g["imu_m"][i][:n]
+        t0, t1 = tuple(int(v) for v in g["t0"][i]), tuple(int(v) for v in g["t1"][i])
+        est = Estimator(0)
+        est.add_camera(1, [450.0, 450.0, 376.0, 240.0], [0.0, 0.0, 0.0, 0.0], 752, 480, [0.0, 0.0, 0.0, 0.0])
+        est.add_imu(par)
+        used, T, sb, cov, _, integ = est.imu_propagation(it, im, par, g["T0"][i], g["sb0"][i], t0, t1, True, True, want_integrals=True)
+        assert used == int(g["used"][i])
+        worst["p"] = max(worst["p"], float(np.max(np.abs(T[:3] - g["T_pred"][i][:3]))))
+        worst["q"] = max(worst["q"], 2.0 * min(np.linalg.norm(T[3:] - g["T_pred"][i][3:]), np.linalg.norm(T[3:] + g["T_pred"][i][3:])))
+        worst["v"] = max(worst["v"], float(np.max(np.abs(sb[:3] - g["v_pred"][i]))))
+        worst["cov"] = max(worst["cov"], float(np.max(np.abs(cov - g["cov"][i])) / np.max(np.abs(g["cov"][i]))))
+        worst["integ"] = max(worst["integ"], float(np.max(np.abs(integ - g["integrals"][i]))))
+        # the factor, through the window the way the pipeline builds it
+        T_SC = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+        f0, f1 = est.new_id(), est.new_id()
+        assert est.add_states(f0, t0, 10, T_SC, it, im, True)
+        assert est.set_T_WS(f0, g["T0"][i]) and est.set_speed_and_bias(f0, g["sb0"][i])
+        assert est.add_states(f1, t1, 10, T_SC, it, im, False)
+        assert est.set_T_WS(f1, g["T1"][i]) and est.set_speed_and_bias(f1, g["sb1"][i])
+        imu = [f for f in est.eval_factors() if f["kind"] == 0]
+        assert len(imu) == 1 and imu[0]["m"] == 15
+        r = imu[0]["r"]
+        worst["chi2"] = max(worst["chi2"], abs(float(r @ r) - float(g["chi2"][i])) / float(g["chi2"][i]))
+        Lc = np.linalg.cholesky(np.linalg.inv(g["P_delta"][i]))
+        worst["e"] = max(worst["e"], float(np.max(np.abs(np.linalg.solve(Lc.T, r) - g["e"][i])) / np.max(np.abs(g["e"][i]))))
+        est.close() if hasattr(est, "close") else None
+    print("gpu vs mpmath imu", worst)
+    assert worst["p"] < 1e-13 and worst["q"] < 1e-13 and worst["v"] < 1e-13 and worst["integ"] < 1e-13, worst
+    assert worst["cov"] < 1e-12 and worst["chi2"] < 1e-9 and worst["e"] < 1e-8, worst

@@ -157,3 +157,27 @@ def test_outlier_loops_in_the_huber_region(gpu_lib, six):
     sg, sc = g.optimize(earliest, cur), c.optimize(earliest, cur)
     compare(g, c, sg, sc)
     assert g.partition()["pieces"] >= 2
+
+
+@pytest.mark.parametrize("six", [False, True])
+def test_cost_and_minimum_match_the_mpmath_fixture(gpu_lib, six):
+    """the HIP path against tests/golden/pg.npz directly (40-digit mpmath restatement of the reference's functors,
+    make_golden_pg.py), no oracle in between: the cost at the SVIn poses (loop edges only; one in the Huber region, yaw
+    differences across +-180 degrees) and, for 4 DoF, the converged solution against the fixture's minimum"""
+    import os
+    from svin_amd.posegraph import PoseGraph
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pg.npz"))
+    loops = {int(k): (int(o), g["loop_t"][i], g["loop_q"][i], float(g["loop_yaw"][i])) for i, (k, o) in enumerate(zip(g["loop_cur"], g["loop_old"]))}
+    pg = PoseGraph(0, six_dof=six, max_iterations=200)
+    n = len(g["t_svin"])
+    for k in range(n):
+        pg.add_keyframe(k, 1, g["t_svin"][k], g["q_svin"][k], loops.get(k))
+    s = pg.optimize(0, n - 1)
+    ref = float(g["cost6_initial" if six else "cost4_initial"])
+    print("gpu", s, "fixture initial", ref, "4-DoF minimum", float(g["cost4_min"]))
+    assert abs(s["initial_cost"] - ref) < 1e-11 * ref
+    if not six:
+        T, _ = pg.poses()
+        assert s["final_cost"] >= g["cost4_min"] * (1 - 1e-12)
+        assert s["final_cost"] - g["cost4_min"] < 2e-5 * g["cost4_min"]
+        assert np.max(np.abs(T - g["t4_min"])) < 2e-3

@@ -126,3 +126,53 @@ def test_sonar_and_depth_errors_match_independent_derivation():
         assert np.max(np.abs(Jm[0][0] - g["depth_J"][i])) < 1e-15
     # the reference's sonar Jacobian has (nearly) the opposite sign of the residual's true derivative: recorded, not fixed
     assert np.max(np.abs(g["J_ref"] - g["J_true"])) > 1.0
+
+
+def imu_case(g, i):
+    n = int(g["imu_n"][i])
+    par = dict(zip(("a_max", "g_max", "sigma_g_c", "sigma_a_c", "sigma_bg", "sigma_ba", "sigma_gw_c", "sigma_aw_c", "tau", "g"),
+                   [float(v) for v in g["params"]]))
+    par["a0"] = [0.0, 0.0, 0.0]
+    return n, par, g["imu_t"][i][:n], g["imu_m"][i][:n], tuple(int(v) for v in g["t0"][i]), tuple(int(v) for v in g["t1"][i])
+
+
+def quat_angle(a, b):
+    return 2.0 * min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+
+
+def test_imu_propagation_and_factor_match_independent_derivation():
+    """I1-I3: the pre-integration loop (incl. interpolated first / last sample and a saturated gyroscope sample), the
+    propagated covariance and the factor's chi^2 = e^T P^-1 e against tests/golden/imu.npz (50-digit mpmath restatement,
+    tests/golden/make_golden_imu.py); the host twin of the product (svin_host_imu_propagation) against the same file"""
+    from svin_amd import estimator
+    g = np.load(os.path.join(GOLD, "imu.npz"))
+    L = orc.lib()
+    for i in range(len(g["imu_n"])):
+        n, par, it, im, t0, t1 = imu_case(g, i)
+        pv = orc.imu_params_vector(par)
+        T, sb, cov, jac = orc.arr(g["T0"][i]).copy(), orc.arr(g["sb0"][i]).copy(), np.zeros((15, 15)), np.zeros((15, 15))
+        used = L.orc_imu_propagation(n, orc.u32ptr(orc.arr(it, np.uint32)), orc.dptr(orc.arr(im)), orc.dptr(pv), orc.dptr(T), orc.dptr(sb),
+                                     t0[0], t0[1], t1[0], t1[1], orc.dptr(cov), orc.dptr(jac))
+        assert used == int(g["used"][i])
+        assert np.max(np.abs(T[:3] - g["T_pred"][i][:3])) < 1e-13 and quat_angle(T[3:], g["T_pred"][i][3:]) < 1e-13
+        assert np.max(np.abs(sb[:3] - g["v_pred"][i])) < 1e-13 and np.array_equal(sb[3:], g["sb0"][i][3:])
+        assert np.max(np.abs(cov - g["cov"][i])) < 1e-12 * np.max(np.abs(g["cov"][i]))
+        # the product's CPU twin
+        nh, Th, sbh, covh, _, integ = estimator.host_imu_propagation(it, im, par, g["T0"][i], g["sb0"][i], t0, t1, True, True)
+        assert nh == used
+        assert np.max(np.abs(Th[:3] - g["T_pred"][i][:3])) < 1e-13 and quat_angle(Th[3:], g["T_pred"][i][3:]) < 1e-13
+        assert np.max(np.abs(sbh[:3] - g["v_pred"][i])) < 1e-13
+        assert np.max(np.abs(covh - g["cov"][i])) < 1e-12 * np.max(np.abs(g["cov"][i]))
+        assert np.max(np.abs(integ - g["integrals"][i])) < 1e-13
+        # the factor
+        m = orc.OracleMap()
+        m.add_param(1, orc.BLOCK_POSE, g["T0"][i])
+        m.add_param(2, orc.BLOCK_SPEEDBIAS, g["sb0"][i])
+        m.add_param(3, orc.BLOCK_POSE, g["T1"][i])
+        m.add_param(4, orc.BLOCK_SPEEDBIAS, g["sb1"][i])
+        rid = m.add_imu(it, im, pv, t0, t1, [1, 2, 3, 4])
+        r, Js, Jm = m.eval(rid)
+        assert abs(r @ r - g["chi2"][i]) < 1e-9 * g["chi2"][i]
+        # weighted residual = S e with S^T S = P^-1: undo the weighting with the golden covariance's Cholesky factor
+        Lc = np.linalg.cholesky(np.linalg.inv(g["P_delta"][i]))
+        assert np.max(np.abs(np.linalg.solve(Lc.T, r) - g["e"][i])) < 1e-9 * np.max(np.abs(g["e"][i]))

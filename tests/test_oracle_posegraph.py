@@ -204,3 +204,65 @@ def test_converged_4dof_solution_is_the_minimum_scipy_finds():
     t_scipy = spec.t_svin.copy()
     t_scipy[free] = sol.x[len(free):].reshape(-1, 3)
     assert np.max(np.abs(T - t_scipy)) < 2e-3
+
+
+def _feed_golden(pg, g):
+    loops = {int(k): (int(o), g["loop_t"][i], g["loop_q"][i], float(g["loop_yaw"][i])) for i, (k, o) in enumerate(zip(g["loop_cur"], g["loop_old"]))}
+    for k in range(len(g["t_svin"])):
+        pg.add_keyframe(k, 1, g["t_svin"][k], g["q_svin"][k], loops.get(k))
+    assert min(v[0] for v in loops.values()) == 0
+    return len(g["t_svin"]) - 1
+
+
+def test_error_terms_match_the_mpmath_fixture():
+    """FourDOFError / FourDOFWeightError / PoseGraph3dErrorTerm against tests/golden/pg.npz (40-digit mpmath restatement of
+    the reference's functors, tests/golden/make_golden_pg.py): cost at the SVIn poses (one loop edge in the Huber region, yaw
+    differences crossing +-180 degrees), residual cost at a perturbed state, and the pre-loss Jacobians of three 4-DoF edges"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pg.npz"))
+    pg = orc.OraclePoseGraph(six_dof=False)
+    cur = _feed_golden(pg, g)
+    nodes, nt, ne = pg.build(0, cur)
+    assert nodes == len(g["t_svin"]) and nt == 4 * (nodes - 1)
+    assert abs(pg.cost() - g["cost4_initial"]) < 1e-12 * g["cost4_initial"]
+    for k in range(1, nodes):
+        pg.perturb_node(k, g["d4"][k])
+    assert abs(pg.cost() - g["cost4_pert"]) < 1e-12 * g["cost4_pert"]
+    found = 0
+    for e in range(ne):
+        a, b, is_loop, r, Ja, Jb = pg.eval_edge(e)
+        for i in range(len(g["edge_a"])):
+            if (a, b, is_loop) == (int(g["edge_a"][i]), int(g["edge_b"][i]), bool(g["edge_loop"][i])):
+                found += 1
+                assert np.max(np.abs(r - g["edge_r"][i])) < 1e-12
+                assert np.max(np.abs(Ja - g["edge_Ja"][i])) < 1e-12 and np.max(np.abs(Jb - g["edge_Jb"][i])) < 1e-12
+    assert found == len(g["edge_a"])
+    # 6 DoF
+    pg = orc.OraclePoseGraph(six_dof=True)
+    cur = _feed_golden(pg, g)
+    nodes, nt, ne = pg.build(0, cur)
+    assert abs(pg.cost() - g["cost6_initial"]) < 1e-12 * g["cost6_initial"]
+    rng = np.random.default_rng(5)
+    rng.normal(0, 2.0, nodes), rng.normal(0, 0.05, (nodes, 3))          # the generator's draws before d6
+    d6 = np.c_[rng.normal(0, 0.05, (nodes, 3)), rng.normal(0, 0.02, (nodes, 3))]
+    d6[0] = 0
+    assert np.allclose(g["t_svin"] + d6[:, :3], g["t6_pert"], atol=1e-15)
+    for k in range(1, nodes):
+        v = d6[k, 3:]
+        half = np.sin(np.linalg.norm(v) / 2) * v / np.linalg.norm(v)    # the oracle's tangent is [sin|d| d/|d|, cos|d|]: d = asin(...)
+        d = np.arcsin(np.linalg.norm(half)) * half / np.linalg.norm(half)
+        pg.perturb_node(k, np.r_[d6[k, :3], d])
+    assert abs(pg.cost() - g["cost6_pert"]) < 1e-11 * g["cost6_pert"]
+
+
+def test_converged_4dof_solution_is_the_mpmath_minimum():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pg.npz"))
+    pg = orc.OraclePoseGraph(six_dof=False, max_iterations=200)
+    cur = _feed_golden(pg, g)
+    s = pg.optimize(0, cur)
+    T, _ = pg.poses()
+    print("oracle", s, "mpmath minimum", float(g["cost4_min"]))
+    assert s["final_cost"] >= g["cost4_min"] * (1 - 1e-12)
+    assert s["final_cost"] - g["cost4_min"] < 2e-5 * g["cost4_min"]
+    assert np.max(np.abs(T - g["t4_min"])) < 2e-3
