@@ -154,9 +154,9 @@ def test_imu_propagation_and_factor_match_mpmath_fixture(gpu_lib):
         # the factor, through the window the way the pipeline builds it
         T_SC = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
         f0, f1 = est.new_id(), est.new_id()
-        assert est.add_states(f0, t0, 10, T_SC, it, im, True)
+        assert est.add_states(f0, t0, 400, T_SC, it, im, True)
         assert est.set_T_WS(f0, g["T0"][i]) and est.set_speed_and_bias(f0, g["sb0"][i])
-        assert est.add_states(f1, t1, 10, T_SC, it, im, False)
+        assert est.add_states(f1, t1, 400, T_SC, it, im, False)
         assert est.set_T_WS(f1, g["T1"][i]) and est.set_speed_and_bias(f1, g["sb1"][i])
         imu = [f for f in est.eval_factors() if f["kind"] == 0]
         assert len(imu) == 1 and imu[0]["m"] == 15
