@@ -36,15 +36,41 @@ static void ensureDynamicLds(const void* fn, size_t bytes) {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- small helpers
-__device__ __forceinline__ double waveSum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums without LDS: __shfl_xor compiles to ds_bpermute (one LDS round trip per step and 32-bit half), DPP
+// row rotations are plain VALU operand modifiers.  kCtrl: row_ror:N = 0x120 + N (lane i of a 16-lane row reads lane
+// (i - N) & 15).  Every lane of the row (rowSum16 / rowMax16) or of the wave (waveSum / waveMax) must be active.
+__device__ __forceinline__ double readlaneD(double v, int srcLane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+template <int kCtrl>
+__device__ __forceinline__ double dppRowMov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rowSum16(double v) {  // sum over the 16 lanes of a DPP row, in every lane
+  v += dppRowMov<0x128>(v);
+  v += dppRowMov<0x124>(v);
+  v += dppRowMov<0x122>(v);
+  v += dppRowMov<0x121>(v);
   return v;
 }
-__device__ __forceinline__ double waveMax(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ double rowMax16(double v) {
+  v = fmax(v, dppRowMov<0x128>(v));
+  v = fmax(v, dppRowMov<0x124>(v));
+  v = fmax(v, dppRowMov<0x122>(v));
+  v = fmax(v, dppRowMov<0x121>(v));
   return v;
+}
+__device__ __forceinline__ double waveSum(double v) {
+  v = rowSum16(v);
+  return (readlaneD(v, 0) + readlaneD(v, 16)) + (readlaneD(v, 32) + readlaneD(v, 48));
+}
+__device__ __forceinline__ double waveMax(double v) {
+  v = rowMax16(v);
+  return fmax(fmax(readlaneD(v, 0), readlaneD(v, 16)), fmax(readlaneD(v, 32), readlaneD(v, 48)));
 }
 // block-wide sum; result valid in thread 0.  `red` must hold blockDim/64 doubles.
 __device__ __forceinline__ double blockSum(double v, double* red) {
@@ -63,6 +89,31 @@ __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+#ifdef SVIN_TRACE
+// in-kernel timeline (instrumented variant builds only, tools/build_variant.sh trace -DSVIN_TRACE): 100 MHz wall clock
+// stamps of the LAST launch, slot 2k = earliest / slot 2k+1 = latest stamp any block recorded at trace point k
+__device__ unsigned long long g_trace[128];
+__device__ __forceinline__ void tracePoint(int k) {
+  if (threadIdx.x == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMin(&g_trace[2 * k], now);
+    atomicMax(&g_trace[2 * k + 1], now);
+  }
+}
+extern "C" void svin_debug_trace(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long init[128];
+    for (int i = 0; i < 128; ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), init, sizeof(init));
+    return;
+  }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), 128 * 8);
+}
+#define TRACE(k) tracePoint(k)
+#else
+#define TRACE(k) ((void)0)
+#endif
 
 // partial-sum slots in p.partial (each slot holds up to kMaxPartials doubles)
 constexpr int kMaxPartials = 4096;
@@ -104,38 +155,6 @@ __device__ __forceinline__ bool lastBlockDoneLight(unsigned int* ticket, int* fl
 }
 
 // total cost = reprojection partials (nA blocks) + factor partials (nB) + prior, into SolverScalars (whole block)
-__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) {
-  const int t = threadIdx.x;
-  auto sumSlot = [&](int slot, int n) {
-    double s = 0;
-    for (int i = t; i < n; i += blockDim.x) s += cload(p.partial + (size_t)slot * kMaxPartials + i);
-    return blockSum(s, red);
-  };
-  const double a = sumSlot(PS_COST_REPROJ, nA);
-  const double b = sumSlot(PS_COST_FACTORS, nB);
-  if (t == 0) {
-    const double bf = p.ownsCamera ? b : 0.0;
-    const double pr = (p.ownsCamera && p.priorM > 0) ? cload(&p.scal->costPrior) : 0.0;
-    p.scal->costReproj = a; p.scal->costFactors = bf; p.scal->costPrior = pr;
-    p.scal->cost = a + bf + pr;
-  }
-  if (p.mailbox) {
-    // publish everything the host needs for its accept/reject decision: the scalars as ONE wave-wide store to the
-    // pinned host page (25 serial stores + two system fences cost ~18 us of every iteration), then the sequence number
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // thread 0's stores above are in L2 (this block re-reads them with sc1 loads)
-    __syncthreads();
-    constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
-    static_assert(nD <= 64, "SolverScalars must fit one wave-wide store");
-    if (t < nD) {
-      const double v = __hip_atomic_load(reinterpret_cast<const double*>(p.scal) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      reinterpret_cast<volatile double*>(&p.mailbox->scal)[t] = v;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
-  }
-}
-
 __global__ __launch_bounds__(64) void k_publish_scalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq) {
   constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
   const int t = threadIdx.x;
@@ -172,6 +191,39 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
   return mine;
 }
 
+// Tail of the cost evaluation (last block): everything it needs from memory is requested in ONE round trip -- the
+// two partial lists AND the other scalars of the record (written by earlier kernels) -- then one block sum; the record
+// is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 12 doubles.
+__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) {
+  const int t = threadIdx.x;
+  constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
+  static_assert(nD <= 64, "SolverScalars must fit one wave-wide store");
+  double s[2] = {0, 0};
+  for (int i = t; i < nA; i += blockDim.x) s[0] += cload(p.partial + (size_t)PS_COST_REPROJ * kMaxPartials + i);
+  for (int i = t; i < nB; i += blockDim.x) s[1] += cload(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + i);
+  double rec = (t < nD) ? cload(reinterpret_cast<const double*>(p.scal) + t) : 0.0;  // slot 3 = costPrior of this evaluation (cstore()d)
+  const double mine = blockSumK<2>(s, red, -1);
+  double* fields = red + 8;
+  if (t < 2) fields[t] = mine;
+  if (t == 3) fields[3] = (p.ownsCamera && p.priorM > 0) ? rec : 0.0;
+  __syncthreads();
+  const double a = fields[0], bf = p.ownsCamera ? fields[1] : 0.0, pr = fields[3];
+  if (t == 0) rec = a + bf + pr;
+  if (t == 1) rec = a;
+  if (t == 2) rec = bf;
+  if (t == 3) rec = pr;
+  if (t < 4) reinterpret_cast<double*>(p.scal)[t] = rec;
+  if (p.mailbox) {
+    // publish everything the host needs for its accept/reject decision: the scalars as ONE wave-wide store to the
+    // pinned host page (25 serial stores + two system fences cost ~18 us of every iteration), then the sequence number
+    if (t < nD) reinterpret_cast<volatile double*>(&p.mailbox->scal)[t] = rec;
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
+  }
+}
+
+
 // 1/x to about one ulp without the IEEE division sequence: v_rcp_f64 and two Newton steps
 __device__ __forceinline__ double rcpNewton(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -191,11 +243,6 @@ __device__ __forceinline__ double rsqrtNewton(double x) {
 }
 constexpr int kPanelLd = 17;  // leading dimension of the 16x16 LDS tiles of the dense solvers
 // ---- 16x16 diagonal block in registers (wave 0, lane i = row i), cross-lane traffic through v_readlane.
-__device__ __forceinline__ double readlaneD(double v, int srcLane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
-  return __hiloint2double(hi, lo);
-}
 #ifdef SVIN_CHOL_TIMING
 __device__ double g_cholDbg[4];
 void debugCholTiming(double* out, bool reset) {
@@ -205,63 +252,122 @@ void debugCholTiming(double* out, bool reset) {
 #endif
 // Factorises the tile D (16 x kPanelLd in LDS, full symmetric block) in place: lower triangle <- L, strict upper
 // triangle <- transposed strict lower triangle of L^-1 (D[c][r] = Linv[r][c], c < r); dinv[i] = 1/L_ii.
-// Lane i carries the full symmetric row i, so the pivot row k (= column k) is one lane's registers and is
-// broadcast with v_readlane; the square-root-free elimination a_ij -= a_ik a_kj / a_kk (A = Lt D Lt^T, Lt unit
-// lower) keeps sqrt off the serial chain.  The same broadcast values drive a fused forward substitution: lane j
-// carries column j of Lt^-1 and applies xt_i -= Lt_ik xt_k as soon as column k is known, so the inverse needs
-// no second pass and no LDS traffic.  One rsqrt per lane at the end scales both factors: L = Lt D^1/2,
-// L^-1 = D^-1/2 Lt^-1.
-__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int laneIn, int* failFlag) {
-  // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks and constants of this
-  // routine out of the caller's block-column loop (that costs ~100 registers across the whole kernel -> scratch)
+// The tile lives in the accumulator layout of v_mfma_f64_16x16x4 (lane = 16 g + c, register r = entry (row g + 4r,
+// column c)), so register b of the four lane rows IS the 4 x 16 row block of pivots 4b .. 4b+3.  Per block of four
+// pivots: the 4 x 4 diagonal block is read with v_readlane (uniform) and factorised redundantly by every lane
+// (square-root-free: A = Lt D Lt^T, Lt unit lower, one reciprocal per pivot on the serial chain), the row block is
+// all-gathered across the four lane rows with gfx950's v_permlane16/32_swap (6 swaps), every lane finishes the four
+// pivot rows at its column with the uniform multipliers, and the rank-4 trailing update is ONE MFMA.  The same row
+// operations applied to a running identity give Lt^-1 (second MFMA, same A operand), so the inverse needs no second
+// pass.  One rsqrt per lane scales both factors on their way to LDS: L = Lt D^1/2, L^-1 = D^-1/2 Lt^-1.
+// (2.5 k cycles; the one-row-per-lane routine it replaces -- pivot row through 2(16-k) v_readlane per pivot, every
+// lane updating its whole row -- took 5.5 k: tools/ubench/choldiag.hip keeps both.)
+__device__ __forceinline__ void allGatherRows(double v, double (&out)[4]) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // rows [v0 v0 v2 v2], [v1 v1 v3 v3]
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const auto l02 = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);  // [v0 x4], [v2 x4]
+  const auto h02 = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+  const auto l13 = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);  // [v1 x4], [v3 x4]
+  const auto h13 = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+  out[0] = __hiloint2double((int)h02[0], (int)l02[0]);
+  out[2] = __hiloint2double((int)h02[1], (int)l02[1]);
+  out[1] = __hiloint2double((int)h13[0], (int)l13[0]);
+  out[3] = __hiloint2double((int)h13[1], (int)l13[1]);
+}
+__device__ __forceinline__ double selectByRow(int g, double v0, double v1, double v2, double v3) {
+  double v = v0;
+  v = (g == 1) ? v1 : v;
+  v = (g == 2) ? v2 : v;
+  v = (g == 3) ? v3 : v;
+  return v;
+}
+// 1/x for a pivot: v_rcp_f64 (>= 24 bits) and r (1 + e + e^2), e = 1 - x r: relative error e^3, one dependent
+// operation less than two Newton steps
+__device__ __forceinline__ double rcpPivot(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+// `acc` = the tile in the accumulator layout (what an MFMA update of it leaves in registers); D receives the factors
+__device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv, int laneIn, int* failFlag) {
+  // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks of this routine out of the
+  // caller's block-column loop
   int lane = laneIn;
   asm volatile("" : "+v"(lane));
-  const int li = lane & 15;
+  const int c = lane & 15, g = lane >> 4;
 #ifdef SVIN_CHOL_TIMING
   const long long qd0 = __builtin_readcyclecounter();
 #endif
-  double a[16], x[16];
+  d4_t xacc;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { a[j] = D[li * kPanelLd + j]; x[j] = (j == li) ? 1.0 : 0.0; }
+  for (int r = 0; r < 4; ++r) xacc[r] = (g + 4 * r == c) ? 1.0 : 0.0;
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    double pr[16];
+  for (int b = 0; b < 4; ++b) {
+    // the 4 x 4 diagonal block (lower triangle), uniform: entry (4b + i, 4b + j) sits in lane 16 i + 4b + j
+    const double b00 = readlaneD(acc[b], 4 * b);
+    const double b10 = readlaneD(acc[b], 16 + 4 * b), b11 = readlaneD(acc[b], 16 + 4 * b + 1);
+    const double b20 = readlaneD(acc[b], 32 + 4 * b), b21 = readlaneD(acc[b], 32 + 4 * b + 1), b22 = readlaneD(acc[b], 32 + 4 * b + 2);
+    const double b30 = readlaneD(acc[b], 48 + 4 * b), b31 = readlaneD(acc[b], 48 + 4 * b + 1), b32 = readlaneD(acc[b], 48 + 4 * b + 2),
+                 b33 = readlaneD(acc[b], 48 + 4 * b + 3);
+    double P[4], PX[4];
+    allGatherRows(acc[b], P);
+    if (b == 0) {
 #pragma unroll
-    for (int j = k; j < 16; ++j) pr[j] = readlaneD(a[j], k);
-    const bool ok = pr[k] > 0;
-    bad = bad || !ok;
-    const double rk = rcpNewton(ok ? pr[k] : 1.0);  // branch-free: 1 for a failed pivot
-    const double m = a[k] * rk, mx = x[k] * rk;
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-m, pr[j], a[j]);
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) x[j] = __builtin_fma(-mx, pr[j], x[j]);
-    __builtin_amdgcn_sched_barrier(0);  // keep each column's updates next to its broadcasts (SGPR lifetime)
+      for (int q = 0; q < 4; ++q) PX[q] = (c == q) ? 1.0 : 0.0;
+    } else {
+      allGatherRows(xacc[b], PX);
+    }
+    const double d0 = b00;
+    bad = bad || !(d0 > 0);
+    const double r0 = rcpPivot(d0 > 0 ? d0 : 1.0);  // branch-free: 1 for a failed pivot
+    const double l10 = b10 * r0, l20 = b20 * r0, l30 = b30 * r0;
+    const double d1 = __builtin_fma(-l10, b10, b11);
+    bad = bad || !(d1 > 0);
+    const double r1 = rcpPivot(d1 > 0 ? d1 : 1.0);
+    const double u21 = __builtin_fma(-l20, b10, b21), u31 = __builtin_fma(-l30, b10, b31);
+    const double l21 = u21 * r1, l31 = u31 * r1;
+    const double d2 = __builtin_fma(-l21, u21, __builtin_fma(-l20, b20, b22));
+    bad = bad || !(d2 > 0);
+    const double r2 = rcpPivot(d2 > 0 ? d2 : 1.0);
+    const double u32 = __builtin_fma(-l31, u21, __builtin_fma(-l30, b20, b32));
+    const double l32 = u32 * r2;
+    const double d3 = __builtin_fma(-l32, u32, __builtin_fma(-l31, u31, __builtin_fma(-l30, b30, b33)));
+    bad = bad || !(d3 > 0);
+    const double r3 = rcpPivot(d3 > 0 ? d3 : 1.0);
+    // the four finished pivot rows at my column, and the same row operations on the inverse
+    const double U0 = P[0];
+    const double U1 = __builtin_fma(-l10, U0, P[1]);
+    const double U2 = __builtin_fma(-l21, U1, __builtin_fma(-l20, U0, P[2]));
+    const double U3 = __builtin_fma(-l32, U2, __builtin_fma(-l31, U1, __builtin_fma(-l30, U0, P[3])));
+    const double X0 = PX[0];
+    const double X1 = __builtin_fma(-l10, X0, PX[1]);
+    const double X2 = __builtin_fma(-l21, X1, __builtin_fma(-l20, X0, PX[2]));
+    const double X3 = __builtin_fma(-l32, X2, __builtin_fma(-l31, X1, __builtin_fma(-l30, X0, PX[3])));
+    const double Um = selectByRow(g, U0, U1, U2, U3), Xm = selectByRow(g, X0, X1, X2, X3);
+    const double rm = selectByRow(g, r0, r1, r2, r3), dm = selectByRow(g, d0, d1, d2, d3);
+    if (b < 3) {  // rows > 4b+3: a_ij -= sum_k (U_k[i] / d_k) U_k[j]; rows and columns <= 4b+3 of acc are dead from here on
+      const double aop = -Um * rm;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Um, acc, 0, 0, 0);
+      xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Xm, xacc, 0, 0, 0);
+    }
+    const double rs = rsqrtNewton(dm > 0 ? dm : 1.0);  // 1/L_kk (1 for a failed pivot)
+    const int k = 4 * b + g;
+    D[c * kPanelLd + k] = ((c >= k) ? Um : Xm) * rs;  // L[c][k] below / on the diagonal, Linv[k][c] above
+    if (c == 0) dinv[k] = rs;
   }
-#ifdef SVIN_CHOL_TIMING
-  const long long qd1 = __builtin_readcyclecounter();
-#endif
-  double dk = a[0];
-#pragma unroll
-  for (int k = 1; k < 16; ++k) dk = (li == k) ? a[k] : dk;
-  const double rs = rsqrtNewton(dk > 0 ? dk : 1.0);  // 1/L_kk in lane k (1 for a failed pivot), branch-free
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double rsk = readlaneD(rs, k);
-    a[k] *= rsk;  // L[li][k] for k <= li
-    x[k] *= rsk;  // Linv[k][li] for k >= li
-  }
-  // lanes 16..63 replicate lanes 0..15 (same values to the same addresses): storing from all of them keeps the
-  // compiler from sinking the x recurrence into a divergent block (which spills every broadcast value)
-#pragma unroll
-  for (int j = 0; j < 16; ++j) D[li * kPanelLd + j] = (j > li) ? x[j] : a[j];  // D[c=li][r=j] = Linv[j][li]
-  dinv[li] = rs;
-  if (bad && lane == 0) atomicOr(failFlag, 2);  // after the stores: no block boundary inside the register pipeline
+  if (bad && lane == 0) atomicOr(failFlag, 2);
 #ifdef SVIN_CHOL_TIMING
   const long long qd2 = __builtin_readcyclecounter();
-  if (lane == 0) { g_cholDbg[0] += (double)(qd1 - qd0); g_cholDbg[1] += (double)(qd2 - qd1); }
+  if (lane == 0) { g_cholDbg[0] += (double)(qd2 - qd0); }
 #endif
+}
+__device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane, int* failFlag) {
+  d4_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = D[((lane >> 4) + 4 * r) * kPanelLd + (lane & 15)];
+  cholDiag16Acc(acc, D, dinv, lane, failFlag);
 }
 
 // ================================================================ K1: reprojection evaluation
@@ -1352,7 +1458,7 @@ __device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
   if (t == 0) cstore(&p.scal->costPrior, 0.5 * (*p.priorC0) + tot);
 }
 __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
-  __shared__ double red[4];
+  __shared__ double red[12];
   priorEvalBlock(p, cand, red);
   if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
     __syncthreads();
@@ -1375,8 +1481,10 @@ template <bool WITH_EXT>
 __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost, int hasPrior) {
   __shared__ FactorShared sh;
   const int F = (int)gridDim.x - nR - hasPrior;
+  TRACE(16);
   if ((int)blockIdx.x < F) {
     evalFactorBlock(p, cand, blockIdx.x, sh);
+    TRACE(17);
   } else if ((int)blockIdx.x == F + nR) {
     priorEvalBlock(p, cand, reinterpret_cast<double*>(&sh));
   } else {
@@ -1386,12 +1494,15 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
                                     cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
                                     cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N);
   }
+  TRACE(18);
   if (sumCost) {
     __shared__ int lastFlag;
-    __shared__ double red4[4];
+    __shared__ double red4[12];
     if (lastBlockDoneLight(&p.tickets[TK_EVAL], &lastFlag)) {   // (cost partials and costPrior are cstore()d)
+      TRACE(19);
       reduceCost(p, nR, F, red4);
       if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
+      TRACE(20);
     }
   }
 }
@@ -1914,12 +2025,8 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
         b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        v00 += __shfl_xor(v00, o, 16); v01 += __shfl_xor(v01, o, 16); v02 += __shfl_xor(v02, o, 16);
-        v11 += __shfl_xor(v11, o, 16); v12 += __shfl_xor(v12, o, 16); v22 += __shfl_xor(v22, o, 16);
-        b0 += __shfl_xor(b0, o, 16); b1 += __shfl_xor(b1, o, 16); b2 += __shfl_xor(b2, o, 16);
-      }
+      v00 = rowSum16(v00); v01 = rowSum16(v01); v02 = rowSum16(v02); v11 = rowSum16(v11); v12 = rowSum16(v12); v22 = rowSum16(v22);
+      b0 = rowSum16(b0); b1 = rowSum16(b1); b2 = rowSum16(b2);
       // trust-region metric for the landmark columns (Jacobi scaling fixed at iteration 0)
       double sc0, sc1, sc2;
       if (initScale) {
@@ -2175,12 +2282,8 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
         b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        v00 += __shfl_xor(v00, o, 16); v01 += __shfl_xor(v01, o, 16); v02 += __shfl_xor(v02, o, 16);
-        v11 += __shfl_xor(v11, o, 16); v12 += __shfl_xor(v12, o, 16); v22 += __shfl_xor(v22, o, 16);
-        b0 += __shfl_xor(b0, o, 16); b1 += __shfl_xor(b1, o, 16); b2 += __shfl_xor(b2, o, 16);
-      }
+      v00 = rowSum16(v00); v01 = rowSum16(v01); v02 = rowSum16(v02); v11 = rowSum16(v11); v12 = rowSum16(v12); v22 = rowSum16(v22);
+      b0 = rowSum16(b0); b1 = rowSum16(b1); b2 = rowSum16(b2);
       double sc0, sc1, sc2;
       if (initScale) {
         sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
@@ -2546,7 +2649,8 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
                                                                     int fuseFinalize) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, d = p.d, nT = dpad / 16;
-  const int wave = t >> 6, lane = t & 63, nW = kCholLdsThreads / 64;
+  // the wave index through v_readfirstlane: tile indices and LDS tile addresses become scalar (SALU) arithmetic
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = kCholLdsThreads / 64;
   const int nTilesAll = nT * (nT + 1) / 2;
   double* tiles = smem;
   double* rhs = smem + (size_t)nTilesAll * kTile;  // dpad
@@ -2606,74 +2710,75 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 #ifdef SVIN_CHOL_TIMING
   if (t == 0) p.partial[(size_t)15 * 4096 + 0] += (double)(__builtin_readcyclecounter() - qq0);
 #endif
+  // Per block column kb (its diagonal tile is already factorised: prologue / phase D of the previous step):
+  //   phase P  panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile), one tile
+  //            per wave and turn.  Wave 0 takes the tile right below the diagonal and, from it, updates the NEXT
+  //            diagonal tile C -= X X^T, which stays in its registers; the last wave also advances the forward
+  //            substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb.
+  //   phase D  wave 0 factorises the next diagonal tile out of its registers (the serial chain of the whole solve)
+  //            while the other waves apply the trailing update C(I,J) -= X_I X_J^T.  The tile routine is
+  //            instruction-issue bound, so the wave sharing wave 0's SIMD stays off the matrix pipe and only updates
+  //            the tail of the right-hand side.  The workers own whole tile rows (dealt longest first, serpentine):
+  //            the A operand of a row is read once, the B / C tiles are walked with pointer increments, and the
+  //            operands of the next tile are in flight while the current one is on the matrix pipe.
+  const int lrow = (lane >> 4) * kPanelLd + (lane & 15);  // accumulator layout: + 4 rg kPanelLd
+  const int lop = (lane & 15) * kPanelLd + (lane >> 4);   // operand layout: + 4 q
   for (int kb = 0; kb < nT; ++kb) {
     const int k0 = kb * 16;
-    double* D = tileAt(tiles, kb, kb);  // already factorised (prologue / look-ahead of the previous step)
+    double* D = tileAt(tiles, kb, kb);
 #ifdef SVIN_CHOL_TIMING
     long long q2 = __builtin_readcyclecounter();
 #endif
     const int nR = nT - kb - 1;
-    // phase B: panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile);
-    // the last wave also advances the forward substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb
-    for (int ti = wave; ti < nR; ti += nW) {
-      double* A = tileAt(tiles, kb + 1 + ti, kb);
+    d4_t accD = {0, 0, 0, 0};
+    auto panelSolve = [&](double* A) {
       d4_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kk = 4 * q + (lane >> 4), jj = lane & 15;
-        const double a = A[(lane & 15) * kPanelLd + kk];
+        const double a = A[lop + 4 * q];
         const double b = (jj > kk) ? D[kk * kPanelLd + jj] : ((jj == kk) ? dinv[k0 + kk] : 0.0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) A[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
-    }
-    if (wave == nW - 1) {
-      const int li = lane & 15;
-      double yv = rhs[k0 + li] * dinv[k0 + li];
+      for (int rg = 0; rg < 4; ++rg) A[lrow + 4 * rg * kPanelLd] = acc[rg];
+    };
+    if (wave == 0) {
+      if (nR > 0) {
+        double* A = tileAt(tiles, kb + 1, kb);
+        const double* Cb = tileAt(tiles, kb + 1, kb + 1);
 #pragma unroll
-      for (int c = 0; c < 15; ++c) {
-        const double term = D[c * kPanelLd + li] * rhs[k0 + c];
-        yv += (c < li) ? term : 0.0;
+        for (int rg = 0; rg < 4; ++rg) accD[rg] = Cb[lrow + 4 * rg * kPanelLd];
+        panelSolve(A);
+        waveSync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double x = A[lop + 4 * q];
+          accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, x, accD, 0, 0, 0);
+        }
       }
-      waveSync();
-      if (lane < 16) rhs[k0 + lane] = yv;
+    } else {
+      for (int ti = wave; ti < nR; ti += nW - 1) panelSolve(tileAt(tiles, kb + 1 + ti, kb));
+      if (wave == nW - 1) {
+        const int li = lane & 15;
+        double yv = rhs[k0 + li] * dinv[k0 + li];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+          const double term = D[c * kPanelLd + li] * rhs[k0 + c];
+          yv += (c < li) ? term : 0.0;
+        }
+        waveSync();
+        if (lane < 16) rhs[k0 + lane] = yv;
+      }
     }
     __syncthreads();
 #ifdef SVIN_CHOL_TIMING
     long long q3 = __builtin_readcyclecounter();
     if (t == 0) p.partial[(size_t)15 * 4096 + 2] += (double)(q3 - q2);
 #endif
-    // phase C: trailing update C(I,J) -= L(I,kb) L(J,kb)^T on MFMA.  Look-ahead: wave 0 updates the next diagonal
-    // tile first and factorises it right away.  That routine is VALU-issue bound, so the wave sharing its SIMD
-    // (wave nW/2 for 2 waves per SIMD) stays off the matrix pipe and only updates the tail of the right-hand side;
-    // the other waves take the remaining tiles, software-pipelined (operands of the next tile are fetched before
-    // the current one is written back).
-    const int nUp = nR * (nR + 1) / 2;
     const int quiet = nW / 2;  // shares SIMD 0 with wave 0
-    auto updateTile = [&](int I, int J) {
-      double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
-      const double* A = tileAt(tiles, kb + 1 + I, kb);
-      const double* B = tileAt(tiles, kb + 1 + J, kb);
-      d4_t acc;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double a = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
-        const double b = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
-      return Cb;
-    };
     if (wave == 0) {
-      if (nUp > 0) {
-        double* Cb = updateTile(0, 0);
-        waveSync();
-        cholDiag16Reg(Cb, dinv + k0 + 16, lane, &p.scal->cholFail);
-      }
+      if (nR > 0) cholDiag16Acc(accD, tileAt(tiles, kb + 1, kb + 1), dinv + k0 + 16, lane, &p.scal->cholFail);
     } else if (wave == quiet) {
       for (int i = k0 + 16 + lane; i < dpad; i += 64) {
         const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
@@ -2684,55 +2789,45 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
       }
     } else {
       const int widx = wave - 1 - (wave > quiet ? 1 : 0), nWork = nW - 2;
-      // tile index -> (I, J) of the lower-triangular list (row-major, diagonal included)
-      auto decode = [&](int tile, int& I, int& J) {
-        I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-        if ((I + 1) * (I + 2) / 2 <= tile) ++I;
-        if (I * (I + 1) / 2 > tile) --I;
-        J = tile - I * (I + 1) / 2;
-      };
-      int tile = 1 + widx;
-      if (tile < nUp) {
-        int I, J;
-        decode(tile, I, J);
-        double a[4], bq[4];
+      // rows nR-1 .. 1 of the trailing matrix (row I: tiles (I, 0..I); row 0 is wave 0's tile), dealt to the workers
+      // longest first and back again
+      for (int n = 0; n < nR - 1; ++n) {
+        const int turn = n / nWork, pos = n - turn * nWork;
+        if (((turn & 1) ? nWork - 1 - pos : pos) != widx) continue;
+        const int I = nR - 1 - n;
+        const double* A = tileAt(tiles, kb + 1 + I, kb);
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = -A[lop + 4 * q];
+        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1);
+        const double* B = tileAt(tiles, kb + 1, kb);
+        int rowTiles = kb + 2;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
+        double bq[4];
         d4_t acc;
-        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1 + J);
-        {
-          const double* A = tileAt(tiles, kb + 1 + I, kb);
-          const double* B = tileAt(tiles, kb + 1 + J, kb);
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[lrow + 4 * rg * kPanelLd];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { a[q] = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; bq[q] = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; }
-        }
-        while (true) {
-          const int next = tile + nWork;
-          const bool more = next < nUp;
-          double an[4], bn[4];
+        for (int q = 0; q < 4; ++q) bq[q] = B[lop + 4 * q];
+        for (int J = 0; J <= I; ++J) {
+          const bool more = J < I;
+          double bn[4] = {0, 0, 0, 0};
           d4_t accn = {0, 0, 0, 0};
-          double* Cn = Cb;
           if (more) {
-            int In, Jn;
-            decode(next, In, Jn);
-            Cn = tileAt(tiles, kb + 1 + In, kb + 1 + Jn);
-            const double* A = tileAt(tiles, kb + 1 + In, kb);
-            const double* B = tileAt(tiles, kb + 1 + Jn, kb);
+            B += (size_t)rowTiles * kTile;
+            ++rowTiles;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) accn[rg] = Cn[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)];
+            for (int rg = 0; rg < 4; ++rg) accn[rg] = Cb[kTile + lrow + 4 * rg * kPanelLd];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { an[q] = -A[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; bn[q] = B[(lane & 15) * kPanelLd + 4 * q + (lane >> 4)]; }
+            for (int q = 0; q < 4; ++q) bn[q] = B[lop + 4 * q];
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = acc[rg];
-          if (!more) break;
+          for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kPanelLd] = acc[rg];
+          Cb += kTile;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { a[q] = an[q]; bq[q] = bn[q]; }
+          for (int q = 0; q < 4; ++q) bq[q] = bn[q];
           acc = accn;
-          Cb = Cn;
-          tile = next;
         }
       }
     }
@@ -3465,49 +3560,114 @@ __device__ __forceinline__ DoglegCoeff doglegCoefficients(double gHatSq, double 
   return c;
 }
 // candidate = x [+] delta for item i (variable blocks first, then landmarks); acc += |x - x_cand|^2, |x|^2
+// Quaternion exponential of the retraction on the device: sin(h)/h and cos(h) from their Taylor series for the
+// half-angles a trust-region step produces (h^2 < 1/4: truncation below 1e-21), the library functions beyond.  The
+// library versions cost several hundred instructions each, and this sits on the serial tail of every iteration.
+__device__ __forceinline__ Quat deltaQDev(double ax, double ay, double az) {
+  const double h2 = 0.25 * (ax * ax + ay * ay + az * az);
+  double sc, c;
+  if (h2 < 0.25) {
+    sc = -1.0 / 121645100408832000.0;  // 1/19!
+    sc = __builtin_fma(sc, h2, 1.0 / 355687428096000.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 1307674368000.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 6227020800.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 39916800.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 362880.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 5040.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 120.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 6.0);
+    sc = __builtin_fma(sc, h2, 1.0);
+    c = -1.0 / 6402373705728000.0;  // 1/18!
+    c = __builtin_fma(c, h2, 1.0 / 20922789888000.0);
+    c = __builtin_fma(c, h2, -1.0 / 87178291200.0);
+    c = __builtin_fma(c, h2, 1.0 / 479001600.0);
+    c = __builtin_fma(c, h2, -1.0 / 3628800.0);
+    c = __builtin_fma(c, h2, 1.0 / 40320.0);
+    c = __builtin_fma(c, h2, -1.0 / 720.0);
+    c = __builtin_fma(c, h2, 1.0 / 24.0);
+    c = __builtin_fma(c, h2, -0.5);
+    c = __builtin_fma(c, h2, 1.0);
+  } else {
+    const double h = sqrt(h2);
+    sc = sin(h) / h;
+    c = cos(h);
+  }
+  const double s = 0.5 * sc;
+  return Quat{s * ax, s * ay, s * az, c};
+}
+// poseOplus (dmath.hpp) with the device exponential and one reciprocal per normalisation
+__device__ __forceinline__ void poseOplusDev(const double* x, const double* delta, double* xo) {
+  xo[0] = x[0] + delta[0]; xo[1] = x[1] + delta[1]; xo[2] = x[2] + delta[2];
+  const double n0 = 1.0 / sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  const Quat q = {x[3] * n0, x[4] * n0, x[5] * n0, x[6] * n0};
+  const Quat qn = qmul(deltaQDev(delta[3], delta[4], delta[5]), q);
+  const double n1 = 1.0 / sqrt(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+  xo[3] = qn.x * n1; xo[4] = qn.y * n1; xo[5] = qn.z * n1; xo[6] = qn.w * n1;
+}
+// One item of the retraction x_cand = x [+] (cg v - cn y).  Everything is loaded before the first store: the candidate
+// arrays may alias the inputs as far as the compiler knows, and a store between two loads turns them into serial
+// memory round trips (9 us for the 22 blocks of a 10-keyframe window before this was written this way).
 __device__ __forceinline__ void retractItem(const DeviceProblem& p, int i, double cg, double cn, double* acc) {
   const int nBlk = p.nPose + p.nExt + p.nSb;
   if (i < nBlk) {
     if (i < p.nPose + p.nExt) {
       const bool isPose = i < p.nPose;
       const int slot = isPose ? i : i - p.nPose;
-      const double* x = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
+      const double* xp = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
       double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
       const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
+      double x[7], v[6], y[6], xo[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) x[k] = xp[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = off >= 0 ? p.vC[off + k] : 0.0; y[k] = off >= 0 ? p.yC[off + k] : 0.0; }
       if (off >= 0) {
-        double dl[6], xo[7];
-        for (int k = 0; k < 6; ++k) dl[k] = cg * p.vC[off + k] - cn * p.yC[off + k];
-        poseOplus(x, dl, xo);
-        for (int k = 0; k < 7; ++k) {
-          xc[k] = xo[k];
-          if (p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
+        double dl[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dl[k] = cg * v[k] - cn * y[k];
+        poseOplusDev(x, dl, xo);
+        if (p.ownsCamera) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
         }
       } else {
-        for (int k = 0; k < 7; ++k) xc[k] = x[k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) xo[k] = x[k];
       }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) xc[k] = xo[k];
     } else {
       const int slot = i - p.nPose - p.nExt;
-      const double* x = p.sb + (size_t)slot * 9;
+      const double* xp = p.sb + (size_t)slot * 9;
       double* xc = p.sbC + (size_t)slot * 9;
       const int off = p.sbOff[slot];
+      double x[9], v[9], y[9], xo[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { x[k] = xp[k]; v[k] = off >= 0 ? p.vC[off + k] : 0.0; y[k] = off >= 0 ? p.yC[off + k] : 0.0; }
+#pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const double xo = off >= 0 ? x[k] + (cg * p.vC[off + k] - cn * p.yC[off + k]) : x[k];
-        xc[k] = xo;
-        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo) * (x[k] - xo); acc[1] += x[k] * x[k]; }
+        xo[k] = off >= 0 ? x[k] + (cg * v[k] - cn * y[k]) : x[k];
+        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
       }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xc[k] = xo[k];
     }
   } else if (i < nBlk + p.L) {
     const int l = i - nBlk;
-    const double* x = p.lm + 4 * (size_t)l;
-    double* xc = p.lmC + 4 * (size_t)l;
+    const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
+    const double x[4] = {xx.x, xx.y, xx.z, xx.w};
+    double v[3], y[3], xo[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v[k] = p.vL[3 * l + k]; y[k] = p.yL[3 * l + k]; }
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double xo = x[k] + (cg * p.vL[3 * l + k] - cn * p.yL[3 * l + k]);
-      xc[k] = xo;
-      acc[0] += (x[k] - xo) * (x[k] - xo);
+      xo[k] = x[k] + (cg * v[k] - cn * y[k]);
+      acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]);
       acc[1] += x[k] * x[k];
     }
-    xc[3] = x[3] + 0.0;
+    xo[3] = x[3] + 0.0;
     acc[1] += x[3] * x[3];
+    reinterpret_cast<double4*>(p.lmC)[l] = double4{xo[0], xo[1], xo[2], xo[3]};
   }
 }
 
@@ -3556,6 +3716,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   double acc[kPostK];
 #pragma unroll
   for (int k = 0; k < kPostK; ++k) acc[k] = 0;
+  TRACE(0);
   // clear the accumulators of the next linearisation (nothing reads S / gRed / hC after the solve; gFull is
   // still needed by the last block below and is cleared there)
   for (int i = b * blockDim.x + t; i < p.d * p.d; i += gridDim.x * blockDim.x) p.S[i] = 0.0;
@@ -3565,19 +3726,27 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     const size_t N = (size_t)p.N;
     // the camera-side solution vectors are tiny and read by every observation: one staged copy in LDS instead of a
     // dependent global load per observation (narrow windows; wide ones keep reading them through L2)
-    constexpr int kStageMax = 512;
+    constexpr int kStageMax = 512, kStageBlk = 128;
     __shared__ double sYV[2 * kStageMax];
+    __shared__ int sOff[2 * kStageBlk];
     const bool staged = p.d <= kStageMax;
+    const bool stagedOff = p.nPose <= kStageBlk && p.nExt <= kStageBlk;  // the block -> row maps too (one dependent load less)
     if (staged) {
       for (int i = t; i < p.d; i += blockDim.x) { sYV[i] = p.yC[i]; sYV[kStageMax + i] = p.vC[i]; }
-      __syncthreads();
     }
+    if (stagedOff) {
+      for (int i = t; i < p.nPose; i += blockDim.x) sOff[i] = p.poseOff[i];
+      for (int i = t; i < p.nExt; i += blockDim.x) sOff[kStageBlk + i] = p.extOff[i];
+    }
+    if (staged || stagedOff) __syncthreads();
     const double* yCs = staged ? sYV : p.yC;
     const double* vCs = staged ? sYV + kStageMax : p.vC;
+    const int* poseOffS = stagedOff ? sOff : p.poseOff;
+    const int* extOffS = stagedOff ? sOff + kStageBlk : p.extOff;
     // u_y = Jc y_C, u_v = Jc v_C, Jl and r of observation o
     auto loadObs = [&](size_t o, double* jl, double* uy, double* uv, double* rr) {
       const uint32_t idx = p.obsIdx[o];
-      const int offP = p.poseOff[idx & 0xfff];
+      const int offP = poseOffS[idx & 0xfff];
       uy[0] = uy[1] = uv[0] = uv[1] = 0;
       if (offP >= 0) {
 #pragma unroll
@@ -3587,7 +3756,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         }
       }
       if (WITH_EXT) {
-        const int offE = p.extOff[(idx >> 12) & 0xfff];
+        const int offE = extOffS[(idx >> 12) & 0xfff];
         if (offE >= 0) {
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
@@ -3602,6 +3771,11 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     };
     for (int l = b * 16 + grp; l < p.L; l += nLmBlocks * 16) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      // the landmark's own quantities do not depend on the observation loop: requested up front
+      const double g0 = p.bl[3 * l], g1 = p.bl[3 * l + 1], g2 = p.bl[3 * l + 2];
+      const double* vi = p.Vinv + 6 * (size_t)l;
+      const double vi0 = vi[0], vi1 = vi[1], vi2 = vi[2], vi3 = vi[3], vi4 = vi[4], vi5 = vi[5];
+      const double h0 = p.hL[3 * l], h1 = p.hL[3 * l + 1], h2 = p.hL[3 * l + 2];
       double t0 = 0, t1 = 0, t2 = 0;
       double cjl[6], cuy[2], cuv[2], crr[2];  // first observation of this lane stays in registers
       for (int i = gl; i < n; i += 16) {
@@ -3616,15 +3790,11 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
           cuy[0] = uy[0]; cuy[1] = uy[1]; cuv[0] = uv[0]; cuv[1] = uv[1]; crr[0] = rr[0]; crr[1] = rr[1];
         }
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { t0 += __shfl_xor(t0, o, 16); t1 += __shfl_xor(t1, o, 16); t2 += __shfl_xor(t2, o, 16); }
-      const double g0 = p.bl[3 * l], g1 = p.bl[3 * l + 1], g2 = p.bl[3 * l + 2];
-      const double* vi = p.Vinv + 6 * (size_t)l;
+      t0 = rowSum16(t0); t1 = rowSum16(t1); t2 = rowSum16(t2);
       const double q0 = g0 - t0, q1 = g1 - t1, q2 = g2 - t2;
-      const double y0 = vi[0] * q0 + vi[1] * q1 + vi[2] * q2;
-      const double y1 = vi[1] * q0 + vi[3] * q1 + vi[4] * q2;
-      const double y2 = vi[2] * q0 + vi[4] * q1 + vi[5] * q2;
-      const double h0 = p.hL[3 * l], h1 = p.hL[3 * l + 1], h2 = p.hL[3 * l + 2];
+      const double y0 = vi0 * q0 + vi1 * q1 + vi2 * q2;
+      const double y1 = vi1 * q0 + vi3 * q1 + vi4 * q2;
+      const double y2 = vi2 * q0 + vi4 * q1 + vi5 * q2;
       const double v0 = g0 / h0, v1 = g1 / h1, v2 = g2 / h2;
       if (gl == 0) {
         cstore(p.yL + 3 * l, y0); cstore(p.yL + 3 * l + 1, y1); cstore(p.yL + 3 * l + 2, y2);   // read by the last block's fused step
@@ -3717,9 +3887,13 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
       }
     }
   }
+  TRACE(1);
+  TRACE(b < nLmBlocks ? 8 : (b < nLmBlocks + nFacBlocks ? 9 : 10));
   const double mine = blockSumK<kPostK>(acc, red, 8);
+  TRACE(11);
   if (t < kPostK) cstore(p.partial + (size_t)kPostSlot[t] * kMaxPartials + b, mine);
   if (!lastBlockDoneLight(&p.tickets[TK_POST], &lastFlag)) return;   // partials, y_l and v_l are cstore()d
+  TRACE(2);
   // final reduction over the blocks, fixed order: thread k-strided per slot
 #pragma unroll
   for (int k = 0; k < kPostK; ++k) {
@@ -3729,6 +3903,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     acc[k] = s;
   }
   const double tot = blockSumK<kPostK>(acc, red, 8);
+  TRACE(3);
   __shared__ double grpB[8];
   if (t < kPostK) {
     double* dst = &p.scal->gHatSq;
@@ -3747,7 +3922,9 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     if (t == 0) { p.scal->doglegStepNorm = c.stepNorm; p.scal->jdSq = c.jdSq; p.scal->jdDotR = c.jdDotR; }
     double a2[2] = {0, 0};
     const int nBlkItems = p.nPose + p.nExt + p.nSb;
+    TRACE(4);
     for (int i = t; i < nBlkItems; i += blockDim.x) retractItem(p, i, c.cg, c.cn, a2);
+    TRACE(5);
     // landmarks: eight per thread per round with all loads issued before the first store (one memory latency per
     // round instead of one per landmark)
     constexpr int kPer = 8;
@@ -3778,10 +3955,12 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         }
       }
     }
+    TRACE(6);
     const double tt = blockSumK<2>(a2, red, -1);
     if (t == 0) p.scal->stepNormSq = tt;
     if (t == 1) p.scal->xNormSq = tt;
   }
+  TRACE(7);
 }
 
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius) {
@@ -3794,7 +3973,7 @@ void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadiu
 // final single-block reduction of the cost partials into SolverScalars (used when no later evaluation kernel
 // can take it over, see evaluateAll)
 __global__ __launch_bounds__(256) void k_reduce_cost(DeviceProblem p, int nA, int nB) {
-  __shared__ double red[4];
+  __shared__ double red[12];
   reduceCost(p, nA, nB, red);
 }
 
