@@ -193,26 +193,34 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
 
 // Tail of the cost evaluation (last block): everything it needs from memory is requested in ONE round trip -- the
 // two partial lists AND the other scalars of the record (written by earlier kernels) -- then one block sum; the record
-// is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 12 doubles.
-__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red) {
+// is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 24 doubles.
+// nDefer > 0: the reprojection blocks also took the landmark half of the fused step; their step / state norm partials are
+// added to the (block-only) sums k_post_solve left in the record.
+__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, int nDefer = 0) {
   const int t = threadIdx.x;
   constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
   static_assert(nD <= 64, "SolverScalars must fit one wave-wide store");
-  double s[2] = {0, 0};
+  double s[4] = {0, 0, 0, 0};
   for (int i = t; i < nA; i += blockDim.x) s[0] += cload(p.partial + (size_t)PS_COST_REPROJ * kMaxPartials + i);
   for (int i = t; i < nB; i += blockDim.x) s[1] += cload(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + i);
+  for (int i = t; i < nDefer; i += blockDim.x) {
+    s[2] += cload(p.partial + (size_t)PS_STEP * kMaxPartials + i);
+    s[3] += cload(p.partial + (size_t)PS_XNORM * kMaxPartials + i);
+  }
   double rec = (t < nD) ? cload(reinterpret_cast<const double*>(p.scal) + t) : 0.0;  // slot 3 = costPrior of this evaluation (cstore()d)
-  const double mine = blockSumK<2>(s, red, -1);
-  double* fields = red + 8;
-  if (t < 2) fields[t] = mine;
-  if (t == 3) fields[3] = (p.ownsCamera && p.priorM > 0) ? rec : 0.0;
+  const double mine = blockSumK<4>(s, red, -1);   // red[0..15]
+  double* fields = red + 16;
+  if (t < 4 && t != 3) fields[t == 2 ? 4 : t] = mine;
+  if (t == 3) { fields[5] = mine; fields[3] = (p.ownsCamera && p.priorM > 0) ? rec : 0.0; }
   __syncthreads();
   const double a = fields[0], bf = p.ownsCamera ? fields[1] : 0.0, pr = fields[3];
   if (t == 0) rec = a + bf + pr;
   if (t == 1) rec = a;
   if (t == 2) rec = bf;
   if (t == 3) rec = pr;
-  if (t < 4) reinterpret_cast<double*>(p.scal)[t] = rec;
+  if (nDefer > 0 && t == 4) rec += fields[4];   // stepNormSq
+  if (nDefer > 0 && t == 5) rec += fields[5];   // xNormSq
+  if (t < 4 || (nDefer > 0 && t < 6)) reinterpret_cast<double*>(p.scal)[t] = rec;
   if (p.mailbox) {
     // publish everything the host needs for its accept/reject decision: the scalars as ONE wave-wide store to the
     // pinned host page (25 serial stores + two system fences cost ~18 us of every iteration), then the sequence number
@@ -378,6 +386,16 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane,
 // One block of the reprojection evaluation: `block` is the block index within the evaluation (not necessarily
 // blockIdx.x: the fused evaluation kernel runs these next to the small-factor blocks), `smem` holds
 // (nPose + nExt) * 7 doubles + nCam camera models, `red` 4 doubles.
+// deferred landmark retraction (fused step): inputs of x_cand = x + (cg v_l - cn y_l) and where the results go
+struct LmDefer {
+  double cg, cn;
+  const double* vL;
+  const double* yL;
+  const int* lmPtr;
+  double* lmC;
+  double* stepPartial;
+  double* xPartial;
+};
 template <bool ROBUST, bool WITH_EXT>
 __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double* red, int N, int nPose, int nExt, int nCam,
                                                 const double* __restrict__ pose, const double* __restrict__ ext,
@@ -385,7 +403,8 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
                                                 const double* __restrict__ obsUv, const double* __restrict__ obsW,
                                                 const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
                                                 double* __restrict__ r, double* __restrict__ Jp, double* __restrict__ Jl,
-                                                double* __restrict__ Je, double* __restrict__ costPartial, size_t stride) {
+                                                double* __restrict__ Je, double* __restrict__ costPartial, size_t stride,
+                                                const LmDefer* df = nullptr) {
   double* sPose = smem;                      // nPose*7
   double* sExt = sPose + nPose * 7;          // nExt*7
   CameraModel* sCam = reinterpret_cast<CameraModel*>(sExt + nExt * 7);  // nCam
@@ -398,14 +417,31 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
   }
   __syncthreads();
   const int i = block * blockDim.x + threadIdx.x;
-  double cost = 0;
+  double cost = 0, stepSq = 0, xSq = 0;
   if (i < N) {
     const uint32_t idx = obsIdx[i];
     const int ps = idx & 0xfff, es = (idx >> 12) & 0xfff, cs = (idx >> 24) & 0xf;
     const double2 uv = reinterpret_cast<const double2*>(obsUv)[i];
     const double w = obsW[i];
-    const double4 hp = reinterpret_cast<const double4*>(lm)[obsLm[i]];
-    const double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
+    const int lmi = obsLm[i];
+    const double4 hp = reinterpret_cast<const double4*>(lm)[lmi];
+    double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
+    if (df) {
+      // the landmark half of the fused step (k_post_solve left it to this kernel): x_cand = x + (cg v_l - cn y_l), the
+      // same arithmetic as retractItem; the lane holding the landmark's first observation stores it and counts the norms
+      double xo[4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xo[k] = hpw[k] + (df->cg * df->vL[3 * lmi + k] - df->cn * df->yL[3 * lmi + k]);
+      xo[3] = hpw[3] + 0.0;
+      if (df->lmPtr[lmi] == i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { stepSq += (hpw[k] - xo[k]) * (hpw[k] - xo[k]); xSq += hpw[k] * hpw[k]; }
+        xSq += hpw[3] * hpw[3];
+        reinterpret_cast<double4*>(df->lmC)[lmi] = double4{xo[0], xo[1], xo[2], xo[3]};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hpw[k] = xo[k];
+    }
     double rr[2], jp[12], jl[6], je[12];
     reprojEval(sCam[cs], sPose + ps * 7, hpw, sExt + es * 7, uv.x, uv.y, w, rr, jp, jl, je);
     const double s = rr[0] * rr[0] + rr[1] * rr[1];
@@ -439,8 +475,16 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
     }
   }
   if (costPartial) {
-    const double bs = blockSum(cost, red);
-    if (threadIdx.x == 0) cstore(costPartial + block, bs);
+    if (df) {  // red: >= 12 doubles
+      const double v3[3] = {cost, stepSq, xSq};
+      const double mine = blockSumK<3>(v3, red, -1);
+      if (threadIdx.x == 0) cstore(costPartial + block, mine);
+      if (threadIdx.x == 1) cstore(df->stepPartial + block, mine);
+      if (threadIdx.x == 2) cstore(df->xPartial + block, mine);
+    } else {
+      const double bs = blockSum(cost, red);
+      if (threadIdx.x == 0) cstore(costPartial + block, bs);
+    }
   }
 }
 
@@ -535,6 +579,41 @@ __device__ __forceinline__ void rightJacobianDev(double x, double y, double z, d
 #pragma unroll
   for (int i = 0; i < 9; ++i) J[i] = a * X[i] + b * X2[i];
   J[0] += 1; J[4] += 1; J[8] += 1;
+}
+// Quaternion exponential on the device (retraction, IMU bias correction): sin(h)/h and cos(h) from their Taylor series for the
+// half-angles a trust-region step produces (h^2 < 1/4: truncation below 1e-21), the library functions beyond.  The
+// library versions cost several hundred instructions each, and this sits on the serial tail of every iteration.
+__device__ __forceinline__ Quat deltaQDev(double ax, double ay, double az) {
+  const double h2 = 0.25 * (ax * ax + ay * ay + az * az);
+  double sc, c;
+  if (h2 < 0.25) {
+    sc = -1.0 / 121645100408832000.0;  // 1/19!
+    sc = __builtin_fma(sc, h2, 1.0 / 355687428096000.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 1307674368000.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 6227020800.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 39916800.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 362880.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 5040.0);
+    sc = __builtin_fma(sc, h2, 1.0 / 120.0);
+    sc = __builtin_fma(sc, h2, -1.0 / 6.0);
+    sc = __builtin_fma(sc, h2, 1.0);
+    c = -1.0 / 6402373705728000.0;  // 1/18!
+    c = __builtin_fma(c, h2, 1.0 / 20922789888000.0);
+    c = __builtin_fma(c, h2, -1.0 / 87178291200.0);
+    c = __builtin_fma(c, h2, 1.0 / 479001600.0);
+    c = __builtin_fma(c, h2, -1.0 / 3628800.0);
+    c = __builtin_fma(c, h2, 1.0 / 40320.0);
+    c = __builtin_fma(c, h2, -1.0 / 720.0);
+    c = __builtin_fma(c, h2, 1.0 / 24.0);
+    c = __builtin_fma(c, h2, -0.5);
+    c = __builtin_fma(c, h2, 1.0);
+  } else {
+    const double h = sqrt(h2);
+    sc = sin(h) / h;
+    c = cos(h);
+  }
+  const double s = 0.5 * sc;
+  return Quat{s * ax, s * ay, s * az, c};
 }
 __device__ __forceinline__ void quatPlusMat3(const Quat& q, double* Q) {  // top-left 3x3 of plus(q)
   Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.z; Q[4] = q.w; Q[5] = -q.x; Q[6] = -q.y; Q[7] = q.x; Q[8] = q.w;
@@ -1172,9 +1251,16 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
   const int m = fac.m;
   if (t == 0) sh.flag = 0;
   for (int i = t; i < 15 * 30; i += blockDim.x) sh.F[i] = 0;
-  __syncthreads();
   int ncols = 0;
   for (int b = 0; b < fac.nblk; ++b) ncols += (fac.blkKind[b] == B_SB) ? 9 : 6;
+  // the block table of the linearisation record: four threads of a wave that has nothing else to do (one dependent
+  // load each, off the critical path; thread 0 doing it cost four serial memory round trips per evaluation)
+  if (t >= 192 && t < 196) {
+    const int b = t - 192;
+    if (b < fac.nblk) { lin.off[b] = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); lin.dim[b] = (fac.blkKind[b] == B_SB) ? 9 : 6; }
+    else { lin.off[b] = -1; lin.dim[b] = 0; }
+  }
+  if (t == 196) { lin.m = m; lin.ncols = ncols; }
 
   IMU_TICK(qe0);
   if (fac.kind == F_IMU) {
@@ -1183,36 +1269,51 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
     const double* s0 = blockPtr(p, cand, fac.blkKind[1], fac.blkSlot[1]);
     const double* x1 = blockPtr(p, cand, fac.blkKind[2], fac.blkSlot[2]);
     const double* s1 = blockPtr(p, cand, fac.blkKind[3], fac.blkSlot[3]);
-    const double Delta_t = dtSecDev(im.t1, im.t0);
-    double Db[6];
-    for (int k = 0; k < 6; ++k) Db[k] = s0[3 + k] - im.sb_ref[3 + k];
-    // ImuError.cpp:739: redo_ || |Delta_b_g| * Delta_t > 1e-4   (uniform across the workgroup)
-    const bool redo = im.redo || (sqrt(Db[0] * Db[0] + Db[1] * Db[1] + Db[2] * Db[2]) * Delta_t > 0.0001);
-    __syncthreads();
-    if (redo) {
-      double sbl[9];
-      for (int k = 0; k < 9; ++k) sbl[k] = s0[k];
-      imuRedoPreintegration(im, p.imuT, p.imuMeas, sbl, sh);
-      if (t == 0) { im.redo = 0; im.redoCounter++; }
-      for (int k = 0; k < 6; ++k) Db[k] = 0;
-      __syncthreads();
-    }
-    if (t < 225) sh.W[t] = im.sqrtInfo[t];
-    // stage the small state + parameters through LDS: one round trip instead of ~100 dependent loads in thread 0
-    if (t < 56) sh.st[t] = (&im.Delta_t)[t];
+    // ONE memory round trip for everything the block needs -- parameter blocks, pre-integration state, weights and
+    // the inputs of the redo test (the state / weights are re-staged if the test fires)
+    auto stage = [&]() {
+      if (t < 225) sh.W[t] = im.sqrtInfo[t];
+      if (t < 56) sh.st[t] = (&im.Delta_t)[t];
+    };
+    stage();
     if (t >= 64 && t < 71) sh.xs[t - 64] = x0[t - 64];
     if (t >= 71 && t < 80) sh.xs[7 + t - 71] = s0[t - 71];
     if (t >= 80 && t < 87) sh.xs[16 + t - 80] = x1[t - 80];
     if (t >= 87 && t < 96) sh.xs[23 + t - 87] = s1[t - 87];
+    if (t >= 96 && t < 102) sh.st[56 + t - 96] = im.sb_ref[3 + t - 96];
+    if (t == 102) sh.st[62] = (double)im.redo;
+    if (t == 103) sh.st[63] = dtSecDev(im.t1, im.t0);
+    if (t == 104) sh.st[64] = im.par.g;
     __syncthreads();
+    const double Delta_t = sh.st[63];
+    double Db[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Db[k] = sh.xs[7 + 3 + k] - sh.st[56 + k];
+    // ImuError.cpp:739: redo_ || |Delta_b_g| * Delta_t > 1e-4   (uniform across the workgroup)
+    const bool redo = sh.st[62] != 0.0 || (sqrt(Db[0] * Db[0] + Db[1] * Db[1] + Db[2] * Db[2]) * Delta_t > 0.0001);
+    if (redo) {
+      double sbl[9];
+      for (int k = 0; k < 9; ++k) sbl[k] = sh.xs[7 + k];
+      __syncthreads();
+      imuRedoPreintegration(im, p.imuT, p.imuMeas, sbl, sh);
+      if (t == 0) { im.redo = 0; im.redoCounter++; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Db[k] = 0;
+      __syncthreads();
+      stage();
+      __syncthreads();
+    }
     IMU_TICK(qe1);
     IMU_ACC(8, qe0, qe1, t == 0 && !redo);
-    if (t == 0) {
-      // ImuError.cpp:751-791
-      const double* x0 = sh.xs;
-      const double* s0 = sh.xs + 7;
-      const double* x1 = sh.xs + 16;
-      const double* s1 = sh.xs + 23;
+    // ImuError.cpp:751-791.  The un-weighted Jacobian F = [F0 | F1] (15 x 30, columns pose0(6) sb0(9) pose1(6) sb1(9);
+    // sh.F was zeroed above) and the error are built by the first lane of each of the four waves side by side: every
+    // one derives the few shared quantities itself (a sync would cost more) and then fills its share of the blocks.
+    if ((t & 63) == 0) {
+      const int part = t >> 6;
+      const double* xs0 = sh.xs;
+      const double* ss0 = sh.xs + 7;
+      const double* xs1 = sh.xs + 16;
+      const double* ss1 = sh.xs + 23;
       const double* imDelta_q = sh.st + 1;
       const double* imC_integral = sh.st + 5;
       const double* imC_doubleintegral = sh.st + 14;
@@ -1221,153 +1322,186 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
       const double* imdalpha_db_g = sh.st + 29;
       const double* imdv_db_g = sh.st + 38;
       const double* imdp_db_g = sh.st + 47;
-      const TF T0 = makeTF(x0), T1 = makeTF(x1);
-      const double gz = im.par.g * (6371009.0 / sqrt(6371009.0 * 6371009.0));
-      const double gW[3] = {im.par.g * 0.0, im.par.g * 0.0, gz};
-      double dpv[3], dvv[3];
-      for (int k = 0; k < 3; ++k) {
-        dpv[k] = T0.r[k] - T1.r[k] + s0[k] * Delta_t - 0.5 * gW[k] * Delta_t * Delta_t;
-        dvv[k] = s0[k] - s1[k] - gW[k] * Delta_t;
-      }
-      // F = [F0 | F1] (15 x 30, columns pose0(6) sb0(9) pose1(6) sb1(9)) is written straight into LDS
-      // (sh.F was zeroed by the whole workgroup above); F0 / F1 are views with leading dimension 30
       double* F0 = sh.F;
       double* F1 = sh.F + 15;
-      for (int k = 0; k < 15; ++k) { F0[k * 31] = 1.0; F1[k * 31] = -1.0; }
-      // C_S0_W = C_WS_0^T
-      double Ct[9];
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Ct[a * 3 + b] = T0.C.m[b * 3 + a];
+      auto setB = [](double* F, int r0, int c0, const double* B, double s) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) F[(r0 + a) * 30 + c0 + b] = s * B[a * 3 + b];
+      };
+      const double n0 = 1.0 / sqrt(xs0[3] * xs0[3] + xs0[4] * xs0[4] + xs0[5] * xs0[5] + xs0[6] * xs0[6]);
+      const Quat q0 = {xs0[3] * n0, xs0[4] * n0, xs0[5] * n0, xs0[6] * n0};
+      const double n1 = 1.0 / sqrt(xs1[3] * xs1[3] + xs1[4] * xs1[4] + xs1[5] * xs1[5] + xs1[6] * xs1[6]);
+      const Quat q1inv = {-xs1[3] * n1, -xs1[4] * n1, -xs1[5] * n1, xs1[6] * n1};  // inverse of the normalised q1
       const double a3[3] = {-(imdalpha_db_g[0] * Db[0] + imdalpha_db_g[1] * Db[1] + imdalpha_db_g[2] * Db[2]),
                             -(imdalpha_db_g[3] * Db[0] + imdalpha_db_g[4] * Db[1] + imdalpha_db_g[5] * Db[2]),
                             -(imdalpha_db_g[6] * Db[0] + imdalpha_db_g[7] * Db[1] + imdalpha_db_g[8] * Db[2])};
-      const Quat Dq = qmul(deltaQ(a3[0], a3[1], a3[2]), Quat{imDelta_q[0], imDelta_q[1], imDelta_q[2], imDelta_q[3]});
-      auto setB = [](double* F, int r0, int c0, const double* B, double s) {
+      const Quat Dq = qmul(deltaQDev(a3[0], a3[1], a3[2]), Quat{imDelta_q[0], imDelta_q[1], imDelta_q[2], imDelta_q[3]});
+      IMU_TICK(qeb);
+      IMU_ACC(12, qe1, qeb, !redo && part == 0);
+      if (part == 0) {
+        // position / velocity rows: everything that carries C_S0_W = C_WS_0^T, and the error vector
+        const Mat3 C0 = quatToR(q0);
+        double Ct[9];
+#pragma unroll
         for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) F[(r0 + a) * 30 + c0 + b] = s * B[a * 3 + b];
-      };
-      double X[9], T9[9];
-      setB(F0, 0, 0, Ct, 1.0);
-      crossMxDev(dpv[0], dpv[1], dpv[2], X); mm3(Ct, X, T9); setB(F0, 0, 3, T9, 1.0);
-      setB(F0, 0, 6, Ct, Delta_t);
-      setB(F0, 0, 9, imdp_db_g, 1.0);
-      setB(F0, 0, 12, imC_doubleintegral, -1.0);
-      const Quat q1inv = qinv(T1.q);
-      double Qp[16], Qo[16], Q44[16];
-      quatPlusMat4(qmul(Dq, q1inv), Qp);
-      quatOplusMat4(T0.q, Qo);
-      mm4(Qp, Qo, Q44);
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) F0[(3 + a) * 30 + 3 + b] = Q44[a * 4 + b];
-      double Qo1[16], Qo2[16];
-      quatOplusMat4(qmul(q1inv, T0.q), Qo1);
-      quatOplusMat4(Dq, Qo2);
-      mm4(Qo1, Qo2, Q44);
-      double TL[9], nd[9];
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) { TL[a * 3 + b] = Q44[a * 4 + b]; nd[a * 3 + b] = -imdalpha_db_g[a * 3 + b]; }
-      mm3(TL, nd, T9);
-      setB(F0, 3, 9, T9, 1.0);
-      crossMxDev(dvv[0], dvv[1], dvv[2], X); mm3(Ct, X, T9); setB(F0, 6, 3, T9, 1.0);
-      setB(F0, 6, 6, Ct, 1.0);
-      setB(F0, 6, 9, imdv_db_g, 1.0);
-      setB(F0, 6, 12, imC_integral, -1.0);
-      setB(F1, 0, 0, Ct, -1.0);
-      double Qp2[16], Qp3[16], Qt[16];
-      quatPlusMat4(Dq, Qp2);
-      quatPlusMat4(q1inv, Qp3);
-      mm4(Qp2, Qo, Qt);
-      mm4(Qt, Qp3, Q44);
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) F1[(3 + a) * 30 + 3 + b] = -Q44[a * 4 + b];
-      setB(F1, 6, 6, Ct, -1.0);
-      // error
-      const Vec3 v1 = rotate(Mat3{{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}}, Vec3{dpv[0], dpv[1], dpv[2]});
-      const Vec3 v2 = rotate(Mat3{{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}}, Vec3{dvv[0], dvv[1], dvv[2]});
-      const double v1a[3] = {v1.x, v1.y, v1.z}, v2a[3] = {v2.x, v2.y, v2.z};
-      for (int a = 0; a < 3; ++a) {
-        double s1 = 0, s2 = 0;
-        for (int k = 0; k < 6; ++k) { s1 += F0[a * 30 + 9 + k] * Db[k]; s2 += F0[(6 + a) * 30 + 9 + k] * Db[k]; }
-        sh.e[a] = v1a[a] + imacc_doubleintegral[a] + s1;
-        sh.e[6 + a] = v2a[a] + imacc_integral[a] + s2;
-      }
-      const Quat qd = qmul(Dq, qmul(q1inv, T0.q));
-      sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
-      for (int k = 0; k < 6; ++k) sh.e[9 + k] = s0[3 + k] - s1[3 + k];
-      IMU_TICK(qe2);
-      IMU_ACC(9, qe1, qe2, !redo);
-      IMU_ACC(11, qe1, qe1 + 1, !redo);
-    }
-  } else if (t == 0) {
-    for (int k = 0; k < m * m; ++k) sh.W[k] = fac.sqrtInfo[k];
-    const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
-    if (fac.kind == F_POSE_PRIOR) {  // PoseError.cpp:87-132
-      const TF Tm = makeTF(fac.meas), Tx = makeTF(x0);
-      const Quat dq = qnormalized(qmul(Tm.q, qnormalized(qinv(Tx.q))));
-      for (int k = 0; k < 3; ++k) sh.e[k] = Tm.r[k] - Tx.r[k];
-      sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
-      double Q[9];
-      quatPlusMat3(dq, Q);
-      for (int a = 0; a < 3; ++a) {
-        sh.F[a * 6 + a] = -1.0;
-        for (int b = 0; b < 3; ++b) sh.F[(3 + a) * 6 + 3 + b] = -Q[a * 3 + b];
-      }
-    } else if (fac.kind == F_SB_PRIOR) {  // SpeedAndBiasError.cpp:83-113
-      for (int k = 0; k < 9; ++k) { sh.e[k] = fac.meas[k] - x0[k]; sh.F[k * 9 + k] = -1.0; }
-    } else if (fac.kind == F_RELPOSE) {  // RelativePoseError.cpp:79-147
-      const double* x1 = blockPtr(p, cand, fac.blkKind[1], fac.blkSlot[1]);
-      const TF T0 = makeTF(x0), T1 = makeTF(x1);
-      const Quat dq = qnormalized(qmul(T1.q, qnormalized(qinv(T0.q))));
-      for (int k = 0; k < 3; ++k) sh.e[k] = T1.r[k] - T0.r[k];
-      sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
-      double Q[9], Qo[9];
-      quatPlusMat3(dq, Q);
-      quatOplusMat3(dq, Qo);
-      for (int a = 0; a < 3; ++a) {
-        sh.F[a * 12 + a] = -1.0;
-        sh.F[a * 12 + 6 + a] = 1.0;
-        for (int b = 0; b < 3; ++b) {
-          sh.F[(3 + a) * 12 + 3 + b] = -Q[a * 3 + b];
-          sh.F[(3 + a) * 12 + 6 + 3 + b] = Qo[a * 3 + b];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) Ct[a * 3 + b] = C0.m[b * 3 + a];
+        const double gpar = sh.st[64];
+        const double gz = gpar * (6371009.0 / sqrt(6371009.0 * 6371009.0));
+        const double gW[3] = {gpar * 0.0, gpar * 0.0, gz};
+        double dpv[3], dvv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dpv[k] = xs0[k] - xs1[k] + ss0[k] * Delta_t - 0.5 * gW[k] * Delta_t * Delta_t;
+          dvv[k] = ss0[k] - ss1[k] - gW[k] * Delta_t;
         }
+        double X[9], T9[9];
+        setB(F0, 0, 0, Ct, 1.0);
+        crossMxDev(dpv[0], dpv[1], dpv[2], X); mm3(Ct, X, T9); setB(F0, 0, 3, T9, 1.0);
+        setB(F0, 0, 6, Ct, Delta_t);
+        crossMxDev(dvv[0], dvv[1], dvv[2], X); mm3(Ct, X, T9); setB(F0, 6, 3, T9, 1.0);
+        setB(F0, 6, 6, Ct, 1.0);
+        setB(F1, 0, 0, Ct, -1.0);
+        setB(F1, 6, 6, Ct, -1.0);
+        IMU_TICK(qec);
+        IMU_ACC(13, qeb, qec, !redo);
+        const Mat3 CtM = {{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}};
+        const Vec3 v1 = rotate(CtM, Vec3{dpv[0], dpv[1], dpv[2]});
+        const Vec3 v2 = rotate(CtM, Vec3{dvv[0], dvv[1], dvv[2]});
+        const double v1a[3] = {v1.x, v1.y, v1.z}, v2a[3] = {v2.x, v2.y, v2.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          // bias columns of the position / velocity rows: [dp_db_g | -C_doubleintegral], [dv_db_g | -C_integral]
+          double s1 = 0, s2 = 0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            s1 += imdp_db_g[a * 3 + k] * Db[k] - imC_doubleintegral[a * 3 + k] * Db[3 + k];
+            s2 += imdv_db_g[a * 3 + k] * Db[k] - imC_integral[a * 3 + k] * Db[3 + k];
+          }
+          sh.e[a] = v1a[a] + imacc_doubleintegral[a] + s1;
+          sh.e[6 + a] = v2a[a] + imacc_integral[a] + s2;
+        }
+        const Quat qd = qmul(Dq, qmul(q1inv, q0));
+        sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sh.e[9 + k] = ss0[3 + k] - ss1[3 + k];
+      } else if (part == 1) {
+        // d e_q / d alpha_0 = [plus(Dq q1^-1) oplus(q0)]_3x3, the identity diagonals, the pre-integral bias blocks
+#pragma unroll
+        for (int k = 9; k < 15; ++k) { F0[k * 31] = 1.0; F1[k * 31] = -1.0; }  // bias rows (the other diagonal blocks are written whole)
+        double Qp[16], Qo[16], Q44[16];
+        quatPlusMat4(qmul(Dq, q1inv), Qp);
+        quatOplusMat4(q0, Qo);
+        mm4(Qp, Qo, Q44);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) F0[(3 + a) * 30 + 3 + b] = Q44[a * 4 + b];
+        setB(F0, 0, 9, imdp_db_g, 1.0);
+        setB(F0, 0, 12, imC_doubleintegral, -1.0);
+        setB(F0, 6, 9, imdv_db_g, 1.0);
+        setB(F0, 6, 12, imC_integral, -1.0);
+      } else if (part == 2) {
+        // d e_q / d b_g = [oplus(q1^-1 q0) oplus(Dq)]_3x3 (-dalpha_db_g)
+        double Qo1[16], Qo2[16], Q44[16];
+        quatOplusMat4(qmul(q1inv, q0), Qo1);
+        quatOplusMat4(Dq, Qo2);
+        mm4(Qo1, Qo2, Q44);
+        double TL[9], nd[9], T9[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) { TL[a * 3 + b] = Q44[a * 4 + b]; nd[a * 3 + b] = -imdalpha_db_g[a * 3 + b]; }
+        mm3(TL, nd, T9);
+        setB(F0, 3, 9, T9, 1.0);
+      } else {
+        // d e_q / d alpha_1 = -[plus(Dq) oplus(q0) plus(q1^-1)]_3x3
+        double Qo[16], Qp2[16], Qp3[16], Qt[16], Q44[16];
+        quatOplusMat4(q0, Qo);
+        quatPlusMat4(Dq, Qp2);
+        quatPlusMat4(q1inv, Qp3);
+        mm4(Qp2, Qo, Qt);
+        mm4(Qt, Qp3, Q44);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) F1[(3 + a) * 30 + 3 + b] = -Q44[a * 4 + b];
       }
-    } else if (fac.kind == F_SONAR) {  // SonarError.cpp:118-183 (reference sign/anchor quirks kept)
-      const TF Tx = makeTF(x0);
-      const double range = fac.meas[0], heading = fac.meas[1];
-      const double d[3] = {Tx.r[0] - fac.meas[2], Tx.r[1] - fac.meas[3], Tx.r[2] - fac.meas[4]};
-      sh.e[0] = range - sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-      const TF Tso = makeTF(fac.aux);
-      // T_WSo = T_WS * T_SSo ; point = T_WSo * (range cos h, range sin h, 0)
-      const Vec3 rso = rotate(Tx.C, Vec3{Tso.r[0], Tso.r[1], Tso.r[2]});
-      const Quat qwso = qnormalized(qmul(Tx.q, Tso.q));
-      const Mat3 Cwso = quatToR(qwso);
-      const Vec3 pp = rotate(Cwso, Vec3{range * cos(heading), range * sin(heading), 0.0});
-      const double sp[3] = {pp.x + rso.x + Tx.r[0], pp.y + rso.y + Tx.r[1], pp.z + rso.z + Tx.r[2]};
-      for (int a = 0; a < 3; ++a) sh.F[a] = (Tx.r[a] - sp[a]) / range;
-    } else if (fac.kind == F_DEPTH) {  // DepthError.cpp:75-139
-      sh.e[0] = x0[2] - (-1 * fac.meas[0] + fac.meas[1]);
-      sh.F[2] = 1.0;
+      IMU_TICK(qe2);
+      IMU_ACC(9, qe1, qe2, !redo && part == 0);
+      IMU_ACC(11, qe1, qe1 + 1, !redo && part == 0);
+    }
+  } else {
+    for (int k = t; k < m * m; k += blockDim.x) sh.W[k] = fac.sqrtInfo[k];
+    if (t == 0) {
+      const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
+      if (fac.kind == F_POSE_PRIOR) {  // PoseError.cpp:87-132
+        const TF Tm = makeTF(fac.meas), Tx = makeTF(x0);
+        const Quat dq = qnormalized(qmul(Tm.q, qnormalized(qinv(Tx.q))));
+        for (int k = 0; k < 3; ++k) sh.e[k] = Tm.r[k] - Tx.r[k];
+        sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
+        double Q[9];
+        quatPlusMat3(dq, Q);
+        for (int a = 0; a < 3; ++a) {
+          sh.F[a * 6 + a] = -1.0;
+          for (int b = 0; b < 3; ++b) sh.F[(3 + a) * 6 + 3 + b] = -Q[a * 3 + b];
+        }
+      } else if (fac.kind == F_SB_PRIOR) {  // SpeedAndBiasError.cpp:83-113
+        for (int k = 0; k < 9; ++k) { sh.e[k] = fac.meas[k] - x0[k]; sh.F[k * 9 + k] = -1.0; }
+      } else if (fac.kind == F_RELPOSE) {  // RelativePoseError.cpp:79-147
+        const double* x1 = blockPtr(p, cand, fac.blkKind[1], fac.blkSlot[1]);
+        const TF T0 = makeTF(x0), T1 = makeTF(x1);
+        const Quat dq = qnormalized(qmul(T1.q, qnormalized(qinv(T0.q))));
+        for (int k = 0; k < 3; ++k) sh.e[k] = T1.r[k] - T0.r[k];
+        sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
+        double Q[9], Qo[9];
+        quatPlusMat3(dq, Q);
+        quatOplusMat3(dq, Qo);
+        for (int a = 0; a < 3; ++a) {
+          sh.F[a * 12 + a] = -1.0;
+          sh.F[a * 12 + 6 + a] = 1.0;
+          for (int b = 0; b < 3; ++b) {
+            sh.F[(3 + a) * 12 + 3 + b] = -Q[a * 3 + b];
+            sh.F[(3 + a) * 12 + 6 + 3 + b] = Qo[a * 3 + b];
+          }
+        }
+      } else if (fac.kind == F_SONAR) {  // SonarError.cpp:118-183 (reference sign/anchor quirks kept)
+        const TF Tx = makeTF(x0);
+        const double range = fac.meas[0], heading = fac.meas[1];
+        const double d[3] = {Tx.r[0] - fac.meas[2], Tx.r[1] - fac.meas[3], Tx.r[2] - fac.meas[4]};
+        sh.e[0] = range - sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const TF Tso = makeTF(fac.aux);
+        // T_WSo = T_WS * T_SSo ; point = T_WSo * (range cos h, range sin h, 0)
+        const Vec3 rso = rotate(Tx.C, Vec3{Tso.r[0], Tso.r[1], Tso.r[2]});
+        const Quat qwso = qnormalized(qmul(Tx.q, Tso.q));
+        const Mat3 Cwso = quatToR(qwso);
+        const Vec3 pp = rotate(Cwso, Vec3{range * cos(heading), range * sin(heading), 0.0});
+        const double sp[3] = {pp.x + rso.x + Tx.r[0], pp.y + rso.y + Tx.r[1], pp.z + rso.z + Tx.r[2]};
+        for (int a = 0; a < 3; ++a) sh.F[a] = (Tx.r[a] - sp[a]) / range;
+      } else if (fac.kind == F_DEPTH) {  // DepthError.cpp:75-139
+        sh.e[0] = x0[2] - (-1 * fac.meas[0] + fac.meas[1]);
+        sh.F[2] = 1.0;
+      }
     }
   }
   __syncthreads();
-  // r = W e ; J = W F
-  for (int a = t; a < m; a += blockDim.x) {
-    double s = 0;
-    for (int k = 0; k < m; ++k) s += sh.W[a * m + k] * sh.e[k];
-    lin.r[a] = s;
-    sh.rw[a] = s;
-  }
-  for (int idx = t; idx < m * ncols; idx += blockDim.x) {
-    const int a = idx / ncols, c = idx % ncols;
-    double s = 0;
-    for (int k = 0; k < m; ++k) s += sh.W[a * m + k] * sh.F[k * ncols + c];
-    lin.J[a * ncols + c] = s;
-  }
-  if (t == 0) {
-    lin.m = m; lin.ncols = ncols;
-    for (int b = 0; b < 4; ++b) {
-      if (b < fac.nblk) { lin.off[b] = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); lin.dim[b] = (fac.blkKind[b] == B_SB) ? 9 : 6; }
-      else { lin.off[b] = -1; lin.dim[b] = 0; }
+  // r = W e ; J = W F.  Thread (a = t & 15, c = t >> 4, + 16): row a, columns c and c + 16 -- no integer division
+  {
+    const int a = t & 15, c0 = t >> 4;
+    if (a < m) {
+      if (c0 == 0) {
+        double sr = 0;
+        for (int k = 0; k < m; ++k) sr += sh.W[a * m + k] * sh.e[k];
+        lin.r[a] = sr;
+        sh.rw[a] = sr;
+      }
+      for (int c = c0; c < ncols; c += 16) {
+        double sj = 0;
+        for (int k = 0; k < m; ++k) sj += sh.W[a * m + k] * sh.F[k * ncols + c];
+        lin.J[a * ncols + c] = sj;
+      }
     }
   }
   __syncthreads();
@@ -1389,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_eval_factors(DeviceProblem p, int cand,
   if (costBlocksA >= 0) {
     __shared__ int lastFlag;
     if (lastBlockDone(&p.tickets[TK_EVAL], &lastFlag)) {
-      reduceCost(p, costBlocksA, (int)gridDim.x, sh.rw);
+      reduceCost(p, costBlocksA, (int)gridDim.x, sh.P);
       if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
     }
   }
@@ -1458,7 +1592,7 @@ __device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
   if (t == 0) cstore(&p.scal->costPrior, 0.5 * (*p.priorC0) + tot);
 }
 __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
-  __shared__ double red[12];
+  __shared__ double red[24];
   priorEvalBlock(p, cand, red);
   if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
     __syncthreads();
@@ -1489,18 +1623,27 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
     priorEvalBlock(p, cand, reinterpret_cast<double*>(&sh));
   } else {
     double* smem = reinterpret_cast<double*>(&sh);  // poses / extrinsics / cameras staged in the same LDS
-    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 8, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
-                                    cand ? p.extC : p.ext, cand ? p.lmC : p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
+    const bool defer = cand && p.lmDeferred;
+    LmDefer df;
+    if (defer) {
+      df.cg = p.scal->spareA0; df.cn = p.scal->spareA1;   // the dogleg coefficients of the fused step (k_post_solve)
+      df.vL = p.vL; df.yL = p.yL; df.lmPtr = p.lmPtr; df.lmC = p.lmC;
+      df.stepPartial = p.partial + (size_t)PS_STEP * kMaxPartials;
+      df.xPartial = p.partial + (size_t)PS_XNORM * kMaxPartials;
+    }
+    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 16, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
+                                    cand ? p.extC : p.ext, defer ? p.lm : (cand ? p.lmC : p.lm), p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
                                     cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
-                                    cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N);
+                                    cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N,
+                                    defer ? &df : nullptr);
   }
   TRACE(18);
   if (sumCost) {
     __shared__ int lastFlag;
-    __shared__ double red4[12];
+    __shared__ double red4[24];
     if (lastBlockDoneLight(&p.tickets[TK_EVAL], &lastFlag)) {   // (cost partials and costPrior are cstore()d)
       TRACE(19);
-      reduceCost(p, nR, F, red4);
+      reduceCost(p, nR, F, red4, (cand && p.lmDeferred) ? nR : 0);
       if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
       TRACE(20);
     }
@@ -3560,41 +3703,6 @@ __device__ __forceinline__ DoglegCoeff doglegCoefficients(double gHatSq, double 
   return c;
 }
 // candidate = x [+] delta for item i (variable blocks first, then landmarks); acc += |x - x_cand|^2, |x|^2
-// Quaternion exponential of the retraction on the device: sin(h)/h and cos(h) from their Taylor series for the
-// half-angles a trust-region step produces (h^2 < 1/4: truncation below 1e-21), the library functions beyond.  The
-// library versions cost several hundred instructions each, and this sits on the serial tail of every iteration.
-__device__ __forceinline__ Quat deltaQDev(double ax, double ay, double az) {
-  const double h2 = 0.25 * (ax * ax + ay * ay + az * az);
-  double sc, c;
-  if (h2 < 0.25) {
-    sc = -1.0 / 121645100408832000.0;  // 1/19!
-    sc = __builtin_fma(sc, h2, 1.0 / 355687428096000.0);
-    sc = __builtin_fma(sc, h2, -1.0 / 1307674368000.0);
-    sc = __builtin_fma(sc, h2, 1.0 / 6227020800.0);
-    sc = __builtin_fma(sc, h2, -1.0 / 39916800.0);
-    sc = __builtin_fma(sc, h2, 1.0 / 362880.0);
-    sc = __builtin_fma(sc, h2, -1.0 / 5040.0);
-    sc = __builtin_fma(sc, h2, 1.0 / 120.0);
-    sc = __builtin_fma(sc, h2, -1.0 / 6.0);
-    sc = __builtin_fma(sc, h2, 1.0);
-    c = -1.0 / 6402373705728000.0;  // 1/18!
-    c = __builtin_fma(c, h2, 1.0 / 20922789888000.0);
-    c = __builtin_fma(c, h2, -1.0 / 87178291200.0);
-    c = __builtin_fma(c, h2, 1.0 / 479001600.0);
-    c = __builtin_fma(c, h2, -1.0 / 3628800.0);
-    c = __builtin_fma(c, h2, 1.0 / 40320.0);
-    c = __builtin_fma(c, h2, -1.0 / 720.0);
-    c = __builtin_fma(c, h2, 1.0 / 24.0);
-    c = __builtin_fma(c, h2, -0.5);
-    c = __builtin_fma(c, h2, 1.0);
-  } else {
-    const double h = sqrt(h2);
-    sc = sin(h) / h;
-    c = cos(h);
-  }
-  const double s = 0.5 * sc;
-  return Quat{s * ax, s * ay, s * az, c};
-}
 // poseOplus (dmath.hpp) with the device exponential and one reciprocal per normalisation
 __device__ __forceinline__ void poseOplusDev(const double* x, const double* delta, double* xo) {
   xo[0] = x[0] + delta[0]; xo[1] = x[1] + delta[1]; xo[2] = x[2] + delta[2];
@@ -3607,51 +3715,51 @@ __device__ __forceinline__ void poseOplusDev(const double* x, const double* delt
 // One item of the retraction x_cand = x [+] (cg v - cn y).  Everything is loaded before the first store: the candidate
 // arrays may alias the inputs as far as the compiler knows, and a store between two loads turns them into serial
 // memory round trips (9 us for the 22 blocks of a 10-keyframe window before this was written this way).
+// value-level retraction of one parameter block (7 doubles for a pose / extrinsics block, 9 for speed and biases)
+__device__ __forceinline__ void retractBlockValues(bool isSb, bool has, bool count, const double* x, const double* v, const double* y,
+                                                   double cg, double cn, double* xo, double* acc) {
+  if (!isSb) {
+    if (has) {
+      double dl[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dl[k] = cg * v[k] - cn * y[k];
+      poseOplusDev(x, dl, xo);
+      if (count) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) xo[k] = x[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      xo[k] = has ? x[k] + (cg * v[k] - cn * y[k]) : x[k];
+      if (has && count) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
+    }
+  }
+}
 __device__ __forceinline__ void retractItem(const DeviceProblem& p, int i, double cg, double cn, double* acc) {
   const int nBlk = p.nPose + p.nExt + p.nSb;
   if (i < nBlk) {
-    if (i < p.nPose + p.nExt) {
-      const bool isPose = i < p.nPose;
-      const int slot = isPose ? i : i - p.nPose;
-      const double* xp = (isPose ? p.pose : p.ext) + (size_t)slot * 7;
-      double* xc = (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
-      const int off = isPose ? p.poseOff[slot] : p.extOff[slot];
-      double x[7], v[6], y[6], xo[7];
+    const bool isSb = i >= p.nPose + p.nExt, isPose = i < p.nPose;
+    const int slot = isSb ? i - p.nPose - p.nExt : (isPose ? i : i - p.nPose);
+    const int len = isSb ? 9 : 7, nd = isSb ? 9 : 6;
+    const double* xp = isSb ? p.sb + (size_t)slot * 9 : (isPose ? p.pose : p.ext) + (size_t)slot * 7;
+    double* xc = isSb ? p.sbC + (size_t)slot * 9 : (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
+    const int off = isSb ? p.sbOff[slot] : (isPose ? p.poseOff[slot] : p.extOff[slot]);
+    double x[9], v[9], y[9], xo[9];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) x[k] = xp[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { v[k] = off >= 0 ? p.vC[off + k] : 0.0; y[k] = off >= 0 ? p.yC[off + k] : 0.0; }
-      if (off >= 0) {
-        double dl[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dl[k] = cg * v[k] - cn * y[k];
-        poseOplusDev(x, dl, xo);
-        if (p.ownsCamera) {
-#pragma unroll
-          for (int k = 0; k < 7; ++k) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) xo[k] = x[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 7; ++k) xc[k] = xo[k];
-    } else {
-      const int slot = i - p.nPose - p.nExt;
-      const double* xp = p.sb + (size_t)slot * 9;
-      double* xc = p.sbC + (size_t)slot * 9;
-      const int off = p.sbOff[slot];
-      double x[9], v[9], y[9], xo[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { x[k] = xp[k]; v[k] = off >= 0 ? p.vC[off + k] : 0.0; y[k] = off >= 0 ? p.yC[off + k] : 0.0; }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        xo[k] = off >= 0 ? x[k] + (cg * v[k] - cn * y[k]) : x[k];
-        if (off >= 0 && p.ownsCamera) { acc[0] += (x[k] - xo[k]) * (x[k] - xo[k]); acc[1] += x[k] * x[k]; }
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xc[k] = xo[k];
+    for (int k = 0; k < 9; ++k) {
+      x[k] = k < len ? xp[k] : 0.0;
+      v[k] = (off >= 0 && k < nd) ? p.vC[off + k] : 0.0;
+      y[k] = (off >= 0 && k < nd) ? p.yC[off + k] : 0.0;
     }
+    retractBlockValues(isSb, off >= 0, p.ownsCamera != 0, x, v, y, cg, cn, xo, acc);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (k < len) xc[k] = xo[k];
   } else if (i < nBlk + p.L) {
     const int l = i - nBlk;
     const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
@@ -3700,6 +3808,12 @@ __global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double ra
 // partial slots of the post-solve pass
 constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
 __device__ __constant__ int kPostSlot[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};
+// the same table for compile-time indices (a __constant__ lookup is a memory round trip: nine of them, each followed by its
+// dependent partial load, used to serialise the tail of the post-solve pass)
+__device__ constexpr int postSlotC(int k) {
+  constexpr int tbl[kPostK] = {PS_JV_SQ, PS_JY_SQ, PS_JVJY, PS_JV_DOT, PS_JY_DOT, PS_GHAT, PS_GNHAT, PS_GDOTGN, PS_GRADMAX};
+  return tbl[k];
+}
 
 // One pass over the whole linearisation right after the reduced solve (y_C, and v_C = g/htil from the solver):
 //  landmark blocks (16 lanes per landmark): back-substitution y_l = Vinv (b_l - sum_i Jl_i^T Jc_i y_C), v_l = g_l/htil_l,
@@ -3721,24 +3835,42 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   // still needed by the last block below and is cleared there)
   for (int i = b * blockDim.x + t; i < p.d * p.d; i += gridDim.x * blockDim.x) p.S[i] = 0.0;
   for (int i = b * blockDim.x + t; i < p.d; i += gridDim.x * blockDim.x) { p.gRed[i] = 0.0; p.hC[i] = 0.0; }
+  // Staged in LDS by every block at its start: the camera-side solution vectors (tiny, read by every observation: one
+  // copy instead of a dependent global load per observation; wide windows keep reading them through L2), the block ->
+  // row maps, and -- because any block may turn out to be the last one, whose tail is the serial end of the
+  // iteration -- the parameter blocks themselves, so that the fused retraction below starts without a memory round trip
+  constexpr int kStageMax = 512, kStageBlk = 128, kStageItems = 96;
+  __shared__ double sYV[2 * kStageMax];
+  __shared__ int sOff[2 * kStageBlk];
+  __shared__ double sItemX[kStageItems * 9];
+  __shared__ int sItemOff[kStageItems];
+  const bool staged = p.d <= kStageMax;
+  const bool stagedOff = p.nPose <= kStageBlk && p.nExt <= kStageBlk;
+  const int nBlkItems = p.nPose + p.nExt + p.nSb;
+  const bool stagedItems = fuseRadius > 0.0 && staged && nBlkItems <= kStageItems;
+  const int cholFailIn = p.scal->cholFail;  // set by earlier kernels only
+  if (staged) {
+    for (int i = t; i < p.d; i += blockDim.x) { sYV[i] = p.yC[i]; sYV[kStageMax + i] = p.vC[i]; }
+  }
+  if (stagedOff) {
+    for (int i = t; i < p.nPose; i += blockDim.x) sOff[i] = p.poseOff[i];
+    for (int i = t; i < p.nExt; i += blockDim.x) sOff[kStageBlk + i] = p.extOff[i];
+  }
+  if (stagedItems && t < nBlkItems) {
+    const bool isSb = t >= p.nPose + p.nExt, isPose = t < p.nPose;
+    const int slot = isSb ? t - p.nPose - p.nExt : (isPose ? t : t - p.nPose);
+    const double* xp = isSb ? p.sb + (size_t)slot * 9 : (isPose ? p.pose : p.ext) + (size_t)slot * 7;
+    sItemOff[t] = isSb ? p.sbOff[slot] : (isPose ? p.poseOff[slot] : p.extOff[slot]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sItemX[t * 9 + k] = (k < (isSb ? 9 : 7)) ? xp[k] : 0.0;
+  }
+  // (the observation range of this lane group's first landmark rides on the same round trip)
+  int firstStart = 0, firstEnd = 0;
+  if (b < nLmBlocks && b * 16 + (t >> 4) < p.L) { firstStart = p.lmPtr[b * 16 + (t >> 4)]; firstEnd = p.lmPtr[b * 16 + (t >> 4) + 1]; }
+  if (staged || stagedOff || stagedItems) __syncthreads();
   if (b < nLmBlocks) {
     const int grp = t >> 4, gl = t & 15;
     const size_t N = (size_t)p.N;
-    // the camera-side solution vectors are tiny and read by every observation: one staged copy in LDS instead of a
-    // dependent global load per observation (narrow windows; wide ones keep reading them through L2)
-    constexpr int kStageMax = 512, kStageBlk = 128;
-    __shared__ double sYV[2 * kStageMax];
-    __shared__ int sOff[2 * kStageBlk];
-    const bool staged = p.d <= kStageMax;
-    const bool stagedOff = p.nPose <= kStageBlk && p.nExt <= kStageBlk;  // the block -> row maps too (one dependent load less)
-    if (staged) {
-      for (int i = t; i < p.d; i += blockDim.x) { sYV[i] = p.yC[i]; sYV[kStageMax + i] = p.vC[i]; }
-    }
-    if (stagedOff) {
-      for (int i = t; i < p.nPose; i += blockDim.x) sOff[i] = p.poseOff[i];
-      for (int i = t; i < p.nExt; i += blockDim.x) sOff[kStageBlk + i] = p.extOff[i];
-    }
-    if (staged || stagedOff) __syncthreads();
     const double* yCs = staged ? sYV : p.yC;
     const double* vCs = staged ? sYV + kStageMax : p.vC;
     const int* poseOffS = stagedOff ? sOff : p.poseOff;
@@ -3770,7 +3902,8 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
       rr[0] = p.rCur[o]; rr[1] = p.rCur[N + o];
     };
     for (int l = b * 16 + grp; l < p.L; l += nLmBlocks * 16) {
-      const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      const bool first = l == b * 16 + grp;
+      const int start = first ? firstStart : p.lmPtr[l], n = (first ? firstEnd : p.lmPtr[l + 1]) - start;
       // the landmark's own quantities do not depend on the observation loop: requested up front
       const double g0 = p.bl[3 * l], g1 = p.bl[3 * l + 1], g2 = p.bl[3 * l + 2];
       const double* vi = p.Vinv + 6 * (size_t)l;
@@ -3894,23 +4027,50 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   if (t < kPostK) cstore(p.partial + (size_t)kPostSlot[t] * kMaxPartials + b, mine);
   if (!lastBlockDoneLight(&p.tickets[TK_POST], &lastFlag)) return;   // partials, y_l and v_l are cstore()d
   TRACE(2);
-  // final reduction over the blocks, fixed order: thread k-strided per slot
+  // The tail from here on is the serial end of the iteration: one round trip for the partials of the nine sums, then the
+  // first round of landmarks with their y_l / v_l (eight per thread) in the shadow of the arithmetic.
+  constexpr int kPer = 8;
+  double lx[kPer][4], lv[kPer][3], ly[kPer][3];
+  auto loadLandmarks = [&](int l0) {
 #pragma unroll
-  for (int k = 0; k < kPostK; ++k) {
-    double s = 0;
-    const double* src = p.partial + (size_t)kPostSlot[k] * kMaxPartials;
-    for (int i = t; i < (int)gridDim.x; i += blockDim.x) { const double x = cload(src + i); s = (k == 8) ? fmax(s, x) : s + x; }
-    acc[k] = s;
+    for (int u = 0; u < kPer; ++u) {
+      const int l = min(l0 + u * (int)blockDim.x + t, p.L - 1);
+      const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
+      lx[u][0] = xx.x; lx[u][1] = xx.y; lx[u][2] = xx.z; lx[u][3] = xx.w;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lv[u][k] = cload(p.vL + 3 * l + k); ly[u][k] = cload(p.yL + 3 * l + k); }
+    }
+  };
+  // final reduction over the blocks, fixed order: thread k-strided per slot; the first round's nine loads per thread are
+  // all in flight before the first one is consumed (and ahead of the landmark loads: the memory counter retires in order)
+  {
+    double x0[kPostK];
+#pragma unroll
+    for (int k = 0; k < kPostK; ++k) x0[k] = (t < (int)gridDim.x) ? cload(p.partial + (size_t)postSlotC(k) * kMaxPartials + t) : 0.0;
+#pragma unroll
+    for (int k = 0; k < kPostK; ++k) {
+      double s = x0[k];
+      const double* src = p.partial + (size_t)postSlotC(k) * kMaxPartials;
+      for (int i = t + blockDim.x; i < (int)gridDim.x; i += blockDim.x) { const double x = cload(src + i); s = (k == 8) ? fmax(s, x) : s + x; }
+      acc[k] = s;
+    }
   }
+  TRACE(12);
+  // the landmark loads (64 per thread: ~2 us of this CU's load pipe) go out once the partials are in -- queued ahead of
+  // them they delay the partial loads of the other waves -- and land while the sums, the dogleg coefficients and the block
+  // retraction are being computed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const bool lmHere = fuseRadius > 0.0 && p.L > 0 && !p.lmDeferred;
+  if (lmHere) loadLandmarks(0);
   const double tot = blockSumK<kPostK>(acc, red, 8);
   TRACE(3);
   __shared__ double grpB[8];
   if (t < kPostK) {
     double* dst = &p.scal->gHatSq;
-    //                     A  B  C  D  E  gHat gnHat gDotGn
-    const int field[8] = {1, 4, 5, 6, 7, 0, 2, 3};
-    if (t < 8) { dst[field[t]] = tot; grpB[field[t]] = tot; }
-    else { p.scal->gradMax = tot; p.scal->failMax = (double)p.scal->cholFail; p.scal->cholFail = 0; }
+    // slot order A B C D E gHat gnHat gDotGn -> fields 1 4 5 6 7 0 2 3 of group B
+    const int field = (t == 0) ? 1 : (t == 1) ? 4 : (t == 2) ? 5 : (t == 3) ? 6 : (t == 4) ? 7 : (t == 5) ? 0 : (t == 6) ? 2 : 3;
+    if (t < 8) { dst[field] = tot; grpB[field] = tot; }
+    else { p.scal->gradMax = tot; p.scal->failMax = (double)cholFailIn; p.scal->cholFail = 0; }
   }
   for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
   if (t == 0) p.tickets[TK_POST] = 0;
@@ -3920,24 +4080,35 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     __syncthreads();
     const DoglegCoeff c = doglegCoefficients(grpB[0], grpB[1], grpB[2], grpB[3], grpB[4], grpB[5], grpB[6], grpB[7], fuseRadius);
     if (t == 0) { p.scal->doglegStepNorm = c.stepNorm; p.scal->jdSq = c.jdSq; p.scal->jdDotR = c.jdDotR; }
+    if (t == 1 && p.lmDeferred) { p.scal->spareA0 = c.cg; p.scal->spareA1 = c.cn; }   // for the candidate evaluation's landmark step
     double a2[2] = {0, 0};
-    const int nBlkItems = p.nPose + p.nExt + p.nSb;
     TRACE(4);
-    for (int i = t; i < nBlkItems; i += blockDim.x) retractItem(p, i, c.cg, c.cn, a2);
-    TRACE(5);
-    // landmarks: eight per thread per round with all loads issued before the first store (one memory latency per
-    // round instead of one per landmark)
-    constexpr int kPer = 8;
-    for (int l0 = 0; l0 < p.L; l0 += kPer * (int)blockDim.x) {
-      double x[kPer][4], v[kPer][3], y[kPer][3];
+    if (stagedItems) {
+      if (t < nBlkItems) {
+        const bool isSb = t >= p.nPose + p.nExt, isPose = t < p.nPose;
+        const int slot = isSb ? t - p.nPose - p.nExt : (isPose ? t : t - p.nPose);
+        const int off = sItemOff[t], nd = isSb ? 9 : 6;
+        double x[9], v[9], y[9], xo[9];
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const int l = min(l0 + u * (int)blockDim.x + t, p.L - 1);
-        const double4 xx = reinterpret_cast<const double4*>(p.lm)[l];
-        x[u][0] = xx.x; x[u][1] = xx.y; x[u][2] = xx.z; x[u][3] = xx.w;
+        for (int k = 0; k < 9; ++k) {
+          x[k] = sItemX[t * 9 + k];
+          v[k] = (off >= 0 && k < nd) ? sYV[kStageMax + off + k] : 0.0;
+          y[k] = (off >= 0 && k < nd) ? sYV[off + k] : 0.0;
+        }
+        retractBlockValues(isSb, off >= 0, p.ownsCamera != 0, x, v, y, c.cg, c.cn, xo, a2);
+        double* xc = isSb ? p.sbC + (size_t)slot * 9 : (isPose ? p.poseC : p.extC) + (size_t)slot * 7;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v[u][k] = cload(p.vL + 3 * l + k); y[u][k] = cload(p.yL + 3 * l + k); }
+        for (int k = 0; k < 9; ++k)
+          if (k < (isSb ? 9 : 7)) xc[k] = xo[k];
       }
+    } else {
+      for (int i = t; i < nBlkItems; i += blockDim.x) retractItem(p, i, c.cg, c.cn, a2);
+    }
+    TRACE(5);
+    // landmarks: eight per thread per round, all loads of a round issued before its first store (the first round was
+    // requested at the top of the tail)
+    for (int l0 = 0; lmHere && l0 < p.L; l0 += kPer * (int)blockDim.x) {
+      if (l0 > 0) loadLandmarks(l0);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         const int l = l0 + u * (int)blockDim.x + t;
@@ -3945,12 +4116,12 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
           double xo[4];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            xo[k] = x[u][k] + (c.cg * v[u][k] - c.cn * y[u][k]);
-            a2[0] += (x[u][k] - xo[k]) * (x[u][k] - xo[k]);
-            a2[1] += x[u][k] * x[u][k];
+            xo[k] = lx[u][k] + (c.cg * lv[u][k] - c.cn * ly[u][k]);
+            a2[0] += (lx[u][k] - xo[k]) * (lx[u][k] - xo[k]);
+            a2[1] += lx[u][k] * lx[u][k];
           }
-          xo[3] = x[u][3] + 0.0;
-          a2[1] += x[u][3] * x[u][3];
+          xo[3] = lx[u][3] + 0.0;
+          a2[1] += lx[u][3] * lx[u][3];
           reinterpret_cast<double4*>(p.lmC)[l] = double4{xo[0], xo[1], xo[2], xo[3]};
         }
       }
@@ -3973,7 +4144,7 @@ void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadiu
 // final single-block reduction of the cost partials into SolverScalars (used when no later evaluation kernel
 // can take it over, see evaluateAll)
 __global__ __launch_bounds__(256) void k_reduce_cost(DeviceProblem p, int nA, int nB) {
-  __shared__ double red[12];
+  __shared__ double red[24];
   reduceCost(p, nA, nB, red);
 }
 

@@ -151,6 +151,8 @@ struct DeviceProblem {
   unsigned int* tickets;                     // last-block-done counters of the fused reductions
   ScalarMailbox* mailbox;                    // host-visible copy of the scalars (nullptr: disabled)
   unsigned long long mailboxSeq;             // sequence number to publish with this evaluation
+  int lmDeferred;                            // fused step: the landmark part of the retraction is taken by the candidate evaluation
+  int padDeferred;
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

@@ -1174,6 +1174,9 @@ void Window::solve(size_t numIter, bool verbose) {
   // retracts the whole window quickly enough
   static const bool noFuseStep = getenv("SVIN_NO_FUSE_STEP") != nullptr;   // A/B switch for profiling
   const bool fuseStep = !noFuseStep && !dist && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
+  // fused step: the landmark half of the retraction rides in the candidate evaluation (k_eval_all), which reads every
+  // landmark anyway -- the serial tail of k_post_solve only moves the ~20 parameter blocks
+  const bool deferLm = fuseStep && canFuseEvaluation(p) && !getenv("SVIN_SPLIT_EVAL") && !getenv("SVIN_NO_DEFER_LM") && p.L > 0 && p.N > 0;
   evaluateAll(false, s);
   AR(scalD, 4, 0);
   publish();
@@ -1221,13 +1224,16 @@ void Window::solve(size_t numIter, bool verbose) {
         specValid = false;
         AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
         launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
+        p.lmDeferred = deferLm ? 1 : 0;
         launchDoglegPrepare(p, s, fuseStep ? radius : -1.0);
         accumulatorsClean = true;
         AR(scalD + kScalGroupB, 8, 0);
         AR(scalD + kScalGroupMax, 2, 1);
       }
       if (reuse || !fuseStep) launchDoglegStep(p, radius, s);
+      p.lmDeferred = (deferLm && !reuse) ? 1 : 0;
       evaluateAll(true, s);
+      p.lmDeferred = 0;
       if (speculate && accumulatorsClean && iteration < (int)numIter) {
         DeviceProblem q = p;   // the problem as it looks after an accepted step
         std::swap(q.pose, q.poseC); std::swap(q.ext, q.extC); std::swap(q.sb, q.sbC); std::swap(q.lm, q.lmC);
@@ -1544,8 +1550,8 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
       for (int i = 0; i < reps; ++i) { launchEvalFactors(prob_, false, stream_); HIP_OK(hipStreamSynchronize(stream_)); }
       double d2[16];
       debugImuTiming(d2, false);
-      std::printf("[imu eval cycles, no redo] factors counted %.0f: staging %.0f, serial F/e block %.0f, whole block %.0f\n", d2[11],
-                  d2[8] / d2[11], d2[9] / d2[11], d2[10] / d2[11]);
+      std::printf("[imu eval cycles, no redo] factors counted %.0f: staging %.0f, serial F/e block %.0f (shared quantities %.0f, position/velocity blocks %.0f), whole block %.0f\n", d2[11],
+                  d2[8] / d2[11], d2[9] / d2[11], d2[12] / d2[11], d2[13] / d2[11], d2[10] / d2[11]);
       hipEvent_t a, b;
       HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
       for (int variant = 0; variant < 3; ++variant) {

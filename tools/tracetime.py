@@ -11,7 +11,7 @@ from svin_amd import synthetic as syn
 from svin_amd.estimator import Estimator, load_library
 
 NAMES = {0: "post: block start", 1: "post: work done", 2: "post: last block in", 3: "post: sums reduced", 4: "post: dogleg coefficients",
-         5: "post: blocks retracted", 6: "post: landmarks retracted", 7: "post: block end", 8: "post: landmark blocks done", 9: "post: factor blocks done", 10: "post: camera block done", 11: "post: block sums done", 12: "post: partials loaded (extra)",
+         5: "post: blocks retracted", 6: "post: landmarks retracted", 7: "post: block end", 8: "post: landmark blocks done", 9: "post: factor blocks done", 10: "post: camera block done", 11: "post: block sums done", 12: "post: partials loaded",
          16: "eval: block start", 17: "eval: factor block done", 18: "eval: block work done", 19: "eval: last block in", 20: "eval: cost reduced",
          24: "schur: block start", 25: "schur: block end", 28: "reduce: start", 29: "reduce: end"}
 spec = syn.make_window()
