@@ -654,7 +654,7 @@ struct FactorShared {
   // re-preintegration (imuIntegrate): per-step inputs (P0), the two serial chains (P1), the blocks of F_delta
   // per step (P2/P3, double buffered for the covariance wave) and the published integrals
   double pre[64 * 33];
-  double fb[128 * 87];
+  double fb[128 * 93];   // 128 steps x kFbLd
   double seq[65 * 13];
   double tot[64];
   double tile[16 * kPanelLd];  // 15x15 covariance / information padded to the 16x16 wave-level factorisation
@@ -686,7 +686,7 @@ struct ImuState {
 constexpr int kImuSuper = 64;  // integration steps per round of the per-step phases P0..P3
 constexpr int kImuBlock = 128;  // integration steps per block of the covariance stage (sh.fb)
 constexpr int kPreLd = 33;     // odd row strides keep the one-thread-per-step phases off the same LDS banks
-constexpr int kFbLd = 87;
+constexpr int kFbLd = 93;   // 87 entries of the step + the five process-noise values of P4 (87..91); sh.fb is sized for it
 constexpr int kSeqLd = 13;
 
 // -crossMx(v)[i][j] = sign * v[comp]  (sign 0 on the diagonal)
@@ -771,6 +771,31 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
   }
   // (qDiag, dKind): accumulator register q holds row (lane>>4)+4q, column lane&15 -- the F descriptor's pairing
   // with rows and columns swapped; the diagonal test is symmetric, so one loop serves both.
+  // P4 segments: N = F_delta - I transposed in the A-operand layout, N[(lane>>4)+4q][lane&15] = tS * fb[tIdx] (rows 0..8
+  // only: q < 3), and where the process noise of row (lane>>4)+4q sits in the step's fb row
+  int tIdx[4], rowKind[4];
+  double tS[4];
+  for (int q = 0; q < 4; ++q) {
+    const int i = (lane >> 4) + 4 * q, c = lane & 15;   // row, column of F
+    tIdx[q] = 86; tS[q] = 0.0;
+    rowKind[q] = (i < 15) ? 87 + i / 3 : 86;   // index of this row's process noise in the step's fb row (86: zero)
+    if (i < 9 && c < 15) {
+      const int br = i / 3, ii = i % 3, bc = c / 3, jj = c % 3;
+      int comp; double sg;
+      if (br == 0) {
+        if (bc == 1) { negCrossDesc(ii, jj, comp, sg); tIdx[q] = comp; tS[q] = sg; }
+        else if (bc == 2) { if (ii == jj) { tIdx[q] = 3; tS[q] = 1.0; } }
+        else if (bc == 3) { tIdx[q] = 4 + ii * 3 + jj; tS[q] = 1.0; }
+        else if (bc == 4) { tIdx[q] = 13 + ii * 3 + jj; tS[q] = 1.0; }
+      } else if (br == 1) {
+        if (bc == 3) { tIdx[q] = 22 + ii * 3 + jj; tS[q] = 1.0; }
+      } else {
+        if (bc == 1) { negCrossDesc(ii, jj, comp, sg); tIdx[q] = 31 + comp; tS[q] = sg; }
+        else if (bc == 3) { tIdx[q] = 34 + ii * 3 + jj; tS[q] = 1.0; }
+        else if (bc == 4) { tIdx[q] = 43 + ii * 3 + jj; tS[q] = 1.0; }
+      }
+    }
+  }
 
   for (int blk0 = 0; blk0 < n; blk0 += kImuBlock) {
    const int nb = min(kImuBlock, n - blk0);
@@ -948,6 +973,8 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
         for (int k = 0; k < 3; ++k) { fb[31 + k] = 0.5 * Csa[k] * dt; fb[64 + k] = 0.25 * Csa[k] * dt * dt; }
         fb[52] = pr[26]; fb[53] = pr[27]; fb[54] = 1.0;
         fb[85] = 0.0; fb[86] = 0.0;
+        // Q_delta by row kind (P4): position, angle, velocity, gyro bias, accelerometer bias
+        fb[87] = 0.5 * dt * dt * pr[27]; fb[88] = pr[26]; fb[89] = pr[27]; fb[90] = dt * sgw2; fb[91] = dt * saw2;
       }
     }
     IMU_TICK(qp5);
@@ -979,10 +1006,15 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     __syncthreads();
    }
    // ---------------- P4: covariance of the block.  The recurrence P <- F P F^T + Q is split into four segments,
-   // one per wave (= per SIMD, each with its own matrix pipe): segment w integrates its own covariance P_w from
-   // zero together with its transition product Phi_w = F...F; wave 0 then chains the segments:
-   // P <- Phi_w P Phi_w^T + P_w.  (Exact in exact arithmetic; the additions associate differently from the
-   // step-by-step recurrence, i.e. rounding-level differences only.)
+   // one per wave (= per SIMD, each with its own matrix pipe).  A segment starts from zero, so its covariance is the sum
+   //   P_w = sum_k L_k Q_k L_k^T,   L_k = F_hi-1 ... F_k+1  (the steps after k),
+   // and its transition product is Phi_w = L_lo-1.  Walking the steps BACKWARDS with M = L_k^T in the accumulator layout,
+   //   P_w += M^T Q_k M   (both MFMA operands are M's own registers: lane (c, g) register q = M[g + 4q][c]),
+   //   M   <- F_k^T M     (A operand = F_k^T gathered from LDS, B operand = M's registers),
+   // costs 8 MFMAs per step in two chains that overlap (the forward form F (F P)^T + the product for Phi took 12 in a
+   // single dependent chain of 8), and nothing but the entries of F_k crosses LDS.  Wave 0 then chains the segments:
+   // P <- Phi_w P Phi_w^T + P_w.  (Exact in exact arithmetic; the additions associate differently from the step-by-step
+   // recurrence, i.e. rounding-level differences only.)
    {
     IMU_TICK(qc0);
     const int seg = (nb + 3) / 4;
@@ -990,55 +1022,54 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     d4_t Xs = {0, 0, 0, 0}, Ph;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q, col = lane & 15; Ph[q] = (row == col && row < 15) ? 1.0 : 0.0; }
-    int par = 0;
+    const int par = 0;
     if (lo < hi) {
-      // inputs of step i+1 are gathered from LDS while the MFMAs of step i run
-      const double* row = sh.fb + (size_t)lo * kFbLd;
-      double g[4], dt = row[3], sg2 = row[52], sa2 = row[53], ex = row[54];
+      // inputs of the next step (the one before) are gathered from LDS while the MFMAs of the current one run
+      const double* row = sh.fb + (size_t)(hi - 1) * kFbLd;
+      double g[3], qd[4], ex = row[54];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g[q] = row[fIdx[q]];
-      for (int i = lo; i < hi; ++i) {
-        const double* rn = sh.fb + (size_t)min(i + 1, hi - 1) * kFbLd;
-        double gn[4];
+      for (int q = 0; q < 3; ++q) g[q] = row[tIdx[q]];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gn[q] = rn[fIdx[q]];
-        const double dtn = rn[3], sg2n = rn[52], sa2n = rn[53], exn = rn[54];
+      for (int q = 0; q < 4; ++q) qd[q] = row[rowKind[q]];
+      for (int i = hi - 1; i >= lo; --i) {
+        const double* rn = sh.fb + (size_t)max(i - 1, lo) * kFbLd;
+        double gn[3], qn[4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gn[q] = rn[tIdx[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qn[q] = rn[rowKind[q]];
+        const double exn = rn[54];
         if (ex != 0.0) {
-          double f[4];
+          double aq[4], nq[3];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) f[q] = fC0[q] + fS[q] * g[q];
-          d4_t V = {0, 0, 0, 0};
+          for (int q = 0; q < 4; ++q) aq[q] = Ph[q] * qd[q];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) V = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[q], f[q], V, 0, 0, 0);   // X^T F^T
-          d4_t Pn = {0, 0, 0, 0};
+          for (int q = 0; q < 3; ++q) nq[q] = tS[q] * g[q];
+          // F^T M = M + N^T M; N has rows 0..8 only, i.e. three of the four k-chunks.  The chain through M goes first,
+          // the noise term fills the matrix pipe behind it
+          d4_t Mn = Ph;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], Ph[q], Pn, 0, 0, 0);  // F Phi
-          d4_t Y = {0, 0, 0, 0};
+          for (int q = 0; q < 3; ++q) Mn = __builtin_amdgcn_mfma_f64_16x16x4f64(nq[q], Ph[q], Mn, 0, 0, 0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(f[q], V[q], Y, 0, 0, 0);   // F (X^T F^T)
-          // Q_delta on the diagonal: every lane owns at most one diagonal entry (accumulator register qDiag)
-          double add = dt * saw2;
-          add = (dKind == 4) ? dt * sgw2 : add;
-          add = (dKind == 3) ? sa2 : add;
-          add = (dKind == 2) ? sg2 : add;
-          add = (dKind == 1) ? 0.5 * dt * dt * sa2 : add;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Xs[q] = Y[q] + ((q == qDiag) ? add : 0.0);
-          Ph = Pn;
-          par ^= 1;
+          for (int q = 0; q < 4; ++q) Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], Ph[q], Xs, 0, 0, 0);   // M^T Q M
+          Ph = Mn;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = gn[q];
-        dt = dtn; sg2 = sg2n; sa2 = sa2n; ex = exn;
+        for (int q = 0; q < 3; ++q) g[q] = gn[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qd[q] = qn[q];
+        ex = exn;
       }
     }
+    IMU_TICK(qcs);
+    IMU_ACC(14, qc0, qcs, t == 0);
     // publish Phi_w and P_w (true orientation) as 16x16 tiles; sh.pre is free between the rounds
     double* phiT = sh.pre + wave * 512;
     double* pT = phiT + 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = (lane >> 4) + 4 * q, col = lane & 15;
-      phiT[row * 16 + col] = Ph[q];
+      phiT[col * 16 + row] = Ph[q];   // Ph = Phi^T
       pT[par ? col * 16 + row : row * 16 + col] = Xs[q];
     }
     __syncthreads();
@@ -2061,6 +2092,14 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   const long long qd0 = __builtin_readcyclecounter();
   long long qdA = 0, qdL = 0, qdG = 0;
 #endif
+  // the pose -> row map of the reduced system rides on the same round trip as the first chunk's observation ranges (it was
+  // a dependent global load per observation)
+  constexpr int kStagePose = 256;
+  __shared__ int sPoseOff[kStagePose];
+  const bool stagedPose = p.nPose <= kStagePose;
+  if (stagedPose)
+    for (int i = t; i < p.nPose; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
+  const int* poseOffS = stagedPose ? sPoseOff : p.poseOff;
   for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
 #ifdef SVIN_SCHUR_TIMING
@@ -2157,13 +2196,30 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     const int l = chunk * kDenseLm + grp;
     if (l < p.L) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+      // everything this lane needs of its first observation (a landmark rarely has more than 16) is requested in ONE round
+      // trip: residual, landmark Jacobian, packed indices and the pose Jacobian of the second pass below
+      const bool has0 = gl < n;
+      const size_t o0 = (size_t)start + (has0 ? gl : 0);
+      double pr0[2] = {0, 0}, pjl[6] = {0, 0, 0, 0, 0, 0}, pjp[12];
+      uint32_t pidx = 0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) pjp[k] = 0;
+      if (has0) {
+        pidx = p.obsIdx[o0];
+        pr0[0] = p.rCur[o0]; pr0[1] = p.rCur[N + o0];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pjl[k] = p.JlCur[k * N + o0];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pjp[k] = p.JpCur[k * N + o0];
+      }
       // V = sum Jl^T Jl, b = sum Jl^T r over the landmark's observations (16 lanes)
       double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
-        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
-        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        const bool first = i == gl;
+        const double r0 = first ? pr0[0] : p.rCur[o], r1 = first ? pr0[1] : p.rCur[N + o];
+        const double a0 = first ? pjl[0] : p.JlCur[o], a1 = first ? pjl[1] : p.JlCur[N + o], a2 = first ? pjl[2] : p.JlCur[2 * N + o];
+        const double c0 = first ? pjl[3] : p.JlCur[3 * N + o], c1 = first ? pjl[4] : p.JlCur[4 * N + o], c2 = first ? pjl[5] : p.JlCur[5 * N + o];
         v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
         v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
         b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
@@ -2211,17 +2267,18 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       // there), and the pose block of A with Jp^T r into this wave's copy
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const uint32_t idx = p.obsIdx[o];
-        const int offP = p.poseOff[idx & 0xfff];
+        const bool first = i == gl;
+        const uint32_t idx = first ? pidx : p.obsIdx[o];
+        const int offP = poseOffS[idx & 0xfff];
         const int offE = WITH_EXT ? p.extOff[(idx >> 12) & 0xfff] : -1;
         if (offP < 0 && offE < 0) continue;
-        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
-        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        const double a0 = first ? pjl[0] : p.JlCur[o], a1 = first ? pjl[1] : p.JlCur[N + o], a2 = first ? pjl[2] : p.JlCur[2 * N + o];
+        const double c0 = first ? pjl[3] : p.JlCur[3 * N + o], c1 = first ? pjl[4] : p.JlCur[4 * N + o], c2 = first ? pjl[5] : p.JlCur[5 * N + o];
         // one 6-block of camera-side Jacobian: rows of G (and, with fixed extrinsics, the block of A + Jc^T r)
         auto addBlock = [&](const double* J, int off) {
           double jc[12];
 #pragma unroll
-          for (int k = 0; k < 12; ++k) jc[k] = J[k * N + o];
+          for (int k = 0; k < 12; ++k) jc[k] = (first && J == p.JpCur) ? pjp[k] : J[k * N + o];
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
             const double j0 = jc[a], j1 = jc[6 + a];
@@ -2231,7 +2288,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
             atomicAdd(&g[1], e0 * i10 + e1 * i11);
             atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
             if (!A_MFMA) {
-              const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+              const double r0 = first ? pr0[0] : p.rCur[o], r1 = first ? pr0[1] : p.rCur[N + o];
               double* ap = Amine + (size_t)(off / 6) * kPoseAcc;
 #pragma unroll
               for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jc[c] + j1 * jc[6 + c]);
@@ -4160,13 +4217,16 @@ void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s) {
 // ================================================================ K9: landmark quality (Estimator.cpp:902-923)
 // H = sum J_lm^T J_lm over all observations WITHOUT loss correction (Map::getLhs), symmetric 3x3
 // eigenvalues by cyclic Jacobi, quality = sqrt(lmin)/sqrt(lmax) (0 if lmin < 1e-12).
-__global__ void k_landmark_quality(DeviceProblem p, double* __restrict__ quality) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= p.L) return;
+// 16 lanes per landmark, one observation per lane and turn (a thread per landmark walked its ~10 observations serially:
+// 23 us for 2 000 landmarks)
+__global__ __launch_bounds__(256) void k_landmark_quality(DeviceProblem p, double* __restrict__ quality) {
+  const int l = blockIdx.x * 16 + (threadIdx.x >> 4), gl = threadIdx.x & 15;
+  if (l >= p.L) return;   // whole 16-lane rows leave together
   double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-  const double* hp = p.lm + 4 * (size_t)l;
-  const double hpw[4] = {hp[0], hp[1], hp[2], hp[3]};
-  for (int o = p.lmPtr[l]; o < p.lmPtr[l + 1]; ++o) {
+  const double4 hp = reinterpret_cast<const double4*>(p.lm)[l];
+  const double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
+  const int oEnd = p.lmPtr[l + 1];
+  for (int o = p.lmPtr[l] + gl; o < oEnd; o += 16) {
     const uint32_t idx = p.obsIdx[o];
     double rr[2], jp[12], jl[6], je[12];
     reprojEval(p.cams[(idx >> 24) & 0xf], p.pose + (size_t)(idx & 0xfff) * 7, hpw, p.ext + (size_t)((idx >> 12) & 0xfff) * 7,
@@ -4174,6 +4234,8 @@ __global__ void k_landmark_quality(DeviceProblem p, double* __restrict__ quality
     a00 += jl[0] * jl[0] + jl[3] * jl[3]; a01 += jl[0] * jl[1] + jl[3] * jl[4]; a02 += jl[0] * jl[2] + jl[3] * jl[5];
     a11 += jl[1] * jl[1] + jl[4] * jl[4]; a12 += jl[1] * jl[2] + jl[4] * jl[5]; a22 += jl[2] * jl[2] + jl[5] * jl[5];
   }
+  a00 = rowSum16(a00); a01 = rowSum16(a01); a02 = rowSum16(a02); a11 = rowSum16(a11); a12 = rowSum16(a12); a22 = rowSum16(a22);
+  if (gl != 0) return;
   // cyclic Jacobi on the symmetric 3x3
   for (int sweep = 0; sweep < 12; ++sweep) {
     const double off = fabs(a01) + fabs(a02) + fabs(a12);
@@ -4210,7 +4272,7 @@ __global__ void k_landmark_quality(DeviceProblem p, double* __restrict__ quality
 
 void launchLandmarkQuality(const DeviceProblem& p, double* quality, hipStream_t s) {
   if (p.L == 0) return;
-  hipLaunchKernelGGL(k_landmark_quality, dim3((p.L + 127) / 128), dim3(128), 0, s, p, quality);
+  hipLaunchKernelGGL(k_landmark_quality, dim3((p.L + 15) / 16), dim3(256), 0, s, p, quality);
 }
 
 }  // namespace svin

@@ -1570,8 +1570,8 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
         std::printf("[eval timing, no redo] %s: %.2f us\n", variant == 0 ? "evaluateAll (fused, cost summed)" : variant == 1 ? "factors only" : "fused, no cost sum", 1e3 * tot / 20);
       }
     }
-    std::printf("[imu redo cycles] P0 %.0f P1dq %.0f P1cross %.0f P2 %.0f P3 %.0f cov %.0f integrate %.0f post %.0f\n", dbg[0] / n,
-                dbg[1] / n, dbg[6] / n, dbg[7] / n, dbg[5] / n, dbg[2] / n, dbg[3] / n, dbg[4] / n);
+    std::printf("[imu redo cycles] P0 %.0f P1dq %.0f P1cross %.0f P2 %.0f P3 %.0f cov %.0f (segment loop of wave 0 %.0f) integrate %.0f post %.0f\n", dbg[0] / n,
+                dbg[1] / n, dbg[6] / n, dbg[7] / n, dbg[5] / n, dbg[2] / n, dbg[14] / n, dbg[3] / n, dbg[4] / n);
   }
 #endif
   DeviceProblem& p = prob_;

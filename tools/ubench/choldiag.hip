@@ -270,6 +270,69 @@ __device__ __forceinline__ void cholMfma2(double* D, double* dinv, int lane, int
   }
   if ((!(dmin > 0) || !(dlast > 0)) && lane == 0) atomicOr(failFlag, 2);
 }
+
+// ---- variant 4: variant 3 with the dependent-operation chain of the 4 x 4 block cut down.  A dependent f64 operation
+// costs ~20 cycles of latency and the block factorisation is one long chain, so: fraction-free (Bareiss) elimination --
+// p1 = d0 d1, p2 = d0 d1 d2, p3 = d0 d1 d2 d3 come out of mul/fma pairs without waiting for any reciprocal, the
+// reciprocals run beside the chain -- and sums of disjoint selects instead of select chains.
+__device__ __forceinline__ double rcpFast(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double pick4(int g, double v0, double v1, double v2, double v3) {
+  return ((g == 0 ? v0 : 0.0) + (g == 1 ? v1 : 0.0)) + ((g == 2 ? v2 : 0.0) + (g == 3 ? v3 : 0.0));
+}
+__device__ __forceinline__ void cholMfma3(double* D, double* dinv, int lane, int* failFlag) {
+  const int c = lane & 15, g = lane >> 4;
+  d4_t acc, xacc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] = D[(g + 4 * r) * kLd + c]; xacc[r] = (g + 4 * r == c) ? 1.0 : 0.0; }
+  const double mBase = (lane == 0 || lane == 17 || lane == 34 || lane == 51) ? 1.0 : 0.0;
+  double pmin = 1.0, plast = 1.0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const double b00 = readlaneD(acc[b], 4 * b);
+    const double b10 = readlaneD(acc[b], 16 + 4 * b), b11 = readlaneD(acc[b], 16 + 4 * b + 1);
+    const double b20 = readlaneD(acc[b], 32 + 4 * b), b21 = readlaneD(acc[b], 32 + 4 * b + 1), b22 = readlaneD(acc[b], 32 + 4 * b + 2);
+    const double b30 = readlaneD(acc[b], 48 + 4 * b), b31 = readlaneD(acc[b], 48 + 4 * b + 1), b32 = readlaneD(acc[b], 48 + 4 * b + 2),
+                 b33 = readlaneD(acc[b], 48 + 4 * b + 3);
+    const double r0 = rcpFast(b00);
+    // step 0 (scaled by d0)
+    const double c11 = __builtin_fma(-b10, b10, b11 * b00), c21 = __builtin_fma(-b20, b10, b21 * b00), c31 = __builtin_fma(-b30, b10, b31 * b00);
+    const double c22 = __builtin_fma(-b20, b20, b22 * b00), c32 = __builtin_fma(-b30, b20, b32 * b00), c33 = __builtin_fma(-b30, b30, b33 * b00);
+    const double rp1 = rcpFast(c11);
+    // step 1 (scaled by d0 d1)
+    const double e22 = __builtin_fma(-c21, c21, c22 * c11) * r0, e32 = __builtin_fma(-c31, c21, c32 * c11) * r0, e33 = __builtin_fma(-c31, c31, c33 * c11) * r0;
+    const double rp2 = rcpFast(e22);
+    // step 2 (scaled by d0 d1 d2)
+    const double f33 = __builtin_fma(-e32, e32, e33 * e22) * rp1;
+    const double rp3 = rcpFast(f33);
+    pmin = fmin(fmin(pmin, b00), fmin(c11, fmin(e22, f33)));
+    plast = f33;
+    const double r1 = b00 * rp1, r2 = c11 * rp2, r3 = e22 * rp3;   // 1 / d_k
+    const double l10 = b10 * r0, l20 = b20 * r0, l30 = b30 * r0, l21 = c21 * rp1, l31 = c31 * rp1, l32 = e32 * rp2;
+    const double m20 = __builtin_fma(l21, l10, -l20), m31 = __builtin_fma(l32, l21, -l31);
+    const double m30 = __builtin_fma(-l32, m20, __builtin_fma(l31, l10, -l30));
+    const double mop = ((mBase + (lane == 1 ? -l10 : 0.0)) + ((lane == 2 ? m20 : 0.0) + (lane == 18 ? -l21 : 0.0))) +
+                       (((lane == 3 ? m30 : 0.0) + (lane == 19 ? m31 : 0.0)) + (lane == 35 ? -l32 : 0.0));
+    const d4_t zero = {0, 0, 0, 0};
+    const d4_t Ur = __builtin_amdgcn_mfma_f64_16x16x4f64(mop, acc[b], zero, 0, 0, 0);    // reg 0: U_g[c]
+    const d4_t Xr = __builtin_amdgcn_mfma_f64_16x16x4f64(mop, xacc[b], zero, 0, 0, 0);
+    const double Um = Ur[0], Xm = Xr[0];
+    const double rm = pick4(g, r0, r1, r2, r3);
+    if (b < 3) {
+      const double aop = -Um * rm;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Um, acc, 0, 0, 0);
+      xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Xm, xacc, 0, 0, 0);
+    }
+    const double rs = rm * rsqrtNewton(rm);   // sqrt(1/d) = 1/L_kk
+    const int k = 4 * b + g;
+    D[c * kLd + k] = ((c >= k) ? Um : Xm) * rs;
+    if (c == 0) dinv[k] = rs;
+  }
+  if ((!(pmin > 0) || !(plast > 0)) && lane == 0) atomicOr(failFlag, 2);
+}
 template <int VARIANT>
 __global__ __launch_bounds__(64) void bench(const double* A, double* out, double* dinvOut, int reps, long long* cyc) {
   __shared__ double T[16 * kLd], dv[16];
@@ -279,7 +342,7 @@ __global__ __launch_bounds__(64) void bench(const double* A, double* out, double
     for (int e = lane; e < 256; e += 64) T[(e >> 4) * kLd + (e & 15)] = A[e];
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
-    if (VARIANT == 0) cholOld(T, dv, lane); else if (VARIANT == 1) cholNew(T, dv, lane); else if (VARIANT == 2) cholMfma(T, dv, lane, (int*)(cyc + 8)); else cholMfma2(T, dv, lane, (int*)(cyc + 8));
+    if (VARIANT == 0) cholOld(T, dv, lane); else if (VARIANT == 1) cholNew(T, dv, lane); else if (VARIANT == 2) cholMfma(T, dv, lane, (int*)(cyc + 8)); else if (VARIANT == 3) cholMfma2(T, dv, lane, (int*)(cyc + 8)); else cholMfma3(T, dv, lane, (int*)(cyc + 8));
     __syncthreads();
     tot += __builtin_readcyclecounter() - t0;
   }
@@ -293,16 +356,17 @@ int main() {
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) B[i * 16 + j] = (rand() % 2001 - 1000) / 1000.0;
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = (i == j) ? 4.0 : 0.0; for (int k = 0; k < 16; ++k) s += B[i * 16 + k] * B[j * 16 + k]; A[i * 16 + j] = s; }
   double *dA, *dO, *dD; long long* dC;
-  OK(hipMalloc(&dA, 256 * 8)); OK(hipMalloc(&dO, 4 * 256 * 8)); OK(hipMalloc(&dD, 4 * 16 * 8)); OK(hipMalloc(&dC, 128));
+  OK(hipMalloc(&dA, 256 * 8)); OK(hipMalloc(&dO, 5 * 256 * 8)); OK(hipMalloc(&dD, 5 * 16 * 8)); OK(hipMalloc(&dC, 128));
   OK(hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice));
   OK(hipMemset(dC, 0, 128));
   hipLaunchKernelGGL(bench<0>, dim3(1), dim3(64), 0, 0, dA, dO, dD, 200, dC);
   hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, dA, dO + 256, dD + 16, 200, dC + 1);
   hipLaunchKernelGGL(bench<2>, dim3(1), dim3(64), 0, 0, dA, dO + 512, dD + 32, 200, dC + 2);
   hipLaunchKernelGGL(bench<3>, dim3(1), dim3(64), 0, 0, dA, dO + 768, dD + 48, 200, dC + 3);
+  hipLaunchKernelGGL(bench<4>, dim3(1), dim3(64), 0, 0, dA, dO + 1024, dD + 64, 200, dC + 4);
   OK(hipDeviceSynchronize());
-  std::vector<double> O(1024), Dv(64); long long c[4];
-  OK(hipMemcpy(O.data(), dO, 1024 * 8, hipMemcpyDeviceToHost)); OK(hipMemcpy(Dv.data(), dD, 64 * 8, hipMemcpyDeviceToHost)); OK(hipMemcpy(c, dC, 32, hipMemcpyDeviceToHost));
+  std::vector<double> O(1280), Dv(80); long long c[5];
+  OK(hipMemcpy(O.data(), dO, 1280 * 8, hipMemcpyDeviceToHost)); OK(hipMemcpy(Dv.data(), dD, 80 * 8, hipMemcpyDeviceToHost)); OK(hipMemcpy(c, dC, 40, hipMemcpyDeviceToHost));
   double worst = 0, worstD = 0;
   for (int e = 0; e < 256; ++e) worst = fmax(worst, fabs(O[e] - O[256 + e]));
   for (int e = 0; e < 16; ++e) worstD = fmax(worstD, fabs(Dv[e] - Dv[16 + e]));
@@ -318,5 +382,9 @@ int main() {
   for (int e = 0; e < 256; ++e) w3 = fmax(w3, fabs(O[e] - O[768 + e]));
   for (int e = 0; e < 16; ++e) w3d = fmax(w3d, fabs(Dv[e] - Dv[48 + e]));
   printf("MFMA-blocked, pivot rows through MFMA: %lld cycles per tile; max |difference to one-row-per-lane| tile %.3e dinv %.3e\n", c[3], w3, w3d);
+  double w4 = 0, w4d = 0;
+  for (int e = 0; e < 256; ++e) w4 = fmax(w4, fabs(O[e] - O[1024 + e]));
+  for (int e = 0; e < 16; ++e) w4d = fmax(w4d, fabs(Dv[e] - Dv[64 + e]));
+  printf("MFMA-blocked, fraction-free 4x4 block: %lld cycles per tile; max |difference to one-row-per-lane| tile %.3e dinv %.3e\n", c[4], w4, w4d);
   return 0;
 }
