@@ -564,15 +564,40 @@ __device__ __forceinline__ void mm3(const double* A, const double* B, double* C)
 __device__ __forceinline__ void crossMxDev(double x, double y, double z, double* C) {
   C[0] = 0; C[1] = -z; C[2] = y; C[3] = z; C[4] = 0; C[5] = -x; C[6] = -y; C[7] = x; C[8] = 0;
 }
+// rightJacobian (okvis::kinematics::rightJacobian as ImuError uses it): I + a [phi]x + b [phi]x^2 with
+// a = -(1 - cos Phi) / Phi^2, b = (Phi - sin Phi) / Phi^3 and the constants -1/2, 1/6 below Phi = 1e-4 like the reference.
+// Between 1e-4 and 1/2 rad -- every IMU step: Phi = |omega| dt -- the two coefficients come from their Taylor series:
+// the closed forms cancel catastrophically there (relative error ~1e-16 / Phi^2) and cost two library calls on the
+// one-thread-per-step stage of the re-integration.
 __device__ __forceinline__ void rightJacobianDev(double x, double y, double z, double* J) {
-  const double Phi = sqrt(x * x + y * y + z * z);
+  const double Phi2 = x * x + y * y + z * z;
   double X[9], X2[9];
   crossMxDev(x, y, z, X);
   mm3(X, X, X2);
   double a, b;
-  if (Phi < 1.0e-4) { a = -0.5; b = 1.0 / 6.0; }
-  else {
-    const double Phi2 = Phi * Phi, Phi3 = Phi2 * Phi;
+  if (Phi2 < 1.0e-8) { a = -0.5; b = 1.0 / 6.0; }
+  else if (Phi2 < 0.25) {
+    // a = -(1/2 - P/24 + P^2/720 - ...), b = 1/6 - P/120 + P^2/5040 - ...   (P = Phi^2)
+    double ta = 1.0 / 20922789888000.0;   // 1/16!
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 87178291200.0);
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 479001600.0);
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 3628800.0);
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 40320.0);
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 720.0);
+    ta = __builtin_fma(ta, -Phi2, 1.0 / 24.0);
+    ta = __builtin_fma(ta, -Phi2, 0.5);
+    a = -ta;
+    double tb = 1.0 / 355687428096000.0;  // 1/17!
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 1307674368000.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 6227020800.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 39916800.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 362880.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 5040.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 120.0);
+    tb = __builtin_fma(tb, -Phi2, 1.0 / 6.0);
+    b = tb;
+  } else {
+    const double Phi = sqrt(Phi2), Phi3 = Phi2 * Phi;
     a = -(1.0 - cos(Phi)) / Phi2;
     b = (Phi - sin(Phi)) / Phi3;
   }
@@ -840,10 +865,10 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       if (as) sigma_a_c *= 100;
       const double wt[3] = {0.5 * (w0[0] + w1[0]) - sb[3], 0.5 * (w0[1] + w1[1]) - sb[4], 0.5 * (w0[2] + w1[2]) - sb[5]};
       const double at[3] = {0.5 * (a0[0] + a1[0]) - sb[6], 0.5 * (a0[1] + a1[1]) - sb[7], 0.5 * (a0[2] + a1[2]) - sb[8]};
-      const double theta_half = sqrt(wt[0] * wt[0] + wt[1] * wt[1] + wt[2] * wt[2]) * 0.5 * dt;
-      const double sc = sinc(theta_half);
-      const Quat dq = {sc * wt[0] * 0.5 * dt, sc * wt[1] * 0.5 * dt, sc * wt[2] * 0.5 * dt, cos(theta_half)};
-      const Mat3 Rdqi = quatToR(qinv(dq));
+      // dq = [sinc(theta/2) omega dt / 2, cos(theta/2)]  (ImuError.cpp:151-157) = the quaternion exponential of omega dt
+      const Quat dq = deltaQDev(wt[0] * dt, wt[1] * dt, wt[2] * dt);
+      const double dqn = 1.0 / (dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w);
+      const Mat3 Rdqi = quatToR(Quat{-dq.x * dqn, -dq.y * dqn, -dq.z * dqn, dq.w * dqn});
       double RJ[9];
       rightJacobianDev(wt[0] * dt, wt[1] * dt, wt[2] * dt, RJ);
       double* pr = sh.pre + t * kPreLd;
@@ -2931,6 +2956,9 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 #endif
     const int nR = nT - kb - 1;
     d4_t accD = {0, 0, 0, 0};
+    // X^T = L^-1 A^T: with the operands in this order the product comes out TRANSPOSED in the accumulator layout, which is
+    // X in the operand layout (lane (row, g) register r = X[row][4r + g]) -- exactly what the trailing update reads, so
+    // wave 0 feeds it to the update of the next diagonal tile straight from its registers
     auto panelSolve = [&](double* A) {
       d4_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -2938,10 +2966,11 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
         const int kk = 4 * q + (lane >> 4), jj = lane & 15;
         const double a = A[lop + 4 * q];
         const double b = (jj > kk) ? D[kk * kPanelLd + jj] : ((jj == kk) ? dinv[k0 + kk] : 0.0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) A[lrow + 4 * rg * kPanelLd] = acc[rg];
+      for (int rg = 0; rg < 4; ++rg) A[lop + 4 * rg] = acc[rg];
+      return acc;
     };
     if (wave == 0) {
       if (nR > 0) {
@@ -2949,13 +2978,9 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
         const double* Cb = tileAt(tiles, kb + 1, kb + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) accD[rg] = Cb[lrow + 4 * rg * kPanelLd];
-        panelSolve(A);
-        waveSync();
+        const d4_t xT = panelSolve(A);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double x = A[lop + 4 * q];
-          accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, x, accD, 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[q], xT[q], accD, 0, 0, 0);
       }
     } else {
       for (int ti = wave; ti < nR; ti += nW - 1) panelSolve(tileAt(tiles, kb + 1 + ti, kb));
@@ -3906,57 +3931,97 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   const int nBlkItems = p.nPose + p.nExt + p.nSb;
   const bool stagedItems = fuseRadius > 0.0 && staged && nBlkItems <= kStageItems;
   const int cholFailIn = p.scal->cholFail;  // set by earlier kernels only
+  // Memory round trips of a landmark block: (1) the observation range of the lane group's first landmark, (2) that
+  // observation's Jacobians and residual.  The staging loads are issued between the two and land in their shadow.
+  struct RawObs { uint32_t idx; double jp[12], je[12], jl[6], rr[2]; };
+  const size_t N = (size_t)p.N;
+  auto loadRaw = [&](size_t o, RawObs& w) {
+    w.idx = p.obsIdx[o];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w.jp[k] = p.JpCur[k * N + o];
+    if (WITH_EXT) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) w.je[k] = p.JeCur[k * N + o];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w.jl[k] = p.JlCur[k * N + o];
+    w.rr[0] = p.rCur[o]; w.rr[1] = p.rCur[N + o];
+  };
+  int firstStart = 0, firstEnd = 0;
+  const bool lmBlock = b < nLmBlocks && b * 16 + (t >> 4) < p.L;
+  if (lmBlock) { firstStart = p.lmPtr[b * 16 + (t >> 4)]; firstEnd = p.lmPtr[b * 16 + (t >> 4) + 1]; }
+  double sy0 = 0, sy1 = 0, sv0 = 0, sv1 = 0;
   if (staged) {
-    for (int i = t; i < p.d; i += blockDim.x) { sYV[i] = p.yC[i]; sYV[kStageMax + i] = p.vC[i]; }
+    if (t < p.d) { sy0 = p.yC[t]; sv0 = p.vC[t]; }
+    if (t + 256 < p.d) { sy1 = p.yC[t + 256]; sv1 = p.vC[t + 256]; }
   }
+  int so0 = -1, so1 = -1;
   if (stagedOff) {
-    for (int i = t; i < p.nPose; i += blockDim.x) sOff[i] = p.poseOff[i];
-    for (int i = t; i < p.nExt; i += blockDim.x) sOff[kStageBlk + i] = p.extOff[i];
+    if (t < p.nPose) so0 = p.poseOff[t];
+    if (t < p.nExt) so1 = p.extOff[t];
   }
+  double ix[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int ioff = -1;
   if (stagedItems && t < nBlkItems) {
     const bool isSb = t >= p.nPose + p.nExt, isPose = t < p.nPose;
     const int slot = isSb ? t - p.nPose - p.nExt : (isPose ? t : t - p.nPose);
     const double* xp = isSb ? p.sb + (size_t)slot * 9 : (isPose ? p.pose : p.ext) + (size_t)slot * 7;
-    sItemOff[t] = isSb ? p.sbOff[slot] : (isPose ? p.poseOff[slot] : p.extOff[slot]);
+    ioff = isSb ? p.sbOff[slot] : (isPose ? p.poseOff[slot] : p.extOff[slot]);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sItemX[t * 9 + k] = (k < (isSb ? 9 : 7)) ? xp[k] : 0.0;
+    for (int k = 0; k < 9; ++k) ix[k] = (k < (isSb ? 9 : 7)) ? xp[k] : 0.0;
   }
-  // (the observation range of this lane group's first landmark rides on the same round trip)
-  int firstStart = 0, firstEnd = 0;
-  if (b < nLmBlocks && b * 16 + (t >> 4) < p.L) { firstStart = p.lmPtr[b * 16 + (t >> 4)]; firstEnd = p.lmPtr[b * 16 + (t >> 4) + 1]; }
+  RawObs raw0;
+  const bool has0 = lmBlock && (t & 15) < firstEnd - firstStart;
+  if (has0) loadRaw((size_t)firstStart + (t & 15), raw0);
+  if (staged) {
+    if (t < p.d) { sYV[t] = sy0; sYV[kStageMax + t] = sv0; }
+    if (t + 256 < p.d) { sYV[t + 256] = sy1; sYV[kStageMax + t + 256] = sv1; }
+  }
+  if (stagedOff) {
+    if (t < p.nPose) sOff[t] = so0;
+    if (t < p.nExt) sOff[kStageBlk + t] = so1;
+  }
+  if (stagedItems && t < nBlkItems) {
+    sItemOff[t] = ioff;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sItemX[t * 9 + k] = ix[k];
+  }
   if (staged || stagedOff || stagedItems) __syncthreads();
   if (b < nLmBlocks) {
     const int grp = t >> 4, gl = t & 15;
-    const size_t N = (size_t)p.N;
     const double* yCs = staged ? sYV : p.yC;
     const double* vCs = staged ? sYV + kStageMax : p.vC;
     const int* poseOffS = stagedOff ? sOff : p.poseOff;
     const int* extOffS = stagedOff ? sOff + kStageBlk : p.extOff;
-    // u_y = Jc y_C, u_v = Jc v_C, Jl and r of observation o
-    auto loadObs = [&](size_t o, double* jl, double* uy, double* uv, double* rr) {
-      const uint32_t idx = p.obsIdx[o];
-      const int offP = poseOffS[idx & 0xfff];
+    // u_y = Jc y_C, u_v = Jc v_C, Jl and r of an observation whose raw data are in registers
+    auto finishObs = [&](const RawObs& w, double* jl, double* uy, double* uv, double* rr) {
+      const int offP = poseOffS[w.idx & 0xfff];
       uy[0] = uy[1] = uv[0] = uv[1] = 0;
       if (offP >= 0) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          const double j0 = p.JpCur[a * N + o], j1 = p.JpCur[(6 + a) * N + o], y = yCs[offP + a], v = vCs[offP + a];
+          const double j0 = w.jp[a], j1 = w.jp[6 + a], y = yCs[offP + a], v = vCs[offP + a];
           uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
         }
       }
       if (WITH_EXT) {
-        const int offE = extOffS[(idx >> 12) & 0xfff];
+        const int offE = extOffS[(w.idx >> 12) & 0xfff];
         if (offE >= 0) {
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
-            const double j0 = p.JeCur[a * N + o], j1 = p.JeCur[(6 + a) * N + o], y = yCs[offE + a], v = vCs[offE + a];
+            const double j0 = w.je[a], j1 = w.je[6 + a], y = yCs[offE + a], v = vCs[offE + a];
             uy[0] += j0 * y; uy[1] += j1 * y; uv[0] += j0 * v; uv[1] += j1 * v;
           }
         }
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) jl[k] = p.JlCur[k * N + o];
-      rr[0] = p.rCur[o]; rr[1] = p.rCur[N + o];
+      for (int k = 0; k < 6; ++k) jl[k] = w.jl[k];
+      rr[0] = w.rr[0]; rr[1] = w.rr[1];
+    };
+    auto loadObs = [&](size_t o, double* jl, double* uy, double* uv, double* rr) {
+      RawObs w;
+      loadRaw(o, w);
+      finishObs(w, jl, uy, uv, rr);
     };
     for (int l = b * 16 + grp; l < p.L; l += nLmBlocks * 16) {
       const bool first = l == b * 16 + grp;
@@ -3970,7 +4035,8 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
       double cjl[6], cuy[2], cuv[2], crr[2];  // first observation of this lane stays in registers
       for (int i = gl; i < n; i += 16) {
         double jl[6], uy[2], uv[2], rr[2];
-        loadObs((size_t)start + i, jl, uy, uv, rr);
+        if (first && i == gl) finishObs(raw0, jl, uy, uv, rr);
+        else loadObs((size_t)start + i, jl, uy, uv, rr);
         t0 += jl[0] * uy[0] + jl[3] * uy[1];
         t1 += jl[1] * uy[0] + jl[4] * uy[1];
         t2 += jl[2] * uy[0] + jl[5] * uy[1];
@@ -4014,23 +4080,37 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     }
   } else if (b < nLmBlocks + nFacBlocks) {
     if (p.ownsCamera) {
-      const int wave = t >> 6, lane = t & 63;
+      // one wave per factor, lane = (row a = lane & 15, column quarter lane >> 4): the row's products with v_C and y_C are
+      // split over four lanes (a thread per row walked up to 30 columns of dependent global loads: these blocks were the
+      // last to finish), the solution vectors come from the staged copy
+      const int wave = t >> 6, lane = t & 63, a = lane & 15, cq = lane >> 4;
+      const double* yCf = staged ? sYV : p.yC;
+      const double* vCf = staged ? sYV + kStageMax : p.vC;
       for (int f = (b - nLmBlocks) * 4 + wave; f < p.F; f += nFacBlocks * 4) {
         const FactorLin& lin = p.linCur[f];
-        if (lane < lin.m) {
-          double uv = 0, uy = 0;
-          int base = 0;
-          for (int bb = 0; bb < 4; ++bb) {
-            if (lin.off[bb] >= 0)
-              for (int c = 0; c < lin.dim[bb]; ++c) {
-                const double j = lin.J[lane * lin.ncols + base + c];
-                uv += j * p.vC[lin.off[bb] + c];
-                uy += j * p.yC[lin.off[bb] + c];
-              }
-            base += lin.dim[bb];
+        const int m = lin.m, ncols = lin.ncols;
+        const int o0 = lin.off[0], o1 = lin.off[1], o2 = lin.off[2], o3 = lin.off[3];
+        const int d0 = lin.dim[0], d1 = lin.dim[1], d2 = lin.dim[2];
+        double uv = 0, uy = 0;
+        if (a < m) {
+          for (int c = cq; c < ncols; c += 4) {
+            // column c -> (block, offset within the block)
+            const int bb = (c >= d0) + (c >= d0 + d1) + (c >= d0 + d1 + d2);
+            const int off = bb == 0 ? o0 : (bb == 1 ? o1 : (bb == 2 ? o2 : o3));
+            const int cc = c - (bb == 0 ? 0 : (bb == 1 ? d0 : (bb == 2 ? d0 + d1 : d0 + d1 + d2)));
+            if (off >= 0) {
+              const double j = lin.J[a * ncols + c];
+              uv += j * vCf[off + cc];
+              uy += j * yCf[off + cc];
+            }
           }
-          const double r = lin.r[lane];
-          acc[0] += uv * uv; acc[1] += uy * uy; acc[2] += uv * uy; acc[3] += uv * r; acc[4] += uy * r;
+        }
+        // the four column quarters of a row sit in the four 16-lane rows of the wave
+        const double uvA = uv + __shfl_xor(uv, 16, 64), uyA = uy + __shfl_xor(uy, 16, 64);
+        const double uvT = uvA + __shfl_xor(uvA, 32, 64), uyT = uyA + __shfl_xor(uyA, 32, 64);
+        if (cq == 0 && a < m) {
+          const double r = lin.r[a];
+          acc[0] += uvT * uvT; acc[1] += uyT * uyT; acc[2] += uvT * uyT; acc[3] += uvT * r; acc[4] += uyT * r;
         }
       }
     }
