@@ -120,6 +120,16 @@ int svin_ba_add_observations(svin_ba* h, int n, const uint64_t* landmark_ids, co
 int svin_ba_remove_observation(svin_ba* h, uint64_t landmark_id, uint64_t pose_id, uint64_t cam_idx,
                                uint64_t keypoint_idx);                                 /* :452-474 */
 int svin_ba_remove_observation_by_id(svin_ba* h, uint64_t residual_id);               /* :432-449 */
+/* HomogeneousPointError on a landmark (okvis_ceres/src/HomogeneousPointError.cpp:48-117, <3,4>): error = landmark -
+ * measurement (first three homogeneous components), weighted by the upper Cholesky factor of the 3x3 information
+ * (row-major; the variance constructor :52-55 is information = I / variance).  okvis::Estimator never adds one; the
+ * entry point is for callers that build such priors themselves (the reference does it through Map::addResidualBlock).
+ * It takes part in the Schur elimination of its landmark, the cost and the landmark quality like any residual of the
+ * block.  Returns the residual id (0: unknown landmark / information not positive definite).  A landmark that carries
+ * one does not take part in svin_ba_apply_marginalization_strategy (error if it is observed from a leaving frame). */
+uint64_t svin_ba_add_homogeneous_point_error(svin_ba* h, uint64_t landmark_id, const double measurement[4],
+                                             const double information[9]);
+int svin_ba_remove_homogeneous_point_error(svin_ba* h, uint64_t residual_id);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 int svin_ba_optimize(svin_ba* h, uint64_t num_iter, uint64_t num_threads_ignored, int verbose); /* :876-929 */
@@ -251,6 +261,11 @@ int svin_host_reprojection_error(int distortion_model, const double intr[4], con
                                  const double T_WS[7], const double hp_W[4], const double T_SC[7], const double uv[2],
                                  const double information[4], double residual[2], double* J_pose_min, double* J_lm_min,
                                  double* J_ext_min, double* J_pose, double* J_lm, double* J_ext);
+
+/* svin_host_homogeneous_point_error: HomogeneousPointError::EvaluateWithMinimalJacobians (HomogeneousPointError.cpp:85-117):
+ * residual[3]; J_min 3x3 (= the square-root information); J 3x4 (last column zero).  Jacobian pointers may be NULL. */
+int svin_host_homogeneous_point_error(const double hp_W[4], const double measurement[4], const double information[9],
+                                      double residual[3], double* J_min, double* J);
 
 /* ---- inspection / parity hooks (ErrorInterface::EvaluateWithMinimalJacobians, Map::getLhs) ---- */
 /* Evaluates every reprojection residual of the window on the GPU at the current estimates.

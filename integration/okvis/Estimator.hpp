@@ -164,6 +164,12 @@ class Estimator : public VioBackendInterface {
   bool removeObservation(uint64_t landmarkId, uint64_t poseId, size_t camIdx, size_t keypointIdx) override {   // :452-474
     return check(svin_ba_remove_observation(h_, landmarkId, poseId, camIdx, keypointIdx), "svin_ba_remove_observation");
   }
+  /// NOT a member of the reference's Estimator: the route by which a caller puts an okvis::ceres::HomogeneousPointError on a
+  /// landmark of the window (the reference does it with mapPtr_->addResidualBlock(std::make_shared<HomogeneousPointError>(..)),
+  /// HomogeneousPointError.cpp:48-117).  information: 3x3 row-major.  Returns the residual id, 0 on failure.
+  uint64_t addHomogeneousPointError(uint64_t landmarkId, const Eigen::Vector4d& measurement, const double information[9]) {
+    return svin_ba_add_homogeneous_point_error(h_, landmarkId, measurement.data(), information);
+  }
 
   /// Estimator::applyMarginalizationStrategy (Estimator.cpp:495-814)
   bool applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, okvis::MapPointVector& removedLandmarks) {

@@ -140,6 +140,15 @@ int svin_ba_remove_observation_by_id(svin_ba* h, uint64_t rid) {
   GUARD_BEGIN return h->w.removeObservationById(rid);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+uint64_t svin_ba_add_homogeneous_point_error(svin_ba* h, uint64_t lm, const double* meas, const double* info) {
+  if (!h || !meas || !info) return 0;
+  try { return h->w.addLandmarkPrior(lm, meas, info); } catch (const std::exception& e) { svin::lastError() = e.what(); return 0; }
+}
+int svin_ba_remove_homogeneous_point_error(svin_ba* h, uint64_t rid) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.removeLandmarkPrior(rid);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_optimize(svin_ba* h, uint64_t num_iter, uint64_t, int verbose) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.optimize(num_iter, verbose != 0);

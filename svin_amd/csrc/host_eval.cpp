@@ -314,4 +314,32 @@ int svin_host_reprojection_error(int model, const double intr[4], const double* 
   return 1;
 }
 
+int svin_host_homogeneous_point_error(const double hp[4], const double meas[4], const double info[9], double residual[3],
+                                      double* J_min, double* J) {
+  if (!hp || !meas || !info || !residual) return -1;
+  // squareRootInformation_ = L^T, information = L L^T (HomogeneousPointError.cpp:66-75)
+  double L[9] = {0};
+  for (int j = 0; j < 3; ++j) {
+    double dsum = info[j * 3 + j];
+    for (int k = 0; k < j; ++k) dsum -= L[j * 3 + k] * L[j * 3 + k];
+    if (!(dsum > 0)) return 0;
+    L[j * 3 + j] = std::sqrt(dsum);
+    for (int i = j + 1; i < 3; ++i) {
+      double v = info[i * 3 + j];
+      for (int k = 0; k < j; ++k) v -= L[i * 3 + k] * L[j * 3 + k];
+      L[i * 3 + j] = v / L[j * 3 + j];
+    }
+  }
+  const double e[3] = {hp[0] - meas[0], hp[1] - meas[1], hp[2] - meas[2]};   // HomogeneousPointManifold::minus
+  for (int a = 0; a < 3; ++a) {
+    residual[a] = L[0 * 3 + a] * e[0] + L[1 * 3 + a] * e[1] + L[2 * 3 + a] * e[2];
+    for (int b = 0; b < 3; ++b) {
+      if (J_min) J_min[a * 3 + b] = L[b * 3 + a];
+      if (J) J[a * 4 + b] = L[b * 3 + a];
+    }
+    if (J) J[a * 4 + 3] = 0.0;
+  }
+  return 1;
+}
+
 }  // extern "C"

@@ -173,17 +173,19 @@ void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, uns
 // Block-wide reduction of K values at once: out[k] valid in threads 0..K-1 (as `mine`), `red` holds 4*K doubles.
 template <int K>
 __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, int kMaxIndex) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nW = (blockDim.x + 63) >> 6;
+  // 16-lane row sums by DPP, the rows (four per wave) meet in LDS: `red` holds 4 * (blockDim / 64) * K doubles.
+  // (Finishing each wave's sum in registers first costs 11 more instructions per value on what is usually a serial tail.)
+  const int lane = threadIdx.x & 63, row = threadIdx.x >> 4, nRows = (blockDim.x + 15) >> 4;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const double s = (k == kMaxIndex) ? waveMax(v[k]) : waveSum(v[k]);
-    if (lane == 0) red[w * K + k] = s;
+    const double s = (k == kMaxIndex) ? rowMax16(v[k]) : rowSum16(v[k]);
+    if ((lane & 15) == 0) red[row * K + k] = s;
   }
   __syncthreads();
   double mine = 0;
   if ((int)threadIdx.x < K) {
-    for (int i = 0; i < nW; ++i) {
+    for (int i = 0; i < nRows; ++i) {
       const double x = red[i * K + threadIdx.x];
       mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
     }
@@ -193,7 +195,7 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
 
 // Tail of the cost evaluation (last block): everything it needs from memory is requested in ONE round trip -- the
 // two partial lists AND the other scalars of the record (written by earlier kernels) -- then one block sum; the record
-// is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 24 doubles.
+// is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 72 doubles.
 // nDefer > 0: the reprojection blocks also took the landmark half of the fused step; their step / state norm partials are
 // added to the (block-only) sums k_post_solve left in the record.
 __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, int nDefer = 0) {
@@ -208,8 +210,8 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, 
     s[3] += cload(p.partial + (size_t)PS_XNORM * kMaxPartials + i);
   }
   double rec = (t < nD) ? cload(reinterpret_cast<const double*>(p.scal) + t) : 0.0;  // slot 3 = costPrior of this evaluation (cstore()d)
-  const double mine = blockSumK<4>(s, red, -1);   // red[0..15]
-  double* fields = red + 16;
+  const double mine = blockSumK<4>(s, red, -1);   // red[0..63]
+  double* fields = red + 64;
   if (t < 4 && t != 3) fields[t == 2 ? 4 : t] = mine;
   if (t == 3) { fields[5] = mine; fields[3] = (p.ownsCamera && p.priorM > 0) ? rec : 0.0; }
   __syncthreads();
@@ -404,7 +406,7 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
                                                 const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
                                                 double* __restrict__ r, double* __restrict__ Jp, double* __restrict__ Jl,
                                                 double* __restrict__ Je, double* __restrict__ costPartial, size_t stride,
-                                                const LmDefer* df = nullptr) {
+                                                const LmDefer* df = nullptr, const double* __restrict__ lmPrior = nullptr) {
   double* sPose = smem;                      // nPose*7
   double* sExt = sPose + nPose * 7;          // nExt*7
   CameraModel* sCam = reinterpret_cast<CameraModel*>(sExt + nExt * 7);  // nCam
@@ -443,9 +445,26 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
       for (int k = 0; k < 4; ++k) hpw[k] = xo[k];
     }
     double rr[2], jp[12], jl[6], je[12];
-    reprojEval(sCam[cs], sPose + ps * 7, hpw, sExt + es * 7, uv.x, uv.y, w, rr, jp, jl, je);
+    const bool isPrior = cs == kPriorCam;
+    if (isPrior) {
+      // HomogeneousPointError (HomogeneousPointError.cpp:77-117) as two pseudo-observations of its landmark: e = lm - meas
+      // (first three components), r = S e with S the upper-triangular square-root information; uv = (index into the
+      // prior table, part): part 0 carries rows 0 and 1 of S, part 1 row 2 and a zero row.  No loss function.
+      const double* pr = lmPrior + 12 * (int)uv.x;
+      const bool second = uv.y != 0.0;
+      const double e0 = hpw[0] - pr[0], e1 = hpw[1] - pr[1], e2 = hpw[2] - pr[2];
+      const double* Sa = pr + 3 + (second ? 6 : 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { jl[k] = Sa[k]; jl[3 + k] = second ? 0.0 : pr[6 + k]; }
+      rr[0] = jl[0] * e0 + jl[1] * e1 + jl[2] * e2;
+      rr[1] = jl[3] * e0 + jl[4] * e1 + jl[5] * e2;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { jp[k] = 0.0; je[k] = 0.0; }
+    } else {
+      reprojEval(sCam[cs], sPose + ps * 7, hpw, sExt + es * 7, uv.x, uv.y, w, rr, jp, jl, je);
+    }
     const double s = rr[0] * rr[0] + rr[1] * rr[1];
-    if (ROBUST) {
+    if (ROBUST && !isPrior) {
       // Ceres Corrector for CauchyLoss(1): rho'' < 0 always -> residual and Jacobian scale by sqrt(rho')
       double rho0, rho1, rho2;
       cauchyLoss(s, rho0, rho1, rho2);
@@ -475,7 +494,7 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
     }
   }
   if (costPartial) {
-    if (df) {  // red: >= 12 doubles
+    if (df) {  // red: >= 48 doubles
       const double v3[3] = {cost, stepSq, xSq};
       const double mine = blockSumK<3>(v3, red, -1);
       if (threadIdx.x == 0) cstore(costPartial + block, mine);
@@ -496,11 +515,12 @@ __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt,
                                                      const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
                                                      double* __restrict__ r, double* __restrict__ Jp,
                                                      double* __restrict__ Jl, double* __restrict__ Je,
-                                                     double* __restrict__ costPartial, size_t stride) {
+                                                     double* __restrict__ costPartial, size_t stride,
+                                                     const double* __restrict__ lmPrior) {
   extern __shared__ double smem[];
   __shared__ double red[4];
   evalReprojBlock<ROBUST, WITH_EXT>(blockIdx.x, smem, red, N, nPose, nExt, nCam, pose, ext, lm, cams, obsUv, obsW, obsIdx,
-                                    obsLm, r, Jp, Jl, Je, costPartial, stride);
+                                    obsLm, r, Jp, Jl, Je, costPartial, stride, nullptr, lmPrior);
 }
 
 static int evalGrid(int N) { return (N + 127) / 128; }
@@ -519,7 +539,7 @@ void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_
   double* cp = p.partial + (size_t)PS_COST_REPROJ * kMaxPartials;
 #define LAUNCH(R, E)                                                                                              \
   hipLaunchKernelGGL((k_eval_reproj<R, E>), dim3(grid), dim3(128), smem, s, p.N, p.nPose, p.nExt, p.nCam, pose, ext, \
-                     lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, r, Jp, Jl, Je, cp, (size_t)p.N)
+                     lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, r, Jp, Jl, Je, cp, (size_t)p.N, p.lmPrior)
   if (robust) { if (p.anyExtVariable) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (p.anyExtVariable) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -537,11 +557,11 @@ void launchEvalReprojBatched(const DeviceProblem& p, int copies, double* rOut, d
   if (p.anyExtVariable)
     hipLaunchKernelGGL((k_eval_reproj<true, true>), dim3(grid), dim3(128), smem, s, NB, p.nPose, p.nExt, p.nCam, p.pose,
                        p.ext, p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, rOut, JpOut, JlOut, JeOut,
-                       (double*)nullptr, (size_t)NB);
+                       (double*)nullptr, (size_t)NB, p.lmPrior);
   else
     hipLaunchKernelGGL((k_eval_reproj<true, false>), dim3(grid), dim3(128), smem, s, NB, p.nPose, p.nExt, p.nCam,
                        p.pose, p.ext, p.lm, p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm, rOut, JpOut, JlOut, JeOut,
-                       (double*)nullptr, (size_t)NB);
+                       (double*)nullptr, (size_t)NB, p.lmPrior);
 }
 
 // ================================================================ K2: small factors (one workgroup each)
@@ -1648,7 +1668,7 @@ __device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
   if (t == 0) cstore(&p.scal->costPrior, 0.5 * (*p.priorC0) + tot);
 }
 __global__ __launch_bounds__(256) void k_prior_eval(DeviceProblem p, int cand, int costBlocksA) {
-  __shared__ double red[24];
+  __shared__ double red[72];
   priorEvalBlock(p, cand, red);
   if (costBlocksA >= 0) {  // last evaluation kernel of the stream: sum the total cost here
     __syncthreads();
@@ -1687,16 +1707,16 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
       df.stepPartial = p.partial + (size_t)PS_STEP * kMaxPartials;
       df.xPartial = p.partial + (size_t)PS_XNORM * kMaxPartials;
     }
-    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 16, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
+    evalReprojBlock<true, WITH_EXT>(blockIdx.x - F, smem + 48, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
                                     cand ? p.extC : p.ext, defer ? p.lm : (cand ? p.lmC : p.lm), p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
                                     cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
                                     cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N,
-                                    defer ? &df : nullptr);
+                                    defer ? &df : nullptr, p.lmPrior);
   }
   TRACE(18);
   if (sumCost) {
     __shared__ int lastFlag;
-    __shared__ double red4[24];
+    __shared__ double red4[72];
     if (lastBlockDoneLight(&p.tickets[TK_EVAL], &lastFlag)) {   // (cost partials and costPrior are cstore()d)
       TRACE(19);
       reduceCost(p, nR, F, red4, (cand && p.lmDeferred) ? nR : 0);
@@ -3864,7 +3884,7 @@ __device__ __forceinline__ void retractItem(const DeviceProblem& p, int i, doubl
 // stand-alone dogleg step + retraction (re-used linearisation after a rejected step, multi-GPU mode, wide windows);
 // the last block reduces the norms
 __global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) {
-  __shared__ double red[4 * 2];
+  __shared__ double red[16 * 2];
   __shared__ int lastFlag;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const SolverScalars& sc = *p.scal;
@@ -3906,7 +3926,7 @@ __device__ constexpr int postSlotC(int k) {
 //  whichever block finishes last reduces all partials into SolverScalars group B.
 template <bool WITH_EXT>
 __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) {
-  __shared__ double red[4 * kPostK];
+  __shared__ double red[16 * kPostK];
   __shared__ int lastFlag;
   const int t = threadIdx.x, b = blockIdx.x;
   double acc[kPostK];
@@ -4281,7 +4301,7 @@ void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadiu
 // final single-block reduction of the cost partials into SolverScalars (used when no later evaluation kernel
 // can take it over, see evaluateAll)
 __global__ __launch_bounds__(256) void k_reduce_cost(DeviceProblem p, int nA, int nB) {
-  __shared__ double red[24];
+  __shared__ double red[72];
   reduceCost(p, nA, nB, red);
 }
 
@@ -4309,8 +4329,14 @@ __global__ __launch_bounds__(256) void k_landmark_quality(DeviceProblem p, doubl
   for (int o = p.lmPtr[l] + gl; o < oEnd; o += 16) {
     const uint32_t idx = p.obsIdx[o];
     double rr[2], jp[12], jl[6], je[12];
-    reprojEval(p.cams[(idx >> 24) & 0xf], p.pose + (size_t)(idx & 0xfff) * 7, hpw, p.ext + (size_t)((idx >> 12) & 0xfff) * 7,
-               p.obsUv[2 * (size_t)o], p.obsUv[2 * (size_t)o + 1], p.obsW[o], rr, jp, jl, je);
+    if (((idx >> 24) & 0xf) == kPriorCam) {   // landmark prior: its rows of S (Map::getLhs sums every residual of the block)
+      const double* pr = p.lmPrior + 12 * (int)p.obsUv[2 * (size_t)o];
+      const bool second = p.obsUv[2 * (size_t)o + 1] != 0.0;
+      for (int k = 0; k < 3; ++k) { jl[k] = pr[3 + (second ? 6 : 0) + k]; jl[3 + k] = second ? 0.0 : pr[6 + k]; }
+    } else {
+      reprojEval(p.cams[(idx >> 24) & 0xf], p.pose + (size_t)(idx & 0xfff) * 7, hpw, p.ext + (size_t)((idx >> 12) & 0xfff) * 7,
+                 p.obsUv[2 * (size_t)o], p.obsUv[2 * (size_t)o + 1], p.obsW[o], rr, jp, jl, je);
+    }
     a00 += jl[0] * jl[0] + jl[3] * jl[3]; a01 += jl[0] * jl[1] + jl[3] * jl[4]; a02 += jl[0] * jl[2] + jl[3] * jl[5];
     a11 += jl[1] * jl[1] + jl[4] * jl[4]; a12 += jl[1] * jl[2] + jl[4] * jl[5]; a22 += jl[2] * jl[2] + jl[5] * jl[5];
   }

@@ -20,6 +20,7 @@
 namespace svin {
 
 constexpr int kMaxCams = 8;
+constexpr int kPriorCam = 15;   // camera field of a packed index that marks a landmark-prior pseudo-observation (HomogeneousPointError)
 
 // packed per-observation index: pose slot (12 bit) | ext slot (12 bit) | camera (4 bit)
 inline __host__ __device__ uint32_t packObs(int pose, int ext, int cam) {
@@ -153,6 +154,7 @@ struct DeviceProblem {
   unsigned long long mailboxSeq;             // sequence number to publish with this evaluation
   int lmDeferred;                            // fused step: the landmark part of the retraction is taken by the candidate evaluation
   int padDeferred;
+  const double* lmPrior;                     // landmark priors: 12 doubles each (measurement xyz, upper-triangular sqrt information row-major)
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

@@ -819,6 +819,26 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     rit++;
     if (rit == states_.rend()) return 1;
   }
+  if (numLandmarkPriors_ > 0) {
+    // Landmarks that carry a HomogeneousPointError stay out of the marginalisation: the reference's policy loop assumes
+    // every residual of a landmark is a ReprojectionError (Estimator.cpp:689-698) and never meets one, because Estimator
+    // adds none.  Observed from a frame that is about to leave, such a landmark cannot be handled: refuse before anything
+    // is modified.
+    std::vector<uint64_t> leaving;
+    size_t kept = 0;
+    for (auto r2 = rit; r2 != states_.rend(); ++r2) {
+      if (!r2->second.isKeyframe || kept >= numKeyframes) leaving.push_back(r2->second.id);
+      else kept++;
+    }
+    for (const auto& kv : landmarks_) {
+      if (kv.second.priors.empty()) continue;
+      for (const Observation& o : kv.second.obs)
+        if (std::find(leaving.begin(), leaving.end(), o.poseId) != leaving.end()) {
+          lastError() = "applyMarginalizationStrategy: a landmark with a HomogeneousPointError is observed from a frame that leaves the window";
+          return -1;
+        }
+    }
+  }
   // :509-514 the old prior leaves the graph; its content is re-used below
   const bool hadPrior = hasPrior_;
   if (hadPrior) {
@@ -925,6 +945,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         if (poseId >= currentKfId) { marginalize = false; hasNewObservations = true; }
         if (contains(allLinearizedFrames, poseId)) obsCount++;
       }
+      if (!lm.priors.empty()) { pit++; continue; }   // see the guard at the top
       if (lm.obs.empty()) {
         removed.push_back(pit->first);
         pit = landmarks_.erase(pit);

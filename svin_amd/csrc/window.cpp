@@ -509,6 +509,43 @@ uint64_t Window::addObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, ui
   obsRes2Lm_[o.resId] = lmId;
   return o.resId;
 }
+// HomogeneousPointError(measurement, information) (HomogeneousPointError.cpp:58-75): squareRootInformation_ = L^T with
+// information = L L^T (Eigen::LLT)
+uint64_t Window::addLandmarkPrior(uint64_t lmId, const double* meas4, const double* info9) {
+  auto lit = landmarks_.find(lmId);
+  if (lit == landmarks_.end() || !meas4 || !info9) return 0;
+  double L[9] = {0};
+  for (int j = 0; j < 3; ++j) {
+    double dsum = info9[j * 3 + j];
+    for (int k = 0; k < j; ++k) dsum -= L[j * 3 + k] * L[j * 3 + k];
+    if (!(dsum > 0)) { lastError() = "addLandmarkPrior: information matrix is not positive definite"; return 0; }
+    L[j * 3 + j] = std::sqrt(dsum);
+    for (int i = j + 1; i < 3; ++i) {
+      double v = info9[i * 3 + j];
+      for (int k = 0; k < j; ++k) v -= L[i * 3 + k] * L[j * 3 + k];
+      L[i * 3 + j] = v / L[j * 3 + j];
+    }
+  }
+  Landmark::Prior pr;
+  pr.resId = nextResId_++;
+  std::memcpy(pr.meas, meas4, sizeof(pr.meas));
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) pr.sqrtInfo[a * 3 + b] = L[b * 3 + a];
+  lit->second.priors.push_back(pr);
+  lmPriorRes2Lm_[pr.resId] = lmId;
+  ++numLandmarkPriors_;
+  return pr.resId;
+}
+int Window::removeLandmarkPrior(uint64_t resId) {
+  auto it = lmPriorRes2Lm_.find(resId);
+  if (it == lmPriorRes2Lm_.end()) return 0;
+  Landmark& lm = landmarks_.at(it->second);
+  for (size_t i = 0; i < lm.priors.size(); ++i)
+    if (lm.priors[i].resId == resId) { lm.priors.erase(lm.priors.begin() + i); break; }
+  lmPriorRes2Lm_.erase(it);
+  --numLandmarkPriors_;
+  return 1;
+}
 int Window::removeObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint64_t kp) {  // :452-474
   auto lit = landmarks_.find(lmId);
   if (lit == landmarks_.end()) return 0;
@@ -618,6 +655,8 @@ int Window::residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const {
   auto lit = landmarks_.find(blockId);
   if (lit != landmarks_.end()) {
     for (const Observation& o : lit->second.obs) out.push_back(o.resId);
+    for (const Landmark::Prior& pr : lit->second.priors) out.push_back(pr.resId);
+    std::sort(out.begin(), out.end());
     return 1;
   }
   const Block* b = findBlock(blockId);
@@ -633,6 +672,7 @@ int Window::residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const {
 int Window::residualKind(uint64_t resId) const {
   if (obsRes2Lm_.count(resId)) return 100;
   if (hasPrior_ && resId == priorResId_) return 101;
+  if (lmPriorRes2Lm_.count(resId)) return 102;
   auto it = factors_.find(resId);
   return it == factors_.end() ? -1 : it->second.kind;
 }
@@ -649,6 +689,8 @@ int Window::parametersOf(uint64_t resId, std::vector<uint64_t>& out) const {
     for (const PriorBlockHost& pb : priorBlocks_) out.push_back(pb.id);
     return 1;
   }
+  auto pt = lmPriorRes2Lm_.find(resId);
+  if (pt != lmPriorRes2Lm_.end()) { out = {pt->second}; return 1; }
   auto it = factors_.find(resId);
   if (it == factors_.end()) return 0;
   for (int b = 0; b < it->second.nblk; ++b) out.push_back(it->second.blocks[b]);
@@ -748,7 +790,8 @@ void Window::pack() {
   // come from a small linear table (a window holds a few dozen states) instead of one hash lookup per observation.
   size_t nLmObs = 0, nObs = 0;
   for (const auto& kv : landmarks_)
-    if (!kv.second.obs.empty()) { ++nLmObs; nObs += kv.second.obs.size(); }
+    if (!kv.second.obs.empty() || !kv.second.priors.empty()) { ++nLmObs; nObs += kv.second.obs.size() + 2 * kv.second.priors.size(); }
+  std::vector<double> hLmPrior;   // 12 doubles per HomogeneousPointError: measurement xyz, sqrt information (row-major)
   std::vector<double> hLm(4 * nLmObs), hUv(2 * nObs), hW(nObs);
   std::vector<int> hLmPtr(nLmObs + 1), hObsLm(nObs);
   std::vector<uint32_t> hIdx(nObs);
@@ -773,13 +816,14 @@ void Window::pack() {
   std::vector<const Landmark*> lmOrder;
   lmOrder.reserve(nLmObs);
   for (const auto& kv : landmarks_)
-    if (!kv.second.obs.empty()) lmOrder.push_back(&kv.second);
+    if (!kv.second.obs.empty() || !kv.second.priors.empty()) lmOrder.push_back(&kv.second);
   if (poseIds_.size() > 42) {
     std::vector<std::pair<int, const Landmark*>> keyed;
     keyed.reserve(lmOrder.size());
     for (const Landmark* lm : lmOrder) {
       int first = INT32_MAX;
       for (const Observation& ob : lm->obs) first = std::min(first, poseCache.at(ob.poseId));
+      if (lm->obs.empty()) first = 0;
       keyed.emplace_back(first, lm);
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
@@ -799,6 +843,20 @@ void Window::pack() {
         hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(ob.extId), ob.cam);
         hObsLm[o] = (int)slot;
         ++o;
+      }
+      // a HomogeneousPointError = two pseudo-observations of its landmark (rows 0-1 and row 2 of S); their pose / extrinsics
+      // Jacobians are written as zeros by the evaluation, so the slots they name (0, 0) only receive zeros
+      for (const Landmark::Prior& pr : lm.priors) {
+        const double k = (double)(hLmPrior.size() / 12);
+        hLmPrior.insert(hLmPrior.end(), pr.meas, pr.meas + 3);
+        hLmPrior.insert(hLmPrior.end(), pr.sqrtInfo, pr.sqrtInfo + 9);
+        for (int part = 0; part < 2; ++part) {
+          hUv[2 * o] = k; hUv[2 * o + 1] = (double)part;
+          hW[o] = 1.0;
+          hIdx[o] = packObs(0, 0, kPriorCam);
+          hObsLm[o] = (int)slot;
+          ++o;
+        }
       }
       hLmPtr[++slot] = (int)o;
     }
@@ -869,6 +927,7 @@ void Window::pack() {
   upload(dCams_, cameras_, s);
   upload(dLmPtr_, hLmPtr, s); upload(dObsLm_, hObsLm, s); upload(dObsUv_, hUv, s); upload(dObsW_, hW, s);
   upload(dObsIdx_, hIdx, s);
+  upload(dLmPrior_, hLmPrior, s);
   for (int k = 0; k < 2; ++k) { dLin_[k].reserve(std::max<size_t>((size_t)32 * N, 1)); dFacLin_[k].reserve(std::max(F, 1)); }
   upload(dFactors_, hFac, s); upload(dImus_, hImu, s); upload(dImuT_, hImuT, s); upload(dImuM_, hImuM, s);
   if (hasPrior_) {
@@ -997,6 +1056,7 @@ void Window::pack() {
   p.schurPanels = schurPanels ? 1 : 0; p.nPanelBlocks = nPanelBlocks; p.nPanelPairs = nPanelPairs;
   p.panelWork = reinterpret_cast<const int4*>(dPanelWork_.p); p.panelChunks = dPanelChunks_.p; p.panelPairPtr = dPanelPairPtr_.p;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
+  p.lmPrior = dLmPrior_.p;
   curSet_ = 0;
   auto setLin = [&](int set, double*& r, double*& Jp, double*& Jl, double*& Je) {
     double* base = dLin_[set].p;
@@ -1355,6 +1415,16 @@ int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t*
       }
       ++n;
     }
+    for (const Landmark::Prior& pr : l.priors)   // the two pseudo-observations of a HomogeneousPointError: pose 0, camera 15
+      for (int part = 0; part < 2; ++part) {
+        if (n < cap) {
+          if (rid) rid[n] = pr.resId;
+          if (lm) lm[n] = l.id;
+          if (pose) pose[n] = 0;
+          if (cam) cam[n] = kPriorCam;
+        }
+        ++n;
+      }
   }
   return n;
 }

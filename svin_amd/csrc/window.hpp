@@ -54,6 +54,10 @@ struct Landmark {
   double quality = 0, distance = 0;
   bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
   std::vector<Observation> obs;  // insertion order
+  // HomogeneousPointError residuals on this landmark (HomogeneousPointError.cpp:48-117): measurement and the
+  // upper-triangular square-root information (row-major); not added by okvis::Estimator, available to callers
+  struct Prior { uint64_t resId = 0; double meas[4] = {0, 0, 0, 1}; double sqrtInfo[9] = {0}; };
+  std::vector<Prior> priors;
 };
 
 struct Factor {
@@ -151,6 +155,9 @@ class Window {
   uint64_t addObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
   int removeObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp);
   int removeObservationById(uint64_t resId);
+  // HomogeneousPointError on a landmark (information = 3x3 symmetric positive definite, row-major); 0 on failure
+  uint64_t addLandmarkPrior(uint64_t lm, const double* meas4, const double* information9);
+  int removeLandmarkPrior(uint64_t resId);
   int optimize(size_t numIter, bool verbose);
   int prepare();
   int solvePrepared(size_t numIter, bool verbose);
@@ -186,7 +193,7 @@ class Window {
   int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
   int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
   int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
-  int residualKind(uint64_t resId) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, else FactorKind
+  int residualKind(uint64_t resId) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, 102 landmark prior, else FactorKind
   const std::map<uint64_t, State>& states() const { return states_; }
   const std::map<uint64_t, Landmark>& landmarks() const { return landmarks_; }
   uint64_t currentKeyframeId() const;
@@ -263,6 +270,9 @@ class Window {
   std::unordered_map<uint64_t, Block> blocks_;
   std::map<uint64_t, Factor> factors_;
   std::unordered_map<uint64_t, uint64_t> obsRes2Lm_;  // reprojection residual id -> landmark id
+  std::unordered_map<uint64_t, uint64_t> lmPriorRes2Lm_;  // HomogeneousPointError residual id -> landmark id
+  size_t numLandmarkPriors_ = 0;
+  DevBuf<double> dLmPrior_;
   uint64_t nextResId_ = 1;
 
   // marginalisation prior (host bookkeeping + device matrices mirrored on the host for the C API)

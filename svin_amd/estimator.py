@@ -64,7 +64,8 @@ EXPORTS = [
     "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl",
     "svin_ba_parameter_block_exists", "svin_ba_set_parameter_block_constant", "svin_ba_is_parameter_block_constant",
     "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
-    "svin_host_imu_propagation", "svin_host_reprojection_error",
+    "svin_host_imu_propagation", "svin_host_reprojection_error", "svin_host_homogeneous_point_error",
+    "svin_ba_add_homogeneous_point_error", "svin_ba_remove_homogeneous_point_error",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -110,6 +111,9 @@ def load_library():
         C.POINTER(u64), C.POINTER(i32))
     sig("svin_ba_remove_observation", i32, vp, u64, u64, u64, u64)
     sig("svin_ba_remove_observation_by_id", i32, vp, u64)
+    sig("svin_ba_add_homogeneous_point_error", u64, vp, u64, pd, pd)
+    sig("svin_ba_remove_homogeneous_point_error", i32, vp, u64)
+    sig("svin_host_homogeneous_point_error", i32, pd, pd, pd, pd, pd, pd)
     sig("svin_ba_optimize", i32, vp, u64, u64, i32)
     sig("svin_ba_prepare", i32, vp)
     sig("svin_ba_solve_prepared", i32, vp, u64, i32)
@@ -202,6 +206,17 @@ def host_imu_propagation(imu_t, imu_m, params, T, sb, t0, t1, want_cov=False, wa
     n = L.svin_host_imu_propagation(s.ctypes.data_as(C.c_void_p), len(s), C.byref(q), _d(T), _d(sb), t0[0], t0[1], t1[0], t1[1],
                                     _d(cov), _d(jac), _d(integ))
     return n, T, sb, cov, jac, integ
+
+
+def host_homogeneous_point_error(hp, measurement, information):
+    """CPU twin of HomogeneousPointError::EvaluateWithMinimalJacobians: (residual[3], J_min 3x3, J 3x4)"""
+    L = load_library()
+    r, Jm, J = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 4))
+    rc = L.svin_host_homogeneous_point_error(_d(_arr(hp)), _d(_arr(measurement)), _d(_arr(np.asarray(information, float).reshape(3, 3))),
+                                             _d(r), _d(Jm), _d(J))
+    if rc != 1:
+        raise RuntimeError("svin_host_homogeneous_point_error failed (%d)" % rc)
+    return r, Jm, J
 
 
 def host_reprojection_error(model, intr, dist, T_WS, hp, T_SC, uv, information):
@@ -347,6 +362,15 @@ class Estimator:
 
     def remove_observation_by_id(self, rid):
         return bool(self._check(self.L.svin_ba_remove_observation_by_id(self.h, rid), "remove_observation_by_id"))
+
+    def add_homogeneous_point_error(self, lid, measurement, information=None, variance=None):
+        """HomogeneousPointError on a landmark; information 3x3 or variance (information = I / variance); returns the residual id"""
+        info = np.eye(3) / variance if information is None else np.asarray(information, float).reshape(3, 3)
+        m, info = _arr(measurement), _arr(info)
+        return int(self.L.svin_ba_add_homogeneous_point_error(self.h, lid, _d(m), _d(info)))
+
+    def remove_homogeneous_point_error(self, rid):
+        return bool(self._check(self.L.svin_ba_remove_homogeneous_point_error(self.h, rid), "remove_homogeneous_point_error"))
 
     # -- hot path ---------------------------------------------------------------------------------
     def optimize(self, num_iter, num_threads=1, verbose=False):

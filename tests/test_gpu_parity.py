@@ -887,3 +887,76 @@ def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P
     assert o["selfH"] < 1e-9
     assert o["dH"] < 1e-6 and o["dJtJ"] < 1e-6
     assert worst < (1e-4 if rig == "euroc" else 5e-3)
+
+
+@pytest.mark.parametrize("rig", ["euroc", "rig_v2"])
+def test_homogeneous_point_error_in_the_window(gpu_lib, rig):
+    """U6: HomogeneousPointError residuals on landmarks of the window (svin_ba_add_homogeneous_point_error; the oracle adds
+    the same term through its Map).  They ride as pseudo-observations of their landmark -- Schur elimination, cost,
+    back-substitution and landmark quality see them like any residual of the block.  Checked: residual / Jacobian of the
+    pseudo-observations, cost and iterates against the oracle, a prior-only landmark (no observations) being pulled onto
+    its measurement (TestHomogeneousPointError.cpp:97-99: final cost < 1e-10 for that term), the graph queries, removal,
+    and that marginalisation refuses to touch such landmarks."""
+    from oracle import orc
+    spec = syn.make_window(P=4, L=120, n_obs=1000, seed=71, rig=rig)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    rng = np.random.default_rng(3)
+    L = orc.lib()
+    cmap = cpu.map()
+    pri = []
+    for k in range(0, 40, 3):
+        pg, pc = gpu.get_landmark(lg[k])["point"], cpu.get_landmark(lc[k])["point"]
+        assert np.array_equal(pg, pc)
+        meas = np.r_[pg[:3] + rng.normal(size=3) * 0.05, 1.0]
+        var = float(rng.uniform(0.001, 0.05))
+        rid = gpu.add_homogeneous_point_error(lg[k], meas, variance=var)
+        assert rid != 0
+        assert L.orc_map_add_hpoint_error(cmap.h, orc.dptr(orc.arr(meas)), var, lc[k]) != 0
+        pri.append((k, rid, meas, var))
+    # a landmark nobody observes, held only by its prior (GPU side only)
+    far = gpu.new_id()
+    target, start = np.array([2.0, -1.0, 4.0, 1.0]), np.array([2.5, -0.5, 5.0, 1.0])
+    assert gpu.add_landmark(far, start)
+    rid_far = gpu.add_homogeneous_point_error(far, target, variance=0.01)
+    assert rid_far != 0
+    ids, kind = gpu.parameters_of(rid_far)
+    assert ids == [far] and kind == 102 and rid_far in gpu.residuals_of(far)
+    assert gpu.add_homogeneous_point_error(123456789, target, variance=0.01) == 0          # unknown landmark
+    assert gpu.add_homogeneous_point_error(far, target, information=-np.eye(3)) == 0        # not positive definite
+    # residuals / Jacobians of the pseudo-observations at the initial state
+    ev = gpu.eval_reprojection(robust=True)
+    assert int(np.sum(ev["cam"] == 15)) == 2 * (len(pri) + 1)
+    for k, rid, meas, var in pri:
+        rows = [i for i in range(len(ev["r"])) if ev["res_id"][i] == rid]
+        assert len(rows) == 2 and all(ev["lm_id"][i] == lg[k] for i in rows)
+        e = gpu.get_landmark(lg[k])["point"][:3] - meas[:3]
+        r3 = np.r_[ev["r"][rows[0]], ev["r"][rows[1]][:1]]
+        assert np.max(np.abs(r3 - e / np.sqrt(var))) < 1e-12 and ev["r"][rows[1]][1] == 0.0
+        assert np.max(np.abs(ev["Jl"][rows[0]] - np.eye(3)[:2] / np.sqrt(var))) < 1e-12
+        assert np.max(np.abs(ev["Jl"][rows[1]] - np.array([[0, 0, 1 / np.sqrt(var)], [0, 0, 0]]))) < 1e-12
+        assert np.all(ev["Jp"][rows[0]] == 0) and np.all(ev["Je"][rows[1]] == 0)
+    for e in (gpu, cpu):
+        e.set_solver_options(1e-12, 1e-12, 1e-12)
+    gpu.optimize(30)
+    cpu.optimize(30)
+    sg, sc = gpu.summary(), cpu.summary()
+    log(rig, "landmark priors: gpu", sg, "cpu", sc)
+    # the far landmark's term, 0.5 |r|^2 at the start, is part of the GPU's initial cost only
+    far_cost0 = 0.5 * float(np.sum((start[:3] - target[:3]) ** 2)) / 0.01
+    assert abs((sg["initial_cost"] - far_cost0) - sc["initial_cost"]) <= 1e-9 * sc["initial_cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    worst_lm = max(np.max(np.abs(gpu.get_landmark(a)["point"] - cpu.get_landmark(b)["point"])) for a, b in zip(lg, lc))
+    worst_q = max(abs(gpu.get_landmark(a)["quality"] - cpu.get_landmark(b)["quality"]) for a, b in zip(lg, lc))
+    log(rig, "pose", worst, "lm", worst_lm, "quality", worst_q)
+    assert worst < 1e-6 and worst_lm < 1e-5 and worst_q < 1e-6
+    assert np.max(np.abs(gpu.get_landmark(far)["point"][:3] - target[:3])) < 1e-6     # pulled onto its measurement
+    # marginalisation refuses while a prior-carrying landmark is observed from a leaving frame ...
+    with pytest.raises(RuntimeError):
+        gpu.apply_marginalization(2, 1)
+    # ... and works again once the priors are gone
+    for k, rid, meas, var in pri:
+        assert gpu.remove_homogeneous_point_error(rid)
+    assert gpu.remove_homogeneous_point_error(rid_far) and not gpu.remove_homogeneous_point_error(rid_far)
+    ok, removed = gpu.apply_marginalization(2, 1)
+    assert ok

@@ -69,3 +69,27 @@ def test_host_reprojection_error_matches_golden_and_oracle():
                                               g["reproj_T_SC"][k], g["reproj_uv"][k], info)
         for a, b in ((o["r"], r), (o["Jp"], Jm[0]), (o["Jl"], Jm[1]), (o["Je"], Jm[2]), (o["J_pose"], Js[0]), (o["J_lm"], Js[1]), (o["J_ext"], Js[2])):
             assert np.max(np.abs(a - b)) <= 1e-10 * max(1.0, np.max(np.abs(b)))
+
+
+def test_host_homogeneous_point_error_matches_oracle():
+    """U6: svin_host_homogeneous_point_error against the oracle's HomogeneousPointError (variance form) and against the
+    definition r = L^T (lm - meas), information = L L^T, for a full information matrix"""
+    rng = np.random.default_rng(11)
+    L = orc.lib()
+    for k in range(8):
+        hp = np.r_[rng.normal(size=3) * 3, 1.0]
+        meas = np.r_[hp[:3] + rng.normal(size=3) * 0.1, 1.0]
+        var = float(rng.uniform(0.01, 2.0))
+        r, Jm, J = estimator.host_homogeneous_point_error(hp, meas, np.eye(3) / var)
+        m = orc.OracleMap()
+        m.add_param(1, orc.BLOCK_HPOINT, hp)
+        rid = L.orc_map_add_hpoint_error(m.h, orc.dptr(orc.arr(meas)), var, 1)
+        ro, Js, Jmo = m.eval(rid)
+        assert np.max(np.abs(r - ro)) < 1e-15 and np.max(np.abs(Jm - Jmo[0])) < 1e-15
+        assert np.max(np.abs(J - Js[0].reshape(3, 4))) < 1e-15
+        A = rng.normal(size=(3, 3))
+        info = A @ A.T + np.eye(3)
+        r, Jm, J = estimator.host_homogeneous_point_error(hp, meas, info)
+        Lc = np.linalg.cholesky(info)
+        assert np.max(np.abs(r - Lc.T @ (hp[:3] - meas[:3]))) < 1e-13 and np.max(np.abs(Jm - Lc.T)) < 1e-13
+        assert np.max(np.abs(J[:, :3] - Lc.T)) < 1e-13 and np.all(J[:, 3] == 0)
