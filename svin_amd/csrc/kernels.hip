@@ -1330,13 +1330,13 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
   int ncols = 0;
   for (int b = 0; b < fac.nblk; ++b) ncols += (fac.blkKind[b] == B_SB) ? 9 : 6;
   // the block table of the linearisation record: four threads of a wave that has nothing else to do (one dependent
-  // load each, off the critical path; thread 0 doing it cost four serial memory round trips per evaluation)
+  // load each; thread 0 doing it cost four serial memory round trips per evaluation).  The loads go out here, the
+  // stores at the very end: a global store ahead of a barrier holds the whole workgroup until it has completed.
+  int tblOff = -1, tblDim = 0;
   if (t >= 192 && t < 196) {
     const int b = t - 192;
-    if (b < fac.nblk) { lin.off[b] = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); lin.dim[b] = (fac.blkKind[b] == B_SB) ? 9 : 6; }
-    else { lin.off[b] = -1; lin.dim[b] = 0; }
+    if (b < fac.nblk) { tblOff = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); tblDim = (fac.blkKind[b] == B_SB) ? 9 : 6; }
   }
-  if (t == 196) { lin.m = m; lin.ncols = ncols; }
 
   IMU_TICK(qe0);
   if (fac.kind == F_IMU) {
@@ -1587,6 +1587,8 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
     for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
     cstore(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + f, 0.5 * c);
   }
+  if (t >= 192 && t < 196) { lin.off[t - 192] = tblOff; lin.dim[t - 192] = tblDim; }
+  if (t == 196) { lin.m = m; lin.ncols = ncols; }
   IMU_TICK(qe3);
   IMU_ACC(10, qe0, qe3, t == 0 && fac.kind == F_IMU);
 }

@@ -11,6 +11,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYC
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS --kernel-trace -d $OUT/pmc2 -o b -- python $REPO/tools/solver_kernels.py > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA --kernel-trace -d $OUT/pmc3 -o b -- python $REPO/tools/solver_kernels.py > $OUT/pmc3.log 2>&1
 for p in pmc1 pmc2 pmc3; do python $REPO/tools/pmc_summary.py $OUT/$p/b_results.db > $OUT/$p.txt 2>&1; done
+python $REPO/tools/mfma_report.py $OUT/pmc1/b_results.db $OUT/pmc3/b_results.db > $OUT/mfma_report.txt 2>&1
 # 3. HBM traffic of the Jacobian-evaluation kernel on the HBM-resident batch (separate passes: FETCH_SIZE 3 slots, WRITE_SIZE 2)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/k1f -o b -- python $REPO/tools/k1_bench.py > $OUT/k1f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/k1w -o b -- python $REPO/tools/k1_bench.py > $OUT/k1w.log 2>&1
