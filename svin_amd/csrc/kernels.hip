@@ -389,14 +389,15 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane,
 // blockIdx.x: the fused evaluation kernel runs these next to the small-factor blocks), `smem` holds
 // (nPose + nExt) * 7 doubles + nCam camera models, `red` 4 doubles.
 // deferred landmark retraction (fused step): inputs of x_cand = x + (cg v_l - cn y_l) and where the results go
-struct LmDefer {
-  double cg, cn;
-  const double* vL;
-  const double* yL;
-  const int* lmPtr;
-  double* lmC;
-  double* stepPartial;
-  double* xPartial;
+struct LmDefer {   // passed BY VALUE (through a pointer it lands in scratch and every access turns into scratch + flat loads)
+  int on = 0;
+  double cg = 0, cn = 0;
+  const double* vL = nullptr;
+  const double* yL = nullptr;
+  const int* lmPtr = nullptr;
+  double* lmC = nullptr;
+  double* stepPartial = nullptr;
+  double* xPartial = nullptr;
 };
 template <bool ROBUST, bool WITH_EXT>
 __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double* red, int N, int nPose, int nExt, int nCam,
@@ -406,7 +407,7 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
                                                 const uint32_t* __restrict__ obsIdx, const int* __restrict__ obsLm,
                                                 double* __restrict__ r, double* __restrict__ Jp, double* __restrict__ Jl,
                                                 double* __restrict__ Je, double* __restrict__ costPartial, size_t stride,
-                                                const LmDefer* df = nullptr, const double* __restrict__ lmPrior = nullptr) {
+                                                const LmDefer df = LmDefer(), const double* __restrict__ lmPrior = nullptr) {
   double* sPose = smem;                      // nPose*7
   double* sExt = sPose + nPose * 7;          // nExt*7
   CameraModel* sCam = reinterpret_cast<CameraModel*>(sExt + nExt * 7);  // nCam
@@ -428,18 +429,18 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
     const int lmi = obsLm[i];
     const double4 hp = reinterpret_cast<const double4*>(lm)[lmi];
     double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
-    if (df) {
+    if (df.on) {
       // the landmark half of the fused step (k_post_solve left it to this kernel): x_cand = x + (cg v_l - cn y_l), the
       // same arithmetic as retractItem; the lane holding the landmark's first observation stores it and counts the norms
       double xo[4];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) xo[k] = hpw[k] + (df->cg * df->vL[3 * lmi + k] - df->cn * df->yL[3 * lmi + k]);
+      for (int k = 0; k < 3; ++k) xo[k] = hpw[k] + (df.cg * df.vL[3 * lmi + k] - df.cn * df.yL[3 * lmi + k]);
       xo[3] = hpw[3] + 0.0;
-      if (df->lmPtr[lmi] == i) {
+      if (df.lmPtr[lmi] == i) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { stepSq += (hpw[k] - xo[k]) * (hpw[k] - xo[k]); xSq += hpw[k] * hpw[k]; }
         xSq += hpw[3] * hpw[3];
-        reinterpret_cast<double4*>(df->lmC)[lmi] = double4{xo[0], xo[1], xo[2], xo[3]};
+        reinterpret_cast<double4*>(df.lmC)[lmi] = double4{xo[0], xo[1], xo[2], xo[3]};
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) hpw[k] = xo[k];
@@ -494,12 +495,12 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
     }
   }
   if (costPartial) {
-    if (df) {  // red: >= 48 doubles
+    if (df.on) {  // red: >= 48 doubles
       const double v3[3] = {cost, stepSq, xSq};
       const double mine = blockSumK<3>(v3, red, -1);
       if (threadIdx.x == 0) cstore(costPartial + block, mine);
-      if (threadIdx.x == 1) cstore(df->stepPartial + block, mine);
-      if (threadIdx.x == 2) cstore(df->xPartial + block, mine);
+      if (threadIdx.x == 1) cstore(df.stepPartial + block, mine);
+      if (threadIdx.x == 2) cstore(df.xPartial + block, mine);
     } else {
       const double bs = blockSum(cost, red);
       if (threadIdx.x == 0) cstore(costPartial + block, bs);
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(128) void k_eval_reproj(int N, int nPose, int nExt,
   extern __shared__ double smem[];
   __shared__ double red[4];
   evalReprojBlock<ROBUST, WITH_EXT>(blockIdx.x, smem, red, N, nPose, nExt, nCam, pose, ext, lm, cams, obsUv, obsW, obsIdx,
-                                    obsLm, r, Jp, Jl, Je, costPartial, stride, nullptr, lmPrior);
+                                    obsLm, r, Jp, Jl, Je, costPartial, stride, LmDefer(), lmPrior);
 }
 
 static int evalGrid(int N) { return (N + 127) / 128; }
@@ -1028,22 +1029,36 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     IMU_TICK(qp6);
     // ---------------- P3: running sums in step order; B012 / pterm / F09 need the sums *before* the step
     if (wave == 0 && ns > 0) {
-      for (int i0 = 0; i0 < ns; i0 += 4) {
-        double dtv[4], inc[4], qv[4];
+      // eight steps per group; the three inputs of the NEXT group are requested before the current group's results are
+      // stored (the stores and the loads hit the same LDS array: in source order the compiler would have to finish one
+      // group, latency and all, before starting the next)
+      constexpr int kG = 8;
+      // row pointers advance by a group; inside a group every access is base + compile-time offset (rows past the round's
+      // last step are read but never used: they lie inside sh.fb / the arrays behind it)
+      const double* pDt = fbw + 3;
+      const double* pInc = fbw + iInc;
+      const double* pQ = fbw + iQ;
+      double* pOut = fbw + iOut;
+      double dtv[kG], inc[kG], qv[kG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double* row = fbw + min(i0 + u, ns - 1) * kFbLd;
-          dtv[u] = row[3]; inc[u] = row[iInc]; qv[u] = row[iQ];
-        }
+      for (int u = 0; u < kG; ++u) { dtv[u] = pDt[u * kFbLd]; inc[u] = pInc[u * kFbLd]; qv[u] = pQ[u * kFbLd]; }
+      for (int i0 = 0; i0 < ns; i0 += kG) {
+        pDt += kG * kFbLd; pInc += kG * kFbLd; pQ += kG * kFbLd;
+        double dtn[kG], incn[kG], qvn[kG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kG; ++u) { dtn[u] = pDt[u * kFbLd]; incn[u] = pInc[u * kFbLd]; qvn[u] = pQ[u * kFbLd]; }
+#pragma unroll
+        for (int u = 0; u < kG; ++u) {
           if (i0 + u < ns) {
             const double a = run1 * dtv[u];
-            fbw[(i0 + u) * kFbLd + iOut] = outSign * a + qv[u];
+            pOut[u * kFbLd] = outSign * a + qv[u];
             run2 += a + qv[u];
             run1 += incSign * inc[u];
           }
         }
+        pOut += kG * kFbLd;
+#pragma unroll
+        for (int u = 0; u < kG; ++u) { dtv[u] = dtn[u]; inc[u] = incn[u]; qv[u] = qvn[u]; }
       }
     }
     IMU_TICK(qp7);
@@ -1704,6 +1719,7 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
     const bool defer = cand && p.lmDeferred;
     LmDefer df;
     if (defer) {
+      df.on = 1;
       df.cg = p.scal->spareA0; df.cn = p.scal->spareA1;   // the dogleg coefficients of the fused step (k_post_solve)
       df.vL = p.vL; df.yL = p.yL; df.lmPtr = p.lmPtr; df.lmC = p.lmC;
       df.stepPartial = p.partial + (size_t)PS_STEP * kMaxPartials;
@@ -1713,7 +1729,7 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
                                     cand ? p.extC : p.ext, defer ? p.lm : (cand ? p.lmC : p.lm), p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
                                     cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
                                     cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N,
-                                    defer ? &df : nullptr, p.lmPrior);
+                                    df, p.lmPrior);
   }
   TRACE(18);
   if (sumCost) {
@@ -2141,12 +2157,11 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
 #endif
   // the pose -> row map of the reduced system rides on the same round trip as the first chunk's observation ranges (it was
   // a dependent global load per observation)
-  constexpr int kStagePose = 256;
-  __shared__ int sPoseOff[kStagePose];
-  const bool stagedPose = p.nPose <= kStagePose;
-  if (stagedPose)
-    for (int i = t; i < p.nPose; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
-  const int* poseOffS = stagedPose ? sPoseOff : p.poseOff;
+  // (kDensePoseCap poses at most: the host only takes this kernel for windows that narrow; a pointer that may be LDS or
+  // global would turn every access into a FLAT instruction)
+  __shared__ int sPoseOff[kDensePoseCap];
+  for (int i = t; i < p.nPose && i < kDensePoseCap; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
+  const int* poseOffS = sPoseOff;
   for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
 #ifdef SVIN_SCHUR_TIMING
@@ -4010,11 +4025,10 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   }
   if (staged || stagedOff || stagedItems) __syncthreads();
   if (b < nLmBlocks) {
+   // the body is instantiated twice, once on the staged LDS copies and once on the global arrays: ONE pointer variable that
+   // may hold either address space makes every access through it a FLAT instruction (15-36 of them per observation here)
+   auto landmarkBlock = [&](const double* yCs, const double* vCs, const int* poseOffS, const int* extOffS) __attribute__((always_inline)) {
     const int grp = t >> 4, gl = t & 15;
-    const double* yCs = staged ? sYV : p.yC;
-    const double* vCs = staged ? sYV + kStageMax : p.vC;
-    const int* poseOffS = stagedOff ? sOff : p.poseOff;
-    const int* extOffS = stagedOff ? sOff + kStageBlk : p.extOff;
     // u_y = Jc y_C, u_v = Jc v_C, Jl and r of an observation whose raw data are in registers
     auto finishObs = [&](const RawObs& w, double* jl, double* uy, double* uv, double* rr) {
       const int offP = poseOffS[w.idx & 0xfff];
@@ -4100,14 +4114,16 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
         acc[4] += jy0 * rr[0] + jy1 * rr[1];
       }
     }
+   };
+   if (staged && stagedOff) landmarkBlock(sYV, sYV + kStageMax, sOff, sOff + kStageBlk);
+   else landmarkBlock(p.yC, p.vC, p.poseOff, p.extOff);
   } else if (b < nLmBlocks + nFacBlocks) {
     if (p.ownsCamera) {
       // one wave per factor, lane = (row a = lane & 15, column quarter lane >> 4): the row's products with v_C and y_C are
       // split over four lanes (a thread per row walked up to 30 columns of dependent global loads: these blocks were the
       // last to finish), the solution vectors come from the staged copy
       const int wave = t >> 6, lane = t & 63, a = lane & 15, cq = lane >> 4;
-      const double* yCf = staged ? sYV : p.yC;
-      const double* vCf = staged ? sYV + kStageMax : p.vC;
+     auto factorBlock = [&](const double* yCf, const double* vCf) __attribute__((always_inline)) {
       for (int f = (b - nLmBlocks) * 4 + wave; f < p.F; f += nFacBlocks * 4) {
         const FactorLin& lin = p.linCur[f];
         const int m = lin.m, ncols = lin.ncols;
@@ -4135,6 +4151,9 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
           acc[0] += uvT * uvT; acc[1] += uyT * uyT; acc[2] += uvT * uyT; acc[3] += uvT * r; acc[4] += uyT * r;
         }
       }
+     };
+     if (staged) factorBlock(sYV, sYV + kStageMax);
+     else factorBlock(p.yC, p.vC);
     }
   } else if (p.ownsCamera) {
     // camera part of the scaled-gradient norms
@@ -4344,35 +4363,27 @@ __global__ __launch_bounds__(256) void k_landmark_quality(DeviceProblem p, doubl
   }
   a00 = rowSum16(a00); a01 = rowSum16(a01); a02 = rowSum16(a02); a11 = rowSum16(a11); a12 = rowSum16(a12); a22 = rowSum16(a22);
   if (gl != 0) return;
-  // cyclic Jacobi on the symmetric 3x3
+  // cyclic Jacobi on the symmetric 3x3 (one lane per landmark: this part is serial).  A sweep ends the iteration when the
+  // off-diagonal mass is below 1e-16 of the trace -- the eigenvalues then move by less than off^2 / gap -- instead of
+  // waiting for exact zeros (up to 12 sweeps of IEEE divisions and square roots were 2/3 of this kernel's 18 us); the
+  // rotation uses reciprocal / reciprocal-square-root with Newton steps.
+  auto rotate = [](double& app, double& aqq, double& apq, double& apr, double& aqr) {
+    // annihilates apq; (p, q) diagonal entries, apr / aqr the third row's couplings
+    const double th = (aqq - app) * 0.5 * rcpNewton(apq);
+    const double tt = copysign(1.0, th) * rcpNewton(fabs(th) + sqrt(th * th + 1.0));
+    const double c = rsqrtNewton(tt * tt + 1.0), sn = tt * c;
+    const double npp = app - tt * apq, nqq = aqq + tt * apq;
+    const double npr = c * apr - sn * aqr, nqr = sn * apr + c * aqr;
+    app = npp; aqq = nqq; apq = 0.0; apr = npr; aqr = nqr;
+  };
+  const double tiny = 1.0e-16 * (fabs(a00) + fabs(a11) + fabs(a22));
   for (int sweep = 0; sweep < 12; ++sweep) {
     const double off = fabs(a01) + fabs(a02) + fabs(a12);
-    if (off == 0.0) break;
-    // rotate (0,1)
-    if (a01 != 0.0) {
-      const double th = (a11 - a00) / (2.0 * a01);
-      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-      const double n00 = a00 - tt * a01, n11 = a11 + tt * a01;
-      const double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
-      a00 = n00; a11 = n11; a01 = 0; a02 = n02; a12 = n12;
-    }
-    if (a02 != 0.0) {
-      const double th = (a22 - a00) / (2.0 * a02);
-      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-      const double n00 = a00 - tt * a02, n22 = a22 + tt * a02;
-      const double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
-      a00 = n00; a22 = n22; a02 = 0; a01 = n01; a12 = n12;
-    }
-    if (a12 != 0.0) {
-      const double th = (a22 - a11) / (2.0 * a12);
-      const double tt = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-      const double n11 = a11 - tt * a12, n22 = a22 + tt * a12;
-      const double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
-      a11 = n11; a22 = n22; a12 = 0; a01 = n01; a02 = n02;
-    }
+    if (off <= tiny) break;
+    const double skip = 1.0e-20 * tiny;   // an entry this small is zero for every purpose (and 1 / it would overflow)
+    if (fabs(a01) > skip) rotate(a00, a11, a01, a02, a12);
+    if (fabs(a02) > skip) rotate(a00, a22, a02, a01, a12);
+    if (fabs(a12) > skip) rotate(a11, a22, a12, a01, a02);
   }
   const double smallest = fmin(a00, fmin(a11, a22)), largest = fmax(a00, fmax(a11, a22));
   quality[l] = (smallest < 1.0e-12) ? 0.0 : sqrt(smallest) / sqrt(largest);

@@ -20,6 +20,7 @@
 namespace svin {
 
 constexpr int kMaxCams = 8;
+constexpr int kDensePoseCap = 256;   // k_schur_dense stages the pose -> row map of at most this many poses in LDS
 constexpr int kPriorCam = 15;   // camera field of a packed index that marks a landmark-prior pseudo-observation (HomogeneousPointError)
 
 // packed per-observation index: pose slot (12 bit) | ext slot (12 bit) | camera (4 bit)

@@ -950,7 +950,7 @@ void Window::pack() {
   int nSlabs = 1;
   // windows whose camera block fits 16 x 16 MFMA tiles (dC <= 254, e.g. 42 poses or 10 poses with per-frame extrinsics):
   // dense Gram-matrix Schur complement on MFMA
-  const bool schurDense = dC > 0 && dC + 2 <= 256 && !getenv("SVIN_SCHUR_PAIRWISE");
+  const bool schurDense = dC > 0 && dC + 2 <= 256 && poseIds_.size() <= (size_t)kDensePoseCap && !getenv("SVIN_SCHUR_PAIRWISE");
   if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
   // dense Schur with the A part on MFMA (variable extrinsics, or more than 8 tile rows): within every chunk of 16
