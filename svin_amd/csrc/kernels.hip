@@ -64,6 +64,15 @@ __device__ __forceinline__ double rowMax16(double v) {
   v = fmax(v, dppRowMov<0x121>(v));
   return v;
 }
+// DPP move for wave-wide scans: kCtrl row_shr:N = 0x110 + N (within 16-lane rows), row_bcast:15 = 0x142 (lane 15 of a row
+// to the whole next row; row mask 0xa = rows 1 and 3), row_bcast:31 = 0x143 (lane 31 to rows 2 and 3: row mask 0xc),
+// wave_shr:1 = 0x138.  Lanes that receive nothing get 0.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dppScanMov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double waveSum(double v) {
   v = rowSum16(v);
   return (readlaneD(v, 0) + readlaneD(v, 16)) + (readlaneD(v, 32) + readlaneD(v, 48));
@@ -911,17 +920,27 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       const double* pr = sh.pre + min(lane, ns - 1) * kPreLd;
       const bool act = lane < ns && pr[28] != 0.0;
       Quat q = act ? Quat{pr[4], pr[5], pr[6], pr[7]} : Quat{0, 0, 0, 1};
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const Quat lo = {__shfl_up(q.x, o, 64), __shfl_up(q.y, o, 64), __shfl_up(q.z, o, 64), __shfl_up(q.w, o, 64)};
-        const Quat c = qmul(lo, q);   // earlier steps on the left
-        if (lane >= o) q = c;
+      // inclusive scan without LDS (__shfl_up is ds_bpermute: 8 LDS round trips per level here): four levels inside the
+      // 16-lane rows (row_shr), then the row totals travel down the wave (row_bcast:15, row_bcast:31)
+#define SVIN_QSCAN(CTRL, MASK, COND)                                                                                 \
+      {                                                                                                             \
+        const Quat lo = {dppScanMov<CTRL, MASK>(q.x), dppScanMov<CTRL, MASK>(q.y), dppScanMov<CTRL, MASK>(q.z),     \
+                         dppScanMov<CTRL, MASK>(q.w)};                                                              \
+        const Quat c = qmul(lo, q); /* earlier steps on the left */                                                 \
+        if (COND) q = c;                                                                                            \
       }
-      Quat e = {__shfl_up(q.x, 1, 64), __shfl_up(q.y, 1, 64), __shfl_up(q.z, 1, 64), __shfl_up(q.w, 1, 64)};
+      SVIN_QSCAN(0x111, 0xf, (lane & 15) >= 1)
+      SVIN_QSCAN(0x112, 0xf, (lane & 15) >= 2)
+      SVIN_QSCAN(0x114, 0xf, (lane & 15) >= 4)
+      SVIN_QSCAN(0x118, 0xf, (lane & 15) >= 8)
+      SVIN_QSCAN(0x142, 0xa, (lane >> 4) & 1)
+      SVIN_QSCAN(0x143, 0xc, lane >= 32)
+#undef SVIN_QSCAN
+      Quat e = {dppScanMov<0x138, 0xf>(q.x), dppScanMov<0x138, 0xf>(q.y), dppScanMov<0x138, 0xf>(q.z), dppScanMov<0x138, 0xf>(q.w)};
       if (lane == 0) e = Quat{0, 0, 0, 1};
       const Quat before = qmul(Dq, e);     // Delta_q before step `lane`
       if (lane < ns) { double* sq = sh.seq + lane * kSeqLd; sq[0] = before.x; sq[1] = before.y; sq[2] = before.z; sq[3] = before.w; }
-      const Quat tot = {__shfl(q.x, ns - 1, 64), __shfl(q.y, ns - 1, 64), __shfl(q.z, ns - 1, 64), __shfl(q.w, ns - 1, 64)};
+      const Quat tot = {readlaneD(q.x, ns - 1), readlaneD(q.y, ns - 1), readlaneD(q.z, ns - 1), readlaneD(q.w, ns - 1)};
       Dq = qmul(Dq, tot);
       if (lane == 0) { double* sq = sh.seq + ns * kSeqLd; sq[0] = Dq.x; sq[1] = Dq.y; sq[2] = Dq.z; sq[3] = Dq.w; }
     }
@@ -933,28 +952,30 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       double R[9], B[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) { R[k] = act ? pr[8 + k] : ((k % 4 == 0) ? 1.0 : 0.0); B[k] = act ? pr[17 + k] : 0.0; }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Re[9], Be[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { Re[k] = __shfl_up(R[k], o, 64); Be[k] = __shfl_up(B[k], o, 64); }
-        double Rn[9], Bn[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            Rn[3 * r + c] = R[3 * r] * Re[c] + R[3 * r + 1] * Re[3 + c] + R[3 * r + 2] * Re[6 + c];
-            Bn[3 * r + c] = (R[3 * r] * Be[c] + R[3 * r + 1] * Be[3 + c] + R[3 * r + 2] * Be[6 + c]) + B[3 * r + c];
-          }
-        if (lane >= o) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { R[k] = Rn[k]; B[k] = Bn[k]; }
-        }
+#define SVIN_ASCAN(CTRL, MASK, COND)                                                                                 \
+      {                                                                                                             \
+        double Re[9], Be[9], Rn[9], Bn[9];                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 9; ++k) { Re[k] = dppScanMov<CTRL, MASK>(R[k]); Be[k] = dppScanMov<CTRL, MASK>(B[k]); } \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                               \
+          _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                           \
+            Rn[3 * r + c] = R[3 * r] * Re[c] + R[3 * r + 1] * Re[3 + c] + R[3 * r + 2] * Re[6 + c];                 \
+            Bn[3 * r + c] = (R[3 * r] * Be[c] + R[3 * r + 1] * Be[3 + c] + R[3 * r + 2] * Be[6 + c]) + B[3 * r + c]; \
+          }                                                                                                         \
+        if (COND) {                                                                                                 \
+          _Pragma("unroll") for (int k = 0; k < 9; ++k) { R[k] = Rn[k]; B[k] = Bn[k]; }                             \
+        }                                                                                                           \
       }
+      SVIN_ASCAN(0x111, 0xf, (lane & 15) >= 1)
+      SVIN_ASCAN(0x112, 0xf, (lane & 15) >= 2)
+      SVIN_ASCAN(0x114, 0xf, (lane & 15) >= 4)
+      SVIN_ASCAN(0x118, 0xf, (lane & 15) >= 8)
+      SVIN_ASCAN(0x142, 0xa, (lane >> 4) & 1)
+      SVIN_ASCAN(0x143, 0xc, lane >= 32)
+#undef SVIN_ASCAN
       // exclusive prefix applied to the state at the start of the round; the inclusive one of the last step ends it
       double Re[9], Be[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) { Re[k] = __shfl_up(R[k], 1, 64); Be[k] = __shfl_up(B[k], 1, 64); }
+      for (int k = 0; k < 9; ++k) { Re[k] = dppScanMov<0x138, 0xf>(R[k]); Be[k] = dppScanMov<0x138, 0xf>(B[k]); }
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { Re[k] = (k % 4 == 0) ? 1.0 : 0.0; Be[k] = 0.0; }
@@ -969,7 +990,7 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
           if (lane < ns) sh.seq[lane * kSeqLd + 4 + 3 * r + c] = bef;
         }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) cross[k] = __shfl(after[k], ns - 1, 64);
+      for (int k = 0; k < 9; ++k) cross[k] = readlaneD(after[k], ns - 1);
 #pragma unroll
       for (int k = 0; k < 9; ++k)
         if (lane == k) sh.seq[ns * kSeqLd + 4 + k] = cross[k];
