@@ -194,9 +194,17 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
   __syncthreads();
   double mine = 0;
   if ((int)threadIdx.x < K) {
-    for (int i = 0; i < nRows; ++i) {
-      const double x = red[i * K + threadIdx.x];
-      mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
+    if (nRows == 16) {   // 256 threads: all sixteen partials requested at once (with a run-time bound: one LDS latency per term)
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = red[i * K + threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x[i]) : mine + x[i];
+    } else {
+      for (int i = 0; i < nRows; ++i) {
+        const double x = red[i * K + threadIdx.x];
+        mine = ((int)threadIdx.x == kMaxIndex) ? fmax(mine, x) : mine + x;
+      }
     }
   }
   return mine;
@@ -235,8 +243,10 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, 
   if (p.mailbox) {
     // publish everything the host needs for its accept/reject decision: the scalars as ONE wave-wide store to the
     // pinned host page (25 serial stores + two system fences cost ~18 us of every iteration), then the sequence number
+    TRACE(21);
     if (t < nD) reinterpret_cast<volatile double*>(&p.mailbox->scal)[t] = rec;
     __threadfence_system();
+    TRACE(22);
     __syncthreads();
     if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&p.mailbox->seq) = p.mailboxSeq;
   }
@@ -1475,8 +1485,6 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
         setB(F0, 0, 6, Ct, Delta_t);
         crossMxDev(dvv[0], dvv[1], dvv[2], X); mm3(Ct, X, T9); setB(F0, 6, 3, T9, 1.0);
         setB(F0, 6, 6, Ct, 1.0);
-        setB(F1, 0, 0, Ct, -1.0);
-        setB(F1, 6, 6, Ct, -1.0);
         IMU_TICK(qec);
         IMU_ACC(13, qeb, qec, !redo);
         const Mat3 CtM = {{Ct[0], Ct[1], Ct[2], Ct[3], Ct[4], Ct[5], Ct[6], Ct[7], Ct[8]}};
@@ -1495,10 +1503,6 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
           sh.e[a] = v1a[a] + imacc_doubleintegral[a] + s1;
           sh.e[6 + a] = v2a[a] + imacc_integral[a] + s2;
         }
-        const Quat qd = qmul(Dq, qmul(q1inv, q0));
-        sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sh.e[9 + k] = ss0[3 + k] - ss1[3 + k];
       } else if (part == 1) {
         // d e_q / d alpha_0 = [plus(Dq q1^-1) oplus(q0)]_3x3, the identity diagonals, the pre-integral bias blocks
 #pragma unroll
@@ -1540,10 +1544,26 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
         for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int b = 0; b < 3; ++b) F1[(3 + a) * 30 + 3 + b] = -Q44[a * 4 + b];
+        // (this lane is the least loaded of the four: it also takes the -C_S0_W blocks of the second pose and the
+        // orientation / bias rows of the error vector)
+        const Mat3 C0 = quatToR(q0);
+        double nCt[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) nCt[a * 3 + b] = -C0.m[b * 3 + a];
+        setB(F1, 0, 0, nCt, 1.0);
+        setB(F1, 6, 6, nCt, 1.0);
+        const Quat qd = qmul(Dq, qmul(q1inv, q0));
+        sh.e[3] = 2 * qd.x; sh.e[4] = 2 * qd.y; sh.e[5] = 2 * qd.z;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sh.e[9 + k] = ss0[3 + k] - ss1[3 + k];
       }
       IMU_TICK(qe2);
       IMU_ACC(9, qe1, qe2, !redo && part == 0);
       IMU_ACC(11, qe1, qe1 + 1, !redo && part == 0);
+      IMU_ACC(15, qe1, qe2, !redo && part == 3);
+      IMU_ACC(14, qe1, qe2, !redo && part == 1);
     }
   } else {
     for (int k = t; k < m * m; k += blockDim.x) sh.W[k] = fac.sqrtInfo[k];
@@ -1602,7 +1622,29 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
   // r = W e ; J = W F.  Thread (a = t & 15, c = t >> 4, + 16): row a, columns c and c + 16 -- no integer division
   {
     const int a = t & 15, c0 = t >> 4;
-    if (a < m) {
+    if (fac.kind == F_IMU) {
+      // m = 15, ncols = 30 at compile time: the row of W is read once, every LDS access has an immediate offset (with the
+      // run-time bounds below this was ~120 instructions per output)
+      if (a < 15) {
+        double w[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) w[k] = sh.W[a * 15 + k];
+        if (c0 == 0) {
+          double sr = 0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) sr += w[k] * sh.e[k];
+          lin.r[a] = sr;
+          sh.rw[a] = sr;
+        }
+        double s0 = 0, s1 = 0;
+        const bool second = c0 + 16 < 30;
+        const double* Fc = sh.F + c0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) { s0 += w[k] * Fc[k * 30]; s1 += w[k] * Fc[k * 30 + (second ? 16 : 0)]; }
+        lin.J[a * 30 + c0] = s0;
+        if (second) lin.J[a * 30 + c0 + 16] = s1;
+      }
+    } else if (a < m) {
       if (c0 == 0) {
         double sr = 0;
         for (int k = 0; k < m; ++k) sr += sh.W[a * m + k] * sh.e[k];
@@ -1617,11 +1659,11 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
     }
   }
   __syncthreads();
-  // cost partial: 0.5 |r|^2
-  if (t == 0) {
-    double c = 0;
-    for (int a = 0; a < m; ++a) c += sh.rw[a] * sh.rw[a];
-    cstore(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + f, 0.5 * c);
+  // cost partial: 0.5 |r|^2 (the residuals sit in the first 16 lanes: one DPP row sum)
+  if (t < 64) {
+    const double rv = ((t & 15) < m && t < 16) ? sh.rw[t & 15] : 0.0;
+    const double c = rowSum16(rv * rv);
+    if (t == 0) cstore(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + f, 0.5 * c);
   }
   if (t >= 192 && t < 196) { lin.off[t - 192] = tblOff; lin.dim[t - 192] = tblDim; }
   if (t == 196) { lin.m = m; lin.ncols = ncols; }

@@ -1620,8 +1620,8 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
       for (int i = 0; i < reps; ++i) { launchEvalFactors(prob_, false, stream_); HIP_OK(hipStreamSynchronize(stream_)); }
       double d2[16];
       debugImuTiming(d2, false);
-      std::printf("[imu eval cycles, no redo] factors counted %.0f: staging %.0f, serial F/e block %.0f (shared quantities %.0f, position/velocity blocks %.0f), whole block %.0f\n", d2[11],
-                  d2[8] / d2[11], d2[9] / d2[11], d2[12] / d2[11], d2[13] / d2[11], d2[10] / d2[11]);
+      std::printf("[imu eval cycles, no redo] factors counted %.0f: staging %.0f, serial F/e block %.0f (shared quantities %.0f, position/velocity blocks %.0f; part 1 %.0f, part 3 %.0f), whole block %.0f\n", d2[11],
+                  d2[8] / d2[11], d2[9] / d2[11], d2[12] / d2[11], d2[13] / d2[11], d2[14] / d2[11], d2[15] / d2[11], d2[10] / d2[11]);
       hipEvent_t a, b;
       HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
       for (int variant = 0; variant < 3; ++variant) {

@@ -12,7 +12,7 @@ from svin_amd.estimator import Estimator, load_library
 
 NAMES = {0: "post: block start", 1: "post: work done", 2: "post: last block in", 3: "post: sums reduced", 4: "post: dogleg coefficients",
          5: "post: blocks retracted", 6: "post: landmarks retracted", 7: "post: block end", 8: "post: landmark blocks done", 9: "post: factor blocks done", 10: "post: camera block done", 11: "post: block sums done", 12: "post: partials loaded",
-         16: "eval: block start", 17: "eval: factor block done", 18: "eval: block work done", 19: "eval: last block in", 20: "eval: cost reduced",
+         16: "eval: block start", 17: "eval: factor block done", 18: "eval: block work done", 19: "eval: last block in", 20: "eval: cost reduced", 21: "eval: sums ready, before mailbox", 22: "eval: after system fence",
          24: "schur: block start", 25: "schur: block end", 28: "reduce: start", 29: "reduce: end"}
 spec = syn.make_window()
 est = Estimator(0)
@@ -25,7 +25,7 @@ for it in (0, 1, 10):
     out = np.zeros(128, np.uint64)
     L.svin_debug_trace(out.ctypes.data_as(C.c_void_p), 0)
     print("---- after optimize(%d)" % it)
-    for grp in (range(0, 13), range(16, 21), range(24, 30)):
+    for grp in (range(0, 13), range(16, 23), range(24, 30)):
         t0 = min((int(out[2 * k]) for k in grp if k in NAMES and out[2 * k + 1] != 0), default=None)
         if t0 is None:
             continue
