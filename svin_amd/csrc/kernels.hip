@@ -99,6 +99,12 @@ __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Kernel-argument fields a kernel needs first, fetched in ONE batch of scalar loads: left to the compiler every field of the
+// by-value DeviceProblem is loaded at its first use with its own s_waitcnt -- about ten serial scalar-memory latencies before
+// a block issues its first real load (the empty "camera block" of k_post_solve finished 2.5 us after it started).
+#define SVIN_ARGS(...) asm volatile("" ::__VA_ARGS__)
+#define SA(x) "s"(x)
+
 #ifdef SVIN_TRACE
 // in-kernel timeline (instrumented variant builds only, tools/build_variant.sh trace -DSVIN_TRACE): 100 MHz wall clock
 // stamps of the LAST launch, slot 2k = earliest / slot 2k+1 = latest stamp any block recorded at trace point k
@@ -1771,6 +1777,14 @@ template <bool WITH_EXT>
 __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost, int hasPrior) {
   __shared__ FactorShared sh;
   const int F = (int)gridDim.x - nR - hasPrior;
+  if ((int)blockIdx.x < F) {
+    SVIN_ARGS(SA(p.factors), SA(p.imus), SA(p.linCand), SA(p.linCur), SA(p.poseC), SA(p.pose), SA(p.sbC), SA(p.sb), SA(p.extC), SA(p.ext),
+              SA(p.poseOff), SA(p.sbOff), SA(p.extOff), SA(p.partial), SA(p.imuT), SA(p.imuMeas));
+  } else {
+    SVIN_ARGS(SA(p.poseC), SA(p.pose), SA(p.extC), SA(p.ext), SA(p.lm), SA(p.lmC), SA(p.cams), SA(p.obsUv), SA(p.obsW), SA(p.obsIdx),
+              SA(p.obsLm), SA(p.rCand), SA(p.JpCand), SA(p.JlCand), SA(p.partial), SA(p.scal), SA(p.vL), SA(p.yL), SA(p.lmPtr), SA(p.N),
+              SA(p.nPose), SA(p.nExt), SA(p.nCam));
+  }
   TRACE(16);
   if ((int)blockIdx.x < F) {
     evalFactorBlock(p, cand, blockIdx.x, sh);
@@ -2189,6 +2203,8 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     else priorAccumulateBlock(p, e - nFacBlocks);
     return;
   }
+  SVIN_ARGS(SA(p.lmPtr), SA(p.poseOff), SA(p.rCur), SA(p.JlCur), SA(p.JpCur), SA(p.obsIdx), SA(p.scaleL), SA(p.Vinv), SA(p.bl), SA(p.hL),
+            SA(p.slabs), SA(p.scal), SA(p.L), SA(p.N), SA(p.dC), SA(p.nPose), SA(p.anyExtVariable), SA(p.aBlocks), SA(p.dCPose));
   const size_t N = (size_t)p.N;
   const bool WITH_EXT = A_MFMA && p.anyExtVariable != 0;
   const int dC = p.dC, nP = dC / 6;          // reduced 6-blocks (poses, then variable extrinsics)
@@ -2769,6 +2785,7 @@ __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
 constexpr int kSlabParts = 16;
 __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   __shared__ double part[256];
+  SVIN_ARGS(SA(p.slabs), SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.nSlabs), SA(p.dC), SA(p.d));
   const int dC = p.dC;
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
   const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
@@ -2973,6 +2990,7 @@ constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: barr
 __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
                                                                     int fuseFinalize) {
   extern __shared__ double smem[];
+  SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS));
   const int t = threadIdx.x, d = p.d, nT = dpad / 16;
   // the wave index through v_readfirstlane: tile indices and LDS tile addresses become scalar (SALU) arithmetic
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = kCholLdsThreads / 64;
@@ -4012,6 +4030,8 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   double acc[kPostK];
 #pragma unroll
   for (int k = 0; k < kPostK; ++k) acc[k] = 0;
+  SVIN_ARGS(SA(p.lmPtr), SA(p.yC), SA(p.vC), SA(p.poseOff), SA(p.extOff), SA(p.scal), SA(p.pose), SA(p.sb), SA(p.sbOff), SA(p.obsIdx),
+            SA(p.JpCur), SA(p.JlCur), SA(p.rCur), SA(p.S), SA(p.d), SA(p.L), SA(p.N), SA(p.nPose), SA(p.nExt), SA(p.nSb));
   TRACE(0);
   // clear the accumulators of the next linearisation (nothing reads S / gRed / hC after the solve; gFull is
   // still needed by the last block below and is cleared there)
@@ -4049,7 +4069,19 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   };
   int firstStart = 0, firstEnd = 0;
   const bool lmBlock = b < nLmBlocks && b * 16 + (t >> 4) < p.L;
-  if (lmBlock) { firstStart = p.lmPtr[b * 16 + (t >> 4)]; firstEnd = p.lmPtr[b * 16 + (t >> 4) + 1]; }
+  if (b < nLmBlocks) {
+    // the five range ends a wave needs (four landmarks) through the scalar cache: wave-uniform addresses, a read-only
+    // table that stays resident from iteration to iteration -- a vector load from L2 / HBM was the first of this
+    // block's two dependent round trips
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int base = b * 16 + wv * 4;
+    int e[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) e[k] = p.lmPtr[min(base + k, p.L)];
+    const int g4 = (t >> 4) & 3;
+    firstStart = g4 == 0 ? e[0] : (g4 == 1 ? e[1] : (g4 == 2 ? e[2] : e[3]));
+    firstEnd = g4 == 0 ? e[1] : (g4 == 1 ? e[2] : (g4 == 2 ? e[3] : e[4]));
+  }
   double sy0 = 0, sy1 = 0, sv0 = 0, sv1 = 0;
   if (staged) {
     if (t < p.d) { sy0 = p.yC[t]; sv0 = p.vC[t]; }
@@ -4306,15 +4338,21 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   const double tot = blockSumK<kPostK>(acc, red, 8);
   TRACE(3);
   __shared__ double grpB[8];
-  if (t < kPostK) {
-    double* dst = &p.scal->gHatSq;
-    // slot order A B C D E gHat gnHat gDotGn -> fields 1 4 5 6 7 0 2 3 of group B
-    const int field = (t == 0) ? 1 : (t == 1) ? 4 : (t == 2) ? 5 : (t == 3) ? 6 : (t == 4) ? 7 : (t == 5) ? 0 : (t == 6) ? 2 : 3;
-    if (t < 8) { dst[field] = tot; grpB[field] = tot; }
-    else { p.scal->gradMax = tot; p.scal->failMax = (double)cholFailIn; p.scal->cholFail = 0; }
-  }
-  for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
-  if (t == 0) p.tickets[TK_POST] = 0;
+  // slot order A B C D E gHat gnHat gDotGn -> fields 1 4 5 6 7 0 2 3 of group B
+  const int field = (t == 0) ? 1 : (t == 1) ? 4 : (t == 2) ? 5 : (t == 3) ? 6 : (t == 4) ? 7 : (t == 5) ? 0 : (t == 6) ? 2 : 3;
+  if (t < 8) grpB[field] = tot;
+  // (the global stores of the record, the clearing of gFull and the ticket reset wait until the very end: a global store
+  // ahead of the barrier below would hold the whole block until it has completed)
+  auto publishGroupB = [&]() {
+    if (t < kPostK) {
+      double* dst = &p.scal->gHatSq;
+      if (t < 8) dst[field] = tot;
+      else { p.scal->gradMax = tot; p.scal->failMax = (double)cholFailIn; p.scal->cholFail = 0; }
+    }
+    for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
+    if (t == 0) p.tickets[TK_POST] = 0;
+  };
+  if (fuseRadius <= 0.0) publishGroupB();
   if (fuseRadius > 0.0) {
     // single-GPU narrow windows: this block also takes the dogleg step and retracts (k_step_retract's work) --
     // one launch less on the critical path of every accepted iteration
@@ -4325,14 +4363,19 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     double a2[2] = {0, 0};
     TRACE(4);
     if (stagedItems) {
-      if (t < nBlkItems) {
-        const bool isSb = t >= p.nPose + p.nExt, isPose = t < p.nPose;
-        const int slot = isSb ? t - p.nPose - p.nExt : (isPose ? t : t - p.nPose);
-        const int off = sItemOff[t], nd = isSb ? 9 : 6;
+      // pose / extrinsics blocks on wave 0, speed-and-bias blocks on wave 1: the two code paths run side by side instead of
+      // one after the other inside a wave
+      const int nPE = p.nPose + p.nExt;
+      const bool split = nPE <= 64 && p.nSb <= 64;
+      const int item = split ? (t < 64 ? (t < nPE ? t : -1) : (t < 128 && t - 64 < p.nSb ? nPE + t - 64 : -1)) : (t < nBlkItems ? t : -1);
+      if (item >= 0) {
+        const bool isSb = item >= nPE, isPose = item < p.nPose;
+        const int slot = isSb ? item - nPE : (isPose ? item : item - p.nPose);
+        const int off = sItemOff[item], nd = isSb ? 9 : 6;
         double x[9], v[9], y[9], xo[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          x[k] = sItemX[t * 9 + k];
+          x[k] = sItemX[item * 9 + k];
           v[k] = (off >= 0 && k < nd) ? sYV[kStageMax + off + k] : 0.0;
           y[k] = (off >= 0 && k < nd) ? sYV[off + k] : 0.0;
         }
@@ -4371,6 +4414,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     const double tt = blockSumK<2>(a2, red, -1);
     if (t == 0) p.scal->stepNormSq = tt;
     if (t == 1) p.scal->xNormSq = tt;
+    publishGroupB();
   }
   TRACE(7);
 }
