@@ -2241,7 +2241,11 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   __shared__ int sPoseOff[kDensePoseCap];
   for (int i = t; i < p.nPose && i < kDensePoseCap; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
   const int* poseOffS = sPoseOff;
-  for (int i = t; i < rows * kDenseLd + (int)extraLds; i += blockDim.x) smem[i] = 0.0;
+  {
+    const int nz = rows * kDenseLd + (int)extraLds;   // 16-byte stores: half the LDS instructions of the clear
+    for (int i = t; i < (nz >> 1); i += blockDim.x) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};
+    if ((nz & 1) && t == 0) smem[nz - 1] = 0.0;
+  }
   __syncthreads();
 #ifdef SVIN_SCHUR_TIMING
   const long long qd1 = __builtin_readcyclecounter();
@@ -2523,9 +2527,11 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         acc[k] = c;
       }
     }
-    __syncthreads();
-    for (int i = t; i < rows * kDenseLd + (A_MFMA ? (useBlocks ? (int)extraLds : 0) : 4 * nP * kPoseAcc); i += blockDim.x) smem[i] = 0.0;
-    __syncthreads();
+    if ((chunk + nChunkBlocks) * kDenseLm < p.L) {   // another chunk follows (wide problems only): clear the staging tiles for it
+      __syncthreads();
+      for (int i = t; i < rows * kDenseLd + (A_MFMA ? (useBlocks ? (int)extraLds : 0) : 4 * nP * kPoseAcc); i += blockDim.x) smem[i] = 0.0;
+      __syncthreads();
+    }
 #ifdef SVIN_SCHUR_TIMING
     qdG += __builtin_readcyclecounter() - qc2;
 #endif
