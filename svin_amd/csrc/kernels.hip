@@ -1070,32 +1070,52 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
       // stored (the stores and the loads hit the same LDS array: in source order the compiler would have to finish one
       // group, latency and all, before starting the next)
       constexpr int kG = 8;
-      // row pointers advance by a group; inside a group every access is base + compile-time offset (rows past the round's
-      // last step are read but never used: they lie inside sh.fb / the arrays behind it)
+      // Eight steps per group, row pointers advance by a group, inside a group every access is base + compile-time offset.
+      // The inputs of the NEXT group are requested before the current group's results are stored (same LDS array: in source
+      // order the compiler would finish one group, latency and all, before starting the next); two register sets alternate
+      // (no copies), full groups run without per-step conditions -- a branch per step made every step its own basic block
+      // with no overlap between the steps' dependent chains (160 cycles per step), selects cost six instructions per step --
+      // and only the last, partial group of a round is masked.
       const double* pDt = fbw + 3;
       const double* pInc = fbw + iInc;
       const double* pQ = fbw + iQ;
       double* pOut = fbw + iOut;
-      double dtv[kG], inc[kG], qv[kG];
+      auto loadGroup = [&](double (&dt8)[kG], double (&in8)[kG], double (&q8)[kG]) {
 #pragma unroll
-      for (int u = 0; u < kG; ++u) { dtv[u] = pDt[u * kFbLd]; inc[u] = pInc[u * kFbLd]; qv[u] = pQ[u * kFbLd]; }
-      for (int i0 = 0; i0 < ns; i0 += kG) {
+        for (int u = 0; u < kG; ++u) { dt8[u] = pDt[u * kFbLd]; in8[u] = pInc[u * kFbLd]; q8[u] = pQ[u * kFbLd]; }
         pDt += kG * kFbLd; pInc += kG * kFbLd; pQ += kG * kFbLd;
-        double dtn[kG], incn[kG], qvn[kG];
-#pragma unroll
-        for (int u = 0; u < kG; ++u) { dtn[u] = pDt[u * kFbLd]; incn[u] = pInc[u * kFbLd]; qvn[u] = pQ[u * kFbLd]; }
+      };
+      auto runGroup = [&](const double (&dt8)[kG], const double (&in8)[kG], const double (&q8)[kG]) {
 #pragma unroll
         for (int u = 0; u < kG; ++u) {
-          if (i0 + u < ns) {
-            const double a = run1 * dtv[u];
-            pOut[u * kFbLd] = outSign * a + qv[u];
-            run2 += a + qv[u];
-            run1 += incSign * inc[u];
-          }
+          const double a = run1 * dt8[u];
+          pOut[u * kFbLd] = outSign * a + q8[u];
+          run2 += a + q8[u];
+          run1 += incSign * in8[u];
         }
         pOut += kG * kFbLd;
+      };
+      double dtA[kG], inA[kG], qA[kG], dtB[kG], inB[kG], qB[kG];
+      const int nFull = ns / kG;   // full groups
+      int gI = 0;
+      if (nFull > 0) loadGroup(dtA, inA, qA);
+      while (gI + 2 <= nFull) {
+        loadGroup(dtB, inB, qB);
+        runGroup(dtA, inA, qA);
+        if (gI + 2 < nFull) loadGroup(dtA, inA, qA);
+        runGroup(dtB, inB, qB);
+        gI += 2;
+      }
+      if (gI < nFull) { runGroup(dtA, inA, qA); ++gI; }
+      const int rem = ns - nFull * kG;   // steps of the partial group: masked (rows past the end are read but contribute zeros
+      if (rem > 0) {                     // and are stored into rows nobody reads; a round's rows end inside sh.fb)
+        loadGroup(dtA, inA, qA);
 #pragma unroll
-        for (int u = 0; u < kG; ++u) { dtv[u] = dtn[u]; inc[u] = incn[u]; qv[u] = qvn[u]; }
+        for (int u = 0; u < kG; ++u) {
+          const bool ok = u < rem;
+          dtA[u] = ok ? dtA[u] : 0.0; inA[u] = ok ? inA[u] : 0.0; qA[u] = ok ? qA[u] : 0.0;
+        }
+        runGroup(dtA, inA, qA);
       }
     }
     IMU_TICK(qp7);
@@ -1123,7 +1143,7 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
     if (lo < hi) {
       // inputs of the next step (the one before) are gathered from LDS while the MFMAs of the current one run
       const double* row = sh.fb + (size_t)(hi - 1) * kFbLd;
-      double g[3], qd[4], ex = row[54];
+      double g[3], qd[4];
 #pragma unroll
       for (int q = 0; q < 3; ++q) g[q] = row[tIdx[q]];
 #pragma unroll
@@ -1135,8 +1155,9 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
         for (int q = 0; q < 3; ++q) gn[q] = rn[tIdx[q]];
 #pragma unroll
         for (int q = 0; q < 4; ++q) qn[q] = rn[rowKind[q]];
-        const double exn = rn[54];
-        if (ex != 0.0) {
+        // (a step that was not executed has an all-zero row: N = 0, Q = 0 -- its products add nothing, so no branch: a
+        // branch per step makes every step its own basic block and nothing of one step overlaps with the next)
+        {
           double aq[4], nq[3];
 #pragma unroll
           for (int q = 0; q < 4; ++q) aq[q] = Ph[q] * qd[q];
@@ -1150,12 +1171,19 @@ __device__ void imuIntegrate(const DevImu& im, const uint32_t* __restrict__ T, c
 #pragma unroll
           for (int q = 0; q < 4; ++q) Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q], Ph[q], Xs, 0, 0, 0);   // M^T Q M
           Ph = Mn;
+          // an MFMA holds the matrix pipe for 64 cycles = 16 issue slots of this wave: the gathers and moves of the next step
+          // are slotted between the seven MFMAs instead of queueing behind the last one
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) g[q] = gn[q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) qd[q] = qn[q];
-        ex = exn;
       }
     }
     IMU_TICK(qcs);
@@ -1225,14 +1253,6 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   const int t = threadIdx.x;
   ImuState st;
   imuIntegrate<true>(im, imuT + 2 * (size_t)im.sampleStart, imuM + 6 * (size_t)im.sampleStart, sb, sh, st);
-  // store the state (thread 0) -- every thread holds identical values
-  if (t == 0) {
-    im.Delta_q[0] = st.Dq.x; im.Delta_q[1] = st.Dq.y; im.Delta_q[2] = st.Dq.z; im.Delta_q[3] = st.Dq.w;
-    for (int k = 0; k < 9; ++k) { im.C_integral[k] = st.Ci[k]; im.C_doubleintegral[k] = st.Cdi[k]; im.dalpha_db_g[k] = st.dal[k]; im.dv_db_g[k] = st.dv[k]; im.dp_db_g[k] = st.dp[k]; }
-    for (int k = 0; k < 3; ++k) { im.acc_integral[k] = st.ai[k]; im.acc_doubleintegral[k] = st.adi[k]; }
-    for (int k = 0; k < 9; ++k) im.sb_ref[k] = sb[k];
-    im.Delta_t = st.Delta_t;
-  }
   // symmetrise P, information = P^-1 (via Cholesky), symmetrise, sqrtInfo = chol(information)^T  (:246-258).
   // Both factorisations run on the register-resident 16x16 routine of the reduced solver (one wave, identity
   // padding): it returns L and L^-1 together, so information = L^-T L^-1 needs no triangular solves.
@@ -1241,7 +1261,8 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   const int wave = t >> 6, lane = t & 63;
   if (t < 225) sh.T[t] = 0.5 * sh.P[t] + 0.5 * sh.P[(t % 15) * 15 + t / 15];
   __syncthreads();
-  if (t < 225) im.P_delta[t] = sh.T[t];
+  const double pDeltaMine = (t < 225) ? sh.T[t] : 0.0;   // (all global stores of this routine wait until its end: one ahead of
+                                                           // a barrier holds the whole workgroup until the store has completed)
   {
     const int r = t >> 4, c = t & 15;
     sh.tile[r * kPanelLd + c] = (r < 15 && c < 15) ? sh.T[r * 15 + c] : ((r == c) ? 1.0 : 0.0);
@@ -1262,7 +1283,7 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   __syncthreads();
   if (t < 225) { sh.P[t] = 0.5 * sh.Fd[t] + 0.5 * sh.Fd[(t % 15) * 15 + t / 15]; }
   __syncthreads();
-  if (t < 225) im.information[t] = sh.P[t];
+  const double infoMine = (t < 225) ? sh.P[t] : 0.0;
   {
     const int r = t >> 4, c = t & 15;
     sh.tile[r * kPanelLd + c] = (r < 15 && c < 15) ? sh.P[r * 15 + c] : ((r == c) ? 1.0 : 0.0);
@@ -1273,6 +1294,16 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   if (t < 225) {
     const int a = t / 15, b = t % 15;
     im.sqrtInfo[t] = (b >= a) ? sh.tile[b * kPanelLd + a] : 0.0;  // L^T
+    im.P_delta[t] = pDeltaMine;
+    im.information[t] = infoMine;
+  }
+  // the pre-integrated state (thread 0) -- every thread holds identical values
+  if (t == 0) {
+    im.Delta_q[0] = st.Dq.x; im.Delta_q[1] = st.Dq.y; im.Delta_q[2] = st.Dq.z; im.Delta_q[3] = st.Dq.w;
+    for (int k = 0; k < 9; ++k) { im.C_integral[k] = st.Ci[k]; im.C_doubleintegral[k] = st.Cdi[k]; im.dalpha_db_g[k] = st.dal[k]; im.dv_db_g[k] = st.dv[k]; im.dp_db_g[k] = st.dp[k]; }
+    for (int k = 0; k < 3; ++k) { im.acc_integral[k] = st.ai[k]; im.acc_doubleintegral[k] = st.adi[k]; }
+    for (int k = 0; k < 9; ++k) im.sb_ref[k] = sb[k];
+    im.Delta_t = st.Delta_t;
   }
   __syncthreads();
   IMU_TICK(qPost1);
