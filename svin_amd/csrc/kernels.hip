@@ -64,6 +64,9 @@ __device__ __forceinline__ double rowMax16(double v) {
   v = fmax(v, dppRowMov<0x121>(v));
   return v;
 }
+// Workgroup barrier that only orders LDS traffic: __syncthreads() also waits for every outstanding global access of the
+// thread, so a global store issued just before it holds the whole workgroup for a memory round trip.
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // DPP move for wave-wide scans: kCtrl row_shr:N = 0x110 + N (within 16-lane rows), row_bcast:15 = 0x142 (lane 15 of a row
 // to the whole next row; row mask 0xa = rows 1 and 3), row_bcast:31 = 0x143 (lane 31 to rows 2 and 3: row mask 0xc),
 // wave_shr:1 = 0x138.  Lanes that receive nothing get 0.
@@ -1293,9 +1296,17 @@ __device__ void imuRedoPreintegration(DevImu& im, const uint32_t* __restrict__ i
   __syncthreads();
   if (t < 225) {
     const int a = t / 15, b = t % 15;
-    im.sqrtInfo[t] = (b >= a) ? sh.tile[b * kPanelLd + a] : 0.0;  // L^T
+    const double w = (b >= a) ? sh.tile[b * kPanelLd + a] : 0.0;  // L^T
+    im.sqrtInfo[t] = w;
+    sh.W[t] = w;   // the factor evaluation that follows reads the weights and the state from LDS, not back from memory
     im.P_delta[t] = pDeltaMine;
     im.information[t] = infoMine;
+  }
+  if (t == 64) {   // staged copy of the pre-integrated state, in the order of the DevImu fields from Delta_t on
+    double* q = sh.st;
+    q[0] = st.Delta_t; q[1] = st.Dq.x; q[2] = st.Dq.y; q[3] = st.Dq.z; q[4] = st.Dq.w;
+    for (int k = 0; k < 9; ++k) { q[5 + k] = st.Ci[k]; q[14 + k] = st.Cdi[k]; q[29 + k] = st.dal[k]; q[38 + k] = st.dv[k]; q[47 + k] = st.dp[k]; }
+    for (int k = 0; k < 3; ++k) { q[23 + k] = st.ai[k]; q[26 + k] = st.adi[k]; }
   }
   // the pre-integrated state (thread 0) -- every thread holds identical values
   if (t == 0) {
@@ -1458,9 +1469,7 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
       if (t == 0) { im.redo = 0; im.redoCounter++; }
 #pragma unroll
       for (int k = 0; k < 6; ++k) Db[k] = 0;
-      __syncthreads();
-      stage();
-      __syncthreads();
+      // (imuRedoPreintegration left the new weights in sh.W and the new state in sh.st and ended on a barrier)
     }
     IMU_TICK(qe1);
     IMU_ACC(8, qe0, qe1, t == 0 && !redo);
@@ -1695,7 +1704,7 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
       }
     }
   }
-  __syncthreads();
+  ldsBarrier();   // sh.rw only: the stores of r and J above need not have landed
   // cost partial: 0.5 |r|^2 (the residuals sit in the first 16 lanes: one DPP row sum)
   if (t < 64) {
     const double rv = ((t & 15) < m && t < 16) ? sh.rw[t & 15] : 0.0;
@@ -2369,6 +2378,10 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     const long long qc1 = __builtin_readcyclecounter();
     qdA += qc1 - qc0;
 #endif
+    double lmStore[12];
+    bool lmStoreBad = false;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) lmStore[k] = 0.0;
     const int l = chunk * kDenseLm + grp;
     if (l < p.L) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
@@ -2429,12 +2442,12 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
       const double i21 = -l21 * i11 * i22;
       const double i20 = -(l20 * i00 + l21 * i10) * i22;
       if (gl == 0) {
-        if (bad) atomicOr(&p.scal->cholFail, 1);
-        double* vi = p.Vinv + 6 * (size_t)l;  // Vinv = Linv^T Linv
-        vi[0] = i00 * i00 + i10 * i10 + i20 * i20; vi[1] = i10 * i11 + i20 * i21; vi[2] = i20 * i22;
-        vi[3] = i11 * i11 + i21 * i21; vi[4] = i21 * i22; vi[5] = i22 * i22;
-        p.bl[3 * l] = b0; p.bl[3 * l + 1] = b1; p.bl[3 * l + 2] = b2;
-        p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
+        // (the landmark's quantities for the later kernels are stored after the MFMA part of the chunk: a global store ahead
+        // of the barrier below would hold the workgroup until it has completed)
+        lmStore[0] = i00 * i00 + i10 * i10 + i20 * i20; lmStore[1] = i10 * i11 + i20 * i21; lmStore[2] = i20 * i22;   // Vinv = Linv^T Linv
+        lmStore[3] = i11 * i11 + i21 * i21; lmStore[4] = i21 * i22; lmStore[5] = i22 * i22;
+        lmStore[6] = b0; lmStore[7] = b1; lmStore[8] = b2; lmStore[9] = ht0; lmStore[10] = ht1; lmStore[11] = ht2;
+        lmStoreBad = bad;
         // augmented row dC: c = Linv b  (row dC+1 stays zero under G)
         double* cr = Gt + (size_t)dC * kDenseLd + 3 * grp;
         cr[0] = i00 * b0; cr[1] = i10 * b0 + i11 * b1; cr[2] = i20 * b0 + i21 * b1 + i22 * b2;
@@ -2557,6 +2570,14 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
         for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
         acc[k] = c;
       }
+    }
+    if (l < p.L && gl == 0) {   // the deferred per-landmark stores of this chunk
+      if (lmStoreBad) atomicOr(&p.scal->cholFail, 1);
+      double* vi = p.Vinv + 6 * (size_t)l;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vi[k] = lmStore[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { p.bl[3 * l + k] = lmStore[6 + k]; p.hL[3 * l + k] = lmStore[9 + k]; }
     }
     if ((chunk + nChunkBlocks) * kDenseLm < p.L) {   // another chunk follows (wide problems only): clear the staging tiles for it
       __syncthreads();
