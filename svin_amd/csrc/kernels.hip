@@ -2227,14 +2227,19 @@ constexpr int kPoseAcc = 28;              // per pose: 21 (upper 6x6) + 6 (Jp^T 
 // index of (a, c), a <= c, in the packed upper triangle of a 6x6 block
 __device__ __forceinline__ int sym6(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
 
-// MAXT: accumulator tiles per wave (9: up to 8 tile rows, dC <= 126; 34: up to 16 tile rows, dC <= 254).
+// MAXT: accumulator tiles per wave (9 on 4 waves: up to 8 tile rows, dC <= 126; 10 / 17 on 8 waves: up to 12 / 16 tile rows,
+// dC <= 190 / 254).
 // A_MFMA: the A part goes through the same MFMA path as G (U = [.. Jc_o^T ..] in batches of obsBatch observations, two
 // columns each, U U^T added to the tiles; the augmented rows carry r) instead of per-wave block copies.  Required with
 // variable extrinsics (their Jacobians add rows to G, and A gets pose-extrinsics cross blocks) and used for the
 // 34-tile variant (the block-copy merge does not fit the register file next to 34 accumulator tiles).
 __host__ __device__ constexpr int denseObsBatch(int rows) { return rows <= 128 ? 32 : (rows <= 192 ? 16 : 8); }
-template <int MAXT, bool A_MFMA>
-__global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
+// NW: waves per workgroup.  The landmark part always runs on the first 256 threads (16 lanes x 16 landmarks); with NW = 8 the
+// tiles are dealt over twice as many waves (clear, merge, products and slab stores take half as long per wave, and 10 tiles
+// per wave stay in registers where 20 spill).
+template <int MAXT, bool A_MFMA, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
+  static_assert(A_MFMA || NW == 4, "the per-wave block copies of A exist for four waves");
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
   if (b >= nChunkBlocks) {
@@ -2261,7 +2266,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   double* Across = Aw + (size_t)nP * kPoseAcc;
   const size_t extraLds = useBlocks ? (size_t)nP * kPoseAcc + (size_t)nEB * nPB * 36
                                     : (A_MFMA ? (size_t)rows * ldU : (size_t)4 * nP * kPoseAcc);
-  const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, grp = t >> 4, gl = t & 15;   // scalar: the tile tests below are SALU
   double* Amine = Aw + (size_t)wave * nP * kPoseAcc;
   // accumulator tiles (I >= J) owned by this wave: tile index tl = wave, wave + 4, ...
   constexpr int kMaxTiles = MAXT;
@@ -2295,14 +2300,14 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   auto rankUpdate = [&](const double* T, int ld, int nK4, double sign, unsigned tileMask) {
 #pragma unroll
     for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
-      const int tl = wave + 4 * k;
+      const int tl = wave + NW * k;
       if (tl < nTiles) {
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= tl) ++I;
         const int J = tl - I * (I + 1) / 2;
         if (!((tileMask >> I) & 1u) || !((tileMask >> J) & 1u)) continue;
-        const double* A = T + (size_t)(16 * I + (lane & 15)) * ld + (lane >> 4);
-        const double* B = T + (size_t)(16 * J + (lane & 15)) * ld + (lane >> 4);
+        const double* A = T + (size_t)(16 * J + (lane & 15)) * ld + (lane >> 4);   // rows: the smaller tile index (upper triangle)
+        const double* B = T + (size_t)(16 * I + (lane & 15)) * ld + (lane >> 4);
         d4_t c = acc[k];
         for (int q = 0; q < nK4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * A[4 * q], B[4 * q], c, 0, 0, 0);
         acc[k] = c;
@@ -2382,7 +2387,7 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     bool lmStoreBad = false;
 #pragma unroll
     for (int k = 0; k < 12; ++k) lmStore[k] = 0.0;
-    const int l = chunk * kDenseLm + grp;
+    const int l = (t < 256) ? chunk * kDenseLm + grp : p.L;
     if (l < p.L) {
       const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
       // everything this lane needs of its first observation (a landmark rarely has more than 16) is requested in ONE round
@@ -2530,42 +2535,54 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
     if (useBlocks && t < dC) hcAcc += Ash[(size_t)(t / 6) * kPoseAcc + sym6(t % 6, t % 6)];
 #pragma unroll
     for (int k = 0; k < kMaxTiles; ++k) {  // compile-time k: the accumulators stay in registers
-      const int tl = wave + 4 * k;
+      const int tl = wave + NW * k;
       if (tl < nTiles) {
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= tl) ++I;
         const int J = tl - I * (I + 1) / 2;
+        // the wave owns the UPPER-triangle tile (R, C) = (J, I), R <= C: rows from tile R, columns from tile C -- the slab
+        // rows are then written contiguously.  Only tiles near the diagonal (6x6 blocks straddle at most two tiles), the
+        // tile column of the two gradient columns and the extrinsics x pose rectangle receive anything from A: the
+        // tests are wave-uniform, every other tile goes straight to the products
+        const int R = J, C = I;
         d4_t c = acc[k];
+        const bool gradTile = C == (dC >> 4) || C == ((dC + 1) >> 4);
+        const bool diagTile = C - R <= 1;
+        const bool crossTile = useBlocks && 16 * C + 15 >= p.dCPose && 16 * R < p.dCPose;
+        if (gradTile || diagTile || crossTile) {
+          const int cc = 16 * C + (lane & 15);
+          const int c6 = cc / 6, ce = cc - 6 * c6;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int r = 16 * I + (lane >> 4) + 4 * rg, cc = 16 * J + (lane & 15);
-          int idx = -1, ps = 0;
-          if (cc < dC) {
-            ps = cc / 6;
-            if (r < dC) { if (r / 6 == ps) { const int a = r % 6, e = cc % 6; idx = sym6(min(a, e), max(a, e)); } }
-            else if (r <= dC + 1) idx = 21 + cc % 6;
-          }
-          if (!A_MFMA && idx >= 0) {
-            double s = 0;
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * R + (lane >> 4) + 4 * rg;
+            const int r6 = r / 6, ra = r - 6 * r6;
+            int idx = -1;
+            if (r < dC) {
+              if (cc < dC) { if (r6 == c6) idx = sym6(min(ra, ce), max(ra, ce)); }
+              else if (cc <= dC + 1) idx = 21 + ra;   // both gradient columns start from Jc^T r
+            }
+            if (!A_MFMA && idx >= 0) {
+              double s = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + ps) * kPoseAcc + idx];
-            c[rg] += s;
-          }
-          if (useBlocks) {
-            if (idx >= 0) {   // diagonal block / gradient rows
-              c[rg] += Ash[(size_t)ps * kPoseAcc + idx];
-            } else if (cc < dC && r < dC) {   // extrinsics x pose cross block, stored [extrinsics row][pose column]
-              const bool rExt = r >= p.dCPose, cExt = cc >= p.dCPose;
-              if (rExt != cExt) {
-                const int eb = (rExt ? r : cc) / 6 - nPB, pb = (rExt ? cc : r) / 6;
-                const int ea = (rExt ? r : cc) % 6, pe = (rExt ? cc : r) % 6;
-                c[rg] += Across[((size_t)eb * nPB + pb) * 36 + ea * 6 + pe];
+              for (int w = 0; w < 4; ++w) s += Aw[((size_t)w * nP + r6) * kPoseAcc + idx];
+              c[rg] += s;
+            }
+            if (useBlocks) {
+              if (idx >= 0) {   // diagonal block / gradient columns
+                c[rg] += Ash[(size_t)r6 * kPoseAcc + idx];
+              } else if (crossTile && cc < dC && r < dC) {   // extrinsics x pose cross block, stored [extrinsics row][pose column]
+                const bool rExt = r >= p.dCPose, cExt = cc >= p.dCPose;
+                if (rExt != cExt) {
+                  const int eb = (rExt ? r6 : c6) - nPB, pb = rExt ? c6 : r6;
+                  const int ea = rExt ? ra : ce, pe = rExt ? ce : ra;
+                  c[rg] += Across[((size_t)eb * nPB + pb) * 36 + ea * 6 + pe];
+                }
               }
             }
           }
         }
-        const double* A = Gt + (size_t)(16 * I + (lane & 15)) * kDenseLd + (lane >> 4);
-        const double* B = Gt + (size_t)(16 * J + (lane & 15)) * kDenseLd + (lane >> 4);
+        const double* A = Gt + (size_t)(16 * R + (lane & 15)) * kDenseLd + (lane >> 4);
+        const double* B = Gt + (size_t)(16 * C + (lane & 15)) * kDenseLd + (lane >> 4);
 #pragma unroll
         for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
         acc[k] = c;
@@ -2596,21 +2613,22 @@ __global__ __launch_bounds__(256) void k_schur_dense(DeviceProblem p, double mu,
   if (t < dC) slab[(size_t)dC * dC + 2 * dC + t] = hcAcc;
 #pragma unroll
   for (int k = 0; k < kMaxTiles; ++k) {
-    const int tl = wave + 4 * k;
+    const int tl = wave + NW * k;
     if (tl < nTiles) {
       int I = 0;
       while ((I + 1) * (I + 2) / 2 <= tl) ++I;
       const int J = tl - I * (I + 1) / 2;
+      const int c = 16 * I + (lane & 15), c6 = c / 6;   // tile (R, C) = (J, I) of the upper triangle: 16 contiguous doubles per row
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int r = 16 * I + (lane >> 4) + 4 * rg, c = 16 * J + (lane & 15);
+        const int r = 16 * J + (lane >> 4) + 4 * rg;
         const double v = acc[k][rg];
         if (r < dC && c < dC) {
           // k_reduce_slabs only reads the upper block triangle (6x6 blocks, diagonal blocks full)
-          if (r / 6 <= c / 6) slab[(size_t)r * dC + c] = v;
-          if (I != J) slab[(size_t)c * dC + r] = v;
-        } else if ((r == dC || r == dC + 1) && c < dC) {
-          slab[(size_t)dC * dC + (r - dC) * dC + c] = v;  // reduced gradient / full camera gradient
+          if (I != J || r / 6 <= c6) slab[(size_t)r * dC + c] = v;
+          if (I != J && r / 6 == c6) slab[(size_t)c * dC + r] = v;   // a diagonal 6x6 block that straddles two tiles
+        } else if (r < dC && c <= dC + 1) {
+          slab[(size_t)dC * dC + (c - dC) * dC + r] = v;  // reduced gradient / full camera gradient
         }
       }
     }
@@ -2979,15 +2997,16 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     const dim3 grid(p.nSlabs + nFac + nPri);
     DeviceProblem pb = p;
     pb.aBlocks = aBlocks ? 1 : 0;
-#define LAUNCH(MAXT, E)                                                                                             \
+#define LAUNCH(MAXT, E, NWV)                                                                                        \
   do {                                                                                                              \
-    ensureDynamicLds((const void*)k_schur_dense<MAXT, E>, ldsBytes); \
-    hipLaunchKernelGGL((k_schur_dense<MAXT, E>), grid, dim3(256), ldsBytes, s, pb, mu, initScale ? 1 : 0, p.nSlabs, \
+    ensureDynamicLds((const void*)k_schur_dense<MAXT, E, NWV>, ldsBytes); \
+    hipLaunchKernelGGL((k_schur_dense<MAXT, E, NWV>), grid, dim3(64 * NWV), ldsBytes, s, pb, mu, initScale ? 1 : 0, p.nSlabs, \
                        nFac);                                                                                       \
   } while (0)
-    if (nTr > 8) LAUNCH(34, true);
-    else if (aMfma) LAUNCH(9, true);
-    else LAUNCH(9, false);
+    if (nTr > 12) LAUNCH(17, true, 8);        // <= 16 tile rows: 136 tiles over 8 waves
+    else if (nTr > 8) LAUNCH(10, true, 8);    // <= 12 tile rows: 78 tiles
+    else if (aMfma) LAUNCH(9, true, 4);
+    else LAUNCH(9, false, 4);
 #undef LAUNCH
   } else if (p.L > 0 && p.N > 0 && dC > 0 && p.schurPanels) {
     const size_t ldsBytes = ((size_t)2 * kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc + kDenseK) * 8;
