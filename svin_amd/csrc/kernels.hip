@@ -3891,6 +3891,416 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
   }
 }
 
+// ================================================================ K6'': left-looking LDS Cholesky, 176 < dpad <= 272
+// The lower triangle of a 17 x 17-tile system (306 KB) does not fit LDS, but a left-looking factorisation never needs
+// all of it at once: when block column k is finished, what later columns still read are the tiles L(I, j), I > k,
+// j <= k -- at most (nT - 1 - k)(k + 1) <= 72 tiles (147 KB).  Every tile (I, j) lives from its panel solve (step j)
+// to the last update of block column I (step I - 1), and three families share the slots of the rectangle
+// rows h.., columns 0..h-1 (h = ceil(nT / 2)):
+//     I <  h           -> slot of rectangle tile (h + j, I)    (born at step I, when (I, .) has just died)
+//     I >= h, j <  h   -> its own slot
+//     I >= h, j >= h   -> slot of rectangle tile (j, I - h)    (row j dies before step j's panel solve)
+// (tools/ll_schedule.py replays the schedule and checks that no live tile is overwritten.)  Finished tiles are also
+// written through to global memory for the backward substitution.
+//   wave 0          the serial chain: diagonal tile k out of its registers (cholDiag16Acc), then forward substitution
+//                   of the right-hand side block k, then the last update of diagonal tile k + 1
+//   waves 1-7       own the tiles of one block column at a time, TRANSPOSED in MFMA accumulators: C(I,c)^T.  An
+//                   accumulator-layout tile is directly the B operand of a K = 16 product (register q = rows 4q + g),
+//                   so the panel solve X^T = L_cc^-1 C^T runs out of registers, and X^T in the accumulator layout is X
+//                   in the operand layout -- it goes to its LDS slot (XOR-swizzled, unpadded) and to global memory.
+//                   While wave 0 factorises diagonal tile k they apply the updates j < k to block column k + 1
+//                   (look-ahead); after the panel solve of column k only the update j = k is left.
+//                   (wave 4 shares its SIMD with wave 0; the chain has slack -- the look-ahead is the longer phase)
+// Two LDS-only barriers per block column.  The backward substitution stages L back from global memory in batches of
+// whole tile rows (bottom rows first) and sweeps them row by row.
+constexpr int kLLThreads = 512;
+#ifdef SVIN_LL_TIMING
+__device__ int g_llCount;
+#endif
+__host__ __device__ constexpr int llHalf(int nT) { return (nT + 1) / 2; }
+__host__ __device__ constexpr int llSlots(int nT) { return (nT - llHalf(nT)) * llHalf(nT); }
+__host__ __device__ constexpr size_t llLdsDoubles(int nT) { return (size_t)llSlots(nT) * 256 + 2 * 256 + 16 * kPanelLd + 16 + 2 * 16 * nT; }
+// (branch-free on purpose: as a chain of conditionals the compiler turns every slot lookup of the update loops into three
+// scalar branches)
+__device__ __forceinline__ int llSlot(int I, int j, int h) {
+  const int low = (I < h) ? 1 : 0, left = (j < h) ? 1 : 0;
+  const int sA = j * h + I, sB = (I - h) * h + j, sC = (j - h) * h + (I - h);
+  return low * sA + (1 - low) * (left * sB + (1 - left) * sC);
+}
+
+// T_u -= A B_u^T for NV tiles at once (independent accumulators: their MFMAs interleave), DIAG: also Td -= A A^T
+// (separate references, not arrays: the accumulators have to stay in registers)
+#define SVIN_MFMA_SUB(T, x, y) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-(x), (y), T, 0, 0, 0)
+template <int NV, bool DIAG>
+__device__ __forceinline__ void llUpdate(const double (&a)[4], const double (&b0)[4], const double (&b1)[4], const double (&b2)[4],
+                                         d4_t& T0, d4_t& T1, d4_t& T2, d4_t& Td) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (DIAG) SVIN_MFMA_SUB(Td, a[q], a[q]);
+    if (NV > 0) SVIN_MFMA_SUB(T0, a[q], b0[q]);
+    if (NV > 1) SVIN_MFMA_SUB(T1, a[q], b1[q]);
+    if (NV > 2) SVIN_MFMA_SUB(T2, a[q], b2[q]);
+  }
+}
+// n tiles; rows: how many of the first two are real rows (the last worker's third tile is the diagonal one)
+__device__ __forceinline__ void llUpdateN(int n, int rows, const double (&a)[4], const double (&b0)[4], const double (&b1)[4],
+                                          const double (&b2)[4], d4_t& T0, d4_t& T1, d4_t& T2) {
+  // one short block per tile (uniform branches): variants with interleaved accumulators cost more registers than the
+  // kernel has (their merge points keep copies of every accumulator alive)
+  d4_t none = {0, 0, 0, 0};
+  if (rows > 0) llUpdate<1, false>(a, b0, b0, b0, T0, T0, T0, none);
+  if (rows > 1) llUpdate<1, false>(a, b1, b1, b1, T1, T1, T1, none);
+  if (n > 2) llUpdate<1, false>(a, b2, b2, b2, T2, T2, T2, none);
+}
+// X_u^T = Linv T_u for NV tiles
+template <int NV>
+__device__ __forceinline__ void llPanel(const double (&li4)[4], d4_t& T0, d4_t& T1, d4_t& T2) {
+  d4_t x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (NV > 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(li4[q], T0[q], x0, 0, 0, 0);
+    if (NV > 1) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(li4[q], T1[q], x1, 0, 0, 0);
+    if (NV > 2) x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(li4[q], T2[q], x2, 0, 0, 0);
+  }
+  if (NV > 0) T0 = x0;
+  if (NV > 1) T1 = x1;
+  if (NV > 2) T2 = x2;
+}
+
+__global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize) {
+  extern __shared__ double smem[];
+  SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS),
+            SA(p.cholL));
+  const int t = threadIdx.x, d = p.d, nT = dpad / 16, h = llHalf(nT);
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int g = lane >> 4, cc = lane & 15;
+  const int ldS = p.ldS ? p.ldS : d;
+  double* slots = smem;                                  // llSlots(nT) unpadded, swizzled 16 x 16 tiles
+  double* H1 = slots + (size_t)llSlots(nT) * 256;        // look-ahead result of the next diagonal tile, two buffers, [r][lane]
+  double* diagBuf = H1 + 512;                            // factorised diagonal tile (16 x kPanelLd), as cholDiag16Acc leaves it
+  double* dinv16 = diagBuf + 16 * kPanelLd;
+  double* rhs = dinv16 + 16;                             // dpad
+  double* damp = rhs + dpad;                             // dpad: mu * htil per row (added to the diagonal tiles as they are taken up)
+  double* Lg = p.cholL;                                  // tile (I, j), j <= I, at (I (I + 1) / 2 + j) * 256, row-major 16 x 16
+  double* dinvG = Lg + (size_t)(nT * (nT + 1) / 2) * 256;  // dpad
+  int* fail = &p.scal->cholFail;
+  const int lopS = cc * 16 + (g ^ cc);                   // swizzled operand-layout offset of (row cc, column g): ^ 4q for column 4q + g
+  const int widx = wave - 1;                             // workers: waves 1 .. 7 -> 0 .. 6
+  const bool worker = wave != 0;
+  constexpr int nWork = 7, kTurns = 3;                   // (17 - 1) rows at most over 7 workers
+  const bool diagW = widx == nWork - 1;                  // the look-ahead of the next diagonal tile rides with the worker that has the fewest rows
+  // rows of block column c owned by this worker: c + 1 + widx + 6 u, u < rowsOf(c)
+  auto rowsOf = [&](int c) { const int n = nT - (c + 1 + widx); return n <= 0 ? 0 : min(kTurns, (n + nWork - 1) / nWork); };
+
+  // S tile (R, C), R <= C, in the accumulator layout: lane (g, cc) register r = S[16 R + g + 4 r][16 C + cc], identity padding;
+  // read from the lower triangle like the other loaders
+  auto loadS = [&](int R, int C) {
+    d4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
+      const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
+      const double x = p.S[(size_t)ci * ldS + cj];
+      v[r] = (gi < d && gj < d) ? x : ((gi == gj) ? 1.0 : 0.0);
+    }
+    return v;
+  };
+  // the same without the padding select: the value is not touched before maskS (a select right behind the load would expose
+  // its whole latency where the tile is only being prefetched)
+  auto loadSRaw = [&](int R, int C) {
+    d4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
+      const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
+      v[r] = p.S[(size_t)ci * ldS + cj];
+    }
+    return v;
+  };
+  auto maskS = [&](d4_t v, int R, int C) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
+      v[r] = (gi < d && gj < d) ? v[r] : ((gi == gj) ? 1.0 : 0.0);
+    }
+    return v;
+  };
+  auto slotAt = [&](int I, int j) { return slots + (size_t)llSlot(I, j, h) * 256; };
+  auto readOp = [&](const double* tile, double (&o)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = tile[lopS ^ (4 * q)];
+  };
+
+#ifdef SVIN_LL_TIMING
+  long long qT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long q0 = __builtin_readcyclecounter(), q1;
+#define LLT(i) do { q1 = __builtin_readcyclecounter(); qT[i] += q1 - q0; q0 = q1; } while (0)
+#else
+#define LLT(i) do { } while (0)
+#endif
+  // ---- prologue: damping / right-hand side, the first two block columns
+  // per wave three tiles of the current block column (Tc), of the next one (Tn) and the prefetched S tiles of the one after
+  // (Tp).  The last worker never owns a third row (6 + 14 > 15): its third entry is the next DIAGONAL tile.  Wave 0 keeps the
+  // diagonal tile it is factorising in Tc[0] (the register file is the scarce resource of this kernel: every spill reload
+  // is a vmcnt(0) wait behind the write-through stores and the prefetches)
+  d4_t Tc[kTurns], Tn[kTurns], Tp[kTurns];
+#pragma unroll
+  for (int u = 0; u < kTurns; ++u) { Tc[u] = d4_t{0, 0, 0, 0}; Tn[u] = d4_t{0, 0, 0, 0}; Tp[u] = d4_t{0, 0, 0, 0}; }
+  d4_t& accD = Tc[0];
+  if (wave == 0) accD = loadSRaw(0, 0);
+  if (worker) {
+#pragma unroll
+    for (int u = 0; u < kTurns; ++u) {
+      const int I0 = 1 + widx + nWork * u, I1 = 2 + widx + nWork * u;
+      if (I0 < nT) Tc[u] = loadSRaw(0, I0);
+      if (I1 < nT) Tp[u] = loadSRaw(1, I1);
+    }
+    if (diagW && nT > 1) Tp[2] = loadSRaw(1, 1);
+#pragma unroll
+    for (int u = 0; u < kTurns; ++u) Tc[u] = maskS(Tc[u], 0, 1 + widx + nWork * u);
+  }
+  if (wave == 0) accD = maskS(accD, 0, 0);
+  if (t < dpad) {
+    const double dmp = (fuseFinalize && t < d) ? finalizeRow(p, t, mu, initScale) : 0.0;
+    rhs[t] = (t < d) ? p.gRed[t] : 0.0;
+    damp[t] = dmp;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (g + 4 * r == cc) accD[r] += damp[cc];
+  }
+  LLT(0);
+
+  for (int k = 0; k < nT; ++k) {
+    const int k0 = 16 * k;
+    // ================= phase FD(k): last update (j = k - 1) of block column k, then look-ahead of block column k + 1
+    if (wave == 0) {
+      if (k >= 1) {
+        const double* Hb = H1 + (k & 1) * 256;
+        const double dmp = damp[k0 + cc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accD[r] = Hb[r * 64 + lane] + ((g + 4 * r == cc) ? dmp : 0.0);
+        double x[4];
+        readOp(slotAt(k, k - 1), x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[q], x[q], accD, 0, 0, 0);
+      }
+      LLT(6);
+      cholDiag16Acc(accD, diagBuf, dinv16, lane, fail);
+      LLT(7);
+    } else if (worker) {
+      if (k >= 1) {
+        // forward substitution: rhs_I -= X(I, k-1) y_{k-1} out of the registers of the panel solve (Tc = X^T, lane (g, cc)
+        // register r = X[cc][g + 4r])
+        double yk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yk[r] = rhs[k0 - 16 + g + 4 * r];
+#pragma unroll
+        for (int u = 0; u < kTurns; ++u) {
+          const int I = k + widx + nWork * u;
+          if (I < nT) {
+            const double s = Tc[u][0] * yk[0] + Tc[u][1] * yk[1] + Tc[u][2] * yk[2] + Tc[u][3] * yk[3];
+            double sg[4];
+            allGatherRows(s, sg);   // the four lane rows' partial sums (v_permlane swaps, no LDS round trip)
+            if (g == 0) rhs[16 * I + cc] -= (sg[0] + sg[1]) + (sg[2] + sg[3]);
+          }
+        }
+        // C(I, k)^T -= L(k, k-1) L(I, k-1)^T: every operand is requested before the first product
+        {
+          const int nv = rowsOf(k);
+          if (nv > 0) {
+            double a[4], b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
+            readOp(slotAt(k, k - 1), a);
+            if (nv > 0) readOp(slotAt(k + 1 + widx, k - 1), b0);
+            if (nv > 1) readOp(slotAt(k + 1 + widx + nWork, k - 1), b1);
+            if (nv > 2) readOp(slotAt(k + 1 + widx + 2 * nWork, k - 1), b2);
+            llUpdateN(nv, nv, a, b0, b1, b2, Tn[0], Tn[1], Tn[2]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kTurns; ++u) Tc[u] = Tn[u];
+      }
+      LLT(1);
+      const int c = k + 1;   // look-ahead column
+      if (c < nT) {
+#pragma unroll
+        for (int u = 0; u < kTurns; ++u) Tn[u] = maskS(Tp[u], c, (diagW && u == 2) ? c : c + 1 + widx + nWork * u);
+        // the block column after it is requested now: one step of latency cover
+        if (c + 1 < nT) {
+#pragma unroll
+          for (int u = 0; u < kTurns; ++u) {
+            const int I = c + 2 + widx + nWork * u;
+            if (I < nT) Tp[u] = loadSRaw(c + 1, I);
+          }
+          if (diagW) Tp[2] = loadSRaw(c + 1, c + 1);
+        }
+        LLT(6);
+        const int nv = rowsOf(c);
+        if (nv > 0 || diagW) {
+          // updates j < k, tile by tile: one accumulator takes the whole chain of products while the operands of step j + 1
+          // are already in flight (two operand sets of one tile pair fit the register file, two sets of all tiles do not)
+          auto chain = [&](d4_t& T, int I, bool isDiag) {
+            double a0[4], b0[4], a1[4], b1[4];
+            readOp(slotAt(c, 0), a0);
+            if (!isDiag) readOp(slotAt(I, 0), b0);
+            for (int j = 0; j < k; j += 2) {
+              if (j + 1 < k) {
+                readOp(slotAt(c, j + 1), a1);
+                if (!isDiag) readOp(slotAt(I, j + 1), b1);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) SVIN_MFMA_SUB(T, a0[q], isDiag ? a0[q] : b0[q]);
+              if (j + 1 < k) {
+                if (j + 2 < k) {
+                  readOp(slotAt(c, j + 2), a0);
+                  if (!isDiag) readOp(slotAt(I, j + 2), b0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) SVIN_MFMA_SUB(T, a1[q], isDiag ? a1[q] : b1[q]);
+              }
+            }
+          };
+          if (k > 0) {
+            if (nv > 0) chain(Tn[0], c + 1 + widx, false);
+            if (nv > 1) chain(Tn[1], c + 1 + widx + nWork, false);
+            if (diagW) chain(Tn[2], c, true);
+            else if (nv > 2) chain(Tn[2], c + 1 + widx + 2 * nWork, false);
+          }
+        }
+        LLT(7);
+        if (diagW) {
+          double* Hb = H1 + (c & 1) * 256;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Hb[r * 64 + lane] = Tn[2][r];
+        }
+      }
+    }
+    LLT(1);
+    ldsBarrier();
+    LLT(2);
+    // ================= phase P(k): panel solve of block column k; wave 0: y_k and the write-through of the diagonal tile
+    if (wave == 0) {
+      const int li = cc;
+      double yv = rhs[k0 + li] * dinv16[li];
+#pragma unroll
+      for (int c = 0; c < 15; ++c) {
+        const double term = diagBuf[c * kPanelLd + li] * rhs[k0 + c];
+        yv += (c < li) ? term : 0.0;
+      }
+      double dv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { const int e = lane + 64 * m; dv[m] = diagBuf[(e & 15) * kPanelLd + (e >> 4)]; }   // transposed: the backward solve reads columns
+      const double di = dinv16[cc];
+      waveSync();
+      if (lane < 16) rhs[k0 + lane] = yv;
+      double* Dg = Lg + (size_t)(k * (k + 1) / 2 + k) * 256;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) Dg[lane + 64 * m] = dv[m];
+      if (lane < 16) dinvG[k0 + lane] = di;
+    } else if (worker) {
+      double li4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 4 * q + g;
+        li4[q] = (cc > kk) ? diagBuf[kk * kPanelLd + cc] : ((cc == kk) ? dinv16[kk] : 0.0);
+      }
+      const int nv = rowsOf(k);
+      if (nv > 0) llPanel<1>(li4, Tc[0], Tc[1], Tc[2]);
+      if (nv > 1) llPanel<1>(li4, Tc[1], Tc[1], Tc[2]);
+      if (nv > 2) llPanel<1>(li4, Tc[2], Tc[1], Tc[2]);
+#pragma unroll
+      for (int u = 0; u < kTurns; ++u) {
+        const int I = k + 1 + widx + nWork * u;
+        if (u < nv) {
+          double* sl = slotAt(I, k);
+          double* Xg = Lg + (size_t)(I * (I + 1) / 2 + k) * 256 + cc * 16 + g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sl[lopS ^ (4 * r)] = Tc[u][r]; Xg[4 * r] = Tc[u][r]; }
+        }
+      }
+    }
+    LLT(3);
+    ldsBarrier();
+    LLT(4);
+  }
+
+  // ================= backward substitution L^T x = y: tile rows staged back from global memory, bottom rows first
+  __syncthreads();   // the write-through stores have completed
+  {
+    double* stage = smem;
+    const int cap = (int)(((size_t)llSlots(nT) * 256 + 512 + 16 * kPanelLd + 16) / 256) - (dpad + 255) / 256 - 1;
+    double* dinvAll = stage + (size_t)cap * 256;   // dpad doubles
+    // a batch (<= 75 tiles = 38 doubles per thread) is requested in one go; the next batch's values wait in registers while
+    // the current one is swept, so only the first round trip to L2 is exposed
+    constexpr int kHold = 38;
+    double hold[kHold];
+    auto batchLo = [&](int top) {
+      int lo = top, used = top + 1;
+      while (lo > 0 && used + lo <= cap) { used += lo; --lo; }   // rows lo .. top, row i = i + 1 tiles (diagonal included)
+      return lo;
+    };
+    // global order is row-major over (i, j): a batch is one contiguous range of tiles
+    auto request = [&](int lo, int top) {
+      const int e0 = lo * (lo + 1) / 2 * 256, e1 = (top + 1) * (top + 2) / 2 * 256;
+#pragma unroll
+      for (int m = 0; m < kHold; ++m) hold[m] = Lg[min(e0 + t + m * kLLThreads, e1 - 1)];
+    };
+    int top = nT - 1;
+    request(batchLo(top), top);
+    for (int i = t; i < dpad; i += blockDim.x) dinvAll[i] = dinvG[i];
+    while (top >= 0) {
+      const int lo = batchLo(top);
+      const int firstTile = lo * (lo + 1) / 2, nTilesB = (top + 1) * (top + 2) / 2 - firstTile;
+#pragma unroll
+      for (int m = 0; m < kHold; ++m) { const int e = t + m * kLLThreads; if (e < nTilesB * 256) stage[e] = hold[m]; }
+      if (lo > 0) request(batchLo(lo - 1), lo - 1);
+      ldsBarrier();
+      // x_i = L_ii^-T y_i by the wave that owns block i of the right-hand side (threads 16 i .. 16 i + 15 all sit in wave
+      // i / 4): after the sweep of row i + 1 it can go on to the next solve without a workgroup barrier.  The diagonal tile
+      // is staged transposed: Dt[r * 16 + li] = Linv[r][li]
+      auto solveRow = [&](int i) {
+        const double* Dt = stage + (size_t)(i * (i + 1) / 2 - firstTile + i) * 256;
+        const int li = cc;
+        double yv = rhs[16 * i + li] * dinvAll[16 * i + li];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+          const double term = Dt[r * 16 + li] * rhs[16 * i + r];
+          yv += (r > li) ? term : 0.0;
+        }
+        waveSync();
+        if (lane < 16) rhs[16 * i + lane] = yv;
+      };
+      if (wave == (top >> 2)) solveRow(top);
+      ldsBarrier();
+      for (int i = top; i >= lo; --i) {
+        const double* rowT = stage + (size_t)(i * (i + 1) / 2 - firstTile) * 256;   // tiles (i, 0 .. i)
+        if (t < 16 * i) {
+          const double* col = rowT + (size_t)(t >> 4) * 256 + (t & 15);   // L(16 i + kk, t)
+          double s = 0;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) s += col[kk * 16] * rhs[16 * i + kk];
+          rhs[t] -= s;
+        }
+        if (i - 1 >= lo && wave == ((i - 1) >> 2)) { waveSync(); solveRow(i - 1); }
+        ldsBarrier();
+      }
+      top = lo - 1;
+    }
+  }
+  for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
+#ifdef SVIN_LL_TIMING
+  LLT(5);
+  __shared__ int llPrint;
+  if (t == 0) llPrint = atomicAdd(&g_llCount, 1);
+  __syncthreads();
+  if (llPrint == 12 && lane == 0)
+    printf("[ll wave %d] prologue %lld  FD(F/rest) %lld (prefetch|w0 final) %lld (lookahead|w0 diag) %lld  waitB1 %lld  P %lld  waitB2 %lld  backsub %lld\n", wave, qT[0], qT[1], qT[6], qT[7], qT[2], qT[3], qT[4], qT[5]);
+#endif
+#undef LLT
+}
+
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
@@ -3899,6 +4309,11 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
                        fuseFinalize ? 1 : 0);
+  } else if (nT >= 12 && nT <= 17 && std::getenv("SVIN_NO_LL") == nullptr) {
+    // one workgroup, left-looking: at most 72 live tiles in LDS, finished tiles written through to p.cholL
+    const size_t ldsLL = llLdsDoubles(nT) * 8;
+    ensureDynamicLds((const void*)k_chol_solve_ll, ldsLL);
+    hipLaunchKernelGGL(k_chol_solve_ll, dim3(1), dim3(kLLThreads), ldsLL, s, p, dpad, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
   } else {
     // multi-workgroup blocked factorisation, 64-wide panels; p.cholL holds (dpad64 + 64) x dpad64 doubles, its tail
     // the 1/L_ii vector

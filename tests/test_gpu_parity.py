@@ -612,6 +612,25 @@ def test_wide_window_global_paths(gpu_lib):
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("P,rig", [(12, "euroc"), (13, "euroc"), (14, "euroc"), (15, "euroc"), (17, "euroc"), (18, "euroc"),
+                                   (8, "rig_v2"), (10, "rig_v2")])
+def test_left_looking_lds_solver_sizes(gpu_lib, P, rig):
+    """Reduced systems of 12..17 tile rows (176 < d <= 272: 12-18 keyframes with fixed extrinsics, 8-10 with per-frame
+    extrinsics) go through the one-workgroup left-looking LDS Cholesky (k_chol_solve_ll): every tile-row count, whole
+    optimisation against the oracle."""
+    spec = syn.make_window(P=P, L=500, n_obs=6000, seed=100 + P, rig=rig, frame_dt=0.25)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    gpu.optimize(8)
+    cpu.optimize(8)
+    sg, sc = gpu.summary(), cpu.summary()
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    log("left-looking solver P", P, rig, "gpu", sg, "cpu", sc, "pose diff", worst)
+    assert sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert sg["final_cost"] < sg["initial_cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    assert worst < 1e-4
+
+
 def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
     """the landmark-sharded solve (2 ranks emulated by 2 threads on one GPU, all-reduce through a
     barrier) must reproduce the single-GPU solve."""
