@@ -3988,7 +3988,9 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
   const int widx = wave - 1;                             // workers: waves 1 .. 7 -> 0 .. 6
   const bool worker = wave != 0;
   constexpr int nWork = 7, kTurns = 3;                   // (17 - 1) rows at most over 7 workers
-  const bool diagW = widx == nWork - 1;                  // the look-ahead of the next diagonal tile rides with the worker that has the fewest rows
+  // the look-ahead of diagonal tile (c, c) rides with the first worker that has one row less than the others in block column c
+  // (the rows are dealt round-robin: worker (nT - c - 1) mod 7; at most two rows there, its third entry is free)
+  auto diagOwner = [&](int c) { return widx == (nT - c - 1) % nWork; };
   // rows of block column c owned by this worker: c + 1 + widx + 6 u, u < rowsOf(c)
   auto rowsOf = [&](int c) { const int n = nT - (c + 1 + widx); return n <= 0 ? 0 : min(kTurns, (n + nWork - 1) / nWork); };
 
@@ -4040,7 +4042,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #endif
   // ---- prologue: damping / right-hand side, the first two block columns
   // per wave three tiles of the current block column (Tc), of the next one (Tn) and the prefetched S tiles of the one after
-  // (Tp).  The last worker never owns a third row (6 + 14 > 15): its third entry is the next DIAGONAL tile.  Wave 0 keeps the
+  // (Tp).  The third entry of the worker with the fewest rows holds the next DIAGONAL tile.  Wave 0 keeps the
   // diagonal tile it is factorising in Tc[0] (the register file is the scarce resource of this kernel: every spill reload
   // is a vmcnt(0) wait behind the write-through stores and the prefetches)
   d4_t Tc[kTurns], Tn[kTurns], Tp[kTurns];
@@ -4055,7 +4057,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
       if (I0 < nT) Tc[u] = loadSRaw(0, I0);
       if (I1 < nT) Tp[u] = loadSRaw(1, I1);
     }
-    if (diagW && nT > 1) Tp[2] = loadSRaw(1, 1);
+    if (nT > 1 && diagOwner(1)) Tp[2] = loadSRaw(1, 1);
 #pragma unroll
     for (int u = 0; u < kTurns; ++u) Tc[u] = maskS(Tc[u], 0, 1 + widx + nWork * u);
   }
@@ -4125,6 +4127,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
       LLT(1);
       const int c = k + 1;   // look-ahead column
       if (c < nT) {
+        const bool diagW = diagOwner(c);
 #pragma unroll
         for (int u = 0; u < kTurns; ++u) Tn[u] = maskS(Tp[u], c, (diagW && u == 2) ? c : c + 1 + widx + nWork * u);
         // the block column after it is requested now: one step of latency cover
@@ -4134,7 +4137,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
             const int I = c + 2 + widx + nWork * u;
             if (I < nT) Tp[u] = loadSRaw(c + 1, I);
           }
-          if (diagW) Tp[2] = loadSRaw(c + 1, c + 1);
+          if (diagOwner(c + 1)) Tp[2] = loadSRaw(c + 1, c + 1);
         }
         LLT(6);
         const int nv = rowsOf(c);
