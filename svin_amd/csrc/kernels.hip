@@ -3,11 +3,13 @@
 // K1  k_eval_reproj      reprojection residual + minimal Jacobians + Cauchy corrector (fused K4)
 // K2  k_eval_factors     IMU (incl. conditional re-preintegration) and the small unary/binary factors
 // K3  k_prior_*          marginalisation prior in H-space
-// K5  k_schur            per-landmark V/b, wave-reduced; pairwise Schur blocks accumulated in LDS-private
-//                        copies of the reduced camera matrix, flushed as slabs and reduced deterministically
-// K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS, trailing update on v_mfma_f64_16x16x4_f64
-//     k_big_chol_chain   (d > 176) one-launch tile Cholesky over many workgroups + super-panel backward substitution
-// K7  k_backsub / k_dogleg_step / k_retract
+// K5  k_schur_dense      landmark elimination as a Gram matrix S = A - G G^T on v_mfma_f64_16x16x4_f64 (narrow windows);
+//     k_schur_panels     the same in 96-row panel pairs (wide windows); k_schur: pairwise blocks with LDS atomics (fallback)
+//     k_reduce_slabs     deterministic sum of the per-workgroup slabs
+// K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS (d <= 176), trailing update on MFMA
+//     k_chol_solve_ll    (176 < d <= 272) left-looking variant: at most 72 live tiles in LDS behind a slot map
+//     k_big_chol_chain   (d > 272) one-launch tile Cholesky over many workgroups + super-panel backward substitution
+// K7  k_post_solve       back-substitution, J*v / J*y sums, dogleg step and retraction (k_step_retract for rejected steps)
 // K8  cost reductions    per-block partials + single-block final reduce (deterministic)
 // K9  k_landmark_quality
 // Reference arithmetic: see dmath.hpp and the per-kernel comments.
@@ -3296,32 +3298,15 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
 }
 
 // ================================================================ K6': reduced systems beyond the LDS-resident solver
-// Blocked right-looking Cholesky with 64-wide panels over several workgroups (d > 176, e.g. per-frame extrinsics or
-// wide windows).  The right-hand side rides along as one extra row block below the matrix, so the forward
-// substitution falls out of the panel solves; per panel two launches:
-//   k_big_panel  every workgroup factorises the 64x64 diagonal block redundantly in LDS (4x4 tiles, the register
-//                routine on the diagonal tiles, MFMA for the rest) and solves its own 64-row slab of the panel
-//                X = A L^-T with MFMA (block forward substitution over the four tile columns);
-//   k_big_syrk   one workgroup per 64x64 block of the trailing matrix: C -= X_I X_J^T on MFMA.
-// k_big_back finishes with the backward substitution in one workgroup.
+// Blocked Cholesky over 64x64 blocks on many workgroups (d > 272, wide windows).  The right-hand side rides along as one
+// extra row block below the matrix, so the forward substitution falls out of the block solves; k_big_back finishes with
+// the backward substitution.
 constexpr int kNB = 64;
 constexpr int kBigTileLd = kPanelLd;                 // 16 x 17 LDS tiles
 constexpr int kBigBlockLds = 16 * 16 * kBigTileLd;   // a 64x64 block as 4x4 tiles
 
-// global (row-major, leading dimension ld) 64x64 block -> 4x4 LDS tiles and back; 256 threads
-__device__ __forceinline__ void loadBlock64(const double* g, int ld, double* tiles) {
-  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-    const int r = e >> 6, c = e & 63;
-    tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)] = g[(size_t)r * ld + c];
-  }
-}
-__device__ __forceinline__ void storeBlock64(double* g, int ld, const double* tiles) {
-  for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
-    const int r = e >> 6, c = e & 63;
-    g[(size_t)r * ld + c] = tiles[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)];
-  }
-}
-// the same through agent-scope relaxed atomics (sc1: the access itself is coherent across the XCDs' L2s), for blocks
+// global (row-major, leading dimension ld) 64x64 block <-> 4x4 LDS tiles, 256 threads,
+// through agent-scope relaxed atomics (sc1: the access itself is coherent across the XCDs' L2s), for blocks
 // handed between workgroups of one launch without an L2 write-back / invalidate
 __device__ __forceinline__ void loadBlock64Coherent(const double* g, int ld, double* tiles) {
   for (int e = threadIdx.x; e < 64 * 64; e += blockDim.x) {
@@ -3445,68 +3430,6 @@ __global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, dou
   }
 }
 
-__global__ __launch_bounds__(256) void k_big_panel(DeviceProblem p, int dpad, int k0, double* dinvG, double* diagF) {
-  extern __shared__ double smem[];
-  double* Dt = smem;                         // diagonal block, 16 tiles
-  double* At = smem + kBigBlockLds;          // this workgroup's slab, 16 tiles
-  double* dinv = At + kBigBlockLds;          // 64
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double* M = p.cholL;
-  loadBlock64(M + (size_t)k0 * dpad + k0, dpad, Dt);
-  const int r0 = k0 + kNB + kNB * (int)blockIdx.x;   // first row of the slab
-  const bool hasSlab = r0 < dpad + kNB;
-  if (hasSlab) loadBlock64(M + (size_t)r0 * dpad + k0, dpad, At);
-  __syncthreads();
-  factor64(Dt, dinv, &p.scal->cholFail);
-  if (blockIdx.x == 0) {   // the factor itself: L below / L_tt^-T above the diagonal of the diagonal tiles, 1/L_ii.
-    // It goes to its own buffer: the other workgroups may still be loading the unfactorised block from M.
-    storeBlock64(diagF + (size_t)k0 * kNB, kNB, Dt);
-    if (threadIdx.x < kNB) dinvG[k0 + threadIdx.x] = dinv[threadIdx.x];
-  }
-  if (!hasSlab) return;
-  slabSolve64(Dt, At, dinv);
-  __syncthreads();
-  storeBlock64(M + (size_t)r0 * dpad + k0, dpad, At);
-}
-
-// trailing update: block (bi, bj), bi >= bj, of the rows / columns behind panel k0 (the right-hand-side row block is
-// the last bi; it has no columns of its own)
-__global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int k0) {
-  extern __shared__ double smem[];
-  double* Xi = smem;
-  double* Xj = smem + kBigBlockLds;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nCol = (dpad - k0 - kNB) / kNB;          // column blocks behind the panel
-  // blockIdx.x -> (bi, bj): bj < nCol, bj <= bi <= nCol (bi == nCol is the rhs row block)
-  int bj = 0, rem = blockIdx.x;
-  while (rem >= nCol + 1 - bj) { rem -= nCol + 1 - bj; ++bj; }
-  const int bi = bj + rem;
-  double* M = p.cholL;
-  const int ri = k0 + kNB + kNB * bi, rj = k0 + kNB + kNB * bj;
-  loadBlock64(M + (size_t)ri * dpad + k0, dpad, Xi);
-  if (bi != bj) loadBlock64(M + (size_t)rj * dpad + k0, dpad, Xj);
-  __syncthreads();
-  const double* XJ = (bi == bj) ? Xi : Xj;
-  for (int tj = 0; tj < 4; ++tj) {   // wave owns row tile `wave` of the 64x64 output block
-    double* C = M + (size_t)(ri + 16 * wave) * dpad + rj + 16 * tj;
-    d4_t acc;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[rg] = C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const double* A = Xi + (wave * 4 + kt) * (16 * kBigTileLd);
-      const double* B = XJ + (tj * 4 + kt) * (16 * kBigTileLd);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
-                                                   B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)] = acc[rg];
-  }
-}
-
-// ---------------------------------------------------------------- one-launch tile Cholesky (d > 176)
 // Left-looking over 64x64 blocks in ONE launch: task (I, J), I >= J (I = nb is the right-hand-side row block), owns
 // block (I, J): C = A(I,J) - sum_{k<J} X(I,k) X(J,k)^T on MFMA (C in registers), then potrf (I == J, factor64) or
 // X = C L_JJ^-T (slabSolve64).  Tasks are numbered column by column and dealt round-robin to <= 256 co-resident
@@ -3515,8 +3438,8 @@ __global__ __launch_bounds__(256) void k_big_syrk(DeviceProblem p, int dpad, int
 // Finished blocks cross XCD L2s: they are written and read with agent-scope relaxed atomics (sc1 accesses, coherent by
 // themselves), the writer waits for its stores to complete before ready[I][J] is set, the reader polls ready[I][J]
 // before it loads -- no L2 write-back / invalidate (buffer_wbl2 / buffer_inv cost ~10 us per hand-over here).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
-// Superseded by k_big_chol_chain below (kept for A/B runs: SVIN_BIG_CHOL_TASKS=1); the per-panel launch pair
-// (k_big_panel + k_big_syrk) stays as the launch-based fallback (SVIN_BIG_CHOL_LAUNCHES=1).
+// (k_big_chol_chain below; its predecessors -- a launch pair per 64-wide panel, then plain block tasks without the
+// critical-path workgroup -- are in the history of this file.)
 constexpr int kSpinMax = 1 << 20;
 // Workgroups of one solve: all must be co-resident (1 per CU: 104 KB of LDS each).  120 leaves room for a second
 // solve of another handle / stream on the same GPU (2 x 120 <= 256 CUs); roots with more than kPersistWideTasks
@@ -3530,102 +3453,6 @@ __device__ __forceinline__ bool pollReady(const int* f) {
   }
   return false;
 }
-__global__ __launch_bounds__(256) void k_big_chol_tasks(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
-  extern __shared__ double smem[];
-  double* Xi = smem;                       // X(I, k) / the slab during the solve
-  double* Xj = smem + kBigBlockLds;        // X(J, k)
-  double* Dt = smem + 2 * kBigBlockLds;    // diagonal block
-  double* dinv = Dt + kBigBlockLds;        // 64
-  int* seen = reinterpret_cast<int*>(dinv + kNB);   // [0] = all dependencies of the first sweep present, [1] = wait ok
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int nb = dpad / kNB;
-  double* M = p.cholL;
-  const int nTasks = nb * (nb + 1) / 2 + nb;
-  bool gaveUp = false;                     // (thread 0) a wait ran into its bound: stop waiting, the result is flagged bad
-  int J = 0, colStart = 0;                 // tasks of column J: colStart .. colStart + (nb - J), I = J + (t - colStart)
-  for (int task = blockIdx.x; task < nTasks; task += gridDim.x) {
-    while (task >= colStart + (nb - J + 1)) { colStart += nb - J + 1; ++J; }
-    const int I = J + (task - colStart);
-    // C <- A(I, J), row tile `wave`, 4 column tiles
-    d4_t acc[4];
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-      const double* C = M + (size_t)(kNB * I + 16 * wave) * dpad + kNB * J + 16 * tj;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) acc[tj][rg] = C[(size_t)((lane >> 4) + 4 * rg) * dpad + (lane & 15)];
-    }
-    // one parallel look at all dependencies: usually everything but the last columns is already there
-    if (tid == 0) seen[0] = J;
-    __syncthreads();
-    int firstMissing = J;
-    for (int k = tid; k < J; k += blockDim.x) {
-      const bool ok = __hip_atomic_load(ready + I * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-                      __hip_atomic_load(ready + J * nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      if (!ok) firstMissing = min(firstMissing, k);
-    }
-    if (firstMissing < J) atomicMin(seen, firstMissing);
-    __syncthreads();
-    const int kSafe = seen[0];   // dependencies k < kSafe are present
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    __syncthreads();
-    for (int k = 0; k < J; ++k) {
-      if (k >= kSafe) {
-        if (tid == 0 && !gaveUp) {
-          const bool ok = pollReady(ready + I * nb + k) && pollReady(ready + J * nb + k);
-          if (!ok) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
-      loadBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * k, dpad, Xi);
-      if (I != J) loadBlock64Coherent(M + (size_t)(kNB * J) * dpad + kNB * k, dpad, Xj);
-      __syncthreads();
-      const double* XJ = (I == J) ? Xi : Xj;
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          const double* A = Xi + (wave * 4 + kt) * (16 * kBigTileLd);
-          const double* B = XJ + (tj * 4 + kt) * (16 * kBigTileLd);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
-                                                           B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc[tj], 0, 0, 0);
-        }
-      __syncthreads();
-    }
-    if (I == J) {
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          Dt[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
-      __syncthreads();
-      factor64(Dt, dinv, &p.scal->cholFail);
-      storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
-      if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (tid == 0 && !gaveUp && !pollReady(ready + J * nb + J)) { atomicOr(&p.scal->cholFail, 2); gaveUp = true; }
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      loadBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, Dt);
-      if (tid < kNB) dinv[tid] = __hip_atomic_load(dinvG + kNB * J + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          Xi[(wave * 4 + tj) * (16 * kBigTileLd) + ((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[tj][rg];
-      __syncthreads();
-      slabSolve64(Dt, Xi, dinv);
-      __syncthreads();
-      storeBlock64Coherent(M + (size_t)(kNB * I) * dpad + kNB * J, dpad, Xi);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's coherent stores have completed (vmcnt 0)
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(ready + I * nb + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 // ---------------------------------------------------------------- tile Cholesky with a critical-path workgroup
 // Same left-looking block tasks, but the two blocks per column that sit on the critical path -- the diagonal block
 // (J, J) and the block below it (J+1, J) -- belong to ONE workgroup (the chain) that keeps L_JJ and X(J+1, J) in LDS
@@ -4094,33 +3921,32 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
       LLT(7);
     } else if (worker) {
       if (k >= 1) {
-        // forward substitution: rhs_I -= X(I, k-1) y_{k-1} out of the registers of the panel solve (Tc = X^T, lane (g, cc)
-        // register r = X[cc][g + 4r])
-        double yk[4];
+        // the operands of the last update C(I, k)^T -= L(k, k-1) L(I, k-1)^T are requested first; the forward substitution
+        // rhs_I -= X(I, k-1) y_{k-1} (out of the registers of the panel solve: Tc = X^T, lane (g, cc) register r =
+        // X[cc][g + 4r]) runs while they are on their way
+        const int nv = rowsOf(k), nvPrev = rowsOf(k - 1);
+        double a[4], b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
+        if (nv > 0) {
+          readOp(slotAt(k, k - 1), a);
+          readOp(slotAt(k + 1 + widx, k - 1), b0);
+          if (nv > 1) readOp(slotAt(k + 1 + widx + nWork, k - 1), b1);
+          if (nv > 2) readOp(slotAt(k + 1 + widx + 2 * nWork, k - 1), b2);
+        }
+        double yk[4], rOld[kTurns];
 #pragma unroll
         for (int r = 0; r < 4; ++r) yk[r] = rhs[k0 - 16 + g + 4 * r];
 #pragma unroll
+        for (int u = 0; u < kTurns; ++u) rOld[u] = (u < nvPrev) ? rhs[16 * (k + widx + nWork * u) + cc] : 0.0;
+#pragma unroll
         for (int u = 0; u < kTurns; ++u) {
-          const int I = k + widx + nWork * u;
-          if (I < nT) {
+          if (u < nvPrev) {
             const double s = Tc[u][0] * yk[0] + Tc[u][1] * yk[1] + Tc[u][2] * yk[2] + Tc[u][3] * yk[3];
             double sg[4];
             allGatherRows(s, sg);   // the four lane rows' partial sums (v_permlane swaps, no LDS round trip)
-            if (g == 0) rhs[16 * I + cc] -= (sg[0] + sg[1]) + (sg[2] + sg[3]);
+            if (g == 0) rhs[16 * (k + widx + nWork * u) + cc] = rOld[u] - ((sg[0] + sg[1]) + (sg[2] + sg[3]));
           }
         }
-        // C(I, k)^T -= L(k, k-1) L(I, k-1)^T: every operand is requested before the first product
-        {
-          const int nv = rowsOf(k);
-          if (nv > 0) {
-            double a[4], b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
-            readOp(slotAt(k, k - 1), a);
-            if (nv > 0) readOp(slotAt(k + 1 + widx, k - 1), b0);
-            if (nv > 1) readOp(slotAt(k + 1 + widx + nWork, k - 1), b1);
-            if (nv > 2) readOp(slotAt(k + 1 + widx + 2 * nWork, k - 1), b2);
-            llUpdateN(nv, nv, a, b0, b1, b2, Tn[0], Tn[1], Tn[2]);
-          }
-        }
+        if (nv > 0) llUpdateN(nv, nv, a, b0, b1, b2, Tn[0], Tn[1], Tn[2]);
 #pragma unroll
         for (int u = 0; u < kTurns; ++u) Tc[u] = Tn[u];
       }
@@ -4323,16 +4149,11 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     const int dp = ((p.d + kNB - 1) / kNB) * kNB;
     double* dinvG = p.cholL + (size_t)(dp + kNB) * dp;
     double* diagF = dinvG + dp;   // per panel the factorised 64x64 diagonal block (dp x 64)
-    const size_t ldsPanel = ((size_t)2 * kBigBlockLds + kNB) * 8, ldsSyrk = (size_t)2 * kBigBlockLds * 8;
-    ensureDynamicLds((const void*)k_big_panel, ldsPanel);
-    ensureDynamicLds((const void*)k_big_syrk, ldsSyrk);
     const int nb = dp / kNB;
     int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 1) x nb block flags
-    static const bool perPanelLaunches = std::getenv("SVIN_BIG_CHOL_LAUNCHES") != nullptr;
     hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
                        (nb + 3) * nb);
-    static const bool plainTasks = std::getenv("SVIN_BIG_CHOL_TASKS") != nullptr;
-    if (!perPanelLaunches && !plainTasks) {
+    {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
       ensureDynamicLds((const void*)k_big_chol_chain, ldsTasks);
       int nHelperTasks = 0;
@@ -4341,22 +4162,6 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
                          dim3(1 + std::max(1, std::min(nHelperTasks, (nHelperTasks > kPersistWideTasks ? kPersistWideGrid : kPersistMaxGrid) - 1))),
                          dim3(256), ldsTasks, s, p, dp,
                          dinvG, diagF, ready);
-    } else if (!perPanelLaunches) {
-      const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
-      ensureDynamicLds((const void*)k_big_chol_tasks, ldsTasks);
-      const int nTasks = nb * (nb + 1) / 2 + nb;
-      hipLaunchKernelGGL(k_big_chol_tasks, dim3(std::min(nTasks, kPersistMaxGrid)), dim3(256), ldsTasks, s, p, dp, dinvG, diagF,
-                         ready);
-    } else {
-      for (int k0 = 0; k0 < dp; k0 += kNB) {
-        const int nRowBlocks = (dp + kNB - k0 - kNB) / kNB;   // slabs below the diagonal block, rhs block included
-        hipLaunchKernelGGL(k_big_panel, dim3(nRowBlocks), dim3(256), ldsPanel, s, p, dp, k0, dinvG, diagF);
-        const int nCol = (dp - k0 - kNB) / kNB;
-        if (nCol > 0) {
-          const int nBlocks = nCol * (nCol + 1) / 2 + nCol;   // lower-triangular blocks + the rhs row block
-          hipLaunchKernelGGL(k_big_syrk, dim3(nBlocks), dim3(256), ldsSyrk, s, p, dp, k0);
-        }
-      }
     }
     const size_t ldsBack = ((size_t)kBackSpan + 8 * 64 + kNB * (kNB + 1) + kNB) * 8;
     for (int c1 = dp; c1 > 0; c1 -= kBackSpan) {
