@@ -283,7 +283,7 @@ def window_record(name, spec, device, steps, warmup, iters):
 
 def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
     """ONE config-#4 window (64 KF / 50 000 landmarks / 500 000 residuals) with its landmarks split over the ranks: every
-    rank holds all states and its landmark range; per iteration one RCCL all-reduce of [S | g | h] (d^2 + 3d doubles) and
+    rank holds all states and its landmark range; per iteration one RCCL all-reduce of [lower triangle of S | g | h] (d (d + 1) / 2 + 3 d doubles) and
     three small ones of trust-region scalars, all enqueued on the solver's stream (svin_ba_set_distributed_rccl)."""
     import torch
     from svin_amd import synthetic as syn
@@ -310,7 +310,7 @@ def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
                 ms_per_iteration=1e3 * sum(times) / max(sum(its), 1), median_ms_per_step=1e3 * float(np.median(times)),
                 iterations_per_step=sum(its) / steps, final_cost=last["final_cost"], initial_cost=last["initial_cost"],
                 landmarks_per_rank=mine.L, residuals_per_rank=mine.N,
-                allreduce_bytes_per_iteration=8 * (d * d + 3 * d) + 8 * (8 + 2 + 8),
+                allreduce_bytes_per_iteration=8 * (d * (d + 1) // 2 + 3 * d) + 8 * (8 + 2 + 8),
                 collective="ncclAllReduce (RCCL), FP64 sum, in place, on the solver's HIP stream")
 
 

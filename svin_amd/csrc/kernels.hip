@@ -186,6 +186,31 @@ __global__ __launch_bounds__(64) void k_publish_scalars(const SolverScalars* sca
   __syncthreads();
   if (t == 0) *reinterpret_cast<volatile unsigned long long*>(&mailbox->seq) = seq;
 }
+// Sharded mode: the message of the per-iteration all-reduce is the LOWER triangle of S (the solvers read nothing else)
+// followed by gRed | gFull | hC, packed row by row into p.cholL (free until the solver starts): d (d + 1) / 2 + 3 d doubles
+// instead of d^2 + 3 d.  One workgroup per row; block d copies the vectors.
+__global__ __launch_bounds__(256) void k_pack_lower(DeviceProblem p, int unpack) {
+  const int d = p.d, i = blockIdx.x, ld = p.ldS ? p.ldS : d;
+  double* msg = p.cholL;
+  if (i < d) {
+    double* row = p.S + (size_t)i * ld;
+    double* m = msg + (size_t)i * (i + 1) / 2;
+    for (int j = threadIdx.x; j <= i; j += blockDim.x) {
+      if (unpack) row[j] = m[j]; else m[j] = row[j];
+    }
+  } else {
+    double* m = msg + (size_t)d * (d + 1) / 2;
+    for (int j = threadIdx.x; j < 3 * d; j += blockDim.x) {
+      double* v = (j < d) ? p.gRed + j : ((j < 2 * d) ? p.gFull + (j - d) : p.hC + (j - 2 * d));
+      if (unpack) *v = m[j]; else m[j] = *v;
+    }
+  }
+}
+size_t packedSystemDoubles(const DeviceProblem& p) { return (size_t)p.d * (p.d + 1) / 2 + (size_t)3 * p.d; }
+void launchPackSystem(const DeviceProblem& p, bool unpack, hipStream_t s) {
+  if (p.d <= 0) return;
+  hipLaunchKernelGGL(k_pack_lower, dim3(p.d + 1), dim3(256), 0, s, p, unpack ? 1 : 0);
+}
 void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq, hipStream_t s) {
   hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, scal, mailbox, seq);
 }

@@ -1282,7 +1282,11 @@ void Window::solve(size_t numIter, bool verbose) {
         if (!(specValid && specMu == mu && !initScale))
           launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/!accumulatorsClean);  // pack() / k_post_solve cleared them
         specValid = false;
-        AR(p.S, (size_t)p.d * p.d + (size_t)3 * std::max(p.d, 1), 0);
+        if (dist && p.d > 0) {   // one message: lower triangle of S + gRed + gFull + hC (half of what the full matrix would be)
+          launchPackSystem(p, /*unpack=*/false, s);
+          AR(p.cholL, packedSystemDoubles(p), 0);
+          launchPackSystem(p, /*unpack=*/true, s);
+        }
         launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
         p.lmDeferred = deferLm ? 1 : 0;
         launchDoglegPrepare(p, s, fuseStep ? radius : -1.0);

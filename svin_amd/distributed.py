@@ -3,7 +3,7 @@
 One process per GPU.  Every rank holds all states (poses, speed/bias, extrinsics) and the factors
 between them; landmarks -- with *all* their observations -- are partitioned into contiguous ranges, one
 per rank.  Per Gauss-Newton iteration each rank eliminates its own landmarks and accumulates a partial
-reduced camera system; ONE all-reduce (sum, FP64, d*d + 3d doubles) makes the system identical on every
+reduced camera system; ONE all-reduce (sum, FP64, the lower triangle + three vectors: d (d + 1) / 2 + 3 d doubles) makes the system identical on every
 rank, which then solves it redundantly and back-substitutes only its own landmarks.  Two more tiny
 all-reduces carry the trust-region scalars.  The collective is RCCL over xGMI (`torch.distributed`
 backend "nccl"); on CPU the same code path runs over gloo for the tests.
