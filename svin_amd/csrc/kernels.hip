@@ -3861,17 +3861,25 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
   };
   // the same without the padding select: the value is not touched before maskS (a select right behind the load would expose
   // its whole latency where the tile is only being prefetched)
+  const int laneS = cc * ldS + g;
   auto loadSRaw = [&](int R, int C) {
     d4_t v;
+    if (16 * C + 15 < d) {   // interior tile (R <= C): one scalar base, one lane offset, no clamping (and fewer registers)
+      const double* base = p.S + (size_t)(16 * C) * ldS + 16 * R;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
-      const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
-      v[r] = p.S[(size_t)ci * ldS + cj];
+      for (int r = 0; r < 4; ++r) v[r] = base[laneS + 4 * r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
+        const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
+        v[r] = p.S[(size_t)ci * ldS + cj];
+      }
     }
     return v;
   };
   auto maskS = [&](d4_t v, int R, int C) {
+    if (16 * C + 15 < d) return v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = 16 * R + g + 4 * r, gj = 16 * C + cc;
