@@ -3752,7 +3752,7 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
 //     I <  h           -> slot of rectangle tile (h + j, I)    (born at step I, when (I, .) has just died)
 //     I >= h, j <  h   -> its own slot
 //     I >= h, j >= h   -> slot of rectangle tile (j, I - h)    (row j dies before step j's panel solve)
-// (tools/ll_schedule.py replays the schedule and checks that no live tile is overwritten.)  Finished tiles are also
+// (tests/test_ll_schedule.py replays the schedule on the CPU with this slot map and checks that no live tile is overwritten.)  Finished tiles are also
 // written through to global memory for the backward substitution.
 //   wave 0          the serial chain: diagonal tile k out of its registers (cholDiag16Acc), then forward substitution
 //                   of the right-hand side block k, then the last update of diagonal tile k + 1
@@ -3774,12 +3774,15 @@ __host__ __device__ constexpr int llSlots(int nT) { return (nT - llHalf(nT)) * l
 __host__ __device__ constexpr size_t llLdsDoubles(int nT) { return (size_t)llSlots(nT) * 256 + 2 * 256 + 16 * kPanelLd + 16 + 2 * 16 * nT; }
 // (branch-free on purpose: as a chain of conditionals the compiler turns every slot lookup of the update loops into three
 // scalar branches)
-__device__ __forceinline__ int llSlot(int I, int j, int h) {
+__host__ __device__ __forceinline__ int llSlot(int I, int j, int h) {
   const int low = (I < h) ? 1 : 0, left = (j < h) ? 1 : 0;
   const int sA = j * h + I, sB = (I - h) * h + j, sC = (j - h) * h + (I - h);
   return low * sA + (1 - low) * (left * sB + (1 - left) * sC);
 }
 
+// the slot map as the kernel uses it, for the CPU replay of the schedule (tests/test_ll_schedule.py)
+extern "C" int svin_debug_ll_slot(int I, int j, int nT) { return llSlot(I, j, llHalf(nT)); }
+extern "C" int svin_debug_ll_slots(int nT) { return llSlots(nT); }
 // T_u -= A B_u^T for NV tiles at once (independent accumulators: their MFMAs interleave), DIAG: also Td -= A A^T
 // (separate references, not arrays: the accumulators have to stay in registers)
 #define SVIN_MFMA_SUB(T, x, y) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-(x), (y), T, 0, 0, 0)
