@@ -3579,37 +3579,66 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
   bool gaveUp = false;
   d4_t acc[4];
   if (blockIdx.x == 0) {
+    // The critical-path workgroup.  Per block column it used to pay five exposed round trips (three block loads, two
+    // store drains ahead of a flag); now everything a step reads from other workgroups is requested in ONE go at its top
+    // (the helpers run ahead, their flags are normally long set), and a flag is raised where the wait for its stores is
+    // free: X(J, J-1) of the previous step together with that batch of loads (the diagonal factor is still flagged at once:
+    // deferring it past the update of the block below made the helpers late for the next step).
     double* S = L.B;    // X(J, J-1) from the previous column
     double* W = L.A;    // work block
+    d4_t accB[4];
+    double wreg[16];
     for (int J = 0; J < nb; ++J) {
-      // diagonal block
-      if (J >= 2) tileWait(pd + J, gaveUp, fail);
+      // flags of this step's inputs: PD(J), PS(J) (blocks minus the updates k <= J - 2) and X(J+1, J-1)
+      if (J >= 1) {
+        if (tid == 0 && !gaveUp) {
+          bool ok = pollReady(ready + (J + 1) * nb + (J - 1));
+          if (J >= 2) ok = ok && pollReady(pd + J) && pollReady(ps + J);
+          if (!ok) { atomicOr(fail, 2); gaveUp = true; }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       tileAccLoad(acc, M + (size_t)(kNB * J) * dpad + kNB * J, dpad, true);
+      tileAccLoad(accB, M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, true);   // (row block J + 1 <= nb: the last one is the right-hand side)
+      if (J >= 1) {
+        const double* g = M + (size_t)(kNB * (J + 1)) * dpad + kNB * (J - 1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const int e = tid + 256 * m;
+          wreg[m] = __hip_atomic_load(g + (size_t)(e >> 6) * dpad + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // X(J, J-1) of the previous step: its stores drain together with the loads above
+        tilePublish(ready + J * nb + (J - 1));
+      }
+      // diagonal block
       if (J >= 1) tileMfmaSub(acc, S, S);
       tileAccToLds(acc, L.Dt);
       __syncthreads();
       factor64(L.Dt, L.dinv, fail);
       storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, L.Dt);
       if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, L.dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tilePublish(ready + J * nb + J);
-      // the block below it (row block J + 1 <= nb: the last one is the right-hand side)
-      if (J >= 2) tileWait(ps + J, gaveUp, fail);
-      tileAccLoad(acc, M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, true);
+      // the block below it (its operand goes to LDS first: the store drain of the flag below then overlaps something)
       if (J >= 1) {
-        tileWait(ready + (J + 1) * nb + (J - 1), gaveUp, fail);
-        loadBlock64Coherent(M + (size_t)(kNB * (J + 1)) * dpad + kNB * (J - 1), dpad, W);
-        __syncthreads();
-        tileMfmaSub(acc, W, S);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const int e = tid + 256 * m, r = e >> 6, c = e & 63;
+          W[((r >> 4) * 4 + (c >> 4)) * (16 * kBigTileLd) + (r & 15) * kBigTileLd + (c & 15)] = wreg[m];
+        }
+      }
+      tilePublish(ready + J * nb + J);   // right away: the helpers' column-J solves sit on the path to the next step's inputs
+      if (J >= 1) {
+        tileMfmaSub(accB, W, S);
         __syncthreads();
       }
-      tileAccToLds(acc, W);
+      tileAccToLds(accB, W);
       __syncthreads();
       slabSolve64(L.Dt, W, L.dinv);
       __syncthreads();
       storeBlock64Coherent(M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, W);
-      tilePublish(ready + (J + 1) * nb + J);
       double* t = S; S = W; W = t;
     }
+    tilePublish(ready + nb * nb + (nb - 1));
     return;
   }
   // helpers
@@ -3867,7 +3896,8 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
   const int laneS = cc * ldS + g;
   auto loadSRaw = [&](int R, int C) {
     d4_t v;
-    if (16 * C + 15 < d) {   // interior tile (R <= C): one scalar base, one lane offset, no clamping (and fewer registers)
+    if (R < C && 16 * C + 15 < d) {   // interior off-diagonal tile: one scalar base, one lane offset, no clamping (and fewer
+                                      // registers); diagonal tiles go through min / max: only the lower triangle of S is valid for every caller
       const double* base = p.S + (size_t)(16 * C) * ldS + 16 * R;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = base[laneS + 4 * r];
