@@ -3565,6 +3565,9 @@ __device__ __forceinline__ void tileAccumulate(d4_t acc[4], const TileLds& L, do
     __syncthreads();
   }
 }
+#ifdef SVIN_CHAIN_TIMING
+__device__ int g_chainCount;
+#endif
 __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpad, double* dinvG, double* diagF, int* ready) {
   extern __shared__ double smem[];
   TileLds L;
@@ -3588,6 +3591,12 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
     double* W = L.A;    // work block
     d4_t accB[4];
     double wreg[16];
+#ifdef SVIN_CHAIN_TIMING
+    long long cT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_readcyclecounter(), c1;
+#define CHT(i) do { c1 = __builtin_readcyclecounter(); cT[i] += c1 - c0; c0 = c1; } while (0)
+#else
+#define CHT(i) do { } while (0)
+#endif
     for (int J = 0; J < nb; ++J) {
       // flags of this step's inputs: PD(J), PS(J) (blocks minus the updates k <= J - 2) and X(J+1, J-1)
       if (J >= 1) {
@@ -3599,6 +3608,7 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
+      CHT(0);
       tileAccLoad(acc, M + (size_t)(kNB * J) * dpad + kNB * J, dpad, true);
       tileAccLoad(accB, M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, true);   // (row block J + 1 <= nb: the last one is the right-hand side)
       if (J >= 1) {
@@ -3612,10 +3622,13 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
         tilePublish(ready + J * nb + (J - 1));
       }
       // diagonal block
+      CHT(1);
       if (J >= 1) tileMfmaSub(acc, S, S);
       tileAccToLds(acc, L.Dt);
       __syncthreads();
+      CHT(2);
       factor64(L.Dt, L.dinv, fail);
+      CHT(3);
       storeBlock64Coherent(diagF + (size_t)(kNB * J) * kNB, kNB, L.Dt);
       if (tid < kNB) __hip_atomic_store(dinvG + kNB * J + tid, L.dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // the block below it (its operand goes to LDS first: the store drain of the flag below then overlaps something)
@@ -3627,18 +3640,28 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
         }
       }
       tilePublish(ready + J * nb + J);   // right away: the helpers' column-J solves sit on the path to the next step's inputs
+      CHT(4);
       if (J >= 1) {
         tileMfmaSub(accB, W, S);
         __syncthreads();
       }
       tileAccToLds(accB, W);
       __syncthreads();
+      CHT(5);
       slabSolve64(L.Dt, W, L.dinv);
       __syncthreads();
+      CHT(6);
       storeBlock64Coherent(M + (size_t)(kNB * (J + 1)) * dpad + kNB * J, dpad, W);
+      CHT(7);
       double* t = S; S = W; W = t;
     }
     tilePublish(ready + nb * nb + (nb - 1));
+#ifdef SVIN_CHAIN_TIMING
+    if (tid == 0 && atomicAdd(&g_chainCount, 1) == 6)
+      printf("[chain nb %d] flags %lld  loads+publish %lld  mfmaSS %lld  factor64 %lld  storeD+publish %lld  W+mfma %lld  slabSolve %lld  storeX %lld\n",
+             nb, cT[0], cT[1], cT[2], cT[3], cT[4], cT[5], cT[6], cT[7]);
+#endif
+#undef CHT
     return;
   }
   // helpers
