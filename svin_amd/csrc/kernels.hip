@@ -3348,49 +3348,70 @@ __device__ __forceinline__ void storeBlock64Coherent(double* g, int ld, const do
   }
 }
 // in-LDS factorisation of a 64x64 SPD block (4x4 tiles, diagonal tiles fully symmetric) by 4 waves:
-// lower tiles <- L, strict upper triangle of the diagonal tiles <- L_tt^-T, dinv <- 1/L_ii
+// lower tiles <- L, strict upper triangle of the diagonal tiles <- L_tt^-T, dinv <- 1/L_ii.
+// Per tile column, as in k_chol_solve_lds: phase P = panel solves (X^T = L^-1 A^T on MFMA, so that X lands in the operand
+// layout); wave 0 takes the tile right below the diagonal and from it updates the NEXT diagonal tile in its registers;
+// phase D = wave 0 factorises that tile out of its registers while waves 1-3 update the other trailing tiles.  Two barriers
+// per tile column and no LDS round trip of the pivot tile (it was three barriers with the pivot tile through LDS:
+// 25.3 k -> see DESIGN.md for the cycles per 64-column step).
 __device__ void factor64(double* T, double* dinv, int* failFlag) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   auto tile = [&](int I, int J) { return T + (I * 4 + J) * (16 * kBigTileLd); };
+  const int lrow = (lane >> 4) * kBigTileLd + (lane & 15);   // accumulator layout: + 4 rg ld
+  const int lop = (lane & 15) * kBigTileLd + (lane >> 4);    // operand layout: + 4 q
+  if (wave == 0) cholDiag16Reg(tile(0, 0), dinv, lane, failFlag);
+  __syncthreads();
   for (int kb = 0; kb < 4; ++kb) {
-    if (wave == 0) cholDiag16Reg(tile(kb, kb), dinv + 16 * kb, lane, failFlag);
-    __syncthreads();
     const double* D = tile(kb, kb);
-    {  // panel: X = A L^-T for the tiles below (one per wave)
-      const int ti = kb + 1 + wave;
-      if (ti < 4) {
-        double* A = tile(ti, kb);
-        d4_t acc = {0, 0, 0, 0};
+    const int nR = 3 - kb;   // tiles below the diagonal in this tile column
+    auto panelSolve = [&](double* A) {
+      d4_t acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kk = 4 * q + (lane >> 4), jj = lane & 15;
-          const double a = A[(lane & 15) * kBigTileLd + kk];
-          const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * kb + kk] : 0.0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) A[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
+      for (int q = 0; q < 4; ++q) {
+        const int kk = 4 * q + (lane >> 4), jj = lane & 15;
+        const double a = A[lop + 4 * q];
+        const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * kb + kk] : 0.0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
       }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) A[lop + 4 * rg] = acc[rg];
+      return acc;
+    };
+    d4_t accD = {0, 0, 0, 0};
+    if (wave == 0) {
+      if (nR > 0) {
+        const double* Cb = tile(kb + 1, kb + 1);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) accD[rg] = Cb[lrow + 4 * rg * kBigTileLd];
+        const d4_t xT = panelSolve(tile(kb + 1, kb));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[q], xT[q], accD, 0, 0, 0);
+      }
+    } else if (wave < nR) {
+      panelSolve(tile(kb + 1 + wave, kb));
     }
     __syncthreads();
-    // trailing tiles (I, J), kb < J <= I < 4 (both triangles of the diagonal tiles: MFMA computes the full tile)
-    int cnt = 0;
-    for (int I = kb + 1; I < 4; ++I)
-      for (int J = kb + 1; J <= I; ++J, ++cnt) {
-        if ((cnt & 3) != wave) continue;
-        double* Cb = tile(I, J);
-        const double* A = tile(I, kb);
-        const double* B = tile(J, kb);
-        d4_t acc;
+    if (wave == 0) {
+      if (nR > 0) cholDiag16Acc(accD, tile(kb + 1, kb + 1), dinv + 16 * (kb + 1), lane, failFlag);
+    } else {
+      // trailing tiles (I, J), kb + 1 <= J <= I < 4 without the next diagonal tile, dealt to waves 1-3 (both triangles of
+      // the diagonal tiles: MFMA computes the full tile)
+      int cnt = 0;
+      for (int I = kb + 2; I < 4; ++I)
+        for (int J = kb + 1; J <= I; ++J, ++cnt) {
+          if (cnt % 3 != wave - 1) continue;
+          double* Cb = tile(I, J);
+          const double* A = tile(I, kb);
+          const double* B = tile(J, kb);
+          d4_t acc;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
+          for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[lrow + 4 * rg * kBigTileLd];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
-                                                     B[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[lop + 4 * q], B[lop + 4 * q], acc, 0, 0, 0);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Cb[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
-      }
+          for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kBigTileLd] = acc[rg];
+        }
+    }
     __syncthreads();
   }
 }
