@@ -3417,40 +3417,43 @@ __device__ void factor64(double* T, double* dinv, int* failFlag) {
 }
 
 // X = A L^-T for a 64x64 slab in LDS tiles (At, in place) against a factorised diagonal block (Dt, dinv) from
-// factor64: wave w owns row tile w; block forward substitution over the tile columns j
+// factor64: wave w owns row tile w; block forward substitution over the tile columns j.  Everything between the first read
+// and the last write of a row stays in registers: the tiles are taken TRANSPOSED into the accumulator layout, which is the B
+// operand layout of a K = 16 product, so X_j^T = L_jj^-1 (A_j^T - sum_{i<j} L_ji X_i^T) chains from accumulator to operand
+// without a trip through LDS (it was a store, a wave barrier and a reload per tile column: 6.3 k cycles per slab).
 __device__ __forceinline__ void slabSolve64(const double* Dt, double* At, const double* dinv) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lop = (lane & 15) * kBigTileLd + (lane >> 4);   // (row l & 15, column l >> 4): + 4 q
   auto dt = [&](int I, int J) { return Dt + (I * 4 + J) * (16 * kBigTileLd); };
   auto at = [&](int I, int J) { return At + (I * 4 + J) * (16 * kBigTileLd); };
-  for (int j = 0; j < 4; ++j) {
-    double* X = at(wave, j);
-    d4_t acc;
+  d4_t X[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) acc[rg] = X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)];
+  for (int j = 0; j < 4; ++j) {
+    d4_t T;
+    const double* A = at(wave, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[r] = A[lop + 4 * r];   // A_j^T: lane (g, c) register r = A[c][g + 4r]
+#pragma unroll
     for (int i = 0; i < j; ++i) {
-      const double* Xi = at(wave, i);
       const double* Lji = dt(j, i);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)],
-                                                   Lji[(lane & 15) * kBigTileLd + 4 * q + (lane >> 4)], acc, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lji[lop + 4 * q], X[i][q], T, 0, 0, 0);
     }
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = acc[rg];
-    waveSync();
     const double* D = dt(j, j);
     d4_t out = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int kk = 4 * q + (lane >> 4), jj = lane & 15;
-      const double a = X[(lane & 15) * kBigTileLd + kk];
       const double b = (jj > kk) ? D[kk * kBigTileLd + jj] : ((jj == kk) ? dinv[16 * j + kk] : 0.0);
-      out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, out, 0, 0, 0);
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(b, T[q], out, 0, 0, 0);
     }
-    waveSync();
+    X[j] = out;
+  }
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) X[((lane >> 4) + 4 * rg) * kBigTileLd + (lane & 15)] = out[rg];
-    waveSync();
+  for (int j = 0; j < 4; ++j) {
+    double* A = at(wave, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[lop + 4 * r] = X[j][r];
   }
 }
 
