@@ -2682,6 +2682,9 @@ constexpr int kPanelRows = 96;
 constexpr int kPanelSlab = kPanelRows * kPanelRows + 3 * kPanelRows;
 constexpr int kPanelChunksPerBlock = 8;
 
+#ifdef SVIN_SCHUR_TIMING
+__device__ int g_panelCount;
+#endif
 __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu, int initScale, int nWorkBlocks, int nFacBlocks) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
@@ -2709,19 +2712,76 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
 #pragma unroll
   for (int k = 0; k < kMaxTiles; ++k) acc[k] = d4_t{0, 0, 0, 0};
   double gRedAcc = 0, gFullAcc = 0, hcAcc = 0;      // thread r < kPanelRows (diagonal pairs)
+  // A chunk used to cost five dependent round trips to HBM (chunk id -> observation range -> residual and landmark Jacobian ->
+  // packed index -> pose row -> pose Jacobian) with ONE workgroup per CU to hide them (32 us per chunk, most of it waiting).
+  // Now the block's chunk ids and observation ranges and the pose -> row map are staged in LDS up front, and everything a lane
+  // needs of its first observation of chunk ci + 1 (a landmark rarely has more than 16) is requested while chunk ci is being
+  // worked on.
+  constexpr int kPoseStage = 1024;
+  __shared__ int sPoseOff[kPoseStage];
+  __shared__ int sStart[kPanelChunksPerBlock * kDenseLm], sCount[kPanelChunksPerBlock * kDenseLm], sLm[kPanelChunksPerBlock * kDenseLm];
+  // tile rows (16 rows each) of the two panels that the current chunk writes to: a tile whose row or column block got
+  // nothing is skipped (16 landmarks see a dozen consecutive frames, not all sixteen of a panel)
+  __shared__ unsigned sTouched[2];
+  if (t < 2) sTouched[t] = 0u;
+  const bool stagedPose = p.nPose <= kPoseStage;
+  if (stagedPose)
+    for (int i = t; i < p.nPose; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
+  if (t < kPanelChunksPerBlock * kDenseLm) {
+    const int ci = t >> 4, gq = t & 15;
+    int st = 0, cnt = 0, lq = -1;
+    if (ci < work.w) {
+      const int lm = p.panelChunks[work.z + ci] * kDenseLm + gq;
+      if (lm < p.L) { lq = lm; st = p.lmPtr[lm]; cnt = p.lmPtr[lm + 1] - st; }
+    }
+    sStart[t] = st; sCount[t] = cnt; sLm[t] = lq;
+  }
   for (int i = t; i < ldsDoubles; i += blockDim.x) smem[i] = 0.0;
   __syncthreads();
+  // first observation of this lane in a chunk: index, residual, landmark and pose Jacobian, and the landmark's column scales
+  uint32_t preIdx = 0;
+  double preR[2] = {0, 0}, preJl[6] = {0, 0, 0, 0, 0, 0}, preJp[12], preSc[3] = {1, 1, 1};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) preJp[k] = 0;
+  auto fetch = [&](int ci) {
+    const int st = sStart[ci * kDenseLm + grp], cnt = sCount[ci * kDenseLm + grp], lq = sLm[ci * kDenseLm + grp];
+    if (gl < cnt) {
+      const size_t o = (size_t)st + gl;
+      preIdx = p.obsIdx[o];
+      preR[0] = p.rCur[o]; preR[1] = p.rCur[N + o];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) preJl[k] = p.JlCur[k * N + o];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) preJp[k] = p.JpCur[k * N + o];
+    }
+    if (!initScale && lq >= 0) { preSc[0] = p.scaleL[3 * lq]; preSc[1] = p.scaleL[3 * lq + 1]; preSc[2] = p.scaleL[3 * lq + 2]; }
+  };
+#ifdef SVIN_SCHUR_TIMING
+  long long pT[6] = {0, 0, 0, 0, 0, 0}, pq0 = __builtin_readcyclecounter(), pq1;
+#define PNT(i) do { pq1 = __builtin_readcyclecounter(); pT[i] += pq1 - pq0; pq0 = pq1; } while (0)
+#else
+#define PNT(i) do { } while (0)
+#endif
+  if (work.w > 0) fetch(0);
+  PNT(0);
   for (int ci = 0; ci < work.w; ++ci) {
-    const int chunk = p.panelChunks[work.z + ci];
-    const int l = chunk * kDenseLm + grp;
-    if (l < p.L) {
-      const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+    const int l = sLm[ci * kDenseLm + grp];
+    const int start = sStart[ci * kDenseLm + grp], n = sCount[ci * kDenseLm + grp];
+    const uint32_t curIdx = preIdx;
+    double curR[2] = {preR[0], preR[1]}, curJl[6], curJp[12], curSc[3] = {preSc[0], preSc[1], preSc[2]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) curJl[k] = preJl[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) curJp[k] = preJp[k];
+    if (ci + 1 < work.w) fetch(ci + 1);
+    if (l >= 0) {
       double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const double r0 = p.rCur[o], r1 = p.rCur[N + o];
-        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
-        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        const bool first = i == gl;
+        const double r0 = first ? curR[0] : p.rCur[o], r1 = first ? curR[1] : p.rCur[N + o];
+        const double a0 = first ? curJl[0] : p.JlCur[o], a1 = first ? curJl[1] : p.JlCur[N + o], a2 = first ? curJl[2] : p.JlCur[2 * N + o];
+        const double c0 = first ? curJl[3] : p.JlCur[3 * N + o], c1 = first ? curJl[4] : p.JlCur[4 * N + o], c2 = first ? curJl[5] : p.JlCur[5 * N + o];
         v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
         v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
         b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
@@ -2733,7 +2793,7 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
         if (gl == 0) { p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2; }
       } else {
-        sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2];
+        sc0 = curSc[0]; sc1 = curSc[1]; sc2 = curSc[2];
       }
       const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
       const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
@@ -2765,18 +2825,22 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
       }
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const int offP = p.poseOff[p.obsIdx[o] & 0xfff];
+        const bool first = i == gl;
+        const int pi = (int)((first ? curIdx : p.obsIdx[o]) & 0xfff);
+        int offP;
+        if (stagedPose) offP = sPoseOff[pi]; else offP = p.poseOff[pi];
         if (offP < 0) continue;
         const bool inI = offP >= r0I && offP < r0I + kPanelRows;
         const bool inJ = !diag && offP >= r0J && offP < r0J + kPanelRows;
         if (!inI && !inJ) continue;
-        const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
-        const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+        const double a0 = first ? curJl[0] : p.JlCur[o], a1 = first ? curJl[1] : p.JlCur[N + o], a2 = first ? curJl[2] : p.JlCur[2 * N + o];
+        const double c0 = first ? curJl[3] : p.JlCur[3 * N + o], c1 = first ? curJl[4] : p.JlCur[4 * N + o], c2 = first ? curJl[5] : p.JlCur[5 * N + o];
         double jc[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) jc[k] = p.JpCur[k * N + o];
+        for (int k = 0; k < 12; ++k) jc[k] = first ? curJp[k] : p.JpCur[k * N + o];
         double* Gt = inI ? GtI : GtJ;
         const int rl = offP - (inI ? r0I : r0J);
+        atomicOr(&sTouched[inI ? 0 : 1], (1u << (rl >> 4)) | (1u << ((rl + 5) >> 4)));
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
           const double j0 = jc[a], j1 = jc[6 + a];
@@ -2786,7 +2850,7 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
           atomicAdd(&g[1], e0 * i10 + e1 * i11);
           atomicAdd(&g[2], e0 * i20 + e1 * i21 + e2 * i22);
           if (diag) {
-            const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+            const double r0 = first ? curR[0] : p.rCur[o], r1 = first ? curR[1] : p.rCur[N + o];
             double* ap = Amine + (size_t)(rl / 6) * kPoseAcc;
 #pragma unroll
             for (int c = a; c < 6; ++c) atomicAdd(&ap[sym6(a, c)], j0 * jc[c] + j1 * jc[6 + c]);
@@ -2795,7 +2859,9 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         }
       }
     }
+    PNT(1);
     __syncthreads();
+    PNT(2);
     if (diag && t < kPanelRows) {  // gradient and column norms of this panel's rows
       const int ps = t / 6, a = t % 6;
       double hc = 0, gf = 0;
@@ -2808,12 +2874,16 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
       for (int k = 0; k < kDenseK; ++k) gc += GtI[(size_t)t * kDenseLd + k] * cvec[k];
       hcAcc += hc; gFullAcc += gf; gRedAcc += gf - gc;
     }
+    const unsigned touchedI = __builtin_amdgcn_readfirstlane(sTouched[0]);
+    const unsigned touchedJ = diag ? touchedI : __builtin_amdgcn_readfirstlane(sTouched[1]);
 #pragma unroll
     for (int k = 0; k < kMaxTiles; ++k) {
       const int tl = wave + 4 * k;           // 36 tiles: tile row ti (panel I), tile column tj (panel J)
       const int ti = tl / 6, tj = tl % 6;
+      if (!((touchedI >> ti) & 1u) || !((touchedJ >> tj) & 1u)) continue;   // (wave-uniform)
+      if (diag && ti < tj) continue;   // a diagonal pair is symmetric: k_reduce_panel_slabs mirrors its lower tiles
       d4_t c = acc[k];
-      if (diag) {
+      if (diag && ti - tj <= 1) {   // 6x6 blocks of A straddle at most two neighbouring tiles
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 16 * ti + (lane >> 4) + 4 * rg, cc = 16 * tj + (lane & 15);
@@ -2832,9 +2902,12 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
       for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
       acc[k] = c;
     }
+    PNT(3);
     __syncthreads();
-    for (int i = t; i < ldsDoubles; i += blockDim.x) smem[i] = 0.0;
+    for (int i = t; i < (ldsDoubles >> 1); i += blockDim.x) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};   // (ldsDoubles is even)
+    if (t < 2) sTouched[t] = 0u;
     __syncthreads();
+    PNT(4);
   }
   double* slab = p.slabs + (size_t)b * kPanelSlab;
 #pragma unroll
@@ -2847,6 +2920,13 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
     double* v = slab + kPanelRows * kPanelRows;
     v[t] = gRedAcc; v[kPanelRows + t] = gFullAcc; v[2 * kPanelRows + t] = hcAcc;
   }
+#ifdef SVIN_SCHUR_TIMING
+  PNT(5);
+  if ((b == 3 || b == 400) && (t == 0 || t == 64) && atomicAdd(&g_panelCount, 1) < 4)
+    printf("[panels block %d wave %d, %d chunks, diag %d] prologue %lld  landmark part %lld  wait %lld  vectors+tiles %lld  clear %lld  slab %lld\n", b, t >> 6,
+           work.w, (int)diag, pT[0], pT[1], pT[2], pT[3], pT[4], pT[5]);
+#endif
+#undef PNT
 }
 
 // sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors
@@ -2869,9 +2949,11 @@ __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
   const double s = (s0 + s1) + (s2 + s3);
   if (e < kPanelRows * kPanelRows) {
     const int r = kPanelRows * pI + e / kPanelRows, c = kPanelRows * pJ + e % kPanelRows;
-    if (r < p.dC && c < p.dC) {
+    // diagonal pairs carry their lower tiles only (16 x 16 tiles, the diagonal tiles full)
+    const int ti = (e / kPanelRows) >> 4, tj = (e % kPanelRows) >> 4;
+    if (r < p.dC && c < p.dC && (pI != pJ || ti >= tj)) {
       p.S[(size_t)r * p.d + c] += s;
-      if (pI != pJ) p.S[(size_t)c * p.d + r] += s;
+      if (pI != pJ || ti > tj) p.S[(size_t)c * p.d + r] += s;
     }
   } else if (pI == pJ) {
     const int v = e - kPanelRows * kPanelRows, which = v / kPanelRows, r = kPanelRows * pI + v % kPanelRows;
