@@ -2931,22 +2931,34 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
 
 // sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors
 __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
+  // 16 entries x 16 partitions of the pair's slabs per workgroup, like k_reduce_slabs (a diagonal pair of a wide window has
+  // 100-200 slabs: one thread per entry walking all of them was 50 dependent rounds of loads, 35 us)
+  __shared__ double part[256];
   const int pair = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= kPanelSlab) return;
+  const int e16 = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + e16;
   const int b0 = p.panelPairPtr[pair], b1 = p.panelPairPtr[pair + 1];
   if (b0 == b1) return;
   const int pI = p.panelWork[b0].x, pJ = p.panelWork[b0].y;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int k = b0;
-  for (; k + 3 < b1; k += 4) {
-    s0 += p.slabs[(size_t)k * kPanelSlab + e];
-    s1 += p.slabs[(size_t)(k + 1) * kPanelSlab + e];
-    s2 += p.slabs[(size_t)(k + 2) * kPanelSlab + e];
-    s3 += p.slabs[(size_t)(k + 3) * kPanelSlab + e];
+  if (e < kPanelSlab) {
+    const int per = (b1 - b0 + 15) / 16;
+    int k = b0 + q * per;
+    const int k1 = min(b1, k + per);
+    for (; k + 3 < k1; k += 4) {
+      s0 += p.slabs[(size_t)k * kPanelSlab + e];
+      s1 += p.slabs[(size_t)(k + 1) * kPanelSlab + e];
+      s2 += p.slabs[(size_t)(k + 2) * kPanelSlab + e];
+      s3 += p.slabs[(size_t)(k + 3) * kPanelSlab + e];
+    }
+    for (; k < k1; ++k) s0 += p.slabs[(size_t)k * kPanelSlab + e];
   }
-  for (; k < b1; ++k) s0 += p.slabs[(size_t)k * kPanelSlab + e];
-  const double s = (s0 + s1) + (s2 + s3);
+  part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q != 0 || e >= kPanelSlab) return;
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += part[16 * k + e16];
   if (e < kPanelRows * kPanelRows) {
     const int r = kPanelRows * pI + e / kPanelRows, c = kPanelRows * pJ + e % kPanelRows;
     // diagonal pairs carry their lower tiles only (16 x 16 tiles, the diagonal tiles full)
@@ -3122,7 +3134,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     ensureDynamicLds((const void*)k_schur_panels, ldsBytes);
     hipLaunchKernelGGL(k_schur_panels, dim3(p.nPanelBlocks + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0,
                        p.nPanelBlocks, nFac);
-    hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 255) / 256, p.nPanelPairs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 15) / 16, p.nPanelPairs), dim3(256), 0, s, p);
     return;
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;
