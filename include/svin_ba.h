@@ -182,6 +182,14 @@ int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, 
  * KeypointIdentifier order (frame, camera, keypoint); any output may be NULL; returns the number of observations */
 int svin_ba_get_landmark_observations(svin_ba* h, uint64_t landmark_id, uint64_t* frame_ids, uint64_t* cam_idx,
                                       uint64_t* keypoint_idx, uint64_t* residual_ids, int cap);
+/* svin_ba_get_landmarks + svin_ba_get_landmark_observations for ALL landmarks in one call (the PointMap with its
+ * observation maps that Estimator::getLandmarks :974-990 copies and applyMarginalizationStrategy's caller walks): landmarks
+ * in ascending id order, obs_ptr (cap_landmarks + 1 entries) is a CSR into the per-observation arrays, each landmark's
+ * entries in KeypointIdentifier order.  Any output may be NULL.  Returns the number of landmarks, *n_obs_total the number
+ * of observations (either may exceed its capacity: call again with larger buffers). */
+int svin_ba_get_all_landmark_observations(svin_ba* h, int cap_landmarks, uint64_t* ids, svin_landmark_info* infos,
+                                          int32_t* obs_ptr, int cap_obs, uint64_t* frame_ids, uint64_t* cam_idx,
+                                          uint64_t* keypoint_idx, uint64_t* residual_ids, int32_t* n_obs_total);
 int svin_ba_set_T_WS(svin_ba* h, uint64_t pose_id, const double T[7]);
 int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t pose_id, uint64_t imu_idx, const double sb[9]);
 int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t pose_id, uint64_t cam_idx, const double T[7]);
@@ -220,9 +228,20 @@ int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t block_id);         
  * count (may exceed cap), SVIN_ERR_NOT_FOUND for an unknown block */
 int svin_ba_residuals_of(svin_ba* h, uint64_t block_id, uint64_t* residual_ids, int cap);
 /* Map::parameters(residual) (src/Map.cpp:602-620): block ids in the cost function's parameter order (reprojection:
- * pose, landmark, extrinsics); *kind receives 100 reprojection / 101 marginalisation prior / the factor kind
- * (0 imu, 1 pose prior, 2 speed-bias prior, 3 relative pose, 4 sonar, 5 depth); returns the count */
+ * pose, landmark, extrinsics); *kind receives 100 reprojection / 101 marginalisation prior
+ * / 102 HomogeneousPointError on a landmark / the factor kind (0 imu, 1 pose prior, 2 speed-bias prior, 3 relative
+ * pose, 4 sonar, 5 depth); returns the count (it may exceed cap: the prior lists every block it touches) */
 int svin_ba_parameters_of(svin_ba* h, uint64_t residual_id, uint64_t* block_ids, int cap, int32_t* kind);
+
+/* Map::parameterBlockPtr (Map.hpp:166-170) / id2parameterBlockMap (:188) as values: *type 0 pose (PoseParameterBlock),
+ * 1 extrinsics (PoseParameterBlock), 2 speed/bias (SpeedAndBiasParameterBlock), 3 landmark
+ * (HomogeneousPointParameterBlock); values (up to 9 doubles) = ParameterBlock::parameters(), (sec, nsec) = timestamp(),
+ * fixed = fixed(), initialized = HomogeneousPointParameterBlock::initialized().  Any output may be NULL.  Returns the
+ * ambient dimension (7 / 9 / 4), SVIN_ERR_NOT_FOUND for an unknown id.  _ids: every parameter block id, ascending;
+ * returns the count (may exceed cap). */
+int svin_ba_get_parameter_block(svin_ba* h, uint64_t block_id, int32_t* type, double* values, uint32_t* sec,
+                                uint32_t* nsec, int32_t* fixed, int32_t* initialized);
+int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap);
 
 /* ---- keyframe hand-off to pose_graph: the estimator-side content of the keyframe message that
  * ThreadedKFVio::optimizationLoop assembles (okvis_multisensor_processing/src/ThreadedKFVio.cpp:1147-1240).  For every
@@ -266,6 +285,32 @@ int svin_host_reprojection_error(int distortion_model, const double intr[4], con
  * residual[3]; J_min 3x3 (= the square-root information); J 3x4 (last column zero).  Jacobian pointers may be NULL. */
 int svin_host_homogeneous_point_error(const double hp_W[4], const double measurement[4], const double information[9],
                                       double residual[3], double* J_min, double* J);
+
+/* svin_host_pose_information / svin_host_pose_error: okvis::ceres::PoseError (src/PoseError.cpp:52-132, <6,7>) as
+ * ProbabilisticStereoTriangulator.cpp:87-99 uses it.  _information does what PoseError::setInformation does (:70-76):
+ * sqrt_information (6x6 row-major) = the upper Cholesky factor with Eigen::LLT's stop-at-a-non-positive-pivot
+ * behaviour, covariance = information^-1 by LU with partial pivoting; either output may be NULL.  _error: residual[6],
+ * J_min 6x6, J 6x7 (= J_min * PoseManifold::liftJacobian) row-major, either may be NULL.  The unweighted error and
+ * Jacobian are the function the factor kernel evaluates for its pose priors (dmath.hpp poseErrorEval). */
+int svin_host_pose_information(const double information[36], double* sqrt_information, double* covariance);
+int svin_host_pose_error(const double measurement[7], const double sqrt_information[36], const double T_WS[7],
+                         double residual[6], double* J_min, double* J);
+
+/* The parameter-block manifolds (src/PoseManifold.cpp, src/HomogeneousPointManifold.cpp) for the shim's
+ * ParameterBlock / Manifold classes; kinds in the order of Map::Parameterization (Map.hpp:97-105).  Jacobians row-major:
+ * plus ambient x tangent, lift and minus tangent x ambient.  Pose6d plus IS the retraction the device applies
+ * (dmath.hpp poseOplus).  Returns 1, SVIN_ERR_INVALID_ARG for a NULL pointer or an unknown kind. */
+#define SVIN_MANIFOLD_HPOINT 0
+#define SVIN_MANIFOLD_POSE6D 1
+#define SVIN_MANIFOLD_POSE3D 2
+#define SVIN_MANIFOLD_POSE4D 3
+#define SVIN_MANIFOLD_POSE2D 4
+int svin_host_manifold_dims(int kind, int* ambient, int* tangent);
+int svin_host_manifold_plus(int kind, const double* x, const double* delta, double* x_plus_delta);
+int svin_host_manifold_minus(int kind, const double* x_plus_delta, const double* x, double* delta);
+int svin_host_manifold_plus_jacobian(int kind, const double* x, double* J);
+int svin_host_manifold_lift_jacobian(int kind, const double* x, double* J);
+int svin_host_manifold_minus_jacobian(int kind, const double* x, double* J);
 
 /* ---- inspection / parity hooks (ErrorInterface::EvaluateWithMinimalJacobians, Map::getLhs) ---- */
 /* Evaluates every reprojection residual of the window on the GPU at the current estimates.

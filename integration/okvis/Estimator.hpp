@@ -245,21 +245,13 @@ class Estimator : public VioBackendInterface {
   size_t getLandmarks(okvis::PointMap& landmarks) const override {
     std::lock_guard<std::mutex> l(statesMutex_);
     landmarks.clear();
-    forEachLandmark([&](uint64_t id, const svin_landmark_info& li) {
-      okvis::MapPoint mp;
-      fillMapPoint(id, li, mp);
-      landmarks.insert(std::make_pair(id, mp));
-    });
+    forEachLandmark([&](const okvis::MapPoint& mp) { landmarks.insert(std::make_pair(mp.id, mp)); });
     return landmarks.size();
   }
   size_t getLandmarks(okvis::MapPointVector& landmarks) const {
     std::lock_guard<std::mutex> l(statesMutex_);
     landmarks.clear();
-    forEachLandmark([&](uint64_t id, const svin_landmark_info& li) {
-      okvis::MapPoint mp;
-      fillMapPoint(id, li, mp);
-      landmarks.push_back(mp);
-    });
+    forEachLandmark([&](const okvis::MapPoint& mp) { landmarks.push_back(mp); });
     return landmarks.size();
   }
   okvis::MultiFramePtr multiFrame(uint64_t frameId) const override {
@@ -414,14 +406,28 @@ class Estimator : public VioBackendInterface {
     for (int i = 0; i < m && i < n; ++i)
       mp.observations.insert(std::make_pair(okvis::KeypointIdentifier(f[i], (size_t)c[i], (size_t)k[i]), r[i]));
   }
+  /// every landmark with its observation map from TWO boundary crossings (size query + fill), whatever the window size
   template <class F>
   void forEachLandmark(F&& fn) const {
-    const int n = svin_ba_get_landmarks(h_, nullptr, nullptr, 0);
+    int32_t nObs = 0;
+    const int n = svin_ba_get_all_landmark_observations(h_, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, &nObs);
     if (n <= 0) return;
-    std::vector<uint64_t> ids((size_t)n);
+    std::vector<uint64_t> ids((size_t)n), f((size_t)nObs + 1), c((size_t)nObs + 1), k((size_t)nObs + 1), r((size_t)nObs + 1);
     std::vector<svin_landmark_info> infos((size_t)n);
-    const int m = svin_ba_get_landmarks(h_, ids.data(), infos.data(), n);
-    for (int i = 0; i < m && i < n; ++i) fn(ids[i], infos[i]);
+    std::vector<int32_t> ptr((size_t)n + 1);
+    const int m = svin_ba_get_all_landmark_observations(h_, n, ids.data(), infos.data(), ptr.data(), nObs, f.data(), c.data(), k.data(), r.data(), &nObs);
+    okvis::MapPoint mp;
+    for (int i = 0; i < m && i < n; ++i) {
+      const svin_landmark_info& li = infos[i];
+      mp.id = ids[i];
+      mp.point = Eigen::Vector4d(li.point[0], li.point[1], li.point[2], li.point[3]);
+      mp.quality = li.quality;
+      mp.distance = li.distance;
+      mp.observations.clear();
+      for (int32_t o = ptr[i]; o < ptr[i + 1]; ++o)
+        mp.observations.insert(std::make_pair(okvis::KeypointIdentifier(f[o], (size_t)c[o], (size_t)k[o]), r[o]));
+      fn(mp);
+    }
   }
 
   svin_ba* h_;

@@ -9,6 +9,8 @@
 
 #include <svin_ba.h>
 
+#include <Eigen/Core>
+
 #include <cstddef>
 #include <string>
 

@@ -16,22 +16,20 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
-// The frontend stores residual ids as ::ceres::ResidualBlockId (implementation/Estimator.hpp:84 casts them to uint64_t).
-// Without Ceres in the build the name is provided here: an opaque pointer-sized handle carrying the core's id.
-#ifndef CERES_PUBLIC_TYPES_H_
-namespace ceres {
-struct ResidualBlock;
-typedef ResidualBlock* ResidualBlockId;
-enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
-enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
-enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };
-}  // namespace ceres
-#endif
+#include <okvis/Time.hpp>
+#include <okvis/ceres/CeresTypes.hpp>   // ::ceres::ResidualBlockId & co. without Ceres
+#include <okvis/ceres/ErrorInterface.hpp>
+#include <okvis/ceres/HomogeneousPointParameterBlock.hpp>
+#include <okvis/ceres/ParameterBlock.hpp>
+#include <okvis/ceres/PoseParameterBlock.hpp>
+#include <okvis/ceres/SpeedAndBiasParameterBlock.hpp>
 
 namespace okvis {
 namespace ceres {
@@ -69,9 +67,54 @@ class Map {
 
   enum Parameterization { HomogeneousPoint, Pose6d, Pose3d, Pose4d, Pose2d, Trivial };   // Map.hpp:97-105
 
-  typedef std::pair<uint64_t, int> ResidualBlockSpec;                    ///< residual id, kind (svin_ba_parameters_of)
-  typedef std::vector<uint64_t> ResidualBlockCollection;                 ///< residual ids (Map::residuals)
-  typedef std::vector<uint64_t> ParameterBlockCollection;                ///< parameter block ids (Map::parameters)
+  /// Map.hpp:71-86.  lossFunctionPtr is always NULL here: the Cauchy loss of the reprojection residuals
+  /// (Estimator.cpp:69) is applied inside the device solver, there is no ::ceres::LossFunction object to point to.
+  struct ResidualBlockSpec {
+    ResidualBlockSpec() : residualBlockId(0), lossFunctionPtr(0) {}
+    ResidualBlockSpec(::ceres::ResidualBlockId id, ::ceres::LossFunction* loss, std::shared_ptr<ErrorInterface> e)
+        : residualBlockId(id), lossFunctionPtr(loss), errorInterfacePtr(e) {}
+    ::ceres::ResidualBlockId residualBlockId;
+    ::ceres::LossFunction* lossFunctionPtr;
+    std::shared_ptr<ErrorInterface> errorInterfacePtr;
+  };
+  typedef std::pair<uint64_t, std::shared_ptr<okvis::ceres::ParameterBlock> > ParameterBlockSpec;   // Map.hpp:87
+  typedef std::vector<ResidualBlockSpec> ResidualBlockCollection;                                    // :90
+  typedef std::vector<ParameterBlockSpec> ParameterBlockCollection;                                  // :93
+  typedef std::unordered_map<uint64_t, std::shared_ptr<okvis::ceres::ParameterBlock> > Id2ParameterBlock_Map;   // :183
+
+  /// What errorInterfacePtr returns for a residual of the device window: the sizes and the type of the error term.
+  /// Evaluating it at caller-supplied parameters is not available on this object (the residual lives on the GPU:
+  /// svin_ba_eval_reprojection / svin_ba_eval_factors evaluate the window's residuals in bulk) and throws.
+  class ResidualView : public ErrorInterface {
+   public:
+    ResidualView(int kind, size_t residualDim, std::vector<size_t> dims) : kind_(kind), m_(residualDim), dims_(std::move(dims)) {}
+    size_t residualDim() const override { return m_; }
+    size_t parameterBlocks() const override { return dims_.size(); }
+    size_t parameterBlockDim(size_t i) const override { return dims_.at(i); }
+    bool EvaluateWithMinimalJacobians(double const* const*, double*, double**, double**) const override {
+      throw Exception("okvis::ceres::Map (svin_ba shim): residuals of the device window are evaluated on the GPU "
+                      "(svin_ba_eval_reprojection / svin_ba_eval_factors), not through ErrorInterface");
+    }
+    std::string typeInfo() const override {
+      switch (kind_) {
+        case 100: return "ReprojectionError";
+        case 101: return "MarginalizationError";
+        case 102: return "HomogeneousPointError";
+        case 0: return "ImuError";
+        case 1: return "PoseError";
+        case 2: return "SpeedAndBiasError";
+        case 3: return "RelativePoseError";
+        case 4: return "SonarError";
+        case 5: return "DepthError";
+      }
+      return "unknown";
+    }
+    int kind() const { return kind_; }   ///< svin_ba_parameters_of's kind
+   private:
+    int kind_;
+    size_t m_;
+    std::vector<size_t> dims_;
+  };
 
   explicit Map(svin_ba* handle = nullptr) : h_(handle) {}
   void attach(svin_ba* handle) { h_ = handle; }
@@ -112,25 +155,103 @@ class Map {
     if (svin_ba_parameter_block_exists(h_, id) != 1) return false;
     return parameterization == Pose6d || parameterization == HomogeneousPoint || parameterization == Trivial;
   }
+  /// Map::parameterBlockPtr (Map.hpp:166-170): a snapshot of the block (values, id, fixed, time stamp / initialised flag)
+  std::shared_ptr<okvis::ceres::ParameterBlock> parameterBlockPtr(uint64_t id) const {
+    need();
+    int32_t type = -1, fixed = 0, init = 1;
+    uint32_t sec = 0, nsec = 0;
+    double x[9];
+    if (svin_ba_get_parameter_block(h_, id, &type, x, &sec, &nsec, &fixed, &init) < 0) return std::shared_ptr<okvis::ceres::ParameterBlock>();
+    std::shared_ptr<okvis::ceres::ParameterBlock> out;
+    if (type == 0 || type == 1) {
+      auto b = std::make_shared<PoseParameterBlock>();
+      b->setTimestamp(okvis::Time(sec, nsec));
+      out = b;
+    } else if (type == 2) {
+      auto b = std::make_shared<SpeedAndBiasParameterBlock>();
+      b->setTimestamp(okvis::Time(sec, nsec));
+      out = b;
+    } else {
+      auto b = std::make_shared<HomogeneousPointParameterBlock>();
+      b->setInitialized(init != 0);
+      out = b;
+    }
+    out->setParameters(x);
+    out->setId(id);
+    out->setFixed(fixed != 0);
+    return out;
+  }
+  /// Map::id2parameterBlockMap (Map.hpp:188): every block of the window, as snapshots (returned by value)
+  Id2ParameterBlock_Map id2parameterBlockMap() const {
+    need();
+    Id2ParameterBlock_Map out;
+    const int n = svin_ba_parameter_block_ids(h_, nullptr, 0);
+    if (n <= 0) return out;
+    std::vector<uint64_t> ids((size_t)n);
+    svin_ba_parameter_block_ids(h_, ids.data(), n);
+    for (uint64_t id : ids) out.emplace(id, parameterBlockPtr(id));
+    return out;
+  }
+  /// Map::errorInterfacePtr (Map.hpp:173-180): sizes and type of the residual (see ResidualView)
+  std::shared_ptr<okvis::ceres::ErrorInterface> errorInterfacePtr(::ceres::ResidualBlockId residual) const {
+    return errorInterfacePtr(reinterpret_cast<uint64_t>(residual));
+  }
+  std::shared_ptr<okvis::ceres::ErrorInterface> errorInterfacePtr(uint64_t residualId) const {
+    need();
+    int32_t kind = -1;
+    const std::vector<uint64_t> ids = parameterIds(residualId, &kind);
+    if (ids.empty()) return std::shared_ptr<okvis::ceres::ErrorInterface>();
+    std::vector<size_t> dims;
+    size_t m = 0;
+    for (uint64_t id : ids) {
+      const int d = svin_ba_get_parameter_block(h_, id, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      dims.push_back(d > 0 ? (size_t)d : 0);
+    }
+    switch (kind) {
+      case 100: m = 2; break;
+      case 101: {   // the prior's dimension (svin_ba_get_prior reports -m when the capacity is too small)
+        const int pm = svin_ba_get_prior(h_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        m = (size_t)(pm < 0 ? -pm : pm);
+        break;
+      }
+      case 102: m = 3; break;
+      case 0: m = 15; break;
+      case 1: case 3: m = 6; break;
+      case 2: m = 9; break;
+      default: m = 1;
+    }
+    return std::make_shared<ResidualView>(kind, m, dims);
+  }
   /// Map::residuals (Map.cpp:576-587): every residual touching the block, in insertion order
   ResidualBlockCollection residuals(uint64_t id) const {
     need();
     ResidualBlockCollection out;
     const int n = svin_ba_residuals_of(h_, id, nullptr, 0);
     if (n <= 0) return out;
-    out.resize((size_t)n);
-    svin_ba_residuals_of(h_, id, out.data(), n);
+    std::vector<uint64_t> rids((size_t)n);
+    svin_ba_residuals_of(h_, id, rids.data(), n);
+    for (uint64_t r : rids) out.push_back(ResidualBlockSpec(reinterpret_cast< ::ceres::ResidualBlockId>(r), nullptr, errorInterfacePtr(r)));
     return out;
   }
   /// Map::parameters (Map.cpp:602-620): the blocks of a residual in the cost function's parameter order
   ParameterBlockCollection parameters(::ceres::ResidualBlockId residual) const { return parameters(reinterpret_cast<uint64_t>(residual)); }
   ParameterBlockCollection parameters(uint64_t residualId, int* kind = nullptr) const {
     need();
-    uint64_t ids[64];
+    ParameterBlockCollection out;
     int32_t k = -1;
-    const int n = svin_ba_parameters_of(h_, residualId, ids, 64, &k);
+    for (uint64_t id : parameterIds(residualId, &k)) out.push_back(ParameterBlockSpec(id, parameterBlockPtr(id)));
     if (kind) *kind = k;
-    return n > 0 ? ParameterBlockCollection(ids, ids + n) : ParameterBlockCollection();
+    return out;
+  }
+  /// the ids only (no snapshots): two calls, the prior of a wide window touches hundreds of blocks
+  std::vector<uint64_t> parameterIds(uint64_t residualId, int32_t* kind = nullptr) const {
+    need();
+    std::vector<uint64_t> ids;
+    const int n = svin_ba_parameters_of(h_, residualId, nullptr, 0, kind);
+    if (n <= 0) return ids;
+    ids.resize((size_t)n);
+    svin_ba_parameters_of(h_, residualId, ids.data(), n, kind);
+    return ids;
   }
   /// Map::removeResidualBlock (Map.cpp:467-492) for reprojection residuals (what Estimator::removeObservation does)
   bool removeResidualBlock(::ceres::ResidualBlockId residual) {

@@ -270,6 +270,52 @@ int svin_ba_get_landmark_observations(svin_ba* h, uint64_t id, uint64_t* frames,
   }
   return (int)sorted.size();
 }
+int svin_ba_get_all_landmark_observations(svin_ba* h, int cap_landmarks, uint64_t* ids, svin_landmark_info* infos, int32_t* obs_ptr,
+                                          int cap_obs, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids, int32_t* n_obs_total) {
+  if (!h || cap_landmarks < 0 || cap_obs < 0) return SVIN_ERR_INVALID_ARG;
+  int n = 0, total = 0;
+  std::vector<const svin::Observation*> sorted;
+  for (const auto& kv : h->w.landmarks()) {
+    const Landmark& lm = kv.second;
+    if (n < cap_landmarks) {
+      if (ids) ids[n] = kv.first;
+      if (infos) fillInfo(lm, infos + n);
+      if (obs_ptr) obs_ptr[n] = total;
+      sorted.clear();
+      for (const svin::Observation& o : lm.obs) sorted.push_back(&o);
+      std::sort(sorted.begin(), sorted.end(), [](const svin::Observation* a, const svin::Observation* b) {
+        if (a->poseId != b->poseId) return a->poseId < b->poseId;
+        if (a->cam != b->cam) return a->cam < b->cam;
+        return a->kp < b->kp;
+      });
+      for (size_t i = 0; i < sorted.size(); ++i) {
+        const int at = total + (int)i;
+        if (at >= cap_obs) break;
+        if (frames) frames[at] = sorted[i]->poseId;
+        if (cams) cams[at] = (uint64_t)sorted[i]->cam;
+        if (kps) kps[at] = sorted[i]->kp;
+        if (rids) rids[at] = sorted[i]->resId;
+      }
+    }
+    total += (int)lm.obs.size();
+    ++n;
+  }
+  if (obs_ptr && n <= cap_landmarks) obs_ptr[n] = total;
+  if (n_obs_total) *n_obs_total = total;
+  return n;
+}
+int svin_ba_get_parameter_block(svin_ba* h, uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed,
+                                int32_t* initialized) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  return h->w.getParameterBlock(id, type, values, sec, nsec, fixed, initialized);
+}
+int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap) {
+  if (!h || cap < 0 || (cap > 0 && !ids)) return SVIN_ERR_INVALID_ARG;
+  std::vector<uint64_t> v;
+  h->w.parameterBlockIds(v);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
+  return (int)v.size();
+}
 int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmark(id);

@@ -106,6 +106,54 @@ SVIN_HD void poseMinus(const double* xp, const double* x, double* d) {
   d[3] = 2 * dq.x; d[4] = 2 * dq.y; d[5] = 2 * dq.z;
 }
 
+// top-left 3x3 blocks of the quaternion product matrices (operators.hpp:91-133): plus(q) p = q * p, oplus(q) p = p * q
+SVIN_HD void quatPlusMat3(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.z; Q[4] = q.w; Q[5] = -q.x; Q[6] = -q.y; Q[7] = q.x; Q[8] = q.w;
+}
+SVIN_HD void quatOplusMat3(const Quat& q, double* Q) {
+  Q[0] = q.w; Q[1] = q.z; Q[2] = -q.y; Q[3] = -q.z; Q[4] = q.w; Q[5] = q.x; Q[6] = q.y; Q[7] = -q.x; Q[8] = q.w;
+}
+// PoseError (okvis_ceres/src/PoseError.cpp:87-132) before weighting: e = [meas.r - x.r ; 2 vec(meas.q * x.q^-1)] with both
+// quaternions normalised the way Transformation's constructor does, F = de/d(delta) = -[I 0; 0 plus(dq)(0:3, 0:3)]
+// (6x6 row-major, written completely).  Shared by the factor kernel (kind F_POSE_PRIOR) and svin_host_pose_error.
+SVIN_HD void poseErrorEval(const double* meas, const double* x, double* e, double* F) {
+  const Quat qm = qnormalized(Quat{meas[3], meas[4], meas[5], meas[6]});
+  const Quat qx = qnormalized(Quat{x[3], x[4], x[5], x[6]});
+  const Quat dq = qnormalized(qmul(qm, qnormalized(qinv(qx))));
+  e[0] = meas[0] - x[0]; e[1] = meas[1] - x[1]; e[2] = meas[2] - x[2];
+  e[3] = 2 * dq.x; e[4] = 2 * dq.y; e[5] = 2 * dq.z;
+  double Q[9];
+  quatPlusMat3(dq, Q);
+  for (int k = 0; k < 36; ++k) F[k] = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    F[a * 6 + a] = -1.0;
+    for (int b = 0; b < 3; ++b) F[(3 + a) * 6 + 3 + b] = -Q[a * 3 + b];
+  }
+}
+
+// Host-side data preparation (factor construction, not per-iteration arithmetic): the upper square-root information
+// L^T of information = L L^T with Eigen::LLT's behaviour on a non-positive pivot -- it returns at that pivot and what
+// matrixL() then reads is the partially factorised matrix (PoseError.cpp:70-76 on diag(1e4,1e4,1e4,0,0,1e8); SURVEY.md
+// section 7).  n <= 15, out = n x n row-major.
+inline void sqrtInformationUpper(const double* info, int n, double* out) {
+  double A[225];
+  for (int k = 0; k < n * n; ++k) A[k] = info[k];
+  for (int k = 0; k < n; ++k) {
+    double x = A[k * n + k];
+    for (int j = 0; j < k; ++j) x -= A[k * n + j] * A[k * n + j];
+    if (x <= 0) break;
+    x = sqrt(x);
+    A[k * n + k] = x;
+    for (int i = k + 1; i < n; ++i) {
+      double s = A[i * n + k];
+      for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j];
+      A[i * n + k] = s / x;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? A[j * n + i] : 0.0;
+}
+
 // ---------------------------------------------------------------- distortion + projection
 // d = distort(u), Jd = dd/du (row-major 2x2).  Returns false when the model rejects the point.
 SVIN_HD bool distortPoint(const CameraModel& c, double u0, double u1, double& d0, double& d1, double* Jd) {

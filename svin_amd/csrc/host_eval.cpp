@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 #include "dmath.hpp"
 
@@ -339,6 +340,205 @@ int svin_host_homogeneous_point_error(const double hp[4], const double meas[4], 
     }
     if (J) J[a * 4 + 3] = 0.0;
   }
+  return 1;
+}
+
+
+// ---- PoseError, the parameter-block manifolds: what okvis_frontend's ProbabilisticStereoTriangulator (:87-99,
+// :128-140) and the Ceres-free shim classes under integration/okvis/ceres/ evaluate on the CPU.
+int svin_host_pose_information(const double information[36], double* sqrt_information, double* covariance) {
+  if (!information) return SVIN_ERR_INVALID_ARG;
+  // squareRootInformation_ = LLT(information).matrixL().transpose() (PoseError.cpp:70-76) with Eigen's behaviour on a
+  // non-positive pivot: the factorisation stops there and the untouched remainder of the matrix is read as the factor
+  if (sqrt_information) svin::sqrtInformationUpper(information, 6, sqrt_information);
+  if (covariance) {
+    // covariance_ = information.inverse() (PoseError.cpp:72): Eigen's fixed-size 6x6 inverse is PartialPivLU; a singular
+    // information matrix (the reference passes diag(1e4,1e4,1e4,0,0,1e8), Estimator.cpp:189-192) gives inf / nan there
+    // and here alike -- nothing reads covariance() in that case
+    double A[36], B[36];
+    for (int k = 0; k < 36; ++k) { A[k] = information[k]; B[k] = (k % 7 == 0) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < 6; ++r)
+        if (std::fabs(A[r * 6 + c]) > std::fabs(A[piv * 6 + c])) piv = r;
+      if (piv != c)
+        for (int k = 0; k < 6; ++k) { std::swap(A[c * 6 + k], A[piv * 6 + k]); std::swap(B[c * 6 + k], B[piv * 6 + k]); }
+      const double d = A[c * 6 + c];
+      for (int r = c + 1; r < 6; ++r) {
+        const double f = A[r * 6 + c] / d;
+        for (int k = c; k < 6; ++k) A[r * 6 + k] -= f * A[c * 6 + k];
+        for (int k = 0; k < 6; ++k) B[r * 6 + k] -= f * B[c * 6 + k];
+      }
+    }
+    for (int k = 0; k < 6; ++k)
+      for (int r = 5; r >= 0; --r) {
+        double v = B[r * 6 + k];
+        for (int c = r + 1; c < 6; ++c) v -= A[r * 6 + c] * covariance[c * 6 + k];
+        covariance[r * 6 + k] = v / A[r * 6 + r];
+      }
+  }
+  return 1;
+}
+
+static void poseLift(const double* x, double* L) {   // PoseManifold::liftJacobian (PoseManifold.cpp:128-140), 6x7 row-major
+  for (int k = 0; k < 42; ++k) L[k] = 0.0;
+  L[0] = L[8] = L[16] = 1.0;
+  const double qx = -x[3], qy = -x[4], qz = -x[5], qw = x[6];   // the conjugate, not normalised (:131)
+  const double O[12] = {qw, qz, -qy, qx, -qz, qw, qx, qy, qy, -qx, qw, qz};   // rows 0..2 of oplus(q^-1)
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 4; ++c) L[(3 + a) * 7 + 3 + c] = 2.0 * O[a * 4 + c];
+}
+
+int svin_host_pose_error(const double measurement[7], const double sqrt_information[36], const double T_WS[7], double residual[6],
+                         double* J_min, double* J) {
+  if (!measurement || !sqrt_information || !T_WS || !residual) return SVIN_ERR_INVALID_ARG;
+  double e[6], F[36], WF[36];
+  svin::poseErrorEval(measurement, T_WS, e, F);
+  for (int a = 0; a < 6; ++a) {
+    double s = 0;
+    for (int k = 0; k < 6; ++k) s += sqrt_information[a * 6 + k] * e[k];
+    residual[a] = s;
+  }
+  if (!J_min && !J) return 1;
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 6; ++c) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += sqrt_information[a * 6 + k] * F[k * 6 + c];
+      WF[a * 6 + c] = s;
+    }
+  if (J_min) std::memcpy(J_min, WF, sizeof(WF));
+  if (J) {   // J0 = J0_minimal * J_lift (PoseError.cpp:116-120)
+    double L[42];
+    poseLift(T_WS, L);
+    for (int a = 0; a < 6; ++a)
+      for (int c = 0; c < 7; ++c) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += WF[a * 6 + k] * L[k * 7 + c];
+        J[a * 7 + c] = s;
+      }
+  }
+  return 1;
+}
+
+// the tangent directions of the pose manifolds inside the 6-vector [dr ; dalpha] (PoseManifold.cpp:59-82, :172-196 3d,
+// :262-288 4d, :350-374 2d)
+static int poseTangent(int kind, int idx[6]) {
+  switch (kind) {
+    case SVIN_MANIFOLD_POSE6D: for (int k = 0; k < 6; ++k) idx[k] = k; return 6;
+    case SVIN_MANIFOLD_POSE3D: idx[0] = 3; idx[1] = 4; idx[2] = 5; return 3;
+    case SVIN_MANIFOLD_POSE4D: idx[0] = 0; idx[1] = 1; idx[2] = 2; idx[3] = 5; return 4;
+    case SVIN_MANIFOLD_POSE2D: idx[0] = 3; idx[1] = 4; return 2;
+  }
+  return 0;
+}
+
+int svin_host_manifold_dims(int kind, int* ambient, int* tangent) {
+  int idx[6];
+  int a = 7, t = poseTangent(kind, idx);
+  if (kind == SVIN_MANIFOLD_HPOINT) { a = 4; t = 3; }
+  else if (t == 0) return SVIN_ERR_INVALID_ARG;
+  if (ambient) *ambient = a;
+  if (tangent) *tangent = t;
+  return 1;
+}
+
+int svin_host_manifold_plus(int kind, const double* x, const double* delta, double* x_plus_delta) {
+  if (!x || !delta || !x_plus_delta) return SVIN_ERR_INVALID_ARG;
+  if (kind == SVIN_MANIFOLD_HPOINT) {   // HomogeneousPointManifold.cpp:57-67, Euclidean
+    for (int k = 0; k < 3; ++k) x_plus_delta[k] = x[k] + delta[k];
+    x_plus_delta[3] = x[3] + 0.0;
+    return 1;
+  }
+  int idx[6];
+  const int t = poseTangent(kind, idx);
+  if (!t) return SVIN_ERR_INVALID_ARG;
+  double d6[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < t; ++k) d6[idx[k]] = delta[k];
+  double out[7];
+  svin::poseOplus(x, d6, out);   // Transformation::oplus, the retraction the device applies (dmath.hpp)
+  std::memcpy(x_plus_delta, out, sizeof(out));
+  return 1;
+}
+
+int svin_host_manifold_minus(int kind, const double* x_plus_delta, const double* x, double* delta) {
+  if (!x || !delta || !x_plus_delta) return SVIN_ERR_INVALID_ARG;
+  if (kind == SVIN_MANIFOLD_HPOINT) {   // HomogeneousPointManifold.cpp:80-91
+    for (int k = 0; k < 3; ++k) delta[k] = x_plus_delta[k] - x[k];
+    return 1;
+  }
+  int idx[6];
+  const int t = poseTangent(kind, idx);
+  if (!t) return SVIN_ERR_INVALID_ARG;
+  double d6[6];
+  svin::poseMinus(x_plus_delta, x, d6);   // PoseManifold.cpp:93-102 (the 3d / 4d / 2d forms keep a subset: :199-211, :295-305, :381-392)
+  for (int k = 0; k < t; ++k) delta[k] = d6[idx[k]];
+  return 1;
+}
+
+int svin_host_manifold_plus_jacobian(int kind, const double* x, double* J) {
+  if (!x || !J) return SVIN_ERR_INVALID_ARG;
+  if (kind == SVIN_MANIFOLD_HPOINT) {   // 4x3 (HomogeneousPointManifold.cpp:104-113)
+    for (int k = 0; k < 12; ++k) J[k] = 0.0;
+    J[0] = J[4] = J[8] = 1.0;
+    return 1;
+  }
+  int idx[6];
+  const int t = poseTangent(kind, idx);
+  if (!t) return SVIN_ERR_INVALID_ARG;
+  // full 7x6: [I 0; 0 oplus(q) * 0.5 (first three columns)].  6d and 4d go through Transformation::oplusJacobian, whose
+  // q_ was normalised by the constructor (PoseManifold.cpp:105-111, :310-318); 3d and 2d use the raw quaternion (:216-227, :397-408)
+  Quat q = Quat{x[3], x[4], x[5], x[6]};
+  if (kind == SVIN_MANIFOLD_POSE6D || kind == SVIN_MANIFOLD_POSE4D) q = svin::qnormalized(q);
+  const double O[16] = {q.w, q.z, -q.y, q.x, -q.z, q.w, q.x, q.y, q.y, -q.x, q.w, q.z, -q.x, -q.y, -q.z, q.w};
+  double full[42];
+  for (int k = 0; k < 42; ++k) full[k] = 0.0;
+  full[0] = full[7] = full[14] = 1.0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j) full[(3 + i) * 6 + 3 + j] = 0.5 * O[i * 4 + j];
+  for (int r = 0; r < 7; ++r)
+    for (int k = 0; k < t; ++k) J[r * t + k] = full[r * 6 + idx[k]];
+  return 1;
+}
+
+int svin_host_manifold_lift_jacobian(int kind, const double* x, double* J) {
+  if (!x || !J) return SVIN_ERR_INVALID_ARG;
+  if (kind == SVIN_MANIFOLD_HPOINT) {   // 3x4 (HomogeneousPointManifold.cpp:126-135)
+    for (int k = 0; k < 12; ++k) J[k] = 0.0;
+    J[0] = J[5] = J[10] = 1.0;
+    return 1;
+  }
+  int idx[6];
+  const int t = poseTangent(kind, idx);
+  if (!t) return SVIN_ERR_INVALID_ARG;
+  double L[42];
+  poseLift(x, L);   // the rows of the 6d lift the manifold keeps (PoseManifold.cpp:128-140, :241-254, :333-343, :423-436)
+  for (int k = 0; k < t; ++k)
+    for (int c = 0; c < 7; ++c) J[k * 7 + c] = L[idx[k] * 7 + c];
+  return 1;
+}
+
+int svin_host_manifold_minus_jacobian(int kind, const double* x, double* J) {
+  if (!x || !J) return SVIN_ERR_INVALID_ARG;
+  if (kind == SVIN_MANIFOLD_HPOINT) {   // 3x4 (HomogeneousPointManifold.cpp:115-124)
+    for (int k = 0; k < 12; ++k) J[k] = 0.0;
+    J[0] = J[5] = J[10] = 1.0;
+    return 1;
+  }
+  int idx[6];
+  const int t = poseTangent(kind, idx);
+  if (!t) return SVIN_ERR_INVALID_ARG;
+  // 6x7: [I 0; 0 2 plus(q)(0:3, :)] with the last column negated (PoseManifold.cpp:114-125 -- the reference's own
+  // "not sure why the last column is coming negative"; kept as it is)
+  const double qx = x[3], qy = x[4], qz = x[5], qw = x[6];
+  const double P[12] = {qw, -qz, qy, qx, qz, qw, -qx, qy, -qy, qx, qw, qz};
+  double full[42];
+  for (int k = 0; k < 42; ++k) full[k] = 0.0;
+  full[0] = full[8] = full[16] = 1.0;
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 4; ++c) full[(3 + a) * 7 + 3 + c] = 2.0 * P[a * 4 + c];
+  for (int a = 0; a < 6; ++a) full[a * 7 + 6] = -full[a * 7 + 6];
+  for (int k = 0; k < t; ++k)
+    for (int c = 0; c < 7; ++c) J[k * 7 + c] = full[idx[k] * 7 + c];
   return 1;
 }
 

@@ -211,6 +211,15 @@ void launchPackSystem(const DeviceProblem& p, bool unpack, hipStream_t s) {
   if (p.d <= 0) return;
   hipLaunchKernelGGL(k_pack_lower, dim3(p.d + 1), dim3(256), 0, s, p, unpack ? 1 : 0);
 }
+// Sharded mode: the wall-clock time limit (Estimator::setOptimizationTimeLimit) is the one host decision that is not a
+// function of all-reduced numbers.  Each rank writes its own vote into the free slots of scalar group A right before that
+// group's all-reduce; every rank then reads the same sum and stops (or not) together.
+__global__ __launch_bounds__(64) void k_set_stop_vote(SolverScalars* scal, double vote) {
+  if (threadIdx.x == 0) { scal->spareA0 = vote; scal->spareA1 = 0.0; }
+}
+void launchSetStopVote(SolverScalars* scal, double vote, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_stop_vote, dim3(1), dim3(64), 0, s, scal, vote);
+}
 void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq, hipStream_t s) {
   hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, scal, mailbox, seq);
 }
@@ -716,12 +725,7 @@ __device__ __forceinline__ Quat deltaQDev(double ax, double ay, double az) {
   const double s = 0.5 * sc;
   return Quat{s * ax, s * ay, s * az, c};
 }
-__device__ __forceinline__ void quatPlusMat3(const Quat& q, double* Q) {  // top-left 3x3 of plus(q)
-  Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.z; Q[4] = q.w; Q[5] = -q.x; Q[6] = -q.y; Q[7] = q.x; Q[8] = q.w;
-}
-__device__ __forceinline__ void quatOplusMat3(const Quat& q, double* Q) {  // top-left 3x3 of oplus(q)
-  Q[0] = q.w; Q[1] = q.z; Q[2] = -q.y; Q[3] = -q.z; Q[4] = q.w; Q[5] = q.x; Q[6] = q.y; Q[7] = -q.x; Q[8] = q.w;
-}
+// quatPlusMat3 / quatOplusMat3: dmath.hpp
 __device__ __forceinline__ void quatPlusMat4(const Quat& q, double* Q) {
   Q[0] = q.w; Q[1] = -q.z; Q[2] = q.y; Q[3] = q.x;
   Q[4] = q.z; Q[5] = q.w; Q[6] = -q.x; Q[7] = q.y;
@@ -1643,16 +1647,7 @@ __device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorS
     if (t == 0) {
       const double* x0 = blockPtr(p, cand, fac.blkKind[0], fac.blkSlot[0]);
       if (fac.kind == F_POSE_PRIOR) {  // PoseError.cpp:87-132
-        const TF Tm = makeTF(fac.meas), Tx = makeTF(x0);
-        const Quat dq = qnormalized(qmul(Tm.q, qnormalized(qinv(Tx.q))));
-        for (int k = 0; k < 3; ++k) sh.e[k] = Tm.r[k] - Tx.r[k];
-        sh.e[3] = 2 * dq.x; sh.e[4] = 2 * dq.y; sh.e[5] = 2 * dq.z;
-        double Q[9];
-        quatPlusMat3(dq, Q);
-        for (int a = 0; a < 3; ++a) {
-          sh.F[a * 6 + a] = -1.0;
-          for (int b = 0; b < 3; ++b) sh.F[(3 + a) * 6 + 3 + b] = -Q[a * 3 + b];
-        }
+        poseErrorEval(fac.meas, x0, sh.e, sh.F);   // dmath.hpp: the function svin_host_pose_error runs on the CPU
       } else if (fac.kind == F_SB_PRIOR) {  // SpeedAndBiasError.cpp:83-113
         for (int k = 0; k < 9; ++k) { sh.e[k] = fac.meas[k] - x0[k]; sh.F[k * 9 + k] = -1.0; }
       } else if (fac.kind == F_RELPOSE) {  // RelativePoseError.cpp:79-147

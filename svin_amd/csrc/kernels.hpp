@@ -194,6 +194,7 @@ void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadiu
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s);  // delta, J*delta pass, candidate, norms
 // sharded mode: the (all-reduced) scalars + sequence number into the pinned-host mailbox, as one wave-wide store
 void launchPublishScalars(const SolverScalars* scal, ScalarMailbox* mailbox, unsigned long long seq, hipStream_t s);
+void launchSetStopVote(SolverScalars* scal, double vote, hipStream_t s);
 // sharded mode: [lower triangle of S | gRed | gFull | hC] <-> one contiguous message in p.cholL (packedSystemDoubles long)
 size_t packedSystemDoubles(const DeviceProblem& p);
 void launchPackSystem(const DeviceProblem& p, bool unpack, hipStream_t s);

@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <dlfcn.h>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
+
+#include <rccl/rccl.h>   // declarations only; librccl is opened with dlopen when the sharded mode is switched on
 
 namespace svin {
 
@@ -35,81 +38,76 @@ static double dtSecHost(TimeStamp a, TimeStamp b) {  // okvis Duration normalisa
   return (double)s + 1e-9 * (double)ns;
 }
 
-// Cholesky-based square-root information with Eigen's "return at the first non-positive pivot and
-// leave the remainder in place" semantics (PoseError.cpp:70-76).  This is
-// constant data preparation at factor construction, not part of the per-iteration arithmetic.
-static void sqrtInformationUpper(const double* info, int n, double* out) {
-  std::vector<double> A(info, info + n * n);
-  for (int k = 0; k < n; ++k) {
-    double x = A[k * n + k];
-    for (int j = 0; j < k; ++j) x -= A[k * n + j] * A[k * n + j];
-    if (x <= 0) break;
-    x = std::sqrt(x);
-    A[k * n + k] = x;
-    for (int i = k + 1; i < n; ++i) {
-      double s = A[i * n + k];
-      for (int j = 0; j < k; ++j) s -= A[i * n + j] * A[k * n + j];
-      A[i * n + k] = s / x;
-    }
-  }
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) out[i * n + j] = (j >= i) ? A[j * n + i] : 0.0;
-}
+// sqrtInformationUpper: dmath.hpp (shared with svin_host_pose_information)
 
 // ------------------------------------------------------------------------------------------ RCCL (resolved at run time)
 // The library is looked up with dlopen when the landmark-sharded mode is switched on: a process that already holds an
 // RCCL (torch.distributed's) gets that one (same SONAME), a single-GPU user never needs it to be installed.
 namespace {
+// Types and enums come from the installed header (declarations only: no link-time dependency, the symbols are resolved
+// with dlsym below), so every call is made through the library's own prototype.
 struct RcclApi {
   void* lib = nullptr;
-  int (*getUniqueId)(void*) = nullptr;
-  void* commInitRankRaw = nullptr;   // (ncclComm_t*, int nranks, ncclUniqueId BY VALUE, int rank): cast where it is called
-  int (*allReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*commDestroy)(void*) = nullptr;
-  const char* (*getErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclGetErrorString) getErrorString = nullptr;
 };
-struct UniqueId { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
 RcclApi& rccl() {
   static RcclApi api;
-  if (api.lib) return api;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (api.lib) break;
-  }
-  if (!api.lib) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
-  auto sym = [&](const char* n) {
-    void* f = dlsym(api.lib, n);
-    if (!f) throw std::runtime_error(std::string("RCCL symbol missing: ") + n);
-    return f;
-  };
-  api.getUniqueId = reinterpret_cast<int (*)(void*)>(sym("ncclGetUniqueId"));
-  api.commInitRankRaw = sym("ncclCommInitRank");
-  api.allReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(sym("ncclAllReduce"));
-  api.commDestroy = reinterpret_cast<int (*)(void*)>(sym("ncclCommDestroy"));
-  api.getErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+  static std::once_flag once;
+  std::call_once(once, [] {   // an exception leaves the flag unset: the next call tries again from scratch
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) throw std::runtime_error(std::string("RCCL not found: ") + dlerror());
+    auto sym = [&](const char* n) {
+      void* f = dlsym(a.lib, n);
+      if (!f) throw std::runtime_error(std::string("RCCL symbol missing: ") + n);
+      return f;
+    };
+    a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(sym("ncclGetUniqueId"));
+    a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(sym("ncclCommInitRank"));
+    a.allReduce = reinterpret_cast<decltype(a.allReduce)>(sym("ncclAllReduce"));
+    a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(sym("ncclCommDestroy"));
+    a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(sym("ncclGetErrorString"));
+    api = a;   // published only when every symbol has resolved
+  });
   return api;
 }
-void rcclCheck(int r, const char* what) {
-  if (r != 0) throw std::runtime_error(std::string(what) + ": " + rccl().getErrorString(r));
+void rcclCheck(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + rccl().getErrorString(r));
 }
 }  // namespace
 
 int Window::rcclUniqueId(unsigned char* out128) {
-  UniqueId id;
+  ncclUniqueId id;
   std::memset(&id, 0, sizeof(id));
   rcclCheck(rccl().getUniqueId(&id), "ncclGetUniqueId");
+  static_assert(sizeof(id.internal) == 128, "svin_ba.h hands the id over as 128 bytes");
   std::memcpy(out128, id.internal, 128);
   return 1;
 }
 int Window::setDistributedRccl(int rank, int world, const unsigned char* id128) {
   HIP_OK(hipSetDevice(device_));
-  UniqueId id;
+  ncclUniqueId id;
   std::memcpy(id.internal, id128, 128);
-  typedef int (*InitFn)(void**, int, UniqueId, int);
-  if (rcclComm_) { (void)rccl().commDestroy(rcclComm_); rcclComm_ = nullptr; }
-  rcclCheck(reinterpret_cast<InitFn>(rccl().commInitRankRaw)(&rcclComm_, world, id, rank), "ncclCommInitRank");
+  dropRcclComm();
+  ncclComm_t comm = nullptr;
+  rcclCheck(rccl().commInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  rcclComm_ = comm;
   rank_ = rank; world_ = world; allreduce_ = nullptr; allreduceUser_ = nullptr;
   return 1;
+}
+void Window::dropRcclComm() {
+  if (rcclComm_) { (void)rccl().commDestroy(static_cast<ncclComm_t>(rcclComm_)); rcclComm_ = nullptr; }
+}
+void Window::setDistributed(int rank, int world, AllReduceFn fn, void* user) {
+  dropRcclComm();   // the callback form replaces a native communicator (solve() prefers rcclComm_ when it is set)
+  rank_ = rank; world_ = world; allreduce_ = fn; allreduceUser_ = user;
 }
 
 Window::Window(int device) : device_(device) {
@@ -135,7 +133,7 @@ Window::Window(int device) : device_(device) {
   }
 }
 Window::~Window() {
-  if (rcclComm_) (void)rccl().commDestroy(rcclComm_);
+  dropRcclComm();
   if (stageEvt_) (void)hipEventDestroy(stageEvt_);
   if (stageHost_) (void)hipHostFree(stageHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
@@ -301,6 +299,7 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
   if (imuM == nullptr || imuT == nullptr) nImu = 0;
   double T_WS[7], sb[9], integrals[7];
   const bool first = states_.empty();
+  bool insertedIntegrals = false;
   if (first) {
     if (!initPoseFromImu(imuM, nImu, T_WS)) return 0;  // :110-113
     if (!(numKeypoints > 10)) return 0;                 // :116-122
@@ -312,6 +311,7 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
     std::memcpy(sb, blocks_.at(last.sb.at(0).id).x, sizeof(sb));
     const int used = imuPropagation(imuT, imuM, nImu, imus_[0], T_WS, sb, last.stamp, stamp, nullptr, nullptr, integrals);
     if (used < 1) return 0;  // :159-162
+    insertedIntegrals = imuIntegrals_.count(frameId) == 0;
     setImuPreIntegral(frameId, integrals);  // :165
   }
   ++stateCount_;  // :171 (before the id check, like the reference)
@@ -321,11 +321,15 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
   std::vector<uint64_t> extIds(cameras_.size(), 0), sbIds(imus_.size(), 0);
   {
     std::vector<uint64_t> drawn{frameId};
+    // a provider's id that is already taken is the host's error; the built-in counter simply skips what callers chose
     auto draw = [&]() -> uint64_t {
-      const uint64_t id = newId();
-      if (id == 0 || idInUse(id) || std::find(drawn.begin(), drawn.end(), id) != drawn.end()) return 0;
-      drawn.push_back(id);
-      return id;
+      for (int tries = idProvider_ ? 1 : (1 << 20); tries > 0; --tries) {
+        const uint64_t id = newId();
+        if (id == 0 || idInUse(id) || std::find(drawn.begin(), drawn.end(), id) != drawn.end()) continue;
+        drawn.push_back(id);
+        return id;
+      }
+      return 0;
     };
     bool ok = true;
     for (size_t i = 0; i < cameras_.size(); ++i) {
@@ -336,6 +340,8 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
     if (!ok) {
       lastError() = "addStates: the id provider returned an id that is already in use (frames, landmarks and the "
                     "estimator's internal blocks share ONE id space, see svin_ba_set_id_provider / svin_ba_reserve_ids)";
+      --stateCount_;                                              // the error path leaves the window as it was (svin_ba.h)
+      if (insertedIntegrals) imuIntegrals_.erase(frameId);
       return -1;
     }
   }
@@ -719,6 +725,43 @@ int Window::describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* 
     for (size_t i = 0; i < s.sb.size(); ++i) if (s.sb[i].id == id) { *frame = s.id; *kind = 2; *index = (int)i; return 1; }
   }
   return 0;
+}
+
+int Window::getParameterBlock(uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed,
+                              int32_t* initialized) const {
+  auto lit = landmarks_.find(id);
+  if (lit != landmarks_.end()) {
+    if (type) *type = 3;
+    if (values) std::memcpy(values, lit->second.hp, 4 * sizeof(double));
+    if (sec) *sec = 0;
+    if (nsec) *nsec = 0;
+    if (fixed) *fixed = 0;
+    if (initialized) *initialized = lit->second.initialized ? 1 : 0;
+    return 4;
+  }
+  const Block* b = findBlock(id);
+  if (!b) return -2;
+  const int dim = b->kind == B_SB ? 9 : 7;
+  if (type) *type = b->kind == B_POSE ? 0 : b->kind == B_EXT ? 1 : 2;
+  if (values) std::memcpy(values, b->x, dim * sizeof(double));
+  if (fixed) *fixed = b->fixed ? 1 : 0;
+  if (initialized) *initialized = 1;
+  // every block addStates creates carries the frame's time stamp (Estimator.cpp:126, :208-214, :232); a fixed block
+  // whose frame has left the window keeps none
+  uint64_t frame = 0;
+  int32_t k = 0, idx = 0;
+  TimeStamp t;
+  t.sec = 0; t.nsec = 0;
+  if (describeBlock(id, &frame, &k, &idx) == 1) t = states_.at(frame).stamp;
+  if (sec) *sec = t.sec;
+  if (nsec) *nsec = t.nsec;
+  return dim;
+}
+void Window::parameterBlockIds(std::vector<uint64_t>& out) const {
+  out.clear();
+  for (const auto& kv : blocks_) out.push_back(kv.first);
+  for (const auto& kv : landmarks_) out.push_back(kv.first);
+  std::sort(out.begin(), out.end());
 }
 
 // ------------------------------------------------------------------------------------------ pack: host graph -> HBM
@@ -1216,8 +1259,8 @@ void Window::solve(size_t numIter, bool verbose) {
   const bool dist = world_ > 1 || (forceDist && rcclComm_);
   auto AR = [&](void* ptr, size_t n, int op) {
     if (!dist) return;
-    if (rcclComm_) {   // native: enqueued on the solver's stream, in place (ncclDouble = 8, ncclSum = 0, ncclMax = 2)
-      rcclCheck(rccl().allReduce(ptr, ptr, n, 8, op == 0 ? 0 : 2, rcclComm_, s), "ncclAllReduce");
+    if (rcclComm_) {   // native: enqueued on the solver's stream, in place
+      rcclCheck(rccl().allReduce(ptr, ptr, n, ncclDouble, op == 0 ? ncclSum : ncclMax, static_cast<ncclComm_t>(rcclComm_), s), "ncclAllReduce");
       return;
     }
     HIP_OK(hipStreamSynchronize(s));
@@ -1250,6 +1293,7 @@ void Window::solve(size_t numIter, bool verbose) {
   int invalid = 0;
   int iteration = 0;
   double lastIterTime = 0;
+  double stopVotes = 0.0;   // sharded mode: number of ranks whose clock asked to stop (identical on every rank)
   auto swapSets = [&]() {
     std::swap(p.pose, p.poseC); std::swap(p.ext, p.extC); std::swap(p.sb, p.sbC); std::swap(p.lm, p.lmC);
     std::swap(p.rCur, p.rCand); std::swap(p.JpCur, p.JpCand); std::swap(p.JlCur, p.JlCand); std::swap(p.JeCur, p.JeCand);
@@ -1271,7 +1315,11 @@ void Window::solve(size_t numIter, bool verbose) {
   bool specValid = false;          // the accumulators hold the build of the candidate with damping specMu
   double specMu = 0;
   while (true) {
-    if (timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) { finish(2); break; }
+    // the time-limit callback (CeresIterationCallback.hpp:80-94).  One GPU: this rank's clock.  Sharded: a rank that left
+    // the loop on its own clock would leave the others blocked in the next all-reduce, so the ranks vote (below, with the
+    // evaluation's all-reduce) and stop on the common result
+    if (!dist && timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) { finish(2); break; }
+    if (dist && stopVotes > 0.0) { finish(2); break; }
     if (iteration >= (int)numIter) { finish(1); break; }
     if (radius <= 1e-32) { finish(0); break; }
     const double tIter = nowSec();
@@ -1309,9 +1357,12 @@ void Window::solve(size_t numIter, bool verbose) {
         accumulatorsClean = false;
         specValid = true;
       }
+      if (dist)   // this iteration will be complete when the vote is read: `iteration` already counts it
+        launchSetStopVote(p.scal, (timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) ? 1.0 : 0.0, s);
       AR(scalD, 8, 0);
       publish();
       sc = readScalars();
+      if (dist) stopVotes = sc.spareA0;
       sc.cholFail = sc.failMax != 0.0 ? 1 : 0;  // the device flag itself is re-armed by k_post_solve
       if (!reuse && sc.cholFail) {
         specValid = false;   // (its damping assumed an accepted step)

@@ -204,7 +204,8 @@ class Window {
   // landmark-sharded multi-GPU mode: every rank holds all states and the factors between them, plus its own
   // range of landmarks; `fn` all-reduces `count` doubles at device address `ptr` in place (op 0 = sum, 1 = max).
   typedef int (*AllReduceFn)(void* ptr, uint64_t count, int op, void* user);
-  void setDistributed(int rank, int world, AllReduceFn fn, void* user) { rank_ = rank; world_ = world; allreduce_ = fn; allreduceUser_ = user; }
+  void setDistributed(int rank, int world, AllReduceFn fn, void* user);
+  void dropRcclComm();
   // the same with RCCL called natively on the handle's stream (no host synchronisation, no callback): `id` is the
   // 128-byte ncclUniqueId rank 0 obtained from rcclUniqueId() and the host distributed to every rank
   static int rcclUniqueId(unsigned char* out128);
@@ -220,6 +221,10 @@ class Window {
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                int32_t* nBlocks, int capM);
   int describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) const;
+  // Map::parameterBlockPtr / id2parameterBlockMap as values (Map.hpp:166-170, :188): type 0 pose, 1 extrinsics, 2 speed/bias,
+  // 3 landmark; returns the ambient dimension (7 / 9 / 4) or SVIN_ERR_NOT_FOUND
+  int getParameterBlock(uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed, int32_t* initialized) const;
+  void parameterBlockIds(std::vector<uint64_t>& out) const;
   int benchJacobianEval(int copies, int iters, double* meanMs, double* bytes);
   int benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs);
 

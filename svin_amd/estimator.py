@@ -66,6 +66,10 @@ EXPORTS = [
     "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
     "svin_host_imu_propagation", "svin_host_reprojection_error", "svin_host_homogeneous_point_error",
     "svin_ba_add_homogeneous_point_error", "svin_ba_remove_homogeneous_point_error",
+    "svin_host_pose_information", "svin_host_pose_error", "svin_host_manifold_dims", "svin_host_manifold_plus",
+    "svin_host_manifold_minus", "svin_host_manifold_plus_jacobian", "svin_host_manifold_lift_jacobian",
+    "svin_host_manifold_minus_jacobian", "svin_ba_get_parameter_block", "svin_ba_parameter_block_ids",
+    "svin_ba_get_all_landmark_observations",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -177,6 +181,16 @@ def load_library():
     sig("svin_ba_init_pose_from_imu", i32, C.c_void_p, i32, pd)
     sig("svin_ba_imu_propagation_integrals", i32, vp, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd,
         pd)
+    sig("svin_host_pose_information", i32, pd, pd, pd)
+    sig("svin_host_pose_error", i32, pd, pd, pd, pd, pd, pd)
+    sig("svin_host_manifold_dims", i32, i32, pi32, pi32)
+    sig("svin_host_manifold_plus", i32, i32, pd, pd, pd)
+    sig("svin_host_manifold_minus", i32, i32, pd, pd, pd)
+    for name in ("plus_jacobian", "lift_jacobian", "minus_jacobian"):
+        sig("svin_host_manifold_" + name, i32, i32, pd, pd)
+    sig("svin_ba_get_parameter_block", i32, vp, u64, pi32, pd, C.POINTER(u32), C.POINTER(u32), pi32, pi32)
+    sig("svin_ba_parameter_block_ids", i32, vp, pu64, i32)
+    sig("svin_ba_get_all_landmark_observations", i32, vp, i32, pu64, C.POINTER(LandmarkInfo), pi32, i32, pu64, pu64, pu64, pu64, pi32)
     _LIB = L
     return L
 
@@ -217,6 +231,48 @@ def host_homogeneous_point_error(hp, measurement, information):
     if rc != 1:
         raise RuntimeError("svin_host_homogeneous_point_error failed (%d)" % rc)
     return r, Jm, J
+
+
+MANIFOLD_HPOINT, MANIFOLD_POSE6D, MANIFOLD_POSE3D, MANIFOLD_POSE4D, MANIFOLD_POSE2D = range(5)
+
+
+def host_pose_information(information):
+    """PoseError::setInformation (svin_host_pose_information): (sqrt_information 6x6 upper, covariance 6x6)"""
+    L = load_library()
+    W, cov = np.zeros((6, 6)), np.zeros((6, 6))
+    if L.svin_host_pose_information(_d(_arr(np.asarray(information, float).reshape(6, 6))), _d(W), _d(cov)) != 1:
+        raise RuntimeError("svin_host_pose_information failed")
+    return W, cov
+
+
+def host_pose_error(measurement, information, T_WS):
+    """CPU twin of PoseError::EvaluateWithMinimalJacobians (svin_host_pose_error): (residual[6], J_min 6x6, J 6x7)"""
+    L = load_library()
+    W, _ = host_pose_information(information)
+    r, Jm, J = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 7))
+    if L.svin_host_pose_error(_d(_arr(measurement)), _d(W), _d(_arr(T_WS)), _d(r), _d(Jm), _d(J)) != 1:
+        raise RuntimeError("svin_host_pose_error failed")
+    return r, Jm, J
+
+
+def host_manifold(kind, x, delta=None):
+    """the parameter-block manifolds (svin_host_manifold_*): dict with dims, plus / minus (if delta is given) and the Jacobians"""
+    L = load_library()
+    na, nt = C.c_int32(), C.c_int32()
+    if L.svin_host_manifold_dims(kind, C.byref(na), C.byref(nt)) != 1:
+        raise RuntimeError("unknown manifold kind %r" % (kind,))
+    na, nt = na.value, nt.value
+    x = _arr(x)
+    out = dict(ambient=na, tangent=nt, J_plus=np.zeros((na, nt)), J_lift=np.zeros((nt, na)), J_minus=np.zeros((nt, na)))
+    L.svin_host_manifold_plus_jacobian(kind, _d(x), _d(out["J_plus"]))
+    L.svin_host_manifold_lift_jacobian(kind, _d(x), _d(out["J_lift"]))
+    L.svin_host_manifold_minus_jacobian(kind, _d(x), _d(out["J_minus"]))
+    if delta is not None:
+        xp, d = np.zeros(na), np.zeros(nt)
+        L.svin_host_manifold_plus(kind, _d(x), _d(_arr(delta)), _d(xp))
+        L.svin_host_manifold_minus(kind, _d(xp), _d(x), _d(d))
+        out["plus"], out["minus"] = xp, d
+    return out
 
 
 def host_reprojection_error(model, intr, dist, T_WS, hp, T_SC, uv, information):
@@ -509,9 +565,40 @@ class Estimator:
         return [int(v) for v in out[:n]]
 
     def parameters_of(self, rid):
-        out, kind = np.zeros(64, np.uint64), C.c_int32()
-        n = self._check(self.L.svin_ba_parameters_of(self.h, rid, out.ctypes.data_as(pu64), 64, C.byref(kind)), "parameters_of")
+        kind = C.c_int32()
+        n = self._check(self.L.svin_ba_parameters_of(self.h, rid, None, 0, C.byref(kind)), "parameters_of")   # the count first: a prior lists every block it touches
+        out = np.zeros(max(n, 1), np.uint64)
+        self.L.svin_ba_parameters_of(self.h, rid, out.ctypes.data_as(pu64), n, C.byref(kind))
         return [int(v) for v in out[:n]], int(kind.value)
+
+    def parameter_block(self, bid):
+        """Map::parameterBlockPtr as a value: dict(type 0 pose / 1 extrinsics / 2 speed-bias / 3 landmark, values, stamp, fixed, initialized)"""
+        t, fx, ini, sec, nsec, x = C.c_int32(), C.c_int32(), C.c_int32(), u32(), u32(), np.zeros(9)
+        dim = self._check(self.L.svin_ba_get_parameter_block(self.h, bid, C.byref(t), _d(x), C.byref(sec), C.byref(nsec), C.byref(fx), C.byref(ini)),
+                          "get_parameter_block")
+        return dict(type=t.value, values=x[:dim].copy(), stamp=(sec.value, nsec.value), fixed=bool(fx.value), initialized=bool(ini.value))
+
+    def parameter_block_ids(self):
+        n = self.L.svin_ba_parameter_block_ids(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.uint64)
+        self.L.svin_ba_parameter_block_ids(self.h, out.ctypes.data_as(pu64), n)
+        return [int(v) for v in out[:n]]
+
+    def all_landmark_observations(self):
+        """getLandmarks with the observation maps in ONE call: {id: (info dict, [(frame, cam, keypoint, residual id)])}"""
+        tot = C.c_int32()
+        n = self.L.svin_ba_get_all_landmark_observations(self.h, 0, None, None, None, 0, None, None, None, None, C.byref(tot))
+        m = tot.value
+        ids, infos, ptr = np.zeros(max(n, 1), np.uint64), (LandmarkInfo * max(n, 1))(), np.zeros(n + 1, np.int32)
+        a = [np.zeros(max(m, 1), np.uint64) for _ in range(4)]
+        self.L.svin_ba_get_all_landmark_observations(self.h, n, ids.ctypes.data_as(pu64), infos, ptr.ctypes.data_as(pi32), m,
+                                                     *[x.ctypes.data_as(pu64) for x in a], C.byref(tot))
+        out = {}
+        for i in range(n):
+            info = dict(point=np.array(infos[i].point[:]), quality=infos[i].quality, distance=infos[i].distance,
+                        n_obs=infos[i].num_observations, initialized=bool(infos[i].initialized))
+            out[int(ids[i])] = (info, [tuple(int(x[k]) for x in a) for k in range(ptr[i], ptr[i + 1])])
+        return out
 
     def current_keyframe_id(self):
         return int(self.L.svin_ba_current_keyframe_id(self.h))

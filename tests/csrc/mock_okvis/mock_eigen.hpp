@@ -9,7 +9,8 @@ template <class T> struct aligned_allocator : std::allocator<T> {
   template <class U> aligned_allocator(const aligned_allocator<U>&) {}
   template <class U> struct rebind { typedef aligned_allocator<U> other; };
 };
-template <class S, int R, int C>
+enum { ColMajor = 0, RowMajor = 1 };
+template <class S, int R, int C, int O = ColMajor>
 struct Matrix {
   S v[R * C > 0 ? R * C : 1] = {};
   Matrix() = default;
@@ -18,8 +19,8 @@ struct Matrix {
   Matrix(S a, S b, S c, S d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
   S& operator[](int i) { return v[i]; }
   const S& operator[](int i) const { return v[i]; }
-  S& operator()(int i, int j) { return v[j * R + i]; }               // column-major like Eigen's default
-  const S& operator()(int i, int j) const { return v[j * R + i]; }
+  S& operator()(int i, int j) { return v[O == RowMajor ? i * C + j : j * R + i]; }   // column-major like Eigen's default
+  const S& operator()(int i, int j) const { return v[O == RowMajor ? i * C + j : j * R + i]; }
   S* data() { return v; }
   const S* data() const { return v; }
 };

@@ -132,7 +132,25 @@ int main(int argc, char** argv) {
   }
   // Map view: the residuals of the newest pose and the blocks of the first of them
   auto res = est.map()->residuals(est.currentFrameId());
-  std::printf("map residuals_of_current %zu first_params %zu exists %d\n", res.size(), res.empty() ? 0 : est.map()->parameters(res[0]).size(),
+  std::printf("map residuals_of_current %zu first_params %zu exists %d\n", res.size(), res.empty() ? 0 : est.map()->parameters(res[0].residualBlockId).size(),
               (int)est.map()->parameterBlockExists(est.currentFrameId()));
+  // snapshots of the window's blocks through the reference's accessors (Map.hpp:166-188)
+  auto pb = est.map()->parameterBlockPtr(est.currentFrameId());
+  auto all = est.map()->id2parameterBlockMap();
+  size_t nPose = 0, nSb = 0, nLm = 0;
+  for (auto& kv : all) {
+    const std::string t = kv.second->typeInfo();
+    nPose += t == "PoseParameterBlock";
+    nSb += t == "SpeedAndBiasParameterBlock";
+    nLm += t == "HomogeneousPointParameterBlock";
+  }
+  std::printf("blockptr %s dim %zu fixed %d x0 %.17g qw %.17g all %zu pose %zu sb %zu lm %zu missing %d\n", pb->typeInfo().c_str(), pb->dimension(), (int)pb->fixed(),
+              pb->parameters()[0], pb->parameters()[6], all.size(), nPose, nSb, nLm, (int)(est.map()->parameterBlockPtr(999999999ULL) == nullptr));
+  if (!res.empty()) {
+    auto ei = res.back().errorInterfacePtr;
+    auto ps = est.map()->parameters(res.back().residualBlockId);
+    std::printf("errif %s dim %zu blocks %zu firstdim %zu snapshot_id %llu\n", ei->typeInfo().c_str(), ei->residualDim(), ei->parameterBlocks(), ei->parameterBlockDim(0),
+                (unsigned long long)ps[0].second->id());
+  }
   return 0;
 }

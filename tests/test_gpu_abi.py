@@ -431,3 +431,46 @@ def test_host_evaluators_match_device(gpu_lib):
         for key in ("Jp", "Jl", "Je"):
             worst = max(worst, float(np.max(np.abs(o[key] - ev[key][i])) / max(1.0, np.max(np.abs(ev[key][i])))))
     assert worst < 1e-12, worst
+
+
+def test_parameter_block_snapshots_and_batched_landmark_readback(gpu_lib):
+    """Map::parameterBlockPtr / id2parameterBlockMap as values (Map.hpp:166-188, svin_ba_get_parameter_block / _ids) against the
+    oracle's Map parameter by parameter after an optimisation, and svin_ba_get_all_landmark_observations (the PointMap with
+    its observation maps in one call, Estimator.cpp:974-990) against the per-landmark getters."""
+    spec = syn.make_window(P=5, L=200, n_obs=1800, seed=21, rig="rig_v2", keyframe_every=2)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    for e in (gpu, cpu):
+        e.optimize(4)
+    m = cpu.map()
+    ids = gpu.parameter_block_ids()
+    assert ids == sorted(ids) and set(lg).issubset(ids) and set(fg).issubset(ids)
+    n_by_type = {0: 0, 1: 0, 2: 0, 3: 0}
+    for bid in ids:
+        b = gpu.parameter_block(bid)
+        n_by_type[b["type"]] += 1
+        ref = m.get_param(bid)
+        assert len(ref) == len(b["values"]) == {0: 7, 1: 7, 2: 9, 3: 4}[b["type"]]
+        if b["type"] == 3:
+            np.testing.assert_allclose(b["values"], ref, rtol=1e-6, atol=1e-7)
+            assert b["initialized"] and not b["fixed"]
+        else:
+            assert np.abs(b["values"] - ref).max() < 1e-6, (bid, b["values"], ref)
+            assert b["fixed"] == m.is_constant(bid)
+    assert n_by_type[0] == len(fg) and n_by_type[2] == len(fg) and n_by_type[1] >= 2 and n_by_type[3] == len(lg)
+    # poses carry their frame's time stamp and equal get_T_WS bit for bit
+    for k, fid in enumerate(fg):
+        b = gpu.parameter_block(fid)
+        assert b["type"] == 0 and np.array_equal(b["values"], gpu.get_T_WS(fid)) and b["stamp"] == tuple(int(v) for v in spec.stamps[k])
+    with pytest.raises(RuntimeError):
+        gpu.parameter_block(123456789)
+    # batched landmark read-back == the per-landmark calls
+    allobs = gpu.all_landmark_observations()
+    lms = gpu.get_landmarks()
+    assert list(allobs.keys()) == list(lms.keys()) and len(allobs) == len(lg)
+    total = 0
+    for lid, (info, obs) in allobs.items():
+        assert obs == gpu.landmark_observations(lid)
+        assert np.array_equal(info["point"], lms[lid]["point"]) and info["n_obs"] == len(obs) == lms[lid]["n_obs"]
+        assert info["quality"] == lms[lid]["quality"]
+        total += len(obs)
+    assert total == len(spec.obs) if hasattr(spec, "obs") else total > 1000

@@ -59,6 +59,11 @@ def parse(out):
             misc.update(landmarks=int(t[1]), observations=int(t[3]), current_kf=int(t[5]), current=int(t[7]))
         elif t[0] == "map":
             misc.update(res_current=int(t[2]), first_params=int(t[4]), exists=int(t[6]))
+        elif t[0] == "blockptr":
+            misc["blockptr"] = dict(type=t[1], dim=int(t[3]), fixed=int(t[5]), x0=float(t[7]), qw=float(t[9]), all=int(t[11]), pose=int(t[13]), sb=int(t[15]),
+                                    lm=int(t[17]), missing=int(t[19]))
+        elif t[0] == "errif":
+            misc["errif"] = dict(type=t[1], dim=int(t[3]), blocks=int(t[5]), firstdim=int(t[7]), snap=int(t[9]))
         elif t[0] == "frame":
             misc.setdefault("removed", []).append(int(t[3]))
             misc["state_count"] = int(t[5])
@@ -107,5 +112,14 @@ def test_cpp_shim_matches_ctypes_mirror(gpu_lib, tmp_path, rig, num_kf):
     for lid, lm in lms.items():
         assert same(lm["hp"], all_lm[lid]["point"]) and same(lm["q"], all_lm[lid]["quality"]) and lm["nobs"] == all_lm[lid]["n_obs"] and lm["init"] == 1
     assert misc["exists"] == 1 and misc["res_current"] == len(est.residuals_of(est.current_frame_id())) and misc["first_params"] >= 1
+    # Map::parameterBlockPtr / id2parameterBlockMap / errorInterfacePtr snapshots (Ceres-free value types of the shim)
+    bp, cur = misc["blockptr"], est.get_T_WS(est.current_frame_id())
+    assert bp["type"] == "PoseParameterBlock" and bp["dim"] == 7 and bp["fixed"] == 0 and same(bp["x0"], cur[0]) and same(bp["qw"], cur[6]) and bp["missing"] == 1
+    blocks = [est.parameter_block(b)["type"] for b in est.parameter_block_ids()]
+    assert bp["all"] == len(blocks) and bp["pose"] == blocks.count(0) + blocks.count(1) and bp["sb"] == blocks.count(2) and bp["lm"] == blocks.count(3) == len(all_lm)
+    last = est.residuals_of(est.current_frame_id())[-1]
+    ps, kind = est.parameters_of(last)
+    want = {100: ("ReprojectionError", 2), 0: ("ImuError", 15), 1: ("PoseError", 6), 4: ("SonarError", 1), 5: ("DepthError", 1)}[kind]
+    assert (misc["errif"]["type"], misc["errif"]["dim"]) == want and misc["errif"]["blocks"] == len(ps) and misc["errif"]["firstdim"] == 7 and misc["errif"]["snap"] == ps[0]
     if num_kf:
         assert misc["removed"] == removed and misc["state_count"] == spec.P

@@ -19,9 +19,13 @@ def build_shim_smoke(out):
 
 def test_shim_headers_are_self_contained(tmp_path):
     """each header on its own, every warning an error; a second translation unit proves there are no ODR-breaking definitions"""
-    for hdr in ("okvis/Estimator.hpp", "okvis/ceres/Map.hpp", "okvis/ceres/HomogeneousPointError.hpp"):
+    for hdr in ("okvis/Estimator.hpp", "okvis/ceres/Map.hpp", "okvis/ceres/HomogeneousPointError.hpp", "okvis/ceres/CeresTypes.hpp",
+                "okvis/ceres/ErrorInterface.hpp", "okvis/ceres/ParameterBlock.hpp", "okvis/ceres/ParameterBlockSized.hpp",
+                "okvis/ceres/PoseParameterBlock.hpp", "okvis/ceres/SpeedAndBiasParameterBlock.hpp", "okvis/ceres/HomogeneousPointParameterBlock.hpp",
+                "okvis/ceres/ManifoldAdditionalInterfaces.hpp", "okvis/ceres/PoseManifold.hpp", "okvis/ceres/HomogeneousPointManifold.hpp",
+                "okvis/ceres/PoseError.hpp"):
         src = tmp_path / "tu.cpp"
-        pre = "#include <mock_eigen.hpp>\n" if "HomogeneousPoint" in hdr else ""
+        pre = ""
         src.write_text(pre + "#include <%s>\n#include <%s>\nint main() { return 0; }\n" % (hdr, hdr))
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror"] + INC + [str(src)])
 
@@ -86,3 +90,137 @@ def test_cpu_shim_classes_match_the_c_abi(tmp_path):
     assert got == want, (got, want)
     t = out[3].split()
     assert int(t[1]) == 1 and float(t[2]) == o["Jl"][0, 0]
+
+
+def _compile(tmp_path, name):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror"] + INC + [os.path.join(ROOT, "tests", "csrc", name + ".cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "svin_amd"), "-lsvin_ba", "-Wl,-rpath," + os.path.join(ROOT, "svin_amd"), "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_no_shim_header_includes_ceres():
+    """the shim set is Ceres-free -- no header under integration/ includes a ceres/ header"""
+    import re
+    for d, _, files in os.walk(os.path.join(ROOT, "integration")):
+        for f in files:
+            text = open(os.path.join(d, f)).read()
+            assert not re.search(r'^\s*#\s*include\s*[<"]ceres/', text, re.M), f
+
+
+def test_frontend_calls_on_ceres_free_shim_match_oracle(tmp_path):
+    """tests/csrc/shim_frontend_calls.cpp makes the calls of ProbabilisticStereoTriangulator.cpp:87-99 / :266-300 and
+    VioKeyframeWindowMatchingAlgorithm.cpp:453 against integration/okvis/ceres/{PoseError, PoseParameterBlock,
+    HomogeneousPointParameterBlock, ReprojectionError, PoseManifold*, HomogeneousPointManifold}.hpp; what it prints is
+    held against the oracle (PoseError, the manifolds, ReprojectionError) to 1e-12 and, for the manifolds the oracle does
+    not restate (3d / 4d / 2d), against the reference's own criterion (ManifoldAdditionalInterfaces::verify)."""
+    import numpy as np
+    from oracle import orc
+    exe = _compile(tmp_path, "shim_frontend_calls")
+    rng = np.random.default_rng(5)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    Tab = np.concatenate([[0.11, -0.02, 0.015], q])
+    A = rng.normal(size=(6, 6))
+    info = A @ A.T + np.diag([50, 60, 70, 800, 900, 1000.0])
+    q2 = q + 0.05 * rng.normal(size=4); q2 /= np.linalg.norm(q2)
+    Tx = np.concatenate([[0.13, 0.01, -0.02], q2])
+    delta = np.array([0.01, -0.02, 0.03, 0.02, -0.01, 0.015])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "error_terms.npz"))
+    intr = list(g["reproj_intr"]) + list(g["reproj_dist"][7][:4])
+    hPA = np.array([0.4, -0.3, 5.0, 1.0])
+    uv = np.array([380.0, 250.0])
+    lines = [" ".join(repr(float(v)) for v in a) for a in (Tab, info.reshape(-1), Tx, delta)]
+    lines.append("RadialTangentialDistortion 752 480 %d %s" % (len(intr), " ".join(repr(float(v)) for v in intr)))
+    lines += [" ".join(repr(float(v)) for v in a) for a in (hPA, uv)]
+    path = tmp_path / "in.txt"
+    path.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, check=True).stdout.splitlines()
+
+    def vec(i, tag):
+        assert out[i].startswith(tag + " "), (out[i][:20], tag)
+        return np.array([float(v) for v in out[i][len(tag):].split()])
+
+    L = orc.lib()
+    m = orc.OracleMap()
+    BLOCK_POSE = 0
+    m.add_param(1, BLOCK_POSE, Tab)
+    m.add_param(2, BLOCK_POSE, Tx)
+    rid1 = L.orc_map_add_pose_error(m.h, orc.dptr(orc.arr(Tab)), orc.dptr(orc.arr(info.reshape(-1))), 1)
+    rid2 = L.orc_map_add_pose_error(m.h, orc.dptr(orc.arr(Tab)), orc.dptr(orc.arr(info.reshape(-1))), 2)
+    rid3 = L.orc_map_add_pose_error_var(m.h, orc.dptr(orc.arr(Tab)), 0.04, 0.0009, 2)
+    tol = dict(rtol=1e-12, atol=1e-12)
+    # ProbabilisticStereoTriangulator.cpp:87-99: evaluated at its own measurement
+    assert out[0] == "pose_at_measurement 1"
+    r, J, Jm = m.eval(rid1)
+    np.testing.assert_allclose(vec(1, "r"), r, **tol)
+    np.testing.assert_allclose(vec(2, "Jmin").reshape(6, 6), Jm[0], **tol)
+    np.testing.assert_allclose(vec(3, "J").reshape(6, 7), J[0], **tol)
+    H = vec(2, "Jmin").reshape(6, 6)
+    np.testing.assert_allclose(H.T @ H, info, rtol=1e-10)   # J_min^T J_min = the information at the measurement (what the triangulator wants)
+    # away from the measurement
+    assert out[4].startswith("pose_away 1 dim 6 blocks 1 bdim 7 type PoseError id 7 fixed 0 t 3 4")
+    r, J, Jm = m.eval(rid2)
+    np.testing.assert_allclose(vec(5, "r"), r, **tol)
+    np.testing.assert_allclose(vec(6, "Jmin").reshape(6, 6), Jm[0], **tol)
+    np.testing.assert_allclose(vec(7, "J").reshape(6, 7), J[0], **tol)
+    np.testing.assert_allclose(vec(8, "cov").reshape(6, 6, order="F"), np.linalg.inv(info), rtol=1e-10)   # mock Eigen: column-major
+    t = out[9].split()
+    assert t[0] == "pose_nojac" and t[1] == "1" and abs(float(t[2]) - r[5]) < 1e-12
+    np.testing.assert_allclose(vec(10, "r_var"), m.eval(rid3)[0], **tol)
+    # parameter-block operations == the oracle's pose manifold
+    xp, dm, Jp, Jl = np.zeros(7), np.zeros(6), np.zeros(42), np.zeros(42)
+    L.orc_manifold_plus(BLOCK_POSE, orc.dptr(Tx), orc.dptr(delta), orc.dptr(xp))
+    L.orc_manifold_minus(BLOCK_POSE, orc.dptr(xp), orc.dptr(Tx), orc.dptr(dm))
+    L.orc_manifold_plus_jacobian(BLOCK_POSE, orc.dptr(Tx), orc.dptr(Jp))
+    L.orc_manifold_lift_jacobian(BLOCK_POSE, orc.dptr(Tx), orc.dptr(Jl))
+    np.testing.assert_allclose(vec(11, "pb_plus"), xp, **tol)
+    np.testing.assert_allclose(vec(12, "pb_minus"), dm, **tol)
+    np.testing.assert_allclose(vec(13, "pb_Jplus"), Jp, **tol)
+    np.testing.assert_allclose(vec(14, "pb_Jlift"), Jl, **tol)
+    t = out[15].split()
+    assert t[0] == "pb_estimate" and float(t[1]) == Tx[0] and float(t[2]) == Tx[3] and float(t[3]) == Tx[6] and t[5:] == ["dim", "7", "min", "6", "type", "PoseParameterBlock"]
+    # manifolds: 6 lines each
+    i = 16
+    Jmn = np.zeros(42)
+    L.orc_pose_minus_jacobian(orc.dptr(Tx), orc.dptr(Jmn))
+    keep = {"m6": [0, 1, 2, 3, 4, 5], "m3": [3, 4, 5], "m4": [0, 1, 2, 5], "m2": [3, 4]}
+    for tag in ("m6", "m3", "m4", "m2", "mh"):
+        head = out[i].split()
+        assert head[0] == tag and head[-2:] == ["verify", "1"], out[i]   # the reference's own acceptance criterion
+        na, nt = int(head[2]), int(head[3])
+        plus, minus = vec(i + 1, tag + " plus"), vec(i + 2, tag + " minus")
+        Jplus, Jlift, Jminus = (vec(i + 3, tag + " Jplus").reshape(na, nt), vec(i + 4, tag + " Jlift").reshape(nt, na),
+                                vec(i + 5, tag + " Jminus").reshape(nt, na))
+        np.testing.assert_allclose(Jlift @ Jplus, np.eye(nt), atol=1e-12)
+        if tag == "mh":
+            np.testing.assert_allclose(plus, [0.3 + delta[0], -1.2 + delta[1], 4.0 + delta[2], 1.0], **tol)
+            np.testing.assert_allclose(minus, delta[:3], atol=1e-15)
+        else:
+            k = keep[tag]
+            d6 = np.zeros(6); d6[k] = delta[:nt]
+            L.orc_manifold_plus(BLOCK_POSE, orc.dptr(Tx), orc.dptr(d6), orc.dptr(xp))
+            L.orc_manifold_minus(BLOCK_POSE, orc.dptr(xp), orc.dptr(Tx), orc.dptr(dm))
+            np.testing.assert_allclose(plus, xp, **tol)
+            np.testing.assert_allclose(minus, dm[k], **tol)
+            np.testing.assert_allclose(Jlift, Jl.reshape(6, 7)[k], **tol)
+            np.testing.assert_allclose(Jminus, Jmn.reshape(6, 7)[k], **tol)
+            if tag in ("m6", "m4"):
+                np.testing.assert_allclose(Jplus, Jp.reshape(7, 6)[:, k], **tol)
+        i += 6
+    assert out[i] == "numdiff 1"
+    t = out[i + 1].replace("|", " ").split()
+    assert [float(v) for v in t[1:5]] == [0.3, -1.2, 4.0, 1.0] and t[5:7] == ["init", "1"] and float(t[7]) == 3.0 and float(t[8]) == 1.0 and t[9:] == ["init", "0", "dim", "4", "min", "3", "HomogeneousPointParameterBlock"]
+    t = out[i + 2].split()
+    assert abs(float(t[1]) - 1.8) < 1e-15 and abs(float(t[2]) - 0.3) < 1e-15 and t[3] == "SpeedAndBiasParameterBlock"
+    # ProbabilisticStereoTriangulator.cpp:292-300: ReprojectionError fed from the parameter blocks (pose B = T_AB, identity extrinsics)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    m.add_param(10, BLOCK_POSE, Tab)
+    m.add_param(11, 2, hPA)        # BLOCK_HPOINT
+    m.add_param(12, BLOCK_POSE, ident)
+    rid = m.add_reproj(1, g["reproj_intr"], g["reproj_dist"][7][:4], uv, np.eye(2) / (0.53 * 0.53), 0, 10, 11, 12)
+    r, J, Jm = m.eval(rid)
+    t = out[i + 3].split()
+    assert t[:2] == ["reprojB", "1"]
+    np.testing.assert_allclose([float(t[2]), float(t[3])], r, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(vec(i + 4, "J_TB_min").reshape(2, 6), Jm[0], rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(vec(i + 5, "J_hpB_min").reshape(2, 3), Jm[1], rtol=1e-11, atol=1e-10)
