@@ -1936,7 +1936,7 @@ __device__ void priorAccumulateBlock(const DeviceProblem& p, int block) {
   const int ri = priorRowToReduced(p, i), rj = priorRowToReduced(p, j);
   if (ri < 0 || rj < 0) return;
   const double h = priorHeff(p, i, j);
-  atomicAdd(&p.S[(size_t)ri * p.d + rj], h);
+  atomicAdd(&p.S[(size_t)ri * p.ldS + rj], h);
   if (i == j) {
     atomicAdd(&p.hC[ri], h);
     // gradient: (M^T grad)(i)
@@ -1977,7 +1977,7 @@ __device__ void factorsAccumulate(const DeviceProblem& p, int f, int* colRow) {
     if (ra < 0 || rb < 0) continue;
     double s = 0;
     for (int k = 0; k < m; ++k) s += lin.J[k * nc + a] * lin.J[k * nc + b];
-    atomicAdd(&p.S[(size_t)ra * p.d + rb], s);
+    atomicAdd(&p.S[(size_t)ra * p.ldS + rb], s);
     if (a == b) {
       atomicAdd(&p.hC[ra], s);
       double g = 0;
@@ -2959,8 +2959,8 @@ __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
     // diagonal pairs carry their lower tiles only (16 x 16 tiles, the diagonal tiles full)
     const int ti = (e / kPanelRows) >> 4, tj = (e % kPanelRows) >> 4;
     if (r < p.dC && c < p.dC && (pI != pJ || ti >= tj)) {
-      p.S[(size_t)r * p.d + c] += s;
-      if (pI != pJ || ti > tj) p.S[(size_t)c * p.d + r] += s;
+      p.S[(size_t)r * p.ldS + c] += s;
+      if (pI != pJ || ti > tj) p.S[(size_t)c * p.ldS + r] += s;
     }
   } else if (pI == pJ) {
     const int v = e - kPanelRows * kPanelRows, which = v / kPanelRows, r = kPanelRows * pI + v % kPanelRows;
@@ -2977,7 +2977,7 @@ __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
 constexpr int kSlabParts = 16;
 __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
   __shared__ double part[256];
-  SVIN_ARGS(SA(p.slabs), SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.nSlabs), SA(p.dC), SA(p.d));
+  SVIN_ARGS(SA(p.slabs), SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.nSlabs), SA(p.dC), SA(p.ldS));
   const int dC = p.dC;
   const size_t slabSize = (size_t)dC * dC + 3 * dC;
   const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
@@ -3016,8 +3016,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
 #pragma unroll
     for (int k = 0; k < kSlabParts; ++k) s += part[16 * k + e];
     if (idx < dC * dC) {
-      p.S[(size_t)rr * p.d + cc] += s;
-      if ((rr / 6) < (cc / 6)) p.S[(size_t)cc * p.d + rr] += s;
+      p.S[(size_t)rr * p.ldS + cc] += s;
+      if ((rr / 6) < (cc / 6)) p.S[(size_t)cc * p.ldS + rr] += s;
     } else {
       const int v = idx - dC * dC;
       if (v < dC) p.gRed[v] += s;
@@ -3039,13 +3039,13 @@ __device__ __forceinline__ double finalizeRow(const DeviceProblem& p, int i, dou
 __global__ void k_finalize_diag(DeviceProblem p, double mu, int initScale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.d) return;
-  p.S[(size_t)i * p.d + i] += finalizeRow(p, i, mu, initScale);
+  p.S[(size_t)i * p.ldS + i] += finalizeRow(p, i, mu, initScale);
 }
 
 __global__ void k_zero_build(DeviceProblem p) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int d = p.d;
-  if (i < d * d) p.S[i] = 0.0;
+  if (i < p.ldS * d) p.S[i] = 0.0;
   if (i < d) { p.gRed[i] = 0.0; p.gFull[i] = 0.0; p.hC[i] = 0.0; }
   if (i == 0) p.scal->cholFail = 0;
 }
@@ -3090,7 +3090,7 @@ void launchGatherStaged(void* block, const GatherArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_gather_staged, dim3(16, a.n), dim3(256), 0, s, reinterpret_cast<unsigned char*>(block), a);
 }
 void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_zero_build, dim3((p.d * p.d + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_zero_build, dim3((p.ldS * p.d + 255) / 256), dim3(256), 0, s, p);
 }
 // zeroFirst = false: the accumulators are already clear (pack() clears them, and k_post_solve clears them again
 // for the next linearisation of the trust-region loop)
@@ -3179,11 +3179,63 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
 constexpr int kTile = 16 * kPanelLd;  // doubles per tile
 __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
 
-constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: barrier + LDS pressure, the diagonal block is the critical path)
-__global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
+constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: LDS pressure, the diagonal block is the critical path)
+constexpr int kCholFlagInts = 32;
+// Flags of the barrier-free factorisation (LDS ints, monotonic counters, written by exactly one wave each):
+//   fl[0]       pivotDone  number of diagonal tiles whose factor D(kb) and 1/L_ii are in LDS
+//   fl[1 + I]   xReady[I]  number of block columns for which the panel tile X(I, .) of tile row I is stored
+//   fl[13 + I]  rowUpd[I]  number of block columns applied to every tile of tile row I
+//   fl[26]      a bounded spin gave up (a bug, not a numerical event: reported through cholFail bit 2)
+__device__ __forceinline__ void cholFlagSet(int* f, int v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the LDS writes of this wave are complete before the flag shows
+  if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// kSleep: s_sleep units (64 clocks) between polls -- 1 on the waves whose wait is on the critical path, more for the wave
+// that shares wave 0's SIMD (every poll of a waiting wave takes issue slots from the pivot routine)
+template <int kSleep = 1>
+__device__ __forceinline__ void cholFlagWait(int* f, int v, int* bail) {
+  int spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+    __builtin_amdgcn_s_sleep(kSleep);
+    if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// all of f[0 .. n) >= v, polled with one LDS read per round (lane j reads f[j])
+template <int kSleep = 1>
+__device__ __forceinline__ void cholFlagWaitAll(int* f, int n, int v, int lane, int* bail) {
+  int spins = 0;
+  while (true) {
+    const int x = (lane < n) ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : v;
+    if (__all(x >= v)) break;
+    __builtin_amdgcn_s_sleep(kSleep);
+    if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// Round 3: the factorisation has NO workgroup barrier between the load and the backward substitution.  Round 2 ran two
+// phases per block column with a barrier after each (P: panel solves, D: pivot tile on wave 0 next to the trailing update of
+// the others), so wave 0 -- the serial chain of the whole solve, 150 pivots -- waited twice per column for the slowest
+// worker (in-kernel timeline, profiles/r03_chol_timeline_before.txt: 10 x (1.4 k + 4.8 k) cycles of 90 k).  Now every tile
+// row I >= 2 has an OWNER wave for the whole factorisation, and the waves meet through the counters above:
+//   wave 0      per column kb: pivot tile kb out of its registers -> pivotDone; panel solve of the tile right below it
+//               (tile row kb+1, waits for rowUpd[kb+1]) -> xReady[kb+1]; update of the next diagonal tile in registers.
+//               Its loop never waits for more than the look-ahead row.
+//   owners      (waves 1-3, 5-7; rows dealt largest first, serpentine, so the short early rows -- the look-ahead rows -- sit
+//               on the lightly loaded waves) per column: panel solves of their rows once pivotDone allows, then the
+//               trailing update of each row as soon as the panel tiles xReady[kb+1 .. I-1] it multiplies with exist.
+//               They run as far behind wave 0 as the dependencies allow; the imbalance of the first columns (nine tile
+//               products in row 9 against a 3 k-cycle pivot tile) is absorbed instead of stalling the chain.
+//   wave 4      shares SIMD 0 with wave 0 and stays off the matrix pipe: forward substitution of the right-hand side.
+// Load phase: wave 0 loads ONLY tile (0, 0), straight into the accumulator layout, and factorises it while the other
+// waves are still waiting for theirs; the damping is added by the lanes that hold the diagonal entries (no second
+// barrier); gFull and the damped diagonal metric stay in registers / LDS, so the kernel ends with stores only.
+// (two waves per SIMD by construction: the register budget is 256 VGPRs, which keeps a wave's ~45 loads in ONE batch)
+__global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
                                                                     int fuseFinalize) {
   extern __shared__ double smem[];
-  SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS));
+  SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS),
+            SA(p.sPadded), SA(dpad), SA(mu), SA(initScale), SA(fuseFinalize));
   const int t = threadIdx.x, d = p.d, nT = dpad / 16;
   // the wave index through v_readfirstlane: tile indices and LDS tile addresses become scalar (SALU) arithmetic
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = kCholLdsThreads / 64;
@@ -3191,224 +3243,383 @@ __global__ __launch_bounds__(kCholLdsThreads) void k_chol_solve_lds(DeviceProble
   double* tiles = smem;
   double* rhs = smem + (size_t)nTilesAll * kTile;  // dpad
   double* dinv = rhs + dpad;                       // dpad
+  double* htil = dinv + dpad;                      // dpad: damped diagonal metric (the steepest-descent scaling)
+  int* fl = reinterpret_cast<int*>(htil + dpad);   // kCholFlagInts
+  int* bail = fl + 26;
+  const int g = lane >> 4, c = lane & 15;
 #ifdef SVIN_CHOL_TIMING
   const long long ql0 = __builtin_readcyclecounter();
+  long long qWait = 0, qBusy = 0;
+#define CHOL_T0 const long long qa_ = __builtin_readcyclecounter()
+#define CHOL_WAITED qWait += __builtin_readcyclecounter() - qa_
+// raw stamp `which` of block column kb, relative to the kernel start (last launch wins)
+#define CHOL_STAMP(which, kb) do { if (lane == 0) p.partial[(size_t)15 * 4096 + 64 + (which) * 12 + (kb)] = (double)(__builtin_readcyclecounter() - ql0); } while (0)
+#else
+#define CHOL_T0
+#define CHOL_WAITED
+#define CHOL_STAMP(which, kb)
 #endif
-  // right-hand side and diagonal damping (one element per thread, d <= 176 < blockDim): their global loads
-  // are in flight together with the tile loads below
+  const int ldS = p.ldS ? p.ldS : d;
+  // right-hand side, full gradient, and (without the fused metric) the metric of an earlier pass: one element per thread
   const double rhsMine = (t < d) ? p.gRed[t] : 0.0;
-  double dampMine = 0.0;
-  // load the lower triangle of S tile by tile (identity padding): every wave first issues the loads of all its
-  // tiles (independent, <= kMaxTilesPerWave x 4 values per lane in flight), then writes them to LDS -- the copy
-  // is bound by one global-memory latency instead of one per element
-  {
-    constexpr int kMaxTilesPerWave = 9;  // nT <= 11 -> 66 tiles over 8 waves
-    double v[kMaxTilesPerWave][4];
+  const double gFullMine = (t < d) ? p.gFull[t] : 0.0;
+  const double htilOld = (!fuseFinalize && t < d) ? p.htilC[t] : 1.0;
+  if (t < kCholFlagInts) fl[t] = 0;
+  // one tile in the accumulator layout (lane (g, c), register rg = entry (g + 4 rg, c)); identity padding; the lower
+  // triangle is read, diagonal tiles come out fully symmetric (the MFMA trailing update preserves that)
+  // split in two so that a wave can request ALL its tiles before it looks at the first value: tileRequest issues the
+  // loads (always a valid element of the lower triangle), tileSelect substitutes the identity padding afterwards.
+  // p.sPadded (the window's own S): the buffer has dpad rows of ldS >= dpad doubles with zeros beyond d, so an OFF-diagonal
+  // tile is a plain 16 x 16 block -- uniform base + one lane offset, no clamps, no select (the address arithmetic of the
+  // clamped form, ~14 VALU instructions per element on 7 waves, was what the load phase spent its time on).
+  const int laneOff = g * ldS + c;
+  auto tileRequest = [&](int I, int J, double (&x)[4]) {
+    if (p.sPadded && I != J) {
+      const double* base = p.S + (size_t)(16 * I) * ldS + 16 * J;   // wave-uniform
 #pragma unroll
-    for (int it = 0; it < kMaxTilesPerWave; ++it) {
-      const int tl = wave + it * nW;
-      int I = 0;
-      while ((I + 1) * (I + 2) / 2 <= tl) ++I;
-      const int J = tl - I * (I + 1) / 2;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
-        // branch-free: always read a valid element of the lower triangle, select afterwards.  Diagonal tiles are
-        // kept fully symmetric (the MFMA trailing update preserves that).
-        const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
-        const double x = p.S[(size_t)ci * (p.ldS ? p.ldS : d) + cj];
-        v[it][rg] = (gi < d && gj < d) ? x : ((gi == gj) ? 1.0 : 0.0);
-      }
+      for (int rg = 0; rg < 4; ++rg) x[rg] = base[(size_t)(4 * rg) * ldS + laneOff];
+      return;
     }
-    if (fuseFinalize && t < d) dampMine = finalizeRow(p, t, mu, initScale);
 #pragma unroll
-    for (int it = 0; it < kMaxTilesPerWave; ++it) {
-      const int tl = wave + it * nW;
-      if (tl < nTilesAll) {
-        double* dst = tiles + (size_t)tl * kTile;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) dst[((lane >> 4) + 4 * rg) * kPanelLd + (lane & 15)] = v[it][rg];
-      }
+    for (int rg = 0; rg < 4; ++rg) {
+      const int gi = 16 * I + g + 4 * rg, gj = 16 * J + c;
+      const int ci = min(max(gi, gj), d - 1), cj = min(min(gi, gj), d - 1);
+      x[rg] = p.S[(size_t)ci * ldS + cj];
     }
-  }
-  if (t < dpad) rhs[t] = rhsMine;
-  __syncthreads();
-  if (fuseFinalize) {  // metric + damping on the diagonal (k_finalize_diag) applied to the LDS copy
-    if (t < d) tileAt(tiles, t >> 4, t >> 4)[(t & 15) * kPanelLd + (t & 15)] += dampMine;
-    __syncthreads();
-  }
-#ifdef SVIN_CHOL_TIMING
-  long long qq0 = __builtin_readcyclecounter();
-  if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(qq0 - ql0);
-#endif
-  if (wave == 0) cholDiag16Reg(tileAt(tiles, 0, 0), dinv, lane, &p.scal->cholFail);
-  __syncthreads();
-#ifdef SVIN_CHOL_TIMING
-  if (t == 0) p.partial[(size_t)15 * 4096 + 0] += (double)(__builtin_readcyclecounter() - qq0);
-#endif
-  // Per block column kb (its diagonal tile is already factorised: prologue / phase D of the previous step):
-  //   phase P  panel solve X = A L^-T as a 16x16x16 product on MFMA (B operand = L^-T from the diagonal tile), one tile
-  //            per wave and turn.  Wave 0 takes the tile right below the diagonal and, from it, updates the NEXT
-  //            diagonal tile C -= X X^T, which stays in its registers; the last wave also advances the forward
-  //            substitution of the right-hand side: y'_kb = L_kb^-1 rhs_kb.
-  //   phase D  wave 0 factorises the next diagonal tile out of its registers (the serial chain of the whole solve)
-  //            while the other waves apply the trailing update C(I,J) -= X_I X_J^T.  The tile routine is
-  //            instruction-issue bound, so the wave sharing wave 0's SIMD stays off the matrix pipe and only updates
-  //            the tail of the right-hand side.  The workers own whole tile rows (dealt longest first, serpentine):
-  //            the A operand of a row is read once, the B / C tiles are walked with pointer increments, and the
-  //            operands of the next tile are in flight while the current one is on the matrix pipe.
-  const int lrow = (lane >> 4) * kPanelLd + (lane & 15);  // accumulator layout: + 4 rg kPanelLd
-  const int lop = (lane & 15) * kPanelLd + (lane >> 4);   // operand layout: + 4 q
-  for (int kb = 0; kb < nT; ++kb) {
-    const int k0 = kb * 16;
-    double* D = tileAt(tiles, kb, kb);
-#ifdef SVIN_CHOL_TIMING
-    long long q2 = __builtin_readcyclecounter();
-#endif
-    const int nR = nT - kb - 1;
-    d4_t accD = {0, 0, 0, 0};
-    // X^T = L^-1 A^T: with the operands in this order the product comes out TRANSPOSED in the accumulator layout, which is
-    // X in the operand layout (lane (row, g) register r = X[row][4r + g]) -- exactly what the trailing update reads, so
-    // wave 0 feeds it to the update of the next diagonal tile straight from its registers
-    auto panelSolve = [&](double* A) {
-      d4_t acc = {0, 0, 0, 0};
+  };
+  auto tileSelect = [&](int I, int J, double (&x)[4]) {
+    if (p.sPadded && I != J) return;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int gi = 16 * I + g + 4 * rg, gj = 16 * J + c;
+      x[rg] = (gi < d && gj < d) ? x[rg] : ((gi == gj) ? 1.0 : 0.0);
+    }
+  };
+  // A lane holds at most one diagonal entry of a diagonal tile: row 16 I + c in register (c - g) / 4.  The metric inputs of
+  // that row (hC, scaleC) are requested together with the tile; `dampDiag` then adds mu * htil to the entry and keeps htil.
+  const bool diagLane = ((c - g) & 3) == 0 && c >= g;
+  const int diagReg = (c - g) >> 2;
+  auto dampDiag = [&](int I, bool valid, double hc, double scIn, double (&v)[4]) {
+    const int i = 16 * I + c;
+    double damp = 0.0;
+    if (valid && diagLane && i < d) {
+      double sc = scIn;
+      if (initScale) { sc = 1.0 / (1.0 + sqrt(hc)); p.scaleC[i] = sc; }
+      const double ht = fmin(fmax(hc * sc * sc, 1e-6), 1e32) / (sc * sc);
+      p.htilC[i] = ht;
+      htil[i] = ht;
+      damp = mu * ht;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) v[rg] += (rg == diagReg) ? damp : 0.0;
+  };
+  // (rhsMine / htilOld go to LDS right before the load barrier: storing them here would wait for their loads before the
+  //  first tile load is issued)
+  const int lrow = g * kPanelLd + c;  // accumulator layout: + 4 rg kPanelLd
+  const int lop = c * kPanelLd + g;   // operand layout: + 4 q
+  // X^T = L^-1 A^T: with the operands in this order the product comes out TRANSPOSED in the accumulator layout, which is
+  // X in the operand layout (lane (row, g) register r = X[row][4r + g]) -- exactly what the trailing update reads
+  auto panelSolve = [&](double* A, const double* D, int k0) {
+    // all twelve operands requested before the first product (one LDS latency instead of four on a dependent chain)
+    double a[4], bD[4], bI[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 4 * q + g;
+      a[q] = A[lop + 4 * q];
+      bD[q] = D[kk * kPanelLd + c];
+      bI[q] = dinv[k0 + kk];
+    }
+    d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = 4 * q + g;
+      const double b = (c > kk) ? bD[q] : ((c == kk) ? bI[q] : 0.0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) A[lop + 4 * rg] = acc[rg];
+    return acc;
+  };
+  // tile (I, J) -= X(I, kb) X(J, kb)^T for J = kb+1 .. I (the trailing update of one tile row).  TWO tiles at a time on
+  // independent accumulators: the four products of one tile are a dependent chain (64 cycles each on the matrix pipe), a
+  // second chain fills the gaps -- with two owner waves per SIMD the pipe stays busy -- and the operands of the next pair
+  // are in flight meanwhile.  The A operand X(I, kb) is read once per row, B / C tiles are walked by pointer increments.
+  auto updateRow = [&](int I, int kb) {
+    const double* A = tileAt(tiles, I, kb);
+    double a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = -A[lop + 4 * q];
+    double* Cb = tileAt(tiles, I, kb + 1);
+    const double* B = tileAt(tiles, kb + 1, kb);
+    int rowTiles = kb + 2;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
+    const int nTl = I - kb;  // tiles in this row segment
+    double b0[4], b1[4] = {0, 0, 0, 0};
+    d4_t c0, c1 = {0, 0, 0, 0};
+    double* Cf = Cb;   // fetch cursor (tile about to be requested); Cb stays on the pair being computed
+    auto fetch = [&](double (&bq)[4], d4_t& cq) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) cq[rg] = Cf[lrow + 4 * rg * kPanelLd];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = B[lop + 4 * q];
+      B += (size_t)rowTiles * kTile;
+      ++rowTiles;
+      Cf += kTile;
+    };
+    fetch(b0, c0);
+    if (nTl > 1) fetch(b1, c1);
+    for (int J = 0; J < nTl; J += 2) {
+      const bool two = J + 1 < nTl;
+      double nb0[4] = {0, 0, 0, 0}, nb1[4] = {0, 0, 0, 0};
+      d4_t nc0 = {0, 0, 0, 0}, nc1 = {0, 0, 0, 0};
+      if (J + 2 < nTl) fetch(nb0, nc0);
+      if (J + 3 < nTl) fetch(nb1, nc1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int kk = 4 * q + (lane >> 4), jj = lane & 15;
-        const double a = A[lop + 4 * q];
-        const double b = (jj > kk) ? D[kk * kPanelLd + jj] : ((jj == kk) ? dinv[k0 + kk] : 0.0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[q], c0, 0, 0, 0);
+        if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], c1, 0, 0, 0);
       }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) A[lop + 4 * rg] = acc[rg];
-      return acc;
-    };
-    if (wave == 0) {
-      if (nR > 0) {
+      for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kPanelLd] = c0[rg];
+      if (two) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Cb[kTile + lrow + 4 * rg * kPanelLd] = c1[rg];
+      }
+      Cb += 2 * kTile;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { b0[q] = nb0[q]; b1[q] = nb1[q]; }
+      c0 = nc0;
+      c1 = nc1;
+    }
+  };
+  if (wave == 0) {
+    // ------------------------------------------------------------------------------------------ the serial chain
+    double v0[4];
+    tileRequest(0, 0, v0);
+    const int i0 = min(c, d - 1);
+    const double hc0 = fuseFinalize ? p.hC[i0] : 0.0, sc0 = (fuseFinalize && !initScale) ? p.scaleC[i0] : 1.0;
+    tileSelect(0, 0, v0);
+    if (fuseFinalize) dampDiag(0, true, hc0, sc0, v0);
+    d4_t accD = {v0[0], v0[1], v0[2], v0[3]};
+    for (int kb = 0; kb < nT; ++kb) {
+      const int k0 = 16 * kb;
+      double* D = tileAt(tiles, kb, kb);
+      CHOL_STAMP(0, kb);
+      cholDiag16Acc(accD, D, dinv + k0, lane, &p.scal->cholFail);
+      CHOL_STAMP(1, kb);
+      cholFlagSet(fl + 0, kb + 1, lane);
+      CHOL_STAMP(2, kb);
+      if (kb == 0) {
+        if (t < dpad) { rhs[t] = rhsMine; if (!fuseFinalize) htil[t] = htilOld; }
+        ldsBarrier();   // the other waves have stored their tiles (their only barrier before the backward substitution)
+#ifdef SVIN_CHOL_TIMING
+        if (t == 0) p.partial[(size_t)15 * 4096 + 1] += (double)(__builtin_readcyclecounter() - ql0);
+#endif
+      }
+      if (kb + 1 < nT) {
+        CHOL_STAMP(3, kb);
+        if (kb > 0) { CHOL_T0; cholFlagWait(fl + 13 + kb + 1, kb, bail); CHOL_WAITED; }
+        CHOL_STAMP(4, kb);
         double* A = tileAt(tiles, kb + 1, kb);
         const double* Cb = tileAt(tiles, kb + 1, kb + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) accD[rg] = Cb[lrow + 4 * rg * kPanelLd];
-        const d4_t xT = panelSolve(A);
+        const d4_t xT = panelSolve(A, D, k0);
+        CHOL_STAMP(5, kb);
+        // the first product of the diagonal update is on the matrix pipe while the stores of X drain and the flag goes out
+        accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[0], xT[0], accD, 0, 0, 0);
+        cholFlagSet(fl + 1 + kb + 1, kb + 1, lane);
+        CHOL_STAMP(6, kb);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[q], xT[q], accD, 0, 0, 0);
+        for (int q = 1; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[q], xT[q], accD, 0, 0, 0);
       }
-    } else {
-      for (int ti = wave; ti < nR; ti += nW - 1) panelSolve(tileAt(tiles, kb + 1 + ti, kb));
-      if (wave == nW - 1) {
-        const int li = lane & 15;
-        double yv = rhs[k0 + li] * dinv[k0 + li];
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ load (waves 1-7)
+    {
+      // Diagonal tiles 1 .. nT-1: tile `wave` and tile 7 + `wave` (nT <= 11); off-diagonal tiles dealt round robin, at most
+      // eight per wave (55 at nT = 11).  Tile indices are scalar and computed first, so that what follows is ONE batch of
+      // loads without a branch in it (out-of-range slots re-read a valid tile and are not stored).
+      constexpr int kMaxOff = 8;
+      const int nOff = nT * (nT - 1) / 2;
+      int dI[2], oI[kMaxOff], oJ[kMaxOff];
+      dI[0] = min(wave, nT - 1);
+      dI[1] = min(7 + wave, nT - 1);
 #pragma unroll
-        for (int c = 0; c < 15; ++c) {
-          const double term = D[c * kPanelLd + li] * rhs[k0 + c];
-          yv += (c < li) ? term : 0.0;
+      for (int it = 0; it < kMaxOff; ++it) {
+        const int e = min((wave - 1) + 7 * it, max(nOff - 1, 0));
+        // I (I - 1) / 2 <= e < I (I + 1) / 2 without a loop (ten independent scalar compares; a search loop costs a
+        // dependent multiply per step and these indices gate the very first loads): e <= 54 at nT = 11
+        const int I = 1 + (e >= 1) + (e >= 3) + (e >= 6) + (e >= 10) + (e >= 15) + (e >= 21) + (e >= 28) + (e >= 36) + (e >= 45);
+        oI[it] = __builtin_amdgcn_readfirstlane(I);
+        oJ[it] = __builtin_amdgcn_readfirstlane(e - I * (I - 1) / 2);
+      }
+      double vd[2][4], hcv[2], scv[2], vo[kMaxOff][4];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        tileRequest(dI[sl], dI[sl], vd[sl]);
+        const int i = min(16 * dI[sl] + c, d - 1);
+        hcv[sl] = fuseFinalize ? p.hC[i] : 0.0;
+        scv[sl] = (fuseFinalize && !initScale) ? p.scaleC[i] : 1.0;
+      }
+#pragma unroll
+      for (int it = 0; it < kMaxOff; ++it) tileRequest(oI[it], oJ[it], vo[it]);
+      if (wave == 1) CHOL_STAMP(8, 0);   // requests issued
+      __builtin_amdgcn_sched_barrier(0);   // nothing that consumes a loaded value moves above this line: one batch of ~44 loads
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) tileSelect(dI[sl], dI[sl], vd[sl]);
+#pragma unroll
+      for (int it = 0; it < kMaxOff; ++it) tileSelect(oI[it], oJ[it], vo[it]);
+#ifdef SVIN_CHOL_TIMING
+      if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP(8, 1); }   // all values have arrived
+#endif
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bool valid = (sl == 0 ? wave : 7 + wave) < nT;
+        if (fuseFinalize) dampDiag(dI[sl], valid, hcv[sl], scv[sl], vd[sl]);
+        if (valid) {
+          double* dst = tileAt(tiles, dI[sl], dI[sl]);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) dst[lrow + 4 * rg * kPanelLd] = vd[sl][rg];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kMaxOff; ++it) {
+        if ((wave - 1) + 7 * it < nOff) {
+          double* dst = tileAt(tiles, oI[it], oJ[it]);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) dst[lrow + 4 * rg * kPanelLd] = vo[it][rg];
+        }
+      }
+    }
+    if (wave == 1) CHOL_STAMP(8, 2);   // tiles stored to LDS
+    if (t < dpad) { rhs[t] = rhsMine; if (!fuseFinalize) htil[t] = htilOld; }
+    ldsBarrier();   // LDS only: the global stores of the metric (scaleC / htilC) need not have landed
+    if (wave == 1) CHOL_STAMP(8, 3);   // past the load barrier
+    const int quiet = nW / 2;  // shares SIMD 0 with wave 0
+    if (wave == quiet) {
+      // ---------------------------------------------------------------------------------------- forward substitution
+      for (int kb = 0; kb < nT; ++kb) {
+        const int k0 = 16 * kb;
+        const double* D = tileAt(tiles, kb, kb);
+        { CHOL_T0; cholFlagWait<8>(fl + 0, kb + 1, bail); CHOL_WAITED; }
+        double yv = rhs[k0 + c] * dinv[k0 + c];   // y'_kb = L_kb^-1 rhs_kb (strict lower part of L^-1 sits transposed above the diagonal)
+#pragma unroll
+        for (int cc = 0; cc < 15; ++cc) {
+          const double term = D[cc * kPanelLd + c] * rhs[k0 + cc];
+          yv += (cc < c) ? term : 0.0;
         }
         waveSync();
         if (lane < 16) rhs[k0 + lane] = yv;
-      }
-    }
-    __syncthreads();
-#ifdef SVIN_CHOL_TIMING
-    long long q3 = __builtin_readcyclecounter();
-    if (t == 0) p.partial[(size_t)15 * 4096 + 2] += (double)(q3 - q2);
-#endif
-    const int quiet = nW / 2;  // shares SIMD 0 with wave 0
-    if (wave == 0) {
-      if (nR > 0) cholDiag16Acc(accD, tileAt(tiles, kb + 1, kb + 1), dinv + k0 + 16, lane, &p.scal->cholFail);
-    } else if (wave == quiet) {
-      for (int i = k0 + 16 + lane; i < dpad; i += 64) {
-        const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
-        double sacc = 0;
+        waveSync();
+        if (kb + 1 < nT) {
+          { CHOL_T0; cholFlagWaitAll<8>(fl + 1 + kb + 1, nT - kb - 1, kb + 1, lane, bail); CHOL_WAITED; }
+          for (int i = k0 + 16 + lane; i < dpad; i += 64) {
+            const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
+            double sacc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
-        rhs[i] -= sacc;
+            for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
+            rhs[i] -= sacc;
+          }
+          waveSync();
+        }
       }
     } else {
+      // ---------------------------------------------------------------------------------------- tile-row owners
       const int widx = wave - 1 - (wave > quiet ? 1 : 0), nWork = nW - 2;
-      // rows nR-1 .. 1 of the trailing matrix (row I: tiles (I, 0..I); row 0 is wave 0's tile), dealt to the workers
-      // longest first and back again
-      for (int n = 0; n < nR - 1; ++n) {
-        const int turn = n / nWork, pos = n - turn * nWork;
-        if (((turn & 1) ? nWork - 1 - pos : pos) != widx) continue;
-        const int I = nR - 1 - n;
-        const double* A = tileAt(tiles, kb + 1 + I, kb);
-        double a[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = -A[lop + 4 * q];
-        double* Cb = tileAt(tiles, kb + 1 + I, kb + 1);
-        const double* B = tileAt(tiles, kb + 1, kb);
-        int rowTiles = kb + 2;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
-        double bq[4];
-        d4_t acc;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) acc[rg] = Cb[lrow + 4 * rg * kPanelLd];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = B[lop + 4 * q];
-        for (int J = 0; J <= I; ++J) {
-          const bool more = J < I;
-          double bn[4] = {0, 0, 0, 0};
-          d4_t accn = {0, 0, 0, 0};
-          if (more) {
-            B += (size_t)rowTiles * kTile;
-            ++rowTiles;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) accn[rg] = Cb[kTile + lrow + 4 * rg * kPanelLd];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bn[q] = B[lop + 4 * q];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kPanelLd] = acc[rg];
-          Cb += kTile;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bq[q] = bn[q];
-          acc = accn;
+      auto owns = [&](int I) {   // rows nT-1 .. 2 dealt largest first and back again
+        const int n = nT - 1 - I, turn = n / nWork, pos = n - turn * nWork;
+        return ((turn & 1) ? nWork - 1 - pos : pos) == widx;
+      };
+      for (int kb = 0; kb + 2 < nT; ++kb) {
+        const int k0 = 16 * kb;
+        const double* D = tileAt(tiles, kb, kb);
+        bool waited = false;
+        // the look-ahead row kb+2 is what wave 0 waits for next: its panel tile and its two tiles come before anything else
+        const int la = kb + 2;
+        if (owns(la)) {
+          { CHOL_T0; cholFlagWait(fl + 0, kb + 1, bail); CHOL_WAITED; waited = true; }
+          panelSolve(tileAt(tiles, la, kb), D, k0);
+          cholFlagSet(fl + 1 + la, kb + 1, lane);
+          { CHOL_T0; cholFlagWait(fl + 1 + kb + 1, kb + 1, bail); CHOL_WAITED; }
+          updateRow(la, kb);
+          cholFlagSet(fl + 13 + la, kb + 1, lane);
+          CHOL_STAMP(7, kb);
+        }
+        for (int I = kb + 3; I < nT; ++I) {
+          if (!owns(I)) continue;
+          if (wave == 5) CHOL_STAMP(9, kb);    // row 6: step start
+          if (!waited) { CHOL_T0; cholFlagWait(fl + 0, kb + 1, bail); CHOL_WAITED; waited = true; }
+          if (wave == 5) CHOL_STAMP(10, kb);   // pivot seen
+          panelSolve(tileAt(tiles, I, kb), D, k0);
+          cholFlagSet(fl + 1 + I, kb + 1, lane);
+          if (wave == 5) CHOL_STAMP(11, kb);   // panel tile out
+        }
+        for (int I = kb + 3; I < nT; ++I) {
+          if (!owns(I)) continue;
+          // needs the panel tiles of rows kb+1 .. I-1 (row I is mine)
+          { CHOL_T0; cholFlagWaitAll(fl + 1 + kb + 1, I - kb - 1, kb + 1, lane, bail); CHOL_WAITED; }
+          if (wave == 5) CHOL_STAMP(12, kb);   // operands there
+          updateRow(I, kb);
+          cholFlagSet(fl + 13 + I, kb + 1, lane);
+          if (wave == 5) CHOL_STAMP(13, kb);   // row updated
         }
       }
     }
-#ifdef SVIN_CHOL_TIMING
-    if (lane == 0 && kb < 3) p.partial[(size_t)15 * 4096 + 32 + kb * 8 + wave] += (double)(__builtin_readcyclecounter() - q3);
-#endif
-    __syncthreads();
-#ifdef SVIN_CHOL_TIMING
-    long long q4 = __builtin_readcyclecounter();
-    if (t == 0) p.partial[(size_t)15 * 4096 + 3] += (double)(q4 - q3);
-#endif
   }
 #ifdef SVIN_CHOL_TIMING
-  long long q5 = __builtin_readcyclecounter();
+  const long long qf = __builtin_readcyclecounter();
+  if (lane == 0) { p.partial[(size_t)15 * 4096 + 32 + wave] += (double)(qf - ql0); p.partial[(size_t)15 * 4096 + 40 + wave] += (double)qWait; }
 #endif
-  // backward substitution L^T y = y': wave 0 solves the 16x16 diagonal system with L^-T, then every thread
-  // removes that block's contribution from one earlier row
+  __syncthreads();   // factor, 1/L_ii and the forward-substituted right-hand side are complete
+  if (t == 0 && *bail) atomicOr(&p.scal->cholFail, 4);
+#ifdef SVIN_CHOL_TIMING
+  long long q5 = __builtin_readcyclecounter();
+  if (t == 0) p.partial[(size_t)15 * 4096 + 3] += (double)(q5 - ql0);
+#endif
+  // Backward substitution L^T y = y', one barrier per block: wave 0 first takes block kb+1's contribution to the rows of
+  // block kb (the only rows the next solve needs), then solves y_kb with L_kb^-T; the other waves meanwhile remove block
+  // kb+1's contribution from the rows above block kb.
   for (int kb = nT - 1; kb >= 0; --kb) {
     const int k0 = kb * 16;
-    const double* D = tileAt(tiles, kb, kb);
     if (wave == 0) {
-      const int li = lane & 15;
-      double yv = rhs[k0 + li] * dinv[k0 + li];
+      const double* D = tileAt(tiles, kb, kb);
+      double rv = rhs[k0 + c];
+      if (kb + 1 < nT) {
+        const double* Lb = tileAt(tiles, kb + 1, kb) + c;   // L(k0 + 16 + k, k0 + c)
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sacc += Lb[k * kPanelLd] * rhs[k0 + 16 + k];
+        rv -= sacc;
+        waveSync();
+        if (lane < 16) rhs[k0 + lane] = rv;
+        waveSync();
+      }
+      double yv = rv * dinv[k0 + c];
 #pragma unroll
       for (int r = 1; r < 16; ++r) {
-        const double term = D[li * kPanelLd + r] * rhs[k0 + r];
-        yv += (r > li) ? term : 0.0;
+        const double term = D[c * kPanelLd + r] * rhs[k0 + r];
+        yv += (r > c) ? term : 0.0;
       }
       waveSync();
       if (lane < 16) rhs[k0 + lane] = yv;
-    }
-    __syncthreads();
-    for (int i = t; i < k0; i += blockDim.x) {
-      const double* col = tileAt(tiles, kb, i >> 4) + (i & 15);  // L(k0+k, i)
-      double sacc = 0;
+    } else if (kb + 1 < nT) {
+      for (int i = t - 64; i < k0; i += kCholLdsThreads - 64) {
+        const double* col = tileAt(tiles, kb + 1, i >> 4) + (i & 15);  // L(k0 + 16 + k, i)
+        double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + k];
-      rhs[i] -= sacc;
+        for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + 16 + k];
+        rhs[i] -= sacc;
+      }
     }
-    __syncthreads();
+    ldsBarrier();
   }
 #ifdef SVIN_CHOL_TIMING
   if (t == 0) p.partial[(size_t)15 * 4096 + 4] += (double)(__builtin_readcyclecounter() - q5);
 #endif
-  for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
+  if (t < d) { p.yC[t] = rhs[t]; p.vC[t] = gFullMine / htil[t]; }  // Gauss-Newton solution + steepest-descent direction
+#undef CHOL_T0
+#undef CHOL_WAITED
+#undef CHOL_STAMP
 }
 
 // ================================================================ K6': reduced systems beyond the LDS-resident solver
@@ -4335,7 +4546,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
-  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 2 * dpad) * 8;
+  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 3 * dpad) * 8 + kCholFlagInts * 4;
   if (ldsBytes <= 156 * 1024) {
     ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
@@ -4537,7 +4748,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   TRACE(0);
   // clear the accumulators of the next linearisation (nothing reads S / gRed / hC after the solve; gFull is
   // still needed by the last block below and is cleared there)
-  for (int i = b * blockDim.x + t; i < p.d * p.d; i += gridDim.x * blockDim.x) p.S[i] = 0.0;
+  for (int i = b * blockDim.x + t; i < p.ldS * p.d; i += gridDim.x * blockDim.x) p.S[i] = 0.0;
   for (int i = b * blockDim.x + t; i < p.d; i += gridDim.x * blockDim.x) { p.gRed[i] = 0.0; p.hC[i] = 0.0; }
   // Staged in LDS by every block at its start: the camera-side solution vectors (tiny, read by every observation: one
   // copy instead of a dependent global load per observation; wide windows keep reading them through L2), the block ->

@@ -141,7 +141,10 @@ struct DeviceProblem {
   double *priorMv, *priorMy;                    // scratch m
   // normal equations
   double *S, *gRed, *gFull, *hC, *htilC, *scaleC;
-  int ldS;   // leading dimension of S as seen by launchSolveReduced (0 = d); lets a caller solve a trailing principal block in place
+  int sPadded;   // S has ((d + 15) / 16) * 16 rows of ldS doubles, zero beyond row / column d (the window's own buffer)
+  int ldS;   // leading dimension of S.  The window sets it to d rounded up to 16 doubles (every 16-column tile row segment is then ONE
+             // 128-byte cache line: the tile loads of the solvers touch half as many lines); 0 = d for a caller that only uses
+             // launchSolveReduced on a principal block of its own matrix (pose graph root)
   double *Vinv, *bl, *hL, *scaleL;           // per landmark 6 / 3 / 3 / 3
   double *slabs; int nSlabs;                 // per-workgroup private copies of the leading dC x dC block (+2 dC vectors)
   double *yC, *yL;                           // Gauss-Newton solution (cam d, landmarks 3L)

@@ -979,7 +979,8 @@ void Window::pack() {
   }
   const int dpad = ((d + 15) / 16) * 16;
   // S and the camera-side vectors share one allocation: [S | gRed | gFull | hC | ...] is all-reduced as one message
-  dS_.reserve((size_t)d * d + (size_t)12 * std::max(d, 1) + 64);
+  const int sS = ((std::max(d, 1) + 15) / 16) * 16;   // row stride of S: whole 128-byte lines per 16-column tile segment
+  dS_.reserve((size_t)sS * sS + (size_t)12 * std::max(d, 1) + 64);   // sS rows as well: the solver reads whole tiles without clamping
   dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
   {
     const size_t dp64 = ((size_t)d + 63) / 64 * 64;  // multi-workgroup solver: (dp64 + 64) x dp64 matrix + 1/L_ii + diagonal factors
@@ -1124,9 +1125,11 @@ void Window::pack() {
   }
   const int dd = std::max(d, 1);
   // accumulators start clear: the trust-region loop never launches k_zero_build (k_post_solve re-clears them)
-  HIP_OK(hipMemsetAsync(dS_.p, 0, sizeof(double) * ((size_t)d * d + (size_t)12 * dd), s));
+  HIP_OK(hipMemsetAsync(dS_.p, 0, sizeof(double) * ((size_t)sS * sS + (size_t)12 * dd), s));
   p.S = dS_.p;
-  double* vecBase = dS_.p + (size_t)d * d;
+  p.ldS = sS;
+  p.sPadded = 1;
+  double* vecBase = dS_.p + (size_t)sS * sS;
   p.gRed = vecBase; p.gFull = vecBase + dd; p.hC = vecBase + 2 * dd; p.htilC = vecBase + 3 * dd;
   p.scaleC = vecBase + 4 * dd; p.yC = vecBase + 5 * dd; p.deltaC = vecBase + 6 * dd; p.vC = vecBase + 7 * dd;
   const size_t LL = std::max(L, 1);
@@ -1544,7 +1547,7 @@ int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32
   launchBuildNormalEquations(p, mu, true, stream_);
   SolverScalars sc = readScalars();
   if (cost) *cost = sc.cost;
-  if (S) HIP_OK(hipMemcpy(S, p.S, sizeof(double) * (size_t)p.d * p.d, hipMemcpyDeviceToHost));
+  if (S) HIP_OK(hipMemcpy2D(S, sizeof(double) * p.d, p.S, sizeof(double) * p.ldS, sizeof(double) * p.d, p.d, hipMemcpyDeviceToHost));
   if (g) HIP_OK(hipMemcpy(g, p.gRed, sizeof(double) * p.d, hipMemcpyDeviceToHost));
   if (nBlocks) *nBlocks = (int)redBlockIds_.size();
   for (size_t i = 0; i < redBlockIds_.size(); ++i) {
@@ -1741,21 +1744,32 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
   if (getenv("SVIN_CHOL_TIMING")) {
     double dbg[5];
     HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096, sizeof(dbg), hipMemcpyDeviceToHost));
-    std::printf("[chol cycles per launch] diag0 %.0f load %.0f trsm %.0f mfma %.0f back %.0f\n", dbg[0] / iters, dbg[1] / iters,
-                dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
+    std::printf("[chol cycles per launch] load + first pivot tile %.0f  factorisation done (from kernel start) %.0f  backward substitution %.0f\n",
+                dbg[1] / iters, dbg[3] / iters, dbg[4] / iters);
 #ifdef SVIN_CHOL_TIMING
     {
-      double w[24];
+      double w[16];
       HIP_OK(hipMemcpy(w, p.partial + (size_t)15 * 4096 + 32, sizeof(w), hipMemcpyDeviceToHost));
-      for (int kb = 0; kb < 3; ++kb) {
-        std::printf("[phase C busy cycles kb=%d]", kb);
-        for (int k = 0; k < 8; ++k) std::printf(" w%d %.0f", k, w[kb * 8 + k] / iters);
-        std::printf("\n");
-      }
+      std::printf("[per wave: cycles until its part of the factorisation was done | of which waiting on flags]");
+      for (int k = 0; k < 8; ++k) std::printf("  w%d %.0f | %.0f", k, w[k] / iters, w[8 + k] / iters);
+      std::printf("\n");
     }
     double dd[4];
     debugCholTiming(dd, false);
-    std::printf("[diag block cycles per launch] eliminate %.0f scale+store %.0f inverse %.0f\n", dd[0] / iters, dd[1] / iters, dd[2] / iters);
+    std::printf("[pivot tiles, cycles per launch] %.0f\n", dd[0] / iters);
+    {
+      double st[14 * 12];
+      HIP_OK(hipMemcpy(st, p.partial + (size_t)15 * 4096 + 64, sizeof(st), hipMemcpyDeviceToHost));
+      const char* names[14] = {"w0 pivot start", "w0 pivot end", "w0 pivotDone set", "w0 at look-ahead wait", "w0 past the wait", "w0 panel solved",
+                              "w0 xReady set", "owner: look-ahead row ready", "w1 load: issued|arrived|stored|barrier", "w5 (row 6) step start", "w5 pivot seen", "w5 panel tile out",
+                              "w5 operands there", "w5 row updated"};
+      std::printf("[stamps of the last launch, cycles from kernel start, per block column]\n");
+      for (int w = 0; w < 14; ++w) {
+        std::printf("  %-28s", names[w]);
+        for (int kb = 0; kb < 11; ++kb) std::printf(" %7.0f", st[w * 12 + kb]);
+        std::printf("\n");
+      }
+    }
 #endif
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -266,8 +266,11 @@ def test_one_id_space_with_caller_chosen_ids(gpu_lib):
     est.optimize(8)
     # (per-frame extrinsics: the pose blocks of the camera system are accumulated with LDS atomics -> run-to-run rounding)
     assert max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f_a, f_ref)) < 1e-9
-    # (b) no provider, caller ids 1..N: without reserve_ids the first internal id collides and add_states refuses
+    # (b) a provider that hands out an id that is already a landmark id: the host's error -- add_states refuses and leaves the
+    # window (frames, state count, pre-integrals) as it was
     est = Estimator(0)
+    bad = Counter()
+    est.set_id_provider(bad.new_id)
     for cam in spec.cameras:
         est.add_camera(cam["model"], cam["intr"], cam["dist"], cam["width"], cam["height"], spec.extr_sigmas)
     est.add_imu(spec.imu_params)
@@ -278,10 +281,17 @@ def test_one_id_space_with_caller_chosen_ids(gpu_lib):
     sel = slice(0, 12)
     with pytest.raises(RuntimeError, match="id"):
         est.add_states(fid, (int(spec.stamps[0, 0]), int(spec.stamps[0, 1])), 400, T_SC, spec.imu_t[sel], spec.imu_meas[sel], True)
-    assert est.num_frames() == 0               # the window is untouched
-    est.reserve_ids(fid)
+    assert est.num_frames() == 0 and est.state_count() == 0
+    # (c) no provider, caller ids 1..N: the built-in counter skips every id that is in use (no reserve_ids needed; it only
+    # saves the skipping)
+    est = Estimator(0)
+    for cam in spec.cameras:
+        est.add_camera(cam["model"], cam["intr"], cam["dist"], cam["width"], cam["height"], spec.extr_sigmas)
+    est.add_imu(spec.imu_params)
+    for l in range(spec.L):
+        assert est.add_landmark(1 + l, spec.lm_init[l])
     assert est.add_states(fid, (int(spec.stamps[0, 0]), int(spec.stamps[0, 1])), 400, T_SC, spec.imu_t[sel], spec.imu_meas[sel], True)
-    assert est.num_frames() == 1
+    assert est.num_frames() == 1 and est.state_count() == 1
     assert est.get_landmark(1)["point"][3] == spec.lm_init[0][3] and est.get_T_WS(fid) is not None
     assert est.new_id() == fid + 4             # 2 extrinsics + 1 speed/bias were drawn above the reservation
     # a frame id that is already a landmark id is the reference's `false` (Map::addParameterBlock refuses it)
