@@ -281,10 +281,14 @@ def window_record(name, spec, device, steps, warmup, iters):
     return rec, est
 
 
+XGMI_LINK_GBS = 153.0   # per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+
+
 def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
     """ONE config-#4 window (64 KF / 50 000 landmarks / 500 000 residuals) with its landmarks split over the ranks: every
-    rank holds all states and its landmark range; per iteration one RCCL all-reduce of [lower triangle of S | g | h] (d (d + 1) / 2 + 3 d doubles) and
-    three small ones of trust-region scalars, all enqueued on the solver's stream (svin_ba_set_distributed_rccl)."""
+    rank holds all states, its landmark range and every world-th small factor; per iteration one RCCL all-reduce of
+    [lower triangle of S | g | h] (d (d + 1) / 2 + 3 d doubles) and two small ones of trust-region scalars, all enqueued on
+    the solver's stream (svin_ba_set_distributed_rccl)."""
     import torch
     from svin_amd import synthetic as syn
     from svin_amd import distributed as sd
@@ -304,14 +308,37 @@ def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per step: the slowest rank
     times = [float(v) for v in t.cpu()]
     d = 64 * 15
+    n_sys = d * (d + 1) // 2 + 3 * d
+    # the collectives on their own (HIP events on the solver's stream): the system message, and the scalar message
+    ar_us = est.bench_allreduce(n_sys, 20)
+    ar_small_us = est.bench_allreduce(24, 50)
+    tt = torch.tensor([ar_us, ar_small_us], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ar_us, ar_small_us = float(tt[0]), float(tt[1])
+    # NCCL's conventions: algorithm bandwidth = bytes / time; bus bandwidth = algbw x 2 (n - 1) / n, the rate every link of a
+    # ring carries -- what the per-link xGMI figure bounds
+    algbw = 8.0 * n_sys / (ar_us * 1e-6) / 1e9
+    busbw = algbw * 2.0 * (world - 1) / world if world > 1 else 0.0
+    # K1 on this rank's share (HBM-resident replicas of its observation set), like the headline roofline object
+    k1_ms, k1_bytes = est.bench_jacobian_eval(16, 10)
+    k1 = torch.tensor([k1_bytes / (k1_ms * 1e-3) / 1e9], dtype=torch.float64, device="cuda")
+    dist.all_reduce(k1, op=dist.ReduceOp.MIN)
+    ms_it = 1e3 * sum(times) / max(sum(its), 1)
     return dict(workload="configs[3]: ONE window, 64 KF / 50000 landmarks / 500000 residuals, landmarks sharded over %d GPUs, "
-                         "optimize(%d) per step" % (world, iters),
-                value=sum(its) / sum(times), unit="GN iterations/s", n_gpus=world, steps=steps, scaling="strong",
-                ms_per_iteration=1e3 * sum(times) / max(sum(its), 1), median_ms_per_step=1e3 * float(np.median(times)),
+                         "small factors dealt frame by frame, optimize(%d) per step" % (world, iters),
+                value=sum(its) / sum(times), unit="GN iterations/s", n_gpus=world, steps=steps, warmup=warmup, scaling="strong",
+                ms_per_iteration=ms_it, median_ms_per_step=1e3 * float(np.median(times)),
                 iterations_per_step=sum(its) / steps, final_cost=last["final_cost"], initial_cost=last["initial_cost"],
                 landmarks_per_rank=mine.L, residuals_per_rank=mine.N,
-                allreduce_bytes_per_iteration=8 * (d * (d + 1) // 2 + 3 * d) + 8 * (8 + 2 + 8),
-                collective="ncclAllReduce (RCCL), FP64 sum, in place, on the solver's HIP stream")
+                allreduce_bytes_per_iteration=8 * n_sys + 8 * (24 + 8),
+                allreduce_us={"system_message": ar_us, "scalar_message": ar_small_us, "per_iteration": ar_us + 2.0 * ar_small_us,
+                              "share_of_iteration": (ar_us + 2.0 * ar_small_us) * 1e-3 / ms_it},
+                allreduce_GBps={"algbw": algbw, "busbw": busbw, "xgmi_link_peak": XGMI_LINK_GBS,
+                                "frac_of_link": busbw / XGMI_LINK_GBS if world > 1 else None},
+                k1_roofline_per_gpu={"achieved": float(k1[0]), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": float(k1[0]) / HBM_PEAK_GBS,
+                                     "note": "slowest rank, 16 HBM-resident replicas of its observation share"},
+                collective="ncclAllReduce (RCCL), FP64 sum, in place, on the solver's HIP stream; 3 per iteration: "
+                           "[lower(S) | g | h], [8 dogleg sums | the ranks' (gradient max, failure flag) pairs], [8 cost / step sums | stop vote]")
 
 
 def main():
@@ -423,7 +450,7 @@ def main():
             done = threading.Event()
 
             def watchdog():
-                if not done.wait(float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "240"))):
+                if not done.wait(float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "300"))):
                     if rank == 0:
                         out["sharded_config4"] = {"error": "timed out (watchdog)"}
                         out.update(extras)
@@ -431,7 +458,7 @@ def main():
                     os._exit(0)
             threading.Thread(target=watchdog, daemon=True).start()
             try:
-                rec = sharded_config4(rank, world, local_rank, dist, 5, 1)
+                rec = sharded_config4(rank, world, local_rank, dist, 20, 3)
             except Exception as ex:
                 rec = {"error": repr(ex)}
             done.set()

@@ -339,6 +339,10 @@ int svin_ba_describe_block(svin_ba* h, uint64_t block_id, uint64_t* frame_id, in
  * milliseconds measured with HIP events on the handle's stream; *bytes_per_launch receives the
  * algorithmic byte count of one launch. */
 int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes_per_launch);
+/* the collective of the sharded solve on its own: `iters` in-place FP64 sum all-reduces of n_doubles values through the
+ * communicator of svin_ba_set_distributed_rccl, on the handle's stream, timed with HIP events (mean microseconds per
+ * all-reduce).  Collective: every rank calls it with the same arguments. */
+int svin_ba_bench_allreduce(svin_ba* h, uint64_t n_doubles, int iters, double* mean_us);
 /* mean wall time (ms) of one reprojection-evaluation launch on the plain window (cache-resident) */
 int svin_ba_bench_kernel_times(svin_ba* h, int iters, double* eval_ms, double* build_ms, double* solve_ms);
 

@@ -509,6 +509,11 @@ int svin_ba_describe_block(svin_ba* h, uint64_t id, uint64_t* frame, int32_t* ki
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.describeBlock(id, frame, kind, index);
 }
+int svin_ba_bench_allreduce(svin_ba* h, uint64_t n_doubles, int iters, double* mean_us) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.benchAllReduce((size_t)n_doubles, iters, mean_us);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);

@@ -277,7 +277,7 @@ __device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, 
   if (t < 4 && t != 3) fields[t == 2 ? 4 : t] = mine;
   if (t == 3) { fields[5] = mine; fields[3] = (p.ownsCamera && p.priorM > 0) ? rec : 0.0; }
   __syncthreads();
-  const double a = fields[0], bf = p.ownsCamera ? fields[1] : 0.0, pr = fields[3];
+  const double a = fields[0], bf = fields[1], pr = fields[3];   // (sharded: this rank's factors -- the sum over ranks follows)
   if (t == 0) rec = a + bf + pr;
   if (t == 1) rec = a;
   if (t == 2) rec = bf;
@@ -1759,14 +1759,13 @@ void launchImuPropagation(const DevImu* im, const uint32_t* T, const double* M, 
 }
 
 void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost) {
-  if (p.F == 0 || !p.ownsCamera) return;
+  if (p.F == 0) return;
   hipLaunchKernelGGL(k_eval_factors, dim3(p.F), dim3(256), 0, s, p, cand ? 1 : 0,
                      sumCost ? (p.N > 0 ? evalGrid(p.N) : 0) : -1);
 }
 // which kernel of evaluateAll sums the cost: 2 = prior evaluation, 1 = factor evaluation, 0 = separate launch
 int costSummedBy(const DeviceProblem& p) {
-  if (!p.ownsCamera) return 0;
-  if (p.priorM > 0) return 2;
+  if (p.priorM > 0) return 2;   // (priorM is zero on the ranks that do not own the prior)
   return p.F > 0 ? 1 : 0;
 }
 
@@ -1886,7 +1885,7 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
 // fused evaluation possible: factors and observations present, camera-owning rank, staging area fits
 bool canFuseEvaluation(const DeviceProblem& p) {
   const size_t stage = (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
-  return p.F > 0 && p.N > 0 && p.ownsCamera && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
+  return p.F > 0 && p.N > 0 && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
 }
 void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s) {
   const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
@@ -3097,7 +3096,7 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
 void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst) {
   const int dC = p.dC;
   if (zeroFirst) launchZeroBuild(p, s);
-  const int nFac = (p.F > 0 && p.ownsCamera) ? p.F : 0;
+  const int nFac = p.F;   // this rank's factors
   const int nPri = priorAccBlocks(p);  // the prior rides along as extra blocks of the same launch
   if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
     const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
@@ -4926,7 +4925,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
    if (staged && stagedOff) landmarkBlock(sYV, sYV + kStageMax, sOff, sOff + kStageBlk);
    else landmarkBlock(p.yC, p.vC, p.poseOff, p.extOff);
   } else if (b < nLmBlocks + nFacBlocks) {
-    if (p.ownsCamera) {
+    {
       // one wave per factor, lane = (row a = lane & 15, column quarter lane >> 4): the row's products with v_C and y_C are
       // split over four lanes (a thread per row walked up to 30 columns of dependent global loads: these blocks were the
       // last to finish), the solution vectors come from the staged copy
@@ -5060,7 +5059,13 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     if (t < kPostK) {
       double* dst = &p.scal->gHatSq;
       if (t < 8) dst[field] = tot;
-      else { p.scal->gradMax = tot; p.scal->failMax = (double)cholFailIn; p.scal->cholFail = 0; }
+      else {
+        p.scal->gradMax = tot; p.scal->failMax = (double)cholFailIn; p.scal->cholFail = 0;
+        if (p.world > 1 || p.rank < 0) {   // sharded: my pair in my slot, zeros elsewhere (the sum all-reduce gathers)
+          const int me = p.rank < 0 ? 0 : p.rank;
+          for (int k = 0; k < kScalGatherSlots / 2; ++k) { p.scal->gather[2 * k] = (k == me) ? tot : 0.0; p.scal->gather[2 * k + 1] = (k == me) ? (double)cholFailIn : 0.0; }
+        }
+      }
     }
     for (int i = t; i < p.d; i += blockDim.x) p.gFull[i] = 0.0;
     if (t == 0) p.tickets[TK_POST] = 0;

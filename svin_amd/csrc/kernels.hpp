@@ -85,9 +85,12 @@ struct SolverScalars {
   double jvDotJy;         // (J v).(J y)
   double jvDotR;          // (J v).r
   double jyDotR;          // (J y).r
-  // --- 2 max-reduced scalars
+  // --- sharded mode: every rank's (gradMax, failMax) pair in its own slot, the other slots zero, so that the SUM all-reduce
+  // of [group B | gather] in ONE message gathers them and the host takes the max (a max all-reduce of its own before)
+  double gather[16];
+  // --- 2 max-reduced scalars (one GPU: written directly; sharded: the host fills them from `gather`)
   double gradMax;         // max |g_full|
-  double failMax;         // (double)cholFail, for the max all-reduce
+  double failMax;         // (double)cholFail
   // --- derived on the device from the (all-reduced) sums and the trust-region radius
   double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
   double doglegStepNorm;
@@ -99,13 +102,15 @@ struct ScalarMailbox {
   SolverScalars scal;
   unsigned long long seq;
 };
-constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGroupMax = 16;  // offsets (doubles) of the all-reduced groups
+constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGather = 16, kScalGatherSlots = 16;  // offsets (doubles) of the all-reduced groups
 
 struct DeviceProblem {
   // sizes
   int nPose, nExt, nSb, L, N, F, nImu, d, dC, priorM, priorBlocks, nCam;
   int anyExtVariable;
-  int ownsCamera;   // landmark-sharded mode: only one rank accumulates the non-landmark factors / camera-side norms
+  int ownsCamera;   // landmark-sharded mode: only one rank takes the marginalisation prior and the camera-side norms (the small
+                    // factors are dealt to the ranks frame by frame at pack() time: each rank's F counts its own)
+  int rank, world;  // sharded mode (0, 1 otherwise)
   // tables
   double *pose, *ext, *sb, *lm;
   double *poseC, *extC, *sbC, *lmC;

@@ -1,6 +1,7 @@
 // svin_amd host core (see window.hpp).  Reference line numbers cite
 // /root/reference/okvis_ros/okvis/okvis_ceres/src/Estimator.cpp unless another file is named.
 #include "window.hpp"
+#include "trust_region.hpp"
 #include <atomic>
 #include <cstdint>
 #include <algorithm>
@@ -915,8 +916,12 @@ void Window::pack() {
     kind = b.kind;
     slot = (b.kind == B_POSE) ? poseSlot_.at(id) : (b.kind == B_EXT ? extSlot_.at(id) : sbSlot_.at(id));
   };
+  // sharded mode: the small factors are dealt to the ranks frame by frame (factors are created in frame order: IMU factor
+  // k -> k+1, the priors of a frame, its relative-extrinsics and sonar / depth terms); every rank still holds all states
+  int factorOrdinal = 0;
   for (auto& kv : factors_) {
     Factor& f = kv.second;
+    if (!ownsFactorOrdinal(factorOrdinal++)) continue;
     DevFactor df;
     std::memset(&df, 0, sizeof(df));
     df.kind = f.kind; df.nblk = f.nblk; df.m = f.m; df.imuIndex = -1;
@@ -1090,6 +1095,9 @@ void Window::pack() {
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
   p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;
+  p.rank = (world_ <= 1 && rcclComm_ && getenv("SVIN_FORCE_DISTRIBUTED")) ? -1 : rank_;   // -1: one-rank communicator exercising the sharded path
+  p.world = world_;
+  if (!p.ownsCamera) p.priorM = 0;   // the prior is evaluated and accumulated on one rank only
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
   p.obsOrder = orderObs ? dObsOrder_.p : nullptr;
   p.dCPose = dCPose;
@@ -1205,8 +1213,10 @@ void Window::downloadStates() {
   for (auto& kv : landmarks_)
     if (kv.second.obs.empty()) kv.second.quality = 0.0;
   int k = 0;
-  for (auto& kv : factors_)
-    if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+  for (uint64_t fid : factorIds_) {   // the factors this rank packed, in pack() order
+    Factor& f = factors_.at(fid);
+    if (f.kind == F_IMU) f.imu = hImu[k++];
+  }
 }
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
@@ -1275,7 +1285,7 @@ void Window::solve(size_t numIter, bool verbose) {
   auto publish = [&]() {
     if (distNative_ && mailbox_) launchPublishScalars(p.scal, mailboxDev_, mailboxSeq_, s);
   };
-  double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..17] max group
+  double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..31] the ranks' (gradMax, failMax) pairs
   // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
   // retracts the whole window quickly enough
   static const bool noFuseStep = getenv("SVIN_NO_FUSE_STEP") != nullptr;   // A/B switch for profiling
@@ -1287,14 +1297,11 @@ void Window::solve(size_t numIter, bool verbose) {
   AR(scalD, 4, 0);
   publish();
   SolverScalars sc = readScalars();
-  double x_cost = sc.cost;
-  summary_.initial_cost = x_cost;
-  double radius = 1e4;
-  const double min_mu = 1e-8, max_mu = 1.0, mu_increase = 10.0;
-  double mu = min_mu;
-  bool reuse = false, initScale = true;
-  int invalid = 0;
-  int iteration = 0;
+  TrustRegionHost tr;   // every decision of the loop (trust_region.hpp: HIP-free, replayed on the CPU by the tests)
+  tr.fTol = fTol_; tr.gTol = gTol_; tr.pTol = pTol_;
+  tr.maxIterations = (int)numIter;
+  tr.start(sc.cost);
+  summary_.initial_cost = sc.cost;
   double lastIterTime = 0;
   double stopVotes = 0.0;   // sharded mode: number of ranks whose clock asked to stop (identical on every rank)
   auto swapSets = [&]() {
@@ -1303,10 +1310,15 @@ void Window::solve(size_t numIter, bool verbose) {
     std::swap(p.linCur, p.linCand);
     std::swap(p.priorDchi, p.priorDchiC); std::swap(p.priorGrad, p.priorGradC); std::swap(p.priorM3, p.priorM3C);
   };
-  auto finish = [&](int term) {
-    summary_.termination = term;
-    summary_.final_cost = x_cost;
-    summary_.iterations = iteration;
+  auto toTr = [&](const SolverScalars& r) {
+    TrScalars t;
+    t.cost = r.cost; t.stepNormSq = r.stepNormSq; t.xNormSq = r.xNormSq; t.gradMax = r.gradMax; t.failMax = r.failMax;
+    t.jdSq = r.jdSq; t.jdDotR = r.jdDotR; t.doglegStepNorm = r.doglegStepNorm;
+    if (dist) {   // every rank's (gradMax, failMax) pair was gathered by the sum all-reduce of [group B | gather]
+      t.gradMax = 0.0; t.failMax = 0.0;
+      for (int k = 0; k < kScalGatherSlots / 2; ++k) { t.gradMax = std::max(t.gradMax, r.gather[2 * k]); t.failMax = std::max(t.failMax, r.gather[2 * k + 1]); }
+    }
+    return t;
   };
   // Speculative build (single GPU): most steps are accepted, and the host needs ~7 us from the mailbox to the first
   // launch of the next iteration.  Right behind the candidate evaluation the normal equations of the NEXT iteration
@@ -1321,97 +1333,64 @@ void Window::solve(size_t numIter, bool verbose) {
     // the time-limit callback (CeresIterationCallback.hpp:80-94).  One GPU: this rank's clock.  Sharded: a rank that left
     // the loop on its own clock would leave the others blocked in the next all-reduce, so the ranks vote (below, with the
     // evaluation's all-reduce) and stop on the common result
-    if (!dist && timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) { finish(2); break; }
-    if (dist && stopVotes > 0.0) { finish(2); break; }
-    if (iteration >= (int)numIter) { finish(1); break; }
-    if (radius <= 1e-32) { finish(0); break; }
+    const bool stop = dist ? stopVotes > 0.0
+                           : (timeLimit_ >= 0.0 && tr.iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_);
+    if (!tr.beginIteration(stop)) break;
     const double tIter = nowSec();
-    ++iteration;
-    bool stepOk = true;
     while (true) {
-      if (!reuse) {
-        if (!(specValid && specMu == mu && !initScale))
-          launchAccumulateNormalEquations(p, mu, initScale, s, /*zeroFirst=*/!accumulatorsClean);  // pack() / k_post_solve cleared them
+      if (!tr.reuse) {
+        if (!(specValid && specMu == tr.mu && !tr.initScale))
+          launchAccumulateNormalEquations(p, tr.mu, tr.initScale, s, /*zeroFirst=*/!accumulatorsClean);  // pack() / k_post_solve cleared them
         specValid = false;
         if (dist && p.d > 0) {   // one message: lower triangle of S + gRed + gFull + hC (half of what the full matrix would be)
           launchPackSystem(p, /*unpack=*/false, s);
           AR(p.cholL, packedSystemDoubles(p), 0);
           launchPackSystem(p, /*unpack=*/true, s);
         }
-        launchSolveReduced(p, s, mu, initScale, /*fuseFinalize=*/true);
+        launchSolveReduced(p, s, tr.mu, tr.initScale, /*fuseFinalize=*/true);
         p.lmDeferred = deferLm ? 1 : 0;
-        launchDoglegPrepare(p, s, fuseStep ? radius : -1.0);
+        launchDoglegPrepare(p, s, fuseStep ? tr.radius : -1.0);
         accumulatorsClean = true;
-        AR(scalD + kScalGroupB, 8, 0);
-        AR(scalD + kScalGroupMax, 2, 1);
+        AR(scalD + kScalGroupB, 8 + kScalGatherSlots, 0);   // group B and every rank's (gradMax, failMax) pair: one message
       }
-      if (reuse || !fuseStep) launchDoglegStep(p, radius, s);
-      p.lmDeferred = (deferLm && !reuse) ? 1 : 0;
+      if (tr.reuse || !fuseStep) launchDoglegStep(p, tr.radius, s);
+      p.lmDeferred = (deferLm && !tr.reuse) ? 1 : 0;
       evaluateAll(true, s);
       p.lmDeferred = 0;
-      if (speculate && accumulatorsClean && iteration < (int)numIter) {
+      if (speculate && accumulatorsClean && tr.iteration < (int)numIter) {
         DeviceProblem q = p;   // the problem as it looks after an accepted step
         std::swap(q.pose, q.poseC); std::swap(q.ext, q.extC); std::swap(q.sb, q.sbC); std::swap(q.lm, q.lmC);
         std::swap(q.rCur, q.rCand); std::swap(q.JpCur, q.JpCand); std::swap(q.JlCur, q.JlCand); std::swap(q.JeCur, q.JeCand);
         std::swap(q.linCur, q.linCand);
         std::swap(q.priorDchi, q.priorDchiC); std::swap(q.priorGrad, q.priorGradC); std::swap(q.priorM3, q.priorM3C);
-        specMu = std::max(min_mu, 2.0 * mu / mu_increase);
+        specMu = tr.muAfterAccept();
         launchAccumulateNormalEquations(q, specMu, false, s, /*zeroFirst=*/false);
         accumulatorsClean = false;
         specValid = true;
       }
       if (dist)   // this iteration will be complete when the vote is read: `iteration` already counts it
-        launchSetStopVote(p.scal, (timeLimit_ >= 0.0 && iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) ? 1.0 : 0.0, s);
+        launchSetStopVote(p.scal, (timeLimit_ >= 0.0 && tr.iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) ? 1.0 : 0.0, s);
       AR(scalD, 8, 0);
       publish();
       sc = readScalars();
       if (dist) stopVotes = sc.spareA0;
-      sc.cholFail = sc.failMax != 0.0 ? 1 : 0;  // the device flag itself is re-armed by k_post_solve
-      if (!reuse && sc.cholFail) {
-        specValid = false;   // (its damping assumed an accepted step)
-        mu *= mu_increase;
-        if (mu < max_mu) continue;
-        stepOk = false;
-      }
+      if (tr.retryFactorisation(toTr(sc))) { specValid = false; continue; }   // (the speculative damping assumed an accepted step)
       break;
     }
-    if (!reuse) { initScale = false; reuse = true; }
-    if (sc.gradMax <= gTol_) { --iteration; finish(0); break; }
-    const double model_cost_change = -(sc.jdDotR + 0.5 * sc.jdSq);
-    if (!stepOk || !(model_cost_change > 0.0)) {
-      if (++invalid >= 5) { finish(3); break; }
-      mu *= mu_increase;
-      reuse = false;
-      specValid = false;
-      lastIterTime = nowSec() - tIter;
-      continue;
-    }
-    invalid = 0;
-    const double step_norm = std::sqrt(sc.stepNormSq), x_norm = std::sqrt(sc.xNormSq);
-    if (step_norm <= pTol_ * (x_norm + pTol_)) { finish(0); break; }
-    const double candidate_cost = sc.cost;
-    const double cost_change = x_cost - candidate_cost;
-    if (std::fabs(cost_change) <= fTol_ * x_cost) { finish(0); break; }
-    const double relative_decrease = cost_change / model_cost_change;
-    if (relative_decrease > 1e-3) {
-      swapSets();
-      x_cost = candidate_cost;
-      summary_.num_successful_steps++;
-      if (relative_decrease < 0.25) radius *= 0.5;
-      if (relative_decrease > 0.75) radius = std::max(radius, 3.0 * sc.doglegStepNorm);
-      radius = std::min(radius, 1e16);
-      mu = std::max(min_mu, 2.0 * mu / mu_increase);
-      reuse = false;
-    } else {
-      radius *= 0.5;
-      reuse = true;
-      specValid = false;   // rejected: the speculative build is discarded (accumulators are re-zeroed before the next one)
-    }
+    const TrustRegionHost::Outcome o = tr.endIteration(toTr(sc));
+    if (o == TrustRegionHost::kTerminated) break;
+    if (o == TrustRegionHost::kInvalid) { specValid = false; lastIterTime = nowSec() - tIter; continue; }
+    if (o == TrustRegionHost::kAccepted) swapSets();
+    else specValid = false;   // rejected: the speculative build is discarded (accumulators are re-zeroed before the next one)
     if (verbose)
-      std::printf("[svin_ba] it %d cost %.9e rel_dec %.3e radius %.3e step %.3e\n", iteration, x_cost, relative_decrease,
-                  radius, step_norm);
+      std::printf("[svin_ba] it %d cost %.9e rel_dec %.3e radius %.3e step %.3e\n", tr.iteration, tr.x_cost, tr.relative_decrease,
+                  tr.radius, tr.last_step_norm);
     lastIterTime = nowSec() - tIter;
   }
+  summary_.termination = tr.termination;
+  summary_.final_cost = tr.x_cost;
+  summary_.iterations = tr.iteration;
+  summary_.num_successful_steps = tr.successful;
   summary_.total_time = nowSec() - tStart;
   distNative_ = false;
 }
@@ -1520,12 +1499,14 @@ int Window::evalFactors(int32_t* kind, int32_t* m, int32_t* ncols, double* r, do
   HIP_OK(hipStreamSynchronize(stream_));
   // evaluation may re-preintegrate: keep the state, exactly like ImuError's mutable members
   int k = 0;
-  for (auto& kv : factors_)
-    if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+  for (uint64_t fid : factorIds_) {
+    Factor& f = factors_.at(fid);
+    if (f.kind == F_IMU) f.imu = hImu[k++];
+  }
   int i = 0;
-  for (auto& kv : factors_) {
+  for (uint64_t fid : factorIds_) {
     if (i >= cap) break;
-    const Factor& f = kv.second;
+    const Factor& f = factors_.at(fid);
     if (kind) kind[i] = f.kind;
     if (rids) rids[i] = f.id;
     if (m) m[i] = h[i].m;
@@ -1559,8 +1540,10 @@ int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32
   if (p.nImu > 0) {
     HIP_OK(hipMemcpy(hImu.data(), p.imus, sizeof(DevImu) * p.nImu, hipMemcpyDeviceToHost));
     int k = 0;
-    for (auto& kv : factors_)
-      if (kv.second.kind == F_IMU) kv.second.imu = hImu[k++];
+    for (uint64_t fid : factorIds_) {
+      Factor& f = factors_.at(fid);
+      if (f.kind == F_IMU) f.imu = hImu[k++];
+    }
   }
   return p.d;
 }
@@ -1658,6 +1641,31 @@ void debugImuTiming(double* out, bool reset);
 #ifdef SVIN_CHOL_TIMING
 void debugCholTiming(double* out, bool reset);
 #endif
+// the collective of the sharded solve, stand-alone: `iters` in-place sum all-reduces of nDoubles FP64 values on the solver's
+// stream between two HIP events (the communicator svin_ba_set_distributed_rccl created; collective: every rank calls it)
+int Window::benchAllReduce(size_t nDoubles, int iters, double* meanUs) {
+  if (!rcclComm_) { lastError() = "benchAllReduce: no RCCL communicator (svin_ba_set_distributed_rccl first)"; return -1; }
+  if (nDoubles == 0 || iters <= 0) return -1;
+  HIP_OK(hipSetDevice(device_));
+  DevBuf<double> buf;
+  buf.reserve(nDoubles);
+  HIP_OK(hipMemsetAsync(buf.p, 0, sizeof(double) * nDoubles, stream_));
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w)
+    rcclCheck(rccl().allReduce(buf.p, buf.p, nDoubles, ncclDouble, ncclSum, static_cast<ncclComm_t>(rcclComm_), stream_), "ncclAllReduce");
+  HIP_OK(hipEventRecord(e0, stream_));
+  for (int i = 0; i < iters; ++i)
+    rcclCheck(rccl().allReduce(buf.p, buf.p, nDoubles, ncclDouble, ncclSum, static_cast<ncclComm_t>(rcclComm_), stream_), "ncclAllReduce");
+  HIP_OK(hipEventRecord(e1, stream_));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (meanUs) *meanUs = 1e3 * (double)ms / iters;
+  return 1;
+}
+
 int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs) {
   pack();
 #ifdef SVIN_IMU_TIMING

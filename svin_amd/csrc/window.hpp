@@ -206,6 +206,7 @@ class Window {
   typedef int (*AllReduceFn)(void* ptr, uint64_t count, int op, void* user);
   void setDistributed(int rank, int world, AllReduceFn fn, void* user);
   void dropRcclComm();
+  bool ownsFactorOrdinal(int ordinal) const { return world_ <= 1 || ordinal % world_ == rank_; }
   // the same with RCCL called natively on the handle's stream (no host synchronisation, no callback): `id` is the
   // 128-byte ncclUniqueId rank 0 obtained from rcclUniqueId() and the host distributed to every rank
   static int rcclUniqueId(unsigned char* out128);
@@ -226,6 +227,7 @@ class Window {
   int getParameterBlock(uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed, int32_t* initialized) const;
   void parameterBlockIds(std::vector<uint64_t>& out) const;
   int benchJacobianEval(int copies, int iters, double* meanMs, double* bytes);
+  int benchAllReduce(size_t nDoubles, int iters, double* meanUs);   // native RCCL all-reduce on the solver stream, HIP events
   int benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs);
 
  private:

@@ -69,7 +69,7 @@ EXPORTS = [
     "svin_host_pose_information", "svin_host_pose_error", "svin_host_manifold_dims", "svin_host_manifold_plus",
     "svin_host_manifold_minus", "svin_host_manifold_plus_jacobian", "svin_host_manifold_lift_jacobian",
     "svin_host_manifold_minus_jacobian", "svin_ba_get_parameter_block", "svin_ba_parameter_block_ids",
-    "svin_ba_get_all_landmark_observations",
+    "svin_ba_get_all_landmark_observations", "svin_ba_bench_allreduce",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -190,6 +190,7 @@ def load_library():
         sig("svin_host_manifold_" + name, i32, i32, pd, pd)
     sig("svin_ba_get_parameter_block", i32, vp, u64, pi32, pd, C.POINTER(u32), C.POINTER(u32), pi32, pi32)
     sig("svin_ba_parameter_block_ids", i32, vp, pu64, i32)
+    sig("svin_ba_bench_allreduce", i32, vp, u64, i32, pd)
     sig("svin_ba_get_all_landmark_observations", i32, vp, i32, pu64, C.POINTER(LandmarkInfo), pi32, i32, pu64, pu64, pu64, pu64, pi32)
     _LIB = L
     return L
@@ -724,6 +725,12 @@ class Estimator:
         ms, by = np.zeros(1), np.zeros(1)
         self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
         return float(ms[0]), float(by[0])
+
+    def bench_allreduce(self, n_doubles, iters=20):
+        """mean microseconds of one native RCCL all-reduce of n_doubles FP64 values on the solver stream (collective call)"""
+        us = np.zeros(1)
+        self._check(self.L.svin_ba_bench_allreduce(self.h, int(n_doubles), int(iters), _d(us)), "bench_allreduce")
+        return float(us[0])
 
     def bench_kernel_times(self, iters):
         a, b, c = np.zeros(1), np.zeros(1), np.zeros(1)

@@ -710,6 +710,37 @@ def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
     assert est.summary()["iterations"] == ref.summary()["iterations"] and worst < 1e-8, worst
 
 
+def test_native_rccl_path_full_config4_size(gpu_lib, monkeypatch):
+    """BASELINE configs[3] at its full size (64 KF / 50 000 landmarks / 500 000 residuals, d = 960) through the sharded
+    code path with a one-rank RCCL communicator (packed lower-triangle message, [group B | gathered maxima] message, stop
+    vote, scalars published after the reduction): same iterates as the plain single-GPU solve.  Then the time-limit
+    callback in sharded mode: the ranks stop on the all-reduced vote (termination 2 = USER_SUCCESS), after the minimum
+    number of iterations."""
+    from svin_amd.estimator import Estimator, rccl_unique_id
+    spec = syn.make_window(P=64, L=50000, n_obs=500000, seed=20250629, frame_dt=0.25)
+    ref = Estimator(0)
+    f_ref, _ = syn.feed(ref, spec)
+    ref.optimize(3)
+    est = Estimator(0)
+    f, _ = syn.feed(est, spec)
+    est.set_distributed_rccl(0, 1, rccl_unique_id())
+    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    est.optimize(3)
+    s, s_ref = est.summary(), ref.summary()
+    worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
+    log("native RCCL, one rank, config #4 full size: summary", s, "reference", s_ref, "pose diff", worst)
+    assert s["iterations"] == s_ref["iterations"] == 3 and s["successful"] == s_ref["successful"]
+    assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"] and worst < 1e-8
+    us = est.bench_allreduce(960 * 961 // 2 + 3 * 960, 5)
+    assert 0.0 < us < 1e5
+    # time limit: a limit that is already over when the first iteration ends -> stop after min_iterations = 2
+    assert est.set_time_limit(1e-6, 2)
+    est.optimize(10)
+    s = est.summary()
+    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    assert s["termination"] == 2 and 2 <= s["iterations"] <= 3, s
+
+
 def drop_underdetermined_landmarks(spec):
     """removes the observations of landmarks seen fewer than three times: with mu = 0 their 3x3 block is singular or
     nearly so, and a linearisation compared at 1e-9 needs every landmark block to be invertible without damping"""
