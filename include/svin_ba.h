@@ -331,6 +331,17 @@ int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* blo
 /* marginalisation prior: returns its dimension m; H (m x m), b0 (m), J (m x m), e0 (m) may be NULL */
 int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* block_ids,
                       int32_t* block_ordering, int32_t* block_mdim, int32_t* n_blocks, int cap_m);
+/* the linear system of the last svin_ba_apply_marginalization_strategy AFTER MarginalizationError::addResidualBlock (M1,
+ * src/MarginalizationError.cpp:126-397) and BEFORE marginalizeOut, kept only when SVIN_MARG_KEEP_PRE is set in the
+ * environment (inspection: lets a test arbitrate M1 and M2 / M3 separately): H = [U W; W^T blockdiag(V)], b = [ba; bb] with
+ * U m x m (dense blocks, old prior first), W m x 3 n_landmarks, V 3x3 per landmark; marg_rows[i] = 1 for the dense rows that
+ * are marginalised.  *m / *n_landmarks always receive the sizes; returns 1 when the arrays were filled (capacities suffice). */
+int svin_ba_get_marg_pre(svin_ba* h, int32_t* m, int32_t* n_landmarks, double* U, double* ba, double* W, double* V,
+                         double* bb, int32_t* marg_rows, int cap_m, int cap_landmarks);
+/* ... and its ordering: the dense blocks (id, first row, number of rows; 0 rows = a fixed block) and the landmark ids in the
+ * order of their 3x3 blocks.  Returns the number of dense blocks. */
+int svin_ba_get_marg_pre_blocks(svin_ba* h, uint64_t* dense_ids, int32_t* dense_ord, int32_t* dense_mdim, int cap_dense,
+                                uint64_t* landmark_ids, int cap_landmarks);
 /* semantic description of an internal parameter-block id: kind 0 pose / 1 extrinsics / 2 speed-bias */
 int svin_ba_describe_block(svin_ba* h, uint64_t block_id, uint64_t* frame_id, int32_t* kind, int32_t* index);
 

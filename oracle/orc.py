@@ -139,6 +139,9 @@ def _bind(L):
     sig("orc_project", i32, i32, pd, pd, i32, i32, pd, pd, pd)
     sig("orc_project_homogeneous", i32, i32, pd, pd, i32, i32, pd, pd, pd)
     sig("orc_distort", i32, i32, pd, pd, pd, pd)
+    sig("orc_marg_pre_blocks", i32, vp, pu64, pi32, pi32, pi32, pd, i32, pi32)
+    sig("orc_marg_log_count", i32, vp)
+    sig("orc_marg_log_entry", i32, vp, i32, pu64, pi32, pi32, pd, pu64, pi32, pd, i32)
     sig("orc_manifold_plus", None, i32, pd, pd, pd)
     sig("orc_manifold_minus", None, i32, pd, pd, pd)
     sig("orc_manifold_plus_jacobian", None, i32, pd, pd)
@@ -408,6 +411,12 @@ class OracleEstimator:
         self.L.orc_landmark_ids(self.h, u64ptr(ids), len(ids))
         return [int(i) for i in ids[:n]]
 
+    def is_keyframe(self, fid):
+        return bool(self.L.orc_is_keyframe(self.h, fid))
+
+    def is_in_imu_window(self, fid):
+        return bool(self.L.orc_is_in_imu_window(self.h, fid))
+
     def num_frames(self):
         return int(self.L.orc_num_frames(self.h))
 
@@ -458,6 +467,24 @@ class OracleEstimator:
         rg = rg.reshape(-1, 2)
         return dict(n=n, H=H, b0=b0, lm=[tuple(int(v) for v in r) for r in rg[:nl.value]],
                     dense=[tuple(int(v) for v in r) for r in rg[nl.value:]])
+
+    def marg_m1_log(self):
+        """what M1 linearised in the last applyMarginalization (definitions only) + the blocks with ordering / linearisation points:
+        dict(blocks=[dict(id, ordering, mdim, type, lin)], had_prior, log=[dict(res_id, kind, loss, loss_param, ids, defn)])"""
+        n = self.L.orc_marg_pre_blocks(self.h, None, None, None, None, None, 0, None)
+        ids, od, md, ty, lin, hp = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), \
+            np.zeros(max(n, 1), np.int32), np.zeros((max(n, 1), 9)), C.c_int32()
+        self.L.orc_marg_pre_blocks(self.h, u64ptr(ids), i32ptr(od), i32ptr(md), i32ptr(ty), dptr(lin), n, C.byref(hp))
+        blocks = [dict(id=int(ids[i]), ordering=int(od[i]), mdim=int(md[i]), type=int(ty[i]), lin=lin[i].copy()) for i in range(n)]
+        log = []
+        for i in range(self.L.orc_marg_log_count(self.h)):
+            rid, kind, loss, lp, ids4, nid = C.c_uint64(), C.c_int32(), C.c_int32(), np.zeros(1), np.zeros(4, np.uint64), C.c_int32()
+            nd = self.L.orc_marg_log_entry(self.h, i, C.byref(rid), C.byref(kind), C.byref(loss), dptr(lp), u64ptr(ids4), C.byref(nid), None, 0)
+            defn = np.zeros(max(nd, 1))
+            self.L.orc_marg_log_entry(self.h, i, None, None, None, None, None, None, dptr(defn), nd)
+            log.append(dict(res_id=int(rid.value), kind=int(kind.value), loss=int(loss.value), loss_param=float(lp[0]),
+                            ids=[int(v) for v in ids4[:nid.value]], defn=defn[:nd].copy()))
+        return dict(blocks=blocks, had_prior=bool(hp.value), log=log)
 
     def keyframe_points(self, frame_id, cam=0):
         p64 = C.POINTER(C.c_uint64)

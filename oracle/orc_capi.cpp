@@ -188,6 +188,45 @@ int orc_marg_pre(void* h, double* H, double* b0, int* nLm, int* nDense, int* ran
   }
   return p.n;
 }
+// test hook (orc_marg.hpp PreMarg): the blocks as M1 left them -- id, first row, minimal dimension, type (0 pose, 1 speed/bias,
+// 2 landmark), linearisation point (9 doubles) -- and the residuals M1 linearised since the previous marginalizeOut
+int orc_marg_pre_blocks(void* h, uint64_t* ids, int* ordering, int* mdim, int* type, double* lin9, int cap, int* hadPrior) {
+  auto m = static_cast<Estimator*>(h)->marginalizationError();
+  if (!m) return 0;
+  const auto& p = m->preMarg();
+  if (hadPrior) *hadPrior = p.hadPrior ? 1 : 0;
+  int n = 0;
+  for (auto& inf : p.infos) {
+    if (n < cap) {
+      if (ids) ids[n] = inf.id;
+      if (ordering) ordering[n] = inf.orderingIdx;
+      if (mdim) mdim[n] = inf.mdim;
+      if (type) type[n] = inf.type;
+      if (lin9) std::memcpy(lin9 + 9 * n, inf.lin, sizeof(double) * 9);
+    }
+    ++n;
+  }
+  return n;
+}
+int orc_marg_log_count(void* h) {
+  auto m = static_cast<Estimator*>(h)->marginalizationError();
+  return m ? (int)m->preMarg().log.size() : 0;
+}
+// entry i: returns the length of its definition vector (written to def when cap suffices); ids4: its parameter blocks
+int orc_marg_log_entry(void* h, int i, uint64_t* resId, int* kind, int* loss, double* lossParam, uint64_t* ids4, int* nIds, double* def,
+                       int cap) {
+  auto m = static_cast<Estimator*>(h)->marginalizationError();
+  if (!m || i < 0 || i >= (int)m->preMarg().log.size()) return -1;
+  const auto& e = m->preMarg().log[i];
+  if (resId) *resId = e.resId;
+  if (kind) *kind = e.kind;
+  if (loss) *loss = e.loss;
+  if (lossParam) *lossParam = e.lossParam;
+  if (nIds) *nIds = (int)e.ids.size();
+  if (ids4) for (size_t k = 0; k < e.ids.size() && k < 4; ++k) ids4[k] = e.ids[k];
+  if (def && (int)e.def.size() <= cap) std::memcpy(def, e.def.data(), sizeof(double) * e.def.size());
+  return (int)e.def.size();
+}
 // per connected block: id, orderingIdx, mdim ; returns number of blocks
 int orc_marg_blocks(void* h, uint64_t* ids, int* ordering, int* mdim, double* lin9, int cap) {
   auto m = static_cast<Estimator*>(h)->marginalizationError();

@@ -34,6 +34,37 @@ bool MarginalizationError::addResidualBlock(uint64_t resId, bool keep) {
   if (!map_->residualExists(resId)) return false;
   const ResidualBlock rb = map_->residual(resId);  // copy (we may remove it)
   valid_ = false;
+  {   // test hook: what was linearised (definition only, see orc_marg.hpp M1Entry)
+    M1Entry e;
+    e.resId = resId; e.kind = (int)rb.err->kind(); e.loss = rb.loss; e.lossParam = rb.lossParam; e.ids = rb.params;
+    std::vector<double>& d = e.def;
+    if (auto* r = dynamic_cast<const ReprojectionError*>(rb.err.get())) {
+      d = {r->z[0], r->z[1], r->sqrtInfo[0], r->sqrtInfo[1], r->sqrtInfo[2], r->sqrtInfo[3], (double)r->camIdx, (double)r->cam.model,
+           r->cam.fu, r->cam.fv, r->cam.cu, r->cam.cv};
+      d.insert(d.end(), r->cam.k, r->cam.k + 8);
+    } else if (auto* im = dynamic_cast<const ImuError*>(rb.err.get())) {
+      d = {(double)im->t0.sec, (double)im->t0.nsec, (double)im->t1.sec, (double)im->t1.nsec, im->redo ? 1.0 : 0.0};
+      d.insert(d.end(), im->sb_ref, im->sb_ref + 9);
+      const ImuParameters& q = im->par;
+      const double pv[10] = {q.a_max, q.g_max, q.sigma_g_c, q.sigma_a_c, q.sigma_bg, q.sigma_ba, q.sigma_gw_c, q.sigma_aw_c, q.tau, q.g};
+      d.insert(d.end(), pv, pv + 10);
+      d.push_back((double)im->meas.size());
+      for (const ImuSample& sm : im->meas) {
+        d.push_back((double)sm.t.sec); d.push_back((double)sm.t.nsec);
+        d.insert(d.end(), sm.gyr, sm.gyr + 3);
+        d.insert(d.end(), sm.acc, sm.acc + 3);
+      }
+    } else if (auto* pe = dynamic_cast<const PoseError*>(rb.err.get())) {
+      d.assign(pe->meas.p, pe->meas.p + 7);
+      d.insert(d.end(), pe->sqrtInfo, pe->sqrtInfo + 36);
+    } else if (auto* se = dynamic_cast<const SpeedAndBiasError*>(rb.err.get())) {
+      d.assign(se->meas, se->meas + 9);
+      d.insert(d.end(), se->sqrtInfo, se->sqrtInfo + 81);
+    } else if (auto* re = dynamic_cast<const RelativePoseError*>(rb.err.get())) {
+      d.assign(re->sqrtInfo, re->sqrtInfo + 36);
+    }
+    m1log_.push_back(std::move(e));
+  }
   const int nb = (int)rb.params.size();
   // :139-228 book-keeping
   for (int i = 0; i < nb; ++i) {
@@ -163,6 +194,7 @@ bool MarginalizationError::marginalizeOut(const std::vector<uint64_t>& idsIn) {
   std::sort(pairsDense.begin(), pairsDense.end(), byFirst);
   valid_ = false;
   pre_.n = n_; pre_.H = H_; pre_.b0 = b0_; pre_.lm = pairsLm; pre_.dense = pairsDense;   // test hook, see orc_marg.hpp
+  pre_.infos = infos_; pre_.log.swap(m1log_); m1log_.clear(); pre_.hadPrior = logStartedWithPrior_; logStartedWithPrior_ = true;
 
   // ---- landmark part (:557-619)
   if (!pairsLm.empty()) {

@@ -42,10 +42,24 @@ class MarginalizationError : public ErrorTerm {
   // test hook: the system as it stood when the last marginalizeOut() began (after M1, before M2), the marginalised index
   // ranges (first row, size) of the landmark and of the dense part, both in THAT ordering -- lets an independent
   // high-precision restatement of M2 / M3 arbitrate between two double-precision implementations
+  // M1Entry: one addResidualBlock call since the previous marginalizeOut -- WHICH residual was linearised (kind, loss, its
+  // parameter blocks) and its DEFINITION (measurement, weights, for an IMU factor the samples and the bias its
+  // pre-integration currently refers to).  No number the oracle computed from them: tests/mp_m1.py evaluates residual,
+  // Jacobians and corrector again from these definitions at 40 digits.
+  struct M1Entry {
+    uint64_t resId = 0;
+    int kind = 0, loss = 0;
+    double lossParam = 0;
+    std::vector<uint64_t> ids;
+    std::vector<double> def;
+  };
   struct PreMarg {
     int n = 0;
     std::vector<double> H, b0;
     std::vector<std::pair<int, int>> lm, dense;
+    std::vector<Info> infos;      // the blocks with their ordering and linearisation points, as M1 left them
+    std::vector<M1Entry> log;     // the residuals M1 took in since the previous marginalizeOut
+    bool hadPrior = false;        // a previous prior (H, b0) was already in the system when the log starts
   };
   const PreMarg& preMarg() const { return pre_; }
 
@@ -60,6 +74,8 @@ class MarginalizationError : public ErrorTerm {
   bool valid_ = false;
   std::vector<double> J_, e0_;
   PreMarg pre_;
+  std::vector<M1Entry> m1log_;
+  bool logStartedWithPrior_ = false;
 };
 
 // helpers shared with tests: pseudo-inverse square root of a symmetric PSD matrix

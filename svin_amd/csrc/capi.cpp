@@ -505,6 +505,34 @@ int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, 
   GUARD_BEGIN return h->w.getPrior(H, b0, J, e0, ids, ord, mdim, nb, cap_m);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_get_marg_pre(svin_ba* h, int32_t* m, int32_t* n_landmarks, double* U, double* ba, double* W, double* V, double* bb,
+                         int32_t* marg_rows, int cap_m, int cap_landmarks) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  const auto& q = h->w.margPre();
+  if (m) *m = q.m;
+  if (n_landmarks) *n_landmarks = q.Lm;
+  if (q.m > cap_m || q.Lm > cap_landmarks) return 0;
+  if (U) std::memcpy(U, q.U.data(), sizeof(double) * q.U.size());
+  if (ba) std::memcpy(ba, q.ba.data(), sizeof(double) * q.m);
+  if (W) std::memcpy(W, q.W.data(), sizeof(double) * q.W.size());
+  if (V) std::memcpy(V, q.V.data(), sizeof(double) * q.V.size());
+  if (bb) std::memcpy(bb, q.bb.data(), sizeof(double) * q.bb.size());
+  if (marg_rows) for (size_t i = 0; i < q.margRows.size(); ++i) marg_rows[i] = q.margRows[i];
+  return 1;
+}
+int svin_ba_get_marg_pre_blocks(svin_ba* h, uint64_t* dense_ids, int32_t* dense_ord, int32_t* dense_mdim, int cap_dense, uint64_t* landmark_ids,
+                                int cap_landmarks) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  const auto& q = h->w.margPre();
+  for (size_t i = 0; i < q.denseIds.size() && (int)i < cap_dense; ++i) {
+    if (dense_ids) dense_ids[i] = q.denseIds[i];
+    if (dense_ord) dense_ord[i] = q.denseOrd[i];
+    if (dense_mdim) dense_mdim[i] = q.denseMdim[i];
+  }
+  for (size_t i = 0; i < q.lmIds.size() && (int)i < cap_landmarks; ++i)
+    if (landmark_ids) landmark_ids[i] = q.lmIds[i];
+  return (int)q.denseIds.size();
+}
 int svin_ba_describe_block(svin_ba* h, uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.describeBlock(id, frame, kind, index);

@@ -1167,6 +1167,29 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       launchEvalFactors(q, false, s);
       hipLaunchKernelGGL(k_marg_accum_factors, dim3(1), dim3(256), 0, s, q, md);
     }
+    if (getenv("SVIN_MARG_KEEP_PRE")) {   // inspection: the system after M1 (svin_ba_get_marg_pre), before anything is eliminated
+      HIP_OK(hipStreamSynchronize(s));
+      margPre_.m = m; margPre_.Lm = Lm;
+      margPre_.U.assign((size_t)m * m, 0.0); margPre_.ba.assign(std::max(m, 1), 0.0);
+      margPre_.W.assign((size_t)m * 3 * Lm, 0.0); margPre_.V.assign((size_t)9 * Lm, 0.0); margPre_.bb.assign((size_t)3 * Lm, 0.0);
+      if (m > 0) {
+        HIP_OK(hipMemcpy(margPre_.U.data(), bU.p, sizeof(double) * m * m, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(margPre_.ba.data(), bVec.p, sizeof(double) * m, hipMemcpyDeviceToHost));
+      }
+      if (Lm > 0) {
+        if (m > 0) HIP_OK(hipMemcpy(margPre_.W.data(), bW2.p, sizeof(double) * m * 3 * Lm, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(margPre_.V.data(), bV.p, sizeof(double) * 9 * Lm, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(margPre_.bb.data(), md.bb, sizeof(double) * 3 * Lm, hipMemcpyDeviceToHost));
+      }
+      margPre_.margRows.clear();
+      margPre_.denseIds.clear(); margPre_.denseOrd.clear(); margPre_.denseMdim.clear();
+      margPre_.lmIds.assign(lmOrder.begin(), lmOrder.end());
+      for (const PriorBlockHost& pb : dense) { margPre_.denseIds.push_back(pb.id); margPre_.denseOrd.push_back(pb.ord); margPre_.denseMdim.push_back(pb.mdim); }
+      for (const PriorBlockHost& pb : dense) {
+        const bool mg = std::binary_search(toMarginalize.begin(), toMarginalize.end(), pb.id);
+        for (int k = 0; k < pb.mdim; ++k) margPre_.margRows.push_back(mg ? 1 : 0);
+      }
+    }
     // M2 landmark part
     if (Lm > 0 && m > 0) {
       hipLaunchKernelGGL(k_marg_lm_prepare, dim3((Lm + 127) / 128), dim3(128), 0, s, md, vb);

@@ -125,6 +125,16 @@ struct MargBuffers {
   DevBuf<SolverScalars> bScal;
 };
 
+// inspection copy of the marginalisation system after M1 (SVIN_MARG_KEEP_PRE=1): U m x m, ba, W m x 3Lm, V 9 Lm, bb 3 Lm,
+// and per dense row whether it is about to be marginalised
+struct MargPre {
+  int m = 0, Lm = 0;
+  std::vector<double> U, ba, W, V, bb;
+  std::vector<int> margRows;
+  std::vector<uint64_t> denseIds, lmIds;   // the dense blocks (first row denseOrd, denseMdim rows each) and the landmarks, in order
+  std::vector<int> denseOrd, denseMdim;
+};
+
 class Window {
  public:
   explicit Window(int device);
@@ -222,6 +232,7 @@ class Window {
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                int32_t* nBlocks, int capM);
   int describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) const;
+  const MargPre& margPre() const { return margPre_; }
   // Map::parameterBlockPtr / id2parameterBlockMap as values (Map.hpp:166-170, :188): type 0 pose, 1 extrinsics, 2 speed/bias,
   // 3 landmark; returns the ambient dimension (7 / 9 / 4) or SVIN_ERR_NOT_FOUND
   int getParameterBlock(uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed, int32_t* initialized) const;
@@ -321,6 +332,7 @@ class Window {
   DevBuf<double> dPriorH_, dPriorBp_, dPriorScratch_;
   DevBuf<PriorBlock> dPriorBlk_;
   DevBuf<double> dS_, dVec_, dLmVec_, dSlabs_, dChol_, dPartial_, dQuality_;
+  MargPre margPre_;
   DevBuf<SolverScalars> dScal_;
   MargBuffers margBuf_;
   ScalarMailbox* mailbox_ = nullptr;      // pinned host memory, written by the device

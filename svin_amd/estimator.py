@@ -69,7 +69,7 @@ EXPORTS = [
     "svin_host_pose_information", "svin_host_pose_error", "svin_host_manifold_dims", "svin_host_manifold_plus",
     "svin_host_manifold_minus", "svin_host_manifold_plus_jacobian", "svin_host_manifold_lift_jacobian",
     "svin_host_manifold_minus_jacobian", "svin_ba_get_parameter_block", "svin_ba_parameter_block_ids",
-    "svin_ba_get_all_landmark_observations", "svin_ba_bench_allreduce",
+    "svin_ba_get_all_landmark_observations", "svin_ba_bench_allreduce", "svin_ba_get_marg_pre", "svin_ba_get_marg_pre_blocks",
 ]
 
 ID_PROVIDER_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
@@ -191,6 +191,8 @@ def load_library():
     sig("svin_ba_get_parameter_block", i32, vp, u64, pi32, pd, C.POINTER(u32), C.POINTER(u32), pi32, pi32)
     sig("svin_ba_parameter_block_ids", i32, vp, pu64, i32)
     sig("svin_ba_bench_allreduce", i32, vp, u64, i32, pd)
+    sig("svin_ba_get_marg_pre", i32, vp, pi32, pi32, pd, pd, pd, pd, pd, pi32, i32, i32)
+    sig("svin_ba_get_marg_pre_blocks", i32, vp, pu64, pi32, pi32, i32, pu64, i32)
     sig("svin_ba_get_all_landmark_observations", i32, vp, i32, pu64, C.POINTER(LandmarkInfo), pi32, i32, pu64, pu64, pu64, pu64, pi32)
     _LIB = L
     return L
@@ -725,6 +727,41 @@ class Estimator:
         ms, by = np.zeros(1), np.zeros(1)
         self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
         return float(ms[0]), float(by[0])
+
+    def marg_pre(self):
+        """system of the last marginalisation after M1, before M2 (needs SVIN_MARG_KEEP_PRE=1): dict(H, b0, lm ranges, dense ranges)
+        in the GPU's ordering [dense rows | landmarks], the form tests/mp_marg.py takes"""
+        m, L = C.c_int32(), C.c_int32()
+        self.L.svin_ba_get_marg_pre(self.h, C.byref(m), C.byref(L), None, None, None, None, None, None, 0, 0)
+        m, L = m.value, L.value
+        if m == 0:
+            return None
+        U, ba, W, V, bb = np.zeros((m, m)), np.zeros(m), np.zeros((m, 3 * L)), np.zeros((L, 3, 3)), np.zeros(3 * L)
+        rows = np.zeros(m, np.int32)
+        assert self.L.svin_ba_get_marg_pre(self.h, None, None, _d(U), _d(ba), _d(W), _d(V), _d(bb), rows.ctypes.data_as(pi32), m, L) == 1
+        n = m + 3 * L
+        H, b = np.zeros((n, n)), np.zeros(n)
+        H[:m, :m], H[:m, m:], H[m:, :m] = U, W, W.T
+        for l in range(L):
+            H[m + 3 * l:m + 3 * l + 3, m + 3 * l:m + 3 * l + 3] = V[l]
+        b[:m], b[m:] = ba, bb
+        dense, i = [], 0
+        while i < m:   # maximal runs of marginalised dense rows
+            if rows[i]:
+                j = i
+                while j < m and rows[j]:
+                    j += 1
+                dense.append((i, j - i))
+                i = j
+            else:
+                i += 1
+        nd = self.L.svin_ba_get_marg_pre_blocks(self.h, None, None, None, 0, None, 0)
+        ids, od, md, lids = np.zeros(max(nd, 1), np.uint64), np.zeros(max(nd, 1), np.int32), np.zeros(max(nd, 1), np.int32), np.zeros(max(L, 1), np.uint64)
+        self.L.svin_ba_get_marg_pre_blocks(self.h, ids.ctypes.data_as(pu64), od.ctypes.data_as(pi32), md.ctypes.data_as(pi32), nd,
+                                           lids.ctypes.data_as(pu64), L)
+        rows_of = {int(ids[i]): (int(od[i]), int(md[i])) for i in range(nd)}
+        rows_of.update({int(lids[l]): (m + 3 * l, 3) for l in range(L)})
+        return dict(H=H, b0=b, lm=[(m + 3 * l, 3) for l in range(L)], dense=dense, m=m, n_landmarks=L, rows_of=rows_of)
 
     def bench_allreduce(self, n_doubles, iters=20):
         """mean microseconds of one native RCCL all-reduce of n_doubles FP64 values on the solver stream (collective call)"""

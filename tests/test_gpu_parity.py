@@ -553,6 +553,82 @@ def test_marginalization_one_shot(gpu_lib, rig, kw):
         assert abs(o["rank_g"] - exact["rank"]) <= len(exact["rel_eigs_small"]) - clear
 
 
+def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch):
+    """M1 AND M2 of the HIP path against a 40-digit chain that starts from the raw residual definitions (tests/mp_m1.py +
+    tests/mp_marg.py; structure -- which residuals, ordering, which rows leave -- from the oracle's log, every number
+    recomputed): five marginalisations in sequence on identical states (the oracle's snapshots are injected before each
+    call).  Checked per call: the GPU's system after M1 (SVIN_MARG_KEEP_PRE) and its prior after M2, each next to the
+    oracle's distance from the same exact result."""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    import mp_m1
+    from test_marginalization_m1_exact import tiny_sequence_spec, scaled
+    monkeypatch.setenv("SVIN_MARG_KEEP_PRE", "1")
+    spec = tiny_sequence_spec()
+    cpu, gpu = orc.OracleEstimator(), Estimator(0)
+    rec = []
+
+    def cb_cpu(k, fid):
+        if k < 4:
+            return
+        cpu.optimize(6)
+        snap = snapshot_states(cpu)
+        ok, removed = cpu.apply_marginalization(2, 2)
+        assert ok
+        rec.append(dict(snap=snap, removed=sorted(int(i) for i in removed), log=cpu.marg_m1_log(), pre=cpu.marg_pre(), prior=cpu.marg()))
+    syn.feed(cpu, spec, on_frame=cb_cpu)
+    chain = mp_m1.ExactChain()
+    step = [0]
+    worst = dict(gpu_m1=0.0, cpu_m1=0.0, gpu_m2=0.0, cpu_m2=0.0)
+
+    def cb_gpu(k, fid):
+        if k < 4:
+            return
+        r = rec[step[0]]
+        step[0] += 1
+        gpu.optimize(6)
+        inject_states(gpu, r["snap"])
+        ok, removed = gpu.apply_marginalization(2, 2)
+        assert ok and sorted(int(i) for i in removed) == r["removed"]
+        H, b0 = chain.m1(r["log"])
+        # the GPU's post-M1 system, rows permuted into the log's ordering by block id
+        pg = gpu.marg_pre()
+        n = H.shape[0]
+        assert pg is not None and pg["H"].shape[0] == n
+        perm = np.zeros(n, int)
+        for b in r["log"]["blocks"]:
+            if b["mdim"] > 0:
+                o, m = pg["rows_of"][b["id"]]
+                assert m == b["mdim"], (b, o, m)
+                perm[b["ordering"]:b["ordering"] + m] = np.arange(o, o + m)
+        Hg, bg = pg["H"][np.ix_(perm, perm)], pg["b0"][perm]
+        dHg, dbg, bs = scaled(Hg, bg, H, b0)
+        dHc, dbc, _ = scaled(r["pre"]["H"], r["pre"]["b0"], H, b0)
+        log("m1 vs exact, frame", k, ": gpu H %.2e b0 %.2e | oracle H %.2e b0 %.2e" % (dHg, dbg, dHc, dbc))
+        worst["gpu_m1"], worst["cpu_m1"] = max(worst["gpu_m1"], dHg, dbg / max(1.0, bs)), max(worst["cpu_m1"], dHc, dbc / max(1.0, bs))
+        assert dHg < 1e-10 and dbg < 1e-10 * max(1.0, bs), (k, dHg, dbg, bs)
+        ex = chain.m2(r["pre"]["lm"], r["pre"]["dense"])
+        # priors after M2: the GPU's kept blocks against the chain's, by block id
+        mg, mc = gpu.marg(), r["prior"]
+        assert mg["n"] == mc["n"] == ex["H"].shape[0]
+        keyc = {(b["frame"], b["kind"], b["index"]): b for b in mc["blocks"]}
+        p2 = np.zeros(mg["n"], int)
+        for b in mg["blocks"]:
+            if b["frame"] is not None:
+                for q in range(b["mdim"]):
+                    p2[keyc[(b["frame"], b["kind"], b["index"])]["ordering"] + q] = b["ordering"] + q
+        dHg2, dbg2, bs2 = scaled(mg["H"][np.ix_(p2, p2)], mg["b0"][p2], ex["H"], ex["b0"])
+        dHc2, dbc2, _ = scaled(mc["H"], mc["b0"], ex["H"], ex["b0"])
+        log("m2 vs exact, frame", k, ": gpu H %.2e b0 %.2e | oracle H %.2e b0 %.2e" % (dHg2, dbg2, dHc2, dbc2))
+        worst["gpu_m2"], worst["cpu_m2"] = max(worst["gpu_m2"], dHg2, dbg2 / max(1.0, bs2)), max(worst["cpu_m2"], dHc2, dbc2 / max(1.0, bs2))
+        assert dHg2 < 1e-8 and dbg2 < 1e-8 * max(1.0, bs2), (k, dHg2, dbg2, bs2)
+    syn.feed(gpu, spec, on_frame=cb_gpu)
+    assert step[0] == len(rec) == 5
+    log("distance to the exact chain, worst of five marginalisations:", worst)
+    # (the GPU carries its OWN previous prior from call to call, the chain the exact one: from the second call on its M1
+    # distance includes what its previous M2 left -- the same holds for the oracle column next to it)
+
+
 @pytest.mark.parametrize("rig,kw", [("euroc", {}), ("rig_v2", dict(sonar=True, depth=True))])
 def test_marginalization_is_deterministic(gpu_lib, rig, kw):
     """M1 accumulates in a fixed order (no atomics): the same states in, the same prior out -- bit for bit"""
@@ -906,6 +982,32 @@ def test_marginalization_large_prior_per_frame_extrinsics(gpu_lib):
     sens = max(pose_diff(cpu2.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(cpu2.frame_ids(), cf))
     log("rig v2 5+3: final window pose difference GPU vs oracle", worst, "; oracle vs oracle with landmarks moved by 1e-13 m", sens)
     assert worst < max(1e-4, 30 * sens) and worst < 5e-3
+
+
+def test_marginalization_sequence_euroc_reference_window(gpu_lib):
+    """BASELINE configs[0]: the EuRoC constants (config_fpga_p2_euroc.yaml: fixed extrinsics, its IMU noise densities) with
+    the window the reference ships for it -- numKeyframes 5, numImuFrames 3 (:55-56) -- over thirteen frames, optimize(10)
+    per frame like ThreadedKFVio (max_num_iterations 10), marginalisation every frame.  Same removed-landmark lists, same
+    frames, priors consistent, final window within the north star's 1e-4 of the oracle."""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    spec = syn.make_window(P=13, L=300, n_obs=3500, seed=46, rig="euroc", keyframe_every=2, frame_dt=0.3)
+    gpu, cpu = Estimator(0), orc.OracleEstimator()
+    fg, lg, rg = run_sequence(gpu, spec, 5, 3, 10)
+    fc, lc, rc = run_sequence(cpu, spec, 5, 3, 10)
+    log("euroc 5+3: removed landmarks per frame gpu", rg, "cpu", rc)
+    assert rg == rc and fg == fc and sum(rg) > 0
+    assert gpu.num_frames() == cpu.num_frames() <= 8 and gpu.num_landmarks() == cpu.num_landmarks()
+    assert gpu.frame_ids() == cpu.frame_ids()
+    assert [gpu.is_keyframe(f) for f in gpu.frame_ids()] == [cpu.is_keyframe(f) for f in cpu.frame_ids()]
+    mg, mc = gpu.marg(), cpu.marg()
+    assert mg is not None and mc is not None and mg["n"] == mc["n"]
+    o = compare_priors(mg, mc, "euroc 5+3 sequence prior")
+    assert o["selfH"] < 1e-9 and o["dH"] < 1e-2 and o["dJtJ"] < 1e-2
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(gpu.frame_ids(), cpu.frame_ids()))
+    worst_sb = max(float(np.max(np.abs(gpu.get_speed_and_bias(a) - cpu.get_speed_and_bias(a)))) for a in gpu.frame_ids() if gpu.is_in_imu_window(a))
+    log("euroc 5+3: final window pose difference", worst, "speed/bias", worst_sb)
+    assert worst < 1e-4 and worst_sb < 1e-4
 
 
 @pytest.mark.parametrize("rig,window,P", [("euroc", (2, 3), 8), ("rig_v2", (5, 3), 13)])
