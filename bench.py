@@ -100,8 +100,8 @@ def cpu_baseline(spec, budget_s=6.0):
                 threads={str(nt): r["value"] for nt, r in rows.items()},
                 sample="%d x optimize(10) on the full config-#2 window (%d iterations, %.1f s) per thread count; oracle/ C++ "
                        "restatement of the reference's Ceres path (analytic Jacobians, landmark Schur, dense Cholesky), g++ -O3 "
-                       "-march=native; threads = residual evaluation + Schur elimination like ceres num_threads; host has %d "
-                       "logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
+                       "-march=native; only the 1-thread figure is a baseline -- the port's OpenMP loops (residual evaluation, Schur "
+                       "elimination) scale poorly and are NOT a stand-in for Ceres at num_threads = 2; host has %d logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
 
 
 _REAL_STDOUT = None
@@ -278,7 +278,74 @@ def window_record(name, spec, device, steps, warmup, iters):
                upload_ms=1e3 * last["upload_time"], P=spec.P, L=spec.L, N=spec.N)
     if kinds:
         rec["factor_kinds"] = kinds   # 0 imu 1 pose prior 2 speed/bias prior 3 relative extrinsics 4 sonar 5 depth
+    # the kernels of one iteration on their own (HIP events on the solver's stream) and the roofline of the dominant ones
+    try:
+        ev, bu, so = est.bench_kernel_times(5)
+        d = 6 * spec.P * (1 + (2 if "rig v2" in name else 0)) + 9 * spec.P     # poses (+ per-frame extrinsics) + speed/bias
+        chol_flops = d ** 3 / 3.0 + 2.0 * d * d
+        n_l = np.bincount(spec.obs_lm, minlength=spec.L).astype(float)
+        schur_flops = float(np.sum(3.0 * (6.0 * n_l) ** 2))      # sum_l (6 n_l x 3)(3 x 6 n_l), lower triangle
+        rec["kernel_ms"] = {"eval_reproj": ev, "build_normal_equations": bu, "chol_solve_backsub": so}
+        rec["roofline"] = {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "d": d,
+            "solve": {"kernel": "k_chol_solve_lds" if d <= 176 else ("k_chol_solve_ll" if d <= 272 else "k_big_chol_chain + k_big_back"),
+                      "launch_ms": so, "flops": chol_flops, "achieved": chol_flops / (so * 1e-3) / 1e12,
+                      "frac": chol_flops / (so * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS},
+            "schur": {"kernel": "k_schur_dense" if spec.P <= 20 else "k_schur_panels", "launch_ms": bu, "flops": schur_flops,
+                      "achieved": schur_flops / (bu * 1e-3) / 1e12, "frac": schur_flops / (bu * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS},
+            "note": "algorithmic flops (Cholesky d^3/3 + two triangular solves; Schur complement sum_l 3 (6 n_l)^2) over the launch time: "
+                    "both are latency-bound chains at these sizes (DESIGN.md 3), the fractions say how far from the matrix pipes' rate"}
+        rec["roofline"]["achieved"] = rec["roofline"]["solve"]["achieved"] if so >= bu else rec["roofline"]["schur"]["achieved"]
+        rec["roofline"]["frac"] = rec["roofline"]["achieved"] / F64_MFMA_PEAK_TFLOPS
+        rec["roofline"]["kernel"] = rec["roofline"]["solve"]["kernel"] if so >= bu else rec["roofline"]["schur"]["kernel"]
+        rec["roofline"]["traffic"] = None
+    except Exception as ex:
+        rec["roofline"] = {"error": repr(ex)}
     return rec, est
+
+
+def sliding_window_record(device, with_oracle=True):
+    """SVIn's operating mode: a window fed frame by frame -- addStates, ~1 000 addObservation, optimize(10),
+    applyMarginalizationStrategy(5 keyframes, 3 IMU frames) -- host work and PCIe included, the oracle beside it."""
+    from svin_amd import synthetic as syn
+    from svin_amd.estimator import Estimator
+
+    def run(est, spec):
+        rows, timing = [], {}
+
+        def on_frame(k, fid):
+            t0 = time.perf_counter()
+            est.optimize(10)
+            t1 = time.perf_counter()
+            ok, removed = est.apply_marginalization(5, 3)
+            t2 = time.perf_counter()
+            s = est.summary()
+            rows.append(dict(optimize=t1 - t0, marginalise=t2 - t1, iterations=s["iterations"], upload=s.get("upload_time", 0.0),
+                             solve=s.get("solve_time", 0.0), download=s.get("download_time", 0.0), removed=len(removed)))
+        syn.feed(est, spec, on_frame=on_frame, timing=timing)
+        return rows[4:], timing      # steady state: the window is full from the fifth frame on
+    spec = syn.make_window(P=24, L=2400, n_obs=24000, seed=7, rig="euroc", keyframe_every=2, frame_dt=0.25)
+    rows, timing = run(Estimator(device), spec)
+    med = lambda key: float(np.median([r[key] for r in rows]))   # noqa: E731
+    add_obs = float(np.median(timing["add_observations_s"])) if timing.get("add_observations_s") else 0.0
+    frame = med("optimize") + med("marginalise") + add_obs
+    rec = dict(workload="sliding window, 5 keyframes + 3 IMU frames, ~1000 new observations per frame, optimize(10) + "
+                        "applyMarginalizationStrategy per frame, %d steady-state frames" % len(rows),
+               ms_per_frame=1e3 * frame, frames_per_s=1.0 / frame,
+               ms={"add_observations": 1e3 * add_obs, "optimize_call": 1e3 * med("optimize"), "pack_upload": 1e3 * med("upload"),
+                   "device_solve": 1e3 * med("solve"), "read_back": 1e3 * med("download"), "marginalise_call": 1e3 * med("marginalise")},
+               host_ms_per_frame=1e3 * (frame - med("solve")),
+               iterations_per_frame=float(np.mean([r["iterations"] for r in rows])),
+               note="marginalise_call returns after the host policy has enqueued M1-M3 (device part asynchronous, ~1 ms, hidden "
+                    "behind the next frame's front-end work); host_ms_per_frame = everything but the device solve")
+    if with_oracle:
+        from oracle import orc
+        orows, _ = run(orc.OracleEstimator(), spec)
+        of = float(np.median([r["optimize"] for r in orows])) + float(np.median([r["marginalise"] for r in orows]))
+        rec["cpu_baseline"] = dict(ms_per_frame=1e3 * of, frames_per_s=1.0 / of, cores=1, kind="port",
+                                   sample="the same %d frames through oracle/ (1 thread)" % len(orows))
+        rec["speedup_vs_cpu_baseline"] = of / frame
+    return rec
 
 
 XGMI_LINK_GBS = 153.0   # per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
@@ -403,7 +470,11 @@ def main():
                        # median of >= 30 runs; `value` itself is total iterations / total time of the K steps
                        "median_ms_per_step": 1e3 * med, "value_at_median": (its[0] / med) * world,
                        "min_ms_per_step": 1e3 * min(times), "max_ms_per_step": 1e3 * max(times),
-                       "timed_region_s_incl_untimed_upload": t_region},
+                       "timed_region_s_incl_untimed_upload": t_region,
+                       # the boundary hands over host buffers: the same solves with pack + upload and the read-back of states,
+                       # landmarks and qualities counted (never `value`, which is measured with the inputs resident in HBM)
+                       "pcie_inclusive": {"value": its[-1] / (med + last["upload_time"] + last["download_time"]), "unit": "GN iterations/s",
+                                          "upload_ms": 1e3 * last["upload_time"], "download_ms": 1e3 * last["download_time"]}},
         }
         # roofline of the dominant streaming kernel (K1 reprojection residual + Jacobian evaluation) on an
         # HBM-resident batch of replicas; HIP events on the kernel's own stream
@@ -480,12 +551,24 @@ def main():
                 extras["error"] = repr(ex)
         if rank == 0:
             try:
+                extras["sliding_window"] = sliding_window_record(local_rank, with_oracle=not args.no_cpu_baseline)
+            except Exception as ex:
+                extras["sliding_window"] = {"error": repr(ex)}
+        if rank == 0:
+            try:
                 pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=False)
                 extras["config5"] = {k: pg[k] for k in ("value", "unit", "ms_per_step")}
                 extras["config5"].update(workload=pg["config"]["workload"], iterations_per_step=pg["config"]["iterations_per_step"],
                                          ms_per_iteration=pg["ms_per_step"] / pg["config"]["iterations_per_step"])
             except Exception as ex:
                 extras["config5"] = {"error": repr(ex)}
+            try:
+                pg6 = posegraph_record(argparse.Namespace(six_dof=True), 0, 1, local_rank, None, 2, 1, cpu=False)
+                extras["config5_6dof"] = {k: pg6[k] for k in ("value", "unit", "ms_per_step")}
+                extras["config5_6dof"].update(workload=pg6["config"]["workload"], iterations_per_step=pg6["config"]["iterations_per_step"],
+                                              ms_per_iteration=pg6["ms_per_step"] / pg6["config"]["iterations_per_step"])
+            except Exception as ex:
+                extras["config5_6dof"] = {"error": repr(ex)}
             out.update(extras)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -76,9 +76,10 @@ uint64_t svin_ba_new_id(svin_ba* h);            /* IdProvider::instance().newId(
  * internal extrinsics / speed-bias block ids (src/Estimator.cpp:217,234) all come from the process-wide
  * okvis::IdProvider.  A host that owns such a provider installs it here (the shim passes a trampoline to
  * IdProvider::instance().newId()); the core then draws its internal ids -- and svin_ba_new_id() -- from it.
- * Without a provider the core counts upwards from the largest id svin_ba_reserve_ids() has been told about
- * (call it with the largest caller-chosen id before add_states).  An internal id that collides with any known
- * frame / landmark / block id makes add_states fail with SVIN_ERR_INVALID_ARG and leaves the window unchanged. */
+ * Without a provider the core counts upwards from the largest id it has seen (svin_ba_reserve_ids() raises that
+ * mark) and steps over any id a frame / landmark / block of the window already uses.  With a provider installed, an
+ * id it hands out that collides with a known frame / landmark / block id makes add_states fail with
+ * SVIN_ERR_INVALID_ARG and leaves the window -- state count and IMU integrals included -- unchanged. */
 typedef uint64_t (*svin_id_provider_fn)(void* user);
 int svin_ba_set_id_provider(svin_ba* h, svin_id_provider_fn fn, void* user);
 int svin_ba_reserve_ids(svin_ba* h, uint64_t largest_id_seen);

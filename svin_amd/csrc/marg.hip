@@ -934,8 +934,12 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         if (!isReproj(rid) && factors_.count(rid)) addFactorToJob(rid);
     }
     const uint64_t currentKfId = allLinearizedFrames.at(0);
+    const uint64_t newestLeaving = *std::max_element(removeFrames.begin(), removeFrames.end());
     for (auto pit = landmarks_.begin(); pit != landmarks_.end();) {  // :671-766
       Landmark& lm = pit->second;
+      // nobody in the leaving frames has seen it (its oldest observation is newer than all of them): the walk below
+      // would end in `skipLandmark` -- the common case, answered from one cached field
+      if (!lm.obs.empty() && lm.minPose > newestLeaving) { pit++; continue; }
       bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
       size_t obsCount = 0;
       // first pass straight over the observation list (no copies): most landmarks are skipped here
@@ -1110,10 +1114,19 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     auto& bImu = mb.bImu;
     auto &bImuM = mb.bImuM, &bPartial = mb.bPartial;
     auto& bScal = mb.bScal;
-    up(bPose, hPose); up(bExt, hExt); up(bSb, hSb); up(bLm, hLm); up(bUv, hUv); up(bW, hW);
-    up(bOP, oPose); up(bOE, oExt); up(bOS, oSb); up(bLmPtr, hLmPtr); up(bObsLm, hObsLm); up(bIdx, hIdx);
-    up(bFac, hFac); up(bImu, hImu); up(bImuT, hImuT); up(bImuM, hImuM);
-    up(dCams_, cameras_);
+    {   // the job's tables: one pinned block, one DMA, one scatter kernel (17 pageable copies cost ~100 us of enqueueing)
+      std::vector<StagedCopy> pending;
+      auto stage = [&](auto& buf, const auto& host) {
+        using T = typename std::decay_t<decltype(host)>::value_type;
+        buf.reserve(std::max<size_t>(host.size() + 16 / sizeof(T) + 1, 1));   // room for the 16-byte rounding of the copy
+        if (!host.empty()) pending.push_back({host.data(), sizeof(T) * host.size(), buf.p});
+      };
+      stage(bPose, hPose); stage(bExt, hExt); stage(bSb, hSb); stage(bLm, hLm); stage(bUv, hUv); stage(bW, hW);
+      stage(bOP, oPose); stage(bOE, oExt); stage(bOS, oSb); stage(bLmPtr, hLmPtr); stage(bObsLm, hObsLm); stage(bIdx, hIdx);
+      stage(bFac, hFac); stage(bImu, hImu); stage(bImuT, hImuT); stage(bImuM, hImuM);
+      stage(dCams_, cameras_);
+      flushStaged(pending, s);
+    }
     bLin.reserve(std::max<size_t>((size_t)32 * N, 1));
     bFacLin.reserve(std::max(F, 1));
     bPartial.reserve((size_t)16 * 4096);

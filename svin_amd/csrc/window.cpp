@@ -214,6 +214,10 @@ void Window::removeObsRecord(Landmark& lm, size_t idx) {
   if (Block* b = findBlock(o.extId)) b->nObs--;
   obsRes2Lm_.erase(o.resId);
   lm.obs.erase(lm.obs.begin() + idx);
+  if (o.poseId == lm.minPose) {
+    lm.minPose = UINT64_MAX;
+    for (const Observation& q : lm.obs) lm.minPose = std::min(lm.minPose, q.poseId);
+  }
 }
 void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (Map.cpp:322-333)
   Block* b = findBlock(id);
@@ -511,6 +515,7 @@ uint64_t Window::addObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, ui
   o.uv[0] = uv[0]; o.uv[1] = uv[1];
   o.size = size;
   lit->second.obs.push_back(o);
+  lit->second.minPose = std::min(lit->second.minPose, o.poseId);
   blocks_.at(o.poseId).nObs++;
   blocks_.at(o.extId).nObs++;
   obsRes2Lm_[o.resId] = lmId;
@@ -772,6 +777,37 @@ static void upload(DevBuf<T>& buf, const std::vector<T>& host, hipStream_t s) {
   if (!host.empty()) HIP_OK(hipMemcpyAsync(buf.p, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice, s));
 }
 
+// Every host array of a job goes into ONE pinned block behind a segment table: one DMA, one scatter kernel (separate
+// pageable copies cost ~4 us of enqueueing and ~4 us of draining EACH).  The sources are copied here, the caller's vectors
+// may go away right after the call.
+void Window::flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s) {
+  if (pending.empty()) return;
+  auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
+  const size_t tableBytes = r16(sizeof(StageSegment) * pending.size());
+  size_t total = tableBytes;
+  for (const StagedCopy& pe : pending) total += r16(pe.bytes);
+  if (stageEvt_) HIP_OK(hipEventSynchronize(stageEvt_));   // the previous block may still be on its way
+  else HIP_OK(hipEventCreateWithFlags(&stageEvt_, hipEventDisableTiming));
+  if (total > stageHostCap_) {
+    if (stageHost_) (void)hipHostFree(stageHost_);
+    stageHostCap_ = std::max<size_t>(2 * total, 1 << 20);
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&stageHost_), stageHostCap_, hipHostMallocDefault));
+  }
+  stageDev_.reserve(std::max<size_t>(total, 16));
+  StageSegment* table = reinterpret_cast<StageSegment*>(stageHost_);
+  size_t off = tableBytes;
+  for (size_t i = 0; i < pending.size(); ++i) {
+    const size_t b16 = r16(pending[i].bytes);
+    table[i] = StageSegment{(unsigned long long)off, (unsigned long long)b16, pending[i].dst};
+    std::memcpy(stageHost_ + off, pending[i].src, pending[i].bytes);
+    if (b16 > pending[i].bytes) std::memset(stageHost_ + off + pending[i].bytes, 0, b16 - pending[i].bytes);
+    off += b16;
+  }
+  HIP_OK(hipMemcpyAsync(stageDev_.p, stageHost_, total, hipMemcpyHostToDevice, s));
+  HIP_OK(hipEventRecord(stageEvt_, s));
+  launchScatterStaged(stageDev_.p, (int)pending.size(), s);
+}
+
 void Window::pack() {
   const double tPack0 = nowSec();
   poseIds_.clear(); extIds_.clear(); sbIds_.clear(); lmIds_.clear(); factorIds_.clear();
@@ -961,8 +997,7 @@ void Window::pack() {
   hipStream_t s = stream_;
   // every host array of the window goes into one pinned block behind a segment table: one DMA, one scatter kernel
   // (18 separate pageable copies cost ~70 us of enqueueing and ~70 us of draining per pack())
-  struct Pending { const void* src; size_t bytes; void* dst; };
-  std::vector<Pending> pending;
+  std::vector<StagedCopy> pending;
   auto upload = [&](auto& buf, const auto& host, hipStream_t) {
     using T = typename std::remove_reference<decltype(host)>::type::value_type;
     buf.reserve(std::max<size_t>(host.size() + 16 / sizeof(T) + 1, 1));   // room for the 16-byte rounding of the copy
@@ -1060,34 +1095,7 @@ void Window::pack() {
     dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
   }
 
-  {  // flush the staged arrays
-    auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
-    const size_t tableBytes = r16(sizeof(StageSegment) * pending.size());
-    size_t total = tableBytes;
-    for (const Pending& pe : pending) total += r16(pe.bytes);
-    if (stageEvt_) HIP_OK(hipEventSynchronize(stageEvt_));   // the previous block may still be on its way
-    else HIP_OK(hipEventCreateWithFlags(&stageEvt_, hipEventDisableTiming));
-    if (total > stageHostCap_) {
-      if (stageHost_) (void)hipHostFree(stageHost_);
-      stageHostCap_ = std::max<size_t>(2 * total, 1 << 20);
-      HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&stageHost_), stageHostCap_, hipHostMallocDefault));
-    }
-    stageDev_.reserve(std::max<size_t>(total, 16));
-    StageSegment* table = reinterpret_cast<StageSegment*>(stageHost_);
-    size_t off = tableBytes;
-    for (size_t i = 0; i < pending.size(); ++i) {
-      const size_t b16 = r16(pending[i].bytes);
-      table[i] = StageSegment{(unsigned long long)off, (unsigned long long)b16, pending[i].dst};
-      std::memcpy(stageHost_ + off, pending[i].src, pending[i].bytes);
-      if (b16 > pending[i].bytes) std::memset(stageHost_ + off + pending[i].bytes, 0, b16 - pending[i].bytes);
-      off += b16;
-    }
-    if (!pending.empty()) {
-      HIP_OK(hipMemcpyAsync(stageDev_.p, stageHost_, total, hipMemcpyHostToDevice, s));
-      HIP_OK(hipEventRecord(stageEvt_, s));
-      launchScatterStaged(stageDev_.p, (int)pending.size(), s);
-    }
-  }
+  flushStaged(pending, s);
 
   DeviceProblem& p = prob_;
   std::memset(&p, 0, sizeof(p));

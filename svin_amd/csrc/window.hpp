@@ -54,6 +54,8 @@ struct Landmark {
   double quality = 0, distance = 0;
   bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
   std::vector<Observation> obs;  // insertion order
+  uint64_t minPose = UINT64_MAX;   // smallest frame id among obs (frame ids grow with time): lets the marginalisation policy skip a
+                                  // landmark nobody in the leaving frames has seen without walking its observation list
   // HomogeneousPointError residuals on this landmark (HomogeneousPointError.cpp:48-117): measurement and the
   // upper-triangular square-root information (row-major); not added by okvis::Estimator, available to callers
   struct Prior { uint64_t resId = 0; double meas[4] = {0, 0, 0, 1}; double sqrtInfo[9] = {0}; };
@@ -269,6 +271,8 @@ class Window {
   void* rcclComm_ = nullptr;   // ncclComm_t of the native path (RCCL resolved at run time, see window.cpp)
   hipStream_t stream_ = nullptr;
   // staged upload of pack(): pinned host block + its device twin (segment table first), see launchScatterStaged
+  struct StagedCopy { const void* src; size_t bytes; void* dst; };
+  void flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s);
   unsigned char* stageHost_ = nullptr;
   size_t stageHostCap_ = 0;
   DevBuf<unsigned char> stageDev_;
