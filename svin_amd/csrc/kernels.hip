@@ -349,6 +349,43 @@ __device__ __forceinline__ void allGatherRows(double v, double (&out)[4]) {
   out[1] = __hiloint2double((int)h13[0], (int)l13[0]);
   out[3] = __hiloint2double((int)h13[1], (int)l13[1]);
 }
+// One DPP move of a double (two 32-bit halves); rows outside kRowMask keep `old`
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dppMovD(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// a DPP move that writes every lane (no `old` operand to initialise)
+template <int kCtrl>
+__device__ __forceinline__ double dppBcastD(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// v replicated over the four lane rows (lane (g, c) holds v[c]) -> out[q] = v[4 q + g]: row g rotated left by g (row_ror
+// by 16 - g, on rows 1-3), then lane 4 q of every row broadcast to its row (row_newbcast)
+__device__ __forceinline__ void colToRowForm(double v, double (&out)[4]) {
+  double u = v;
+  u = dppMovD<0x120 + 15, 0x2>(u, v);
+  u = dppMovD<0x120 + 14, 0x4>(u, v);
+  u = dppMovD<0x120 + 13, 0x8>(u, v);
+  out[0] = dppBcastD<0x150 + 0>(u);
+  out[1] = dppBcastD<0x150 + 4>(u);
+  out[2] = dppBcastD<0x150 + 8>(u);
+  out[3] = dppBcastD<0x150 + 12>(u);
+}
+// sum of a value over the four lane rows (lanes c, 16 + c, 32 + c, 48 + c), on every lane: three swaps, two additions
+__device__ __forceinline__ double sumLaneRows(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // rows [v0 v0 v2 v2], [v1 v1 v3 v3]
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);  // [s01 s01 s23 s23]
+  const unsigned slo = (unsigned)__double2loint(s), shi = (unsigned)__double2hiint(s);
+  const auto l32 = __builtin_amdgcn_permlane32_swap(slo, slo, false, false);  // [s01 x4], [s23 x4]
+  const auto h32 = __builtin_amdgcn_permlane32_swap(shi, shi, false, false);
+  return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
 __device__ __forceinline__ double selectByRow(int g, double v0, double v1, double v2, double v3) {
   double v = v0;
   v = (g == 1) ? v1 : v;
@@ -363,7 +400,10 @@ __device__ __forceinline__ double rcpPivot(double x) {
   const double e = __builtin_fma(-x, r, 1.0);
   return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
-// `acc` = the tile in the accumulator layout (what an MFMA update of it leaves in registers); D receives the factors
+// `acc` = the tile in the accumulator layout (what an MFMA update of it leaves in registers); D receives the factors.
+// kInvOnly: D <- the TRANSPOSED inverse factor alone (upper triangle and diagonal L^-T, zeros below): every consumer that
+// multiplies with L^-1 reads the tile as it is, without a select per operand (k_chol_solve_lds never reads L of a pivot tile)
+template <bool kInvOnly = false>
 __device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv, int laneIn, int* failFlag) {
   // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks of this routine out of the
   // caller's block-column loop
@@ -428,7 +468,8 @@ __device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv,
     }
     const double rs = rsqrtNewton(dm > 0 ? dm : 1.0);  // 1/L_kk (1 for a failed pivot)
     const int k = 4 * b + g;
-    D[c * kPanelLd + k] = ((c >= k) ? Um : Xm) * rs;  // L[c][k] below / on the diagonal, Linv[k][c] above
+    if (kInvOnly) D[c * kPanelLd + k] = (c > k) ? 0.0 : Xm * rs;   // Linv[k][c] on and above the diagonal
+    else D[c * kPanelLd + k] = ((c >= k) ? Um : Xm) * rs;  // L[c][k] below / on the diagonal, Linv[k][c] above
     if (c == 0) dinv[k] = rs;
   }
   if (bad && lane == 0) atomicOr(failFlag, 2);
@@ -3179,15 +3220,20 @@ constexpr int kTile = 16 * kPanelLd;  // doubles per tile
 __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return base + (size_t)(I * (I + 1) / 2 + J) * kTile; }
 
 constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: LDS pressure, the diagonal block is the critical path)
-constexpr int kCholFlagInts = 32;
+constexpr int kCholFlagInts = 48;
 // Flags of the barrier-free factorisation (LDS ints, monotonic counters, written by exactly one wave each):
 //   fl[0]       pivotDone  number of diagonal tiles whose factor D(kb) and 1/L_ii are in LDS
 //   fl[1 + I]   xReady[I]  number of block columns for which the panel tile X(I, .) of tile row I is stored
 //   fl[13 + I]  rowUpd[I]  number of block columns applied to every tile of tile row I
+//   fl[27]      ySteps     solution blocks stored by the backward substitution; fl[28 + kb] farDone[kb] (see there)
 //   fl[26]      a bounded spin gave up (a bug, not a numerical event: reported through cholFail bit 2)
+// Everything the flags guard lives in LDS, and the DS operations of one wave execute in issue order: "data stores, then flag
+// store" on the writer and "flag load, then data loads" on the reader are ordered by the hardware.  The compiler is held to
+// that order by memory clobbers; a release / acquire fence pair would add an s_waitcnt (one LDS round trip) on either side.
 __device__ __forceinline__ void cholFlagSet(int* f, int v, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the LDS writes of this wave are complete before the flag shows
+  asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
 }
 // kSleep: s_sleep units (64 clocks) between polls -- 1 on the waves whose wait is on the critical path, more for the wave
 // that shares wave 0's SIMD (every poll of a waiting wave takes issue slots from the pivot routine)
@@ -3198,7 +3244,7 @@ __device__ __forceinline__ void cholFlagWait(int* f, int v, int* bail) {
     __builtin_amdgcn_s_sleep(kSleep);
     if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 // all of f[0 .. n) >= v, polled with one LDS read per round (lane j reads f[j])
 template <int kSleep = 1>
@@ -3210,7 +3256,7 @@ __device__ __forceinline__ void cholFlagWaitAll(int* f, int n, int v, int lane, 
     __builtin_amdgcn_s_sleep(kSleep);
     if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 // Round 3: the factorisation has NO workgroup barrier between the load and the backward substitution.  Round 2 ran two
 // phases per block column with a barrier after each (P: panel solves, D: pivot tile on wave 0 next to the trailing update of
@@ -3252,8 +3298,17 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #define CHOL_T0 const long long qa_ = __builtin_readcyclecounter()
 #define CHOL_WAITED qWait += __builtin_readcyclecounter() - qa_
 // raw stamp `which` of block column kb, relative to the kernel start (last launch wins)
-#define CHOL_STAMP(which, kb) do { if (lane == 0) p.partial[(size_t)15 * 4096 + 64 + (which) * 12 + (kb)] = (double)(__builtin_readcyclecounter() - ql0); } while (0)
+// (into LDS, copied out at the end: a global store per stamp makes the next acquire fence wait for it -- ~1 k cycles)
+  double* stampBuf = reinterpret_cast<double*>(fl + kCholFlagInts);
+  if (t < 240) stampBuf[t] = 0;
+#define CHOL_STAMP(which, kb) do { if (lane == 0) stampBuf[(which) * 12 + (kb)] = (double)(__builtin_readcyclecounter() - ql0); } while (0)
+#ifdef SVIN_CHOL_TIMING_FINE
+#define CHOL_STAMP_FINE(which, kb) CHOL_STAMP(which, kb)
 #else
+#define CHOL_STAMP_FINE(which, kb)
+#endif
+#else
+#define CHOL_STAMP_FINE(which, kb)
 #define CHOL_T0
 #define CHOL_WAITED
 #define CHOL_STAMP(which, kb)
@@ -3319,22 +3374,17 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   // X^T = L^-1 A^T: with the operands in this order the product comes out TRANSPOSED in the accumulator layout, which is
   // X in the operand layout (lane (row, g) register r = X[row][4r + g]) -- exactly what the trailing update reads
   auto panelSolve = [&](double* A, const double* D, int k0) {
-    // all twelve operands requested before the first product (one LDS latency instead of four on a dependent chain)
-    double a[4], bD[4], bI[4];
+    // all eight operands requested before the first product (one LDS latency instead of four on a dependent chain); the
+    // pivot tile holds L^-T with zeros below the diagonal, so row kk of it IS column kk of L^-1 -- no select
+    double a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int kk = 4 * q + g;
       a[q] = A[lop + 4 * q];
-      bD[q] = D[kk * kPanelLd + c];
-      bI[q] = dinv[k0 + kk];
+      b[q] = D[(4 * q + g) * kPanelLd + c];
     }
     d4_t acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int kk = 4 * q + g;
-      const double b = (c > kk) ? bD[q] : ((c == kk) ? bI[q] : 0.0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[q], acc, 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[q], a[q], acc, 0, 0, 0);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) A[lop + 4 * rg] = acc[rg];
     return acc;
@@ -3403,7 +3453,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       const int k0 = 16 * kb;
       double* D = tileAt(tiles, kb, kb);
       CHOL_STAMP(0, kb);
-      cholDiag16Acc(accD, D, dinv + k0, lane, &p.scal->cholFail);
+      cholDiag16Acc<true>(accD, D, dinv + k0, lane, &p.scal->cholFail);
       CHOL_STAMP(1, kb);
       cholFlagSet(fl + 0, kb + 1, lane);
       CHOL_STAMP(2, kb);
@@ -3501,12 +3551,9 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         const int k0 = 16 * kb;
         const double* D = tileAt(tiles, kb, kb);
         { CHOL_T0; cholFlagWait<8>(fl + 0, kb + 1, bail); CHOL_WAITED; }
-        double yv = rhs[k0 + c] * dinv[k0 + c];   // y'_kb = L_kb^-1 rhs_kb (strict lower part of L^-1 sits transposed above the diagonal)
+        double yv = 0;   // y'_kb = L_kb^-1 rhs_kb: column c of the stored L^-T (zeros below its diagonal)
 #pragma unroll
-        for (int cc = 0; cc < 15; ++cc) {
-          const double term = D[cc * kPanelLd + c] * rhs[k0 + cc];
-          yv += (cc < c) ? term : 0.0;
-        }
+        for (int cc = 0; cc < 16; ++cc) yv = __builtin_fma(D[cc * kPanelLd + c], rhs[k0 + cc], yv);
         waveSync();
         if (lane < 16) rhs[k0 + lane] = yv;
         waveSync();
@@ -3575,50 +3622,152 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   long long q5 = __builtin_readcyclecounter();
   if (t == 0) p.partial[(size_t)15 * 4096 + 3] += (double)(q5 - ql0);
 #endif
-  // Backward substitution L^T y = y', one barrier per block: wave 0 first takes block kb+1's contribution to the rows of
-  // block kb (the only rows the next solve needs), then solves y_kb with L_kb^-T; the other waves meanwhile remove block
-  // kb+1's contribution from the rows above block kb.
-  for (int kb = nT - 1; kb >= 0; --kb) {
-    const int k0 = kb * 16;
-    if (wave == 0) {
-      const double* D = tileAt(tiles, kb, kb);
-      double rv = rhs[k0 + c];
-      if (kb + 1 < nT) {
-        const double* Lb = tileAt(tiles, kb + 1, kb) + c;   // L(k0 + 16 + k, k0 + c)
-        double sacc = 0;
+  // Backward substitution L^T y = y' without a barrier.  Wave 0 runs the chain entirely in registers: a 16-vector that is
+  // REPLICATED over the columns of an MFMA result (accumulator layout: lane (g, c) register r = v[g + 4 r]) is exactly the B
+  // operand of the next 16x16x4 product, so  rv = y'_kb - L(kb+1, kb)^T y_kb+1  and  y_kb = L_kb^-T rv  are two chains of
+  // four products with no LDS round trip and no cross-lane step between them (the round-2 form -- every lane a 16-term
+  // dot product, two LDS round trips and a barrier per block -- took 1.4 k cycles per block).  The contributions of the
+  // blocks further down (j >= kb + 2) are taken off the chain: block kb has a helper wave that adds L(j, kb)^T y_j as the
+  // y_j appear (four FMAs per lane, summed over the lane rows once at the end) and hands y'_kb over through farDone[kb].
+  int* ySteps = fl + 27;    // number of solution blocks wave 0 has stored (from the bottom)
+  int* farDone = fl + 28;   // [kb] = 1: rhs block kb holds y'_kb minus the contributions of the blocks j >= kb + 2
+  // Handshakes without fences: the DS operations of one wave execute in issue order, so "data stores, then flag store" on the
+  // writer and "flag load, then data loads" in ONE batch on the reader (repeated until the flag shows) need no s_waitcnt in
+  // between -- a release / acquire pair costs two LDS round trips per hand-over, and wave 0 is a single in-order
+  // instruction stream: whatever it waits for is on the chain.  The compiler is held to the order by memory clobbers.
+#define LDS_ORDER() asm volatile("" ::: "memory")
+  // (plain LDS loads behind a clobber are re-issued every time; a volatile access through the generic pointer turns into
+  //  FLAT loads with system scope and a wait after each)
+  if (wave == 0) {
+    // One iteration = store y_kb+1, compute y_kb: two dependent 16 x 16 matrix-vector products, t = L(kb+1, kb)^T y_kb+1 and
+    // y_kb = L_kb^-T (y'_kb - t).  On the VALU: the vector lives REPLICATED over the four lane rows (lane (g, c) holds v[c]),
+    // colToRowForm hands lane (g, c) the entries v[4 q + g] with seven DPP moves, four FMAs per lane and the sum over the lane
+    // rows (v_permlane swaps) give the product in the replicated form again -- 388 cycles per step against 632 for two chains
+    // of four v_mfma_f64_16x16x4 on a column-replicated operand (64 cycles of matrix pipe each: tools/ubench/matvec_chain.hip),
+    // and no LDS round trip on the chain.  Every LDS request of an iteration goes out before its arithmetic starts.
+    auto diagOps = [&](const double* D, double (&oD)[4]) {   // L_kb^-1[4q + g][c]: the stored L^-T read along its rows
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sacc += Lb[k * kPanelLd] * rhs[k0 + 16 + k];
-        rv -= sacc;
-        waveSync();
-        if (lane < 16) rhs[k0 + lane] = rv;
-        waveSync();
-      }
-      double yv = rv * dinv[k0 + c];
+      for (int q = 0; q < 4; ++q) oD[q] = D[lop + 4 * q];
+    };
+    auto belowOps = [&](const double* Lb, double (&oL)[4]) {   // L(16 (kb+1) + 4q + g, 16 kb + c) out of tile (kb+1, kb)
 #pragma unroll
-      for (int r = 1; r < 16; ++r) {
-        const double term = D[c * kPanelLd + r] * rhs[k0 + r];
-        yv += (r > c) ? term : 0.0;
-      }
-      waveSync();
-      if (lane < 16) rhs[k0 + lane] = yv;
-    } else if (kb + 1 < nT) {
-      for (int i = t - 64; i < k0; i += kCholLdsThreads - 64) {
-        const double* col = tileAt(tiles, kb + 1, i >> 4) + (i & 15);  // L(k0 + 16 + k, i)
-        double sacc = 0;
+      for (int q = 0; q < 4; ++q) oL[q] = Lb[lrow + 4 * q * kPanelLd];
+    };
+    auto matVec = [&](const double (&m)[4], double v) {   // sum_k m[k][c] v[k], replicated
+      double vq[4];
+      colToRowForm(v, vq);
+      double acc = m[0] * vq[0];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sacc += col[k * kPanelLd] * rhs[k0 + 16 + k];
-        rhs[i] -= sacc;
-      }
+      for (int q = 1; q < 4; ++q) acc = __builtin_fma(m[q], vq[q], acc);
+      return sumLaneRows(acc);
+    };
+    double aD[4], aL[4] = {0, 0, 0, 0};
+    double y;
+    int lateSpins = 0;
+    // tile (kb+1, kb) sits right before the pivot tile (kb+1, kb+1), the pivot tile (kb, kb) kb + 2 tiles before that
+    const double* Dn = tileAt(tiles, nT - 1, nT - 1);   // pivot tile of the block whose operands are requested next
+    {
+      double lD[4];
+      diagOps(Dn, lD);
+      const double rv = rhs[16 * (nT - 1) + c];
+      if (nT > 1) { belowOps(Dn - kTile, aL); Dn -= (size_t)nT * kTile; diagOps(Dn, aD); }
+      y = matVec(lD, rv);
     }
-    ldsBarrier();
+    CHOL_STAMP(15, 0);   // first block solved, loop entry
+#pragma unroll 2
+    for (int kb = nT - 2; kb >= 0; --kb) {
+      const int k0 = 16 * kb;
+      CHOL_STAMP_FINE(14, kb);
+      if (g == 0) rhs[k0 + 16 + c] = y;
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(ySteps, nT - 1 - kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      LDS_ORDER();
+      const bool far = kb + 2 < nT;
+      int f = far ? __hip_atomic_load(farDone + kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1;
+      LDS_ORDER();
+      double rr = rhs[k0 + c];
+      double nD[4] = {0, 0, 0, 0}, nL[4] = {0, 0, 0, 0};
+      if (kb > 0) { belowOps(Dn - kTile, nL); Dn -= (size_t)(kb + 1) * kTile; diagOps(Dn, nD); }
+      __builtin_amdgcn_sched_barrier(0);
+      CHOL_STAMP_FINE(17, kb);
+      const double tv = matVec(aL, y);
+      CHOL_STAMP_FINE(18, kb);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(f));   // the flag is looked at HERE, not where it was requested
+      int spins = 0;
+      while (f < 1) {   // the helper is late: ask again (flag first, data behind it)
+        LDS_ORDER();
+        f = __hip_atomic_load(farDone + kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        LDS_ORDER();
+        rr = rhs[k0 + c];
+        if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+      }
+      lateSpins += spins;
+      CHOL_STAMP_FINE(19, kb);
+      y = matVec(aD, rr - tv);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { aD[q] = nD[q]; aL[q] = nL[q]; }
+    }
+    CHOL_STAMP(16, 0);   // loop exit
+    if (g == 0) rhs[c] = y;
+#ifdef SVIN_CHOL_TIMING
+    if (lane == 0) p.partial[(size_t)15 * 4096 + 5] += (double)lateSpins;
+#endif
+  } else {
+    // target blocks of this wave: wave - 1 and wave + 6 (nT <= 11: blocks 0 .. nT-3 have contributions from further down)
+    const int tgt0 = wave - 1, tgt1 = wave + 6;
+    const bool on0 = tgt0 + 2 < nT, on1 = tgt1 + 2 < nT;
+    double s0 = 0, s1 = 0;
+    const double rhs0 = on0 ? rhs[16 * tgt0 + c] : 0.0, rhs1 = on1 ? rhs[16 * tgt1 + c] : 0.0;   // final since the barrier above
+    if (on0) {
+      for (int j = nT - 1; j >= tgt0 + 2; --j) {
+        const bool use1 = on1 && j >= tgt1 + 2;
+        const double* L0 = tileAt(tiles, j, tgt0);
+        const double* L1 = tileAt(tiles, j, use1 ? tgt1 : tgt0);
+        double l0[4], l1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { l0[q] = L0[lrow + 4 * q * kPanelLd]; l1[q] = L1[lrow + 4 * q * kPanelLd]; }
+        // the flag alone is polled (one broadcast read per round): seven waves re-reading y_j with every poll kept the LDS
+        // pipe ~80 % busy and wave 0's own LDS traffic queued behind them
+        int spins = 0;
+        while (__hip_atomic_load(ySteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nT - j) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+        }
+        LDS_ORDER();
+        double yj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yj[q] = rhs[16 * j + 4 * q + g];
+        if (use1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s1 = __builtin_fma(l1[q], yj[q], s1);
+          if (j == tgt1 + 2) {
+            const double tot = sumLaneRows(s1);
+            if (g == 0) rhs[16 * tgt1 + c] = rhs1 - tot;
+            LDS_ORDER();
+            if (lane == 0) __hip_atomic_store(farDone + tgt1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0 = __builtin_fma(l0[q], yj[q], s0);
+      }
+      const double tot = sumLaneRows(s0);
+      if (g == 0) rhs[16 * tgt0 + c] = rhs0 - tot;
+      LDS_ORDER();
+      if (lane == 0) __hip_atomic_store(farDone + tgt0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
+#undef LDS_ORDER
+  __syncthreads();
 #ifdef SVIN_CHOL_TIMING
   if (t == 0) p.partial[(size_t)15 * 4096 + 4] += (double)(__builtin_readcyclecounter() - q5);
+  if (t < 240) p.partial[(size_t)15 * 4096 + 64 + t] = stampBuf[t];
 #endif
   if (t < d) { p.yC[t] = rhs[t]; p.vC[t] = gFullMine / htil[t]; }  // Gauss-Newton solution + steepest-descent direction
 #undef CHOL_T0
 #undef CHOL_WAITED
 #undef CHOL_STAMP
+#undef CHOL_STAMP_FINE
 }
 
 // ================================================================ K6': reduced systems beyond the LDS-resident solver
@@ -4545,7 +4694,11 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
+#ifdef SVIN_CHOL_TIMING
+  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 3 * dpad) * 8 + kCholFlagInts * 4 + 240 * 8;
+#else
   const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 3 * dpad) * 8 + kCholFlagInts * 4;
+#endif
   if (ldsBytes <= 156 * 1024) {
     ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,

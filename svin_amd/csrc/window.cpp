@@ -1758,10 +1758,10 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
 #endif
   if (solveMs) *solveMs = timeIt([&]() { launchSolveReduced(p, s); });
   if (getenv("SVIN_CHOL_TIMING")) {
-    double dbg[5];
+    double dbg[6];
     HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096, sizeof(dbg), hipMemcpyDeviceToHost));
-    std::printf("[chol cycles per launch] load + first pivot tile %.0f  factorisation done (from kernel start) %.0f  backward substitution %.0f\n",
-                dbg[1] / iters, dbg[3] / iters, dbg[4] / iters);
+    std::printf("[chol cycles per launch] load + first pivot tile %.0f  factorisation done (from kernel start) %.0f  backward substitution %.0f (wave 0 asked %.1f times more for a late block)\n",
+                dbg[1] / iters, dbg[3] / iters, dbg[4] / iters, dbg[5] / iters);
 #ifdef SVIN_CHOL_TIMING
     {
       double w[16];
@@ -1774,13 +1774,14 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
     debugCholTiming(dd, false);
     std::printf("[pivot tiles, cycles per launch] %.0f\n", dd[0] / iters);
     {
-      double st[14 * 12];
+      double st[20 * 12];
       HIP_OK(hipMemcpy(st, p.partial + (size_t)15 * 4096 + 64, sizeof(st), hipMemcpyDeviceToHost));
-      const char* names[14] = {"w0 pivot start", "w0 pivot end", "w0 pivotDone set", "w0 at look-ahead wait", "w0 past the wait", "w0 panel solved",
+      const char* names[20] = {"w0 pivot start", "w0 pivot end", "w0 pivotDone set", "w0 at look-ahead wait", "w0 past the wait", "w0 panel solved",
                               "w0 xReady set", "owner: look-ahead row ready", "w1 load: issued|arrived|stored|barrier", "w5 (row 6) step start", "w5 pivot seen", "w5 panel tile out",
-                              "w5 operands there", "w5 row updated"};
+                              "w5 operands there", "w5 row updated", "back: w0 step start", "back: loop entry", "back: loop exit", "back: requests out",
+                              "back: first product done", "back: far part there"};
       std::printf("[stamps of the last launch, cycles from kernel start, per block column]\n");
-      for (int w = 0; w < 14; ++w) {
+      for (int w = 0; w < 20; ++w) {
         std::printf("  %-28s", names[w]);
         for (int kb = 0; kb < 11; ++kb) std::printf(" %7.0f", st[w * 12 + kb]);
         std::printf("\n");
