@@ -404,7 +404,7 @@ __device__ __forceinline__ double rcpPivot(double x) {
 // kInvOnly: D <- the TRANSPOSED inverse factor alone (upper triangle and diagonal L^-T, zeros below): every consumer that
 // multiplies with L^-1 reads the tile as it is, without a select per operand (k_chol_solve_lds never reads L of a pivot tile)
 template <bool kInvOnly = false>
-__device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv, int laneIn, int* failFlag) {
+__device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv, int laneIn, int* failFlag, long long* cyc = nullptr) {
   // opaque copy of the lane id: keeps the compiler from hoisting the per-lane masks of this routine out of the
   // caller's block-column loop
   int lane = laneIn;
@@ -474,8 +474,8 @@ __device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv,
   }
   if (bad && lane == 0) atomicOr(failFlag, 2);
 #ifdef SVIN_CHOL_TIMING
-  const long long qd2 = __builtin_readcyclecounter();
-  if (lane == 0) { g_cholDbg[0] += (double)(qd2 - qd0); }
+  // (kept in LDS-free form: a global read-modify-write here cost the instrumented chain ~1.3 k cycles per tile)
+  if (cyc) *cyc += __builtin_readcyclecounter() - qd0;
 #endif
 }
 __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane, int* failFlag) {
@@ -3397,14 +3397,20 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     const double* A = tileAt(tiles, I, kb);
     double a[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = -A[lop + 4 * q];
+    for (int q = 0; q < 4; ++q) {
+      a[q] = -A[lop + 4 * q];
+      asm volatile("" : "+v"(a[q]));   // negated once, kept (the compiler re-derives -x in front of every product otherwise)
+    }
     double* Cb = tileAt(tiles, I, kb + 1);
     const double* B = tileAt(tiles, kb + 1, kb);
     int rowTiles = kb + 2;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
     const int nTl = I - kb;  // tiles in this row segment
-    double b0[4], b1[4] = {0, 0, 0, 0};
-    d4_t c0, c1 = {0, 0, 0, 0};
-    double* Cf = Cb;   // fetch cursor (tile about to be requested); Cb stays on the pair being computed
+    // The body is BRANCH-FREE over a pair of tiles: every pass requests the next pair and runs eight products, whether the
+    // tiles exist or not (a row segment of odd length computes one product chain on whatever lies behind the row -- LDS reads
+    // past the tiles are harmless -- and does not store it).  With the second tile and the prefetch under wave-uniform
+    // branches the compiler met every product at a control-flow join: worst-case s_nop 9 in front of it and s_waitcnt
+    // lgkmcnt(0/1) on the prefetch just issued -- 940 cycles per tile where the shared matrix pipe allows 560.
+    const double* Cf = Cb;   // fetch cursor (tile about to be requested); Cb stays on the pair being computed
     auto fetch = [&](double (&bq)[4], d4_t& cq) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) cq[rg] = Cf[lrow + 4 * rg * kPanelLd];
@@ -3414,30 +3420,37 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       ++rowTiles;
       Cf += kTile;
     };
-    fetch(b0, c0);
-    if (nTl > 1) fetch(b1, c1);
-    for (int J = 0; J < nTl; J += 2) {
-      const bool two = J + 1 < nTl;
-      double nb0[4] = {0, 0, 0, 0}, nb1[4] = {0, 0, 0, 0};
-      d4_t nc0 = {0, 0, 0, 0}, nc1 = {0, 0, 0, 0};
-      if (J + 2 < nTl) fetch(nb0, nc0);
-      if (J + 3 < nTl) fetch(nb1, nc1);
+    auto products = [&](const double (&p0)[4], d4_t& q0, const double (&p1)[4], d4_t& q1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[q], c0, 0, 0, 0);
-        if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], c1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], p0[q], q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], p1[q], q1, 0, 0, 0);
       }
+    };
+    auto store = [&](const d4_t& q0, const d4_t& q1, bool two) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kPanelLd] = c0[rg];
+      for (int rg = 0; rg < 4; ++rg) Cb[lrow + 4 * rg * kPanelLd] = q0[rg];
       if (two) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Cb[kTile + lrow + 4 * rg * kPanelLd] = c1[rg];
+        for (int rg = 0; rg < 4; ++rg) Cb[kTile + lrow + 4 * rg * kPanelLd] = q1[rg];
       }
       Cb += 2 * kTile;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { b0[q] = nb0[q]; b1[q] = nb1[q]; }
-      c0 = nc0;
-      c1 = nc1;
+    };
+    // two register sets take turns (no rotation copies): set X is computed while set Y is in flight
+    double bx0[4], bx1[4], by0[4], by1[4];
+    d4_t cx0, cx1, cy0, cy1;
+    fetch(bx0, cx0);
+    fetch(bx1, cx1);
+    for (int J = 0; J < nTl; J += 4) {
+      fetch(by0, cy0);
+      fetch(by1, cy1);
+      products(bx0, cx0, bx1, cx1);
+      store(cx0, cx1, J + 1 < nTl);
+      if (J + 2 >= nTl) break;
+      fetch(bx0, cx0);
+      fetch(bx1, cx1);
+      products(by0, cy0, by1, cy1);
+      store(cy0, cy1, J + 3 < nTl);
     }
   };
   if (wave == 0) {
@@ -3449,14 +3462,21 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     tileSelect(0, 0, v0);
     if (fuseFinalize) dampDiag(0, true, hc0, sc0, v0);
     d4_t accD = {v0[0], v0[1], v0[2], v0[3]};
+#ifdef SVIN_CHOL_TIMING
+    long long pivotCycles = 0;
+#endif
     for (int kb = 0; kb < nT; ++kb) {
       const int k0 = 16 * kb;
       double* D = tileAt(tiles, kb, kb);
       CHOL_STAMP(0, kb);
+#ifdef SVIN_CHOL_TIMING
+      cholDiag16Acc<true>(accD, D, dinv + k0, lane, &p.scal->cholFail, &pivotCycles);
+#else
       cholDiag16Acc<true>(accD, D, dinv + k0, lane, &p.scal->cholFail);
-      CHOL_STAMP(1, kb);
+#endif
+      CHOL_STAMP_FINE(1, kb);
       cholFlagSet(fl + 0, kb + 1, lane);
-      CHOL_STAMP(2, kb);
+      CHOL_STAMP_FINE(2, kb);
       if (kb == 0) {
         if (t < dpad) { rhs[t] = rhsMine; if (!fuseFinalize) htil[t] = htilOld; }
         ldsBarrier();   // the other waves have stored their tiles (their only barrier before the backward substitution)
@@ -3465,23 +3485,26 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #endif
       }
       if (kb + 1 < nT) {
-        CHOL_STAMP(3, kb);
+        CHOL_STAMP_FINE(3, kb);
         if (kb > 0) { CHOL_T0; cholFlagWait(fl + 13 + kb + 1, kb, bail); CHOL_WAITED; }
-        CHOL_STAMP(4, kb);
+        CHOL_STAMP_FINE(4, kb);
         double* A = tileAt(tiles, kb + 1, kb);
         const double* Cb = tileAt(tiles, kb + 1, kb + 1);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) accD[rg] = Cb[lrow + 4 * rg * kPanelLd];
         const d4_t xT = panelSolve(A, D, k0);
-        CHOL_STAMP(5, kb);
+        CHOL_STAMP_FINE(5, kb);
         // the first product of the diagonal update is on the matrix pipe while the stores of X drain and the flag goes out
         accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[0], xT[0], accD, 0, 0, 0);
         cholFlagSet(fl + 1 + kb + 1, kb + 1, lane);
-        CHOL_STAMP(6, kb);
+        CHOL_STAMP_FINE(6, kb);
 #pragma unroll
         for (int q = 1; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-xT[q], xT[q], accD, 0, 0, 0);
       }
     }
+#ifdef SVIN_CHOL_TIMING
+    if (lane == 0) g_cholDbg[0] += (double)pivotCycles;
+#endif
   } else {
     // ------------------------------------------------------------------------------------------ load (waves 1-7)
     {
@@ -3512,14 +3535,14 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       }
 #pragma unroll
       for (int it = 0; it < kMaxOff; ++it) tileRequest(oI[it], oJ[it], vo[it]);
-      if (wave == 1) CHOL_STAMP(8, 0);   // requests issued
+      if (wave == 1) CHOL_STAMP_FINE(8, 0);   // requests issued
       __builtin_amdgcn_sched_barrier(0);   // nothing that consumes a loaded value moves above this line: one batch of ~44 loads
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) tileSelect(dI[sl], dI[sl], vd[sl]);
 #pragma unroll
       for (int it = 0; it < kMaxOff; ++it) tileSelect(oI[it], oJ[it], vo[it]);
 #ifdef SVIN_CHOL_TIMING
-      if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP(8, 1); }   // all values have arrived
+      if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP_FINE(8, 1); }   // all values have arrived
 #endif
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
@@ -3540,10 +3563,10 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         }
       }
     }
-    if (wave == 1) CHOL_STAMP(8, 2);   // tiles stored to LDS
+    if (wave == 1) CHOL_STAMP_FINE(8, 2);   // tiles stored to LDS
     if (t < dpad) { rhs[t] = rhsMine; if (!fuseFinalize) htil[t] = htilOld; }
     ldsBarrier();   // LDS only: the global stores of the metric (scaleC / htilC) need not have landed
-    if (wave == 1) CHOL_STAMP(8, 3);   // past the load barrier
+    if (wave == 1) CHOL_STAMP_FINE(8, 3);   // past the load barrier
     const int quiet = nW / 2;  // shares SIMD 0 with wave 0
     if (wave == quiet) {
       // ---------------------------------------------------------------------------------------- forward substitution
@@ -3589,25 +3612,25 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
           { CHOL_T0; cholFlagWait(fl + 1 + kb + 1, kb + 1, bail); CHOL_WAITED; }
           updateRow(la, kb);
           cholFlagSet(fl + 13 + la, kb + 1, lane);
-          CHOL_STAMP(7, kb);
+          CHOL_STAMP_FINE(7, kb);
         }
         for (int I = kb + 3; I < nT; ++I) {
           if (!owns(I)) continue;
-          if (wave == 5) CHOL_STAMP(9, kb);    // row 6: step start
+          if (wave == 5) CHOL_STAMP_FINE(9, kb);    // row 6: step start
           if (!waited) { CHOL_T0; cholFlagWait(fl + 0, kb + 1, bail); CHOL_WAITED; waited = true; }
-          if (wave == 5) CHOL_STAMP(10, kb);   // pivot seen
+          if (wave == 5) CHOL_STAMP_FINE(10, kb);   // pivot seen
           panelSolve(tileAt(tiles, I, kb), D, k0);
           cholFlagSet(fl + 1 + I, kb + 1, lane);
-          if (wave == 5) CHOL_STAMP(11, kb);   // panel tile out
+          if (wave == 5) CHOL_STAMP_FINE(11, kb);   // panel tile out
         }
         for (int I = kb + 3; I < nT; ++I) {
           if (!owns(I)) continue;
           // needs the panel tiles of rows kb+1 .. I-1 (row I is mine)
           { CHOL_T0; cholFlagWaitAll(fl + 1 + kb + 1, I - kb - 1, kb + 1, lane, bail); CHOL_WAITED; }
-          if (wave == 5) CHOL_STAMP(12, kb);   // operands there
+          if (wave == 5) CHOL_STAMP_FINE(12, kb);   // operands there
           updateRow(I, kb);
           cholFlagSet(fl + 13 + I, kb + 1, lane);
-          if (wave == 5) CHOL_STAMP(13, kb);   // row updated
+          if (wave == 5) CHOL_STAMP_FINE(13, kb);   // row updated
         }
       }
     }
