@@ -3238,17 +3238,18 @@ __device__ __forceinline__ void cholFlagSet(int* f, int v, int lane) {
 // kSleep: s_sleep units (64 clocks) between polls -- 1 on the waves whose wait is on the critical path, more for the wave
 // that shares wave 0's SIMD (every poll of a waiting wave takes issue slots from the pivot routine)
 template <int kSleep = 1>
-__device__ __forceinline__ void cholFlagWait(int* f, int v, int* bail) {
+__device__ __forceinline__ int cholFlagWait(int* f, int v, int* bail) {   // returns the number of polls that failed
   int spins = 0;
   while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
     __builtin_amdgcn_s_sleep(kSleep);
     if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
   }
   asm volatile("" ::: "memory");
+  return spins;
 }
 // all of f[0 .. n) >= v, polled with one LDS read per round (lane j reads f[j])
 template <int kSleep = 1>
-__device__ __forceinline__ void cholFlagWaitAll(int* f, int n, int v, int lane, int* bail) {
+__device__ __forceinline__ int cholFlagWaitAll(int* f, int n, int v, int lane, int* bail) {
   int spins = 0;
   while (true) {
     const int x = (lane < n) ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : v;
@@ -3257,6 +3258,7 @@ __device__ __forceinline__ void cholFlagWaitAll(int* f, int n, int v, int lane, 
     if (++spins > (1 << 18)) { __hip_atomic_store(bail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
   }
   asm volatile("" ::: "memory");
+  return spins;
 }
 // Round 3: the factorisation has NO workgroup barrier between the load and the backward substitution.  Round 2 ran two
 // phases per block column with a barrier after each (P: panel solves, D: pivot tile on wave 0 next to the trailing update of
@@ -3295,8 +3297,10 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #ifdef SVIN_CHOL_TIMING
   const long long ql0 = __builtin_readcyclecounter();
   long long qWait = 0, qBusy = 0;
-#define CHOL_T0 const long long qa_ = __builtin_readcyclecounter()
-#define CHOL_WAITED qWait += __builtin_readcyclecounter() - qa_
+// time spent waiting on flags, in failed polls (~150-200 cycles each: s_sleep 1 + an LDS read); a cycle stamp on either side of
+// every wait costs more than most waits (s_memtime + its s_waitcnt: ~250 cycles)
+#define CHOL_SPINS(x) qWait += (x)
+#define CHOL_NOTE(which, kb, val) do { if (lane == 0) stampBuf[(which) * 12 + (kb)] = (double)(val); } while (0)
 // raw stamp `which` of block column kb, relative to the kernel start (last launch wins)
 // (into LDS, copied out at the end: a global store per stamp makes the next acquire fence wait for it -- ~1 k cycles)
   double* stampBuf = reinterpret_cast<double*>(fl + kCholFlagInts);
@@ -3309,8 +3313,8 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #endif
 #else
 #define CHOL_STAMP_FINE(which, kb)
-#define CHOL_T0
-#define CHOL_WAITED
+#define CHOL_SPINS(x) (void)(x)
+#define CHOL_NOTE(which, kb, val) (void)(val)
 #define CHOL_STAMP(which, kb)
 #endif
   const int ldS = p.ldS ? p.ldS : d;
@@ -3393,7 +3397,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   // independent accumulators: the four products of one tile are a dependent chain (64 cycles each on the matrix pipe), a
   // second chain fills the gaps -- with two owner waves per SIMD the pipe stays busy -- and the operands of the next pair
   // are in flight meanwhile.  The A operand X(I, kb) is read once per row, B / C tiles are walked by pointer increments.
-  auto updateRow = [&](int I, int kb) {
+  auto updateRow = [&](int I, int kb, int skip) {   // tiles (I, kb+1+skip .. I)
     const double* A = tileAt(tiles, I, kb);
     double a[4];
 #pragma unroll
@@ -3401,10 +3405,10 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       a[q] = -A[lop + 4 * q];
       asm volatile("" : "+v"(a[q]));   // negated once, kept (the compiler re-derives -x in front of every product otherwise)
     }
-    double* Cb = tileAt(tiles, I, kb + 1);
-    const double* B = tileAt(tiles, kb + 1, kb);
-    int rowTiles = kb + 2;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
-    const int nTl = I - kb;  // tiles in this row segment
+    double* Cb = tileAt(tiles, I, kb + 1 + skip);
+    const double* B = tileAt(tiles, kb + 1 + skip, kb);
+    int rowTiles = kb + 2 + skip;  // tiles in the block row of B's tile: the next row's tile (., kb) lies that many tiles on
+    const int nTl = I - kb - skip;  // tiles in this row segment
     // The body is BRANCH-FREE over a pair of tiles: every pass requests the next pair and runs eight products, whether the
     // tiles exist or not (a row segment of odd length computes one product chain on whatever lies behind the row -- LDS reads
     // past the tiles are harmless -- and does not store it).  With the second tile and the prefetch under wave-uniform
@@ -3453,6 +3457,22 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       store(cy0, cy1, J + 3 < nTl);
     }
   };
+  // tile (I, kb+1) -= X(I, kb) X(kb+1, kb)^T alone: the one tile of row I that the NEXT column's panel solve needs
+  auto updateOne = [&](int I, int kb) {
+    const double* A = tileAt(tiles, I, kb);
+    const double* B = tileAt(tiles, kb + 1, kb);
+    double* C = tileAt(tiles, I, kb + 1);
+    double a[4], b[4];
+    d4_t cq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = -A[lop + 4 * q]; b[q] = B[lop + 4 * q]; }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) cq[rg] = C[lrow + 4 * rg * kPanelLd];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cq = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], cq, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) C[lrow + 4 * rg * kPanelLd] = cq[rg];
+  };
   if (wave == 0) {
     // ------------------------------------------------------------------------------------------ the serial chain
     double v0[4];
@@ -3486,7 +3506,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       }
       if (kb + 1 < nT) {
         CHOL_STAMP_FINE(3, kb);
-        if (kb > 0) { CHOL_T0; cholFlagWait(fl + 13 + kb + 1, kb, bail); CHOL_WAITED; }
+        if (kb > 0) { const int sp = cholFlagWait(fl + 13 + kb + 1, kb, bail); CHOL_SPINS(sp); CHOL_NOTE(3, kb, sp); }
         CHOL_STAMP_FINE(4, kb);
         double* A = tileAt(tiles, kb + 1, kb);
         const double* Cb = tileAt(tiles, kb + 1, kb + 1);
@@ -3568,69 +3588,90 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     ldsBarrier();   // LDS only: the global stores of the metric (scaleC / htilC) need not have landed
     if (wave == 1) CHOL_STAMP_FINE(8, 3);   // past the load barrier
     const int quiet = nW / 2;  // shares SIMD 0 with wave 0
-    if (wave == quiet) {
-      // ---------------------------------------------------------------------------------------- forward substitution
-      for (int kb = 0; kb < nT; ++kb) {
-        const int k0 = 16 * kb;
-        const double* D = tileAt(tiles, kb, kb);
-        { CHOL_T0; cholFlagWait<8>(fl + 0, kb + 1, bail); CHOL_WAITED; }
-        double yv = 0;   // y'_kb = L_kb^-1 rhs_kb: column c of the stored L^-T (zeros below its diagonal)
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) yv = __builtin_fma(D[cc * kPanelLd + c], rhs[k0 + cc], yv);
-        waveSync();
-        if (lane < 16) rhs[k0 + lane] = yv;
-        waveSync();
-        if (kb + 1 < nT) {
-          { CHOL_T0; cholFlagWaitAll<8>(fl + 1 + kb + 1, nT - kb - 1, kb + 1, lane, bail); CHOL_WAITED; }
-          for (int i = k0 + 16 + lane; i < dpad; i += 64) {
-            const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
-            double sacc = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
-            rhs[i] -= sacc;
-          }
-          waveSync();
-        }
-      }
-    } else {
-      // ---------------------------------------------------------------------------------------- tile-row owners
-      const int widx = wave - 1 - (wave > quiet ? 1 : 0), nWork = nW - 2;
-      auto owns = [&](int I) {   // rows nT-1 .. 2 dealt largest first and back again
-        const int n = nT - 1 - I, turn = n / nWork, pos = n - turn * nWork;
-        return ((turn & 1) ? nWork - 1 - pos : pos) == widx;
-      };
-      for (int kb = 0; kb + 2 < nT; ++kb) {
+    {
+      // ------------------------------------------------------------------ tile-row owners (and the forward substitution)
+      // Rows nT-1 .. nT-6: ONE row per owner wave (1-3, 5-7).  The rows above those (2 .. nT-7: rows 2 and 3 at nT = 10) go to the
+      // wave that shares SIMD 0 with wave 0, ahead of its forward substitution: they are the look-ahead rows of the first
+      // columns, and on an owner wave they queued behind that wave's other row -- wave 0 polled 36 + 15 times (~9 k cycles)
+      // for rows 3 and 4 while their owner finished four more tiles of the column before.  SIMD 0's matrix pipe carries wave
+      // 0's sixteen products per column; ten more chains in the first two columns cost it less than those waits.
+      const bool isQuiet = wave == quiet;
+      // waves w and w + 4 share a SIMD: the longest row goes with the shortest (9 | 4, 8 | 5, 7 | 6 at nT = 10) -- two long rows on
+      // one matrix pipe starve each other (their look-ahead turns came 5 k cycles late), two short ones leave it idle
+      const int nWork = nW - 2, widx = wave < quiet ? wave - 1 : nWork + quiet - wave;
+      const int rowMaxQ = nT - 1 - nWork;   // last row of the quiet wave (none if < 2)
+      auto owns = [&](int I) { return isQuiet ? (I >= 2 && I <= rowMaxQ) : (I > rowMaxQ && nT - 1 - I == widx); };
+      const int kbEnd = isQuiet ? rowMaxQ - 1 : nT - 2;   // columns kb < kbEnd have work for this wave
+      // Per column kb and own row I (ascending, the look-ahead row kb+2 first):  panel tile X(I, kb);  then tile (I, kb+1) ALONE
+      // -- it needs wave 0's panel tile only -- and, if pivot kb+1 is out already (rows far from the diagonal run behind wave 0),
+      // the panel tile X(I, kb+1) right away: the other rows wait for panel tiles, not for finished rows, and an owner that
+      // first completes its whole row (up to nine products) holds all of them up;  then the rest of the row.
+      unsigned early = 0;   // bit I: X(I, kb+1) was solved ahead of column kb+1
+      for (int kb = 0; kb < kbEnd; ++kb) {
         const int k0 = 16 * kb;
         const double* D = tileAt(tiles, kb, kb);
         bool waited = false;
-        // the look-ahead row kb+2 is what wave 0 waits for next: its panel tile and its two tiles come before anything else
-        const int la = kb + 2;
-        if (owns(la)) {
-          { CHOL_T0; cholFlagWait(fl + 0, kb + 1, bail); CHOL_WAITED; waited = true; }
-          panelSolve(tileAt(tiles, la, kb), D, k0);
-          cholFlagSet(fl + 1 + la, kb + 1, lane);
-          { CHOL_T0; cholFlagWait(fl + 1 + kb + 1, kb + 1, bail); CHOL_WAITED; }
-          updateRow(la, kb);
-          cholFlagSet(fl + 13 + la, kb + 1, lane);
+        const unsigned done = early;
+        early = 0;
+        if (((done >> (kb + 2)) & 1) && owns(kb + 2)) {   // look-ahead row whose panel tile is there already
+          CHOL_SPINS(cholFlagWait(fl + 1 + kb + 1, kb + 1, bail));
+          updateRow(kb + 2, kb, 0);
+          cholFlagSet(fl + 13 + kb + 2, kb + 1, lane);
           CHOL_STAMP_FINE(7, kb);
         }
-        for (int I = kb + 3; I < nT; ++I) {
-          if (!owns(I)) continue;
-          if (wave == 5) CHOL_STAMP_FINE(9, kb);    // row 6: step start
-          if (!waited) { CHOL_T0; cholFlagWait(fl + 0, kb + 1, bail); CHOL_WAITED; waited = true; }
-          if (wave == 5) CHOL_STAMP_FINE(10, kb);   // pivot seen
+        for (int I = kb + 2; I < nT; ++I) {
+          if (!owns(I) || ((done >> I) & 1)) continue;
+          if (!waited) CHOL_SPINS(cholFlagWait(fl + 0, kb + 1, bail)); waited = true;
           panelSolve(tileAt(tiles, I, kb), D, k0);
           cholFlagSet(fl + 1 + I, kb + 1, lane);
-          if (wave == 5) CHOL_STAMP_FINE(11, kb);   // panel tile out
+          if (I == kb + 2) {   // the look-ahead row: wave 0 waits for its two tiles next
+            CHOL_SPINS(cholFlagWait(fl + 1 + kb + 1, kb + 1, bail));
+            updateRow(I, kb, 0);
+            cholFlagSet(fl + 13 + I, kb + 1, lane);
+            CHOL_STAMP_FINE(7, kb);
+          }
         }
         for (int I = kb + 3; I < nT; ++I) {
           if (!owns(I)) continue;
-          // needs the panel tiles of rows kb+1 .. I-1 (row I is mine)
-          { CHOL_T0; cholFlagWaitAll(fl + 1 + kb + 1, I - kb - 1, kb + 1, lane, bail); CHOL_WAITED; }
-          if (wave == 5) CHOL_STAMP_FINE(12, kb);   // operands there
-          updateRow(I, kb);
+          CHOL_SPINS(cholFlagWait(fl + 1 + kb + 1, kb + 1, bail));
+          updateOne(I, kb);
+          if (__hip_atomic_load(fl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= kb + 2) {
+            asm volatile("" ::: "memory");
+            panelSolve(tileAt(tiles, I, kb + 1), tileAt(tiles, kb + 1, kb + 1), k0 + 16);
+            cholFlagSet(fl + 1 + I, kb + 2, lane);
+            early |= 1u << I;
+          }
+          {
+            // the rest needs the panel tiles of rows kb+2 .. I-1 (row I is mine)
+            CHOL_SPINS(cholFlagWaitAll(fl + 1 + kb + 2, I - kb - 2, kb + 1, lane, bail));
+            updateRow(I, kb, 1);
+          }
           cholFlagSet(fl + 13 + I, kb + 1, lane);
-          if (wave == 5) CHOL_STAMP_FINE(13, kb);   // row updated
+        }
+      }
+      if (isQuiet) {
+        // ------------------------------------------------------------------------------------ forward substitution
+        for (int kb = 0; kb < nT; ++kb) {
+          const int k0 = 16 * kb;
+          const double* D = tileAt(tiles, kb, kb);
+          CHOL_SPINS(cholFlagWait<8>(fl + 0, kb + 1, bail));
+          double yv = 0;   // y'_kb = L_kb^-1 rhs_kb: column c of the stored L^-T (zeros below its diagonal)
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) yv = __builtin_fma(D[cc * kPanelLd + c], rhs[k0 + cc], yv);
+          waveSync();
+          if (lane < 16) rhs[k0 + lane] = yv;
+          waveSync();
+          if (kb + 1 < nT) {
+            CHOL_SPINS(cholFlagWaitAll<8>(fl + 1 + kb + 1, nT - kb - 1, kb + 1, lane, bail));
+            for (int i = k0 + 16 + lane; i < dpad; i += 64) {
+              const double* row = tileAt(tiles, i >> 4, kb) + (i & 15) * kPanelLd;
+              double sacc = 0;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) sacc += row[k] * rhs[k0 + k];
+              rhs[i] -= sacc;
+            }
+            waveSync();
+          }
         }
       }
     }
@@ -3787,8 +3828,8 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   if (t < 240) p.partial[(size_t)15 * 4096 + 64 + t] = stampBuf[t];
 #endif
   if (t < d) { p.yC[t] = rhs[t]; p.vC[t] = gFullMine / htil[t]; }  // Gauss-Newton solution + steepest-descent direction
-#undef CHOL_T0
-#undef CHOL_WAITED
+#undef CHOL_SPINS
+#undef CHOL_NOTE
 #undef CHOL_STAMP
 #undef CHOL_STAMP_FINE
 }

@@ -1766,7 +1766,7 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
     {
       double w[16];
       HIP_OK(hipMemcpy(w, p.partial + (size_t)15 * 4096 + 32, sizeof(w), hipMemcpyDeviceToHost));
-      std::printf("[per wave: cycles until its part of the factorisation was done | of which waiting on flags]");
+      std::printf("[per wave: cycles until its part of the factorisation was done | failed flag polls (~150-200 cycles each)]");
       for (int k = 0; k < 8; ++k) std::printf("  w%d %.0f | %.0f", k, w[k] / iters, w[8 + k] / iters);
       std::printf("\n");
     }
@@ -1776,7 +1776,7 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
     {
       double st[20 * 12];
       HIP_OK(hipMemcpy(st, p.partial + (size_t)15 * 4096 + 64, sizeof(st), hipMemcpyDeviceToHost));
-      const char* names[20] = {"w0 pivot start", "w0 pivot end", "w0 pivotDone set", "w0 at look-ahead wait", "w0 past the wait", "w0 panel solved",
+      const char* names[20] = {"w0 pivot start", "w0 pivot end", "w0 pivotDone set", "w0 look-ahead wait (polls)", "w0 past the wait", "w0 panel solved",
                               "w0 xReady set", "owner: look-ahead row ready", "w1 load: issued|arrived|stored|barrier", "w5 (row 6) step start", "w5 pivot seen", "w5 panel tile out",
                               "w5 operands there", "w5 row updated", "back: w0 step start", "back: loop entry", "back: loop exit", "back: requests out",
                               "back: first product done", "back: far part there"};
