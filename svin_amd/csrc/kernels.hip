@@ -4542,7 +4542,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
         for (int q = 0; q < 4; ++q) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[q], x[q], accD, 0, 0, 0);
       }
       LLT(6);
-      cholDiag16Acc(accD, diagBuf, dinv16, lane, fail);
+      cholDiag16Acc<true>(accD, diagBuf, dinv16, lane, fail);   // diagBuf <- L_kk^-T (zeros below the diagonal)
       LLT(7);
     } else if (worker) {
       if (k >= 1) {
@@ -4637,15 +4637,12 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
     // ================= phase P(k): panel solve of block column k; wave 0: y_k and the write-through of the diagonal tile
     if (wave == 0) {
       const int li = cc;
-      double yv = rhs[k0 + li] * dinv16[li];
+      double yv = 0;
 #pragma unroll
-      for (int c = 0; c < 15; ++c) {
-        const double term = diagBuf[c * kPanelLd + li] * rhs[k0 + c];
-        yv += (c < li) ? term : 0.0;
-      }
+      for (int c = 0; c < 16; ++c) yv = __builtin_fma(diagBuf[c * kPanelLd + li], rhs[k0 + c], yv);   // row li of L_kk^-1
       double dv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { const int e = lane + 64 * m; dv[m] = diagBuf[(e & 15) * kPanelLd + (e >> 4)]; }   // transposed: the backward solve reads columns
+      for (int m = 0; m < 4; ++m) { const int e = lane + 64 * m; dv[m] = diagBuf[(e & 15) * kPanelLd + (e >> 4)]; }   // transposed: L_kk^-1 row-major, as the backward solve reads it
       const double di = dinv16[cc];
       waveSync();
       if (lane < 16) rhs[k0 + lane] = yv;
@@ -4658,7 +4655,7 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kk = 4 * q + g;
-        li4[q] = (cc > kk) ? diagBuf[kk * kPanelLd + cc] : ((cc == kk) ? dinv16[kk] : 0.0);
+        li4[q] = diagBuf[kk * kPanelLd + cc];   // L_kk^-1[cc][kk]
       }
       const int nv = rowsOf(k);
       if (nv > 0) llPanel<1>(li4, Tc[0], Tc[1], Tc[2]);
@@ -4686,62 +4683,171 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
     double* stage = smem;
     const int cap = (int)(((size_t)llSlots(nT) * 256 + 512 + 16 * kPanelLd + 16) / 256) - (dpad + 255) / 256 - 1;
     double* dinvAll = stage + (size_t)cap * 256;   // dpad doubles
-    // a batch (<= 75 tiles = 38 doubles per thread) is requested in one go; the next batch's values wait in registers while
-    // the current one is swept, so only the first round trip to L2 is exposed
-    constexpr int kHold = 38;
-    double hold[kHold];
+    // Round 3: the tile rows come back through the LDS-DMA path (global_load_lds_dwordx4: 1 KB per wave instruction, no
+    // register round trip, no ds_write pass) into TWO half-size buffers: while one batch of whole tile rows is solved and swept,
+    // the next one streams in.  (Through registers -- 38 doubles per thread per batch, then 38 ds_writes -- staging cost 7.5 k
+    // cycles per batch, more than the solves of the batch.)
+    const int capHalf = cap / 2;   // >= nT tiles: the longest tile row fits (cap >= 2 nT for 12 <= nT <= 17)
     auto batchLo = [&](int top) {
       int lo = top, used = top + 1;
-      while (lo > 0 && used + lo <= cap) { used += lo; --lo; }   // rows lo .. top, row i = i + 1 tiles (diagonal included)
+      while (lo > 0 && used + lo <= capHalf) { used += lo; --lo; }   // rows lo .. top, row i = i + 1 tiles (diagonal included)
       return lo;
     };
-    // global order is row-major over (i, j): a batch is one contiguous range of tiles
-    auto request = [&](int lo, int top) {
-      const int e0 = lo * (lo + 1) / 2 * 256, e1 = (top + 1) * (top + 2) / 2 * 256;
-#pragma unroll
-      for (int m = 0; m < kHold; ++m) hold[m] = Lg[min(e0 + t + m * kLLThreads, e1 - 1)];
+    // global order is row-major over (i, j): a batch is one contiguous range of tiles, copied linearly
+    auto request = [&](int lo, int top, double* buf) {
+      const size_t e0 = (size_t)(lo * (lo + 1) / 2) * 256;
+      const int nChunks = ((top + 1) * (top + 2) / 2 - lo * (lo + 1) / 2) * 2;   // 1 KB each
+      const char* src = reinterpret_cast<const char*>(Lg + e0) + lane * 16;
+      for (int ch = wave; ch < nChunks; ch += kLLThreads / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ch * 1024),
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(buf) + (size_t)ch * 1024), 16, 0, 0);
     };
+    // Round 3: no barrier per tile row.  Per batch (tile rows lo .. top staged in LDS) wave 0 runs the chain -- per row two
+    // dependent 16 x 16 matrix-vector products on the VALU, the vector replicated over the lane rows (colToRowForm /
+    // sumLaneRows, as in k_chol_solve_lds: ~450 cycles per row against ~2.8 k for a 16-term dot product per lane, a sweep and
+    // two barriers) -- and takes the contribution of row i + 1 to block i itself; waves 1-7 own the columns (thread t - 64 =
+    // column) and sweep row j over the columns left of block j - 1 as soon as y_j is flagged.  Hand-overs through two kinds
+    // of monotonic LDS counters (progress value of row j: nT - j), no fences (DS operations of a wave execute in order).
+    int* yCount = reinterpret_cast<int*>(damp);   // damp is dead after the factorisation
+    int* sweepCount = yCount + 1;                 // [wave]
+    int* bailB = yCount + 9;
+    if (t < 16) yCount[t] = 0;
+#ifdef SVIN_LL_TIMING
+    long long bsStage = 0, bsChain = 0, bsTail = 0, bsSpins = 0, bsMark = __builtin_readcyclecounter();
+#define BST(acc) do { const long long n_ = __builtin_readcyclecounter(); acc += n_ - bsMark; bsMark = n_; } while (0)
+#else
+#define BST(acc) do { } while (0)
+#endif
     int top = nT - 1;
-    request(batchLo(top), top);
-    for (int i = t; i < dpad; i += blockDim.x) dinvAll[i] = dinvG[i];
+    double swAcc[3] = {0, 0, 0};
+    // (buffer addresses by arithmetic on `stage`: picked out of an array of pointers they lose their LDS address space and every
+    //  tile read turns into a FLAT load)
+    int cur = 0;
+    request(batchLo(top), top, stage);
+    (void)dinvAll;
+    (void)dinvG;
     while (top >= 0) {
       const int lo = batchLo(top);
-      const int firstTile = lo * (lo + 1) / 2, nTilesB = (top + 1) * (top + 2) / 2 - firstTile;
+      const int firstTile = lo * (lo + 1) / 2;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the batch have landed
+      ldsBarrier();                                       // ... and everybody else's; the other buffer is free
+      if (lo > 0) request(batchLo(lo - 1), lo - 1, stage + (size_t)((cur ^ 1) * capHalf) * 256);
+      BST(bsStage);
+      double* stageB = stage + (size_t)(cur * capHalf) * 256;
+      auto tileB = [&](int i, int j) { return stageB + (size_t)(i * (i + 1) / 2 - firstTile + j) * 256; };
+      if (wave == 0) {
+        // row-major unpadded tiles: entry (4q + g, c) of a tile sits at lane + 64 q -- both products read their matrix like that
+        auto ops = [&](const double* tile, double (&o)[4]) {
 #pragma unroll
-      for (int m = 0; m < kHold; ++m) { const int e = t + m * kLLThreads; if (e < nTilesB * 256) stage[e] = hold[m]; }
-      if (lo > 0) request(batchLo(lo - 1), lo - 1);
-      ldsBarrier();
-      // x_i = L_ii^-T y_i by the wave that owns block i of the right-hand side (threads 16 i .. 16 i + 15 all sit in wave
-      // i / 4): after the sweep of row i + 1 it can go on to the next solve without a workgroup barrier.  The diagonal tile
-      // is staged transposed: Dt[r * 16 + li] = Linv[r][li]
-      auto solveRow = [&](int i) {
-        const double* Dt = stage + (size_t)(i * (i + 1) / 2 - firstTile + i) * 256;
-        const int li = cc;
-        double yv = rhs[16 * i + li] * dinvAll[16 * i + li];
+          for (int q = 0; q < 4; ++q) o[q] = tile[lane + 64 * q];
+        };
+        auto matVec = [&](const double (&m)[4], double v) {   // sum_k m[k][c] v[k], replicated
+          double vq[4];
+          colToRowForm(v, vq);
+          double acc = m[0] * vq[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) {
-          const double term = Dt[r * 16 + li] * rhs[16 * i + r];
-          yv += (r > li) ? term : 0.0;
+          for (int q = 1; q < 4; ++q) acc = __builtin_fma(m[q], vq[q], acc);
+          return sumLaneRows(acc);
+        };
+        // "the sweeps of rows top .. `row` have reached the columns of `block`" + the block itself, requested together (flag
+        // first: DS operations execute in order) and looked at after the product that does not depend on them
+        auto sweepFlag = [&](int block) { return __hip_atomic_load(sweepCount + 1 + (block % 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        double aD[4], aL[4] = {0, 0, 0, 0};
+        ops(tileB(top, top), aD);
+        double y = 0;
+        for (int i = top; i >= lo; --i) {
+          double nD[4] = {0, 0, 0, 0}, nL[4] = {0, 0, 0, 0};
+          if (i < top) {   // y_{i+1} out first: the sweepers start on it while this row is solved
+            if (g == 0) rhs[16 * (i + 1) + cc] = y;
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(yCount, nT - (i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+          }
+          const int need = (i + 2 <= top) ? nT - (i + 2) : 0;
+          int f = sweepFlag(i);
+          asm volatile("" ::: "memory");
+          double rr = rhs[16 * i + cc];
+          if (i > lo) { ops(tileB(i - 1, i - 1), nD); ops(tileB(i, i - 1), nL); }
+          __builtin_amdgcn_sched_barrier(0);
+          const double tv = (i < top) ? matVec(aL, y) : 0.0;
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" : "+v"(f));
+          int spins = 0;
+          while (f < need) {
+            asm volatile("" ::: "memory");
+            f = sweepFlag(i);
+            asm volatile("" ::: "memory");
+            rr = rhs[16 * i + cc];
+#ifdef SVIN_LL_TIMING
+            ++bsSpins;
+#endif
+            if (++spins > (1 << 18)) { __hip_atomic_store(bailB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+          }
+          y = matVec(aD, rr - tv);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { aD[q] = nD[q]; aL[q] = nL[q]; }
         }
-        waveSync();
-        if (lane < 16) rhs[16 * i + lane] = yv;
-      };
-      if (wave == (top >> 2)) solveRow(top);
-      ldsBarrier();
-      for (int i = top; i >= lo; --i) {
-        const double* rowT = stage + (size_t)(i * (i + 1) / 2 - firstTile) * 256;   // tiles (i, 0 .. i)
-        if (t < 16 * i) {
-          const double* col = rowT + (size_t)(t >> 4) * 256 + (t & 15);   // L(16 i + kk, t)
-          double s = 0;
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) s += col[kk * 16] * rhs[16 * i + kk];
-          rhs[t] -= s;
+        if (g == 0) rhs[16 * lo + cc] = y;
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(yCount, nT - lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (lo > 0) {   // the contribution of row lo to block lo - 1 (its tile leaves LDS with this batch)
+          double bL[4];
+          ops(tileB(lo, lo - 1), bL);
+          const double tv = matVec(bL, y);
+          if (lo + 1 <= top) {
+            int spins = 0;
+            while (sweepFlag(lo - 1) < nT - (lo + 1)) {
+              if (++spins > (1 << 18)) { __hip_atomic_store(bailB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+            }
+            asm volatile("" ::: "memory");
+          }
+          if (g == 0) rhs[16 * (lo - 1) + cc] -= tv;
         }
-        if (i - 1 >= lo && wave == ((i - 1) >> 2)) { waveSync(); solveRow(i - 1); }
-        ldsBarrier();
+      } else {
+        // Sweepers: wave w folds the rows further down into the blocks b = w - 1, w + 6, w + 13 (lane (g, c): four FMAs per row
+        // and block on the tile read as it lies, entry (4q + g, c) at lane + 64 q -- conflict-free; a thread per COLUMN read
+        // its tile 4-way conflicted, sixteen times per row, and seven such waves kept the LDS pipe busier than the chain could
+        // bear).  The sum over the lane rows waits until the block's last contribution (row b + 2), across batches.
+        for (int j = top; j >= lo; --j) {
+          int spins = 0;
+          while (__hip_atomic_load(yCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nT - j) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 18)) { __hip_atomic_store(bailB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+          }
+          asm volatile("" ::: "memory");
+          double yq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yq[q] = rhs[16 * j + 4 * q + g];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int bt = wave - 1 + 7 * u;
+            if (bt + 2 <= j) {
+              const double* tl = tileB(j, bt);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) swAcc[u] = __builtin_fma(tl[lane + 64 * q], yq[q], swAcc[u]);
+              if (bt + 2 == j) {
+                const double tot = sumLaneRows(swAcc[u]);
+                if (g == 0) rhs[16 * bt + cc] -= tot;
+              }
+            }
+          }
+          asm volatile("" ::: "memory");
+          if (lane == 0) __hip_atomic_store(sweepCount + wave, nT - j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+        }
       }
+      if (wave == 0) BST(bsChain);
+      BST(bsTail);
+      cur ^= 1;
       top = lo - 1;
     }
+    ldsBarrier();
+#ifdef SVIN_LL_TIMING
+    if (t == 0 && g_llCount == 12) printf("[ll backsub wave 0] staging + barrier %lld  chain %lld  waiting for the sweepers at the batch end %lld  late polls %lld\n", bsStage, bsChain, bsTail, bsSpins);
+#endif
+#undef BST
+    if (t == 0 && *bailB) atomicOr(fail, 4);
   }
   for (int i = t; i < d; i += blockDim.x) { p.yC[i] = rhs[i]; p.vC[i] = p.gFull[i] / p.htilC[i]; }  // + steepest-descent direction
 #ifdef SVIN_LL_TIMING
