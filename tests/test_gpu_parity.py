@@ -707,6 +707,24 @@ def test_left_looking_lds_solver_sizes(gpu_lib, P, rig):
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("P", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+def test_lds_resident_solver_sizes(gpu_lib, P):
+    """Reduced systems of 2..11 tile rows (d = 15 P <= 176) go through the LDS-resident barrier-free Cholesky
+    (k_chol_solve_lds): its row ownership changes with the tile-row count (one row per owner wave for the last six rows, the rows
+    above them on the wave next to the chain's), so every count is run as a whole optimisation against the oracle."""
+    spec = syn.make_window(P=P, L=400, n_obs=4000, seed=200 + P, rig="euroc", frame_dt=0.25)
+    gpu, cpu, fg, fc, lg, lc = make_pair(spec)
+    gpu.optimize(8)
+    cpu.optimize(8)
+    sg, sc = gpu.summary(), cpu.summary()
+    worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(fg, fc))
+    log("LDS-resident solver P", P, "gpu", sg, "cpu", sc, "pose diff", worst)
+    assert sg["iterations"] == sc["iterations"] and sg["successful"] == sc["successful"]
+    assert sg["final_cost"] < sg["initial_cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+    assert worst < 1e-4
+
+
 def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
     """the landmark-sharded solve (2 ranks emulated by 2 threads on one GPU, all-reduce through a
     barrier) must reproduce the single-GPU solve."""
