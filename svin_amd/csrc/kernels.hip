@@ -3357,19 +3357,30 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   // that row (hC, scaleC) are requested together with the tile; `dampDiag` then adds mu * htil to the entry and keeps htil.
   const bool diagLane = ((c - g) & 3) == 0 && c >= g;
   const int diagReg = (c - g) >> 2;
+  // (the metric's global stores are handed back to the caller: waves 1-7 issue them AFTER the load barrier, whose vmcnt(0) --
+  //  for the LDS-DMA pieces -- would otherwise wait for them too)
+  struct MetricOut { int i; double sc, ht; };
   auto dampDiag = [&](int I, bool valid, double hc, double scIn, double (&v)[4]) {
     const int i = 16 * I + c;
     double damp = 0.0;
+    MetricOut out{-1, 0.0, 0.0};
     if (valid && diagLane && i < d) {
       double sc = scIn;
-      if (initScale) { sc = 1.0 / (1.0 + sqrt(hc)); p.scaleC[i] = sc; }
+      if (initScale) sc = 1.0 / (1.0 + sqrt(hc));
       const double ht = fmin(fmax(hc * sc * sc, 1e-6), 1e32) / (sc * sc);
-      p.htilC[i] = ht;
       htil[i] = ht;
       damp = mu * ht;
+      out = MetricOut{i, sc, ht};
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) v[rg] += (rg == diagReg) ? damp : 0.0;
+    return out;
+  };
+  auto storeMetric = [&](const MetricOut& m) {
+    if (m.i >= 0) {
+      if (initScale) p.scaleC[m.i] = m.sc;
+      p.htilC[m.i] = m.ht;
+    }
   };
   // (rhsMine / htilOld go to LDS right before the load barrier: storing them here would wait for their loads before the
   //  first tile load is issued)
@@ -3480,7 +3491,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     const int i0 = min(c, d - 1);
     const double hc0 = fuseFinalize ? p.hC[i0] : 0.0, sc0 = (fuseFinalize && !initScale) ? p.scaleC[i0] : 1.0;
     tileSelect(0, 0, v0);
-    if (fuseFinalize) dampDiag(0, true, hc0, sc0, v0);
+    if (fuseFinalize) storeMetric(dampDiag(0, true, hc0, sc0, v0));
     d4_t accD = {v0[0], v0[1], v0[2], v0[3]};
 #ifdef SVIN_CHOL_TIMING
     long long pivotCycles = 0;
@@ -3527,18 +3538,24 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #endif
   } else {
     // ------------------------------------------------------------------------------------------ load (waves 1-7)
-    {
-      // Diagonal tiles 1 .. nT-1: tile `wave` and tile 7 + `wave` (nT <= 11); off-diagonal tiles dealt round robin, at most
-      // eight per wave (55 at nT = 11).  Tile indices are scalar and computed first, so that what follows is ONE batch of
+    // The wave next to wave 0 loads nothing: the two share SIMD 0's VALU, and while wave 0 factorises its first tile the address
+    // arithmetic of a loader there took twice as long as anywhere else (it reached the load barrier 1.4-2.5 k cycles after the
+    // other six) and slowed that first pivot tile down as well.
+    const int ldr = wave < nW / 2 ? wave - 1 : wave - 2;   // loader index 0 .. 5 (waves 1-3, 5-7)
+    if (wave != nW / 2) {
+      // Diagonal tiles 1 .. nT-1: tiles 1 + ldr and 7 + ldr (nT <= 11); off-diagonal tiles dealt round robin, at most
+      // ten per loader (55 at nT = 11).  Tile indices are scalar and computed first, so that what follows is ONE batch of
       // loads without a branch in it (out-of-range slots re-read a valid tile and are not stored).
-      constexpr int kMaxOff = 8;
+      constexpr int kMaxOff = 10, kLoaders = 6;
       const int nOff = nT * (nT - 1) / 2;
       int dI[2], oI[kMaxOff], oJ[kMaxOff];
-      dI[0] = min(wave, nT - 1);
-      dI[1] = min(7 + wave, nT - 1);
+      dI[0] = min(1 + ldr, nT - 1);
+      dI[1] = min(7 + ldr, nT - 1);
+      const bool dmaOff = p.sPadded != 0;
 #pragma unroll
       for (int it = 0; it < kMaxOff; ++it) {
-        const int e = min((wave - 1) + 7 * it, max(nOff - 1, 0));
+        if (dmaOff) { oI[it] = 1; oJ[it] = 0; continue; }   // (the DMA path walks whole tile rows: no index search)
+        const int e = min(ldr + kLoaders * it, max(nOff - 1, 0));
         // I (I - 1) / 2 <= e < I (I + 1) / 2 without a loop (ten independent scalar compares; a search loop costs a
         // dependent multiply per step and these indices gate the very first loads): e <= 54 at nT = 11
         const int I = 1 + (e >= 1) + (e >= 3) + (e >= 6) + (e >= 10) + (e >= 15) + (e >= 21) + (e >= 28) + (e >= 36) + (e >= 45);
@@ -3546,6 +3563,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         oJ[it] = __builtin_amdgcn_readfirstlane(e - I * (I - 1) / 2);
       }
       double vd[2][4], hcv[2], scv[2], vo[kMaxOff][4];
+      MetricOut metricOut[2] = {{-1, 0.0, 0.0}, {-1, 0.0, 0.0}};
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         tileRequest(dI[sl], dI[sl], vd[sl]);
@@ -3553,35 +3571,76 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         hcv[sl] = fuseFinalize ? p.hC[i] : 0.0;
         scv[sl] = (fuseFinalize && !initScale) ? p.scaleC[i] : 1.0;
       }
+      // Off-diagonal tiles of a padded S go through the LDS-DMA path (global_load_lds_dwordx4: 16 bytes per lane, 1 KB of
+      // CONSECUTIVE LDS per wave instruction, no register round trip and no ds_write pass).  The 16 x 17 tile is 136 pairs
+      // of doubles; pair p sits in row (2p) / 17 at column (2p) % 17 and is two consecutive doubles of S as well -- also
+      // across the padding column: (row, 16) | (row + 1, 0) is fetched from one double to the left of the next row's first
+      // element (what lands in the padding is never read).  Three instructions per tile, the third on eight lanes.
+      if (dmaOff) {
+        const double* laneSrc[3];
 #pragma unroll
-      for (int it = 0; it < kMaxOff; ++it) tileRequest(oI[it], oJ[it], vo[it]);
+        for (int k = 0; k < 3; ++k) {
+          const int off = 2 * (lane + 64 * k), row = (off * 241) >> 12, col = off - 17 * row;   // off / 17 for off < 272
+          laneSrc[k] = p.S + ((col == 16) ? (row + 1) * ldS - 1 : row * ldS + col);
+        }
+        // whole tile rows, the longest with the shortest (rows 1 + ldr and nT - 1 - ldr: 10-11 tiles per loader at nT = 10, 11):
+        // along a row the tiles are 16 columns apart in S and adjacent in LDS -- two pointer increments per tile
+        auto dmaRow = [&](int I) {
+          size_t so = (size_t)(16 * I) * ldS;
+          char* dst = reinterpret_cast<char*>(tileAt(tiles, I, 0));
+          for (int J = 0; J < I; ++J) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(laneSrc[0] + so),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(laneSrc[1] + so),
+                                             (__attribute__((address_space(3))) void*)(dst + 1024), 16, 0, 0);
+            if (lane < 8)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(laneSrc[2] + so),
+                                               (__attribute__((address_space(3))) void*)(dst + 2048), 16, 0, 0);
+            so += 16;
+            dst += kTile * 8;
+          }
+        };
+        const int rowA = 1 + ldr, rowB = nT - 1 - ldr;
+        if (rowB > rowA) dmaRow(rowB);
+        if (rowA <= rowB && rowA < nT) dmaRow(rowA);
+      } else {
+#pragma unroll
+        for (int it = 0; it < kMaxOff; ++it) tileRequest(oI[it], oJ[it], vo[it]);
+      }
       if (wave == 1) CHOL_STAMP_FINE(8, 0);   // requests issued
       __builtin_amdgcn_sched_barrier(0);   // nothing that consumes a loaded value moves above this line: one batch of ~44 loads
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) tileSelect(dI[sl], dI[sl], vd[sl]);
+      if (!dmaOff) {
 #pragma unroll
-      for (int it = 0; it < kMaxOff; ++it) tileSelect(oI[it], oJ[it], vo[it]);
+        for (int it = 0; it < kMaxOff; ++it) tileSelect(oI[it], oJ[it], vo[it]);
+      }
 #ifdef SVIN_CHOL_TIMING
       if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP_FINE(8, 1); }   // all values have arrived
 #endif
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
-        const bool valid = (sl == 0 ? wave : 7 + wave) < nT;
-        if (fuseFinalize) dampDiag(dI[sl], valid, hcv[sl], scv[sl], vd[sl]);
+        const bool valid = (sl == 0 ? 1 + ldr : 7 + ldr) < nT;
+        if (fuseFinalize) metricOut[sl] = dampDiag(dI[sl], valid, hcv[sl], scv[sl], vd[sl]);
         if (valid) {
           double* dst = tileAt(tiles, dI[sl], dI[sl]);
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) dst[lrow + 4 * rg * kPanelLd] = vd[sl][rg];
         }
       }
+      if (!dmaOff) {
 #pragma unroll
-      for (int it = 0; it < kMaxOff; ++it) {
-        if ((wave - 1) + 7 * it < nOff) {
-          double* dst = tileAt(tiles, oI[it], oJ[it]);
+        for (int it = 0; it < kMaxOff; ++it) {
+          if (ldr + kLoaders * it < nOff) {
+            double* dst = tileAt(tiles, oI[it], oJ[it]);
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) dst[lrow + 4 * rg * kPanelLd] = vo[it][rg];
+            for (int rg = 0; rg < 4; ++rg) dst[lrow + 4 * rg * kPanelLd] = vo[it][rg];
+          }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of this wave have landed
+      storeMetric(metricOut[0]);
+      storeMetric(metricOut[1]);
     }
     if (wave == 1) CHOL_STAMP_FINE(8, 2);   // tiles stored to LDS
     if (t < dpad) { rhs[t] = rhsMine; if (!fuseFinalize) htil[t] = htilOld; }
