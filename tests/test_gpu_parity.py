@@ -725,6 +725,18 @@ def test_lds_resident_solver_sizes(gpu_lib, P):
     assert worst < 1e-4
 
 
+def test_one_workgroup_solvers_repeat_themselves(gpu_lib):
+    """The two one-workgroup dense solvers hand tiles between their waves through LDS counters without fences (DS operations of
+    a wave execute in order).  A hand-over that is wrong once in a thousand launches would show as a run that ends differently:
+    25 repeated optimisations for every tile-row count (2..18 keyframes), all must reproduce the first
+    (tools/solver_stress.py; 600 repetitions = 77 000 solver launches were run when the scheme went in)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "solver_stress.py"), "25"], capture_output=True, text=True, timeout=600)
+    log(r.stdout[-600:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
     """the landmark-sharded solve (2 ranks emulated by 2 threads on one GPU, all-reduce through a
     barrier) must reproduce the single-GPU solve."""
