@@ -48,8 +48,9 @@ __device__ __forceinline__ double readlaneD(double v, int srcLane) {
 }
 template <int kCtrl>
 __device__ __forceinline__ double dppRowMov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, false);
+  // (only used with row rotations: every lane receives a value, so no `old` operand has to be zeroed first)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), kCtrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), kCtrl, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double rowSum16(double v) {  // sum over the 16 lanes of a DPP row, in every lane

@@ -230,8 +230,8 @@ template <int kCtrl>
 __device__ __forceinline__ double dppRowMov(double v) {
   const long long b = __double_as_longlong(v);
   int lo = (int)b, hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, kCtrl, 0xf, 0xf, false);   // (row rotations only: every lane receives a value)
+  hi = __builtin_amdgcn_mov_dpp(hi, kCtrl, 0xf, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
 }
 // sum over the 16 lanes of a DPP row, in every lane; all 16 lanes must be active.  (__shfl_xor(.., 16) compiles to
