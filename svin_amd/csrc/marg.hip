@@ -286,7 +286,9 @@ __shared__ JacobiShared gJacobiShared;
 // LPG lanes per pair; P = lds_double* (the LDS images: every column has jacobiLd(n) addressable entries with a zero
 // tail) or double* (global memory, leading dimension n).
 // Returns the number of sweeps.  kHasQ: rotate the rows of Q along with G (compile-time: each use gets a straight-line round).
-template <int LPG, class P, bool kHasQ>
+// NU > 0: the columns have exactly NU slices of LPG entries (compile-time: the register loops of a round then have no exit
+// test between their LDS reads -- with the test each slice was its own LDS round trip, three in a row at n = 45)
+template <int LPG, class P, bool kHasQ, int NU = 0>
 __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag) {
   constexpr bool padded = std::is_same<P, lds_double*>::value;
   constexpr int kRegCols = kJacobiRegLen / LPG;
@@ -334,12 +336,19 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag) {
         double al = 0, be = 0, ga = 0;
         double xs[kRegCols], ys[kRegCols];
         if (inRegs) {
+          if (NU > 0) {
 #pragma unroll
-          for (int u = 0; u < kRegCols; ++u) {
-            if (LPG * u >= n) break;
-            const double x = gp[LPG * u], y = gq[LPG * u];
-            xs[u] = x; ys[u] = y;
-            al += x * x; be += y * y; ga += x * y;
+            for (int u = 0; u < (NU > 0 ? NU : 1); ++u) { xs[u] = gp[LPG * u]; ys[u] = gq[LPG * u]; }
+#pragma unroll
+            for (int u = 0; u < (NU > 0 ? NU : 1); ++u) { al += xs[u] * xs[u]; be += ys[u] * ys[u]; ga += xs[u] * ys[u]; }
+          } else {
+#pragma unroll
+            for (int u = 0; u < kRegCols; ++u) {
+              if (LPG * u >= n) break;
+              const double x = gp[LPG * u], y = gq[LPG * u];
+              xs[u] = x; ys[u] = y;
+              al += x * x; be += y * y; ga += x * y;
+            }
           }
         } else {
           for (int i = gl; i < n; i += LPG) { const double x = gp[i - gl], y = gq[i - gl]; al += x * x; be += y * y; ga += x * y; }
@@ -353,11 +362,19 @@ __device__ int jacobiEigBlock(P G, P Q, int n, int ld, int* flag) {
         double c, s;
         jacobiRotation(al, be, ga, c, s);
         if (inRegs) {
+          if (NU > 0) {
 #pragma unroll
-          for (int u = 0; u < kRegCols; ++u) {
-            if (LPG * u >= n) break;
-            gp[LPG * u] = c * xs[u] - s * ys[u];
-            gq[LPG * u] = s * xs[u] + c * ys[u];
+            for (int u = 0; u < (NU > 0 ? NU : 1); ++u) {
+              gp[LPG * u] = c * xs[u] - s * ys[u];
+              gq[LPG * u] = s * xs[u] + c * ys[u];
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < kRegCols; ++u) {
+              if (LPG * u >= n) break;
+              gp[LPG * u] = c * xs[u] - s * ys[u];
+              gq[LPG * u] = s * xs[u] + c * ys[u];
+            }
           }
         } else {
           for (int i = gl; i < n; i += LPG) {
@@ -619,7 +636,21 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   }
   __syncthreads();
   const long long tPrep = wall_clock64(), cPrep = clock64();
-  jacobiEigBlock<kJacobiLanes, P, false>(lds, (P) nullptr, n, ld, a.flag);
+  if (inLds) {
+    switch ((n + kJacobiLanes - 1) / kJacobiLanes) {   // slices per column: <= 9 for the LDS image (n <= 136)
+      case 1: jacobiEigBlock<kJacobiLanes, P, false, 1>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 2: jacobiEigBlock<kJacobiLanes, P, false, 2>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 3: jacobiEigBlock<kJacobiLanes, P, false, 3>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 4: jacobiEigBlock<kJacobiLanes, P, false, 4>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 5: jacobiEigBlock<kJacobiLanes, P, false, 5>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 6: jacobiEigBlock<kJacobiLanes, P, false, 6>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 7: jacobiEigBlock<kJacobiLanes, P, false, 7>(lds, (P) nullptr, n, ld, a.flag); break;
+      case 8: jacobiEigBlock<kJacobiLanes, P, false, 8>(lds, (P) nullptr, n, ld, a.flag); break;
+      default: jacobiEigBlock<kJacobiLanes, P, false, 9>(lds, (P) nullptr, n, ld, a.flag); break;
+    }
+  } else {
+    jacobiEigBlock<kJacobiLanes, P, false>(lds, (P) nullptr, n, ld, a.flag);
+  }
   const long long tEig = wall_clock64(), cEig = clock64();
   // row j = sigma_j u_j
   for (int j = grp; j < n; j += nGroups) {
