@@ -351,6 +351,11 @@ int svin_ba_describe_block(svin_ba* h, uint64_t block_id, uint64_t* frame_id, in
  * milliseconds measured with HIP events on the handle's stream; *bytes_per_launch receives the
  * algorithmic byte count of one launch. */
 int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes_per_launch);
+/* the same, plus *back_to_back_ms: the `iters` launches enqueued back to back between ONE pair of HIP events, divided by
+ * `iters` (the write-back of launch i overlaps launch i + 1; a per-launch bracket can stop the clock while up to an
+ * Infinity Cache's worth of stores is still on the die) */
+int svin_ba_bench_jacobian_eval_b2b(svin_ba* h, int copies, int iters, double* mean_ms, double* back_to_back_ms,
+                                    double* bytes_per_launch);
 /* the collective of the sharded solve on its own: `iters` in-place FP64 sum all-reduces of n_doubles values through the
  * communicator of svin_ba_set_distributed_rccl, on the handle's stream, timed with HIP events (mean microseconds per
  * all-reduce).  Collective: every rank calls it with the same arguments. */

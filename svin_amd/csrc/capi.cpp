@@ -200,6 +200,10 @@ int svin_ba_get_summary(svin_ba* h, svin_summary* out) {
 }
 int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user) {
   if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SVIN_ERR_INVALID_ARG;
+  if (world > svin::kScalGatherSlots / 2) {   // every rank publishes its (gradient max, factorisation flag) pair in a slot of its own
+    svin::lastError() = "set_distributed: at most " + std::to_string(svin::kScalGatherSlots / 2) + " ranks (one node of MI355X)";
+    return SVIN_ERR_INVALID_ARG;
+  }
   h->w.setDistributed(rank, world, fn, user);
   return 1;
 }
@@ -210,6 +214,10 @@ int svin_ba_rccl_unique_id(unsigned char id_out[128]) {
 }
 int svin_ba_set_distributed_rccl(svin_ba* h, int rank, int world, const unsigned char id[128]) {
   if (!h || !id || world < 1 || rank < 0 || rank >= world) return SVIN_ERR_INVALID_ARG;
+  if (world > svin::kScalGatherSlots / 2) {
+    svin::lastError() = "set_distributed_rccl: at most " + std::to_string(svin::kScalGatherSlots / 2) + " ranks (one node of MI355X)";
+    return SVIN_ERR_INVALID_ARG;
+  }
   GUARD_BEGIN return h->w.setDistributedRccl(rank, world, id);
   GUARD_END(SVIN_ERR_DEVICE)
 }
@@ -545,6 +553,11 @@ int svin_ba_bench_allreduce(svin_ba* h, uint64_t n_doubles, int iters, double* m
 int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_bench_jacobian_eval_b2b(svin_ba* h, int copies, int iters, double* mean_ms, double* b2b_ms, double* bytes) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes, b2b_ms);
   GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_bench_kernel_times(svin_ba* h, int iters, double* e, double* b, double* s) {

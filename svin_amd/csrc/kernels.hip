@@ -3227,7 +3227,7 @@ constexpr int kCholFlagInts = 48;
 //   fl[1 + I]   xReady[I]  number of block columns for which the panel tile X(I, .) of tile row I is stored
 //   fl[13 + I]  rowUpd[I]  number of block columns applied to every tile of tile row I
 //   fl[27]      ySteps     solution blocks stored by the backward substitution; fl[28 + kb] farDone[kb] (see there)
-//   fl[26]      a bounded spin gave up (a bug, not a numerical event: reported through cholFail bit 2)
+//   fl[26]      a bounded spin gave up (a bug, not a numerical event: reported through cholFail bit 4 -- kCholFailSync, Window::solve throws on it)
 // Everything the flags guard lives in LDS, and the DS operations of one wave execute in issue order: "data stores, then flag
 // store" on the writer and "flag load, then data loads" on the reader are ordered by the hardware.  The compiler is held to
 // that order by memory clobbers; a release / acquire fence pair would add an s_waitcnt (one LDS round trip) on either side.
@@ -4058,7 +4058,7 @@ __global__ __launch_bounds__(256) void k_big_load(DeviceProblem p, int dpad, dou
 // number, which are either finished, running elsewhere or earlier in the same workgroup, so the waits cannot cycle.
 // Finished blocks cross XCD L2s: they are written and read with agent-scope relaxed atomics (sc1 accesses, coherent by
 // themselves), the writer waits for its stores to complete before ready[I][J] is set, the reader polls ready[I][J]
-// before it loads -- no L2 write-back / invalidate (buffer_wbl2 / buffer_inv cost ~10 us per hand-over here).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail instead of hanging.
+// before it loads -- no L2 write-back / invalidate (buffer_wbl2 / buffer_inv cost ~10 us per hand-over here).  Every wait is bounded (kSpinMax polls): a stuck wait raises cholFail bit 8 (kCholFailSync: Window::solve throws) instead of hanging.
 // (k_big_chol_chain below; its predecessors -- a launch pair per 64-wide panel, then plain block tasks without the
 // critical-path workgroup -- are in the history of this file.)
 constexpr int kSpinMax = 1 << 20;
@@ -4119,7 +4119,7 @@ __device__ __forceinline__ void tileMfmaSub(d4_t acc[4], const double* Xa, const
     }
 }
 __device__ __forceinline__ void tileWait(const int* flag, bool& gaveUp, int* fail) {
-  if (threadIdx.x == 0 && !gaveUp && !pollReady(flag)) { atomicOr(fail, 2); gaveUp = true; }
+  if (threadIdx.x == 0 && !gaveUp && !pollReady(flag)) { atomicOr(fail, 8); gaveUp = true; }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -4149,7 +4149,7 @@ __device__ __forceinline__ void tileAccumulate(d4_t acc[4], const TileLds& L, do
     if (k >= kSafe) {
       if (tid == 0 && !gaveUp) {
         const bool ok = pollReady(ready + I * nb + k) && pollReady(ready + J * nb + k);
-        if (!ok) { atomicOr(fail, 2); gaveUp = true; }
+        if (!ok) { atomicOr(fail, 8); gaveUp = true; }
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -4199,7 +4199,7 @@ __global__ __launch_bounds__(256) void k_big_chol_chain(DeviceProblem p, int dpa
         if (tid == 0 && !gaveUp) {
           bool ok = pollReady(ready + (J + 1) * nb + (J - 1));
           if (J >= 2) ok = ok && pollReady(pd + J) && pollReady(ps + J);
-          if (!ok) { atomicOr(fail, 2); gaveUp = true; }
+          if (!ok) { atomicOr(fail, 8); gaveUp = true; }
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -94,7 +94,8 @@ struct SolverScalars {
   // --- derived on the device from the (all-reduced) sums and the trust-region radius
   double jdSq, jdDotR;    // |J delta|^2 , (J delta).r   (model cost change)
   double doglegStepNorm;
-  int cholFail;           // != 0 when S or a landmark block is not positive definite
+  int cholFail;           // bits 1 | 2: S or a landmark block is not positive definite (numerical: the mu ladder retries);
+                          // bits 4 | 8 (kCholFailSync): a bounded device-side wait of a solver kernel gave up (a fault: solve() throws)
   int pad;
 };
 // pinned-host mailbox: the kernel that sums the cost publishes all scalars + the sequence number of that evaluation
@@ -102,6 +103,7 @@ struct ScalarMailbox {
   SolverScalars scal;
   unsigned long long seq;
 };
+constexpr int kCholFailSync = 4 | 8;
 constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGather = 16, kScalGatherSlots = 16;  // offsets (doubles) of the all-reduced groups
 
 struct DeviceProblem {

@@ -6,7 +6,7 @@
 // decisions read come from ONE record per evaluation (SolverScalars); in the landmark-sharded mode every field read here is
 // either all-reduced or computed redundantly from all-reduced data, so the ranks take identical decisions
 // (tests/test_trust_region_host.py feeds two instances the same reduced fields and different rank-local ones).
-// Included by window.cpp (the driver: launches + read-back) and by tests/csrc/trust_region_replay.cpp (g++, no GPU).
+// Included by window.cpp (the driver: launches + read-back) and by tests/csrc/trust_region_shim.cpp (g++, no GPU).
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -194,6 +194,7 @@ static void eraseOne(std::vector<uint64_t>& v, uint64_t x) {
 }
 uint64_t Window::addFactor(Factor&& f) {
   f.id = nextResId_++;
+  f.dealKey = factorSeq_++;
   for (int b = 0; b < f.nblk; ++b) blocks_.at(f.blocks[b]).residuals.push_back(f.id);
   const uint64_t id = f.id;
   factors_[id] = std::move(f);
@@ -952,12 +953,11 @@ void Window::pack() {
     kind = b.kind;
     slot = (b.kind == B_POSE) ? poseSlot_.at(id) : (b.kind == B_EXT ? extSlot_.at(id) : sbSlot_.at(id));
   };
-  // sharded mode: the small factors are dealt to the ranks frame by frame (factors are created in frame order: IMU factor
+  // sharded mode: the small factors are dealt to the ranks by creation number (factors are created in frame order: IMU factor
   // k -> k+1, the priors of a frame, its relative-extrinsics and sonar / depth terms); every rank still holds all states
-  int factorOrdinal = 0;
   for (auto& kv : factors_) {
     Factor& f = kv.second;
-    if (!ownsFactorOrdinal(factorOrdinal++)) continue;
+    if (!ownsFactor(f)) continue;
     DevFactor df;
     std::memset(&df, 0, sizeof(df));
     df.kind = f.kind; df.nblk = f.nblk; df.m = f.m; df.imuIndex = -1;
@@ -1225,6 +1225,11 @@ void Window::downloadStates() {
     Factor& f = factors_.at(fid);
     if (f.kind == F_IMU) f.imu = hImu[k++];
   }
+  // sharded: the IMU factors another rank evaluated were re-integrated (or not) over there; whoever evaluates them here next
+  // (rank 0's marginalisation job, a window that goes back to one GPU) starts from a fresh pre-integration
+  if (world_ > 1)
+    for (auto& kv : factors_)
+      if (kv.second.kind == F_IMU && !ownsFactor(kv.second)) kv.second.imu.redo = 1;
 }
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
@@ -1301,6 +1306,9 @@ void Window::solve(size_t numIter, bool verbose) {
   // fused step: the landmark half of the retraction rides in the candidate evaluation (k_eval_all), which reads every
   // landmark anyway -- the serial tail of k_post_solve only moves the ~20 parameter blocks
   const bool deferLm = fuseStep && canFuseEvaluation(p) && !getenv("SVIN_SPLIT_EVAL") && !getenv("SVIN_NO_DEFER_LM") && p.L > 0 && p.N > 0;
+  // the stop vote (k_set_stop_vote) travels in the slots k_post_solve uses for the fused dogleg coefficients of the deferred
+  // landmark step: the two never meet because a sharded solve takes neither the fused nor the deferred step
+  if (dist && (fuseStep || deferLm)) throw std::logic_error("sharded solve with a fused step");
   evaluateAll(false, s);
   AR(scalD, 4, 0);
   publish();
@@ -1376,12 +1384,22 @@ void Window::solve(size_t numIter, bool verbose) {
         accumulatorsClean = false;
         specValid = true;
       }
-      if (dist)   // this iteration will be complete when the vote is read: `iteration` already counts it
-        launchSetStopVote(p.scal, (timeLimit_ >= 0.0 && tr.iteration >= minIterations_ && (nowSec() - tStart) + lastIterTime > timeLimit_) ? 1.0 : 0.0, s);
+      if (dist) {  // this iteration will be complete when the vote is read: `iteration` already counts it, and its own duration
+                   // so far stands in for the callback's iteration_time_in_seconds (CeresIterationCallback.hpp:86-89)
+        const double tNow = nowSec();
+        launchSetStopVote(p.scal, (timeLimit_ >= 0.0 && tr.iteration >= minIterations_ && (tNow - tStart) + (tNow - tIter) > timeLimit_) ? 1.0 : 0.0, s);
+      }
       AR(scalD, 8, 0);
       publish();
       sc = readScalars();
       if (dist) stopVotes = sc.spareA0;
+      // failMax carries the cholFail bits (max over the ranks): 4 | 8 = a bounded wait inside a solver kernel timed out.  That is
+      // a synchronisation fault, not a numerical event -- it must not disappear into the mu ladder as "not positive definite"
+      if (toTr(sc).failMax >= 4.0) {
+        distNative_ = false;
+        throw std::runtime_error("svin_ba: a device-side wait in the reduced-system solver timed out (cholFail " +
+                                 std::to_string((int)toTr(sc).failMax) + "): synchronisation fault, not a numerical failure");
+      }
       if (tr.retryFactorisation(toTr(sc))) { specValid = false; continue; }   // (the speculative damping assumed an accepted step)
       break;
     }
@@ -1584,7 +1602,7 @@ int Window::getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids
 }
 
 // ------------------------------------------------------------------------------------------ measurement hooks
-int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* bytes) {
+int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* bytes, double* backToBackMs) {
   pack();
   const DeviceProblem& p = prob_;
   const size_t N = (size_t)p.N, NB = N * copies;
@@ -1634,8 +1652,19 @@ int Window::benchJacobianEval(int copies, int iters, double* meanMs, double* byt
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     total += ms;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (meanMs) *meanMs = total / iters;
+  // the same launches back to back under ONE event pair: the drain of launch i (its last stores leaving the Infinity Cache)
+  // overlaps launch i + 1 instead of being cut off by the stop event -- the figure a per-launch bracket cannot flatter
+  if (backToBackMs) {
+    HIP_OK(hipEventRecord(e0, stream_));
+    for (int it = 0; it < iters; ++it) launchEvalReprojBatched(q, copies, r, Jp, Jl, Je, stream_);
+    HIP_OK(hipEventRecord(e1, stream_));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    *backToBackMs = (double)ms / iters;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   // algorithmic bytes per residual: read uv 16 + w 8 + packed index 4 + landmark index 4
   // + landmark 32/obs-per-landmark; write r 16 + Jp 96 + Jl 48 (+ Je 96 when extrinsics are variable)
   const double perRes = 16 + 8 + 4 + 4 + 32.0 * p.L / (double)N + 16 + 96 + 48 + (p.anyExtVariable ? 96 : 0);

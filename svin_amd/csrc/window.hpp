@@ -75,6 +75,7 @@ struct Factor {
   std::vector<uint32_t> imuT;   // 2 per sample
   std::vector<double> imuMeas;  // 6 per sample
   DevImu imu;                   // persistent pre-integration state (synced back after each solve)
+  uint64_t dealKey = 0;         // creation number among the factors of this window (which rank owns it in sharded mode)
 };
 
 struct StateInfo { uint64_t id = 0; bool exists = false; };
@@ -218,7 +219,9 @@ class Window {
   typedef int (*AllReduceFn)(void* ptr, uint64_t count, int op, void* user);
   void setDistributed(int rank, int world, AllReduceFn fn, void* user);
   void dropRcclComm();
-  bool ownsFactorOrdinal(int ordinal) const { return world_ <= 1 || ordinal % world_ == rank_; }
+  // sharded mode: a small factor belongs to the rank its creation number names.  The number is given once (addFactor) and
+  // never shifts when other factors leave the window, so an IMU factor's pre-integration state stays with one rank.
+  bool ownsFactor(const Factor& f) const { return world_ <= 1 || (int)(f.dealKey % (uint64_t)world_) == rank_; }
   // the same with RCCL called natively on the handle's stream (no host synchronisation, no callback): `id` is the
   // 128-byte ncclUniqueId rank 0 obtained from rcclUniqueId() and the host distributed to every rank
   static int rcclUniqueId(unsigned char* out128);
@@ -239,7 +242,7 @@ class Window {
   // 3 landmark; returns the ambient dimension (7 / 9 / 4) or SVIN_ERR_NOT_FOUND
   int getParameterBlock(uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed, int32_t* initialized) const;
   void parameterBlockIds(std::vector<uint64_t>& out) const;
-  int benchJacobianEval(int copies, int iters, double* meanMs, double* bytes);
+  int benchJacobianEval(int copies, int iters, double* meanMs, double* bytes, double* backToBackMs = nullptr);
   int benchAllReduce(size_t nDoubles, int iters, double* meanUs);   // native RCCL all-reduce on the solver stream, HIP events
   int benchKernelTimes(int iters, double* evalMs, double* buildMs, double* solveMs);
 
@@ -296,6 +299,7 @@ class Window {
   size_t numLandmarkPriors_ = 0;
   DevBuf<double> dLmPrior_;
   uint64_t nextResId_ = 1;
+  uint64_t factorSeq_ = 0;      // Factor::dealKey of the next factor
 
   // marginalisation prior (host bookkeeping + device matrices mirrored on the host for the C API)
   bool hasPrior_ = false;

@@ -56,7 +56,7 @@ EXPORTS = [
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
     "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
-    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_kernel_times",
+    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_bench_kernel_times",
     "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
     "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
@@ -154,6 +154,7 @@ def load_library():
     sig("svin_ba_get_prior", i32, vp, pd, pd, pd, pd, pu64, pi32, pi32, pi32, i32)
     sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
+    sig("svin_ba_bench_jacobian_eval_b2b", i32, vp, i32, i32, pd, pd, pd)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
     sig("svin_host_imu_propagation", i32, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd, pd)
     sig("svin_host_reprojection_error", i32, i32, pd, pd, i32, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd)
@@ -727,6 +728,12 @@ class Estimator:
         ms, by = np.zeros(1), np.zeros(1)
         self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
         return float(ms[0]), float(by[0])
+
+    def bench_jacobian_eval_b2b(self, copies, iters):
+        """(mean ms per launch with one event pair per launch, ms per launch with the launches back to back under one pair, bytes)"""
+        ms, b2b, by = np.zeros(1), np.zeros(1), np.zeros(1)
+        self._check(self.L.svin_ba_bench_jacobian_eval_b2b(self.h, copies, iters, _d(ms), _d(b2b), _d(by)), "bench_jacobian_eval_b2b")
+        return float(ms[0]), float(b2b[0]), float(by[0])
 
     def marg_pre(self):
         """system of the last marginalisation after M1, before M2 (needs SVIN_MARG_KEEP_PRE=1): dict(H, b0, lm ranges, dense ranges)
