@@ -346,6 +346,18 @@ int svin_ba_get_marg_pre_blocks(svin_ba* h, uint64_t* dense_ids, int32_t* dense_
 /* semantic description of an internal parameter-block id: kind 0 pose / 1 extrinsics / 2 speed-bias */
 int svin_ba_describe_block(svin_ba* h, uint64_t block_id, uint64_t* frame_id, int32_t* kind, int32_t* index);
 
+/* ---- device-resident window (design in svin_amd/csrc/resident.hpp).  A narrow window (<= 42 pose blocks, one
+ * GPU, no HomogeneousPointError) keeps its landmark-major observation table on the device from frame to frame: optimize()
+ * sends the observations added / removed since the last call and one kernel rebuilds the table (the reference re-reads
+ * its four hash containers, Map.cpp:341-376, :467-492).  mode 0 (default): resident whenever the window qualifies;
+ * mode 1: always the host path (graph -> arrays on the host, full upload) -- the form the tests compare the resident one with. */
+int svin_ba_set_pack_mode(svin_ba* h, int mode);
+/* inspection: builds the device tables exactly as optimize() would and copies the observation CSR back: sizes first (call
+ * with null arrays), then lm_ptr[L + 1], obs_lm[N], obs_idx[N] (pose slot | extrinsics slot << 12 | camera << 24), uv[2 N],
+ * w[N], lm[4 L], obs_order[N] (-1 when the window needs no per-chunk pose order); *resident = 1 when the resident path built it */
+int svin_ba_debug_csr(svin_ba* h, int32_t* n_landmarks, int32_t* n_observations, int32_t* lm_ptr, int32_t* obs_lm,
+                      uint32_t* obs_idx, double* uv, double* w, double* lm, int32_t* obs_order, int32_t* resident);
+
 /* ---- measurement hook: the Jacobian-evaluation kernel on `copies` replicas of the current window's
  * observation set (HBM-resident working set). Runs `iters` launches, returns the mean kernel time in
  * milliseconds measured with HIP events on the handle's stream; *bytes_per_launch receives the

@@ -120,14 +120,7 @@ uint64_t svin_ba_add_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_
 int svin_ba_add_observations(svin_ba* h, int n, const uint64_t* lm, const uint64_t* pose, const uint64_t* cam, const uint64_t* kp,
                              const double* uv, const double* size, uint64_t* out_ids) {
   if (!h || n < 0 || (n > 0 && (!lm || !pose || !cam || !kp || !uv || !size))) return SVIN_ERR_INVALID_ARG;
-  GUARD_BEGIN
-  int added = 0;
-  for (int i = 0; i < n; ++i) {
-    const uint64_t id = h->w.addObservation(lm[i], pose[i], cam[i], kp[i], uv + 2 * (size_t)i, size[i]);
-    if (out_ids) out_ids[i] = id;
-    added += id != 0;
-  }
-  return added;
+  GUARD_BEGIN return h->w.addObservations(n, lm, pose, cam, kp, uv, size, out_ids);
   GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_remove_observation(svin_ba* h, uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp) {
@@ -261,7 +254,7 @@ int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, 
 int svin_ba_get_landmark_observations(svin_ba* h, uint64_t id, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids,
                                       int cap) {
   if (!h || cap < 0) return SVIN_ERR_INVALID_ARG;
-  const Landmark* lm = h->w.landmark(id);
+  const Landmark* lm = h->w.landmarkGraph(id);
   if (!lm) return SVIN_ERR_NOT_FOUND;
   std::vector<const svin::Observation*> sorted;
   for (const svin::Observation& o : lm->obs) sorted.push_back(&o);
@@ -326,7 +319,7 @@ int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap) {
 }
 int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) {
   if (!h) return SVIN_ERR_INVALID_ARG;
-  const Landmark* lm = h->w.landmark(id);
+  const Landmark* lm = h->w.landmarkGraph(id);
   return lm ? (lm->initialized ? 1 : 0) : SVIN_ERR_NOT_FOUND;
 }
 int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t id, int initialized) {
@@ -366,7 +359,7 @@ int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_W
   splitSamples(imu, n_imu, t, m);
   return Window::initPoseFromImu(m.data(), n_imu, T_WS) ? 1 : 0;
 }
-int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) { return h && h->w.landmark(id) ? 1 : 0; }
+int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) { return h && h->w.landmarkExists(id) ? 1 : 0; }
 int svin_ba_set_T_WS(svin_ba* h, uint64_t id, const double T[7]) { return h ? h->w.set_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
 int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, const double sb[9]) {
   return h ? h->w.setSpeedAndBias(id, imu, sb) : SVIN_ERR_INVALID_ARG;
@@ -376,7 +369,7 @@ int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, cons
 }
 int svin_ba_set_landmark(svin_ba* h, uint64_t id, const double hp[4]) { return h ? h->w.setLandmark(id, hp) : SVIN_ERR_INVALID_ARG; }
 uint64_t svin_ba_num_frames(svin_ba* h) { return h ? h->w.states().size() : 0; }
-uint64_t svin_ba_num_landmarks(svin_ba* h) { return h ? h->w.landmarks().size() : 0; }
+uint64_t svin_ba_num_landmarks(svin_ba* h) { return h ? h->w.numLandmarks() : 0; }
 uint64_t svin_ba_current_keyframe_id(svin_ba* h) { return h ? h->w.currentKeyframeId() : 0; }
 uint64_t svin_ba_current_frame_id(svin_ba* h) { return (h && !h->w.states().empty()) ? h->w.states().rbegin()->first : 0; }
 uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age) { return h ? h->w.frameIdByAge(age) : 0; }
@@ -395,7 +388,7 @@ int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap) {
 int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   int n = 0;
-  for (auto& kv : h->w.landmarks()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
+  for (auto& kv : h->w.landmarksGraph()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
   return n;
 }
 int svin_ba_parameter_block_exists(svin_ba* h, uint64_t id) { return h ? (h->w.parameterBlockExists(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; }
@@ -553,6 +546,17 @@ int svin_ba_bench_allreduce(svin_ba* h, uint64_t n_doubles, int iters, double* m
 int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_ms, double* bytes) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_set_pack_mode(svin_ba* h, int mode) {
+  if (!h || mode < 0 || mode > 1) return SVIN_ERR_INVALID_ARG;
+  h->w.setPackMode(mode);
+  return 1;
+}
+int svin_ba_debug_csr(svin_ba* h, int32_t* n_landmarks, int32_t* n_observations, int32_t* lm_ptr, int32_t* obs_lm, uint32_t* obs_idx,
+                      double* uv, double* w, double* lm, int32_t* obs_order, int32_t* resident) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.debugCsr(n_landmarks, n_observations, lm_ptr, obs_lm, obs_idx, uv, w, lm, obs_order, resident);
   GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_bench_jacobian_eval_b2b(svin_ba* h, int copies, int iters, double* mean_ms, double* b2b_ms, double* bytes) {

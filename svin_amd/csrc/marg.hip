@@ -890,7 +890,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     ++rit;
   }
   // the job: residuals to linearise (copied out of the graph as they are removed) and blocks to marginalise
-  struct JobObs { Observation o; uint64_t lmId; };
+  struct JobObs { Observation o; uint64_t lmId, extId; };
   std::vector<Factor> jobFactors;
   std::vector<JobObs> jobObs;
   std::vector<uint64_t> toMarginalize;
@@ -898,9 +898,24 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
   std::vector<PriorBlockHost> dense = priorBlocks_;
   std::vector<uint64_t> lmOrder;
   std::unordered_map<uint64_t, std::vector<double>> lmLin;  // linearisation points of marginalised landmarks
+  // (one flag per block handle: the landmark pass asks "is it connected already" twice per linearised residual)
+  std::vector<char> connected[3];
+  for (int k = 0; k < 3; ++k) connected[k].assign(std::max(nextBlockH_[k], 1), 0);
+  for (const PriorBlockHost& pb : dense)
+    if (const Block* b = findBlock(pb.id)) connected[b->kind][b->handle] = 1;
+  auto connectBlock = [&](const Block& b) {
+    if (connected[b.kind][b.handle]) return;
+    connected[b.kind][b.handle] = 1;
+    PriorBlockHost pb;
+    pb.id = b.id; pb.kind = b.kind; pb.dim = (b.kind == B_SB) ? 9 : 7;
+    pb.mdim = b.fixed ? 0 : ((b.kind == B_SB) ? 9 : 6);
+    std::memcpy(pb.lin, b.x, sizeof(double) * pb.dim);
+    dense.push_back(pb);
+  };
   auto connectDense = [&](uint64_t id) {
     for (const PriorBlockHost& pb : dense) if (pb.id == id) return;
     const Block& b = blocks_.at(id);
+    connected[b.kind][b.handle] = 1;
     PriorBlockHost pb;
     pb.id = id; pb.kind = b.kind; pb.dim = (b.kind == B_SB) ? 9 : 7;
     pb.mdim = b.fixed ? 0 : ((b.kind == B_SB) ? 9 : 6);
@@ -914,7 +929,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     jobFactors.push_back(it->second);
     removeFactor(rid);
   };
-  auto isReproj = [&](uint64_t rid) { return obsRes2Lm_.count(rid) != 0; };
+  auto isReproj = [&](uint64_t rid) { return obsRes2Lm_.count(rid); };
   auto isPrior = [&](uint64_t rid) { return rid != 0 && !isReproj(rid) && !factors_.count(rid); };
 
   for (uint64_t fid : removeAllButPose) {  // :541-605
@@ -935,6 +950,14 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     }
   }
   bool reDoFixation = false;
+  bool landmarksDone = false;
+  // The job's observation tables come out of the device-resident CSR when it mirrors the graph as it is now (nothing was
+  // added or removed since the last solve); otherwise they are assembled here from the records the policy removes.
+  const bool deviceJob = residentValid_ && residentUsed_ && addLog_.empty() && remLog_.empty() && setLog_.empty() && res_.N == (int)numObs_;
+  if (!deviceJob) syncLandmarks();   // the linearisation points of the marginalised landmarks are read from the host graph
+  std::vector<unsigned char> poseClass;
+  std::vector<uint64_t> margLandmarks;
+  int nJobObs = 0;
   for (uint64_t fid : removeFrames) {  // :607-770
     auto it = states_.find(fid);
     it->second.pose.exists = false;
@@ -964,86 +987,92 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       for (uint64_t rid : res)
         if (!isReproj(rid) && factors_.count(rid)) addFactorToJob(rid);
     }
-    const uint64_t currentKfId = allLinearizedFrames.at(0);
-    const uint64_t newestLeaving = *std::max_element(removeFrames.begin(), removeFrames.end());
-    for (auto pit = landmarks_.begin(); pit != landmarks_.end();) {  // :671-766
-      Landmark& lm = pit->second;
-      // nobody in the leaving frames has seen it (its oldest observation is newer than all of them): the walk below
-      // would end in `skipLandmark` -- the common case, answered from one cached field
-      if (!lm.obs.empty() && lm.minPose > newestLeaving) { pit++; continue; }
-      bool skipLandmark = true, hasNewObservations = false, justDelete = false, marginalize = true, errorTermAdded = false;
-      size_t obsCount = 0;
-      // first pass straight over the observation list (no copies): most landmarks are skipped here
-      for (const Observation& o : lm.obs) {
-        const uint64_t poseId = o.poseId;
-        if (contains(removeFrames, poseId)) skipLandmark = false;
-        if (poseId >= currentKfId) { marginalize = false; hasNewObservations = true; }
-        if (contains(allLinearizedFrames, poseId)) obsCount++;
-      }
-      if (!lm.priors.empty()) { pit++; continue; }   // see the guard at the top
-      if (lm.obs.empty()) {
-        removed.push_back(pit->first);
-        pit = landmarks_.erase(pit);
-        continue;
-      }
-      if (skipLandmark) { pit++; continue; }
-      std::vector<uint64_t> residuals;
-      residuals.reserve(lm.obs.size());
-      for (const Observation& o : lm.obs) residuals.push_back(o.resId);
-      auto poseOf = [&](uint64_t rid) {
-        for (const Observation& o : lm.obs) if (o.resId == rid) return o.poseId;
-        return (uint64_t)0;
+    if (!landmarksDone) {  // :671-766
+      // The reference walks every landmark once per leaving frame.  What it does with a landmark depends only on the three
+      // frame sets, which are fixed for the whole call, and applying it a second time changes nothing -- so ONE pass, over the
+      // landmarks a leaving frame has seen (Block::seenLm) and the ones without observations, in handle order (the order of
+      // the device-resident CSR, whose gather kernel picks the same residuals: resident.hpp margObsAction).
+      landmarksDone = true;
+      const double tl0 = nowSec();
+      const size_t obs0 = numObs_;
+      const uint64_t currentKfId = allLinearizedFrames.at(0);
+      std::vector<unsigned char>& cls = poseClass;
+      cls.assign(std::max(nextBlockH_[B_POSE], 1), 0);
+      for (uint64_t f : removeFrames) cls[blocks_.at(f).handle] |= kMargRemove;
+      for (uint64_t f : allLinearizedFrames) cls[blocks_.at(f).handle] |= kMargLin;
+      for (auto st = states_.lower_bound(currentKfId); st != states_.end(); ++st)
+        if (const Block* pb = findBlock(st->second.pose.id)) cls[pb->handle] |= kMargNew;
+      std::vector<int> cand;
+      ++visitStamp_;
+      auto consider = [&](int h) {
+        Landmark* lp = (h >= 0 && h < (int)lmByHandle_.size()) ? lmByHandle_[h] : nullptr;
+        if (!lp || lp->visit == visitStamp_) return;
+        lp->visit = visitStamp_;
+        cand.push_back(h);
       };
-      auto dropObservation = [&](uint64_t rid) {   // Estimator::removeObservation(rid) on this landmark
-        for (size_t i = 0; i < lm.obs.size(); ++i)
-          if (lm.obs[i].resId == rid) { removeObsRecord(lm, i); return; }
-      };
-      for (size_t r = 0; r < residuals.size(); ++r) {
-        const uint64_t rid = residuals[r];
-        const uint64_t poseId = poseOf(rid);
-        if ((contains(removeFrames, poseId) && hasNewObservations) ||
-            (!contains(allLinearizedFrames, poseId) && marginalize)) {
-          dropObservation(rid);
-          residuals.erase(residuals.begin() + r);
-          r--;
-        } else if (marginalize && contains(allLinearizedFrames, poseId)) {
-          if (obsCount < 2) {
-            dropObservation(rid);
-            residuals.erase(residuals.begin() + r);
-            r--;
-          } else {
-            errorTermAdded = true;
-            for (size_t i = 0; i < lm.obs.size(); ++i)
-              if (lm.obs[i].resId == rid) {
-                connectDense(lm.obs[i].poseId);
-                connectDense(lm.obs[i].extId);
-                if (!contains(lmOrder, lm.id)) { lmOrder.push_back(lm.id); lmLin[lm.id].assign(lm.hp, lm.hp + 4); }
-                jobObs.push_back({lm.obs[i], lm.id});
-                removeObsRecord(lm, i);
-                break;
-              }
-          }
+      for (uint64_t f : removeFrames) for (int h : blocks_.at(f).seenLm) consider(h);
+      for (int h : emptyLm_) {
+        Landmark* lp = (h >= 0 && h < (int)lmByHandle_.size()) ? lmByHandle_[h] : nullptr;
+        if (lp && lp->obs.empty()) consider(h);
+      }
+      emptyLm_.clear();
+      std::sort(cand.begin(), cand.end());
+      const double tl1 = nowSec();
+      for (int h : cand) {
+        Landmark& lm = *lmByHandle_[h];
+        if (!lm.priors.empty()) continue;   // see the guard at the top
+        if (lm.obs.empty()) {
+          removed.push_back(lm.id);
+          eraseLandmark(lm);
+          continue;
         }
-        if (residuals.size() == 0) { justDelete = true; marginalize = false; }
+        bool skipLandmark = true, hasNewObservations = false, marginalize = true, errorTermAdded = false;
+        int obsCount = 0;
+        for (const Observation& o : lm.obs) {
+          const int c = cls[o.poseH];
+          if (c & kMargRemove) skipLandmark = false;
+          if (c & kMargNew) { marginalize = false; hasNewObservations = true; }
+          if (c & kMargLin) obsCount++;
+        }
+        if (skipLandmark) continue;
+        for (size_t i = 0; i < lm.obs.size();) {
+          const int action = margObsAction(cls[lm.obs[i].poseH], hasNewObservations, marginalize, obsCount);
+          if (action == 0) { ++i; continue; }
+          if (action == 2) {
+            errorTermAdded = true;
+            connectBlock(*blockByHandle_[B_POSE][lm.obs[i].poseH]);
+            connectBlock(*blockByHandle_[B_EXT][lm.obs[i].extH]);
+            if (lmOrder.empty() || lmOrder.back() != lm.id) {
+              lmOrder.push_back(lm.id);
+              if (!deviceJob) lmLin[lm.id].assign(lm.hp, lm.hp + 4);
+            }
+            if (!deviceJob) jobObs.push_back({lm.obs[i], lm.id, extIdOf(lm.obs[i])});
+            ++nJobObs;
+          }
+          removeObsRecord(lm, i);
+        }
+        if (lm.obs.empty() && !errorTermAdded) {   // every residual was dropped: "justDelete"
+          removed.push_back(lm.id);
+          eraseLandmark(lm);
+        } else if (marginalize && errorTermAdded) {
+          toMarginalize.push_back(lm.id);
+          margLandmarks.push_back(lm.id);
+          removed.push_back(lm.id);
+          eraseLandmark(lm);
+        }
       }
-      if (justDelete) {
-        removed.push_back(pit->first);
-        pit = landmarks_.erase(pit);
-        continue;
-      }
-      if (marginalize && errorTermAdded) {
-        toMarginalize.push_back(pit->first);
-        removed.push_back(pit->first);
-        pit = landmarks_.erase(pit);
-        continue;
-      }
-      pit++;
+      if (timing)
+        std::printf("[marg] landmark pass: %zu candidates collected in %.0f us, handled in %.0f us; %zu observations removed, %zu landmarks erased\n",
+                    cand.size(), 1e6 * (tl1 - tl0), 1e6 * (nowSec() - tl1), obs0 - numObs_, removed.size());
     }
     states_.erase(it->second.id);
   }
 
   // ---- device job (M1-M3)
   tm1 = nowSec();
+  std::sort(removed.begin(), removed.end());   // PointMap order (the reference erases while walking its std::map)
+  std::sort(margLandmarks.begin(), margLandmarks.end());
+  obsCachePose_ = 0;
   std::sort(toMarginalize.begin(), toMarginalize.end());
   toMarginalize.erase(std::unique(toMarginalize.begin(), toMarginalize.end()), toMarginalize.end());
   bool anyWork = !toMarginalize.empty();
@@ -1068,27 +1097,37 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     }
     if (hExt.empty()) { hExt.assign(7, 0.0); hExt[6] = 1.0; oExt.push_back(-1); }
     if (hPose.empty()) { hPose.assign(7, 0.0); hPose[6] = 1.0; oPose.push_back(-1); }
-    for (int l = 0; l < Lm; ++l) {
-      sLm[lmOrder[l]] = l;
-      const std::vector<double>& hp = lmLin.at(lmOrder[l]);
-      hLm.insert(hLm.end(), hp.begin(), hp.end());
-    }
-    // observations sorted landmark-major
-    std::stable_sort(jobObs.begin(), jobObs.end(), [&](const JobObs& a, const JobObs& b) { return sLm.at(a.lmId) < sLm.at(b.lmId); });
-    const int N = (int)jobObs.size();
+    if (!deviceJob)
+      for (int l = 0; l < Lm; ++l) {
+        sLm[lmOrder[l]] = l;
+        const std::vector<double>& hp = lmLin.at(lmOrder[l]);
+        hLm.insert(hLm.end(), hp.begin(), hp.end());
+      }
+    // observations sorted landmark-major (the policy hands them over landmark by landmark already)
+    if (!deviceJob)
+      std::stable_sort(jobObs.begin(), jobObs.end(), [&](const JobObs& a, const JobObs& b) { return sLm.at(a.lmId) < sLm.at(b.lmId); });
+    const int N = nJobObs;
     std::vector<double> hUv, hW;
     std::vector<uint32_t> hIdx;
-    std::vector<int> hObsLm, hLmPtr(Lm + 1, 0);
+    std::vector<int> hObsLm, hLmPtr(deviceJob ? 0 : Lm + 1, 0);
     bool anyExtVar = false;
+    // device job: the tables below are written by k_window_marg_gather from the resident CSR; it needs to know the class of
+    // every pose handle and where a block sits in the job's tables
+    std::vector<int> jobPoseSlot, jobExtSlot;
+    if (deviceJob) {
+      jobPoseSlot.assign(std::max(nextBlockH_[B_POSE], 1), -1); jobExtSlot.assign(std::max(nextBlockH_[B_EXT], 1), -1);
+      for (const auto& kv : sPose) jobPoseSlot[blocks_.at(kv.first).handle] = kv.second;
+      for (const auto& kv : sExt) jobExtSlot[blocks_.at(kv.first).handle] = kv.second;
+    }
     for (const JobObs& jo : jobObs) {
       hUv.push_back(jo.o.uv[0]); hUv.push_back(jo.o.uv[1]);
       hW.push_back(std::sqrt(64.0 / (jo.o.size * jo.o.size)));
-      const int es = sExt.count(jo.o.extId) ? sExt.at(jo.o.extId) : 0;
+      const int es = sExt.count(jo.extId) ? sExt.at(jo.extId) : 0;
       hIdx.push_back(packObs(sPose.at(jo.o.poseId), es, jo.o.cam));
       hObsLm.push_back(sLm.at(jo.lmId));
       hLmPtr[sLm.at(jo.lmId) + 1]++;
     }
-    for (int l = 0; l < Lm; ++l) hLmPtr[l + 1] += hLmPtr[l];
+    if (!deviceJob) for (int l = 0; l < Lm; ++l) hLmPtr[l + 1] += hLmPtr[l];
     for (int o : oExt) if (o >= 0) anyExtVar = true;
     // factors
     std::vector<DevFactor> hFac;
@@ -1119,18 +1158,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       hFac.push_back(df);
     }
     const int F = (int)hFac.size();
-    // The job is asynchronous (nothing below waits for the device): the staging copies of the uploaded arrays are
-    // kept in margHold_ until the next job has synchronised with the stream.
-    HIP_OK(hipStreamSynchronize(s));
-    margHold_.clear();
-    auto up = [&](auto& buf, const auto& host) {
-      using V = std::decay_t<decltype(host)>;
-      auto keep = std::make_shared<V>(host);
-      margHold_.push_back(keep);
-      buf.reserve(std::max<size_t>(keep->size(), 1));
-      if (!keep->empty())
-        HIP_OK(hipMemcpyAsync(buf.p, keep->data(), sizeof((*keep)[0]) * keep->size(), hipMemcpyHostToDevice, s));
-    };
+    // The job is asynchronous (nothing below waits for the device): every table travels in the one pinned block of
+    // flushStaged, which waits for the previous block's DMA itself.
     tm2 = nowSec();
     double* dbgScal = nullptr;
     // persistent job buffers (grow-only): hipMalloc / hipFree per call used to cost more than the algebra
@@ -1145,6 +1174,16 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     auto& bImu = mb.bImu;
     auto &bImuM = mb.bImuM, &bPartial = mb.bPartial;
     auto& bScal = mb.bScal;
+    // M2 dense part: which rows stay (the new prior) and which are marginalised
+    std::vector<int> keepIdx, margIdx;
+    for (const PriorBlockHost& pb : dense) {
+      const bool marg = std::binary_search(toMarginalize.begin(), toMarginalize.end(), pb.id);
+      for (int k = 0; k < pb.mdim; ++k) (marg ? margIdx : keepIdx).push_back(pb.ord + k);
+      if (!marg) kept.push_back(pb);
+    }
+    const int nk = (int)keepIdx.size(), nm = (int)margIdx.size();
+    std::vector<int> idxLists(keepIdx);
+    idxLists.insert(idxLists.end(), margIdx.begin(), margIdx.end());
     {   // the job's tables: one pinned block, one DMA, one scatter kernel (17 pageable copies cost ~100 us of enqueueing)
       std::vector<StagedCopy> pending;
       auto stage = [&](auto& buf, const auto& host) {
@@ -1156,7 +1195,27 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       stage(bOP, oPose); stage(bOE, oExt); stage(bOS, oSb); stage(bLmPtr, hLmPtr); stage(bObsLm, hObsLm); stage(bIdx, hIdx);
       stage(bFac, hFac); stage(bImu, hImu); stage(bImuT, hImuT); stage(bImuM, hImuM);
       stage(dCams_, cameras_);
+      stage(bIdxList, idxLists);
+      if (deviceJob) {
+        stage(res_.poseClass, poseClass); stage(res_.poseSlotOfH, jobPoseSlot); stage(res_.extSlotOfH, jobExtSlot);
+        bLm.reserve(std::max<size_t>((size_t)4 * Lm, 1)); bUv.reserve(std::max<size_t>((size_t)2 * N, 1)); bW.reserve(std::max<size_t>(N, 1));
+        bLmPtr.reserve((size_t)Lm + 1); bObsLm.reserve(std::max<size_t>(N, 1)); bIdx.reserve(std::max<size_t>(N, 1));
+        res_.margScratch.reserve(std::max<size_t>((size_t)2 * res_.L, 1));
+      }
       flushStaged(pending, s);
+      if (deviceJob && (N > 0 || Lm > 0)) {
+        MargGatherArgs ga;
+        std::memset(&ga, 0, sizeof(ga));
+        ga.L = res_.L; ga.H = res_.H; ga.expectN = N; ga.expectLm = Lm;
+        ga.lmPtr = res_.lmPtr[res_.cur].p; ga.handleOfSlot = res_.handleOfSlot[res_.cur].p;
+        ga.uv = res_.uv[res_.cur].p; ga.w = res_.w[res_.cur].p; ga.hnd = res_.hnd[res_.cur].p;
+        ga.lmHp = res_.lmHp.p;
+        ga.poseClass = res_.poseClass.p; ga.jobPoseSlot = res_.poseSlotOfH.p; ga.jobExtSlot = res_.extSlotOfH.p;
+        ga.jLmPtr = bLmPtr.p; ga.jObsLm = bObsLm.p; ga.jIdx = bIdx.p; ga.jUv = bUv.p; ga.jW = bW.p; ga.jLm = bLm.p;
+        ga.scratch = res_.margScratch.p;
+        ga.status = resStatusDev_;
+        launchWindowMargGather(ga, s);
+      }
     }
     bLin.reserve(std::max<size_t>((size_t)32 * N, 1));
     bFacLin.reserve(std::max(F, 1));
@@ -1165,16 +1224,22 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     bFlag.reserve(8);
     const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
     bU.reserve(mm * mm); bW2.reserve(mm * L3); bV.reserve((size_t)9 * std::max(Lm, 1)); bVec.reserve(mm + 2 * L3 + 16);
-    HIP_OK(hipMemsetAsync(bU.p, 0, sizeof(double) * mm * mm, s));
-    HIP_OK(hipMemsetAsync(bW2.p, 0, sizeof(double) * mm * L3, s));
-    HIP_OK(hipMemsetAsync(bV.p, 0, sizeof(double) * 9 * std::max(Lm, 1), s));
-    HIP_OK(hipMemsetAsync(bVec.p, 0, sizeof(double) * (mm + 2 * L3 + 16), s));
-    // old prior content (H_, b0_) occupies the leading block
-    if (hadPrior && priorM_ > 0) {
-      // the previous prior (H | b0) is still on the device, exactly where k_marg_dense left it
-      HIP_OK(hipMemcpy2DAsync(bU.p, sizeof(double) * m, mb.bHk.p, sizeof(double) * priorM_, sizeof(double) * priorM_,
-                              priorM_, hipMemcpyDeviceToDevice, s));
-      HIP_OK(hipMemcpyAsync(bVec.p, mb.bHk.p + (size_t)priorM_ * priorM_, sizeof(double) * priorM_, hipMemcpyDeviceToDevice, s));
+    {   // four clears as one launch, the two copies of the old prior as another (they land inside the cleared U and ba)
+      FillJobs clears;
+      clears.n = 0;
+      addFill(clears, bU.p, nullptr, mm * mm);
+      addFill(clears, bW2.p, nullptr, mm * L3);
+      addFill(clears, bV.p, nullptr, (size_t)9 * std::max(Lm, 1));
+      addFill(clears, bVec.p, nullptr, mm + 2 * L3 + 16);
+      launchFillJobs(clears, s);
+      // old prior content (H_, b0_) occupies the leading block: it is still on the device, exactly where k_marg_dense left it
+      if (hadPrior && priorM_ > 0) {
+        FillJobs copies;
+        copies.n = 0;
+        addFill(copies, bU.p, mb.bHk.p, (size_t)priorM_ * priorM_, priorM_, m, priorM_);
+        addFill(copies, bVec.p, mb.bHk.p + (size_t)priorM_ * priorM_, priorM_);
+        launchFillJobs(copies, s);
+      }
     }
     DeviceProblem q;
     std::memset(&q, 0, sizeof(q));
@@ -1241,13 +1306,6 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       hipLaunchKernelGGL(k_marg_lm_update, dim3((m * m + 255) / 256), dim3(256), 0, s, md);
     }
     // M2 dense part
-    std::vector<int> keepIdx, margIdx;
-    for (const PriorBlockHost& pb : dense) {
-      const bool marg = std::binary_search(toMarginalize.begin(), toMarginalize.end(), pb.id);
-      for (int k = 0; k < pb.mdim; ++k) (marg ? margIdx : keepIdx).push_back(pb.ord + k);
-      if (!marg) kept.push_back(pb);
-    }
-    const int nk = (int)keepIdx.size(), nm = (int)margIdx.size();
     int ordk = 0;
     for (PriorBlockHost& pb : kept) { pb.ord = ordk; ordk += pb.mdim; }
     Hk.assign((size_t)nk * nk, 0.0);
@@ -1256,9 +1314,6 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     bHk.reserve(std::max<size_t>((size_t)nk * nk + nk, 1));
     if (nk > 0) {
       if (nm > 0) {
-        std::vector<int> lists(keepIdx);
-        lists.insert(lists.end(), margIdx.begin(), margIdx.end());
-        up(bIdxList, lists);
         bScratch.reserve((size_t)2 * nm * nm + (size_t)nk * nm + 2 * nm + 16);
         DenseArgs da;
         da.m = m; da.nk = nk; da.nm = nm;
@@ -1269,7 +1324,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         da.flag = bFlag.p;
         {
           const size_t lds = jacobiLdsBytes(nm);
-          if (lds) (void)hipFuncSetAttribute((const void*)k_marg_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          // (the attribute call costs microseconds: only when the requirement grows)
+          if (lds > margLdsSet_[0]) { (void)hipFuncSetAttribute((const void*)k_marg_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); margLdsSet_[0] = lds; }
           hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, lds ? 1 : 0);
         }
       } else {
@@ -1298,7 +1354,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
         const int mode = forceFallback ? (ldsBoth ? 1 : 0) : (ldsOne ? 4 : 6);
         const size_t lds = (mode == 4) ? std::max(ldsOne, ldsBoth) : (mode == 1 ? ldsBoth : 0);
-        if (lds) (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > margLdsSet_[1]) { (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); margLdsSet_[1] = lds; }
         hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0);
       }
       priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
@@ -1330,7 +1386,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
   tm4 = nowSec();
   // ---- graph update (:710-716, :788-811)
   for (uint64_t id : toMarginalize)
-    if (!lmLin.count(id)) removeBlock(id);
+    if (!std::binary_search(margLandmarks.begin(), margLandmarks.end(), id)) removeBlock(id);
   int nk = 0;
   for (const PriorBlockHost& pb : kept) nk += pb.mdim;
   if (nk > 0) {

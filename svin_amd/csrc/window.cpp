@@ -137,6 +137,8 @@ Window::~Window() {
   dropRcclComm();
   if (stageEvt_) (void)hipEventDestroy(stageEvt_);
   if (stageHost_) (void)hipHostFree(stageHost_);
+  if (resStatus_) (void)hipHostFree(resStatus_);
+  if (lmSyncHost_) (void)hipHostFree(lmSyncHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -178,7 +180,13 @@ Block* Window::addBlock(uint64_t id, int kind, const double* x) {  // Map::addPa
   Block b;
   b.id = id; b.kind = kind;
   std::memcpy(b.x, x, sizeof(double) * (kind == B_SB ? 9 : 7));
-  return &(blocks_[id] = b);
+  if (!freeBlockH_[kind].empty()) { b.handle = freeBlockH_[kind].back(); freeBlockH_[kind].pop_back(); }
+  else b.handle = nextBlockH_[kind]++;
+  if (b.handle > 4095) throw std::runtime_error("window too wide for the packed index");
+  Block* nb = &(blocks_[id] = b);
+  if ((int)blockByHandle_[kind].size() <= nb->handle) blockByHandle_[kind].resize(nb->handle + 1, nullptr);
+  blockByHandle_[kind][nb->handle] = nb;
+  return nb;
 }
 Block* Window::findBlock(uint64_t id) {
   auto it = blocks_.find(id);
@@ -187,6 +195,15 @@ Block* Window::findBlock(uint64_t id) {
 const Block* Window::findBlock(uint64_t id) const {
   auto it = blocks_.find(id);
   return it == blocks_.end() ? nullptr : &it->second;
+}
+// the observations of a frame arrive together: its pose block and the two extrinsics blocks answer from four remembered
+// pointers instead of a hash lookup each (unordered_map nodes do not move; removeBlock clears the cache)
+Block* Window::cachedBlock(uint64_t id) {
+  for (Block* b : blockCache_)
+    if (b && b->id == id) return b;
+  Block* b = findBlock(id);
+  if (b) { blockCache_[blockCacheNext_] = b; blockCacheNext_ = (blockCacheNext_ + 1) & 3; }
+  return b;
 }
 static void eraseOne(std::vector<uint64_t>& v, uint64_t x) {
   for (size_t i = 0; i < v.size(); ++i)
@@ -210,15 +227,29 @@ void Window::removeFactor(uint64_t id) {
   factors_.erase(it);
 }
 void Window::removeObsRecord(Landmark& lm, size_t idx) {
-  const Observation o = lm.obs[idx];
-  if (Block* b = findBlock(o.poseId)) b->nObs--;
-  if (Block* b = findBlock(o.extId)) b->nObs--;
+  const Observation& o = lm.obs[idx];
+  if (Block* b = blockByHandle_[B_POSE][o.poseH]) b->nObs--;
+  if (Block* b = blockByHandle_[B_EXT][o.extH]) b->nObs--;
   obsRes2Lm_.erase(o.resId);
+  if (residentValid_) {   // the device copy learns about it with the next flush (resident.hpp)
+    if (o.pendEpoch == epoch_) addLog_[o.pendIdx].lmH = -1;   // never got there: withdrawn
+    else remLog_.push_back(WinRem{lm.handle, (uint32_t)o.resId});
+  }
+  const uint64_t poseId = o.poseId;
   lm.obs.erase(lm.obs.begin() + idx);
-  if (o.poseId == lm.minPose) {
+  --numObs_;
+  if (lm.obs.empty()) { --numLmObserved_; emptyLm_.push_back(lm.handle); }
+  if (poseId == lm.minPose) {
     lm.minPose = UINT64_MAX;
     for (const Observation& q : lm.obs) lm.minPose = std::min(lm.minPose, q.poseId);
   }
+}
+void Window::eraseLandmark(Landmark& lm) {
+  while (!lm.obs.empty()) removeObsRecord(lm, lm.obs.size() - 1);
+  const uint64_t id = lm.id;
+  lmByHandle_[lm.handle] = nullptr;
+  lmIndex_.erase(id);
+  landmarks_.erase(id);
 }
 void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (Map.cpp:322-333)
   Block* b = findBlock(id);
@@ -230,10 +261,14 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
     for (auto& kv : landmarks_) {
       Landmark& lm = kv.second;
       for (size_t i = 0; i < lm.obs.size();)
-        if (lm.obs[i].poseId == id || lm.obs[i].extId == id) removeObsRecord(lm, i);
+        if (lm.obs[i].poseId == id || (b->kind == B_EXT && lm.obs[i].extH == b->handle)) removeObsRecord(lm, i);
         else ++i;
     }
   }
+  for (Block*& c : blockCache_) c = nullptr;
+  obsCachePose_ = 0;
+  blockByHandle_[b->kind][b->handle] = nullptr;
+  freeBlockH_[b->kind].push_back(b->handle);
   blocks_.erase(id);
 }
 
@@ -300,6 +335,7 @@ bool Window::initPoseFromImu(const double* imuM, int n, double* T) {
 int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, const double* T_SC, int nCam,
                       const uint32_t* imuT, const double* imuM, int nImu, bool asKeyframe, const double* sonar,
                       int nSonar, const double* depth, int nDepth, double firstDepth) {
+  obsCachePose_ = 0;
   if (nCam != (int)cameras_.size()) { lastError() = "addStates: T_SC count != number of cameras"; return -1; }
   if (imus_.empty()) { lastError() = "addStates: no IMU added"; return -1; }
   if (imuM == nullptr || imuT == nullptr) nImu = 0;
@@ -394,6 +430,7 @@ int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, 
     double mean[3] = {0, 0, 0};
     size_t cnt = 0;
     double vl[3] = {0, 0, 0};
+    syncLandmarks();
     for (auto rit = landmarks_.rbegin(); rit != landmarks_.rend(); ++rit) {
       const double* pt = rit->second.hp;
       if (std::fabs(pt[3]) > 1.0e-8) { vl[0] = pt[0] / pt[3]; vl[1] = pt[1] / pt[3]; vl[2] = pt[2] / pt[3]; }
@@ -496,30 +533,91 @@ int Window::addLandmark(uint64_t id, const double* hp) {  // :414-429
     dist = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
   }
   lm.distance = dist;
-  landmarks_[id] = lm;
+  lm.handle = nextLmHandle_++;
+  Landmark* node = &(landmarks_[id] = lm);
+  lmByHandle_.push_back(node);
+  lmIndex_.set(id, (uint64_t)lm.handle);
+  emptyLm_.push_back(lm.handle);
+  if (residentValid_) {
+    WinLmSet st;
+    st.h = lm.handle; st.setQuality = 1; st.quality = 0.0;
+    std::memcpy(st.hp, hp, sizeof(st.hp));
+    setLog_.push_back(st);
+  }
   return 1;
 }
 
 uint64_t Window::addObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint64_t kp, const double* uv,
                                 double size) {  // implementation/Estimator.hpp:47-87
-  auto lit = landmarks_.find(lmId);
-  auto sit = states_.find(poseId);
-  if (lit == landmarks_.end() || sit == states_.end() || cam >= cameras_.size()) return 0;
-  for (const Observation& o : lit->second.obs)
-    if (o.poseId == poseId && (uint64_t)o.cam == cam && o.kp == kp) return 0;  // duplicate -> NULL
+  uint64_t hnd = 0;
+  if (!lmIndex_.find(lmId, &hnd)) return 0;
+  return addObservationTo(*lmByHandle_[(size_t)hnd], poseId, cam, kp, uv, size);
+}
+int Window::addObservations(int n, const uint64_t* lmIds, const uint64_t* pose, const uint64_t* cam, const uint64_t* kp,
+                            const double* uv, const double* size, uint64_t* outIds) {
+  // Two passes: the landmark records of a frame's matches are scattered over the heap (std::map nodes, one vector each);
+  // resolving the ids first and prefetching node and observation list a few entries ahead hides most of those misses.
+  static thread_local std::vector<Landmark*> nodes;
+  nodes.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    uint64_t hnd = 0;
+    nodes[i] = lmIndex_.find(lmIds[i], &hnd) ? lmByHandle_[(size_t)hnd] : nullptr;
+    if (nodes[i]) __builtin_prefetch(nodes[i]);
+  }
+  constexpr int kAhead = 8;
+  int added = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i + kAhead < n && nodes[i + kAhead]) {
+      const Landmark& nx = *nodes[i + kAhead];
+      const Observation* d = nx.obs.data();
+      if (d) { __builtin_prefetch(d); __builtin_prefetch(d + nx.obs.size(), 1); }
+    }
+    const uint64_t id = nodes[i] ? addObservationTo(*nodes[i], pose[i], cam[i], kp[i], uv + 2 * (size_t)i, size[i]) : 0;
+    if (outIds) outIds[i] = id;
+    added += id != 0;
+  }
+  return added;
+}
+uint64_t Window::addObservationTo(Landmark& lm, uint64_t poseId, uint64_t cam, uint64_t kp, const double* uv, double size) {
+  if (cam >= cameras_.size()) return 0;
+  Block* pb = cachedBlock(poseId);
+  if (!pb || pb->kind != B_POSE) return 0;
+  // the extrinsics blocks of the frame: the state table is consulted once per frame, then obsCacheExt_ answers
+  if (obsCachePose_ != poseId) {
+    auto sit = states_.find(poseId);
+    if (sit == states_.end()) return 0;
+    for (size_t c = 0; c < cameras_.size() && c < 16; ++c) obsCacheExt_[c] = sit->second.ext.at(c).id;
+    obsCachePose_ = poseId;
+  }
+  if (poseId <= lm.maxPose)   // (the first observation from a new frame cannot repeat an older one)
+    for (const Observation& o : lm.obs)
+      if (o.poseId == poseId && (uint64_t)o.cam == cam && o.kp == kp) return 0;  // duplicate -> NULL
+  Block* eb = cachedBlock(obsCacheExt_[cam]);
+  if (!eb) return 0;
   Observation o;
   o.resId = nextResId_++;
   o.poseId = poseId;
-  o.extId = sit->second.ext.at(cam).id;
-  o.cam = (int)cam;
+  o.cam = (uint8_t)cam;
   o.kp = kp;
   o.uv[0] = uv[0]; o.uv[1] = uv[1];
   o.size = size;
-  lit->second.obs.push_back(o);
-  lit->second.minPose = std::min(lit->second.minPose, o.poseId);
-  blocks_.at(o.poseId).nObs++;
-  blocks_.at(o.extId).nObs++;
-  obsRes2Lm_[o.resId] = lmId;
+  o.poseH = (uint16_t)pb->handle; o.extH = (uint16_t)eb->handle;
+  if (residentValid_) {
+    o.pendIdx = (uint32_t)addLog_.size(); o.pendEpoch = epoch_;
+    WinAdd ad;
+    ad.lmH = lm.handle; ad.seq = (uint32_t)o.resId; ad.hnd = packObs(o.poseH, o.extH, o.cam); ad.pad = 0;
+    ad.u = uv[0]; ad.v = uv[1]; ad.w = std::sqrt(64.0 / (size * size));
+    addLog_.push_back(ad);
+  }
+  if (lm.obs.empty()) ++numLmObserved_;
+  ++numObs_;
+  lm.obs.push_back(o);
+  lm.minPose = std::min(lm.minPose, o.poseId);
+  lm.maxPose = std::max(lm.maxPose, o.poseId);
+  pb->nObs++;
+  eb->nObs++;
+  pb->seenLm.push_back(lm.handle);
+  obsRes2Lm_.set(o.resId, (uint64_t)reinterpret_cast<uintptr_t>(&lm));
   return o.resId;
 }
 // HomogeneousPointError(measurement, information) (HomogeneousPointError.cpp:58-75): squareRootInformation_ = L^T with
@@ -569,9 +667,9 @@ int Window::removeObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint
   return 0;
 }
 int Window::removeObservationById(uint64_t resId) {  // :432-449
-  auto it = obsRes2Lm_.find(resId);
-  if (it == obsRes2Lm_.end()) return 0;
-  Landmark& lm = landmarks_.at(it->second);
+  uint64_t node = 0;
+  if (!obsRes2Lm_.find(resId, &node)) return 0;
+  Landmark& lm = *reinterpret_cast<Landmark*>((uintptr_t)node);
   for (size_t i = 0; i < lm.obs.size(); ++i)
     if (lm.obs[i].resId == resId) { removeObsRecord(lm, i); return 1; }
   return 0;
@@ -598,7 +696,9 @@ int Window::getCameraSensorStates(uint64_t id, size_t cam, double* T) const {
 }
 const Landmark* Window::landmark(uint64_t id) const {
   auto it = landmarks_.find(id);
-  return it == landmarks_.end() ? nullptr : &it->second;
+  if (it == landmarks_.end()) return nullptr;
+  syncLandmarks();
+  return &it->second;
 }
 static void normalisedPose(const double* T, double* out) {  // PoseParameterBlock::setEstimate keeps a Transformation
   const Quat q = qnormalized(Quat{T[3], T[4], T[5], T[6]});
@@ -626,7 +726,14 @@ int Window::setCameraSensorStates(uint64_t id, size_t cam, const double* T) {
 int Window::setLandmark(uint64_t id, const double* hp) {
   auto it = landmarks_.find(id);
   if (it == landmarks_.end()) return 0;
+  syncLandmarks();   // (a later fetch must not bring back the value this call replaces)
   std::memcpy(it->second.hp, hp, 4 * sizeof(double));
+  if (residentValid_) {
+    WinLmSet st;
+    st.h = it->second.handle; st.setQuality = 0; st.quality = 0.0;
+    std::memcpy(st.hp, hp, sizeof(st.hp));
+    setLog_.push_back(st);
+  }
   return 1;
 }
 int Window::setLandmarkInitialized(uint64_t id, bool init) {
@@ -678,7 +785,7 @@ int Window::residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const {
   if (b->nObs > 0)      // reprojection residuals live in their landmark's list only
     for (const auto& kv : landmarks_)
       for (const Observation& o : kv.second.obs)
-        if (o.poseId == blockId || o.extId == blockId) out.push_back(o.resId);
+        if (o.poseId == blockId || (b->kind == B_EXT && o.extH == b->handle)) out.push_back(o.resId);
   std::sort(out.begin(), out.end());   // ids grow with insertion: this IS insertion order across both kinds
   return 1;
 }
@@ -691,11 +798,11 @@ int Window::residualKind(uint64_t resId) const {
 }
 int Window::parametersOf(uint64_t resId, std::vector<uint64_t>& out) const {
   out.clear();
-  auto ot = obsRes2Lm_.find(resId);
-  if (ot != obsRes2Lm_.end()) {   // ReprojectionError: pose, landmark, extrinsics (ReprojectionErrorBase.hpp:50-54)
-    const Landmark& lm = landmarks_.at(ot->second);
+  uint64_t obsNode = 0;
+  if (obsRes2Lm_.find(resId, &obsNode)) {   // ReprojectionError: pose, landmark, extrinsics (ReprojectionErrorBase.hpp:50-54)
+    const Landmark& lm = *reinterpret_cast<const Landmark*>((uintptr_t)obsNode);
     for (const Observation& o : lm.obs)
-      if (o.resId == resId) { out = {o.poseId, lm.id, o.extId}; return 1; }
+      if (o.resId == resId) { out = {o.poseId, lm.id, extIdOf(o)}; return 1; }
     return 0;
   }
   if (hasPrior_ && resId == priorResId_) {
@@ -738,6 +845,7 @@ int Window::getParameterBlock(uint64_t id, int32_t* type, double* values, uint32
                               int32_t* initialized) const {
   auto lit = landmarks_.find(id);
   if (lit != landmarks_.end()) {
+    syncLandmarks();
     if (type) *type = 3;
     if (values) std::memcpy(values, lit->second.hp, 4 * sizeof(double));
     if (sec) *sec = 0;
@@ -769,6 +877,150 @@ void Window::parameterBlockIds(std::vector<uint64_t>& out) const {
   for (const auto& kv : blocks_) out.push_back(kv.first);
   for (const auto& kv : landmarks_) out.push_back(kv.first);
   std::sort(out.begin(), out.end());
+}
+
+// ------------------------------------------------------------------------------------------ device-resident window
+bool Window::useResident() const {   // (called by pack() once the state tables are known)
+  static const bool forceHost = getenv("SVIN_HOST_PACK") != nullptr;
+  return packMode_ == 0 && !forceHost && world_ <= 1 && rcclComm_ == nullptr && numLandmarkPriors_ == 0 &&
+         poseIds_.size() <= (size_t)kResidentPoseCap;
+}
+void Window::invalidateResident() {
+  syncLandmarks();
+  residentValid_ = false;
+  addLog_.clear(); remLog_.clear(); setLog_.clear();
+  ++epoch_;
+}
+// Handles are creation numbers and are never re-used, so the per-handle tables grow with the landmarks ever created.  When
+// the live ones have become a small part of the range the survivors are renumbered in id order (the order the reference's
+// std::map walks them in) and the device copy is rebuilt from the graph.  Host graph authoritative (invalidateResident first).
+void Window::renumberLandmarkHandles() {
+  std::vector<int> newOf(lmByHandle_.size(), -1);
+  std::vector<Landmark*> fresh;
+  fresh.reserve(landmarks_.size());
+  for (auto& kv : landmarks_) {
+    newOf[kv.second.handle] = (int)fresh.size();
+    kv.second.handle = (int)fresh.size();
+    lmIndex_.set(kv.first, (uint64_t)kv.second.handle);
+    fresh.push_back(&kv.second);
+  }
+  lmByHandle_.swap(fresh);
+  nextLmHandle_ = (int)lmByHandle_.size();
+  auto remap = [&](std::vector<int>& v) {
+    size_t k = 0;
+    for (int h : v)
+      if (h >= 0 && h < (int)newOf.size() && newOf[h] >= 0) v[k++] = newOf[h];
+    v.resize(k);
+  };
+  remap(emptyLm_);
+  for (auto& kv : blocks_) remap(kv.second.seenLm);
+}
+void Window::checkResidentStatus() {
+  if (resStatus_ && *resStatus_ != 0) {
+    const int code = *resStatus_;
+    *resStatus_ = 0;
+    invalidateResident();
+    throw std::runtime_error("svin_ba: the device-resident window disagrees with the host graph (status " + std::to_string(code) + ")");
+  }
+}
+void Window::flushPendingQuality() const {
+  if (!qualityPending_) return;
+  qualityPending_ = false;
+  if (qualityProb_.L > 0) launchLandmarkQuality(qualityProb_, dQuality_.p, stream_);
+  launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, qualityProb_.lm, dQuality_.p, res_.lmHp.p, res_.qualH.p, stream_);
+}
+void Window::syncLandmarks() const {
+  if (!lmStale_) return;
+  flushPendingQuality();
+  lmStale_ = false;
+  const size_t H = (size_t)hFlushed_;
+  if (H == 0) return;
+  if (5 * H > lmSyncCap_) {
+    if (lmSyncHost_) (void)hipHostFree(lmSyncHost_);
+    lmSyncCap_ = std::max<size_t>(10 * H, 1 << 14);
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&lmSyncHost_), lmSyncCap_ * sizeof(double), hipHostMallocDefault));
+  }
+  HIP_OK(hipMemcpyAsync(lmSyncHost_, res_.lmHp.p, sizeof(double) * 4 * H, hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipMemcpyAsync(lmSyncHost_ + 4 * H, res_.qualH.p, sizeof(double) * H, hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  for (size_t h = 0; h < H && h < lmByHandle_.size(); ++h) {
+    Landmark* lm = lmByHandle_[h];
+    if (!lm) continue;
+    std::memcpy(lm->hp, lmSyncHost_ + 4 * h, 4 * sizeof(double));
+    lm->quality = lmSyncHost_[4 * H + h];
+  }
+}
+// stages this frame's delta (or, when the device copy is not valid, the whole graph as one delta) and fills the rebuild
+// kernel's arguments; pack() launches it behind the scatter of the staged block
+void Window::flushResident(hipStream_t s, bool wantOrder, std::vector<StagedCopy>& pending, ResidentArgs& ra) {
+  Resident& R = res_;
+  if (residentValid_ && (size_t)nextLmHandle_ > std::max<size_t>(8192, 8 * landmarks_.size())) invalidateResident();
+  const bool full = !residentValid_;
+  if (full) {
+    if ((size_t)nextLmHandle_ > std::max<size_t>(4096, 2 * landmarks_.size())) renumberLandmarkHandles();
+    addLog_.clear(); remLog_.clear(); setLog_.clear();
+    ++epoch_;
+    for (Landmark* lm : lmByHandle_) {
+      if (!lm) continue;
+      WinLmSet st;
+      st.h = lm->handle; st.setQuality = 1; st.quality = lm->quality;
+      std::memcpy(st.hp, lm->hp, sizeof(st.hp));
+      setLog_.push_back(st);
+      for (Observation& o : lm->obs) {
+        o.pendEpoch = 0;
+        WinAdd ad;
+        ad.lmH = lm->handle; ad.seq = (uint32_t)o.resId; ad.hnd = packObs(o.poseH, o.extH, o.cam); ad.pad = 0;
+        ad.u = o.uv[0]; ad.v = o.uv[1]; ad.w = std::sqrt(64.0 / (o.size * o.size));
+        addLog_.push_back(ad);
+      }
+    }
+    R.N = 0; R.L = 0; R.H = 0;
+  }
+  const size_t H = (size_t)nextLmHandle_, N = numObs_, L = numLmObserved_;
+  const int cur = R.cur, nxt = 1 - R.cur;
+  // per-handle tables keep their contents; new handles start from zero
+  const size_t Hc = std::max<size_t>(H, 1);
+  R.cnt.growKeep(Hc, R.H, s); R.addsH.growKeep(Hc, R.H, s); R.addCur.growKeep(Hc, R.H, s);
+  R.lmHp.growKeep(4 * Hc, 4 * (size_t)R.H, s); R.qualH.growKeep(Hc, R.H, s);
+  R.slotOfH[cur].growKeep(Hc, R.H, s);
+  if (full) {
+    HIP_OK(hipMemsetAsync(R.cnt.p, 0, sizeof(int) * R.cnt.cap, s));
+    HIP_OK(hipMemsetAsync(R.addsH.p, 0, sizeof(int) * R.addsH.cap, s));
+    HIP_OK(hipMemsetAsync(R.addCur.p, 0, sizeof(int) * R.addCur.cap, s));
+  }
+  R.live.growKeep(std::max<size_t>(std::max(N, (size_t)R.N), 1), R.N, s);
+  // the set the new CSR is written into
+  R.slotOfH[nxt].reserve(Hc);
+  R.lmPtr[nxt].reserve(L + 2); R.handleOfSlot[nxt].reserve(L + 1);
+  R.uv[nxt].reserve(2 * N + 2); R.w[nxt].reserve(N + 1); R.hnd[nxt].reserve(N + 1); R.seq[nxt].reserve(N + 1); R.obsLm[nxt].reserve(N + 1);
+  if (!R.lmPtr[cur].p) { R.lmPtr[cur].reserve(2); R.handleOfSlot[cur].reserve(1); R.uv[cur].reserve(2); R.w[cur].reserve(1); R.hnd[cur].reserve(1); R.seq[cur].reserve(1); R.obsLm[cur].reserve(1); }
+  auto stage = [&](auto& buf, const auto& host) {
+    using T = typename std::decay_t<decltype(host)>::value_type;
+    buf.reserve(std::max<size_t>(host.size() + 16 / sizeof(T) + 1, 1));
+    if (!host.empty()) pending.push_back({host.data(), sizeof(T) * host.size(), buf.p});
+  };
+  stage(R.adds, addLog_); stage(R.rems, remLog_); stage(R.sets, setLog_);
+  if (!resStatus_) {
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&resStatus_), 64, hipHostMallocMapped));
+    *resStatus_ = 0;
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&resStatusDev_), resStatus_, 0));
+  }
+  ra.nAdd = (int)addLog_.size(); ra.nRem = (int)remLog_.size(); ra.nSet = (int)setLog_.size(); ra.H = (int)H;
+  ra.Nold = R.N; ra.Lold = R.L; ra.Nnew = (int)N; ra.Lnew = (int)L;
+  ra.wantOrder = wantOrder ? 1 : 0;
+  ra.adds = R.adds.p; ra.rems = R.rems.p; ra.sets = R.sets.p;
+  ra.lmPtrOld = R.lmPtr[cur].p; ra.handleOfSlotOld = R.handleOfSlot[cur].p; ra.slotOfHOld = R.slotOfH[cur].p;
+  ra.uvOld = R.uv[cur].p; ra.wOld = R.w[cur].p; ra.hndOld = R.hnd[cur].p; ra.seqOld = R.seq[cur].p; ra.obsLmOld = R.obsLm[cur].p;
+  ra.obsLm = R.obsLm[nxt].p;
+  ra.live = R.live.p;
+  ra.lmPtrNew = R.lmPtr[nxt].p; ra.handleOfSlotNew = R.handleOfSlot[nxt].p; ra.slotOfHNew = R.slotOfH[nxt].p;
+  ra.uvNew = R.uv[nxt].p; ra.wNew = R.w[nxt].p; ra.hndNew = R.hnd[nxt].p; ra.seqNew = R.seq[nxt].p;
+  ra.cnt = R.cnt.p; ra.addsH = R.addsH.p; ra.addCur = R.addCur.p; ra.lmHp = R.lmHp.p; ra.qualH = R.qualH.p;
+  ra.status = resStatusDev_;
+  // from here on the device copy is what the logs are relative to
+  R.cur = nxt; R.N = (int)N; R.L = (int)L; R.H = (int)H;
+  hFlushed_ = (int)H;
+  residentValid_ = true;
 }
 
 // ------------------------------------------------------------------------------------------ pack: host graph -> HBM
@@ -809,7 +1061,11 @@ void Window::flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s) 
   launchScatterStaged(stageDev_.p, (int)pending.size(), s);
 }
 
-void Window::pack() {
+void Window::pack(bool solveFollows) {
+  // the qualities of the last solve: a new solve replaces them before anybody can look; any other caller (inspection hooks,
+  // prepare()) keeps them -- they are computed now, while that solve's tables are still intact
+  if (solveFollows) qualityPending_ = false;
+  else flushPendingQuality();
   const double tPack0 = nowSec();
   poseIds_.clear(); extIds_.clear(); sbIds_.clear(); lmIds_.clear(); factorIds_.clear();
   poseSlot_.clear(); extSlot_.clear(); sbSlot_.clear();
@@ -867,14 +1123,23 @@ void Window::pack() {
     if (b.fixed) hSbOff[i] = -1;
     else { hSbOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 9; }
   }
-  // landmarks + observations (landmark-major).  Sized in a first pass and filled by index; pose / extrinsics slots
-  // come from a small linear table (a window holds a few dozen states) instead of one hash lookup per observation.
+  // landmarks + observations (landmark-major).  Two ways to the same arrays: the device-resident window takes this frame's
+  // delta and rebuilds its CSR on the device (resident.hpp); the host path below walks the whole graph and uploads everything
+  // (wide windows with their panel work lists, landmark priors, sharded mode, and the reference the tests hold the resident
+  // path against).  Both list the landmarks with observations in HANDLE order, the observations in insertion order.
+  const bool resident = useResident();
+  residentUsed_ = resident;
+  if (!resident) {
+    syncLandmarks();         // the host graph becomes the authority again ...
+    invalidateResident();    // ... and the device copy is rebuilt from it when the window next qualifies
+  }
   size_t nLmObs = 0, nObs = 0;
-  for (const auto& kv : landmarks_)
-    if (!kv.second.obs.empty() || !kv.second.priors.empty()) { ++nLmObs; nObs += kv.second.obs.size() + 2 * kv.second.priors.size(); }
+  if (!resident)
+    for (const Landmark* lm : lmByHandle_)
+      if (lm && (!lm->obs.empty() || !lm->priors.empty())) { ++nLmObs; nObs += lm->obs.size() + 2 * lm->priors.size(); }
   std::vector<double> hLmPrior;   // 12 doubles per HomogeneousPointError: measurement xyz, sqrt information (row-major)
   std::vector<double> hLm(4 * nLmObs), hUv(2 * nObs), hW(nObs);
-  std::vector<int> hLmPtr(nLmObs + 1), hObsLm(nObs);
+  std::vector<int> hLmPtr(resident ? 0 : nLmObs + 1), hObsLm(nObs);
   std::vector<uint32_t> hIdx(nObs);
   lmIds_.resize(nLmObs);
   struct SlotCache {
@@ -892,25 +1157,26 @@ void Window::pack() {
     }
   };
   const SlotCache poseCache(poseSlot_), extCache(extSlot_);
-  // landmark order of the CSR: id order; for wide windows sorted by the first pose that observes the landmark, so that
-  // a chunk of 16 consecutive landmarks touches few 96-row panels of the camera matrix (k_schur_panels work list)
+  // landmark order of the CSR: handle order (creation order; id order when ids grow with time, as the reference's IdProvider
+  // makes them); for wide windows sorted by the first pose that observes the landmark, so that a chunk of 16 consecutive
+  // landmarks touches few 96-row panels of the camera matrix (k_schur_panels work list)
   std::vector<const Landmark*> lmOrder;
-  lmOrder.reserve(nLmObs);
-  for (const auto& kv : landmarks_)
-    if (!kv.second.obs.empty() || !kv.second.priors.empty()) lmOrder.push_back(&kv.second);
-  if (poseIds_.size() > 42) {
-    std::vector<std::pair<int, const Landmark*>> keyed;
-    keyed.reserve(lmOrder.size());
-    for (const Landmark* lm : lmOrder) {
-      int first = INT32_MAX;
-      for (const Observation& ob : lm->obs) first = std::min(first, poseCache.at(ob.poseId));
-      if (lm->obs.empty()) first = 0;
-      keyed.emplace_back(first, lm);
+  if (!resident) {
+    lmOrder.reserve(nLmObs);
+    for (const Landmark* lm : lmByHandle_)
+      if (lm && (!lm->obs.empty() || !lm->priors.empty())) lmOrder.push_back(lm);
+    if (poseIds_.size() > (size_t)kResidentPoseCap) {
+      std::vector<std::pair<int, const Landmark*>> keyed;
+      keyed.reserve(lmOrder.size());
+      for (const Landmark* lm : lmOrder) {
+        int first = INT32_MAX;
+        for (const Observation& ob : lm->obs) first = std::min(first, poseCache.at(ob.poseId));
+        if (lm->obs.empty()) first = 0;
+        keyed.emplace_back(first, lm);
+      }
+      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      for (size_t i = 0; i < keyed.size(); ++i) lmOrder[i] = keyed[i].second;
     }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-    for (size_t i = 0; i < keyed.size(); ++i) lmOrder[i] = keyed[i].second;
-  }
-  {
     size_t slot = 0, o = 0;
     hLmPtr[0] = 0;
     for (const Landmark* lmp : lmOrder) {
@@ -921,7 +1187,7 @@ void Window::pack() {
         hUv[2 * o] = ob.uv[0]; hUv[2 * o + 1] = ob.uv[1];
         // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
         hW[o] = std::sqrt(64.0 / (ob.size * ob.size));
-        hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(ob.extId), ob.cam);
+        hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(extIdOf(ob)), ob.cam);
         hObsLm[o] = (int)slot;
         ++o;
       }
@@ -942,7 +1208,7 @@ void Window::pack() {
       hLmPtr[++slot] = (int)o;
     }
   }
-  const int L = (int)lmIds_.size(), N = (int)hObsLm.size();
+  const int L = resident ? (int)numLmObserved_ : (int)lmIds_.size(), N = resident ? (int)numObs_ : (int)hObsLm.size();
   // factors
   std::vector<DevFactor> hFac;
   std::vector<DevImu> hImu;
@@ -1003,14 +1269,27 @@ void Window::pack() {
     buf.reserve(std::max<size_t>(host.size() + 16 / sizeof(T) + 1, 1));   // room for the 16-byte rounding of the copy
     if (!host.empty()) pending.push_back({host.data(), sizeof(T) * host.size(), buf.p});
   };
-  upload(dPose_, hPose, s); upload(dExt_, hExt, s); upload(dSb_, hSb, s); upload(dLm_, hLm, s);
+  upload(dPose_, hPose, s); upload(dExt_, hExt, s); upload(dSb_, hSb, s);
   dPoseC_.reserve(std::max<size_t>(hPose.size(), 1)); dExtC_.reserve(std::max<size_t>(hExt.size(), 1));
-  dSbC_.reserve(std::max<size_t>(hSb.size(), 1)); dLmC_.reserve(std::max<size_t>(hLm.size(), 1));
+  dSbC_.reserve(std::max<size_t>(hSb.size(), 1)); dLmC_.reserve(std::max<size_t>((size_t)4 * L, 1));
   upload(dPoseOff_, hPoseOff, s); upload(dExtOff_, hExtOff, s); upload(dSbOff_, hSbOff, s);
   upload(dCams_, cameras_, s);
-  upload(dLmPtr_, hLmPtr, s); upload(dObsLm_, hObsLm, s); upload(dObsUv_, hUv, s); upload(dObsW_, hW, s);
-  upload(dObsIdx_, hIdx, s);
-  upload(dLmPrior_, hLmPrior, s);
+  ResidentArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  // this frame's slot of every pose / extrinsics block handle (the resident observation records name blocks by handle)
+  std::vector<int> hPoseSlotOfH, hExtSlotOfH;
+  if (resident) {
+    hPoseSlotOfH.assign(std::max(nextBlockH_[B_POSE], 1), -1); hExtSlotOfH.assign(std::max(nextBlockH_[B_EXT], 1), -1);
+    for (size_t i = 0; i < poseIds_.size(); ++i) hPoseSlotOfH[blocks_.at(poseIds_[i]).handle] = (int)i;
+    for (size_t i = 0; i < extIds_.size(); ++i) hExtSlotOfH[blocks_.at(extIds_[i]).handle] = (int)i;
+    upload(res_.poseSlotOfH, hPoseSlotOfH, s); upload(res_.extSlotOfH, hExtSlotOfH, s);
+    dLm_.reserve(std::max<size_t>((size_t)4 * L, 1)); dObsIdx_.reserve(std::max<size_t>(N, 1));
+  } else {
+    upload(dLm_, hLm, s);
+    upload(dLmPtr_, hLmPtr, s); upload(dObsLm_, hObsLm, s); upload(dObsUv_, hUv, s); upload(dObsW_, hW, s);
+    upload(dObsIdx_, hIdx, s);
+    upload(dLmPrior_, hLmPrior, s);
+  }
   for (int k = 0; k < 2; ++k) { dLin_[k].reserve(std::max<size_t>((size_t)32 * N, 1)); dFacLin_[k].reserve(std::max(F, 1)); }
   upload(dFactors_, hFac, s); upload(dImus_, hImu, s); upload(dImuT_, hImuT, s); upload(dImuM_, hImuM, s);
   if (hasPrior_) {
@@ -1041,7 +1320,8 @@ void Window::pack() {
   // landmarks the observations are visited pose by pose, so that a batch only touches a few tile rows (counting sort)
   std::vector<int> hObsOrder;
   const bool orderObs = schurDense && (anyExtVar || (dC + 2 + 15) / 16 > 8) && N > 0;
-  if (orderObs) {
+  if (orderObs && resident) dObsOrder_.reserve((size_t)N);   // counting sort per chunk on the device (k_window_rebuild, phase 4)
+  if (orderObs && !resident) {
     hObsOrder.resize(N);
     std::vector<int> cnt;
     for (int l0 = 0; l0 < L; l0 += 16) {
@@ -1095,10 +1375,22 @@ void Window::pack() {
     dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
   }
 
+  if (schurPanels && resident) throw std::logic_error("resident window needs a panel work list");
+  if (resident) flushResident(s, orderObs, pending, ra);   // stages the delta; the rebuild kernel follows the scatter
   flushStaged(pending, s);
+  if (resident) {
+    addLog_.clear(); remLog_.clear(); setLog_.clear();   // (copied into the staged block by flushStaged)
+    ++epoch_;
+    ra.nPoseSlots = (int)poseIds_.size();
+    ra.obsIdx = dObsIdx_.p; ra.lm = dLm_.p; ra.obsOrder = dObsOrder_.p;
+    ra.poseSlotOfH = res_.poseSlotOfH.p; ra.extSlotOfH = res_.extSlotOfH.p;
+    launchWindowRebuild(ra, s);
+  }
 
   DeviceProblem& p = prob_;
   std::memset(&p, 0, sizeof(p));
+  FillJobs clears;
+  clears.n = 0;
   p.nPose = (int)poseIds_.size(); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
@@ -1116,6 +1408,7 @@ void Window::pack() {
   p.schurPanels = schurPanels ? 1 : 0; p.nPanelBlocks = nPanelBlocks; p.nPanelPairs = nPanelPairs;
   p.panelWork = reinterpret_cast<const int4*>(dPanelWork_.p); p.panelChunks = dPanelChunks_.p; p.panelPairPtr = dPanelPairPtr_.p;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
+  if (resident) { p.lmPtr = res_.lmPtr[res_.cur].p; p.obsUv = res_.uv[res_.cur].p; p.obsW = res_.w[res_.cur].p; p.obsLm = res_.obsLm[res_.cur].p; }
   p.lmPrior = dLmPrior_.p;
   curSet_ = 0;
   auto setLin = [&](int set, double*& r, double*& Jp, double*& Jl, double*& Je) {
@@ -1137,11 +1430,11 @@ void Window::pack() {
     p.priorDchi = ps; p.priorGrad = ps + priorM; p.priorDchiC = ps + 2 * priorM; p.priorGradC = ps + 3 * priorM;
     p.priorMv = ps + 4 * priorM; p.priorMy = ps + 5 * priorM;
     p.priorM3 = ps + 6 * priorM; p.priorM3C = p.priorM3 + 9 * hPb.size();
-    HIP_OK(hipMemsetAsync(ps, 0, sizeof(double) * (6 * (size_t)priorM + 18 * hPb.size()), s));
+    addFill(clears, ps, nullptr, 6 * (size_t)priorM + 18 * hPb.size());
   }
   const int dd = std::max(d, 1);
   // accumulators start clear: the trust-region loop never launches k_zero_build (k_post_solve re-clears them)
-  HIP_OK(hipMemsetAsync(dS_.p, 0, sizeof(double) * ((size_t)sS * sS + (size_t)12 * dd), s));
+  addFill(clears, dS_.p, nullptr, (size_t)sS * sS + (size_t)12 * dd);
   p.S = dS_.p;
   p.ldS = sS;
   p.sPadded = 1;
@@ -1156,8 +1449,10 @@ void Window::pack() {
   p.scal = dScal_.p;
   p.partial = dPartial_.p;
   p.tickets = reinterpret_cast<unsigned int*>(dPartial_.p + (size_t)14 * 4096);  // zeroed with the partials
-  HIP_OK(hipMemsetAsync(dScal_.p, 0, sizeof(SolverScalars), s));
-  HIP_OK(hipMemsetAsync(dPartial_.p, 0, sizeof(double) * 16 * 4096, s));
+  static_assert(sizeof(SolverScalars) % 8 == 0, "cleared in 8-byte words");
+  addFill(clears, dScal_.p, nullptr, sizeof(SolverScalars) / 8);
+  addFill(clears, dPartial_.p, nullptr, (size_t)16 * 4096);
+  launchFillJobs(clears, s);   // one launch instead of four hipMemsetAsync
   if (getenv("SVIN_PACK_TIMING")) {
     const double tPack2 = nowSec();
     HIP_OK(hipStreamSynchronize(s));
@@ -1169,10 +1464,17 @@ void Window::pack() {
 void Window::downloadStates() {
   hipStream_t s = stream_;
   const DeviceProblem& p = prob_;
+  const bool resident = residentUsed_;   // landmark points and qualities stay on the device, keyed by handle (syncLandmarks fetches)
   std::vector<double> hPose(poseIds_.size() * 7), hExt(std::max<size_t>(extIds_.size(), 1) * 7), hSb(sbIds_.size() * 9),
-      hLm((size_t)p.L * 4), hQ(p.L);
+      hLm(resident ? 0 : (size_t)p.L * 4), hQ(resident ? 0 : p.L);
   std::vector<DevImu> hImu(p.nImu);
-  if (p.L > 0) launchLandmarkQuality(p, dQuality_.p, s);
+  if (p.L > 0 && !resident) launchLandmarkQuality(p, dQuality_.p, s);
+  if (resident && res_.H > 0) {
+    launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, p.lm, nullptr, res_.lmHp.p, res_.qualH.p, s);
+    lmStale_ = true;
+    qualityPending_ = true;
+    qualityProb_ = p;
+  }
   {  // one gather kernel + one DMA into the pinned block instead of six read-backs
     GatherArgs ga;
     std::memset(&ga, 0, sizeof(ga));
@@ -1190,7 +1492,7 @@ void Window::downloadStates() {
     add(p.pose, hPose.data(), sizeof(double) * hPose.size());
     if (!extIds_.empty()) add(p.ext, hExt.data(), sizeof(double) * extIds_.size() * 7);
     add(p.sb, hSb.data(), sizeof(double) * hSb.size());
-    if (p.L > 0) {
+    if (p.L > 0 && !resident) {
       add(p.lm, hLm.data(), sizeof(double) * hLm.size());
       add(dQuality_.p, hQ.data(), sizeof(double) * p.L);
     }
@@ -1212,14 +1514,18 @@ void Window::downloadStates() {
   for (size_t i = 0; i < poseIds_.size(); ++i) std::memcpy(blocks_.at(poseIds_[i]).x, &hPose[7 * i], 7 * sizeof(double));
   for (size_t i = 0; i < extIds_.size(); ++i) std::memcpy(blocks_.at(extIds_[i]).x, &hExt[7 * i], 7 * sizeof(double));
   for (size_t i = 0; i < sbIds_.size(); ++i) std::memcpy(blocks_.at(sbIds_[i]).x, &hSb[9 * i], 9 * sizeof(double));
-  for (size_t i = 0; i < lmIds_.size(); ++i) {
-    Landmark& lm = landmarks_.at(lmIds_[i]);
-    std::memcpy(lm.hp, &hLm[4 * i], 4 * sizeof(double));
-    lm.quality = hQ[i];
+  if (!resident) {
+    for (size_t i = 0; i < lmIds_.size(); ++i) {
+      Landmark& lm = landmarks_.at(lmIds_[i]);
+      std::memcpy(lm.hp, &hLm[4 * i], 4 * sizeof(double));
+      lm.quality = hQ[i];
+    }
+    // Estimator::optimize also sets quality of unobserved landmarks: getLhs yields H = 0 -> quality 0 (:910-913)
+    for (auto& kv : landmarks_)
+      if (kv.second.obs.empty()) kv.second.quality = 0.0;
+  } else {
+    checkResidentStatus();   // (k_window_store_landmarks does the same per handle on the device)
   }
-  // Estimator::optimize also sets quality of unobserved landmarks: getLhs yields H = 0 -> quality 0 (:910-913)
-  for (auto& kv : landmarks_)
-    if (kv.second.obs.empty()) kv.second.quality = 0.0;
   int k = 0;
   for (uint64_t fid : factorIds_) {   // the factors this rank packed, in pack() order
     Factor& f = factors_.at(fid);
@@ -1443,9 +1749,19 @@ int Window::finish() {
   return 1;
 }
 int Window::optimize(size_t numIter, bool verbose) {
-  prepare();
-  solvePrepared(numIter, verbose);
-  return finish();
+  // (prepare / solvePrepared / finish with their synchronisation points are the measurement form; here the solve is enqueued
+  // right behind the upload and the rebuild of the resident window)
+  const double t0 = nowSec();
+  pack(/*solveFollows=*/true);
+  const double t1 = nowSec();
+  summary_.upload_time = t1 - t0;   // host time of pack(): the device part overlaps the first launches of the solve
+  maxIterationsOption_ = numIter;
+  solve(numIter, verbose);
+  const double t2 = nowSec();
+  summary_.solve_time = t2 - t1;    // the trust-region loop ends on a host decision: the device has caught up
+  downloadStates();
+  summary_.download_time = nowSec() - t2;
+  return 1;
 }
 
 int Window::setOptimizationTimeLimit(double timeLimit, int minIter) {  // :932-951
@@ -1467,7 +1783,12 @@ int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t*
   HIP_OK(hipStreamSynchronize(stream_));
   // same order as pack(): landmarks in CSR order (lmIds_), observations in insertion order
   int n = 0;
-  for (uint64_t id : lmIds_) {
+  std::vector<uint64_t> order(lmIds_);
+  if (residentUsed_) {
+    order.clear();
+    for (const Landmark* lp : lmByHandle_) if (lp && !lp->obs.empty()) order.push_back(lp->id);
+  }
+  for (uint64_t id : order) {
     const Landmark& l = landmarks_.at(id);
     for (const Observation& o : l.obs) {
       if (n < cap) {
@@ -1490,6 +1811,29 @@ int Window::observationIds(uint64_t* rid, uint64_t* lm, uint64_t* pose, int32_t*
       }
   }
   return n;
+}
+int Window::debugCsr(int32_t* L, int32_t* N, int32_t* lmPtr, int32_t* obsLm, uint32_t* obsIdx, double* uv, double* w, double* lm,
+                     int32_t* obsOrder, int32_t* residentOut) {
+  pack();
+  HIP_OK(hipStreamSynchronize(stream_));
+  if (residentUsed_) checkResidentStatus();
+  const DeviceProblem& p = prob_;
+  if (L) *L = p.L;
+  if (N) *N = p.N;
+  if (residentOut) *residentOut = residentUsed_ ? 1 : 0;
+  if (lmPtr && p.L > 0) HIP_OK(hipMemcpy(lmPtr, p.lmPtr, sizeof(int) * (p.L + 1), hipMemcpyDeviceToHost));
+  if (lm && p.L > 0) HIP_OK(hipMemcpy(lm, p.lm, sizeof(double) * 4 * p.L, hipMemcpyDeviceToHost));
+  if (p.N > 0) {
+    if (obsLm) HIP_OK(hipMemcpy(obsLm, p.obsLm, sizeof(int) * p.N, hipMemcpyDeviceToHost));
+    if (obsIdx) HIP_OK(hipMemcpy(obsIdx, p.obsIdx, sizeof(uint32_t) * p.N, hipMemcpyDeviceToHost));
+    if (uv) HIP_OK(hipMemcpy(uv, p.obsUv, sizeof(double) * 2 * p.N, hipMemcpyDeviceToHost));
+    if (w) HIP_OK(hipMemcpy(w, p.obsW, sizeof(double) * p.N, hipMemcpyDeviceToHost));
+    if (obsOrder) {
+      if (p.obsOrder) HIP_OK(hipMemcpy(obsOrder, p.obsOrder, sizeof(int) * p.N, hipMemcpyDeviceToHost));
+      else for (int i = 0; i < p.N; ++i) obsOrder[i] = -1;
+    }
+  }
+  return 1;
 }
 int Window::evalReprojection(bool robust, double* r, double* Jp, double* Jl, double* Je, int cap) {
   pack();

@@ -19,8 +19,12 @@
 #include <unordered_map>
 #include <vector>
 #include "kernels.hpp"
+#include "resident.hpp"
 
 namespace svin {
+
+constexpr int kResidentPoseCap = 42;   // windows up to this many pose blocks keep their observation CSR on the device; wider ones
+                                       // (the panel Schur kernels with their host-built work lists) are re-packed by the host
 
 struct TimeStamp {
   uint32_t sec = 0, nsec = 0;
@@ -38,24 +42,36 @@ struct Block {
   double x[9] = {0};
   std::vector<uint64_t> residuals;  // ids of the factors / the prior touching it (insertion order)
   int nObs = 0;                     // reprojection residuals touching it (they live in Landmark::obs only)
+  int handle = -1;                  // stable small number among the blocks of its kind (recycled): how the device-resident
+                                    // observation records name their pose / extrinsics block (resident.hpp)
+  std::vector<int> seenLm;          // pose blocks: handles of the landmarks observed from this frame, one entry per observation
+                                    // (candidates of the marginalisation policy when the frame leaves; may name dead landmarks)
 };
 
+// one cache line per record: addObservation's duplicate check and the marginalisation policy walk these lists
 struct Observation {
-  uint64_t resId = 0, poseId = 0, extId = 0;
-  int cam = 0;
+  uint64_t resId = 0, poseId = 0;
   uint64_t kp = 0;
   double uv[2] = {0, 0};
   double size = 1.0;
+  uint32_t pendIdx = 0, pendEpoch = 0;   // position in the add log while the record has not reached the device (resident.hpp)
+  uint16_t poseH = 0, extH = 0;           // Block::handle of the pose and the extrinsics block (the extrinsics id: Window::extIdOf)
+  uint8_t cam = 0;
 };
+static_assert(sizeof(Observation) == 64, "Observation is meant to fill one cache line");
 
 struct Landmark {
+  // what addObservation and the marginalisation policy touch comes first (one or two cache lines of the map node)
+  std::vector<Observation> obs;  // insertion order
   uint64_t id = 0;
+  uint64_t maxPose = 0;            // upper bound of the frame ids among obs: an observation from a newer frame cannot be a duplicate
+  uint64_t minPose = UINT64_MAX;   // smallest frame id among obs (frame ids grow with time): lets the marginalisation policy skip a
+                                   // landmark nobody in the leaving frames has seen without walking its observation list
+  int handle = -1;               // creation number (resident.hpp): CSR order of the device-resident window
+  uint32_t visit = 0;            // scratch stamp of the marginalisation policy (a landmark is handled once per call)
+  bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
   double hp[4] = {0, 0, 0, 1};
   double quality = 0, distance = 0;
-  bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
-  std::vector<Observation> obs;  // insertion order
-  uint64_t minPose = UINT64_MAX;   // smallest frame id among obs (frame ids grow with time): lets the marginalisation policy skip a
-                                  // landmark nobody in the leaving frames has seen without walking its observation list
   // HomogeneousPointError residuals on this landmark (HomogeneousPointError.cpp:48-117): measurement and the
   // upper-triangular square-root information (row-major); not added by okvis::Estimator, available to callers
   struct Prior { uint64_t resId = 0; double meas[4] = {0, 0, 0, 1}; double sqrtInfo[9] = {0}; };
@@ -115,6 +131,70 @@ struct DevBuf {
     if (hipMalloc(&p, c * sizeof(T)) != hipSuccess) { p = nullptr; cap = 0; throw std::runtime_error("hipMalloc failed"); }
     cap = c;
   }
+  // the same, keeping the first `keep` elements (device-to-device copy on `s`) and clearing the rest of the new allocation
+  void growKeep(size_t n, size_t keep, hipStream_t s) {
+    if (n <= cap) return;
+    size_t c = cap ? cap : 64;
+    while (c < n) c *= 2;
+    T* q = nullptr;
+    if (hipMalloc(&q, c * sizeof(T)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+    if (keep > cap) keep = cap;
+    if (p && keep) (void)hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+    (void)hipMemsetAsync(q + keep, 0, (c - keep) * sizeof(T), s);
+    if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); }
+    p = q; cap = c;
+  }
+};
+
+// open-addressing map uint64 -> uint64 (linear probing, backward-shift deletion): residual id -> landmark id and landmark
+// id -> handle are looked up once per addObservation / removeObservation -- a node-based std::unordered_map spends more time
+// in malloc / free than the rest of the call
+class FlatMap64 {
+ public:
+  static constexpr uint64_t kEmpty = UINT64_MAX;   // (values are handles and node addresses: never this)
+  FlatMap64() { rehash(1024); }
+  size_t size() const { return n_; }
+  bool find(uint64_t key, uint64_t* val) const {
+    for (size_t i = slot(key);; i = (i + 1) & mask_) {
+      if (e_[i].val == kEmpty) return false;
+      if (e_[i].key == key) { if (val) *val = e_[i].val; return true; }
+    }
+  }
+  bool count(uint64_t key) const { return find(key, nullptr); }
+  void set(uint64_t key, uint64_t val) {
+    if ((n_ + 1) * 2 > mask_ + 1) rehash(2 * (mask_ + 1));
+    for (size_t i = slot(key);; i = (i + 1) & mask_) {
+      if (e_[i].val == kEmpty) { e_[i].key = key; e_[i].val = val; ++n_; return; }
+      if (e_[i].key == key) { e_[i].val = val; return; }
+    }
+  }
+  bool erase(uint64_t key) {
+    size_t i = slot(key);
+    for (;; i = (i + 1) & mask_) {
+      if (e_[i].val == kEmpty) return false;
+      if (e_[i].key == key) break;
+    }
+    for (size_t j = (i + 1) & mask_;; j = (j + 1) & mask_) {   // close the gap: move back every entry that probes through it
+      if (e_[j].val == kEmpty) break;
+      const size_t home = slot(e_[j].key);
+      if (((j - home) & mask_) >= ((j - i) & mask_)) { e_[i] = e_[j]; i = j; }
+    }
+    e_[i].val = kEmpty;
+    --n_;
+    return true;
+  }
+
+ private:
+  struct Entry { uint64_t key, val; };
+  size_t slot(uint64_t k) const { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask_; }
+  void rehash(size_t cap) {
+    std::vector<Entry> old = std::move(e_);
+    e_.assign(cap, Entry{0, kEmpty});
+    mask_ = cap - 1; n_ = 0;
+    for (const Entry& en : old) if (en.val != kEmpty) set(en.key, en.val);
+  }
+  std::vector<Entry> e_;
+  size_t mask_ = 0, n_ = 0;
 };
 
 // device buffers of the marginalisation job (marg.hip), kept across calls
@@ -151,7 +231,7 @@ class Window {
   void setIdProvider(IdProviderFn fn, void* user) { idProvider_ = fn; idProviderUser_ = user; }
   void reserveIds(uint64_t maxSeen) { if (maxSeen > idCounter_) idCounter_ = maxSeen; }
   uint64_t newId() { return idProvider_ ? idProvider_(idProviderUser_) : ++idCounter_; }
-  bool idInUse(uint64_t id) const { return blocks_.count(id) || landmarks_.count(id) || states_.count(id); }
+  bool idInUse(uint64_t id) const { return blocks_.count(id) || lmIndex_.count(id) || states_.count(id); }
   int addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig);
   int setCameraGeometry(size_t cam, int model, const double* intr, const double* dist, int nDist, int w, int h);
   int addImu(const ImuParams& p);
@@ -166,6 +246,9 @@ class Window {
                 const double* depth, int nDepth, double firstDepth);
   int addLandmark(uint64_t id, const double* hp);
   uint64_t addObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
+  // the same for a batch (what a frontend holds after matching): identical results, the landmark records are prefetched
+  int addObservations(int n, const uint64_t* lm, const uint64_t* pose, const uint64_t* cam, const uint64_t* kp, const double* uv,
+                      const double* size, uint64_t* outIds);
   int removeObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp);
   int removeObservationById(uint64_t resId);
   // HomogeneousPointError on a landmark (information = 3x3 symmetric positive definite, row-major); 0 on failure
@@ -188,7 +271,7 @@ class Window {
   int get_T_WS(uint64_t id, double* T) const;
   int getSpeedAndBias(uint64_t id, size_t imu, double* sb) const;
   int getCameraSensorStates(uint64_t id, size_t cam, double* T) const;
-  const Landmark* landmark(uint64_t id) const;
+  const Landmark* landmark(uint64_t id) const;   // (fetches the landmark points from the device first when a solve has moved them)
   int set_T_WS(uint64_t id, const double* T);
   int setSpeedAndBias(uint64_t id, size_t imu, const double* sb);
   int setCameraSensorStates(uint64_t id, size_t cam, const double* T);
@@ -201,14 +284,28 @@ class Window {
   // okvis::ceres::Map graph queries answered from the core's own graph (Map.cpp:495-620).  Residual ids are the ids
   // addObservation / the factors / the prior were given; block ids are frame ids (pose), internal ids (extrinsics,
   // speed/bias) and landmark ids.
-  bool parameterBlockExists(uint64_t id) const { return blocks_.count(id) || landmarks_.count(id); }   // Map.cpp:77-80
+  bool parameterBlockExists(uint64_t id) const { return blocks_.count(id) || lmIndex_.count(id); }   // Map.cpp:77-80
   int setParameterBlockConstant(uint64_t id, bool constant);     // Map.cpp:495-510 (landmarks: SVIN_ERR_UNSUPPORTED)
   int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
   int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
   int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
   int residualKind(uint64_t resId) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, 102 landmark prior, else FactorKind
   const std::map<uint64_t, State>& states() const { return states_; }
-  const std::map<uint64_t, Landmark>& landmarks() const { return landmarks_; }
+  const std::map<uint64_t, Landmark>& landmarks() const { syncLandmarks(); return landmarks_; }
+  size_t numLandmarks() const { return landmarks_.size(); }
+  const Landmark* landmarkGraph(uint64_t id) const {   // structure only (observation list, flags): no fetch from the device
+    auto it = landmarks_.find(id);
+    return it == landmarks_.end() ? nullptr : &it->second;
+  }
+  const std::map<uint64_t, Landmark>& landmarksGraph() const { return landmarks_; }
+  bool landmarkExists(uint64_t id) const { return lmIndex_.count(id); }
+  // ---- device-resident window (resident.hpp): 0 = resident whenever the window qualifies (narrow, one GPU, no landmark
+  // priors), 1 = always the host path (Window::pack's graph -> array pass and full upload: the reference the tests compare with)
+  void setPackMode(int mode) { packMode_ = mode; }
+  // inspection: pack() and copy the observation CSR the solver would read (sizes first: call with null pointers)
+  int debugCsr(int32_t* L, int32_t* N, int32_t* lmPtr, int32_t* obsLm, uint32_t* obsIdx, double* uv, double* w, double* lm,
+               int32_t* obsOrder, int32_t* resident);
+  void syncLandmarks() const;   // landmark points / qualities of the last solve: device tables -> host graph (no-op when current)
   uint64_t currentKeyframeId() const;
   uint64_t frameIdByAge(size_t age) const;
   bool isInImuWindow(uint64_t id) const;
@@ -253,11 +350,14 @@ class Window {
   uint64_t addFactor(Factor&& f);
   void removeFactor(uint64_t id);
   void removeObsRecord(Landmark& lm, size_t idx);
+  void eraseLandmark(Landmark& lm);   // (its observations are gone already)
+  uint64_t addObservationTo(Landmark& lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
+  uint64_t extIdOf(const Observation& o) const { return blockByHandle_[B_EXT][o.extH]->id; }
   Block* findBlock(uint64_t id);
   const Block* findBlock(uint64_t id) const;
 
   // device side
-  void pack();                 // host graph -> device arrays (sets prob_)
+  void pack(bool solveFollows = false);   // host graph -> device arrays (sets prob_); solveFollows: called by optimize()
   void downloadStates();       // device tables -> host blocks / landmarks / imu states
   void evaluateAll(bool cand, hipStream_t s);
   void solve(size_t numIter, bool verbose);
@@ -294,7 +394,57 @@ class Window {
   std::map<uint64_t, Landmark> landmarks_;
   std::unordered_map<uint64_t, Block> blocks_;
   std::map<uint64_t, Factor> factors_;
-  std::unordered_map<uint64_t, uint64_t> obsRes2Lm_;  // reprojection residual id -> landmark id
+  FlatMap64 obsRes2Lm_;        // reprojection residual id -> its Landmark node (address; std::map nodes do not move)
+  FlatMap64 lmIndex_;          // landmark id -> handle
+  std::vector<Landmark*> lmByHandle_;   // handle -> node of landmarks_ (nullptr: gone); std::map nodes do not move
+  int nextLmHandle_ = 0;
+  size_t numObs_ = 0, numLmObserved_ = 0;   // reprojection residuals in the graph / landmarks with at least one
+  std::vector<int> emptyLm_;   // handles of landmarks that had no observation at some point (the marginalisation policy erases them)
+  std::vector<int> freeBlockH_[3];      // recycled Block::handle per kind
+  int nextBlockH_[3] = {0, 0, 0};
+  std::vector<Block*> blockByHandle_[3];
+  uint32_t visitStamp_ = 0;
+  // delta of the graph since the last flush to the device (only kept while the device copy is valid)
+  std::vector<WinAdd> addLog_;
+  std::vector<WinRem> remLog_;
+  std::vector<WinLmSet> setLog_;
+  uint32_t epoch_ = 1;         // identifies the add log an Observation::pendIdx refers to
+  int packMode_ = 0;
+  bool residentValid_ = false; // the device holds the window as of the last flush; the logs describe what changed since
+  bool residentUsed_ = false;  // the last pack() took the resident path
+  mutable bool lmStale_ = false;   // the device's per-handle landmark tables are newer than Landmark::hp / quality
+  int hFlushed_ = 0;           // landmark handles below this have device-side values
+  // Landmark qualities (Estimator.cpp:902-923) are only ever read through getLandmark(s): the resident path computes them
+  // when somebody asks (or before the tables of that solve are overwritten), not at the end of every optimize()
+  mutable bool qualityPending_ = false;
+  mutable DeviceProblem qualityProb_;
+  void flushPendingQuality() const;
+  struct Resident {
+    DevBuf<double> uv[2], w[2], lmHp, qualH;
+    DevBuf<uint32_t> hnd[2], seq[2];
+    DevBuf<int> lmPtr[2], handleOfSlot[2], slotOfH[2], obsLm[2], cnt, addsH, addCur, poseSlotOfH, extSlotOfH, margScratch;
+    DevBuf<unsigned char> live, poseClass;
+    DevBuf<WinAdd> adds;
+    DevBuf<WinRem> rems;
+    DevBuf<WinLmSet> sets;
+    int cur = 0, N = 0, L = 0, H = 0;
+  };
+  mutable Resident res_;
+  int* resStatus_ = nullptr;      // pinned, device-visible: consistency flag of the rebuild / gather kernels
+  int* resStatusDev_ = nullptr;
+  mutable double* lmSyncHost_ = nullptr;   // pinned read-back area of syncLandmarks
+  mutable size_t lmSyncCap_ = 0;
+  bool useResident() const;
+  void invalidateResident();      // the next pack() uploads the whole graph again
+  void renumberLandmarkHandles();
+  void flushResident(hipStream_t s, bool wantOrder, std::vector<StagedCopy>& pending, ResidentArgs& ra);
+  void checkResidentStatus();
+  Block* cachedBlock(uint64_t id);
+  Block* blockCache_[4] = {nullptr, nullptr, nullptr, nullptr};
+  int blockCacheNext_ = 0;
+  size_t margLdsSet_[2] = {0, 0};   // dynamic LDS already granted to k_marg_dense / k_marg_final (hipFuncSetAttribute is not free)
+  uint64_t obsCachePose_ = 0;     // frame whose extrinsics block ids obsCacheExt_ holds (0: none)
+  uint64_t obsCacheExt_[16] = {0};
   std::unordered_map<uint64_t, uint64_t> lmPriorRes2Lm_;  // HomogeneousPointError residual id -> landmark id
   size_t numLandmarkPriors_ = 0;
   DevBuf<double> dLmPrior_;
@@ -307,7 +457,6 @@ class Window {
   std::vector<PriorBlockHost> priorBlocks_;
   std::vector<double> priorH_, priorB0_, priorJ_, priorE0_;  // H/b0 as marginalised; J,e0 from M3
   bool priorHostValid_ = false;                              // host copies above fetched from the device (getPrior)
-  std::vector<std::shared_ptr<void>> margHold_;              // host staging of the last (asynchronous) marginalisation job
   int priorM_ = 0;
 
   // solver options

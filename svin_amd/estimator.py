@@ -56,7 +56,7 @@ EXPORTS = [
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
     "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
-    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_bench_kernel_times",
+    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_bench_kernel_times",
     "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
     "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
@@ -155,6 +155,8 @@ def load_library():
     sig("svin_ba_describe_block", i32, vp, u64, pu64, pi32, pi32)
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_jacobian_eval_b2b", i32, vp, i32, i32, pd, pd, pd)
+    sig("svin_ba_set_pack_mode", i32, vp, i32)
+    sig("svin_ba_debug_csr", i32, vp, pi32, pi32, pi32, pi32, C.POINTER(C.c_uint32), pd, pd, pd, pi32, pi32)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
     sig("svin_host_imu_propagation", i32, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd, pd)
     sig("svin_host_reprojection_error", i32, i32, pd, pd, i32, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd, pd)
@@ -728,6 +730,27 @@ class Estimator:
         ms, by = np.zeros(1), np.zeros(1)
         self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
         return float(ms[0]), float(by[0])
+
+    def set_pack_mode(self, mode):
+        """0: device-resident window whenever it qualifies (default); 1: always the host graph -> array pass + full upload"""
+        self._check(self.L.svin_ba_set_pack_mode(self.h, int(mode)), "set_pack_mode")
+
+    def debug_csr(self):
+        """the observation CSR optimize() would solve on, copied back from the device"""
+        L, N, res = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.L.svin_ba_debug_csr(self.h, C.byref(L), C.byref(N), None, None, None, None, None, None, None, C.byref(res)),
+                    "debug_csr")
+        L, N = L.value, N.value
+        out = dict(L=L, N=N, lm_ptr=np.zeros(L + 1, np.int32), obs_lm=np.zeros(N, np.int32), obs_idx=np.zeros(N, np.uint32),
+                   uv=np.zeros((N, 2)), w=np.zeros(N), lm=np.zeros((L, 4)), obs_order=np.zeros(N, np.int32))
+        L2, N2 = C.c_int32(), C.c_int32()
+        self._check(self.L.svin_ba_debug_csr(
+            self.h, C.byref(L2), C.byref(N2), out["lm_ptr"].ctypes.data_as(C.POINTER(C.c_int32)),
+            out["obs_lm"].ctypes.data_as(C.POINTER(C.c_int32)), out["obs_idx"].ctypes.data_as(C.POINTER(C.c_uint32)),
+            _d(out["uv"]), _d(out["w"]), _d(out["lm"]), out["obs_order"].ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res)), "debug_csr")
+        assert (L2.value, N2.value) == (L, N)
+        out["resident"] = bool(res.value)
+        return out
 
     def bench_jacobian_eval_b2b(self, copies, iters):
         """(mean ms per launch with one event pair per launch, ms per launch with the launches back to back under one pair, bytes)"""
