@@ -162,7 +162,9 @@ def init_distributed(args):
             os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # (rank 0 measures the sub-records alone while the others wait at the final barrier: minutes, not seconds)
+            import datetime
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=45))
     return rank, world, local_rank, dist
 
 
@@ -408,6 +410,48 @@ def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
                            "[lower(S) | g | h], [8 dogleg sums | the ranks' (gradient max, failure flag) pairs], [8 cost / step sums | stop vote]")
 
 
+def run_sharded_children(world, force_sharded):
+    """starts `world` fresh ranks of `bench.py --sharded-child` and returns rank 0's record (or what went wrong)"""
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith("TORCHELASTIC") and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_PORT", "GROUP_WORLD_SIZE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        env["SVIN_FORCE_DISTRIBUTED"] = "1"   # a one-rank communicator still takes the sharded code path
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), "--sharded-child", "--gpus", str(world)]
+    if force_sharded:
+        cmd.append("--force-sharded")
+    timeout = float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "420"))
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "the sharded ranks did not finish within %.0f s (killed)" % timeout}
+    for line in r.stdout.decode(errors="replace").splitlines()[::-1]:
+        if line.startswith("SHARDED_JSON:"):
+            rec = json.loads(line[len("SHARDED_JSON:"):])
+            if r.returncode != 0:
+                rec["launcher_returncode"] = r.returncode
+            return rec
+    return {"error": "the sharded ranks ended with return code %d and no record" % r.returncode,
+            "stderr_tail": r.stderr.decode(errors="replace")[-1500:]}
+
+
+def main_sharded_child(args):
+    """one rank of the sharded config-#4 sub-record (started by run_sharded_children)"""
+    rank, world, local_rank, dist = init_distributed(args)
+    try:
+        rec = sharded_config4(rank, world, local_rank, dist, 20, 3)
+    except Exception as ex:   # noqa: BLE001
+        rec = {"error": repr(ex)}
+    if rank == 0:
+        os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, ("SHARDED_JSON:" + json.dumps(rec) + "\n").encode())
+    if "error" in rec:
+        os._exit(3)    # (no further collective: the other ranks may be anywhere)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,7 +467,13 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded config-#4 sub-record even with one rank (one-rank RCCL communicator: every collective "
                          "really runs): the only way to exercise that code path on a 1-GPU box")
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sharded_child:
+        protect_stdout()
+        if args.gpus == 1:
+            args.force_sharded = True
+        return main_sharded_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     protect_stdout()
@@ -529,27 +579,12 @@ def main():
     del est
     if not args.no_extras:
         extras = {}
-        if (world > 1 or args.force_sharded) and not os.environ.get("SVIN_BENCH_NO_SHARDED"):
-            if world == 1:
-                os.environ["SVIN_FORCE_DISTRIBUTED"] = "1"   # a one-rank communicator still takes the sharded code path
-            # watchdog: a collective that never returns must not cost the headline line
-            done = threading.Event()
-
-            def watchdog():
-                if not done.wait(float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "300"))):
-                    if rank == 0:
-                        out["sharded_config4"] = {"error": "timed out (watchdog)"}
-                        out.update(extras)
-                        emit(out)
-                    os._exit(0)
-            threading.Thread(target=watchdog, daemon=True).start()
-            try:
-                rec = sharded_config4(rank, world, local_rank, dist, 20, 3)
-            except Exception as ex:
-                rec = {"error": repr(ex)}
-            done.set()
-            if rank == 0:
-                extras["sharded_config4"] = rec
+        if (world > 1 or args.force_sharded) and not os.environ.get("SVIN_BENCH_NO_SHARDED") and rank == 0:
+            # The sharded window runs in ranks of its OWN (one fresh process per GPU, started from here): a collective that
+            # never returns, an exception on one rank or a rank that dies -- under a launcher the death of any rank ends all
+            # of them, headline line included -- then costs this sub-record and nothing else.  The ranks of the headline
+            # measurement wait at the final barrier meanwhile (their GPUs are idle).
+            extras["sharded_config4"] = run_sharded_children(world, args.force_sharded)
         if rank == 0:
             try:
                 spec3 = syn.make_window(P=10, L=4000, n_obs=40000, seed=20250629, rig="rig_v2", sonar=True, depth=True)

@@ -12,10 +12,10 @@ namespace {
 
 constexpr int kRebuildThreads = 1024;
 
-// values other threads of the workgroup produced with atomics (device-scope read: never a stale L1 line)
-__device__ __forceinline__ int ldAtomic(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Values other threads of the workgroup produced with atomics in an earlier phase.  A workgroup shares its CU's vector L1,
+// the atomics execute in L2 and the kernel has not read these lines before the barrier that follows them, so a plain load
+// after that barrier sees them (and the compiler may issue a thread's loads back to back: an atomic load waits for each).
+__device__ __forceinline__ int ldAtomic(const int* p) { return *p; }
 
 // exclusive prefix sums of a pair of ints over the workgroup; wsum: 17 int2 of LDS.  Ends with a barrier.
 __device__ int2 blockScanExclusive(int2 v, int2* wsum, int2& total) {
@@ -58,11 +58,10 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
   for (int i = t; i < a.nRem; i += nt) {
     const WinRem r = a.rems[i];
     const int s = a.slotOfHOld[r.lmH];
-    bool found = false;
-    if (s >= 0)
-      for (int o = a.lmPtrOld[s], e = a.lmPtrOld[s + 1]; o < e; ++o)
-        if (a.seqOld[o] == r.seq && a.live[o]) { a.live[o] = 0; found = true; break; }
-    if (found) atomicSub(&a.cnt[r.lmH], 1);
+    int at = -1;
+    if (s >= 0)   // no early exit: the loads of the whole segment go out together (a sequence number occurs once per landmark)
+      for (int o = a.lmPtrOld[s], e = a.lmPtrOld[s + 1]; o < e; ++o) at = (a.seqOld[o] == r.seq) ? o : at;
+    if (at >= 0 && a.live[at]) { a.live[at] = 0; atomicSub(&a.cnt[r.lmH], 1); }
     else atomicOr(&err, 1);
   }
   for (int i = t; i < a.nAdd; i += nt) {

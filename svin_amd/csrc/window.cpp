@@ -246,10 +246,10 @@ void Window::removeObsRecord(Landmark& lm, size_t idx) {
 }
 void Window::eraseLandmark(Landmark& lm) {
   while (!lm.obs.empty()) removeObsRecord(lm, lm.obs.size() - 1);
-  const uint64_t id = lm.id;
-  lmByHandle_[lm.handle] = nullptr;
-  lmIndex_.erase(id);
-  landmarks_.erase(id);
+  const int h = lm.handle;
+  lmByHandle_[h] = nullptr;
+  lmIndex_.erase(lm.id);
+  landmarks_.erase(lmIterByHandle_[h]);
 }
 void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (Map.cpp:322-333)
   Block* b = findBlock(id);
@@ -534,8 +534,10 @@ int Window::addLandmark(uint64_t id, const double* hp) {  // :414-429
   }
   lm.distance = dist;
   lm.handle = nextLmHandle_++;
-  Landmark* node = &(landmarks_[id] = lm);
+  auto ins = landmarks_.emplace(id, lm).first;
+  Landmark* node = &ins->second;
   lmByHandle_.push_back(node);
+  lmIterByHandle_.push_back(ins);
   lmIndex_.set(id, (uint64_t)lm.handle);
   emptyLm_.push_back(lm.handle);
   if (residentValid_) {
@@ -898,11 +900,13 @@ void Window::renumberLandmarkHandles() {
   std::vector<int> newOf(lmByHandle_.size(), -1);
   std::vector<Landmark*> fresh;
   fresh.reserve(landmarks_.size());
-  for (auto& kv : landmarks_) {
-    newOf[kv.second.handle] = (int)fresh.size();
-    kv.second.handle = (int)fresh.size();
-    lmIndex_.set(kv.first, (uint64_t)kv.second.handle);
-    fresh.push_back(&kv.second);
+  lmIterByHandle_.clear();
+  for (auto it = landmarks_.begin(); it != landmarks_.end(); ++it) {
+    newOf[it->second.handle] = (int)fresh.size();
+    it->second.handle = (int)fresh.size();
+    lmIndex_.set(it->first, (uint64_t)it->second.handle);
+    fresh.push_back(&it->second);
+    lmIterByHandle_.push_back(it);
   }
   lmByHandle_.swap(fresh);
   nextLmHandle_ = (int)lmByHandle_.size();

@@ -397,6 +397,7 @@ class Window {
   FlatMap64 obsRes2Lm_;        // reprojection residual id -> its Landmark node (address; std::map nodes do not move)
   FlatMap64 lmIndex_;          // landmark id -> handle
   std::vector<Landmark*> lmByHandle_;   // handle -> node of landmarks_ (nullptr: gone); std::map nodes do not move
+  std::vector<std::map<uint64_t, Landmark>::iterator> lmIterByHandle_;   // the same as iterators (erase without a search)
   int nextLmHandle_ = 0;
   size_t numObs_ = 0, numLmObserved_ = 0;   // reprojection residuals in the graph / landmarks with at least one
   std::vector<int> emptyLm_;   // handles of landmarks that had no observation at some point (the marginalisation policy erases them)

@@ -61,7 +61,8 @@ class _DevArray:
 
 
 def make_torch_allreduce(group=None, device="cuda"):
-    """all-reduce callback backed by torch.distributed (nccl == RCCL on ROCm; gloo on CPU)."""
+    """all-reduce callback backed by torch.distributed: device "cuda" (nccl == RCCL on ROCm, in place on the GPU buffer),
+    "stage" (GPU buffer staged through host memory for a CPU backend such as gloo) or "cpu" (host buffer, gloo)."""
     import torch
     import torch.distributed as dist
 
@@ -70,6 +71,14 @@ def make_torch_allreduce(group=None, device="cuda"):
             if device == "cuda":
                 t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+                torch.cuda.synchronize()
+            elif device == "stage":
+                # the solver's buffer lives on the GPU, the collective runs on a CPU backend (gloo): device -> host, reduce,
+                # host -> device.  What a run without RCCL (two processes sharing ONE GPU in the tests) has to do.
+                t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=group)
+                t.copy_(h)
                 torch.cuda.synchronize()
             else:
                 buf = (C.c_double * count).from_address(ptr)

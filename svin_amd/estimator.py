@@ -109,8 +109,7 @@ def load_library():
     sig("svin_ba_add_states", i32, vp, u64, u32, u32, u64, pd, i32, C.c_void_p, i32, i32, pd, i32, pd, i32, f64)
     sig("svin_ba_add_landmark", i32, vp, u64, pd)
     sig("svin_ba_add_observation", u64, vp, u64, u64, u64, u64, pd, f64)
-    sig("svin_ba_add_observations", i32, vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), pd, pd,
-        C.POINTER(u64))
+    sig("svin_ba_add_observations", i32, vp, i32, vp, vp, vp, vp, vp, vp, vp)   # (plain addresses: the call sits in the frame loop)
     sig("svin_ba_keyframe_points", i32, vp, u64, u64, i32, C.POINTER(u64), pd, C.POINTER(u64), pd, C.POINTER(i32), i32,
         C.POINTER(u64), C.POINTER(i32))
     sig("svin_ba_remove_observation", i32, vp, u64, u64, u64, u64)
@@ -399,9 +398,8 @@ class Estimator:
         uvs = np.ascontiguousarray(uvs, np.float64).reshape(n, 2)
         sizes = np.ascontiguousarray(sizes, np.float64)
         out = np.zeros(n, np.uint64)
-        p64 = C.POINTER(C.c_uint64)
-        self._check(self.L.svin_ba_add_observations(self.h, n, *[x.ctypes.data_as(p64) for x in a], _d(uvs), _d(sizes),
-                                                    out.ctypes.data_as(p64)), "add_observations")
+        self._check(self.L.svin_ba_add_observations(self.h, n, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                                    uvs.ctypes.data, sizes.ctypes.data, out.ctypes.data), "add_observations")
         return out
 
     def keyframe_points(self, frame_id, cam=0):
