@@ -244,6 +244,30 @@ int svin_ba_get_parameter_block(svin_ba* h, uint64_t block_id, int32_t* type, do
                                 uint32_t* nsec, int32_t* fixed, int32_t* initialized);
 int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap);
 
+/* ---- okvis::ceres::Map as a graph BUILDER (Map.cpp:255-376, :322-333, :467-492): parameter blocks and residual blocks added one
+ * by one, outside any frame -- what the reference's own tests do (okvis_ceres/test/TestMap.cpp, TestHomogeneousPointError.cpp,
+ * TestPoseError ...).  The residual kinds are the reference's error-term classes; a device solver cannot call a caller's virtual
+ * cost function, so each class has its entry point.  type: 0 = pose (T_WS, or extrinsics T_SC from its first use as the third
+ * block of a reprojection residual), 2 = speed and bias, 3 = homogeneous point.  Returns 1 / 0 (id in use, Map.cpp:257-260). */
+int svin_ba_map_add_parameter_block(svin_ba* h, uint64_t block_id, int type, const double* values);
+/* ParameterBlock::setParameters on any block of the graph (pose / extrinsics 7, speed and bias 9, landmark 4) */
+int svin_ba_set_parameter_block(svin_ba* h, uint64_t block_id, const double* values);
+/* Map::removeParameterBlock: the block and every residual on it (blocks of a frame: applyMarginalizationStrategy instead -> 0) */
+int svin_ba_map_remove_parameter_block(svin_ba* h, uint64_t block_id);
+/* PoseError(measurement, information)  src/PoseError.cpp:49-132; returns the residual id (0 = refused) */
+uint64_t svin_ba_map_add_pose_error(svin_ba* h, uint64_t block_id, const double measurement[7], const double information[36]);
+/* SpeedAndBiasError(measurement, information)  src/SpeedAndBiasError.cpp:47-113 */
+uint64_t svin_ba_map_add_speed_and_bias_error(svin_ba* h, uint64_t block_id, const double measurement[9], const double information[81]);
+/* RelativePoseError(information) between two pose (or two extrinsics) blocks  src/RelativePoseError.cpp:48-147 */
+uint64_t svin_ba_map_add_relative_pose_error(svin_ba* h, uint64_t block0, uint64_t block1, const double information[36]);
+/* ReprojectionError<geometry of camera cam_idx>(uv, information) under CauchyLoss(1) on (pose, landmark, extrinsics)
+ * (ReprojectionErrorBase.hpp:50-54, Estimator.cpp:69).  information: 2 x 2 row-major, a positive multiple of the identity
+ * (the device stores one weight per residual, as Estimator::addObservation's 64 / size^2 * I needs). */
+uint64_t svin_ba_map_add_reprojection_error(svin_ba* h, uint64_t pose_block, uint64_t landmark_id, uint64_t extrinsics_block,
+                                            uint64_t cam_idx, const double uv[2], const double information[4]);
+/* Map::removeResidualBlock for any residual of the graph (Map.cpp:467-492) */
+int svin_ba_map_remove_residual_block(svin_ba* h, uint64_t residual_id);
+
 /* ---- keyframe hand-off to pose_graph: the estimator-side content of the keyframe message that
  * ThreadedKFVio::optimizationLoop assembles (okvis_multisensor_processing/src/ThreadedKFVio.cpp:1147-1240).  For every
  * landmark whose first observation in `frame_id` (MapPoint::observations order: frame, camera, keypoint) is in camera

@@ -10,7 +10,20 @@
 namespace ceres {
 struct ResidualBlock;
 typedef ResidualBlock* ResidualBlockId;   // opaque handle carrying the core's residual id
-class LossFunction;                       // never defined: the Cauchy loss lives in the device solver
+/// The loss objects a caller hands to Map::addResidualBlock.  They carry no arithmetic: the device solver applies
+/// CauchyLoss(1) to reprojection residuals (Estimator.cpp:69) and no loss to everything else; Map checks that the object it is
+/// given names exactly that.
+class LossFunction {
+ public:
+  virtual ~LossFunction() {}
+};
+class CauchyLoss : public LossFunction {
+ public:
+  explicit CauchyLoss(double a) : a_(a) {}
+  double a() const { return a_; }
+ private:
+  double a_;
+};
 enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
 enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
 enum TerminationType { CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE };

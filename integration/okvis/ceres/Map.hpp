@@ -4,9 +4,13 @@
 // okvis_ceres see it: the public `options` / `summary` members Estimator::optimize and the tests write and read
 // (Map.hpp:341-347), `solve()`, and the graph queries.  The graph itself lives in libsvin_ba.so (the handle the owning
 // okvis::Estimator created); this class is a view onto it.  What does NOT survive, and why:
-//   * addParameterBlock / addResidualBlock with caller-supplied ::ceres::CostFunction objects (Map.cpp:255-376): a
-//     device solver cannot call virtual CPU cost functions.  The window is built through okvis::Estimator
-//     (addStates / addLandmark / addObservation), which is how the pipeline builds it anyway.
+//   * addResidualBlock with an ARBITRARY caller-supplied ::ceres::CostFunction (Map.cpp:341-376): a device solver cannot
+//     call virtual CPU cost functions.  What is there instead: addParameterBlock, and addResidualBlock for the error-term
+//     classes of this directory (PoseError, HomogeneousPointError, ReprojectionError<GEOMETRY> under CauchyLoss(1)) -- each
+//     maps onto a factor kind of the device solver (svin_ba_map_*), so that a program shaped like the reference's own tests
+//     (okvis_ceres/test/TestHomogeneousPointError.cpp:57-99, TestMap.cpp:60-150) builds its graph block by block, checks
+//     Jacobians with isJacobianCorrect, solves and reads the estimates back from its parameter-block objects.  Landmarks
+//     cannot be held constant (the landmark elimination has no such path): setParameterBlockConstant returns false for them.
 //   * ::ceres::Problem / Manifold pointers (DO_NOT_TAKE_OWNERSHIP plumbing, Map.cpp:59-64): there is no Ceres.
 //   * computeCovariance (Map.hpp:352-372): debug code of the reference, never called.
 #ifndef INTEGRATION_OKVIS_CERES_MAP_HPP_
@@ -14,8 +18,11 @@
 
 #include <svin_ba.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -26,9 +33,12 @@
 #include <okvis/Time.hpp>
 #include <okvis/ceres/CeresTypes.hpp>   // ::ceres::ResidualBlockId & co. without Ceres
 #include <okvis/ceres/ErrorInterface.hpp>
+#include <okvis/ceres/HomogeneousPointError.hpp>
 #include <okvis/ceres/HomogeneousPointParameterBlock.hpp>
 #include <okvis/ceres/ParameterBlock.hpp>
+#include <okvis/ceres/PoseError.hpp>
 #include <okvis/ceres/PoseParameterBlock.hpp>
+#include <okvis/ceres/ReprojectionError.hpp>
 #include <okvis/ceres/SpeedAndBiasParameterBlock.hpp>
 
 namespace okvis {
@@ -116,9 +126,143 @@ class Map {
     std::vector<size_t> dims_;
   };
 
-  explicit Map(svin_ba* handle = nullptr) : h_(handle) {}
-  void attach(svin_ba* handle) { h_ = handle; }
+  /// A Map of its own (the reference's tests construct one directly, TestMap.cpp:74) creates its backend handle with the
+  /// first block; the Map inside an okvis::Estimator is attached to the estimator's.
+  explicit Map(svin_ba* handle = nullptr) : h_(handle), owned_(false) {}
+  ~Map() { if (owned_ && h_) svin_ba_destroy(h_); }
+  Map(const Map&) = delete;
+  Map& operator=(const Map&) = delete;
+  void attach(svin_ba* handle) {
+    if (owned_ && h_) svin_ba_destroy(h_);
+    h_ = handle; owned_ = false;
+  }
   svin_ba* handle() const { return h_; }
+
+  // ---- graph building (Map.cpp:255-376)
+  /// Map::addParameterBlock (Map.cpp:255-319).  The block object stays with the caller and the Map (shared_ptr, like the
+  /// reference: ceres never owns it); solve() sends its current parameters to the device and writes the result back into it.
+  bool addParameterBlock(std::shared_ptr<okvis::ceres::ParameterBlock> parameterBlock, int parameterization = Trivial, const int /*group*/ = -1) {
+    ensureHandle();
+    int type = -1;
+    if (parameterBlock->dimension() == 7 && (parameterization == Pose6d || parameterization == Trivial)) type = 0;
+    else if (parameterBlock->dimension() == 9 && parameterization == Trivial) type = 2;
+    else if (parameterBlock->dimension() == 4 && (parameterization == HomogeneousPoint || parameterization == Trivial)) type = 3;
+    if (type < 0) throw std::runtime_error("okvis::ceres::Map (svin_ba shim): this block / parameterisation pair has no device counterpart");
+    if (svin_ba_map_add_parameter_block(h_, parameterBlock->id(), type, parameterBlock->parameters()) != 1) return false;   // id in use
+    blocks_[parameterBlock->id()] = parameterBlock;
+    if (parameterBlock->fixed()) svin_ba_set_parameter_block_constant(h_, parameterBlock->id(), 1);
+    return true;
+  }
+  bool removeParameterBlock(uint64_t id) {   // Map.cpp:322-333
+    need();
+    if (svin_ba_map_remove_parameter_block(h_, id) != 1) return false;
+    blocks_.erase(id);
+    for (auto it = built_.begin(); it != built_.end();) {
+      bool touches = false;
+      for (const auto& b : it->second.blocks) touches |= b->id() == id;
+      it = touches ? built_.erase(it) : std::next(it);
+    }
+    return true;
+  }
+  bool removeParameterBlock(std::shared_ptr<okvis::ceres::ParameterBlock> parameterBlock) { return removeParameterBlock(parameterBlock->id()); }
+  bool setParameterBlockConstant(std::shared_ptr<okvis::ceres::ParameterBlock> b) { b->setFixed(true); return setParameterBlockConstant(b->id()); }
+  bool setParameterBlockVariable(std::shared_ptr<okvis::ceres::ParameterBlock> b) { b->setFixed(false); return setParameterBlockVariable(b->id()); }
+
+  /// Map::addResidualBlock (Map.cpp:341-376) for the error terms of this directory.  PoseError: no loss.
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<PoseError> e, ::ceres::LossFunction* loss, std::shared_ptr<okvis::ceres::ParameterBlock> x0) {
+    need(); noLoss(loss);
+    double meas[7], info[36];
+    const okvis::kinematics::Transformation& T = e->measurement();
+    for (int k = 0; k < 3; ++k) meas[k] = T.r()[k];
+    meas[3] = T.q().x(); meas[4] = T.q().y(); meas[5] = T.q().z(); meas[6] = T.q().w();
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) info[a * 6 + b] = e->information()(a, b);
+    return record(svin_ba_map_add_pose_error(h_, x0->id(), meas, info), e, {x0});
+  }
+  /// HomogeneousPointError(measurement, information) on a landmark block: no loss (TestHomogeneousPointError.cpp:74-78)
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<HomogeneousPointError> e, ::ceres::LossFunction* loss,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> x0) {
+    need(); noLoss(loss);
+    const double meas[4] = {e->measurement()[0], e->measurement()[1], e->measurement()[2], e->measurement()[3]};
+    return record(svin_ba_add_homogeneous_point_error(h_, x0->id(), meas, e->informationRowMajor()), e, {x0});
+  }
+  /// ReprojectionError<GEOMETRY>(geometry, cameraId, measurement, information) under CauchyLoss(1) on (T_WS, hp_W, T_SC)
+  /// (TestMap.cpp:104-108, Estimator::addObservation).  information: a multiple of the identity.
+  template <class GEOMETRY_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ReprojectionError<GEOMETRY_T> > e, ::ceres::LossFunction* loss,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> pose, std::shared_ptr<okvis::ceres::ParameterBlock> point,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> extrinsics) {
+    need();
+    const ::ceres::CauchyLoss* cauchy = dynamic_cast<const ::ceres::CauchyLoss*>(loss);
+    if (!cauchy || cauchy->a() != 1.0)
+      throw std::runtime_error("okvis::ceres::Map (svin_ba shim): reprojection residuals are solved under CauchyLoss(1) (Estimator.cpp:69)");
+    const void* key = e->cameraGeometry().get();
+    auto it = cams_.find(key);
+    if (it == cams_.end()) {
+      const double sig[4] = {0, 0, 0, 0};
+      const int cam = svin_ba_add_camera(h_, e->distortionModel(), e->intrinsicsArray(), e->distortionArray(), e->numDistortionCoefficients(),
+                                         (int)e->cameraGeometry()->imageWidth(), (int)e->cameraGeometry()->imageHeight(), sig);
+      if (cam < 0) throw std::runtime_error(std::string("svin_ba_add_camera: ") + svin_ba_last_error());
+      it = cams_.emplace(key, cam).first;
+    }
+    const double uv[2] = {e->measurement()[0], e->measurement()[1]};
+    return record(svin_ba_map_add_reprojection_error(h_, pose->id(), point->id(), extrinsics->id(), (uint64_t)it->second, uv, e->informationRowMajor()),
+                  e, {pose, point, extrinsics});
+  }
+  /// Map::removeResidualBlock (Map.cpp:467-492), any residual of the graph
+  bool removeResidualBlock(::ceres::ResidualBlockId residual) {
+    need();
+    const uint64_t rid = reinterpret_cast<uint64_t>(residual);
+    built_.erase(rid);
+    return svin_ba_map_remove_residual_block(h_, rid) == 1;
+  }
+  /// Map::isJacobianCorrect (Map.cpp:153-252): central differences (delta 1e-8) through the blocks' plus() against the
+  /// analytic minimal Jacobians of the error term, max |difference| / ||numeric|| <= relTol per block.  For residuals added
+  /// through addResidualBlock (the object is evaluated on the CPU by the library's host twins).
+  bool isJacobianCorrect(::ceres::ResidualBlockId residual, double relTol = 1e-6) const {
+    auto it = built_.find(reinterpret_cast<uint64_t>(residual));
+    if (it == built_.end()) throw std::runtime_error("okvis::ceres::Map (svin_ba shim): isJacobianCorrect needs a residual added through addResidualBlock");
+    const Built& r = it->second;
+    const size_t nb = r.blocks.size(), m = r.m;
+    std::vector<const double*> par(nb);
+    std::vector<std::vector<double> > J(nb), Jmin(nb), Jnum(nb);
+    std::vector<double*> Jp(nb), Jminp(nb);
+    for (size_t i = 0; i < nb; ++i) {
+      par[i] = r.blocks[i]->parameters();
+      J[i].assign(m * r.blocks[i]->dimension(), 0.0); Jmin[i].assign(m * r.blocks[i]->minimalDimension(), 0.0);
+      Jnum[i].assign(m * r.blocks[i]->minimalDimension(), 0.0);
+      Jp[i] = J[i].data(); Jminp[i] = Jmin[i].data();
+    }
+    const double delta = 1e-8;
+    std::vector<double> rp(m), rm(m), res(m);
+    for (size_t i = 0; i < nb; ++i) {
+      const size_t dim = r.blocks[i]->dimension(), md = r.blocks[i]->minimalDimension();
+      std::vector<double> xp(dim), xm(dim), step(md);
+      for (size_t j = 0; j < md; ++j) {
+        std::fill(step.begin(), step.end(), 0.0);
+        step[j] = delta;
+        r.blocks[i]->plus(r.blocks[i]->parameters(), step.data(), xp.data());
+        step[j] = -delta;
+        r.blocks[i]->plus(r.blocks[i]->parameters(), step.data(), xm.data());
+        par[i] = xp.data();
+        r.eval(par.data(), rp.data(), nullptr, nullptr);
+        par[i] = xm.data();
+        r.eval(par.data(), rm.data(), nullptr, nullptr);
+        par[i] = r.blocks[i]->parameters();
+        for (size_t k = 0; k < m; ++k) Jnum[i][k * md + j] = (rp[k] - rm[k]) / (2.0 * delta);
+      }
+    }
+    r.eval(par.data(), res.data(), Jp.data(), Jminp.data());
+    bool ok = true;
+    for (size_t i = 0; i < nb; ++i) {
+      double norm = 0, maxDiff = 0;
+      for (size_t k = 0; k < Jnum[i].size(); ++k) {
+        norm += Jnum[i][k] * Jnum[i][k];
+        maxDiff = std::max(maxDiff, std::fabs(Jnum[i][k] - Jmin[i][k]));
+      }
+      if (maxDiff / std::sqrt(norm) > relTol) ok = false;
+    }
+    return ok;
+  }
 
   Options options;   ///< public like the reference's (Map.hpp:341)
   Summary summary;   ///< public like the reference's (Map.hpp:344)
@@ -126,6 +270,9 @@ class Map {
   /// Map::solve (Map.hpp:347): ::ceres::Solve(options, problem, &summary)
   void solve() {
     need();
+    // blocks added through addParameterBlock are optimised "in place" (ceres works on their memory in the reference): their
+    // current parameters go to the device, the result comes back into the same objects
+    for (const auto& kv : blocks_) svin_ba_set_parameter_block(h_, kv.first, kv.second->parameters());
     svin_ba_set_solver_tolerances(h_, options.function_tolerance, options.gradient_tolerance, options.parameter_tolerance);
     if (svin_ba_optimize(h_, (uint64_t)options.max_num_iterations, (uint64_t)options.num_threads,
                          options.minimizer_progress_to_stdout ? 1 : 0) < 0)
@@ -141,6 +288,10 @@ class Map {
     summary.termination_type = s.termination == 0 ? ::ceres::CONVERGENCE
                                : s.termination == 1 ? ::ceres::NO_CONVERGENCE
                                : s.termination == 2 ? ::ceres::USER_SUCCESS : ::ceres::FAILURE;
+    for (const auto& kv : blocks_) {
+      double x[9];
+      if (svin_ba_get_parameter_block(h_, kv.first, nullptr, x, nullptr, nullptr, nullptr, nullptr) > 0) kv.second->setParameters(x);
+    }
   }
 
   bool parameterBlockExists(uint64_t id) const { need(); return svin_ba_parameter_block_exists(h_, id) == 1; }   // Map.cpp:77-80
@@ -253,17 +404,41 @@ class Map {
     svin_ba_parameters_of(h_, residualId, ids.data(), n, kind);
     return ids;
   }
-  /// Map::removeResidualBlock (Map.cpp:467-492) for reprojection residuals (what Estimator::removeObservation does)
-  bool removeResidualBlock(::ceres::ResidualBlockId residual) {
-    need();
-    return svin_ba_remove_observation_by_id(h_, reinterpret_cast<uint64_t>(residual)) == 1;
-  }
 
  private:
   void need() const {
     if (!h_) throw std::runtime_error("okvis::ceres::Map (svin_ba shim): not attached to an estimator handle");
   }
+  void ensureHandle() {
+    if (h_) return;
+    h_ = svin_ba_create(0);
+    if (!h_) throw std::runtime_error(std::string("svin_ba_create: ") + svin_ba_last_error());
+    owned_ = true;
+  }
+  static void noLoss(const ::ceres::LossFunction* loss) {
+    if (loss) throw std::runtime_error("okvis::ceres::Map (svin_ba shim): only reprojection residuals take a loss function (CauchyLoss(1))");
+  }
+  /// a residual added through addResidualBlock: the error-term object (kept alive, evaluated by isJacobianCorrect) and its blocks
+  struct Built {
+    std::function<bool(double const* const*, double*, double**, double**)> eval;
+    size_t m;
+    std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> > blocks;
+  };
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId record(uint64_t rid, std::shared_ptr<ERROR_T> e, std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> > blocks) {
+    if (rid == 0) return nullptr;   // refused: unknown block, wrong block type (Map.cpp:349-351 returns NULL too)
+    Built b;
+    b.eval = [e](double const* const* p, double* r, double** J, double** Jm) { return e->EvaluateWithMinimalJacobians(p, r, J, Jm); };
+    b.m = e->residualDim();
+    b.blocks = std::move(blocks);
+    built_[rid] = std::move(b);
+    return reinterpret_cast< ::ceres::ResidualBlockId>(rid);
+  }
   svin_ba* h_;
+  bool owned_;
+  std::map<uint64_t, std::shared_ptr<okvis::ceres::ParameterBlock> > blocks_;   ///< blocks added through addParameterBlock
+  std::unordered_map<uint64_t, Built> built_;
+  std::map<const void*, int> cams_;                                             ///< camera geometry object -> backend camera index
 };
 
 }  // namespace ceres

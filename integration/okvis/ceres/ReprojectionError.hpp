@@ -57,6 +57,13 @@ class ReprojectionError {
   const measurement_t& measurement() const { return measurement_; }
   const covariance_t& information() const { return information_; }
   uint64_t cameraId() const { return cameraId_; }
+  // what okvis::ceres::Map::addResidualBlock hands to the backend (svin_ba_add_camera / svin_ba_map_add_reprojection_error)
+  std::shared_ptr<const camera_geometry_t> cameraGeometry() const { return cameraGeometry_; }
+  int distortionModel() const { return model_; }
+  int numDistortionCoefficients() const { return nDist_; }
+  const double* intrinsicsArray() const { return intr_; }
+  const double* distortionArray() const { return dist_; }
+  const double* informationRowMajor() const { return info_; }
   void setCameraId(uint64_t cameraId) { cameraId_ = cameraId; }
   size_t residualDim() const { return kNumResiduals; }
   size_t parameterBlocks() const { return 3; }

@@ -122,6 +122,7 @@ def _bind(L):
     sig("orc_map_add_sonar_error", u64, vp, pd, f64, f64, f64, i32, pd, u64)
     sig("orc_map_add_depth_error", u64, vp, f64, f64, f64, u64)
     sig("orc_map_add_hpoint_error", u64, vp, pd, f64, u64)
+    sig("orc_map_remove_param", i32, vp, u64)
     sig("orc_map_remove_residual", i32, vp, u64)
     sig("orc_map_residuals_of", i32, vp, u64, pu64, i32)
     sig("orc_map_parameters_of", i32, vp, u64, pu64, i32)
@@ -248,6 +249,13 @@ class OracleMap:
 
     def remove_residual(self, rid):
         return bool(self.L.orc_map_remove_residual(self.h, rid))
+
+    def remove_param(self, pid):
+        return bool(self.L.orc_map_remove_param(self.h, pid))
+
+    def add_hpoint_error(self, meas, variance, pid):
+        meas = arr(meas)
+        return self.L.orc_map_add_hpoint_error(self.h, dptr(meas), float(variance), pid)
 
     def dims(self, rid):
         d = np.zeros(64, np.int32)

@@ -334,6 +334,7 @@ int orc_map_parameters_of(void* m, uint64_t rid, uint64_t* ids, int cap) {
 }
 int orc_map_is_constant(void* m, uint64_t pid) { return static_cast<Map*>(m)->param(pid).fixed ? 1 : 0; }
 int orc_map_remove_residual(void* m, uint64_t rid) { return static_cast<Map*>(m)->removeResidualBlock(rid) ? 1 : 0; }
+int orc_map_remove_param(void* m, uint64_t id) { return static_cast<Map*>(m)->removeParameterBlock(id) ? 1 : 0; }   // Map.cpp:322-333
 // dims: m, nb, then per block dim / mdim
 int orc_map_residual_dims(void* m, uint64_t rid, int* dims, int cap) {
   Map* mp = static_cast<Map*>(m);

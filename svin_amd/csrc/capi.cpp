@@ -548,6 +548,47 @@ int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_
   GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_map_add_parameter_block(svin_ba* h, uint64_t id, int type, const double* values) {
+  if (!h || !values) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.mapAddParameterBlock(id, type, values);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_set_parameter_block(svin_ba* h, uint64_t id, const double* values) {
+  if (!h || !values) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.mapSetParameterBlock(id, values);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_map_remove_parameter_block(svin_ba* h, uint64_t id) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.mapRemoveParameterBlock(id);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+uint64_t svin_ba_map_add_pose_error(svin_ba* h, uint64_t block, const double meas[7], const double information[36]) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddPoseError(block, meas, information);
+  GUARD_END(0)
+}
+uint64_t svin_ba_map_add_speed_and_bias_error(svin_ba* h, uint64_t block, const double meas[9], const double information[81]) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddSpeedAndBiasError(block, meas, information);
+  GUARD_END(0)
+}
+uint64_t svin_ba_map_add_relative_pose_error(svin_ba* h, uint64_t block0, uint64_t block1, const double information[36]) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddRelativePoseError(block0, block1, information);
+  GUARD_END(0)
+}
+uint64_t svin_ba_map_add_reprojection_error(svin_ba* h, uint64_t pose_block, uint64_t landmark, uint64_t extrinsics_block, uint64_t cam,
+                                            const double uv[2], const double information[4]) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddReprojectionError(pose_block, landmark, extrinsics_block, cam, uv, information);
+  GUARD_END(0)
+}
+int svin_ba_map_remove_residual_block(svin_ba* h, uint64_t rid) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.mapRemoveResidualBlock(rid);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_set_pack_mode(svin_ba* h, int mode) {
   if (!h || mode < 0 || mode > 1) return SVIN_ERR_INVALID_ARG;
   h->w.setPackMode(mode);

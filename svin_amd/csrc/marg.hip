@@ -1121,7 +1121,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     }
     for (const JobObs& jo : jobObs) {
       hUv.push_back(jo.o.uv[0]); hUv.push_back(jo.o.uv[1]);
-      hW.push_back(std::sqrt(64.0 / (jo.o.size * jo.o.size)));
+      hW.push_back(obsWeight(jo.o.size));
       const int es = sExt.count(jo.extId) ? sExt.at(jo.extId) : 0;
       hIdx.push_back(packObs(sPose.at(jo.o.poseId), es, jo.o.cam));
       hObsLm.push_back(sLm.at(jo.lmId));

@@ -40,6 +40,7 @@ static double dtSecHost(TimeStamp a, TimeStamp b) {  // okvis Duration normalisa
 }
 
 // sqrtInformationUpper: dmath.hpp (shared with svin_host_pose_information)
+static void normalisedPose(const double* T, double* out);
 
 // ------------------------------------------------------------------------------------------ RCCL (resolved at run time)
 // The library is looked up with dlopen when the landmark-sharded mode is switched on: a process that already holds an
@@ -596,6 +597,10 @@ uint64_t Window::addObservationTo(Landmark& lm, uint64_t poseId, uint64_t cam, u
       if (o.poseId == poseId && (uint64_t)o.cam == cam && o.kp == kp) return 0;  // duplicate -> NULL
   Block* eb = cachedBlock(obsCacheExt_[cam]);
   if (!eb) return 0;
+  return addObservationRecord(lm, pb, eb, cam, kp, uv, size);
+}
+uint64_t Window::addObservationRecord(Landmark& lm, Block* pb, Block* eb, uint64_t cam, uint64_t kp, const double* uv, double size) {
+  const uint64_t poseId = pb->id;
   Observation o;
   o.resId = nextResId_++;
   o.poseId = poseId;
@@ -608,7 +613,7 @@ uint64_t Window::addObservationTo(Landmark& lm, uint64_t poseId, uint64_t cam, u
     o.pendIdx = (uint32_t)addLog_.size(); o.pendEpoch = epoch_;
     WinAdd ad;
     ad.lmH = lm.handle; ad.seq = (uint32_t)o.resId; ad.hnd = packObs(o.poseH, o.extH, o.cam); ad.pad = 0;
-    ad.u = uv[0]; ad.v = uv[1]; ad.w = std::sqrt(64.0 / (size * size));
+    ad.u = uv[0]; ad.v = uv[1]; ad.w = obsWeight(size);
     addLog_.push_back(ad);
   }
   if (lm.obs.empty()) ++numLmObserved_;
@@ -659,6 +664,111 @@ int Window::removeLandmarkPrior(uint64_t resId) {
   --numLandmarkPriors_;
   return 1;
 }
+// ------------------------------------------------------------------------------------------ Map interface (Map.cpp:255-376)
+int Window::mapAddParameterBlock(uint64_t id, int type, const double* values) {
+  if (!values) return -1;
+  if (type == 3) return addLandmark(id, values);
+  if (type != 0 && type != 2) return -1;
+  if (idInUse(id)) return 0;   // Map.cpp:257-260
+  double x[9];
+  if (type == 0) normalisedPose(values, x);
+  else std::memcpy(x, values, 9 * sizeof(double));
+  return addBlock(id, type == 0 ? B_POSE : B_SB, x) ? 1 : 0;
+}
+int Window::mapSetParameterBlock(uint64_t id, const double* values) {
+  if (!values) return -1;
+  if (lmIndex_.count(id)) return setLandmark(id, values);
+  Block* b = findBlock(id);
+  if (!b) return 0;
+  if (b->kind == B_SB) std::memcpy(b->x, values, 9 * sizeof(double));
+  else normalisedPose(values, b->x);
+  return 1;
+}
+int Window::mapRemoveParameterBlock(uint64_t id) {   // Map.cpp:322-333: the residuals of the block go with it
+  uint64_t hnd = 0;
+  if (lmIndex_.find(id, &hnd)) {
+    Landmark& lm = *lmByHandle_[(size_t)hnd];
+    while (!lm.priors.empty()) removeLandmarkPrior(lm.priors.back().resId);
+    eraseLandmark(lm);
+    return 1;
+  }
+  if (!findBlock(id) || states_.count(id)) return 0;   // (the blocks of a frame leave through applyMarginalizationStrategy)
+  for (const auto& kv : states_) {
+    for (const StateInfo& e : kv.second.ext) if (e.id == id) return 0;
+    for (const StateInfo& b : kv.second.sb) if (b.id == id) return 0;
+  }
+  removeBlock(id);
+  return 1;
+}
+uint64_t Window::mapAddPoseError(uint64_t blockId, const double* meas7, const double* information36) {
+  Block* b = findBlock(blockId);
+  if (!b || b->kind == B_SB || !meas7 || !information36) return 0;
+  Factor f;
+  f.kind = F_POSE_PRIOR; f.nblk = 1; f.blocks[0] = blockId; f.m = 6;
+  normalisedPose(meas7, f.meas);
+  sqrtInformationUpper(information36, 6, f.sqrtInfo);
+  return addFactor(std::move(f));
+}
+uint64_t Window::mapAddSpeedAndBiasError(uint64_t blockId, const double* meas9, const double* information81) {
+  Block* b = findBlock(blockId);
+  if (!b || b->kind != B_SB || !meas9 || !information81) return 0;
+  Factor f;
+  f.kind = F_SB_PRIOR; f.nblk = 1; f.blocks[0] = blockId; f.m = 9;
+  std::memcpy(f.meas, meas9, 9 * sizeof(double));
+  sqrtInformationUpper(information81, 9, f.sqrtInfo);
+  return addFactor(std::move(f));
+}
+uint64_t Window::mapAddRelativePoseError(uint64_t block0, uint64_t block1, const double* information36) {
+  Block *b0 = findBlock(block0), *b1 = findBlock(block1);
+  if (!b0 || !b1 || b0->kind == B_SB || b1->kind == B_SB || b0->kind != b1->kind || !information36) return 0;
+  Factor f;
+  f.kind = F_RELPOSE; f.nblk = 2; f.blocks[0] = block0; f.blocks[1] = block1; f.m = 6;
+  sqrtInformationUpper(information36, 6, f.sqrtInfo);
+  return addFactor(std::move(f));
+}
+// ReprojectionError<GEOMETRY>(geometry of camera `cam`, uv, information) with CauchyLoss(1) on (pose, landmark, extrinsics):
+// what Estimator::addObservation creates, with the blocks named by the caller.  The device kernels store ONE weight per
+// residual (Estimator only ever passes 64 / size^2 * I), so the information has to be a multiple of the identity.
+uint64_t Window::mapAddReprojectionError(uint64_t poseBlock, uint64_t landmark, uint64_t extBlock, uint64_t cam, const double* uv,
+                                         const double* information4) {
+  uint64_t hnd = 0;
+  if (!uv || !information4 || cam >= cameras_.size() || !lmIndex_.find(landmark, &hnd)) return 0;
+  if (information4[1] != 0.0 || information4[2] != 0.0 || information4[0] != information4[3] || !(information4[0] > 0.0)) {
+    lastError() = "map_add_reprojection_error: the information matrix must be a positive multiple of the identity";
+    return 0;
+  }
+  Block *pb = findBlock(poseBlock), *eb = findBlock(extBlock);
+  if (!pb || !eb || pb == eb || pb->kind != B_POSE) return 0;
+  if (eb->kind == B_POSE) {
+    // a 7-dimensional block added through the Map interface becomes an extrinsics block with its first use as one
+    if (eb->nObs != 0 || states_.count(extBlock)) { lastError() = "map_add_reprojection_error: the extrinsics block is in use as a pose"; return 0; }
+    for (uint64_t rid : eb->residuals) {
+      auto it = factors_.find(rid);
+      if (it != factors_.end() && it->second.kind == F_RELPOSE) { lastError() = "map_add_reprojection_error: relative-pose residuals tie the block to poses"; return 0; }
+    }
+    blockByHandle_[B_POSE][eb->handle] = nullptr;
+    freeBlockH_[B_POSE].push_back(eb->handle);
+    eb->kind = B_EXT;
+    if (!freeBlockH_[B_EXT].empty()) { eb->handle = freeBlockH_[B_EXT].back(); freeBlockH_[B_EXT].pop_back(); }
+    else eb->handle = nextBlockH_[B_EXT]++;
+    if ((int)blockByHandle_[B_EXT].size() <= eb->handle) blockByHandle_[B_EXT].resize(eb->handle + 1, nullptr);
+    blockByHandle_[B_EXT][eb->handle] = eb;
+    for (Block*& c : blockCache_) c = nullptr;
+  }
+  if (eb->kind != B_EXT) return 0;
+  Landmark& lm = *lmByHandle_[(size_t)hnd];
+  // (no duplicate rule at this level: Map::addResidualBlock accepts any number of residuals on the same blocks; the key point
+  // index of the record is the residual id it is about to get)
+  return addObservationRecord(lm, pb, eb, cam, nextResId_, uv, -std::sqrt(information4[0]));
+}
+int Window::mapRemoveResidualBlock(uint64_t resId) {   // Map.cpp:467-492
+  if (obsRes2Lm_.count(resId)) return removeObservationById(resId);
+  if (lmPriorRes2Lm_.count(resId)) return removeLandmarkPrior(resId);
+  if (!factors_.count(resId)) return 0;
+  removeFactor(resId);
+  return 1;
+}
+
 int Window::removeObservation(uint64_t lmId, uint64_t poseId, uint64_t cam, uint64_t kp) {  // :452-474
   auto lit = landmarks_.find(lmId);
   if (lit == landmarks_.end()) return 0;
@@ -974,7 +1084,7 @@ void Window::flushResident(hipStream_t s, bool wantOrder, std::vector<StagedCopy
         o.pendEpoch = 0;
         WinAdd ad;
         ad.lmH = lm->handle; ad.seq = (uint32_t)o.resId; ad.hnd = packObs(o.poseH, o.extH, o.cam); ad.pad = 0;
-        ad.u = o.uv[0]; ad.v = o.uv[1]; ad.w = std::sqrt(64.0 / (o.size * o.size));
+        ad.u = o.uv[0]; ad.v = o.uv[1]; ad.w = obsWeight(o.size);
         addLog_.push_back(ad);
       }
     }
@@ -1089,7 +1199,7 @@ void Window::pack(bool solveFollows) {
     std::vector<uint64_t> orphans;
     for (const auto& kv : blocks_) {
       const Block& b = kv.second;
-      if (!b.fixed || (b.residuals.empty() && b.nObs == 0)) continue;
+      if (b.residuals.empty() && b.nObs == 0) continue;   // (a variable block outside every frame: added through the Map interface)
       const bool known = (b.kind == B_POSE) ? poseSlot_.count(b.id) : (b.kind == B_EXT ? extSlot_.count(b.id) : sbSlot_.count(b.id));
       if (!known) orphans.push_back(b.id);
     }
@@ -1112,6 +1222,21 @@ void Window::pack(bool solveFollows) {
     std::memcpy(&hPose[7 * i], b.x, 7 * sizeof(double));
     if (b.fixed) hPoseOff[i] = -1;
     else { hPoseOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 6; }
+  }
+  // A graph whose blocks are all landmarks (or all constant): okvis_ceres/test/TestHomogeneousPointError.cpp builds one.  The
+  // landmark elimination lives in the Schur kernels, which walk a landmark's residuals against a camera system -- so such a
+  // graph gets ONE phantom pose block behind the real ones: identity pose, a unit PoseError at the identity (residual and
+  // gradient zero, decoupled from everything), six rows in the reduced system.  It exists in the packed arrays only.
+  bool anyVariable = d > 0;
+  for (uint64_t id : extIds_) anyVariable |= !blocks_.at(id).fixed;
+  for (uint64_t id : sbIds_) anyVariable |= !blocks_.at(id).fixed;
+  const bool phantom = !anyVariable && (numObs_ + numLandmarkPriors_) > 0;
+  const int phantomSlot = (int)poseIds_.size();
+  if (phantom) {
+    const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
+    hPose.insert(hPose.end(), ident, ident + 7);
+    hPoseOff.push_back(d);
+    d += 6;
   }
   const int dCPose = d;
   for (size_t i = 0; i < extIds_.size(); ++i) {
@@ -1190,7 +1315,7 @@ void Window::pack(bool solveFollows) {
       for (const Observation& ob : lm.obs) {
         hUv[2 * o] = ob.uv[0]; hUv[2 * o + 1] = ob.uv[1];
         // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
-        hW[o] = std::sqrt(64.0 / (ob.size * ob.size));
+        hW[o] = obsWeight(ob.size);
         hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(extIdOf(ob)), ob.cam);
         hObsLm[o] = (int)slot;
         ++o;
@@ -1245,6 +1370,15 @@ void Window::pack(bool solveFollows) {
     }
     factorIds_.push_back(f.id);
     hFac.push_back(df);
+  }
+  if (phantom) {
+    DevFactor df;
+    std::memset(&df, 0, sizeof(df));
+    df.kind = F_POSE_PRIOR; df.nblk = 1; df.m = 6; df.imuIndex = -1;
+    df.blkKind[0] = B_POSE; df.blkSlot[0] = phantomSlot;
+    df.meas[6] = 1.0;
+    for (int k = 0; k < 6; ++k) df.sqrtInfo[k * 6 + k] = 1.0;
+    hFac.push_back(df);   // (not in factorIds_: the inspection hooks report the graph's factors)
   }
   const int F = (int)hFac.size();
   // prior
@@ -1395,7 +1529,7 @@ void Window::pack(bool solveFollows) {
   std::memset(&p, 0, sizeof(p));
   FillJobs clears;
   clears.n = 0;
-  p.nPose = (int)poseIds_.size(); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
+  p.nPose = (int)(hPose.size() / 7); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
   p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;

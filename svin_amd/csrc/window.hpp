@@ -10,6 +10,7 @@
 // include/okvis/implementation/Estimator.hpp, src/Map.cpp, src/MarginalizationError.cpp.
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -59,6 +60,9 @@ struct Observation {
   uint8_t cam = 0;
 };
 static_assert(sizeof(Observation) == 64, "Observation is meant to fill one cache line");
+// square-root information of a reprojection residual: Estimator::addObservation passes 64 / size^2 * I (implementation/
+// Estimator.hpp:69-71); a residual added through the Map interface with information s * I stores -sqrt(s) in `size`
+inline double obsWeight(double size) { return size > 0 ? std::sqrt(64.0 / (size * size)) : -size; }
 
 struct Landmark {
   // what addObservation and the marginalisation policy touch comes first (one or two cache lines of the map node)
@@ -251,6 +255,19 @@ class Window {
                       const double* size, uint64_t* outIds);
   int removeObservation(uint64_t lm, uint64_t pose, uint64_t cam, uint64_t kp);
   int removeObservationById(uint64_t resId);
+  // ---- okvis::ceres::Map::addParameterBlock / addResidualBlock / remove* (Map.cpp:255-376, :322-333, :467-492) for callers
+  // that build a graph block by block instead of through addStates (the reference's own tests do).  A block added here belongs
+  // to no frame; type: 0 = 7-dimensional pose (T_WS or, once a reprojection residual names it as such, extrinsics T_SC),
+  // 2 = speed and bias (9), 3 = homogeneous point (4).
+  int mapAddParameterBlock(uint64_t id, int type, const double* values);
+  int mapSetParameterBlock(uint64_t id, const double* values);
+  int mapRemoveParameterBlock(uint64_t id);
+  uint64_t mapAddPoseError(uint64_t blockId, const double* meas7, const double* information36);                 // PoseError.cpp:49-132
+  uint64_t mapAddSpeedAndBiasError(uint64_t blockId, const double* meas9, const double* information81);         // SpeedAndBiasError.cpp:47-113
+  uint64_t mapAddRelativePoseError(uint64_t block0, uint64_t block1, const double* information36);              // RelativePoseError.cpp:48-147
+  uint64_t mapAddReprojectionError(uint64_t poseBlock, uint64_t landmark, uint64_t extBlock, uint64_t cam, const double* uv,
+                                   const double* information4);                                                 // ReprojectionError + CauchyLoss(1)
+  int mapRemoveResidualBlock(uint64_t resId);
   // HomogeneousPointError on a landmark (information = 3x3 symmetric positive definite, row-major); 0 on failure
   uint64_t addLandmarkPrior(uint64_t lm, const double* meas4, const double* information9);
   int removeLandmarkPrior(uint64_t resId);
@@ -352,6 +369,7 @@ class Window {
   void removeObsRecord(Landmark& lm, size_t idx);
   void eraseLandmark(Landmark& lm);   // (its observations are gone already)
   uint64_t addObservationTo(Landmark& lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
+  uint64_t addObservationRecord(Landmark& lm, Block* pb, Block* eb, uint64_t cam, uint64_t kp, const double* uv, double size);
   uint64_t extIdOf(const Observation& o) const { return blockByHandle_[B_EXT][o.extH]->id; }
   Block* findBlock(uint64_t id);
   const Block* findBlock(uint64_t id) const;

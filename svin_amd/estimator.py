@@ -56,7 +56,10 @@ EXPORTS = [
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
     "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
-    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_bench_kernel_times",
+    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr",
+    "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
+    "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
+    "svin_ba_map_remove_residual_block", "svin_ba_bench_kernel_times",
     "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
     "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
@@ -155,6 +158,14 @@ def load_library():
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_jacobian_eval_b2b", i32, vp, i32, i32, pd, pd, pd)
     sig("svin_ba_set_pack_mode", i32, vp, i32)
+    sig("svin_ba_map_add_parameter_block", i32, vp, u64, i32, pd)
+    sig("svin_ba_set_parameter_block", i32, vp, u64, pd)
+    sig("svin_ba_map_remove_parameter_block", i32, vp, u64)
+    sig("svin_ba_map_add_pose_error", u64, vp, u64, pd, pd)
+    sig("svin_ba_map_add_speed_and_bias_error", u64, vp, u64, pd, pd)
+    sig("svin_ba_map_add_relative_pose_error", u64, vp, u64, u64, pd)
+    sig("svin_ba_map_add_reprojection_error", u64, vp, u64, u64, u64, u64, pd, pd)
+    sig("svin_ba_map_remove_residual_block", i32, vp, u64)
     sig("svin_ba_debug_csr", i32, vp, pi32, pi32, pi32, pi32, C.POINTER(C.c_uint32), pd, pd, pd, pi32, pi32)
     sig("svin_ba_bench_kernel_times", i32, vp, i32, pd, pd, pd)
     sig("svin_host_imu_propagation", i32, C.c_void_p, i32, C.POINTER(ImuParams), pd, pd, u32, u32, u32, u32, pd, pd, pd)
@@ -728,6 +739,45 @@ class Estimator:
         ms, by = np.zeros(1), np.zeros(1)
         self._check(self.L.svin_ba_bench_jacobian_eval(self.h, copies, iters, _d(ms), _d(by)), "bench_jacobian_eval")
         return float(ms[0]), float(by[0])
+
+    # -- okvis::ceres::Map as a graph builder (Map.cpp:255-376) ---------------------------------------------
+    BLOCK_POSE, BLOCK_SPEED_AND_BIAS, BLOCK_HOMOGENEOUS_POINT = 0, 2, 3
+
+    def map_add_parameter_block(self, bid, btype, values):
+        v = _arr(values)
+        return self._check(self.L.svin_ba_map_add_parameter_block(self.h, bid, btype, _d(v)), "map_add_parameter_block") == 1
+
+    def set_parameter_block(self, bid, values):
+        v = _arr(values)
+        return self._check(self.L.svin_ba_set_parameter_block(self.h, bid, _d(v)), "set_parameter_block") == 1
+
+    def get_parameter_block(self, bid):
+        t, fx, ini = C.c_int32(), C.c_int32(), C.c_int32()
+        x = np.zeros(9)
+        d = self.L.svin_ba_get_parameter_block(self.h, bid, C.byref(t), _d(x), None, None, C.byref(fx), C.byref(ini))
+        return None if d < 0 else x[:d].copy()
+
+    def map_remove_parameter_block(self, bid):
+        return self._check(self.L.svin_ba_map_remove_parameter_block(self.h, bid), "map_remove_parameter_block") == 1
+
+    def map_add_pose_error(self, bid, measurement, information):
+        m, i = _arr(measurement), _arr(np.asarray(information, float).reshape(6, 6))
+        return int(self.L.svin_ba_map_add_pose_error(self.h, bid, _d(m), _d(i)))
+
+    def map_add_speed_and_bias_error(self, bid, measurement, information):
+        m, i = _arr(measurement), _arr(np.asarray(information, float).reshape(9, 9))
+        return int(self.L.svin_ba_map_add_speed_and_bias_error(self.h, bid, _d(m), _d(i)))
+
+    def map_add_relative_pose_error(self, b0, b1, information):
+        i = _arr(np.asarray(information, float).reshape(6, 6))
+        return int(self.L.svin_ba_map_add_relative_pose_error(self.h, b0, b1, _d(i)))
+
+    def map_add_reprojection_error(self, pose, landmark, ext, cam, uv, information):
+        u, i = _arr(uv), _arr(np.asarray(information, float).reshape(2, 2))
+        return int(self.L.svin_ba_map_add_reprojection_error(self.h, pose, landmark, ext, cam, _d(u), _d(i)))
+
+    def map_remove_residual_block(self, rid):
+        return self._check(self.L.svin_ba_map_remove_residual_block(self.h, rid), "map_remove_residual_block") == 1
 
     def set_pack_mode(self, mode):
         """0: device-resident window whenever it qualifies (default); 1: always the host graph -> array pass + full upload"""

@@ -1,0 +1,143 @@
+// Two programs of the reference's test suite, re-created against integration/okvis/ceres/Map.hpp (the graph is built block by
+// block through okvis::ceres::Map, solved on the GPU, the estimates are read back from the caller's parameter-block objects):
+//   part 1  okvis_ceres/test/TestHomogeneousPointError.cpp:57-99 -- 100 points, one HomogeneousPointError (variance 0.1)
+//           each, points disturbed, isJacobianCorrect per residual, solve, final_cost < 1e-10;
+//   part 2  okvis_ceres/test/TestMap.cpp:60-150 in the form the device supports (landmarks stay variable, held by a weak
+//           HomogeneousPointError each; the reference holds them constant): pose + constant extrinsics + N points with
+//           Cauchy-robustified ReprojectionError<equidistant pinhole>, some residuals / blocks removed again, 10 iterations,
+//           the pose must come back to the truth (quaternion 1e-2, translation 1e-1: the reference's thresholds).
+// Prints one line per part for tests/test_gpu_shim.py.
+#include <okvis/MultiFrame.hpp>
+#include <okvis/ceres/Map.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <memory>
+
+namespace {
+struct Rng {   // deterministic uniform numbers in [-1, 1)
+  uint64_t s = 0x2545F4914F6CDD1Dull;
+  double next() {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return (double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+  }
+};
+void quatRotate(const double q[4], const double v[3], double out[3]) {   // q = (x, y, z, w)
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  for (int i = 0; i < 3; ++i) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+void quatMul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+okvis::kinematics::Transformation makeT(const double r[3], const double q[4]) {
+  return okvis::kinematics::Transformation(Eigen::Vector3d(r[0], r[1], r[2]), Eigen::Quaterniond(q[3], q[0], q[1], q[2]));
+}
+}  // namespace
+
+int main() {
+  Rng rng;
+  {  // ---------------------------------------------------------------- part 1
+    okvis::ceres::Map map;
+    int jacOk = 0;
+    std::vector<std::shared_ptr<okvis::ceres::HomogeneousPointParameterBlock> > blocks;
+    std::vector<Eigen::Vector4d> truth;
+    for (size_t i = 0; i < 100; ++i) {
+      Eigen::Vector4d point(100.0 * rng.next(), 100.0 * rng.next(), 100.0 * rng.next(), 1.0);
+      std::shared_ptr<okvis::ceres::HomogeneousPointParameterBlock> block(new okvis::ceres::HomogeneousPointParameterBlock(point, i + 1));
+      if (!map.addParameterBlock(block, okvis::ceres::Map::HomogeneousPoint)) return 3;
+      map.setParameterBlockVariable(i + 1);
+      std::shared_ptr<okvis::ceres::HomogeneousPointError> err(new okvis::ceres::HomogeneousPointError(block->estimate(), 0.1));
+      ::ceres::ResidualBlockId id = map.addResidualBlock(err, NULL, block);
+      if (!id) return 4;
+      Eigen::Vector4d disturbed(point[0] + 0.2 * rng.next(), point[1] + 0.2 * rng.next(), point[2] + 0.2 * rng.next(), 1.0);
+      block->setEstimate(disturbed);
+      jacOk += map.isJacobianCorrect(id) ? 1 : 0;
+      blocks.push_back(block);
+      truth.push_back(point);
+    }
+    map.options.minimizer_progress_to_stdout = false;
+    map.solve();
+    double worst = 0;
+    for (size_t i = 0; i < blocks.size(); ++i)
+      for (int k = 0; k < 3; ++k) worst = std::max(worst, std::fabs(blocks[i]->estimate()[k] - truth[i][k]));
+    std::printf("hpe final_cost %.6e initial_cost %.6e jac_ok %d worst %.3e iterations %d\n", map.summary.final_cost, map.summary.initial_cost,
+                jacOk, worst, (int)map.summary.iterations.size() - 1);
+  }
+  {  // ---------------------------------------------------------------- part 2
+    double rWS[3] = {10.0 * rng.next(), 10.0 * rng.next(), 10.0 * rng.next()};
+    double qWS[4] = {rng.next(), rng.next(), rng.next(), rng.next()};
+    double n = std::sqrt(qWS[0] * qWS[0] + qWS[1] * qWS[1] + qWS[2] * qWS[2] + qWS[3] * qWS[3]);
+    for (double& v : qWS) v /= n;
+    double dq[4] = {0.005 * rng.next(), 0.005 * rng.next(), 0.005 * rng.next(), 1.0};
+    n = std::sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    for (double& v : dq) v /= n;
+    double qInit[4], rInit[3] = {rWS[0] + 0.3 * rng.next(), rWS[1] + 0.3 * rng.next(), rWS[2] + 0.3 * rng.next()};
+    quatMul(qWS, dq, qInit);
+    const double rSC[3] = {0.1, -0.05, 0.02};
+    double qSC[4] = {0.02, -0.01, 0.03, 1.0};
+    n = std::sqrt(qSC[0] * qSC[0] + qSC[1] * qSC[1] + qSC[2] * qSC[2] + qSC[3] * qSC[3]);
+    for (double& v : qSC) v /= n;
+    std::shared_ptr<okvis::ceres::PoseParameterBlock> pose(new okvis::ceres::PoseParameterBlock(makeT(rInit, qInit), 1, okvis::Time(0, 0)));
+    std::shared_ptr<okvis::ceres::PoseParameterBlock> extr(new okvis::ceres::PoseParameterBlock(makeT(rSC, qSC), 2, okvis::Time(0, 0)));
+    okvis::ceres::Map map;
+    if (!map.addParameterBlock(pose, okvis::ceres::Map::Pose6d) || !map.addParameterBlock(extr, okvis::ceres::Map::Pose6d)) return 5;
+    map.setParameterBlockConstant(extr);
+    // PinholeCamera<EquidistantDistortion>::createTestObject (PinholeCamera.hpp:276-280, EquidistantDistortion test coefficients)
+    typedef okvis::cameras::CameraBase Geometry;
+    std::shared_ptr<const Geometry> geometry(new Geometry(752, 480, "EquidistantDistortion", {350.0, 360.0, 378.0, 238.0, -0.21, 0.14, 0.0006, 0.0003}));
+    ::ceres::CauchyLoss loss(1);
+    const size_t N = 300;
+    int jacOk = 0, removedBlocks = 0, removedResiduals = 0;
+    const double Tws[7] = {rWS[0], rWS[1], rWS[2], qWS[0], qWS[1], qWS[2], qWS[3]};
+    const double Tsc[7] = {rSC[0], rSC[1], rSC[2], qSC[0], qSC[1], qSC[2], qSC[3]};
+    const double intr[4] = {350.0, 360.0, 378.0, 238.0}, dist[4] = {-0.21, 0.14, 0.0006, 0.0003}, zero2[2] = {0, 0}, eye2[4] = {1, 0, 0, 1};
+    for (size_t i = 0; i < N; ++i) {
+      const double depth = (double)(i % 10) * 3 + 2.0;
+      const double pc[3] = {0.6 * rng.next() * depth, 0.4 * rng.next() * depth, depth};
+      double ps[3], pw[3];
+      quatRotate(qSC, pc, ps);
+      for (int k = 0; k < 3; ++k) ps[k] += rSC[k];
+      quatRotate(qWS, ps, pw);
+      for (int k = 0; k < 3; ++k) pw[k] += rWS[k];
+      const double hp[4] = {pw[0], pw[1], pw[2], 1.0};
+      double r[2];
+      if (svin_host_reprojection_error(SVIN_DIST_EQUIDISTANT, intr, dist, 4, Tws, hp, Tsc, zero2, eye2, r, nullptr, nullptr, nullptr, nullptr,
+                                       nullptr, nullptr) != 1) return 6;
+      Eigen::Vector2d kp(-r[0] + rng.next(), -r[1] + rng.next());   // the projection (residual = measurement - projection) + noise
+      Eigen::Vector4d start(pw[0] + 0.05 * rng.next(), pw[1] + 0.05 * rng.next(), pw[2] + 0.05 * rng.next(), 1.0);
+      std::shared_ptr<okvis::ceres::HomogeneousPointParameterBlock> point(new okvis::ceres::HomogeneousPointParameterBlock(start, i + 3));
+      if (!map.addParameterBlock(point, okvis::ceres::Map::HomogeneousPoint)) return 7;
+      std::shared_ptr<okvis::ceres::HomogeneousPointError> hold(new okvis::ceres::HomogeneousPointError(start, 4.0));
+      if (!map.addResidualBlock(hold, NULL, point)) return 8;
+      okvis::ceres::ReprojectionError<Geometry>::covariance_t information;
+      information(0, 0) = 1.0; information(1, 1) = 1.0; information(0, 1) = 0.0; information(1, 0) = 0.0;
+      std::shared_ptr<okvis::ceres::ReprojectionError<Geometry> > cost(new okvis::ceres::ReprojectionError<Geometry>(geometry, 1, kp, information));
+      ::ceres::ResidualBlockId id = map.addResidualBlock(cost, &loss, pose, point, extr);
+      if (!id) return 9;
+      jacOk += map.isJacobianCorrect(id) ? 1 : 0;
+      if (i % 10 == 0) {   // "randomly delete some just for fun to test" (TestMap.cpp:117-122)
+        if (i % 20 == 0) removedBlocks += map.removeParameterBlock(point) ? 1 : 0;
+        else removedResiduals += map.removeResidualBlock(id) ? 1 : 0;
+      }
+    }
+    map.options.max_num_iterations = 10;
+    map.solve();
+    const okvis::kinematics::Transformation est = pose->estimate();
+    const double qe[4] = {est.q().x(), est.q().y(), est.q().z(), est.q().w()};
+    const double qinv[4] = {-qe[0], -qe[1], -qe[2], qe[3]};
+    double qd[4];
+    quatMul(qWS, qinv, qd);
+    const double dRot = 2.0 * std::sqrt(qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2]);
+    const double dTr = std::sqrt((est.r()[0] - rWS[0]) * (est.r()[0] - rWS[0]) + (est.r()[1] - rWS[1]) * (est.r()[1] - rWS[1]) +
+                                 (est.r()[2] - rWS[2]) * (est.r()[2] - rWS[2]));
+    std::printf("map final_cost %.6e initial_cost %.6e jac_ok %d of %d removed_blocks %d removed_residuals %d d_rot %.3e d_trans %.3e iterations %d exists3 %d\n",
+                map.summary.final_cost, map.summary.initial_cost, jacOk, (int)N, removedBlocks, removedResiduals, dRot, dTr,
+                (int)map.summary.iterations.size() - 1, map.parameterBlockExists(3) ? 1 : 0);
+  }
+  return 0;
+}

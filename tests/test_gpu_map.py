@@ -1,0 +1,174 @@
+"""okvis::ceres::Map as a graph builder on the HIP path (Map.cpp:255-376): parameter blocks and residual blocks
+added one by one through the C ABI (svin_ba_map_*), outside any frame -- the shape of the reference's own tests
+(okvis_ceres/test/TestMap.cpp, TestHomogeneousPointError.cpp:60-99, TestPoseError) -- and the independent fixed point
+tests/golden/tiny_window.npz (scipy least_squares, a solver that shares nothing with this code) on the device solver."""
+import os
+
+import numpy as np
+import pytest
+
+from svin_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def quat_close(a, b):
+    return min(np.linalg.norm(a - b), np.linalg.norm(a + b))
+
+
+def test_tiny_window_fixed_point_matches_independent_minimiser(gpu_lib):
+    """The only solver-independent pin of optimize(): 2 poses (one constant) / 2 constant extrinsics / 12 landmarks / 48
+    Cauchy-robustified reprojection residuals; the HIP path must reach the minimum scipy's least_squares found, to the
+    tolerances tests/test_oracle_golden.py holds the oracle to (criterion of the reference: TestEstimator.cpp:209-212)."""
+    from svin_amd.estimator import Estimator
+    g = np.load(os.path.join(GOLD, "tiny_window.npz"))
+    est = Estimator(0)
+    for c in range(2):
+        est.add_camera(syn.DIST_RADTAN, g["intr"], g["dist"], 752, 480, [0.0, 0.0, 0.0, 0.0])
+    size = float(g["size"])
+    info = 64.0 / (size * size) * np.eye(2)
+    assert est.map_add_parameter_block(1, est.BLOCK_POSE, g["T0"]) and est.set_parameter_block_constant(1)
+    assert est.map_add_parameter_block(2, est.BLOCK_POSE, g["T1_init"])
+    for c in range(2):
+        assert est.map_add_parameter_block(3 + c, est.BLOCK_POSE, g["T_SC"][c]) and est.set_parameter_block_constant(3 + c)
+    nL = len(g["lm_init"])
+    for l in range(nL):
+        assert est.map_add_parameter_block(10 + l, est.BLOCK_HOMOGENEOUS_POINT, np.r_[g["lm_init"][l], 1.0])
+        for f, pose in enumerate((1, 2)):
+            for c in range(2):
+                assert est.map_add_reprojection_error(pose, 10 + l, 3 + c, c, g["uv"][f, c, l], info) != 0
+    assert not est.map_add_parameter_block(2, est.BLOCK_POSE, g["T1_init"])          # Map.cpp:257-260: a known id is refused
+    est.set_solver_options(1e-16, 1e-16, 1e-16)
+    est.optimize(500)
+    s = est.summary()
+    T1 = est.get_parameter_block(2)
+    lm = np.stack([est.get_parameter_block(10 + l)[:3] for l in range(nL)])
+    print("gpu cost", s["final_cost"], "scipy cost", float(g["cost"]), "dT", np.linalg.norm(T1[:3] - g["T1_opt"][:3]), "dlm",
+          np.max(np.abs(lm - g["lm_opt"])), "iterations", s["iterations"])
+    assert s["final_cost"] <= float(g["cost"]) * (1 + 1e-9)
+    assert abs(s["final_cost"] - float(g["cost"])) < 1e-4 * float(g["cost"])
+    assert np.linalg.norm(T1[:3] - g["T1_opt"][:3]) < 2e-3
+    assert quat_close(T1[3:], g["T1_opt"][3:]) < 1e-3
+    assert np.max(np.abs(lm - g["lm_opt"])) < 3e-2
+    assert np.array_equal(est.get_parameter_block(1), g["T0"] / np.r_[1, 1, 1, [np.linalg.norm(g["T0"][3:])] * 4])  # the constant pose stayed
+    # the same problem through the oracle's Map: identical fixed point, to the tolerance the solvers converge to
+    from oracle import orc
+    m = orc.OracleMap()
+    L = orc.lib()
+    m.add_param(1, orc.BLOCK_POSE, g["T0"]); m.set_constant(1)
+    m.add_param(2, orc.BLOCK_POSE, g["T1_init"])
+    for c in range(2):
+        m.add_param(3 + c, orc.BLOCK_POSE, g["T_SC"][c]); m.set_constant(3 + c)
+    for l in range(nL):
+        m.add_param(10 + l, orc.BLOCK_HPOINT, np.r_[g["lm_init"][l], 1.0])
+        for f, pose in enumerate((1, 2)):
+            for c in range(2):
+                m.add_reproj(orc.DIST_RADTAN, g["intr"], g["dist"], g["uv"][f, c, l], info, orc.LOSS_CAUCHY, pose, 10 + l, 3 + c)
+    L.orc_map_set_tolerances(m.h, 1e-16, 1e-16, 1e-16)
+    so = m.solve(500)
+    To = m.get_param(2)
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-9 * so["final_cost"]
+    assert np.linalg.norm(T1[:3] - To[:3]) < 1e-6 and quat_close(T1[3:], To[3:]) < 1e-6
+
+
+def test_homogeneous_point_errors_alone_converge_to_zero(gpu_lib):
+    """TestHomogeneousPointError.cpp:57-99: 100 points, one HomogeneousPointError (variance 0.1) each, points disturbed by
+    0.2, solve: 'this must converge to zero, since it is not an overdetermined system' (final_cost < 1e-10).  A graph without
+    a single pose: the reduced camera system is empty."""
+    from svin_amd.estimator import Estimator
+    rng = np.random.default_rng(5)
+    est = Estimator(0)
+    pts, rids = [], []
+    for i in range(100):
+        p = np.r_[100.0 * rng.uniform(-1, 1, 3), 1.0]
+        pts.append(p)
+        assert est.map_add_parameter_block(1000 + i, est.BLOCK_HOMOGENEOUS_POINT, p)
+        rid = est.add_homogeneous_point_error(1000 + i, p, variance=0.1)
+        assert rid != 0
+        rids.append(rid)
+        assert est.set_parameter_block(1000 + i, p + np.r_[0.2 * rng.uniform(-1, 1, 3), 0.0])
+    est.optimize(50)
+    s = est.summary()
+    print("homogeneous point errors alone:", s)
+    assert s["final_cost"] < 1e-10
+    for i in range(100):
+        assert np.max(np.abs(est.get_parameter_block(1000 + i) - pts[i])) < 1e-6
+    # Map::removeResidualBlock / removeParameterBlock
+    assert est.map_remove_residual_block(rids[0]) and not est.map_remove_residual_block(rids[0])
+    assert est.map_remove_parameter_block(1000) and not est.parameter_block_exists(1000)
+    assert est.residuals_of(1001) == [rids[1]]
+    assert est.map_remove_parameter_block(1001)
+    with pytest.raises(RuntimeError):   # the residual went with its block (Map.cpp:322-333)
+        est.parameters_of(rids[1])
+
+
+def test_map_built_window_against_oracle_map(gpu_lib):
+    """TestMap.cpp:60-150 in the form the device supports (landmarks stay variable): one pose with a PoseError, a constant
+    extrinsics block, 300 landmarks with a weak HomogeneousPointError each, Cauchy-robustified reprojection residuals of an
+    equidistant camera, a speed/bias block with a SpeedAndBiasError; some residuals and blocks removed again.  Cost and fixed
+    point against the oracle's Map (the CPU restatement of Map.cpp) built by the same calls."""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    rng = np.random.default_rng(11)
+    intr, dist = [350.0, 360.0, 378.0, 238.0], [-0.21, 0.14, 0.0006, 0.0003]   # PinholeCamera::createTestObject (PinholeCamera.hpp:276-280)
+    T_WS = np.r_[rng.uniform(-3, 3, 3), 0, 0, 0, 1.0]
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    T_WS[3:] = q
+    T_SC = np.r_[0.1, -0.05, 0.02, 0.0, 0.0, 0.0, 1.0]
+    est, m, L = Estimator(0), orc.OracleMap(), orc.lib()
+    est.add_camera(syn.DIST_EQUIDISTANT, intr, dist, 752, 480, [0, 0, 0, 0])
+    T_init = T_WS.copy(); T_init[:3] += 0.05 * rng.normal(size=3)
+    dq = np.r_[0.01 * rng.normal(size=3), 1.0]; dq /= np.linalg.norm(dq)
+    x, y, z, w = T_WS[3:]; a, b, c, d = dq
+    T_init[3:] = [w * a + x * d + y * c - z * b, w * b - x * c + y * d + z * a, w * c + x * b - y * a + z * d, w * d - x * a - y * b - z * c]
+    assert est.map_add_parameter_block(1, est.BLOCK_POSE, T_init) and est.map_add_parameter_block(2, est.BLOCK_POSE, T_SC)
+    assert est.set_parameter_block_constant(2)
+    m.add_param(1, orc.BLOCK_POSE, T_init); m.add_param(2, orc.BLOCK_POSE, T_SC); m.set_constant(2)
+    info6 = np.diag([1e-2] * 3 + [1e-1] * 3)
+    assert est.map_add_pose_error(1, T_init, info6) != 0
+    L.orc_map_add_pose_error(m.h, orc.dptr(orc.arr(T_init)), orc.dptr(orc.arr(info6)), 1)
+    # rotation of T_WS and T_SC to place points in front of the camera
+    def rot(qv):
+        x, y, z, w = qv
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    Rws, Rsc = rot(T_WS[3:]), rot(T_SC[3:])
+    rids, n = [], 300
+    for i in range(n):
+        pc = np.r_[rng.uniform(-1.5, 1.5, 2), 1.0] * (3.0 * (i % 10) + 2.0)
+        pw = Rws @ (Rsc @ pc + T_SC[:3]) + T_WS[:3]
+        # equidistant projection of the true point + pixel noise
+        r = np.hypot(pc[0], pc[1]); th = np.arctan2(r, pc[2])
+        thd = th * (1 + dist[0] * th ** 2 + dist[1] * th ** 4 + dist[2] * th ** 6 + dist[3] * th ** 8)
+        s = thd / r if r > 1e-8 else 1.0
+        uv = np.array([intr[0] * s * pc[0] + intr[2], intr[1] * s * pc[1] + intr[3]]) + rng.uniform(-1, 1, 2)
+        hp = np.r_[pw + 0.05 * rng.normal(size=3), 1.0]
+        assert est.map_add_parameter_block(10 + i, est.BLOCK_HOMOGENEOUS_POINT, hp)
+        m.add_param(10 + i, orc.BLOCK_HPOINT, hp)
+        rid = est.map_add_reprojection_error(1, 10 + i, 2, 0, uv, np.eye(2))
+        ro = m.add_reproj(orc.DIST_EQUIDISTANT, intr, dist, uv, np.eye(2), orc.LOSS_CAUCHY, 1, 10 + i, 2)
+        assert rid != 0
+        pr = est.add_homogeneous_point_error(10 + i, hp, variance=4.0)
+        po = m.add_hpoint_error(hp, 4.0, 10 + i)
+        rids.append((rid, ro, pr, po))
+        if i % 10 == 0:
+            if i % 20 == 0:   # "randomly delete some just for fun to test" (TestMap.cpp:117-122)
+                assert est.map_remove_parameter_block(10 + i)
+                m.remove_param(10 + i)
+            else:
+                assert est.map_remove_residual_block(rid)
+                m.remove_residual(ro)
+    est.set_solver_options(1e-14, 1e-14, 1e-14)
+    L.orc_map_set_tolerances(m.h, 1e-14, 1e-14, 1e-14)
+    est.optimize(30)
+    so = m.solve(30)
+    s = est.summary()
+    T, To = est.get_parameter_block(1), m.get_param(1)
+    print("map window: gpu", s["final_cost"], s["iterations"], "oracle", so["final_cost"], so["iterations"], "dT", np.linalg.norm(T[:3] - To[:3]))
+    assert s["iterations"] == so["iterations"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-9 * so["final_cost"]
+    assert np.linalg.norm(T[:3] - To[:3]) < 1e-8 and quat_close(T[3:], To[3:]) < 1e-8
+    # TestMap.cpp:140-144: converged to the true pose within the test's tolerances
+    assert quat_close(T[3:], T_WS[3:]) * 2 < 1e-2 and np.linalg.norm(T[:3] - T_WS[:3]) < 1e-1

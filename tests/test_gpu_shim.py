@@ -123,3 +123,25 @@ def test_cpp_shim_matches_ctypes_mirror(gpu_lib, tmp_path, rig, num_kf):
     assert (misc["errif"]["type"], misc["errif"]["dim"]) == want and misc["errif"]["blocks"] == len(ps) and misc["errif"]["firstdim"] == 7 and misc["errif"]["snap"] == ps[0]
     if num_kf:
         assert misc["removed"] == removed and misc["state_count"] == spec.P
+
+
+def test_reference_shaped_map_programs_run_on_the_gpu(gpu_lib, tmp_path):
+    """tests/csrc/shim_map_tests.cpp: okvis_ceres/test/TestHomogeneousPointError.cpp:57-99 and TestMap.cpp:60-150 re-created
+    against integration/okvis/ceres/Map.hpp -- the graph built block by block (Map::addParameterBlock / addResidualBlock with the
+    shim's PoseError / HomogeneousPointError / ReprojectionError objects), Jacobians checked with Map::isJacobianCorrect,
+    solved on the GPU, estimates read back from the caller's parameter-block objects.  Thresholds are the reference's."""
+    import subprocess
+    from test_shim_compile import _compile
+    exe = _compile(tmp_path, "shim_map_tests")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-2000:])
+    lines = {l.split()[0]: l.split() for l in p.stdout.splitlines() if l.strip()}
+    print(p.stdout)
+    kv = lambda t: {t[i]: t[i + 1] for i in range(1, len(t) - 1, 2)}   # noqa: E731
+    hpe = kv(lines["hpe"])
+    assert float(hpe["final_cost"]) < 1e-10 and int(hpe["jac_ok"]) == 100 and float(hpe["worst"]) < 1e-6   # TestHomogeneousPointError.cpp:97-99
+    mp = lines["map"]
+    m = kv(mp[:mp.index("jac_ok")] + ["jac_ok", mp[mp.index("jac_ok") + 1]] + mp[mp.index("removed_blocks"):])
+    assert int(m["jac_ok"]) == 300 and int(m["removed_blocks"]) == 15 and int(m["removed_residuals"]) == 15 and int(m["exists3"]) == 0
+    assert float(m["d_rot"]) < 1e-2 and float(m["d_trans"]) < 1e-1                                              # TestMap.cpp:140-144
+    assert float(m["final_cost"]) < float(m["initial_cost"])

@@ -99,6 +99,12 @@ def _compile(tmp_path, name):
     return exe
 
 
+def test_reference_shaped_map_program_builds(tmp_path):
+    """tests/csrc/shim_map_tests.cpp (TestHomogeneousPointError / TestMap re-created on okvis::ceres::Map as a graph builder)
+    compiles with every warning an error and resolves the svin_ba_map_* symbols; it runs in tests/test_gpu_shim.py"""
+    assert os.path.exists(_compile(tmp_path, "shim_map_tests"))
+
+
 def test_no_shim_header_includes_ceres():
     """the shim set is Ceres-free -- no header under integration/ includes a ceres/ header"""
     import re
