@@ -350,6 +350,106 @@ def sliding_window_record(device, with_oracle=True):
     return rec
 
 
+def concurrent_record(device, n_handles=8, steps=12):
+    """SVIn runs the estimator and pose_graph side by side (okvis_ros/launch/svin_stereorig_v2.xml:17-34): one svin_ba handle
+    working through the sliding window while one svin_pg handle optimises the configs[4] graph from another thread, each on its
+    own stream -- and n_handles independent svin_ba handles solving configs[1] windows from n_handles threads (what one MI355X
+    delivers in aggregate).  Times are the library's own (taken inside the calls: a Python thread returning from a call may
+    wait for the interpreter lock, the device does not)."""
+    import threading
+    from svin_amd import synthetic as syn
+    from svin_amd import synthetic_pg as spg
+    from svin_amd.estimator import Estimator
+    from svin_amd.posegraph import PoseGraph
+    wspec = syn.make_window(P=24, L=2400, n_obs=24000, seed=7, rig="euroc", keyframe_every=2, frame_dt=0.25)
+    pspec = spg.make_pose_graph(n=5000, laps=20, loop_every=25, seed=7)
+
+    def slide(stop=None):
+        est, solves = Estimator(device), []
+
+        def on_frame(k, fid):
+            est.optimize(10)
+            s = est.summary()
+            if k >= 4:
+                solves.append(s["solve_time"] / max(s["iterations"], 1))
+            est.apply_marginalization(5, 3)
+        syn.feed(est, wspec, on_frame=on_frame)
+        if stop is not None:
+            stop.set()
+        return float(np.median(solves))
+
+    def posegraph(stop=None, reps=3):
+        out = []
+        while (stop is None and len(out) < reps) or (stop is not None and not (stop.is_set() and len(out) >= 1)):
+            g = PoseGraph(device)
+            earliest, cur = spg.feed(g, pspec)
+            s = g.optimize(earliest, cur)
+            g.close()
+            out.append(s["solve_seconds"] / max(s["iterations"], 1))
+            if len(out) > 50:
+                break
+        return float(np.median(out))
+    alone_ba, alone_pg = slide(), posegraph()
+    res, stop = {}, threading.Event()
+    ta = threading.Thread(target=lambda: res.__setitem__("ba", slide(stop)))
+    tb = threading.Thread(target=lambda: res.__setitem__("pg", posegraph(stop)))
+    tb.start(); ta.start(); ta.join(); tb.join()
+    rec = dict(pair=dict(sliding_window_ms_per_iteration={"alone": 1e3 * alone_ba, "beside_pose_graph": 1e3 * res["ba"],
+                                                          "slowdown": res["ba"] / alone_ba},
+                         pose_graph_ms_per_iteration={"alone": 1e3 * alone_pg, "beside_sliding_window": 1e3 * res["pg"],
+                                                      "slowdown": res["pg"] / alone_pg}))
+    # n independent windows of configs[1], one handle and one thread each
+    spec = syn.make_window(seed=20250629)
+    ests = []
+    for _ in range(n_handles):
+        e = Estimator(device)
+        fids, lids = syn.feed(e, spec)
+        ests.append((e, fids, lids, snapshot_init(e, fids, lids, spec)))
+
+    # Every step: all threads reset and upload their window (Python, serialised by the interpreter lock), meet at a barrier,
+    # then all call svin_ba_solve_prepared at once (the lock is released inside the call): the solves really overlap.
+    gate = threading.Barrier(n_handles)
+    walls = []
+
+    def work(i, out, barrier):
+        e, fids, lids, snap = ests[i]
+        t_solve, its = 0.0, 0
+        for k in range(steps + 2):
+            reset_state(e, fids, lids, snap)
+            e.prepare()
+            if barrier is not None:
+                barrier.wait()
+                t0 = time.perf_counter()
+            e.solve_prepared(10)
+            if barrier is not None:
+                barrier.wait()
+                if i == 0 and k >= 2:
+                    walls.append(time.perf_counter() - t0)
+            s = e.summary()
+            if k >= 2:
+                t_solve += s["solve_time"]; its += s["iterations"]
+        out[i] = (t_solve, its)
+    one = {}
+    work(0, one, None)
+    many = {}
+    th = [threading.Thread(target=work, args=(i, many, gate)) for i in range(n_handles)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    per = [many[i][1] / many[i][0] for i in range(n_handles)]
+    its_step = sum(many[i][1] for i in range(n_handles)) / float(steps)
+    rec["handles_%d" % n_handles] = dict(
+        one_handle_alone=one[0][1] / one[0][0], per_handle_when_all_run=float(np.mean(per)), slowest_handle=float(min(per)),
+        aggregate=its_step / float(np.median(walls)), unit="GN iterations/s",
+        sum_of_per_handle_rates=float(sum(per)),
+        note="every step all handles start optimize(10) of their own configs[1] window together (barrier) on their own threads "
+             "and streams; aggregate = iterations of all handles per step / wall time from the barrier until the last handle has "
+             "returned (median over the steps, Python barrier overhead included); per-handle rates from the time inside "
+             "svin_ba_solve_prepared")
+    return rec
+
+
 XGMI_LINK_GBS = 153.0   # per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
 
 
@@ -604,6 +704,11 @@ def main():
                 extras["sliding_window"] = sliding_window_record(local_rank, with_oracle=not args.no_cpu_baseline)
             except Exception as ex:
                 extras["sliding_window"] = {"error": repr(ex)}
+        if rank == 0:
+            try:
+                extras["concurrent"] = concurrent_record(local_rank)
+            except Exception as ex:
+                extras["concurrent"] = {"error": repr(ex)}
         if rank == 0:
             try:
                 pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=False)
