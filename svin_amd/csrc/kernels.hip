@@ -2721,15 +2721,75 @@ constexpr int kPanelChunksPerBlock = 8;
 #ifdef SVIN_SCHUR_TIMING
 __device__ int g_panelCount;
 #endif
-__global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu, int initScale, int nWorkBlocks, int nFacBlocks) {
+// Two workgroups per CU (round 4): the three phases of a chunk -- landmark part (VALU), tile products (MFMA), clearing -- run one
+// after the other inside a workgroup, and with ONE workgroup of four waves per CU (92 KB of LDS, 414 registers) nothing ever ran
+// beside them: matrix pipes 16 % busy, VALU 19 %, LDS 5 % (profiles/r03_solver_pmc.txt).  A second resident workgroup fills
+// those gaps without any hand-written producer / consumer protocol, so the footprint is cut to fit two: the per-wave pose
+// blocks of A exist for diagonal pairs only and take the place of the second G tile there, the staged pose map holds 256 poses,
+// and the register budget is 256 per lane (__launch_bounds__(256, 2)).
+// Per-landmark quantities of a wide window, ONCE per build: V_l, b_l, the metric, L_l^-1 of the damped block and c_l = L_l^-1 b_l.
+// A chunk of 16 landmarks is worked on by every panel pair its observations touch (three to six of them): each pair used to
+// repeat this pass over all observations of the chunk, now it reads nine doubles per landmark.  16 lanes per landmark.
+__global__ __launch_bounds__(256) void k_panels_landmarks(DeviceProblem p, double mu, int initScale) {
+  const int t = threadIdx.x, grp = t >> 4, gl = t & 15;
+  const int l = blockIdx.x * 16 + grp;
+  if (l >= p.L) return;
+  const size_t N = (size_t)p.N;
+  const int start = p.lmPtr[l], n = p.lmPtr[l + 1] - start;
+  double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
+  for (int i = gl; i < n; i += 16) {
+    const size_t o = (size_t)start + i;
+    const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+    const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+    const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+    v00 += a0 * a0 + c0 * c0; v01 += a0 * a1 + c0 * c1; v02 += a0 * a2 + c0 * c2;
+    v11 += a1 * a1 + c1 * c1; v12 += a1 * a2 + c1 * c2; v22 += a2 * a2 + c2 * c2;
+    b0 += a0 * r0 + c0 * r1; b1 += a1 * r0 + c1 * r1; b2 += a2 * r0 + c2 * r1;
+  }
+  v00 = rowSum16(v00); v01 = rowSum16(v01); v02 = rowSum16(v02); v11 = rowSum16(v11); v12 = rowSum16(v12); v22 = rowSum16(v22);
+  b0 = rowSum16(b0); b1 = rowSum16(b1); b2 = rowSum16(b2);
+  if (gl != 0) return;
+  double sc0, sc1, sc2;
+  if (initScale) {
+    sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
+    p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2;
+  } else {
+    sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2];
+  }
+  const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
+  const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
+  const double ht2 = fmin(fmax(v22 * sc2 * sc2, 1e-6), 1e32) / (sc2 * sc2);
+  const double d00 = v00 + mu * ht0, d11 = v11 + mu * ht1, d22 = v22 + mu * ht2;
+  bool bad = !(d00 > 0);
+  const double i00 = rsqrtNewton(bad ? 1.0 : d00);
+  const double l10 = v01 * i00, l20 = v02 * i00;
+  const double t11 = d11 - l10 * l10;
+  bad = bad || !(t11 > 0);
+  const double i11 = rsqrtNewton(t11 > 0 ? t11 : 1.0);
+  const double l21 = (v12 - l20 * l10) * i11;
+  const double t22 = d22 - l20 * l20 - l21 * l21;
+  bad = bad || !(t22 > 0);
+  const double i22 = rsqrtNewton(t22 > 0 ? t22 : 1.0);
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  if (bad) atomicOr(&p.scal->cholFail, 1);
+  double* vi = p.Vinv + 6 * (size_t)l;
+  vi[0] = i00 * i00 + i10 * i10 + i20 * i20; vi[1] = i10 * i11 + i20 * i21; vi[2] = i20 * i22;
+  vi[3] = i11 * i11 + i21 * i21; vi[4] = i21 * i22; vi[5] = i22 * i22;
+  p.bl[3 * l] = b0; p.bl[3 * l + 1] = b1; p.bl[3 * l + 2] = b2;
+  p.hL[3 * l] = ht0; p.hL[3 * l + 1] = ht1; p.hL[3 * l + 2] = ht2;
+  double* f = p.lmFactor + 9 * (size_t)l;
+  f[0] = i00; f[1] = i10; f[2] = i11; f[3] = i20; f[4] = i21; f[5] = i22;
+  f[6] = i00 * b0; f[7] = i10 * b0 + i11 * b1; f[8] = i20 * b0 + i21 * b1 + i22 * b2;
+}
+
+template <int kWavesPerSimd, bool kPrefetch, bool kPre>
+__global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProblem p, double mu, int initScale, int nWorkBlocks, int nFacBlocks) {
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
-  if (b >= nWorkBlocks) {
-    const int e = b - nWorkBlocks;
-    if (e < nFacBlocks) factorsAccumulate(p, e, reinterpret_cast<int*>(smem));
-    else priorAccumulateBlock(p, e - nFacBlocks);
-    return;
-  }
+  (void)nWorkBlocks; (void)nFacBlocks;   // (the small factors and the prior have a launch of their own, k_factors_only: inlined here
+                                         // their register needs decided this kernel's allocation)
   const int4 work = p.panelWork[b];  // x = I, y = J, z = first entry of panelChunks, w = number of chunks
   const int pI = work.x, pJ = work.y;
   const bool diag = pI == pJ;
@@ -2738,9 +2798,9 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
   constexpr int nPB = kPanelRows / 6;              // pose blocks per panel
   double* GtI = smem;                               // kPanelRows x kDenseLd
   double* GtJ = diag ? GtI : smem + (size_t)kPanelRows * kDenseLd;
-  double* Aw = smem + (size_t)2 * kPanelRows * kDenseLd;   // 4 waves x nPB x kPoseAcc (diagonal pairs)
-  double* cvec = Aw + (size_t)4 * nPB * kPoseAcc;           // kDenseK: c_l = L_l^-1 b_l of the chunk's landmarks
-  const int ldsDoubles = 2 * kPanelRows * kDenseLd + 4 * nPB * kPoseAcc + kDenseK;
+  double* Aw = smem + (size_t)kPanelRows * kDenseLd;        // diagonal pairs: 4 waves x nPB x kPoseAcc, where GtJ is otherwise
+  double* cvec = diag ? Aw + (size_t)4 * nPB * kPoseAcc : smem + (size_t)2 * kPanelRows * kDenseLd;   // kDenseK: c_l = L_l^-1 b_l
+  const int ldsDoubles = diag ? kPanelRows * kDenseLd + 4 * nPB * kPoseAcc + kDenseK : 2 * kPanelRows * kDenseLd + kDenseK;   // (even)
   const int wave = t >> 6, lane = t & 63, grp = t >> 4, gl = t & 15;
   double* Amine = Aw + (size_t)wave * nPB * kPoseAcc;
   constexpr int kMaxTiles = 9;                      // 6 x 6 tiles over 4 waves
@@ -2753,7 +2813,7 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
   // Now the block's chunk ids and observation ranges and the pose -> row map are staged in LDS up front, and everything a lane
   // needs of its first observation of chunk ci + 1 (a landmark rarely has more than 16) is requested while chunk ci is being
   // worked on.
-  constexpr int kPoseStage = 1024;
+  constexpr int kPoseStage = 256;
   __shared__ int sPoseOff[kPoseStage];
   __shared__ int sStart[kPanelChunksPerBlock * kDenseLm], sCount[kPanelChunksPerBlock * kDenseLm], sLm[kPanelChunksPerBlock * kDenseLm];
   // tile rows (16 rows each) of the two panels that the current chunk writes to: a tile whose row or column block got
@@ -2776,10 +2836,11 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
   __syncthreads();
   // first observation of this lane in a chunk: index, residual, landmark and pose Jacobian, and the landmark's column scales
   uint32_t preIdx = 0;
-  double preR[2] = {0, 0}, preJl[6] = {0, 0, 0, 0, 0, 0}, preJp[12], preSc[3] = {1, 1, 1};
-#pragma unroll
-  for (int k = 0; k < 12; ++k) preJp[k] = 0;
+  // (the pose Jacobian is not among them: with two workgroups per CU its latency is covered by the other workgroup, and the 48
+  // registers of a prefetched and a current copy are what kept the kernel at one wave per SIMD)
+  double preR[2] = {0, 0}, preJl[6] = {0, 0, 0, 0, 0, 0}, preSc[3] = {1, 1, 1};
   auto fetch = [&](int ci) {
+    if (!kPrefetch) return;
     const int st = sStart[ci * kDenseLm + grp], cnt = sCount[ci * kDenseLm + grp], lq = sLm[ci * kDenseLm + grp];
     if (gl < cnt) {
       const size_t o = (size_t)st + gl;
@@ -2787,8 +2848,6 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
       preR[0] = p.rCur[o]; preR[1] = p.rCur[N + o];
 #pragma unroll
       for (int k = 0; k < 6; ++k) preJl[k] = p.JlCur[k * N + o];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) preJp[k] = p.JpCur[k * N + o];
     }
     if (!initScale && lq >= 0) { preSc[0] = p.scaleL[3 * lq]; preSc[1] = p.scaleL[3 * lq + 1]; preSc[2] = p.scaleL[3 * lq + 2]; }
   };
@@ -2804,17 +2863,21 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
     const int l = sLm[ci * kDenseLm + grp];
     const int start = sStart[ci * kDenseLm + grp], n = sCount[ci * kDenseLm + grp];
     const uint32_t curIdx = preIdx;
-    double curR[2] = {preR[0], preR[1]}, curJl[6], curJp[12], curSc[3] = {preSc[0], preSc[1], preSc[2]};
+    double curR[2] = {preR[0], preR[1]}, curJl[6], curSc[3] = {preSc[0], preSc[1], preSc[2]};
 #pragma unroll
     for (int k = 0; k < 6; ++k) curJl[k] = preJl[k];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) curJp[k] = preJp[k];
     if (ci + 1 < work.w) fetch(ci + 1);
     if (l >= 0) {
+     double i00, i10, i11, i20, i21, i22;
+     if (kPre) {   // (k_panels_landmarks has been there)
+      const double* f = p.lmFactor + 9 * (size_t)l;
+      i00 = f[0]; i10 = f[1]; i11 = f[2]; i20 = f[3]; i21 = f[4]; i22 = f[5];
+      if (gl < 3) cvec[3 * grp + gl] = f[6 + gl];
+     } else {
       double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, b0 = 0, b1 = 0, b2 = 0;
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const bool first = i == gl;
+        const bool first = kPrefetch && i == gl;
         const double r0 = first ? curR[0] : p.rCur[o], r1 = first ? curR[1] : p.rCur[N + o];
         const double a0 = first ? curJl[0] : p.JlCur[o], a1 = first ? curJl[1] : p.JlCur[N + o], a2 = first ? curJl[2] : p.JlCur[2 * N + o];
         const double c0 = first ? curJl[3] : p.JlCur[3 * N + o], c1 = first ? curJl[4] : p.JlCur[4 * N + o], c2 = first ? curJl[5] : p.JlCur[5 * N + o];
@@ -2829,25 +2892,26 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         sc0 = 1.0 / (1.0 + sqrt(v00)); sc1 = 1.0 / (1.0 + sqrt(v11)); sc2 = 1.0 / (1.0 + sqrt(v22));
         if (gl == 0) { p.scaleL[3 * l] = sc0; p.scaleL[3 * l + 1] = sc1; p.scaleL[3 * l + 2] = sc2; }
       } else {
-        sc0 = curSc[0]; sc1 = curSc[1]; sc2 = curSc[2];
+        if (kPrefetch) { sc0 = curSc[0]; sc1 = curSc[1]; sc2 = curSc[2]; }
+        else { sc0 = p.scaleL[3 * l]; sc1 = p.scaleL[3 * l + 1]; sc2 = p.scaleL[3 * l + 2]; }
       }
       const double ht0 = fmin(fmax(v00 * sc0 * sc0, 1e-6), 1e32) / (sc0 * sc0);
       const double ht1 = fmin(fmax(v11 * sc1 * sc1, 1e-6), 1e32) / (sc1 * sc1);
       const double ht2 = fmin(fmax(v22 * sc2 * sc2, 1e-6), 1e32) / (sc2 * sc2);
       const double d00 = v00 + mu * ht0, d11 = v11 + mu * ht1, d22 = v22 + mu * ht2;
       bool bad = !(d00 > 0);
-      const double i00 = rsqrtNewton(bad ? 1.0 : d00);
+      i00 = rsqrtNewton(bad ? 1.0 : d00);
       const double l10 = v01 * i00, l20 = v02 * i00;
       const double t11 = d11 - l10 * l10;
       bad = bad || !(t11 > 0);
-      const double i11 = rsqrtNewton(t11 > 0 ? t11 : 1.0);
+      i11 = rsqrtNewton(t11 > 0 ? t11 : 1.0);
       const double l21 = (v12 - l20 * l10) * i11;
       const double t22 = d22 - l20 * l20 - l21 * l21;
       bad = bad || !(t22 > 0);
-      const double i22 = rsqrtNewton(t22 > 0 ? t22 : 1.0);
-      const double i10 = -l10 * i00 * i11;
-      const double i21 = -l21 * i11 * i22;
-      const double i20 = -(l20 * i00 + l21 * i10) * i22;
+      i22 = rsqrtNewton(t22 > 0 ? t22 : 1.0);
+      i10 = -l10 * i00 * i11;
+      i21 = -l21 * i11 * i22;
+      i20 = -(l20 * i00 + l21 * i10) * i22;
       if (gl == 0) {
         // every pair that sees this chunk computes the same per-landmark quantities; all of them store (same values)
         if (bad) atomicOr(&p.scal->cholFail, 1);
@@ -2859,9 +2923,10 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         double* cr = cvec + 3 * grp;
         cr[0] = i00 * b0; cr[1] = i10 * b0 + i11 * b1; cr[2] = i20 * b0 + i21 * b1 + i22 * b2;
       }
+     }
       for (int i = gl; i < n; i += 16) {
         const size_t o = (size_t)start + i;
-        const bool first = i == gl;
+        const bool first = kPrefetch && i == gl;
         const int pi = (int)((first ? curIdx : p.obsIdx[o]) & 0xfff);
         int offP;
         if (stagedPose) offP = sPoseOff[pi]; else offP = p.poseOff[pi];
@@ -2873,7 +2938,7 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
         const double c0 = first ? curJl[3] : p.JlCur[3 * N + o], c1 = first ? curJl[4] : p.JlCur[4 * N + o], c2 = first ? curJl[5] : p.JlCur[5 * N + o];
         double jc[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) jc[k] = first ? curJp[k] : p.JpCur[k * N + o];
+        for (int k = 0; k < 12; ++k) jc[k] = p.JpCur[k * N + o];
         double* Gt = inI ? GtI : GtJ;
         const int rl = offP - (inI ? r0I : r0J);
         atomicOr(&sTouched[inI ? 0 : 1], (1u << (rl >> 4)) | (1u << ((rl + 5) >> 4)));
@@ -2940,6 +3005,7 @@ __global__ __launch_bounds__(256) void k_schur_panels(DeviceProblem p, double mu
     }
     PNT(3);
     __syncthreads();
+    // (clearing only the tile rows the chunk wrote to was measured: the index arithmetic costs more than the stores it saves)
     for (int i = t; i < (ldsDoubles >> 1); i += blockDim.x) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};   // (ldsDoubles is even)
     if (t < 2) sTouched[t] = 0u;
     __syncthreads();
@@ -3166,10 +3232,23 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     else LAUNCH(9, false, 4);
 #undef LAUNCH
   } else if (p.L > 0 && p.N > 0 && dC > 0 && p.schurPanels) {
-    const size_t ldsBytes = ((size_t)2 * kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc + kDenseK) * 8;
-    ensureDynamicLds((const void*)k_schur_panels, ldsBytes);
-    hipLaunchKernelGGL(k_schur_panels, dim3(p.nPanelBlocks + nFac + nPri), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0,
-                       p.nPanelBlocks, nFac);
+    // off-diagonal pairs: two G tiles + c; diagonal pairs: one G tile + the per-wave pose blocks + c (smaller)
+    const size_t ldsBytes = ((size_t)2 * kPanelRows * kDenseLd + kDenseK) * 8;
+    static_assert(2 * kPanelRows * kDenseLd >= kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc, "diagonal pairs fit the same allocation");
+    // Round 4 (config #4, build of the normal equations 1.01 ms -> 0.67 ms, A/B in one gpurun call): two workgroups per CU instead
+    // of one (0.79: 86 spilled registers with the next chunk's first observation prefetched, 0.73 without the prefetch and without
+    // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).  SVIN_PANELS_OLD=1 launches
+    // the round-3 form (one workgroup per CU, prefetch, every pair recomputing V, b, L^-1) for comparison.
+    static const bool oldForm = std::getenv("SVIN_PANELS_OLD") != nullptr;
+    if (oldForm) {
+      ensureDynamicLds((const void*)k_schur_panels<1, true, false>, ldsBytes);
+      hipLaunchKernelGGL((k_schur_panels<1, true, false>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
+    } else {
+      hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
+      ensureDynamicLds((const void*)k_schur_panels<2, false, true>, ldsBytes);
+      hipLaunchKernelGGL((k_schur_panels<2, false, true>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
+    }
+    if (nFac + nPri > 0) hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
     hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 15) / 16, p.nPanelPairs), dim3(256), 0, s, p);
     return;
   } else if (p.L > 0 && p.N > 0 && dC > 0) {

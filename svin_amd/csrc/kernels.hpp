@@ -166,6 +166,8 @@ struct DeviceProblem {
   int lmDeferred;                            // fused step: the landmark part of the retraction is taken by the candidate evaluation
   int padDeferred;
   const double* lmPrior;                     // landmark priors: 12 doubles each (measurement xyz, upper-triangular sqrt information row-major)
+  double* lmFactor;                          // wide windows: per landmark L^-1 of (V + mu D) (6) and c = L^-1 b (3), written by
+                                             // k_panels_landmarks once per build, read by every panel pair of k_schur_panels
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

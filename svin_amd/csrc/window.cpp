@@ -1438,7 +1438,7 @@ void Window::pack(bool solveFollows) {
   // S and the camera-side vectors share one allocation: [S | gRed | gFull | hC | ...] is all-reduced as one message
   const int sS = ((std::max(d, 1) + 15) / 16) * 16;   // row stride of S: whole 128-byte lines per 16-column tile segment
   dS_.reserve((size_t)sS * sS + (size_t)12 * std::max(d, 1) + 64);   // sS rows as well: the solver reads whole tiles without clamping
-  dLmVec_.reserve((size_t)(6 + 3 * 7) * std::max(L, 1));
+  dLmVec_.reserve((size_t)(6 + 3 * 7 + 9) * std::max(L, 1));
   {
     const size_t dp64 = ((size_t)d + 63) / 64 * 64;  // multi-workgroup solver: (dp64 + 64) x dp64 matrix + 1/L_ii + diagonal factors
     dChol_.reserve(std::max<size_t>(solveReducedScratchDoubles(d), 1));
@@ -1582,6 +1582,7 @@ void Window::pack(bool solveFollows) {
   const size_t LL = std::max(L, 1);
   p.Vinv = dLmVec_.p; p.bl = dLmVec_.p + 6 * LL; p.hL = dLmVec_.p + 9 * LL; p.scaleL = dLmVec_.p + 12 * LL;
   p.yL = dLmVec_.p + 15 * LL; p.deltaL = dLmVec_.p + 18 * LL; p.vL = dLmVec_.p + 21 * LL;
+  p.lmFactor = dLmVec_.p + 27 * LL;
   p.slabs = dSlabs_.p; p.nSlabs = nSlabs;
   p.cholL = dChol_.p;
   p.scal = dScal_.p;
