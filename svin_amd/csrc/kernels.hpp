@@ -185,6 +185,7 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s);
 // Staged upload: the host arrays of a window arrive as ONE block (one DMA from pinned memory); the segment table at
 // the head of the block tells this kernel where each array belongs.  Offsets and sizes are multiples of 16 bytes.
 struct StageSegment { unsigned long long srcOff, bytes; void* dst; };
+constexpr unsigned long long kStageClear = ~0ull;   // srcOff of a segment that clears `bytes` (a multiple of 16) at dst instead of copying
 void launchScatterStaged(const void* block, int nSeg, hipStream_t s);
 // the reverse for the read-back: up to 8 device arrays gathered into one block (offsets / sizes multiples of 16 bytes,
 // sizes rounded up: the sources are over-allocated accordingly)

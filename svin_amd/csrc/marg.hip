@@ -1035,21 +1035,31 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
           if (c & kMargLin) obsCount++;
         }
         if (skipLandmark) continue;
-        for (size_t i = 0; i < lm.obs.size();) {
-          const int action = margObsAction(cls[lm.obs[i].poseH], hasNewObservations, marginalize, obsCount);
-          if (action == 0) { ++i; continue; }
+        size_t keep = 0;   // the list is compacted once (an erase per removed record moves its tail every time)
+        for (size_t i = 0; i < lm.obs.size(); ++i) {
+          const Observation& ob = lm.obs[i];
+          const int action = margObsAction(cls[ob.poseH], hasNewObservations, marginalize, obsCount);
+          if (action == 0) {
+            if (keep != i) lm.obs[keep] = ob;
+            ++keep;
+            continue;
+          }
           if (action == 2) {
             errorTermAdded = true;
-            connectBlock(*blockByHandle_[B_POSE][lm.obs[i].poseH]);
-            connectBlock(*blockByHandle_[B_EXT][lm.obs[i].extH]);
+            connectBlock(*blockByHandle_[B_POSE][ob.poseH]);
+            connectBlock(*blockByHandle_[B_EXT][ob.extH]);
             if (lmOrder.empty() || lmOrder.back() != lm.id) {
               lmOrder.push_back(lm.id);
               if (!deviceJob) lmLin[lm.id].assign(lm.hp, lm.hp + 4);
             }
-            if (!deviceJob) jobObs.push_back({lm.obs[i], lm.id, extIdOf(lm.obs[i])});
+            if (!deviceJob) jobObs.push_back({ob, lm.id, extIdOf(ob)});
             ++nJobObs;
           }
-          removeObsRecord(lm, i);
+          detachObsRecord(lm, ob);
+        }
+        if (keep != lm.obs.size()) {
+          lm.obs.resize(keep);
+          afterObsRemoval(lm);
         }
         if (lm.obs.empty() && !errorTermAdded) {   // every residual was dropped: "justDelete"
           removed.push_back(lm.id);
@@ -1184,8 +1194,15 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     const int nk = (int)keepIdx.size(), nm = (int)margIdx.size();
     std::vector<int> idxLists(keepIdx);
     idxLists.insert(idxLists.end(), margIdx.begin(), margIdx.end());
+    const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
+    bU.reserve(mm * mm + 2); bW2.reserve(mm * L3 + 2); bV.reserve((size_t)9 * std::max(Lm, 1) + 2); bVec.reserve(mm + 2 * L3 + 16);
     {   // the job's tables: one pinned block, one DMA, one scatter kernel (17 pageable copies cost ~100 us of enqueueing)
       std::vector<StagedCopy> pending;
+      // U, W, V and the vectors start from zero: clears riding in the same launch
+      pending.push_back({nullptr, sizeof(double) * mm * mm, bU.p});
+      pending.push_back({nullptr, sizeof(double) * mm * L3, bW2.p});
+      pending.push_back({nullptr, sizeof(double) * 9 * (size_t)std::max(Lm, 1), bV.p});
+      pending.push_back({nullptr, sizeof(double) * (mm + 2 * L3 + 14), bVec.p});
       auto stage = [&](auto& buf, const auto& host) {
         using T = typename std::decay_t<decltype(host)>::value_type;
         buf.reserve(std::max<size_t>(host.size() + 16 / sizeof(T) + 1, 1));   // room for the 16-byte rounding of the copy
@@ -1222,16 +1239,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     bPartial.reserve((size_t)16 * 4096);
     bScal.reserve(1);
     bFlag.reserve(8);
-    const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
-    bU.reserve(mm * mm); bW2.reserve(mm * L3); bV.reserve((size_t)9 * std::max(Lm, 1)); bVec.reserve(mm + 2 * L3 + 16);
-    {   // four clears as one launch, the two copies of the old prior as another (they land inside the cleared U and ba)
-      FillJobs clears;
-      clears.n = 0;
-      addFill(clears, bU.p, nullptr, mm * mm);
-      addFill(clears, bW2.p, nullptr, mm * L3);
-      addFill(clears, bV.p, nullptr, (size_t)9 * std::max(Lm, 1));
-      addFill(clears, bVec.p, nullptr, mm + 2 * L3 + 16);
-      launchFillJobs(clears, s);
+    {   // (the four clears rode in the scatter launch of the staged block) the two copies of the old prior land inside the cleared U / ba
       // old prior content (H_, b0_) occupies the leading block: it is still on the device, exactly where k_marg_dense left it
       if (hadPrior && priorM_ > 0) {
         FillJobs copies;

@@ -189,6 +189,37 @@ __global__ __launch_bounds__(256) void k_window_store_landmarks(int H, const int
   if (quality) qualH[h] = quality[s];
 }
 
+constexpr int kFinishBlocksPerSegment = 4;
+__global__ __launch_bounds__(256) void k_window_finish(FinishArgs a) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b < a.nLmBlocks) {
+    const int h = b * blockDim.x + t;
+    if (h < a.H) {
+      const int s = a.slotOfH[h];
+      if (s >= 0)
+        for (int k = 0; k < 4; ++k) a.lmHp[4 * (size_t)h + k] = a.lm[4 * (size_t)s + k];
+    }
+  } else {
+    const int g = b - a.nLmBlocks, seg = g / kFinishBlocksPerSegment, part = g % kFinishBlocksPerSegment;
+    if (seg < a.ga.n) {
+      const uint4* src = reinterpret_cast<const uint4*>(a.ga.src[seg]);
+      uint4* dst = reinterpret_cast<uint4*>(a.hostBlock + a.ga.off[seg]);
+      const size_t n16 = a.ga.bytes[seg] / 16;
+      for (size_t i = (size_t)part * blockDim.x + t; i < n16; i += (size_t)kFinishBlocksPerSegment * blockDim.x) dst[i] = src[i];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) {
+    const unsigned int done = atomicAdd(a.ticket, 1u);
+    if (done == gridDim.x - 1) {   // every workgroup's stores are out (each fenced before it took its ticket)
+      *a.ticket = 0u;
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(a.hostSeq) = a.seq;
+    }
+  }
+}
+
 // The landmark part of the marginalisation policy (Estimator.cpp:671-766) over the resident CSR: which reprojection residuals
 // are linearised into the prior, as the job tables marg.hip's M1 kernels read.  Landmarks in CSR order, the residuals of a
 // landmark in insertion order -- the order the host policy walks them in.
@@ -270,6 +301,9 @@ void launchWindowStoreLandmarks(int H, const int* slotOfH, const double* lm, con
                                 hipStream_t s) {
   if (H <= 0) return;
   hipLaunchKernelGGL(k_window_store_landmarks, dim3((H + 255) / 256), dim3(256), 0, s, H, slotOfH, lm, quality, lmHp, qualH);
+}
+void launchWindowFinish(const FinishArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_finish, dim3(a.nLmBlocks + kFinishBlocksPerSegment * a.ga.n), dim3(256), 0, s, a);
 }
 void launchWindowMargGather(const MargGatherArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_window_marg_gather, dim3(1), dim3(kRebuildThreads), 0, s, a);

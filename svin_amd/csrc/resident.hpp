@@ -66,6 +66,21 @@ void launchWindowRebuild(const ResidentArgs& a, hipStream_t s);
 void launchWindowStoreLandmarks(int H, const int* slotOfH, const double* lm, const double* quality, double* lmHp, double* qualH,
                                 hipStream_t s);
 
+// The same plus the read-back of the states in ONE launch: up to 8 device arrays (pose / extrinsics / speed-bias tables, IMU
+// pre-integration states) are written straight into a host-mapped pinned block, the last workgroup to finish publishes a
+// sequence number there -- the host polls it instead of paying for a gather launch, a DMA start and a stream synchronisation
+// (35 us per optimize() of a sliding window; ~10 us this way).
+struct FinishArgs {
+  int H, nLmBlocks;
+  const int* slotOfH; const double* lm; double* lmHp;
+  GatherArgs ga;                      // sources, byte offsets into the host block, sizes (multiples of 16)
+  unsigned char* hostBlock;           // device address of the mapped host block
+  unsigned long long* hostSeq;        // device address of the mapped sequence number
+  unsigned long long seq;
+  unsigned int* ticket;               // device counter (zero between launches)
+};
+void launchWindowFinish(const FinishArgs& a, hipStream_t s);
+
 // Marginalisation job tables out of the resident CSR.  Every pose handle carries the class bits the policy loop tests
 // (Estimator.cpp:671-766): kMargRemove = the frame leaves the window, kMargLin = it is outside the IMU window ("linearised"),
 // kMargNew = its id is not older than the current keyframe.

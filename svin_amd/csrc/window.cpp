@@ -119,6 +119,9 @@ Window::Window(int device) : device_(device) {
   if (device < 0 || device >= count) throw std::runtime_error("svin_ba: invalid device index");
   HIP_OK(hipSetDevice(device));
   HIP_OK(hipStreamCreate(&stream_));
+  HIP_OK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&evUploaded_, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&evImuReady_, hipEventDisableTiming));
   std::memset(&prob_, 0, sizeof(prob_));
   // zero-copy mailbox for the per-iteration scalars: the last evaluation kernel stores SolverScalars and a sequence
   // number straight into pinned host memory, the host polls it -- no copy kernel, no stream synchronisation on the
@@ -139,8 +142,12 @@ Window::~Window() {
   if (stageEvt_) (void)hipEventDestroy(stageEvt_);
   if (stageHost_) (void)hipHostFree(stageHost_);
   if (resStatus_) (void)hipHostFree(resStatus_);
+  if (statesHost_) (void)hipHostFree(statesHost_);
   if (lmSyncHost_) (void)hipHostFree(lmSyncHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
+  if (evUploaded_) (void)hipEventDestroy(evUploaded_);
+  if (evImuReady_) (void)hipEventDestroy(evImuReady_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -227,8 +234,8 @@ void Window::removeFactor(uint64_t id) {
   }
   factors_.erase(it);
 }
-void Window::removeObsRecord(Landmark& lm, size_t idx) {
-  const Observation& o = lm.obs[idx];
+// everything a removed observation takes with it except its slot in lm.obs (the caller erases it, or compacts the list once)
+void Window::detachObsRecord(Landmark& lm, const Observation& o) {
   if (Block* b = blockByHandle_[B_POSE][o.poseH]) b->nObs--;
   if (Block* b = blockByHandle_[B_EXT][o.extH]) b->nObs--;
   obsRes2Lm_.erase(o.resId);
@@ -236,14 +243,17 @@ void Window::removeObsRecord(Landmark& lm, size_t idx) {
     if (o.pendEpoch == epoch_) addLog_[o.pendIdx].lmH = -1;   // never got there: withdrawn
     else remLog_.push_back(WinRem{lm.handle, (uint32_t)o.resId});
   }
-  const uint64_t poseId = o.poseId;
-  lm.obs.erase(lm.obs.begin() + idx);
   --numObs_;
+}
+void Window::afterObsRemoval(Landmark& lm) {
   if (lm.obs.empty()) { --numLmObserved_; emptyLm_.push_back(lm.handle); }
-  if (poseId == lm.minPose) {
-    lm.minPose = UINT64_MAX;
-    for (const Observation& q : lm.obs) lm.minPose = std::min(lm.minPose, q.poseId);
-  }
+  lm.minPose = UINT64_MAX;
+  for (const Observation& q : lm.obs) lm.minPose = std::min(lm.minPose, q.poseId);
+}
+void Window::removeObsRecord(Landmark& lm, size_t idx) {
+  detachObsRecord(lm, lm.obs[idx]);
+  lm.obs.erase(lm.obs.begin() + idx);
+  afterObsRemoval(lm);
 }
 void Window::eraseLandmark(Landmark& lm) {
   while (!lm.obs.empty()) removeObsRecord(lm, lm.obs.size() - 1);
@@ -537,6 +547,7 @@ int Window::addLandmark(uint64_t id, const double* hp) {  // :414-429
   lm.handle = nextLmHandle_++;
   auto ins = landmarks_.emplace(id, lm).first;
   Landmark* node = &ins->second;
+  node->obs.reserve(12);   // (a landmark collects about ten observations: no reallocation on the way there)
   lmByHandle_.push_back(node);
   lmIterByHandle_.push_back(ins);
   lmIndex_.set(id, (uint64_t)lm.handle);
@@ -613,7 +624,8 @@ uint64_t Window::addObservationRecord(Landmark& lm, Block* pb, Block* eb, uint64
     o.pendIdx = (uint32_t)addLog_.size(); o.pendEpoch = epoch_;
     WinAdd ad;
     ad.lmH = lm.handle; ad.seq = (uint32_t)o.resId; ad.hnd = packObs(o.poseH, o.extH, o.cam); ad.pad = 0;
-    ad.u = uv[0]; ad.v = uv[1]; ad.w = obsWeight(size);
+    if (size != lastObsSize_) { lastObsSize_ = size; lastObsWeight_ = obsWeight(size); }   // (key point sizes repeat: one division and root per size)
+    ad.u = uv[0]; ad.v = uv[1]; ad.w = lastObsWeight_;
     addLog_.push_back(ad);
   }
   if (lm.obs.empty()) ++numLmObserved_;
@@ -1152,7 +1164,7 @@ void Window::flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s) 
   auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
   const size_t tableBytes = r16(sizeof(StageSegment) * pending.size());
   size_t total = tableBytes;
-  for (const StagedCopy& pe : pending) total += r16(pe.bytes);
+  for (const StagedCopy& pe : pending) if (pe.src) total += r16(pe.bytes);
   if (stageEvt_) HIP_OK(hipEventSynchronize(stageEvt_));   // the previous block may still be on its way
   else HIP_OK(hipEventCreateWithFlags(&stageEvt_, hipEventDisableTiming));
   if (total > stageHostCap_) {
@@ -1165,6 +1177,10 @@ void Window::flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s) 
   size_t off = tableBytes;
   for (size_t i = 0; i < pending.size(); ++i) {
     const size_t b16 = r16(pending[i].bytes);
+    if (!pending[i].src) {   // a clear (the destination is over-allocated to the rounded size like every staged array)
+      table[i] = StageSegment{kStageClear, (unsigned long long)b16, pending[i].dst};
+      continue;
+    }
     table[i] = StageSegment{(unsigned long long)off, (unsigned long long)b16, pending[i].dst};
     std::memcpy(stageHost_ + off, pending[i].src, pending[i].bytes);
     if (b16 > pending[i].bytes) std::memset(stageHost_ + off + pending[i].bytes, 0, b16 - pending[i].bytes);
@@ -1513,9 +1529,17 @@ void Window::pack(bool solveFollows) {
     dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
   }
 
+  // the accumulators start clear (the trust-region loop never launches k_zero_build: k_post_solve re-clears them); the clears
+  // ride in the scatter launch of the staged block
+  const int sSq = ((std::max(d, 1) + 15) / 16) * 16;
+  pending.push_back({nullptr, sizeof(double) * ((size_t)sSq * sSq + (size_t)12 * std::max(d, 1)), dS_.p});
+  pending.push_back({nullptr, sizeof(SolverScalars), dScal_.p});
+  pending.push_back({nullptr, sizeof(double) * 16 * 4096, dPartial_.p});
+  if (hasPrior_) pending.push_back({nullptr, sizeof(double) * (6 * (size_t)priorM + 18 * hPb.size()), dPriorScratch_.p});
   if (schurPanels && resident) throw std::logic_error("resident window needs a panel work list");
   if (resident) flushResident(s, orderObs, pending, ra);   // stages the delta; the rebuild kernel follows the scatter
   flushStaged(pending, s);
+  if (solveFollows && resident) HIP_OK(hipEventRecord(evUploaded_, s));   // (the side stream of the early IMU pre-integration waits for the tables)
   if (resident) {
     addLog_.clear(); remLog_.clear(); setLog_.clear();   // (copied into the staged block by flushStaged)
     ++epoch_;
@@ -1527,8 +1551,6 @@ void Window::pack(bool solveFollows) {
 
   DeviceProblem& p = prob_;
   std::memset(&p, 0, sizeof(p));
-  FillJobs clears;
-  clears.n = 0;
   p.nPose = (int)(hPose.size() / 7); p.nExt = (int)std::max<size_t>(extIds_.size(), 1); p.nSb = (int)sbIds_.size();
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
@@ -1568,11 +1590,10 @@ void Window::pack(bool solveFollows) {
     p.priorDchi = ps; p.priorGrad = ps + priorM; p.priorDchiC = ps + 2 * priorM; p.priorGradC = ps + 3 * priorM;
     p.priorMv = ps + 4 * priorM; p.priorMy = ps + 5 * priorM;
     p.priorM3 = ps + 6 * priorM; p.priorM3C = p.priorM3 + 9 * hPb.size();
-    addFill(clears, ps, nullptr, 6 * (size_t)priorM + 18 * hPb.size());
   }
   const int dd = std::max(d, 1);
   // accumulators start clear: the trust-region loop never launches k_zero_build (k_post_solve re-clears them)
-  addFill(clears, dS_.p, nullptr, (size_t)sS * sS + (size_t)12 * dd);
+
   p.S = dS_.p;
   p.ldS = sS;
   p.sPadded = 1;
@@ -1588,10 +1609,23 @@ void Window::pack(bool solveFollows) {
   p.scal = dScal_.p;
   p.partial = dPartial_.p;
   p.tickets = reinterpret_cast<unsigned int*>(dPartial_.p + (size_t)14 * 4096);  // zeroed with the partials
-  static_assert(sizeof(SolverScalars) % 8 == 0, "cleared in 8-byte words");
-  addFill(clears, dScal_.p, nullptr, sizeof(SolverScalars) / 8);
-  addFill(clears, dPartial_.p, nullptr, (size_t)16 * 4096);
-  launchFillJobs(clears, s);   // one launch instead of four hipMemsetAsync
+  static_assert(sizeof(SolverScalars) % 16 == 0, "cleared in 16-byte words by the scatter kernel");
+  // optimize() on the resident path: a factor that still has to be pre-integrated (the frame's new ImuError, redo_ = true,
+  // ImuError.cpp:739) is evaluated once on a side stream while the main stream rebuilds the observation table -- the two
+  // do not depend on each other, and the ~40 us integration chain is otherwise the first thing the solve waits for.  The
+  // results of this evaluation are discarded (the solve's first evaluation repeats it, now without the integration); only
+  // the pre-integration state stays.  Not in prepare(): there the upload is outside the measured region and the solve is not.
+  static const bool noEarlyImu = getenv("SVIN_NO_EARLY_IMU") != nullptr;
+  if (solveFollows && resident && !noEarlyImu && F > 0) {
+    bool anyRedo = false;
+    for (const DevImu& im : hImu) anyRedo |= im.redo != 0;
+    if (anyRedo) {
+      HIP_OK(hipStreamWaitEvent(stream2_, evUploaded_, 0));
+      launchEvalFactors(p, false, stream2_, false);
+      HIP_OK(hipEventRecord(evImuReady_, stream2_));
+      HIP_OK(hipStreamWaitEvent(s, evImuReady_, 0));
+    }
+  }
   if (getenv("SVIN_PACK_TIMING")) {
     const double tPack2 = nowSec();
     HIP_OK(hipStreamSynchronize(s));
@@ -1608,8 +1642,10 @@ void Window::downloadStates() {
       hLm(resident ? 0 : (size_t)p.L * 4), hQ(resident ? 0 : p.L);
   std::vector<DevImu> hImu(p.nImu);
   if (p.L > 0 && !resident) launchLandmarkQuality(p, dQuality_.p, s);
+  static const bool noZeroCopy = getenv("SVIN_NO_ZERO_COPY_STATES") != nullptr;   // A/B switch
+  const bool zeroCopy = resident && !noZeroCopy;   // the states arrive through a host-mapped block written by k_window_finish
   if (resident && res_.H > 0) {
-    launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, p.lm, nullptr, res_.lmHp.p, res_.qualH.p, s);
+    if (!zeroCopy) launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, p.lm, nullptr, res_.lmHp.p, res_.qualH.p, s);
     lmStale_ = true;
     qualityPending_ = true;
     qualityProb_ = p;
@@ -1636,7 +1672,37 @@ void Window::downloadStates() {
       add(dQuality_.p, hQ.data(), sizeof(double) * p.L);
     }
     if (p.nImu > 0) add(p.imus, hImu.data(), sizeof(DevImu) * p.nImu);
-    if (ga.n > 0) {
+    if (zeroCopy) {
+      if (off + 64 > statesHostCap_) {
+        HIP_OK(hipStreamSynchronize(s));
+        if (statesHost_) (void)hipHostFree(statesHost_);
+        statesHostCap_ = std::max<size_t>(2 * (off + 64), 1 << 18);
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&statesHost_), statesHostCap_, hipHostMallocMapped));
+        std::memset(statesHost_, 0, 64);
+        HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&statesHostDev_), statesHost_, 0));
+        if (!finishTicket_.p) { finishTicket_.reserve(4); HIP_OK(hipMemsetAsync(finishTicket_.p, 0, 16, s)); }
+      }
+      FinishArgs fa;
+      std::memset(&fa, 0, sizeof(fa));
+      fa.H = res_.H; fa.nLmBlocks = (res_.H + 255) / 256;
+      fa.slotOfH = res_.slotOfH[res_.cur].p; fa.lm = p.lm; fa.lmHp = res_.lmHp.p;
+      fa.ga = ga;
+      fa.hostBlock = statesHostDev_ + 64;   // (the first 64 bytes hold the sequence number)
+      fa.hostSeq = reinterpret_cast<unsigned long long*>(statesHostDev_);
+      fa.seq = ++statesSeq_;
+      fa.ticket = reinterpret_cast<unsigned int*>(finishTicket_.p);
+      launchWindowFinish(fa, s);
+      volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(statesHost_);
+      const double tSpin = nowSec();
+      bool ok = false;
+      for (unsigned long long spins = 0;; ++spins) {
+        if (*seq == statesSeq_) { ok = true; break; }
+        if ((spins & 1023) == 1023 && nowSec() - tSpin > 2.0) break;
+      }
+      if (!ok) HIP_OK(hipStreamSynchronize(s));
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (int i = 0; i < ga.n; ++i) std::memcpy(outs[i].dst, statesHost_ + 64 + ga.off[i], outs[i].bytes);
+    } else if (ga.n > 0) {
       if (stageEvt_) HIP_OK(hipEventSynchronize(stageEvt_));
       if (off > stageHostCap_) {
         if (stageHost_) (void)hipHostFree(stageHost_);
@@ -1647,8 +1713,10 @@ void Window::downloadStates() {
       launchGatherStaged(stageDev_.p, ga, s);
       HIP_OK(hipMemcpyAsync(stageHost_, stageDev_.p, off, hipMemcpyDeviceToHost, s));
     }
-    HIP_OK(hipStreamSynchronize(s));
-    for (int i = 0; i < ga.n; ++i) std::memcpy(outs[i].dst, stageHost_ + ga.off[i], outs[i].bytes);
+    if (!zeroCopy) {
+      HIP_OK(hipStreamSynchronize(s));
+      for (int i = 0; i < ga.n; ++i) std::memcpy(outs[i].dst, stageHost_ + ga.off[i], outs[i].bytes);
+    }
   }
   for (size_t i = 0; i < poseIds_.size(); ++i) std::memcpy(blocks_.at(poseIds_[i]).x, &hPose[7 * i], 7 * sizeof(double));
   for (size_t i = 0; i < extIds_.size(); ++i) std::memcpy(blocks_.at(extIds_[i]).x, &hExt[7 * i], 7 * sizeof(double));

@@ -367,6 +367,8 @@ class Window {
   uint64_t addFactor(Factor&& f);
   void removeFactor(uint64_t id);
   void removeObsRecord(Landmark& lm, size_t idx);
+  void detachObsRecord(Landmark& lm, const Observation& o);
+  void afterObsRemoval(Landmark& lm);
   void eraseLandmark(Landmark& lm);   // (its observations are gone already)
   uint64_t addObservationTo(Landmark& lm, uint64_t pose, uint64_t cam, uint64_t kp, const double* uv, double size);
   uint64_t addObservationRecord(Landmark& lm, Block* pb, Block* eb, uint64_t cam, uint64_t kp, const double* uv, double size);
@@ -391,6 +393,8 @@ class Window {
   bool distNative_ = false;    // the current solve all-reduces through rcclComm_ (scalars published after the reduction)
   void* rcclComm_ = nullptr;   // ncclComm_t of the native path (RCCL resolved at run time, see window.cpp)
   hipStream_t stream_ = nullptr;
+  hipStream_t stream2_ = nullptr;                       // side stream: the early IMU pre-integration of optimize() (pack())
+  hipEvent_t evUploaded_ = nullptr, evImuReady_ = nullptr;
   // staged upload of pack(): pinned host block + its device twin (segment table first), see launchScatterStaged
   struct StagedCopy { const void* src; size_t bytes; void* dst; };
   void flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s);
@@ -451,6 +455,11 @@ class Window {
   mutable Resident res_;
   int* resStatus_ = nullptr;      // pinned, device-visible: consistency flag of the rebuild / gather kernels
   int* resStatusDev_ = nullptr;
+  unsigned char* statesHost_ = nullptr;      // pinned, device-visible: [sequence number | states of the last solve] (k_window_finish)
+  unsigned char* statesHostDev_ = nullptr;
+  size_t statesHostCap_ = 0;
+  unsigned long long statesSeq_ = 0;
+  DevBuf<int> finishTicket_;
   mutable double* lmSyncHost_ = nullptr;   // pinned read-back area of syncLandmarks
   mutable size_t lmSyncCap_ = 0;
   bool useResident() const;
@@ -462,6 +471,7 @@ class Window {
   Block* blockCache_[4] = {nullptr, nullptr, nullptr, nullptr};
   int blockCacheNext_ = 0;
   size_t margLdsSet_[2] = {0, 0};   // dynamic LDS already granted to k_marg_dense / k_marg_final (hipFuncSetAttribute is not free)
+  double lastObsSize_ = 0.0, lastObsWeight_ = 0.0;
   uint64_t obsCachePose_ = 0;     // frame whose extrinsics block ids obsCacheExt_ holds (0: none)
   uint64_t obsCacheExt_[16] = {0};
   std::unordered_map<uint64_t, uint64_t> lmPriorRes2Lm_;  // HomogeneousPointError residual id -> landmark id

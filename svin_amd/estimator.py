@@ -475,10 +475,14 @@ class Estimator:
         return bool(self.L.svin_ba_set_optimization_time_limit(self.h, tl, min_iter))
 
     def apply_marginalization(self, num_kf, num_imu):
-        ids = np.zeros(1 << 16, np.uint64)
-        n = C.c_int()
-        r = self._check(self.L.svin_ba_apply_marginalization_strategy(self.h, num_kf, num_imu, ids.ctypes.data_as(pu64),
-                                                                      len(ids), C.byref(n)), "apply_marginalization")
+        ids = getattr(self, "_removed_buf", None)   # (a fresh 512 KB array per call cost more than the policy loop it serves)
+        if ids is None:
+            ids = self._removed_buf = np.zeros(1 << 16, np.uint64)
+            self._removed_ptr = ids.ctypes.data_as(pu64)
+            self._removed_n = C.c_int()
+        n = self._removed_n
+        r = self._check(self.L.svin_ba_apply_marginalization_strategy(self.h, num_kf, num_imu, self._removed_ptr, len(ids), C.byref(n)),
+                        "apply_marginalization")
         return bool(r), ids[:n.value].copy()
 
     def summary(self):
