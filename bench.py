@@ -301,6 +301,18 @@ def window_record(name, spec, device, steps, warmup, iters):
         rec["roofline"]["frac"] = rec["roofline"]["achieved"] / F64_MFMA_PEAK_TFLOPS
         rec["roofline"]["kernel"] = rec["roofline"]["solve"]["kernel"] if so >= bu else rec["roofline"]["schur"]["kernel"]
         rec["roofline"]["traffic"] = None
+        if spec.P > 20:
+            # MFMA flops k_schur_panels executes (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) over the algorithmic count
+            # for THIS window: measured under the profiler (tools/run_r04_profiles.sh), quoted when it describes the same window
+            try:
+                with open(os.path.join(ROOT, "profiles", "r04_config4_mfma.json")) as fh:
+                    mf = json.load(fh)
+                if abs(mf["algorithmic_flops_per_launch"] - schur_flops) < 1e-6 * schur_flops:
+                    rec["roofline"]["executed_over_algorithmic"] = mf["executed_over_algorithmic"]
+                    rec["roofline"]["executed_mfma_flops_per_launch"] = mf["executed_mfma_flops_per_launch"]
+                    rec["roofline"]["executed_source"] = "profiles/r04_config4_mfma.json"
+            except (OSError, KeyError, ValueError):
+                pass
     except Exception as ex:
         rec["roofline"] = {"error": repr(ex)}
     return rec, est
@@ -338,6 +350,9 @@ def sliding_window_record(device, with_oracle=True):
                    "device_solve": 1e3 * med("solve"), "read_back": 1e3 * med("download"), "marginalise_call": 1e3 * med("marginalise")},
                host_ms_per_frame=1e3 * (frame - med("solve")),
                iterations_per_frame=float(np.mean([r["iterations"] for r in rows])),
+               window="device-resident (svin_amd/csrc/resident.hpp): per frame the host sends the ~1000 new observation records, the "
+                      "removed ones and the state tables; one kernel rebuilds the landmark-major table, the marginalisation job's tables "
+                      "are gathered on the device, landmark points / qualities are fetched when asked for",
                note="marginalise_call returns after the host policy has enqueued M1-M3 (device part asynchronous, ~1 ms, hidden "
                     "behind the next frame's front-end work); host_ms_per_frame = everything but the device solve")
     if with_oracle:
@@ -635,12 +650,36 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         ms1, nbytes1 = est.bench_jacobian_eval(1, 50)
         # a second point far beyond the Infinity Cache: 1 024 replicas = 4 GB of Jacobians per launch
+        def device_copy_gbps(total_bytes):
+            """a plain device-to-device copy moving `total_bytes` (half read, half written), back to back: what the memory
+            system of this box gives a two-stream kernel at that footprint"""
+            n = int(total_bytes // 16)
+            a = torch.empty(n, dtype=torch.float64, device="cuda")
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            return 16.0 * n / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
         try:
             msb_each, msb, nbytesb = est.bench_jacobian_eval_b2b(1024, 10)
             big = {"replicas": 1024, "bytes_per_launch": nbytesb, "launch_ms_back_to_back": msb, "launch_ms_per_launch_events": msb_each,
-                   "GBps": nbytesb / (msb * 1e-3) / 1e9, "frac": nbytesb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                   "GBps": nbytesb / (msb * 1e-3) / 1e9, "frac": nbytesb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "device_copy_same_footprint_GBps": device_copy_gbps(nbytesb),
+                   "note": "beyond ~1.5 GB of footprint this box's memory system slows down for every kernel: a plain device copy "
+                           "falls from ~5.4 (1 GB) to ~5.2 (4 GB) and ~4.4 TB/s (8 GB), K1 from 6.2-6.4 to 4.3; at 1 GB the 180 MB of "
+                           "K1's inputs also stay in the 256 MiB Infinity Cache from launch to launch (tools/k1_sweep.py, DESIGN.md 5)"}
         except Exception as ex:   # noqa: BLE001
             big = {"error": repr(ex)}
+        try:
+            copy_1gb = device_copy_gbps(nbytes)
+        except Exception:   # noqa: BLE001
+            copy_1gb = None
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of
         # tools/k1_bench.py, gfx950 FETCH_SIZE x2 correction; committed summary profiles/*_k1_pmc.json).  Counters
         # cannot be read from inside this process, so the committed measurement is quoted when it describes the same
@@ -665,6 +704,7 @@ def main():
                                                  "frac": nbytes / (ms_each * 1e-3) / 1e9 / HBM_PEAK_GBS},
                            "replicas_1024": big,
                            "frac_of_copy_ceiling": ach / HBM_COPY_CEILING_GBS,
+                           "device_copy_same_footprint_GBps": copy_1gb,
                            # SURVEY 8(d) prices a residual at 191.2 B (fixed extrinsics); this layout stores the landmark
                            # index explicitly (+4 B) and `achieved` counts it -- the figure without it:
                            "achieved_survey_bytes": 191.2 * n_res / (ms * 1e-3) / 1e9,
@@ -711,15 +751,19 @@ def main():
                 extras["concurrent"] = {"error": repr(ex)}
         if rank == 0:
             try:
-                pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=False)
-                extras["config5"] = {k: pg[k] for k in ("value", "unit", "ms_per_step")}
+                pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=not args.no_cpu_baseline)
+                extras["config5"] = {k: pg[k] for k in ("value", "unit", "ms_per_step", "cpu_baseline") if k in pg}
+                if "speedup_vs_cpu_baseline" in pg["config"]:
+                    extras["config5"]["speedup_vs_cpu_baseline"] = pg["config"]["speedup_vs_cpu_baseline"]
                 extras["config5"].update(workload=pg["config"]["workload"], iterations_per_step=pg["config"]["iterations_per_step"],
                                          ms_per_iteration=pg["ms_per_step"] / pg["config"]["iterations_per_step"])
             except Exception as ex:
                 extras["config5"] = {"error": repr(ex)}
             try:
-                pg6 = posegraph_record(argparse.Namespace(six_dof=True), 0, 1, local_rank, None, 2, 1, cpu=False)
-                extras["config5_6dof"] = {k: pg6[k] for k in ("value", "unit", "ms_per_step")}
+                pg6 = posegraph_record(argparse.Namespace(six_dof=True), 0, 1, local_rank, None, 2, 1, cpu=not args.no_cpu_baseline)
+                extras["config5_6dof"] = {k: pg6[k] for k in ("value", "unit", "ms_per_step", "cpu_baseline") if k in pg6}
+                if "speedup_vs_cpu_baseline" in pg6["config"]:
+                    extras["config5_6dof"]["speedup_vs_cpu_baseline"] = pg6["config"]["speedup_vs_cpu_baseline"]
                 extras["config5_6dof"].update(workload=pg6["config"]["workload"], iterations_per_step=pg6["config"]["iterations_per_step"],
                                               ms_per_iteration=pg6["ms_per_step"] / pg6["config"]["iterations_per_step"])
             except Exception as ex:

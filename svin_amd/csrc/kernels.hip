@@ -490,6 +490,10 @@ __device__ __forceinline__ void cholDiag16Reg(double* D, double* dinv, int lane,
 // The linearisation buffers are write-once streams (160-256 B per observation, nothing of them is re-read by this
 // kernel): non-temporal stores keep them from thrashing L2 on their way to HBM -- measured 4.3 -> 6.4 TB/s on the
 // HBM-resident batch, neutral for the single cache-resident window of the solver (profiles/r01_k1_variants.txt).
+// Round 4: a tile-major output (the 20 rows of 64 observations kept together: one contiguous 10 KB tile per wave instead of twenty
+// streams N x 8 bytes apart) was measured on the roofline batch and changes nothing (6.4 vs 6.25 TB/s at 1 GB, 4.3 vs 4.3 at 4 GB):
+// what bounds the kernel beyond ~1.5 GB of footprint is the memory system, not the layout -- a plain device-to-device copy falls
+// from 5.4 to 4.4 TB/s over the same range (tools/k1_sweep.py).
 #define K1_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
 // One block of the reprojection evaluation: `block` is the block index within the evaluation (not necessarily
 // blockIdx.x: the fused evaluation kernel runs these next to the small-factor blocks), `smem` holds
@@ -2819,7 +2823,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
   // tile rows (16 rows each) of the two panels that the current chunk writes to: a tile whose row or column block got
   // nothing is skipped (16 landmarks see a dozen consecutive frames, not all sixteen of a panel)
   __shared__ unsigned sTouched[2];
+  // ... and, per tile row, which of the twelve 4-column steps of the product hold anything: a landmark's three columns of G are
+  // non-zero only in the rows of the poses that see it, so for most (tile row, tile column, step) triples one operand is all
+  // zero -- the counters showed 20 executed MFMA flops per algorithmic one (profiles/r04_config4_mfma.json, before this mask)
+  __shared__ unsigned sKMask[2][6];
   if (t < 2) sTouched[t] = 0u;
+  if (t < 12) sKMask[t / 6][t % 6] = 0u;
   const bool stagedPose = p.nPose <= kPoseStage;
   if (stagedPose)
     for (int i = t; i < p.nPose; i += blockDim.x) sPoseOff[i] = p.poseOff[i];
@@ -2942,6 +2951,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
         double* Gt = inI ? GtI : GtJ;
         const int rl = offP - (inI ? r0I : r0J);
         atomicOr(&sTouched[inI ? 0 : 1], (1u << (rl >> 4)) | (1u << ((rl + 5) >> 4)));
+        {
+          const unsigned kbits = (1u << ((3 * grp) >> 2)) | (1u << ((3 * grp + 2) >> 2));   // the steps columns 3 grp .. 3 grp + 2 fall into
+          unsigned* km = sKMask[inI ? 0 : 1];
+          atomicOr(&km[rl >> 4], kbits);
+          if (((rl + 5) >> 4) != (rl >> 4)) atomicOr(&km[(rl + 5) >> 4], kbits);
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
           const double j0 = jc[a], j1 = jc[6 + a];
@@ -2999,8 +3014,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
       }
       const double* A = GtI + (size_t)(16 * ti + (lane & 15)) * kDenseLd + (lane >> 4);
       const double* B = GtJ + (size_t)(16 * tj + (lane & 15)) * kDenseLd + (lane >> 4);
+      const unsigned steps = __builtin_amdgcn_readfirstlane(sKMask[0][ti]) & __builtin_amdgcn_readfirstlane(sKMask[diag ? 0 : 1][tj]);
 #pragma unroll
-      for (int q = 0; q < kDenseK / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);
+      for (int q = 0; q < kDenseK / 4; ++q)
+        if ((steps >> q) & 1u) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[4 * q], B[4 * q], c, 0, 0, 0);   // (wave-uniform)
       acc[k] = c;
     }
     PNT(3);
@@ -3008,6 +3025,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
     // (clearing only the tile rows the chunk wrote to was measured: the index arithmetic costs more than the stores it saves)
     for (int i = t; i < (ldsDoubles >> 1); i += blockDim.x) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};   // (ldsDoubles is even)
     if (t < 2) sTouched[t] = 0u;
+    if (t < 12) sKMask[t / 6][t % 6] = 0u;
     __syncthreads();
     PNT(4);
   }

@@ -7,7 +7,7 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/build/variants"; mkdir -p "$out/obj_$name"
 cd "$root/svin_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $*"
-for f in kernels.hip marg.hip posegraph.hip; do hipcc $FLAGS -c $f -o "$out/obj_$name/$f.o" & done
+for f in kernels.hip marg.hip posegraph.hip resident.hip; do hipcc $FLAGS -c $f -o "$out/obj_$name/$f.o" & done
 for f in window.cpp capi.cpp host_eval.cpp; do hipcc $FLAGS -x hip -c $f -o "$out/obj_$name/$f.o" & done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/$name.so" "$out/obj_$name"/*.o
