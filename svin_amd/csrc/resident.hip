@@ -55,6 +55,8 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
     for (int k = 0; k < 4; ++k) a.lmHp[4 * (size_t)s.h + k] = s.hp[k];
     if (s.setQuality) a.qualH[s.h] = s.quality;
   }
+  if (a.valuesOnly)
+    for (int h = a.Hprev + t; h < a.H; h += nt) a.slotOfHNew[h] = -1;
   for (int i = t; i < a.nRem; i += nt) {
     const WinRem r = a.rems[i];
     const int s = a.slotOfHOld[r.lmH];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
   }
   __syncthreads();
   // ---- phase 1: slots and segment starts of the landmarks that have observations, in handle order
-  {
+  if (!a.valuesOnly) {
     const int per = (a.H + nt - 1) / nt;
     const int h0 = min(a.H, t * per), h1 = min(a.H, h0 + per);
     int2 mine = make_int2(0, 0);
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
     return;
   }
   // ---- phase 2: surviving observations first (order kept), this frame's additions behind them
+  if (!a.valuesOnly)
   for (int o = t; o < a.Nold; o += nt) {   // one thread per old observation: its rank among the survivors of its landmark
     if (!a.live[o]) continue;
     const int s = a.obsLmOld[o];

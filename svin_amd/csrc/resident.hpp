@@ -43,6 +43,9 @@ struct ResidentArgs {
   int nAdd, nRem, nSet, H;        // delta sizes; handles in use: [0, H)
   int Nold, Lold, Nnew, Lnew;     // sizes of the old CSR and -- as the host graph counts them -- of the new one
   int wantOrder, nPoseSlots;      // per-chunk pose ordering (DeviceProblem::obsOrder) wanted; pose slots of the window
+  int valuesOnly, Hprev;          // no observation was added or removed since the last flush: the CSR stays as it is ("old" and
+                                  // "new" name the same set), only landmark points, slot-packed indices and the order are refreshed;
+                                  // handles [Hprev, H) are new landmarks without observations
   const WinAdd* adds; const WinRem* rems; const WinLmSet* sets;
   // old CSR (read) / new CSR (written): the two sets take turns
   const int* lmPtrOld; const int* handleOfSlotOld; const int* slotOfHOld;

@@ -1103,7 +1103,10 @@ void Window::flushResident(hipStream_t s, bool wantOrder, std::vector<StagedCopy
     R.N = 0; R.L = 0; R.H = 0;
   }
   const size_t H = (size_t)nextLmHandle_, N = numObs_, L = numLmObserved_;
-  const int cur = R.cur, nxt = 1 - R.cur;
+  // nothing was added or removed (a second optimize() of the same window, the benchmark's loop, Map::solve after setEstimate):
+  // the table stays, only what depends on values and slots is refreshed
+  const bool valuesOnly = !full && addLog_.empty() && remLog_.empty() && N == (size_t)R.N && L == (size_t)R.L;
+  const int cur = R.cur, nxt = valuesOnly ? R.cur : 1 - R.cur;
   // per-handle tables keep their contents; new handles start from zero
   const size_t Hc = std::max<size_t>(H, 1);
   R.cnt.growKeep(Hc, R.H, s); R.addsH.growKeep(Hc, R.H, s); R.addCur.growKeep(Hc, R.H, s);
@@ -1132,6 +1135,7 @@ void Window::flushResident(hipStream_t s, bool wantOrder, std::vector<StagedCopy
     HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&resStatusDev_), resStatus_, 0));
   }
   ra.nAdd = (int)addLog_.size(); ra.nRem = (int)remLog_.size(); ra.nSet = (int)setLog_.size(); ra.H = (int)H;
+  ra.valuesOnly = valuesOnly ? 1 : 0; ra.Hprev = R.H;
   ra.Nold = R.N; ra.Lold = R.L; ra.Nnew = (int)N; ra.Lnew = (int)L;
   ra.wantOrder = wantOrder ? 1 : 0;
   ra.adds = R.adds.p; ra.rems = R.rems.p; ra.sets = R.sets.p;
@@ -1823,10 +1827,18 @@ void Window::solve(size_t numIter, bool verbose) {
   // landmark step: the two never meet because a sharded solve takes neither the fused nor the deferred step
   if (dist && (fuseStep || deferLm)) throw std::logic_error("sharded solve with a fused step");
   evaluateAll(false, s);
+  TrustRegionHost tr;   // every decision of the loop (trust_region.hpp: HIP-free, replayed on the CPU by the tests)
+  // The first build depends on no decision (initial damping, metric fixed here): it is enqueued right behind the initial
+  // evaluation instead of after the host has seen that evaluation's cost (one mailbox round trip of an idle device per solve).
+  bool firstBuilt = false;
+  const double firstMu = tr.mu;
+  if (!dist && numIter > 0) {
+    launchAccumulateNormalEquations(p, firstMu, true, s, /*zeroFirst=*/false);   // pack() cleared the accumulators
+    firstBuilt = true;
+  }
   AR(scalD, 4, 0);
   publish();
   SolverScalars sc = readScalars();
-  TrustRegionHost tr;   // every decision of the loop (trust_region.hpp: HIP-free, replayed on the CPU by the tests)
   tr.fTol = fTol_; tr.gTol = gTol_; tr.pTol = pTol_;
   tr.maxIterations = (int)numIter;
   tr.start(sc.cost);
@@ -1868,7 +1880,10 @@ void Window::solve(size_t numIter, bool verbose) {
     const double tIter = nowSec();
     while (true) {
       if (!tr.reuse) {
-        if (!(specValid && specMu == tr.mu && !tr.initScale))
+        const bool haveFirst = firstBuilt && tr.initScale && tr.mu == firstMu;   // the build enqueued ahead of the loop
+        if (firstBuilt && !haveFirst) accumulatorsClean = false;                 // (a retry with more damping: it has to go)
+        firstBuilt = false;
+        if (!haveFirst && !(specValid && specMu == tr.mu && !tr.initScale))
           launchAccumulateNormalEquations(p, tr.mu, tr.initScale, s, /*zeroFirst=*/!accumulatorsClean);  // pack() / k_post_solve cleared them
         specValid = false;
         if (dist && p.d > 0) {   // one message: lower triangle of S + gRed + gFull + hC (half of what the full matrix would be)
