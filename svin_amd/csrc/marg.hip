@@ -841,6 +841,7 @@ static double nowSec() {
 }
 
 int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed) {
+  quiesce();
   const bool timing = getenv("SVIN_MARG_TIMING") != nullptr;
   const double tm0 = nowSec();
   double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
@@ -1196,8 +1197,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     idxLists.insert(idxLists.end(), margIdx.begin(), margIdx.end());
     const size_t mm = std::max(m, 1), L3 = std::max(3 * Lm, 1);
     bU.reserve(mm * mm + 2); bW2.reserve(mm * L3 + 2); bV.reserve((size_t)9 * std::max(Lm, 1) + 2); bVec.reserve(mm + 2 * L3 + 16);
+    auto pendingPtr = std::make_shared<std::vector<StagedCopy>>();
+    std::vector<StagedCopy>& pending = *pendingPtr;
     {   // the job's tables: one pinned block, one DMA, one scatter kernel (17 pageable copies cost ~100 us of enqueueing)
-      std::vector<StagedCopy> pending;
       // U, W, V and the vectors start from zero: clears riding in the same launch
       pending.push_back({nullptr, sizeof(double) * mm * mm, bU.p});
       pending.push_back({nullptr, sizeof(double) * mm * L3, bW2.p});
@@ -1219,7 +1221,64 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         bLmPtr.reserve((size_t)Lm + 1); bObsLm.reserve(std::max<size_t>(N, 1)); bIdx.reserve(std::max<size_t>(N, 1));
         res_.margScratch.reserve(std::max<size_t>((size_t)2 * res_.L, 1));
       }
-      flushStaged(pending, s);
+    }
+    // ---- everything the launches below need is fixed from here on; no allocation and no host table is touched after this point,
+    // so the launches themselves (a DMA, the scatter and 6-13 kernels: 25-50 us of API calls) can be issued by the handle's
+    // enqueue thread while this call goes on with the graph update and returns (Window::quiesce joins it before the stream, the
+    // job buffers or the prior are touched again)
+    bLin.reserve(std::max<size_t>((size_t)32 * N, 1));
+    bFacLin.reserve(std::max(F, 1));
+    bPartial.reserve((size_t)16 * 4096);
+    bScal.reserve(1);
+    bFlag.reserve(8);
+    int ordk = 0;
+    for (PriorBlockHost& pb : kept) { pb.ord = ordk; ordk += pb.mdim; }
+    Hk.assign((size_t)nk * nk, 0.0);
+    bk.assign(nk, 0.0);
+    auto &bHk = mb.bHk, &bOut = mb.bOut;
+    const int oldPriorM = (hadPrior && priorM_ > 0) ? priorM_ : 0;
+    const double* oldPrior = mb.bHk.p;   // (H | b0) of the previous prior: bHk is only ever re-allocated below when it has to grow ...
+    DevBuf<double> oldPriorKeep;         // ... and then the old allocation is kept alive until the job has copied out of it
+    if (std::max<size_t>((size_t)nk * nk + nk, 1) > bHk.cap && oldPriorM > 0) { std::swap(oldPriorKeep.p, bHk.p); std::swap(oldPriorKeep.cap, bHk.cap); }
+    bHk.reserve(std::max<size_t>((size_t)nk * nk + nk, 1));
+    if (nk > 0 && nm > 0) bScratch.reserve((size_t)2 * nm * nm + (size_t)nk * nm + 2 * nm + 16);
+    const size_t n2k = (size_t)nk * nk;
+    if (nk > 0) bOut.reserve(5 * n2k + 4 * nk + 16);
+    if (nk > 0) priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
+    const int nPoseJ = (int)(hPose.size() / 7), nExtJ = (int)(hExt.size() / 7), nSbJ = (int)jSb.size(), nImuJ = (int)hImu.size();
+    const int nCamJ = (int)cameras_.size();
+    const bool keepPre = getenv("SVIN_MARG_KEEP_PRE") != nullptr;
+    // the host tables the staged block is filled from must outlive this call when the job is issued by the enqueue thread
+    struct JobTables {
+      std::vector<double> hPose, hExt, hSb, hLm, hUv, hW, hImuM;
+      std::vector<int> oPose, oExt, oSb, hObsLm, hLmPtr, idxLists, jobPoseSlot, jobExtSlot;
+      std::vector<uint32_t> hIdx, hImuT;
+      std::vector<DevFactor> hFac;
+      std::vector<DevImu> hImu;
+      std::vector<unsigned char> poseClass;
+      std::vector<CameraModel> cams;
+      DevBuf<double> oldPriorKeep;
+    };
+    auto tables = std::make_shared<JobTables>();
+    static const bool syncJob = getenv("SVIN_MARG_SYNC_ENQUEUE") != nullptr;   // A/B switch: issue the launches from this thread
+    const bool runInline = timing || keepPre || syncJob;
+    double** dbgScalPtr = runInline ? &dbgScal : nullptr;
+    // (explicit captures: the job buffers are reached through `this` -- a by-value capture of the DevBuf aliases above would copy,
+    // and later free, the buffers themselves; lmOrder / dense / toMarginalize are only read by the inline inspection path)
+    auto launchJob = [this, tables, pendingPtr, N, Lm, m, F, nk, nm, mm, L3, n2k, oldPriorM, oldPrior, anyExtVar, deviceJob, nPoseJ, nExtJ,
+                      nSbJ, nImuJ, nCamJ, keepPre, dbgScalPtr, s, &lmOrder, &dense, &toMarginalize]() {
+      MargBuffers& mb = margBuf_;
+      auto &bPose = mb.bPose, &bExt = mb.bExt, &bSb = mb.bSb, &bLm = mb.bLm, &bUv = mb.bUv, &bW = mb.bW, &bLin = mb.bLin,
+           &bU = mb.bU, &bW2 = mb.bW2, &bV = mb.bV, &bVec = mb.bVec, &bScratch = mb.bScratch;
+      auto &bOP = mb.bOP, &bOE = mb.bOE, &bOS = mb.bOS, &bLmPtr = mb.bLmPtr, &bObsLm = mb.bObsLm, &bIdxList = mb.bIdxList, &bFlag = mb.bFlag;
+      auto &bIdx = mb.bIdx, &bImuT = mb.bImuT;
+      auto& bFac = mb.bFac;
+      auto& bFacLin = mb.bFacLin;
+      auto& bImu = mb.bImu;
+      auto &bImuM = mb.bImuM, &bPartial = mb.bPartial;
+      auto& bScal = mb.bScal;
+      auto &bHk = mb.bHk, &bOut = mb.bOut;
+      flushStaged(*pendingPtr, s);
       if (deviceJob && (N > 0 || Lm > 0)) {
         MargGatherArgs ga;
         std::memset(&ga, 0, sizeof(ga));
@@ -1233,26 +1292,20 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         ga.status = resStatusDev_;
         launchWindowMargGather(ga, s);
       }
-    }
-    bLin.reserve(std::max<size_t>((size_t)32 * N, 1));
-    bFacLin.reserve(std::max(F, 1));
-    bPartial.reserve((size_t)16 * 4096);
-    bScal.reserve(1);
-    bFlag.reserve(8);
     {   // (the four clears rode in the scatter launch of the staged block) the two copies of the old prior land inside the cleared U / ba
       // old prior content (H_, b0_) occupies the leading block: it is still on the device, exactly where k_marg_dense left it
-      if (hadPrior && priorM_ > 0) {
+      if (oldPriorM > 0) {
         FillJobs copies;
         copies.n = 0;
-        addFill(copies, bU.p, mb.bHk.p, (size_t)priorM_ * priorM_, priorM_, m, priorM_);
-        addFill(copies, bVec.p, mb.bHk.p + (size_t)priorM_ * priorM_, priorM_);
+        addFill(copies, bU.p, oldPrior, (size_t)oldPriorM * oldPriorM, oldPriorM, m, oldPriorM);
+        addFill(copies, bVec.p, oldPrior + (size_t)oldPriorM * oldPriorM, oldPriorM);
         launchFillJobs(copies, s);
       }
     }
     DeviceProblem q;
     std::memset(&q, 0, sizeof(q));
-    q.nPose = (int)(hPose.size() / 7); q.nExt = (int)(hExt.size() / 7); q.nSb = (int)jSb.size();
-    q.L = Lm; q.N = N; q.F = F; q.nImu = (int)hImu.size(); q.d = m; q.dC = 0; q.nCam = (int)cameras_.size();
+    q.nPose = nPoseJ; q.nExt = nExtJ; q.nSb = nSbJ;
+    q.L = Lm; q.N = N; q.F = F; q.nImu = nImuJ; q.d = m; q.dC = 0; q.nCam = nCamJ;
     q.anyExtVariable = anyExtVar ? 1 : 0;
     q.ownsCamera = 1;
     q.pose = bPose.p; q.ext = bExt.p; q.sb = bSb.p; q.lm = bLm.p;
@@ -1284,7 +1337,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       launchEvalFactors(q, false, s);
       hipLaunchKernelGGL(k_marg_accum_factors, dim3(1), dim3(256), 0, s, q, md);
     }
-    if (getenv("SVIN_MARG_KEEP_PRE")) {   // inspection: the system after M1 (svin_ba_get_marg_pre), before anything is eliminated
+    if (keepPre) {   // inspection: the system after M1 (svin_ba_get_marg_pre), before anything is eliminated
       HIP_OK(hipStreamSynchronize(s));
       margPre_.m = m; margPre_.Lm = Lm;
       margPre_.U.assign((size_t)m * m, 0.0); margPre_.ba.assign(std::max(m, 1), 0.0);
@@ -1314,15 +1367,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       hipLaunchKernelGGL(k_marg_lm_update, dim3((m * m + 255) / 256), dim3(256), 0, s, md);
     }
     // M2 dense part
-    int ordk = 0;
-    for (PriorBlockHost& pb : kept) { pb.ord = ordk; ordk += pb.mdim; }
-    Hk.assign((size_t)nk * nk, 0.0);
-    bk.assign(nk, 0.0);
-    auto &bHk = mb.bHk, &bOut = mb.bOut;
-    bHk.reserve(std::max<size_t>((size_t)nk * nk + nk, 1));
     if (nk > 0) {
       if (nm > 0) {
-        bScratch.reserve((size_t)2 * nm * nm + (size_t)nk * nm + 2 * nm + 16);
         DenseArgs da;
         da.m = m; da.nk = nk; da.nm = nm;
         da.keep = bIdxList.p; da.marg = bIdxList.p + nk;
@@ -1341,15 +1387,14 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         HIP_OK(hipMemcpyAsync(bHk.p + (size_t)m * m, bVec.p, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
       }
       // M3
-      const size_t n2 = (size_t)nk * nk;
-      bOut.reserve(5 * n2 + 4 * nk + 16);
+      const size_t n2 = n2k;
       FinalArgs fa;
       fa.n = nk; fa.H = bHk.p; fa.b0 = bHk.p + n2;
       fa.G = bOut.p; fa.Q = bOut.p + n2; fa.J = bOut.p + 2 * n2; fa.Ht = bOut.p + 3 * n2;
       fa.e0 = bOut.p + 4 * n2; fa.bp = bOut.p + 4 * n2 + nk; fa.scal = bOut.p + 4 * n2 + 2 * nk;
       fa.tmp = bOut.p + 4 * n2 + 2 * nk + 8;
       fa.flag = bFlag.p;
-      dbgScal = fa.scal;
+      if (dbgScalPtr) *dbgScalPtr = fa.scal;
       {
         // Eigen-solver of the prior (k_marg_final's `useLds`):
         //   4  A + delta I = R^T R, one-sided Jacobi on the rows of R, image in LDS (default: n <= 136)
@@ -1365,8 +1410,18 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         if (lds > margLdsSet_[1]) { (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); margLdsSet_[1] = lds; }
         hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0);
       }
-      priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     }
+    };
+    // move the host tables behind the staged pointers into the job (a vector's storage does not move with it)
+    tables->hPose = std::move(hPose); tables->hExt = std::move(hExt); tables->hSb = std::move(hSb); tables->hLm = std::move(hLm);
+    tables->hUv = std::move(hUv); tables->hW = std::move(hW); tables->hImuM = std::move(hImuM);
+    tables->oPose = std::move(oPose); tables->oExt = std::move(oExt); tables->oSb = std::move(oSb); tables->hObsLm = std::move(hObsLm);
+    tables->hLmPtr = std::move(hLmPtr); tables->idxLists = std::move(idxLists); tables->jobPoseSlot = std::move(jobPoseSlot);
+    tables->jobExtSlot = std::move(jobExtSlot); tables->hIdx = std::move(hIdx); tables->hImuT = std::move(hImuT);
+    tables->hFac = std::move(hFac); tables->hImu = std::move(hImu); tables->poseClass = std::move(poseClass);
+    std::swap(tables->oldPriorKeep.p, oldPriorKeep.p); std::swap(tables->oldPriorKeep.cap, oldPriorKeep.cap);
+    if (runInline) launchJob();
+    else enqueueAsync(std::move(launchJob));
     tm3 = nowSec();
     if (timing) {
       HIP_OK(hipStreamSynchronize(s));

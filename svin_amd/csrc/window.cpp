@@ -94,6 +94,7 @@ int Window::rcclUniqueId(unsigned char* out128) {
   return 1;
 }
 int Window::setDistributedRccl(int rank, int world, const unsigned char* id128) {
+  quiesce();
   HIP_OK(hipSetDevice(device_));
   ncclUniqueId id;
   std::memcpy(id.internal, id128, 128);
@@ -108,6 +109,7 @@ void Window::dropRcclComm() {
   if (rcclComm_) { (void)rccl().commDestroy(static_cast<ncclComm_t>(rcclComm_)); rcclComm_ = nullptr; }
 }
 void Window::setDistributed(int rank, int world, AllReduceFn fn, void* user) {
+  quiesce();
   dropRcclComm();   // the callback form replaces a native communicator (solve() prefers rcclComm_ when it is set)
   rank_ = rank; world_ = world; allreduce_ = fn; allreduceUser_ = user;
 }
@@ -138,6 +140,13 @@ Window::Window(int device) : device_(device) {
   }
 }
 Window::~Window() {
+  try { quiesce(); } catch (...) {}
+  {
+    std::lock_guard<std::mutex> lock(enqueueMutex_);
+    enqueueStop_ = true;
+    enqueueCv_.notify_all();
+  }
+  if (enqueueThread_.joinable()) enqueueThread_.join();
   dropRcclComm();
   if (stageEvt_) (void)hipEventDestroy(stageEvt_);
   if (stageHost_) (void)hipHostFree(stageHost_);
@@ -153,6 +162,7 @@ Window::~Window() {
 
 // ------------------------------------------------------------------------------------------ sensors
 int Window::addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig) {
+  quiesce();
   if ((int)cameras_.size() >= 15) return -1;
   CameraModel c;
   std::memset(&c, 0, sizeof(c));
@@ -166,6 +176,7 @@ int Window::addCamera(int model, const double* intr, const double* dist, int nDi
   return (int)cameras_.size() - 1;
 }
 int Window::setCameraGeometry(size_t cam, int model, const double* intr, const double* dist, int nDist, int w, int h) {
+  quiesce();
   // the reference learns the camera geometry from the multi-frame of each observation (implementation/Estimator.hpp:62-66:
   // multiFramePtr->geometryAs<GEOMETRY_TYPE>(camIdx)); a shim that registers the extrinsics parameters first
   // (Estimator::addCamera) hands the geometry over with this call when the first multi-frame arrives
@@ -286,6 +297,7 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
 // ------------------------------------------------------------------------------------------ IMU prediction
 int Window::imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
                            TimeStamp t0, TimeStamp t1, double* cov, double* jac, double* integrals) {
+  quiesce();
   if (n <= 0) return -1;
   DevImu im;
   std::memset(&im, 0, sizeof(im));
@@ -1003,6 +1015,43 @@ void Window::parameterBlockIds(std::vector<uint64_t>& out) const {
   std::sort(out.begin(), out.end());
 }
 
+// ------------------------------------------------------------------------------------------ enqueue thread
+void Window::enqueueLoop() {
+  (void)hipSetDevice(device_);
+  std::unique_lock<std::mutex> lock(enqueueMutex_);
+  while (true) {
+    enqueueCv_.wait(lock, [&] { return enqueueStop_ || (enqueueBusy_ && enqueueJob_); });
+    if (enqueueStop_) return;
+    std::function<void()> job = std::move(enqueueJob_);
+    enqueueJob_ = nullptr;
+    lock.unlock();
+    std::exception_ptr err;
+    try { job(); } catch (...) { err = std::current_exception(); }
+    job = nullptr;   // (releases the host tables of the job)
+    lock.lock();
+    enqueueError_ = err;
+    enqueueBusy_ = false;
+    enqueueCv_.notify_all();
+  }
+}
+void Window::enqueueAsync(std::function<void()> job) {
+  quiesce();
+  std::lock_guard<std::mutex> lock(enqueueMutex_);
+  if (!enqueueThread_.joinable()) enqueueThread_ = std::thread([this] { enqueueLoop(); });
+  enqueueJob_ = std::move(job);
+  enqueueBusy_ = true;
+  enqueueCv_.notify_all();
+}
+void Window::quiesce() const {
+  std::unique_lock<std::mutex> lock(enqueueMutex_);
+  enqueueCv_.wait(lock, [&] { return !enqueueBusy_; });
+  if (enqueueError_) {
+    std::exception_ptr e = enqueueError_;
+    enqueueError_ = nullptr;
+    std::rethrow_exception(e);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ device-resident window
 bool Window::useResident() const {   // (called by pack() once the state tables are known)
   static const bool forceHost = getenv("SVIN_HOST_PACK") != nullptr;
@@ -1051,12 +1100,14 @@ void Window::checkResidentStatus() {
 }
 void Window::flushPendingQuality() const {
   if (!qualityPending_) return;
+  quiesce();
   qualityPending_ = false;
   if (qualityProb_.L > 0) launchLandmarkQuality(qualityProb_, dQuality_.p, stream_);
   launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, qualityProb_.lm, dQuality_.p, res_.lmHp.p, res_.qualH.p, stream_);
 }
 void Window::syncLandmarks() const {
   if (!lmStale_) return;
+  quiesce();
   flushPendingQuality();
   lmStale_ = false;
   const size_t H = (size_t)hFlushed_;
@@ -1196,6 +1247,7 @@ void Window::flushStaged(const std::vector<StagedCopy>& pending, hipStream_t s) 
 }
 
 void Window::pack(bool solveFollows) {
+  quiesce();
   // the qualities of the last solve: a new solve replaces them before anybody can look; any other caller (inspection hooks,
   // prepare()) keeps them -- they are computed now, while that solve's tables are still intact
   if (solveFollows) qualityPending_ = false;
@@ -1639,6 +1691,7 @@ void Window::pack(bool solveFollows) {
 }
 
 void Window::downloadStates() {
+  quiesce();
   hipStream_t s = stream_;
   const DeviceProblem& p = prob_;
   const bool resident = residentUsed_;   // landmark points and qualities stay on the device, keyed by handle (syncLandmarks fetches)
@@ -2141,6 +2194,7 @@ int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32
 }
 int Window::getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                      int32_t* nBlocks, int capM) {
+  quiesce();
   if (!hasPrior_) return 0;
   const int m = priorM_;
   if (m > capM) return -m;
@@ -2247,6 +2301,7 @@ void debugCholTiming(double* out, bool reset);
 // the collective of the sharded solve, stand-alone: `iters` in-place sum all-reduces of nDoubles FP64 values on the solver's
 // stream between two HIP events (the communicator svin_ba_set_distributed_rccl created; collective: every rank calls it)
 int Window::benchAllReduce(size_t nDoubles, int iters, double* meanUs) {
+  quiesce();
   if (!rcclComm_) { lastError() = "benchAllReduce: no RCCL communicator (svin_ba_set_distributed_rccl first)"; return -1; }
   if (nDoubles == 0 || iters <= 0) return -1;
   HIP_OK(hipSetDevice(device_));

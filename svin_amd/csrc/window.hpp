@@ -11,11 +11,16 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -239,7 +244,7 @@ class Window {
   int addCamera(int model, const double* intr, const double* dist, int nDist, int w, int h, const double* sig);
   int setCameraGeometry(size_t cam, int model, const double* intr, const double* dist, int nDist, int w, int h);
   int addImu(const ImuParams& p);
-  void clearCameras() { cameras_.clear(); extrinsics_.clear(); }   // Estimator.cpp:91
+  void clearCameras() { quiesce(); cameras_.clear(); extrinsics_.clear(); }   // Estimator.cpp:91
   void clearImus() { imus_.clear(); }                                // Estimator.cpp:94
   size_t numCameras() const { return cameras_.size(); }
   size_t numImus() const { return imus_.size(); }
@@ -462,6 +467,18 @@ class Window {
   DevBuf<int> finishTicket_;
   mutable double* lmSyncHost_ = nullptr;   // pinned read-back area of syncLandmarks
   mutable size_t lmSyncCap_ = 0;
+  // The launches of an asynchronous device job (the marginalisation's M1-M3: a DMA, the scatter and 6-13 kernels) are issued by
+  // a thread of the handle's own while the call that assembled the job returns; quiesce() -- at the top of everything that
+  // touches the stream, the job buffers, the staging block or the prior -- waits for it (and rethrows what it threw).
+  void enqueueAsync(std::function<void()> job);
+  void quiesce() const;
+  void enqueueLoop();
+  mutable std::thread enqueueThread_;
+  mutable std::mutex enqueueMutex_;
+  mutable std::condition_variable enqueueCv_;
+  mutable std::function<void()> enqueueJob_;
+  mutable bool enqueueBusy_ = false, enqueueStop_ = false;
+  mutable std::exception_ptr enqueueError_;
   bool useResident() const;
   void invalidateResident();      // the next pack() uploads the whole graph again
   void renumberLandmarkHandles();
