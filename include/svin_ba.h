@@ -222,7 +222,8 @@ int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap);   /* returns the n
  * speed/bias: svin_ba_describe_block tells which), landmark ids.  Residual ids: what add_observation returned, the
  * ids of the non-reprojection factors (svin_ba_eval_factors lists them) and of the marginalisation prior. */
 int svin_ba_parameter_block_exists(svin_ba* h, uint64_t block_id);                    /* Map::parameterBlockExists */
-/* Map::setParameterBlockConstant / Variable (src/Map.cpp:495-510); landmarks: SVIN_ERR_UNSUPPORTED, unknown id: 0 */
+/* Map::setParameterBlockConstant / Variable (src/Map.cpp:495-510) on any block, landmarks included (a window with a constant
+ * landmark is packed by the host and cannot marginalise a frame that sees it); unknown id: 0 */
 int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t block_id, int constant);
 int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t block_id);               /* ParameterBlock::fixed() */
 /* Map::residuals(id) (src/Map.cpp:576-587): ids of every residual touching the block, in insertion order; returns the

@@ -9,8 +9,7 @@
 //     classes of this directory (PoseError, HomogeneousPointError, ReprojectionError<GEOMETRY> under CauchyLoss(1)) -- each
 //     maps onto a factor kind of the device solver (svin_ba_map_*), so that a program shaped like the reference's own tests
 //     (okvis_ceres/test/TestHomogeneousPointError.cpp:57-99, TestMap.cpp:60-150) builds its graph block by block, checks
-//     Jacobians with isJacobianCorrect, solves and reads the estimates back from its parameter-block objects.  Landmarks
-//     cannot be held constant (the landmark elimination has no such path): setParameterBlockConstant returns false for them.
+//     Jacobians with isJacobianCorrect, solves and reads the estimates back from its parameter-block objects.
 //   * ::ceres::Problem / Manifold pointers (DO_NOT_TAKE_OWNERSHIP plumbing, Map.cpp:59-64): there is no Ceres.
 //   * computeCovariance (Map.hpp:352-372): debug code of the reference, never called.
 #ifndef INTEGRATION_OKVIS_CERES_MAP_HPP_

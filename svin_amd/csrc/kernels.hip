@@ -535,7 +535,13 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
     const uint32_t idx = obsIdx[i];
     const int ps = idx & 0xfff, es = (idx >> 12) & 0xfff, cs = (idx >> 24) & 0xf;
     const double2 uv = reinterpret_cast<const double2*>(obsUv)[i];
-    const double w = obsW[i];
+    // a NEGATIVE weight marks an observation of a landmark that is held constant (Map::setParameterBlockConstant on a
+    // HomogeneousPointParameterBlock, TestMap.cpp:93): the residual and the pose / extrinsics Jacobians are the usual ones, the
+    // landmark Jacobian is written as zero -- V_l, b_l and the landmark's columns of the Schur complement then vanish exactly and
+    // its step is zero, without a second code path in any kernel downstream
+    const double wRaw = obsW[i];
+    const bool lmConstant = wRaw < 0.0;
+    const double w = fabs(wRaw);
     const int lmi = obsLm[i];
     const double4 hp = reinterpret_cast<const double4*>(lm)[lmi];
     double hpw[4] = {hp.x, hp.y, hp.z, hp.w};
@@ -592,6 +598,10 @@ __device__ __forceinline__ void evalReprojBlock(int block, double* smem, double*
       }
     } else {
       cost = 0.5 * s;
+    }
+    if (lmConstant) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jl[k] = 0.0;
     }
     K1_STORE(&r[i], rr[0]);
     K1_STORE(&r[stride + i], rr[1]);
@@ -5665,7 +5675,7 @@ __global__ __launch_bounds__(256) void k_landmark_quality(DeviceProblem p, doubl
       for (int k = 0; k < 3; ++k) { jl[k] = pr[3 + (second ? 6 : 0) + k]; jl[3 + k] = second ? 0.0 : pr[6 + k]; }
     } else {
       reprojEval(p.cams[(idx >> 24) & 0xf], p.pose + (size_t)(idx & 0xfff) * 7, hpw, p.ext + (size_t)((idx >> 12) & 0xfff) * 7,
-                 p.obsUv[2 * (size_t)o], p.obsUv[2 * (size_t)o + 1], p.obsW[o], rr, jp, jl, je);
+                 p.obsUv[2 * (size_t)o], p.obsUv[2 * (size_t)o + 1], fabs(p.obsW[o]), rr, jp, jl, je);   // (Map::getLhs does not ask whether the block is constant)
     }
     a00 += jl[0] * jl[0] + jl[3] * jl[3]; a01 += jl[0] * jl[1] + jl[3] * jl[4]; a02 += jl[0] * jl[2] + jl[3] * jl[5];
     a11 += jl[1] * jl[1] + jl[4] * jl[4]; a12 += jl[1] * jl[2] + jl[4] * jl[5]; a22 += jl[2] * jl[2] + jl[5] * jl[5];

@@ -851,7 +851,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     rit++;
     if (rit == states_.rend()) return 1;
   }
-  if (numLandmarkPriors_ > 0) {
+  if (numLandmarkPriors_ > 0 || numFixedLandmarks_ > 0) {
     // Landmarks that carry a HomogeneousPointError stay out of the marginalisation: the reference's policy loop assumes
     // every residual of a landmark is a ReprojectionError (Estimator.cpp:689-698) and never meets one, because Estimator
     // adds none.  Observed from a frame that is about to leave, such a landmark cannot be handled: refuse before anything
@@ -863,10 +863,10 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       else kept++;
     }
     for (const auto& kv : landmarks_) {
-      if (kv.second.priors.empty()) continue;
+      if (kv.second.priors.empty() && !kv.second.fixed) continue;
       for (const Observation& o : kv.second.obs)
         if (std::find(leaving.begin(), leaving.end(), o.poseId) != leaving.end()) {
-          lastError() = "applyMarginalizationStrategy: a landmark with a HomogeneousPointError is observed from a frame that leaves the window";
+          lastError() = "applyMarginalizationStrategy: a landmark with a HomogeneousPointError, or a constant one, is observed from a frame that leaves the window";
           return -1;
         }
     }
@@ -1021,7 +1021,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       const double tl1 = nowSec();
       for (int h : cand) {
         Landmark& lm = *lmByHandle_[h];
-        if (!lm.priors.empty()) continue;   // see the guard at the top
+        if (!lm.priors.empty() || lm.fixed) continue;   // see the guard at the top
         if (lm.obs.empty()) {
           removed.push_back(lm.id);
           eraseLandmark(lm);

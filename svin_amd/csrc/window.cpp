@@ -269,6 +269,7 @@ void Window::removeObsRecord(Landmark& lm, size_t idx) {
 void Window::eraseLandmark(Landmark& lm) {
   while (!lm.obs.empty()) removeObsRecord(lm, lm.obs.size() - 1);
   const int h = lm.handle;
+  if (lm.fixed) --numFixedLandmarks_;
   lmByHandle_[h] = nullptr;
   lmIndex_.erase(lm.id);
   landmarks_.erase(lmIterByHandle_[h]);
@@ -897,13 +898,25 @@ void Window::setImuPreIntegral(uint64_t poseId, const double* in7) {
 }
 int Window::setParameterBlockConstant(uint64_t id, bool constant) {
   Block* b = findBlock(id);
-  if (!b) return landmarks_.count(id) ? -4 : 0;   // the landmark-elimination kernels have no "fixed landmark" path
+  if (!b) {
+    uint64_t hnd = 0;
+    if (!lmIndex_.find(id, &hnd)) return 0;
+    // a constant landmark (okvis::Estimator never makes one; Map-level callers and the reference's TestMap do): its observations
+    // are packed with a negative weight, which the evaluation turns into a zero landmark Jacobian.  Such windows take the host path.
+    Landmark& lm = *lmByHandle_[(size_t)hnd];
+    if (lm.fixed != constant) { lm.fixed = constant; numFixedLandmarks_ += constant ? 1 : -1; }
+    return 1;
+  }
   b->fixed = constant;
   return 1;
 }
 int Window::isParameterBlockConstant(uint64_t id) const {
   const Block* b = findBlock(id);
-  if (!b) return landmarks_.count(id) ? 0 : -2;
+  if (!b) {
+    uint64_t hnd = 0;
+    if (!lmIndex_.find(id, &hnd)) return -2;
+    return lmByHandle_[(size_t)hnd]->fixed ? 1 : 0;
+  }
   return b->fixed ? 1 : 0;
 }
 int Window::residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const {
@@ -986,7 +999,7 @@ int Window::getParameterBlock(uint64_t id, int32_t* type, double* values, uint32
     if (values) std::memcpy(values, lit->second.hp, 4 * sizeof(double));
     if (sec) *sec = 0;
     if (nsec) *nsec = 0;
-    if (fixed) *fixed = 0;
+    if (fixed) *fixed = lit->second.fixed ? 1 : 0;
     if (initialized) *initialized = lit->second.initialized ? 1 : 0;
     return 4;
   }
@@ -1055,7 +1068,7 @@ void Window::quiesce() const {
 // ------------------------------------------------------------------------------------------ device-resident window
 bool Window::useResident() const {   // (called by pack() once the state tables are known)
   static const bool forceHost = getenv("SVIN_HOST_PACK") != nullptr;
-  return packMode_ == 0 && !forceHost && world_ <= 1 && rcclComm_ == nullptr && numLandmarkPriors_ == 0 &&
+  return packMode_ == 0 && !forceHost && world_ <= 1 && rcclComm_ == nullptr && numLandmarkPriors_ == 0 && numFixedLandmarks_ == 0 &&
          poseIds_.size() <= (size_t)kResidentPoseCap;
 }
 void Window::invalidateResident() {
@@ -1387,7 +1400,7 @@ void Window::pack(bool solveFollows) {
       for (const Observation& ob : lm.obs) {
         hUv[2 * o] = ob.uv[0]; hUv[2 * o + 1] = ob.uv[1];
         // information = I * 64/size^2 ; sqrt information = its (scalar) Cholesky factor
-        hW[o] = obsWeight(ob.size);
+        hW[o] = lm.fixed ? -obsWeight(ob.size) : obsWeight(ob.size);
         hIdx[o] = packObs(poseCache.at(ob.poseId), extCache.at(extIdOf(ob)), ob.cam);
         hObsLm[o] = (int)slot;
         ++o;

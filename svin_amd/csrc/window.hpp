@@ -79,6 +79,7 @@ struct Landmark {
   int handle = -1;               // creation number (resident.hpp): CSR order of the device-resident window
   uint32_t visit = 0;            // scratch stamp of the marginalisation policy (a landmark is handled once per call)
   bool initialized = true;       // HomogeneousPointParameterBlock::initialized_ (constructor default, HomogeneousPointParameterBlock.hpp:68)
+  bool fixed = false;            // Map::setParameterBlockConstant: its observations are packed with a negative weight (kernels.hip K1)
   double hp[4] = {0, 0, 0, 1};
   double quality = 0, distance = 0;
   // HomogeneousPointError residuals on this landmark (HomogeneousPointError.cpp:48-117): measurement and the
@@ -307,7 +308,7 @@ class Window {
   // addObservation / the factors / the prior were given; block ids are frame ids (pose), internal ids (extrinsics,
   // speed/bias) and landmark ids.
   bool parameterBlockExists(uint64_t id) const { return blocks_.count(id) || lmIndex_.count(id); }   // Map.cpp:77-80
-  int setParameterBlockConstant(uint64_t id, bool constant);     // Map.cpp:495-510 (landmarks: SVIN_ERR_UNSUPPORTED)
+  int setParameterBlockConstant(uint64_t id, bool constant);     // Map.cpp:495-510
   int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
   int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
   int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
@@ -493,6 +494,7 @@ class Window {
   uint64_t obsCacheExt_[16] = {0};
   std::unordered_map<uint64_t, uint64_t> lmPriorRes2Lm_;  // HomogeneousPointError residual id -> landmark id
   size_t numLandmarkPriors_ = 0;
+  size_t numFixedLandmarks_ = 0;
   DevBuf<double> dLmPrior_;
   uint64_t nextResId_ = 1;
   uint64_t factorSeq_ = 0;      // Factor::dealKey of the next factor

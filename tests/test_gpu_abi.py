@@ -392,9 +392,10 @@ def test_map_graph_queries_match_oracle(gpu_lib):
         gpu.residuals_of(987654321)
     lid = gpu.landmark_ids()[3]
     assert gpu.residuals_of(lid) == sorted(m.residuals_of(lid)) and len(gpu.residuals_of(lid)) == gpu.get_landmark(lid)["n_obs"]
-    with pytest.raises(RuntimeError):
-        gpu.set_parameter_block_constant(lid, True)       # no fixed-landmark path in the elimination kernels
-    # hold one pose constant on both sides: it must not move, everything else follows the oracle
+    # hold one landmark and one pose constant on both sides: they must not move, everything else follows the oracle
+    assert gpu.set_parameter_block_constant(lid, True) and gpu.is_parameter_block_constant(lid)
+    assert cpu.L.orc_map_set_constant(m.h, lid, 1)
+    lm_before = gpu.get_landmark(lid)["point"].copy()
     hold = gpu.frame_ids()[-2]
     assert gpu.set_parameter_block_constant(hold, True) and gpu.is_parameter_block_constant(hold)
     assert cpu.L.orc_map_set_constant(m.h, hold, 1)
@@ -402,6 +403,9 @@ def test_map_graph_queries_match_oracle(gpu_lib):
     for e in (gpu, cpu):
         e.optimize(6)
     assert np.array_equal(gpu.get_T_WS(hold), before) and np.array_equal(cpu.get_T_WS(hold), before_c)
+    assert np.array_equal(gpu.get_landmark(lid)["point"], lm_before)
+    assert gpu.set_parameter_block_constant(lid, False) and not gpu.is_parameter_block_constant(lid)
+    cpu.L.orc_map_set_constant(m.h, lid, 0)
     assert gpu.summary()["iterations"] == cpu.summary()["iterations"]
     worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(a)) for a in gpu.frame_ids())
     assert worst < 1e-4, worst

@@ -103,10 +103,11 @@ def test_homogeneous_point_errors_alone_converge_to_zero(gpu_lib):
         est.parameters_of(rids[1])
 
 
-def test_map_built_window_against_oracle_map(gpu_lib):
-    """TestMap.cpp:60-150 in the form the device supports (landmarks stay variable): one pose with a PoseError, a constant
-    extrinsics block, 300 landmarks with a weak HomogeneousPointError each, Cauchy-robustified reprojection residuals of an
-    equidistant camera, a speed/bias block with a SpeedAndBiasError; some residuals and blocks removed again.  Cost and fixed
+@pytest.mark.parametrize("constant_landmarks", [False, True])
+def test_map_built_window_against_oracle_map(gpu_lib, constant_landmarks):
+    """TestMap.cpp:60-150: one pose (with a weak PoseError), a constant extrinsics block, 300 landmarks -- CONSTANT as in the
+    reference ("no point optimization", :93) or variable under a weak HomogeneousPointError each --, Cauchy-robustified
+    reprojection residuals of an equidistant camera; some residuals and blocks removed again.  Cost, iteration count and fixed
     point against the oracle's Map (the CPU restatement of Map.cpp) built by the same calls."""
     from svin_amd.estimator import Estimator
     from oracle import orc
@@ -150,9 +151,13 @@ def test_map_built_window_against_oracle_map(gpu_lib):
         rid = est.map_add_reprojection_error(1, 10 + i, 2, 0, uv, np.eye(2))
         ro = m.add_reproj(orc.DIST_EQUIDISTANT, intr, dist, uv, np.eye(2), orc.LOSS_CAUCHY, 1, 10 + i, 2)
         assert rid != 0
-        pr = est.add_homogeneous_point_error(10 + i, hp, variance=4.0)
-        po = m.add_hpoint_error(hp, 4.0, 10 + i)
-        rids.append((rid, ro, pr, po))
+        if constant_landmarks:
+            assert est.set_parameter_block_constant(10 + i) and est.is_parameter_block_constant(10 + i)
+            m.set_constant(10 + i)
+        else:
+            est.add_homogeneous_point_error(10 + i, hp, variance=4.0)
+            m.add_hpoint_error(hp, 4.0, 10 + i)
+        rids.append((rid, ro))
         if i % 10 == 0:
             if i % 20 == 0:   # "randomly delete some just for fun to test" (TestMap.cpp:117-122)
                 assert est.map_remove_parameter_block(10 + i)
@@ -170,5 +175,8 @@ def test_map_built_window_against_oracle_map(gpu_lib):
     assert s["iterations"] == so["iterations"]
     assert abs(s["final_cost"] - so["final_cost"]) < 1e-9 * so["final_cost"]
     assert np.linalg.norm(T[:3] - To[:3]) < 1e-8 and quat_close(T[3:], To[3:]) < 1e-8
+    if constant_landmarks:   # the points did not move
+        for i in (1, 7, 123):
+            assert np.array_equal(est.get_parameter_block(10 + i), m.get_param(10 + i))
     # TestMap.cpp:140-144: converged to the true pose within the test's tolerances
     assert quat_close(T[3:], T_WS[3:]) * 2 < 1e-2 and np.linalg.norm(T[:3] - T_WS[:3]) < 1e-1
