@@ -245,6 +245,13 @@ int svin_ba_get_parameter_block(svin_ba* h, uint64_t block_id, int32_t* type, do
                                 uint32_t* nsec, int32_t* fixed, int32_t* initialized);
 int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap);
 
+/* ErrorInterface::residualDim / parameterBlocks / parameterBlockDim and the type of a LIST of residuals in one call (what
+ * Map::residuals(block) needs per entry of its collection, Map.cpp:576-587): kind as svin_ba_parameters_of reports it, the
+ * residual dimension, the number of blocks and the ambient dimensions of the first four (the marginalisation prior, kind 101,
+ * lists its blocks through svin_ba_parameters_of).  Unknown ids: kind -1.  Returns the number of known residuals. */
+int svin_ba_residual_info(svin_ba* h, int n, const uint64_t* residual_ids, int32_t* kind, int32_t* residual_dim,
+                          int32_t* n_blocks, int32_t* block_dims /* 4 per residual */);
+
 /* ---- okvis::ceres::Map as a graph BUILDER (Map.cpp:255-376, :322-333, :467-492): parameter blocks and residual blocks added one
  * by one, outside any frame -- what the reference's own tests do (okvis_ceres/test/TestMap.cpp, TestHomogeneousPointError.cpp,
  * TestPoseError ...).  The residual kinds are the reference's error-term classes; a device solver cannot call a caller's virtual

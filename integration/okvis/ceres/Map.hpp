@@ -380,7 +380,19 @@ class Map {
     if (n <= 0) return out;
     std::vector<uint64_t> rids((size_t)n);
     svin_ba_residuals_of(h_, id, rids.data(), n);
-    for (uint64_t r : rids) out.push_back(ResidualBlockSpec(reinterpret_cast< ::ceres::ResidualBlockId>(r), nullptr, errorInterfacePtr(r)));
+    // sizes and types of all of them in ONE call (a pose block of a window is touched by a thousand reprojection residuals)
+    std::vector<int32_t> kind((size_t)n), m((size_t)n), nb((size_t)n), dims((size_t)4 * n);
+    svin_ba_residual_info(h_, n, rids.data(), kind.data(), m.data(), nb.data(), dims.data());
+    for (int i = 0; i < n; ++i) {
+      std::shared_ptr<ErrorInterface> e;
+      if (kind[i] == 101) e = errorInterfacePtr(rids[i]);   // the prior: its block list comes from svin_ba_parameters_of
+      else if (kind[i] >= 0) {
+        std::vector<size_t> d;
+        for (int b = 0; b < nb[i] && b < 4; ++b) d.push_back((size_t)dims[4 * i + b]);
+        e = std::make_shared<ResidualView>(kind[i], (size_t)m[i], d);
+      }
+      out.push_back(ResidualBlockSpec(reinterpret_cast< ::ceres::ResidualBlockId>(rids[i]), nullptr, e));
+    }
     return out;
   }
   /// Map::parameters (Map.cpp:602-620): the blocks of a residual in the cost function's parameter order

@@ -548,6 +548,12 @@ int svin_ba_bench_jacobian_eval(svin_ba* h, int copies, int iters, double* mean_
   GUARD_BEGIN return h->w.benchJacobianEval(copies, iters, mean_ms, bytes);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_residual_info(svin_ba* h, int n, const uint64_t* residual_ids, int32_t* kind, int32_t* residual_dim, int32_t* n_blocks,
+                          int32_t* block_dims) {
+  if (!h || n < 0 || (n > 0 && !residual_ids)) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.residualInfo(n, residual_ids, kind, residual_dim, n_blocks, block_dims);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_map_add_parameter_block(svin_ba* h, uint64_t id, int type, const double* values) {
   if (!h || !values) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.mapAddParameterBlock(id, type, values);

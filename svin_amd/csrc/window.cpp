@@ -945,6 +945,30 @@ int Window::residualKind(uint64_t resId) const {
   auto it = factors_.find(resId);
   return it == factors_.end() ? -1 : it->second.kind;
 }
+int Window::residualInfo(int n, const uint64_t* resIds, int32_t* kind, int32_t* m, int32_t* nBlocks, int32_t* dims4) const {
+  int known = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t rid = resIds[i];
+    int k = residualKind(rid), mm = 0, nb = 0, d[4] = {0, 0, 0, 0};
+    if (k == 100) { mm = 2; nb = 3; d[0] = 7; d[1] = 4; d[2] = 7; }                       // ReprojectionErrorBase.hpp:50-54
+    else if (k == 101) { mm = priorM_; nb = (int)priorBlocks_.size(); }                   // (its block list: svin_ba_parameters_of)
+    else if (k == 102) { mm = 3; nb = 1; d[0] = 4; }
+    else if (k >= 0) {
+      const Factor& f = factors_.at(rid);
+      mm = f.m; nb = f.nblk;
+      for (int b = 0; b < f.nblk; ++b) {
+        const Block* blk = findBlock(f.blocks[b]);
+        d[b] = blk ? (blk->kind == B_SB ? 9 : 7) : 0;
+      }
+    }
+    if (k >= 0) ++known;
+    if (kind) kind[i] = k;
+    if (m) m[i] = mm;
+    if (nBlocks) nBlocks[i] = nb;
+    if (dims4) for (int b = 0; b < 4; ++b) dims4[4 * i + b] = d[b];
+  }
+  return known;
+}
 int Window::parametersOf(uint64_t resId, std::vector<uint64_t>& out) const {
   out.clear();
   uint64_t obsNode = 0;

@@ -312,7 +312,10 @@ class Window {
   int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
   int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
   int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
-  int residualKind(uint64_t resId) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, 102 landmark prior, else FactorKind
+  int residualKind(uint64_t resId) const;
+  // kind, residual dimension and the ambient dimensions of the blocks of a list of residuals in one call (what the shim's
+  // Map::residuals / errorInterfacePtr need per residual: sizes and type, ErrorInterface::residualDim / parameterBlockDim)
+  int residualInfo(int n, const uint64_t* resIds, int32_t* kind, int32_t* m, int32_t* nBlocks, int32_t* dims4) const;   // -1 unknown, 100 reprojection, 101 marginalisation prior, 102 landmark prior, else FactorKind
   const std::map<uint64_t, State>& states() const { return states_; }
   const std::map<uint64_t, Landmark>& landmarks() const { syncLandmarks(); return landmarks_; }
   size_t numLandmarks() const { return landmarks_.size(); }

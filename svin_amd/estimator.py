@@ -56,7 +56,7 @@ EXPORTS = [
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
     "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize",
-    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr",
+    "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_residual_info",
     "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
     "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
     "svin_ba_map_remove_residual_block", "svin_ba_bench_kernel_times",
@@ -158,6 +158,7 @@ def load_library():
     sig("svin_ba_bench_jacobian_eval", i32, vp, i32, i32, pd, pd)
     sig("svin_ba_bench_jacobian_eval_b2b", i32, vp, i32, i32, pd, pd, pd)
     sig("svin_ba_set_pack_mode", i32, vp, i32)
+    sig("svin_ba_residual_info", i32, vp, i32, pu64, pi32, pi32, pi32, pi32)
     sig("svin_ba_map_add_parameter_block", i32, vp, u64, i32, pd)
     sig("svin_ba_set_parameter_block", i32, vp, u64, pd)
     sig("svin_ba_map_remove_parameter_block", i32, vp, u64)
@@ -782,6 +783,17 @@ class Estimator:
 
     def map_remove_residual_block(self, rid):
         return self._check(self.L.svin_ba_map_remove_residual_block(self.h, rid), "map_remove_residual_block") == 1
+
+    def residual_info(self, rids):
+        """[(kind, residual dimension, [block dimensions])] for a list of residual ids (one call)"""
+        r = np.ascontiguousarray(rids, np.uint64)
+        n = len(r)
+        kind, m, nb, dims = (np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32),
+                             np.zeros(4 * max(n, 1), np.int32))
+        p32 = C.POINTER(C.c_int32)
+        self._check(self.L.svin_ba_residual_info(self.h, n, r.ctypes.data_as(pu64), kind.ctypes.data_as(p32), m.ctypes.data_as(p32),
+                                                 nb.ctypes.data_as(p32), dims.ctypes.data_as(p32)), "residual_info")
+        return [(int(kind[i]), int(m[i]), [int(x) for x in dims[4 * i:4 * i + min(int(nb[i]), 4)]]) for i in range(n)]
 
     def set_pack_mode(self, mode):
         """0: device-resident window whenever it qualifies (default); 1: always the host graph -> array pass + full upload"""

@@ -390,6 +390,15 @@ def test_map_graph_queries_match_oracle(gpu_lib):
     assert not gpu.parameter_block_exists(987654321)
     with pytest.raises(RuntimeError):
         gpu.residuals_of(987654321)
+    # ErrorInterface sizes of a whole residual list in one call (svin_ba_residual_info): against the oracle's error terms
+    some = sorted(gpu.residuals_of(gpu.frame_ids()[1]))[:400]
+    for rid, (kind, mdim, dims) in zip(some, gpu.residual_info(some)):
+        pars, k2 = gpu.parameters_of(rid)
+        assert kind == k2
+        if kind != 101:
+            assert mdim == {100: 2, 102: 3, 0: 15, 1: 6, 2: 9, 3: 6, 4: 1, 5: 1}[kind] and len(dims) == len(pars)
+            assert dims == [len(gpu.parameter_block(b)["values"]) for b in pars]
+    assert gpu.residual_info([987654321])[0][0] == -1
     lid = gpu.landmark_ids()[3]
     assert gpu.residuals_of(lid) == sorted(m.residuals_of(lid)) and len(gpu.residuals_of(lid)) == gpu.get_landmark(lid)["n_obs"]
     # hold one landmark and one pose constant on both sides: they must not move, everything else follows the oracle

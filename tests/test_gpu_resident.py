@@ -125,11 +125,12 @@ def same_states(ests, tag, tol=0.0):
                 assert np.max(np.abs(va - vb)) <= tol, "%s: frame %d differs by %g" % (tag, f, float(np.max(np.abs(va - vb))))
 
 
-@pytest.mark.parametrize("rig", ["euroc", "rig_v2"])   # rig_v2: per-frame extrinsics -> the per-chunk pose order is built on the device
-def test_resident_csr_equals_host_rebuild_for_50_frames(gpu_lib, rig):
+@pytest.mark.parametrize("rig", ["euroc", "rig_v2", "rig_v2_sonar_depth"])   # rig_v2: per-frame extrinsics -> the per-chunk pose order is built on
+def test_resident_csr_equals_host_rebuild_for_50_frames(gpu_lib, rig):           # the device; sonar: addStates reads the landmarks every frame (lazy fetch)
     """add / remove / set / optimise / marginalise interleaved for 50 frames: device CSR == host rebuild, every frame"""
     from svin_amd.estimator import Estimator
-    spec = syn.make_window(P=50, L=1500, n_obs=22000, seed=31, rig=rig, keyframe_every=3, frame_dt=0.2)
+    kw = dict(sonar=True, depth=True) if rig == "rig_v2_sonar_depth" else {}
+    spec = syn.make_window(P=50 if not kw else 30, L=1500, n_obs=22000, seed=31, rig=rig.split("_sonar")[0], keyframe_every=3, frame_dt=0.2, **kw)
     a, b = Estimator(0), Estimator(0)
     b.set_pack_mode(1)
     drv = Driver([a, b], spec, seed=5)
@@ -177,7 +178,7 @@ def test_resident_csr_equals_host_rebuild_for_50_frames(gpu_lib, rig):
         ra = [e.apply_marginalization(4, 3) for e in drv.ests]
         assert ra[0][0] and ra[1][0] and list(ra[0][1]) == list(ra[1][1]), "%s frame %d: removed landmarks differ" % (rig, k)
         removed_total += len(ra[0][1])
-    assert removed_total > 100
+    assert removed_total > (100 if not kw else 40)
     ma, mb = a.marg(), b.marg()
     assert (ma is None) == (mb is None)
     if ma is not None:
