@@ -318,7 +318,7 @@ def window_record(name, spec, device, steps, warmup, iters):
     return rec, est
 
 
-def sliding_window_record(device, with_oracle=True):
+def sliding_window_record(device, with_oracle=True, rig="euroc"):
     """SVIn's operating mode: a window fed frame by frame -- addStates, ~1 000 addObservation, optimize(10),
     applyMarginalizationStrategy(5 keyframes, 3 IMU frames) -- host work and PCIe included, the oracle beside it."""
     from svin_amd import synthetic as syn
@@ -338,13 +338,16 @@ def sliding_window_record(device, with_oracle=True):
                              solve=s.get("solve_time", 0.0), download=s.get("download_time", 0.0), removed=len(removed)))
         syn.feed(est, spec, on_frame=on_frame, timing=timing)
         return rows[4:], timing      # steady state: the window is full from the fifth frame on
-    spec = syn.make_window(P=24, L=2400, n_obs=24000, seed=7, rig="euroc", keyframe_every=2, frame_dt=0.25)
+    spec = syn.make_window(P=24, L=2400, n_obs=24000, seed=7, rig=rig, keyframe_every=2, frame_dt=0.25,
+                           **({"sonar": True, "depth": True} if rig == "rig_v2" else {}))
     rows, timing = run(Estimator(device), spec)
     med = lambda key: float(np.median([r[key] for r in rows]))   # noqa: E731
     add_obs = float(np.median(timing["add_observations_s"])) if timing.get("add_observations_s") else 0.0
     frame = med("optimize") + med("marginalise") + add_obs
-    rec = dict(workload="sliding window, 5 keyframes + 3 IMU frames, ~1000 new observations per frame, optimize(10) + "
-                        "applyMarginalizationStrategy per frame, %d steady-state frames" % len(rows),
+    rec = dict(workload="sliding window (%s), 5 keyframes + 3 IMU frames, ~1000 new observations per frame, optimize(10) + "
+                        "applyMarginalizationStrategy per frame, %d steady-state frames"
+                        % ("EuRoC stereo rig, fixed extrinsics" if rig == "euroc" else
+                           "SVIn stereo_rig_v2: 2 cameras with variable extrinsics + sonar + depth", len(rows)),
                ms_per_frame=1e3 * frame, frames_per_s=1.0 / frame,
                ms={"add_observations": 1e3 * add_obs, "optimize_call": 1e3 * med("optimize"), "pack_upload": 1e3 * med("upload"),
                    "device_solve": 1e3 * med("solve"), "read_back": 1e3 * med("download"), "marginalise_call": 1e3 * med("marginalise")},
@@ -742,6 +745,7 @@ def main():
         if rank == 0:
             try:
                 extras["sliding_window"] = sliding_window_record(local_rank, with_oracle=not args.no_cpu_baseline)
+                extras["sliding_window_rig_v2"] = sliding_window_record(local_rank, with_oracle=not args.no_cpu_baseline, rig="rig_v2")
             except Exception as ex:
                 extras["sliding_window"] = {"error": repr(ex)}
         if rank == 0:
