@@ -361,6 +361,13 @@ int svin_ba_eval_factors(svin_ba* h, int32_t* kind, int32_t* m, int32_t* ncols, 
  * describe the ordering. Returns d. */
 int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* block_ids, int32_t* block_offsets,
                       int32_t* n_blocks, int cap_d, double* cost);
+/* the Gauss-Newton step y of that system, (S + mu D) y = g, as the device solver computes it (the path the size of the window
+ * selects: LDS-resident, left-looking, blocked, blocked behind the speed / bias chain elimination).  Returns d (or -d if
+ * cap_d < d). */
+int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d);
+/* doubles [offset, offset + count) of the reduced-system solver's scratch buffer after the last solve (tests of the solver
+ * kernels' intermediate results).  Returns 1, 0 if the range is outside the buffer. */
+int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out);
 /* marginalisation prior: returns its dimension m; H (m x m), b0 (m), J (m x m), e0 (m) may be NULL */
 int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* block_ids,
                       int32_t* block_ordering, int32_t* block_mdim, int32_t* n_blocks, int cap_m);

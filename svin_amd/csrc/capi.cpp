@@ -500,6 +500,16 @@ int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* ids
   GUARD_BEGIN return h->w.linearize(mu, S, g, ids, off, nb, cap_d, cost);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d) {
+  if (!h || !y) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out) {
+  if (!h || !out) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.debugPeekSolverScratch(offset, count, out);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord,
                       int32_t* mdim, int32_t* nb, int cap_m) {
   if (!h) return SVIN_ERR_INVALID_ARG;

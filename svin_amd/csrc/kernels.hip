@@ -4502,6 +4502,373 @@ __global__ __launch_bounds__(512) void k_big_back(DeviceProblem p, int dpad, int
   }
 }
 
+// ================================================================ K6''': the speed / bias chain eliminated ahead of the blocked Cholesky
+// In a wide window the reduced system is [poses + extrinsics (dC rows, dense) | speed / bias blocks (9 rows each)], and the
+// speed / bias part is a CHAIN: block b couples with b - 1 and b + 1 only (the IMU factors), whatever the landmarks do to the
+// pose part.  At configs[3] (64 key frames) that is 576 of the 960 unknowns -- nine of the fifteen 64-column steps of
+// k_big_chol_chain, each ~23 us of critical path, spent on a block-tridiagonal matrix.  Eliminating the chain first leaves a
+// dC x dC system for the blocked Cholesky:
+//     S_ss = L L^T,   Y = L^-1 [S_sk | g_s],   S_kk' = S_kk - Y_k^T Y_k,   g_k' = g_k - Y_k^T y_g,   x_s = L^-T (y_g - Y_k x_k)
+// A chain factorised end to end is 64 dependent 9x9 steps (that is what lost at d = 150 in round 2).  Here the elimination
+// order is cyclic reduction: level by level the blocks b = s (mod 2 s), s = 1, 2, 4, ..., whose two neighbours b - s, b + s
+// survive the level; all blocks of a level are independent, so the chain costs log2(n) + 1 dependent block steps.  Per block
+// the factor is three 9x9 matrices: G = L_bb^-1, F_lo = G S(b, b-s), F_hi = G S(b+s, b)^T (S = the matrix as that level sees
+// it) -- L's two off-diagonal blocks are F_lo^T and F_hi^T.
+//   k_sb_factor    one workgroup: the chain's factor (levels in LDS, one barrier-separated pass per level)
+//   k_sb_forward   8 columns of [S_sk | g_s] per workgroup, the level sweep in LDS: Y
+//   k_sb_load      replaces k_big_load: M = S_kk - Y^T Y on MFMA (one 16x16 tile per workgroup, K split over its 4 waves),
+//                  right-hand side row, identity padding, flags
+//   k_sb_back      after k_big_back: t = y_g - Y_k x_k over many workgroups, the last one to finish walks the levels backwards
+struct SbElimArgs {
+  int n;        // chain blocks: rows dC + 9 b of the reduced system
+  int dK;       // kept unknowns (= dC)
+  int dp;       // dK rounded up to 64: the blocked solver's matrix is (dp + 64) x dp
+  int ldY;      // leading dimension of Y: dK + 1 columns (the last one is the right-hand side), rounded up to 16
+  int rowsY;    // 9 n rounded up to 4 (the pad rows are zero)
+  double* Lf;   // n records of kSbRec doubles
+  double* Y;
+  double* tvec; // 9 n
+  int* counter; // last-workgroup ticket of k_sb_back
+};
+constexpr int kSbRec = 264, kSbG = 0, kSbFlo = 88, kSbFhi = 176;   // 9x9 row-major each (16-byte aligned starts)
+constexpr int kSbMaxChain = 64;                                    // k_sb_factor keeps the whole chain in LDS
+
+// 9x9 SPD block (row-major in LDS) -> G = L^-1 (row-major, zeros above the diagonal), one thread, all in registers
+__device__ __forceinline__ bool cholInverse9(const double* Din, double* Gout) {
+  double L[45];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Din[i * 9 + j];
+  double inv[9];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double s = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    if (!(s > 0.0)) { ok = false; s = 1.0; }
+    double rs = rsqrt(s);
+    rs = rs * fma(-0.5 * s * rs, rs, 1.5);   // one Newton step: the factor must hold to the last bits (IMU information ~1e10 next to ~1e3)
+    inv[j] = rs;
+    L[j * (j + 1) / 2 + j] = s * rs;
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = v * rs;
+    }
+  }
+  // X = L^-1, column by column: X_jj = 1 / L_jj, X_ij = -(1 / L_ii) sum_{j <= k < i} L_ik X_kj
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double X[9];
+    X[j] = inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = j; k < i; ++k) s += L[i * (i + 1) / 2 + k] * X[k];
+      X[i] = -inv[i] * s;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Gout[i * 9 + j] = (i >= j) ? X[i] : 0.0;
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(512) void k_sb_factor(DeviceProblem p, SbElimArgs a, double mu, int initScale, int fuseFinalize) {
+  extern __shared__ double smem[];
+  const int n = a.n, t = threadIdx.x, nT = blockDim.x;
+  double* D = smem;                         // [n][81] diagonal blocks as the current level sees them
+  double* C = D + n * 81;                   // [n][81] coupling of block b with its lower active neighbour: rows b, columns b - s
+  double* G = C + n * 81;                   // [(n + 1) / 2][81]   this level's factors
+  double* F = G + ((n + 1) / 2) * 81;       // [(n + 1) / 2][2][81]
+  const int ld = p.ldS ? p.ldS : p.d, r0 = a.dK;
+  if (t == 0) *a.counter = 0;
+  for (int e = t; e < n * 81; e += nT) {
+    const int b = e / 81, i = (e % 81) / 9, j = e % 9;
+    const int gi = r0 + 9 * b + i, gj = r0 + 9 * b + j;
+    double x = p.S[(size_t)max(gi, gj) * ld + min(gi, gj)];
+    if (i == j && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
+    D[e] = x;
+    C[e] = (b > 0) ? p.S[(size_t)gi * ld + (gj - 9)] : 0.0;
+  }
+  __syncthreads();
+  for (int s = 1;; s *= 2) {
+    const bool last = s >= n;                                   // block 0 alone is left
+    const int nE = last ? 1 : (n - s + 2 * s - 1) / (2 * s);    // eliminated now: b = s + 2 s e < n
+    if (t < nE) {
+      const int b = last ? 0 : s + 2 * s * t;
+      if (!cholInverse9(D + b * 81, G + t * 81)) atomicOr(&p.scal->cholFail, 1);
+    }
+    __syncthreads();
+    // F_lo = G C[b], F_hi = G C[b + s]^T, column by column; G and F also go to the record of block b
+    for (int task = t; task < nE * 18; task += nT) {
+      const int e = task / 18, which = (task % 18) / 9, c = task % 9;
+      const int b = last ? 0 : s + 2 * s * e;
+      const double* Ge = G + e * 81;
+      double v[9];
+      const bool have = !last && (which == 0 || b + s < n);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = !have ? 0.0 : (which == 0 ? C[b * 81 + k * 9 + c] : C[(b + s) * 81 + c * 9 + k]);
+      double* rec = a.Lf + (size_t)b * kSbRec;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k <= i; ++k) acc += Ge[i * 9 + k] * v[k];
+        F[(e * 2 + which) * 81 + i * 9 + c] = acc;
+        rec[(which == 0 ? kSbFlo : kSbFhi) + i * 9 + c] = acc;
+      }
+      // (18 threads per block: each also copies its share of G)
+      for (int q = task % 18; q < 81; q += 18) rec[kSbG + q] = Ge[q];
+    }
+    __syncthreads();
+    if (last) break;
+    // the survivors m = 0 (mod 2 s) collect: D[m] -= F_hi(m - s)^T F_hi(m - s) + F_lo(m + s)^T F_lo(m + s), and their new
+    // lower neighbour is m - 2 s: C[m] = -F_hi(m - s)^T F_lo(m - s)
+    const int nR = (n + 2 * s - 1) / (2 * s);
+    for (int task = t; task < nR * 162; task += nT) {
+      const int m = 2 * s * (task / 162), q = task % 162, which = q / 81, i = (q % 81) / 9, j = q % 9;
+      if (which == 0) {
+        double acc = 0.0;
+        if (m >= s) {
+          const double* Fh = F + (((m - s - s) / (2 * s)) * 2 + 1) * 81;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc += Fh[k * 9 + i] * Fh[k * 9 + j];
+        }
+        if (m + s < n) {
+          const double* Fl = F + ((m / (2 * s)) * 2 + 0) * 81;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc += Fl[k * 9 + i] * Fl[k * 9 + j];
+        }
+        D[m * 81 + i * 9 + j] -= acc;
+      } else if (m >= 2 * s) {
+        const double* Fh = F + (((m - 2 * s) / (2 * s)) * 2 + 1) * 81;
+        const double* Fl = Fh - 81;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += Fh[k * 9 + i] * Fl[k * 9 + j];
+        C[m * 81 + i * 9 + j] = -acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kSbCols = 8;
+__global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs a) {
+  extern __shared__ double w[];   // [rowsY][8]
+  const int t = threadIdx.x, c = t & (kSbCols - 1), q = t / kSbCols, nQ = blockDim.x / kSbCols, n = a.n;
+  const int col = blockIdx.x * kSbCols + c;
+  const int ld = p.ldS ? p.ldS : p.d;
+  for (int r = q; r < a.rowsY; r += nQ) {
+    double x = 0.0;
+    if (r < 9 * n) {
+      const int gi = a.dK + r;
+      x = (col < a.dK) ? p.S[(size_t)gi * ld + col] : ((col == a.dK) ? p.gRed[gi] : 0.0);
+    }
+    w[r * kSbCols + c] = x;
+  }
+  __syncthreads();
+  auto solveBlock = [&](int b) {   // w_b <- G_b w_b
+    const double* Gb = a.Lf + (size_t)b * kSbRec + kSbG;
+    double v[9], y[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = w[(9 * b + k) * kSbCols + c];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k <= i; ++k) acc += Gb[i * 9 + k] * v[k];
+      y[i] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[(9 * b + k) * kSbCols + c] = y[k];
+  };
+  for (int s = 1; s < n; s *= 2) {
+    const int nE = (n - s + 2 * s - 1) / (2 * s);
+    for (int e = q; e < nE; e += nQ) solveBlock(s + 2 * s * e);
+    __syncthreads();
+    const int nR = (n + 2 * s - 1) / (2 * s);
+    for (int e = q; e < nR; e += nQ) {   // w_m -= F_hi(m - s)^T y_{m-s} + F_lo(m + s)^T y_{m+s}
+      const int m = 2 * s * e;
+      double acc[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[j] = 0.0;
+      if (m >= s) {
+        const int b = m - s;
+        const double* Fh = a.Lf + (size_t)b * kSbRec + kSbFhi;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const double y = w[(9 * b + i) * kSbCols + c];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[j] += Fh[i * 9 + j] * y;
+        }
+      }
+      if (m + s < n) {
+        const int b = m + s;
+        const double* Fl = a.Lf + (size_t)b * kSbRec + kSbFlo;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const double y = w[(9 * b + i) * kSbCols + c];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[j] += Fl[i * 9 + j] * y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) w[(9 * m + j) * kSbCols + c] -= acc[j];
+    }
+    __syncthreads();
+  }
+  if (q == 0) solveBlock(0);
+  __syncthreads();
+  if (col < a.ldY)
+    for (int r = q; r < a.rowsY; r += nQ) a.Y[(size_t)r * a.ldY + col] = w[r * kSbCols + c];
+}
+
+__global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, double mu, int initScale, int fuseFinalize, int* ready,
+                                                 int nReady) {
+  __shared__ double red[3 * 256];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int dK = a.dK, dp = a.dp, nT = (dK + 15) / 16, nTiles = nT * (nT + 1) / 2, nRhs = (dK + 63) / 64;
+  const int ld = p.ldS ? p.ldS : p.d;
+  double* M = p.cholL;
+  for (int i = blockIdx.x * blockDim.x + t; i < nReady; i += gridDim.x * blockDim.x) ready[i] = 0;
+  // everything outside the tiles and the right-hand side row: identity padding, zero scratch rows
+  const size_t total = (size_t)(dp + kNB) * dp;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + t; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(idx / dp), gj = (int)(idx - (size_t)gi * dp);
+    if (gi < 16 * nT && gj < 16 * nT) continue;
+    if (gi == dp && gj < dK) continue;
+    M[idx] = (gi < dp && gi == gj) ? 1.0 : 0.0;
+  }
+  if ((int)blockIdx.x < nTiles) {
+    int I = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
+    while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
+    const int J = blockIdx.x - I * (I + 1) / 2;
+    d4_t acc = {0, 0, 0, 0};
+    const int steps = a.rowsY / 4, s0 = steps * wave / 4, s1 = steps * (wave + 1) / 4;
+    const double* ya = a.Y + (size_t)(lane >> 4) * a.ldY + 16 * I + (lane & 15);
+    const double* yb = a.Y + (size_t)(lane >> 4) * a.ldY + 16 * J + (lane & 15);
+    const size_t stride = (size_t)4 * a.ldY;
+    ya += s0 * stride; yb += s0 * stride;
+    int st = s0;
+    for (; st + 4 <= s1; st += 4, ya += 4 * stride, yb += 4 * stride) {   // eight loads in flight per wave
+      const double a0 = ya[0], a1 = ya[stride], a2 = ya[2 * stride], a3 = ya[3 * stride];
+      const double b0 = yb[0], b1 = yb[stride], b2 = yb[2 * stride], b3 = yb[3 * stride];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+    }
+    for (; st < s1; ++st, ya += stride, yb += stride) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[0], yb[0], acc, 0, 0, 0);
+    if (wave > 0) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) red[(wave - 1) * 256 + rg * 64 + lane] = acc[rg];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const double yy = ((acc[rg] + red[rg * 64 + lane]) + red[256 + rg * 64 + lane]) + red[512 + rg * 64 + lane];
+        const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
+        if (I == J && gj > gi) continue;   // the diagonal tiles are mirrored from their lower triangle
+        double x = (gi == gj) ? 1.0 : 0.0;
+        if (gi < dK && gj < dK) {
+          x = p.S[(size_t)gi * ld + gj] - yy;
+          if (gi == gj && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
+        }
+        M[(size_t)gi * dp + gj] = x;
+        M[(size_t)gj * dp + gi] = x;
+      }
+    }
+  } else if ((int)blockIdx.x < nTiles + nRhs) {
+    // g_k' = g_k - Y_k^T y_g: 64 columns per workgroup, the rows split over its 4 waves
+    const int j = (blockIdx.x - nTiles) * 64 + lane;
+    double s = 0.0;
+    if (j < dK)
+      for (int r = wave; r < 9 * a.n; r += 4) s += a.Y[(size_t)r * a.ldY + j] * a.Y[(size_t)r * a.ldY + dK];
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < dK) M[(size_t)dp * dp + j] = p.gRed[j] - (((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sb_back(DeviceProblem p, SbElimArgs a) {
+  extern __shared__ double smem[];   // the last workgroup: all records (n x kSbRec), x (9 n), u (9 n)
+  __shared__ int isLast;
+  const int t = threadIdx.x, n = a.n;
+  {
+    const int r = blockIdx.x * 16 + (t >> 4), cl = t & 15;
+    double s = 0.0;
+    if (r < 9 * n)
+      for (int j = cl; j < a.dK; j += 16) s += a.Y[(size_t)r * a.ldY + j] * p.yC[j];
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
+    if (cl == 0 && r < 9 * n) __hip_atomic_store(a.tvec + r, a.Y[(size_t)r * a.ldY + a.dK] - s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (t == 0) isLast = (atomicAdd(a.counter, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!isLast) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double* rec = smem;
+  double* x = rec + (size_t)n * kSbRec;
+  double* u = x + 9 * n;
+  {
+    const double2* src = reinterpret_cast<const double2*>(a.Lf);
+    double2* dst = reinterpret_cast<double2*>(rec);
+    for (int e = t; e < n * kSbRec / 2; e += blockDim.x) dst[e] = src[e];
+  }
+  for (int r = t; r < 9 * n; r += blockDim.x) x[r] = __hip_atomic_load(a.tvec + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  // L^T x = t from the last eliminated block to the first: x_b = G_b^T (t_b - F_lo x_{b-s} - F_hi x_{b+s})
+  auto applyGt = [&](int b, int i, const double* rhs) {
+    const double* Gb = rec + (size_t)b * kSbRec + kSbG;
+    double acc = 0.0;
+    for (int k = i; k < 9; ++k) acc += Gb[k * 9 + i] * rhs[k];
+    return acc;
+  };
+  if (t < 9) u[t] = x[t];
+  __syncthreads();
+  if (t < 9) x[t] = applyGt(0, t, u);
+  __syncthreads();
+  int sTop = 1;
+  while (2 * sTop < n) sTop *= 2;
+  for (int s = sTop; s >= 1; s >>= 1) {
+    const int nE = (n - s + 2 * s - 1) / (2 * s);
+    for (int task = t; task < 9 * nE; task += blockDim.x) {
+      const int e = task / 9, i = task % 9, b = s + 2 * s * e;
+      const double* Fl = rec + (size_t)b * kSbRec + kSbFlo + i * 9;
+      const double* Fh = rec + (size_t)b * kSbRec + kSbFhi + i * 9;
+      double acc = x[9 * b + i];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc -= Fl[j] * x[9 * (b - s) + j];
+      if (b + s < n) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc -= Fh[j] * x[9 * (b + s) + j];
+      }
+      u[task] = acc;
+    }
+    __syncthreads();
+    for (int task = t; task < 9 * nE; task += blockDim.x) {
+      const int e = task / 9, i = task % 9, b = s + 2 * s * e;
+      x[9 * b + i] = applyGt(b, i, u + 9 * e);
+    }
+    __syncthreads();
+  }
+  for (int r = t; r < 9 * n; r += blockDim.x) {
+    const int gi = a.dK + r;
+    p.yC[gi] = x[r];
+    p.vC[gi] = p.gFull[gi] / p.htilC[gi];
+  }
+}
+
 // ================================================================ K6'': left-looking LDS Cholesky, 176 < dpad <= 272
 // The lower triangle of a 17 x 17-tile system (306 KB) does not fit LDS, but a left-looking factorisation never needs
 // all of it at once: when block column k is finished, what later columns still read are the tiles L(I, j), I > k,
@@ -5032,6 +5399,21 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #undef LLT
 }
 
+// whether (and where in p.cholL) the speed / bias chain is eliminated ahead of the blocked solver
+static bool planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
+  if (std::getenv("SVIN_NO_SB_ELIM") != nullptr || p.sbChain < 8 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return false;
+  a.n = p.sbChain; a.dK = p.dC; a.dp = ((p.dC + kNB - 1) / kNB) * kNB;
+  a.ldY = ((a.dK + 1 + 15) / 16) * 16;
+  a.rowsY = ((9 * a.n + 3) / 4) * 4;
+  const size_t nb = a.dp / kNB;
+  size_t off0 = (size_t)(a.dp + kNB) * a.dp + a.dp + (size_t)a.dp * kNB + ((nb + 3) * nb + 1) / 2 + 2;
+  off0 = (off0 + 1) & ~(size_t)1;
+  a.Lf = p.cholL + off0;
+  a.Y = a.Lf + (size_t)a.n * kSbRec;
+  a.tvec = a.Y + (size_t)a.rowsY * a.ldY;
+  a.counter = reinterpret_cast<int*>(a.tvec + a.rowsY);
+  return off0 + (size_t)a.n * kSbRec + (size_t)a.rowsY * a.ldY + a.rowsY + 2 <= solveReducedScratchDoubles(p.d);
+}
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
@@ -5051,14 +5433,29 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     hipLaunchKernelGGL(k_chol_solve_ll, dim3(1), dim3(kLLThreads), ldsLL, s, p, dpad, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
   } else {
     // multi-workgroup blocked factorisation, 64-wide panels; p.cholL holds (dpad64 + 64) x dpad64 doubles, its tail
-    // the 1/L_ii vector
-    const int dp = ((p.d + kNB - 1) / kNB) * kNB;
+    // the 1/L_ii vector.  With a speed / bias chain (p.sbChain blocks behind the dC kept rows) the chain is eliminated first and
+    // the blocked solver only sees the kept rows.
+    SbElimArgs sb;
+    const bool elim = planSbElimination(p, sb);
+    const int dp = elim ? sb.dp : ((p.d + kNB - 1) / kNB) * kNB;
     double* dinvG = p.cholL + (size_t)(dp + kNB) * dp;
     double* diagF = dinvG + dp;   // per panel the factorised 64x64 diagonal block (dp x 64)
     const int nb = dp / kNB;
-    int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 1) x nb block flags
-    hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
-                       (nb + 3) * nb);
+    int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 3) x nb block flags
+    if (elim) {
+      const size_t ldsFactor = ((size_t)sb.n * 162 + (size_t)((sb.n + 1) / 2) * 243) * 8;
+      ensureDynamicLds((const void*)k_sb_factor, ldsFactor);
+      hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(512), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
+      const size_t ldsFwd = (size_t)sb.rowsY * kSbCols * 8;
+      ensureDynamicLds((const void*)k_sb_forward, ldsFwd);
+      hipLaunchKernelGGL(k_sb_forward, dim3(sb.ldY / kSbCols), dim3(256), ldsFwd, s, p, sb);
+      const int nT = (sb.dK + 15) / 16;
+      hipLaunchKernelGGL(k_sb_load, dim3(nT * (nT + 1) / 2 + (sb.dK + 63) / 64), dim3(256), 0, s, p, sb, mu, initScale ? 1 : 0,
+                         fuseFinalize ? 1 : 0, ready, (nb + 3) * nb);
+    } else {
+      hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
+                         (nb + 3) * nb);
+    }
     {
       const size_t ldsTasks = ((size_t)3 * kBigBlockLds + kNB + 2) * 8;
       ensureDynamicLds((const void*)k_big_chol_chain, ldsTasks);
@@ -5076,6 +5473,11 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
       if (nChunks > 0) hipLaunchKernelGGL(k_big_back_gemv, dim3((c1 - c0) / kNB, nChunks), dim3(512), 0, s, p, dp, c0, c1);
       hipLaunchKernelGGL(k_big_back, dim3(1), dim3(512), ldsBack, s, p, dp, c0, c1, nChunks, (const double*)dinvG,
                          (const double*)diagF);
+    }
+    if (elim) {
+      const size_t ldsBackSb = ((size_t)sb.n * kSbRec + 18 * (size_t)sb.n) * 8;
+      ensureDynamicLds((const void*)k_sb_back, ldsBackSb);
+      hipLaunchKernelGGL(k_sb_back, dim3((9 * sb.n + 15) / 16), dim3(256), ldsBackSb, s, p, sb);
     }
   }
 }

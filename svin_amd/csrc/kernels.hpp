@@ -168,6 +168,9 @@ struct DeviceProblem {
   const double* lmPrior;                     // landmark priors: 12 doubles each (measurement xyz, upper-triangular sqrt information row-major)
   double* lmFactor;                          // wide windows: per landmark L^-1 of (V + mu D) (6) and c = L^-1 b (3), written by
                                              // k_panels_landmarks once per build, read by every panel pair of k_schur_panels
+  int sbChain;                               // > 0: the rows dC .. d are sbChain variable speed / bias blocks (9 rows each) that
+                                             // couple only with their neighbours in this order (IMU factors) and with the kept rows:
+                                             // the blocked solver eliminates them as a chain first (k_sb_factor ...)
 };
 
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.

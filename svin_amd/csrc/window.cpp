@@ -1505,6 +1505,36 @@ void Window::pack(bool solveFollows) {
       hPb.push_back(q);
     }
   }
+  // Do the variable speed / bias blocks form a chain behind the kept rows -- every factor (of ANY rank: the all-reduced system
+  // holds them all) and the prior tying two of them only ties neighbours in the order of the rows?  Then the wide-window solver
+  // eliminates them ahead of its blocked Cholesky (kernels.hip, k_sb_factor ...).
+  int sbChain = 0;
+  {
+    std::vector<int> chainPos(sbIds_.size(), -1);
+    int n = 0;
+    bool ok = true;
+    for (size_t i = 0; i < sbIds_.size(); ++i)
+      if (hSbOff[i] >= 0) { ok = ok && hSbOff[i] == dC + 9 * n; chainPos[i] = n++; }
+    auto neighbours = [&](const int* pos, int cnt) {
+      for (int x = 0; x < cnt; ++x)
+        for (int y = x + 1; y < cnt; ++y) ok = ok && std::abs(pos[x] - pos[y]) == 1;
+    };
+    for (const auto& kv : factors_) {
+      int pos[4], cnt = 0;
+      for (int b = 0; b < kv.second.nblk; ++b) {
+        const Block& blk = blocks_.at(kv.second.blocks[b]);
+        if (blk.kind != B_POSE && blk.kind != B_EXT && !blk.fixed) pos[cnt++] = chainPos[sbSlot_.at(blk.id)];
+      }
+      neighbours(pos, cnt);
+    }
+    if (hasPrior_) {
+      std::vector<int> pos;
+      for (const PriorBlockHost& pb : priorBlocks_)
+        if (pb.kind != B_POSE && pb.kind != B_EXT && chainPos[sbSlot_.at(pb.id)] >= 0) pos.push_back(chainPos[sbSlot_.at(pb.id)]);
+      neighbours(pos.data(), (int)pos.size());
+    }
+    if (ok && d == dC + 9 * n) sbChain = n;
+  }
   // ---- device allocation + upload
   const double tPack1 = nowSec();
   hipStream_t s = stream_;
@@ -1697,6 +1727,7 @@ void Window::pack(bool solveFollows) {
   p.Vinv = dLmVec_.p; p.bl = dLmVec_.p + 6 * LL; p.hL = dLmVec_.p + 9 * LL; p.scaleL = dLmVec_.p + 12 * LL;
   p.yL = dLmVec_.p + 15 * LL; p.deltaL = dLmVec_.p + 18 * LL; p.vL = dLmVec_.p + 21 * LL;
   p.lmFactor = dLmVec_.p + 27 * LL;
+  p.sbChain = sbChain;
   p.slabs = dSlabs_.p; p.nSlabs = nSlabs;
   p.cholL = dChol_.p;
   p.scal = dScal_.p;
@@ -2228,6 +2259,29 @@ int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32
     }
   }
   return p.d;
+}
+// inspection hook: the Gauss-Newton step of the reduced system as the solver kernels compute it (whichever of the four paths the
+// size selects), for the tests to hold against a host solve of linearize()'s system
+int Window::debugReducedSolve(double mu, double* y, int capD) {
+  distNative_ = false;
+  pack();
+  DeviceProblem& p = prob_;
+  if (p.d > capD) return -p.d;
+  evaluateAll(false, stream_);
+  launchBuildNormalEquations(p, mu, true, stream_);
+  launchSolveReduced(p, stream_);
+  HIP_OK(hipMemcpyAsync(y, p.yC, sizeof(double) * p.d, hipMemcpyDeviceToHost, stream_));
+  HIP_OK(hipStreamSynchronize(stream_));
+  return p.d;
+}
+// inspection hook: doubles [off, off + count) of the reduced-system solver's scratch buffer (the factor, the eliminated chain's
+// records and Y: layout in kernels.hip, launchSolveReduced) after the last solve
+int Window::debugPeekSolverScratch(uint64_t off, uint64_t count, double* out) {
+  quiesce();
+  if (!prob_.cholL || off + count > solveReducedScratchDoubles(prob_.d)) return 0;
+  HIP_OK(hipStreamSynchronize(stream_));
+  HIP_OK(hipMemcpy(out, prob_.cholL + off, sizeof(double) * count, hipMemcpyDeviceToHost));
+  return 1;
 }
 int Window::getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                      int32_t* nBlocks, int capM) {

@@ -307,6 +307,8 @@ class Window {
                   int cap);
   int linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks, int capD,
                 double* cost);
+  int debugReducedSolve(double mu, double* y, int capD);
+  int debugPeekSolverScratch(uint64_t off, uint64_t count, double* out);
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                int32_t* nBlocks, int capM);
   int describeBlock(uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) const;

@@ -1,0 +1,76 @@
+"""The reduced-system solve on its own: (S + mu D) y = g as each device path computes it -- LDS-resident (d <= 176), left-looking
+(d <= 272), blocked over many workgroups, and blocked behind the speed / bias chain elimination (kernels.hip, k_sb_factor /
+k_sb_forward / k_sb_load / k_sb_back: cyclic reduction over the 9x9 blocks the IMU factors chain together) -- against a host
+solve (numpy, LAPACK) of the very system svin_ba_linearize returns.  FP64 on systems whose entries span ~1e2 (landmark
+information) to ~1e10 (IMU information): 1e-10 relative to |y| with mu = 1e-4; with mu = 1e-9 the conditioning of the system
+itself separates two correct solvers by ~1e-8 (LAPACK against the device paths that were there before the elimination), so
+the bound is 1e-6 there."""
+import os
+
+import numpy as np
+import pytest
+
+from svin_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def host_solve(lin):
+    S = np.tril(lin["S"]) + np.tril(lin["S"], -1).T
+    return np.linalg.solve(S, lin["g"])
+
+
+def window(P, L, n_obs, rig="euroc", seed=11):
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=P, L=L, n_obs=n_obs, seed=seed, rig=rig, frame_dt=0.25)
+    est = Estimator(0)
+    syn.feed(est, spec)
+    return est
+
+
+@pytest.mark.parametrize("P,L,n_obs,rig,path", [
+    (10, 400, 4000, "euroc", "LDS-resident, d = 150"),
+    (16, 600, 6000, "euroc", "left-looking, d = 240"),
+    (24, 800, 8000, "euroc", "blocked + chain of 24, dK = 144 (padded to 192)"),
+    (29, 800, 8000, "euroc", "blocked + chain of 29 (not a power of two)"),
+    (48, 1500, 15000, "euroc", "blocked + chain of 48, dK = 288 (padded to 320)"),
+    (64, 2500, 25000, "euroc", "blocked + chain of 64, dK = 384"),
+    (64, 2500, 25000, "test4", "per-frame extrinsics: dK = 1152, chain of 64"),
+])
+def test_device_solve_equals_host_solve(gpu_lib, monkeypatch, P, L, n_obs, rig, path):
+    est = window(P, L, n_obs, rig)
+    for mu, tol in ((1e-4, 1e-10), (1e-9, 1e-6)):
+        lin = est.linearize(mu)
+        y_ref = host_solve(lin)
+        scale = np.abs(y_ref).max()
+        monkeypatch.delenv("SVIN_NO_SB_ELIM", raising=False)
+        y = est.debug_reduced_solve(mu)
+        err = np.abs(y - y_ref).max() / scale
+        monkeypatch.setenv("SVIN_NO_SB_ELIM", "1")
+        y_dense = est.debug_reduced_solve(mu)
+        err_dense = np.abs(y_dense - y_ref).max() / scale
+        print("%s, mu %g: d %d, |y| %.3g, device vs host %.2e (chain elimination off: %.2e)" % (path, mu, lin["d"], scale, err, err_dense))
+        assert y.shape == y_ref.shape and err < tol and err_dense < tol
+
+
+def test_chain_elimination_is_used_and_can_be_switched_off(gpu_lib, monkeypatch):
+    """the two blocked paths give different roundings of the same step (so the switch really selects code), and the solver
+    converges to the same optimum either way"""
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=32, L=1000, n_obs=10000, seed=5, frame_dt=0.25)
+    res = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SVIN_NO_SB_ELIM", "1")
+        else:
+            monkeypatch.delenv("SVIN_NO_SB_ELIM", raising=False)
+        est = Estimator(0)
+        frames, _ = syn.feed(est, spec)
+        y = est.debug_reduced_solve(1e-6)
+        est.optimize(8)
+        res[off] = (y, est.summary(), np.array([est.get_T_WS(f) for f in frames]))
+    (y0, s0, p0), (y1, s1, p1) = res[False], res[True]
+    assert np.any(y0 != y1) and np.abs(y0 - y1).max() < 1e-9 * np.abs(y1).max()
+    assert s0["iterations"] == s1["iterations"] and s0["successful"] == s1["successful"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-9 * s1["final_cost"]
+    assert np.abs(p0 - p1).max() < 1e-8

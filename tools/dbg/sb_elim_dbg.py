@@ -1,0 +1,107 @@
+"""Debug aid for the speed / bias chain elimination (kernels.hip, k_sb_factor ...): replays the cyclic reduction in numpy on the
+system svin_ba_linearize returns and compares every intermediate the kernels leave in the solver scratch (records G / F_lo /
+F_hi, Y, the reduced matrix, t) -- says which kernel went wrong first.   python tools/dbg/sb_elim_dbg.py [P]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from svin_amd import synthetic as syn           # noqa: E402
+from svin_amd.estimator import Estimator        # noqa: E402
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+mu = 1e-4
+spec = syn.make_window(P=P, L=800, n_obs=8000, seed=11, frame_dt=0.25)
+est = Estimator(0)
+syn.feed(est, spec)
+lin = est.linearize(mu)
+H = np.tril(lin["S"]) + np.tril(lin["S"], -1).T
+g = lin["g"]
+d = lin["d"]
+n = P
+dK = d - 9 * n
+y_dev = est.debug_reduced_solve(mu)
+y_ref = np.linalg.solve(H, g)
+print("d", d, "dK", dK, "n", n, "device vs host", np.abs(y_dev - y_ref).max() / np.abs(y_ref).max())
+
+# scratch layout (planSbElimination)
+dp = (dK + 63) // 64 * 64
+nb = dp // 64
+ldY = (dK + 1 + 15) // 16 * 16
+rowsY = (9 * n + 3) // 4 * 4
+off0 = (dp + 64) * dp + dp + dp * 64 + ((nb + 3) * nb + 1) // 2 + 2
+off0 = (off0 + 1) & ~1
+REC = 264
+Lf = est.debug_peek_solver_scratch(off0, n * REC).reshape(n, REC)
+Y = est.debug_peek_solver_scratch(off0 + n * REC, rowsY * ldY).reshape(rowsY, ldY)
+tv = est.debug_peek_solver_scratch(off0 + n * REC + rowsY * ldY, rowsY)
+
+# numpy replay
+D = [H[dK + 9 * b:dK + 9 * b + 9, dK + 9 * b:dK + 9 * b + 9].copy() for b in range(n)]
+Cc = [(H[dK + 9 * b:dK + 9 * b + 9, dK + 9 * b - 9:dK + 9 * b].copy() if b > 0 else np.zeros((9, 9))) for b in range(n)]
+G = [None] * n
+Flo = [np.zeros((9, 9)) for _ in range(n)]
+Fhi = [np.zeros((9, 9)) for _ in range(n)]
+level = {}
+s = 1
+while True:
+    last = s >= n
+    nE = 1 if last else (n - s + 2 * s - 1) // (2 * s)
+    for e in range(nE):
+        b = 0 if last else s + 2 * s * e
+        level[b] = s
+        G[b] = np.linalg.inv(np.linalg.cholesky(D[b]))
+        if not last:
+            Flo[b] = G[b] @ Cc[b]
+            if b + s < n:
+                Fhi[b] = G[b] @ Cc[b + s].T
+    if last:
+        break
+    newC = {}
+    for e in range((n + 2 * s - 1) // (2 * s)):
+        m = 2 * s * e
+        if m >= s:
+            D[m] -= Fhi[m - s].T @ Fhi[m - s]
+        if m + s < n:
+            D[m] -= Flo[m + s].T @ Flo[m + s]
+        if m >= 2 * s:
+            newC[m] = -Fhi[m - s].T @ Flo[m - s]
+    for m, v in newC.items():
+        Cc[m] = v
+    s *= 2
+for b in range(n):
+    eg = np.abs(Lf[b, 0:81].reshape(9, 9) - G[b]).max() / np.abs(G[b]).max()
+    el = np.abs(Lf[b, 88:169].reshape(9, 9) - Flo[b]).max() / max(np.abs(Flo[b]).max(), 1e-300)
+    eh = np.abs(Lf[b, 176:257].reshape(9, 9) - Fhi[b]).max() / max(np.abs(Fhi[b]).max(), 1e-300)
+    if max(eg, el, eh) > 1e-9 or not np.isfinite(eg + el + eh):
+        print("record of block %d (level s = %d): G %.2e F_lo %.2e F_hi %.2e" % (b, level[b], eg, el, eh))
+print("records compared")
+w = np.concatenate([H[dK:, :dK], g[dK:, None]], axis=1).copy()
+blk = lambda b: slice(9 * b, 9 * b + 9)   # noqa: E731
+s = 1
+while s < n:
+    for e in range((n - s + 2 * s - 1) // (2 * s)):
+        b = s + 2 * s * e
+        w[blk(b)] = G[b] @ w[blk(b)]
+    for e in range((n + 2 * s - 1) // (2 * s)):
+        m = 2 * s * e
+        if m >= s:
+            w[blk(m)] -= Fhi[m - s].T @ w[blk(m - s)]
+        if m + s < n:
+            w[blk(m)] -= Flo[m + s].T @ w[blk(m + s)]
+    s *= 2
+w[blk(0)] = G[0] @ w[blk(0)]
+eY = np.abs(Y[:9 * n, :dK + 1] - w)
+print("Y: max abs diff %.3e of %.3e; worst row %d col %d; pad rows zero: %s; nan count %d" %
+      (np.nanmax(eY), np.abs(w).max(), *np.unravel_index(np.nanargmax(eY), eY.shape), bool(np.all(Y[9 * n:] == 0)), int(np.isnan(Y).sum())))
+M = est.debug_peek_solver_scratch(0, (dp + 64) * dp).reshape(dp + 64, dp)
+Mref = H[:dK, :dK] - w[:, :dK].T @ w[:, :dK]
+# the blocked factorisation has overwritten the lower blocks; the strictly upper 64-blocks keep what k_sb_load wrote
+iu = np.triu_indices(dK, 64)
+print("reduced matrix (untouched upper part): max rel diff %.3e" % (np.abs(M[:dK, :dK][iu] - Mref[iu]).max() / np.abs(Mref).max()))
+gk = g[:dK] - w[:, :dK].T @ w[:, dK]
+xk = np.linalg.solve(Mref, gk)
+print("kept part of the solution: device vs replay %.3e" % (np.abs(y_dev[:dK] - xk).max() / np.abs(xk).max()))
+t = w[:, dK] - w[:, :dK] @ xk
+print("t: %.3e" % (np.abs(tv[:9 * n] - t).max() / np.abs(t).max()))
