@@ -4533,14 +4533,22 @@ struct SbElimArgs {
 constexpr int kSbRec = 264, kSbG = 0, kSbFlo = 88, kSbFhi = 176;   // 9x9 row-major each (16-byte aligned starts)
 constexpr int kSbMaxChain = 64;                                    // k_sb_factor keeps the whole chain in LDS
 
-// 9x9 SPD block (row-major in LDS) -> G = L^-1 (row-major, zeros above the diagonal), one thread, all in registers
-__device__ __forceinline__ bool cholInverse9(const double* Din, double* Gout) {
+// 1 / sqrt(s) to the last bits: the hardware estimate (v_rsq_f64, ~2^-26) refined by a third-order and a second-order step
+__device__ __forceinline__ double rsqrtRefined(double s) {
+  const double y0 = __builtin_amdgcn_rsq(s);
+  const double e0 = fma(-s * y0, y0, 1.0);
+  const double y1 = fma(y0 * e0, fma(e0, 0.375, 0.5), y0);
+  const double e1 = fma(-s * y1, y1, 1.0);
+  return fma(0.5 * y1, e1, y1);
+}
+// 9x9 SPD block (row-major in LDS) -> its Cholesky factor, packed lower triangle L[i (i + 1) / 2 + j] with the RECIPROCAL diagonal
+// (1 / L_ii at i (i + 3) / 2), one thread, all in registers
+__device__ __forceinline__ bool cholPacked9(const double* Din, double* Lout) {
   double L[45];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Din[i * 9 + j];
-  double inv[9];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
@@ -4548,10 +4556,8 @@ __device__ __forceinline__ bool cholInverse9(const double* Din, double* Gout) {
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
     if (!(s > 0.0)) { ok = false; s = 1.0; }
-    double rs = rsqrt(s);
-    rs = rs * fma(-0.5 * s * rs, rs, 1.5);   // one Newton step: the factor must hold to the last bits (IMU information ~1e10 next to ~1e3)
-    inv[j] = rs;
-    L[j * (j + 1) / 2 + j] = s * rs;
+    const double rs = rsqrtRefined(s);
+    L[j * (j + 1) / 2 + j] = rs;
 #pragma unroll
     for (int i = j + 1; i < 9; ++i) {
       double v = L[i * (i + 1) / 2 + j];
@@ -4560,25 +4566,26 @@ __device__ __forceinline__ bool cholInverse9(const double* Din, double* Gout) {
       L[i * (i + 1) / 2 + j] = v * rs;
     }
   }
-  // X = L^-1, column by column: X_jj = 1 / L_jj, X_ij = -(1 / L_ii) sum_{j <= k < i} L_ik X_kj
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    double X[9];
-    X[j] = inv[j];
-#pragma unroll
-    for (int i = j + 1; i < 9; ++i) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = j; k < i; ++k) s += L[i * (i + 1) / 2 + k] * X[k];
-      X[i] = -inv[i] * s;
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Gout[i * 9 + j] = (i >= j) ? X[i] : 0.0;
-  }
+  for (int q = 0; q < 45; ++q) Lout[q] = L[q];
   return ok;
 }
+// column j of G = L^-1 from the packed factor: G_jj = 1 / L_jj, G_ij = -(1 / L_ii) sum_{j <= k < i} L_ik G_kj
+__device__ __forceinline__ void inverseColumn9(const double* Lp, int j, double* Gout) {
+  double X[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) s += Lp[i * (i + 1) / 2 + k] * X[k];   // (X_k = 0 above the diagonal, k < j: no test, no branch around a load)
+    X[i] = (i == j) ? Lp[i * (i + 3) / 2] : -Lp[i * (i + 3) / 2] * s;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Gout[i * 9 + j] = X[i];
+}
 
-__global__ __launch_bounds__(512) void k_sb_factor(DeviceProblem p, SbElimArgs a, double mu, int initScale, int fuseFinalize) {
+constexpr int kSbFactorThreads = 576;   // 9 x 64: a level of 32 eliminations has 576 column tasks and 576 row tasks
+__global__ __launch_bounds__(kSbFactorThreads) void k_sb_factor(DeviceProblem p, SbElimArgs a, double mu, int initScale, int fuseFinalize) {
   extern __shared__ double smem[];
   const int n = a.n, t = threadIdx.x, nT = blockDim.x;
   double* D = smem;                         // [n][81] diagonal blocks as the current level sees them
@@ -4587,83 +4594,167 @@ __global__ __launch_bounds__(512) void k_sb_factor(DeviceProblem p, SbElimArgs a
   double* F = G + ((n + 1) / 2) * 81;       // [(n + 1) / 2][2][81]
   const int ld = p.ldS ? p.ldS : p.d, r0 = a.dK;
   if (t == 0) *a.counter = 0;
-  for (int e = t; e < n * 81; e += nT) {
-    const int b = e / 81, i = (e % 81) / 9, j = e % 9;
-    const int gi = r0 + 9 * b + i, gj = r0 + 9 * b + j;
-    double x = p.S[(size_t)max(gi, gj) * ld + min(gi, gj)];
-    if (i == j && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
-    D[e] = x;
-    C[e] = (b > 0) ? p.S[(size_t)gi * ld + (gj - 9)] : 0.0;
+#ifdef SVIN_SB_TIMING
+  long long qT[5] = {0, 0, 0, 0, 0}, q0 = __builtin_readcyclecounter(), q1;
+  int lvl = 0;
+#define SBT(i) do { q1 = __builtin_readcyclecounter(); qT[i] += q1 - q0; if (t == 0 && i > 0) printf("   level %d phase %d: %lld\n", lvl, i, q1 - q0); q0 = __builtin_readcyclecounter(); } while (0)
+#else
+#define SBT(i) do { } while (0)
+#endif
+  {
+    // all loads of a thread are issued before the first one is used (a load and a store per round would pay the L2 latency
+    // nine times over)
+    constexpr int kRounds = (kSbMaxChain * 81 + kSbFactorThreads - 1) / kSbFactorThreads;
+    double dv[kRounds], cv[kRounds];
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+      const int e = t + k * kSbFactorThreads;
+      dv[k] = 0.0; cv[k] = 0.0;
+      if (e < n * 81) {
+        const int b = e / 81, i = (e % 81) / 9, j = e % 9;
+        const int gi = r0 + 9 * b + i, gj = r0 + 9 * b + j;
+        dv[k] = p.S[(size_t)max(gi, gj) * ld + min(gi, gj)];
+        if (b > 0) cv[k] = p.S[(size_t)gi * ld + (gj - 9)];
+      }
+    }
+    static_assert(9 * kSbMaxChain <= kSbFactorThreads, "one diagonal entry per thread");
+    double damp0 = 0.0;
+    if (fuseFinalize && t < 9 * n) damp0 = finalizeRow(p, r0 + t, mu, initScale);
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+      const int e = t + k * kSbFactorThreads;
+      if (e < n * 81) { D[e] = dv[k]; C[e] = cv[k]; }
+    }
+    __syncthreads();
+    if (t < 9 * n) D[(t / 9) * 81 + (t % 9) * 10] += damp0;
   }
   __syncthreads();
+  SBT(0);
+  // (the barriers below are LDS-only: the records' global stores drain behind them -- a __syncthreads would wait for every one)
   for (int s = 1;; s *= 2) {
     const bool last = s >= n;                                   // block 0 alone is left
     const int nE = last ? 1 : (n - s + 2 * s - 1) / (2 * s);    // eliminated now: b = s + 2 s e < n
-    if (t < nE) {
+    if (t < nE) {   // the factor of D[b], packed, into the (still free) F slot of this elimination
       const int b = last ? 0 : s + 2 * s * t;
-      if (!cholInverse9(D + b * 81, G + t * 81)) atomicOr(&p.scal->cholFail, 1);
+      if (!cholPacked9(D + b * 81, F + t * 162)) atomicOr(&p.scal->cholFail, 1);
     }
-    __syncthreads();
-    // F_lo = G C[b], F_hi = G C[b + s]^T, column by column; G and F also go to the record of block b
-    for (int task = t; task < nE * 18; task += nT) {
-      const int e = task / 18, which = (task % 18) / 9, c = task % 9;
+    ldsBarrier();
+    SBT(1);
+    if (t < nE * 9) inverseColumn9(F + (t / 9) * 162, t % 9, G + (t / 9) * 81);
+    ldsBarrier();
+    SBT(4);
+    // F_lo = G C[b], F_hi = G C[b + s]^T on MFMA (9x9 blocks in 16x16x4 tiles, K = 12: three instructions a product, one
+    // elimination per wave at a time -- six operand reads a lane instead of the 54 of a column per thread); G and F also go to
+    // the record of block b.  Operand lane l: row / column l & 15, k = 4 q + (l >> 4); accumulator register rg: row (l >> 4) + 4 rg.
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = nT >> 6, li = lane & 15, lk = lane >> 4;
+    for (int e = wave; e < nE; e += nW) {
       const int b = last ? 0 : s + 2 * s * e;
       const double* Ge = G + e * 81;
-      double v[9];
-      const bool have = !last && (which == 0 || b + s < n);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) v[k] = !have ? 0.0 : (which == 0 ? C[b * 81 + k * 9 + c] : C[(b + s) * 81 + c * 9 + k]);
       double* rec = a.Lf + (size_t)b * kSbRec;
+      for (int q = lane; q < 81; q += 64) rec[kSbG + q] = Ge[q];
+      if (last) break;
+      const bool hasHi = b + s < n;
+      const double* Clo = C + b * 81;
+      const double* Chi = C + (hasHi ? b + s : b) * 81;
+      d4_t lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k <= i; ++k) acc += Ge[i * 9 + k] * v[k];
-        F[(e * 2 + which) * 81 + i * 9 + c] = acc;
-        rec[(which == 0 ? kSbFlo : kSbFhi) + i * 9 + c] = acc;
+      for (int q = 0; q < 3; ++q) {
+        const int k = 4 * q + lk;
+        const bool ok = k < 9 && li < 9;
+        const double one = ok ? 1.0 : 0.0;
+        const double g = Ge[ok ? li * 9 + k : 0] * one;
+        const double cl = Clo[ok ? k * 9 + li : 0] * one;
+        const double ch = Chi[ok ? li * 9 + k : 0] * (hasHi ? one : 0.0);
+        lo = __builtin_amdgcn_mfma_f64_16x16x4f64(g, cl, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f64_16x16x4f64(g, ch, hi, 0, 0, 0);
       }
-      // (18 threads per block: each also copies its share of G)
-      for (int q = task % 18; q < 81; q += 18) rec[kSbG + q] = Ge[q];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int i = lk + 4 * rg;
+        if (i < 9 && li < 9) {
+          F[(e * 2) * 81 + i * 9 + li] = lo[rg];
+          F[(e * 2 + 1) * 81 + i * 9 + li] = hi[rg];
+          rec[kSbFlo + i * 9 + li] = lo[rg];
+          rec[kSbFhi + i * 9 + li] = hi[rg];
+        }
+      }
     }
-    __syncthreads();
+    ldsBarrier();
+    SBT(2);
     if (last) break;
     // the survivors m = 0 (mod 2 s) collect: D[m] -= F_hi(m - s)^T F_hi(m - s) + F_lo(m + s)^T F_lo(m + s), and their new
-    // lower neighbour is m - 2 s: C[m] = -F_hi(m - s)^T F_lo(m - s)
+    // lower neighbour is m - 2 s: C[m] = -F_hi(m - s)^T F_lo(m - s).  The same tiles: a survivor per wave at a time, D[m] in the
+    // accumulator, nine MFMA.  (Per-thread versions -- an entry, then a row of an output per thread -- were bound by their LDS
+    // reads: 2 and 1.1 per multiply-add, 7 200 and 6 000 cycles a level.)
     const int nR = (n + 2 * s - 1) / (2 * s);
-    for (int task = t; task < nR * 162; task += nT) {
-      const int m = 2 * s * (task / 162), q = task % 162, which = q / 81, i = (q % 81) / 9, j = q % 9;
-      if (which == 0) {
-        double acc = 0.0;
-        if (m >= s) {
-          const double* Fh = F + (((m - s - s) / (2 * s)) * 2 + 1) * 81;
+    for (int e = wave; e < nR; e += nW) {
+      const int m = 2 * s * e;
+      const bool below = m >= 2 * s, above = m + s < n;             // eliminated neighbours m - s and m + s
+      const double* Fh = F + ((below ? (m - 2 * s) / (2 * s) : 0) * 2 + 1) * 81;   // F_hi(m - s); F_lo(m - s) sits right before it
+      const double* Fa = F + ((above ? m / (2 * s) : 0) * 2) * 81;                 // F_lo(m + s)
+      double* Dm = D + m * 81;
+      d4_t accD, accC = {0, 0, 0, 0};
 #pragma unroll
-          for (int k = 0; k < 9; ++k) acc += Fh[k * 9 + i] * Fh[k * 9 + j];
+      for (int rg = 0; rg < 4; ++rg) {
+        const int i = lk + 4 * rg;
+        const bool ok = i < 9 && li < 9;
+        accD[rg] = Dm[ok ? i * 9 + li : 0] * (ok ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int k = 4 * q + lk;
+        const bool ok = k < 9 && li < 9;
+        const int idx = ok ? k * 9 + li : 0;
+        const double fh = Fh[idx] * ((ok && below) ? 1.0 : 0.0);
+        const double fs = (Fh - 81)[idx] * ((ok && below) ? 1.0 : 0.0);
+        const double fa = Fa[idx] * ((ok && above) ? 1.0 : 0.0);
+        accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-fh, fh, accD, 0, 0, 0);
+        accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-fa, fa, accD, 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f64_16x16x4f64(-fh, fs, accC, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int i = lk + 4 * rg;
+        if (i < 9 && li < 9) {
+          Dm[i * 9 + li] = accD[rg];
+          if (below) C[m * 81 + i * 9 + li] = accC[rg];
         }
-        if (m + s < n) {
-          const double* Fl = F + ((m / (2 * s)) * 2 + 0) * 81;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) acc += Fl[k * 9 + i] * Fl[k * 9 + j];
-        }
-        D[m * 81 + i * 9 + j] -= acc;
-      } else if (m >= 2 * s) {
-        const double* Fh = F + (((m - 2 * s) / (2 * s)) * 2 + 1) * 81;
-        const double* Fl = Fh - 81;
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc += Fh[k * 9 + i] * Fl[k * 9 + j];
-        C[m * 81 + i * 9 + j] = -acc;
       }
     }
-    __syncthreads();
+    ldsBarrier();
+    SBT(3);
+#ifdef SVIN_SB_TIMING
+    ++lvl;
+#endif
   }
+#ifdef SVIN_SB_TIMING
+  if (t == 0) printf("[k_sb_factor n %d] load %lld  cholesky (all levels) %lld  inverse %lld  F %lld  survivors %lld\n", n, qT[0], qT[1], qT[4], qT[2], qT[3]);
+#endif
+#undef SBT
 }
 
-constexpr int kSbCols = 8;
+constexpr int kSbCols = 8, kSbLdsRec = 243;   // records in LDS: G | F_lo | F_hi back to back (an odd stride: eight blocks per wave, eight banks apart)
 __global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs a) {
-  extern __shared__ double w[];   // [rowsY][8]
+  extern __shared__ double smem[];
+  double* w = smem;                                   // [rowsY][8]
+  double* R = smem + (size_t)a.rowsY * kSbCols;       // [n][243]: every workgroup sweeps all levels, so the records come to LDS once
   const int t = threadIdx.x, c = t & (kSbCols - 1), q = t / kSbCols, nQ = blockDim.x / kSbCols, n = a.n;
   const int col = blockIdx.x * kSbCols + c;
   const int ld = p.ldS ? p.ldS : p.d;
+  for (int base = 0; base < n * kSbLdsRec; base += 8 * 256) {   // eight loads in flight per thread
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = base + k * 256 + t;
+      const int b = e / kSbLdsRec, r = e % kSbLdsRec;
+      v[k] = (e < n * kSbLdsRec) ? a.Lf[(size_t)b * kSbRec + (r < 81 ? r : (r < 162 ? kSbFlo + r - 81 : kSbFhi + r - 162))] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = base + k * 256 + t;
+      if (e < n * kSbLdsRec) R[e] = v[k];
+    }
+  }
   for (int r = q; r < a.rowsY; r += nQ) {
     double x = 0.0;
     if (r < 9 * n) {
@@ -4674,7 +4765,7 @@ __global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs 
   }
   __syncthreads();
   auto solveBlock = [&](int b) {   // w_b <- G_b w_b
-    const double* Gb = a.Lf + (size_t)b * kSbRec + kSbG;
+    const double* Gb = R + b * kSbLdsRec;
     double v[9], y[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = w[(9 * b + k) * kSbCols + c];
@@ -4698,25 +4789,28 @@ __global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs 
       double acc[9];
 #pragma unroll
       for (int j = 0; j < 9; ++j) acc[j] = 0.0;
-      if (m >= s) {
-        const int b = m - s;
-        const double* Fh = a.Lf + (size_t)b * kSbRec + kSbFhi;
+      // (a missing neighbour reads the other one's record against a zero vector: the same code in every lane)
+      const bool below = m >= s, above = m + s < n;
+      const int bB = below ? m - s : m + s, bA = above ? m + s : m - s;
+      const double wB = below ? 1.0 : 0.0, wA = above ? 1.0 : 0.0;
+      double y[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const double y = w[(9 * b + i) * kSbCols + c];
+      for (int i = 0; i < 9; ++i) y[i] = w[(9 * bB + i) * kSbCols + c] * wB;
+      {
+        const double* Fh = R + bB * kSbLdsRec + 162;
 #pragma unroll
-          for (int j = 0; j < 9; ++j) acc[j] += Fh[i * 9 + j] * y;
-        }
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[j] += Fh[i * 9 + j] * y[i];
       }
-      if (m + s < n) {
-        const int b = m + s;
-        const double* Fl = a.Lf + (size_t)b * kSbRec + kSbFlo;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const double y = w[(9 * b + i) * kSbCols + c];
+      for (int i = 0; i < 9; ++i) y[i] = w[(9 * bA + i) * kSbCols + c] * wA;
+      {
+        const double* Fl = R + bA * kSbLdsRec + 81;
 #pragma unroll
-          for (int j = 0; j < 9; ++j) acc[j] += Fl[i * 9 + j] * y;
-        }
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[j] += Fl[i * 9 + j] * y[i];
       }
 #pragma unroll
       for (int j = 0; j < 9; ++j) w[(9 * m + j) * kSbCols + c] -= acc[j];
@@ -4757,13 +4851,12 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
     const size_t stride = (size_t)4 * a.ldY;
     ya += s0 * stride; yb += s0 * stride;
     int st = s0;
-    for (; st + 4 <= s1; st += 4, ya += 4 * stride, yb += 4 * stride) {   // eight loads in flight per wave
-      const double a0 = ya[0], a1 = ya[stride], a2 = ya[2 * stride], a3 = ya[3 * stride];
-      const double b0 = yb[0], b1 = yb[stride], b2 = yb[2 * stride], b3 = yb[3 * stride];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+    for (; st + 12 <= s1; st += 12, ya += 12 * stride, yb += 12 * stride) {   // 24 loads in flight per wave: the loop is L2 latency, not MFMA
+      double av[12], bv[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { av[k] = ya[k * stride]; bv[k] = yb[k * stride]; }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], bv[k], acc, 0, 0, 0);
     }
     for (; st < s1; ++st, ya += stride, yb += stride) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[0], yb[0], acc, 0, 0, 0);
     if (wave > 0) {
@@ -5445,8 +5538,8 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     if (elim) {
       const size_t ldsFactor = ((size_t)sb.n * 162 + (size_t)((sb.n + 1) / 2) * 243) * 8;
       ensureDynamicLds((const void*)k_sb_factor, ldsFactor);
-      hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(512), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
-      const size_t ldsFwd = (size_t)sb.rowsY * kSbCols * 8;
+      hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(kSbFactorThreads), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
+      const size_t ldsFwd = ((size_t)sb.rowsY * kSbCols + (size_t)sb.n * kSbLdsRec) * 8;
       ensureDynamicLds((const void*)k_sb_forward, ldsFwd);
       hipLaunchKernelGGL(k_sb_forward, dim3(sb.ldY / kSbCols), dim3(256), ldsFwd, s, p, sb);
       const int nT = (sb.dK + 15) / 16;
