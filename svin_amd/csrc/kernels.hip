@@ -4529,6 +4529,9 @@ struct SbElimArgs {
   double* Y;
   double* tvec; // 9 n
   int* counter; // last-workgroup ticket of k_sb_back
+  int compact;  // the kept system goes to Sout / gOut (a single-workgroup solver takes it from there) instead of the blocked solver's matrix
+  int ldOut;    // leading dimension (= rows) of Sout: dK rounded up to 16, zero beyond dK
+  double *Sout, *gOut;
 };
 constexpr int kSbRec = 264, kSbG = 0, kSbFlo = 88, kSbFhi = 176;   // 9x9 row-major each (16-byte aligned starts)
 constexpr int kSbMaxChain = 64;                                    // k_sb_factor keeps the whole chain in LDS
@@ -4584,6 +4587,7 @@ __device__ __forceinline__ void inverseColumn9(const double* Lp, int j, double* 
   for (int i = 0; i < 9; ++i) Gout[i * 9 + j] = X[i];
 }
 
+constexpr int kSbLdsRec = 243;   // records in LDS: G | F_lo | F_hi back to back (an odd stride: eight blocks per wave, eight banks apart)
 constexpr int kSbFactorThreads = 576;   // 9 x 64: a level of 32 eliminations has 576 column tasks and 576 row tasks
 __global__ __launch_bounds__(kSbFactorThreads) void k_sb_factor(DeviceProblem p, SbElimArgs a, double mu, int initScale, int fuseFinalize) {
   extern __shared__ double smem[];
@@ -4733,7 +4737,7 @@ __global__ __launch_bounds__(kSbFactorThreads) void k_sb_factor(DeviceProblem p,
 #undef SBT
 }
 
-constexpr int kSbCols = 8, kSbLdsRec = 243;   // records in LDS: G | F_lo | F_hi back to back (an odd stride: eight blocks per wave, eight banks apart)
+constexpr int kSbCols = 8;   // records in LDS: G | F_lo | F_hi back to back (an odd stride: eight blocks per wave, eight banks apart)
 __global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs a) {
   extern __shared__ double smem[];
   double* w = smem;                                   // [rowsY][8]
@@ -4829,10 +4833,11 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int dK = a.dK, dp = a.dp, nT = (dK + 15) / 16, nTiles = nT * (nT + 1) / 2, nRhs = (dK + 63) / 64;
   const int ld = p.ldS ? p.ldS : p.d;
-  double* M = p.cholL;
+  double* M = a.compact ? a.Sout : p.cholL;
+  const int ldM = a.compact ? a.ldOut : dp;
   for (int i = blockIdx.x * blockDim.x + t; i < nReady; i += gridDim.x * blockDim.x) ready[i] = 0;
-  // everything outside the tiles and the right-hand side row: identity padding, zero scratch rows
-  const size_t total = (size_t)(dp + kNB) * dp;
+  // everything outside the tiles and the right-hand side row: identity padding, zero scratch rows (the compact matrix is all tiles)
+  const size_t total = a.compact ? 0 : (size_t)(dp + kNB) * dp;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + t; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int gi = (int)(idx / dp), gj = (int)(idx - (size_t)gi * dp);
     if (gi < 16 * nT && gj < 16 * nT) continue;
@@ -4870,13 +4875,13 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
         const double yy = ((acc[rg] + red[rg * 64 + lane]) + red[256 + rg * 64 + lane]) + red[512 + rg * 64 + lane];
         const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
         if (I == J && gj > gi) continue;   // the diagonal tiles are mirrored from their lower triangle
-        double x = (gi == gj) ? 1.0 : 0.0;
+        double x = (gi == gj && !a.compact) ? 1.0 : 0.0;   // (the single-workgroup solvers pad with the identity themselves)
         if (gi < dK && gj < dK) {
           x = p.S[(size_t)gi * ld + gj] - yy;
           if (gi == gj && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
         }
-        M[(size_t)gi * dp + gj] = x;
-        M[(size_t)gj * dp + gi] = x;
+        M[(size_t)gi * ldM + gj] = x;
+        M[(size_t)gj * ldM + gi] = x;
       }
     }
   } else if ((int)blockIdx.x < nTiles + nRhs) {
@@ -4887,7 +4892,7 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
       for (int r = wave; r < 9 * a.n; r += 4) s += a.Y[(size_t)r * a.ldY + j] * a.Y[(size_t)r * a.ldY + dK];
     red[wave * 64 + lane] = s;
     __syncthreads();
-    if (wave == 0 && j < dK) M[(size_t)dp * dp + j] = p.gRed[j] - (((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane]);
+    if (wave == 0 && j < dK) (a.compact ? a.gOut : M + (size_t)dp * dp)[j] = p.gRed[j] - (((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane]);
   }
 }
 
@@ -5492,58 +5497,85 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #undef LLT
 }
 
-// whether (and where in p.cholL) the speed / bias chain is eliminated ahead of the blocked solver
-static bool planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
-  if (std::getenv("SVIN_NO_SB_ELIM") != nullptr || p.sbChain < 8 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return false;
-  a.n = p.sbChain; a.dK = p.dC; a.dp = ((p.dC + kNB - 1) / kNB) * kNB;
+// LDS bytes of k_chol_solve_lds for nT tile rows
+static size_t cholLdsBytes(int nT) {
+#ifdef SVIN_CHOL_TIMING
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 240 * 8;
+#else
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4;
+#endif
+}
+static int solverClass(int d) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
+  const int nT = (d + 15) / 16;
+  if (cholLdsBytes(nT) <= 156 * 1024) return 0;
+  if (nT >= 12 && nT <= 17 && std::getenv("SVIN_NO_LL") == nullptr) return 1;
+  return 2;
+}
+// Whether (and where in p.cholL) the speed / bias chain is eliminated ahead of the dense solve: 0 = no, 1 = the kept rows go
+// to the blocked solver's matrix (k_sb_load writes it instead of k_big_load), 2 = the kept system is small enough for one of
+// the single-workgroup solvers: k_sb_load writes it as a compact padded matrix S' + right-hand side g', which that solver
+// takes through a DeviceProblem view.  A system the LDS-resident solver takes whole is left alone (14 us at d = 150: the
+// elimination's four launches cost more), and so is a chain of fewer than 8 blocks ahead of the blocked solver.
+static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
+  if (std::getenv("SVIN_NO_SB_ELIM") != nullptr || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
+  if (solverClass(p.d) == 0) return 0;
+  // Measured (tools/sb_elim_time.py, reduced solve with / without): d = 180 66 / 64 us, 240: 73 / 91, 270: 85 / 113, 360: 99 / 183,
+  // 600: 185 / 313, 960: 289 / 476 -- the four launches cost ~45 us before they gain anything, so short chains stay with the
+  // dense solvers.  (Tried and dropped: eliminating only the last blocks of a chain in ONE fused launch so that a system a few
+  // rows over the LDS-resident solver's limit -- the stereo_rig_v2 sliding window, d = 180 -- drops into it: 39 + 35 + 10 us
+  // against the left-looking solver's 70.)
+  const int mode = solverClass(p.dC) == 2 ? 1 : 2;
+  if (p.sbChain < (mode == 1 ? 8 : 16)) return 0;
+  a.n = p.sbChain; a.dK = p.dC;
+  a.dp = ((a.dK + kNB - 1) / kNB) * kNB;
   a.ldY = ((a.dK + 1 + 15) / 16) * 16;
   a.rowsY = ((9 * a.n + 3) / 4) * 4;
-  const size_t nb = a.dp / kNB;
-  size_t off0 = (size_t)(a.dp + kNB) * a.dp + a.dp + (size_t)a.dp * kNB + ((nb + 3) * nb + 1) / 2 + 2;
-  off0 = (off0 + 1) & ~(size_t)1;
+  a.compact = mode == 2 ? 1 : 0;
+  size_t off0;
+  if (mode == 1) {
+    const size_t nb = a.dp / kNB;
+    off0 = (size_t)(a.dp + kNB) * a.dp + a.dp + (size_t)a.dp * kNB + ((nb + 3) * nb + 1) / 2 + 2;
+    off0 = (off0 + 1) & ~(size_t)1;
+    a.Sout = nullptr; a.gOut = nullptr; a.ldOut = 0;
+  } else {
+    const size_t dpadK = ((size_t)a.dK + 15) / 16 * 16;
+    a.ldOut = (int)dpadK;
+    a.Sout = p.cholL + dpadK * dpadK;      // behind the kept solver's own spill / write-through area
+    a.gOut = a.Sout + dpadK * dpadK;
+    off0 = 2 * dpadK * dpadK + dpadK;
+  }
   a.Lf = p.cholL + off0;
   a.Y = a.Lf + (size_t)a.n * kSbRec;
   a.tvec = a.Y + (size_t)a.rowsY * a.ldY;
   a.counter = reinterpret_cast<int*>(a.tvec + a.rowsY);
-  return off0 + (size_t)a.n * kSbRec + (size_t)a.rowsY * a.ldY + a.rowsY + 2 <= solveReducedScratchDoubles(p.d);
+  return off0 + (size_t)a.n * kSbRec + (size_t)a.rowsY * a.ldY + a.rowsY + 2 <= solveReducedScratchDoubles(p.d, true) ? mode : 0;
 }
-void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
+// the dense solve of p's system (or, with `sb`, of the kept rows the chain elimination left in the blocked solver's matrix)
+static void launchSolveDense(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize, const SbElimArgs* sb) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
-#ifdef SVIN_CHOL_TIMING
-  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 3 * dpad) * 8 + kCholFlagInts * 4 + 240 * 8;
-#else
-  const size_t ldsBytes = ((size_t)nT * (nT + 1) / 2 * kTile + 3 * dpad) * 8 + kCholFlagInts * 4;
-#endif
-  if (ldsBytes <= 156 * 1024) {
+  const int cls = solverClass(p.d);
+  if (cls == 0) {
+    const size_t ldsBytes = cholLdsBytes(nT);
     ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
     hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
                        fuseFinalize ? 1 : 0);
-  } else if (nT >= 12 && nT <= 17 && std::getenv("SVIN_NO_LL") == nullptr) {
+  } else if (cls == 1) {
     // one workgroup, left-looking: at most 72 live tiles in LDS, finished tiles written through to p.cholL
     const size_t ldsLL = llLdsDoubles(nT) * 8;
     ensureDynamicLds((const void*)k_chol_solve_ll, ldsLL);
     hipLaunchKernelGGL(k_chol_solve_ll, dim3(1), dim3(kLLThreads), ldsLL, s, p, dpad, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
   } else {
     // multi-workgroup blocked factorisation, 64-wide panels; p.cholL holds (dpad64 + 64) x dpad64 doubles, its tail
-    // the 1/L_ii vector.  With a speed / bias chain (p.sbChain blocks behind the dC kept rows) the chain is eliminated first and
-    // the blocked solver only sees the kept rows.
-    SbElimArgs sb;
-    const bool elim = planSbElimination(p, sb);
-    const int dp = elim ? sb.dp : ((p.d + kNB - 1) / kNB) * kNB;
+    // the 1/L_ii vector.  Behind a chain elimination the matrix is already there (k_sb_load) and only spans the kept rows.
+    const int dp = sb ? sb->dp : ((p.d + kNB - 1) / kNB) * kNB;
     double* dinvG = p.cholL + (size_t)(dp + kNB) * dp;
     double* diagF = dinvG + dp;   // per panel the factorised 64x64 diagonal block (dp x 64)
     const int nb = dp / kNB;
     int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 3) x nb block flags
-    if (elim) {
-      const size_t ldsFactor = ((size_t)sb.n * 162 + (size_t)((sb.n + 1) / 2) * 243) * 8;
-      ensureDynamicLds((const void*)k_sb_factor, ldsFactor);
-      hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(kSbFactorThreads), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
-      const size_t ldsFwd = ((size_t)sb.rowsY * kSbCols + (size_t)sb.n * kSbLdsRec) * 8;
-      ensureDynamicLds((const void*)k_sb_forward, ldsFwd);
-      hipLaunchKernelGGL(k_sb_forward, dim3(sb.ldY / kSbCols), dim3(256), ldsFwd, s, p, sb);
-      const int nT = (sb.dK + 15) / 16;
-      hipLaunchKernelGGL(k_sb_load, dim3(nT * (nT + 1) / 2 + (sb.dK + 63) / 64), dim3(256), 0, s, p, sb, mu, initScale ? 1 : 0,
+    if (sb) {
+      const int nTk = (sb->dK + 15) / 16;
+      hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb->dK + 63) / 64), dim3(256), 0, s, p, *sb, mu, initScale ? 1 : 0,
                          fuseFinalize ? 1 : 0, ready, (nb + 3) * nb);
     } else {
       hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
@@ -5567,12 +5599,31 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
       hipLaunchKernelGGL(k_big_back, dim3(1), dim3(512), ldsBack, s, p, dp, c0, c1, nChunks, (const double*)dinvG,
                          (const double*)diagF);
     }
-    if (elim) {
-      const size_t ldsBackSb = ((size_t)sb.n * kSbRec + 18 * (size_t)sb.n) * 8;
-      ensureDynamicLds((const void*)k_sb_back, ldsBackSb);
-      hipLaunchKernelGGL(k_sb_back, dim3((9 * sb.n + 15) / 16), dim3(256), ldsBackSb, s, p, sb);
-    }
   }
+}
+void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
+  SbElimArgs sb;
+  const int elim = planSbElimination(p, sb);
+  if (!elim) { launchSolveDense(p, s, mu, initScale, fuseFinalize, nullptr); return; }
+  const size_t ldsFactor = ((size_t)sb.n * 162 + (size_t)((sb.n + 1) / 2) * 243) * 8;
+  ensureDynamicLds((const void*)k_sb_factor, ldsFactor);
+  hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(kSbFactorThreads), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
+  const size_t ldsFwd = ((size_t)sb.rowsY * kSbCols + (size_t)sb.n * kSbLdsRec) * 8;
+  ensureDynamicLds((const void*)k_sb_forward, ldsFwd);
+  hipLaunchKernelGGL(k_sb_forward, dim3(sb.ldY / kSbCols), dim3(256), ldsFwd, s, p, sb);
+  if (elim == 1) {
+    launchSolveDense(p, s, mu, initScale, fuseFinalize, &sb);
+  } else {
+    const int nTk = (sb.dK + 15) / 16;
+    hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb.dK + 63) / 64), dim3(256), 0, s, p, sb, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, (int*)nullptr, 0);
+    DeviceProblem q = p;   // the kept system as a problem of its own: rows 0 .. dK of every vector are the kept rows
+    q.d = sb.dK; q.S = sb.Sout; q.ldS = sb.ldOut; q.sPadded = 1; q.gRed = sb.gOut; q.sbChain = 0;
+    launchSolveDense(q, s, 0.0, false, false, nullptr);   // (metric and damping are in S' already)
+  }
+  const size_t ldsBackSb = ((size_t)sb.n * kSbRec + 18 * (size_t)sb.n) * 8;
+  ensureDynamicLds((const void*)k_sb_back, ldsBackSb);
+  hipLaunchKernelGGL(k_sb_back, dim3((9 * sb.n + 15) / 16), dim3(256), ldsBackSb, s, p, sb);
 }
 
 // ================================================================ post-solve pass and dogleg step

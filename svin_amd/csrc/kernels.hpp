@@ -199,10 +199,13 @@ void launchFinalizeNormalEquations(const DeviceProblem& p, double mu, bool initS
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, bool initScale = false, bool fuseFinalize = false);
 // doubles DeviceProblem::cholL must hold for a reduced system of d unknowns: the LDS-resident solver's spill copy, or
 // the blocked solver's (d64 + 64) x d64 matrix + 1/L_ii + factorised diagonal blocks + block-ready flags
-inline size_t solveReducedScratchDoubles(int d) {
+// (withChain: room for the speed / bias chain elimination next to either solver -- the compact kept system, the chain's records,
+// Y and t; a window's buffer is sized with it, the pose graph's root solve has no chain)
+inline size_t solveReducedScratchDoubles(int d, bool withChain = false) {
   const size_t dpad = ((size_t)d + 15) / 16 * 16, d64 = ((size_t)d + 63) / 64 * 64, nb = d64 / 64;
   const size_t big = (d64 + 64) * d64 + d64 + d64 * 64 + ((nb + 3) * nb + 1) / 2 + 2;
-  return dpad * dpad > big ? dpad * dpad : big;
+  const size_t chain = withChain ? 2 * dpad * dpad + (dpad + 8) * (dpad + 32) + 64 * 264 + 64 : 0;
+  return (dpad * dpad > big ? dpad * dpad : big) + chain;
 }
 // post-solve pass (back-substitution, J*v / J*y sums, norms); fuseRadius > 0: its last block also takes the dogleg
 // step with that radius and retracts (single GPU, narrow windows) -- launchDoglegStep is then not needed

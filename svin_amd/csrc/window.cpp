@@ -1580,7 +1580,7 @@ void Window::pack(bool solveFollows) {
   dLmVec_.reserve((size_t)(6 + 3 * 7 + 9) * std::max(L, 1));
   {
     const size_t dp64 = ((size_t)d + 63) / 64 * 64;  // multi-workgroup solver: (dp64 + 64) x dp64 matrix + 1/L_ii + diagonal factors
-    dChol_.reserve(std::max<size_t>(solveReducedScratchDoubles(d), 1));
+    dChol_.reserve(std::max<size_t>(solveReducedScratchDoubles(d, true), 1));
   }
   dPartial_.reserve((size_t)16 * 4096);
   dScal_.reserve(1);
@@ -2278,7 +2278,7 @@ int Window::debugReducedSolve(double mu, double* y, int capD) {
 // records and Y: layout in kernels.hip, launchSolveReduced) after the last solve
 int Window::debugPeekSolverScratch(uint64_t off, uint64_t count, double* out) {
   quiesce();
-  if (!prob_.cholL || off + count > solveReducedScratchDoubles(prob_.d)) return 0;
+  if (!prob_.cholL || off + count > solveReducedScratchDoubles(prob_.d, true)) return 0;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipMemcpy(out, prob_.cholL + off, sizeof(double) * count, hipMemcpyDeviceToHost));
   return 1;

@@ -1,6 +1,7 @@
 """The reduced-system solve on its own: (S + mu D) y = g as each device path computes it -- LDS-resident (d <= 176), left-looking
-(d <= 272), blocked over many workgroups, and blocked behind the speed / bias chain elimination (kernels.hip, k_sb_factor /
-k_sb_forward / k_sb_load / k_sb_back: cyclic reduction over the 9x9 blocks the IMU factors chain together) -- against a host
+(d <= 272), blocked over many workgroups, and each of the three behind the speed / bias chain elimination (kernels.hip,
+k_sb_factor / k_sb_forward / k_sb_load / k_sb_back: cyclic reduction over the 9x9 blocks the IMU factors chain together; the
+kept rows then go to whichever dense solver their number selects) -- against a host
 solve (numpy, LAPACK) of the very system svin_ba_linearize returns.  FP64 on systems whose entries span ~1e2 (landmark
 information) to ~1e10 (IMU information): 1e-10 relative to |y| with mu = 1e-4; with mu = 1e-9 the conditioning of the system
 itself separates two correct solvers by ~1e-8 (LAPACK against the device paths that were there before the elimination), so
@@ -29,13 +30,17 @@ def window(P, L, n_obs, rig="euroc", seed=11):
 
 
 @pytest.mark.parametrize("P,L,n_obs,rig,path", [
-    (10, 400, 4000, "euroc", "LDS-resident, d = 150"),
-    (16, 600, 6000, "euroc", "left-looking, d = 240"),
-    (24, 800, 8000, "euroc", "blocked + chain of 24, dK = 144 (padded to 192)"),
-    (29, 800, 8000, "euroc", "blocked + chain of 29 (not a power of two)"),
-    (48, 1500, 15000, "euroc", "blocked + chain of 48, dK = 288 (padded to 320)"),
-    (64, 2500, 25000, "euroc", "blocked + chain of 64, dK = 384"),
-    (64, 2500, 25000, "test4", "per-frame extrinsics: dK = 1152, chain of 64"),
+    (10, 400, 4000, "euroc", "LDS-resident whole, d = 150 (no elimination)"),
+    (12, 500, 5000, "euroc", "d = 180: left-looking whole (a chain of 12 is too short to pay for its four launches)"),
+    (8, 500, 5000, "rig_v2", "stereo_rig_v2, d = 204: left-looking whole"),
+    (16, 600, 6000, "euroc", "d = 240: chain of 16, kept 96 rows LDS-resident (was left-looking)"),
+    (18, 700, 7000, "euroc", "d = 270: chain of 18, kept 108 rows LDS-resident (was left-looking)"),
+    (24, 800, 8000, "euroc", "d = 360: chain of 24, kept 144 rows LDS-resident (was blocked)"),
+    (29, 800, 8000, "euroc", "d = 435: chain of 29 (not a power of two), kept 174 rows LDS-resident (was blocked)"),
+    (40, 1200, 12000, "euroc", "d = 600: chain of 40, kept 240 rows left-looking (was blocked)"),
+    (48, 1500, 15000, "euroc", "d = 720: chain of 48, kept 288 rows blocked (padded to 320)"),
+    (64, 2500, 25000, "euroc", "d = 960: chain of 64, kept 384 rows blocked"),
+    (64, 2500, 25000, "test4", "per-frame extrinsics, d = 1728: chain of 64, kept 1152 rows blocked"),
 ])
 def test_device_solve_equals_host_solve(gpu_lib, monkeypatch, P, L, n_obs, rig, path):
     est = window(P, L, n_obs, rig)

@@ -12,7 +12,8 @@ from svin_amd.estimator import Estimator        # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 mu = 1e-4
-spec = syn.make_window(P=P, L=800, n_obs=8000, seed=11, frame_dt=0.25)
+rig = sys.argv[2] if len(sys.argv) > 2 else "euroc"
+spec = syn.make_window(P=P, L=800, n_obs=8000, seed=11, rig=rig, frame_dt=0.25)
 est = Estimator(0)
 syn.feed(est, spec)
 lin = est.linearize(mu)
@@ -26,12 +27,25 @@ y_ref = np.linalg.solve(H, g)
 print("d", d, "dK", dK, "n", n, "device vs host", np.abs(y_dev - y_ref).max() / np.abs(y_ref).max())
 
 # scratch layout (planSbElimination)
+def solver_class(dd):
+    nT = (dd + 15) // 16
+    if (nT * (nT + 1) // 2 * 16 * 17 + 3 * 16 * nT) * 8 + 48 * 4 <= 156 * 1024:
+        return 0
+    return 1 if 12 <= nT <= 17 else 2
+
+
 dp = (dK + 63) // 64 * 64
 nb = dp // 64
 ldY = (dK + 1 + 15) // 16 * 16
 rowsY = (9 * n + 3) // 4 * 4
-off0 = (dp + 64) * dp + dp + dp * 64 + ((nb + 3) * nb + 1) // 2 + 2
-off0 = (off0 + 1) & ~1
+compact = solver_class(dK) < 2
+if compact:
+    dpadK = (dK + 15) // 16 * 16
+    off0 = 2 * dpadK * dpadK + dpadK
+else:
+    off0 = (dp + 64) * dp + dp + dp * 64 + ((nb + 3) * nb + 1) // 2 + 2
+    off0 = (off0 + 1) & ~1
+print("kept system: class", solver_class(dK), "(compact)" if compact else "(blocked)")
 REC = 264
 Lf = est.debug_peek_solver_scratch(off0, n * REC).reshape(n, REC)
 Y = est.debug_peek_solver_scratch(off0 + n * REC, rowsY * ldY).reshape(rowsY, ldY)
@@ -95,11 +109,13 @@ w[blk(0)] = G[0] @ w[blk(0)]
 eY = np.abs(Y[:9 * n, :dK + 1] - w)
 print("Y: max abs diff %.3e of %.3e; worst row %d col %d; pad rows zero: %s; nan count %d" %
       (np.nanmax(eY), np.abs(w).max(), *np.unravel_index(np.nanargmax(eY), eY.shape), bool(np.all(Y[9 * n:] == 0)), int(np.isnan(Y).sum())))
-M = est.debug_peek_solver_scratch(0, (dp + 64) * dp).reshape(dp + 64, dp)
 Mref = H[:dK, :dK] - w[:, :dK].T @ w[:, :dK]
-# the blocked factorisation has overwritten the lower blocks; the strictly upper 64-blocks keep what k_sb_load wrote
-iu = np.triu_indices(dK, 64)
-print("reduced matrix (untouched upper part): max rel diff %.3e" % (np.abs(M[:dK, :dK][iu] - Mref[iu]).max() / np.abs(Mref).max()))
+if compact:
+    M = est.debug_peek_solver_scratch(dpadK * dpadK, dpadK * dpadK).reshape(dpadK, dpadK)
+    print("compact kept matrix: max rel diff %.3e; zero beyond dK: %s" % (np.abs(M[:dK, :dK] - Mref).max() / np.abs(Mref).max(),
+          bool(np.all(M[dK:] == 0) and np.all(M[:, dK:] == 0))))
+    gk_dev = est.debug_peek_solver_scratch(2 * dpadK * dpadK, dK)
+    print("compact right-hand side: %.3e" % (np.abs(gk_dev - (g[:dK] - w[:, :dK].T @ w[:, dK])).max() / np.abs(g[:dK]).max()))
 gk = g[:dK] - w[:, :dK].T @ w[:, dK]
 xk = np.linalg.solve(Mref, gk)
 print("kept part of the solution: device vs replay %.3e" % (np.abs(y_dev[:dK] - xk).max() / np.abs(xk).max()))
