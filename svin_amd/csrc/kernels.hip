@@ -4745,27 +4745,39 @@ __global__ __launch_bounds__(256) void k_sb_forward(DeviceProblem p, SbElimArgs 
   const int t = threadIdx.x, c = t & (kSbCols - 1), q = t / kSbCols, nQ = blockDim.x / kSbCols, n = a.n;
   const int col = blockIdx.x * kSbCols + c;
   const int ld = p.ldS ? p.ldS : p.d;
-  for (int base = 0; base < n * kSbLdsRec; base += 8 * 256) {   // eight loads in flight per thread
-    double v[8];
+  for (int base = 0; base < n * kSbLdsRec; base += 16 * 256) {   // sixteen loads in flight per thread
+    double v[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       const int e = base + k * 256 + t;
       const int b = e / kSbLdsRec, r = e % kSbLdsRec;
       v[k] = (e < n * kSbLdsRec) ? a.Lf[(size_t)b * kSbRec + (r < 81 ? r : (r < 162 ? kSbFlo + r - 81 : kSbFhi + r - 162))] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       const int e = base + k * 256 + t;
       if (e < n * kSbLdsRec) R[e] = v[k];
     }
   }
-  for (int r = q; r < a.rowsY; r += nQ) {
-    double x = 0.0;
-    if (r < 9 * n) {
-      const int gi = a.dK + r;
-      x = (col < a.dK) ? p.S[(size_t)gi * ld + col] : ((col == a.dK) ? p.gRed[gi] : 0.0);
+  {
+    // this workgroup's columns of [S_sk | g_s]: six rows in flight per thread (a load and an LDS store per trip pays the L2
+    // latency rowsY / 32 = 18 times in a row)
+    const double* src = (col < a.dK) ? p.S + (size_t)a.dK * ld + col : p.gRed + a.dK;
+    const size_t stride = (col < a.dK) ? (size_t)ld : 1;
+    const double keep = (col <= a.dK) ? 1.0 : 0.0;
+    for (int r0 = q; r0 < a.rowsY; r0 += 6 * nQ) {
+      double v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int r = r0 + k * nQ;
+        v[k] = src[(size_t)min(r, 9 * n - 1) * stride];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int r = r0 + k * nQ;
+        if (r < a.rowsY) w[r * kSbCols + c] = (r < 9 * n) ? v[k] * keep : 0.0;
+      }
     }
-    w[r * kSbCols + c] = x;
   }
   __syncthreads();
   auto solveBlock = [&](int b) {   // w_b <- G_b w_b
@@ -4831,7 +4843,7 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
                                                  int nReady) {
   __shared__ double red[3 * 256];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int dK = a.dK, dp = a.dp, nT = (dK + 15) / 16, nTiles = nT * (nT + 1) / 2, nRhs = (dK + 63) / 64;
+  const int dK = a.dK, dp = a.dp, nT = (dK + 15) / 16, nTiles = nT * (nT + 1) / 2, nRhs = (dK + 15) / 16;
   const int ld = p.ldS ? p.ldS : p.d;
   double* M = a.compact ? a.Sout : p.cholL;
   const int ldM = a.compact ? a.ldOut : dp;
@@ -4850,6 +4862,16 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
     while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
     const int J = blockIdx.x - I * (I + 1) / 2;
     d4_t acc = {0, 0, 0, 0};
+    // wave 0 finishes the tile: its S entries and the metric of its diagonal entries are requested before the products
+    double sPre[4] = {0, 0, 0, 0}, dampPre[4] = {0, 0, 0, 0};
+    if (wave == 0) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
+        sPre[rg] = p.S[(size_t)min(max(gi, gj), dK - 1) * ld + min(min(gi, gj), dK - 1)];
+        if (gi == gj && gi < dK && fuseFinalize) dampPre[rg] = finalizeRow(p, gi, mu, initScale);
+      }
+    }
     const int steps = a.rowsY / 4, s0 = steps * wave / 4, s1 = steps * (wave + 1) / 4;
     const double* ya = a.Y + (size_t)(lane >> 4) * a.ldY + 16 * I + (lane & 15);
     const double* yb = a.Y + (size_t)(lane >> 4) * a.ldY + 16 * J + (lane & 15);
@@ -4876,23 +4898,30 @@ __global__ __launch_bounds__(256) void k_sb_load(DeviceProblem p, SbElimArgs a, 
         const int gi = 16 * I + (lane >> 4) + 4 * rg, gj = 16 * J + (lane & 15);
         if (I == J && gj > gi) continue;   // the diagonal tiles are mirrored from their lower triangle
         double x = (gi == gj && !a.compact) ? 1.0 : 0.0;   // (the single-workgroup solvers pad with the identity themselves)
-        if (gi < dK && gj < dK) {
-          x = p.S[(size_t)gi * ld + gj] - yy;
-          if (gi == gj && fuseFinalize) x += finalizeRow(p, gi, mu, initScale);
-        }
+        if (gi < dK && gj < dK) x = sPre[rg] - yy + dampPre[rg];
         M[(size_t)gi * ldM + gj] = x;
         M[(size_t)gj * ldM + gi] = x;
       }
     }
   } else if ((int)blockIdx.x < nTiles + nRhs) {
-    // g_k' = g_k - Y_k^T y_g: 64 columns per workgroup, the rows split over its 4 waves
-    const int j = (blockIdx.x - nTiles) * 64 + lane;
-    double s = 0.0;
-    if (j < dK)
-      for (int r = wave; r < 9 * a.n; r += 4) s += a.Y[(size_t)r * a.ldY + j] * a.Y[(size_t)r * a.ldY + dK];
-    red[wave * 64 + lane] = s;
+    // g_k' = g_k - Y_k^T y_g: 16 columns per workgroup, 16 row groups of 9 n / 16 rows, six rows in flight
+    const int cl = t & 15, rr = t >> 4, j = (blockIdx.x - nTiles) * 16 + cl, jc = min(j, dK - 1), rows = 9 * a.n;
+    double sum = 0.0;
+    for (int r0 = rr; r0 < rows; r0 += 6 * 16) {
+      double yv[6], gv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const int r = min(r0 + 16 * k, rows - 1); yv[k] = a.Y[(size_t)r * a.ldY + jc]; gv[k] = a.Y[(size_t)r * a.ldY + dK]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sum += (r0 + 16 * k < rows) ? yv[k] * gv[k] : 0.0;
+    }
+    red[t] = sum;
     __syncthreads();
-    if (wave == 0 && j < dK) (a.compact ? a.gOut : M + (size_t)dp * dp)[j] = p.gRed[j] - (((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane]);
+    if (t < 16 && j < dK) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += red[k * 16 + t];
+      (a.compact ? a.gOut : M + (size_t)dp * dp)[j] = p.gRed[j] - tot;
+    }
   }
 }
 
@@ -4903,8 +4932,16 @@ __global__ __launch_bounds__(256) void k_sb_back(DeviceProblem p, SbElimArgs a) 
   {
     const int r = blockIdx.x * 16 + (t >> 4), cl = t & 15;
     double s = 0.0;
-    if (r < 9 * n)
-      for (int j = cl; j < a.dK; j += 16) s += a.Y[(size_t)r * a.ldY + j] * p.yC[j];
+    if (r < 9 * n) {
+      const double* yr = a.Y + (size_t)r * a.ldY;
+      for (int j0 = cl; j0 < a.dK; j0 += 8 * 16) {
+        double yv[8], xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int j = min(j0 + 16 * k, a.dK - 1); yv[k] = yr[j]; xv[k] = p.yC[j]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (j0 + 16 * k < a.dK) ? yv[k] * xv[k] : 0.0;
+      }
+    }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 16);
     if (cl == 0 && r < 9 * n) __hip_atomic_store(a.tvec + r, a.Y[(size_t)r * a.ldY + a.dK] - s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -4921,7 +4958,15 @@ __global__ __launch_bounds__(256) void k_sb_back(DeviceProblem p, SbElimArgs a) 
   {
     const double2* src = reinterpret_cast<const double2*>(a.Lf);
     double2* dst = reinterpret_cast<double2*>(rec);
-    for (int e = t; e < n * kSbRec / 2; e += blockDim.x) dst[e] = src[e];
+    const int total = n * kSbRec / 2;
+    for (int base = t; base < total; base += 12 * 256) {   // twelve 16-byte loads in flight per thread
+      double2 v[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = src[min(base + k * 256, total - 1)];
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        if (base + k * 256 < total) dst[base + k * 256] = v[k];
+    }
   }
   for (int r = t; r < 9 * n; r += blockDim.x) x[r] = __hip_atomic_load(a.tvec + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
@@ -5575,7 +5620,7 @@ static void launchSolveDense(const DeviceProblem& p, hipStream_t s, double mu, b
     int* ready = reinterpret_cast<int*>(diagF + (size_t)dp * kNB);   // (nb + 3) x nb block flags
     if (sb) {
       const int nTk = (sb->dK + 15) / 16;
-      hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb->dK + 63) / 64), dim3(256), 0, s, p, *sb, mu, initScale ? 1 : 0,
+      hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb->dK + 15) / 16), dim3(256), 0, s, p, *sb, mu, initScale ? 1 : 0,
                          fuseFinalize ? 1 : 0, ready, (nb + 3) * nb);
     } else {
       hipLaunchKernelGGL(k_big_load, dim3(256), dim3(256), 0, s, p, dp, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0, ready,
@@ -5615,7 +5660,7 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
     launchSolveDense(p, s, mu, initScale, fuseFinalize, &sb);
   } else {
     const int nTk = (sb.dK + 15) / 16;
-    hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb.dK + 63) / 64), dim3(256), 0, s, p, sb, mu, initScale ? 1 : 0,
+    hipLaunchKernelGGL(k_sb_load, dim3(nTk * (nTk + 1) / 2 + (sb.dK + 15) / 16), dim3(256), 0, s, p, sb, mu, initScale ? 1 : 0,
                        fuseFinalize ? 1 : 0, (int*)nullptr, 0);
     DeviceProblem q = p;   // the kept system as a problem of its own: rows 0 .. dK of every vector are the kept rows
     q.d = sb.dK; q.S = sb.Sout; q.ldS = sb.ldOut; q.sPadded = 1; q.gRed = sb.gOut; q.sbChain = 0;
