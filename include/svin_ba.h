@@ -134,6 +134,12 @@ int svin_ba_remove_homogeneous_point_error(svin_ba* h, uint64_t residual_id);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 int svin_ba_optimize(svin_ba* h, uint64_t num_iter, uint64_t num_threads_ignored, int verbose); /* :876-929 */
+/* Blocks until everything the handle has enqueued has run -- the device part of the last
+ * svin_ba_apply_marginalization_strategy in particular, which that call only enqueues (okvis runs the whole of
+ * applyMarginalizationStrategy inside the call, src/Estimator.cpp:472-813; here the ~1 ms of device work overlap whatever the
+ * caller does until its next call on the handle, and every call waits for what it needs by itself).  Never required for
+ * correctness: a caller that wants to TIME a later call on its own uses it.  Returns 1. */
+int svin_ba_wait_idle(svin_ba* h);
 int svin_ba_set_optimization_time_limit(svin_ba* h, double time_limit, int min_iterations);    /* :932-951 */
 /* Estimator::applyMarginalizationStrategy :495-814; removed landmark ids are written to
  * removed_ids (capacity cap), *n_removed receives the full count. */

@@ -500,6 +500,11 @@ int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* ids
   GUARD_BEGIN return h->w.linearize(mu, S, g, ids, off, nb, cap_d, cost);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_wait_idle(svin_ba* h) {
+  if (!h) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN h->w.waitIdle(); return 1;
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d) {
   if (!h || !y) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d);

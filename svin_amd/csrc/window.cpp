@@ -153,6 +153,7 @@ Window::~Window() {
   if (resStatus_) (void)hipHostFree(resStatus_);
   if (statesHost_) (void)hipHostFree(statesHost_);
   if (lmSyncHost_) (void)hipHostFree(lmSyncHost_);
+  if (imuPropHost_) (void)hipHostFree(imuPropHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
   if (evUploaded_) (void)hipEventDestroy(evUploaded_);
   if (evImuReady_) (void)hipEventDestroy(evImuReady_);
@@ -298,34 +299,46 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
 // ------------------------------------------------------------------------------------------ IMU prediction
 int Window::imuPropagation(const uint32_t* imuT, const double* imuM, int n, const ImuParams& par, double* T, double* sb,
                            TimeStamp t0, TimeStamp t1, double* cov, double* jac, double* integrals) {
-  quiesce();
+  quiesce();   // (the enqueue thread has handed its launches over; the device may still be running them)
   if (n <= 0) return -1;
+  // One pinned block and its device twin, kept across calls (addStates calls this once per frame: five allocations, four small
+  // copies in and four out cost ~0.1 ms), on the SIDE stream: nothing here depends on what the main stream still holds -- the
+  // marginalisation job of the previous frame above all, which a synchronisation of the main stream would wait for.
+  //   in : DevImu | io (T 7, sb 9, integrals 7, pad 1) | T (2 n uint32) | M (6 n doubles)
+  //   out: io | jac 225 | cov 225 | used
+  constexpr size_t kIo = 24, kOut = kIo + 450 + 2;
+  const size_t offIm = 0, offIo = (sizeof(DevImu) + 15) / 16 * 16, offT = offIo + kOut * 8,
+               offM = offT + ((size_t)2 * n * sizeof(uint32_t) + 15) / 16 * 16, total = offM + (size_t)6 * n * 8;
+  if (total > imuPropCap_) {
+    if (imuPropHost_) (void)hipHostFree(imuPropHost_);
+    imuPropCap_ = total * 2;
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&imuPropHost_), imuPropCap_, hipHostMallocDefault));
+    imuPropDev_.reserve(imuPropCap_);
+  }
   DevImu im;
   std::memset(&im, 0, sizeof(im));
   im.sampleStart = 0; im.sampleCount = n;
   im.t0[0] = t0.sec; im.t0[1] = t0.nsec; im.t1[0] = t1.sec; im.t1[1] = t1.nsec;
   im.par = par;
-  DevBuf<DevImu> dIm; dIm.reserve(1);
-  DevBuf<uint32_t> dT; dT.reserve(2 * (size_t)n);
-  DevBuf<double> dM; dM.reserve(6 * (size_t)n);
-  constexpr int kIo = 24;   // T(7) sb(9) | acc_doubleintegral(3) acc_integral(3) Delta_t | pad
-  DevBuf<double> dIo; dIo.reserve(kIo + 450);
-  DevBuf<int> dUsed; dUsed.reserve(1);
-  double io[kIo] = {0};
+  std::memcpy(imuPropHost_ + offIm, &im, sizeof(im));
+  double* io = reinterpret_cast<double*>(imuPropHost_ + offIo);
+  std::memset(io, 0, kOut * 8);
   std::memcpy(io, T, 7 * sizeof(double));
   std::memcpy(io + 7, sb, 9 * sizeof(double));
-  HIP_OK(hipMemcpyAsync(dIm.p, &im, sizeof(im), hipMemcpyHostToDevice, stream_));
-  HIP_OK(hipMemcpyAsync(dT.p, imuT, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice, stream_));
-  HIP_OK(hipMemcpyAsync(dM.p, imuM, sizeof(double) * 6 * n, hipMemcpyHostToDevice, stream_));
-  HIP_OK(hipMemcpyAsync(dIo.p, io, sizeof(io), hipMemcpyHostToDevice, stream_));
-  launchImuPropagation(dIm.p, dT.p, dM.p, dIo.p, jac ? dIo.p + kIo : nullptr, cov ? dIo.p + kIo + 225 : nullptr, dUsed.p,
-                       stream_);
-  int used = -1;
-  HIP_OK(hipMemcpyAsync(io, dIo.p, sizeof(io), hipMemcpyDeviceToHost, stream_));
-  HIP_OK(hipMemcpyAsync(&used, dUsed.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  if (jac) HIP_OK(hipMemcpyAsync(jac, dIo.p + kIo, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  if (cov) HIP_OK(hipMemcpyAsync(cov, dIo.p + kIo + 225, 225 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  HIP_OK(hipStreamSynchronize(stream_));
+  std::memcpy(imuPropHost_ + offT, imuT, sizeof(uint32_t) * 2 * n);
+  std::memcpy(imuPropHost_ + offM, imuM, sizeof(double) * 6 * n);
+  unsigned char* dev = imuPropDev_.p;
+  double* dIo = reinterpret_cast<double*>(dev + offIo);
+  int* dUsed = reinterpret_cast<int*>(dIo + kIo + 450);
+  HIP_OK(hipMemcpyAsync(dev, imuPropHost_, total, hipMemcpyHostToDevice, stream2_));
+  launchImuPropagation(reinterpret_cast<const DevImu*>(dev + offIm), reinterpret_cast<const uint32_t*>(dev + offT),
+                       reinterpret_cast<const double*>(dev + offM), dIo, jac ? dIo + kIo : nullptr, cov ? dIo + kIo + 225 : nullptr, dUsed,
+                       stream2_);
+  HIP_OK(hipMemcpyAsync(io, dIo, kOut * 8, hipMemcpyDeviceToHost, stream2_));
+  HIP_OK(hipStreamSynchronize(stream2_));
+  const int used = *reinterpret_cast<const int*>(io + kIo + 450);
+  if (jac) std::memcpy(jac, io + kIo, 225 * sizeof(double));
+  if (cov) std::memcpy(cov, io + kIo + 225, 225 * sizeof(double));
   if (used >= 0) {
     std::memcpy(T, io, 7 * sizeof(double));
     std::memcpy(sb, io + 7, 9 * sizeof(double));
@@ -1087,6 +1100,13 @@ void Window::quiesce() const {
     enqueueError_ = nullptr;
     std::rethrow_exception(e);
   }
+}
+
+// everything the handle has enqueued -- the marginalisation job of the last applyMarginalizationStrategy above all -- has run
+void Window::waitIdle() {
+  quiesce();
+  HIP_OK(hipStreamSynchronize(stream_));
+  HIP_OK(hipStreamSynchronize(stream2_));
 }
 
 // ------------------------------------------------------------------------------------------ device-resident window

@@ -307,6 +307,7 @@ class Window {
                   int cap);
   int linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks, int capD,
                 double* cost);
+  void waitIdle();
   int debugReducedSolve(double mu, double* y, int capD);
   int debugPeekSolverScratch(uint64_t off, uint64_t count, double* out);
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
@@ -422,6 +423,9 @@ class Window {
   unsigned long long statesSeq_ = 0;
   DevBuf<int> finishTicket_;
   mutable double* lmSyncHost_ = nullptr;   // pinned read-back area of syncLandmarks
+  unsigned char* imuPropHost_ = nullptr;   // imuPropagation: pinned in / out block and its device twin
+  DevBuf<unsigned char> imuPropDev_;
+  size_t imuPropCap_ = 0;
   mutable size_t lmSyncCap_ = 0;
   // The launches of an asynchronous device job (the marginalisation's M1-M3: a DMA, the scatter and 6-13 kernels) are issued by
   // a thread of the handle's own while the call that assembled the job returns; quiesce() -- at the top of everything that

@@ -417,8 +417,10 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
         imu_t_k, imu_m_k = spec.imu_t[sel], spec.imu_meas[sel]
         son = [spec.sonar[k]] if spec.sonar and spec.sonar[k] is not None else None
         dep = [spec.depth[k]] if spec.depth and spec.depth[k] is not None else None
+        t0 = time.perf_counter()
         ok = est.add_states(fid, (int(spec.stamps[k, 0]), int(spec.stamps[k, 1])), 400, T_SC, imu_t_k, imu_m_k,
                             bool(spec.keyframe[k]), son, dep, spec.first_depth)
+        t1 = time.perf_counter()
         assert ok, "add_states failed for frame %d" % k
         if perturb and not defer:
             if k > 0:
@@ -428,6 +430,9 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
             if k > 0:
                 est.set_T_WS(fid, spec.T_WS_true[k])
             est.set_speed_and_bias(fid, spec.sb_true[k])
+        if timing is not None:
+            timing.setdefault("add_states_s", []).append(t1 - t0)
+            timing.setdefault("set_states_s", []).append(time.perf_counter() - t1)
         if hasattr(est, "add_observations") and len(by_frame[k]):   # the product's batched form of the same calls
             idx = by_frame[k]
             cams = spec.obs_cam[idx].astype(np.uint64)
@@ -442,11 +447,15 @@ def feed(est, spec, optimize_each=0, perturb=True, frames=None, on_frame=None, t
                 timing.setdefault("add_observations_s", []).append(time.perf_counter() - t0)
                 timing.setdefault("add_observations_n", []).append(len(idx))
         else:
+            t0 = time.perf_counter()
             for i in by_frame[k]:
                 c = int(spec.obs_cam[i])
                 kp = kp_counter.get((k, c), 0)
                 kp_counter[(k, c)] = kp + 1
                 est.add_observation(lm_ids[int(spec.obs_lm[i])], fid, c, kp, spec.obs_uv[i], float(spec.obs_size[i]))
+            if timing is not None:   # (includes this loop's own Python overhead)
+                timing.setdefault("add_observations_s", []).append(time.perf_counter() - t0)
+                timing.setdefault("add_observations_n", []).append(len(by_frame[k]))
         if optimize_each:
             est.optimize(optimize_each, 1, False)
         if on_frame is not None:

@@ -497,3 +497,30 @@ def test_parameter_block_snapshots_and_batched_landmark_readback(gpu_lib):
         assert info["quality"] == lms[lid]["quality"]
         total += len(obs)
     assert total == len(spec.obs) if hasattr(spec, "obs") else total > 1000
+
+
+def test_wait_idle_after_an_enqueued_marginalisation(gpu_lib):
+    """svin_ba_apply_marginalization_strategy returns once its device job is enqueued; svin_ba_wait_idle returns when it has run:
+    the next optimize() then starts on an idle stream (its solve_time no longer holds the job), results unchanged"""
+    import time
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=14, L=600, n_obs=6000, seed=23, keyframe_every=2, frame_dt=0.25)
+    out = {}
+    for spaced in (False, True):
+        est, solve = Estimator(0), []
+
+        def on_frame(k, fid):
+            if spaced:
+                est.wait_idle()
+            est.optimize(4)
+            solve.append(est.summary()["solve_time"])
+            est.apply_marginalization(5, 3)
+        frames, _ = syn.feed(est, spec, on_frame=on_frame)
+        t0 = time.perf_counter()
+        est.wait_idle()
+        est.wait_idle()        # idempotent, immediate the second time
+        assert time.perf_counter() - t0 < 1.0
+        out[spaced] = (np.array([est.get_T_WS(f) for f in frames[-8:] if est.get_T_WS(f) is not None]), np.median(solve[5:]))
+    assert np.array_equal(out[False][0], out[True][0])
+    print("median solve_time back to back %.3f ms, frames spaced %.3f ms" % (1e3 * out[False][1], 1e3 * out[True][1]))
+    assert out[True][1] <= out[False][1] * 1.05
