@@ -5838,7 +5838,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   // copy instead of a dependent global load per observation; wide windows keep reading them through L2), the block ->
   // row maps, and -- because any block may turn out to be the last one, whose tail is the serial end of the
   // iteration -- the parameter blocks themselves, so that the fused retraction below starts without a memory round trip
-  constexpr int kStageMax = 512, kStageBlk = 128, kStageItems = 96;
+  constexpr int kStageMax = 1024, kStageBlk = 128, kStageItems = 96;   // (1024: config #4's d = 960 -- through L2 the camera vectors were a third dependent round trip per observation)
   __shared__ double sYV[2 * kStageMax];
   __shared__ int sOff[2 * kStageBlk];
   __shared__ double sItemX[kStageItems * 9];
@@ -5879,10 +5879,14 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
     firstStart = g4 == 0 ? e[0] : (g4 == 1 ? e[1] : (g4 == 2 ? e[2] : e[3]));
     firstEnd = g4 == 0 ? e[1] : (g4 == 1 ? e[2] : (g4 == 2 ? e[3] : e[4]));
   }
-  double sy0 = 0, sy1 = 0, sv0 = 0, sv1 = 0;
+  double syv[2 * (kStageMax / 256)];
   if (staged) {
-    if (t < p.d) { sy0 = p.yC[t]; sv0 = p.vC[t]; }
-    if (t + 256 < p.d) { sy1 = p.yC[t + 256]; sv1 = p.vC[t + 256]; }
+#pragma unroll
+    for (int k = 0; k < kStageMax / 256; ++k) {
+      const bool in = t + 256 * k < p.d;
+      syv[2 * k] = in ? p.yC[t + 256 * k] : 0.0;
+      syv[2 * k + 1] = in ? p.vC[t + 256 * k] : 0.0;
+    }
   }
   int so0 = -1, so1 = -1;
   if (stagedOff) {
@@ -5903,8 +5907,9 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   const bool has0 = lmBlock && (t & 15) < firstEnd - firstStart;
   if (has0) loadRaw((size_t)firstStart + (t & 15), raw0);
   if (staged) {
-    if (t < p.d) { sYV[t] = sy0; sYV[kStageMax + t] = sv0; }
-    if (t + 256 < p.d) { sYV[t + 256] = sy1; sYV[kStageMax + t + 256] = sv1; }
+#pragma unroll
+    for (int k = 0; k < kStageMax / 256; ++k)
+      if (t + 256 * k < p.d) { sYV[t + 256 * k] = syv[2 * k]; sYV[kStageMax + t + 256 * k] = syv[2 * k + 1]; }
   }
   if (stagedOff) {
     if (t < p.nPose) sOff[t] = so0;

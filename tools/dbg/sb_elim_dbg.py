@@ -21,6 +21,7 @@ H = np.tril(lin["S"]) + np.tril(lin["S"], -1).T
 g = lin["g"]
 d = lin["d"]
 n = P
+assert n >= 16, "chains shorter than 16 blocks are not eliminated (planSbElimination): nothing to compare"
 dK = d - 9 * n
 y_dev = est.debug_reduced_solve(mu)
 y_ref = np.linalg.solve(H, g)
@@ -51,39 +52,15 @@ Lf = est.debug_peek_solver_scratch(off0, n * REC).reshape(n, REC)
 Y = est.debug_peek_solver_scratch(off0 + n * REC, rowsY * ldY).reshape(rowsY, ldY)
 tv = est.debug_peek_solver_scratch(off0 + n * REC + rowsY * ldY, rowsY)
 
-# numpy replay
-D = [H[dK + 9 * b:dK + 9 * b + 9, dK + 9 * b:dK + 9 * b + 9].copy() for b in range(n)]
-Cc = [(H[dK + 9 * b:dK + 9 * b + 9, dK + 9 * b - 9:dK + 9 * b].copy() if b > 0 else np.zeros((9, 9))) for b in range(n)]
-G = [None] * n
-Flo = [np.zeros((9, 9)) for _ in range(n)]
-Fhi = [np.zeros((9, 9)) for _ in range(n)]
-level = {}
-s = 1
-while True:
-    last = s >= n
-    nE = 1 if last else (n - s + 2 * s - 1) // (2 * s)
-    for e in range(nE):
-        b = 0 if last else s + 2 * s * e
-        level[b] = s
-        G[b] = np.linalg.inv(np.linalg.cholesky(D[b]))
-        if not last:
-            Flo[b] = G[b] @ Cc[b]
-            if b + s < n:
-                Fhi[b] = G[b] @ Cc[b + s].T
-    if last:
-        break
-    newC = {}
-    for e in range((n + 2 * s - 1) // (2 * s)):
-        m = 2 * s * e
-        if m >= s:
-            D[m] -= Fhi[m - s].T @ Fhi[m - s]
-        if m + s < n:
-            D[m] -= Flo[m + s].T @ Flo[m + s]
-        if m >= 2 * s:
-            newC[m] = -Fhi[m - s].T @ Flo[m - s]
-    for m, v in newC.items():
-        Cc[m] = v
-    s *= 2
+# numpy replay (tools/chain_elim_replay.py: the same level schedule and per-block quantities as the kernels)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import chain_elim_replay as cr   # noqa: E402
+_, mid = cr.solve(H, g, dK, n)
+G, Flo, Fhi = mid["G"], mid["Flo"], mid["Fhi"]
+level = {0: 0}
+for s_ in cr.levels(n):
+    for b in cr.eliminated(n, s_):
+        level[b] = s_
 for b in range(n):
     eg = np.abs(Lf[b, 0:81].reshape(9, 9) - G[b]).max() / np.abs(G[b]).max()
     el = np.abs(Lf[b, 88:169].reshape(9, 9) - Flo[b]).max() / max(np.abs(Flo[b]).max(), 1e-300)
@@ -91,21 +68,7 @@ for b in range(n):
     if max(eg, el, eh) > 1e-9 or not np.isfinite(eg + el + eh):
         print("record of block %d (level s = %d): G %.2e F_lo %.2e F_hi %.2e" % (b, level[b], eg, el, eh))
 print("records compared")
-w = np.concatenate([H[dK:, :dK], g[dK:, None]], axis=1).copy()
-blk = lambda b: slice(9 * b, 9 * b + 9)   # noqa: E731
-s = 1
-while s < n:
-    for e in range((n - s + 2 * s - 1) // (2 * s)):
-        b = s + 2 * s * e
-        w[blk(b)] = G[b] @ w[blk(b)]
-    for e in range((n + 2 * s - 1) // (2 * s)):
-        m = 2 * s * e
-        if m >= s:
-            w[blk(m)] -= Fhi[m - s].T @ w[blk(m - s)]
-        if m + s < n:
-            w[blk(m)] -= Flo[m + s].T @ w[blk(m + s)]
-    s *= 2
-w[blk(0)] = G[0] @ w[blk(0)]
+w = mid["Y"]
 eY = np.abs(Y[:9 * n, :dK + 1] - w)
 print("Y: max abs diff %.3e of %.3e; worst row %d col %d; pad rows zero: %s; nan count %d" %
       (np.nanmax(eY), np.abs(w).max(), *np.unravel_index(np.nanargmax(eY), eY.shape), bool(np.all(Y[9 * n:] == 0)), int(np.isnan(Y).sum())))
