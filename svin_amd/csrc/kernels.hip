@@ -6228,7 +6228,7 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
 }
 
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius) {
-  const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 2048) : 0;
+  const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 1024) : 0;
   const int nFac = p.F > 0 ? min((p.F + 3) / 4, 1024) : 0;
   if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
   else hipLaunchKernelGGL(k_post_solve<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
