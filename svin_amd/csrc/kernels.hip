@@ -9,6 +9,8 @@
 // K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS (d <= 176), trailing update on MFMA
 //     k_chol_solve_ll    (176 < d <= 272) left-looking variant: at most 72 live tiles in LDS behind a slot map
 //     k_big_chol_chain   (d > 272) one-launch tile Cholesky over many workgroups + super-panel backward substitution
+//     k_sb_factor / k_sb_forward / k_sb_load / k_sb_back   wide windows: the chain of 9x9 speed / bias blocks eliminated by cyclic
+//                        reduction ahead of whichever of the three dense solvers the kept rows select
 // K7  k_post_solve       back-substitution, J*v / J*y sums, dogleg step and retraction (k_step_retract for rejected steps)
 // K8  cost reductions    per-block partials + single-block final reduce (deterministic)
 // K9  k_landmark_quality
