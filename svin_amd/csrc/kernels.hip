@@ -2732,7 +2732,7 @@ __global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double
 // windows with variable extrinsics keep the pairwise kernel).
 constexpr int kPanelRows = 96;
 constexpr int kPanelSlab = kPanelRows * kPanelRows + 3 * kPanelRows;
-constexpr int kPanelChunksPerBlock = 8;
+static_assert(kPanelChunksPerBlock * 16 <= 256, "one thread per landmark of a workgroup's chunks stages its observation range");
 
 #ifdef SVIN_SCHUR_TIMING
 __device__ int g_panelCount;

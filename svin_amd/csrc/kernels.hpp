@@ -106,6 +106,14 @@ struct ScalarMailbox {
 constexpr int kCholFailSync = 4 | 8;
 constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGather = 16, kScalGatherSlots = 16;  // offsets (doubles) of the all-reduced groups
 
+// wide windows: 16-landmark chunks one workgroup of k_schur_panels works through (the host builds the work list: Window::pack).
+// Config #4 on one GPU, 8 / 12 / 16: k_schur_panels 523 / 545 / 551 us, k_reduce_panel_slabs (one 74 KB slab per workgroup) 45 / 25 /
+// 19 us -- a wash on one GPU, and a rank of an 8-GPU run has an eighth of the chunks: 8 keeps its ~210 workgroups from becoming ~105.
+#ifndef SVIN_PANEL_CHUNKS
+#define SVIN_PANEL_CHUNKS 8
+#endif
+constexpr int kPanelChunksPerBlock = SVIN_PANEL_CHUNKS;
+
 struct DeviceProblem {
   // sizes
   int nPose, nExt, nSb, L, N, F, nImu, d, dC, priorM, priorBlocks, nCam;

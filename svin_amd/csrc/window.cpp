@@ -1636,7 +1636,7 @@ void Window::pack(bool solveFollows) {
   std::vector<int> hPanelWork, hPanelChunks, hPanelPairPtr;
   int nPanelBlocks = 0, nPanelPairs = 0;
   if (schurPanels) {
-    constexpr int kRows = 96, kChunk = 16, kPerBlock = 8;
+    constexpr int kRows = 96, kChunk = 16, kPerBlock = kPanelChunksPerBlock;
     const int nPan = (dC + kRows - 1) / kRows;
     nPanelPairs = nPan * (nPan + 1) / 2;
     std::vector<std::vector<int>> lists(nPanelPairs);
