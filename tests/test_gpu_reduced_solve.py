@@ -39,6 +39,7 @@ def window(P, L, n_obs, rig="euroc", seed=11):
     (29, 800, 8000, "euroc", "d = 435: chain of 29 (not a power of two), kept 174 rows LDS-resident (was blocked)"),
     (40, 1200, 12000, "euroc", "d = 600: chain of 40, kept 240 rows left-looking (was blocked)"),
     (48, 1500, 15000, "euroc", "d = 720: chain of 48, kept 288 rows blocked (padded to 320)"),
+    (50, 1500, 15000, "euroc", "d = 750: chain of 50, kept 300 rows blocked (not a multiple of 16: padded to 320)"),
     (64, 2500, 25000, "euroc", "d = 960: chain of 64, kept 384 rows blocked"),
     (64, 2500, 25000, "test4", "per-frame extrinsics, d = 1728: chain of 64, kept 1152 rows blocked"),
 ])
