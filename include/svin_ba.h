@@ -371,6 +371,13 @@ int svin_ba_linearize(svin_ba* h, double mu, double* S, double* g, uint64_t* blo
  * selects: LDS-resident, left-looking, blocked, blocked behind the speed / bias chain elimination).  Returns d (or -d if
  * cap_d < d). */
 int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d);
+/* the same with the choice svin_ba_optimize makes: fuse_finalize != 0 applies the metric and the damping inside the solver's
+ * load phase (the fused form every trust-region iteration runs), 0 is svin_ba_debug_reduced_solve. */
+int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, double* y, int cap_d);
+/* process-wide A/B switches of the reduced solve, for tests and tools: "SVIN_NO_LL" (no left-looking one-workgroup solver),
+ * "SVIN_NO_SB_ELIM" (no speed / bias chain elimination).  Each is initialised from the environment variable of the same name
+ * the first time a solve looks at it and only changes through this call afterwards.  Returns 1, 0 for an unknown name. */
+int svin_ba_debug_set_switch(const char* name, int value);
 /* doubles [offset, offset + count) of the reduced-system solver's scratch buffer after the last solve (tests of the solver
  * kernels' intermediate results).  Returns 1, 0 if the range is outside the buffer. */
 int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out);

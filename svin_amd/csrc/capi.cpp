@@ -24,6 +24,18 @@ struct svin_ba {
     return errval;                            \
   }
 
+// function-try-block tail for the entry points that are host look-ups most of the time but may reach quiesce() /
+// syncLandmarks() (which rethrow what the asynchronous marginalisation job threw, or a HIP error): nothing crosses the C ABI
+#define CATCH_ALL(errval)                     \
+  catch (const std::exception& e) {           \
+    lastError() = e.what();                   \
+    return errval;                            \
+  }                                           \
+  catch (...) {                               \
+    lastError() = "unknown error";            \
+    return errval;                            \
+  }
+
 static void splitSamples(const svin_imu_sample* imu, int n, std::vector<uint32_t>& t, std::vector<double>& m) {
   t.resize(2 * (size_t)n);
   m.resize(6 * (size_t)n);
@@ -56,24 +68,24 @@ svin_ba* svin_ba_create(int device) {
 }
 void svin_ba_destroy(svin_ba* h) { delete h; }
 const char* svin_ba_last_error(void) { return lastError().c_str(); }
-uint64_t svin_ba_new_id(svin_ba* h) { return h ? h->w.newId() : 0; }
-int svin_ba_set_id_provider(svin_ba* h, svin_id_provider_fn fn, void* user) {
+uint64_t svin_ba_new_id(svin_ba* h) try { return h ? h->w.newId() : 0; } CATCH_ALL(0)
+int svin_ba_set_id_provider(svin_ba* h, svin_id_provider_fn fn, void* user) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.setIdProvider(fn, user);
   return 1;
-}
-int svin_ba_reserve_ids(svin_ba* h, uint64_t largest) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_reserve_ids(svin_ba* h, uint64_t largest) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.reserveIds(largest);
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_set_camera_geometry(svin_ba* h, uint64_t cam, int model, const double intr[4], const double* dist, int n_dist,
-                                int width, int height) {
+                                int width, int height) try {
   if (!h || !intr || (n_dist > 0 && !dist) || n_dist < 0 || n_dist > 8) return SVIN_ERR_INVALID_ARG;
   return h->w.setCameraGeometry(cam, model, intr, dist, n_dist, width, height) ? 1 : SVIN_ERR_NOT_FOUND;
-}
-int svin_ba_clear_cameras(svin_ba* h) { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearCameras(); return 1; }
-int svin_ba_clear_imus(svin_ba* h) { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearImus(); return 1; }
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_clear_cameras(svin_ba* h) try { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearCameras(); return 1; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_clear_imus(svin_ba* h) try { if (!h) return SVIN_ERR_INVALID_ARG; h->w.clearImus(); return 1; } CATCH_ALL(SVIN_ERR_DEVICE)
 
 int svin_ba_add_camera(svin_ba* h, int model, const double intr[4], const double* dist, int n_dist, int width, int height,
                        const double sigmas[4]) {
@@ -86,11 +98,11 @@ int svin_ba_add_imu(svin_ba* h, const svin_imu_params* p) {
   GUARD_BEGIN return h->w.addImu(toParams(p));
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]) {
+int svin_ba_set_sonar_extrinsics(svin_ba* h, const double T_SSo[7]) try {
   if (!h || !T_SSo) return SVIN_ERR_INVALID_ARG;
   h->w.setSonarExtrinsics(T_SSo);
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_add_states(svin_ba* h, uint64_t frame_id, uint32_t sec, uint32_t nsec, uint64_t num_keypoints,
                        const double* T_SC, int n_cam, const svin_imu_sample* imu, int n_imu, int as_keyframe,
                        const double* sonar, int n_sonar, const double* depth, int n_depth, double first_depth) {
@@ -162,15 +174,15 @@ int svin_ba_finish(svin_ba* h) {
   GUARD_BEGIN return h->w.finish();
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_invalidate_preintegration(svin_ba* h) {
+int svin_ba_invalidate_preintegration(svin_ba* h) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.invalidatePreintegration();
   return 1;
-}
-int svin_ba_set_optimization_time_limit(svin_ba* h, double tl, int min_iter) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_optimization_time_limit(svin_ba* h, double tl, int min_iter) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.setOptimizationTimeLimit(tl, min_iter);
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t nkf, uint64_t nimu, uint64_t* removed, int cap,
                                            int* n_removed) {
   if (!h || cap < 0 || (cap > 0 && !removed)) return SVIN_ERR_INVALID_ARG;
@@ -182,7 +194,7 @@ int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t nkf, uint64_t ni
   return r;
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_get_summary(svin_ba* h, svin_summary* out) {
+int svin_ba_get_summary(svin_ba* h, svin_summary* out) try {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;
   const Summary& s = h->w.summary();
   out->initial_cost = s.initial_cost; out->final_cost = s.final_cost; out->iterations = s.iterations;
@@ -190,8 +202,8 @@ int svin_ba_get_summary(svin_ba* h, svin_summary* out) {
   out->total_time_s = s.total_time; out->upload_time_s = s.upload_time; out->solve_time_s = s.solve_time;
   out->download_time_s = s.download_time;
   return 1;
-}
-int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn fn, void* user) try {
   if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SVIN_ERR_INVALID_ARG;
   if (world > svin::kScalGatherSlots / 2) {   // every rank publishes its (gradient max, factorisation flag) pair in a slot of its own
     svin::lastError() = "set_distributed: at most " + std::to_string(svin::kScalGatherSlots / 2) + " ranks (one node of MI355X)";
@@ -199,7 +211,7 @@ int svin_ba_set_distributed(svin_ba* h, int rank, int world, svin_allreduce_fn f
   }
   h->w.setDistributed(rank, world, fn, user);
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_rccl_unique_id(unsigned char id_out[128]) {
   if (!id_out) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return Window::rcclUniqueId(id_out);
@@ -214,32 +226,32 @@ int svin_ba_set_distributed_rccl(svin_ba* h, int rank, int world, const unsigned
   GUARD_BEGIN return h->w.setDistributedRccl(rank, world, id);
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_set_solver_tolerances(svin_ba* h, double f, double g, double p) {
+int svin_ba_set_solver_tolerances(svin_ba* h, double f, double g, double p) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   h->w.setTolerances(f, g, p);
   return 1;
-}
-int svin_ba_get_T_WS(svin_ba* h, uint64_t id, double T[7]) { return h ? h->w.get_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
-int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, double sb[9]) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_T_WS(svin_ba* h, uint64_t id, double T[7]) try { return h ? h->w.get_T_WS(id, T) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, double sb[9]) try {
   return h ? h->w.getSpeedAndBias(id, imu, sb) : SVIN_ERR_INVALID_ARG;
-}
-int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, double T[7]) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, double T[7]) try {
   return h ? h->w.getCameraSensorStates(id, cam, T) : SVIN_ERR_INVALID_ARG;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 static void fillInfo(const Landmark& lm, svin_landmark_info* out) {
   for (int k = 0; k < 4; ++k) out->point[k] = lm.hp[k];
   out->quality = lm.quality; out->distance = lm.distance;
   out->num_observations = (int32_t)lm.obs.size();
   out->initialized = lm.initialized ? 1 : 0;
 }
-int svin_ba_get_landmark(svin_ba* h, uint64_t id, svin_landmark_info* out) {
+int svin_ba_get_landmark(svin_ba* h, uint64_t id, svin_landmark_info* out) try {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmark(id);
   if (!lm) return 0;
   fillInfo(*lm, out);
   return 1;
-}
-int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, int cap) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, int cap) try {
   if (!h || cap < 0) return SVIN_ERR_INVALID_ARG;
   int n = 0;
   for (const auto& kv : h->w.landmarks()) {
@@ -250,9 +262,9 @@ int svin_ba_get_landmarks(svin_ba* h, uint64_t* ids, svin_landmark_info* infos, 
     ++n;
   }
   return n;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_get_landmark_observations(svin_ba* h, uint64_t id, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids,
-                                      int cap) {
+                                      int cap) try {
   if (!h || cap < 0) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmarkGraph(id);
   if (!lm) return SVIN_ERR_NOT_FOUND;
@@ -270,9 +282,9 @@ int svin_ba_get_landmark_observations(svin_ba* h, uint64_t id, uint64_t* frames,
     if (rids) rids[i] = sorted[i]->resId;
   }
   return (int)sorted.size();
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_get_all_landmark_observations(svin_ba* h, int cap_landmarks, uint64_t* ids, svin_landmark_info* infos, int32_t* obs_ptr,
-                                          int cap_obs, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids, int32_t* n_obs_total) {
+                                          int cap_obs, uint64_t* frames, uint64_t* cams, uint64_t* kps, uint64_t* rids, int32_t* n_obs_total) try {
   if (!h || cap_landmarks < 0 || cap_obs < 0) return SVIN_ERR_INVALID_ARG;
   int n = 0, total = 0;
   std::vector<const svin::Observation*> sorted;
@@ -304,54 +316,54 @@ int svin_ba_get_all_landmark_observations(svin_ba* h, int cap_landmarks, uint64_
   if (obs_ptr && n <= cap_landmarks) obs_ptr[n] = total;
   if (n_obs_total) *n_obs_total = total;
   return n;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_get_parameter_block(svin_ba* h, uint64_t id, int32_t* type, double* values, uint32_t* sec, uint32_t* nsec, int32_t* fixed,
-                                int32_t* initialized) {
+                                int32_t* initialized) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.getParameterBlock(id, type, values, sec, nsec, fixed, initialized);
-}
-int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_parameter_block_ids(svin_ba* h, uint64_t* ids, int cap) try {
   if (!h || cap < 0 || (cap > 0 && !ids)) return SVIN_ERR_INVALID_ARG;
   std::vector<uint64_t> v;
   h->w.parameterBlockIds(v);
   for (int i = 0; i < (int)v.size() && i < cap; ++i) ids[i] = v[i];
   return (int)v.size();
-}
-int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_is_landmark_initialized(svin_ba* h, uint64_t id) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   const Landmark* lm = h->w.landmarkGraph(id);
   return lm ? (lm->initialized ? 1 : 0) : SVIN_ERR_NOT_FOUND;
-}
-int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t id, int initialized) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_landmark_initialized(svin_ba* h, uint64_t id, int initialized) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.setLandmarkInitialized(id, initialized != 0) ? 1 : SVIN_ERR_NOT_FOUND;
-}
-int svin_ba_set_keyframe(svin_ba* h, uint64_t id, int is_kf) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_keyframe(svin_ba* h, uint64_t id, int is_kf) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.setKeyframe(id, is_kf != 0) ? 1 : SVIN_ERR_NOT_FOUND;
-}
-int svin_ba_timestamp(svin_ba* h, uint64_t id, uint32_t* sec, uint32_t* nsec) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_timestamp(svin_ba* h, uint64_t id, uint32_t* sec, uint32_t* nsec) try {
   if (!h || !sec || !nsec) return SVIN_ERR_INVALID_ARG;
   auto it = h->w.states().find(id);
   if (it == h->w.states().end()) return SVIN_ERR_NOT_FOUND;
   *sec = it->second.stamp.sec; *nsec = it->second.stamp.nsec;
   return 1;
-}
-int svin_ba_state_count(svin_ba* h) { return h ? h->w.stateCount() : SVIN_ERR_INVALID_ARG; }
-int svin_ba_get_imu_preintegral(svin_ba* h, uint64_t pose_id, double adi[3], double ai[3], double* dt) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_state_count(svin_ba* h) try { return h ? h->w.stateCount() : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_imu_preintegral(svin_ba* h, uint64_t pose_id, double adi[3], double ai[3], double* dt) try {
   if (!h || !adi || !ai || !dt) return SVIN_ERR_INVALID_ARG;
   double v[7];
   if (!h->w.getImuPreIntegral(pose_id, v)) return 0;
   for (int k = 0; k < 3; ++k) { adi[k] = v[k]; ai[k] = v[3 + k]; }
   *dt = v[6];
   return 1;
-}
-int svin_ba_set_imu_preintegral(svin_ba* h, uint64_t pose_id, const double adi[3], const double ai[3], double dt) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_imu_preintegral(svin_ba* h, uint64_t pose_id, const double adi[3], const double ai[3], double dt) try {
   if (!h || !adi || !ai) return SVIN_ERR_INVALID_ARG;
   const double v[7] = {adi[0], adi[1], adi[2], ai[0], ai[1], ai[2], dt};
   h->w.setImuPreIntegral(pose_id, v);
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_WS[7]) {
   if (!T_WS || n_imu < 0 || (n_imu > 0 && !imu)) return SVIN_ERR_INVALID_ARG;
   std::vector<uint32_t> t;
@@ -359,43 +371,43 @@ int svin_ba_init_pose_from_imu(const svin_imu_sample* imu, int n_imu, double T_W
   splitSamples(imu, n_imu, t, m);
   return Window::initPoseFromImu(m.data(), n_imu, T_WS) ? 1 : 0;
 }
-int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) { return h && h->w.landmarkExists(id) ? 1 : 0; }
-int svin_ba_set_T_WS(svin_ba* h, uint64_t id, const double T[7]) { return h ? h->w.set_T_WS(id, T) : SVIN_ERR_INVALID_ARG; }
-int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, const double sb[9]) {
+int svin_ba_is_landmark_added(svin_ba* h, uint64_t id) try { return h && h->w.landmarkExists(id) ? 1 : 0; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_T_WS(svin_ba* h, uint64_t id, const double T[7]) try { return h ? h->w.set_T_WS(id, T) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_speed_and_bias(svin_ba* h, uint64_t id, uint64_t imu, const double sb[9]) try {
   return h ? h->w.setSpeedAndBias(id, imu, sb) : SVIN_ERR_INVALID_ARG;
-}
-int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, const double T[7]) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_camera_sensor_states(svin_ba* h, uint64_t id, uint64_t cam, const double T[7]) try {
   return h ? h->w.setCameraSensorStates(id, cam, T) : SVIN_ERR_INVALID_ARG;
-}
-int svin_ba_set_landmark(svin_ba* h, uint64_t id, const double hp[4]) { return h ? h->w.setLandmark(id, hp) : SVIN_ERR_INVALID_ARG; }
-uint64_t svin_ba_num_frames(svin_ba* h) { return h ? h->w.states().size() : 0; }
-uint64_t svin_ba_num_landmarks(svin_ba* h) { return h ? h->w.numLandmarks() : 0; }
-uint64_t svin_ba_current_keyframe_id(svin_ba* h) { return h ? h->w.currentKeyframeId() : 0; }
-uint64_t svin_ba_current_frame_id(svin_ba* h) { return (h && !h->w.states().empty()) ? h->w.states().rbegin()->first : 0; }
-uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age) { return h ? h->w.frameIdByAge(age) : 0; }
-int svin_ba_is_keyframe(svin_ba* h, uint64_t id) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_landmark(svin_ba* h, uint64_t id, const double hp[4]) try { return h ? h->w.setLandmark(id, hp) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+uint64_t svin_ba_num_frames(svin_ba* h) try { return h ? h->w.states().size() : 0; } CATCH_ALL(0)
+uint64_t svin_ba_num_landmarks(svin_ba* h) try { return h ? h->w.numLandmarks() : 0; } CATCH_ALL(0)
+uint64_t svin_ba_current_keyframe_id(svin_ba* h) try { return h ? h->w.currentKeyframeId() : 0; } CATCH_ALL(0)
+uint64_t svin_ba_current_frame_id(svin_ba* h) try { return (h && !h->w.states().empty()) ? h->w.states().rbegin()->first : 0; } CATCH_ALL(0)
+uint64_t svin_ba_frame_id_by_age(svin_ba* h, uint64_t age) try { return h ? h->w.frameIdByAge(age) : 0; } CATCH_ALL(0)
+int svin_ba_is_keyframe(svin_ba* h, uint64_t id) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   auto it = h->w.states().find(id);
   return it == h->w.states().end() ? SVIN_ERR_NOT_FOUND : (it->second.isKeyframe ? 1 : 0);
-}
-int svin_ba_is_in_imu_window(svin_ba* h, uint64_t id) { return h ? (h->w.isInImuWindow(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; }
-int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_is_in_imu_window(svin_ba* h, uint64_t id) try { return h ? (h->w.isInImuWindow(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_frame_ids(svin_ba* h, uint64_t* ids, int cap) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   int n = 0;
   for (auto& kv : h->w.states()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
   return n;
-}
-int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_landmark_ids(svin_ba* h, uint64_t* ids, int cap) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   int n = 0;
   for (auto& kv : h->w.landmarksGraph()) { if (n < cap && ids) ids[n] = kv.first; ++n; }
   return n;
-}
-int svin_ba_parameter_block_exists(svin_ba* h, uint64_t id) { return h ? (h->w.parameterBlockExists(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; }
-int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t id, int constant) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_parameter_block_exists(svin_ba* h, uint64_t id) try { return h ? (h->w.parameterBlockExists(id) ? 1 : 0) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t id, int constant) try {
   return h ? h->w.setParameterBlockConstant(id, constant != 0) : SVIN_ERR_INVALID_ARG;
-}
-int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t id) { return h ? h->w.isParameterBlockConstant(id) : SVIN_ERR_INVALID_ARG; }
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t id) try { return h ? h->w.isParameterBlockConstant(id) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_residuals_of(svin_ba* h, uint64_t id, uint64_t* out, int cap) {
   if (!h || cap < 0 || (cap > 0 && !out)) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN
@@ -510,6 +522,12 @@ int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d) {
   GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, double* y, int cap_d) {
+  if (!h || !y) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d, fuse_finalize != 0);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_debug_set_switch(const char* name, int value) { return svin::setSolverSwitch(name, value); }
 int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out) {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.debugPeekSolverScratch(offset, count, out);
@@ -522,7 +540,7 @@ int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, 
   GUARD_END(SVIN_ERR_DEVICE)
 }
 int svin_ba_get_marg_pre(svin_ba* h, int32_t* m, int32_t* n_landmarks, double* U, double* ba, double* W, double* V, double* bb,
-                         int32_t* marg_rows, int cap_m, int cap_landmarks) {
+                         int32_t* marg_rows, int cap_m, int cap_landmarks) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   const auto& q = h->w.margPre();
   if (m) *m = q.m;
@@ -535,9 +553,9 @@ int svin_ba_get_marg_pre(svin_ba* h, int32_t* m, int32_t* n_landmarks, double* U
   if (bb) std::memcpy(bb, q.bb.data(), sizeof(double) * q.bb.size());
   if (marg_rows) for (size_t i = 0; i < q.margRows.size(); ++i) marg_rows[i] = q.margRows[i];
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_get_marg_pre_blocks(svin_ba* h, uint64_t* dense_ids, int32_t* dense_ord, int32_t* dense_mdim, int cap_dense, uint64_t* landmark_ids,
-                                int cap_landmarks) {
+                                int cap_landmarks) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   const auto& q = h->w.margPre();
   for (size_t i = 0; i < q.denseIds.size() && (int)i < cap_dense; ++i) {
@@ -548,11 +566,11 @@ int svin_ba_get_marg_pre_blocks(svin_ba* h, uint64_t* dense_ids, int32_t* dense_
   for (size_t i = 0; i < q.lmIds.size() && (int)i < cap_landmarks; ++i)
     if (landmark_ids) landmark_ids[i] = q.lmIds[i];
   return (int)q.denseIds.size();
-}
-int svin_ba_describe_block(svin_ba* h, uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) {
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_describe_block(svin_ba* h, uint64_t id, uint64_t* frame, int32_t* kind, int32_t* index) try {
   if (!h) return SVIN_ERR_INVALID_ARG;
   return h->w.describeBlock(id, frame, kind, index);
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_bench_allreduce(svin_ba* h, uint64_t n_doubles, int iters, double* mean_us) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.benchAllReduce((size_t)n_doubles, iters, mean_us);
@@ -610,11 +628,11 @@ int svin_ba_map_remove_residual_block(svin_ba* h, uint64_t rid) {
   GUARD_BEGIN return h->w.mapRemoveResidualBlock(rid);
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_set_pack_mode(svin_ba* h, int mode) {
+int svin_ba_set_pack_mode(svin_ba* h, int mode) try {
   if (!h || mode < 0 || mode > 1) return SVIN_ERR_INVALID_ARG;
   h->w.setPackMode(mode);
   return 1;
-}
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_debug_csr(svin_ba* h, int32_t* n_landmarks, int32_t* n_observations, int32_t* lm_ptr, int32_t* obs_lm, uint32_t* obs_idx,
                       double* uv, double* w, double* lm, int32_t* obs_order, int32_t* resident) {
   if (!h) return SVIN_ERR_INVALID_ARG;

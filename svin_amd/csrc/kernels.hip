@@ -17,14 +17,16 @@
 // Reference arithmetic: see dmath.hpp and the per-kernel comments.
 #include "kernels.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 
 namespace svin {
 
 // hipFuncSetAttribute once per kernel and size (it is a driver call: ~2 us on the host path of every launch otherwise)
-static void ensureDynamicLds(const void* fn, size_t bytes) {
+void ensureDynamicLds(const void* fn, size_t bytes) {
   static std::mutex mtx;
   static std::unordered_map<unsigned long long, size_t> granted;   // (device, kernel) -> bytes
   int dev = 0;
@@ -35,6 +37,28 @@ static void ensureDynamicLds(const void* fn, size_t bytes) {
   if (it != granted.end() && it->second >= bytes) return;
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   granted[key] = bytes;
+}
+
+// A/B switches of the reduced solve: read from the environment ONCE (launchSolveReduced runs several times per trust-region
+// iteration, also on the enqueue thread: getenv there would race with a setenv of the host process), changed afterwards through
+// setSolverSwitch only (svin_ba_debug_set_switch: tests and tools).
+static std::atomic<int> gNoLL{-1}, gNoSbElim{-1};
+static bool switchOn(std::atomic<int>& sw, const char* env) {
+  int v = sw.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = std::getenv(env) != nullptr ? 1 : 0;
+    int expected = -1;
+    if (!sw.compare_exchange_strong(expected, v)) v = expected;
+  }
+  return v != 0;
+}
+int setSolverSwitch(const char* name, int value) {
+  if (!name) return 0;
+  const std::string n(name);
+  if (n == "SVIN_NO_LL") gNoLL.store(value ? 1 : 0);
+  else if (n == "SVIN_NO_SB_ELIM") gNoSbElim.store(value ? 1 : 0);
+  else return 0;
+  return 1;
 }
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -5555,7 +5579,7 @@ static size_t cholLdsBytes(int nT) {
 static int solverClass(int d) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
   const int nT = (d + 15) / 16;
   if (cholLdsBytes(nT) <= 156 * 1024) return 0;
-  if (nT >= 12 && nT <= 17 && std::getenv("SVIN_NO_LL") == nullptr) return 1;
+  if (nT >= 12 && nT <= 17 && !switchOn(gNoLL, "SVIN_NO_LL")) return 1;
   return 2;
 }
 // Whether (and where in p.cholL) the speed / bias chain is eliminated ahead of the dense solve: 0 = no, 1 = the kept rows go
@@ -5564,7 +5588,7 @@ static int solverClass(int d) {   // 0 = LDS-resident, 1 = left-looking in one w
 // takes through a DeviceProblem view.  A system the LDS-resident solver takes whole is left alone (14 us at d = 150: the
 // elimination's four launches cost more), and so is a chain of fewer than 8 blocks ahead of the blocked solver.
 static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
-  if (std::getenv("SVIN_NO_SB_ELIM") != nullptr || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
+  if (switchOn(gNoSbElim, "SVIN_NO_SB_ELIM") || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
   if (solverClass(p.d) == 0) return 0;
   // Measured (tools/sb_elim_time.py, reduced solve with / without): d = 180 66 / 64 us, 240: 73 / 91, 270: 85 / 113, 360: 99 / 183,
   // 600: 185 / 313, 960: 289 / 476 -- the four launches cost ~45 us before they gain anything, so short chains stay with the

@@ -1378,9 +1378,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         da.flag = bFlag.p;
         {
           const size_t lds = jacobiLdsBytes(nm);
-          // (the attribute call costs microseconds: only when the requirement grows)
-          if (lds > margLdsSet_[0]) { (void)hipFuncSetAttribute((const void*)k_marg_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); margLdsSet_[0] = lds; }
+          if (lds) ensureDynamicLds((const void*)k_marg_dense, lds);
           hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, lds ? 1 : 0);
+          HIP_OK(hipGetLastError());   // (a refused launch would leave a garbage prior behind)
         }
       } else {
         HIP_OK(hipMemcpyAsync(bHk.p, bU.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, s));
@@ -1407,8 +1407,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
         const int mode = forceFallback ? (ldsBoth ? 1 : 0) : (ldsOne ? 4 : 6);
         const size_t lds = (mode == 4) ? std::max(ldsOne, ldsBoth) : (mode == 1 ? ldsBoth : 0);
-        if (lds > margLdsSet_[1]) { (void)hipFuncSetAttribute((const void*)k_marg_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); margLdsSet_[1] = lds; }
+        if (lds) ensureDynamicLds((const void*)k_marg_final, lds);
         hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0);
+        HIP_OK(hipGetLastError());
       }
     }
     };

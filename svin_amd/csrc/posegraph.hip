@@ -1548,7 +1548,7 @@ svin_pg* svin_pg_create(int device, int six_dof, int max_iterations) {
 void svin_pg_destroy(svin_pg* h) { delete h; }
 const char* svin_pg_last_error(void) { return g_pgError.c_str(); }
 int svin_pg_add_keyframe(svin_pg* h, int index, int sequence, const double* t, const double* q, int loop_index,
-                         const double* loop_rel_t, const double* loop_rel_q, double loop_rel_yaw_deg) {
+                         const double* loop_rel_t, const double* loop_rel_q, double loop_rel_yaw_deg) try {
   if (!h || !t || !q) return -1;
   svin::pg::Keyframe kf;
   kf.index = index; kf.sequence = sequence;
@@ -1566,6 +1566,9 @@ int svin_pg_add_keyframe(svin_pg* h, int index, int sequence, const double* t, c
   h->g.applyDrift(kf);
   h->g.kfs.push_back(kf);
   return 1;
+} catch (const std::exception& e) {   // (allocation failure of the keyframe list: nothing crosses the C ABI)
+  g_pgError = e.what();
+  return -3;
 }
 int svin_pg_num_keyframes(const svin_pg* h) { return h ? (int)h->g.kfs.size() : -1; }
 int svin_pg_optimize(svin_pg* h, int earliest_loop_index, int cur_index) {

@@ -100,8 +100,16 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
     }
   }
   __syncthreads();
-  if (err) {   // the counts disagree with the host graph: report, leave the new CSR empty rather than inconsistent
+  if (err) {   // the counts disagree with the host graph: report, and leave an EMPTY BUT VALID CSR behind -- the host has
+    // already switched to the new set and the solve is enqueued right behind this launch; it throws when it reads the status
+    // (downloadStates), but until then the solve's kernels walk these arrays: every landmark without observations, every
+    // observation record pointing at slot 0 with weight 0
     if (t == 0) *a.status = err;
+    for (int s = t; s <= a.Lnew; s += nt) a.lmPtrNew[s] = 0;
+    for (int o = t; o < a.Nnew; o += nt) {
+      a.obsIdx[o] = packObs(0, 0, 0); a.obsLm[o] = 0; a.wNew[o] = 0.0;
+      a.uvNew[2 * (size_t)o] = 0.0; a.uvNew[2 * (size_t)o + 1] = 0.0;
+    }
     return;
   }
   // ---- phase 2: surviving observations first (order kept), this frame's additions behind them
@@ -144,8 +152,8 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
     for (int o = beg; o < end; ++o) {
       const uint32_t hn = a.hndNew[o];
       const int ps = a.poseSlotOfH[hn & 0xfff], es = a.extSlotOfH[(hn >> 12) & 0xfff];
-      if (ps < 0 || es < 0) atomicOr(&err, 16);
-      a.obsIdx[o] = packObs(ps, es, (int)(hn >> 24));
+      if (ps < 0 || es < 0) atomicOr(&err, 16);   // (reported at the end; the record stays addressable: slot 0)
+      a.obsIdx[o] = packObs(ps < 0 ? 0 : ps, es < 0 ? 0 : es, (int)(hn >> 24));
       a.obsLm[o] = s;
     }
     for (int k = 0; k < 4; ++k) a.lm[4 * (size_t)s + k] = a.lmHp[4 * (size_t)h + k];

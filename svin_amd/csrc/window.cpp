@@ -290,7 +290,7 @@ void Window::removeBlock(uint64_t id) {  // Map::removeParameterBlock cascades (
     }
   }
   for (Block*& c : blockCache_) c = nullptr;
-  obsCachePose_ = 0;
+  obsCacheValid_ = false;
   blockByHandle_[b->kind][b->handle] = nullptr;
   freeBlockH_[b->kind].push_back(b->handle);
   blocks_.erase(id);
@@ -372,7 +372,7 @@ bool Window::initPoseFromImu(const double* imuM, int n, double* T) {
 int Window::addStates(uint64_t frameId, TimeStamp stamp, uint64_t numKeypoints, const double* T_SC, int nCam,
                       const uint32_t* imuT, const double* imuM, int nImu, bool asKeyframe, const double* sonar,
                       int nSonar, const double* depth, int nDepth, double firstDepth) {
-  obsCachePose_ = 0;
+  obsCacheValid_ = false;
   if (nCam != (int)cameras_.size()) { lastError() = "addStates: T_SC count != number of cameras"; return -1; }
   if (imus_.empty()) { lastError() = "addStates: no IMU added"; return -1; }
   if (imuM == nullptr || imuT == nullptr) nImu = 0;
@@ -623,11 +623,12 @@ uint64_t Window::addObservationTo(Landmark& lm, uint64_t poseId, uint64_t cam, u
   Block* pb = cachedBlock(poseId);
   if (!pb || pb->kind != B_POSE) return 0;
   // the extrinsics blocks of the frame: the state table is consulted once per frame, then obsCacheExt_ answers
-  if (obsCachePose_ != poseId) {
+  if (!obsCacheValid_ || obsCachePose_ != poseId) {
     auto sit = states_.find(poseId);
     if (sit == states_.end()) return 0;
     for (size_t c = 0; c < cameras_.size() && c < 16; ++c) obsCacheExt_[c] = sit->second.ext.at(c).id;
     obsCachePose_ = poseId;
+    obsCacheValid_ = true;
   }
   if (poseId <= lm.maxPose)   // (the first observation from a new frame cannot repeat an older one)
     for (const Observation& o : lm.obs)
@@ -2282,14 +2283,19 @@ int Window::linearize(double mu, double* S, double* g, uint64_t* blockIds, int32
 }
 // inspection hook: the Gauss-Newton step of the reduced system as the solver kernels compute it (whichever of the four paths the
 // size selects), for the tests to hold against a host solve of linearize()'s system
-int Window::debugReducedSolve(double mu, double* y, int capD) {
+int Window::debugReducedSolve(double mu, double* y, int capD, bool fuseFinalize) {
   distNative_ = false;
   pack();
   DeviceProblem& p = prob_;
   if (p.d > capD) return -p.d;
   evaluateAll(false, stream_);
-  launchBuildNormalEquations(p, mu, true, stream_);
-  launchSolveReduced(p, stream_);
+  if (fuseFinalize) {   // what solve() enqueues: metric and damping applied inside the solver's load phase
+    launchAccumulateNormalEquations(p, mu, true, stream_, /*zeroFirst=*/true);
+    launchSolveReduced(p, stream_, mu, true, /*fuseFinalize=*/true);
+  } else {
+    launchBuildNormalEquations(p, mu, true, stream_);
+    launchSolveReduced(p, stream_);
+  }
   HIP_OK(hipMemcpyAsync(y, p.yC, sizeof(double) * p.d, hipMemcpyDeviceToHost, stream_));
   HIP_OK(hipStreamSynchronize(stream_));
   return p.d;

@@ -308,7 +308,7 @@ class Window {
   int linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks, int capD,
                 double* cost);
   void waitIdle();
-  int debugReducedSolve(double mu, double* y, int capD);
+  int debugReducedSolve(double mu, double* y, int capD, bool fuseFinalize = false);
   int debugPeekSolverScratch(uint64_t off, uint64_t count, double* out);
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
                int32_t* nBlocks, int capM);
@@ -447,9 +447,9 @@ class Window {
   Block* cachedBlock(uint64_t id);
   Block* blockCache_[4] = {nullptr, nullptr, nullptr, nullptr};
   int blockCacheNext_ = 0;
-  size_t margLdsSet_[2] = {0, 0};   // dynamic LDS already granted to k_marg_dense / k_marg_final (hipFuncSetAttribute is not free)
   double lastObsSize_ = 0.0, lastObsWeight_ = 0.0;
-  uint64_t obsCachePose_ = 0;     // frame whose extrinsics block ids obsCacheExt_ holds (0: none)
+  uint64_t obsCachePose_ = 0;     // frame whose extrinsics block ids obsCacheExt_ holds ...
+  bool obsCacheValid_ = false;    // ... if any (frame id 0 is a legal id, so the id itself cannot say)
   uint64_t obsCacheExt_[16] = {0};
   std::unordered_map<uint64_t, uint64_t> lmPriorRes2Lm_;  // HomogeneousPointError residual id -> landmark id
   size_t numLandmarkPriors_ = 0;

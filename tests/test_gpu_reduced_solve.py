@@ -16,6 +16,14 @@ from svin_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def sb_elim_switch(gpu_lib):
+    """the library reads SVIN_NO_SB_ELIM once per process; tests flip the switch through the debug entry point and leave it off"""
+    from svin_amd.estimator import Estimator
+    yield lambda off: Estimator.debug_set_switch("SVIN_NO_SB_ELIM", off)
+    Estimator.debug_set_switch("SVIN_NO_SB_ELIM", False)
+
+
 def host_solve(lin):
     S = np.tril(lin["S"]) + np.tril(lin["S"], -1).T
     return np.linalg.solve(S, lin["g"])
@@ -43,33 +51,34 @@ def window(P, L, n_obs, rig="euroc", seed=11):
     (64, 2500, 25000, "euroc", "d = 960: chain of 64, kept 384 rows blocked"),
     (64, 2500, 25000, "test4", "per-frame extrinsics, d = 1728: chain of 64, kept 1152 rows blocked"),
 ])
-def test_device_solve_equals_host_solve(gpu_lib, monkeypatch, P, L, n_obs, rig, path):
+def test_device_solve_equals_host_solve(gpu_lib, sb_elim_switch, P, L, n_obs, rig, path):
     est = window(P, L, n_obs, rig)
     for mu, tol in ((1e-4, 1e-10), (1e-9, 1e-6)):
         lin = est.linearize(mu)
         y_ref = host_solve(lin)
         scale = np.abs(y_ref).max()
-        monkeypatch.delenv("SVIN_NO_SB_ELIM", raising=False)
-        y = est.debug_reduced_solve(mu)
-        err = np.abs(y - y_ref).max() / scale
-        monkeypatch.setenv("SVIN_NO_SB_ELIM", "1")
-        y_dense = est.debug_reduced_solve(mu)
-        err_dense = np.abs(y_dense - y_ref).max() / scale
-        print("%s, mu %g: d %d, |y| %.3g, device vs host %.2e (chain elimination off: %.2e)" % (path, mu, lin["d"], scale, err, err_dense))
-        assert y.shape == y_ref.shape and err < tol and err_dense < tol
+        err = {}
+        for off in (False, True):
+            sb_elim_switch(off)
+            # fused = metric and damping applied in the solver's load phase (k_sb_factor / k_sb_load or the dense solver's own
+            # load): the form every iteration of optimize() runs
+            for fused in (False, True):
+                y = est.debug_reduced_solve(mu, fused=fused)
+                assert y.shape == y_ref.shape
+                err[off, fused] = np.abs(y - y_ref).max() / scale
+        print("%s, mu %g: d %d, |y| %.3g, device vs host %.2e (fused %.2e; chain elimination off: %.2e, fused %.2e)" %
+              (path, mu, lin["d"], scale, err[False, False], err[False, True], err[True, False], err[True, True]))
+        assert max(err.values()) < tol
 
 
-def test_chain_elimination_is_used_and_can_be_switched_off(gpu_lib, monkeypatch):
+def test_chain_elimination_is_used_and_can_be_switched_off(gpu_lib, sb_elim_switch):
     """the two blocked paths give different roundings of the same step (so the switch really selects code), and the solver
     converges to the same optimum either way"""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=32, L=1000, n_obs=10000, seed=5, frame_dt=0.25)
     res = {}
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("SVIN_NO_SB_ELIM", "1")
-        else:
-            monkeypatch.delenv("SVIN_NO_SB_ELIM", raising=False)
+        sb_elim_switch(off)
         est = Estimator(0)
         frames, _ = syn.feed(est, spec)
         y = est.debug_reduced_solve(1e-6)
