@@ -374,6 +374,12 @@ int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d);
 /* the same with the choice svin_ba_optimize makes: fuse_finalize != 0 applies the metric and the damping inside the solver's
  * load phase (the fused form every trust-region iteration runs), 0 is svin_ba_debug_reduced_solve. */
 int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, double* y, int cap_d);
+/* the eigen-solver of the marginalisation prior (M3, MarginalizationError.cpp:725-758: Eigen::SelfAdjointEigenSolver there;
+ * here Householder tridiagonalisation + divide and conquer in one workgroup, svin_amd/csrc/symeig.hpp) on an arbitrary
+ * symmetric matrix A (n x n, row-major, n <= 128), on the current HIP device: eigenvalues ascending, eigenvectors[i * n + j] =
+ * component i of vector j, device_ms (may be NULL) = the fastest of three launches.  Returns 1, 0 if n is out of range,
+ * -1 if the result is not finite.  Test hook. */
+int svin_ba_debug_sym_eig(int n, const double* A, double* eigenvalues, double* eigenvectors, double* device_ms);
 /* process-wide A/B switches of the reduced solve, for tests and tools: "SVIN_NO_LL" (no left-looking one-workgroup solver),
  * "SVIN_NO_SB_ELIM" (no speed / bias chain elimination).  Each is initialised from the environment variable of the same name
  * the first time a solve looks at it and only changes through this call afterwards.  Returns 1, 0 for an unknown name. */

@@ -527,6 +527,11 @@ int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, dou
   GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d, fuse_finalize != 0);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_debug_sym_eig(int n, const double* A, double* eigenvalues, double* eigenvectors, double* device_ms) {
+  if (!A || !eigenvalues || !eigenvectors) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN return svin::debugSymEig(n, A, eigenvalues, eigenvectors, device_ms);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_debug_set_switch(const char* name, int value) { return svin::setSolverSwitch(name, value); }
 int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out) {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;

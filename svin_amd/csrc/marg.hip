@@ -11,6 +11,7 @@
 // rank-revealing thresholds of the eliminated blocks; it is applied to exactly those blocks here
 // (U - W V^+ W^T with V^+ = D^-1 (D^-1 V D^-1)^+ D^-1), which is the same matrix in exact arithmetic.
 #include "window.hpp"
+#include "symeig.hpp"
 #include <chrono>
 #include <memory>
 #include <type_traits>
@@ -716,8 +717,171 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   return true;
 }
 
-__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds, int fallbackLds) {
+// ---- M3 by a direct eigen-solve (round 5): tridiagonalisation + divide and conquer (symeig.hpp) instead of ~1 400 dependent
+// Jacobi rounds.  H = p A p (A with a unit diagonal), A = U S U^T; J = (p U sqrt(S))^T, e0 = -(sqrt(S)^+ U^T p^-1) b0 with the
+// eigenvalues <= eps n lambda_max dropped (MarginalizationError.cpp:739-742), and the H-space form the solver reads: Ht = J^T J,
+// bp = J^T e0, c0 = e0.e0.  Writes flag[4] = 1 when it has produced the prior; k_marg_final, enqueued right behind it with
+// `skipIfDone`, then returns at once -- otherwise (a non-finite result) it runs the Jacobi solve as before.
+__global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
   extern __shared__ double jacobiLds[];
+  lds_double* X = toLds(jacobiLds);
+  const int t = threadIdx.x, n = a.n, ld = n | 1;
+  double* p = a.tmp;            // n
+  double* ev = a.tmp + n;       // n
+  double* lamp = a.tmp + 2 * n; // n: eigenvalue or 0 (dropped)
+  const long long tStart = wall_clock64();
+  for (int i = t; i < n; i += 1024) p[i] = margScale(a.H[(size_t)i * n + i]);
+  __syncthreads();
+  for (int idx = t; idx < n * ld; idx += 1024) {
+    const int r = idx / ld, c = idx - r * ld;
+    X[idx] = (c < n) ? 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (p[r] * p[c]) : 0.0;
+  }
+  __syncthreads();
+  const long long tPrep = wall_clock64();
+  const bool ok = symeig::solve(X, n, ld, a.G);
+  const long long tEig = wall_clock64();
+  if (!ok) {
+    if (t == 0) a.flag[4] = 0;
+    return;
+  }
+  // X[i * ld + j] = component i of eigenvector j, symeig::gS.d[j] = eigenvalue j (ascending)
+  const double mx = symeig::gS.d[n - 1], mn = symeig::gS.d[0];
+  const double tol = 2.220446049250313e-16 * n * mx;
+  if (t < n) {
+    const double l = symeig::gS.d[t];
+    ev[t] = l;
+    lamp[t] = l > tol ? l : 0.0;
+  }
+  if (t < 64) {
+    int c = 0;
+    for (int j = t; j < n; j += 64) c += symeig::gS.d[j] <= tol;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (t == 0) { a.flag[2] = c; a.flag[1] = 0; a.scal[1] = mn; a.scal[2] = mx; }
+  }
+  // e0_j = -(1 / sqrt(l_j)) u_j . (b0 / p): 8 lanes per eigenvector
+  {
+    const int j = t >> 3, sub = t & 7;
+    double s = 0;
+    if (j < n)
+      for (int i = sub; i < n; i += 8) s += X[i * ld + j] * (a.b0[i] / p[i]);
+    s = symeig::sum8(s);
+    if (j < n && sub == 0) { const double l = symeig::gS.d[j]; a.e0[j] = l > tol ? -sqrt(1.0 / l) * s : 0.0; }
+  }
+  // J = (p U sqrt(S))^T: row j = eigen-direction j
+  for (int idx = t; idx < n * n; idx += 1024) {
+    const int j = idx / n, i = idx - j * n;
+    const double l = symeig::gS.d[j];
+    a.J[idx] = l > tol ? p[i] * X[i * ld + j] * sqrt(l) : 0.0;
+  }
+  __syncthreads();
+  // Ht = J^T J = p (U S U^T) p: 16 x 16 tiles on v_mfma_f64_16x16x4, both operands rows of X
+  {
+    const int wave = t >> 6, l = t & 63, tr = (n + 15) >> 4;
+    for (int id = wave; id < tr * tr; id += 16) {
+      const int ra = (id / tr) * 16 + (l & 15), cb = (id % tr) * 16 + (l & 15);
+      symeig::d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < n; kk += 4) {
+        const int j = kk + (l >> 4);
+        const double av = (ra < n && j < n) ? (double)X[ra * ld + j] : 0.0;
+        const double bv = (cb < n && j < n) ? (double)X[cb * ld + j] * lamp[j] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = (id / tr) * 16 + (l >> 4) + 4 * rg;
+        if (r < n && cb < n) a.Ht[(size_t)r * n + cb] = acc[rg] * p[r] * p[cb];
+      }
+    }
+  }
+  // bp = J^T e0
+  {
+    const int i = t >> 3, sub = t & 7;
+    double s = 0;
+    if (i < n)
+      for (int j = sub; j < n; j += 8) s += X[i * ld + j] * sqrt(lamp[j]) * a.e0[j];
+    s = symeig::sum8(s);
+    if (i < n && sub == 0) a.bp[i] = p[i] * s;
+  }
+  if (t < 64) {
+    double c = 0;
+    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    c = waveSumM(c);
+    if (t == 0) {
+      a.scal[0] = c;
+      a.scal[3] = (double)(tPrep - tStart); a.scal[4] = (double)(tEig - tPrep); a.scal[5] = (double)(wall_clock64() - tEig);
+      a.scal[6] = 0.0;
+      a.scal[7] = (double)n;
+      a.flag[3] = -7;   // marks the mode in the SVIN_MARG_TIMING line
+      __threadfence();
+      a.flag[4] = 1;
+    }
+  }
+}
+constexpr int kSymEigMaxN = symeig::kMaxN;
+static size_t symEigLdsBytes(int n) { return (size_t)n * (n | 1) * sizeof(double); }
+
+// inspection hook (svin_ba_debug_sym_eig): the solver on an arbitrary symmetric matrix
+__global__ __launch_bounds__(1024) void k_sym_eig_debug(int n, const double* A, double* lam, double* Xout, double* scratch, int* okOut) {
+  extern __shared__ double jacobiLds[];
+  lds_double* X = toLds(jacobiLds);
+  const int t = threadIdx.x, ld = n | 1;
+  for (int idx = t; idx < n * ld; idx += 1024) {
+    const int r = idx / ld, c = idx - r * ld;
+    X[idx] = (c < n) ? 0.5 * (A[(size_t)r * n + c] + A[(size_t)c * n + r]) : 0.0;
+  }
+  __syncthreads();
+  const bool ok = symeig::solve(X, n, ld, scratch);
+  if (t == 0) *okOut = ok ? 1 : 0;
+  if (t < n) lam[t] = symeig::gS.d[t];
+#ifdef SVIN_SYMEIG_TIMING
+  if (t < 80) scratch[t] = t < symeig::gS.nstamp ? (double)(symeig::gS.stamp[t] - symeig::gS.stamp[0]) : -1.0;
+#endif
+  for (int idx = t; idx < n * n; idx += 1024) { const int i = idx / n, j = idx - i * n; Xout[idx] = X[i * ld + j]; }
+}
+int debugSymEig(int n, const double* A, double* lam, double* X, double* deviceMs) {
+  if (n < 1 || n > kSymEigMaxN) return 0;
+  double *dA, *dLam, *dX, *dS; int* dOk;
+  const size_t n2 = (size_t)n * n;
+  HIP_OK(hipMalloc(&dA, sizeof(double) * (3 * n2 + n))); dX = dA + n2; dS = dX + n2; dLam = dS + n2;
+  HIP_OK(hipMalloc(&dOk, sizeof(int)));
+  HIP_OK(hipMemcpy(dA, A, sizeof(double) * n2, hipMemcpyHostToDevice));
+  const size_t lds = symEigLdsBytes(n);
+  ensureDynamicLds((const void*)k_sym_eig_debug, lds);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {   // (the first launch pays the code upload)
+    HIP_OK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_sym_eig_debug, dim3(1), dim3(1024), lds, 0, n, dA, dLam, dX, dS, dOk);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(e1, 0));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    best = std::min(best, ms);
+  }
+  int ok = 0;
+  HIP_OK(hipMemcpy(&ok, dOk, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(lam, dLam, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(X, dX, sizeof(double) * n2, hipMemcpyDeviceToHost));
+#ifdef SVIN_SYMEIG_TIMING
+  if (n2 >= 80) {   // stage stamps of the last launch (100 MHz ticks since the first), one line
+    double st[80];
+    HIP_OK(hipMemcpy(st, dS, sizeof(st), hipMemcpyDeviceToHost));
+    std::printf("[symeig] n %d stamps(us):", n);
+    for (int i = 0; i < 80 && st[i] >= 0; ++i) std::printf(" %.1f", st[i] / 100.0);
+    std::printf("\n");
+  }
+#endif
+  if (deviceMs) *deviceMs = best;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dA); (void)hipFree(dOk);
+  return ok ? 1 : -1;
+}
+
+__global__ __launch_bounds__(1024) void k_marg_final(FinalArgs a, int useLds, int fallbackLds, int skipIfDone) {
+  extern __shared__ double jacobiLds[];
+  if (skipIfDone && a.flag[4] == 1) return;   // k_marg_final_dc, enqueued ahead of this launch, has produced the prior
   // modes: 4 = Cholesky-preconditioned Jacobi, image in LDS; 6 = the same with the image in global memory (priors too
   // large for LDS); 1 / 0 = the fall-back, one-sided Jacobi on A itself with G and Q in LDS / in global memory
   // (also what runs when a pivot of the factorisation is not positive: `fallbackLds` says whether G and Q both fit)
@@ -1407,8 +1571,18 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
         const int mode = forceFallback ? (ldsBoth ? 1 : 0) : (ldsOne ? 4 : 6);
         const size_t lds = (mode == 4) ? std::max(ldsOne, ldsBoth) : (mode == 1 ? ldsBoth : 0);
+        // default since round 5: the direct solve (tridiagonalisation + divide and conquer) for priors up to 128 unknowns, the
+        // Jacobi kernel behind it as the fall-back for a non-finite result (it returns at once when flag[4] says "done");
+        // SVIN_MARG_EIG=cholesky / jacobi select the round-2 solvers alone
+        const bool direct = !want && nk <= kSymEigMaxN;
+        if (direct) {
+          const size_t ldsDc = symEigLdsBytes(nk);
+          ensureDynamicLds((const void*)k_marg_final_dc, ldsDc);
+          hipLaunchKernelGGL(k_marg_final_dc, dim3(1), dim3(1024), ldsDc, s, fa);
+          HIP_OK(hipGetLastError());
+        }
         if (lds) ensureDynamicLds((const void*)k_marg_final, lds);
-        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0);
+        hipLaunchKernelGGL(k_marg_final, dim3(1), dim3(1024), lds, s, fa, mode, (mode == 4 && ldsBoth) ? 1 : 0, direct ? 1 : 0);
         HIP_OK(hipGetLastError());
       }
     }

@@ -1,0 +1,590 @@
+// Symmetric eigen-decomposition of one n x n matrix (n <= 128) by ONE workgroup of 1024 threads, the matrix resident in LDS:
+// Householder tridiagonalisation -> Cuppen's divide and conquer with Gu / Eisenstat vectors, bottom-up from 1 x 1 leaves ->
+// back-transformation.  Used by the marginalisation prior (marg.hip, M3: MarginalizationError::updateErrorComputation,
+// okvis_ceres/src/MarginalizationError.cpp:725-758, which calls Eigen::SelfAdjointEigenSolver = tridiagonalisation +
+// implicit QL; the decomposition itself is third-party arithmetic, what the reference fixes is the use of its result).
+//
+// Why not Jacobi (rounds 1-4): a one-sided Jacobi sweep is n - 1 dependent tournament rounds and these priors take 10-13
+// sweeps however they are preconditioned (110 of 117 eigenvalues sit in [1e-3, 3.4], 60 of them in five 12-fold clusters of
+// the extrinsics chain): ~1 400 rounds of 1.0-1.6 us.  The tridiagonalisation is n dependent steps, and a tridiagonal
+// eigenproblem splits: log2 n merge levels whose work is the secular equation (one root per lane group), the Loewner formula
+// and one matrix product each.  Deflation takes the clusters out (numerically multiple eigenvalues are what divide and conquer
+// deflates), orthogonality comes from Gu / Eisenstat's recomputed z (no re-orthogonalisation, no cluster heuristics).
+// The algorithm is replayed in numpy by tools/sym_eig_dc_replay.py (tests/test_sym_eig_dc_host.py holds the replay against
+// LAPACK; tests/test_gpu_sym_eig.py holds this code against LAPACK through svin_ba_debug_sym_eig).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace svin {
+namespace symeig {
+
+using lds_double = __attribute__((address_space(3))) double;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxN = 128;
+constexpr int kThreads = 1024;
+constexpr double kEps = 2.220446049250313e-16;
+
+// Small per-phase arrays next to the n x ld image (static __shared__; the phases reuse the union)
+struct Small {
+  double d[kMaxN], e[kMaxN], tau[kMaxN];   // tridiagonal (d becomes the eigenvalues of the solved blocks), Householder scalars
+  union {
+    struct { double v[2][kMaxN], p[kMaxN], w[kMaxN]; } hh;                       // tridiagonalisation
+    struct { double v[2][kMaxN], part[8 * kMaxN]; } bt;                          // back-transformation
+    struct {
+      double z[kMaxN], dcur[kMaxN], ztil[kMaxN];     // per column of the merge: z, d after the deflation rotations, z-hat (0: deflated)
+      double cd[kMaxN], cz[kMaxN];                   // compact (non-deflated, ascending) poles and weights of each block, at [lo, lo + K)
+      double rtau[kMaxN], cinv[kMaxN], newd[kMaxN];  // per root: tau, 1 / |v_j|; eigenvalues of the merged block before the final sort
+      double oorgd[kMaxN], otau[kMaxN], oinv[kMaxN], dnext[kMaxN];   // per OUTPUT column
+      double rotC[kMaxN], rotS[kMaxN];
+      int sorted[kMaxN], kind[kMaxN], ndl[kMaxN], dfl[kMaxN], rorg[kMaxN];
+      int okind[kMaxN], osrc[kMaxN], rotP[kMaxN], rotQ[kMaxN], K[kMaxN], nrot[kMaxN];
+    } dc;
+  } u;
+  int bad;
+  long long stamp[80];   // 100 MHz wall-clock stamps of the stages (SVIN_SYMEIG_TIMING builds: tools/symeig_time.py)
+  int nstamp;
+};
+
+// one instance per kernel that uses the solver; named directly (not passed by reference) so that every access is a DS instruction:
+// through a generic reference the compiler emits FLAT loads
+__shared__ Small gS;
+
+#ifdef SVIN_SYMEIG_TIMING
+#define SYMEIG_STAMP() do { if (threadIdx.x == 0 && gS.nstamp < 80) gS.stamp[gS.nstamp++] = wall_clock64(); } while (0)
+#else
+#define SYMEIG_STAMP() do { } while (0)
+#endif
+
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int kCtrl>
+__device__ __forceinline__ double dppMov(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_mov_dpp(lo, kCtrl, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, kCtrl, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+template <int kCtrl>
+__device__ __forceinline__ int dppMovI(int v) { return __builtin_amdgcn_mov_dpp(v, kCtrl, 0xf, 0xf, false); }
+// Reductions over aligned groups of 8 lanes, the result in every lane of the group and BIT-IDENTICAL in all of them (each step
+// combines the same two operands in either order, and + * max are commutative): the lanes of a group take the same branches.
+// row_half_mirror = 0x141 (lane i of a half row reads lane 7 - i), quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E.
+__device__ __forceinline__ double sum8(double v) {
+  v += dppMov<0x141>(v);
+  v += dppMov<0xB1>(v);
+  v += dppMov<0x4E>(v);
+  return v;
+}
+__device__ __forceinline__ double prod8(double v) {
+  v *= dppMov<0x141>(v);
+  v *= dppMov<0xB1>(v);
+  v *= dppMov<0x4E>(v);
+  return v;
+}
+__device__ __forceinline__ double max8(double v) {
+  v = fmax(v, dppMov<0x141>(v));
+  v = fmax(v, dppMov<0xB1>(v));
+  v = fmax(v, dppMov<0x4E>(v));
+  return v;
+}
+__device__ __forceinline__ int min8i(int v) {
+  v = min(v, dppMovI<0x141>(v));
+  v = min(v, dppMovI<0xB1>(v));
+  v = min(v, dppMovI<0x4E>(v));
+  return v;
+}
+// sum over the wave, in every lane (row rotations + the four row totals through v_readlane)
+__device__ __forceinline__ double readlaneD(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double waveSumAll(double v) {
+  v += dppMov<0x128>(v);   // row_ror:8, 4, 2, 1
+  v += dppMov<0x124>(v);
+  v += dppMov<0x122>(v);
+  v += dppMov<0x121>(v);
+  return (readlaneD(v, 0) + readlaneD(v, 16)) + (readlaneD(v, 32) + readlaneD(v, 48));
+}
+
+// ---------------------------------------------------------------------------------------------- stage 1: tridiagonalisation
+// Householder reduction of the symmetric matrix in Q (full storage, row-major, leading dimension ld) to tridiagonal form,
+// unblocked (LAPACK dsytd2, lower): per column k one reflector H_k = I - tau v v^T, v = (1, A[k+2.., k] / (alpha - beta)),
+// A22 <- A22 - v w^T - w v^T with w = p - (tau / 2)(p.v) v, p = tau A22 v.  d, e, tau go to S; v stays below the sub-diagonal
+// of column k.  Four LDS-only barriers per column.
+__device__ __forceinline__ void tridiagonalize(lds_double* Q, int n, int ld) {
+  Small& S = gS;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  for (int k = 0; k + 2 < n; ++k) {
+    const int m = n - k - 1;
+    if (wave == 0) {
+      double s = 0;
+      for (int i = k + 2 + lane; i < n; i += 64) { const double x = Q[i * ld + k]; s += x * x; }
+      s = waveSumAll(s);
+      const double alpha = Q[(k + 1) * ld + k];
+      double beta = alpha, tk = 0.0, scale = 0.0;
+      if (s != 0.0) {
+        beta = -copysign(sqrt(alpha * alpha + s), alpha);
+        tk = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      for (int i = k + 1 + lane; i < n; i += 64) {
+        const double v = (i == k + 1) ? 1.0 : Q[i * ld + k] * scale;
+        S.u.hh.v[0][i] = v;
+        if (i > k + 1) Q[i * ld + k] = v;
+      }
+      if (lane == 0) { S.tau[k] = tk; S.e[k] = beta; S.d[k] = Q[k * ld + k]; }
+    }
+    ldsBarrier();
+    const double tk = S.tau[k];
+    if (tk != 0.0) {   // (uniform)
+      const int r = t >> 3, sub = t & 7, i = k + 1 + r;
+      {
+        double s = 0;
+        if (r < m)
+          for (int j = k + 1 + sub; j < n; j += 8) s += Q[i * ld + j] * S.u.hh.v[0][j];
+        s = sum8(s);
+        if (r < m && sub == 0) S.u.hh.p[i] = tk * s;
+      }
+      ldsBarrier();
+      if (wave == 0) {
+        double s = 0;
+        for (int q = k + 1 + lane; q < n; q += 64) s += S.u.hh.p[q] * S.u.hh.v[0][q];
+        s = waveSumAll(s);
+        const double al = -0.5 * tk * s;
+        for (int q = k + 1 + lane; q < n; q += 64) S.u.hh.w[q] = S.u.hh.p[q] + al * S.u.hh.v[0][q];
+      }
+      ldsBarrier();
+      if (r < m) {
+        const double vi = S.u.hh.v[0][i], wi = S.u.hh.w[i];
+        for (int j = k + 1 + sub; j < n; j += 8) Q[i * ld + j] -= vi * S.u.hh.w[j] + wi * S.u.hh.v[0][j];
+      }
+      ldsBarrier();
+    }
+  }
+  if (t == 0) {
+    if (n >= 2) {
+      S.d[n - 2] = Q[(n - 2) * ld + (n - 2)];
+      S.e[n - 2] = Q[(n - 1) * ld + (n - 2)];
+      S.tau[n - 2] = 0.0;
+    }
+    S.d[n - 1] = Q[(n - 1) * ld + (n - 1)];
+    S.e[n - 1] = 0.0;
+    S.tau[n - 1] = 0.0;
+  }
+  ldsBarrier();
+}
+
+// ---------------------------------------------------------------------------------------------- stage 2: divide and conquer
+// step x with c + S / (dI - x) + R / (dJ - x) = 0 and lo < tau + x < hi; NaN if there is none
+__device__ __forceinline__ double quadRootIn(double c, double S, double dI, double R, double dJ, double lo, double hi, double tau) {
+  const double a = c, b = -(c * (dI + dJ) + S + R), cc = c * dI * dJ + S * dJ + R * dI;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if (a == 0.0) {
+    const double x = (b != 0.0) ? cc / (-b) : nan;
+    return (x == x && lo < tau + x && tau + x < hi) ? x : nan;
+  }
+  const double disc = b * b - 4.0 * a * cc;
+  if (!(disc >= 0.0)) return nan;
+  const double q = -0.5 * (b + copysign(sqrt(disc), b));
+  const double x1 = q / a, x2 = (q != 0.0) ? cc / q : nan;
+  if (x1 == x1 && lo < tau + x1 && tau + x1 < hi) return x1;
+  if (x2 == x2 && lo < tau + x2 && tau + x2 < hi) return x2;
+  return nan;
+}
+
+// Root i (0-based, ascending) of 1 + rho sum_k z_k^2 / (d_k - lambda) over the K compact poles cd[0..K) (strictly ascending)
+// with weights cz[k]^2 > 0: lambda = cd[org] + tau, org the nearer of the two poles that bracket the root (the last root: the
+// last pole), so that d_k - lambda = (cd[k] - cd[org]) - tau carries no cancellation.  Executed by an aligned group of 8 lanes
+// (sub = lane in the group: the pole sums are split over them, every scalar decision is taken redundantly and identically).
+// Each step keeps the origin pole with its exact weight and models everything else as r + R / (d_q - x), fitted to value and
+// slope, q = the pole that dominates that slope (dlaed4's fixed-weight scheme with the fitted pole chosen by dominance); the
+// bracket is kept, a step that leaves it is replaced by regula falsi (Illinois).  `active` = this group has a root to find;
+// inactive groups run along (the reductions need every lane) on harmless numbers.
+__device__ __forceinline__ void secularRoot(bool active, int i, int K, const double* cd, const double* cz, double rho, int sub,
+                            int& orgOut, double& tauOut) {
+  if (!active) { i = 0; K = 1; }
+  int org = 0, I = i;
+  double tau = 0.0, lo = 0.0, hi = 0.0;
+  const bool last = (i == K - 1);
+  bool done = !active;
+  if (K == 1) {
+    const double z = active ? (double)cz[0] : 1.0;
+    tau = rho * z * z;
+    done = true;
+  } else if (!last) {
+    const int J = i + 1;
+    const double dI0 = cd[I], gap = cd[J] - dI0, mid = 0.5 * gap;
+    double s = 0;
+    for (int k = sub; k < K; k += 8)
+      if (k != I && k != J) { const double z = cz[k]; s += z * z / ((cd[k] - dI0) - mid); }
+    s = sum8(s);
+    const double zI = cz[I], zJ = cz[J];
+    const double rest = 1.0 + rho * s, SI = rho * zI * zI, SJ = rho * zJ * zJ;
+    const double f = rest + SI / (-mid) + SJ / (gap - mid);
+    double dI, dJ;
+    if (f > 0) { org = I; lo = 0.0; hi = mid; dI = 0.0; dJ = gap; }
+    else { org = J; lo = -mid; hi = 0.0; dI = -gap; dJ = 0.0; }
+    const double x = quadRootIn(rest, SI, dI, SJ, dJ, lo, hi, 0.0);
+    tau = (x == x) ? x : 0.5 * (lo + hi);
+  } else {
+    org = K - 1;
+    const double dO = cd[org];
+    double s2 = 0;
+    for (int k = sub; k < K; k += 8) { const double z = cz[k]; s2 += z * z; }
+    s2 = sum8(s2);
+    lo = 0.0; hi = rho * s2;
+    const double mid = 0.5 * hi;
+    double s = 0;
+    for (int k = sub; k < K - 2; k += 8) { const double z = cz[k]; s += z * z / ((cd[k] - dO) - mid); }
+    s = sum8(s);
+    const double zA = cz[K - 2], zB = cz[K - 1];
+    const double x = quadRootIn(1.0 + rho * s, rho * zA * zA, cd[K - 2] - dO, rho * zB * zB, 0.0, lo, hi, 0.0);
+    tau = (x == x) ? x : mid;
+  }
+  const double dOrg = cd[org], zO = cz[org], So = rho * zO * zO;
+  double flo = 0.0, fhi = 0.0;
+  bool haveLo = false, haveHi = false;
+  int side = 0;
+  for (int it = 0; it < 48; ++it) {
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;   // (wave-uniform)
+    double psi = 0, phi = 0, dpsi = 0, dphi = 0, best = -1.0;
+    int bestk = 0x7fffffff;
+    for (int k = sub; k < K; k += 8) {
+      const double den = (cd[k] - dOrg) - tau;
+      const double r = 1.0 / den, z = cz[k];
+      const double tt = z * z * r, t2 = tt * r;
+      if (k <= I || last) { psi += tt; dpsi += t2; }
+      else { phi += tt; dphi += t2; }
+      if (k != org && t2 > best) { best = t2; bestk = k; }
+    }
+    psi = rho * sum8(psi); phi = rho * sum8(phi); dpsi = rho * sum8(dpsi); dphi = rho * sum8(dphi);
+    const double bmax = max8(best);
+    bestk = min8i(best == bmax ? bestk : 0x7fffffff);
+    if (done) continue;
+    const double f = 1.0 + psi + phi;
+    const double erretm = 8.0 * (fabs(psi) + fabs(phi)) + 2.0 + fabs(tau) * (dpsi + dphi);
+    if (fabs(f) <= kEps * erretm || !(f == f)) { done = true; continue; }
+    if (f > 0) {
+      hi = tau; fhi = f; haveHi = true;
+      if (side == 1 && haveLo) flo *= 0.5;
+      side = 1;
+    } else {
+      lo = tau; flo = f; haveLo = true;
+      if (side == -1 && haveHi) fhi *= 0.5;
+      side = -1;
+    }
+    if (hi - lo <= 4.0 * kEps * fmax(fabs(lo), fabs(hi))) { done = true; continue; }
+    const double dO = -tau;
+    const double dq = (cd[bestk < K ? bestk : org] - dOrg) - tau;
+    const double w = psi + phi - So / dO, dw = dpsi + dphi - So / (dO * dO);
+    const double R = dw * dq * dq, r0 = w - dw * dq;
+    const double x = (bestk < K) ? quadRootIn(1.0 + r0, So, dO, R, dq, lo, hi, tau) : __longlong_as_double(0x7ff8000000000000LL);
+    double nw = tau + x;
+    if (!(x == x) || !(lo < nw && nw < hi)) {
+      nw = 0.5 * (lo + hi);
+      if (haveLo && haveHi && fhi != flo) {
+        const double rf = lo - flo * (hi - lo) / (fhi - flo);
+        if (lo < rf && rf < hi) nw = rf;
+      }
+    }
+    tau = nw;
+  }
+  orgOut = org;
+  tauOut = tau;
+}
+
+// One level of the bottom-up recursion: every pair of solved neighbouring blocks [lo, lo + b) | [lo + b, min(lo + 2b, n)) is
+// merged.  T restricted to the pair = diag(T1', T2') + |e_k| w w^T, w = e_k-hat + sign(e_k) e_(k+1)-hat, k = lo + b - 1 (the
+// tear was subtracted from d_k, d_(k+1) before the leaves were "solved"), so in the basis of the two solved halves the pair is
+// D + rho z z^T with z = (last row of Q1 | sign * first row of Q2) / sqrt 2, rho = 2 |e_k|  (LAPACK dlaed1 .. dlaed3).
+__device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) {
+  Small& S = gS;
+  const int t = threadIdx.x;
+  auto& D = S.u.dc;
+  const int two = 2 * b;
+  // ---- 1: z, the merged order of the poles
+  if (t < n) {
+    const int c = t, lo = (c / two) * two, mid = lo + b, hi = min(lo + two, n);
+    if (mid < n) {
+      const int k = mid - 1;
+      const double sg = (S.e[k] >= 0.0) ? 1.0 : -1.0;
+      const double z = (c < mid) ? Q[k * ld + c] : sg * Q[(k + 1) * ld + c];
+      D.z[c] = z * 0.70710678118654752440;
+      const double dc = S.d[c];
+      D.dcur[c] = dc;
+      int rank = 0;
+      for (int q = lo; q < hi; ++q) { const double dq = S.d[q]; rank += (dq < dc || (dq == dc && q < c)) ? 1 : 0; }
+      D.sorted[lo + rank] = c;
+    }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 2: deflation (dlaed2), one lane per pair of blocks, in the merged order
+  if (t < n && (t % two) == 0 && t + b < n) {
+    const int lo = t, mid = lo + b, hi = min(lo + two, n), m = hi - lo, k = mid - 1;
+    const double rho = 2.0 * fabs(S.e[k]);
+    double dmax = 0, zmax = 0;
+    for (int q = lo; q < hi; ++q) { dmax = fmax(dmax, fabs(D.dcur[q])); zmax = fmax(zmax, fabs(D.z[q])); }
+    const double tol = 8.0 * kEps * fmax(dmax, zmax);
+    int K = 0, nd = 0, nr = 0;
+    if (rho * zmax <= tol) {
+      for (int s = 0; s < m; ++s) { const int idx = D.sorted[lo + s]; D.kind[idx] = 1; D.dfl[lo + nd++] = idx; }
+    } else {
+      int pj = -1;
+      for (int s = 0; s < m; ++s) {
+        const int idx = D.sorted[lo + s];
+        if (rho * fabs(D.z[idx]) <= tol) { D.kind[idx] = 1; D.dfl[lo + nd++] = idx; continue; }
+        if (pj < 0) { pj = idx; continue; }
+        const int nj = idx;
+        double sn = D.z[pj], cs = D.z[nj];
+        const double tau = hypot(cs, sn), tt = D.dcur[nj] - D.dcur[pj];
+        cs /= tau; sn = -sn / tau;
+        if (fabs(tt * cs * sn) <= tol) {   // two close poles: rotate the weight of pj into nj
+          D.z[nj] = tau; D.z[pj] = 0.0;
+          D.rotP[lo + nr] = pj; D.rotQ[lo + nr] = nj; D.rotC[lo + nr] = cs; D.rotS[lo + nr] = sn; ++nr;
+          const double dp = D.dcur[pj], dn = D.dcur[nj];
+          D.dcur[pj] = dp * cs * cs + dn * sn * sn;
+          D.dcur[nj] = dp * sn * sn + dn * cs * cs;
+          D.kind[pj] = 1; D.dfl[lo + nd++] = pj;
+          pj = nj;
+        } else {
+          D.kind[pj] = 0; D.ndl[lo + K++] = pj;
+          pj = nj;
+        }
+      }
+      if (pj >= 0) { D.kind[pj] = 0; D.ndl[lo + K++] = pj; }
+    }
+    for (int q = 0; q < K; ++q) { const int c = D.ndl[lo + q]; D.cd[lo + q] = D.dcur[c]; D.cz[lo + q] = D.z[c]; }
+    for (int q = 0; q < nd; ++q) { const int c = D.dfl[lo + q]; D.newd[lo + K + q] = D.dcur[c]; D.ztil[c] = 0.0; }
+    D.K[lo] = K; D.nrot[lo] = nr;
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 3: the deflation rotations on the columns of Q (one thread per row, the list in order)
+  if (t < n) {
+    const int r = t, lo = (r / two) * two;
+    if (lo + b < n) {
+      const int nr = D.nrot[lo];
+      for (int q = 0; q < nr; ++q) {
+        const int p = D.rotP[lo + q], qq = D.rotQ[lo + q];
+        const double cs = D.rotC[lo + q], sn = D.rotS[lo + q];
+        const double x = Q[r * ld + p], y = Q[r * ld + qq];
+        Q[r * ld + p] = cs * x + sn * y;
+        Q[r * ld + qq] = cs * y - sn * x;
+      }
+    }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 4: secular equation, 8 lanes per root
+  {
+    const int g = t >> 3, sub = t & 7;
+    const int lo = (g / two) * two;
+    const bool merged = g < n && lo + b < n;
+    const int K = merged ? D.K[lo] : 0, i = g - lo;
+    const bool active = merged && i < K;
+    const double rho = merged ? 2.0 * fabs(S.e[lo + b - 1]) : 1.0;
+    int org; double tau;
+    secularRoot(active, i, K, D.cd + lo, D.cz + lo, rho, sub, org, tau);
+    if (active && sub == 0) { D.rorg[g] = org; D.rtau[g] = tau; }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 5: Gu / Eisenstat: the weights for which the computed roots are the exact eigenvalues
+  {
+    const int g = t >> 3, sub = t & 7;
+    const int lo = (g / two) * two;
+    const bool merged = g < n && lo + b < n;
+    const int K = merged ? D.K[lo] : 0, k = g - lo;
+    const bool active = merged && k < K;
+    double prod = 1.0;
+    if (active) {
+      const double dk = D.cd[lo + k];
+      for (int j = sub; j < K; j += 8) {
+        const double num = (D.cd[lo + D.rorg[lo + j]] - dk) + D.rtau[lo + j];   // lambda_j - d_k
+        prod *= (j == k) ? num : num / (D.cd[lo + j] - dk);
+      }
+    }
+    prod = prod8(prod);
+    if (active && sub == 0) {
+      const double rho = 2.0 * fabs(S.e[lo + b - 1]);
+      D.ztil[D.ndl[lo + k]] = copysign(sqrt(fabs(prod) / rho), D.cz[lo + k]);
+    }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 6: the norms of the new vectors, the new eigenvalues
+  {
+    const int g = t >> 3, sub = t & 7;
+    const int lo = (g / two) * two;
+    const bool merged = g < n && lo + b < n;
+    const int K = merged ? D.K[lo] : 0, j = g - lo;
+    const bool active = merged && j < K;
+    double s = 0;
+    if (active) {
+      const double dO = D.cd[lo + D.rorg[g]], tau = D.rtau[g];
+      for (int k = sub; k < K; k += 8) {
+        const double v = D.ztil[D.ndl[lo + k]] / ((D.cd[lo + k] - dO) - tau);
+        s += v * v;
+      }
+    }
+    s = sum8(s);
+    if (active && sub == 0) {
+      D.cinv[g] = 1.0 / sqrt(s);
+      D.newd[g] = D.cd[lo + D.rorg[g]] + D.rtau[g];
+    }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 7: where each new column goes (ascending eigenvalues), what it is made of
+  if (t < n) {
+    const int s = t, lo = (s / two) * two, hi = min(lo + two, n);
+    if (lo + b < n) {
+      const int K = D.K[lo], q = s - lo;
+      const double v = D.newd[s];
+      int rank = 0;
+      for (int r = lo; r < hi; ++r) { const double w = D.newd[r]; rank += (w < v || (w == v && r < s)) ? 1 : 0; }
+      const int o = lo + rank;
+      D.dnext[o] = v;
+      if (q < K) {
+        D.okind[o] = 0;
+        D.oorgd[o] = D.cd[lo + D.rorg[s]];
+        D.otau[o] = D.rtau[s];
+        D.oinv[o] = D.cinv[s];
+      } else {
+        D.okind[o] = 1;
+        D.osrc[o] = D.dfl[lo + q - K];
+      }
+    }
+  }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  // ---- 8: Q <- Q [V | deflated columns] per pair of blocks, 16 x 16 tiles on v_mfma_f64_16x16x4 (A[i = l & 15][k = l >> 4],
+  // B[k = l >> 4][j = l & 15], C: column l & 15, row (l >> 4) + 4 reg).  The B operand is generated on the fly: for a root column
+  // z-hat_k / ((d_k - d_org) - tau) / |v|, for a deflated column a unit vector; at most four tiles per wave, all products in
+  // registers before anything is written (a row of the new Q depends on the same row of the old one only).
+  {
+    const int wave = t >> 6, l = t & 63;
+    d4 acc[4];
+    int tLo[4], tRt[4], tCt[4], tM[4], nTiles = 0;
+    int tileBase = 0;
+    for (int lo = 0; lo + b < n; lo += two) {   // (wave-uniform walk over the pairs)
+      const int m = min(lo + two, n) - lo, tr = (m + 15) >> 4, cnt = tr * tr;
+      for (int id = wave - (tileBase % 16); id < cnt; id += 16) {
+        if (id < 0) continue;
+        if (nTiles < 4) { tLo[nTiles] = lo; tRt[nTiles] = id / tr; tCt[nTiles] = id % tr; tM[nTiles] = m; ++nTiles; }
+      }
+      tileBase += cnt;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+      if (q < nTiles) {
+        const int lo = tLo[q], m = tM[q], hi = lo + m;
+        const int r = lo + tRt[q] * 16 + (l & 15), o = lo + tCt[q] * 16 + (l & 15);
+        const bool rOk = r < hi, oOk = o < hi;
+        const int ok = oOk ? D.okind[o] : 1, osrc = oOk ? D.osrc[o] : -1;
+        const double od = oOk ? D.oorgd[o] : 0.0, ot = oOk ? D.otau[o] : 1.0, oi = oOk ? D.oinv[o] : 0.0;
+        for (int kk = 0; kk < m; kk += 4) {
+          const int kc = lo + kk + (l >> 4);
+          const bool kOk = kc < hi;
+          const double a = (rOk && kOk) ? (double)Q[r * ld + kc] : 0.0;
+          double bv = 0.0;
+          if (kOk && oOk) {
+            if (ok == 1) bv = (kc == osrc) ? 1.0 : 0.0;
+            else if (D.kind[kc] == 0) bv = D.ztil[kc] / ((D.dcur[kc] - od) - ot) * oi;
+          }
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    ldsBarrier();
+    SYMEIG_STAMP();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nTiles) {
+        const int lo = tLo[q], hi = lo + tM[q];
+        const int o = lo + tCt[q] * 16 + (l & 15);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = lo + tRt[q] * 16 + (l >> 4) + 4 * rg;
+          if (r < hi && o < hi) Q[r * ld + o] = acc[q][rg];
+        }
+      }
+    if (t < n) {
+      const int lo = (t / two) * two;
+      if (lo + b < n) S.d[t] = D.dnext[t];
+    }
+  }
+  ldsBarrier();
+}
+
+// Eigen-decomposition of the symmetric matrix in Q (LDS, n x ld, full storage).  On return Q[i * ld + j] = component i of
+// eigenvector j, S.d[j] = eigenvalue j (ascending).  gV: n * n doubles of global scratch (the Householder vectors wait there
+// while the image is the eigenvector matrix of T); the small arrays live in gS.  All kThreads threads of the workgroup must call.  Returns false (uniformly)
+// if a result is not finite.
+__device__ __forceinline__ bool solve(lds_double* Q, int n, int ld, double* gV) {
+  Small& S = gS;
+  const int t = threadIdx.x;
+  if (t == 0) { S.bad = 0; S.nstamp = 0; }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  tridiagonalize(Q, n, ld);
+  SYMEIG_STAMP();
+  for (int idx = t; idx < n * n; idx += kThreads) { const int i = idx / n, j = idx - i * n; gV[idx] = Q[i * ld + j]; }
+  __syncthreads();
+  // leaves: every adjacent pair is torn at some level, so leaf j starts as d_j - |e_(j-1)| - |e_j|
+  if (t < n) S.d[t] = S.d[t] - (t > 0 ? fabs(S.e[t - 1]) : 0.0) - (t + 1 < n ? fabs(S.e[t]) : 0.0);
+  for (int idx = t; idx < n * ld; idx += kThreads) { const int i = idx / ld, j = idx - i * ld; Q[idx] = (i == j) ? 1.0 : 0.0; }
+  ldsBarrier();
+  SYMEIG_STAMP();
+  for (int b = 1; b < n; b <<= 1) mergeLevel(Q, n, ld, b);
+  SYMEIG_STAMP();
+  // back-transformation: X = H_0 H_1 ... H_(n-3) Z, the reflectors in reverse order; v_k from global memory one step ahead
+  {
+    auto& B = S.u.bt;
+    const int j = t & 127, sl = t >> 7;
+    int buf = 0;
+    if (n >= 3 && t < n) B.v[0][t] = (t >= n - 1) ? gV[t * n + (n - 3)] : 0.0;
+    ldsBarrier();
+    for (int k = n - 3; k >= 0; --k) {
+      double nextV = 0.0;
+      if (k > 0 && t < n && t >= k + 1) nextV = gV[t * n + (k - 1)];   // rows >= (k - 1) + 2
+      const double tk = S.tau[k];
+      const double* v = B.v[buf];
+      if (tk != 0.0) {
+        double s = 0;
+        if (j < n) {
+          for (int i = k + 1 + sl; i < n; i += 8) s += ((i == k + 1) ? 1.0 : (double)v[i]) * Q[i * ld + j];
+          B.part[sl * kMaxN + j] = s;
+        }
+        ldsBarrier();
+        if (j < n) {
+          double sj = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sj += B.part[q * kMaxN + j];
+          sj *= tk;
+          for (int i = k + 1 + sl; i < n; i += 8) Q[i * ld + j] -= ((i == k + 1) ? 1.0 : (double)v[i]) * sj;
+        }
+      }
+      if (t < n) B.v[buf ^ 1][t] = nextV;
+      buf ^= 1;
+      ldsBarrier();
+    }
+  }
+  SYMEIG_STAMP();
+  if (t < n) {
+    const double lam = S.d[t];
+    double cs = 0;
+    for (int i = 0; i < n; ++i) cs += Q[i * ld + t];
+    if (!(fabs(lam) < 1.0e300) || !(fabs(cs) < 1.0e300)) S.bad = 1;
+  }
+  __syncthreads();
+  return S.bad == 0;
+}
+
+}  // namespace symeig
+}  // namespace svin

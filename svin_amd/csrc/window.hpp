@@ -507,4 +507,7 @@ class Window {
 
 std::string& lastError();
 
+// inspection hook of the prior's eigen-solver (symeig.hpp; marg.hip): eigenvalues (ascending) and eigenvectors (X[i * n + j] =
+// component i of vector j) of a symmetric n x n matrix, n <= 128, on the current device.  1, 0 (n out of range), -1 (not finite).
+int debugSymEig(int n, const double* A, double* lam, double* X, double* deviceMs);
 }  // namespace svin
