@@ -728,7 +728,6 @@ __global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
   const int t = threadIdx.x, n = a.n, ld = n | 1;
   double* p = a.tmp;            // n
   double* ev = a.tmp + n;       // n
-  double* lamp = a.tmp + 2 * n; // n: eigenvalue or 0 (dropped)
   const long long tStart = wall_clock64();
   for (int i = t; i < n; i += 1024) p[i] = margScale(a.H[(size_t)i * n + i]);
   __syncthreads();
@@ -744,13 +743,20 @@ __global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
     if (t == 0) a.flag[4] = 0;
     return;
   }
-  // X[i * ld + j] = component i of eigenvector j, symeig::gS.d[j] = eigenvalue j (ascending)
+  // X[i * ld + j] = component i of eigenvector j, symeig::gS.d[j] = eigenvalue j (ascending).  Per-vector scalars once, in LDS
+  // (the solver's per-phase arrays are free again): sq = sqrt(l) or 0 (dropped), lamp = l or 0, bt = b0 / p
+  double* sq = symeig::gS.u.dc.z;
+  double* lamp = symeig::gS.u.dc.dcur;
+  double* bt = symeig::gS.u.dc.ztil;
+  double* e0s = symeig::gS.u.dc.cd;
   const double mx = symeig::gS.d[n - 1], mn = symeig::gS.d[0];
   const double tol = 2.220446049250313e-16 * n * mx;
   if (t < n) {
     const double l = symeig::gS.d[t];
     ev[t] = l;
     lamp[t] = l > tol ? l : 0.0;
+    sq[t] = l > tol ? sqrt(l) : 0.0;
+    bt[t] = a.b0[t] / p[t];
   }
   if (t < 64) {
     int c = 0;
@@ -759,22 +765,22 @@ __global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (t == 0) { a.flag[2] = c; a.flag[1] = 0; a.scal[1] = mn; a.scal[2] = mx; }
   }
+  symeig::ldsBarrier();
   // e0_j = -(1 / sqrt(l_j)) u_j . (b0 / p): 8 lanes per eigenvector
   {
     const int j = t >> 3, sub = t & 7;
     double s = 0;
     if (j < n)
-      for (int i = sub; i < n; i += 8) s += X[i * ld + j] * (a.b0[i] / p[i]);
+      for (int i = sub; i < n; i += 8) s += X[i * ld + j] * bt[i];
     s = symeig::sum8(s);
-    if (j < n && sub == 0) { const double l = symeig::gS.d[j]; a.e0[j] = l > tol ? -sqrt(1.0 / l) * s : 0.0; }
+    if (j < n && sub == 0) { const double e = sq[j] > 0.0 ? -s / sq[j] : 0.0; a.e0[j] = e; e0s[j] = e; }
   }
   // J = (p U sqrt(S))^T: row j = eigen-direction j
   for (int idx = t; idx < n * n; idx += 1024) {
     const int j = idx / n, i = idx - j * n;
-    const double l = symeig::gS.d[j];
-    a.J[idx] = l > tol ? p[i] * X[i * ld + j] * sqrt(l) : 0.0;
+    a.J[idx] = p[i] * X[i * ld + j] * sq[j];
   }
-  __syncthreads();
+  symeig::ldsBarrier();
   // Ht = J^T J = p (U S U^T) p: 16 x 16 tiles on v_mfma_f64_16x16x4, both operands rows of X
   {
     const int wave = t >> 6, l = t & 63, tr = (n + 15) >> 4;
@@ -799,13 +805,13 @@ __global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
     const int i = t >> 3, sub = t & 7;
     double s = 0;
     if (i < n)
-      for (int j = sub; j < n; j += 8) s += X[i * ld + j] * sqrt(lamp[j]) * a.e0[j];
+      for (int j = sub; j < n; j += 8) s += X[i * ld + j] * (sq[j] * e0s[j]);
     s = symeig::sum8(s);
     if (i < n && sub == 0) a.bp[i] = p[i] * s;
   }
   if (t < 64) {
     double c = 0;
-    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    for (int k = t; k < n; k += 64) c += e0s[k] * e0s[k];
     c = waveSumM(c);
     if (t == 0) {
       a.scal[0] = c;

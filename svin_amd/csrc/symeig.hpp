@@ -14,6 +14,7 @@
 // LAPACK; tests/test_gpu_sym_eig.py holds this code against LAPACK through svin_ba_debug_sym_eig).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace svin {
 namespace symeig {
@@ -29,18 +30,20 @@ constexpr double kEps = 2.220446049250313e-16;
 struct Small {
   double d[kMaxN], e[kMaxN], tau[kMaxN];   // tridiagonal (d becomes the eigenvalues of the solved blocks), Householder scalars
   union {
-    struct { double v[2][kMaxN], p[kMaxN], w[kMaxN]; } hh;                       // tridiagonalisation
-    struct { double v[2][kMaxN], part[8 * kMaxN]; } bt;                          // back-transformation
+    struct { double v[kMaxN], p[kMaxN], w[kMaxN]; } hh;                          // tridiagonalisation
+    struct { double v[2][4][kMaxN]; } bt;                                        // back-transformation: two blocks of four reflectors
     struct {
       double z[kMaxN], dcur[kMaxN], ztil[kMaxN];     // per column of the merge: z, d after the deflation rotations, z-hat (0: deflated)
       double cd[kMaxN], cz[kMaxN];                   // compact (non-deflated, ascending) poles and weights of each block, at [lo, lo + K)
       double rtau[kMaxN], cinv[kMaxN], newd[kMaxN];  // per root: tau, 1 / |v_j|; eigenvalues of the merged block before the final sort
       double oorgd[kMaxN], otau[kMaxN], oinv[kMaxN], dnext[kMaxN];   // per OUTPUT column
       double rotC[kMaxN], rotS[kMaxN];
+      double ds[kMaxN], zs[kMaxN];                   // d and z in the merged (ascending) order of each pair
       int sorted[kMaxN], kind[kMaxN], ndl[kMaxN], dfl[kMaxN], rorg[kMaxN];
       int okind[kMaxN], osrc[kMaxN], rotP[kMaxN], rotQ[kMaxN], K[kMaxN], nrot[kMaxN];
     } dc;
   } u;
+  double tblk[kMaxN / 4][10];   // the 4 x 4 upper-triangular T of every block of four reflectors (compact WY)
   int bad;
   long long stamp[80];   // 100 MHz wall-clock stamps of the stages (SVIN_SYMEIG_TIMING builds: tools/symeig_time.py)
   int nstamp;
@@ -95,6 +98,29 @@ __device__ __forceinline__ int min8i(int v) {
   v = min(v, dppMovI<0x4E>(v));
   return v;
 }
+// the same over aligned groups of G = 1, 2 or 8 lanes
+template <int G> __device__ __forceinline__ double sumG(double v) {
+  if (G == 8) return sum8(v);
+  if (G == 2) return v + dppMov<0xB1>(v);
+  return v;
+}
+template <int G> __device__ __forceinline__ double maxG(double v) {
+  if (G == 8) return max8(v);
+  if (G == 2) return fmax(v, dppMov<0xB1>(v));
+  return v;
+}
+template <int G> __device__ __forceinline__ int minGi(int v) {
+  if (G == 8) return min8i(v);
+  if (G == 2) return min(v, dppMovI<0xB1>(v));
+  return v;
+}
+// 1 / d by v_rcp_f64 and two Newton steps (the IEEE division sequence is ~4 x as many instructions; these loops do K^2 of them)
+__device__ __forceinline__ double fastRcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
 // sum over the wave, in every lane (row rotations + the four row totals through v_readlane)
 __device__ __forceinline__ double readlaneD(double v, int lane) {
   const long long b = __double_as_longlong(v);
@@ -119,6 +145,7 @@ __device__ __forceinline__ void tridiagonalize(lds_double* Q, int n, int ld) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   for (int k = 0; k + 2 < n; ++k) {
     const int m = n - k - 1;
+    if (k == 0 || k == 58) SYMEIG_STAMP();
     if (wave == 0) {
       double s = 0;
       for (int i = k + 2 + lane; i < n; i += 64) { const double x = Q[i * ld + k]; s += x * x; }
@@ -132,36 +159,40 @@ __device__ __forceinline__ void tridiagonalize(lds_double* Q, int n, int ld) {
       }
       for (int i = k + 1 + lane; i < n; i += 64) {
         const double v = (i == k + 1) ? 1.0 : Q[i * ld + k] * scale;
-        S.u.hh.v[0][i] = v;
+        S.u.hh.v[i] = v;
         if (i > k + 1) Q[i * ld + k] = v;
       }
       if (lane == 0) { S.tau[k] = tk; S.e[k] = beta; S.d[k] = Q[k * ld + k]; }
     }
     ldsBarrier();
+    if (k == 0 || k == 58) SYMEIG_STAMP();
     const double tk = S.tau[k];
     if (tk != 0.0) {   // (uniform)
       const int r = t >> 3, sub = t & 7, i = k + 1 + r;
       {
         double s = 0;
         if (r < m)
-          for (int j = k + 1 + sub; j < n; j += 8) s += Q[i * ld + j] * S.u.hh.v[0][j];
+          for (int j = k + 1 + sub; j < n; j += 8) s += Q[i * ld + j] * S.u.hh.v[j];
         s = sum8(s);
         if (r < m && sub == 0) S.u.hh.p[i] = tk * s;
       }
       ldsBarrier();
+      if (k == 0 || k == 58) SYMEIG_STAMP();
       if (wave == 0) {
         double s = 0;
-        for (int q = k + 1 + lane; q < n; q += 64) s += S.u.hh.p[q] * S.u.hh.v[0][q];
+        for (int q = k + 1 + lane; q < n; q += 64) s += S.u.hh.p[q] * S.u.hh.v[q];
         s = waveSumAll(s);
         const double al = -0.5 * tk * s;
-        for (int q = k + 1 + lane; q < n; q += 64) S.u.hh.w[q] = S.u.hh.p[q] + al * S.u.hh.v[0][q];
+        for (int q = k + 1 + lane; q < n; q += 64) S.u.hh.w[q] = S.u.hh.p[q] + al * S.u.hh.v[q];
       }
       ldsBarrier();
+      if (k == 0 || k == 58) SYMEIG_STAMP();
       if (r < m) {
-        const double vi = S.u.hh.v[0][i], wi = S.u.hh.w[i];
-        for (int j = k + 1 + sub; j < n; j += 8) Q[i * ld + j] -= vi * S.u.hh.w[j] + wi * S.u.hh.v[0][j];
+        const double vi = S.u.hh.v[i], wi = S.u.hh.w[i];
+        for (int j = k + 1 + sub; j < n; j += 8) Q[i * ld + j] -= vi * S.u.hh.w[j] + wi * S.u.hh.v[j];
       }
       ldsBarrier();
+      if (k == 0 || k == 58) SYMEIG_STAMP();
     }
   }
   if (t == 0) {
@@ -203,6 +234,7 @@ __device__ __forceinline__ double quadRootIn(double c, double S, double dI, doub
 // slope, q = the pole that dominates that slope (dlaed4's fixed-weight scheme with the fitted pole chosen by dominance); the
 // bracket is kept, a step that leaves it is replaced by regula falsi (Illinois).  `active` = this group has a root to find;
 // inactive groups run along (the reductions need every lane) on harmless numbers.
+template <int G>
 __device__ __forceinline__ void secularRoot(bool active, int i, int K, const double* cd, const double* cz, double rho, int sub,
                             int& orgOut, double& tauOut) {
   if (!active) { i = 0; K = 1; }
@@ -218,9 +250,9 @@ __device__ __forceinline__ void secularRoot(bool active, int i, int K, const dou
     const int J = i + 1;
     const double dI0 = cd[I], gap = cd[J] - dI0, mid = 0.5 * gap;
     double s = 0;
-    for (int k = sub; k < K; k += 8)
-      if (k != I && k != J) { const double z = cz[k]; s += z * z / ((cd[k] - dI0) - mid); }
-    s = sum8(s);
+    for (int k = sub; k < K; k += G)
+      if (k != I && k != J) { const double z = cz[k]; s += z * z * fastRcp((cd[k] - dI0) - mid); }
+    s = sumG<G>(s);
     const double zI = cz[I], zJ = cz[J];
     const double rest = 1.0 + rho * s, SI = rho * zI * zI, SJ = rho * zJ * zJ;
     const double f = rest + SI / (-mid) + SJ / (gap - mid);
@@ -233,13 +265,13 @@ __device__ __forceinline__ void secularRoot(bool active, int i, int K, const dou
     org = K - 1;
     const double dO = cd[org];
     double s2 = 0;
-    for (int k = sub; k < K; k += 8) { const double z = cz[k]; s2 += z * z; }
-    s2 = sum8(s2);
+    for (int k = sub; k < K; k += G) { const double z = cz[k]; s2 += z * z; }
+    s2 = sumG<G>(s2);
     lo = 0.0; hi = rho * s2;
     const double mid = 0.5 * hi;
     double s = 0;
-    for (int k = sub; k < K - 2; k += 8) { const double z = cz[k]; s += z * z / ((cd[k] - dO) - mid); }
-    s = sum8(s);
+    for (int k = sub; k < K - 2; k += G) { const double z = cz[k]; s += z * z * fastRcp((cd[k] - dO) - mid); }
+    s = sumG<G>(s);
     const double zA = cz[K - 2], zB = cz[K - 1];
     const double x = quadRootIn(1.0 + rho * s, rho * zA * zA, cd[K - 2] - dO, rho * zB * zB, 0.0, lo, hi, 0.0);
     tau = (x == x) ? x : mid;
@@ -252,17 +284,17 @@ __device__ __forceinline__ void secularRoot(bool active, int i, int K, const dou
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;   // (wave-uniform)
     double psi = 0, phi = 0, dpsi = 0, dphi = 0, best = -1.0;
     int bestk = 0x7fffffff;
-    for (int k = sub; k < K; k += 8) {
+    for (int k = sub; k < K; k += G) {
       const double den = (cd[k] - dOrg) - tau;
-      const double r = 1.0 / den, z = cz[k];
+      const double r = fastRcp(den), z = cz[k];
       const double tt = z * z * r, t2 = tt * r;
       if (k <= I || last) { psi += tt; dpsi += t2; }
       else { phi += tt; dphi += t2; }
       if (k != org && t2 > best) { best = t2; bestk = k; }
     }
-    psi = rho * sum8(psi); phi = rho * sum8(phi); dpsi = rho * sum8(dpsi); dphi = rho * sum8(dphi);
-    const double bmax = max8(best);
-    bestk = min8i(best == bmax ? bestk : 0x7fffffff);
+    psi = rho * sumG<G>(psi); phi = rho * sumG<G>(phi); dpsi = rho * sumG<G>(dpsi); dphi = rho * sumG<G>(dphi);
+    const double bmax = maxG<G>(best);
+    bestk = minGi<G>(best == bmax ? bestk : 0x7fffffff);
     if (done) continue;
     const double f = 1.0 + psi + phi;
     const double erretm = 8.0 * (fabs(psi) + fabs(phi)) + 2.0 + fabs(tau) * (dpsi + dphi);
@@ -279,7 +311,8 @@ __device__ __forceinline__ void secularRoot(bool active, int i, int K, const dou
     if (hi - lo <= 4.0 * kEps * fmax(fabs(lo), fabs(hi))) { done = true; continue; }
     const double dO = -tau;
     const double dq = (cd[bestk < K ? bestk : org] - dOrg) - tau;
-    const double w = psi + phi - So / dO, dw = dpsi + dphi - So / (dO * dO);
+    const double rO = fastRcp(dO);
+    const double w = psi + phi - So * rO, dw = dpsi + dphi - So * rO * rO;
     const double R = dw * dq * dq, r0 = w - dw * dq;
     const double x = (bestk < K) ? quadRootIn(1.0 + r0, So, dO, R, dq, lo, hi, tau) : __longlong_as_double(0x7ff8000000000000LL);
     double nw = tau + x;
@@ -315,49 +348,63 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
       D.z[c] = z * 0.70710678118654752440;
       const double dc = S.d[c];
       D.dcur[c] = dc;
-      int rank = 0;
-      for (int q = lo; q < hi; ++q) { const double dq = S.d[q]; rank += (dq < dc || (dq == dc && q < c)) ? 1 : 0; }
+      // both halves are sorted: own position + the number of elements of the other half in front (ties: the lower index first)
+      int rank, a0, a1;
+      if (c < mid) { rank = c - lo; a0 = mid; a1 = hi; } else { rank = c - mid; a0 = lo; a1 = mid; }
+      {
+        int l0 = a0, l1 = a1;   // first q in [a0, a1) that is NOT in front of c
+        while (l0 < l1) {
+          const int q = (l0 + l1) >> 1;
+          const double dq = S.d[q];
+          if (dq < dc || (dq == dc && q < c)) l0 = q + 1; else l1 = q;
+        }
+        rank += l0 - a0;
+      }
       D.sorted[lo + rank] = c;
+      D.ds[lo + rank] = dc;
+      D.zs[lo + rank] = z * 0.70710678118654752440;
     }
   }
   ldsBarrier();
   SYMEIG_STAMP();
-  // ---- 2: deflation (dlaed2), one lane per pair of blocks, in the merged order
+  // ---- 2: deflation (dlaed2), one lane per pair of blocks, walking the merged order.  The state of the walk (the last pole that
+  // still carries weight: index, d, z) lives in registers and the next element is requested before the current one is
+  // processed, so a step is ~40 dependent instructions instead of four dependent LDS round trips.
   if (t < n && (t % two) == 0 && t + b < n) {
     const int lo = t, mid = lo + b, hi = min(lo + two, n), m = hi - lo, k = mid - 1;
     const double rho = 2.0 * fabs(S.e[k]);
     double dmax = 0, zmax = 0;
-    for (int q = lo; q < hi; ++q) { dmax = fmax(dmax, fabs(D.dcur[q])); zmax = fmax(zmax, fabs(D.z[q])); }
+    for (int q = lo; q < hi; ++q) { dmax = fmax(dmax, fabs(D.ds[q])); zmax = fmax(zmax, fabs(D.zs[q])); }
     const double tol = 8.0 * kEps * fmax(dmax, zmax);
     int K = 0, nd = 0, nr = 0;
     if (rho * zmax <= tol) {
       for (int s = 0; s < m; ++s) { const int idx = D.sorted[lo + s]; D.kind[idx] = 1; D.dfl[lo + nd++] = idx; }
     } else {
       int pj = -1;
+      double dP = 0, zP = 0;
+      int idxN = D.sorted[lo];
+      double dN = D.ds[lo], zN = D.zs[lo];
       for (int s = 0; s < m; ++s) {
-        const int idx = D.sorted[lo + s];
-        if (rho * fabs(D.z[idx]) <= tol) { D.kind[idx] = 1; D.dfl[lo + nd++] = idx; continue; }
-        if (pj < 0) { pj = idx; continue; }
-        const int nj = idx;
-        double sn = D.z[pj], cs = D.z[nj];
-        const double tau = hypot(cs, sn), tt = D.dcur[nj] - D.dcur[pj];
-        cs /= tau; sn = -sn / tau;
-        if (fabs(tt * cs * sn) <= tol) {   // two close poles: rotate the weight of pj into nj
-          D.z[nj] = tau; D.z[pj] = 0.0;
-          D.rotP[lo + nr] = pj; D.rotQ[lo + nr] = nj; D.rotC[lo + nr] = cs; D.rotS[lo + nr] = sn; ++nr;
-          const double dp = D.dcur[pj], dn = D.dcur[nj];
-          D.dcur[pj] = dp * cs * cs + dn * sn * sn;
-          D.dcur[nj] = dp * sn * sn + dn * cs * cs;
+        const int idx = idxN;
+        const double dI = dN, zI = zN;
+        if (s + 1 < m) { idxN = D.sorted[lo + s + 1]; dN = D.ds[lo + s + 1]; zN = D.zs[lo + s + 1]; }
+        if (rho * fabs(zI) <= tol) { D.kind[idx] = 1; D.dfl[lo + nd++] = idx; continue; }
+        if (pj < 0) { pj = idx; dP = dI; zP = zI; continue; }
+        const double tau = sqrt(zI * zI + zP * zP), rt = fastRcp(tau);   // (|z| <= 1: no overflow to guard against)
+        const double cs = zI * rt, sn = -zP * rt, tt = dI - dP;
+        if (fabs(tt * cs * sn) <= tol) {   // two close poles: rotate the weight of pj into this one
+          D.rotP[lo + nr] = pj; D.rotQ[lo + nr] = idx; D.rotC[lo + nr] = cs; D.rotS[lo + nr] = sn; ++nr;
+          D.dcur[pj] = dP * cs * cs + dI * sn * sn;
+          D.z[pj] = 0.0;
           D.kind[pj] = 1; D.dfl[lo + nd++] = pj;
-          pj = nj;
+          dP = dP * sn * sn + dI * cs * cs; zP = tau; pj = idx;
         } else {
-          D.kind[pj] = 0; D.ndl[lo + K++] = pj;
-          pj = nj;
+          D.kind[pj] = 0; D.ndl[lo + K] = pj; D.cd[lo + K] = dP; D.cz[lo + K] = zP; D.dcur[pj] = dP; D.z[pj] = zP; ++K;
+          pj = idx; dP = dI; zP = zI;
         }
       }
-      if (pj >= 0) { D.kind[pj] = 0; D.ndl[lo + K++] = pj; }
+      if (pj >= 0) { D.kind[pj] = 0; D.ndl[lo + K] = pj; D.cd[lo + K] = dP; D.cz[lo + K] = zP; D.dcur[pj] = dP; D.z[pj] = zP; ++K; }
     }
-    for (int q = 0; q < K; ++q) { const int c = D.ndl[lo + q]; D.cd[lo + q] = D.dcur[c]; D.cz[lo + q] = D.z[c]; }
     for (int q = 0; q < nd; ++q) { const int c = D.dfl[lo + q]; D.newd[lo + K + q] = D.dcur[c]; D.ztil[c] = 0.0; }
     D.K[lo] = K; D.nrot[lo] = nr;
   }
@@ -379,17 +426,26 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
   }
   ldsBarrier();
   SYMEIG_STAMP();
-  // ---- 4: secular equation, 8 lanes per root
+  // ---- 4: secular equation.  The scalar part of an iteration (~250 instructions: the quadratic, the safeguards) is executed
+  // by every wave that holds a root: one lane per root up to 8 poles, two for 16, eight beyond (measured at n = 117, us per level
+  // with 8 lanes everywhere: 3.5 10.3 10.0 12.8 15.7 23.0 19.6; with one lane up to 16 poles and two beyond: 1.9 4.7 7.6 14.9 22.5
+  // 57.7 41.2 -- a lane's pole sum is a dependent chain, long sums want many lanes, short ones few waves)
   {
-    const int g = t >> 3, sub = t & 7;
-    const int lo = (g / two) * two;
-    const bool merged = g < n && lo + b < n;
-    const int K = merged ? D.K[lo] : 0, i = g - lo;
-    const bool active = merged && i < K;
-    const double rho = merged ? 2.0 * fabs(S.e[lo + b - 1]) : 1.0;
-    int org; double tau;
-    secularRoot(active, i, K, D.cd + lo, D.cz + lo, rho, sub, org, tau);
-    if (active && sub == 0) { D.rorg[g] = org; D.rtau[g] = tau; }
+    auto run = [&](auto lprTag) {
+      constexpr int G = decltype(lprTag)::value;
+      const int g = t / G, sub = t % G;
+      const int lo = (g / two) * two;
+      const bool merged = g < n && lo + b < n;
+      const int K = merged ? gS.u.dc.K[lo] : 0, i = g - lo;
+      const bool active = merged && i < K;
+      const double rho = merged ? 2.0 * fabs(gS.e[lo + b - 1]) : 1.0;
+      int org; double tau;
+      secularRoot<G>(active, i, K, gS.u.dc.cd + (merged ? lo : 0), gS.u.dc.cz + (merged ? lo : 0), rho, sub, org, tau);
+      if (active && sub == 0) { gS.u.dc.rorg[g] = org; gS.u.dc.rtau[g] = tau; }
+    };
+    if (two <= 8) run(std::integral_constant<int, 1>());
+    else if (two == 16) run(std::integral_constant<int, 2>());
+    else run(std::integral_constant<int, 8>());
   }
   ldsBarrier();
   SYMEIG_STAMP();
@@ -405,7 +461,7 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
       const double dk = D.cd[lo + k];
       for (int j = sub; j < K; j += 8) {
         const double num = (D.cd[lo + D.rorg[lo + j]] - dk) + D.rtau[lo + j];   // lambda_j - d_k
-        prod *= (j == k) ? num : num / (D.cd[lo + j] - dk);
+        prod *= (j == k) ? num : num * fastRcp(D.cd[lo + j] - dk);
       }
     }
     prod = prod8(prod);
@@ -427,7 +483,7 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
     if (active) {
       const double dO = D.cd[lo + D.rorg[g]], tau = D.rtau[g];
       for (int k = sub; k < K; k += 8) {
-        const double v = D.ztil[D.ndl[lo + k]] / ((D.cd[lo + k] - dO) - tau);
+        const double v = D.ztil[D.ndl[lo + k]] * fastRcp((D.cd[lo + k] - dO) - tau);
         s += v * v;
       }
     }
@@ -445,8 +501,19 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
     if (lo + b < n) {
       const int K = D.K[lo], q = s - lo;
       const double v = D.newd[s];
+      // newd = [the K roots, ascending | the deflated values in the order they were deflated]: binary search in the roots,
+      // a walk over the (few) deflated ones; ties: the lower slot first
       int rank = 0;
-      for (int r = lo; r < hi; ++r) { const double w = D.newd[r]; rank += (w < v || (w == v && r < s)) ? 1 : 0; }
+      {
+        int l0 = lo, l1 = lo + K;
+        while (l0 < l1) {
+          const int r = (l0 + l1) >> 1;
+          const double w = D.newd[r];
+          if (w < v || (w == v && r < s)) l0 = r + 1; else l1 = r;
+        }
+        rank = l0 - lo;
+        for (int r = lo + K; r < hi; ++r) { const double w = D.newd[r]; rank += (w < v || (w == v && r < s)) ? 1 : 0; }
+      }
       const int o = lo + rank;
       D.dnext[o] = v;
       if (q < K) {
@@ -464,42 +531,82 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
   SYMEIG_STAMP();
   // ---- 8: Q <- Q [V | deflated columns] per pair of blocks, 16 x 16 tiles on v_mfma_f64_16x16x4 (A[i = l & 15][k = l >> 4],
   // B[k = l >> 4][j = l & 15], C: column l & 15, row (l >> 4) + 4 reg).  The B operand is generated on the fly: for a root column
-  // z-hat_k / ((d_k - d_org) - tau) / |v|, for a deflated column a unit vector; at most four tiles per wave, all products in
-  // registers before anything is written (a row of the new Q depends on the same row of the old one only).
+  // z-hat_k / ((d_k - d_org) - tau) / |v|, for a deflated column a unit vector.  At most four tiles per wave, all products in
+  // registers before anything is written (a row of the new Q depends on the same row of the old one only).  Pairs of more than
+  // 32 columns: a wave takes one column tile and up to four row tiles, so that one generated B serves four products.
   {
     const int wave = t >> 6, l = t & 63;
     d4 acc[4];
     int tLo[4], tRt[4], tCt[4], tM[4], nTiles = 0;
-    int tileBase = 0;
-    for (int lo = 0; lo + b < n; lo += two) {   // (wave-uniform walk over the pairs)
-      const int m = min(lo + two, n) - lo, tr = (m + 15) >> 4, cnt = tr * tr;
-      for (int id = wave - (tileBase % 16); id < cnt; id += 16) {
-        if (id < 0) continue;
-        if (nTiles < 4) { tLo[nTiles] = lo; tRt[nTiles] = id / tr; tCt[nTiles] = id % tr; tM[nTiles] = m; ++nTiles; }
+    const int P = (n - b + two - 1) / two;                 // merged pairs of this level
+    const int loLast = (P - 1) * two, mLast = min(loLast + two, n) - loLast;
+    const int trF = (two + 15) >> 4, trL = (mLast + 15) >> 4;
+    const bool wide = two > 32;
+    if (wide) {   // unit = (pair, column tile, half of the row tiles): at most 16 of them for n <= 128
+      int u = wave;
+      for (int p = 0; p < P; ++p) {
+        const int tr = (p == P - 1) ? trL : trF, nh = (tr + 3) >> 2, cnt = tr * nh;
+        if (u >= 0 && u < cnt) {
+          const int ct = u / nh, rh = u - ct * nh;
+          for (int q = 0; q < 4; ++q)
+            if (4 * rh + q < tr) { tLo[nTiles] = p * two; tRt[nTiles] = 4 * rh + q; tCt[nTiles] = ct; tM[nTiles] = (p == P - 1) ? mLast : two; ++nTiles; }
+        }
+        u -= cnt;
       }
-      tileBase += cnt;
+    } else {
+      const int perF = trF * trF, total = (P - 1) * perF + trL * trL;
+      for (int id = wave; id < total && nTiles < 4; id += 16) {
+        const int p = min(id / perF, P - 1), r = id - p * perF, tr = (p == P - 1) ? trL : trF;
+        tLo[nTiles] = p * two; tRt[nTiles] = r / tr; tCt[nTiles] = r - (r / tr) * tr; tM[nTiles] = (p == P - 1) ? mLast : two; ++nTiles;
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-      if (q < nTiles) {
-        const int lo = tLo[q], m = tM[q], hi = lo + m;
-        const int r = lo + tRt[q] * 16 + (l & 15), o = lo + tCt[q] * 16 + (l & 15);
-        const bool rOk = r < hi, oOk = o < hi;
+    for (int q = 0; q < 4; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    auto genB = [&](int o, bool oOk, int ok, int osrc, double od, double ot, double oi, int kc, bool kOk) -> double {
+      double bv = 0.0;
+      if (kOk && oOk) {
+        if (ok == 1) bv = (kc == osrc) ? 1.0 : 0.0;
+        else if (D.kind[kc] == 0) bv = D.ztil[kc] * fastRcp((D.dcur[kc] - od) - ot) * oi;
+      }
+      return bv;
+    };
+    if (wide) {
+      if (nTiles > 0) {
+        const int lo = tLo[0], m = tM[0], hi = lo + m;
+        const int o = lo + tCt[0] * 16 + (l & 15);
+        const bool oOk = o < hi;
         const int ok = oOk ? D.okind[o] : 1, osrc = oOk ? D.osrc[o] : -1;
         const double od = oOk ? D.oorgd[o] : 0.0, ot = oOk ? D.otau[o] : 1.0, oi = oOk ? D.oinv[o] : 0.0;
+        const int r0 = lo + tRt[0] * 16 + (l & 15);
         for (int kk = 0; kk < m; kk += 4) {
           const int kc = lo + kk + (l >> 4);
           const bool kOk = kc < hi;
-          const double a = (rOk && kOk) ? (double)Q[r * ld + kc] : 0.0;
-          double bv = 0.0;
-          if (kOk && oOk) {
-            if (ok == 1) bv = (kc == osrc) ? 1.0 : 0.0;
-            else if (D.kind[kc] == 0) bv = D.ztil[kc] / ((D.dcur[kc] - od) - ot) * oi;
-          }
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[q], 0, 0, 0);
+          const double bv = genB(o, oOk, ok, osrc, od, ot, oi, kc, kOk);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nTiles) {
+              const int r = r0 + 16 * q;
+              const double a = (r < hi && kOk) ? (double)Q[r * ld + kc] : 0.0;
+              acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[q], 0, 0, 0);
+            }
         }
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < nTiles) {
+          const int lo = tLo[q], m = tM[q], hi = lo + m;
+          const int r = lo + tRt[q] * 16 + (l & 15), o = lo + tCt[q] * 16 + (l & 15);
+          const bool rOk = r < hi, oOk = o < hi;
+          const int ok = oOk ? D.okind[o] : 1, osrc = oOk ? D.osrc[o] : -1;
+          const double od = oOk ? D.oorgd[o] : 0.0, ot = oOk ? D.otau[o] : 1.0, oi = oOk ? D.oinv[o] : 0.0;
+          for (int kk = 0; kk < m; kk += 4) {
+            const int kc = lo + kk + (l >> 4);
+            const bool kOk = kc < hi;
+            const double a = (rOk && kOk) ? (double)Q[r * ld + kc] : 0.0;
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, genB(o, oOk, ok, osrc, od, ot, oi, kc, kOk), acc[q], 0, 0, 0);
+          }
+        }
     }
     ldsBarrier();
     SYMEIG_STAMP();
@@ -522,6 +629,43 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
   ldsBarrier();
 }
 
+// The triangular factors of the compact WY form of every block of four consecutive reflectors (LAPACK dlarft, forward /
+// columnwise): H_a H_(a+1) H_(a+2) H_(a+3) = I - V T V^T, T_cc = tau_c, T(0:c, c) = -tau_c T(0:c, 0:c) (V^T v_c)(0:c).  Computed
+// while the reflectors still sit below the sub-diagonal of the image: 8 lanes per inner product v_c . v_c' (six per block).
+__device__ __forceinline__ void tBlocks(lds_double* Q, int n, int ld) {
+  Small& S = gS;
+  const int t = threadIdx.x, nref = n - 2, nblk = (nref + 3) >> 2;
+  if (nref <= 0) return;
+  auto vAt = [&](int k, int i) -> double {   // component i of v_k
+    return (k >= nref || S.tau[k] == 0.0) ? 0.0 : (i == k + 1 ? 1.0 : (i > k + 1 ? (double)Q[i * ld + k] : 0.0));
+  };
+  for (int base = 0; base < nblk * 6; base += kThreads / 8) {
+    const int id = base + (t >> 3), sub = t & 7;
+    const int blk = id / 6, pr = id - 6 * blk;
+    const int c0 = pr < 3 ? 0 : (pr < 5 ? 1 : 2), c1 = pr < 3 ? pr + 1 : (pr < 5 ? pr - 1 : 3);   // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    double g = 0;
+    if (blk < nblk) {
+      const int k0 = 4 * blk + c0, k1 = 4 * blk + c1;
+      for (int i = k1 + 1 + sub; i < n; i += 8) g += vAt(k0, i) * vAt(k1, i);
+    }
+    g = sum8(g);
+    if (blk < nblk && sub == 0) S.tblk[blk][pr < 3 ? pr + 1 : (pr < 5 ? pr + 2 : 8)] = g;   // G01 G02 G03 -> [1..3], G12 G13 -> [5..6], G23 -> [8]
+  }
+  ldsBarrier();
+  if (t < nblk) {
+    double* T = S.tblk[t];
+    auto tauAt = [&](int c) { const int k = 4 * t + c; return k < nref ? S.tau[k] : 0.0; };
+    const double g01 = T[1], g02 = T[2], g03 = T[3], g12 = T[5], g13 = T[6], g23 = T[8];
+    const double t0 = tauAt(0), t1 = tauAt(1), t2 = tauAt(2), t3 = tauAt(3);
+    const double T00 = t0, T11 = t1, T22 = t2, T33 = t3;
+    const double T01 = -t1 * T00 * g01;
+    const double T02 = -t2 * (T00 * g02 + T01 * g12), T12 = -t2 * T11 * g12;
+    const double T03 = -t3 * (T00 * g03 + T01 * g13 + T02 * g23), T13 = -t3 * (T11 * g13 + T12 * g23), T23 = -t3 * T22 * g23;
+    T[0] = T00; T[1] = T01; T[2] = T02; T[3] = T03; T[4] = T11; T[5] = T12; T[6] = T13; T[7] = T22; T[8] = T23; T[9] = T33;
+  }
+  ldsBarrier();
+}
+
 // Eigen-decomposition of the symmetric matrix in Q (LDS, n x ld, full storage).  On return Q[i * ld + j] = component i of
 // eigenvector j, S.d[j] = eigenvalue j (ascending).  gV: n * n doubles of global scratch (the Householder vectors wait there
 // while the image is the eigenvector matrix of T); the small arrays live in gS.  All kThreads threads of the workgroup must call.  Returns false (uniformly)
@@ -533,6 +677,7 @@ __device__ __forceinline__ bool solve(lds_double* Q, int n, int ld, double* gV) 
   ldsBarrier();
   SYMEIG_STAMP();
   tridiagonalize(Q, n, ld);
+  tBlocks(Q, n, ld);
   SYMEIG_STAMP();
   for (int idx = t; idx < n * n; idx += kThreads) { const int i = idx / n, j = idx - i * n; gV[idx] = Q[i * ld + j]; }
   __syncthreads();
@@ -543,35 +688,42 @@ __device__ __forceinline__ bool solve(lds_double* Q, int n, int ld, double* gV) 
   SYMEIG_STAMP();
   for (int b = 1; b < n; b <<= 1) mergeLevel(Q, n, ld, b);
   SYMEIG_STAMP();
-  // back-transformation: X = H_0 H_1 ... H_(n-3) Z, the reflectors in reverse order; v_k from global memory one step ahead
+  // back-transformation: X = H_0 H_1 ... H_(n-3) Z, four reflectors at a time in compact WY form: H_a .. H_(a+3) = I - V T V^T
+  // (T from tBlocks()).  Eight consecutive lanes own one column of Z (the rows dealt round robin), so V^T z, T (V^T z) and the
+  // update need no exchange beyond three DPP steps; the only barrier per block is the one behind the staging of the next V.
   {
     auto& B = S.u.bt;
-    const int j = t & 127, sl = t >> 7;
-    int buf = 0;
-    if (n >= 3 && t < n) B.v[0][t] = (t >= n - 1) ? gV[t * n + (n - 3)] : 0.0;
-    ldsBarrier();
-    for (int k = n - 3; k >= 0; --k) {
-      double nextV = 0.0;
-      if (k > 0 && t < n && t >= k + 1) nextV = gV[t * n + (k - 1)];   // rows >= (k - 1) + 2
-      const double tk = S.tau[k];
-      const double* v = B.v[buf];
-      if (tk != 0.0) {
-        double s = 0;
-        if (j < n) {
-          for (int i = k + 1 + sl; i < n; i += 8) s += ((i == k + 1) ? 1.0 : (double)v[i]) * Q[i * ld + j];
-          B.part[sl * kMaxN + j] = s;
-        }
-        ldsBarrier();
-        if (j < n) {
-          double sj = 0;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) sj += B.part[q * kMaxN + j];
-          sj *= tk;
-          for (int i = k + 1 + sl; i < n; i += 8) Q[i * ld + j] -= ((i == k + 1) ? 1.0 : (double)v[i]) * sj;
-        }
+    const int j = t >> 3, sub = t & 7;
+    const int nref = n - 2, nblk = (nref + 3) >> 2;
+    auto stage = [&](int blk, int buf) {   // V of block blk: v_c[i] for the rows i of the block's support, c = 0 .. 3
+      const int a = 4 * blk;
+      for (int idx = t; idx < 4 * n; idx += kThreads) {
+        const int c = idx / n, i = idx - c * n, k = a + c;
+        double v = 0.0;
+        if (k < nref && S.tau[k] != 0.0) v = (i == k + 1) ? 1.0 : (i > k + 1 ? gV[i * n + k] : 0.0);
+        B.v[buf][c][i] = v;
       }
-      if (t < n) B.v[buf ^ 1][t] = nextV;
-      buf ^= 1;
+    };
+    if (nblk > 0) stage(nblk - 1, 0);
+    ldsBarrier();
+    for (int blk = nblk - 1, buf = 0; blk >= 0; --blk, buf ^= 1) {
+      if (blk > 0) stage(blk - 1, buf ^ 1);
+      const int a = 4 * blk;
+      if (j < n) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int i = a + 1 + sub; i < n; i += 8) {
+          const double q = Q[i * ld + j];
+          s0 += B.v[buf][0][i] * q; s1 += B.v[buf][1][i] * q; s2 += B.v[buf][2][i] * q; s3 += B.v[buf][3][i] * q;
+        }
+        s0 = sum8(s0); s1 = sum8(s1); s2 = sum8(s2); s3 = sum8(s3);
+        const double* T = S.tblk[blk];   // T00 T01 T02 T03 T11 T12 T13 T22 T23 T33
+        const double y0 = T[0] * s0 + T[1] * s1 + T[2] * s2 + T[3] * s3, y1 = T[4] * s1 + T[5] * s2 + T[6] * s3,
+                     y2 = T[7] * s2 + T[8] * s3, y3 = T[9] * s3;
+        for (int i = a + 1 + sub; i < n; i += 8)
+          Q[i * ld + j] -= B.v[buf][0][i] * y0 + B.v[buf][1][i] * y1 + B.v[buf][2][i] * y2 + B.v[buf][3][i] * y3;
+      } else {
+        (void)sum8(0.0); (void)sum8(0.0); (void)sum8(0.0); (void)sum8(0.0);
+      }
       ldsBarrier();
     }
   }
