@@ -1417,24 +1417,44 @@ void Window::pack(bool solveFollows) {
   };
   const SlotCache poseCache(poseSlot_), extCache(extSlot_);
   // landmark order of the CSR: handle order (creation order; id order when ids grow with time, as the reference's IdProvider
-  // makes them); for wide windows sorted by the first pose that observes the landmark, so that a chunk of 16 consecutive
-  // landmarks touches few 96-row panels of the camera matrix (k_schur_panels work list)
+  // makes them); for wide windows sorted by visibility signature (below), so that a chunk of 16 consecutive landmarks
+  // touches few 96-row panels of the camera matrix and the same tile rows inside them (k_schur_panels work list)
   std::vector<const Landmark*> lmOrder;
   if (!resident) {
     lmOrder.reserve(nLmObs);
     for (const Landmark* lm : lmByHandle_)
       if (lm && (!lm->obs.empty() || !lm->priors.empty())) lmOrder.push_back(lm);
     if (poseIds_.size() > (size_t)kResidentPoseCap) {
-      std::vector<std::pair<int, const Landmark*>> keyed;
+      // Wide windows (k_schur_panels): order by VISIBILITY SIGNATURE -- the set of 16-row tiles of the camera matrix a landmark's
+      // observations write to (first tile, last tile, then the bit pattern) -- so that the 16 landmarks of a chunk hit the same
+      // tile rows and the kernel's step masks drop whole products.  A product step (tile row, tile column, 4 columns of G) runs
+      // when both tile rows hold something in those columns; modelled on the host (tools/panel_order_model.py) for the bench
+      // window of configs[3]: executed / algorithmic MFMA flops 9.28 ordered by first pose (measured 9.3), 7.84 by (first, last)
+      // pose, 6.30 by signature.  The rest is granularity: a landmark there sees 9 poses scattered over a span of 28 (its 55 rows
+      // live in ~8 tiles of 16), which no order of the landmarks changes.
+      struct Key { int first, last; uint64_t lo, hi; const Landmark* lm; };
+      std::vector<Key> keyed;
       keyed.reserve(lmOrder.size());
       for (const Landmark* lm : lmOrder) {
-        int first = INT32_MAX;
-        for (const Observation& ob : lm->obs) first = std::min(first, poseCache.at(ob.poseId));
-        if (lm->obs.empty()) first = 0;
-        keyed.emplace_back(first, lm);
+        Key k{INT32_MAX, -1, 0, 0, lm};
+        for (const Observation& ob : lm->obs) {
+          const int off = hPoseOff[poseCache.at(ob.poseId)];
+          if (off < 0) continue;
+          for (int tr : {off >> 4, (off + 5) >> 4}) {
+            k.first = std::min(k.first, tr); k.last = std::max(k.last, tr);
+            if (tr < 64) k.lo |= 1ull << tr; else if (tr < 128) k.hi |= 1ull << (tr - 64);
+          }
+        }
+        if (k.last < 0) k.first = 0;
+        keyed.push_back(k);
       }
-      std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-      for (size_t i = 0; i < keyed.size(); ++i) lmOrder[i] = keyed[i].second;
+      std::stable_sort(keyed.begin(), keyed.end(), [](const Key& a, const Key& b) {
+        if (a.first != b.first) return a.first < b.first;
+        if (a.last != b.last) return a.last < b.last;
+        if (a.hi != b.hi) return a.hi < b.hi;
+        return a.lo < b.lo;
+      });
+      for (size_t i = 0; i < keyed.size(); ++i) lmOrder[i] = keyed[i].lm;
     }
     size_t slot = 0, o = 0;
     hLmPtr[0] = 0;
