@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# cpu_baseline: the oracle's OpenMP regions are short (one evaluation, one Schur elimination per iteration); with the default
+# passive wait policy the workers sleep between them and TWO threads came out slower than one (42 against 25 ms per iteration
+# where spinning workers give 17).  Has to be in the environment before the first OpenMP runtime of the process starts.
+os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
 import numpy as np  # noqa: E402
 
@@ -100,8 +104,9 @@ def cpu_baseline(spec, budget_s=6.0):
                 threads={str(nt): r["value"] for nt, r in rows.items()},
                 sample="%d x optimize(10) on the full config-#2 window (%d iterations, %.1f s) per thread count; oracle/ C++ "
                        "restatement of the reference's Ceres path (analytic Jacobians, landmark Schur, dense Cholesky), g++ -O3 "
-                       "-march=native; only the 1-thread figure is a baseline -- the port's OpenMP loops (residual evaluation, Schur "
-                       "elimination) scale poorly and are NOT a stand-in for Ceres at num_threads = 2; host has %d logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
+                       "-march=native, OMP_WAIT_POLICY=active; the 1-thread figure is the baseline -- the 2-thread one is what the pipeline's setting "
+                       "(ThreadedKFVio.cpp:1086) gives the port's OpenMP loops (residual evaluation, Schur elimination; the dense solve stays "
+                       "serial), not a measurement of Ceres at num_threads = 2; host has %d logical cores" % (one["runs"], one["iterations"], one["seconds"], nproc))
 
 
 _REAL_STDOUT = None
@@ -305,12 +310,12 @@ def window_record(name, spec, device, steps, warmup, iters):
             # MFMA flops k_schur_panels executes (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) over the algorithmic count
             # for THIS window: measured under the profiler (tools/run_r04_profiles.sh), quoted when it describes the same window
             try:
-                with open(os.path.join(ROOT, "profiles", "r04_config4_mfma.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r05_config4_mfma.json")) as fh:
                     mf = json.load(fh)
                 if abs(mf["algorithmic_flops_per_launch"] - schur_flops) < 1e-6 * schur_flops:
                     rec["roofline"]["executed_over_algorithmic"] = mf["executed_over_algorithmic"]
                     rec["roofline"]["executed_mfma_flops_per_launch"] = mf["executed_mfma_flops_per_launch"]
-                    rec["roofline"]["executed_source"] = "profiles/r04_config4_mfma.json"
+                    rec["roofline"]["executed_source"] = "profiles/r05_config4_mfma.json"
             except (OSError, KeyError, ValueError):
                 pass
     except Exception as ex:
@@ -382,6 +387,23 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
                                 note="the handle idle when a frame arrives (svin_ba_wait_idle after the marginalisation, outside the "
                                      "frame's calls): ms_per_frame = median of all calls of a frame = what a 20 Hz front end waits for; "
                                      "marginalisation_job_ms = call + device job, which overlaps the front end's work on the next frame")
+    if rig == "rig_v2":
+        # the dominant kernel of this record's marginalisation job: the eigen-solve of the prior (M3).  Timed on a prior of this very
+        # window's steady state (117 unknowns, tests/golden/prior_matrices.npz) through the solver's own entry point; the flops are
+        # the textbook count of tridiagonalisation (4/3 n^3) + divide and conquer (~4/3 n^3 without deflation) + back-transformation
+        # (2 n^3): a chain of n dependent steps and log2 n merge levels in ONE workgroup, latency-bound by construction
+        try:
+            A = np.load(os.path.join(ROOT, "tests", "golden", "prior_matrices.npz"))["rig_v2_n117"]
+            n = A.shape[0]
+            ms = min(Estimator.debug_sym_eig(A)[2] for _ in range(3))
+            flops = (4.0 / 3.0 + 4.0 / 3.0 + 2.0) * n ** 3
+            rec["roofline"] = dict(bound="mfma", kernel="k_marg_final_dc (eigen-solve of the prior, svin_amd/csrc/symeig.hpp)", n=n, launch_ms=ms,
+                                   flops=flops, achieved=flops / (ms * 1e-3) / 1e12, peak=F64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                   frac=flops / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, traffic=None,
+                                   note="one workgroup, n dependent Householder steps + log2 n merge levels: latency-bound (DESIGN.md); "
+                                        "the Jacobi solve of rounds 1-4 took 2.1 ms on this matrix")
+        except Exception as ex:   # noqa: BLE001
+            rec["roofline"] = {"error": repr(ex)}
     if with_oracle:
         from oracle import orc
         orows = run(orc.OracleEstimator(), spec)
@@ -490,6 +512,39 @@ def concurrent_record(device, n_handles=8, steps=12):
              "returned (median over the steps, Python barrier overhead included); per-handle rates from the time inside "
              "svin_ba_solve_prepared")
     return rec
+
+
+def summary_of(out):
+    """<= 1.5 KB: one number per sub-record (GN / LM iterations per second, milliseconds per frame, roofline fractions)"""
+    def get(*path):
+        cur = out
+        for k in path:
+            if not isinstance(cur, dict) or k not in cur:
+                return None
+            cur = cur[k]
+        return round(cur, 4) if isinstance(cur, float) else cur
+    return {
+        "config2_its": get("value"), "cpu_baseline_its": get("cpu_baseline", "value"),
+        "config3_its": get("config3", "value"), "config4_its": get("config4_single_gpu", "value"),
+        "config4_executed_over_algorithmic": get("config4_single_gpu", "roofline", "executed_over_algorithmic"),
+        "sharded_config4_its": get("sharded_config4", "value"),
+        "config5_its": get("config5", "value"), "config5_6dof_its": get("config5_6dof", "value"),
+        "sliding_ms": get("sliding_window", "ms_per_frame"), "sliding_spaced_ms": get("sliding_window", "frames_spaced", "ms_per_frame"),
+        "sliding_optimize_call_ms": get("sliding_window", "frames_spaced", "ms", "optimize_call"),
+        "marg_job_ms": get("sliding_window", "frames_spaced", "marginalisation_job_ms"),
+        "sliding_cpu_ms": get("sliding_window", "cpu_baseline", "ms_per_frame"),
+        "sliding_rig_v2_ms": get("sliding_window_rig_v2", "ms_per_frame"),
+        "sliding_rig_v2_spaced_ms": get("sliding_window_rig_v2", "frames_spaced", "ms_per_frame"),
+        "marg_job_rig_v2_ms": get("sliding_window_rig_v2", "frames_spaced", "marginalisation_job_ms"),
+        "sliding_rig_v2_cpu_ms": get("sliding_window_rig_v2", "cpu_baseline", "ms_per_frame"),
+        "prior_eigen_solve_n117_ms": get("sliding_window_rig_v2", "roofline", "launch_ms"),
+        "handles8_aggregate_its": get("concurrent", "handles_8", "aggregate"),
+        "handles8_x": (round(out["concurrent"]["handles_8"]["aggregate"] / out["concurrent"]["handles_8"]["one_handle_alone"], 3)
+                       if get("concurrent", "handles_8", "aggregate") and get("concurrent", "handles_8", "one_handle_alone") else None),
+        "k1_frac_b2b": get("roofline", "frac"), "k1_frac_survey_bytes": get("roofline", "frac_survey_bytes"),
+        "k1_frac_4GB": get("roofline", "replicas_1024", "frac"),
+        "pcie_inclusive_its": get("config", "pcie_inclusive", "value"),
+    }
 
 
 XGMI_LINK_GBS = 153.0   # per xGMI link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
@@ -712,7 +767,7 @@ def main():
         # cannot be read from inside this process, so the committed measurement is quoted when it describes the same
         # launch (same replica count and algorithmic bytes); otherwise null.
         traffic, traffic_from = None, None
-        for name in ("r04_k1_pmc.json", "r02_k1_pmc.json", "r01_k1_pmc.json"):
+        for name in ("r05_k1_pmc.json", "r04_k1_pmc.json", "r02_k1_pmc.json", "r01_k1_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh)
@@ -801,6 +856,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(syn.make_window(seed=20250629))
             out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["summary"] = summary_of(out)   # LAST key: the headline of every sub-record survives a truncated tail of this line
         emit(out)
     if dist is not None:
         dist.barrier()
