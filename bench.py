@@ -361,7 +361,10 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
         out = {("%s_call" % c if c in ("optimize", "marginalise") else c): 1e3 * med(c) for c in calls}
         out.update(pack_upload=1e3 * med("upload"), device_solve=1e3 * med("solve"), read_back=1e3 * med("download"))
         return out
-    rows = run(Estimator(device), spec)
+    est_b2b = Estimator(device)
+    rows = run(est_b2b, spec)
+    paths = est_b2b.path_counters()
+    del est_b2b
     frame = float(np.mean([r["all"] for r in rows]))
     med = lambda key: float(np.median([r[key] for r in rows]))   # noqa: E731
     rec = dict(workload="sliding window (%s), 5 keyframes + 3 IMU frames, ~1000 new observations per frame, addStates + "
@@ -370,7 +373,7 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
                            "SVIn stereo_rig_v2: 2 cameras with variable extrinsics + sonar + depth", len(rows)),
                ms_per_frame=1e3 * frame, frames_per_s=1.0 / frame,
                ms=summary(rows),
-               iterations_per_frame=float(np.mean([r["iterations"] for r in rows])),
+               iterations_per_frame=float(np.mean([r["iterations"] for r in rows])), paths=paths,
                optimize_marginalise_add_observations_ms=1e3 * (med("optimize") + med("marginalise") + med("add_observations")),
                window="device-resident (svin_amd/csrc/resident.hpp): per frame the host sends the ~1000 new observation records, the "
                       "removed ones and the state tables; one kernel rebuilds the landmark-major table, the marginalisation job's tables "

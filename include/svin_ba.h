@@ -374,6 +374,12 @@ int svin_ba_debug_reduced_solve(svin_ba* h, double mu, double* y, int cap_d);
 /* the same with the choice svin_ba_optimize makes: fuse_finalize != 0 applies the metric and the damping inside the solver's
  * load phase (the fused form every trust-region iteration runs), 0 is svin_ba_debug_reduced_solve. */
 int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, double* y, int cap_d);
+/* Which path the handle's work took since it was created, so that no fall-back is silent: out[0] optimisations on the
+ * device-resident window (per frame only the new / removed observation records travel), out[1] optimisations that
+ * re-packed the whole window on the host (wide windows with their panel work lists, landmark priors, constant landmarks,
+ * sharded mode, svin_ba_set_pack_mode), out[2] marginalisation jobs whose observation tables were gathered on the device,
+ * out[3] jobs whose tables the host assembled.  Returns 1. */
+int svin_ba_get_path_counters(svin_ba* h, int64_t out[4]);
 /* the eigen-solver of the marginalisation prior (M3, MarginalizationError.cpp:725-758: Eigen::SelfAdjointEigenSolver there;
  * here Householder tridiagonalisation + divide and conquer in one workgroup, svin_amd/csrc/symeig.hpp) on an arbitrary
  * symmetric matrix A (n x n, row-major, n <= 128), on the current HIP device: eigenvalues ascending, eigenvectors[i * n + j] =

@@ -527,6 +527,12 @@ int svin_ba_debug_reduced_solve_ex(svin_ba* h, double mu, int fuse_finalize, dou
   GUARD_BEGIN return h->w.debugReducedSolve(mu, y, cap_d, fuse_finalize != 0);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_get_path_counters(svin_ba* h, int64_t out[4]) try {
+  if (!h || !out) return SVIN_ERR_INVALID_ARG;
+  const long long* c = h->w.pathCounters();
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+  return 1;
+} CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_debug_sym_eig(int n, const double* A, double* eigenvalues, double* eigenvectors, double* device_ms) {
   if (!A || !eigenvalues || !eigenvectors) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return svin::debugSymEig(n, A, eigenvalues, eigenvectors, device_ms);

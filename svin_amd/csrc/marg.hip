@@ -1125,6 +1125,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
   // The job's observation tables come out of the device-resident CSR when it mirrors the graph as it is now (nothing was
   // added or removed since the last solve); otherwise they are assembled here from the records the policy removes.
   const bool deviceJob = residentValid_ && residentUsed_ && addLog_.empty() && remLog_.empty() && setLog_.empty() && res_.N == (int)numObs_;
+  ++pathCounters_[deviceJob ? 2 : 3];
   if (!deviceJob) syncLandmarks();   // the linearisation points of the marginalised landmarks are read from the host graph
   std::vector<unsigned char> poseClass;
   std::vector<uint64_t> margLandmarks;

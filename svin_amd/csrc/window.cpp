@@ -1388,6 +1388,7 @@ void Window::pack(bool solveFollows) {
   // path against).  Both list the landmarks with observations in HANDLE order, the observations in insertion order.
   const bool resident = useResident();
   residentUsed_ = resident;
+  ++pathCounters_[resident ? 0 : 1];   // (svin_ba_get_path_counters: nothing falls back silently)
   if (!resident) {
     syncLandmarks();         // the host graph becomes the authority again ...
     invalidateResident();    // ... and the device copy is rebuilt from it when the window next qualifies

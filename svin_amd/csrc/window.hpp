@@ -308,6 +308,7 @@ class Window {
   int linearize(double mu, double* S, double* g, uint64_t* blockIds, int32_t* blockOff, int32_t* nBlocks, int capD,
                 double* cost);
   void waitIdle();
+  const long long* pathCounters() const { return pathCounters_; }
   int debugReducedSolve(double mu, double* y, int capD, bool fuseFinalize = false);
   int debugPeekSolverScratch(uint64_t off, uint64_t count, double* out);
   int getPrior(double* H, double* b0, double* J, double* e0, uint64_t* ids, int32_t* ord, int32_t* mdim,
@@ -397,6 +398,7 @@ class Window {
   int packMode_ = 0;
   bool residentValid_ = false; // the device holds the window as of the last flush; the logs describe what changed since
   bool residentUsed_ = false;  // the last pack() took the resident path
+  long long pathCounters_[4] = {0, 0, 0, 0};   // pack() resident / host; marginalisation tables gathered on the device / built on the host
   mutable bool lmStale_ = false;   // the device's per-handle landmark tables are newer than Landmark::hp / quality
   int hFlushed_ = 0;           // landmark handles below this have device-side values
   // Landmark qualities (Estimator.cpp:902-923) are only ever read through getLandmark(s): the resident path computes them

@@ -55,7 +55,7 @@ EXPORTS = [
     "svin_ba_set_camera_sensor_states", "svin_ba_set_landmark", "svin_ba_num_frames", "svin_ba_num_landmarks",
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
-    "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize", "svin_ba_debug_reduced_solve", "svin_ba_debug_reduced_solve_ex", "svin_ba_debug_set_switch", "svin_ba_debug_sym_eig", "svin_ba_wait_idle", "svin_ba_debug_peek_solver_scratch",
+    "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize", "svin_ba_debug_reduced_solve", "svin_ba_debug_reduced_solve_ex", "svin_ba_debug_set_switch", "svin_ba_debug_sym_eig", "svin_ba_get_path_counters", "svin_ba_wait_idle", "svin_ba_debug_peek_solver_scratch",
     "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_residual_info",
     "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
     "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
@@ -157,6 +157,7 @@ def load_library():
     sig("svin_ba_debug_reduced_solve_ex", i32, vp, f64, i32, pd, i32)
     sig("svin_ba_debug_set_switch", i32, C.c_char_p, i32)
     sig("svin_ba_debug_sym_eig", i32, i32, pd, pd, pd, pd)
+    sig("svin_ba_get_path_counters", i32, vp, C.POINTER(C.c_int64))
     sig("svin_ba_wait_idle", i32, vp)
     sig("svin_ba_debug_peek_solver_scratch", i32, vp, u64, u64, pd)
     sig("svin_ba_get_prior", i32, vp, pd, pd, pd, pd, pu64, pi32, pi32, pi32, i32)
@@ -733,6 +734,13 @@ class Estimator:
         y = np.zeros(cap)
         d = self._check(self.L.svin_ba_debug_reduced_solve_ex(self.h, float(mu), 1 if fused else 0, _d(y), cap), "debug_reduced_solve")
         return y[:d].copy()
+
+    def path_counters(self):
+        """dict(resident_solves, host_pack_solves, device_gathered_marginalisations, host_assembled_marginalisations)"""
+        out = (C.c_int64 * 4)()
+        self._check(self.L.svin_ba_get_path_counters(self.h, out), "path_counters")
+        return dict(resident_solves=out[0], host_pack_solves=out[1], device_gathered_marginalisations=out[2],
+                    host_assembled_marginalisations=out[3])
 
     @staticmethod
     def debug_sym_eig(A):
