@@ -11,6 +11,8 @@ with the MINIMAL Jacobians J_i.  Error terms restated (definitions, not code):
                       Jacobians: Map::isJacobianCorrect is its own test of that)
   PoseError           e = [z.r - r ; 2 vec(z.q x q^-1)],  r = W e,  J = -W [I 0; 0 plus(dq)_3x3]  (= d e / d delta exactly)
   SpeedAndBiasError   e = z - x,  J = -W
+  RelativePoseError   (src/RelativePoseError.cpp:79-147; between the extrinsics of consecutive frames, stereo_rig_v2)
+                      e = [r_1 - r_0 ; 2 vec(q_1 x q_0^-1)],  J_0 = -W [I 0; 0 plus(dq)_3x3],  J_1 = W [I 0; 0 oplus(dq)_3x3]
   ImuError            the reference's closed form (src/ImuError.cpp:707-800): e and the blocks F0 / F1 evaluated at 40 digits on
                       a 40-digit pre-integration (tests/golden/make_golden_imu.py `integrate`), weighted by the upper Cholesky
                       factor of sym(inv(sym(P_delta))).  Its Jacobians are NOT difference quotients: the reference's analytic
@@ -26,7 +28,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 import make_golden as G          # noqa: E402  (mp helpers: qmul, qrot_inv, distort, pose_plus ...)
 import make_golden_imu as GI     # noqa: E402  (integrate, quat_to_R, cross_mx)
 
-KIND_REPROJ, KIND_IMU, KIND_POSE, KIND_SB = 0, 1, 2, 3      # orc::ErrorTerm::Kind
+KIND_REPROJ, KIND_IMU, KIND_POSE, KIND_SB, KIND_RELPOSE = 0, 1, 2, 3, 4      # orc::ErrorTerm::Kind
 TYPE_POSE, TYPE_SB, TYPE_LM = 0, 1, 2
 
 
@@ -115,6 +117,23 @@ def pose_error(defn, x):
         for b in range(3):
             F[3 + a, 3 + b] = -Q[a, b]
     return W * e, W * F
+
+
+def relative_pose_error(defn, x0, x1):
+    W = mp.matrix(6, 6)
+    for a in range(6):
+        for b in range(6):
+            W[a, b] = mp.mpf(float(defn[6 * a + b]))
+    T0, T1 = normalised_pose(x0), normalised_pose(x1)
+    dq = G.qmul(T1[3:7], qinv(T0[3:7]))
+    e = mp.matrix([T1[0] - T0[0], T1[1] - T0[1], T1[2] - T0[2], 2 * dq[0], 2 * dq[1], 2 * dq[2]])
+    P, O = quat_mats(dq)
+    J0, J1 = -mp.eye(6), mp.eye(6)
+    for a in range(3):
+        for b in range(3):
+            J0[3 + a, 3 + b] = -P[a, b]
+            J1[3 + a, 3 + b] = O[a, b]
+    return W * e, [W * J0, W * J1]
 
 
 def speed_bias_error(defn, x):
@@ -245,6 +264,9 @@ def m1(log, dps=40):
             r, Js = list(rm), [J if active[0] else None]
         elif k == KIND_IMU:
             rm, Jl = imu_error(ent["defn"], *xs)
+            r, Js = list(rm), [J if a else None for J, a in zip(Jl, active)]
+        elif k == KIND_RELPOSE:
+            rm, Jl = relative_pose_error(ent["defn"], *xs)
             r, Js = list(rm), [J if a else None for J, a in zip(Jl, active)]
         else:
             raise NotImplementedError("mp_m1: error-term kind %d" % k)

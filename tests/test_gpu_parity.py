@@ -553,18 +553,26 @@ def test_marginalization_one_shot(gpu_lib, rig, kw):
         assert abs(o["rank_g"] - exact["rank"]) <= len(exact["rel_eigs_small"]) - clear
 
 
-def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("rig", ["euroc", "rig_v2"])
+def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch, rig):
     """M1 AND M2 of the HIP path against a 40-digit chain that starts from the raw residual definitions (tests/mp_m1.py +
     tests/mp_marg.py; structure -- which residuals, ordering, which rows leave -- from the oracle's log, every number
     recomputed): five marginalisations in sequence on identical states (the oracle's snapshots are injected before each
     call).  Checked per call: the GPU's system after M1 (SVIN_MARG_KEEP_PRE) and its prior after M2, each next to the
-    oracle's distance from the same exact result."""
+    oracle's distance from the same exact result.  rig_v2 = the reference's shipped rig: per-frame extrinsics chained by
+    RelativePoseErrors with sigma_c_relative = 1e-8 (3e16 of information); what the sequence tests' wide pose bars are NOT:
+    per marginalisation the HIP path sits at the same rounding distance from the exact chain as on EuRoC (H 1e-12, b0 1e-9 of a
+    standard deviation -- the b0 floor is the relative-extrinsics residual itself, 1e-16 rad of quaternion rounding against
+    sigma = 1e-8 rad, in any double implementation); the 1e-3 .. 1e-4 the 13-frame sequences end apart is what the OPTIMISATIONS
+    between the marginalisations make of such differences (test_marginalization_large_prior_per_frame_extrinsics measures that
+    amplification against the oracle perturbed by 1e-13)."""
     from svin_amd.estimator import Estimator
     from oracle import orc
     import mp_m1
-    from test_marginalization_m1_exact import tiny_sequence_spec, scaled
+    from test_marginalization_m1_exact import tiny_sequence_spec, tiny_sequence_spec_rig_v2, scaled
     monkeypatch.setenv("SVIN_MARG_KEEP_PRE", "1")
-    spec = tiny_sequence_spec()
+    spec = tiny_sequence_spec() if rig == "euroc" else tiny_sequence_spec_rig_v2()
+    bar_b1 = 1e-10 if rig == "euroc" else 2e-9
     cpu, gpu = orc.OracleEstimator(), Estimator(0)
     rec = []
 
@@ -606,7 +614,7 @@ def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch):
         dHc, dbc, _ = scaled(r["pre"]["H"], r["pre"]["b0"], H, b0)
         log("m1 vs exact, frame", k, ": gpu H %.2e b0 %.2e | oracle H %.2e b0 %.2e" % (dHg, dbg, dHc, dbc))
         worst["gpu_m1"], worst["cpu_m1"] = max(worst["gpu_m1"], dHg, dbg / max(1.0, bs)), max(worst["cpu_m1"], dHc, dbc / max(1.0, bs))
-        assert dHg < 1e-10 and dbg < 1e-10 * max(1.0, bs), (k, dHg, dbg, bs)
+        assert dHg < 1e-10 and dbg < bar_b1 * max(1.0, bs), (k, dHg, dbg, bs)
         ex = chain.m2(r["pre"]["lm"], r["pre"]["dense"])
         # priors after M2: the GPU's kept blocks against the chain's, by block id
         mg, mc = gpu.marg(), r["prior"]
@@ -624,7 +632,7 @@ def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch):
         assert dHg2 < 1e-8 and dbg2 < 1e-8 * max(1.0, bs2), (k, dHg2, dbg2, bs2)
     syn.feed(gpu, spec, on_frame=cb_gpu)
     assert step[0] == len(rec) == 5
-    log("distance to the exact chain, worst of five marginalisations:", worst)
+    log(rig, "distance to the exact chain, worst of five marginalisations:", worst)
     # (the GPU carries its OWN previous prior from call to call, the chain the exact one: from the second call on its M1
     # distance includes what its previous M2 left -- the same holds for the oracle column next to it)
 
