@@ -161,33 +161,43 @@ __global__ __launch_bounds__(kRebuildThreads) void k_window_rebuild(ResidentArgs
   }
   for (int i = t; i < a.Nnew; i += nt) a.live[i] = 1;
   __syncthreads();
-  // ---- phase 4: within every chunk of 16 landmarks the observations pose by pose (stable counting sort), what the dense
-  // Schur kernels with the A part on MFMA walk (Window::pack: orderObs)
-  if (a.wantOrder) {
-    const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
-    const int nChunks = (a.Lnew + 15) / 16;
-    for (int c = wave; c < nChunks; c += nw) {
-      const int oBeg = a.lmPtrNew[16 * c], oEnd = a.lmPtrNew[min(a.Lnew, 16 * c + 16)];
-      int carry = oBeg;
-      for (int pb = 0; pb < a.nPoseSlots + 1; pb += 64) {
-        const int p = pb + lane;
-        int n = 0;
-        for (int o = oBeg; o < oEnd; ++o) n += ((int)(a.obsIdx[o] & 0xfff) == p) ? 1 : 0;
-        int inc = n;
-        for (int off = 1; off < 64; off <<= 1) {
-          const int u = __shfl_up(inc, off);
-          if (lane >= off) inc += u;
-        }
-        int at = carry + inc - n;
-        if (n > 0)
-          for (int o = oBeg; o < oEnd; ++o)
-            if ((int)(a.obsIdx[o] & 0xfff) == p) a.obsOrder[at++] = o;
-        carry += __shfl(inc, 63);
-      }
-    }
-  }
+  // (phase 4 -- the per-chunk pose order of the dense Schur kernels with the A part on MFMA -- is k_window_order, one workgroup
+  // per chunk of 16 landmarks, launched right behind this kernel: as the tail of this ONE workgroup it was 140 of the 180 us
+  // a stereo_rig_v2 frame's rebuild took)
   __syncthreads();
   if (t == 0 && err) *a.status = err;
+}
+
+// Within every chunk of 16 landmarks the observations pose by pose (stable counting sort): what the dense Schur kernels with the
+// A part on MFMA walk (Window::pack: orderObs).  One wave per chunk; the chunk's pose slots are staged in LDS once (every lane
+// used to read all of them from global memory, twice).
+__global__ __launch_bounds__(64) void k_window_order(ResidentArgs a) {
+  constexpr int kStage = 1024;
+  __shared__ int sPose[kStage];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int oBeg = a.lmPtrNew[16 * c], oEnd = a.lmPtrNew[min(a.Lnew, 16 * c + 16)], cnt = oEnd - oBeg;
+  const bool staged = cnt <= kStage;
+  if (staged)
+    for (int i = lane; i < cnt; i += 64) sPose[i] = (int)(a.obsIdx[oBeg + i] & 0xfff);
+  __syncthreads();
+  int carry = oBeg;
+  for (int pb = 0; pb < a.nPoseSlots + 1; pb += 64) {
+    const int p = pb + lane;
+    int n = 0;
+    if (staged) for (int i = 0; i < cnt; ++i) n += (sPose[i] == p) ? 1 : 0;
+    else for (int o = oBeg; o < oEnd; ++o) n += ((int)(a.obsIdx[o] & 0xfff) == p) ? 1 : 0;
+    int inc = n;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(inc, off);
+      if (lane >= off) inc += u;
+    }
+    int at = carry + inc - n;
+    if (n > 0) {
+      if (staged) { for (int i = 0; i < cnt; ++i) if (sPose[i] == p) a.obsOrder[at++] = oBeg + i; }
+      else { for (int o = oBeg; o < oEnd; ++o) if ((int)(a.obsIdx[o] & 0xfff) == p) a.obsOrder[at++] = o; }
+    }
+    carry += __shfl(inc, 63);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_window_store_landmarks(int H, const int* slotOfH, const double* lm, const double* quality,
@@ -307,6 +317,7 @@ void launchFillJobs(const FillJobs& f, hipStream_t s) {
 }
 void launchWindowRebuild(const ResidentArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_window_rebuild, dim3(1), dim3(kRebuildThreads), 0, s, a);
+  if (a.wantOrder && a.Lnew > 0) hipLaunchKernelGGL(k_window_order, dim3((a.Lnew + 15) / 16), dim3(64), 0, s, a);
 }
 void launchWindowStoreLandmarks(int H, const int* slotOfH, const double* lm, const double* quality, double* lmHp, double* qualH,
                                 hipStream_t s) {
