@@ -471,13 +471,14 @@ __global__ void k_marg_lm_prepare(MargDev md, double* vb) {
   double* Vw = md.V + 9 * (size_t)l;
   for (int k = 0; k < 9; ++k) Vw[k] = Nm[k];
 }
-// ba -= W vb (uses the original W) ; then W_l <- W_l N_l
-__global__ void k_marg_lm_apply(MargDev md, const double* vb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= md.m) return;
+// ba -= W vb (uses the original W) ; then W_l <- W_l N_l.  One workgroup per row of W, the landmarks dealt over its threads,
+// the row's sum reduced in a fixed order (deterministic); one THREAD per row walking all landmarks took 130-220 us.
+__global__ __launch_bounds__(256) void k_marg_lm_apply(MargDev md, const double* vb) {
+  __shared__ double red[256];
+  const int i = blockIdx.x, t = threadIdx.x;
   double* Wr = md.W + (size_t)i * 3 * md.Lm;
   double s = 0;
-  for (int l = 0; l < md.Lm; ++l) {
+  for (int l = t; l < md.Lm; l += 256) {
     const double w0 = Wr[3 * l], w1 = Wr[3 * l + 1], w2 = Wr[3 * l + 2];
     s += w0 * vb[3 * l] + w1 * vb[3 * l + 1] + w2 * vb[3 * l + 2];
     const double* Nm = md.V + 9 * (size_t)l;
@@ -485,18 +486,36 @@ __global__ void k_marg_lm_apply(MargDev md, const double* vb) {
     Wr[3 * l + 1] = w0 * Nm[1] + w1 * Nm[4] + w2 * Nm[7];
     Wr[3 * l + 2] = w0 * Nm[2] + w1 * Nm[5] + w2 * Nm[8];
   }
-  md.ba[i] -= s;
+  red[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) md.ba[i] -= red[0];
 }
-// U -= Mu Mu^T
-__global__ void k_marg_lm_update(MargDev md) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= md.m * md.m) return;
-  const int i = idx / md.m, j = idx % md.m;
-  const double* a = md.W + (size_t)i * 3 * md.Lm;
-  const double* b = md.W + (size_t)j * 3 * md.Lm;
-  double s = 0;
-  for (int k = 0; k < 3 * md.Lm; ++k) s += a[k] * b[k];
-  md.U[(size_t)i * md.m + j] -= s;
+// U -= Mu Mu^T: 16 x 16 tiles on v_mfma_f64_16x16x4 (A[i = l & 15][k = l >> 4], B[k][j = l & 15], C: column l & 15, row
+// (l >> 4) + 4 reg), one wave per tile over all 3 Lm columns of Mu in order (deterministic).  One thread per entry streaming
+// two rows of Mu from global memory took 100-180 us.
+__global__ __launch_bounds__(64) void k_marg_lm_update(MargDev md) {
+  const int tr = (md.m + 15) >> 4, ti = blockIdx.x / tr, tj = blockIdx.x - ti * tr, l = threadIdx.x;
+  const int K = 3 * md.Lm;
+  const int ra = ti * 16 + (l & 15), rb = tj * 16 + (l & 15);
+  const double* pa = md.W + (size_t)min(ra, md.m - 1) * K;
+  const double* pb = md.W + (size_t)min(rb, md.m - 1) * K;
+  const bool okA = ra < md.m, okB = rb < md.m;
+  typedef double d4m __attribute__((ext_vector_type(4)));
+  d4m acc = {0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < K; kk += 4) {
+    const int k = kk + (l >> 4);
+    const double av = (okA && k < K) ? pa[k] : 0.0, bv = (okB && k < K) ? pb[k] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const int r = ti * 16 + (l >> 4) + 4 * rg, c = tj * 16 + (l & 15);
+    if (r < md.m && c < md.m) md.U[(size_t)r * md.m + c] -= acc[rg];
+  }
 }
 
 // ---------------------------------------------------------------- M2 dense part (:622-667) + M3 (:725-758)
@@ -509,7 +528,7 @@ struct DenseArgs {
   double *Vm, *Qm, *tmp;    // scratch: nm x nm, nm x nm, nk x nm + 2 nm
   int* flag;
 };
-__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds) {
+__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, int prodLds) {
   extern __shared__ double jacobiLds[];
   const int t = threadIdx.x, nt = blockDim.x, nm = a.nm, nk = a.nk, m = a.m;
   double* pm = a.tmp;                 // nm
@@ -547,7 +566,43 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds) {
     a.Qm[idx] = a.Qm[idx] * sc / pm[i];
   }
   __syncthreads();
-  // Mu = W N  (W = U[keep, marg]) : Mu[r][j] = sum_i W[r][i] N[i][j] = sum_i W[r][i] Qm[j][i]
+  // Mu = W N  (W = U[keep, marg]) : Mu[r][j] = sum_i W[r][i] N[i][j] = sum_i W[r][i] Qm[j][i]; then Hk = U[keep, keep] - Mu Mu^T,
+  // bk = ba[keep] - Mu (N^T b_m).  With W, N^T and Mu staged in LDS when the launch has room for them (prodLds: every operand
+  // used to come from global memory once per multiply-add -- a third of this kernel's 220 us at nk = 117, nm = 27).
+  if (prodLds) {
+    __syncthreads();
+    double* sW = jacobiLds;                    // nk x nm
+    double* sN = sW + (size_t)nk * nm;         // nm x nm (row j = column j of N)
+    double* sMu = sN + (size_t)nm * nm;        // nk x nm
+    for (int idx = t; idx < nk * nm; idx += nt) { const int r = idx / nm, i = idx - r * nm; sW[idx] = a.U[(size_t)a.keep[r] * m + a.marg[i]]; }
+    for (int idx = t; idx < nm * nm; idx += nt) sN[idx] = a.Qm[idx];
+    __syncthreads();
+    for (int idx = t; idx < nk * nm; idx += nt) {
+      const int r = idx / nm, j = idx - r * nm;
+      double s = 0;
+      for (int i = 0; i < nm; ++i) s += sW[r * nm + i] * sN[j * nm + i];
+      sMu[idx] = s;
+      Mu[idx] = s;
+    }
+    for (int j = t; j < nm; j += nt) {
+      double s = 0;
+      for (int i = 0; i < nm; ++i) s += sN[j * nm + i] * a.ba[a.marg[i]];
+      pm[j] = s;  // pm reused
+    }
+    __syncthreads();
+    for (int idx = t; idx < nk * nk; idx += nt) {
+      const int r = idx / nk, c = idx - r * nk;
+      double s = 0;
+      for (int j = 0; j < nm; ++j) s += sMu[r * nm + j] * sMu[c * nm + j];
+      a.Hk[idx] = a.U[(size_t)a.keep[r] * m + a.keep[c]] - s;
+    }
+    for (int r = t; r < nk; r += nt) {
+      double s = 0;
+      for (int j = 0; j < nm; ++j) s += sMu[r * nm + j] * pm[j];
+      a.bk[r] = a.ba[a.keep[r]] - s;
+    }
+    return;
+  }
   for (int idx = t; idx < nk * nm; idx += nt) {
     const int r = idx / nm, j = idx % nm;
     double s = 0;
@@ -1534,8 +1589,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     // M2 landmark part
     if (Lm > 0 && m > 0) {
       hipLaunchKernelGGL(k_marg_lm_prepare, dim3((Lm + 127) / 128), dim3(128), 0, s, md, vb);
-      hipLaunchKernelGGL(k_marg_lm_apply, dim3((m + 127) / 128), dim3(128), 0, s, md, (const double*)vb);
-      hipLaunchKernelGGL(k_marg_lm_update, dim3((m * m + 255) / 256), dim3(256), 0, s, md);
+      hipLaunchKernelGGL(k_marg_lm_apply, dim3(m), dim3(256), 0, s, md, (const double*)vb);
+      hipLaunchKernelGGL(k_marg_lm_update, dim3(((m + 15) / 16) * ((m + 15) / 16)), dim3(64), 0, s, md);
     }
     // M2 dense part
     if (nk > 0) {
@@ -1548,9 +1603,12 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         da.Vm = bScratch.p; da.Qm = bScratch.p + (size_t)nm * nm; da.tmp = bScratch.p + (size_t)2 * nm * nm;
         da.flag = bFlag.p;
         {
-          const size_t lds = jacobiLdsBytes(nm);
+          const size_t ldsEig = jacobiLdsBytes(nm);
+          const size_t ldsProd = sizeof(double) * ((size_t)2 * nk * nm + (size_t)nm * nm);   // W, Mu, N^T of the products
+          const bool prodLds = ldsProd <= kJacobiLdsLimit;
+          const size_t lds = std::max(ldsEig, prodLds ? ldsProd : (size_t)0);
           if (lds) ensureDynamicLds((const void*)k_marg_dense, lds);
-          hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, lds ? 1 : 0);
+          hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, ldsEig ? 1 : 0, prodLds ? 1 : 0);
           HIP_OK(hipGetLastError());   // (a refused launch would leave a garbage prior behind)
         }
       } else {
