@@ -98,20 +98,23 @@ __device__ __forceinline__ int min8i(int v) {
   v = min(v, dppMovI<0x4E>(v));
   return v;
 }
-// the same over aligned groups of G = 1, 2 or 8 lanes
+// the same over aligned groups of G = 1, 2, 4 or 8 lanes
 template <int G> __device__ __forceinline__ double sumG(double v) {
   if (G == 8) return sum8(v);
-  if (G == 2) return v + dppMov<0xB1>(v);
+  if (G >= 2) v += dppMov<0xB1>(v);
+  if (G == 4) v += dppMov<0x4E>(v);
   return v;
 }
 template <int G> __device__ __forceinline__ double maxG(double v) {
   if (G == 8) return max8(v);
-  if (G == 2) return fmax(v, dppMov<0xB1>(v));
+  if (G >= 2) v = fmax(v, dppMov<0xB1>(v));
+  if (G == 4) v = fmax(v, dppMov<0x4E>(v));
   return v;
 }
 template <int G> __device__ __forceinline__ int minGi(int v) {
   if (G == 8) return min8i(v);
-  if (G == 2) return min(v, dppMovI<0xB1>(v));
+  if (G >= 2) v = min(v, dppMovI<0xB1>(v));
+  if (G == 4) v = min(v, dppMovI<0x4E>(v));
   return v;
 }
 // 1 / d by v_rcp_f64 and two Newton steps (the IEEE division sequence is ~4 x as many instructions; these loops do K^2 of them)
@@ -134,6 +137,17 @@ __device__ __forceinline__ double waveSumAll(double v) {
   v += dppMov<0x121>(v);
   return (readlaneD(v, 0) + readlaneD(v, 16)) + (readlaneD(v, 32) + readlaneD(v, 48));
 }
+
+__device__ __forceinline__ double waveMaxAll(double v) {
+  v = fmax(v, dppMov<0x128>(v));
+  v = fmax(v, dppMov<0x124>(v));
+  v = fmax(v, dppMov<0x122>(v));
+  v = fmax(v, dppMov<0x121>(v));
+  return fmax(fmax(readlaneD(v, 0), readlaneD(v, 16)), fmax(readlaneD(v, 32), readlaneD(v, 48)));
+}
+// LDS traffic of ONE wave seen by its own lanes in program order (the lanes run in lockstep; the compiler must not move
+// accesses across)
+__device__ __forceinline__ void waveLdsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------- stage 1: tridiagonalisation
 // Householder reduction of the symmetric matrix in Q (full storage, row-major, leading dimension ld) to tridiagonal form,
@@ -329,6 +343,110 @@ __device__ __forceinline__ void secularRoot(bool active, int i, int K, const dou
   tauOut = tau;
 }
 
+// Deflation of the pairs of 16 and more poles (the four top levels at n = 117), one WAVE per pair.  What the one-lane walk
+// spends its time on is walking: 117 dependent steps at the top although a handful of poles deflate.  Here the lanes (two
+// merged positions each) find the poles without weight, compact the others, and test every neighbouring pair of those against
+// its ORIGINAL values in parallel; only where such a test says "deflate" does lane 0 walk on, as dlaed2 would, until a pair
+// does not deflate (from there on the original values -- and so the parallel tests -- hold again).
+__device__ __forceinline__ void deflateWide(int n, int b) {
+  Small& S = gS;
+  auto& D = S.u.dc;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, two = 2 * b;
+  const int P = (n - b + two - 1) / two;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int p = wave; p < P; p += kThreads / 64) {
+    const int lo = p * two, mid = lo + b, hi = min(lo + two, n), m = hi - lo;
+    const double rho = 2.0 * fabs(S.e[mid - 1]);
+    const int s0 = lane, s1 = lane + 64;
+    const bool v0 = s0 < m, v1 = s1 < m;
+    const int idx0 = v0 ? D.sorted[lo + s0] : 0, idx1 = v1 ? D.sorted[lo + s1] : 0;
+    const double d0 = v0 ? (double)D.ds[lo + s0] : 0.0, z0 = v0 ? (double)D.zs[lo + s0] : 0.0;
+    const double d1 = v1 ? (double)D.ds[lo + s1] : 0.0, z1 = v1 ? (double)D.zs[lo + s1] : 0.0;
+    const double dmax = waveMaxAll(fmax(fabs(d0), fabs(d1))), zmax = waveMaxAll(fmax(fabs(z0), fabs(z1)));
+    const double tol = 8.0 * kEps * fmax(dmax, zmax);
+    const bool all = rho * zmax <= tol;
+    const bool sm0 = v0 && (all || rho * fabs(z0) <= tol), sm1 = v1 && (all || rho * fabs(z1) <= tol);
+    const unsigned long long S0 = __builtin_amdgcn_ballot_w64(sm0), S1 = __builtin_amdgcn_ballot_w64(sm1);
+    const unsigned long long B0 = __builtin_amdgcn_ballot_w64(v0 && !sm0), B1 = __builtin_amdgcn_ballot_w64(v1 && !sm1);
+    const int nSmall = __popcll(S0) + __popcll(S1), M = __popcll(B0) + __popcll(B1);
+    // poles without weight: deflated as they are; the others compacted (ascending) into scratch that later steps overwrite
+    int* cIdx = D.rorg + lo; double* cD = D.rtau + lo; double* cZ = D.cinv + lo;
+    if (sm0) { D.kind[idx0] = 1; D.dfl[lo + __popcll(S0 & lt)] = idx0; }
+    if (sm1) { D.kind[idx1] = 1; D.dfl[lo + __popcll(S0) + __popcll(S1 & lt)] = idx1; }
+    if (v0 && !sm0) { const int c = __popcll(B0 & lt); cIdx[c] = idx0; cD[c] = d0; cZ[c] = z0; }
+    if (v1 && !sm1) { const int c = __popcll(B0) + __popcll(B1 & lt); cIdx[c] = idx1; cD[c] = d1; cZ[c] = z1; }
+    waveLdsFence();
+    auto pairDeflates = [&](int i) -> bool {   // compact neighbours (i - 1, i), original values
+      const double zP = cZ[i - 1], zI = cZ[i];
+      const double rt = fastRcp(sqrt(zI * zI + zP * zP));
+      return fabs((cD[i] - cD[i - 1]) * (zI * rt) * (zP * rt)) <= tol;
+    };
+    const int i0 = lane + 1, i1 = lane + 65;
+    const unsigned long long F0 = __builtin_amdgcn_ballot_w64(i0 < M && pairDeflates(i0));   // bit q: pair (q, q + 1)
+    const unsigned long long F1 = __builtin_amdgcn_ballot_w64(i1 < M && pairDeflates(i1));   // bit q: pair (q + 64, q + 65)
+    unsigned long long G0 = 0, G1 = 0;   // compact poles deflated into their right-hand neighbour
+    int nr = 0, nd2 = 0;
+    if ((F0 | F1) != 0ull) {
+      if (lane == 0) {
+        auto nextFlag = [&](int from) -> int {   // first flagged pair index i >= from (pair (i - 1, i)), M if none
+          if (from <= 64) {
+            const unsigned long long r = F0 >> (from - 1);
+            if (r) return from + __builtin_ctzll(r);
+            from = 65;
+          }
+          if (from - 65 < 64) {
+            const unsigned long long r = F1 >> (from - 65);
+            if (r) return from + __builtin_ctzll(r);
+          }
+          return M;
+        };
+        int i = nextFlag(1);
+        while (i < M) {
+          int pj = i - 1, cur = i;
+          double dP = cD[pj], zP = cZ[pj];
+          while (cur < M) {
+            const double dI = cD[cur], zI = cZ[cur];
+            const double tau = sqrt(zI * zI + zP * zP), rt = fastRcp(tau);
+            const double cs = zI * rt, sn = -zP * rt, tt = dI - dP;
+            if (!(fabs(tt * cs * sn) <= tol)) break;
+            const int colP = cIdx[pj];
+            D.rotP[lo + nr] = colP; D.rotQ[lo + nr] = cIdx[cur]; D.rotC[lo + nr] = cs; D.rotS[lo + nr] = sn; ++nr;
+            D.dcur[colP] = dP * cs * cs + dI * sn * sn;
+            D.z[colP] = 0.0;
+            D.kind[colP] = 1; D.dfl[lo + nSmall + nd2++] = colP;
+            if (pj < 64) G0 |= 1ull << pj; else G1 |= 1ull << (pj - 64);
+            dP = dP * sn * sn + dI * cs * cs; zP = tau; pj = cur; ++cur;
+          }
+          cD[pj] = dP; cZ[pj] = zP;
+          i = nextFlag(cur + 1);
+        }
+      }
+      G0 = __shfl(G0, 0); G1 = __shfl(G1, 0);   // (64-bit shuffles: two ds_bpermute each)
+      nr = __shfl(nr, 0); nd2 = __shfl(nd2, 0);
+      waveLdsFence();
+    }
+    // the survivors, in order
+    const bool sv0 = lane < M && !((G0 >> lane) & 1ull), sv1 = lane + 64 < M && !((G1 >> lane) & 1ull);
+    const unsigned long long V0 = __builtin_amdgcn_ballot_w64(sv0), V1 = __builtin_amdgcn_ballot_w64(sv1);
+    const int K = __popcll(V0) + __popcll(V1);
+    // (read everything the survivors need before cd / cz are written: cD / cZ / cIdx alias later-step arrays, not these)
+    if (sv0) {
+      const int q = __popcll(V0 & lt), col = cIdx[lane];
+      const double d = cD[lane], z = cZ[lane];
+      D.ndl[lo + q] = col; D.cd[lo + q] = d; D.cz[lo + q] = z; D.kind[col] = 0; D.dcur[col] = d; D.z[col] = z;
+    }
+    if (sv1) {
+      const int q = __popcll(V0) + __popcll(V1 & lt), col = cIdx[lane + 64];
+      const double d = cD[lane + 64], z = cZ[lane + 64];
+      D.ndl[lo + q] = col; D.cd[lo + q] = d; D.cz[lo + q] = z; D.kind[col] = 0; D.dcur[col] = d; D.z[col] = z;
+    }
+    waveLdsFence();
+    const int nd = nSmall + nd2;
+    for (int q = lane; q < nd; q += 64) { const int c = D.dfl[lo + q]; D.newd[lo + K + q] = D.dcur[c]; D.ztil[c] = 0.0; }
+    if (lane == 0) { D.K[lo] = K; D.nrot[lo] = nr; }
+  }
+}
+
 // One level of the bottom-up recursion: every pair of solved neighbouring blocks [lo, lo + b) | [lo + b, min(lo + 2b, n)) is
 // merged.  T restricted to the pair = diag(T1', T2') + |e_k| w w^T, w = e_k-hat + sign(e_k) e_(k+1)-hat, k = lo + b - 1 (the
 // tear was subtracted from d_k, d_(k+1) before the leaves were "solved"), so in the basis of the two solved halves the pair is
@@ -370,7 +488,8 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
   // ---- 2: deflation (dlaed2), one lane per pair of blocks, walking the merged order.  The state of the walk (the last pole that
   // still carries weight: index, d, z) lives in registers and the next element is requested before the current one is
   // processed, so a step is ~40 dependent instructions instead of four dependent LDS round trips.
-  if (t < n && (t % two) == 0 && t + b < n) {
+  if (two >= 16) deflateWide(n, b);
+  else if (t < n && (t % two) == 0 && t + b < n) {
     const int lo = t, mid = lo + b, hi = min(lo + two, n), m = hi - lo, k = mid - 1;
     const double rho = 2.0 * fabs(S.e[k]);
     double dmax = 0, zmax = 0;
@@ -429,7 +548,8 @@ __device__ __forceinline__ void mergeLevel(lds_double* Q, int n, int ld, int b) 
   // ---- 4: secular equation.  The scalar part of an iteration (~250 instructions: the quadratic, the safeguards) is executed
   // by every wave that holds a root: one lane per root up to 8 poles, two for 16, eight beyond (measured at n = 117, us per level
   // with 8 lanes everywhere: 3.5 10.3 10.0 12.8 15.7 23.0 19.6; with one lane up to 16 poles and two beyond: 1.9 4.7 7.6 14.9 22.5
-  // 57.7 41.2 -- a lane's pole sum is a dependent chain, long sums want many lanes, short ones few waves)
+  // 57.7 41.2; four lanes beyond 16 poles: 25 31 at the two top levels against 18 23 -- a lane's pole sum is a dependent chain,
+  // long sums want many lanes, short ones few waves)
   {
     auto run = [&](auto lprTag) {
       constexpr int G = decltype(lprTag)::value;
