@@ -159,6 +159,15 @@ def init_distributed(args):
                          "ranks itself)" % (args.gpus, world, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     dist = None
+    if getattr(args, "sharded_child", False) and getattr(args, "sharded_transport", "rccl") == "stage":
+        # the ranks of the sharded sub-record on however many GPUs there are (one will do), their collectives over gloo with the
+        # device buffers staged through host memory: every line of the N > 1 record's code except RCCL itself
+        import datetime
+        import torch.distributed as dist
+        local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))
+        return rank, world, local_rank, dist
     if world > 1 or getattr(args, "force_sharded", False):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -566,31 +575,40 @@ def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
     mine = sd.shard_spec(spec, rank, world)
     est = Estimator(local_rank)
     fids, lids = syn.feed(est, mine)
-    sd.init_rccl(est, rank, world)
+    staged = dist.get_backend() != "nccl"     # --sharded-transport=stage: gloo, device buffers staged through host memory
+    if staged:
+        keep_alive = sd.make_torch_allreduce(device="stage")
+        est.set_distributed(rank, world, keep_alive)
+    else:
+        sd.init_rccl(est, rank, world)
     snap = snapshot_init(est, fids, lids, mine)
+    tdev = "cpu" if staged else "cuda"
 
     def sync():
         torch.cuda.synchronize()
         dist.barrier()
     times, its, last = timed_solves(est, fids, lids, snap, steps, warmup, iters, sync)
-    t = torch.tensor(times, dtype=torch.float64, device="cuda")
+    t = torch.tensor(times, dtype=torch.float64, device=tdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per step: the slowest rank
     times = [float(v) for v in t.cpu()]
     d = 64 * 15
     n_sys = d * (d + 1) // 2 + 3 * d
     # the collectives on their own (HIP events on the solver's stream): the system message, and the scalar message
-    ar_us = est.bench_allreduce(n_sys, 20)
-    ar_small_us = est.bench_allreduce(24, 50)
-    tt = torch.tensor([ar_us, ar_small_us], dtype=torch.float64, device="cuda")
+    # (the staged transport has no stream-ordered collective to time: the message costs are the gloo + PCIe round trips)
+    ar_us = est.bench_allreduce(n_sys, 20) if not staged else float("nan")
+    ar_small_us = est.bench_allreduce(24, 50) if not staged else float("nan")
+    tt = torch.tensor([ar_us, ar_small_us], dtype=torch.float64, device=tdev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ar_us, ar_small_us = float(tt[0]), float(tt[1])
     # NCCL's conventions: algorithm bandwidth = bytes / time; bus bandwidth = algbw x 2 (n - 1) / n, the rate every link of a
     # ring carries -- what the per-link xGMI figure bounds
-    algbw = 8.0 * n_sys / (ar_us * 1e-6) / 1e9
-    busbw = algbw * 2.0 * (world - 1) / world if world > 1 else 0.0
+    if staged:
+        ar_us = ar_small_us = None
+    algbw = 8.0 * n_sys / (ar_us * 1e-6) / 1e9 if ar_us else None
+    busbw = (algbw * 2.0 * (world - 1) / world if world > 1 else 0.0) if algbw is not None else None
     # K1 on this rank's share (HBM-resident replicas of its observation set), like the headline roofline object
     k1_ms, k1_bytes = est.bench_jacobian_eval(16, 10)
-    k1 = torch.tensor([k1_bytes / (k1_ms * 1e-3) / 1e9], dtype=torch.float64, device="cuda")
+    k1 = torch.tensor([k1_bytes / (k1_ms * 1e-3) / 1e9], dtype=torch.float64, device=tdev)
     dist.all_reduce(k1, op=dist.ReduceOp.MIN)
     ms_it = 1e3 * sum(times) / max(sum(its), 1)
     return dict(workload="configs[3]: ONE window, 64 KF / 50000 landmarks / 500000 residuals, landmarks sharded over %d GPUs, "
@@ -600,17 +618,19 @@ def sharded_config4(rank, world, local_rank, dist, steps, warmup, iters=5):
                 iterations_per_step=sum(its) / steps, final_cost=last["final_cost"], initial_cost=last["initial_cost"],
                 landmarks_per_rank=mine.L, residuals_per_rank=mine.N,
                 allreduce_bytes_per_iteration=8 * n_sys + 8 * (24 + 8),
-                allreduce_us={"system_message": ar_us, "scalar_message": ar_small_us, "per_iteration": ar_us + 2.0 * ar_small_us,
-                              "share_of_iteration": (ar_us + 2.0 * ar_small_us) * 1e-3 / ms_it},
+                allreduce_us=({"system_message": ar_us, "scalar_message": ar_small_us, "per_iteration": ar_us + 2.0 * ar_small_us,
+                               "share_of_iteration": (ar_us + 2.0 * ar_small_us) * 1e-3 / ms_it} if ar_us else None),
                 allreduce_GBps={"algbw": algbw, "busbw": busbw, "xgmi_link_peak": XGMI_LINK_GBS,
-                                "frac_of_link": busbw / XGMI_LINK_GBS if world > 1 else None},
+                                "frac_of_link": busbw / XGMI_LINK_GBS if (world > 1 and busbw is not None) else None},
                 k1_roofline_per_gpu={"achieved": float(k1[0]), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": float(k1[0]) / HBM_PEAK_GBS,
                                      "note": "slowest rank, 16 HBM-resident replicas of its observation share"},
+                transport="gloo, device buffers staged through host memory (--sharded-transport=stage: all ranks may share one GPU)" if staged
+                          else "RCCL",
                 collective="ncclAllReduce (RCCL), FP64 sum, in place, on the solver's HIP stream; 3 per iteration: "
                            "[lower(S) | g | h], [8 dogleg sums | the ranks' (gradient max, failure flag) pairs], [8 cost / step sums | stop vote]")
 
 
-def run_sharded_children(world, force_sharded):
+def run_sharded_children(world, force_sharded, transport="rccl", steps=None):
     """starts `world` fresh ranks of `bench.py --sharded-child` and returns rank 0's record (or what went wrong)"""
     env = {k: v for k, v in os.environ.items()
            if not k.startswith("TORCHELASTIC") and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
@@ -622,6 +642,9 @@ def run_sharded_children(world, force_sharded):
            "--master-port", str(free_port()), os.path.abspath(__file__), "--sharded-child", "--gpus", str(world)]
     if force_sharded:
         cmd.append("--force-sharded")
+    cmd += ["--sharded-transport", transport]
+    if steps is not None:
+        cmd += ["--steps", str(steps)]
     timeout = float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "420"))
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
@@ -641,7 +664,7 @@ def main_sharded_child(args):
     """one rank of the sharded config-#4 sub-record (started by run_sharded_children)"""
     rank, world, local_rank, dist = init_distributed(args)
     try:
-        rec = sharded_config4(rank, world, local_rank, dist, 20, 3)
+        rec = sharded_config4(rank, world, local_rank, dist, args.steps if args.steps != 30 else 20, 3)
     except Exception as ex:   # noqa: BLE001
         rec = {"error": repr(ex)}
     if rank == 0:
@@ -667,6 +690,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded config-#4 sub-record even with one rank (one-rank RCCL communicator: every collective "
                          "really runs): the only way to exercise that code path on a 1-GPU box")
+    ap.add_argument("--sharded-transport", default="rccl", choices=["rccl", "stage"],
+                    help="collectives of the sharded config-#4 sub-record: rccl (native, on the solver's stream) or stage (gloo over "
+                         "host-staged buffers: the ranks may then share one GPU -- how a 1-GPU box runs the N > 1 record's code)")
     ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sharded_child:
@@ -809,7 +835,7 @@ def main():
             # never returns, an exception on one rank or a rank that dies -- under a launcher the death of any rank ends all
             # of them, headline line included -- then costs this sub-record and nothing else.  The ranks of the headline
             # measurement wait at the final barrier meanwhile (their GPUs are idle).
-            extras["sharded_config4"] = run_sharded_children(world, args.force_sharded)
+            extras["sharded_config4"] = run_sharded_children(world, args.force_sharded, args.sharded_transport)
         if rank == 0:
             try:
                 spec3 = syn.make_window(P=10, L=4000, n_obs=40000, seed=20250629, rig="rig_v2", sonar=True, depth=True)

@@ -54,3 +54,24 @@ def test_two_process_sharded_config4(gpu_lib, tmp_path, size):
         assert r["pose_diff"] < 1e-9 and r["speed_bias_diff"] < 1e-9
         assert r["limit_termination"] == 2 and 2 <= r["limit_iterations"] <= 3
     assert res[0]["final_cost"] == res[1]["final_cost"] and res[0]["limit_iterations"] == res[1]["limit_iterations"]
+
+
+def test_bench_sharded_record_two_ranks_on_one_gpu(gpu_lib):
+    """bench.py's N > 1 sub-record (`sharded_config4`: rank launch through torch.distributed.run, shard, three collectives per
+    iteration, slowest-rank timing, the JSON hand-over) produced by two ranks that share GPU 0 -- --sharded-transport=stage, gloo
+    over host-staged buffers -- so that the first multi-GPU run of the driver is not also the first run of this code.  The
+    record must describe the same solve as the plain one-GPU optimisation of that window."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from svin_amd import synthetic as syn
+    from svin_amd.estimator import Estimator
+    rec = bench.run_sharded_children(2, False, transport="stage", steps=2)
+    print({k: rec.get(k) for k in ("value", "ms_per_iteration", "iterations_per_step", "final_cost", "transport", "error", "stderr_tail")})
+    assert "error" not in rec, rec
+    assert rec["n_gpus"] == 2 and rec["landmarks_per_rank"] == 25000 and rec["transport"].startswith("gloo")
+    est = Estimator(0)
+    syn.feed(est, syn.make_window(P=64, L=50000, n_obs=500000, seed=20250629, frame_dt=0.25))
+    est.optimize(5)
+    s = est.summary()
+    assert rec["iterations_per_step"] == s["iterations"]
+    assert abs(rec["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
