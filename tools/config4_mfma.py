@@ -27,7 +27,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
                launches=len(vals), executed_mfma_flops_per_launch=exe, algorithmic_flops_per_launch=alg, executed_over_algorithmic=exe / alg,
                mean_launch_us_under_counters=float(np.mean(dur)) / 1e3,
                source="rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace -- python tools/config4_mfma.py (MOPS x 512 flops; "
-                      "tools/run_r04_profiles.sh)")
+                      "tools/run_r05_profiles.sh)")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 else:
