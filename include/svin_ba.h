@@ -274,6 +274,17 @@ uint64_t svin_ba_map_add_pose_error(svin_ba* h, uint64_t block_id, const double 
 uint64_t svin_ba_map_add_speed_and_bias_error(svin_ba* h, uint64_t block_id, const double measurement[9], const double information[81]);
 /* RelativePoseError(information) between two pose (or two extrinsics) blocks  src/RelativePoseError.cpp:48-147 */
 uint64_t svin_ba_map_add_relative_pose_error(svin_ba* h, uint64_t block0, uint64_t block1, const double information[36]);
+/* ImuError(measurements, parameters, t_0, t_1) on blocks = (pose_0, speed/bias_0, pose_1, speed/bias_1)  src/ImuError.cpp:58-75,
+ * Map::addResidualBlock src/Map.cpp:341-376: the factor okvis::Estimator::addStates creates between two frames, here between any
+ * four blocks of the map.  Its pre-integration is redone on the device whenever the bias estimate moves (ImuError.cpp:702-706). */
+uint64_t svin_ba_map_add_imu_error(svin_ba* h, const uint64_t blocks[4], const svin_imu_sample* imu, int n_imu, const svin_imu_params* params,
+                                   uint32_t t0_sec, uint32_t t0_nsec, uint32_t t1_sec, uint32_t t1_nsec);
+/* SonarError(range, heading, information, landmark patch) on a pose block  src/SonarError.cpp:57-183 (T_SSo: svin_ba_set_sonar_extrinsics,
+ * identity in the reference); patch_xyz: n_patch Euclidean points, the residual uses their mean (:124-131) */
+uint64_t svin_ba_map_add_sonar_error(svin_ba* h, uint64_t pose_block, double range, double heading, double information,
+                                     const double* patch_xyz, int n_patch);
+/* DepthError(depth, information, first depth) on a pose block  src/DepthError.cpp:50-139 */
+uint64_t svin_ba_map_add_depth_error(svin_ba* h, uint64_t pose_block, double depth, double information, double first_depth);
 /* ReprojectionError<geometry of camera cam_idx>(uv, information) under CauchyLoss(1) on (pose, landmark, extrinsics)
  * (ReprojectionErrorBase.hpp:50-54, Estimator.cpp:69).  information: 2 x 2 row-major, a positive multiple of the identity
  * (the device stores one weight per residual, as Estimator::addObservation's 64 / size^2 * I needs). */

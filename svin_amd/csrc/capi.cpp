@@ -628,6 +628,29 @@ uint64_t svin_ba_map_add_relative_pose_error(svin_ba* h, uint64_t block0, uint64
   GUARD_BEGIN return h->w.mapAddRelativePoseError(block0, block1, information);
   GUARD_END(0)
 }
+uint64_t svin_ba_map_add_imu_error(svin_ba* h, const uint64_t blocks[4], const svin_imu_sample* imu, int n_imu, const svin_imu_params* p,
+                                   uint32_t t0_sec, uint32_t t0_nsec, uint32_t t1_sec, uint32_t t1_nsec) {
+  if (!h || !blocks || !imu || !p || n_imu < 2) return 0;
+  GUARD_BEGIN
+  std::vector<uint32_t> t;
+  std::vector<double> m;
+  splitSamples(imu, n_imu, t, m);
+  TimeStamp a, b;
+  a.sec = t0_sec; a.nsec = t0_nsec; b.sec = t1_sec; b.nsec = t1_nsec;
+  return h->w.mapAddImuError(blocks, t.data(), m.data(), n_imu, toParams(p), a, b);
+  GUARD_END(0)
+}
+uint64_t svin_ba_map_add_sonar_error(svin_ba* h, uint64_t pose_block, double range, double heading, double information,
+                                     const double* patch_xyz, int n_patch) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddSonarError(pose_block, range, heading, information, patch_xyz, n_patch);
+  GUARD_END(0)
+}
+uint64_t svin_ba_map_add_depth_error(svin_ba* h, uint64_t pose_block, double depth, double information, double first_depth) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddDepthError(pose_block, depth, information, first_depth);
+  GUARD_END(0)
+}
 uint64_t svin_ba_map_add_reprojection_error(svin_ba* h, uint64_t pose_block, uint64_t landmark, uint64_t extrinsics_block, uint64_t cam,
                                             const double uv[2], const double information[4]) {
   if (!h) return 0;

@@ -765,6 +765,52 @@ uint64_t Window::mapAddRelativePoseError(uint64_t block0, uint64_t block1, const
   sqrtInformationUpper(information36, 6, f.sqrtInfo);
   return addFactor(std::move(f));
 }
+// ImuError(measurements, parameters, t_0, t_1) on (pose_0, speed/bias_0, pose_1, speed/bias_1)  (ImuError.cpp:58-75, Map.cpp:341-376):
+// what Estimator::addStates creates between consecutive frames, with the blocks named by the caller
+uint64_t Window::mapAddImuError(const uint64_t ids[4], const uint32_t* imuT, const double* imuM, int nImu, const ImuParams& par,
+                                TimeStamp t0, TimeStamp t1) {
+  if (!ids || !imuT || !imuM || nImu < 2) return 0;
+  Block *p0 = findBlock(ids[0]), *s0 = findBlock(ids[1]), *p1 = findBlock(ids[2]), *s1 = findBlock(ids[3]);
+  if (!p0 || !s0 || !p1 || !s1 || p0->kind != B_POSE || p1->kind != B_POSE || s0->kind != B_SB || s1->kind != B_SB) return 0;
+  Factor f;
+  f.kind = F_IMU; f.nblk = 4; f.m = 15;
+  for (int k = 0; k < 4; ++k) f.blocks[k] = ids[k];
+  f.imuT.assign(imuT, imuT + 2 * (size_t)nImu);
+  f.imuMeas.assign(imuM, imuM + 6 * (size_t)nImu);
+  std::memset(&f.imu, 0, sizeof(f.imu));
+  f.imu.sampleCount = nImu;
+  f.imu.t0[0] = t0.sec; f.imu.t0[1] = t0.nsec;
+  f.imu.t1[0] = t1.sec; f.imu.t1[1] = t1.nsec;
+  f.imu.par = par;
+  f.imu.redo = 1;
+  f.imu.Delta_q[3] = 1.0;
+  return addFactor(std::move(f));
+}
+// SonarError(range, heading, information, landmark patch) on a pose block  (SonarError.cpp:57-183; T_SSo as set for the handle:
+// the reference only ever passes the identity); the residual uses the MEAN of the patch (:124-131)
+uint64_t Window::mapAddSonarError(uint64_t poseBlock, double range, double heading, double information, const double* patch, int nPatch) {
+  Block* b = findBlock(poseBlock);
+  if (!b || b->kind != B_POSE || !patch || nPatch < 1 || !(information > 0.0)) return 0;
+  Factor f;
+  f.kind = F_SONAR; f.nblk = 1; f.blocks[0] = poseBlock; f.m = 1;
+  f.meas[0] = range; f.meas[1] = heading;
+  double mean[3] = {0, 0, 0};
+  for (int i = 0; i < nPatch; ++i) { mean[0] += patch[3 * i]; mean[1] += patch[3 * i + 1]; mean[2] += patch[3 * i + 2]; }
+  f.meas[2] = mean[0] / nPatch; f.meas[3] = mean[1] / nPatch; f.meas[4] = mean[2] / nPatch;
+  std::memcpy(f.aux, T_SSo_, sizeof(T_SSo_));
+  f.sqrtInfo[0] = std::sqrt(information);
+  return addFactor(std::move(f));
+}
+// DepthError(depth, information, first depth) on a pose block  (DepthError.cpp:50-139)
+uint64_t Window::mapAddDepthError(uint64_t poseBlock, double depth, double information, double firstDepth) {
+  Block* b = findBlock(poseBlock);
+  if (!b || b->kind != B_POSE || !(information > 0.0)) return 0;
+  Factor f;
+  f.kind = F_DEPTH; f.nblk = 1; f.blocks[0] = poseBlock; f.m = 1;
+  f.meas[0] = depth; f.meas[1] = firstDepth;
+  f.sqrtInfo[0] = std::sqrt(information);
+  return addFactor(std::move(f));
+}
 // ReprojectionError<GEOMETRY>(geometry of camera `cam`, uv, information) with CauchyLoss(1) on (pose, landmark, extrinsics):
 // what Estimator::addObservation creates, with the blocks named by the caller.  The device kernels store ONE weight per
 // residual (Estimator only ever passes 64 / size^2 * I), so the information has to be a multiple of the identity.

@@ -221,6 +221,10 @@ class Window {
   uint64_t mapAddPoseError(uint64_t blockId, const double* meas7, const double* information36);                 // PoseError.cpp:49-132
   uint64_t mapAddSpeedAndBiasError(uint64_t blockId, const double* meas9, const double* information81);         // SpeedAndBiasError.cpp:47-113
   uint64_t mapAddRelativePoseError(uint64_t block0, uint64_t block1, const double* information36);              // RelativePoseError.cpp:48-147
+  uint64_t mapAddImuError(const uint64_t ids[4], const uint32_t* imuT, const double* imuM, int nImu, const ImuParams& par, TimeStamp t0,
+                          TimeStamp t1);                                                                         // ImuError.cpp:58-75
+  uint64_t mapAddSonarError(uint64_t poseBlock, double range, double heading, double information, const double* patch, int nPatch);   // SonarError.cpp:57-183
+  uint64_t mapAddDepthError(uint64_t poseBlock, double depth, double information, double firstDepth);             // DepthError.cpp:50-139
   uint64_t mapAddReprojectionError(uint64_t poseBlock, uint64_t landmark, uint64_t extBlock, uint64_t cam, const double* uv,
                                    const double* information4);                                                 // ReprojectionError + CauchyLoss(1)
   int mapRemoveResidualBlock(uint64_t resId);

@@ -59,6 +59,7 @@ EXPORTS = [
     "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_residual_info",
     "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
     "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
+    "svin_ba_map_add_imu_error", "svin_ba_map_add_sonar_error", "svin_ba_map_add_depth_error",
     "svin_ba_map_remove_residual_block", "svin_ba_bench_kernel_times",
     "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
@@ -172,6 +173,9 @@ def load_library():
     sig("svin_ba_map_add_pose_error", u64, vp, u64, pd, pd)
     sig("svin_ba_map_add_speed_and_bias_error", u64, vp, u64, pd, pd)
     sig("svin_ba_map_add_relative_pose_error", u64, vp, u64, u64, pd)
+    sig("svin_ba_map_add_imu_error", u64, vp, pu64, vp, i32, vp, u32, u32, u32, u32)
+    sig("svin_ba_map_add_sonar_error", u64, vp, u64, f64, f64, f64, pd, i32)
+    sig("svin_ba_map_add_depth_error", u64, vp, u64, f64, f64, f64)
     sig("svin_ba_map_add_reprojection_error", u64, vp, u64, u64, u64, u64, pd, pd)
     sig("svin_ba_map_remove_residual_block", i32, vp, u64)
     sig("svin_ba_debug_csr", i32, vp, pi32, pi32, pi32, pi32, C.POINTER(C.c_uint32), pd, pd, pd, pi32, pi32)
@@ -825,6 +829,21 @@ class Estimator:
     def map_add_relative_pose_error(self, b0, b1, information):
         i = _arr(np.asarray(information, float).reshape(6, 6))
         return int(self.L.svin_ba_map_add_relative_pose_error(self.h, b0, b1, _d(i)))
+
+    def map_add_imu_error(self, blocks4, imu_t, imu_m, params, t0, t1):
+        """ImuError on (pose_0, speed/bias_0, pose_1, speed/bias_1); imu_t (n, 2) uint32 stamps, imu_m (n, 6) gyr | acc"""
+        ids = np.asarray(blocks4, np.uint64)
+        imu = pack_imu(imu_t, imu_m)
+        p = make_imu_params(params)
+        return int(self.L.svin_ba_map_add_imu_error(self.h, ids.ctypes.data_as(pu64), imu.ctypes.data_as(C.c_void_p), len(imu), C.byref(p),
+                                                    int(t0[0]), int(t0[1]), int(t1[0]), int(t1[1])))
+
+    def map_add_sonar_error(self, pose, rng_m, heading, information, patch):
+        pt = _arr(np.asarray(patch, float).reshape(-1, 3))
+        return int(self.L.svin_ba_map_add_sonar_error(self.h, pose, float(rng_m), float(heading), float(information), _d(pt), len(pt)))
+
+    def map_add_depth_error(self, pose, depth, information, first_depth):
+        return int(self.L.svin_ba_map_add_depth_error(self.h, pose, float(depth), float(information), float(first_depth)))
 
     def map_add_reprojection_error(self, pose, landmark, ext, cam, uv, information):
         u, i = _arr(uv), _arr(np.asarray(information, float).reshape(2, 2))

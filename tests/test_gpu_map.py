@@ -180,3 +180,75 @@ def test_map_built_window_against_oracle_map(gpu_lib, constant_landmarks):
             assert np.array_equal(est.get_parameter_block(10 + i), m.get_param(10 + i))
     # TestMap.cpp:140-144: converged to the true pose within the test's tolerances
     assert quat_close(T[3:], T_WS[3:]) * 2 < 1e-2 and np.linalg.norm(T[:3] - T_WS[:3]) < 1e-1
+
+
+def test_imu_sonar_depth_errors_through_the_map_interface(gpu_lib):
+    """Map::addResidualBlock (Map.cpp:341-376) for the factor kinds okvis::Estimator otherwise creates inside addStates --
+    ImuError, SonarError, DepthError -- on blocks named by the caller (svin_ba_map_add_imu_error / _sonar_error / _depth_error):
+    two poses + speed / bias blocks tied by an IMU factor, priors on the first pair, a depth and a sonar term on the second pose,
+    reprojection residuals of 60 landmarks; cost, iteration count and the optimum against the oracle's Map built by the same calls."""
+    from svin_amd.estimator import Estimator
+    from oracle import orc
+    spec = syn.make_window(P=2, L=60, n_obs=None, seed=31, frame_dt=0.4)
+    est, m, L = Estimator(0), orc.OracleMap(), orc.lib()
+    cam0 = spec.cameras[0]
+    for cam in spec.cameras:
+        est.add_camera(cam["model"], cam["intr"], cam["dist"], cam["width"], cam["height"], [0, 0, 0, 0])
+    POSE, SB, EXT, LM0 = (1, 3), (2, 4), (5, 6), 100
+    T = [spec.T_WS_true[0].copy(), spec.T_WS_init[1].copy()]
+    sb = [spec.sb_true[0].copy(), spec.sb_init[1].copy()]
+    for k in range(2):
+        assert est.map_add_parameter_block(POSE[k], est.BLOCK_POSE, T[k]) and est.map_add_parameter_block(SB[k], est.BLOCK_SPEED_AND_BIAS, sb[k])
+        m.add_param(POSE[k], orc.BLOCK_POSE, T[k]); m.add_param(SB[k], orc.BLOCK_SPEEDBIAS, sb[k])
+    for c, cam in enumerate(spec.cameras):
+        assert est.map_add_parameter_block(EXT[c], est.BLOCK_POSE, cam["T_SC"]) and est.set_parameter_block_constant(EXT[c])
+        m.add_param(EXT[c], orc.BLOCK_POSE, cam["T_SC"]); m.set_constant(EXT[c])
+    info6, info9 = np.diag([1e6] * 3 + [1e6] * 3), np.diag([1e2] * 3 + [1e4] * 3 + [1e2] * 3)
+    assert est.map_add_pose_error(POSE[0], T[0], info6) and est.map_add_speed_and_bias_error(SB[0], sb[0], info9)
+    L.orc_map_add_pose_error(m.h, orc.dptr(orc.arr(T[0])), orc.dptr(orc.arr(info6)), POSE[0])
+    L.orc_map_add_speedbias_error(m.h, orc.dptr(orc.arr(sb[0])), 1e-2, 1e-4, 1e-2, SB[0])
+    # the IMU samples between the two frames, as addStates would be handed them
+    t = spec.imu_t[:, 0].astype(float) - float(spec.imu_t[0, 0]) + 1e-9 * spec.imu_t[:, 1]
+    f = spec.stamps[:, 0].astype(float) - float(spec.imu_t[0, 0]) + 1e-9 * spec.stamps[:, 1]
+    sel = (t >= f[0] - 0.02) & (t <= f[1] + 0.02)
+    ids4 = [POSE[0], SB[0], POSE[1], SB[1]]
+    t0, t1 = (int(spec.stamps[0, 0]), int(spec.stamps[0, 1])), (int(spec.stamps[1, 0]), int(spec.stamps[1, 1]))
+    rid_imu = est.map_add_imu_error(ids4, spec.imu_t[sel], spec.imu_meas[sel], spec.imu_params, t0, t1)
+    assert rid_imu != 0
+    m.add_imu(spec.imu_t[sel], spec.imu_meas[sel], orc.imu_params_vector(spec.imu_params), t0, t1, ids4)
+    # depth and sonar on the second pose
+    depth, first_depth = 1.3, 0.2
+    assert est.map_add_depth_error(POSE[1], depth, 5.0, first_depth) != 0
+    L.orc_map_add_depth_error(m.h, depth, 5.0, first_depth, POSE[1])
+    patch = spec.T_WS_true[1][:3] + np.array([[0.9, 0.3, 0.1], [0.95, 0.28, 0.12], [0.88, 0.33, 0.08]])
+    rng_m = float(np.linalg.norm(patch.mean(0) - spec.T_WS_true[1][:3])) + 0.01
+    assert est.map_add_sonar_error(POSE[1], rng_m, 0.3, 1.0, patch) != 0
+    Tid = np.r_[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    L.orc_map_add_sonar_error(m.h, orc.dptr(orc.arr(Tid)), rng_m, 0.3, 1.0, len(patch), orc.dptr(orc.arr(patch)), POSE[1])
+    # landmarks and their reprojection residuals
+    for l in range(spec.L):
+        assert est.map_add_parameter_block(LM0 + l, est.BLOCK_HOMOGENEOUS_POINT, spec.lm_init[l])
+        m.add_param(LM0 + l, orc.BLOCK_HPOINT, spec.lm_init[l])
+    n_res = 0
+    for i in range(spec.N):
+        k, c, l = int(spec.obs_frame[i]), int(spec.obs_cam[i]), int(spec.obs_lm[i])
+        w = 64.0 / spec.obs_size[i] ** 2
+        assert est.map_add_reprojection_error(POSE[k], LM0 + l, EXT[c], c, spec.obs_uv[i], [w, 0, 0, w]) != 0
+        cam = spec.cameras[c]
+        m.add_reproj(cam["model"], cam["intr"], cam["dist"], spec.obs_uv[i], [w, 0, 0, w], orc.LOSS_CAUCHY, POSE[k], LM0 + l, EXT[c])
+        n_res += 1
+    assert n_res > 100
+    est.set_solver_options(1e-14, 1e-14, 1e-14)
+    L.orc_map_set_tolerances(m.h, 1e-14, 1e-14, 1e-14)
+    est.optimize(40)
+    s, so = est.summary(), m.solve(40)
+    print("map-built IMU / sonar / depth graph: gpu", s, "oracle", so)
+    assert s["iterations"] == so["iterations"]
+    assert abs(s["initial_cost"] - so["initial_cost"]) <= 1e-9 * so["initial_cost"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= 1e-9 * max(so["final_cost"], 1e-12)
+    for k in range(2):
+        Tg, To = est.get_parameter_block(POSE[k]), m.get_param(POSE[k])
+        assert np.linalg.norm(Tg[:3] - To[:3]) < 1e-8 and quat_close(Tg[3:], To[3:]) < 1e-8
+        assert np.max(np.abs(est.get_parameter_block(SB[k]) - m.get_param(SB[k]))) < 1e-7
+    # Map::removeResidualBlock on the IMU factor
+    assert est.map_remove_residual_block(rid_imu) and not est.map_remove_residual_block(rid_imu)
