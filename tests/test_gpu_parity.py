@@ -1050,15 +1050,15 @@ def test_marginalization_sequence_euroc_reference_window(gpu_lib):
 
 @pytest.mark.parametrize("rig,window,P", [("euroc", (2, 3), 8), ("rig_v2", (5, 3), 13)])
 def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P):
-    """M3 has ONE eigen-solver (Cholesky-preconditioned one-sided Jacobi: image in LDS, or in global memory for priors
-    beyond 136 unknowns) and ONE fall-back (one-sided Jacobi on A itself, taken when a pivot of the factorisation is not
-    positive; SVIN_MARG_EIG=jacobi forces it).  Both must hand the optimiser the same prior: J^T J, J^T e0 of the last
-    prior of a sliding window, and the window it leads to."""
+    """M3's eigen-solvers: the direct one (round 5: tridiagonalisation + divide and conquer, priors up to 128 unknowns), behind
+    it the Cholesky-preconditioned one-sided Jacobi of rounds 2-4 (SVIN_MARG_EIG=cholesky runs it alone; also the solver of
+    larger priors) and ITS fall-back, the one-sided Jacobi on A itself (SVIN_MARG_EIG=jacobi).  All three must hand the optimiser
+    the same prior: J^T J, J^T e0 of the last prior of a sliding window, and the window it leads to."""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=P, L=250, n_obs=2500 if rig == "euroc" else 3000, seed=44 if rig == "euroc" else 45, rig=rig,
                            keyframe_every=2, frame_dt=0.3)
     out = {}
-    for mode in ("default", "jacobi"):
+    for mode in ("default", "cholesky", "jacobi"):
         if mode == "default":
             monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
         else:
@@ -1070,13 +1070,14 @@ def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P
         assert m is not None
         out[mode] = dict(m=m, removed=removed, poses=[est.get_T_WS(a) for a in est.frame_ids()])
     monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
-    o = compare_priors(out["jacobi"]["m"], out["default"]["m"], "eigen-solver fall-back vs default, %s" % rig)
-    worst = max(pose_diff(a, b) for a, b in zip(out["jacobi"]["poses"], out["default"]["poses"]))
-    log(rig, "pose difference fall-back vs default", worst)
-    assert out["jacobi"]["removed"] == out["default"]["removed"]
-    assert o["selfH"] < 1e-9
-    assert o["dH"] < 1e-6 and o["dJtJ"] < 1e-6
-    assert worst < (1e-4 if rig == "euroc" else 5e-3)
+    for other in ("cholesky", "jacobi"):
+        o = compare_priors(out[other]["m"], out["default"]["m"], "eigen-solver %s vs default (direct), %s" % (other, rig))
+        worst = max(pose_diff(a, b) for a, b in zip(out[other]["poses"], out["default"]["poses"]))
+        log(rig, "pose difference %s vs default" % other, worst)
+        assert out[other]["removed"] == out["default"]["removed"]
+        assert o["selfH"] < 1e-9
+        assert o["dH"] < 1e-6 and o["dJtJ"] < 1e-6
+        assert worst < (1e-4 if rig == "euroc" else 5e-3)
 
 
 @pytest.mark.parametrize("rig", ["euroc", "rig_v2"])
