@@ -547,6 +547,74 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, in
     a.Qm[idx] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
+  // The pseudo-inverse of V' drops the eigenvalues <= eps nm lambda_max (MarginalizationError.hpp:48-220).  The marginalised
+  // pose / speed-bias block is well conditioned in every frame of the sliding windows (eigenvalues of V' 0.5 .. 1.7, unit
+  // diagonal), and then NOTHING is dropped and (V')^+ = (V')^-1 = R^-1 R^-T: a Cholesky factor is a proof -- lambda_min >=
+  // 1 / trace(V'^-1) = 1 / |R^-1|_F^2 and lambda_max <= trace(V') = nm, so 1 / |R^-1|_F^2 > eps nm^2 certifies the rank rule's
+  // outcome without an eigenvalue -- and N = D^-1 R^-1 replaces D^-1 Q sqrt(1 / lambda) (N N^T is the same matrix).  The
+  // eigen-solve below remains for blocks the certificate does not cover (a non-positive pivot, a gauge freedom in the block).
+  __shared__ int sDirect;
+  if (t == 0) sDirect = 0;
+  __syncthreads();
+  if (useLds) {
+    lds_double* sR = toLds(jacobiLds);
+    const int ldr = nm | 1;
+    lds_double* sX = sR + nm * ldr;
+    const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
+    for (int idx = t; idx < nm * ldr; idx += nt) { const int r = idx / ldr, c = idx - r * ldr; sR[idx] = (c >= r && c < nm) ? a.Vm[(size_t)r * nm + c] : 0.0; }
+    __syncthreads();
+    bool pos = true;
+    for (int k = 0; k + 1 < nm && pos; ++k) {   // right-looking on the upper triangle, row k left unscaled: one barrier per step
+      const double pivot = sR[k * ldr + k];
+      if (!(pivot > 0.0)) { pos = false; break; }
+      const double rp = 1.0 / pivot;
+      for (int j = k + 1 + wave; j < nm; j += nWaves) {
+        const double f = sR[k * ldr + j] * rp;
+        for (int i = j + lane; i < nm; i += 64) sR[j * ldr + i] -= f * sR[k * ldr + i];
+      }
+      ldsBarrier();
+    }
+    if (pos && !(sR[(nm - 1) * ldr + (nm - 1)] > 0.0)) pos = false;
+    if (pos) {   // (uniform: every thread read the same pivots)
+      for (int k = wave; k < nm; k += nWaves) {
+        const double rs = rsqrt(sR[k * ldr + k]);
+        for (int i = k + lane; i < nm; i += 64) sR[k * ldr + i] *= rs;
+      }
+      __syncthreads();
+      // X = R^-1 (upper triangular), one column per thread by back substitution; its squared Frobenius norm
+      double fro = 0;
+      if (t < nm) {
+        const int j = t;
+        for (int i = nm - 1; i > j; --i) sX[i * ldr + j] = 0.0;
+        sX[j * ldr + j] = 1.0 / sR[j * ldr + j];
+        for (int i = j - 1; i >= 0; --i) {
+          double acc = 0;
+          for (int k = i + 1; k <= j; ++k) acc += sR[i * ldr + k] * sX[k * ldr + j];
+          sX[i * ldr + j] = -acc / sR[i * ldr + i];
+        }
+        for (int i = 0; i <= j; ++i) fro += sX[i * ldr + j] * sX[i * ldr + j];
+      }
+      __shared__ double sFro[16];
+      fro = waveSumM(fro);
+      if ((t & 63) == 0) sFro[t >> 6] = fro;
+      __syncthreads();
+      if (t == 0) {
+        double f2 = 0;
+        for (int w = 0; w < nWaves; ++w) f2 += sFro[w];
+        sDirect = (f2 > 0.0 && 1.0 / f2 > 2.220446049250313e-16 * (double)nm * (double)nm) ? 1 : 0;
+      }
+      __syncthreads();
+      if (sDirect) {   // N^T row j = column j of N = D^-1 R^-1 e_j
+        for (int idx = t; idx < nm * nm; idx += nt) {
+          const int j = idx / nm, i = idx - j * nm;
+          a.Qm[idx] = (i <= j) ? sX[i * ldr + j] / pm[i] : 0.0;
+        }
+        if (t == 0) a.flag[5] = 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (!sDirect) {
   jacobiEig(a.Vm, a.Qm, nm, a.flag, useLds ? jacobiLds : nullptr);
   // eigenvalues, tolerance, N = D^-1 Q diag(sqrt(1/l)|0)  (column j of N = eigenvector j scaled)
   __shared__ double smax;
@@ -564,6 +632,8 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, in
     const int j = idx / nm, i = idx % nm;
     const double sc = (tv[j] > tol) ? sqrt(1.0 / tv[j]) : 0.0;
     a.Qm[idx] = a.Qm[idx] * sc / pm[i];
+  }
+  if (t == 0) a.flag[5] = 0;
   }
   __syncthreads();
   // Mu = W N  (W = U[keep, marg]) : Mu[r][j] = sum_i W[r][i] N[i][j] = sum_i W[r][i] Qm[j][i]; then Hk = U[keep, keep] - Mu Mu^T,
