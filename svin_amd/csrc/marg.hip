@@ -842,13 +842,124 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
   return true;
 }
 
+// ---- M3 without an eigenvalue, when the prior has full numerical rank (round 5).  The reference drops the eigen-directions of the
+// Jacobi-scaled H = p A p with lambda <= eps n lambda_max (MarginalizationError.cpp:739-742) and takes J = (p U sqrt(S))^T,
+// e0 = -(sqrt(S)^+ U^T p^-1) b0.  The optimiser sees the prior through J^T J, J^T e0 and e0.e0 only, which ANY square root of
+// the kept part delivers -- and when nothing is dropped, the Cholesky factor is one: A = R^T R, J = R p, e0 = -R^-T p^-1 b0,
+// J^T J = H, J^T e0 = -b0.  "Nothing is dropped" is certified, not assumed: lambda_min >= 1 / trace(A^-1) = 1 / |R^-1|_F^2 and
+// lambda_max <= trace(A) = n (unit diagonal), so 1 / |R^-1|_F^2 > eps n^2 implies every eigenvalue is above the reference's
+// threshold.  Steady-state priors of both sliding windows pass (smallest eigenvalue 1e-8, threshold 9e-14); a prior with a
+// gauge freedom, a non-positive pivot or a failed certificate writes flag[4] = 0 and k_marg_final_dc, enqueued behind, does
+// the eigen-solve.  One workgroup: right-looking Cholesky on the upper triangle in LDS (one barrier per column), then R^-1
+// column by column, 8 lanes per column with the column in registers (its Frobenius norm and e0 = -X^T (b0 / p) fall out).
+__global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
+  extern __shared__ double jacobiLds[];
+  lds_double* R = toLds(jacobiLds);
+  const int t = threadIdx.x, nt = 1024, n = a.n, ld = n | 1;
+  const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
+  double* p = a.tmp;            // n
+  double* bt = a.tmp + n;       // n: b0 / p
+  __shared__ double sFro[16];
+  __shared__ int sOk;
+  const long long tStart = wall_clock64();
+  if (t == 0) a.flag[4] = 0;
+  for (int i = t; i < n; i += nt) { const double pi = margScale(a.H[(size_t)i * n + i]); p[i] = pi; bt[i] = a.b0[i] / pi; }
+  __syncthreads();
+  for (int idx = t; idx < n * ld; idx += nt) {
+    const int r = idx / ld, c = idx - r * ld;
+    R[idx] = (c >= r && c < n) ? 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (p[r] * p[c]) : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k + 1 < n; ++k) {
+    const double pivot = R[k * ld + k];
+    if (!(pivot > 0.0)) return;   // (uniform)
+    const double rp = 1.0 / pivot;
+    for (int j = k + 1 + wave; j < n; j += nWaves) {
+      const double f = R[k * ld + j] * rp;
+      for (int i = j + lane; i < n; i += 64) R[j * ld + i] -= f * R[k * ld + i];
+    }
+    ldsBarrier();
+  }
+  if (!(R[(n - 1) * ld + (n - 1)] > 0.0)) return;
+  for (int k = wave; k < n; k += nWaves) {
+    const double rs = rsqrt(R[k * ld + k]);
+    for (int i = k + lane; i < n; i += 64) R[k * ld + i] *= rs;
+  }
+  __syncthreads();
+  const long long tChol = wall_clock64();
+  // X = R^-1, column j by the 8 lanes of group j: lane `sub` keeps X[sub + 8 q][j], q = 0 .. 15
+  {
+    const int j = t >> 3, sub = t & 7;
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = 0.0;
+    for (int i = n - 1; i >= 0; --i) {
+      double acc = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = sub + 8 * q;
+        if (k > i && k <= j && k < n) acc += R[i * ld + k] * x[q];
+      }
+      acc = symeig::sum8(acc);
+      if (i <= j && j < n) {
+        const double xi = (i == j) ? 1.0 / R[j * ld + j] : -acc / R[i * ld + i];
+        if ((i & 7) == sub) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) x[q] = (q == (i >> 3)) ? xi : x[q];
+        }
+      }
+    }
+    double fro = 0, e = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int k = sub + 8 * q; if (k < n) { fro += x[q] * x[q]; e += x[q] * bt[k]; } }
+    e = symeig::sum8(e);
+    if (j < n && sub == 0) a.e0[j] = -e;
+    fro = waveSumM(j < n ? fro : 0.0);
+    if (lane == 0) sFro[wave] = fro;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double f2 = 0;
+    for (int w = 0; w < nWaves; ++w) f2 += sFro[w];
+    sOk = (f2 > 0.0 && f2 < 1.0e300 && 1.0 / f2 > 2.220446049250313e-16 * (double)n * (double)n) ? 1 : 0;
+    a.scal[1] = f2 > 0.0 ? 1.0 / f2 : 0.0;   // (a lower bound of the smallest eigenvalue, an upper bound of the largest)
+    a.scal[2] = (double)n;
+  }
+  __syncthreads();
+  if (!sOk) return;
+  // J = R p (row i = row i of R, columns scaled), Ht = the symmetrised H itself (= J^T J), bp = J^T e0 = -b0, c0 = e0.e0
+  for (int idx = t; idx < n * n; idx += nt) {
+    const int i = idx / n, j = idx - i * n;
+    a.J[idx] = (j >= i) ? (double)R[i * ld + j] * p[j] : 0.0;
+    a.Ht[idx] = 0.5 * (a.H[idx] + a.H[(size_t)j * n + i]);
+  }
+  for (int i = t; i < n; i += nt) a.bp[i] = -a.b0[i];
+  __syncthreads();
+  if (t < 64) {
+    double c = 0;
+    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
+    c = waveSumM(c);
+    if (t == 0) {
+      a.scal[0] = c;
+      a.scal[3] = 0.0; a.scal[4] = (double)(tChol - tStart); a.scal[5] = (double)(wall_clock64() - tChol);
+      a.scal[6] = 0.0;
+      a.scal[7] = (double)n;
+      a.flag[1] = 0; a.flag[2] = 0;
+      a.flag[3] = -8;   // marks the mode in the SVIN_MARG_TIMING line
+      __threadfence();
+      a.flag[4] = 1;
+    }
+  }
+}
+
 // ---- M3 by a direct eigen-solve (round 5): tridiagonalisation + divide and conquer (symeig.hpp) instead of ~1 400 dependent
 // Jacobi rounds.  H = p A p (A with a unit diagonal), A = U S U^T; J = (p U sqrt(S))^T, e0 = -(sqrt(S)^+ U^T p^-1) b0 with the
 // eigenvalues <= eps n lambda_max dropped (MarginalizationError.cpp:739-742), and the H-space form the solver reads: Ht = J^T J,
 // bp = J^T e0, c0 = e0.e0.  Writes flag[4] = 1 when it has produced the prior; k_marg_final, enqueued right behind it with
 // `skipIfDone`, then returns at once -- otherwise (a non-finite result) it runs the Jacobi solve as before.
-__global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a) {
+__global__ __launch_bounds__(1024) void k_marg_final_dc(FinalArgs a, int skipIfDone) {
   extern __shared__ double jacobiLds[];
+  if (skipIfDone && a.flag[4] == 1) return;   // k_marg_final_chol, enqueued ahead of this launch, has produced the prior
   lds_double* X = toLds(jacobiLds);
   const int t = threadIdx.x, n = a.n, ld = n | 1;
   double* p = a.tmp;            // n
@@ -1709,11 +1820,21 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         // default since round 5: the direct solve (tridiagonalisation + divide and conquer) for priors up to 128 unknowns, the
         // Jacobi kernel behind it as the fall-back for a non-finite result (it returns at once when flag[4] says "done");
         // SVIN_MARG_EIG=cholesky / jacobi select the round-2 solvers alone
-        const bool direct = !want && nk <= kSymEigMaxN;
+        // ... and ahead of both, for a prior of full numerical rank (every steady-state prior of the sliding windows), the Cholesky
+        // factor with its certificate that the rank rule drops nothing (k_marg_final_chol); SVIN_MARG_EIG=direct skips it
+        const bool wantDirect = want && std::string(want) == "direct";
+        const bool direct = (!want || wantDirect) && nk <= kSymEigMaxN;
+        const bool chol = !want && nk <= kSymEigMaxN;
+        if (chol) {
+          const size_t ldsC = symEigLdsBytes(nk);
+          ensureDynamicLds((const void*)k_marg_final_chol, ldsC);
+          hipLaunchKernelGGL(k_marg_final_chol, dim3(1), dim3(1024), ldsC, s, fa);
+          HIP_OK(hipGetLastError());
+        }
         if (direct) {
           const size_t ldsDc = symEigLdsBytes(nk);
           ensureDynamicLds((const void*)k_marg_final_dc, ldsDc);
-          hipLaunchKernelGGL(k_marg_final_dc, dim3(1), dim3(1024), ldsDc, s, fa);
+          hipLaunchKernelGGL(k_marg_final_dc, dim3(1), dim3(1024), ldsDc, s, fa, chol ? 1 : 0);
           HIP_OK(hipGetLastError());
         }
         if (lds) ensureDynamicLds((const void*)k_marg_final, lds);

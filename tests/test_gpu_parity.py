@@ -1050,15 +1050,16 @@ def test_marginalization_sequence_euroc_reference_window(gpu_lib):
 
 @pytest.mark.parametrize("rig,window,P", [("euroc", (2, 3), 8), ("rig_v2", (5, 3), 13)])
 def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P):
-    """M3's eigen-solvers: the direct one (round 5: tridiagonalisation + divide and conquer, priors up to 128 unknowns), behind
-    it the Cholesky-preconditioned one-sided Jacobi of rounds 2-4 (SVIN_MARG_EIG=cholesky runs it alone; also the solver of
-    larger priors) and ITS fall-back, the one-sided Jacobi on A itself (SVIN_MARG_EIG=jacobi).  All three must hand the optimiser
-    the same prior: J^T J, J^T e0 of the last prior of a sliding window, and the window it leads to."""
+    """M3's four routes: by default a Cholesky factor when it can certify that the rank rule drops nothing (k_marg_final_chol),
+    else the direct eigen-solve (SVIN_MARG_EIG=direct runs it for every prior: tridiagonalisation + divide and conquer, up to
+    128 unknowns), behind it the Cholesky-preconditioned one-sided Jacobi of rounds 2-4 (SVIN_MARG_EIG=cholesky runs it alone;
+    also the solver of larger priors) and ITS fall-back, the one-sided Jacobi on A itself (SVIN_MARG_EIG=jacobi).  All must hand
+    the optimiser the same prior: J^T J, J^T e0 of the last prior of a sliding window, and the window it leads to."""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=P, L=250, n_obs=2500 if rig == "euroc" else 3000, seed=44 if rig == "euroc" else 45, rig=rig,
                            keyframe_every=2, frame_dt=0.3)
     out = {}
-    for mode in ("default", "cholesky", "jacobi"):
+    for mode in ("default", "direct", "cholesky", "jacobi"):
         if mode == "default":
             monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
         else:
@@ -1070,7 +1071,7 @@ def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P
         assert m is not None
         out[mode] = dict(m=m, removed=removed, poses=[est.get_T_WS(a) for a in est.frame_ids()])
     monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
-    for other in ("cholesky", "jacobi"):
+    for other in ("direct", "cholesky", "jacobi"):
         o = compare_priors(out[other]["m"], out["default"]["m"], "eigen-solver %s vs default (direct), %s" % (other, rig))
         worst = max(pose_diff(a, b) for a, b in zip(out[other]["poses"], out["default"]["poses"]))
         log(rig, "pose difference %s vs default" % other, worst)
