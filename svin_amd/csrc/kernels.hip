@@ -6,7 +6,7 @@
 // K5  k_schur_dense      landmark elimination as a Gram matrix S = A - G G^T on v_mfma_f64_16x16x4_f64 (narrow windows);
 //     k_schur_panels     the same in 96-row panel pairs (wide windows); k_schur: pairwise blocks with LDS atomics (fallback)
 //     k_reduce_slabs     deterministic sum of the per-workgroup slabs
-// K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS (d <= 176), trailing update on MFMA
+// K6  k_chol_solve_lds   blocked Cholesky of the reduced system in LDS (d <= 176; <true>: d = 177 .. 180, the rows beyond eliminated while loading), trailing update on MFMA
 //     k_chol_solve_ll    (176 < d <= 272) left-looking variant: at most 72 live tiles in LDS behind a slot map
 //     k_big_chol_chain   (d > 272) one-launch tile Cholesky over many workgroups + super-panel backward substitution
 //     k_sb_factor / k_sb_forward / k_sb_load / k_sb_back   wide windows: the chain of 9x9 speed / bias blocks eliminated by cyclic
@@ -42,7 +42,7 @@ void ensureDynamicLds(const void* fn, size_t bytes) {
 // A/B switches of the reduced solve: read from the environment ONCE (launchSolveReduced runs several times per trust-region
 // iteration, also on the enqueue thread: getenv there would race with a setenv of the host process), changed afterwards through
 // setSolverSwitch only (svin_ba_debug_set_switch: tests and tools).
-static std::atomic<int> gNoLL{-1}, gNoSbElim{-1};
+static std::atomic<int> gNoLL{-1}, gNoSbElim{-1}, gNoLdsBorder{-1};
 static bool switchOn(std::atomic<int>& sw, const char* env) {
   int v = sw.load(std::memory_order_relaxed);
   if (v < 0) {
@@ -57,6 +57,7 @@ int setSolverSwitch(const char* name, int value) {
   const std::string n(name);
   if (n == "SVIN_NO_LL") gNoLL.store(value ? 1 : 0);
   else if (n == "SVIN_NO_SB_ELIM") gNoSbElim.store(value ? 1 : 0);
+  else if (n == "SVIN_NO_LDS_BORDER") gNoLdsBorder.store(value ? 1 : 0);
   else return 0;
   return 1;
 }
@@ -3359,6 +3360,11 @@ __device__ __forceinline__ double* tileAt(double* base, int I, int J) { return b
 
 constexpr int kCholLdsThreads = 512;  // 8 waves (16 waves measured slower: LDS pressure, the diagonal block is the critical path)
 constexpr int kCholFlagInts = 48;
+#ifdef SVIN_CHOL_TIMING
+constexpr int kCholBorderOff = 240;   // (doubles behind the flags: the timing build's stamp buffer comes first)
+#else
+constexpr int kCholBorderOff = 0;
+#endif
 // Flags of the barrier-free factorisation (LDS ints, monotonic counters, written by exactly one wave each):
 //   fl[0]       pivotDone  number of diagonal tiles whose factor D(kb) and 1/L_ii are in LDS
 //   fl[1 + I]   xReady[I]  number of block columns for which the panel tile X(I, .) of tile row I is stored
@@ -3416,12 +3422,21 @@ __device__ __forceinline__ int cholFlagWaitAll(int* f, int n, int v, int lane, i
 // waves are still waiting for theirs; the damping is added by the lanes that hold the diagonal entries (no second
 // barrier); gFull and the damped diagonal metric stay in registers / LDS, so the kernel ends with stores only.
 // (two waves per SIMD by construction: the register budget is 256 VGPRs, which keeps a wave's ~45 loads in ONE batch)
+// kBorder (d = 177 .. 180: the stereo_rig_v2 sliding window with four speed / bias blocks is 180): the system is `border` <= 4 rows
+// larger than the eleven tile rows LDS holds.  Those rows are eliminated FIRST, while the tiles are loaded: with the border block
+// C = Lc Lc^T (damped like every diagonal entry), B the border's rows under the main block and V = Lc^-1 B (4 x 176),
+//   A' = A - V^T V  (one 16x16x4 product per tile: lane (g, c) supplies -V[g][16 I + c] and V[g][16 J + c]; the same products in the
+//                    same order on either side of the diagonal, so diagonal tiles stay exactly symmetric),
+//   g' = g1 - B^T C^-1 g2,   y2 = C^-1 (g2 - B y1)  after the main solve.
+// Any elimination order is stable for a positive definite matrix; the kernel below this prologue is the d = 176 solver unchanged.
+// The instantiation without border is the code of rounds 3-5 (every border statement sits under if constexpr).
+template <bool kBorder>
 __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
-                                                                    int fuseFinalize) {
+                                                                    int fuseFinalize, int border) {
   extern __shared__ double smem[];
   SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS),
             SA(p.sPadded), SA(dpad), SA(mu), SA(initScale), SA(fuseFinalize));
-  const int t = threadIdx.x, d = p.d, nT = dpad / 16;
+  const int t = threadIdx.x, d = kBorder ? p.d - border : p.d, nT = dpad / 16;   // d: rows of the main block
   // the wave index through v_readfirstlane: tile indices and LDS tile addresses become scalar (SALU) arithmetic
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = kCholLdsThreads / 64;
   const int nTilesAll = nT * (nT + 1) / 2;
@@ -3457,7 +3472,88 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #endif
   const int ldS = p.ldS ? p.ldS : d;
   // right-hand side, full gradient, and (without the fused metric) the metric of an earlier pass: one element per thread
-  const double rhsMine = (t < d) ? p.gRed[t] : 0.0;
+  double rhsMine = (t < d) ? p.gRed[t] : 0.0;
+  // ---- border prologue: every lane factorises the (at most) 4 x 4 border block itself (uniform values)
+  double lgB[4] = {0, 0, 0, 0};            // row g of Lc^-1 (what turns a column of B into this lane row's entry of V)
+  double LiB[4][4], qB[4] = {0, 0, 0, 0};  // Lc^-1 (lower), q = C^-1 g2
+  double htB[4] = {1, 1, 1, 1}, scB[4] = {1, 1, 1, 1};
+  double bEnd[3] = {0, 0, 0};              // row `wave` of B at columns lane, lane + 64, lane + 128 (the product B y1 at the end)
+  auto bAt = [&](int a, int col) { return (a < border) ? p.S[(size_t)(d + a) * ldS + col] : 0.0; };
+  if constexpr (kBorder) {
+    double Cb[4][4], g2[4], bcol[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) Cb[a][b] = (a < border) ? p.S[(size_t)(d + a) * ldS + d + b] : (a == b ? 1.0 : 0.0);
+      g2[a] = (a < border) ? p.gRed[d + a] : 0.0;
+      bcol[a] = (t < d) ? bAt(a, t) : 0.0;
+      const int ia = d + min(a, border - 1);
+      const double hc = fuseFinalize ? p.hC[ia] : 0.0;
+      double sc = (fuseFinalize && !initScale) ? p.scaleC[ia] : 1.0;
+      double ht = fuseFinalize ? 0.0 : p.htilC[ia];
+      if (fuseFinalize) {   // the same metric and damping dampDiag gives a diagonal entry of the main block
+        if (initScale) sc = 1.0 / (1.0 + sqrt(hc));
+        ht = fmin(fmax(hc * sc * sc, 1e-6), 1e32) / (sc * sc);
+        if (a < border) Cb[a][a] += mu * ht;
+      }
+      htB[a] = ht; scB[a] = sc;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bEnd[k] = (wave < 4 && lane + 64 * k < d) ? bAt(wave, lane + 64 * k) : 0.0;
+    // Lc (lower) in place, then its inverse by forward substitution on the unit vectors
+    bool bad = false;
+    double rd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double dj = Cb[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) dj = __builtin_fma(-Cb[j][k], Cb[j][k], dj);
+      bad = bad || !(dj > 0);
+      const double lj = sqrt(dj > 0 ? dj : 1.0);
+      Cb[j][j] = lj;
+      rd[j] = 1.0 / lj;
+#pragma unroll
+      for (int i = j + 1; i < 4; ++i) {
+        double v = Cb[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v = __builtin_fma(-Cb[i][k], Cb[j][k], v);
+        Cb[i][j] = v * rd[j];
+      }
+    }
+    if (bad && t == 0) atomicOr(&p.scal->cholFail, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // column j of Lc^-1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < j) { LiB[i][j] = 0.0; continue; }
+        double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = j; k < i; ++k) v = __builtin_fma(-Cb[i][k], LiB[k][j], v);
+        LiB[i][j] = v * rd[i];
+      }
+    }
+    double u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k <= i; ++k) u[i] = __builtin_fma(LiB[i][k], g2[k], u[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      qB[k] = 0.0;
+#pragma unroll
+      for (int i = k; i < 4; ++i) qB[k] = __builtin_fma(LiB[i][k], u[i], qB[k]);
+      rhsMine = __builtin_fma(-bcol[k], qB[k], rhsMine);   // g' = g1 - B^T q
+      lgB[k] = selectByRow(lane >> 4, LiB[0][k], LiB[1][k], LiB[2][k], LiB[3][k]);
+    }
+  }
+  // entry of V this lane supplies to a tile product, from its own lane row's entry of the column of B: V[g][col] = sum_b Lc^-1[g][b] B[b][col]
+  auto vOf = [&](double bMine) {
+    double P[4];
+    allGatherRows(bMine, P);
+    return __builtin_fma(lgB[3], P[3], __builtin_fma(lgB[2], P[2], __builtin_fma(lgB[1], P[1], lgB[0] * P[0])));
+  };
   const double gFullMine = (t < d) ? p.gFull[t] : 0.0;
   const double htilOld = (!fuseFinalize && t < d) ? p.htilC[t] : 1.0;
   if (t < kCholFlagInts) fl[t] = 0;
@@ -3631,6 +3727,10 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     tileSelect(0, 0, v0);
     if (fuseFinalize) storeMetric(dampDiag(0, true, hc0, sc0, v0));
     d4_t accD = {v0[0], v0[1], v0[2], v0[3]};
+    if constexpr (kBorder) {
+      const double v = vOf(bAt(g, c));
+      accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, accD, 0, 0, 0);
+    }
 #ifdef SVIN_CHOL_TIMING
     long long pivotCycles = 0;
 #endif
@@ -3689,7 +3789,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       int dI[2], oI[kMaxOff], oJ[kMaxOff];
       dI[0] = min(1 + ldr, nT - 1);
       dI[1] = min(7 + ldr, nT - 1);
-      const bool dmaOff = p.sPadded != 0;
+      const bool dmaOff = kBorder || p.sPadded != 0;   // (the border variant is only launched on a padded S)
 #pragma unroll
       for (int it = 0; it < kMaxOff; ++it) {
         if (dmaOff) { oI[it] = 1; oJ[it] = 0; continue; }   // (the DMA path walks whole tile rows: no index search)
@@ -3702,6 +3802,18 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       }
       double vd[2][4], hcv[2], scv[2], vo[kMaxOff][4];
       MetricOut metricOut[2] = {{-1, 0.0, 0.0}, {-1, 0.0, 0.0}};
+      // border: this lane row's entries of B at the columns of the tiles this wave loads -- its two diagonal tiles, its two DMA rows
+      // (rowA, rowB below) and every tile column J < 10 those rows cross; requested with the tiles, turned into V after the batch
+      constexpr int kBorderCols = 10;
+      double bDiag[2] = {0, 0}, bRow[2] = {0, 0}, bJ[kBorderCols];
+      if constexpr (kBorder) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) bDiag[sl] = bAt(g, 16 * dI[sl] + c);
+        bRow[0] = bAt(g, 16 * min(1 + ldr, nT - 1) + c);
+        bRow[1] = bAt(g, 16 * (nT - 1 - ldr) + c);
+#pragma unroll
+        for (int J = 0; J < kBorderCols; ++J) bJ[J] = bAt(g, 16 * J + c);
+      }
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         tileRequest(dI[sl], dI[sl], vd[sl]);
@@ -3756,6 +3868,16 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #ifdef SVIN_CHOL_TIMING
       if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP_FINE(8, 1); }   // all values have arrived
 #endif
+      if constexpr (kBorder) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const double v = vOf(bDiag[sl]);
+          d4_t a = {vd[sl][0], vd[sl][1], vd[sl][2], vd[sl][3]};
+          a = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, a, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) vd[sl][rg] = a[rg];
+        }
+      }
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const bool valid = (sl == 0 ? 1 + ldr : 7 + ldr) < nT;
@@ -3777,6 +3899,31 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of this wave have landed
+      if constexpr (kBorder) {
+        // the off-diagonal tiles this wave brought in (its two DMA rows): tile (I, J) -= V_I^T V_J, in place
+        double vJ[kBorderCols];
+#pragma unroll
+        for (int J = 0; J < kBorderCols; ++J) vJ[J] = vOf(bJ[J]);
+        auto borderRow = [&](int I, double vI) {
+          double* T = tileAt(tiles, I, 0);
+#pragma unroll
+          for (int J = 0; J < kBorderCols; ++J) {
+            if (J < I) {
+              d4_t a;
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) a[rg] = T[lrow + 4 * rg * kPanelLd];
+              a = __builtin_amdgcn_mfma_f64_16x16x4f64(-vI, vJ[J], a, 0, 0, 0);
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) T[lrow + 4 * rg * kPanelLd] = a[rg];
+            }
+            T += kTile;
+          }
+        };
+        const int rowA = 1 + ldr, rowB = nT - 1 - ldr;
+        const double vA = vOf(bRow[0]), vB = vOf(bRow[1]);
+        if (rowB > rowA) borderRow(rowB, vB);
+        if (rowA <= rowB && rowA < nT) borderRow(rowA, vA);
+      }
       storeMetric(metricOut[0]);
       storeMetric(metricOut[1]);
     }
@@ -4025,6 +4172,37 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   if (t < 240) p.partial[(size_t)15 * 4096 + 64 + t] = stampBuf[t];
 #endif
   if (t < d) { p.yC[t] = rhs[t]; p.vC[t] = gFullMine / htil[t]; }  // Gauss-Newton solution + steepest-descent direction
+  if constexpr (kBorder) {
+    // y2 = q - C^-1 (B y1): row a of B y1 on wave a, then one thread per border row
+    double* bord = reinterpret_cast<double*>(fl + kCholFlagInts) + kCholBorderOff;
+    if (wave < 4) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc = __builtin_fma(bEnd[k], (lane + 64 * k < d) ? rhs[lane + 64 * k] : 0.0, acc);
+      acc = waveSum(acc);
+      if (lane == 0) bord[wave] = acc;
+    }
+    ldsBarrier();
+    if (t < border) {
+      double w[4], z = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k <= i; ++k) w[i] = __builtin_fma(LiB[i][k], bord[k], w[i]);
+      }
+      const double q = selectByRow(t, qB[0], qB[1], qB[2], qB[3]);
+      const double ht = selectByRow(t, htB[0], htB[1], htB[2], htB[3]), sc = selectByRow(t, scB[0], scB[1], scB[2], scB[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z = __builtin_fma(selectByRow(t, LiB[i][0], LiB[i][1], LiB[i][2], LiB[i][3]), w[i], z);   // (Lc^-T w)[t]
+      p.yC[d + t] = q - z;
+      p.vC[d + t] = p.gFull[d + t] / ht;
+      if (fuseFinalize) {
+        if (initScale) p.scaleC[d + t] = sc;
+        p.htilC[d + t] = ht;
+      }
+    }
+  }
 #undef CHOL_SPINS
 #undef CHOL_NOTE
 #undef CHOL_STAMP
@@ -5568,17 +5746,23 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #undef LLT
 }
 
-// LDS bytes of k_chol_solve_lds for nT tile rows
+// LDS bytes of k_chol_solve_lds for nT tile rows (+ four doubles of the border variant)
 static size_t cholLdsBytes(int nT) {
 #ifdef SVIN_CHOL_TIMING
-  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 240 * 8;
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 240 * 8 + 4 * 8;
 #else
-  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4;
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 4 * 8;
 #endif
 }
-static int solverClass(int d) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
+constexpr int kCholLdsMaxTiles = 11;   // tile rows of the largest system LDS holds (156 KB)
+// rows beyond the LDS-resident solver's eleven tile rows that it eliminates while loading (k_chol_solve_lds<true>); needs the window's padded S
+static int cholBorderRows(int d, bool padded) {
+  const int m = d - 16 * kCholLdsMaxTiles;
+  return (padded && m >= 1 && m <= 4 && !switchOn(gNoLdsBorder, "SVIN_NO_LDS_BORDER")) ? m : 0;
+}
+static int solverClass(int d, bool padded = false) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
   const int nT = (d + 15) / 16;
-  if (cholLdsBytes(nT) <= 156 * 1024) return 0;
+  if (cholLdsBytes(nT) <= 156 * 1024 || cholBorderRows(d, padded) > 0) return 0;
   if (nT >= 12 && nT <= 17 && !switchOn(gNoLL, "SVIN_NO_LL")) return 1;
   return 2;
 }
@@ -5589,12 +5773,12 @@ static int solverClass(int d) {   // 0 = LDS-resident, 1 = left-looking in one w
 // elimination's four launches cost more), and so is a chain of fewer than 8 blocks ahead of the blocked solver.
 static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
   if (switchOn(gNoSbElim, "SVIN_NO_SB_ELIM") || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
-  if (solverClass(p.d) == 0) return 0;
+  if (solverClass(p.d, p.sPadded != 0) == 0) return 0;
   // Measured (tools/sb_elim_time.py, reduced solve with / without): d = 180 66 / 64 us, 240: 73 / 91, 270: 85 / 113, 360: 99 / 183,
   // 600: 185 / 313, 960: 289 / 476 -- the four launches cost ~45 us before they gain anything, so short chains stay with the
   // dense solvers.  (Tried and dropped: eliminating only the last blocks of a chain in ONE fused launch so that a system a few
-  // rows over the LDS-resident solver's limit -- the stereo_rig_v2 sliding window, d = 180 -- drops into it: 39 + 35 + 10 us
-  // against the left-looking solver's 70.)
+  // rows over the LDS-resident solver's limit drops into it: 39 + 35 + 10 us against the left-looking solver's 70.  d = 177 .. 180
+  // is now the LDS-resident solver's own border variant; the stereo_rig_v2 sliding window is d = 198.)
   const int mode = solverClass(p.dC) == 2 ? 1 : 2;
   if (p.sbChain < (mode == 1 ? 8 : 16)) return 0;
   a.n = p.sbChain; a.dK = p.dC;
@@ -5625,12 +5809,18 @@ static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
 static void launchSolveDense(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize, const SbElimArgs* sb) {
   const int dpad = ((p.d + 15) / 16) * 16;
   const int nT = dpad / 16;
-  const int cls = solverClass(p.d);
-  if (cls == 0) {
+  const int cls = solverClass(p.d, p.sPadded != 0);
+  const int border = cholBorderRows(p.d, p.sPadded != 0);
+  if (cls == 0 && border > 0) {
+    const size_t ldsBytes = cholLdsBytes(kCholLdsMaxTiles);
+    ensureDynamicLds((const void*)k_chol_solve_lds<true>, ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds<true>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, 16 * kCholLdsMaxTiles, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, border);
+  } else if (cls == 0) {
     const size_t ldsBytes = cholLdsBytes(nT);
-    ensureDynamicLds((const void*)k_chol_solve_lds, ldsBytes);
-    hipLaunchKernelGGL(k_chol_solve_lds, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
-                       fuseFinalize ? 1 : 0);
+    ensureDynamicLds((const void*)k_chol_solve_lds<false>, ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds<false>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, 0);
   } else if (cls == 1) {
     // one workgroup, left-looking: at most 72 live tiles in LDS, finished tiles written through to p.cholL
     const size_t ldsLL = llLdsDoubles(nT) * 8;

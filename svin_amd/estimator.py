@@ -760,7 +760,7 @@ class Estimator:
 
     @staticmethod
     def debug_set_switch(name, value):
-        """process-wide A/B switch of the reduced solve ("SVIN_NO_LL", "SVIN_NO_SB_ELIM")"""
+        """process-wide A/B switch of the reduced solve ("SVIN_NO_LL", "SVIN_NO_SB_ELIM", "SVIN_NO_LDS_BORDER")"""
         if load_library().svin_ba_debug_set_switch(name.encode(), 1 if value else 0) != 1:
             raise KeyError(name)
 

@@ -71,6 +71,49 @@ def test_device_solve_equals_host_solve(gpu_lib, sb_elim_switch, P, L, n_obs, ri
         assert max(err.values()) < tol
 
 
+@pytest.mark.parametrize("keyframes,imu_frames,frames,rig,d_expected", [
+    (22, 2, 34, "euroc", 177),    # 25 poses + 3 speed / bias blocks: ONE row beyond the eleven tile rows
+    (4, 3, 16, "rig_v2", 180),    # stereo_rig_v2 + sonar + depth: 8 poses + 16 extrinsics + 4 speed / bias blocks -- four rows beyond
+])
+def test_lds_solver_with_border_rows(gpu_lib, keyframes, imu_frames, frames, rig, d_expected):
+    """d = 177 .. 180 on the LDS-resident solver (k_chol_solve_lds<true>: the rows beyond 176 are eliminated while the tiles are
+    loaded) on the systems of a sliding window that has been through marginalisations (prior + IMU chain + extrinsics chain in the
+    reduced system): against LAPACK, and against the left-looking solver the switch SVIN_NO_LDS_BORDER falls back to."""
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=frames, L=60 * frames, n_obs=600 * frames, seed=3, rig=rig, frame_dt=0.25,
+                           sonar=rig == "rig_v2", depth=rig == "rig_v2")
+    est = Estimator(0)
+    seen, hits = set(), []
+
+    def compare():
+        for mu, tol in ((1e-4, 1e-10), (1e-9, 1e-6)):
+            lin = est.linearize(mu)
+            y_ref = host_solve(lin)
+            scale = np.abs(y_ref).max()
+            err = {}
+            for off in (False, True):
+                Estimator.debug_set_switch("SVIN_NO_LDS_BORDER", off)
+                for fused in (False, True):
+                    err[off, fused] = np.abs(est.debug_reduced_solve(mu, fused=fused) - y_ref).max() / scale
+            print("d %d, mu %g: border variant vs host %.2e (fused %.2e), left-looking %.2e (fused %.2e)" %
+                  (lin["d"], mu, err[False, False], err[False, True], err[True, False], err[True, True]))
+            assert max(err.values()) < tol
+        hits.append(1)
+
+    def on_frame(k, fid):
+        est.optimize(3)
+        d = est.linearize(1e-4)["d"]
+        seen.add(d)
+        if d == d_expected and len(hits) < 2:
+            compare()
+        est.apply_marginalization(keyframes, imu_frames)
+    try:
+        syn.feed(est, spec, on_frame=on_frame)
+    finally:
+        Estimator.debug_set_switch("SVIN_NO_LDS_BORDER", False)
+    assert hits, "no window of %d unknowns in the sequence (sizes seen: %s)" % (d_expected, sorted(seen))
+
+
 def test_chain_elimination_is_used_and_can_be_switched_off(gpu_lib, sb_elim_switch):
     """the two blocked paths give different roundings of the same step (so the switch really selects code), and the solver
     converges to the same optimum either way"""
