@@ -649,10 +649,26 @@ def run_sharded_children(world, force_sharded, transport="rccl", steps=None):
     if steps is not None:
         cmd += ["--steps", str(steps)]
     timeout = float(os.environ.get("SVIN_BENCH_SHARDED_TIMEOUT", "420"))
+    # the launcher and its ranks in a process group of their own: on a timeout the whole group goes (killing the launcher alone
+    # would leave its ranks spinning on the GPUs the remaining sub-records are measured on)
+    import signal
+    import types
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        so, se = proc.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
-        return {"error": "the sharded ranks did not finish within %.0f s (killed)" % timeout}
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except OSError:
+                break
+            try:
+                proc.communicate(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return {"error": "the sharded ranks did not finish within %.0f s (process group killed)" % timeout}
+    r = types.SimpleNamespace(stdout=so, stderr=se, returncode=proc.returncode)
     for line in r.stdout.decode(errors="replace").splitlines()[::-1]:
         if line.startswith("SHARDED_JSON:"):
             rec = json.loads(line[len("SHARDED_JSON:"):])
