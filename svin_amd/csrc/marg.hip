@@ -12,6 +12,7 @@
 // (U - W V^+ W^T with V^+ = D^-1 (D^-1 V D^-1)^+ D^-1), which is the same matrix in exact arithmetic.
 #include "window.hpp"
 #include "symeig.hpp"
+#include "tile16.hpp"
 #include <chrono>
 #include <memory>
 #include <type_traits>
@@ -850,97 +851,173 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
 // lambda_max <= trace(A) = n (unit diagonal), so 1 / |R^-1|_F^2 > eps n^2 implies every eigenvalue is above the reference's
 // threshold.  Steady-state priors of both sliding windows pass (smallest eigenvalue 1e-8, threshold 9e-14); a prior with a
 // gauge freedom, a non-positive pivot or a failed certificate writes flag[4] = 0 and k_marg_final_dc, enqueued behind, does
-// the eigen-solve.  One workgroup: right-looking Cholesky on the upper triangle in LDS (one barrier per column), then R^-1
-// column by column, 8 lanes per column with the column in registers (its Frobenius norm and e0 = -X^T (b0 / p) fall out).
+// the eigen-solve.  One workgroup, everything in 16 x 16 tiles on v_mfma_f64_16x16x4 (the unblocked first version -- one barrier
+// per column, R^-1 column by column on 8 lanes -- took 107 + 154 us at n = 117):
+//   * A = L L^T blocked right-looking over the lower tiles of the LDS image (identity padding to a multiple of 16): per block
+//     column the diagonal tile by wave 0 out of registers (cholDiag16Acc of the dense solvers, tile16.hpp: L and L^-1 of the tile
+//     into a 16 x 17 scratch tile), the panel tiles X = A_IK L_KK^-T one per wave, the trailing tiles A_IJ -= X_I X_J^T dealt over
+//     the 16 waves; three barriers per block column, eight block columns at n = 117;
+//   * Y = L^-1 one block column per wave without a barrier: Y_JJ is the scratch tile's inverse, Y_IJ = -L_II^-1 sum_K L_IK Y_KJ
+//     with the running sum in the accumulator layout, which IS the B operand of the product with L_II^-1; Y_IJ^T goes to the upper
+//     tile (J, I), which the factorisation never reads, so element Y[i][j] sits at image[j][i];
+//   * |Y|_F^2 (the certificate), e0 = -Y (b0 / p) (8 lanes per row), J = L^T p, Ht = the symmetrised H, bp = -b0, c0 = e0.e0.
+static size_t margCholLdsBytes(int n) {
+  const size_t nT = ((size_t)n + 15) / 16, NP = 16 * nT;
+  return (NP * (NP + 1) + nT * 16 * kPanelLd + NP) * sizeof(double);
+}
 __global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
   extern __shared__ double jacobiLds[];
-  lds_double* R = toLds(jacobiLds);
-  const int t = threadIdx.x, nt = 1024, n = a.n, ld = n | 1;
-  const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
+  const int t = threadIdx.x, nt = 1024, n = a.n, nT = (n + 15) >> 4, NP = 16 * nT, ld = NP + 1;
+  const int wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  lds_double* A = toLds(jacobiLds);                       // NP x ld image
+  double* DgGen = jacobiLds + (size_t)NP * ld;            // nT scratch tiles (16 x kPanelLd): L (lower) | L^-1 transposed (strict upper)
+  double* dinvGen = DgGen + nT * 16 * kPanelLd;           // 1 / L_ii
+  lds_double* Dg = toLds(DgGen);
+  lds_double* dinv = toLds(dinvGen);
   double* p = a.tmp;            // n
   double* bt = a.tmp + n;       // n: b0 / p
   __shared__ double sFro[16];
-  __shared__ int sOk;
+  __shared__ int sOk, sFail;
   const long long tStart = wall_clock64();
-  if (t == 0) a.flag[4] = 0;
+  if (t == 0) { a.flag[4] = 0; sFail = 0; }
   for (int i = t; i < n; i += nt) { const double pi = margScale(a.H[(size_t)i * n + i]); p[i] = pi; bt[i] = a.b0[i] / pi; }
   __syncthreads();
-  for (int idx = t; idx < n * ld; idx += nt) {
-    const int r = idx / ld, c = idx - r * ld;
-    R[idx] = (c >= r && c < n) ? 0.5 * (a.H[(size_t)r * n + c] + a.H[(size_t)c * n + r]) / (p[r] * p[c]) : 0.0;
+  for (int idx = t; idx < NP * ld; idx += nt) {
+    const int r = idx / ld, cc = idx - r * ld;
+    A[idx] = (r < n && cc < n) ? 0.5 * (a.H[(size_t)r * n + cc] + a.H[(size_t)cc * n + r]) / (p[r] * p[cc]) : ((r == cc) ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int k = 0; k + 1 < n; ++k) {
-    const double pivot = R[k * ld + k];
-    if (!(pivot > 0.0)) return;   // (uniform)
-    const double rp = 1.0 / pivot;
-    for (int j = k + 1 + wave; j < n; j += nWaves) {
-      const double f = R[k * ld + j] * rp;
-      for (int i = j + lane; i < n; i += 64) R[j * ld + i] -= f * R[k * ld + i];
-    }
-    ldsBarrier();
-  }
-  if (!(R[(n - 1) * ld + (n - 1)] > 0.0)) return;
-  for (int k = wave; k < n; k += nWaves) {
-    const double rs = rsqrt(R[k * ld + k]);
-    for (int i = k + lane; i < n; i += 64) R[k * ld + i] *= rs;
-  }
-  __syncthreads();
-  const long long tChol = wall_clock64();
-  // X = R^-1, column j by the 8 lanes of group j: lane `sub` keeps X[sub + 8 q][j], q = 0 .. 15
-  {
-    const int j = t >> 3, sub = t & 7;
-    double x[16];
+  // ---- A = L L^T over the lower tiles
+  auto loadAcc = [&](int I, int J) {
+    d4_t x;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = 0.0;
-    for (int i = n - 1; i >= 0; --i) {
-      double acc = 0;
+    for (int r = 0; r < 4; ++r) x[r] = A[(16 * I + g + 4 * r) * ld + 16 * J + c];
+    return x;
+  };
+  auto storeAcc = [&](int I, int J, const d4_t& x) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int k = sub + 8 * q;
-        if (k > i && k <= j && k < n) acc += R[i * ld + k] * x[q];
+    for (int r = 0; r < 4; ++r) A[(16 * I + g + 4 * r) * ld + 16 * J + c] = x[r];
+  };
+  // L_KK^-1 [row][col] (lower triangular) out of scratch tile K: strict lower part transposed in the tile's strict upper triangle
+  auto linvAt = [&](int K, int row, int col) {
+    const double off = Dg[K * 16 * kPanelLd + col * kPanelLd + row], dg = dinv[16 * K + row];
+    return (col < row) ? off : ((col == row) ? dg : 0.0);
+  };
+  for (int K = 0; K < nT; ++K) {
+    if (wave == 0) cholDiag16Acc<false>(loadAcc(K, K), DgGen + K * 16 * kPanelLd, dinvGen + 16 * K, lane, &sFail);
+    __syncthreads();
+    {
+      const int I = K + 1 + wave;   // panel tile (I, K) <- A_IK L_KK^-T
+      if (I < nT) {
+        d4_t x = {0.0, 0.0, 0.0, 0.0};
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+          bv[q] = linvAt(K, c, 4 * q + g);   // B[k][j] = L^-1[j][k]
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
+        storeAcc(I, K, x);
       }
-      acc = symeig::sum8(acc);
-      if (i <= j && j < n) {
-        const double xi = (i == j) ? 1.0 / R[j * ld + j] : -acc / R[i * ld + i];
-        if ((i & 7) == sub) {
+    }
+    symeig::ldsBarrier();
+    const int m = nT - 1 - K;
+    for (int id = wave; id < m * (m + 1) / 2; id += 16) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      const int I = K + 1 + r, J = K + 1 + (id - r * (r + 1) / 2);
+      d4_t acc = loadAcc(I, J);
+      double av[4], bv[4];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) x[q] = (q == (i >> 3)) ? xi : x[q];
+      for (int q = 0; q < 4; ++q) {
+        av[q] = -A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+        bv[q] = A[(16 * J + c) * ld + 16 * K + 4 * q + g];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+      storeAcc(I, J, acc);
+    }
+    symeig::ldsBarrier();
+  }
+  if (sFail) return;   // (uniform) a pivot was not positive: the eigen-solve behind this launch decides
+  const long long tChol = wall_clock64();
+  // ---- Y = L^-1, block column J on wave J; |Y|_F^2 on the way
+  {
+    double fro = 0.0;
+    if (wave < nT) {
+      const int J = wave;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // the diagonal tile's own inverse: entries (row 4q + g, column c)
+        const int row = 4 * q + g;
+        const double v = linvAt(J, row, c);
+        if (16 * J + row < n && 16 * J + c < n) fro = __builtin_fma(v, v, fro);
+      }
+      for (int I = J + 1; I < nT; ++I) {
+        d4_t sacc = {0.0, 0.0, 0.0, 0.0};
+        for (int K = J; K < I; ++K) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];                                   // L_IK[i = c][k]
+            bv[q] = (K == J) ? linvAt(J, 4 * q + g, c) : (double)A[(16 * J + c) * ld + 16 * K + 4 * q + g];   // Y_KJ[k][j = c]
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], sacc, 0, 0, 0);
+        }
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-linvAt(I, c, 4 * q + g), sacc[q], y, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          A[(16 * J + c) * ld + 16 * I + g + 4 * r] = y[r];   // Y_IJ[i = g + 4r][j = c], transposed into the upper tile (J, I)
+          fro = __builtin_fma(y[r], y[r], fro);               // (rows / columns of the padding are exactly zero here)
         }
       }
     }
-    double fro = 0, e = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const int k = sub + 8 * q; if (k < n) { fro += x[q] * x[q]; e += x[q] * bt[k]; } }
-    e = symeig::sum8(e);
-    if (j < n && sub == 0) a.e0[j] = -e;
-    fro = waveSumM(j < n ? fro : 0.0);
+    fro = waveSumM(fro);
     if (lane == 0) sFro[wave] = fro;
   }
   __syncthreads();
+  // e0 = -Y (b0 / p): 8 lanes per row
+  {
+    const int i = t >> 3, sub = t & 7;
+    double e = 0.0;
+    if (i < n) {
+      const int bi = i >> 4;
+      for (int j = sub; j <= i; j += 8) {
+        const double yv = ((j >> 4) < bi) ? (double)A[j * ld + i] : linvAt(bi, i & 15, j & 15);
+        e = __builtin_fma(yv, bt[j], e);
+      }
+    }
+    e = symeig::sum8(e);
+    if (i < n && sub == 0) a.e0[i] = -e;
+  }
   if (t == 0) {
     double f2 = 0;
-    for (int w = 0; w < nWaves; ++w) f2 += sFro[w];
+    for (int w = 0; w < 16; ++w) f2 += sFro[w];
     sOk = (f2 > 0.0 && f2 < 1.0e300 && 1.0 / f2 > 2.220446049250313e-16 * (double)n * (double)n) ? 1 : 0;
     a.scal[1] = f2 > 0.0 ? 1.0 / f2 : 0.0;   // (a lower bound of the smallest eigenvalue, an upper bound of the largest)
     a.scal[2] = (double)n;
   }
   __syncthreads();
   if (!sOk) return;
-  // J = R p (row i = row i of R, columns scaled), Ht = the symmetrised H itself (= J^T J), bp = J^T e0 = -b0, c0 = e0.e0
+  // J = L^T p (row i = column i of L, columns scaled), Ht = the symmetrised H itself (= J^T J), bp = J^T e0 = -b0, c0 = e0.e0
   for (int idx = t; idx < n * n; idx += nt) {
     const int i = idx / n, j = idx - i * n;
-    a.J[idx] = (j >= i) ? (double)R[i * ld + j] * p[j] : 0.0;
+    double lji = 0.0;   // L[j][i], j >= i
+    if (j >= i) lji = ((j >> 4) > (i >> 4)) ? (double)A[j * ld + i] : (double)Dg[(j >> 4) * 16 * kPanelLd + (j & 15) * kPanelLd + (i & 15)];
+    a.J[idx] = lji * p[j];
     a.Ht[idx] = 0.5 * (a.H[idx] + a.H[(size_t)j * n + i]);
   }
   for (int i = t; i < n; i += nt) a.bp[i] = -a.b0[i];
   __syncthreads();
   if (t < 64) {
-    double c = 0;
-    for (int k = t; k < n; k += 64) c += a.e0[k] * a.e0[k];
-    c = waveSumM(c);
+    double cs = 0;
+    for (int k = t; k < n; k += 64) cs += a.e0[k] * a.e0[k];
+    cs = waveSumM(cs);
     if (t == 0) {
-      a.scal[0] = c;
+      a.scal[0] = cs;
       a.scal[3] = 0.0; a.scal[4] = (double)(tChol - tStart); a.scal[5] = (double)(wall_clock64() - tChol);
       a.scal[6] = 0.0;
       a.scal[7] = (double)n;
@@ -1826,7 +1903,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         const bool direct = (!want || wantDirect) && nk <= kSymEigMaxN;
         const bool chol = !want && nk <= kSymEigMaxN;
         if (chol) {
-          const size_t ldsC = symEigLdsBytes(nk);
+          const size_t ldsC = margCholLdsBytes(nk);
           ensureDynamicLds((const void*)k_marg_final_chol, ldsC);
           hipLaunchKernelGGL(k_marg_final_chol, dim3(1), dim3(1024), ldsC, s, fa);
           HIP_OK(hipGetLastError());
