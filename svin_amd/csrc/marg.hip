@@ -519,6 +519,110 @@ __global__ __launch_bounds__(64) void k_marg_lm_update(MargDev md) {
   }
 }
 
+static size_t margCholLdsBytes(int n) {
+  const size_t nT = ((size_t)n + 15) / 16, NP = 16 * nT;
+  return (NP * (NP + 1) + nT * 16 * kPanelLd + NP) * sizeof(double);
+}
+// ---- blocked Cholesky and inverse of the factor on an LDS image, 1 024 threads, 16 x 16 tiles on v_mfma_f64_16x16x4 (k_marg_final_chol,
+// k_marg_dense).  A: NP x ld image (NP = 16 nT, ld = NP + 1), full symmetric, identity beyond the matrix; lower tiles <- L (off-diagonal
+// tiles), the diagonal tiles' L and L^-1 go to scratch tiles DgGen (16 x kPanelLd each: L lower, L^-1 transposed strict upper) and
+// dinvGen (1 / L_ii).  Three barriers per block column; *sFail gets a bit when a pivot is not positive (checked by the caller
+// behind the last barrier).
+__device__ __forceinline__ double tileLinvAt(const lds_double* Dg, const lds_double* dinv, int K, int row, int col) {
+  const double off = Dg[K * 16 * kPanelLd + col * kPanelLd + row], dg = dinv[16 * K + row];
+  return (col < row) ? off : ((col == row) ? dg : 0.0);
+}
+__device__ __forceinline__ void tileCholFactor(lds_double* A, int ld, int nT, double* DgGen, double* dinvGen, int* sFail) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  const lds_double* Dg = toLds(DgGen);
+  const lds_double* dinv = toLds(dinvGen);
+  auto loadAcc = [&](int I, int J) {
+    d4_t x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = A[(16 * I + g + 4 * r) * ld + 16 * J + c];
+    return x;
+  };
+  auto storeAcc = [&](int I, int J, const d4_t& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[(16 * I + g + 4 * r) * ld + 16 * J + c] = x[r];
+  };
+  for (int K = 0; K < nT; ++K) {
+    if (wave == 0) cholDiag16Acc<false>(loadAcc(K, K), DgGen + K * 16 * kPanelLd, dinvGen + 16 * K, lane, sFail);
+    __syncthreads();
+    {
+      const int I = K + 1 + wave;   // panel tile (I, K) <- A_IK L_KK^-T
+      if (I < nT) {
+        d4_t x = {0.0, 0.0, 0.0, 0.0};
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+          bv[q] = tileLinvAt(Dg, dinv, K, c, 4 * q + g);   // B[k][j] = L^-1[j][k]
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
+        storeAcc(I, K, x);
+      }
+    }
+    symeig::ldsBarrier();
+    const int m = nT - 1 - K;
+    for (int id = wave; id < m * (m + 1) / 2; id += 16) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      const int I = K + 1 + r, J = K + 1 + (id - r * (r + 1) / 2);
+      d4_t acc = loadAcc(I, J);
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q] = -A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+        bv[q] = A[(16 * J + c) * ld + 16 * K + 4 * q + g];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+      storeAcc(I, J, acc);
+    }
+    symeig::ldsBarrier();
+  }
+}
+// Y = L^-1, block column J on wave J without a barrier: Y_JJ is the scratch tile's inverse, Y_IJ = -L_II^-1 sum_K L_IK Y_KJ with the
+// running sum in the accumulator layout (which IS the B operand of the product with L_II^-1); Y_IJ^T goes to the upper tile (J, I), so
+// element Y[i][j] of two different tile rows sits at A[j * ld + i].  Returns this lane's part of |Y|_F^2 over the n x n matrix.
+__device__ __forceinline__ double tileCholInverse(lds_double* A, int ld, int nT, int n, const lds_double* Dg, const lds_double* dinv) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  double fro = 0.0;
+  if (wave < nT) {
+    const int J = wave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // the diagonal tile's own inverse: entries (row 4q + g, column c)
+      const int row = 4 * q + g;
+      const double v = tileLinvAt(Dg, dinv, J, row, c);
+      if (16 * J + row < n && 16 * J + c < n) fro = __builtin_fma(v, v, fro);
+    }
+    for (int I = J + 1; I < nT; ++I) {
+      d4_t sacc = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];                                                           // L_IK[i = c][k]
+          bv[q] = (K == J) ? tileLinvAt(Dg, dinv, J, 4 * q + g, c) : (double)A[(16 * J + c) * ld + 16 * K + 4 * q + g];   // Y_KJ[k][j = c]
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], sacc, 0, 0, 0);
+      }
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-tileLinvAt(Dg, dinv, I, c, 4 * q + g), sacc[q], y, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        A[(16 * J + c) * ld + 16 * I + g + 4 * r] = y[r];   // Y_IJ[i = g + 4r][j = c], transposed into the upper tile (J, I)
+        fro = __builtin_fma(y[r], y[r], fro);               // (rows / columns of the padding are exactly zero here)
+      }
+    }
+  }
+  return fro;
+}
+
 // ---------------------------------------------------------------- M2 dense part (:622-667) + M3 (:725-758)
 // Single workgroup.  keep/marg index lists select rows of U (m x m).  Outputs the reduced Hk (nk x nk), bk.
 struct DenseArgs {
@@ -529,7 +633,7 @@ struct DenseArgs {
   double *Vm, *Qm, *tmp;    // scratch: nm x nm, nm x nm, nk x nm + 2 nm
   int* flag;
 };
-__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, int prodLds) {
+__global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, int prodLds, int tileChol) {
   extern __shared__ double jacobiLds[];
   const int t = threadIdx.x, nt = blockDim.x, nm = a.nm, nk = a.nk, m = a.m;
   double* pm = a.tmp;                 // nm
@@ -557,58 +661,38 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, in
   __shared__ int sDirect;
   if (t == 0) sDirect = 0;
   __syncthreads();
-  if (useLds) {
-    lds_double* sR = toLds(jacobiLds);
-    const int ldr = nm | 1;
-    lds_double* sX = sR + nm * ldr;
-    const int wave = t >> 6, lane = t & 63, nWaves = nt >> 6;
-    for (int idx = t; idx < nm * ldr; idx += nt) { const int r = idx / ldr, c = idx - r * ldr; sR[idx] = (c >= r && c < nm) ? a.Vm[(size_t)r * nm + c] : 0.0; }
-    __syncthreads();
-    bool pos = true;
-    for (int k = 0; k + 1 < nm && pos; ++k) {   // right-looking on the upper triangle, row k left unscaled: one barrier per step
-      const double pivot = sR[k * ldr + k];
-      if (!(pivot > 0.0)) { pos = false; break; }
-      const double rp = 1.0 / pivot;
-      for (int j = k + 1 + wave; j < nm; j += nWaves) {
-        const double f = sR[k * ldr + j] * rp;
-        for (int i = j + lane; i < nm; i += 64) sR[j * ldr + i] -= f * sR[k * ldr + i];
-      }
-      ldsBarrier();
+  if (tileChol) {   // blocked on 16 x 16 MFMA tiles (tileCholFactor / tileCholInverse above; the unblocked first version took ~40 us at nm = 27)
+    const int nTm = (nm + 15) >> 4, NPm = 16 * nTm, ldm = NPm + 1;
+    lds_double* A = toLds(jacobiLds);
+    double* DgGen = jacobiLds + (size_t)NPm * ldm;
+    double* dinvGen = DgGen + nTm * 16 * kPanelLd;
+    const lds_double* Dg = toLds(DgGen);
+    const lds_double* dinv = toLds(dinvGen);
+    __shared__ int sFailD;
+    __shared__ double sFroD[16];
+    if (t == 0) sFailD = 0;
+    for (int idx = t; idx < NPm * ldm; idx += nt) {
+      const int r = idx / ldm, c = idx - r * ldm;
+      A[idx] = (r < nm && c < nm) ? a.Vm[(size_t)r * nm + c] : ((r == c) ? 1.0 : 0.0);
     }
-    if (pos && !(sR[(nm - 1) * ldr + (nm - 1)] > 0.0)) pos = false;
-    if (pos) {   // (uniform: every thread read the same pivots)
-      for (int k = wave; k < nm; k += nWaves) {
-        const double rs = rsqrt(sR[k * ldr + k]);
-        for (int i = k + lane; i < nm; i += 64) sR[k * ldr + i] *= rs;
-      }
-      __syncthreads();
-      // X = R^-1 (upper triangular), one column per thread by back substitution; its squared Frobenius norm
-      double fro = 0;
-      if (t < nm) {
-        const int j = t;
-        for (int i = nm - 1; i > j; --i) sX[i * ldr + j] = 0.0;
-        sX[j * ldr + j] = 1.0 / sR[j * ldr + j];
-        for (int i = j - 1; i >= 0; --i) {
-          double acc = 0;
-          for (int k = i + 1; k <= j; ++k) acc += sR[i * ldr + k] * sX[k * ldr + j];
-          sX[i * ldr + j] = -acc / sR[i * ldr + i];
-        }
-        for (int i = 0; i <= j; ++i) fro += sX[i * ldr + j] * sX[i * ldr + j];
-      }
-      __shared__ double sFro[16];
-      fro = waveSumM(fro);
-      if ((t & 63) == 0) sFro[t >> 6] = fro;
+    __syncthreads();
+    tileCholFactor(A, ldm, nTm, DgGen, dinvGen, &sFailD);
+    if (!sFailD) {   // (uniform)
+      const double fro = waveSumM(tileCholInverse(A, ldm, nTm, nm, Dg, dinv));
+      if ((t & 63) == 0) sFroD[t >> 6] = fro;
       __syncthreads();
       if (t == 0) {
         double f2 = 0;
-        for (int w = 0; w < nWaves; ++w) f2 += sFro[w];
-        sDirect = (f2 > 0.0 && 1.0 / f2 > 2.220446049250313e-16 * (double)nm * (double)nm) ? 1 : 0;
+        for (int w = 0; w < 16; ++w) f2 += sFroD[w];
+        sDirect = (f2 > 0.0 && f2 < 1.0e300 && 1.0 / f2 > 2.220446049250313e-16 * (double)nm * (double)nm) ? 1 : 0;
       }
       __syncthreads();
-      if (sDirect) {   // N^T row j = column j of N = D^-1 R^-1 e_j
+      if (sDirect) {   // N^T row j = column j of N = D^-1 R^-1 e_j, R^-1 = L^-T: N^T[j][i] = L^-1[j][i] / pm[i], i <= j
         for (int idx = t; idx < nm * nm; idx += nt) {
           const int j = idx / nm, i = idx - j * nm;
-          a.Qm[idx] = (i <= j) ? sX[i * ldr + j] / pm[i] : 0.0;
+          double y = 0.0;
+          if (i <= j) y = ((i >> 4) < (j >> 4)) ? (double)A[i * ldm + j] : tileLinvAt(Dg, dinv, j >> 4, j & 15, i & 15);
+          a.Qm[idx] = y / pm[i];
         }
         if (t == 0) a.flag[5] = 1;
       }
@@ -861,10 +945,6 @@ __device__ bool margFinalCholesky(const FinalArgs& a, P lds, int ld) {
 //     with the running sum in the accumulator layout, which IS the B operand of the product with L_II^-1; Y_IJ^T goes to the upper
 //     tile (J, I), which the factorisation never reads, so element Y[i][j] sits at image[j][i];
 //   * |Y|_F^2 (the certificate), e0 = -Y (b0 / p) (8 lanes per row), J = L^T p, Ht = the symmetrised H, bp = -b0, c0 = e0.e0.
-static size_t margCholLdsBytes(int n) {
-  const size_t nT = ((size_t)n + 15) / 16, NP = 16 * nT;
-  return (NP * (NP + 1) + nT * 16 * kPanelLd + NP) * sizeof(double);
-}
 __global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
   extern __shared__ double jacobiLds[];
   const int t = threadIdx.x, nt = 1024, n = a.n, nT = (n + 15) >> 4, NP = 16 * nT, ld = NP + 1;
@@ -887,95 +967,11 @@ __global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
     A[idx] = (r < n && cc < n) ? 0.5 * (a.H[(size_t)r * n + cc] + a.H[(size_t)cc * n + r]) / (p[r] * p[cc]) : ((r == cc) ? 1.0 : 0.0);
   }
   __syncthreads();
-  // ---- A = L L^T over the lower tiles
-  auto loadAcc = [&](int I, int J) {
-    d4_t x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = A[(16 * I + g + 4 * r) * ld + 16 * J + c];
-    return x;
-  };
-  auto storeAcc = [&](int I, int J, const d4_t& x) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) A[(16 * I + g + 4 * r) * ld + 16 * J + c] = x[r];
-  };
-  // L_KK^-1 [row][col] (lower triangular) out of scratch tile K: strict lower part transposed in the tile's strict upper triangle
-  auto linvAt = [&](int K, int row, int col) {
-    const double off = Dg[K * 16 * kPanelLd + col * kPanelLd + row], dg = dinv[16 * K + row];
-    return (col < row) ? off : ((col == row) ? dg : 0.0);
-  };
-  for (int K = 0; K < nT; ++K) {
-    if (wave == 0) cholDiag16Acc<false>(loadAcc(K, K), DgGen + K * 16 * kPanelLd, dinvGen + 16 * K, lane, &sFail);
-    __syncthreads();
-    {
-      const int I = K + 1 + wave;   // panel tile (I, K) <- A_IK L_KK^-T
-      if (I < nT) {
-        d4_t x = {0.0, 0.0, 0.0, 0.0};
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];
-          bv[q] = linvAt(K, c, 4 * q + g);   // B[k][j] = L^-1[j][k]
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
-        storeAcc(I, K, x);
-      }
-    }
-    symeig::ldsBarrier();
-    const int m = nT - 1 - K;
-    for (int id = wave; id < m * (m + 1) / 2; id += 16) {
-      int r = 0;
-      while ((r + 1) * (r + 2) / 2 <= id) ++r;
-      const int I = K + 1 + r, J = K + 1 + (id - r * (r + 1) / 2);
-      d4_t acc = loadAcc(I, J);
-      double av[4], bv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        av[q] = -A[(16 * I + c) * ld + 16 * K + 4 * q + g];
-        bv[q] = A[(16 * J + c) * ld + 16 * K + 4 * q + g];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-      storeAcc(I, J, acc);
-    }
-    symeig::ldsBarrier();
-  }
+  tileCholFactor(A, ld, nT, DgGen, dinvGen, &sFail);
   if (sFail) return;   // (uniform) a pivot was not positive: the eigen-solve behind this launch decides
   const long long tChol = wall_clock64();
-  // ---- Y = L^-1, block column J on wave J; |Y|_F^2 on the way
   {
-    double fro = 0.0;
-    if (wave < nT) {
-      const int J = wave;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {   // the diagonal tile's own inverse: entries (row 4q + g, column c)
-        const int row = 4 * q + g;
-        const double v = linvAt(J, row, c);
-        if (16 * J + row < n && 16 * J + c < n) fro = __builtin_fma(v, v, fro);
-      }
-      for (int I = J + 1; I < nT; ++I) {
-        d4_t sacc = {0.0, 0.0, 0.0, 0.0};
-        for (int K = J; K < I; ++K) {
-          double av[4], bv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];                                   // L_IK[i = c][k]
-            bv[q] = (K == J) ? linvAt(J, 4 * q + g, c) : (double)A[(16 * J + c) * ld + 16 * K + 4 * q + g];   // Y_KJ[k][j = c]
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], sacc, 0, 0, 0);
-        }
-        d4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-linvAt(I, c, 4 * q + g), sacc[q], y, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          A[(16 * J + c) * ld + 16 * I + g + 4 * r] = y[r];   // Y_IJ[i = g + 4r][j = c], transposed into the upper tile (J, I)
-          fro = __builtin_fma(y[r], y[r], fro);               // (rows / columns of the padding are exactly zero here)
-        }
-      }
-    }
-    fro = waveSumM(fro);
+    const double fro = waveSumM(tileCholInverse(A, ld, nT, n, Dg, dinv));
     if (lane == 0) sFro[wave] = fro;
   }
   __syncthreads();
@@ -986,7 +982,7 @@ __global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
     if (i < n) {
       const int bi = i >> 4;
       for (int j = sub; j <= i; j += 8) {
-        const double yv = ((j >> 4) < bi) ? (double)A[j * ld + i] : linvAt(bi, i & 15, j & 15);
+        const double yv = ((j >> 4) < bi) ? (double)A[j * ld + i] : tileLinvAt(Dg, dinv, bi, i & 15, j & 15);
         e = __builtin_fma(yv, bt[j], e);
       }
     }
@@ -1864,9 +1860,11 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
           const size_t ldsEig = jacobiLdsBytes(nm);
           const size_t ldsProd = sizeof(double) * ((size_t)2 * nk * nm + (size_t)nm * nm);   // W, Mu, N^T of the products
           const bool prodLds = ldsProd <= kJacobiLdsLimit;
-          const size_t lds = std::max(ldsEig, prodLds ? ldsProd : (size_t)0);
+          const size_t ldsTile = margCholLdsBytes(nm);   // the certified Cholesky route of the pseudo-inverse, on tiles
+          const bool tileChol = ldsTile <= kJacobiLdsLimit;
+          const size_t lds = std::max(std::max(ldsEig, prodLds ? ldsProd : (size_t)0), tileChol ? ldsTile : (size_t)0);
           if (lds) ensureDynamicLds((const void*)k_marg_dense, lds);
-          hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, ldsEig ? 1 : 0, prodLds ? 1 : 0);
+          hipLaunchKernelGGL(k_marg_dense, dim3(1), dim3(1024), lds, s, da, ldsEig ? 1 : 0, prodLds ? 1 : 0, tileChol ? 1 : 0);
           HIP_OK(hipGetLastError());   // (a refused launch would leave a garbage prior behind)
         }
       } else {
