@@ -415,7 +415,7 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
                                    note="one workgroup, n dependent Householder steps + log2 n merge levels: latency-bound (DESIGN.md); "
                                         "the Jacobi solve of rounds 1-4 took 2.1 ms on this matrix.  In the steady state of this window "
                                         "the prior has full numerical rank and k_marg_final_chol (Cholesky factor + a certificate that the "
-                                        "rank rule drops nothing, ~0.26 ms at this size) answers in its place; this solve runs when the "
+                                        "rank rule drops nothing, ~0.06 ms at this size) answers in its place; this solve runs when the "
                                         "certificate fails (rank-deficient priors of the first frames)")
         except Exception as ex:   # noqa: BLE001
             rec["roofline"] = {"error": repr(ex)}
