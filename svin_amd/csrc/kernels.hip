@@ -3298,13 +3298,22 @@ __device__ __forceinline__ int cholFlagWaitAll(int* f, int n, int v, int lane, i
 //   g' = g1 - B^T C^-1 g2,   y2 = C^-1 (g2 - B y1)  after the main solve.
 // Any elimination order is stable for a positive definite matrix; the kernel below this prologue is the d = 176 solver unchanged.
 // The instantiation without border is the code of rounds 3-5 (every border statement sits under if constexpr).
-template <bool kBorder>
+// kBorder = 2 (d = 181 .. 200: the stereo_rig_v2 sliding window is 198): up to 24 border rows.  The border block is factorised and
+// V = Lc^-1 B, q = C^-1 g2, Lc^-1 are written to `bscr` by k_chol_border_prepare, one small launch ahead (a 22 x 22 Cholesky per lane
+// is not an option); here every tile takes up to six products with V read from there (L2), the right-hand side g1 - B^T q, and at the
+// end y2 = q - Lc^-T (V y1).
+constexpr int kBorderMaxRows = 24, kBorderMaxQ = kBorderMaxRows / 4, kBorderLdV = 176;
+// layout of the border scratch (doubles): V [32 x 176] | Lc^-1 [32 x 32, row-major, lower] | q [32] | g1 - B^T q [176] | tile-column mask [16]
+constexpr int kBorderMP = 32, kBorderOffLinv = kBorderMP * kBorderLdV, kBorderOffQ = kBorderOffLinv + kBorderMP * kBorderMP,
+              kBorderOffG = kBorderOffQ + kBorderMP /* g1 - B^T q, 176 */, kBorderOffMask = kBorderOffG + kBorderLdV /* 16: tile column J of V is not zero */,
+              kBorderScratchDoubles = kBorderOffMask + 16;
+template <int kBorder>
 __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
-                                                                    int fuseFinalize, int border) {
+                                                                    int fuseFinalize, int border, const double* bscr) {
   extern __shared__ double smem[];
   SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS),
             SA(p.sPadded), SA(dpad), SA(mu), SA(initScale), SA(fuseFinalize));
-  const int t = threadIdx.x, d = kBorder ? p.d - border : p.d, nT = dpad / 16;   // d: rows of the main block
+  const int t = threadIdx.x, d = kBorder != 0 ? p.d - border : p.d, nT = dpad / 16;   // d: rows of the main block
   // the wave index through v_readfirstlane: tile indices and LDS tile addresses become scalar (SALU) arithmetic
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, nW = kCholLdsThreads / 64;
   const int nTilesAll = nT * (nT + 1) / 2;
@@ -3347,7 +3356,30 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   double htB[4] = {1, 1, 1, 1}, scB[4] = {1, 1, 1, 1};
   double bEnd[3] = {0, 0, 0};              // row `wave` of B at columns lane, lane + 64, lane + 128 (the product B y1 at the end)
   auto bAt = [&](int a, int col) { return (a < border) ? p.S[(size_t)(d + a) * ldS + col] : 0.0; };
-  if constexpr (kBorder) {
+  const int nQ = (border + 3) >> 2;   // (kBorder == 2) products per tile
+  // (kBorder == 2) this lane's entries of V for the tile column whose first matrix column is col0: V[4 q + g][col0 + c], q < nQ
+  // (unconditional: the scratch holds kBorderMP rows, zero beyond the border's -- a predicate per load is an exec-mask branch per load)
+  unsigned vMask = 0;   // (kBorder == 2) bit J: tile column J of V is not identically zero
+  if constexpr (kBorder == 2) {
+#pragma unroll
+    for (int J = 0; J < 11; ++J) vMask |= (bscr[kBorderOffMask + J] != 0.0) ? (1u << J) : 0u;
+    vMask = __builtin_amdgcn_readfirstlane(vMask);
+  }
+  const double* vLane = bscr + (kBorder == 2 ? g * kBorderLdV + c : 0);
+  auto vLoad = [&](int col0, double (&v)[kBorderMaxQ]) {
+#pragma unroll
+    for (int q = 0; q < kBorderMaxQ; ++q) v[q] = vLane[q * 4 * kBorderLdV + col0];
+  };
+  double vEnd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // (kBorder == 2) rows wave, wave + 8, wave + 16 of V at columns lane + 64 k: for V y1 at the end
+  if constexpr (kBorder == 2) {
+    if (t < d) rhsMine = bscr[kBorderOffG + t];   // g' = g1 - B^T q, formed by k_chol_border_prepare
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        vEnd[kk][k] = (wave + 8 * kk < border && lane + 64 * k < d) ? bscr[(size_t)(wave + 8 * kk) * kBorderLdV + lane + 64 * k] : 0.0;
+  }
+  if constexpr (kBorder == 1) {
     double Cb[4][4], g2[4], bcol[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -3595,9 +3627,16 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
     tileSelect(0, 0, v0);
     if (fuseFinalize) storeMetric(dampDiag(0, true, hc0, sc0, v0));
     d4_t accD = {v0[0], v0[1], v0[2], v0[3]};
-    if constexpr (kBorder) {
+    if constexpr (kBorder == 1) {
       const double v = vOf(bAt(g, c));
       accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, accD, 0, 0, 0);
+    }
+    if constexpr (kBorder == 2) {
+      double v[kBorderMaxQ];
+      vLoad(0, v);
+#pragma unroll
+      for (int q = 0; q < kBorderMaxQ; ++q)
+        if (q < nQ && (vMask & 1u)) accD = __builtin_amdgcn_mfma_f64_16x16x4f64(-v[q], v[q], accD, 0, 0, 0);
     }
 #ifdef SVIN_CHOL_TIMING
     long long pivotCycles = 0;
@@ -3657,7 +3696,7 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       int dI[2], oI[kMaxOff], oJ[kMaxOff];
       dI[0] = min(1 + ldr, nT - 1);
       dI[1] = min(7 + ldr, nT - 1);
-      const bool dmaOff = kBorder || p.sPadded != 0;   // (the border variant is only launched on a padded S)
+      const bool dmaOff = kBorder != 0 || p.sPadded != 0;   // (the border variants are only launched on a padded S)
 #pragma unroll
       for (int it = 0; it < kMaxOff; ++it) {
         if (dmaOff) { oI[it] = 1; oJ[it] = 0; continue; }   // (the DMA path walks whole tile rows: no index search)
@@ -3674,7 +3713,18 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
       // (rowA, rowB below) and every tile column J < 10 those rows cross; requested with the tiles, turned into V after the batch
       constexpr int kBorderCols = 10;
       double bDiag[2] = {0, 0}, bRow[2] = {0, 0}, bJ[kBorderCols];
-      if constexpr (kBorder) {
+      // (kBorder == 2) every entry of V this wave will need, requested with its tiles: from one launch to the next V crosses the XCDs'
+      // L2s, ~2 us per round trip -- requested tile by tile behind the DMA the update pass took 8 us
+      double vDiag[2][kBorderMaxQ], vRow[2][kBorderMaxQ], vAll[kBorderCols][kBorderMaxQ];
+      if constexpr (kBorder == 2) {
+        vLoad(16 * dI[0], vDiag[0]);
+        vLoad(16 * dI[1], vDiag[1]);
+        vLoad(16 * min(1 + ldr, nT - 1), vRow[0]);
+        vLoad(16 * (nT - 1 - ldr), vRow[1]);
+#pragma unroll
+        for (int J = 0; J < kBorderCols; ++J) vLoad(16 * J, vAll[J]);
+      }
+      if constexpr (kBorder == 1) {
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) bDiag[sl] = bAt(g, 16 * dI[sl] + c);
         bRow[0] = bAt(g, 16 * min(1 + ldr, nT - 1) + c);
@@ -3736,7 +3786,18 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #ifdef SVIN_CHOL_TIMING
       if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CHOL_STAMP_FINE(8, 1); }   // all values have arrived
 #endif
-      if constexpr (kBorder) {
+      if constexpr (kBorder == 2) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          d4_t a = {vd[sl][0], vd[sl][1], vd[sl][2], vd[sl][3]};
+#pragma unroll
+          for (int q = 0; q < kBorderMaxQ; ++q)
+            if (q < nQ && ((vMask >> dI[sl]) & 1u)) a = __builtin_amdgcn_mfma_f64_16x16x4f64(-vDiag[sl][q], vDiag[sl][q], a, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) vd[sl][rg] = a[rg];
+        }
+      }
+      if constexpr (kBorder == 1) {
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
           const double v = vOf(bDiag[sl]);
@@ -3767,7 +3828,66 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces of this wave have landed
-      if constexpr (kBorder) {
+      if constexpr (kBorder == 2) {
+        // the off-diagonal tiles this wave brought in (its two DMA rows): tile (I, J) -= V_I^T V_J, in place; V_J of the next tile is
+        // requested before the products of this one
+        const int rowA = 1 + ldr, rowB = nT - 1 - ldr;
+        const bool hasB = rowB > rowA, hasA = rowA <= rowB && rowA < nT;          // rows this wave brought in
+        const bool actB = hasB && ((vMask >> rowB) & 1u), actA = hasA && ((vMask >> rowA) & 1u);   // ... whose tile column of V is not zero
+        const int nJ = actB ? rowB : (actA ? rowA : 0);
+        double* TB = tileAt(tiles, actB ? rowB : 1, 0);
+        double* TA = tileAt(tiles, actA ? rowA : 1, 0);
+        // one pass over the tile columns serves both rows: V_J is read once, the two tiles' products are independent chains
+        auto step = [&](int J, const double (&vJ)[kBorderMaxQ]) {
+          const bool doA = actA && J < rowA;
+          d4_t xb = {0, 0, 0, 0}, xa = {0, 0, 0, 0};
+          if (actB) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) xb[rg] = TB[lrow + 4 * rg * kPanelLd];
+          }
+          if (doA) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) xa[rg] = TA[lrow + 4 * rg * kPanelLd];
+          }
+          // (one 16x16x4 product occupies the SIMD's matrix pipe for 64 cycles and two loader waves share a SIMD: a product that is
+          //  not needed is not issued -- with both chains unconditional the pass took 8 us)
+          if (doA && actB) {
+#pragma unroll
+            for (int q = 0; q < kBorderMaxQ; ++q) {
+              if (q < nQ) {
+                xb = __builtin_amdgcn_mfma_f64_16x16x4f64(-vRow[1][q], vJ[q], xb, 0, 0, 0);
+                xa = __builtin_amdgcn_mfma_f64_16x16x4f64(-vRow[0][q], vJ[q], xa, 0, 0, 0);
+              }
+            }
+          } else if (actB) {
+#pragma unroll
+            for (int q = 0; q < kBorderMaxQ; ++q)
+              if (q < nQ) xb = __builtin_amdgcn_mfma_f64_16x16x4f64(-vRow[1][q], vJ[q], xb, 0, 0, 0);
+          } else if (doA) {
+#pragma unroll
+            for (int q = 0; q < kBorderMaxQ; ++q)
+              if (q < nQ) xa = __builtin_amdgcn_mfma_f64_16x16x4f64(-vRow[0][q], vJ[q], xa, 0, 0, 0);
+          }
+          if (actB) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) TB[lrow + 4 * rg * kPanelLd] = xb[rg];
+          }
+          if (doA) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) TA[lrow + 4 * rg * kPanelLd] = xa[rg];
+          }
+          TB += kTile;
+          TA += kTile;
+        };
+#pragma unroll
+        for (int J = 0; J < kBorderCols; ++J) {
+          if (J < nJ) {
+            if ((vMask >> J) & 1u) step(J, vAll[J]);
+            else { TB += kTile; TA += kTile; }
+          }
+        }
+      }
+      if constexpr (kBorder == 1) {
         // the off-diagonal tiles this wave brought in (its two DMA rows): tile (I, J) -= V_I^T V_J, in place
         double vJ[kBorderCols];
 #pragma unroll
@@ -3894,6 +4014,19 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #endif
   __syncthreads();   // factor, 1/L_ii and the forward-substituted right-hand side are complete
   if (t == 0 && *bail) atomicOr(&p.scal->cholFail, 4);
+  // (kBorder == 2) what the last step needs from global memory, requested now by the lanes of wave 1 that will take it: column a of
+  // Lc^-1, q, the gradient and the metric of border row a
+  double liCol[kBorderMaxRows], qEnd = 0.0, gEnd = 0.0, hEnd = 1.0;
+  const int aEnd = t - 64;
+  if constexpr (kBorder == 2) {
+    if (aEnd >= 0 && aEnd < border) {
+#pragma unroll
+      for (int i = 0; i < kBorderMaxRows; ++i) liCol[i] = (i >= aEnd && i < border) ? bscr[kBorderOffLinv + i * kBorderMP + aEnd] : 0.0;
+      qEnd = bscr[kBorderOffQ + aEnd];
+      gEnd = p.gFull[d + aEnd];
+      hEnd = p.htilC[d + aEnd];
+    }
+  }
 #ifdef SVIN_CHOL_TIMING
   long long q5 = __builtin_readcyclecounter();
   if (t == 0) p.partial[(size_t)15 * 4096 + 3] += (double)(q5 - ql0);
@@ -4040,7 +4173,27 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
   if (t < 240) p.partial[(size_t)15 * 4096 + 64 + t] = stampBuf[t];
 #endif
   if (t < d) { p.yC[t] = rhs[t]; p.vC[t] = gFullMine / htil[t]; }  // Gauss-Newton solution + steepest-descent direction
-  if constexpr (kBorder) {
+  if constexpr (kBorder == 2) {
+    // y2 = q - Lc^-T (V y1): the rows of V y1 dealt over the waves, then one thread per border row
+    double* bord = reinterpret_cast<double*>(fl + kCholFlagInts) + kCholBorderOff;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc = __builtin_fma(vEnd[kk][k], (lane + 64 * k < d) ? rhs[lane + 64 * k] : 0.0, acc);
+      acc = waveSum(acc);
+      if (lane == 0 && wave + 8 * kk < border) bord[wave + 8 * kk] = acc;
+    }
+    ldsBarrier();
+    if (aEnd >= 0 && aEnd < border) {
+      double z = 0;
+#pragma unroll
+      for (int i = 0; i < kBorderMaxRows; ++i) z = __builtin_fma(liCol[i], (i < border) ? bord[i] : 0.0, z);   // (Lc^-T s)[a]
+      p.yC[d + aEnd] = qEnd - z;
+      p.vC[d + aEnd] = gEnd / hEnd;   // (the metric of the border rows: written by k_chol_border_prepare, or older)
+    }
+  }
+  if constexpr (kBorder == 1) {
     // y2 = q - C^-1 (B y1): row a of B y1 on wave a, then one thread per border row
     double* bord = reinterpret_cast<double*>(fl + kCholFlagInts) + kCholBorderOff;
     if (wave < 4) {
@@ -5614,19 +5767,131 @@ __global__ __launch_bounds__(kLLThreads) void k_chol_solve_ll(DeviceProblem p, i
 #undef LLT
 }
 
-// LDS bytes of k_chol_solve_lds for nT tile rows (+ four doubles of the border variant)
+// ---- border block of the LDS-resident solver's kBorder = 2 variant: one workgroup of four waves, everything on 16 x 16 tiles
+// (tile16.hpp).  C = S[dM .., dM ..] (damped like every diagonal entry of the system; the metric of its rows is stored here),
+// C = Lc Lc^T, Lc^-1, q = C^-1 g2, V = Lc^-1 B with B = S[dM .., 0 .. dM) -- into `scr` (layout: kBorderOff*).  A pivot that is not
+// positive raises cholFail like any other pivot of the system.
+constexpr int kBorderPrepThreads = 256;
+__global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(DeviceProblem p, int dM, double mu, int initScale, int fuseFinalize, int m, double* scr) {
+  constexpr int MP = kBorderMP, ld = MP + 1, nTb = MP / 16;
+  __shared__ double sA[MP * ld];              // the border block, then Lc (lower tiles) / Lc^-1 transposed (upper tiles)
+  __shared__ double sD[nTb * 16 * kPanelLd];  // diagonal scratch tiles
+  __shared__ double sDinv[MP];
+  __shared__ double sLi[MP * ld];             // Lc^-1, dense lower
+  __shared__ double sU[MP], sG[MP], sQ[MP];
+  __shared__ int sFail;
+  const int t = threadIdx.x, ldS = p.ldS ? p.ldS : p.d;
+  const int wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  lds_f64* A = tileToLds(sA);
+  if (t == 0) sFail = 0;
+  // B in the B-operand layout of the products that form V, requested before anything else (it does not depend on the factor): column
+  // tiles J = wave, wave + 4, wave + 8 of the 11, lane (g, c) holds B[4 q + g][16 J + c]
+  double bOp[3][kBorderMaxQ], g1v[3];
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const int col = 16 * (wave + 4 * kk) + c;
+    const bool valid = col < dM;
+#pragma unroll
+    for (int q = 0; q < kBorderMaxQ; ++q) bOp[kk][q] = (valid && 4 * q + g < m) ? p.S[(size_t)(dM + 4 * q + g) * ldS + col] : 0.0;
+    g1v[kk] = valid ? p.gRed[col] : 0.0;
+  }
+  for (int idx = t; idx < MP * ld; idx += kBorderPrepThreads) {
+    const int r = idx / ld, cc = idx - r * ld;
+    double v = (r == cc) ? 1.0 : 0.0;
+    if (r < m && cc < m) {
+      v = p.S[(size_t)(dM + max(r, cc)) * ldS + dM + min(r, cc)];
+      if (r == cc && fuseFinalize) {   // the same metric and damping dampDiag gives a diagonal entry of the main block
+        const double hc = p.hC[dM + r];
+        const double sc = initScale ? 1.0 / (1.0 + sqrt(hc)) : p.scaleC[dM + r];
+        const double ht = fmin(fmax(hc * sc * sc, 1e-6), 1e32) / (sc * sc);
+        v += mu * ht;
+        if (initScale) p.scaleC[dM + r] = sc;
+        p.htilC[dM + r] = ht;
+      }
+    }
+    A[idx] = v;
+  }
+  if (t < MP) sG[t] = (t < m) ? p.gRed[dM + t] : 0.0;
+  __syncthreads();
+  tileCholFactor<kBorderPrepThreads / 64>(A, ld, nTb, sD, sDinv, &sFail);
+  (void)tileCholInverse<kBorderPrepThreads / 64>(A, ld, nTb, MP, tileToLds(sD), tileToLds(sDinv));
+  __syncthreads();
+  if (t == 0 && sFail) atomicOr(&p.scal->cholFail, 1);
+  // Lc^-1 dense (LDS + scratch): element (i, j), j <= i
+  for (int idx = t; idx < MP * MP; idx += kBorderPrepThreads) {
+    const int i = idx / MP, j = idx - i * MP;
+    double v = 0.0;
+    if (j <= i) v = ((j >> 4) < (i >> 4)) ? (double)A[j * ld + i] : tileLinvAt(tileToLds(sD), tileToLds(sDinv), i >> 4, i & 15, j & 15);
+    sLi[i * ld + j] = v;
+    scr[kBorderOffLinv + idx] = v;
+  }
+  __syncthreads();
+  auto sum8 = [](double v) {   // over the 8 lanes of an aligned group
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+  };
+  {   // u = Lc^-1 g2, 8 lanes per row (MP rows x 8 = the workgroup)
+    const int i = t >> 3, sub = t & 7;
+    double u = 0.0;
+    for (int j = sub; j <= i; j += 8) u = __builtin_fma(sLi[i * ld + j], sG[j], u);
+    u = sum8(u);
+    if (sub == 0) sU[i] = u;
+  }
+  __syncthreads();
+  {   // q = Lc^-T u
+    const int a = t >> 3, sub = t & 7;
+    double q = 0.0;
+    for (int i = a + sub; i < MP; i += 8) q = __builtin_fma(sLi[i * ld + a], sU[i], q);
+    q = sum8(q);
+    if (sub == 0) { scr[kBorderOffQ + a] = q; sQ[a] = q; }
+  }
+  __syncthreads();
+  // V = Lc^-1 B on v_mfma_f64_16x16x4: per column tile two row tiles (rows 24 .. 31 come out zero); g1 - B^T q beside it
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const int J = wave + 4 * kk;
+    if (16 * J >= kBorderLdV) continue;   // (wave-uniform)
+    d4_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < kBorderMaxQ; ++q) {
+      const int k = 4 * q + g;
+      v0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sLi[c * ld + k], bOp[kk][q], v0, 0, 0, 0);          // (Lc^-1 is lower triangular: zeros above)
+      v1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sLi[(16 + c) * ld + k], bOp[kk][q], v1, 0, 0, 0);
+      part = __builtin_fma(bOp[kk][q], sQ[k], part);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      scr[(size_t)(g + 4 * r) * kBorderLdV + 16 * J + c] = v0[r];
+      scr[(size_t)(16 + g + 4 * r) * kBorderLdV + 16 * J + c] = v1[r];
+    }
+    part = sumLaneRows(part);
+    if (g == 0) scr[kBorderOffG + 16 * J + c] = g1v[kk] - part;
+    // The border's rows couple with few columns of the main block (speed / bias blocks: the poses their IMU factors touch), and a
+    // column of B that is exactly zero is an exactly zero column of V: the solver skips the tiles of such tile columns
+    bool nz = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nz = nz || v0[r] != 0.0 || v1[r] != 0.0;
+    const bool any = __any(nz) != 0;
+    if (lane == 0) scr[kBorderOffMask + J] = any ? 1.0 : 0.0;
+  }
+}
+
+// LDS bytes of k_chol_solve_lds for nT tile rows (+ kBorderMP doubles of the border variants)
 static size_t cholLdsBytes(int nT) {
 #ifdef SVIN_CHOL_TIMING
-  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 240 * 8 + 4 * 8;
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 240 * 8 + kBorderMP * 8;
 #else
-  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + 4 * 8;
+  return ((size_t)nT * (nT + 1) / 2 * kTile + 3 * 16 * nT) * 8 + kCholFlagInts * 4 + kBorderMP * 8;
 #endif
 }
 constexpr int kCholLdsMaxTiles = 11;   // tile rows of the largest system LDS holds (156 KB)
 // rows beyond the LDS-resident solver's eleven tile rows that it eliminates while loading (k_chol_solve_lds<true>); needs the window's padded S
 static int cholBorderRows(int d, bool padded) {
   const int m = d - 16 * kCholLdsMaxTiles;
-  return (padded && m >= 1 && m <= 4 && !switchOn(gNoLdsBorder, "SVIN_NO_LDS_BORDER")) ? m : 0;
+  return (padded && m >= 1 && m <= kBorderMaxRows && !switchOn(gNoLdsBorder, "SVIN_NO_LDS_BORDER")) ? m : 0;
 }
 static int solverClass(int d, bool padded = false) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
   const int nT = (d + 15) / 16;
@@ -5679,16 +5944,24 @@ static void launchSolveDense(const DeviceProblem& p, hipStream_t s, double mu, b
   const int nT = dpad / 16;
   const int cls = solverClass(p.d, p.sPadded != 0);
   const int border = cholBorderRows(p.d, p.sPadded != 0);
-  if (cls == 0 && border > 0) {
+  if (cls == 0 && border > 4) {
+    // the border block factorised and V, q, Lc^-1 written to the solver's global scratch by a small launch of its own
     const size_t ldsBytes = cholLdsBytes(kCholLdsMaxTiles);
-    ensureDynamicLds((const void*)k_chol_solve_lds<true>, ldsBytes);
-    hipLaunchKernelGGL(k_chol_solve_lds<true>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, 16 * kCholLdsMaxTiles, mu, initScale ? 1 : 0,
-                       fuseFinalize ? 1 : 0, border);
+    hipLaunchKernelGGL(k_chol_border_prepare, dim3(1), dim3(kBorderPrepThreads), 0, s, p, 16 * kCholLdsMaxTiles, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, border, p.cholL);
+    ensureDynamicLds((const void*)k_chol_solve_lds<2>, ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds<2>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, 16 * kCholLdsMaxTiles, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, border, (const double*)p.cholL);
+  } else if (cls == 0 && border > 0) {
+    const size_t ldsBytes = cholLdsBytes(kCholLdsMaxTiles);
+    ensureDynamicLds((const void*)k_chol_solve_lds<1>, ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds<1>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, 16 * kCholLdsMaxTiles, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, border, (const double*)nullptr);
   } else if (cls == 0) {
     const size_t ldsBytes = cholLdsBytes(nT);
-    ensureDynamicLds((const void*)k_chol_solve_lds<false>, ldsBytes);
-    hipLaunchKernelGGL(k_chol_solve_lds<false>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
-                       fuseFinalize ? 1 : 0, 0);
+    ensureDynamicLds((const void*)k_chol_solve_lds<0>, ldsBytes);
+    hipLaunchKernelGGL(k_chol_solve_lds<0>, dim3(1), dim3(kCholLdsThreads), ldsBytes, s, p, dpad, mu, initScale ? 1 : 0,
+                       fuseFinalize ? 1 : 0, 0, (const double*)nullptr);
   } else if (cls == 1) {
     // one workgroup, left-looking: at most 72 live tiles in LDS, finished tiles written through to p.cholL
     const size_t ldsLL = llLdsDoubles(nT) * 8;

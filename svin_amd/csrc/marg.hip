@@ -523,106 +523,6 @@ static size_t margCholLdsBytes(int n) {
   const size_t nT = ((size_t)n + 15) / 16, NP = 16 * nT;
   return (NP * (NP + 1) + nT * 16 * kPanelLd + NP) * sizeof(double);
 }
-// ---- blocked Cholesky and inverse of the factor on an LDS image, 1 024 threads, 16 x 16 tiles on v_mfma_f64_16x16x4 (k_marg_final_chol,
-// k_marg_dense).  A: NP x ld image (NP = 16 nT, ld = NP + 1), full symmetric, identity beyond the matrix; lower tiles <- L (off-diagonal
-// tiles), the diagonal tiles' L and L^-1 go to scratch tiles DgGen (16 x kPanelLd each: L lower, L^-1 transposed strict upper) and
-// dinvGen (1 / L_ii).  Three barriers per block column; *sFail gets a bit when a pivot is not positive (checked by the caller
-// behind the last barrier).
-__device__ __forceinline__ double tileLinvAt(const lds_double* Dg, const lds_double* dinv, int K, int row, int col) {
-  const double off = Dg[K * 16 * kPanelLd + col * kPanelLd + row], dg = dinv[16 * K + row];
-  return (col < row) ? off : ((col == row) ? dg : 0.0);
-}
-__device__ __forceinline__ void tileCholFactor(lds_double* A, int ld, int nT, double* DgGen, double* dinvGen, int* sFail) {
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
-  const lds_double* Dg = toLds(DgGen);
-  const lds_double* dinv = toLds(dinvGen);
-  auto loadAcc = [&](int I, int J) {
-    d4_t x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = A[(16 * I + g + 4 * r) * ld + 16 * J + c];
-    return x;
-  };
-  auto storeAcc = [&](int I, int J, const d4_t& x) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) A[(16 * I + g + 4 * r) * ld + 16 * J + c] = x[r];
-  };
-  for (int K = 0; K < nT; ++K) {
-    if (wave == 0) cholDiag16Acc<false>(loadAcc(K, K), DgGen + K * 16 * kPanelLd, dinvGen + 16 * K, lane, sFail);
-    __syncthreads();
-    {
-      const int I = K + 1 + wave;   // panel tile (I, K) <- A_IK L_KK^-T
-      if (I < nT) {
-        d4_t x = {0.0, 0.0, 0.0, 0.0};
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];
-          bv[q] = tileLinvAt(Dg, dinv, K, c, 4 * q + g);   // B[k][j] = L^-1[j][k]
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
-        storeAcc(I, K, x);
-      }
-    }
-    symeig::ldsBarrier();
-    const int m = nT - 1 - K;
-    for (int id = wave; id < m * (m + 1) / 2; id += 16) {
-      int r = 0;
-      while ((r + 1) * (r + 2) / 2 <= id) ++r;
-      const int I = K + 1 + r, J = K + 1 + (id - r * (r + 1) / 2);
-      d4_t acc = loadAcc(I, J);
-      double av[4], bv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        av[q] = -A[(16 * I + c) * ld + 16 * K + 4 * q + g];
-        bv[q] = A[(16 * J + c) * ld + 16 * K + 4 * q + g];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-      storeAcc(I, J, acc);
-    }
-    symeig::ldsBarrier();
-  }
-}
-// Y = L^-1, block column J on wave J without a barrier: Y_JJ is the scratch tile's inverse, Y_IJ = -L_II^-1 sum_K L_IK Y_KJ with the
-// running sum in the accumulator layout (which IS the B operand of the product with L_II^-1); Y_IJ^T goes to the upper tile (J, I), so
-// element Y[i][j] of two different tile rows sits at A[j * ld + i].  Returns this lane's part of |Y|_F^2 over the n x n matrix.
-__device__ __forceinline__ double tileCholInverse(lds_double* A, int ld, int nT, int n, const lds_double* Dg, const lds_double* dinv) {
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
-  double fro = 0.0;
-  if (wave < nT) {
-    const int J = wave;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {   // the diagonal tile's own inverse: entries (row 4q + g, column c)
-      const int row = 4 * q + g;
-      const double v = tileLinvAt(Dg, dinv, J, row, c);
-      if (16 * J + row < n && 16 * J + c < n) fro = __builtin_fma(v, v, fro);
-    }
-    for (int I = J + 1; I < nT; ++I) {
-      d4_t sacc = {0.0, 0.0, 0.0, 0.0};
-      for (int K = J; K < I; ++K) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];                                                           // L_IK[i = c][k]
-          bv[q] = (K == J) ? tileLinvAt(Dg, dinv, J, 4 * q + g, c) : (double)A[(16 * J + c) * ld + 16 * K + 4 * q + g];   // Y_KJ[k][j = c]
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], sacc, 0, 0, 0);
-      }
-      d4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-tileLinvAt(Dg, dinv, I, c, 4 * q + g), sacc[q], y, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        A[(16 * J + c) * ld + 16 * I + g + 4 * r] = y[r];   // Y_IJ[i = g + 4r][j = c], transposed into the upper tile (J, I)
-        fro = __builtin_fma(y[r], y[r], fro);               // (rows / columns of the padding are exactly zero here)
-      }
-    }
-  }
-  return fro;
-}
-
 // ---------------------------------------------------------------- M2 dense part (:622-667) + M3 (:725-758)
 // Single workgroup.  keep/marg index lists select rows of U (m x m).  Outputs the reduced Hk (nk x nk), bk.
 struct DenseArgs {
@@ -676,9 +576,9 @@ __global__ __launch_bounds__(1024) void k_marg_dense(DenseArgs a, int useLds, in
       A[idx] = (r < nm && c < nm) ? a.Vm[(size_t)r * nm + c] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
-    tileCholFactor(A, ldm, nTm, DgGen, dinvGen, &sFailD);
+    tileCholFactor<16>(A, ldm, nTm, DgGen, dinvGen, &sFailD);
     if (!sFailD) {   // (uniform)
-      const double fro = waveSumM(tileCholInverse(A, ldm, nTm, nm, Dg, dinv));
+      const double fro = waveSumM(tileCholInverse<16>(A, ldm, nTm, nm, Dg, dinv));
       if ((t & 63) == 0) sFroD[t >> 6] = fro;
       __syncthreads();
       if (t == 0) {
@@ -967,11 +867,11 @@ __global__ __launch_bounds__(1024) void k_marg_final_chol(FinalArgs a) {
     A[idx] = (r < n && cc < n) ? 0.5 * (a.H[(size_t)r * n + cc] + a.H[(size_t)cc * n + r]) / (p[r] * p[cc]) : ((r == cc) ? 1.0 : 0.0);
   }
   __syncthreads();
-  tileCholFactor(A, ld, nT, DgGen, dinvGen, &sFail);
+  tileCholFactor<16>(A, ld, nT, DgGen, dinvGen, &sFail);
   if (sFail) return;   // (uniform) a pivot was not positive: the eigen-solve behind this launch decides
   const long long tChol = wall_clock64();
   {
-    const double fro = waveSumM(tileCholInverse(A, ld, nT, n, Dg, dinv));
+    const double fro = waveSumM(tileCholInverse<16>(A, ld, nT, n, Dg, dinv));
     if (lane == 0) sFro[wave] = fro;
   }
   __syncthreads();

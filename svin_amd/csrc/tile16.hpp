@@ -140,4 +140,109 @@ __device__ __forceinline__ void cholDiag16Acc(d4_t acc, double* D, double* dinv,
 #endif
 }
 
+using lds_f64 = __attribute__((address_space(3))) double;
+__device__ __forceinline__ lds_f64* tileToLds(double* p) { return (lds_f64*)p; }
+__device__ __forceinline__ void tileLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- blocked Cholesky and inverse of the factor on an LDS image, NW waves, 16 x 16 tiles on v_mfma_f64_16x16x4 (marg.hip: k_marg_final_chol,
+// k_marg_dense with 16 waves; kernels.hip: k_chol_border_prepare with 4).  A: NP x ld image (NP = 16 nT, ld = NP + 1), full symmetric, identity beyond the matrix; lower tiles <- L (off-diagonal
+// tiles), the diagonal tiles' L and L^-1 go to scratch tiles DgGen (16 x kPanelLd each: L lower, L^-1 transposed strict upper) and
+// dinvGen (1 / L_ii).  Three barriers per block column; *sFail gets a bit when a pivot is not positive (checked by the caller
+// behind the last barrier).
+__device__ __forceinline__ double tileLinvAt(const lds_f64* Dg, const lds_f64* dinv, int K, int row, int col) {
+  const double off = Dg[K * 16 * kPanelLd + col * kPanelLd + row], dg = dinv[16 * K + row];
+  return (col < row) ? off : ((col == row) ? dg : 0.0);
+}
+template <int NW>
+__device__ __forceinline__ void tileCholFactor(lds_f64* A, int ld, int nT, double* DgGen, double* dinvGen, int* sFail) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  const lds_f64* Dg = tileToLds(DgGen);
+  const lds_f64* dinv = tileToLds(dinvGen);
+  auto loadAcc = [&](int I, int J) {
+    d4_t x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = A[(16 * I + g + 4 * r) * ld + 16 * J + c];
+    return x;
+  };
+  auto storeAcc = [&](int I, int J, const d4_t& x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A[(16 * I + g + 4 * r) * ld + 16 * J + c] = x[r];
+  };
+  for (int K = 0; K < nT; ++K) {
+    if (wave == 0) cholDiag16Acc<false>(loadAcc(K, K), DgGen + K * 16 * kPanelLd, dinvGen + 16 * K, lane, sFail);
+    __syncthreads();
+    {
+      for (int I = K + 1 + wave; I < nT; I += NW) {   // panel tile (I, K) <- A_IK L_KK^-T
+        d4_t x = {0.0, 0.0, 0.0, 0.0};
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+          bv[q] = tileLinvAt(Dg, dinv, K, c, 4 * q + g);   // B[k][j] = L^-1[j][k]
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
+        storeAcc(I, K, x);
+      }
+    }
+    tileLdsBarrier();
+    const int m = nT - 1 - K;
+    for (int id = wave; id < m * (m + 1) / 2; id += NW) {
+      int r = 0;
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      const int I = K + 1 + r, J = K + 1 + (id - r * (r + 1) / 2);
+      d4_t acc = loadAcc(I, J);
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q] = -A[(16 * I + c) * ld + 16 * K + 4 * q + g];
+        bv[q] = A[(16 * J + c) * ld + 16 * K + 4 * q + g];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+      storeAcc(I, J, acc);
+    }
+    tileLdsBarrier();
+  }
+}
+// Y = L^-1, block column J on wave J without a barrier: Y_JJ is the scratch tile's inverse, Y_IJ = -L_II^-1 sum_K L_IK Y_KJ with the
+// running sum in the accumulator layout (which IS the B operand of the product with L_II^-1); Y_IJ^T goes to the upper tile (J, I), so
+// element Y[i][j] of two different tile rows sits at A[j * ld + i].  Returns this lane's part of |Y|_F^2 over the n x n matrix.
+template <int NW>
+__device__ __forceinline__ double tileCholInverse(lds_f64* A, int ld, int nT, int n, const lds_f64* Dg, const lds_f64* dinv) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+  double fro = 0.0;
+  for (int J = wave; J < nT; J += NW) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // the diagonal tile's own inverse: entries (row 4q + g, column c)
+      const int row = 4 * q + g;
+      const double v = tileLinvAt(Dg, dinv, J, row, c);
+      if (16 * J + row < n && 16 * J + c < n) fro = __builtin_fma(v, v, fro);
+    }
+    for (int I = J + 1; I < nT; ++I) {
+      d4_t sacc = {0.0, 0.0, 0.0, 0.0};
+      for (int K = J; K < I; ++K) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = A[(16 * I + c) * ld + 16 * K + 4 * q + g];                                                           // L_IK[i = c][k]
+          bv[q] = (K == J) ? tileLinvAt(Dg, dinv, J, 4 * q + g, c) : (double)A[(16 * J + c) * ld + 16 * K + 4 * q + g];   // Y_KJ[k][j = c]
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], sacc, 0, 0, 0);
+      }
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(-tileLinvAt(Dg, dinv, I, c, 4 * q + g), sacc[q], y, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        A[(16 * J + c) * ld + 16 * I + g + 4 * r] = y[r];   // Y_IJ[i = g + 4r][j = c], transposed into the upper tile (J, I)
+        fro = __builtin_fma(y[r], y[r], fro);               // (rows / columns of the padding are exactly zero here)
+      }
+    }
+  }
+  return fro;
+}
+
+
 }  // namespace svin

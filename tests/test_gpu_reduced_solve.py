@@ -45,6 +45,8 @@ def window(P, L, n_obs, rig="euroc", seed=11):
     (18, 700, 7000, "euroc", "d = 270: chain of 18, kept 108 rows LDS-resident (was left-looking)"),
     (24, 800, 8000, "euroc", "d = 360: chain of 24, kept 144 rows LDS-resident (was blocked)"),
     (29, 800, 8000, "euroc", "d = 435: chain of 29 (not a power of two), kept 174 rows LDS-resident (was blocked)"),
+    (32, 1000, 10000, "euroc", "d = 480: chain of 32, kept 192 rows: LDS-resident with a border of 16 rows (k_chol_border_prepare on the compact system)"),
+    (33, 1000, 10000, "euroc", "d = 495: chain of 33, kept 198 rows: LDS-resident with a border of 22 rows"),
     (40, 1200, 12000, "euroc", "d = 600: chain of 40, kept 240 rows left-looking (was blocked)"),
     (48, 1500, 15000, "euroc", "d = 720: chain of 48, kept 288 rows blocked (padded to 320)"),
     (50, 1500, 15000, "euroc", "d = 750: chain of 50, kept 300 rows blocked (not a multiple of 16: padded to 320)"),
@@ -71,19 +73,21 @@ def test_device_solve_equals_host_solve(gpu_lib, sb_elim_switch, P, L, n_obs, ri
         assert max(err.values()) < tol
 
 
-@pytest.mark.parametrize("keyframes,imu_frames,frames,rig,d_expected", [
-    (22, 2, 34, "euroc", 177),    # 25 poses + 3 speed / bias blocks: ONE row beyond the eleven tile rows
-    (4, 3, 16, "rig_v2", 180),    # stereo_rig_v2 + sonar + depth: 8 poses + 16 extrinsics + 4 speed / bias blocks -- four rows beyond
+@pytest.mark.parametrize("keyframes,imu_frames,frames,rig,sizes", [
+    (22, 2, 34, "euroc", (177,)),            # 25 poses + 3 speed / bias blocks: ONE row beyond the eleven tile rows
+    (4, 3, 16, "rig_v2", (180,)),            # stereo_rig_v2 + sonar + depth: 8 poses + 16 extrinsics + 4 speed / bias blocks -- four rows beyond
+    (23, 3, 36, "euroc", (186, 192, 198)),   # 10, 16, 22 rows beyond: the border block goes through k_chol_border_prepare
+    (5, 3, 16, "rig_v2", (186, 198)),        # SVIn's own window (5 keyframes + 3 IMU frames): 198 in its steady state
 ])
-def test_lds_solver_with_border_rows(gpu_lib, keyframes, imu_frames, frames, rig, d_expected):
-    """d = 177 .. 180 on the LDS-resident solver (k_chol_solve_lds<true>: the rows beyond 176 are eliminated while the tiles are
+def test_lds_solver_with_border_rows(gpu_lib, keyframes, imu_frames, frames, rig, sizes):
+    """d = 177 .. 200 on the LDS-resident solver (k_chol_solve_lds<1> / <2>: the rows beyond 176 are eliminated while the tiles are
     loaded) on the systems of a sliding window that has been through marginalisations (prior + IMU chain + extrinsics chain in the
     reduced system): against LAPACK, and against the left-looking solver the switch SVIN_NO_LDS_BORDER falls back to."""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=frames, L=60 * frames, n_obs=600 * frames, seed=3, rig=rig, frame_dt=0.25,
                            sonar=rig == "rig_v2", depth=rig == "rig_v2")
     est = Estimator(0)
-    seen, hits = set(), []
+    seen, hits = set(), set()
 
     def compare():
         for mu, tol in ((1e-4, 1e-10), (1e-9, 1e-6)):
@@ -98,20 +102,20 @@ def test_lds_solver_with_border_rows(gpu_lib, keyframes, imu_frames, frames, rig
             print("d %d, mu %g: border variant vs host %.2e (fused %.2e), left-looking %.2e (fused %.2e)" %
                   (lin["d"], mu, err[False, False], err[False, True], err[True, False], err[True, True]))
             assert max(err.values()) < tol
-        hits.append(1)
 
     def on_frame(k, fid):
         est.optimize(3)
         d = est.linearize(1e-4)["d"]
         seen.add(d)
-        if d == d_expected and len(hits) < 2:
+        if d in sizes and d not in hits:
             compare()
+            hits.add(d)
         est.apply_marginalization(keyframes, imu_frames)
     try:
         syn.feed(est, spec, on_frame=on_frame)
     finally:
         Estimator.debug_set_switch("SVIN_NO_LDS_BORDER", False)
-    assert hits, "no window of %d unknowns in the sequence (sizes seen: %s)" % (d_expected, sorted(seen))
+    assert hits == set(sizes), "sizes %s wanted, reached %s (sizes seen: %s)" % (sizes, sorted(hits), sorted(seen))
 
 
 def test_chain_elimination_is_used_and_can_be_switched_off(gpu_lib, sb_elim_switch):
