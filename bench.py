@@ -304,7 +304,7 @@ def window_record(name, spec, device, steps, warmup, iters):
         rec["kernel_ms"] = {"eval_reproj": ev, "build_normal_equations": bu, "chol_solve_backsub": so}
         rec["roofline"] = {
             "bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "d": d,
-            "solve": {"kernel": "k_chol_solve_lds" if d <= 176 else ("k_chol_solve_ll" if d <= 272 else "k_sb_factor / _forward / _load / _back (speed / bias chain, cyclic reduction) + k_big_chol_chain + k_big_back on the kept rows"),
+            "solve": {"kernel": "k_chol_solve_lds" if d <= 176 else ("k_chol_solve_lds with border rows" if d <= 200 else "k_chol_solve_ll") if d <= 272 else ("k_sb_factor / _forward / _load / _back (speed / bias chain, cyclic reduction) + k_big_chol_chain + k_big_back on the kept rows"),
                       "launch_ms": so, "flops": chol_flops, "achieved": chol_flops / (so * 1e-3) / 1e12,
                       "frac": chol_flops / (so * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS},
             "schur": {"kernel": "k_schur_dense" if spec.P <= 20 else "k_schur_panels", "launch_ms": bu, "flops": schur_flops,
