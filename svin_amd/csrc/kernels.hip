@@ -5913,7 +5913,10 @@ static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
   // rows over the LDS-resident solver's limit drops into it: 39 + 35 + 10 us against the left-looking solver's 70.  d = 177 .. 180
   // is now the LDS-resident solver's own border variant; the stereo_rig_v2 sliding window is d = 198.)
   const int mode = solverClass(p.dC) == 2 ? 1 : 2;
-  if (p.sbChain < (mode == 1 ? 8 : 16)) return 0;
+  // (the compact form needed 16 blocks until the end of round 5, when the kept rows went to the left-looking solver more often than
+  //  not; with the LDS-resident solver taking up to 200 rows a chain of 8 pays: config #3 -- chain of 10, 180 kept rows -- 112.6 -> 83.6 us,
+  //  d = 210 / 225 (chains of 14 / 15) 80.9 -> 65.2 / 90.2 -> 65.6)
+  if (p.sbChain < 8) return 0;
   a.n = p.sbChain; a.dK = p.dC;
   a.dp = ((a.dK + kNB - 1) / kNB) * kNB;
   a.ldY = ((a.dK + 1 + 15) / 16) * 16;

@@ -39,8 +39,10 @@ def window(P, L, n_obs, rig="euroc", seed=11):
 
 @pytest.mark.parametrize("P,L,n_obs,rig,path", [
     (10, 400, 4000, "euroc", "LDS-resident whole, d = 150 (no elimination)"),
-    (12, 500, 5000, "euroc", "d = 180: left-looking whole (a chain of 12 is too short to pay for its four launches)"),
-    (8, 500, 5000, "rig_v2", "stereo_rig_v2, d = 204: left-looking whole"),
+    (12, 500, 5000, "euroc", "d = 180: LDS-resident whole, four border rows (no elimination)"),
+    (14, 500, 5000, "euroc", "d = 210: chain of 14, kept 84 rows LDS-resident (was left-looking whole)"),
+    (8, 500, 5000, "rig_v2", "stereo_rig_v2, d = 216: chain of 8, kept 144 rows LDS-resident (was left-looking whole)"),
+    (10, 600, 6000, "rig_v2", "stereo_rig_v2, d = 270 (config #3's shape): chain of 10, kept 180 rows LDS-resident with four border rows"),
     (16, 600, 6000, "euroc", "d = 240: chain of 16, kept 96 rows LDS-resident (was left-looking)"),
     (18, 700, 7000, "euroc", "d = 270: chain of 18, kept 108 rows LDS-resident (was left-looking)"),
     (24, 800, 8000, "euroc", "d = 360: chain of 24, kept 144 rows LDS-resident (was blocked)"),
