@@ -5784,6 +5784,9 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
   const int wave = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
   lds_f64* A = tileToLds(sA);
   if (t == 0) sFail = 0;
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 0] = (double)wall_clock64();
+#endif
   // B in the B-operand layout of the products that form V, requested before anything else (it does not depend on the factor): column
   // tiles J = wave, wave + 4, wave + 8 of the 11, lane (g, c) holds B[4 q + g][16 J + c]
   double bOp[3][kBorderMaxQ], g1v[3];
@@ -5813,9 +5816,18 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
   }
   if (t < MP) sG[t] = (t < m) ? p.gRed[dM + t] : 0.0;
   __syncthreads();
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 1] = (double)wall_clock64();
+#endif
   tileCholFactor<kBorderPrepThreads / 64>(A, ld, nTb, sD, sDinv, &sFail);
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 2] = (double)wall_clock64();
+#endif
   (void)tileCholInverse<kBorderPrepThreads / 64>(A, ld, nTb, MP, tileToLds(sD), tileToLds(sDinv));
   __syncthreads();
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 3] = (double)wall_clock64();
+#endif
   if (t == 0 && sFail) atomicOr(&p.scal->cholFail, 1);
   // Lc^-1 dense (LDS + scratch): element (i, j), j <= i
   for (int idx = t; idx < MP * MP; idx += kBorderPrepThreads) {
@@ -5826,6 +5838,9 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
     scr[kBorderOffLinv + idx] = v;
   }
   __syncthreads();
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 4] = (double)wall_clock64();
+#endif
   auto sum8 = [](double v) {   // over the 8 lanes of an aligned group
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -5840,6 +5855,9 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
     if (sub == 0) sU[i] = u;
   }
   __syncthreads();
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 5] = (double)wall_clock64();
+#endif
   {   // q = Lc^-T u
     const int a = t >> 3, sub = t & 7;
     double q = 0.0;
@@ -5848,6 +5866,9 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
     if (sub == 0) { scr[kBorderOffQ + a] = q; sQ[a] = q; }
   }
   __syncthreads();
+#ifdef SVIN_BORDER_TIMING
+  if (t == 0) scr[kBorderScratchDoubles + 6] = (double)wall_clock64();
+#endif
   // V = Lc^-1 B on v_mfma_f64_16x16x4: per column tile two row tiles (rows 24 .. 31 come out zero); g1 - B^T q beside it
 #pragma unroll
   for (int kk = 0; kk < 3; ++kk) {
@@ -5877,6 +5898,10 @@ __global__ __launch_bounds__(kBorderPrepThreads) void k_chol_border_prepare(Devi
     const bool any = __any(nz) != 0;
     if (lane == 0) scr[kBorderOffMask + J] = any ? 1.0 : 0.0;
   }
+#ifdef SVIN_BORDER_TIMING
+  __syncthreads();
+  if (t == 0) scr[kBorderScratchDoubles + 7] = (double)wall_clock64();
+#endif
 }
 
 // LDS bytes of k_chol_solve_lds for nT tile rows (+ kBorderMP doubles of the border variants)
