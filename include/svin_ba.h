@@ -397,14 +397,28 @@ int svin_ba_get_path_counters(svin_ba* h, int64_t out[4]);
  * component i of vector j, device_ms (may be NULL) = the fastest of three launches.  Returns 1, 0 if n is out of range,
  * -1 if the result is not finite.  Test hook. */
 int svin_ba_debug_sym_eig(int n, const double* A, double* eigenvalues, double* eigenvectors, double* device_ms);
-/* process-wide A/B switches of the reduced solve, for tests and tools: "SVIN_NO_LL" (no left-looking one-workgroup solver),
- * "SVIN_NO_SB_ELIM" (no speed / bias chain elimination).  Each is initialised from the environment variable of the same name
- * the first time a solve looks at it and only changes through this call afterwards.  Returns 1, 0 for an unknown name. */
+/* Debug / A-B options of the library (svin_amd/csrc/options.hpp; INTEGRATION.md §5 lists them).  Each option is named after the
+ * environment variable that initialises it -- the library looks at the environment ONCE, when the first of them is asked for
+ * (svin_ba_create at the latest) -- and only changes through svin_ba_debug_set_option afterwards; a later setenv() of the host
+ * process is never seen.  None changes a result beyond rounding: they select between implementations of the same arithmetic
+ * ("SVIN_SCHUR_PAIRWISE", "SVIN_NO_LL", "SVIN_NO_SB_ELIM", "SVIN_NO_LDS_BORDER", "SVIN_PANELS_OLD", "SVIN_MARG_EIG" = 0 default
+ * chain / 1 direct / 2 cholesky / 3 jacobi, ...), run the sharded code path with a one-rank communicator
+ * ("SVIN_FORCE_DISTRIBUTED") or switch diagnostics on ("SVIN_MARG_KEEP_PRE", "SVIN_*_TIMING").  Options that shape a handle's
+ * buffers ("SVIN_NO_MAILBOX") are read when the handle is created; the others at the next pack() / solve() / marginalisation.
+ * Test hooks: set returns 1, or 0 for an unknown name; get returns 1 and *value, or 0.  svin_ba_debug_set_switch is the
+ * round-4 spelling of set (value != 0 -> 1). */
+int svin_ba_debug_set_option(const char* name, int value);
+int svin_ba_debug_get_option(const char* name, int* value);
 int svin_ba_debug_set_switch(const char* name, int value);
 /* doubles [offset, offset + count) of the reduced-system solver's scratch buffer after the last solve (tests of the solver
  * kernels' intermediate results).  Returns 1, 0 if the range is outside the buffer. */
 int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out);
-/* marginalisation prior: returns its dimension m; H (m x m), b0 (m), J (m x m), e0 (m) may be NULL */
+/* marginalisation prior: returns its dimension m; H (m x m), b0 (m), J (m x m), e0 (m) may be NULL.
+ * J and e0 are defined up to a left-orthogonal factor: what the solver (and Ceres in the reference) consumes is J^T J, J^T e0
+ * and e0 . e0, and those equal the reference's (MarginalizationError.cpp:746-750).  When the prior has full numerical rank the
+ * default route (k_marg_final_chol, certified: the rank rule of MarginalizationError.cpp:1055-1065 drops nothing) returns the
+ * triangular square root J = L^T P, e0 = -L^-1 P^-1 b0 instead of the eigenbasis form U sqrt(S); a caller that compares J / e0
+ * ROW BY ROW with the reference selects the eigen-solve with svin_ba_debug_set_option("SVIN_MARG_EIG", 1). */
 int svin_ba_get_prior(svin_ba* h, double* H, double* b0, double* J, double* e0, uint64_t* block_ids,
                       int32_t* block_ordering, int32_t* block_mdim, int32_t* n_blocks, int cap_m);
 /* the linear system of the last svin_ba_apply_marginalization_strategy AFTER MarginalizationError::addResidualBlock (M1,

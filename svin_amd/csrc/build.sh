@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $SVIN_EXTRA_FLAGS"
 mkdir -p obj
 # every object depends on every header of the library (a stale object would travel to the GPU box inside the .so)
-HEADERS="kernels.hpp dmath.hpp window.hpp resident.hpp trust_region.hpp symeig.hpp tile16.hpp flat_map.hpp ../../include/svin_ba.h ../../include/svin_pg.h build.sh"
+HEADERS="kernels.hpp options.hpp dmath.hpp window.hpp resident.hpp trust_region.hpp symeig.hpp tile16.hpp flat_map.hpp ../../include/svin_ba.h ../../include/svin_pg.h build.sh"
 stale() {  # stale <object> <source>
   [ ! -f "$1" ] && return 0
   [ "$2" -nt "$1" ] && return 0

@@ -538,7 +538,9 @@ int svin_ba_debug_sym_eig(int n, const double* A, double* eigenvalues, double* e
   GUARD_BEGIN return svin::debugSymEig(n, A, eigenvalues, eigenvectors, device_ms);
   GUARD_END(SVIN_ERR_DEVICE)
 }
-int svin_ba_debug_set_switch(const char* name, int value) { return svin::setSolverSwitch(name, value); }
+int svin_ba_debug_set_option(const char* name, int value) { return svin::setDebugOption(name, value); }
+int svin_ba_debug_get_option(const char* name, int* value) { return svin::debugOptionByName(name, value); }
+int svin_ba_debug_set_switch(const char* name, int value) { return svin::setDebugOption(name, value ? 1 : 0); }
 int svin_ba_debug_peek_solver_scratch(svin_ba* h, uint64_t offset, uint64_t count, double* out) {
   if (!h || !out) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.debugPeekSolverScratch(offset, count, out);

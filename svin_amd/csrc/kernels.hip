@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include "tile16.hpp"
@@ -36,32 +37,15 @@ void ensureDynamicLds(const void* fn, size_t bytes) {
   std::lock_guard<std::mutex> lock(mtx);
   auto it = granted.find(key);
   if (it != granted.end() && it->second >= bytes) return;
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // a refused attribute is not cached: the launch that follows fails, its hipGetLastError() check reports it, and the
+  // next caller tries again instead of trusting a size that was never granted
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize, ") + std::to_string(bytes) + "): " + hipGetErrorString(e));
   granted[key] = bytes;
 }
 
-// A/B switches of the reduced solve: read from the environment ONCE (launchSolveReduced runs several times per trust-region
-// iteration, also on the enqueue thread: getenv there would race with a setenv of the host process), changed afterwards through
-// setSolverSwitch only (svin_ba_debug_set_switch: tests and tools).
-static std::atomic<int> gNoLL{-1}, gNoSbElim{-1}, gNoLdsBorder{-1};
-static bool switchOn(std::atomic<int>& sw, const char* env) {
-  int v = sw.load(std::memory_order_relaxed);
-  if (v < 0) {
-    v = std::getenv(env) != nullptr ? 1 : 0;
-    int expected = -1;
-    if (!sw.compare_exchange_strong(expected, v)) v = expected;
-  }
-  return v != 0;
-}
-int setSolverSwitch(const char* name, int value) {
-  if (!name) return 0;
-  const std::string n(name);
-  if (n == "SVIN_NO_LL") gNoLL.store(value ? 1 : 0);
-  else if (n == "SVIN_NO_SB_ELIM") gNoSbElim.store(value ? 1 : 0);
-  else if (n == "SVIN_NO_LDS_BORDER") gNoLdsBorder.store(value ? 1 : 0);
-  else return 0;
-  return 1;
-}
+// (the A/B switches of the reduced solve -- SVIN_NO_LL, SVIN_NO_SB_ELIM, SVIN_NO_LDS_BORDER -- live in the library's one option
+// table since round 6: options.hpp)
 
 
 // ---------------------------------------------------------------- small helpers
@@ -3140,7 +3124,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     // next to G they are accumulated directly (LDS atomics) and merged into the accumulator tiles once per chunk
     const int nPB = p.dCPose / 6, nEB = dC / 6 - nPB;
     const size_t blocksExtra = (size_t)(dC / 6) * kPoseAcc + (size_t)nEB * nPB * 36;
-    static const bool forceU = std::getenv("SVIN_SCHUR_A_MFMA") != nullptr;
+    const bool forceU = optOn(kOptSchurAMfma);
     const bool aBlocks = aMfma && !forceU && ((size_t)rows * kDenseLd + blocksExtra) * 8 <= 150 * 1024;
     const size_t extra = aBlocks ? blocksExtra : (aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc);
     const size_t ldsBytes = ((size_t)rows * kDenseLd + extra) * 8;
@@ -3166,7 +3150,7 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     // of one (0.79: 86 spilled registers with the next chunk's first observation prefetched, 0.73 without the prefetch and without
     // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).  SVIN_PANELS_OLD=1 launches
     // the round-3 form (one workgroup per CU, prefetch, every pair recomputing V, b, L^-1) for comparison.
-    static const bool oldForm = std::getenv("SVIN_PANELS_OLD") != nullptr;
+    const bool oldForm = optOn(kOptPanelsOld);
     if (oldForm) {
       ensureDynamicLds((const void*)k_schur_panels<1, true, false>, ldsBytes);
       hipLaunchKernelGGL((k_schur_panels<1, true, false>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
@@ -5916,12 +5900,12 @@ constexpr int kCholLdsMaxTiles = 11;   // tile rows of the largest system LDS ho
 // rows beyond the LDS-resident solver's eleven tile rows that it eliminates while loading (k_chol_solve_lds<true>); needs the window's padded S
 static int cholBorderRows(int d, bool padded) {
   const int m = d - 16 * kCholLdsMaxTiles;
-  return (padded && m >= 1 && m <= kBorderMaxRows && !switchOn(gNoLdsBorder, "SVIN_NO_LDS_BORDER")) ? m : 0;
+  return (padded && m >= 1 && m <= kBorderMaxRows && !optOn(kOptNoLdsBorder)) ? m : 0;
 }
 static int solverClass(int d, bool padded = false) {   // 0 = LDS-resident, 1 = left-looking in one workgroup, 2 = blocked over many workgroups
   const int nT = (d + 15) / 16;
   if (cholLdsBytes(nT) <= 156 * 1024 || cholBorderRows(d, padded) > 0) return 0;
-  if (nT >= 12 && nT <= 17 && !switchOn(gNoLL, "SVIN_NO_LL")) return 1;
+  if (nT >= 12 && nT <= 17 && !optOn(kOptNoLL)) return 1;
   return 2;
 }
 // Whether (and where in p.cholL) the speed / bias chain is eliminated ahead of the dense solve: 0 = no, 1 = the kept rows go
@@ -5930,7 +5914,7 @@ static int solverClass(int d, bool padded = false) {   // 0 = LDS-resident, 1 = 
 // takes through a DeviceProblem view.  A system the LDS-resident solver takes whole is left alone (14 us at d = 150: the
 // elimination's four launches cost more), and so is a chain of fewer than 8 blocks ahead of the blocked solver.
 static int planSbElimination(const DeviceProblem& p, SbElimArgs& a) {
-  if (switchOn(gNoSbElim, "SVIN_NO_SB_ELIM") || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
+  if (optOn(kOptNoSbElim) || p.sbChain < 2 || p.sbChain > kSbMaxChain || p.dC < 16 || p.dC + 9 * p.sbChain != p.d) return 0;
   if (solverClass(p.d, p.sPadded != 0) == 0) return 0;
   // Measured (tools/sb_elim_time.py, reduced solve with / without): d = 180 66 / 64 us, 240: 73 / 91, 270: 85 / 113, 360: 99 / 183,
   // 600: 185 / 313, 960: 289 / 476 -- the four launches cost ~45 us before they gain anything, so short chains stay with the
@@ -6031,7 +6015,18 @@ static void launchSolveDense(const DeviceProblem& p, hipStream_t s, double mu, b
     }
   }
 }
+// A refused launch (LDS limit, attribute failure) would leave a stale y_C / v_C behind that the trust-region step consumes silently
+// (ADVICE r5): the error of any launch of the solve is read back here -- hipGetLastError is thread-local and costs no synchronisation.
+static void checkSolverLaunches() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("reduced-system solver launch: ") + hipGetErrorString(e));
+}
+static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize);
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
+  launchSolveReducedUnchecked(p, s, mu, initScale, fuseFinalize);
+  checkSolverLaunches();
+}
+static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   SbElimArgs sb;
   const int elim = planSbElimination(p, sb);
   if (!elim) { launchSolveDense(p, s, mu, initScale, fuseFinalize, nullptr); return; }

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <hip/hip_runtime.h>
 #include "dmath.hpp"
+#include "options.hpp"
 
 namespace svin {
 
@@ -208,8 +209,6 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu = 0.0, 
 // grants a kernel `bytes` of dynamic LDS (hipFuncSetAttribute) once per (device, kernel) and only ever upwards: the attribute
 // belongs to the function for the whole process, so the bookkeeping is process-wide and mutex-protected, not per handle
 void ensureDynamicLds(const void* fn, size_t bytes);
-// process-wide A/B switches of the reduced solve ("SVIN_NO_LL", "SVIN_NO_SB_ELIM": initialised from the environment once); 1 if known
-int setSolverSwitch(const char* name, int value);
 // doubles DeviceProblem::cholL must hold for a reduced system of d unknowns: the LDS-resident solver's spill copy, or
 // the blocked solver's (d64 + 64) x d64 matrix + 1/L_ii + factorised diagonal blocks + block-ready flags
 // (withChain: room for the speed / bias chain elimination next to either solver -- the compact kept system, the chain's records,

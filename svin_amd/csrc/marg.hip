@@ -1056,15 +1056,26 @@ __global__ __launch_bounds__(1024) void k_sym_eig_debug(int n, const double* A, 
 }
 int debugSymEig(int n, const double* A, double* lam, double* X, double* deviceMs) {
   if (n < 1 || n > kSymEigMaxN) return 0;
-  double *dA, *dLam, *dX, *dS; int* dOk;
+  // (a test hook that bench and tests call repeatedly: buffers and events are released on every path, also when a HIP call throws)
+  struct Scratch {
+    double* dA = nullptr; int* dOk = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Scratch() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (dA) (void)hipFree(dA);
+      if (dOk) (void)hipFree(dOk);
+    }
+  } sc;
   const size_t n2 = (size_t)n * n;
-  HIP_OK(hipMalloc(&dA, sizeof(double) * (3 * n2 + n))); dX = dA + n2; dS = dX + n2; dLam = dS + n2;
-  HIP_OK(hipMalloc(&dOk, sizeof(int)));
+  HIP_OK(hipMalloc(&sc.dA, sizeof(double) * (3 * n2 + n)));
+  double *dA = sc.dA, *dX = dA + n2, *dS = dX + n2, *dLam = dS + n2;
+  HIP_OK(hipMalloc(&sc.dOk, sizeof(int)));
+  int* dOk = sc.dOk;
   HIP_OK(hipMemcpy(dA, A, sizeof(double) * n2, hipMemcpyHostToDevice));
   const size_t lds = symEigLdsBytes(n);
   ensureDynamicLds((const void*)k_sym_eig_debug, lds);
-  hipEvent_t e0, e1;
-  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventCreate(&sc.e0)); HIP_OK(hipEventCreate(&sc.e1));
+  const hipEvent_t e0 = sc.e0, e1 = sc.e1;
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {   // (the first launch pays the code upload)
     HIP_OK(hipEventRecord(e0, 0));
@@ -1089,8 +1100,6 @@ int debugSymEig(int n, const double* A, double* lam, double* X, double* deviceMs
   }
 #endif
   if (deviceMs) *deviceMs = best;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(dA); (void)hipFree(dOk);
   return ok ? 1 : -1;
 }
 
@@ -1221,7 +1230,7 @@ static double nowSec() {
 
 int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrames, std::vector<uint64_t>& removed) {
   quiesce();
-  const bool timing = getenv("SVIN_MARG_TIMING") != nullptr;
+  const bool timing = optOn(kOptMargTiming);
   const double tm0 = nowSec();
   double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
   // ---- policy (Estimator.cpp:495-770), operating on the host graph only
@@ -1627,7 +1636,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     if (nk > 0) priorHostValid_ = false;  // results stay on the device (solver reads Ht / bp / c0 in place); getPrior() fetches
     const int nPoseJ = (int)(hPose.size() / 7), nExtJ = (int)(hExt.size() / 7), nSbJ = (int)jSb.size(), nImuJ = (int)hImu.size();
     const int nCamJ = (int)cameras_.size();
-    const bool keepPre = getenv("SVIN_MARG_KEEP_PRE") != nullptr;
+    const bool keepPre = optOn(kOptMargKeepPre);
+    const int margEig = debugOption(kOptMargEig);   // read HERE, on the caller's thread: the job may be issued by the enqueue thread
     // the host tables the staged block is filled from must outlive this call when the job is issued by the enqueue thread
     struct JobTables {
       std::vector<double> hPose, hExt, hSb, hLm, hUv, hW, hImuM;
@@ -1640,13 +1650,13 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       DevBuf<double> oldPriorKeep;
     };
     auto tables = std::make_shared<JobTables>();
-    static const bool syncJob = getenv("SVIN_MARG_SYNC_ENQUEUE") != nullptr;   // A/B switch: issue the launches from this thread
+    const bool syncJob = optOn(kOptMargSyncEnqueue);   // A/B switch: issue the launches from this thread
     const bool runInline = timing || keepPre || syncJob;
     double** dbgScalPtr = runInline ? &dbgScal : nullptr;
     // (explicit captures: the job buffers are reached through `this` -- a by-value capture of the DevBuf aliases above would copy,
     // and later free, the buffers themselves; lmOrder / dense / toMarginalize are only read by the inline inspection path)
     auto launchJob = [this, tables, pendingPtr, N, Lm, m, F, nk, nm, mm, L3, n2k, oldPriorM, oldPrior, anyExtVar, deviceJob, nPoseJ, nExtJ,
-                      nSbJ, nImuJ, nCamJ, keepPre, dbgScalPtr, s, &lmOrder, &dense, &toMarginalize]() {
+                      nSbJ, nImuJ, nCamJ, keepPre, margEig, dbgScalPtr, s, &lmOrder, &dense, &toMarginalize]() {
       MargBuffers& mb = margBuf_;
       auto &bPose = mb.bPose, &bExt = mb.bExt, &bSb = mb.bSb, &bLm = mb.bLm, &bUv = mb.bUv, &bW = mb.bW, &bLin = mb.bLin,
            &bU = mb.bU, &bW2 = mb.bW2, &bV = mb.bV, &bVec = mb.bVec, &bScratch = mb.bScratch;
@@ -1787,8 +1797,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         //   1 / 0  the ONE fall-back: one-sided Jacobi on A itself with G and Q in LDS (n <= 96) / in global memory; taken
         //          inside the kernel when a pivot of the factorisation is not positive, or with SVIN_MARG_EIG=jacobi
         //          (the test that keeps the fall-back honest)
-        const char* want = getenv("SVIN_MARG_EIG");
-        const bool forceFallback = want && std::string(want) == "jacobi";
+        const bool want = margEig != 0;   // SVIN_MARG_EIG: 1 "direct", 2 "cholesky", 3 "jacobi" (options.hpp)
+        const bool forceFallback = margEig == 3;
         const size_t ldsBoth = jacobiLdsBytes(nk), ldsOne = jacobiLdsBytesGOnly(nk);
         const int mode = forceFallback ? (ldsBoth ? 1 : 0) : (ldsOne ? 4 : 6);
         const size_t lds = (mode == 4) ? std::max(ldsOne, ldsBoth) : (mode == 1 ? ldsBoth : 0);
@@ -1797,7 +1807,7 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
         // SVIN_MARG_EIG=cholesky / jacobi select the round-2 solvers alone
         // ... and ahead of both, for a prior of full numerical rank (every steady-state prior of the sliding windows), the Cholesky
         // factor with its certificate that the rank rule drops nothing (k_marg_final_chol); SVIN_MARG_EIG=direct skips it
-        const bool wantDirect = want && std::string(want) == "direct";
+        const bool wantDirect = margEig == 1;
         const bool direct = (!want || wantDirect) && nk <= kSymEigMaxN;
         const bool chol = !want && nk <= kSymEigMaxN;
         if (chol) {
@@ -1837,7 +1847,8 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
       if (mb.bOut.p) HIP_OK(hipMemcpy(sc3, dbgScal, sizeof(sc3), hipMemcpyDeviceToHost));
       std::printf("[marg] m %d Lm %d; Jacobi sweeps of the last eigen-solve: %d; eigenvalues <= tol: %d (min %.3e max %.3e)\n", m, Lm,
                   fl[1], fl[2], sc3[1], sc3[2]);
-      if (mb.bOut.p && sc3[7] > 0) {   // the eigenvalues sit behind p[] in the kernel's scratch
+      if (mb.bOut.p && sc3[7] > 0 && fl[3] != -8) {   // the eigenvalues sit behind p[] in the kernel's scratch (flag[3] == -8: the certified
+                                                        // Cholesky route produced the prior -- tmp + n holds b0 / p there, no eigenvalues exist)
         const int nn = (int)sc3[7];
         std::vector<double> evh(nn);
         HIP_OK(hipMemcpy(evh.data(), dbgScal + 8 + nn, sizeof(double) * nn, hipMemcpyDeviceToHost));

@@ -1471,7 +1471,7 @@ class PoseGraph {
     PG_HIP_OK(hipMemcpy(hq.data(), p.q, sizeof(double) * 4 * nn, hipMemcpyDeviceToHost));
     const auto tWb0 = std::chrono::steady_clock::now();
     writeBack(hy, pitch, roll, ht, hq, kfOfLocal, cur);
-    if (std::getenv("SVIN_PG_TIMING")) {
+    if (optOn(kOptPgTiming)) {
       auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return 1e3 * std::chrono::duration<double>(b - a).count(); };
       const auto tEnd = std::chrono::steady_clock::now();
       std::printf("[pg] problem construction %.3f ms, symbolic %.3f ms, upload + setup %.3f ms, LM loop %.3f ms, download %.3f ms, write back %.3f ms\n",

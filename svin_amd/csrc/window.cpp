@@ -8,6 +8,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <dlfcn.h>
 #include <limits>
 #include <mutex>
@@ -37,6 +39,55 @@ static double dtSecHost(TimeStamp a, TimeStamp b) {  // okvis Duration normalisa
   while (ns < 0) { ns += 1000000000LL; s -= 1; }
   while (ns >= 1000000000LL) { ns -= 1000000000LL; s += 1; }
   return (double)s + 1e-9 * (double)ns;
+}
+
+// ------------------------------------------------------------------------------------------ debug / A-B options (options.hpp)
+namespace {
+struct OptionTable {
+  std::atomic<int> v[kOptCount];
+  const char* name[kOptCount];
+  OptionTable() {
+    static const struct { DebugOption which; const char* env; } kNames[] = {
+        {kOptNoMailbox, "SVIN_NO_MAILBOX"}, {kOptHostPack, "SVIN_HOST_PACK"}, {kOptSchurPairwise, "SVIN_SCHUR_PAIRWISE"},
+        {kOptForceDistributed, "SVIN_FORCE_DISTRIBUTED"}, {kOptNoEarlyImu, "SVIN_NO_EARLY_IMU"}, {kOptPackTiming, "SVIN_PACK_TIMING"},
+        {kOptNoZeroCopyStates, "SVIN_NO_ZERO_COPY_STATES"}, {kOptSplitEval, "SVIN_SPLIT_EVAL"}, {kOptNoFuseStep, "SVIN_NO_FUSE_STEP"},
+        {kOptNoDeferLm, "SVIN_NO_DEFER_LM"}, {kOptNoSpeculation, "SVIN_NO_SPECULATION"}, {kOptCholTiming, "SVIN_CHOL_TIMING"},
+        {kOptPgTiming, "SVIN_PG_TIMING"}, {kOptMargTiming, "SVIN_MARG_TIMING"}, {kOptMargKeepPre, "SVIN_MARG_KEEP_PRE"},
+        {kOptMargSyncEnqueue, "SVIN_MARG_SYNC_ENQUEUE"}, {kOptMargEig, "SVIN_MARG_EIG"}, {kOptSchurAMfma, "SVIN_SCHUR_A_MFMA"},
+        {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
+        {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}};
+    static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
+    for (const auto& n : kNames) {
+      name[n.which] = n.env;
+      const char* e = std::getenv(n.env);   // the library's ONE look at the environment for its switches
+      int val = e ? 1 : 0;
+      if (e && n.which == kOptMargEig) {
+        const std::string w(e);
+        val = w == "direct" ? 1 : (w == "jacobi" ? 3 : 2);   // any other value selects the Cholesky-preconditioned Jacobi solve alone
+      }
+      v[n.which].store(val, std::memory_order_relaxed);
+    }
+  }
+};
+OptionTable& optionTable() {
+  static OptionTable t;   // (thread-safe initialisation; svin_ba_create touches it before the first handle exists)
+  return t;
+}
+}  // namespace
+int debugOption(DebugOption which) { return optionTable().v[which].load(std::memory_order_relaxed); }
+int debugOptionByName(const char* name, int* value) {
+  if (!name) return 0;
+  OptionTable& t = optionTable();
+  for (int k = 0; k < kOptCount; ++k)
+    if (std::strcmp(t.name[k], name) == 0) { if (value) *value = t.v[k].load(std::memory_order_relaxed); return 1; }
+  return 0;
+}
+int setDebugOption(const char* name, int value) {
+  if (!name) return 0;
+  OptionTable& t = optionTable();
+  for (int k = 0; k < kOptCount; ++k)
+    if (std::strcmp(t.name[k], name) == 0) { t.v[k].store(value, std::memory_order_relaxed); return 1; }
+  return 0;
 }
 
 // sqrtInformationUpper: dmath.hpp (shared with svin_host_pose_information)
@@ -128,7 +179,7 @@ Window::Window(int device) : device_(device) {
   // zero-copy mailbox for the per-iteration scalars: the last evaluation kernel stores SolverScalars and a sequence
   // number straight into pinned host memory, the host polls it -- no copy kernel, no stream synchronisation on the
   // critical path of an iteration (SVIN_NO_MAILBOX=1 falls back to memcpy + synchronize)
-  if (!getenv("SVIN_NO_MAILBOX") &&
+  if (!optOn(kOptNoMailbox) &&
       hipHostMalloc(reinterpret_cast<void**>(&mailbox_), sizeof(ScalarMailbox), hipHostMallocMapped) == hipSuccess) {
     std::memset(mailbox_, 0, sizeof(ScalarMailbox));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&mailboxDev_), mailbox_, 0) != hipSuccess) {
@@ -1158,7 +1209,7 @@ void Window::waitIdle() {
 
 // ------------------------------------------------------------------------------------------ device-resident window
 bool Window::useResident() const {   // (called by pack() once the state tables are known)
-  static const bool forceHost = getenv("SVIN_HOST_PACK") != nullptr;
+  const bool forceHost = optOn(kOptHostPack);
   return packMode_ == 0 && !forceHost && world_ <= 1 && rcclComm_ == nullptr && numLandmarkPriors_ == 0 && numFixedLandmarks_ == 0 &&
          poseIds_.size() <= (size_t)kResidentPoseCap;
 }
@@ -1434,7 +1485,6 @@ void Window::pack(bool solveFollows) {
   // path against).  Both list the landmarks with observations in HANDLE order, the observations in insertion order.
   const bool resident = useResident();
   residentUsed_ = resident;
-  ++pathCounters_[resident ? 0 : 1];   // (svin_ba_get_path_counters: nothing falls back silently)
   if (!resident) {
     syncLandmarks();         // the host graph becomes the authority again ...
     invalidateResident();    // ... and the device copy is rebuilt from it when the window next qualifies
@@ -1678,7 +1728,7 @@ void Window::pack(bool solveFollows) {
   int nSlabs = 1;
   // windows whose camera block fits 16 x 16 MFMA tiles (dC <= 254, e.g. 42 poses or 10 poses with per-frame extrinsics):
   // dense Gram-matrix Schur complement on MFMA
-  const bool schurDense = dC > 0 && dC + 2 <= 256 && poseIds_.size() <= (size_t)kDensePoseCap && !getenv("SVIN_SCHUR_PAIRWISE");
+  const bool schurDense = dC > 0 && dC + 2 <= 256 && poseIds_.size() <= (size_t)kDensePoseCap && !optOn(kOptSchurPairwise);
   if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
   // dense Schur with the A part on MFMA (variable extrinsics, or more than 8 tile rows): within every chunk of 16
@@ -1700,7 +1750,7 @@ void Window::pack(bool solveFollows) {
   }
   // wide windows with fixed extrinsics: Gram-matrix Schur complement per pair of 96-row panels (k_schur_panels).
   // Work list: every chunk of 16 landmarks goes to all panel pairs (I >= J) inside the row range its observations touch.
-  const bool schurPanels = !schurDense && !anyExtVar && dC > 0 && L > 0 && !getenv("SVIN_SCHUR_PAIRWISE");
+  const bool schurPanels = !schurDense && !anyExtVar && dC > 0 && L > 0 && !optOn(kOptSchurPairwise);
   std::vector<int> hPanelWork, hPanelChunks, hPanelPairPtr;
   int nPanelBlocks = 0, nPanelPairs = 0;
   if (schurPanels) {
@@ -1766,7 +1816,7 @@ void Window::pack(bool solveFollows) {
   p.L = L; p.N = N; p.F = F; p.nImu = (int)hImu.size(); p.d = d; p.dC = dC; p.nCam = (int)cameras_.size();
   p.priorM = priorM; p.priorBlocks = (int)hPb.size(); p.anyExtVariable = anyExtVar ? 1 : 0;
   p.ownsCamera = (world_ <= 1 || rank_ == 0) ? 1 : 0;
-  p.rank = (world_ <= 1 && rcclComm_ && getenv("SVIN_FORCE_DISTRIBUTED")) ? -1 : rank_;   // -1: one-rank communicator exercising the sharded path
+  p.rank = (world_ <= 1 && rcclComm_ && optOn(kOptForceDistributed)) ? -1 : rank_;   // -1: one-rank communicator exercising the sharded path
   p.world = world_;
   if (!p.ownsCamera) p.priorM = 0;   // the prior is evaluated and accumulated on one rank only
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
@@ -1827,7 +1877,7 @@ void Window::pack(bool solveFollows) {
   // do not depend on each other, and the ~40 us integration chain is otherwise the first thing the solve waits for.  The
   // results of this evaluation are discarded (the solve's first evaluation repeats it, now without the integration); only
   // the pre-integration state stays.  Not in prepare(): there the upload is outside the measured region and the solve is not.
-  static const bool noEarlyImu = getenv("SVIN_NO_EARLY_IMU") != nullptr;
+  const bool noEarlyImu = optOn(kOptNoEarlyImu);
   if (solveFollows && resident && !noEarlyImu && F > 0) {
     bool anyRedo = false;
     for (const DevImu& im : hImu) anyRedo |= im.redo != 0;
@@ -1838,7 +1888,7 @@ void Window::pack(bool solveFollows) {
       HIP_OK(hipStreamWaitEvent(s, evImuReady_, 0));
     }
   }
-  if (getenv("SVIN_PACK_TIMING")) {
+  if (optOn(kOptPackTiming)) {
     const double tPack2 = nowSec();
     HIP_OK(hipStreamSynchronize(s));
     std::printf("[pack] host graph -> arrays %.1f us, allocation + enqueue %.1f us, drain %.1f us\n", 1e6 * (tPack1 - tPack0),
@@ -1855,7 +1905,7 @@ void Window::downloadStates() {
       hLm(resident ? 0 : (size_t)p.L * 4), hQ(resident ? 0 : p.L);
   std::vector<DevImu> hImu(p.nImu);
   if (p.L > 0 && !resident) launchLandmarkQuality(p, dQuality_.p, s);
-  static const bool noZeroCopy = getenv("SVIN_NO_ZERO_COPY_STATES") != nullptr;   // A/B switch
+  const bool noZeroCopy = optOn(kOptNoZeroCopyStates);   // A/B switch
   const bool zeroCopy = resident && !noZeroCopy;   // the states arrive through a host-mapped block written by k_window_finish
   if (resident && res_.H > 0) {
     if (!zeroCopy) launchWindowStoreLandmarks(res_.H, res_.slotOfH[res_.cur].p, p.lm, nullptr, res_.lmHp.p, res_.qualH.p, s);
@@ -1962,7 +2012,7 @@ void Window::evaluateAll(bool cand, hipStream_t s) {
   prob_.mailbox = distNative_ ? nullptr : mailboxDev_;   // sharded: published after the all-reduce (launchPublishScalars)
   prob_.mailboxSeq = ++mailboxSeq_;
   const int who = costSummedBy(prob_);
-  if (canFuseEvaluation(prob_) && !getenv("SVIN_SPLIT_EVAL")) {
+  if (canFuseEvaluation(prob_) && !optOn(kOptSplitEval)) {
     // one launch: the reprojection blocks and the prior run next to the (much longer) IMU factor blocks
     launchEvalAll(prob_, cand, true, s);  // factor, reprojection and prior blocks; the last one sums the cost
     return;
@@ -2007,7 +2057,7 @@ void Window::solve(size_t numIter, bool verbose) {
   summary_.iterations = 0; summary_.num_successful_steps = 0; summary_.termination = 1;
   if (p.d + 3 * p.L == 0) { summary_.termination = 0; summary_.initial_cost = summary_.final_cost = 0; return; }
   // landmark-sharded mode: partial sums are all-reduced at three points per iteration
-  const bool forceDist = getenv("SVIN_FORCE_DISTRIBUTED") != nullptr;   // single-rank RCCL: exercises the sharded code path on one GPU
+  const bool forceDist = optOn(kOptForceDistributed);   // single-rank RCCL: exercises the sharded code path on one GPU
   const bool dist = world_ > 1 || (forceDist && rcclComm_);
   auto AR = [&](void* ptr, size_t n, int op) {
     if (!dist) return;
@@ -2027,11 +2077,11 @@ void Window::solve(size_t numIter, bool verbose) {
   double* scalD = reinterpret_cast<double*>(p.scal);  // [0..7] group A, [8..15] group B, [16..31] the ranks' (gradMax, failMax) pairs
   // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
   // retracts the whole window quickly enough
-  static const bool noFuseStep = getenv("SVIN_NO_FUSE_STEP") != nullptr;   // A/B switch for profiling
+  const bool noFuseStep = optOn(kOptNoFuseStep);   // A/B switch for profiling
   const bool fuseStep = !noFuseStep && !dist && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
   // fused step: the landmark half of the retraction rides in the candidate evaluation (k_eval_all), which reads every
   // landmark anyway -- the serial tail of k_post_solve only moves the ~20 parameter blocks
-  const bool deferLm = fuseStep && canFuseEvaluation(p) && !getenv("SVIN_SPLIT_EVAL") && !getenv("SVIN_NO_DEFER_LM") && p.L > 0 && p.N > 0;
+  const bool deferLm = fuseStep && canFuseEvaluation(p) && !optOn(kOptSplitEval) && !optOn(kOptNoDeferLm) && p.L > 0 && p.N > 0;
   // the stop vote (k_set_stop_vote) travels in the slots k_post_solve uses for the fused dogleg coefficients of the deferred
   // landmark step: the two never meet because a sharded solve takes neither the fused nor the deferred step
   if (dist && (fuseStep || deferLm)) throw std::logic_error("sharded solve with a fused step");
@@ -2074,7 +2124,7 @@ void Window::solve(size_t numIter, bool verbose) {
   // launch of the next iteration.  Right behind the candidate evaluation the normal equations of the NEXT iteration
   // are enqueued on the candidate's linearisation (the sets an accepted step swaps in) with the damping an accepted
   // step gets; on acceptance they are simply kept, otherwise the accumulators are re-zeroed before the next build.
-  static const bool noSpeculation = getenv("SVIN_NO_SPECULATION") != nullptr;
+  const bool noSpeculation = optOn(kOptNoSpeculation);
   const bool speculate = !noSpeculation && (!dist || distNative_);
   bool accumulatorsClean = true;   // S / gRed / hC zero (pack() or k_post_solve), nothing speculative in them
   bool specValid = false;          // the accumulators hold the build of the candidate with damping specMu
@@ -2161,6 +2211,8 @@ void Window::solve(size_t numIter, bool verbose) {
 int Window::prepare() {
   const double t0 = nowSec();
   pack();
+  ++pathCounters_[residentUsed_ ? 0 : 1];   // counted where an optimisation packs, not in pack() itself: linearize(), the
+                                            // inspection hooks and debugReducedSolve() pack too
   HIP_OK(hipStreamSynchronize(stream_));
   summary_.upload_time = nowSec() - t0;
   return 1;
@@ -2184,6 +2236,7 @@ int Window::optimize(size_t numIter, bool verbose) {
   // right behind the upload and the rebuild of the resident window)
   const double t0 = nowSec();
   pack(/*solveFollows=*/true);
+  ++pathCounters_[residentUsed_ ? 0 : 1];   // (svin_ba_get_path_counters: nothing falls back silently)
   const double t1 = nowSec();
   summary_.upload_time = t1 - t0;   // host time of pack(): the device part overlaps the first launches of the solve
   maxIterationsOption_ = numIter;
@@ -2586,12 +2639,12 @@ int Window::benchKernelTimes(int iters, double* evalMs, double* buildMs, double*
                 dbg[1] / iters, dbg[2] / iters, dbg[3] / iters, dbg[4] / iters);
   }
 #endif
-  if (getenv("SVIN_CHOL_TIMING")) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64 * 8));
+  if (optOn(kOptCholTiming)) HIP_OK(hipMemset(p.partial + (size_t)15 * 4096, 0, 64 * 8));
 #ifdef SVIN_CHOL_TIMING
   debugCholTiming(nullptr, true);
 #endif
   if (solveMs) *solveMs = timeIt([&]() { launchSolveReduced(p, s); });
-  if (getenv("SVIN_CHOL_TIMING")) {
+  if (optOn(kOptCholTiming)) {
     double dbg[6];
     HIP_OK(hipMemcpy(dbg, p.partial + (size_t)15 * 4096, sizeof(dbg), hipMemcpyDeviceToHost));
     std::printf("[chol cycles per launch] load + first pivot tile %.0f  factorisation done (from kernel start) %.0f  backward substitution %.0f (wave 0 asked %.1f times more for a late block)\n",

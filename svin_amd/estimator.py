@@ -55,7 +55,7 @@ EXPORTS = [
     "svin_ba_set_camera_sensor_states", "svin_ba_set_landmark", "svin_ba_num_frames", "svin_ba_num_landmarks",
     "svin_ba_current_keyframe_id", "svin_ba_current_frame_id", "svin_ba_frame_id_by_age", "svin_ba_is_keyframe",
     "svin_ba_is_in_imu_window", "svin_ba_frame_ids", "svin_ba_landmark_ids", "svin_ba_imu_propagation",
-    "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize", "svin_ba_debug_reduced_solve", "svin_ba_debug_reduced_solve_ex", "svin_ba_debug_set_switch", "svin_ba_debug_sym_eig", "svin_ba_get_path_counters", "svin_ba_wait_idle", "svin_ba_debug_peek_solver_scratch",
+    "svin_ba_eval_reprojection", "svin_ba_observation_ids", "svin_ba_eval_factors", "svin_ba_linearize", "svin_ba_debug_reduced_solve", "svin_ba_debug_reduced_solve_ex", "svin_ba_debug_set_switch", "svin_ba_debug_set_option", "svin_ba_debug_get_option", "svin_ba_debug_sym_eig", "svin_ba_get_path_counters", "svin_ba_wait_idle", "svin_ba_debug_peek_solver_scratch",
     "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_residual_info",
     "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
     "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
@@ -157,6 +157,8 @@ def load_library():
     sig("svin_ba_debug_reduced_solve", i32, vp, f64, pd, i32)
     sig("svin_ba_debug_reduced_solve_ex", i32, vp, f64, i32, pd, i32)
     sig("svin_ba_debug_set_switch", i32, C.c_char_p, i32)
+    sig("svin_ba_debug_set_option", i32, C.c_char_p, i32)
+    sig("svin_ba_debug_get_option", i32, C.c_char_p, pi32)
     sig("svin_ba_debug_sym_eig", i32, i32, pd, pd, pd, pd)
     sig("svin_ba_get_path_counters", i32, vp, C.POINTER(C.c_int64))
     sig("svin_ba_wait_idle", i32, vp)
@@ -758,11 +760,28 @@ class Estimator:
             raise RuntimeError("svin_ba_debug_sym_eig: %d" % rc)
         return lam, X, float(ms[0])
 
+    _MARG_EIG = {"": 0, None: 0, "direct": 1, "cholesky": 2, "jacobi": 3}
+
+    @staticmethod
+    def debug_set_option(name, value):
+        """process-wide debug / A-B option of the library, named after the environment variable that initialises it
+        (include/svin_ba.h: svin_ba_debug_set_option); "SVIN_MARG_EIG" also takes "direct" / "cholesky" / "jacobi" / None"""
+        if name == "SVIN_MARG_EIG" and not isinstance(value, (int, bool)):
+            value = Estimator._MARG_EIG[value]
+        if load_library().svin_ba_debug_set_option(name.encode(), int(value)) != 1:
+            raise KeyError(name)
+
+    @staticmethod
+    def debug_get_option(name):
+        v = np.zeros(1, dtype=np.int32)
+        if load_library().svin_ba_debug_get_option(name.encode(), v.ctypes.data_as(C.POINTER(C.c_int32))) != 1:
+            raise KeyError(name)
+        return int(v[0])
+
     @staticmethod
     def debug_set_switch(name, value):
-        """process-wide A/B switch of the reduced solve ("SVIN_NO_LL", "SVIN_NO_SB_ELIM", "SVIN_NO_LDS_BORDER")"""
-        if load_library().svin_ba_debug_set_switch(name.encode(), 1 if value else 0) != 1:
-            raise KeyError(name)
+        """round-4 spelling of debug_set_option for the on / off switches of the reduced solve"""
+        Estimator.debug_set_option(name, 1 if value else 0)
 
     def debug_peek_solver_scratch(self, offset, count):
         out = np.zeros(int(count))

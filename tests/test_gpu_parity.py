@@ -266,7 +266,7 @@ def test_reduced_system_parity(gpu_lib, rig):
 
 @pytest.mark.parametrize("P,L,n_obs", [(5, 200, 2000), (10, 500, 5000), (14, 300, 2400), (12, 60, 1400), (3, 40, 200),
                                         (48, 900, 9000), (70, 1500, 12000)])  # last two: panel-pair kernel (dC = 288 / 420)
-def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
+def test_dense_and_pairwise_schur_agree(gpu_lib, debug_option, P, L, n_obs):
     """The landmark-elimination kernels (Gram-matrix form on MFMA: one block for narrow windows, 96-row panel pairs for
     wide ones; pairwise blocks as the general fallback) must produce the same reduced system and the same optimisation
     result on a window both can handle."""
@@ -275,9 +275,9 @@ def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
     out = {}
     for mode in ("dense", "pairwise"):
         if mode == "pairwise":
-            monkeypatch.setenv("SVIN_SCHUR_PAIRWISE", "1")
+            debug_option("SVIN_SCHUR_PAIRWISE", 1)
         else:
-            monkeypatch.delenv("SVIN_SCHUR_PAIRWISE", raising=False)
+            debug_option("SVIN_SCHUR_PAIRWISE", 0)
         est = Estimator(0)
         f, l = syn.feed(est, spec)
         lin = est.linearize(1e-8)
@@ -295,16 +295,16 @@ def test_dense_and_pairwise_schur_agree(gpu_lib, monkeypatch, P, L, n_obs):
     assert worst < 1e-8
 
 
-def test_mailbox_and_memcpy_scalar_paths_agree(gpu_lib, monkeypatch):
+def test_mailbox_and_memcpy_scalar_paths_agree(gpu_lib, debug_option):
     """Per-iteration scalars through the pinned-host mailbox or through memcpy + synchronise: identical runs."""
     from svin_amd.estimator import Estimator
     spec = syn.make_window(P=6, L=300, n_obs=3000, seed=9, rig="euroc")
     res = []
     for no_mailbox in (False, True):
         if no_mailbox:
-            monkeypatch.setenv("SVIN_NO_MAILBOX", "1")
+            debug_option("SVIN_NO_MAILBOX", 1)
         else:
-            monkeypatch.delenv("SVIN_NO_MAILBOX", raising=False)
+            debug_option("SVIN_NO_MAILBOX", 0)
         est = Estimator(0)
         f, l = syn.feed(est, spec)
         est.optimize(15)
@@ -554,7 +554,7 @@ def test_marginalization_one_shot(gpu_lib, rig, kw):
 
 
 @pytest.mark.parametrize("rig", ["euroc", "rig_v2"])
-def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch, rig):
+def test_marginalization_m1_against_exact_chain(gpu_lib, debug_option, rig):
     """M1 AND M2 of the HIP path against a 40-digit chain that starts from the raw residual definitions (tests/mp_m1.py +
     tests/mp_marg.py; structure -- which residuals, ordering, which rows leave -- from the oracle's log, every number
     recomputed): five marginalisations in sequence on identical states (the oracle's snapshots are injected before each
@@ -570,7 +570,7 @@ def test_marginalization_m1_against_exact_chain(gpu_lib, monkeypatch, rig):
     from oracle import orc
     import mp_m1
     from test_marginalization_m1_exact import tiny_sequence_spec, tiny_sequence_spec_rig_v2, scaled
-    monkeypatch.setenv("SVIN_MARG_KEEP_PRE", "1")
+    debug_option("SVIN_MARG_KEEP_PRE", 1)
     spec = tiny_sequence_spec() if rig == "euroc" else tiny_sequence_spec_rig_v2()
     bar_b1 = 1e-10 if rig == "euroc" else 2e-9
     cpu, gpu = orc.OracleEstimator(), Estimator(0)
@@ -787,7 +787,7 @@ def test_landmark_sharded_solve_emulated_two_ranks(gpu_lib):
         assert worst < 1e-9
 
 
-def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
+def test_native_rccl_path_single_rank(gpu_lib, debug_option):
     """The sharded solve with RCCL called natively on the solver's stream (ncclAllReduce in place, scalars published to
     the mailbox after the reduction, speculative build kept).  One GPU cannot hold two RCCL ranks, so the code path is
     driven with a ONE-rank communicator: every collective really runs (and is the identity), the rest of the path is
@@ -800,9 +800,9 @@ def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
     est = Estimator(0)
     f, _ = syn.feed(est, spec)
     est.set_distributed_rccl(0, 1, rccl_unique_id())
-    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 1)
     est.optimize(10)
-    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 0)
     s, s_ref = est.summary(), ref.summary()
     worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
     log("native RCCL, one rank: summary", s, "reference", s_ref, "pose diff", worst)
@@ -817,14 +817,14 @@ def test_native_rccl_path_single_rank(gpu_lib, monkeypatch):
     est = Estimator(0)
     f, _ = syn.feed(est, spec)
     est.set_distributed_rccl(0, 1, rccl_unique_id())
-    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 1)
     est.optimize(6)
-    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 0)
     worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
     assert est.summary()["iterations"] == ref.summary()["iterations"] and worst < 1e-8, worst
 
 
-def test_native_rccl_path_full_config4_size(gpu_lib, monkeypatch):
+def test_native_rccl_path_full_config4_size(gpu_lib, debug_option):
     """BASELINE configs[3] at its full size (64 KF / 50 000 landmarks / 500 000 residuals, d = 960) through the sharded
     code path with a one-rank RCCL communicator (packed lower-triangle message, [group B | gathered maxima] message, stop
     vote, scalars published after the reduction): same iterates as the plain single-GPU solve.  Then the time-limit
@@ -838,7 +838,7 @@ def test_native_rccl_path_full_config4_size(gpu_lib, monkeypatch):
     est = Estimator(0)
     f, _ = syn.feed(est, spec)
     est.set_distributed_rccl(0, 1, rccl_unique_id())
-    monkeypatch.setenv("SVIN_FORCE_DISTRIBUTED", "1")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 1)
     est.optimize(3)
     s, s_ref = est.summary(), ref.summary()
     worst = max(pose_diff(est.get_T_WS(a), ref.get_T_WS(b)) for a, b in zip(f, f_ref))
@@ -851,7 +851,7 @@ def test_native_rccl_path_full_config4_size(gpu_lib, monkeypatch):
     assert est.set_time_limit(1e-6, 2)
     est.optimize(10)
     s = est.summary()
-    monkeypatch.delenv("SVIN_FORCE_DISTRIBUTED")
+    debug_option("SVIN_FORCE_DISTRIBUTED", 0)
     assert s["termination"] == 2 and 2 <= s["iterations"] <= 3, s
 
 
@@ -1049,7 +1049,7 @@ def test_marginalization_sequence_euroc_reference_window(gpu_lib):
 
 
 @pytest.mark.parametrize("rig,window,P", [("euroc", (2, 3), 8), ("rig_v2", (5, 3), 13)])
-def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P):
+def test_prior_eigen_solver_fallback_agrees(gpu_lib, debug_option, rig, window, P):
     """M3's four routes: by default a Cholesky factor when it can certify that the rank rule drops nothing (k_marg_final_chol),
     else the direct eigen-solve (SVIN_MARG_EIG=direct runs it for every prior: tridiagonalisation + divide and conquer, up to
     128 unknowns), behind it the Cholesky-preconditioned one-sided Jacobi of rounds 2-4 (SVIN_MARG_EIG=cholesky runs it alone;
@@ -1061,16 +1061,16 @@ def test_prior_eigen_solver_fallback_agrees(gpu_lib, monkeypatch, rig, window, P
     out = {}
     for mode in ("default", "direct", "cholesky", "jacobi"):
         if mode == "default":
-            monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
+            debug_option("SVIN_MARG_EIG", None)
         else:
-            monkeypatch.setenv("SVIN_MARG_EIG", mode)
+            debug_option("SVIN_MARG_EIG", mode)
         est = Estimator(0)
         est.set_solver_options(1e-12, 1e-12, 1e-12)
         f, l, removed = run_sequence(est, spec, window[0], window[1], 25)
         m = est.marg()
         assert m is not None
         out[mode] = dict(m=m, removed=removed, poses=[est.get_T_WS(a) for a in est.frame_ids()])
-    monkeypatch.delenv("SVIN_MARG_EIG", raising=False)
+    debug_option("SVIN_MARG_EIG", None)
     for other in ("direct", "cholesky", "jacobi"):
         o = compare_priors(out[other]["m"], out["default"]["m"], "eigen-solver %s vs default (direct), %s" % (other, rig))
         worst = max(pose_diff(a, b) for a, b in zip(out[other]["poses"], out["default"]["poses"]))

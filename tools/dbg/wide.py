@@ -9,8 +9,7 @@ import test_gpu_parity as tp
 
 for (P, L, n, dt) in ((16, 600, 9000, 0.25), (30, 900, 9000, 0.25), (44, 1200, 12000, 0.25), (48, 1500, 15000, 0.25)):
     for mode in ("default", "pairwise"):
-        if mode == "pairwise": os.environ["SVIN_SCHUR_PAIRWISE"] = "1"
-        else: os.environ.pop("SVIN_SCHUR_PAIRWISE", None)
+        Estimator.debug_set_option("SVIN_SCHUR_PAIRWISE", 1 if mode == "pairwise" else 0)
         spec = tp.drop_underdetermined_landmarks(syn.make_window(P=P, L=L, n_obs=n, seed=31, frame_dt=dt))
         gpu, cpu, fg, fc, lg, lc = tp.make_pair(spec)
         lin_c = cpu.map().linearize(0.0); lin_g = gpu.linearize(0.0)

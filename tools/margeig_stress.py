@@ -9,8 +9,7 @@ from svin_amd.estimator import Estimator
 
 
 def run(spec, window, mode):
-    if mode: os.environ["SVIN_MARG_EIG"] = mode
-    else: os.environ.pop("SVIN_MARG_EIG", None)
+    Estimator.debug_set_option("SVIN_MARG_EIG", mode or None)   # (the library reads its environment once: options.hpp)
     est = Estimator(0)
     ranks = []
     def on_frame(k, fid):
