@@ -2938,6 +2938,355 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
 #undef PNT
 }
 
+// ---------------------------------------------------------------- wide windows, round 6: the Schur complement by BLOCK PAIRS
+// The tile form above writes the columns of G of 16 landmarks into 96 x 48 LDS tiles and multiplies whole 16 x 16 tiles: on the
+// bench window of configs[3] a landmark sees 9.2 poses scattered over a span of 28, its 55 rows live in ~8 tiles of 16, and 6.3
+// executed MFMA flops per algorithmic one is what no landmark order gets below (profiles/r05_config4_mfma.json).  Here the unit of
+// work is what the algebra is made of:  S = A - sum_l sum_(a, b in poses(l)) E_la E_lb^T,  E_la = (sum_obs Jp^T Jl) L_l^-T  (6 x 3),
+// A = blockdiag_pose sum_obs Jp^T Jp.  A SLOT is a (landmark, distinct variable pose) pair; slots, their observation lists and the
+// work list are structure, built by Window::pack once per window.
+//  * k_panels_landmarks (once per build, as for the tile form): V_l, b_l, the metric, L_l^-1, c_l.  k_blocks_slots, one thread per
+//    slot: E_la and E_la c_l as a RECORD of 24 doubles rec[8 k + row] -- k = 0..2 the column of E, rows 0..5 the pose's tangent
+//    directions, rows 6, 7 of the three columns the six entries of E_la c_l -- and the slot's share of its pose's block of A and of
+//    Jp^T r (27 numbers), added to the workgroup's per-pose accumulators in LDS (ds_add_f64) and written out as one partial per
+//    workgroup; k_blocks_pose_reduce sums the partials into S, gFull, gRed, hC.
+//  * k_schur_blocks: one workgroup per panel pair (I, J) and list of up to 256 ENTRIES (a landmark with slots in both panels:
+//    first slot and count in either), a WAVE per entry: the records of the entry's slots in panel I and in panel J (at most 16
+//    each: a panel is 16 poses) are staged in the wave's own LDS buffers -- requested one entry ahead, the work list itself sits
+//    in LDS, so no global round trip is exposed -- and every slot pair is ONE v_mfma_f64_4x4x4_4b_f64: its four independent
+//    4 x 4 x 4 blocks are the four quadrants of the 8 x 8 padding of a 6 x 6 block product with K = 3 padded to 4 (operand /
+//    result lane layout measured with tools/ubench/mfma_f64_4x4.hip: A lane 16 k + 4 b + i, B lane 16 k + 4 b + j, D lane
+//    16 i + 4 b + j; 16 cycles per instruction = the 16x16x4 form's flop rate).  512 executed flops per 216 algorithmic ones,
+//    whatever the landmarks see.  The 36 valid results go into the pair's 16 x 16 blocks of 6 x 6 in LDS with ds_add_f64 (8 cycles
+//    per instruction and CU); no workgroup barrier between the clear and the flush -- waves never wait for each other.  Diagonal
+//    pairs collect sum_l E_la c_l from the operand lanes that hold it.  The slab a workgroup writes has the tile form's layout:
+//    k_reduce_panel_slabs is unchanged.
+constexpr int kBlkRec = 24;                      // doubles per slot record
+constexpr int kBlkPanelPoses = kPanelRows / 6;   // 16
+constexpr int kBlkStride = kBlkRec + 1;          // ... staged in LDS with a zero behind them: the K = 3 padding of every operand
+constexpr int kBlkBuf = kBlkPanelPoses * kBlkStride;    // a wave's staging buffer: 16 records
+constexpr int kBlkBatch = 8;                     // slot pairs per trip of k_schur_blocks
+constexpr int kBlkPoseLd = 29;                   // per pose block of the landmark pass's accumulators: odd, so that the sixteen slots of a landmark hit different banks
+
+// one THREAD per slot, 1024 slots per workgroup (k_panels_landmarks has left L_l^-1 and c_l in lmFactor): W = sum over the slot's
+// observations of Jp^T Jl (6 x 3), E = W L^-T, E c -> the slot's record; the pose's share of A and Jp^T r -> the workgroup's
+// accumulators.  (The first version did this inside the per-landmark pass, 16 lanes per landmark and four landmarks per group
+// one after the other: six dependent global round trips per landmark and 4-way address conflicts of the LDS atomics -- 119 us.)
+__global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopies) {
+  extern __shared__ double sA[];   // nCopies x per pose block: 21 (upper 6 x 6 of sum Jp^T Jp) + 6 (Jp^T r) + pad
+  const int t = threadIdx.x;
+  const int nBlk = p.dC / 6;
+  for (int i = t; i < nCopies * nBlk * kBlkPoseLd; i += 256) sA[i] = 0.0;
+  __syncthreads();
+  // (consecutive slots are the poses of one landmark, then of the next: the sixteen lanes of a group rarely meet in a pose,
+  // the four groups of a wave often do -- a copy per group)
+  double* sMine = sA + (size_t)((t >> 4) & (nCopies - 1)) * nBlk * kBlkPoseLd;
+  const size_t N = (size_t)p.N;
+  for (int j = 0; j < kBlkSlotsPerWorkgroup / 256; ++j) {
+    const int sl = blockIdx.x * kBlkSlotsPerWorkgroup + 256 * j + t;
+    if (sl >= p.nSlots) break;
+    const int q0 = p.slotObsPtr[sl], q1 = p.slotObsPtr[sl + 1];
+    const int blk = (int)p.slotBlk[sl];
+    const double* f = p.lmFactor + 9 * (size_t)p.slotLm[sl];
+    const double i00 = f[0], i10 = f[1], i11 = f[2], i20 = f[3], i21 = f[4], i22 = f[5], cv0 = f[6], cv1 = f[7], cv2 = f[8];
+    double W[6][3], U[21], gF[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { W[a][0] = W[a][1] = W[a][2] = 0.0; gF[a] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < 21; ++a) U[a] = 0.0;
+    for (int q = q0; q < q1; ++q) {
+      const size_t o = (size_t)p.slotObs[q];
+      const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
+      const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
+      const double r0 = p.rCur[o], r1 = p.rCur[N + o];
+      double jc[12];
+#pragma unroll
+      for (int a = 0; a < 12; ++a) jc[a] = p.JpCur[a * N + o];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double j0 = jc[a], j1 = jc[6 + a];
+        W[a][0] += j0 * a0 + j1 * c0; W[a][1] += j0 * a1 + j1 * c1; W[a][2] += j0 * a2 + j1 * c2;
+#pragma unroll
+        for (int c = a; c < 6; ++c) U[sym6(a, c)] += j0 * jc[c] + j1 * jc[6 + c];
+        gF[a] += j0 * r0 + j1 * r1;
+      }
+    }
+    double* ap = sMine + (size_t)blk * kBlkPoseLd;
+#ifndef SVIN_SLOTS_NOATOM   // (timing experiments only: wrong results)
+#pragma unroll
+    for (int a = 0; a < 21; ++a) atomicAdd(&ap[a], U[a]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) atomicAdd(&ap[21 + a], gF[a]);
+#else
+    if (U[0] + gF[0] == 1.2345) ap[0] = 1.0;
+#endif
+    double rec[kBlkRec];
+    double ec[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double e0 = W[a][0] * i00, e1 = W[a][0] * i10 + W[a][1] * i11, e2 = W[a][0] * i20 + W[a][1] * i21 + W[a][2] * i22;
+      rec[a] = e0; rec[8 + a] = e1; rec[16 + a] = e2;
+      ec[a] = e0 * cv0 + e1 * cv1 + e2 * cv2;
+    }
+    rec[6] = ec[0]; rec[7] = ec[1]; rec[14] = ec[2]; rec[15] = ec[3]; rec[22] = ec[4]; rec[23] = ec[5];
+    double2* out = reinterpret_cast<double2*>(p.slotRec + (size_t)sl * kBlkRec);   // (records are 192 bytes: 16-byte aligned)
+#ifndef SVIN_SLOTS_NOSTORE
+#pragma unroll
+    for (int q = 0; q < kBlkRec / 2; ++q) out[q] = double2{rec[2 * q], rec[2 * q + 1]};
+#else
+    { double sum = 0; for (int q = 0; q < kBlkRec; ++q) sum += rec[q]; if (sum == 1.2345) out[0] = double2{sum, sum}; }
+#endif
+  }
+  __syncthreads();
+  double* part = p.blkPartial + (size_t)blockIdx.x * nBlk * kPoseAcc;
+  for (int i = t; i < nBlk * kPoseAcc; i += 256) {
+    const int blk = i / kPoseAcc, e = i - blk * kPoseAcc;
+    double v = 0;
+    if (e < 27)
+      for (int c = 0; c < nCopies; ++c) v += sA[((size_t)c * nBlk + blk) * kBlkPoseLd + e];
+    part[i] = v;
+  }
+}
+
+// S (pose diagonal blocks), gFull, gRed, hC += the per-pose sums of k_blocks_slots' partials; one workgroup per pose block,
+// 32 lanes per partition of the partials (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void k_blocks_pose_reduce(DeviceProblem p, int nPartials) {
+  __shared__ double part[1024];
+  const int t = threadIdx.x, e = t & 31, q = t >> 5, blk = blockIdx.x;
+  const int nBlk = p.dC / 6;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (e < kPoseAcc) {
+    const int per = (nPartials + 31) / 32;
+    const int k1 = min(nPartials, (q + 1) * per);
+    const double* src = p.blkPartial + (size_t)blk * kPoseAcc + e;
+    const size_t stride = (size_t)nBlk * kPoseAcc;
+    int k = q * per;
+    for (; k + 3 < k1; k += 4) { s0 += src[k * stride]; s1 += src[(k + 1) * stride]; s2 += src[(k + 2) * stride]; s3 += src[(k + 3) * stride]; }
+    for (; k < k1; ++k) s0 += src[k * stride];
+  }
+  part[t] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q != 0 || e >= 27) return;
+  double v = 0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v += part[32 * k + e];
+  if (e < 21) {
+    int a = 0;
+    while (sym6(a + 1, a + 1) <= e) ++a;   // row of the upper-triangle entry
+    const int c = a + (e - sym6(a, a));
+    const int r0 = 6 * blk + a, c0 = 6 * blk + c;
+    p.S[(size_t)r0 * p.ldS + c0] += v;
+    if (a != c) p.S[(size_t)c0 * p.ldS + r0] += v;
+    else p.hC[r0] += v;
+  } else {
+    const int r0 = 6 * blk + (e - 21);
+    p.gFull[r0] += v; p.gRed[r0] += v;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_schur_blocks(DeviceProblem p) {
+  extern __shared__ double smem[];
+  const int t = threadIdx.x, b = blockIdx.x, wave = t >> 6, lane = t & 63;
+  const int4 work = p.panelWork[b];  // x = I, y = J, z = first entry of blkEntries, w = number of entries
+  const int pI = work.x, pJ = work.y;
+  const bool diag = pI == pJ;
+  constexpr int nPB = kBlkPanelPoses;
+  // LDS: the pair's 16 x 16 blocks of 36 (+ a spare one) | per-wave staging buffers (slots in I, slots in J; a diagonal pair uses
+  //      the first) | diagonal pairs: 96 entries of sum E c
+  double* acc = smem;
+  constexpr int accDoubles = (nPB * nPB + 1) * 36;
+  double* bufA = smem + accDoubles + (size_t)wave * 2 * kBlkBuf;
+  double* bufB = diag ? bufA : bufA + kBlkBuf;
+  double* gcv = smem + accDoubles + (size_t)NW * 2 * kBlkBuf;
+  constexpr int ldsDoubles = accDoubles + NW * 2 * kBlkBuf + kPanelRows;   // (even)
+  for (int i = t; i < ldsDoubles / 2; i += 64 * NW) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};
+  // The work list: per wave a sequence of ENTRIES, interleaved (entry NW k + wave is wave's k-th; the host dealt the workgroup's
+  // entries to the waves longest first, so that the waves finish together, and padded the shorter sequences with empty entries):
+  // x = first slot in I, y = first slot in J, z = count in I | count in J << 8 | quads of pair words << 16, w = first pair word.
+  // Descriptors travel through scalar loads two entries ahead, records and first pair words one entry ahead: in the steady state
+  // nothing of an entry's prologue waits for memory -- or for LDS, whose queue is kept full by the atomic adds of twelve waves (a
+  // dependent LDS round trip costs ~700 cycles here: an entry table in LDS and a shared entry counter made the prologue as
+  // long as the pair products, in-kernel stamps).
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int4* ent = p.blkEntries + work.z;
+  const int nSteps = work.w / NW;
+  __syncthreads();
+  // operand lanes (A: 16 k + 4 b + i holds row 4 (b >> 1) + i of the slot in I; B: 16 k + 4 b + j holds row 4 (b & 1) + j of the
+  // slot in J, column k of E; k = 3 is the padding of K and reads the zero every staged record ends with) and result lanes
+  // (16 i + 4 b + j)
+  const int kk = lane >> 4, bq = (lane >> 2) & 3, ij = lane & 3;
+  const double* opA = bufA + (kk < 3 ? 8 * kk + 4 * (bq >> 1) + ij : kBlkRec);
+  const double* opB = bufB + (kk < 3 ? 8 * kk + 4 * (bq & 1) + ij : kBlkRec);
+  const int dRow = 4 * (bq >> 1) + kk, dCol = 4 * (bq & 1) + ij;
+  const bool dValid = dRow < 6 && dCol < 6;
+  double* accLane = acc + dRow * 6 + dCol;
+  // the lanes of the A operand that hold E c (rows 6, 7 of the columns 0..2: b = 2, i = 2, 3) and its entry
+  const bool gcLane = kk < 3 && bq == 2 && ij >= 2;
+  const int gcIdx = 2 * kk + (ij - 2);
+  // Everything an entry needs travels in REGISTERS, requested two entries ahead through VECTOR loads: its records (8 bytes per
+  // lane and trip: 16 records of 24 doubles are six trips; staged with a stride of 25 doubles, the 25th a zero), the pose numbers
+  // of its slots in I, and its pair words, one per lane (up to 256: four registers); its descriptor three entries ahead.  Scalar
+  // loads are kept out of the loop on purpose: a scalar load's result is waited for with lgkmcnt(0), which also drains the
+  // wave's LDS operations, and the LDS queue of this kernel is always full -- with the pair words and descriptors on scalar
+  // loads every trip and every entry paid a ~700-cycle drain (in-kernel stamps: the prologue of an entry cost as much as its
+  // pairs).  `vzero` keeps the compiler from turning the wave-uniform loads back into scalar ones.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Pre { double a[6], b[6]; int blkA; unsigned w[4]; };
+  const int4 none = {0, 0, 0, 0};
+  auto loadDesc = [&](int step) __attribute__((always_inline)) -> int4 {
+    return step < nSteps ? ent[wv + NW * step + vzero] : none;
+  };
+  auto fetch = [&](Pre& P, const int4 dv) __attribute__((always_inline)) {
+    const int nA = __builtin_amdgcn_readfirstlane(dv.z & 0xff), nB = __builtin_amdgcn_readfirstlane((dv.z >> 8) & 0xff);
+    const int nQuads = __builtin_amdgcn_readfirstlane(dv.z >> 16);
+    const uint32_t* pwn = p.blkPairs + (size_t)__builtin_amdgcn_readfirstlane(dv.w) + vzero;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (64 * q < 4 * nQuads) P.w[q] = pwn[64 * q + lane];   // (the pair-word array is padded by 256 words)
+    const double* srcA = p.slotRec + (size_t)__builtin_amdgcn_readfirstlane(dv.x) * kBlkRec;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      if (64 * q < nA * kBlkRec) P.a[q] = srcA[min(64 * q + lane, nA * kBlkRec - 1)];   // (wave-uniform branch; the last trip repeats its last element)
+    if (diag) {
+      if (lane < nA) P.blkA = (int)p.slotBlk[__builtin_amdgcn_readfirstlane(dv.x) + lane];
+    } else {
+      const double* srcB = p.slotRec + (size_t)__builtin_amdgcn_readfirstlane(dv.y) * kBlkRec;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (64 * q < nB * kBlkRec) P.b[q] = srcB[min(64 * q + lane, nB * kBlkRec - 1)];
+    }
+  };
+#ifdef SVIN_BLOCKS_TIMING
+  long long bT[5] = {0, 0, 0, 0, 0}, bq0 = __builtin_readcyclecounter(), bq1;
+  int bPairs = 0, bEntries = 0;
+#define BNT(i) do { bq1 = __builtin_readcyclecounter(); bT[i] += bq1 - bq0; bq0 = bq1; } while (0)
+#else
+#define BNT(i) do { } while (0)
+#endif
+  // one entry: its registers -> the wave's LDS buffers, the request for the entry two steps on into the freed registers, then the pairs
+  auto process = [&](Pre& P, const int4 dCur, const int4 dFetch) __attribute__((always_inline)) {
+    const int nA = __builtin_amdgcn_readfirstlane(dCur.z & 0xff), nB = __builtin_amdgcn_readfirstlane((dCur.z >> 8) & 0xff);
+    const int nQuads = __builtin_amdgcn_readfirstlane(dCur.z >> 16);   // pair words come in fours
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      if (64 * q < nA * kBlkRec) {
+        const int i = 64 * q + lane;
+        if (i < nA * kBlkRec) bufA[i + i / kBlkRec] = P.a[q];
+      }
+    if (!diag) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (64 * q < nB * kBlkRec) {
+          const int i = 64 * q + lane;
+          if (i < nB * kBlkRec) bufB[i + i / kBlkRec] = P.b[q];
+        }
+    }
+    const int paL = P.blkA - nPB * pI;
+    const unsigned wr0 = P.w[0], wr1 = P.w[1], wr2 = P.w[2], wr3 = P.w[3];
+    BNT(4);
+    fetch(P, dFetch);
+    BNT(1);
+#ifdef SVIN_BLOCKS_TIMING
+    ++bEntries; bPairs += diag ? nA * (nA + 1) / 2 : nA * nB;
+#endif
+    if (diag) {   // sum_l E_la c_l, once per slot: the operand lanes that hold it
+      for (int ka = 0; ka < nA; ka += 4) {
+        double ev[4];
+        int pa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kq = min(ka + u, nA - 1);
+          ev[u] = opA[kq * kBlkStride];
+          pa[u] = __builtin_amdgcn_readlane(paL, kq);
+        }
+        if (gcLane) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ka + u < nA) atomicAdd(&gcv[6 * pa[u] + gcIdx], ev[u]);
+        }
+      }
+    }
+    // All slot pairs of the entry as ONE sequence of host-built PAIR WORDS (index of the A record | index of the B record << 9 |
+    // index of the 6 x 6 block in `acc` << 18, padded to whole fours with pairs that add into the spare block), eight per trip:
+    // sixteen operand reads, eight products, eight atomic adds, and no control flow or index arithmetic beyond three bit-field
+    // extracts per pair.  (Measured on the way: a (ka, kb) double loop four pairs at a time -- 2.5 useful pairs per trip, 300
+    // cycles per pair and wave; the same walk flattened with its state in scalar registers -- 38 instructions per pair, two of
+    // them quarter-rate v_mul_lo_u32 for a per-lane stride: 370 cycles per pair and wave.)
+    for (int q = 0; q < nQuads; q += 2) {
+      const unsigned wsrc = q < 16 ? wr0 : (q < 32 ? wr1 : (q < 48 ? wr2 : wr3));   // (wave-uniform selects; sixteen quads per register)
+      const int l0 = (4 * q) & 63;
+      unsigned w[kBlkBatch];
+#pragma unroll
+      for (int u = 0; u < kBlkBatch; ++u) w[u] = (unsigned)__builtin_amdgcn_readlane((int)wsrc, l0 + u);
+      const bool two = q + 1 < nQuads;   // (scalar)
+      double av[kBlkBatch], bv[kBlkBatch], dv[kBlkBatch];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = opA[w[u] & 511u]; bv[u] = opB[(w[u] >> 9) & 511u]; }
+      if (two) {
+#pragma unroll
+        for (int u = 4; u < 8; ++u) { av[u] = opA[w[u] & 511u]; bv[u] = opB[(w[u] >> 9) & 511u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dv[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], 0.0, 0, 0, 0);
+      if (two) {
+#pragma unroll
+        for (int u = 4; u < 8; ++u) dv[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], 0.0, 0, 0, 0);
+      }
+      if (dValid) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) atomicAdd(&accLane[w[u] >> 18], dv[u]);
+        if (two) {
+#pragma unroll
+          for (int u = 4; u < 8; ++u) atomicAdd(&accLane[w[u] >> 18], dv[u]);
+        }
+      }
+    }
+    BNT(2);
+  };
+  Pre P0, P1;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { P0.a[q] = P0.b[q] = P1.a[q] = P1.b[q] = 0.0; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { P0.w[q] = P1.w[q] = 0u; }
+  P0.blkA = P1.blkA = 0;
+  int4 dA = loadDesc(0), dB = loadDesc(1), dC = loadDesc(2), dD = loadDesc(3);
+  fetch(P0, dA);
+  fetch(P1, dB);
+  BNT(0);
+  for (int step = 0; step < nSteps; step += 2) {
+    // (dA, dB: the entries in P0, P1; dC, dD: the two after them, whose records are requested as P0 / P1 are consumed)
+    process(P0, dA, dC);
+    const int4 dE = loadDesc(step + 4);
+    if (step + 1 < nSteps) process(P1, dB, dD);
+    const int4 dF = loadDesc(step + 5);
+    dA = dC; dB = dD; dC = dE; dD = dF;
+  }
+  __syncthreads();
+  BNT(3);
+#ifdef SVIN_BLOCKS_TIMING
+  if ((b == 3 || b == 200 || b == 500) && lane == 0 && wave < 2)
+    printf("[blocks block %d (%d, %d) wave %d: %d entries, %d pairs] prologue %lld  wait for the records + LDS writes %lld  fetch issue %lld  pairs %lld  wait for the others %lld\n", b, pI, pJ, wave,
+           bEntries, bPairs, bT[0], bT[4], bT[1], bT[2], bT[3]);
+#endif
+#undef BNT
+  // ---- the slab (row-major 96 x 96 + three vectors, the tile form's layout)
+  double* slab = p.slabs + (size_t)b * kPanelSlab;
+  for (int e = t; e < kPanelRows * kPanelRows; e += 64 * NW) {
+    const int r = e / kPanelRows, c = e - r * kPanelRows;
+    const int pa = r / 6, ra = r - 6 * pa, pb = c / 6, cb = c - 6 * pb;
+    double v;
+    if (diag && pa < pb) v = acc[(pb * nPB + pa) * 36 + cb * 6 + ra];   // (mirror of the block below the diagonal)
+    else v = acc[(pa * nPB + pb) * 36 + ra * 6 + cb];
+    slab[e] = -v;   // S = A - G G^T: the blocks were accumulated with a plus sign
+  }
+  if (t < kPanelRows) {   // diagonal pairs: gRed's share - sum_l E_la c_l (gFull, hC and A come from k_blocks_pose_reduce)
+    double* v = slab + kPanelRows * kPanelRows;
+    v[t] = diag ? -gcv[t] : 0.0; v[kPanelRows + t] = 0.0; v[2 * kPanelRows + t] = 0.0;
+  }
+}
+
 // sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors
 __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
   // 16 entries x 16 partitions of the pair's slabs per workgroup, like k_reduce_slabs (a diagonal pair of a wide window has
@@ -3148,12 +3497,25 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     static_assert(2 * kPanelRows * kDenseLd >= kPanelRows * kDenseLd + 4 * (kPanelRows / 6) * kPoseAcc, "diagonal pairs fit the same allocation");
     // Round 4 (config #4, build of the normal equations 1.01 ms -> 0.67 ms, A/B in one gpurun call): two workgroups per CU instead
     // of one (0.79: 86 spilled registers with the next chunk's first observation prefetched, 0.73 without the prefetch and without
-    // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).  SVIN_PANELS_OLD=1 launches
-    // the round-3 form (one workgroup per CU, prefetch, every pair recomputing V, b, L^-1) for comparison.
-    const bool oldForm = optOn(kOptPanelsOld);
-    if (oldForm) {
-      ensureDynamicLds((const void*)k_schur_panels<1, true, false>, ldsBytes);
-      hipLaunchKernelGGL((k_schur_panels<1, true, false>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
+    // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).
+    // Round 6: the block-pair form (k_blocks_slots + k_schur_blocks) is the default; pack() decides (DeviceProblem::schurBlocks,
+    // its slot tables) -- SVIN_PANELS_OLD=1 at pack() time keeps the round-4 / 5 tile form, whose work list holds fewer chunks per
+    // workgroup.
+    if (p.schurBlocks) {
+      constexpr int NW = kBlkWaves;
+      const size_t ldsBlk = ((size_t)(kBlkPanelPoses * kBlkPanelPoses + 1) * 36 + (size_t)NW * 2 * kBlkBuf + kPanelRows) * 8;
+      // the landmark pass keeps up to four copies of its per-pose accumulators (one per 16-lane group of a wave: the four landmarks a
+      // wave works on see the same poses, and four lanes adding to one address serialise) -- as many as 64 KB hold
+      int nCopies = 4;
+      while (nCopies > 1 && (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8 > 64 * 1024) nCopies >>= 1;
+      const size_t ldsLm = (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8;
+      const int nSlotBlocks = (p.nSlots + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup;
+      hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
+      ensureDynamicLds((const void*)k_blocks_slots, ldsLm);
+      if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_slots, dim3(nSlotBlocks), dim3(256), ldsLm, s, p, nCopies);
+      ensureDynamicLds((const void*)k_schur_blocks<NW>, ldsBlk);
+      if (p.nPanelBlocks > 0) hipLaunchKernelGGL((k_schur_blocks<NW>), dim3(p.nPanelBlocks), dim3(64 * NW), ldsBlk, s, p);
+      if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_pose_reduce, dim3(dC / 6), dim3(1024), 0, s, p, nSlotBlocks);
     } else {
       hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
       ensureDynamicLds((const void*)k_schur_panels<2, false, true>, ldsBytes);
@@ -6023,6 +6385,7 @@ static void checkSolverLaunches() {
 }
 static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize);
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
+  (void)hipGetLastError();   // (a polling hipEventQuery / hipStreamQuery of another library -- RCCL -- leaves hipErrorNotReady behind: not ours)
   launchSolveReducedUnchecked(p, s, mu, initScale, fuseFinalize);
   checkSolverLaunches();
 }

@@ -114,6 +114,11 @@ constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGather = 16, kScalGatherSlo
 #define SVIN_PANEL_CHUNKS 8
 #endif
 constexpr int kPanelChunksPerBlock = SVIN_PANEL_CHUNKS;
+// block-pair form (round 6): entries (landmark x panel pair) per workgroup of k_schur_blocks
+constexpr int kBlkEntriesPerBlock = 256;
+constexpr int kBlkWaves = 12;               // waves of a k_schur_blocks workgroup (one workgroup per CU: 152 KB of LDS); the host deals the entries to them
+constexpr int kBlkSlotsPerWorkgroup = 1024;   // slots (one thread each, four trips) per workgroup of k_blocks_slots
+constexpr int kBlkMaxPoseBlocks = 512;      // the per-pose accumulators of k_blocks_slots live in LDS (28 doubles per pose block)
 
 struct DeviceProblem {
   // sizes
@@ -134,6 +139,19 @@ struct DeviceProblem {
   const int4* panelWork;                     // per workgroup: panel I, panel J, first chunk entry, chunk count
   const int* panelChunks;                    // chunk ids (16 landmarks each) of the work list
   const int* panelPairPtr;                   // per panel pair: first workgroup (nPanelPairs + 1 entries)
+  // wide window, block-pair form (round 6: k_blocks_slots / k_schur_blocks): a SLOT is a (landmark, distinct variable pose) pair
+  int schurBlocks, nSlots;                   // 1: the panel work list is processed by k_schur_blocks (0: the tile form k_schur_panels)
+  const int* slotPtr;                        // per landmark: first slot (L + 1 entries); a landmark's slots ascend with the pose
+  const unsigned short* slotBlk;             // per slot: pose block of the reduced camera system (poseOff / 6)
+  const int* slotObsPtr;                     // per slot: its observations (nSlots + 1 entries into slotObs)
+  const int* slotObs;                        // observation numbers
+  const int* slotLm;                         // per slot: its landmark
+  double* slotRec;                           // per slot 24 doubles, written once per build: E = (sum Jp^T Jl) L^-T and E c (kernels.hip)
+  const int4* blkEntries;                    // work list of k_schur_blocks (panelWork.z / .w index it): per (panel pair, landmark with
+                                             // slots in both panels) first slot in I, first slot in J, count in I | count in J << 8 |
+                                             // trips << 16, first pair word
+  const uint32_t* blkPairs;                  // pair words, eight per trip: 25 ka | 25 kb << 9 | 36 (16 pa + pb) << 18 (kernels.hip)
+  double* blkPartial;                        // per workgroup of k_blocks_slots: (dC / 6) x 28 sums of Jp^T Jp (21) and Jp^T r (6)
   double *obsUv, *obsW;
   uint32_t* obsIdx;
   int dCPose, aBlocks;   // rows of the variable poses in the reduced camera system; dense Schur: A accumulated block-wise in LDS

@@ -2,6 +2,7 @@
 // /root/reference/okvis_ros/okvis/okvis_ceres/src/Estimator.cpp unless another file is named.
 #include "window.hpp"
 #include "trust_region.hpp"
+#include <array>
 #include <atomic>
 #include <cstdint>
 #include <algorithm>
@@ -1753,7 +1754,110 @@ void Window::pack(bool solveFollows) {
   const bool schurPanels = !schurDense && !anyExtVar && dC > 0 && L > 0 && !optOn(kOptSchurPairwise);
   std::vector<int> hPanelWork, hPanelChunks, hPanelPairPtr;
   int nPanelBlocks = 0, nPanelPairs = 0;
-  if (schurPanels) {
+  // Round 6: the block-pair form (k_schur_blocks) is what runs unless SVIN_PANELS_OLD keeps the tile form (k_schur_panels).  Its
+  // SLOTS -- one per (landmark, distinct variable pose), ascending with the pose inside a landmark, each with the list of its
+  // observations (two for a stereo pair) -- are structure, built here once per pack(); k_blocks_slots writes a 24-double record
+  // per slot and build.  A pose block index has to fit 16 bits.
+  const bool schurBlocks = schurPanels && !optOn(kOptPanelsOld) && dC / 6 <= kBlkMaxPoseBlocks;
+  std::vector<uint32_t> hPairWords;
+  std::vector<int> hSlotPtr, hSlotObsPtr, hSlotObs, hSlotLm, hEntries;   // (staged uploads copy from these when the block is flushed: they live to the end of pack())
+  std::vector<unsigned short> hSlotBlk;
+  if (schurBlocks) {
+    hSlotPtr.resize((size_t)L + 1); hSlotObs.reserve(N); hSlotBlk.reserve(N); hSlotObsPtr.reserve((size_t)N + 1);
+    std::vector<std::pair<int, int>> seen;   // (pose block, observation) of one landmark
+    for (int l = 0; l < L; ++l) {
+      hSlotPtr[l] = (int)hSlotBlk.size();
+      seen.clear();
+      for (int o = hLmPtr[l]; o < hLmPtr[l + 1]; ++o) {
+        const int off = hPoseOff[hIdx[o] & 0xfff];
+        if (off >= 0) seen.emplace_back(off / 6, o);
+      }
+      std::stable_sort(seen.begin(), seen.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+      for (size_t k = 0; k < seen.size(); ++k) {
+        if (k == 0 || seen[k].first != seen[k - 1].first) { hSlotBlk.push_back((unsigned short)seen[k].first); hSlotObsPtr.push_back((int)hSlotObs.size()); hSlotLm.push_back(l); }
+        hSlotObs.push_back(seen[k].second);
+      }
+    }
+    hSlotPtr[L] = (int)hSlotBlk.size();
+    hSlotObsPtr.push_back((int)hSlotObs.size());
+    upload(dSlotPtr_, hSlotPtr, s); upload(dSlotBlk_, hSlotBlk, s); upload(dSlotObsPtr_, hSlotObsPtr, s); upload(dSlotObs_, hSlotObs, s);
+    upload(dSlotLm_, hSlotLm, s);
+    dSlotRec_.reserve(std::max<size_t>(hSlotBlk.size() * 24, 1));
+    dBlkPartial_.reserve(std::max<size_t>(((hSlotBlk.size() + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup) * (size_t)(dC / 6) * 28, 1));
+    // work list: per panel pair (I >= J; a panel is 16 pose blocks = 96 rows) the landmarks with slots in both panels, as ENTRIES
+    // (first slot and count in either panel -- the slots of a panel are a run, they ascend with the pose), cut into workgroups of
+    // kBlkEntriesPerBlock; the pairs in the order k_reduce_panel_slabs expects (panelPairPtr)
+    const int nPan = (dC + 95) / 96;
+    nPanelPairs = nPan * (nPan + 1) / 2;
+    std::vector<std::vector<int>> lists(nPanelPairs);   // four ints per entry: first slot in I, in J, counts, landmark
+    std::vector<int> runPanel, runFirst, runCount;
+    for (int l = 0; l < L; ++l) {
+      runPanel.clear(); runFirst.clear(); runCount.clear();
+      for (int sl = hSlotPtr[l]; sl < hSlotPtr[l + 1]; ++sl) {
+        const int pan = hSlotBlk[sl] / 16;
+        if (runPanel.empty() || runPanel.back() != pan) { runPanel.push_back(pan); runFirst.push_back(sl); runCount.push_back(1); }
+        else ++runCount.back();
+      }
+      for (size_t a = 0; a < runPanel.size(); ++a)
+        for (size_t b = 0; b <= a; ++b) {
+          std::vector<int>& li = lists[runPanel[a] * (runPanel[a] + 1) / 2 + runPanel[b]];
+          li.insert(li.end(), {runFirst[a], runFirst[b], runCount[a] | (runCount[b] << 8), l});
+        }
+    }
+    // ... and every entry's slot pairs as PAIR WORDS for the kernel's inner loop (25 ka | 25 kb << 9 | 36 (16 pa + pb) << 18: the
+    // indices of the two staged records and of the 6 x 6 block in the workgroup's accumulator image), padded to whole fours
+    // (stored in eights) with pairs that add into the spare block 256; a diagonal pair takes the blocks on and below the block diagonal
+    hPanelPairPtr.push_back(0);
+    for (int I = 0; I < nPan; ++I)
+      for (int J = 0; J <= I; ++J) {
+        const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
+        const size_t nEnt = li.size() / 4;
+        for (size_t k = 0; k < nEnt; k += kBlkEntriesPerBlock) {
+          const int cnt = (int)std::min<size_t>(kBlkEntriesPerBlock, nEnt - k);
+          // the workgroup's entries with their pair words ...
+          std::vector<std::array<int, 4>> wgEnt(cnt);
+          for (size_t e = k; e < k + cnt; ++e) {
+            const int fa = li[4 * e], fb = li[4 * e + 1], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
+            const size_t first = hPairWords.size();
+            for (int ka = 0; ka < nA; ++ka)
+              for (int kb = 0; kb < (I == J ? ka + 1 : nB); ++kb) {
+                const int pa = hSlotBlk[fa + ka] - 16 * I, pb = hSlotBlk[fb + kb] - 16 * J;
+                hPairWords.push_back((uint32_t)(25 * ka) | ((uint32_t)(25 * kb) << 9) | ((uint32_t)(36 * (16 * pa + pb)) << 18));
+              }
+            const int nQuads = (int)((hPairWords.size() - first + 3) / 4);   // the kernel works in fours (two per trip) and loads in eights
+            while ((hPairWords.size() - first) % 8) hPairWords.push_back((uint32_t)(36 * 256) << 18);
+            wgEnt[e - k] = {fa, fb, nA | (nB << 8) | (nQuads << 16), (int)first};
+          }
+          // ... dealt to the kBlkWaves waves longest first (each to the wave with the least work so far; an entry costs its pair
+          // quads plus a prologue worth about two), the waves' sequences interleaved and padded to equal length with empty entries
+          std::vector<int> order(cnt);
+          for (int e = 0; e < cnt; ++e) order[e] = e;
+          std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (wgEnt[a][2] >> 16) > (wgEnt[b][2] >> 16); });
+          std::vector<std::vector<int>> perWave(kBlkWaves);
+          std::vector<long> load(kBlkWaves, 0);
+          for (int e : order) {
+            const int wmin = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            perWave[wmin].push_back(e);
+            load[wmin] += (wgEnt[e][2] >> 16) + 2;
+          }
+          size_t steps = 0;
+          for (const auto& pwv : perWave) steps = std::max(steps, pwv.size());
+          hPanelWork.insert(hPanelWork.end(), {I, J, (int)(hEntries.size() / 4), (int)(steps * kBlkWaves)});
+          for (size_t st = 0; st < steps; ++st)
+            for (int wv = 0; wv < kBlkWaves; ++wv) {
+              if (st < perWave[wv].size()) { const auto& en = wgEnt[perWave[wv][st]]; hEntries.insert(hEntries.end(), en.begin(), en.end()); }
+              else hEntries.insert(hEntries.end(), {0, 0, 0, 0});
+            }
+          ++nPanelBlocks;
+        }
+        hPanelPairPtr.push_back(nPanelBlocks);
+      }
+    hPairWords.resize(hPairWords.size() + 256, 0u);   // (a wave requests an entry's words in 64s)
+    upload(dBlkPairs_, hPairWords, s);
+    upload(dPanelWork_, hPanelWork, s); upload(dPanelChunks_, hEntries, s); upload(dPanelPairPtr_, hPanelPairPtr, s);
+    dSlabs_.reserve(std::max<size_t>((size_t)nPanelBlocks * (96 * 96 + 3 * 96), 1));
+  }
+  if (schurPanels && !schurBlocks) {
     constexpr int kRows = 96, kChunk = 16, kPerBlock = kPanelChunksPerBlock;
     const int nPan = (dC + kRows - 1) / kRows;
     nPanelPairs = nPan * (nPan + 1) / 2;
@@ -1786,7 +1890,7 @@ void Window::pack(bool solveFollows) {
       }
     upload(dPanelWork_, hPanelWork, s); upload(dPanelChunks_, hPanelChunks, s); upload(dPanelPairPtr_, hPanelPairPtr, s);
     dSlabs_.reserve(std::max<size_t>((size_t)nPanelBlocks * (kRows * kRows + 3 * kRows), 1));
-  } else {
+  } else if (!schurPanels) {
     dSlabs_.reserve(std::max<size_t>(slabSize * nSlabs, 1));
   }
 
@@ -1827,6 +1931,9 @@ void Window::pack(bool solveFollows) {
   p.cams = dCams_.p;
   p.schurDense = schurDense ? 1 : 0;
   p.schurPanels = schurPanels ? 1 : 0; p.nPanelBlocks = nPanelBlocks; p.nPanelPairs = nPanelPairs;
+  p.schurBlocks = schurBlocks ? 1 : 0; p.nSlots = (int)hSlotBlk.size();
+  p.slotPtr = dSlotPtr_.p; p.slotBlk = dSlotBlk_.p; p.slotObsPtr = dSlotObsPtr_.p; p.slotObs = dSlotObs_.p; p.slotLm = dSlotLm_.p; p.slotRec = dSlotRec_.p;
+  p.blkEntries = reinterpret_cast<const int4*>(dPanelChunks_.p); p.blkPartial = dBlkPartial_.p; p.blkPairs = dBlkPairs_.p;
   p.panelWork = reinterpret_cast<const int4*>(dPanelWork_.p); p.panelChunks = dPanelChunks_.p; p.panelPairPtr = dPanelPairPtr_.p;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
   if (resident) { p.lmPtr = res_.lmPtr[res_.cur].p; p.obsUv = res_.uv[res_.cur].p; p.obsW = res_.w[res_.cur].p; p.obsLm = res_.obsLm[res_.cur].p; }

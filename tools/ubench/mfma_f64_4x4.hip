@@ -74,6 +74,18 @@ __global__ void k_lds(double* out, long long* cyc, int n, int nSlots, const doub
         atomicAdd(sm + ((slot + 1) & (nSlots - 1)) * 64 + lane, c[1]);
         atomicAdd(sm + ((slot + 2) & (nSlots - 1)) * 64 + lane, c[2]);
         atomicAdd(sm + ((slot + 3) & (nSlots - 1)) * 64 + lane, c[3]);
+      } else if (MODE == 5) {   // the Schur kernel's add: 36 valid result lanes, 6 x 6 block of 36 consecutive doubles
+        const int kk = lane >> 4, bq = (lane >> 2) & 3, ij = lane & 3;
+        const int dRow = 4 * (bq >> 1) + kk, dCol = 4 * (bq & 1) + ij;
+        if (dRow < 6 && dCol < 6) atomicAdd(sm + ((5 * i + 11 * u + 3 * wave) & 63) * 36 + dRow * 6 + dCol, a);
+      } else if (MODE == 6) {   // the same 36 lanes, lane l -> double l of the block (no bank shared by two lanes beyond the 32nd)
+        if (lane < 36) atomicAdd(sm + ((5 * i + 11 * u + 3 * wave) & 63) * 36 + lane, a);
+      } else if (MODE == 7) {   // 32 lanes only
+        if (lane < 32) atomicAdd(sm + ((5 * i + 11 * u + 3 * wave) & 63) * 36 + lane, a);
+      } else if (MODE == 8) {   // the Schur kernel's operand read: 24 distinct doubles of a record + a zero, by 64 lanes
+        const int kk = lane >> 4, bq = (lane >> 2) & 3, ij = lane & 3;
+        const int off = kk < 3 ? 8 * kk + 4 * (bq >> 1) + ij : 24;
+        keep += ops[((3 * i + 7 * u + wave) & 63) * 25 + off];
       } else {   // 4: operand from global memory (L2-resident table), product, ds_add
         const double bo = gops[(size_t)(((5 * i + u) * 37 + 11 * wave + 64 * blockIdx.x) & 16383) * 64 + lane];
         const double c = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bo, 0.0, 0, 0, 0);
@@ -110,7 +122,7 @@ int main() {
     printf("%-62s %8.1f cycles per op and wave (%lld cycles, %.3f ms, %d waves x %d blocks)\n", what, (double)c / opsPerWave, c, ms, waves, blocks);
   };
   for (int rep = 0; rep < 2; ++rep) {
-    for (int threads : {64, 256, 512, 1024}) {
+    for (int threads : {64, 512, 768, 1024}) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       float ms; long long h;
 #define RUN(K, label, opsPerIter, blocks, shm, ...) \
@@ -127,6 +139,10 @@ int main() {
       RUN((k_lds<2>), "ds_read operand + 4x4x4_4b + ds_add_f64", 8, 1, shm, out, cyc, n, nSlots, gops)
       RUN((k_lds<3>), "ds_read operand + 16x16x4 + 4 x ds_add_f64", 8, 1, shm, out, cyc, n, nSlots, gops)
       RUN((k_lds<2>), "ds_read operand + 4x4x4_4b + ds_add_f64, 256 blocks", 8, 256, shm, out, cyc, n, nSlots, gops)
+      RUN((k_lds<5>), "ds_add_f64, 36 result lanes of a 6 x 6 block (the kernel's map)", 8, 1, shm, out, cyc, n, nSlots, gops)
+      RUN((k_lds<6>), "ds_add_f64, 36 lanes, lane l -> double l", 8, 1, shm, out, cyc, n, nSlots, gops)
+      RUN((k_lds<7>), "ds_add_f64, 32 lanes, lane l -> double l", 8, 1, shm, out, cyc, n, nSlots, gops)
+      RUN((k_lds<8>), "ds_read_b64 operand pattern (24 doubles + zero, broadcast)", 8, 1, shm, out, cyc, n, nSlots, gops)
       RUN((k_lds<4>), "global (8 MB table) operand + 4x4x4_4b + ds_add_f64, 256 blocks", 8, 256, shm, out, cyc, n, nSlots, gops)
       RUN((k_lds<4>), "global (8 MB table) operand + 4x4x4_4b + ds_add_f64, 512 blocks", 8, 512, shm, out, cyc, n, nSlots, gops)
     }

@@ -6,12 +6,16 @@ import numpy as np
 from svin_amd import synthetic as syn
 from svin_amd.estimator import Estimator
 
-P, L, N = (int(a) for a in (sys.argv[1:4] if len(sys.argv) >= 4 else (64, 50000, 500000)))
+OLD = "--old" in sys.argv      # the round-5 tile form of the Schur complement (k_schur_panels) instead of the block-pair form
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+P, L, N = (int(a) for a in (argv[0:3] if len(argv) >= 3 else (64, 50000, 500000)))
 # SVIN_WIDE_BENCH=1: the window of bench.py's config4 records (seed 20250629, frames 0.25 s apart: more co-visibility, denser S)
 BENCH = os.environ.get("SVIN_WIDE_BENCH") == "1"
 t0 = time.perf_counter()
 spec = syn.make_window(P=P, L=L, n_obs=N, seed=20250629, frame_dt=0.25) if BENCH else syn.make_window(P=P, L=L, n_obs=N, seed=11, rig="euroc")
 print("synthetic window built in %.1f s: P %d L %d N %d" % (time.perf_counter() - t0, spec.P, spec.L, spec.N), flush=True)
+if OLD:
+    Estimator.debug_set_option("SVIN_PANELS_OLD", 1)
 est = Estimator(0)
 t0 = time.perf_counter()
 syn.feed(est, spec)
