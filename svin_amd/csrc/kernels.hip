@@ -2950,23 +2950,32 @@ __global__ __launch_bounds__(256, kWavesPerSimd) void k_schur_panels(DeviceProbl
 //    directions, rows 6, 7 of the three columns the six entries of E_la c_l -- and the slot's share of its pose's block of A and of
 //    Jp^T r (27 numbers), added to the workgroup's per-pose accumulators in LDS (ds_add_f64) and written out as one partial per
 //    workgroup; k_blocks_pose_reduce sums the partials into S, gFull, gRed, hC.
-//  * k_schur_blocks: one workgroup per panel pair (I, J) and list of up to 256 ENTRIES (a landmark with slots in both panels:
-//    first slot and count in either), a WAVE per entry: the records of the entry's slots in panel I and in panel J (at most 16
-//    each: a panel is 16 poses) are staged in the wave's own LDS buffers -- requested one entry ahead, the work list itself sits
-//    in LDS, so no global round trip is exposed -- and every slot pair is ONE v_mfma_f64_4x4x4_4b_f64: its four independent
-//    4 x 4 x 4 blocks are the four quadrants of the 8 x 8 padding of a 6 x 6 block product with K = 3 padded to 4 (operand /
-//    result lane layout measured with tools/ubench/mfma_f64_4x4.hip: A lane 16 k + 4 b + i, B lane 16 k + 4 b + j, D lane
-//    16 i + 4 b + j; 16 cycles per instruction = the 16x16x4 form's flop rate).  512 executed flops per 216 algorithmic ones,
-//    whatever the landmarks see.  The 36 valid results go into the pair's 16 x 16 blocks of 6 x 6 in LDS with ds_add_f64 (8 cycles
-//    per instruction and CU); no workgroup barrier between the clear and the flush -- waves never wait for each other.  Diagonal
-//    pairs collect sum_l E_la c_l from the operand lanes that hold it.  The slab a workgroup writes has the tile form's layout:
-//    k_reduce_panel_slabs is unchanged.
-constexpr int kBlkRec = 24;                      // doubles per slot record
+//  * k_schur_rows: one workgroup (eight waves, two workgroups per CU) per panel pair (I, J) and list of up to 256 ENTRIES (a
+//    landmark with slots in both panels), worked through in BATCHES of up to 360 records: the records of the batch's slots are
+//    staged in LDS by all threads (stride 26 doubles: 24, a zero -- the K = 3 padding of every operand -- and a pad), then every
+//    slot pair is ONE v_mfma_f64_4x4x4_4b_f64: its four independent 4 x 4 x 4 blocks are the four quadrants of the 8 x 8 padding
+//    of a 6 x 6 block product with K = 3 padded to 4 (operand / result lane layout measured with tools/ubench/mfma_f64_4x4.hip:
+//    A lane 16 k + 4 b + i, B lane 16 k + 4 b + j, D lane 16 i + 4 b + j; 16 cycles per instruction = the 16x16x4 form's flop
+//    rate).  512 executed flops per 216 algorithmic ones, whatever the landmarks see.  The 6 x 6 blocks of the pair ACCUMULATE IN
+//    REGISTERS: a wave owns two of the sixteen block rows (the host deals the rows by their pair counts), i.e. 32 accumulators
+//    of two VGPRs, and its pairs arrive as host-built PAIR WORDS (A record | B record << 9 | pose block in J << 18 | "new A" << 24)
+//    sorted by row and A record: B is read for every pair, A once per run, the accumulator is picked through the VGPR index
+//    register.  No
+//    atomics, no accumulator image in LDS, a fixed summation order (the result is bit-reproducible), one barrier pair per batch;
+//    the second workgroup of the CU computes while this one waits for its records.  Diagonal pairs collect sum_l E_la c_l from
+//    the operand lanes that hold it.  At the end the accumulators go through LDS into the slab, which has the tile form's
+//    layout: k_reduce_panel_slabs is unchanged.
+//    (Measured on the way, profiles/r06_schur_blocks_history.txt: accumulators as an LDS image fed by ds_add_f64, a wave per
+//    entry with private staging buffers -- 582 us with four dependent global round trips per entry, 399 with the work list in LDS
+//    and a register prefetch, 234-275 with pair words: bound by the LDS, whose ds_add_f64 takes 8 cycles per instruction whatever
+//    the number of active lanes and whose queue, kept full by twelve waves, turned every dependent LDS or scalar-memory wait of an
+//    entry's prologue into ~700 cycles.)
 constexpr int kBlkPanelPoses = kPanelRows / 6;   // 16
-constexpr int kBlkStride = kBlkRec + 1;          // ... staged in LDS with a zero behind them: the K = 3 padding of every operand
-constexpr int kBlkBuf = kBlkPanelPoses * kBlkStride;    // a wave's staging buffer: 16 records
-constexpr int kBlkBatch = 8;                     // slot pairs per trip of k_schur_blocks
-constexpr int kBlkPoseLd = 29;                   // per pose block of the landmark pass's accumulators: odd, so that the sixteen slots of a landmark hit different banks
+constexpr int kBlkRecChunks = kBlkRec / 2;       // 16-byte pieces of a slot record (9)
+constexpr int kBlkStride = 20;                   // doubles per record staged in LDS: 18, then a pair nothing ever writes (zero: the K = 3 padding of every operand)
+constexpr int kBlkStrideChunks = kBlkStride / 2;
+constexpr int kBlkPoseLd = 35;                   // per pose block of the slot pass's accumulators: odd, so that the sixteen slots of a landmark hit different banks
+constexpr int kBlkPart = 34;                     // doubles per pose block of a partial: 21 (A) + 6 (Jp^T r) + 6 (sum E c) + pad
 
 // one THREAD per slot, 1024 slots per workgroup (k_panels_landmarks has left L_l^-1 and c_l in lmFactor): W = sum over the slot's
 // observations of Jp^T Jl (6 x 3), E = W L^-T, E c -> the slot's record; the pose's share of A and Jp^T r -> the workgroup's
@@ -3025,11 +3034,14 @@ __global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopi
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const double e0 = W[a][0] * i00, e1 = W[a][0] * i10 + W[a][1] * i11, e2 = W[a][0] * i20 + W[a][1] * i21 + W[a][2] * i22;
-      rec[a] = e0; rec[8 + a] = e1; rec[16 + a] = e2;
+      rec[a] = e0; rec[6 + a] = e1; rec[12 + a] = e2;
       ec[a] = e0 * cv0 + e1 * cv1 + e2 * cv2;
     }
-    rec[6] = ec[0]; rec[7] = ec[1]; rec[14] = ec[2]; rec[15] = ec[3]; rec[22] = ec[4]; rec[23] = ec[5];
-    double2* out = reinterpret_cast<double2*>(p.slotRec + (size_t)sl * kBlkRec);   // (records are 192 bytes: 16-byte aligned)
+#ifndef SVIN_SLOTS_NOATOM
+#pragma unroll
+    for (int a = 0; a < 6; ++a) atomicAdd(&ap[27 + a], ec[a]);   // sum_l E_la c_l: the reduced gradient's share
+#endif
+    double2* out = reinterpret_cast<double2*>(p.slotRec + (size_t)sl * kBlkRec);   // (records are 144 bytes: 16-byte aligned)
 #ifndef SVIN_SLOTS_NOSTORE
 #pragma unroll
     for (int q = 0; q < kBlkRec / 2; ++q) out[q] = double2{rec[2 * q], rec[2 * q + 1]};
@@ -3038,11 +3050,11 @@ __global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopi
 #endif
   }
   __syncthreads();
-  double* part = p.blkPartial + (size_t)blockIdx.x * nBlk * kPoseAcc;
-  for (int i = t; i < nBlk * kPoseAcc; i += 256) {
-    const int blk = i / kPoseAcc, e = i - blk * kPoseAcc;
+  double* part = p.blkPartial + (size_t)blockIdx.x * nBlk * kBlkPart;
+  for (int i = t; i < nBlk * kBlkPart; i += 256) {
+    const int blk = i / kBlkPart, e = i - blk * kBlkPart;
     double v = 0;
-    if (e < 27)
+    if (e < 33)
       for (int c = 0; c < nCopies; ++c) v += sA[((size_t)c * nBlk + blk) * kBlkPoseLd + e];
     part[i] = v;
   }
@@ -3052,24 +3064,24 @@ __global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopi
 // 32 lanes per partition of the partials (fixed order: deterministic)
 __global__ __launch_bounds__(1024) void k_blocks_pose_reduce(DeviceProblem p, int nPartials) {
   __shared__ double part[1024];
-  const int t = threadIdx.x, e = t & 31, q = t >> 5, blk = blockIdx.x;
+  const int t = threadIdx.x, e = t & 63, q = t >> 6, blk = blockIdx.x;
   const int nBlk = p.dC / 6;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  if (e < kPoseAcc) {
-    const int per = (nPartials + 31) / 32;
+  if (e < kBlkPart) {
+    const int per = (nPartials + 15) / 16;
     const int k1 = min(nPartials, (q + 1) * per);
-    const double* src = p.blkPartial + (size_t)blk * kPoseAcc + e;
-    const size_t stride = (size_t)nBlk * kPoseAcc;
+    const double* src = p.blkPartial + (size_t)blk * kBlkPart + e;
+    const size_t stride = (size_t)nBlk * kBlkPart;
     int k = q * per;
     for (; k + 3 < k1; k += 4) { s0 += src[k * stride]; s1 += src[(k + 1) * stride]; s2 += src[(k + 2) * stride]; s3 += src[(k + 3) * stride]; }
     for (; k < k1; ++k) s0 += src[k * stride];
   }
   part[t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (q != 0 || e >= 27) return;
+  if (q != 0 || e >= 33) return;
   double v = 0;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) v += part[32 * k + e];
+  for (int k = 0; k < 16; ++k) v += part[64 * k + e];
   if (e < 21) {
     int a = 0;
     while (sym6(a + 1, a + 1) <= e) ++a;   // row of the upper-triangle entry
@@ -3078,214 +3090,216 @@ __global__ __launch_bounds__(1024) void k_blocks_pose_reduce(DeviceProblem p, in
     p.S[(size_t)r0 * p.ldS + c0] += v;
     if (a != c) p.S[(size_t)c0 * p.ldS + r0] += v;
     else p.hC[r0] += v;
-  } else {
+  } else if (e < 27) {
     const int r0 = 6 * blk + (e - 21);
     p.gFull[r0] += v; p.gRed[r0] += v;
+  } else {
+    p.gRed[6 * blk + (e - 27)] -= v;   // gRed = Jp^T r - sum_l E_la c_l
   }
 }
 
+typedef double d16_t __attribute__((ext_vector_type(16)));
+// Four pair words of one block row: words 0 / 1 share their A record, so do words 2 / 3 (the host pads every run of an A record to
+// an even length).  Six operand reads, then four products, each into the accumulator its word names: the VGPR INDEX MODE reaches
+// the C / D operands of v_mfma_f64_4x4x4_4b_f64 (tools/ubench/mfma_gpridx.hip: results right, also for back-to-back products into
+// one accumulator with five wait states between them; 4.2 cycles per pair and CU with 16 waves, against 6.2 for the indexed
+// moves the compiler puts around the product).  The accumulators of a row are pinned to the registers the text names; the index
+// mode writes M0, which the compiler uses for the LDS-DMA base: saved and restored.  Words 0 / 1 (and 2 / 3) never meet in an
+// accumulator (one landmark, two poses; a padding word names the next one), words 1 / 2 may: wait states between them.  The
+// operand reads are counted by lgkmcnt in order once the scalar loads of the compiler's code have drained (first line).
+#define SVIN_ROWS_QUAD(ACC, TUPLE, FIRST)                                                                                    \
+  do {                                                                                                                       \
+    const unsigned wsrc = q < 64 ? Wc0 : Wc1;   /* (wave-uniform) */                                                          \
+    const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, q & 63), w1 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 1); \
+    const unsigned w2 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 2), w3 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 3); \
+    const unsigned pa0 = oA + (w0 & 511u) * (kBlkStride * 8), pa1 = oA + (w2 & 511u) * (kBlkStride * 8);                     \
+    const unsigned pb0 = oB + ((w0 >> 9) & 511u) * (kBlkStride * 8), pb1 = oB + ((w1 >> 9) & 511u) * (kBlkStride * 8);        \
+    const unsigned pb2 = oB + ((w2 >> 9) & 511u) * (kBlkStride * 8), pb3 = oB + ((w3 >> 9) & 511u) * (kBlkStride * 8);        \
+    const unsigned i0 = (w0 >> 17) & 30u, i1 = (w1 >> 17) & 30u, i2 = (w2 >> 17) & 30u, i3 = (w3 >> 17) & 30u;                 \
+    double ta0, ta1, tb0, tb1, tb2, tb3;                                                                                     \
+    unsigned m0Save;                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+                 "ds_read_b64 %[ta0], %[pa0]\n\t"                                                                            \
+                 "ds_read_b64 %[tb0], %[pb0]\n\t"                                                                            \
+                 "ds_read_b64 %[tb1], %[pb1]\n\t"                                                                            \
+                 "ds_read_b64 %[ta1], %[pa1]\n\t"                                                                            \
+                 "ds_read_b64 %[tb2], %[pb2]\n\t"                                                                            \
+                 "ds_read_b64 %[tb3], %[pb3]\n\t"                                                                            \
+                 "s_mov_b32 %[ms], m0\n\t"                                                                                   \
+                 "s_waitcnt lgkmcnt(4)\n\t"                                                                                  \
+                 "s_set_gpr_idx_on %[i0], 0xc\n\t"                                                                           \
+                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta0], %[tb0], " FIRST "\n\t"                                          \
+                 "s_set_gpr_idx_off\n\t"                                                                                     \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                                  \
+                 "s_set_gpr_idx_on %[i1], 0xc\n\t"                                                                           \
+                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta0], %[tb1], " FIRST "\n\t"                                          \
+                 "s_set_gpr_idx_off\n\t"                                                                                     \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
+                 "s_nop 3\n\t"                                                                                               \
+                 "s_set_gpr_idx_on %[i2], 0xc\n\t"                                                                           \
+                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta1], %[tb2], " FIRST "\n\t"                                          \
+                 "s_set_gpr_idx_off\n\t"                                                                                     \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
+                 "s_set_gpr_idx_on %[i3], 0xc\n\t"                                                                           \
+                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta1], %[tb3], " FIRST "\n\t"                                          \
+                 "s_set_gpr_idx_off\n\t"                                                                                     \
+                 "s_mov_b32 m0, %[ms]\n\t"                                                                                   \
+                 "s_nop 4"                                                                                                   \
+                 : "+{" TUPLE "}"(ACC), [ta0] "=&v"(ta0), [ta1] "=&v"(ta1), [tb0] "=&v"(tb0), [tb1] "=&v"(tb1), [tb2] "=&v"(tb2), \
+                   [tb3] "=&v"(tb3), [ms] "=&s"(m0Save)                                                                      \
+                 : [pa0] "v"(pa0), [pa1] "v"(pa1), [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [i0] "s"(i0), \
+                   [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3));                                                                 \
+  } while (0)
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_schur_blocks(DeviceProblem p) {
-  extern __shared__ double smem[];
+__global__ __launch_bounds__(64 * NW, 4) void k_schur_rows(DeviceProblem p) {
+  extern __shared__ double smem[];   // two record buffers of kBlkBatchRecs x kBlkStride doubles; at the end the 96 x 96 image of the slab
   const int t = threadIdx.x, b = blockIdx.x, wave = t >> 6, lane = t & 63;
-  const int4 work = p.panelWork[b];  // x = I, y = J, z = first entry of blkEntries, w = number of entries
-  const int pI = work.x, pJ = work.y;
+  const int4 work = p.panelWork[b];  // x = I, y = J, z = first batch, w = number of batches
+  const int pI = work.x, pJ = work.y, nb = work.w;
   const bool diag = pI == pJ;
   constexpr int nPB = kBlkPanelPoses;
-  // LDS: the pair's 16 x 16 blocks of 36 (+ a spare one) | per-wave staging buffers (slots in I, slots in J; a diagonal pair uses
-  //      the first) | diagonal pairs: 96 entries of sum E c
-  double* acc = smem;
-  constexpr int accDoubles = (nPB * nPB + 1) * 36;
-  double* bufA = smem + accDoubles + (size_t)wave * 2 * kBlkBuf;
-  double* bufB = diag ? bufA : bufA + kBlkBuf;
-  double* gcv = smem + accDoubles + (size_t)NW * 2 * kBlkBuf;
-  constexpr int ldsDoubles = accDoubles + NW * 2 * kBlkBuf + kPanelRows;   // (even)
-  for (int i = t; i < ldsDoubles / 2; i += 64 * NW) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};
-  // The work list: per wave a sequence of ENTRIES, interleaved (entry NW k + wave is wave's k-th; the host dealt the workgroup's
-  // entries to the waves longest first, so that the waves finish together, and padded the shorter sequences with empty entries):
-  // x = first slot in I, y = first slot in J, z = count in I | count in J << 8 | quads of pair words << 16, w = first pair word.
-  // Descriptors travel through scalar loads two entries ahead, records and first pair words one entry ahead: in the steady state
-  // nothing of an entry's prologue waits for memory -- or for LDS, whose queue is kept full by the atomic adds of twelve waves (a
-  // dependent LDS round trip costs ~700 cycles here: an entry table in LDS and a shared entry counter made the prologue as
-  // long as the pair products, in-kernel stamps).
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int4* ent = p.blkEntries + work.z;
-  const int nSteps = work.w / NW;
-  __syncthreads();
+  constexpr int kBuf = kBlkBatchRecs * kBlkStride;   // doubles per buffer
+  // the two block rows this wave owns (255: none)
+  int row0, row1;
+  {
+    const int4 own = p.blkOwn[b];
+    const unsigned words[4] = {(unsigned)own.x, (unsigned)own.y, (unsigned)own.z, (unsigned)own.w};
+    const unsigned wd = words[wave >> 1] >> (16 * (wave & 1));
+    row0 = (int)(wd & 0xffu); row1 = (int)((wd >> 8) & 0xffu);
+  }
+  // (the zero pair behind every record and the last record of either buffer are never written again)
+  for (int i = t; i < kBuf; i += 64 * NW) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};
   // operand lanes (A: 16 k + 4 b + i holds row 4 (b >> 1) + i of the slot in I; B: 16 k + 4 b + j holds row 4 (b & 1) + j of the
-  // slot in J, column k of E; k = 3 is the padding of K and reads the zero every staged record ends with) and result lanes
-  // (16 i + 4 b + j)
+  // slot in J, column k of E; k = 3 is the padding of K and reads the zero pair; rows 6 and 7 read what follows the column --
+  // finite numbers that only reach rows / columns 6 and 7 of the result, which nobody stores) and result lanes (16 i + 4 b + j)
   const int kk = lane >> 4, bq = (lane >> 2) & 3, ij = lane & 3;
-  const double* opA = bufA + (kk < 3 ? 8 * kk + 4 * (bq >> 1) + ij : kBlkRec);
-  const double* opB = bufB + (kk < 3 ? 8 * kk + 4 * (bq & 1) + ij : kBlkRec);
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) double*)smem;
+  const unsigned opA = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq >> 1) + ij : kBlkRec);
+  const unsigned opB = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq & 1) + ij : kBlkRec);
   const int dRow = 4 * (bq >> 1) + kk, dCol = 4 * (bq & 1) + ij;
   const bool dValid = dRow < 6 && dCol < 6;
-  double* accLane = acc + dRow * 6 + dCol;
-  // the lanes of the A operand that hold E c (rows 6, 7 of the columns 0..2: b = 2, i = 2, 3) and its entry
-  const bool gcLane = kk < 3 && bq == 2 && ij >= 2;
-  const int gcIdx = 2 * kk + (ij - 2);
-  // Everything an entry needs travels in REGISTERS, requested two entries ahead through VECTOR loads: its records (8 bytes per
-  // lane and trip: 16 records of 24 doubles are six trips; staged with a stride of 25 doubles, the 25th a zero), the pose numbers
-  // of its slots in I, and its pair words, one per lane (up to 256: four registers); its descriptor three entries ahead.  Scalar
-  // loads are kept out of the loop on purpose: a scalar load's result is waited for with lgkmcnt(0), which also drains the
-  // wave's LDS operations, and the LDS queue of this kernel is always full -- with the pair words and descriptors on scalar
-  // loads every trip and every entry paid a ~700-cycle drain (in-kernel stamps: the prologue of an entry cost as much as its
-  // pairs).  `vzero` keeps the compiler from turning the wave-uniform loads back into scalar ones.
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  struct Pre { double a[6], b[6]; int blkA; unsigned w[4]; };
-  const int4 none = {0, 0, 0, 0};
-  auto loadDesc = [&](int step) __attribute__((always_inline)) -> int4 {
-    return step < nSteps ? ent[wv + NW * step + vzero] : none;
-  };
-  auto fetch = [&](Pre& P, const int4 dv) __attribute__((always_inline)) {
-    const int nA = __builtin_amdgcn_readfirstlane(dv.z & 0xff), nB = __builtin_amdgcn_readfirstlane((dv.z >> 8) & 0xff);
-    const int nQuads = __builtin_amdgcn_readfirstlane(dv.z >> 16);
-    const uint32_t* pwn = p.blkPairs + (size_t)__builtin_amdgcn_readfirstlane(dv.w) + vzero;
+  const int dOff = dRow * 6 + dCol;
+  // The accumulators: one 6 x 6 block (in its 8 x 8 padding: one double per lane) per pose block of panel J, for either owned row
+  d16_t acc0, acc1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (64 * q < 4 * nQuads) P.w[q] = pwn[64 * q + lane];   // (the pair-word array is padded by 256 words)
-    const double* srcA = p.slotRec + (size_t)__builtin_amdgcn_readfirstlane(dv.x) * kBlkRec;
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-      if (64 * q < nA * kBlkRec) P.a[q] = srcA[min(64 * q + lane, nA * kBlkRec - 1)];   // (wave-uniform branch; the last trip repeats its last element)
-    if (diag) {
-      if (lane < nA) P.blkA = (int)p.slotBlk[__builtin_amdgcn_readfirstlane(dv.x) + lane];
-    } else {
-      const double* srcB = p.slotRec + (size_t)__builtin_amdgcn_readfirstlane(dv.y) * kBlkRec;
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-        if (64 * q < nB * kBlkRec) P.b[q] = srcB[min(64 * q + lane, nB * kBlkRec - 1)];
-    }
-  };
+  for (int k = 0; k < 16; ++k) { acc0[k] = 0.0; acc1[k] = 0.0; }
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
 #ifdef SVIN_BLOCKS_TIMING
-  long long bT[5] = {0, 0, 0, 0, 0}, bq0 = __builtin_readcyclecounter(), bq1;
-  int bPairs = 0, bEntries = 0;
+  long long bT[4] = {0, 0, 0, 0}, bq0 = __builtin_readcyclecounter(), bq1;
+  int bPairs = 0;
 #define BNT(i) do { bq1 = __builtin_readcyclecounter(); bT[i] += bq1 - bq0; bq0 = bq1; } while (0)
 #else
 #define BNT(i) do { } while (0)
 #endif
-  // one entry: its registers -> the wave's LDS buffers, the request for the entry two steps on into the freed registers, then the pairs
-  auto process = [&](Pre& P, const int4 dCur, const int4 dFetch) __attribute__((always_inline)) {
-    const int nA = __builtin_amdgcn_readfirstlane(dCur.z & 0xff), nB = __builtin_amdgcn_readfirstlane((dCur.z >> 8) & 0xff);
-    const int nQuads = __builtin_amdgcn_readfirstlane(dCur.z >> 16);   // pair words come in fours
+  // Records travel global memory -> LDS on the DMA path (global_load_lds_dwordx4: no registers, no ds_write pass), nine 16-byte
+  // pieces per record into ten slots of the buffer: thread t of trip j owns slot 512 j + t of the buffer, i.e. piece (512 j + t)
+  // % 10 of record (512 j + t) / 10, and stays idle for piece 9.  Two buffers: batch i + 1 streams in while the pairs of batch
+  // i are worked through; the slot numbers of a batch are fetched one batch earlier, its descriptor two batches earlier, its
+  // pair words one batch earlier -- no dependent global round trip inside the loop.
+  constexpr int kTrips = ((kBlkBatchRecs - 1) * kBlkStrideChunks + 64 * NW - 1) / (64 * NW);
+  // (the host pads both tables with three empty batches: the loads below run past the workgroup's last batch unconditionally --
+  // a conditional load merges with a default value, and the copy behind that merge waits for the load where it is issued)
+  auto loadBatch = [&](int bi) __attribute__((always_inline)) -> int2 { return p.blkBatch[work.z + bi]; };
+  auto loadTab = [&](int bi) __attribute__((always_inline)) -> int4 { return p.blkWaveTab[(work.z + bi) * NW + wv]; };
+  int sl[kTrips];   // slot of the record this thread fetches a piece of in trip j of the next batch to be requested; -1: none
+  // (thread number behind an empty asm: what is derived from it is recomputed where it is used -- hoisted out of the batch loop
+  // it was ten more registers than the kernel has, and a spilled address is a scratch load in front of every request)
+  auto loadSlots = [&](int2 bd) __attribute__((always_inline)) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
-      if (64 * q < nA * kBlkRec) {
-        const int i = 64 * q + lane;
-        if (i < nA * kBlkRec) bufA[i + i / kBlkRec] = P.a[q];
-      }
-    if (!diag) {
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-        if (64 * q < nB * kBlkRec) {
-          const int i = 64 * q + lane;
-          if (i < nB * kBlkRec) bufB[i + i / kBlkRec] = P.b[q];
-        }
+    for (int j = 0; j < kTrips; ++j) {
+      const int c = tt + 64 * NW * j, rec = c / kBlkStrideChunks, part = c - rec * kBlkStrideChunks;
+      sl[j] = (rec < bd.y && part < kBlkRecChunks) ? p.blkRecSlot[bd.x + rec] : -1;
     }
-    const int paL = P.blkA - nPB * pI;
-    const unsigned wr0 = P.w[0], wr1 = P.w[1], wr2 = P.w[2], wr3 = P.w[3];
-    BNT(4);
-    fetch(P, dFetch);
+  };
+  auto requestRecords = [&](int buf) __attribute__((always_inline)) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int j = 0; j < kTrips; ++j) {
+      const int c = tt + 64 * NW * j, rec = c / kBlkStrideChunks, part = c - rec * kBlkStrideChunks;
+      if (sl[j] >= 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.slotRec + (size_t)sl[j] * kBlkRec + 2 * part),
+                                         (__attribute__((address_space(3))) void*)(smem + (size_t)buf * kBuf + 2 * (64 * NW * j + 64 * wv)), 16, 0, 0);
+    }
+  };
+  auto loadWords = [&](const int4& wt, unsigned& W0, unsigned& W1) __attribute__((always_inline)) {
+    W0 = 0u; W1 = 0u;
+    if (lane < wt.y + wt.z) W0 = p.blkPairs[wt.x + lane];
+    if (lane + 64 < wt.y + wt.z) W1 = p.blkPairs[wt.x + 64 + lane];
+  };
+  int2 bdA = loadBatch(2);
+  int4 wtC = loadTab(0), wtN = loadTab(1);
+  loadSlots(loadBatch(0));
+  unsigned Wn0, Wn1;
+  loadWords(wtC, Wn0, Wn1);
+  __syncthreads();   // (the buffers are cleared)
+  requestRecords(0);
+  loadSlots(loadBatch(1));
+  for (int bi = 0; bi < nb; ++bi) {
+    // Everything requested so far has arrived (the prefetched values are operands of the statement: the compiler waits for them
+    // here, knows them complete from here on, and puts no wait of its own behind the requests below -- such a wait would cover
+    // the records just requested as well), and every wave is done with the pairs of batch bi - 1 (the other buffer).
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]), "+v"(sl[4]), "+v"(Wn0), "+v"(Wn1), "+v"(bdA.x), "+v"(bdA.y), "+v"(wtN.x),
+                   "+v"(wtN.y), "+v"(wtN.z)
+                 :
+                 : "memory");
+    static_assert(kTrips == 5, "the operand list above names the five trips");
+    __syncthreads();
+    BNT(0);
+    const unsigned Wc0 = Wn0, Wc1 = Wn1;
+    const int n0 = __builtin_amdgcn_readfirstlane(wtC.y), n1 = __builtin_amdgcn_readfirstlane(wtC.z);
+    if (bi + 1 < nb) requestRecords((bi + 1) & 1);
+    loadSlots(bdA);                 // batch bi + 2
+    loadWords(wtN, Wn0, Wn1);       // batch bi + 1
+    wtC = wtN;
+    bdA = loadBatch(bi + 3); wtN = loadTab(bi + 2);
     BNT(1);
 #ifdef SVIN_BLOCKS_TIMING
-    ++bEntries; bPairs += diag ? nA * (nA + 1) / 2 : nA * nB;
+    bPairs += n0 + n1;
 #endif
-    if (diag) {   // sum_l E_la c_l, once per slot: the operand lanes that hold it
-      for (int ka = 0; ka < nA; ka += 4) {
-        double ev[4];
-        int pa[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int kq = min(ka + u, nA - 1);
-          ev[u] = opA[kq * kBlkStride];
-          pa[u] = __builtin_amdgcn_readlane(paL, kq);
-        }
-        if (gcLane) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (ka + u < nA) atomicAdd(&gcv[6 * pa[u] + gcIdx], ev[u]);
-        }
-      }
-    }
-    // All slot pairs of the entry as ONE sequence of host-built PAIR WORDS (index of the A record | index of the B record << 9 |
-    // index of the 6 x 6 block in `acc` << 18, padded to whole fours with pairs that add into the spare block), eight per trip:
-    // sixteen operand reads, eight products, eight atomic adds, and no control flow or index arithmetic beyond three bit-field
-    // extracts per pair.  (Measured on the way: a (ka, kb) double loop four pairs at a time -- 2.5 useful pairs per trip, 300
-    // cycles per pair and wave; the same walk flattened with its state in scalar registers -- 38 instructions per pair, two of
-    // them quarter-rate v_mul_lo_u32 for a per-lane stride: 370 cycles per pair and wave.)
-    for (int q = 0; q < nQuads; q += 2) {
-      const unsigned wsrc = q < 16 ? wr0 : (q < 32 ? wr1 : (q < 48 ? wr2 : wr3));   // (wave-uniform selects; sixteen quads per register)
-      const int l0 = (4 * q) & 63;
-      unsigned w[kBlkBatch];
-#pragma unroll
-      for (int u = 0; u < kBlkBatch; ++u) w[u] = (unsigned)__builtin_amdgcn_readlane((int)wsrc, l0 + u);
-      const bool two = q + 1 < nQuads;   // (scalar)
-      double av[kBlkBatch], bv[kBlkBatch], dv[kBlkBatch];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { av[u] = opA[w[u] & 511u]; bv[u] = opB[(w[u] >> 9) & 511u]; }
-      if (two) {
-#pragma unroll
-        for (int u = 4; u < 8; ++u) { av[u] = opA[w[u] & 511u]; bv[u] = opB[(w[u] >> 9) & 511u]; }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dv[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], 0.0, 0, 0, 0);
-      if (two) {
-#pragma unroll
-        for (int u = 4; u < 8; ++u) dv[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], 0.0, 0, 0, 0);
-      }
-      if (dValid) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) atomicAdd(&accLane[w[u] >> 18], dv[u]);
-        if (two) {
-#pragma unroll
-          for (int u = 4; u < 8; ++u) atomicAdd(&accLane[w[u] >> 18], dv[u]);
-        }
-      }
-    }
+    const unsigned oA = opA + (unsigned)((bi & 1) * kBuf * 8), oB = opB + (unsigned)((bi & 1) * kBuf * 8);
+    for (int q = 0; q < n0; q += 4) SVIN_ROWS_QUAD(acc0, "v[64:95]", "v[64:65]");
+    for (int q = n0; q < n0 + n1; q += 4) SVIN_ROWS_QUAD(acc1, "v[96:127]", "v[96:97]");
     BNT(2);
-  };
-  Pre P0, P1;
-#pragma unroll
-  for (int q = 0; q < 6; ++q) { P0.a[q] = P0.b[q] = P1.a[q] = P1.b[q] = 0.0; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { P0.w[q] = P1.w[q] = 0u; }
-  P0.blkA = P1.blkA = 0;
-  int4 dA = loadDesc(0), dB = loadDesc(1), dC = loadDesc(2), dD = loadDesc(3);
-  fetch(P0, dA);
-  fetch(P1, dB);
-  BNT(0);
-  for (int step = 0; step < nSteps; step += 2) {
-    // (dA, dB: the entries in P0, P1; dC, dD: the two after them, whose records are requested as P0 / P1 are consumed)
-    process(P0, dA, dC);
-    const int4 dE = loadDesc(step + 4);
-    if (step + 1 < nSteps) process(P1, dB, dD);
-    const int4 dF = loadDesc(step + 5);
-    dA = dC; dB = dD; dC = dE; dD = dF;
   }
-  __syncthreads();
-  BNT(3);
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the last products have written their accumulators)
 #ifdef SVIN_BLOCKS_TIMING
-  if ((b == 3 || b == 200 || b == 500) && lane == 0 && wave < 2)
-    printf("[blocks block %d (%d, %d) wave %d: %d entries, %d pairs] prologue %lld  wait for the records + LDS writes %lld  fetch issue %lld  pairs %lld  wait for the others %lld\n", b, pI, pJ, wave,
-           bEntries, bPairs, bT[0], bT[4], bT[1], bT[2], bT[3]);
+  if ((b == 3 || b == 200 || b == 500) && lane == 0 && (wave == 0 || wave == 5))
+    printf("[rows block %d (%d, %d) wave %d: %d batches, %d pair words] wait + barrier %lld  requests %lld  pairs %lld\n", b, pI, pJ, wave,
+           nb, bPairs, bT[0], bT[1], bT[2]);
 #endif
 #undef BNT
-  // ---- the slab (row-major 96 x 96 + three vectors, the tile form's layout)
+  __syncthreads();
+  // ---- the accumulators into an image of the pair's 16 x 16 blocks (36 doubles each), then the slab
+  double* img = smem;
+  for (int i = t; i < nPB * nPB * 36 / 2; i += 64 * NW) reinterpret_cast<double2*>(smem)[i] = double2{0.0, 0.0};
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (row0 < nPB && dValid) img[(row0 * nPB + k) * 36 + dOff] = acc0[k];
+    if (row1 < nPB && dValid) img[(row1 * nPB + k) * 36 + dOff] = acc1[k];
+  }
+  __syncthreads();
   double* slab = p.slabs + (size_t)b * kPanelSlab;
   for (int e = t; e < kPanelRows * kPanelRows; e += 64 * NW) {
     const int r = e / kPanelRows, c = e - r * kPanelRows;
     const int pa = r / 6, ra = r - 6 * pa, pb = c / 6, cb = c - 6 * pb;
     double v;
-    if (diag && pa < pb) v = acc[(pb * nPB + pa) * 36 + cb * 6 + ra];   // (mirror of the block below the diagonal)
-    else v = acc[(pa * nPB + pb) * 36 + ra * 6 + cb];
+    if (diag && pa < pb) v = img[(pb * nPB + pa) * 36 + cb * 6 + ra];   // (mirror of the block below the diagonal)
+    else v = img[(pa * nPB + pb) * 36 + ra * 6 + cb];
     slab[e] = -v;   // S = A - G G^T: the blocks were accumulated with a plus sign
   }
-  if (t < kPanelRows) {   // diagonal pairs: gRed's share - sum_l E_la c_l (gFull, hC and A come from k_blocks_pose_reduce)
+  if (t < kPanelRows) {   // (the vectors -- gRed, gFull, hC -- and the blocks of A come from k_blocks_pose_reduce)
     double* v = slab + kPanelRows * kPanelRows;
-    v[t] = diag ? -gcv[t] : 0.0; v[kPanelRows + t] = 0.0; v[2 * kPanelRows + t] = 0.0;
+    v[t] = 0.0; v[kPanelRows + t] = 0.0; v[2 * kPanelRows + t] = 0.0;
   }
 }
+#undef SVIN_ROWS_QUAD
+
 
 // sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors
 __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
@@ -3498,23 +3512,23 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     // Round 4 (config #4, build of the normal equations 1.01 ms -> 0.67 ms, A/B in one gpurun call): two workgroups per CU instead
     // of one (0.79: 86 spilled registers with the next chunk's first observation prefetched, 0.73 without the prefetch and without
     // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).
-    // Round 6: the block-pair form (k_blocks_slots + k_schur_blocks) is the default; pack() decides (DeviceProblem::schurBlocks,
+    // Round 6: the block-pair form (k_blocks_slots + k_schur_rows) is the default; pack() decides (DeviceProblem::schurBlocks,
     // its slot tables) -- SVIN_PANELS_OLD=1 at pack() time keeps the round-4 / 5 tile form, whose work list holds fewer chunks per
     // workgroup.
     if (p.schurBlocks) {
       constexpr int NW = kBlkWaves;
-      const size_t ldsBlk = ((size_t)(kBlkPanelPoses * kBlkPanelPoses + 1) * 36 + (size_t)NW * 2 * kBlkBuf + kPanelRows) * 8;
-      // the landmark pass keeps up to four copies of its per-pose accumulators (one per 16-lane group of a wave: the four landmarks a
+      const size_t ldsBlk = (size_t)std::max(2 * kBlkBatchRecs * kBlkStride, kBlkPanelPoses * kBlkPanelPoses * 36) * 8;   // (two record buffers / slab image)
+      // the slot pass keeps up to four copies of its per-pose accumulators (one per 16-lane group of a wave: the four landmarks a
       // wave works on see the same poses, and four lanes adding to one address serialise) -- as many as 64 KB hold
       int nCopies = 4;
-      while (nCopies > 1 && (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8 > 64 * 1024) nCopies >>= 1;
+      while (nCopies > 1 && (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8 > 76 * 1024) nCopies >>= 1;
       const size_t ldsLm = (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8;
       const int nSlotBlocks = (p.nSlots + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup;
       hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
       ensureDynamicLds((const void*)k_blocks_slots, ldsLm);
       if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_slots, dim3(nSlotBlocks), dim3(256), ldsLm, s, p, nCopies);
-      ensureDynamicLds((const void*)k_schur_blocks<NW>, ldsBlk);
-      if (p.nPanelBlocks > 0) hipLaunchKernelGGL((k_schur_blocks<NW>), dim3(p.nPanelBlocks), dim3(64 * NW), ldsBlk, s, p);
+      ensureDynamicLds((const void*)k_schur_rows<NW>, ldsBlk);
+      if (p.nPanelBlocks > 0) hipLaunchKernelGGL((k_schur_rows<NW>), dim3(p.nPanelBlocks), dim3(64 * NW), ldsBlk, s, p);
       if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_pose_reduce, dim3(dC / 6), dim3(1024), 0, s, p, nSlotBlocks);
     } else {
       hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);

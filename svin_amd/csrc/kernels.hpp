@@ -114,9 +114,14 @@ constexpr int kScalGroupA = 0, kScalGroupB = 8, kScalGather = 16, kScalGatherSlo
 #define SVIN_PANEL_CHUNKS 8
 #endif
 constexpr int kPanelChunksPerBlock = SVIN_PANEL_CHUNKS;
-// block-pair form (round 6): entries (landmark x panel pair) per workgroup of k_schur_blocks
+// block-pair form (round 6): entries (landmark x panel pair) per workgroup of k_schur_rows, its waves (the host deals the block
+// rows of a panel pair to them), records a batch stages in LDS (x 20 doubles = 160 bytes: two buffers of 36.8 KB, two workgroups
+// per CU; the last record of a buffer is never staged: all zero, the B operand of the padding pairs), pair words per wave and batch
 constexpr int kBlkEntriesPerBlock = 256;
-constexpr int kBlkWaves = 12;               // waves of a k_schur_blocks workgroup (one workgroup per CU: 152 KB of LDS); the host deals the entries to them
+constexpr int kBlkWaves = 8;
+constexpr int kBlkBatchRecs = 230;
+constexpr int kBlkBatchWords = 128;
+constexpr int kBlkRec = 18;                   // doubles per slot record: E_la (6 x 3), rec[6 k + row]
 constexpr int kBlkSlotsPerWorkgroup = 1024;   // slots (one thread each, four trips) per workgroup of k_blocks_slots
 constexpr int kBlkMaxPoseBlocks = 512;      // the per-pose accumulators of k_blocks_slots live in LDS (28 doubles per pose block)
 
@@ -139,18 +144,20 @@ struct DeviceProblem {
   const int4* panelWork;                     // per workgroup: panel I, panel J, first chunk entry, chunk count
   const int* panelChunks;                    // chunk ids (16 landmarks each) of the work list
   const int* panelPairPtr;                   // per panel pair: first workgroup (nPanelPairs + 1 entries)
-  // wide window, block-pair form (round 6: k_blocks_slots / k_schur_blocks): a SLOT is a (landmark, distinct variable pose) pair
-  int schurBlocks, nSlots;                   // 1: the panel work list is processed by k_schur_blocks (0: the tile form k_schur_panels)
+  // wide window, block-pair form (round 6: k_blocks_slots / k_schur_rows): a SLOT is a (landmark, distinct variable pose) pair
+  int schurBlocks, nSlots;                   // 1: the panel work list is processed by k_schur_rows (0: the tile form k_schur_panels)
   const int* slotPtr;                        // per landmark: first slot (L + 1 entries); a landmark's slots ascend with the pose
   const unsigned short* slotBlk;             // per slot: pose block of the reduced camera system (poseOff / 6)
   const int* slotObsPtr;                     // per slot: its observations (nSlots + 1 entries into slotObs)
   const int* slotObs;                        // observation numbers
   const int* slotLm;                         // per slot: its landmark
-  double* slotRec;                           // per slot 24 doubles, written once per build: E = (sum Jp^T Jl) L^-T and E c (kernels.hip)
-  const int4* blkEntries;                    // work list of k_schur_blocks (panelWork.z / .w index it): per (panel pair, landmark with
-                                             // slots in both panels) first slot in I, first slot in J, count in I | count in J << 8 |
-                                             // trips << 16, first pair word
-  const uint32_t* blkPairs;                  // pair words, eight per trip: 25 ka | 25 kb << 9 | 36 (16 pa + pb) << 18 (kernels.hip)
+  double* slotRec;                           // per slot kBlkRec doubles, written once per build: E = (sum Jp^T Jl) L^-T (kernels.hip)
+  // work list of k_schur_rows (host-built, Window::pack): panelWork.z / .w = first batch / batches of the workgroup
+  const int4* blkOwn;                        // per workgroup: the two block rows of wave w in bytes 2 w, 2 w + 1 (255: none)
+  const int2* blkBatch;                      // per batch: first entry of blkRecSlot, records
+  const int4* blkWaveTab;                    // per (batch, wave): first pair word, pair words of its first / second row (multiples of 4, together at most kBlkBatchWords)
+  const int* blkRecSlot;                     // per staged record: its slot
+  const uint32_t* blkPairs;                  // pair words: A record | B record << 9 | pose block in J << 18; words 2 j and 2 j + 1 share their A record
   double* blkPartial;                        // per workgroup of k_blocks_slots: (dC / 6) x 28 sums of Jp^T Jp (21) and Jp^T r (6)
   double *obsUv, *obsW;
   uint32_t* obsIdx;

@@ -1760,7 +1760,7 @@ void Window::pack(bool solveFollows) {
   // per slot and build.  A pose block index has to fit 16 bits.
   const bool schurBlocks = schurPanels && !optOn(kOptPanelsOld) && dC / 6 <= kBlkMaxPoseBlocks;
   std::vector<uint32_t> hPairWords;
-  std::vector<int> hSlotPtr, hSlotObsPtr, hSlotObs, hSlotLm, hEntries;   // (staged uploads copy from these when the block is flushed: they live to the end of pack())
+  std::vector<int> hSlotPtr, hSlotObsPtr, hSlotObs, hSlotLm, hEntries, hBatch, hWaveTab, hRecSlot;   // (staged uploads copy from these when the block is flushed: they live to the end of pack())
   std::vector<unsigned short> hSlotBlk;
   if (schurBlocks) {
     hSlotPtr.resize((size_t)L + 1); hSlotObs.reserve(N); hSlotBlk.reserve(N); hSlotObsPtr.reserve((size_t)N + 1);
@@ -1782,8 +1782,8 @@ void Window::pack(bool solveFollows) {
     hSlotObsPtr.push_back((int)hSlotObs.size());
     upload(dSlotPtr_, hSlotPtr, s); upload(dSlotBlk_, hSlotBlk, s); upload(dSlotObsPtr_, hSlotObsPtr, s); upload(dSlotObs_, hSlotObs, s);
     upload(dSlotLm_, hSlotLm, s);
-    dSlotRec_.reserve(std::max<size_t>(hSlotBlk.size() * 24, 1));
-    dBlkPartial_.reserve(std::max<size_t>(((hSlotBlk.size() + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup) * (size_t)(dC / 6) * 28, 1));
+    dSlotRec_.reserve(std::max<size_t>(hSlotBlk.size() * kBlkRec, 1));
+    dBlkPartial_.reserve(std::max<size_t>(((hSlotBlk.size() + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup) * (size_t)(dC / 6) * 34, 1));
     // work list: per panel pair (I >= J; a panel is 16 pose blocks = 96 rows) the landmarks with slots in both panels, as ENTRIES
     // (first slot and count in either panel -- the slots of a panel are a run, they ascend with the pose), cut into workgroups of
     // kBlkEntriesPerBlock; the pairs in the order k_reduce_panel_slabs expects (panelPairPtr)
@@ -1804,56 +1804,96 @@ void Window::pack(bool solveFollows) {
           li.insert(li.end(), {runFirst[a], runFirst[b], runCount[a] | (runCount[b] << 8), l});
         }
     }
-    // ... and every entry's slot pairs as PAIR WORDS for the kernel's inner loop (25 ka | 25 kb << 9 | 36 (16 pa + pb) << 18: the
-    // indices of the two staged records and of the 6 x 6 block in the workgroup's accumulator image), padded to whole fours
-    // (stored in eights) with pairs that add into the spare block 256; a diagonal pair takes the blocks on and below the block diagonal
+    // ... and for k_schur_rows (kernels.hip), per panel pair: the sixteen block rows dealt to the kernel's eight waves (two each, by
+    // their pair counts, heaviest first), the entries cut into workgroups of kBlkEntriesPerBlock and those into BATCHES (records
+    // staged in LDS at a time: at most kBlkBatchRecs, and at most kBlkBatchWords pair words per wave), and per batch and wave the
+    // PAIR WORDS in the order the wave works through them: A record | B record << 9 | pose block in J << 18, its first row's, then
+    // its second row's, each sorted by A record (entry, slot in I); the run of an A record is padded to an even length and a row's
+    // words to whole fours with pairs whose B operand is the zero record (the kernel takes the A record of words 2 j, 2 j + 1 from
+    // word 2 j, and words 2 j, 2 j + 1 must name two accumulators).  A diagonal pair takes the blocks on and below the block diagonal.
     hPanelPairPtr.push_back(0);
     for (int I = 0; I < nPan; ++I)
       for (int J = 0; J <= I; ++J) {
         const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
         const size_t nEnt = li.size() / 4;
+        const bool dg = I == J;
+        long rowLoad[16] = {0};
+        for (size_t e = 0; e < nEnt; ++e) {
+          const int fa = li[4 * e], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
+          for (int ka = 0; ka < nA; ++ka) rowLoad[hSlotBlk[fa + ka] - 16 * I] += dg ? ka + 1 : nB;
+        }
+        int rowOrder[16], ownerWave[16], ownerSel[16], ownRows[kBlkWaves][2];
+        long waveLoad[kBlkWaves] = {0};
+        for (int r = 0; r < 16; ++r) rowOrder[r] = r;
+        std::stable_sort(rowOrder, rowOrder + 16, [&](int a, int b) { return rowLoad[a] > rowLoad[b]; });
+        for (int wvv = 0; wvv < kBlkWaves; ++wvv) ownRows[wvv][0] = ownRows[wvv][1] = 255;
+        for (int k = 0; k < 16; ++k) {
+          const int r = rowOrder[k];
+          int best = -1;
+          for (int wvv = 0; wvv < kBlkWaves; ++wvv)
+            if (ownRows[wvv][1] == 255 && (best < 0 || waveLoad[wvv] < waveLoad[best])) best = wvv;
+          const int sel = ownRows[best][0] == 255 ? 0 : 1;
+          ownRows[best][sel] = r; ownerWave[r] = best; ownerSel[r] = sel; waveLoad[best] += rowLoad[r];
+        }
+        int ownWords[4] = {0, 0, 0, 0};
+        for (int wvv = 0; wvv < kBlkWaves; ++wvv)
+          ownWords[wvv >> 1] |= (ownRows[wvv][0] | (ownRows[wvv][1] << 8)) << (16 * (wvv & 1));
         for (size_t k = 0; k < nEnt; k += kBlkEntriesPerBlock) {
-          const int cnt = (int)std::min<size_t>(kBlkEntriesPerBlock, nEnt - k);
-          // the workgroup's entries with their pair words ...
-          std::vector<std::array<int, 4>> wgEnt(cnt);
-          for (size_t e = k; e < k + cnt; ++e) {
-            const int fa = li[4 * e], fb = li[4 * e + 1], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
-            const size_t first = hPairWords.size();
-            for (int ka = 0; ka < nA; ++ka)
-              for (int kb = 0; kb < (I == J ? ka + 1 : nB); ++kb) {
-                const int pa = hSlotBlk[fa + ka] - 16 * I, pb = hSlotBlk[fb + kb] - 16 * J;
-                hPairWords.push_back((uint32_t)(25 * ka) | ((uint32_t)(25 * kb) << 9) | ((uint32_t)(36 * (16 * pa + pb)) << 18));
+          const size_t kEnd = std::min(nEnt, k + kBlkEntriesPerBlock);
+          const int firstBatch = (int)(hBatch.size() / 2);
+          size_t e = k;
+          while (e < kEnd) {
+            std::vector<uint32_t> words[kBlkWaves][2];   // per wave and owned row
+            const int firstRec = (int)hRecSlot.size();
+            int recs = 0;
+            for (; e < kEnd; ++e) {
+              const int fa = li[4 * e], fb = li[4 * e + 1], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
+              const int need = nA + (dg ? 0 : nB);
+              if (recs + need > kBlkBatchRecs - 1) break;
+              int add[kBlkWaves] = {0};   // (every run of an A record is padded to an even number of words)
+              for (int ka = 0; ka < nA; ++ka) add[ownerWave[hSlotBlk[fa + ka] - 16 * I]] += ((dg ? ka + 1 : nB) + 1) & ~1;
+              bool fits = true;
+              for (int wvv = 0; wvv < kBlkWaves; ++wvv) fits = fits && (int)(words[wvv][0].size() + words[wvv][1].size()) + add[wvv] <= kBlkBatchWords - 4;
+              if (!fits) break;
+              const int recA0 = recs, recB0 = dg ? recs : recs + nA;
+              for (int ka = 0; ka < nA; ++ka) hRecSlot.push_back(fa + ka);
+              if (!dg) for (int kb = 0; kb < nB; ++kb) hRecSlot.push_back(fb + kb);
+              recs += need;
+              for (int ka = 0; ka < nA; ++ka) {
+                const int row = hSlotBlk[fa + ka] - 16 * I;
+                std::vector<uint32_t>& wl = words[ownerWave[row]][ownerSel[row]];
+                const int cnt = dg ? ka + 1 : nB;
+                int pb = 0;
+                for (int kb = 0; kb < cnt; ++kb) {
+                  pb = hSlotBlk[fb + kb] - 16 * J;
+                  wl.push_back((uint32_t)(recA0 + ka) | ((uint32_t)(recB0 + kb) << 9) | ((uint32_t)pb << 18));
+                }
+                // (padding word of the run: the zero record as B, an accumulator other than its partner's)
+                if (cnt & 1) wl.push_back((uint32_t)(recA0 + ka) | ((uint32_t)(kBlkBatchRecs - 1) << 9) | ((uint32_t)((pb + 1) & 15) << 18));
               }
-            const int nQuads = (int)((hPairWords.size() - first + 3) / 4);   // the kernel works in fours (two per trip) and loads in eights
-            while ((hPairWords.size() - first) % 8) hPairWords.push_back((uint32_t)(36 * 256) << 18);
-            wgEnt[e - k] = {fa, fb, nA | (nB << 8) | (nQuads << 16), (int)first};
-          }
-          // ... dealt to the kBlkWaves waves longest first (each to the wave with the least work so far; an entry costs its pair
-          // quads plus a prologue worth about two), the waves' sequences interleaved and padded to equal length with empty entries
-          std::vector<int> order(cnt);
-          for (int e = 0; e < cnt; ++e) order[e] = e;
-          std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (wgEnt[a][2] >> 16) > (wgEnt[b][2] >> 16); });
-          std::vector<std::vector<int>> perWave(kBlkWaves);
-          std::vector<long> load(kBlkWaves, 0);
-          for (int e : order) {
-            const int wmin = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            perWave[wmin].push_back(e);
-            load[wmin] += (wgEnt[e][2] >> 16) + 2;
-          }
-          size_t steps = 0;
-          for (const auto& pwv : perWave) steps = std::max(steps, pwv.size());
-          hPanelWork.insert(hPanelWork.end(), {I, J, (int)(hEntries.size() / 4), (int)(steps * kBlkWaves)});
-          for (size_t st = 0; st < steps; ++st)
-            for (int wv = 0; wv < kBlkWaves; ++wv) {
-              if (st < perWave[wv].size()) { const auto& en = wgEnt[perWave[wv][st]]; hEntries.insert(hEntries.end(), en.begin(), en.end()); }
-              else hEntries.insert(hEntries.end(), {0, 0, 0, 0});
             }
+            if (recs == 0) throw std::logic_error("k_schur_rows work list: an entry does not fit a batch");
+            hBatch.insert(hBatch.end(), {firstRec, recs});
+            for (int wvv = 0; wvv < kBlkWaves; ++wvv) {
+              for (int sel = 0; sel < 2; ++sel)   // (a row's words in fours: two more padding words -- both operands the zero record, two accumulators)
+                if (words[wvv][sel].size() % 4) {
+                  const uint32_t z = (uint32_t)(kBlkBatchRecs - 1) | ((uint32_t)(kBlkBatchRecs - 1) << 9);
+                  words[wvv][sel].push_back(z); words[wvv][sel].push_back(z | (1u << 18));
+                }
+              hWaveTab.insert(hWaveTab.end(), {(int)hPairWords.size(), (int)words[wvv][0].size(), (int)words[wvv][1].size(), 0});
+              hPairWords.insert(hPairWords.end(), words[wvv][0].begin(), words[wvv][0].end());
+              hPairWords.insert(hPairWords.end(), words[wvv][1].begin(), words[wvv][1].end());
+            }
+          }
+          hPanelWork.insert(hPanelWork.end(), {I, J, firstBatch, (int)(hBatch.size() / 2) - firstBatch});
+          hEntries.insert(hEntries.end(), ownWords, ownWords + 4);   // (blkOwn: one int4 per workgroup)
           ++nPanelBlocks;
         }
         hPanelPairPtr.push_back(nPanelBlocks);
       }
-    hPairWords.resize(hPairWords.size() + 256, 0u);   // (a wave requests an entry's words in 64s)
-    upload(dBlkPairs_, hPairWords, s);
+    hPairWords.resize(hPairWords.size() + 128, 0u);   // (a wave requests its words in 64s)
+    hBatch.resize(hBatch.size() + 2 * 3, 0); hWaveTab.resize(hWaveTab.size() + (size_t)4 * kBlkWaves * 3, 0);   // (the kernel reads descriptors three batches ahead, unconditionally)
+    upload(dBlkPairs_, hPairWords, s); upload(dBlkBatch_, hBatch, s); upload(dBlkWaveTab_, hWaveTab, s); upload(dBlkRecSlot_, hRecSlot, s);
     upload(dPanelWork_, hPanelWork, s); upload(dPanelChunks_, hEntries, s); upload(dPanelPairPtr_, hPanelPairPtr, s);
     dSlabs_.reserve(std::max<size_t>((size_t)nPanelBlocks * (96 * 96 + 3 * 96), 1));
   }
@@ -1933,7 +1973,8 @@ void Window::pack(bool solveFollows) {
   p.schurPanels = schurPanels ? 1 : 0; p.nPanelBlocks = nPanelBlocks; p.nPanelPairs = nPanelPairs;
   p.schurBlocks = schurBlocks ? 1 : 0; p.nSlots = (int)hSlotBlk.size();
   p.slotPtr = dSlotPtr_.p; p.slotBlk = dSlotBlk_.p; p.slotObsPtr = dSlotObsPtr_.p; p.slotObs = dSlotObs_.p; p.slotLm = dSlotLm_.p; p.slotRec = dSlotRec_.p;
-  p.blkEntries = reinterpret_cast<const int4*>(dPanelChunks_.p); p.blkPartial = dBlkPartial_.p; p.blkPairs = dBlkPairs_.p;
+  p.blkOwn = reinterpret_cast<const int4*>(dPanelChunks_.p); p.blkPartial = dBlkPartial_.p; p.blkPairs = dBlkPairs_.p;
+  p.blkBatch = reinterpret_cast<const int2*>(dBlkBatch_.p); p.blkWaveTab = reinterpret_cast<const int4*>(dBlkWaveTab_.p); p.blkRecSlot = dBlkRecSlot_.p;
   p.panelWork = reinterpret_cast<const int4*>(dPanelWork_.p); p.panelChunks = dPanelChunks_.p; p.panelPairPtr = dPanelPairPtr_.p;
   p.lmPtr = dLmPtr_.p; p.obsUv = dObsUv_.p; p.obsW = dObsW_.p; p.obsIdx = dObsIdx_.p; p.obsLm = dObsLm_.p;
   if (resident) { p.lmPtr = res_.lmPtr[res_.cur].p; p.obsUv = res_.uv[res_.cur].p; p.obsW = res_.w[res_.cur].p; p.obsLm = res_.obsLm[res_.cur].p; }

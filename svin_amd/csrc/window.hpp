@@ -490,7 +490,7 @@ class Window {
   // device buffers
   DevBuf<double> dPose_, dExt_, dSb_, dLm_, dPoseC_, dExtC_, dSbC_, dLmC_;
   DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_, dPanelWork_, dPanelChunks_, dPanelPairPtr_, dObsOrder_;
-  DevBuf<int> dSlotPtr_, dSlotObsPtr_, dSlotObs_, dSlotLm_;   // wide windows, block-pair Schur form: (landmark, pose) slots (kernels.hpp)
+  DevBuf<int> dSlotPtr_, dSlotObsPtr_, dSlotObs_, dSlotLm_, dBlkBatch_, dBlkWaveTab_, dBlkRecSlot_;   // wide windows, block-pair Schur form: (landmark, pose) slots (kernels.hpp)
   DevBuf<unsigned short> dSlotBlk_;
   DevBuf<uint32_t> dBlkPairs_;
   DevBuf<double> dSlotRec_, dBlkPartial_;
