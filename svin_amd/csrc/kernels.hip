@@ -3099,56 +3099,71 @@ __global__ __launch_bounds__(1024) void k_blocks_pose_reduce(DeviceProblem p, in
 }
 
 typedef double d16_t __attribute__((ext_vector_type(16)));
-// Four pair words of one block row: words 0 / 1 share their A record, so do words 2 / 3 (the host pads every run of an A record to
-// an even length).  Six operand reads, then four products, each into the accumulator its word names: the VGPR INDEX MODE reaches
-// the C / D operands of v_mfma_f64_4x4x4_4b_f64 (tools/ubench/mfma_gpridx.hip: results right, also for back-to-back products into
-// one accumulator with five wait states between them; 4.2 cycles per pair and CU with 16 waves, against 6.2 for the indexed
-// moves the compiler puts around the product).  The accumulators of a row are pinned to the registers the text names; the index
-// mode writes M0, which the compiler uses for the LDS-DMA base: saved and restored.  Words 0 / 1 (and 2 / 3) never meet in an
-// accumulator (one landmark, two poses; a padding word names the next one), words 1 / 2 may: wait states between them.  The
-// operand reads are counted by lgkmcnt in order once the scalar loads of the compiler's code have drained (first line).
-#define SVIN_ROWS_QUAD(ACC, TUPLE, FIRST)                                                                                    \
+// EIGHT pair words of one block row per statement.  Words 2 j / 2 j + 1 share their A record (the host pads every run of an A
+// record to an even length and a row's words to whole eights), so a quad is six operand reads and four products, each into the
+// accumulator its word names: the VGPR INDEX MODE reaches the C / D operands of v_mfma_f64_4x4x4_4b_f64 (tools/ubench/
+// mfma_gpridx.hip: results right, also for back-to-back products into one accumulator with five wait states between them; 4.2
+// cycles per pair and CU with 16 waves, against 6.2 for the indexed moves the compiler puts around the product).  The accumulators
+// of a row are pinned to the registers the text names; the index mode writes M0, which the compiler uses for the LDS-DMA base:
+// saved and restored.  Words 2 j / 2 j + 1 never meet in an accumulator (one landmark, two poses; a padding word names the next
+// one), words 2 j + 1 / 2 j + 2 may: four wait states between their products.  The index of the next product is set behind the
+// current one (s_set_gpr_idx_idx; a product has its registers when it issues) and a wait state before it is used.
+// The reads run one quad AHEAD of the products: the statement first requests words 4..7 (operand set B), multiplies words 0..3
+// (set A, requested by the previous statement -- or by SVIN_ROWS_FIRST), requests the NEXT statement's words 0..3 into set A,
+// multiplies words 4..7.  Set A is in flight across the loop's back edge: between two statements the loop only computes scalar
+// offsets, and nothing may touch the twelve registers of set A (tools/dbg/check_rows_asm.py looks at the disassembly).  lgkmcnt
+// counts the reads in order (a scalar load of the compiler's in between only makes a wait longer): a quad's products start when
+// at most the six reads of the quad behind it are in flight.  One address register: a ds_read has taken its address when the
+// next instruction issues.  (The kernel is bound by instruction issue, not by the LDS or the matrix pipe -- 155-173 cycles per
+// word and wave with ~14 instructions per word, whether the reads ran ahead or not: the word format and this statement are what
+// nine instructions per word look like.)
+#define SVIN_ROWS_RD(DST, OFF, LANE) "v_add_u32 %[t], " OFF ", " LANE "\n\tds_read_b64 " DST ", %[t]\n\t"
+#define SVIN_ROWS_QUAD(FIRST, I0, I1, I2, I3, A0, B0, B1, A1, B2, B3)                                                        \
+  "s_waitcnt lgkmcnt(6)\n\ts_set_gpr_idx_on " I0 ", 0xc\n\t"                                                                 \
+  "v_mfma_f64_4x4x4_4b_f64 " FIRST ", " A0 ", " B0 ", " FIRST "\n\ts_set_gpr_idx_idx " I1 "\n\ts_nop 0\n\t"                   \
+  "v_mfma_f64_4x4x4_4b_f64 " FIRST ", " A0 ", " B1 ", " FIRST "\n\ts_set_gpr_idx_idx " I2 "\n\ts_nop 2\n\t"                   \
+  "v_mfma_f64_4x4x4_4b_f64 " FIRST ", " A1 ", " B2 ", " FIRST "\n\ts_set_gpr_idx_idx " I3 "\n\ts_nop 0\n\t"                   \
+  "v_mfma_f64_4x4x4_4b_f64 " FIRST ", " A1 ", " B3 ", " FIRST "\n\ts_set_gpr_idx_off\n\t"
+#define SVIN_ROWS_FIRST(W)                                                                                                   \
+  asm volatile(SVIN_ROWS_RD("%[a0]", "%[sa0]", "%[lA]") SVIN_ROWS_RD("%[b0]", "%[sb0]", "%[lB]") SVIN_ROWS_RD("%[b1]", "%[sb1]", "%[lB]") \
+               SVIN_ROWS_RD("%[a1]", "%[sa1]", "%[lA]") SVIN_ROWS_RD("%[b2]", "%[sb2]", "%[lB]") SVIN_ROWS_RD("%[b3]", "%[sb3]", "%[lB]") \
+               : [a0] "=&v"(opA[0]), [b0] "=&v"(opA[1]), [b1] "=&v"(opA[2]), [a1] "=&v"(opA[3]), [b2] "=&v"(opA[4]), [b3] "=&v"(opA[5]), [t] "=&v"(adr) \
+               : [sa0] "s"(offA(W[0])), [sb0] "s"(offB(W[0])), [sb1] "s"(offB(W[1])), [sa1] "s"(offA(W[2])),                 \
+                 [sb2] "s"(offB(W[2])), [sb3] "s"(offB(W[3])), [lA] "v"(oA), [lB] "v"(oB))
+#define SVIN_ROWS_EIGHT(ACC, TUPLE, FIRST, WA, WB, WN)                                                                       \
+  asm volatile(SVIN_ROWS_RD("%[xa0]", "%[sxa0]", "%[lA]") SVIN_ROWS_RD("%[xb0]", "%[sxb0]", "%[lB]") SVIN_ROWS_RD("%[xb1]", "%[sxb1]", "%[lB]") \
+               SVIN_ROWS_RD("%[xa1]", "%[sxa1]", "%[lA]") SVIN_ROWS_RD("%[xb2]", "%[sxb2]", "%[lB]") SVIN_ROWS_RD("%[xb3]", "%[sxb3]", "%[lB]") \
+               "s_mov_b32 %[ms], m0\n\t"                                                                                     \
+               SVIN_ROWS_QUAD(FIRST, "%[i0]", "%[i1]", "%[i2]", "%[i3]", "%[a0]", "%[b0]", "%[b1]", "%[a1]", "%[b2]", "%[b3]") \
+               SVIN_ROWS_RD("%[a0]", "%[sa0]", "%[lA]") SVIN_ROWS_RD("%[b0]", "%[sb0]", "%[lB]") SVIN_ROWS_RD("%[b1]", "%[sb1]", "%[lB]") \
+               SVIN_ROWS_RD("%[a1]", "%[sa1]", "%[lA]") SVIN_ROWS_RD("%[b2]", "%[sb2]", "%[lB]") SVIN_ROWS_RD("%[b3]", "%[sb3]", "%[lB]") \
+               SVIN_ROWS_QUAD(FIRST, "%[i4]", "%[i5]", "%[i6]", "%[i7]", "%[xa0]", "%[xb0]", "%[xb1]", "%[xa1]", "%[xb2]", "%[xb3]") \
+               "s_mov_b32 m0, %[ms]\n\t"                                                                                     \
+               "s_nop 2"                                                                                                     \
+               : "+{" TUPLE "}"(ACC), [ms] "=&s"(m0Save), [t] "=&v"(adr), [a0] "+v"(opA[0]), [b0] "+v"(opA[1]), [b1] "+v"(opA[2]), \
+                 [a1] "+v"(opA[3]), [b2] "+v"(opA[4]), [b3] "+v"(opA[5]), [xa0] "=&v"(opB[0]), [xb0] "=&v"(opB[1]),           \
+                 [xb1] "=&v"(opB[2]), [xa1] "=&v"(opB[3]), [xb2] "=&v"(opB[4]), [xb3] "=&v"(opB[5])                           \
+               : [sxa0] "s"(offA(WB[0])), [sxb0] "s"(offB(WB[0])), [sxb1] "s"(offB(WB[1])), [sxa1] "s"(offA(WB[2])),         \
+                 [sxb2] "s"(offB(WB[2])), [sxb3] "s"(offB(WB[3])), [sa0] "s"(offA(WN[0])), [sb0] "s"(offB(WN[0])),           \
+                 [sb1] "s"(offB(WN[1])), [sa1] "s"(offA(WN[2])), [sb2] "s"(offB(WN[2])), [sb3] "s"(offB(WN[3])),             \
+                 [i0] "s"(WA[0]), [i1] "s"(WA[1]), [i2] "s"(WA[2]), [i3] "s"(WA[3]),                                         \
+                 [i4] "s"(WB[0]), [i5] "s"(WB[1]), [i6] "s"(WB[2]), [i7] "s"(WB[3]), [lA] "v"(oA), [lB] "v"(oB))
+// one block row's words q0 .. q1 (whole eights)
+#define SVIN_ROWS_ROW(ACC, TUPLE, FIRST, Q0, Q1)                                                                             \
   do {                                                                                                                       \
-    const unsigned wsrc = q < 64 ? Wc0 : Wc1;   /* (wave-uniform) */                                                          \
-    const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, q & 63), w1 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 1); \
-    const unsigned w2 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 2), w3 = (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + 3); \
-    const unsigned pa0 = oA + (w0 & 511u) * (kBlkStride * 8), pa1 = oA + (w2 & 511u) * (kBlkStride * 8);                     \
-    const unsigned pb0 = oB + ((w0 >> 9) & 511u) * (kBlkStride * 8), pb1 = oB + ((w1 >> 9) & 511u) * (kBlkStride * 8);        \
-    const unsigned pb2 = oB + ((w2 >> 9) & 511u) * (kBlkStride * 8), pb3 = oB + ((w3 >> 9) & 511u) * (kBlkStride * 8);        \
-    const unsigned i0 = (w0 >> 17) & 30u, i1 = (w1 >> 17) & 30u, i2 = (w2 >> 17) & 30u, i3 = (w3 >> 17) & 30u;                 \
-    double ta0, ta1, tb0, tb1, tb2, tb3;                                                                                     \
-    unsigned m0Save;                                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
-                 "ds_read_b64 %[ta0], %[pa0]\n\t"                                                                            \
-                 "ds_read_b64 %[tb0], %[pb0]\n\t"                                                                            \
-                 "ds_read_b64 %[tb1], %[pb1]\n\t"                                                                            \
-                 "ds_read_b64 %[ta1], %[pa1]\n\t"                                                                            \
-                 "ds_read_b64 %[tb2], %[pb2]\n\t"                                                                            \
-                 "ds_read_b64 %[tb3], %[pb3]\n\t"                                                                            \
-                 "s_mov_b32 %[ms], m0\n\t"                                                                                   \
-                 "s_waitcnt lgkmcnt(4)\n\t"                                                                                  \
-                 "s_set_gpr_idx_on %[i0], 0xc\n\t"                                                                           \
-                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta0], %[tb0], " FIRST "\n\t"                                          \
-                 "s_set_gpr_idx_off\n\t"                                                                                     \
-                 "s_waitcnt lgkmcnt(3)\n\t"                                                                                  \
-                 "s_set_gpr_idx_on %[i1], 0xc\n\t"                                                                           \
-                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta0], %[tb1], " FIRST "\n\t"                                          \
-                 "s_set_gpr_idx_off\n\t"                                                                                     \
-                 "s_waitcnt lgkmcnt(1)\n\t"                                                                                  \
-                 "s_nop 3\n\t"                                                                                               \
-                 "s_set_gpr_idx_on %[i2], 0xc\n\t"                                                                           \
-                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta1], %[tb2], " FIRST "\n\t"                                          \
-                 "s_set_gpr_idx_off\n\t"                                                                                     \
-                 "s_waitcnt lgkmcnt(0)\n\t"                                                                                  \
-                 "s_set_gpr_idx_on %[i3], 0xc\n\t"                                                                           \
-                 "v_mfma_f64_4x4x4_4b_f64 " FIRST ", %[ta1], %[tb3], " FIRST "\n\t"                                          \
-                 "s_set_gpr_idx_off\n\t"                                                                                     \
-                 "s_mov_b32 m0, %[ms]\n\t"                                                                                   \
-                 "s_nop 4"                                                                                                   \
-                 : "+{" TUPLE "}"(ACC), [ta0] "=&v"(ta0), [ta1] "=&v"(ta1), [tb0] "=&v"(tb0), [tb1] "=&v"(tb1), [tb2] "=&v"(tb2), \
-                   [tb3] "=&v"(tb3), [ms] "=&s"(m0Save)                                                                      \
-                 : [pa0] "v"(pa0), [pa1] "v"(pa1), [pb0] "v"(pb0), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3), [i0] "s"(i0), \
-                   [i1] "s"(i1), [i2] "s"(i2), [i3] "s"(i3));                                                                 \
+    const int q0_ = (Q0), q1_ = (Q1);                                                                                        \
+    if (q0_ < q1_) {                                                                                                         \
+      unsigned wa[4], wb[4], wn[4];                                                                                          \
+      fetchWords(q0_, q1_, wa);                                                                                              \
+      SVIN_ROWS_FIRST(wa);                                                                                                   \
+      for (int q = q0_; q < q1_; q += 8) {                                                                                   \
+        fetchWords(q + 4, q1_, wb);                                                                                          \
+        fetchWords(q + 8, q1_, wn);                                                                                          \
+        SVIN_ROWS_EIGHT(ACC, TUPLE, FIRST, wa, wb, wn);                                                                      \
+        wa[0] = wn[0]; wa[1] = wn[1]; wa[2] = wn[2]; wa[3] = wn[3];                                                          \
+      }                                                                                                                      \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(opA[0]), "+v"(opA[1]), "+v"(opA[2]), "+v"(opA[3]), "+v"(opA[4]), "+v"(opA[5])); /* (the reads past the row's end: of the zero record) */ \
+    }                                                                                                                        \
   } while (0)
 
 template <int NW>
@@ -3175,8 +3190,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_schur_rows(DeviceProblem p) {
   // finite numbers that only reach rows / columns 6 and 7 of the result, which nobody stores) and result lanes (16 i + 4 b + j)
   const int kk = lane >> 4, bq = (lane >> 2) & 3, ij = lane & 3;
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) double*)smem;
-  const unsigned opA = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq >> 1) + ij : kBlkRec);
-  const unsigned opB = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq & 1) + ij : kBlkRec);
+  const unsigned laneA = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq >> 1) + ij : kBlkRec);
+  const unsigned laneB = ldsBase + 8u * (unsigned)(kk < 3 ? 6 * kk + 4 * (bq & 1) + ij : kBlkRec);
   const int dRow = 4 * (bq >> 1) + kk, dCol = 4 * (bq & 1) + ij;
   const bool dValid = dRow < 6 && dCol < 6;
   const int dOff = dRow * 6 + dCol;
@@ -3261,9 +3276,22 @@ __global__ __launch_bounds__(64 * NW, 4) void k_schur_rows(DeviceProblem p) {
 #ifdef SVIN_BLOCKS_TIMING
     bPairs += n0 + n1;
 #endif
-    const unsigned oA = opA + (unsigned)((bi & 1) * kBuf * 8), oB = opB + (unsigned)((bi & 1) * kBuf * 8);
-    for (int q = 0; q < n0; q += 4) SVIN_ROWS_QUAD(acc0, "v[64:95]", "v[64:65]");
-    for (int q = n0; q < n0 + n1; q += 4) SVIN_ROWS_QUAD(acc1, "v[96:127]", "v[96:97]");
+    const unsigned oA = laneA + (unsigned)((bi & 1) * kBuf * 8), oB = laneB + (unsigned)((bi & 1) * kBuf * 8);
+    double opA[6], opB[6];   // (the operands of two quads)
+    unsigned adr, m0Save;    // (the address register of the reads)
+    // four words from q on as scalars; past the row's end a word of the zero record
+    auto fetchWords = [&](int q, int qEnd, unsigned (&w)[4]) __attribute__((always_inline)) {
+      const unsigned wsrc = q < 64 ? Wc0 : Wc1;   // (wave-uniform)
+      constexpr unsigned kZero = ((unsigned)(kBlkBatchRecs - 1) << 24) | ((unsigned)((kBlkBatchRecs - 1) * kBlkStride * 8) << 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = q < qEnd ? (unsigned)__builtin_amdgcn_readlane((int)wsrc, (q & 63) + u) : (kZero | (unsigned)(2 * (u & 1)));
+    };
+    // pair word (host: Window::pack): twice the accumulator's number in bits 0-7 (what the index mode takes from a scalar register: its
+    // low byte), the B record's byte offset in bits 8-23, the A record's number in bits 24-31
+    auto offA = [](unsigned w) __attribute__((always_inline)) -> unsigned { return (w >> 24) * (unsigned)(kBlkStride * 8); };
+    auto offB = [](unsigned w) __attribute__((always_inline)) -> unsigned { return (w >> 8) & 0xffffu; };
+    SVIN_ROWS_ROW(acc0, "v[64:95]", "v[64:65]", 0, n0);
+    SVIN_ROWS_ROW(acc1, "v[96:127]", "v[96:97]", n0, n0 + n1);
     BNT(2);
   }
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (the last products have written their accumulators)
@@ -3298,7 +3326,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_schur_rows(DeviceProblem p) {
     v[t] = 0.0; v[kPanelRows + t] = 0.0; v[2 * kPanelRows + t] = 0.0;
   }
 }
+#undef SVIN_ROWS_ROW
+#undef SVIN_ROWS_EIGHT
+#undef SVIN_ROWS_FIRST
 #undef SVIN_ROWS_QUAD
+#undef SVIN_ROWS_RD
 
 
 // sums the slabs of every panel pair (fixed order) into S (both triangles) and, for diagonal pairs, the vectors

@@ -117,7 +117,7 @@ constexpr int kPanelChunksPerBlock = SVIN_PANEL_CHUNKS;
 // block-pair form (round 6): entries (landmark x panel pair) per workgroup of k_schur_rows, its waves (the host deals the block
 // rows of a panel pair to them), records a batch stages in LDS (x 20 doubles = 160 bytes: two buffers of 36.8 KB, two workgroups
 // per CU; the last record of a buffer is never staged: all zero, the B operand of the padding pairs), pair words per wave and batch
-constexpr int kBlkEntriesPerBlock = 256;
+constexpr int kBlkMinWordsPerBlock = 1024;    // pair words per workgroup, at least (Window::pack cuts the work list by words)
 constexpr int kBlkWaves = 8;
 constexpr int kBlkBatchRecs = 230;
 constexpr int kBlkBatchWords = 128;
@@ -155,9 +155,9 @@ struct DeviceProblem {
   // work list of k_schur_rows (host-built, Window::pack): panelWork.z / .w = first batch / batches of the workgroup
   const int4* blkOwn;                        // per workgroup: the two block rows of wave w in bytes 2 w, 2 w + 1 (255: none)
   const int2* blkBatch;                      // per batch: first entry of blkRecSlot, records
-  const int4* blkWaveTab;                    // per (batch, wave): first pair word, pair words of its first / second row (multiples of 4, together at most kBlkBatchWords)
+  const int4* blkWaveTab;                    // per (batch, wave): first pair word, pair words of its first / second row (multiples of 8, together at most kBlkBatchWords)
   const int* blkRecSlot;                     // per staged record: its slot
-  const uint32_t* blkPairs;                  // pair words: A record | B record << 9 | pose block in J << 18; words 2 j and 2 j + 1 share their A record
+  const uint32_t* blkPairs;                  // pair words: 2 x pose block in J | B record's byte offset << 8 | A record << 24; words 2 j and 2 j + 1 share their A record
   double* blkPartial;                        // per workgroup of k_blocks_slots: (dC / 6) x 28 sums of Jp^T Jp (21) and Jp^T r (6)
   double *obsUv, *obsW;
   uint32_t* obsIdx;

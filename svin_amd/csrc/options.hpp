@@ -32,6 +32,7 @@ enum DebugOption : int {
   kOptNoLL,                // SVIN_NO_LL: no left-looking one-workgroup solver
   kOptNoSbElim,            // SVIN_NO_SB_ELIM: no speed / bias chain elimination
   kOptNoLdsBorder,         // SVIN_NO_LDS_BORDER: no border variants of the LDS-resident solver
+  kOptBlkRounds,           // SVIN_BLK_ROUNDS=n: workgroups of k_schur_rows per place (two places per CU; read by pack(); default 2)
   kOptCount
 };
 

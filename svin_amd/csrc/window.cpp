@@ -31,6 +31,15 @@ std::string& lastError() {
     if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// compute units of the current device (asked once)
+static int deviceComputeUnits() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
 static double nowSec() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -56,12 +65,13 @@ struct OptionTable {
         {kOptPgTiming, "SVIN_PG_TIMING"}, {kOptMargTiming, "SVIN_MARG_TIMING"}, {kOptMargKeepPre, "SVIN_MARG_KEEP_PRE"},
         {kOptMargSyncEnqueue, "SVIN_MARG_SYNC_ENQUEUE"}, {kOptMargEig, "SVIN_MARG_EIG"}, {kOptSchurAMfma, "SVIN_SCHUR_A_MFMA"},
         {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
-        {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}};
+        {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}};
     static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
     for (const auto& n : kNames) {
       name[n.which] = n.env;
       const char* e = std::getenv(n.env);   // the library's ONE look at the environment for its switches
       int val = e ? 1 : 0;
+      if (e && n.which == kOptBlkRounds) val = std::atoi(e);
       if (e && n.which == kOptMargEig) {
         const std::string w(e);
         val = w == "direct" ? 1 : (w == "jacobi" ? 3 : 2);   // any other value selects the Cholesky-preconditioned Jacobi solve alone
@@ -1786,7 +1796,7 @@ void Window::pack(bool solveFollows) {
     dBlkPartial_.reserve(std::max<size_t>(((hSlotBlk.size() + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup) * (size_t)(dC / 6) * 34, 1));
     // work list: per panel pair (I >= J; a panel is 16 pose blocks = 96 rows) the landmarks with slots in both panels, as ENTRIES
     // (first slot and count in either panel -- the slots of a panel are a run, they ascend with the pose), cut into workgroups of
-    // kBlkEntriesPerBlock; the pairs in the order k_reduce_panel_slabs expects (panelPairPtr)
+    // pair words (below); the pairs in the order k_reduce_panel_slabs expects (panelPairPtr)
     const int nPan = (dC + 95) / 96;
     nPanelPairs = nPan * (nPan + 1) / 2;
     std::vector<std::vector<int>> lists(nPanelPairs);   // four ints per entry: first slot in I, in J, counts, landmark
@@ -1805,41 +1815,68 @@ void Window::pack(bool solveFollows) {
         }
     }
     // ... and for k_schur_rows (kernels.hip), per panel pair: the sixteen block rows dealt to the kernel's eight waves (two each, by
-    // their pair counts, heaviest first), the entries cut into workgroups of kBlkEntriesPerBlock and those into BATCHES (records
+    // their pair counts, heaviest first, per workgroup), the entries cut into workgroups by pair words and those into BATCHES (records
     // staged in LDS at a time: at most kBlkBatchRecs, and at most kBlkBatchWords pair words per wave), and per batch and wave the
-    // PAIR WORDS in the order the wave works through them: A record | B record << 9 | pose block in J << 18, its first row's, then
+    // PAIR WORDS (pairWord below) in the order the wave works through them, its first row's, then
     // its second row's, each sorted by A record (entry, slot in I); the run of an A record is padded to an even length and a row's
-    // words to whole fours with pairs whose B operand is the zero record (the kernel takes the A record of words 2 j, 2 j + 1 from
+    // words to whole eights with pairs whose B operand is the zero record (the kernel takes the A record of words 2 j, 2 j + 1 from
     // word 2 j, and words 2 j, 2 j + 1 must name two accumulators).  A diagonal pair takes the blocks on and below the block diagonal.
+    // Workgroups: cut by PAIR WORDS (an entry of a pair of different panels has 17 pairs on the bench window of configs[3], one of a
+    // diagonal pair 12), so many that SVIN_BLK_ROUNDS (default 2) workgroups per place run one after the other -- two places per
+    // CU.  (900 workgroups of 256 entries: 181 us; one round of equal entry counts: 233 us, the heaviest workgroup is the kernel.)
+    // (pair word: twice the accumulator's number | byte offset of the B record in its LDS buffer << 8 | A record << 24 -- what the
+    // kernel needs with the fewest scalar instructions; a staged record is 160 bytes)
+    auto pairWord = [](int recA, int recB, int pb) { return (uint32_t)(2 * pb) | ((uint32_t)(recB * 160) << 8) | ((uint32_t)recA << 24); };
+    static_assert(kBlkBatchRecs <= 256 && kBlkBatchRecs * 160 < 65536, "pair word fields");
+    auto entryWords = [&](const int* en, bool dg) {
+      const int nA = en[2] & 0xff, nB = en[2] >> 8;
+      int wds = 0;
+      for (int ka = 0; ka < nA; ++ka) wds += ((dg ? ka + 1 : nB) + 1) & ~1;
+      return wds;
+    };
+    size_t wordsPerWg = 0;
+    {
+      size_t total = 0;
+      for (int I = 0; I < nPan; ++I)
+        for (int J = 0; J <= I; ++J) {
+          const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
+          for (size_t e = 0; e < li.size() / 4; ++e) total += entryWords(&li[4 * e], I == J);
+        }
+      const int rounds = debugOption(kOptBlkRounds) > 0 ? debugOption(kOptBlkRounds) : 2;
+      const size_t places = (size_t)std::max(1, rounds * 2 * deviceComputeUnits() - nPanelPairs);
+      wordsPerWg = std::max<size_t>(kBlkMinWordsPerBlock, (total + places - 1) / places);
+    }
     hPanelPairPtr.push_back(0);
     for (int I = 0; I < nPan; ++I)
       for (int J = 0; J <= I; ++J) {
         const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
         const size_t nEnt = li.size() / 4;
         const bool dg = I == J;
-        long rowLoad[16] = {0};
-        for (size_t e = 0; e < nEnt; ++e) {
-          const int fa = li[4 * e], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
-          for (int ka = 0; ka < nA; ++ka) rowLoad[hSlotBlk[fa + ka] - 16 * I] += dg ? ka + 1 : nB;
-        }
-        int rowOrder[16], ownerWave[16], ownerSel[16], ownRows[kBlkWaves][2];
-        long waveLoad[kBlkWaves] = {0};
-        for (int r = 0; r < 16; ++r) rowOrder[r] = r;
-        std::stable_sort(rowOrder, rowOrder + 16, [&](int a, int b) { return rowLoad[a] > rowLoad[b]; });
-        for (int wvv = 0; wvv < kBlkWaves; ++wvv) ownRows[wvv][0] = ownRows[wvv][1] = 255;
-        for (int k = 0; k < 16; ++k) {
-          const int r = rowOrder[k];
-          int best = -1;
+        for (size_t k = 0; k < nEnt;) {
+          size_t kEnd = k, wgWords = 0;
+          while (kEnd < nEnt && wgWords < wordsPerWg) wgWords += entryWords(&li[4 * kEnd++], dg);
+          // the workgroup's sixteen block rows dealt to its eight waves, two each: heaviest first, to the wave with the least so far
+          long rowLoad[16] = {0};
+          for (size_t e = k; e < kEnd; ++e) {
+            const int fa = li[4 * e], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
+            for (int ka = 0; ka < nA; ++ka) rowLoad[hSlotBlk[fa + ka] - 16 * I] += ((dg ? ka + 1 : nB) + 1) & ~1;
+          }
+          int rowOrder[16], ownerWave[16], ownerSel[16], ownRows[kBlkWaves][2];
+          long waveLoad[kBlkWaves] = {0};
+          for (int r = 0; r < 16; ++r) rowOrder[r] = r;
+          std::stable_sort(rowOrder, rowOrder + 16, [&](int a, int b) { return rowLoad[a] > rowLoad[b]; });
+          for (int wvv = 0; wvv < kBlkWaves; ++wvv) ownRows[wvv][0] = ownRows[wvv][1] = 255;
+          for (int kk = 0; kk < 16; ++kk) {
+            const int r = rowOrder[kk];
+            int best = -1;
+            for (int wvv = 0; wvv < kBlkWaves; ++wvv)
+              if (ownRows[wvv][1] == 255 && (best < 0 || waveLoad[wvv] < waveLoad[best])) best = wvv;
+            const int sel = ownRows[best][0] == 255 ? 0 : 1;
+            ownRows[best][sel] = r; ownerWave[r] = best; ownerSel[r] = sel; waveLoad[best] += rowLoad[r];
+          }
+          int ownWords[4] = {0, 0, 0, 0};
           for (int wvv = 0; wvv < kBlkWaves; ++wvv)
-            if (ownRows[wvv][1] == 255 && (best < 0 || waveLoad[wvv] < waveLoad[best])) best = wvv;
-          const int sel = ownRows[best][0] == 255 ? 0 : 1;
-          ownRows[best][sel] = r; ownerWave[r] = best; ownerSel[r] = sel; waveLoad[best] += rowLoad[r];
-        }
-        int ownWords[4] = {0, 0, 0, 0};
-        for (int wvv = 0; wvv < kBlkWaves; ++wvv)
-          ownWords[wvv >> 1] |= (ownRows[wvv][0] | (ownRows[wvv][1] << 8)) << (16 * (wvv & 1));
-        for (size_t k = 0; k < nEnt; k += kBlkEntriesPerBlock) {
-          const size_t kEnd = std::min(nEnt, k + kBlkEntriesPerBlock);
+            ownWords[wvv >> 1] |= (ownRows[wvv][0] | (ownRows[wvv][1] << 8)) << (16 * (wvv & 1));
           const int firstBatch = (int)(hBatch.size() / 2);
           size_t e = k;
           while (e < kEnd) {
@@ -1853,7 +1890,7 @@ void Window::pack(bool solveFollows) {
               int add[kBlkWaves] = {0};   // (every run of an A record is padded to an even number of words)
               for (int ka = 0; ka < nA; ++ka) add[ownerWave[hSlotBlk[fa + ka] - 16 * I]] += ((dg ? ka + 1 : nB) + 1) & ~1;
               bool fits = true;
-              for (int wvv = 0; wvv < kBlkWaves; ++wvv) fits = fits && (int)(words[wvv][0].size() + words[wvv][1].size()) + add[wvv] <= kBlkBatchWords - 4;
+              for (int wvv = 0; wvv < kBlkWaves; ++wvv) fits = fits && (int)(words[wvv][0].size() + words[wvv][1].size()) + add[wvv] <= kBlkBatchWords - 12;
               if (!fits) break;
               const int recA0 = recs, recB0 = dg ? recs : recs + nA;
               for (int ka = 0; ka < nA; ++ka) hRecSlot.push_back(fa + ka);
@@ -1866,19 +1903,19 @@ void Window::pack(bool solveFollows) {
                 int pb = 0;
                 for (int kb = 0; kb < cnt; ++kb) {
                   pb = hSlotBlk[fb + kb] - 16 * J;
-                  wl.push_back((uint32_t)(recA0 + ka) | ((uint32_t)(recB0 + kb) << 9) | ((uint32_t)pb << 18));
+                  wl.push_back(pairWord(recA0 + ka, recB0 + kb, pb));
                 }
                 // (padding word of the run: the zero record as B, an accumulator other than its partner's)
-                if (cnt & 1) wl.push_back((uint32_t)(recA0 + ka) | ((uint32_t)(kBlkBatchRecs - 1) << 9) | ((uint32_t)((pb + 1) & 15) << 18));
+                if (cnt & 1) wl.push_back(pairWord(recA0 + ka, kBlkBatchRecs - 1, (pb + 1) & 15));
               }
             }
             if (recs == 0) throw std::logic_error("k_schur_rows work list: an entry does not fit a batch");
             hBatch.insert(hBatch.end(), {firstRec, recs});
             for (int wvv = 0; wvv < kBlkWaves; ++wvv) {
-              for (int sel = 0; sel < 2; ++sel)   // (a row's words in fours: two more padding words -- both operands the zero record, two accumulators)
-                if (words[wvv][sel].size() % 4) {
-                  const uint32_t z = (uint32_t)(kBlkBatchRecs - 1) | ((uint32_t)(kBlkBatchRecs - 1) << 9);
-                  words[wvv][sel].push_back(z); words[wvv][sel].push_back(z | (1u << 18));
+              for (int sel = 0; sel < 2; ++sel)   // (a row's words in eights: padding words in twos -- both operands the zero record, two accumulators)
+                while (words[wvv][sel].size() % 8) {
+                  words[wvv][sel].push_back(pairWord(kBlkBatchRecs - 1, kBlkBatchRecs - 1, 0));
+                  words[wvv][sel].push_back(pairWord(kBlkBatchRecs - 1, kBlkBatchRecs - 1, 1));
                 }
               hWaveTab.insert(hWaveTab.end(), {(int)hPairWords.size(), (int)words[wvv][0].size(), (int)words[wvv][1].size(), 0});
               hPairWords.insert(hPairWords.end(), words[wvv][0].begin(), words[wvv][0].end());
@@ -1888,6 +1925,7 @@ void Window::pack(bool solveFollows) {
           hPanelWork.insert(hPanelWork.end(), {I, J, firstBatch, (int)(hBatch.size() / 2) - firstBatch});
           hEntries.insert(hEntries.end(), ownWords, ownWords + 4);   // (blkOwn: one int4 per workgroup)
           ++nPanelBlocks;
+          k = kEnd;
         }
         hPanelPairPtr.push_back(nPanelBlocks);
       }
