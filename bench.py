@@ -545,6 +545,10 @@ def summary_of(out):
         "config3_its": get("config3", "value"), "config4_its": get("config4_single_gpu", "value"),
         "config4_executed_over_algorithmic": get("config4_single_gpu", "roofline", "executed_over_algorithmic"),
         "sharded_config4_its": get("sharded_config4", "value"),
+        "sharded_allreduce_frac_of_link": get("sharded_config4", "allreduce_GBps", "frac_of_link"),
+        "sharded_allreduce_share_of_iteration": get("sharded_config4", "allreduce_us", "share_of_iteration"),
+        "sharded_k1_frac_per_gpu": get("sharded_config4", "k1_roofline_per_gpu", "frac"),
+        "sharded_speedup_vs_one_gpu": get("sharded_config4", "speedup_vs_one_gpu"),
         "config5_its": get("config5", "value"), "config5_6dof_its": get("config5_6dof", "value"),
         "sliding_ms": get("sliding_window", "ms_per_frame"), "sliding_spaced_ms": get("sliding_window", "frames_spaced", "ms_per_frame"),
         "sliding_optimize_call_ms": get("sliding_window", "frames_spaced", "ms", "optimize_call"),
@@ -684,6 +688,8 @@ def run_sharded_children(world, force_sharded, transport="rccl", steps=None):
 def main_sharded_child(args):
     """one rank of the sharded config-#4 sub-record (started by run_sharded_children)"""
     rank, world, local_rank, dist = init_distributed(args)
+    if os.environ.get("SVIN_BENCH_KILL_RANK") == str(rank):   # tests/test_gpu_multigpu.py: a rank that dies before the first collective
+        os._exit(17)
     try:
         rec = sharded_config4(rank, world, local_rank, dist, args.steps if args.steps != 30 else 20, 3)
     except Exception as ex:   # noqa: BLE001

@@ -3553,7 +3553,10 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       // the slot pass keeps up to four copies of its per-pose accumulators (one per 16-lane group of a wave: the four landmarks a
       // wave works on see the same poses, and four lanes adding to one address serialise) -- as many as 64 KB hold
       int nCopies = 4;
-      while (nCopies > 1 && (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8 > 76 * 1024) nCopies >>= 1;
+#ifndef SVIN_SLOT_COPIES_KB
+#define SVIN_SLOT_COPIES_KB 76
+#endif
+      while (nCopies > 1 && (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8 > SVIN_SLOT_COPIES_KB * 1024) nCopies >>= 1;
       const size_t ldsLm = (size_t)nCopies * (dC / 6) * kBlkPoseLd * 8;
       const int nSlotBlocks = (p.nSlots + kBlkSlotsPerWorkgroup - 1) / kBlkSlotsPerWorkgroup;
       hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);

@@ -122,7 +122,10 @@ constexpr int kBlkWaves = 8;
 constexpr int kBlkBatchRecs = 230;
 constexpr int kBlkBatchWords = 128;
 constexpr int kBlkRec = 18;                   // doubles per slot record: E_la (6 x 3), rec[6 k + row]
-constexpr int kBlkSlotsPerWorkgroup = 1024;   // slots (one thread each, four trips) per workgroup of k_blocks_slots
+#ifndef SVIN_SLOTS_PER_WG
+#define SVIN_SLOTS_PER_WG 1024
+#endif
+constexpr int kBlkSlotsPerWorkgroup = SVIN_SLOTS_PER_WG;   // slots (one thread each, four trips) per workgroup of k_blocks_slots
 constexpr int kBlkMaxPoseBlocks = 512;      // the per-pose accumulators of k_blocks_slots live in LDS (28 doubles per pose block)
 
 struct DeviceProblem {

@@ -78,18 +78,53 @@ def test_reprojection_residuals_and_jacobians(gpu_lib, model, dist, robust):
     assert worst["r"] < 1e-9 and worst["Jp"] < 1e-10 and worst["Jl"] < 1e-10 and worst["Je"] < 1e-10
 
 
-def check_small_factors(gpu, cpu, expect_kinds, n_sonar=None):
-    """every non-reprojection factor of the window: residual, stacked minimal Jacobian, J^T J, J^T r against the oracle"""
+def oracle_imu_sensitivity(cpu, frames, rids):
+    """How far do the weighted quantities of the IMU factors (chi^2 = r^T r, J^T J, J^T r: what the solver consumes) move when the
+    ORACLE's own states move by a few units of the last place?  r and J are scaled by the Cholesky factor of the inverse of the
+    propagated 15 x 15 covariance, whose condition number (1e8 ... 1e10 with the rigs' noise densities) multiplies every rounding
+    error on the way: two correct double-precision implementations that invert P differently (Eigen's LLT solve in the reference,
+    ImuError.cpp:562-564; a tile Cholesky and triangular solves on the device) agree to about that amplification, not to 1e-16.
+    Returns per residual id the relative change of (chi^2, J^T J) and the change of J^T r in units of the column norms of J."""
+    m = cpu.map()
+    base = {rid: m.eval(rid) for rid in rids}
+    saved = [(f, cpu.get_T_WS(f).copy(), cpu.get_speed_and_bias(f).copy()) for f in frames]
+    rng = np.random.default_rng(12)
+    for f, T, sb in saved:
+        T2 = T.copy()
+        T2[:3] *= 1.0 + 4e-16 * rng.normal(size=3)
+        T2[3:] += 4e-16 * rng.normal(size=4)
+        T2[3:] /= np.linalg.norm(T2[3:])
+        assert cpu.set_T_WS(f, T2) and cpu.set_speed_and_bias(f, sb * (1.0 + 4e-16 * rng.normal(size=9)))
+    out = {}
+    for rid in rids:
+        r, _, Jm = base[rid]
+        r2, _, Jm2 = m.eval(rid)
+        J, J2 = np.concatenate(Jm, axis=1), np.concatenate(Jm2, axis=1)
+        cn = np.sqrt(np.maximum(np.sum(J * J, axis=0), 1e-300))
+        out[rid] = (abs(float(r2 @ r2) - float(r @ r)) / max(float(r @ r), 1e-300), rel(J2.T @ J2, J.T @ J),
+                    float(np.max(np.abs(J2.T @ r2 - J.T @ r) / cn)))
+    for f, T, sb in saved:
+        assert cpu.set_T_WS(f, T) and cpu.set_speed_and_bias(f, sb)
+    return out
+
+
+def check_small_factors(gpu, cpu, expect_kinds, n_sonar=None, oracle_frames=None):
+    """every non-reprojection factor of the window: residual, stacked minimal Jacobian, J^T J, J^T r against the oracle.  The rows of
+    an IMU factor are compared loosely (1e-6: they carry the square root of an ill-conditioned information matrix, and a Cholesky
+    factor is only defined up to the rounding of the matrix it factors); what is HELD for them are the weighted invariants the
+    solver consumes -- chi^2, J^T J, J^T r -- at 1e-10 or, where the oracle itself moves more than that under a last-place change
+    of its states, at 50 x that measured sensitivity (oracle_imu_sensitivity; needs `oracle_frames`)."""
     m = cpu.map()
     facs = gpu.eval_factors()
     assert len(facs) > 0
+    sens = oracle_imu_sensitivity(cpu, oracle_frames, [f["res_id"] for f in facs if f["kind"] == 0]) if oracle_frames is not None else {}
     kinds, count = set(), {}
     for f in facs:
         r, Js, Jm = m.eval(f["res_id"])
         J = np.concatenate(Jm, axis=1)
         kinds.add(f["kind"])
         count[f["kind"]] = count.get(f["kind"], 0) + 1
-        tol = {0: 1e-6, 3: 1e-8}.get(f["kind"], 1e-10)  # IMU: different 15x15 inverse; relpose: 1e8-scale weights
+        tol = {0: 1e-6, 3: 1e-8}.get(f["kind"], 1e-10)  # IMU: different 15x15 inverse (see above); relpose: 1e8-scale weights
         dr = np.max(np.abs(f["r"] - r)) / max(1.0, np.max(np.abs(r)))
         dJ = np.max(np.abs(f["J"] - J)) / max(1.0, np.max(np.abs(J)))
         # weighting-independent invariants
@@ -103,6 +138,13 @@ def check_small_factors(gpu, cpu, expect_kinds, n_sonar=None):
         assert dr < tol and dJ < tol, (f["kind"], dr, dJ)
         assert dH < 1e-7
         assert dg < 1e-8 * max(1.0, float(np.max(np.abs(r)))), (f["kind"], dg)
+        if f["kind"] == 0 and f["res_id"] in sens:
+            s_chi, s_H, s_g = sens[f["res_id"]]
+            dchi = abs(float(f["r"] @ f["r"]) - float(r @ r)) / max(float(r @ r), 1e-300)
+            log("  IMU factor invariants: chi^2", dchi, "(oracle sensitivity %.1e)" % s_chi, "J^T J", dH, "(%.1e)" % s_H, "J^T r / sigma", dg, "(%.1e)" % s_g)
+            assert dchi < max(1e-10, 50 * s_chi), (dchi, s_chi)
+            assert dH < max(1e-10, 50 * s_H), (dH, s_H)
+            assert dg < max(1e-10, 50 * s_g) * max(1.0, float(np.max(np.abs(r)))), (dg, s_g)
     assert expect_kinds.issubset(kinds), kinds
     if n_sonar is not None:
         assert count.get(4, 0) == n_sonar, count
@@ -114,7 +156,7 @@ def test_small_factors_parity(gpu_lib):
     rig-v2 window: every frame carries a sonar return whose visual patch exists (U4, Estimator.cpp:265-316)"""
     spec = syn.make_window(P=4, L=300, n_obs=2500, seed=5, rig="rig_v2", sonar=True, depth=True)
     gpu, cpu, fg, fc, lg, lc = make_pair(spec)
-    count = check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
+    count = check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P, oracle_frames=fc)
     assert count[5] == spec.P
     # the same factors after the states have moved (the patch stays what it was at construction, SonarError.cpp:66);
     # both sides evaluate at the ORACLE's optimised states, so that the comparison stays one of the evaluation
@@ -124,6 +166,10 @@ def test_small_factors_parity(gpu_lib):
         assert gpu.set_T_WS(a, cpu.get_T_WS(b)) and gpu.set_speed_and_bias(a, cpu.get_speed_and_bias(b))
         for c in (0, 1):
             assert gpu.set_camera_sensor_states(a, c, cpu.get_camera_sensor_states(b, c))
+    # (no 1e-10 invariants here: each side re-integrates its IMU factors when ITS bias estimate has moved far enough from the
+    # linearisation point of the pre-integration (ImuError.cpp:581-592), so after three iterations of two solvers the two factors
+    # are first-order expansions around slightly different biases -- chi^2 differs by 2e-11, J^T r by 6e-10 sigma, measured --
+    # a second-order effect of the reference's own algorithm, not rounding)
     check_small_factors(gpu, cpu, {0, 1, 2, 3, 4, 5}, n_sonar=spec.P)
 
 
@@ -1004,7 +1050,7 @@ def test_marginalization_large_prior_per_frame_extrinsics(gpu_lib):
     assert mg is not None and mg["n"] == mc["n"] and mg["n"] > 96, mg["n"]
     o = compare_priors(mg, mc, "rig v2 5+3 sequence prior")
     log("prior cost offset |e0|^2 gpu", float(mg["e0"] @ mg["e0"]), "oracle", float(mc["e0"] @ mc["e0"]))
-    assert o["selfH"] < 1e-9 and o["dH"] < 1e-2 and o["dJtJ"] < 1e-2     # the priors differ as the linearisation points do
+    assert o["selfH"] < 1e-9 and o["dH"] < 1e-2 and o["dJtJ"] < 1e-2     # the priors differ as the linearisation points do (bound derived below)
     gf, cf = gpu.frame_ids(), cpu.frame_ids()
     worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(gf, cf))
     # How far apart may two CORRECT double-precision implementations end on this sequence?  The oracle against itself,
@@ -1020,6 +1066,9 @@ def test_marginalization_large_prior_per_frame_extrinsics(gpu_lib):
     sens = max(pose_diff(cpu2.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(cpu2.frame_ids(), cf))
     log("rig v2 5+3: final window pose difference GPU vs oracle", worst, "; oracle vs oracle with landmarks moved by 1e-13 m", sens)
     assert worst < max(1e-4, 30 * sens) and worst < 5e-3
+    # ... and the same yardstick for the PRIOR: the perturbed oracle's last prior against the oracle's
+    o2 = compare_priors(cpu2.marg(), mc, "rig v2 5+3 sequence prior, oracle with landmarks moved by 1e-13 m vs oracle")
+    assert o["dH"] < max(1e-9, 30 * o2["dH"]) and o["dJtJ"] < max(1e-9, 30 * o2["dJtJ"]), (o["dH"], o2["dH"], o["dJtJ"], o2["dJtJ"])
 
 
 def test_marginalization_sequence_euroc_reference_window(gpu_lib):
@@ -1042,6 +1091,14 @@ def test_marginalization_sequence_euroc_reference_window(gpu_lib):
     assert mg is not None and mc is not None and mg["n"] == mc["n"]
     o = compare_priors(mg, mc, "euroc 5+3 sequence prior")
     assert o["selfH"] < 1e-9 and o["dH"] < 1e-2 and o["dJtJ"] < 1e-2
+    # the bound above is a ceiling; the yardstick is how far the ORACLE's prior moves when its initial landmarks move by 1e-13 m
+    # (thirteen optimise + marginalise steps amplify the linearisation points' rounding): the GPU stays within 30 x that
+    spec2 = syn.make_window(P=13, L=300, n_obs=3500, seed=46, rig="euroc", keyframe_every=2, frame_dt=0.3)
+    spec2.lm_init[:, :3] += 1e-13 * np.random.default_rng(1).normal(size=(spec2.L, 3))
+    cpu2 = orc.OracleEstimator()
+    run_sequence(cpu2, spec2, 5, 3, 10)
+    o2 = compare_priors(cpu2.marg(), mc, "euroc 5+3 sequence prior, oracle with landmarks moved by 1e-13 m vs oracle")
+    assert o["dH"] < max(1e-9, 30 * o2["dH"]) and o["dJtJ"] < max(1e-9, 30 * o2["dJtJ"]), (o["dH"], o2["dH"], o["dJtJ"], o2["dJtJ"])
     worst = max(pose_diff(gpu.get_T_WS(a), cpu.get_T_WS(b)) for a, b in zip(gpu.frame_ids(), cpu.frame_ids()))
     worst_sb = max(float(np.max(np.abs(gpu.get_speed_and_bias(a) - cpu.get_speed_and_bias(a)))) for a in gpu.frame_ids() if gpu.is_in_imu_window(a))
     log("euroc 5+3: final window pose difference", worst, "speed/bias", worst_sb)
