@@ -431,6 +431,51 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
     return rec
 
 
+def batched_record(device, sizes=(16, 64), steps=12, warmup=3):
+    """B independent configs[1] windows (their own seeds) through svin_ba_solve_prepared_batch: ONE launch sequence per trust-region
+    round, the window as a grid dimension ("independent replicas processing different windows", on one GPU).  Per step
+    every window starts from its own initial state, is packed and uploaded untimed (inputs resident in HBM), and the batch call is
+    timed; aggregate = the iterations of all windows per step / that time.  `one_window` = the same measurement with B = 1 (the
+    ordinary path: a batch of one is not batched)."""
+    import torch
+    from svin_amd import estimator as E
+    from svin_amd import synthetic as syn
+    from svin_amd.estimator import Estimator
+    out = {"unit": "GN iterations/s", "workload": "B configs[1] windows (10 KF / 2000 landmarks / 20000 residuals, seeds 20250629 + 7 k), optimize(10) per step"}
+    B_max = max(sizes)
+    ws = []
+    for k in range(B_max):
+        spec = syn.make_window(seed=20250629 + 7 * k)
+        est = Estimator(device)
+        fids, lids = syn.feed(est, spec)
+        ws.append((est, fids, lids, snapshot_init(est, fids, lids, spec)))
+    for B in (1,) + tuple(sizes):
+        times, its, nb = [], [], 0
+        for k in range(warmup + steps):
+            for est, fids, lids, snap in ws[:B]:
+                reset_state(est, fids, lids, snap)
+                est.prepare()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nb = E.solve_prepared_batch([w[0] for w in ws[:B]], 10)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            n_it = sum(w[0].summary()["iterations"] for w in ws[:B])
+            for w in ws[:B]:
+                w[0].finish()
+            if k >= warmup:
+                times.append(dt)
+                its.append(n_it)
+        rec = {"aggregate": sum(its) / sum(times), "windows_batched": nb, "ms_per_step": 1e3 * sum(times) / len(times),
+               "iterations_per_step": sum(its) / len(its), "us_per_window_iteration": 1e6 * sum(times) / sum(its)}
+        if B == 1:
+            out["one_window"] = rec
+        else:
+            rec["x_one_window"] = rec["aggregate"] / out["one_window"]["aggregate"]
+            out["B%d" % B] = rec
+    return out
+
+
 def concurrent_record(device, n_handles=8, steps=12):
     """SVIn runs the estimator and pose_graph side by side (okvis_ros/launch/svin_stereorig_v2.xml:17-34): one svin_ba handle
     working through the sliding window while one svin_pg handle optimises the configs[4] graph from another thread, each on its
@@ -562,6 +607,8 @@ def summary_of(out):
         "handles8_aggregate_its": get("concurrent", "handles_8", "aggregate"),
         "handles8_x": (round(out["concurrent"]["handles_8"]["aggregate"] / out["concurrent"]["handles_8"]["one_handle_alone"], 3)
                        if get("concurrent", "handles_8", "aggregate") and get("concurrent", "handles_8", "one_handle_alone") else None),
+        "batched16_aggregate_its": get("batched", "B16", "aggregate"), "batched16_x": get("batched", "B16", "x_one_window"),
+        "batched64_aggregate_its": get("batched", "B64", "aggregate"), "batched64_x": get("batched", "B64", "x_one_window"),
         "k1_frac_b2b": get("roofline", "frac"), "k1_frac_survey_bytes": get("roofline", "frac_survey_bytes"),
         "k1_frac_4GB": get("roofline", "replicas_1024", "frac"),
         "pcie_inclusive_its": get("config", "pcie_inclusive", "value"),
@@ -888,6 +935,10 @@ def main():
                 extras["concurrent"] = concurrent_record(local_rank)
             except Exception as ex:
                 extras["concurrent"] = {"error": repr(ex)}
+            try:
+                extras["batched"] = batched_record(local_rank)
+            except Exception as ex:
+                extras["batched"] = {"error": repr(ex)}
         if rank == 0:
             try:
                 pg = posegraph_record(argparse.Namespace(six_dof=False), 0, 1, local_rank, None, 2, 1, cpu=not args.no_cpu_baseline)

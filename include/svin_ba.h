@@ -151,6 +151,16 @@ int svin_ba_apply_marginalization_strategy(svin_ba* h, uint64_t num_keyframes, u
 int svin_ba_prepare(svin_ba* h);
 int svin_ba_solve_prepared(svin_ba* h, uint64_t num_iter, int verbose);
 int svin_ba_finish(svin_ba* h);
+/* SEVERAL windows at once (the reference has no counterpart: okvis::Estimator::optimize, Estimator.cpp:876-929, is one window per
+ * call and ThreadedKFVio runs one estimator; SURVEY 8(e) names "independent replicas processing different windows" as the other
+ * way to fill the hardware).  Handles of ONE device; windows with the same launch geometry (numbers of states, landmarks,
+ * observations and factors) that the LDS-resident solver takes (reduced system of at most 176 rows, no marginalisation-only
+ * restrictions) share one launch sequence per trust-region round, the window as a grid dimension; the others -- and a window
+ * without a partner -- are optimised one after the other by the ordinary path.  Every window ends exactly (bit for bit) where
+ * svin_ba_optimize / svin_ba_solve_prepared would leave it on its own; *n_batched (may be NULL) = windows that ran in a batch.
+ * solve_prepared_batch expects svin_ba_prepare on every handle (measurement form); optimize_batch = prepare, solve, finish. */
+int svin_ba_solve_prepared_batch(svin_ba* const* handles, int n, uint64_t num_iter, int verbose, int* n_batched);
+int svin_ba_optimize_batch(svin_ba* const* handles, int n, uint64_t num_iter, int verbose, int* n_batched);
 /* forces every IMU factor to re-preintegrate at its next evaluation (ImuError::redo_ = true) */
 int svin_ba_invalidate_preintegration(svin_ba* h);
 int svin_ba_get_summary(svin_ba* h, svin_summary* out);

@@ -169,6 +169,33 @@ int svin_ba_solve_prepared(svin_ba* h, uint64_t num_iter, int verbose) {
   GUARD_BEGIN return h->w.solvePrepared(num_iter, verbose != 0);
   GUARD_END(SVIN_ERR_DEVICE)
 }
+int svin_ba_solve_prepared_batch(svin_ba* const* hs, int n, uint64_t num_iter, int verbose, int* n_batched) {
+  if (n_batched) *n_batched = 0;
+  if (n < 0 || (n > 0 && !hs)) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+    std::vector<svin::Window*> ws((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      if (!hs[i]) return SVIN_ERR_INVALID_ARG;
+      ws[(size_t)i] = &hs[i]->w;
+    }
+    return svin::Window::solvePreparedBatch(ws.data(), n, num_iter, verbose != 0, n_batched);
+  GUARD_END(SVIN_ERR_DEVICE)
+}
+int svin_ba_optimize_batch(svin_ba* const* hs, int n, uint64_t num_iter, int verbose, int* n_batched) {
+  if (n_batched) *n_batched = 0;
+  if (n < 0 || (n > 0 && !hs)) return SVIN_ERR_INVALID_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!hs[i]) return SVIN_ERR_INVALID_ARG;
+  GUARD_BEGIN
+    for (int i = 0; i < n; ++i) hs[i]->w.prepare();
+  GUARD_END(SVIN_ERR_DEVICE)
+  const int rc = svin_ba_solve_prepared_batch(hs, n, num_iter, verbose, n_batched);
+  if (rc != 1) return rc;
+  GUARD_BEGIN
+    for (int i = 0; i < n; ++i) hs[i]->w.finish();
+    return 1;
+  GUARD_END(SVIN_ERR_DEVICE)
+}
 int svin_ba_finish(svin_ba* h) {
   if (!h) return SVIN_ERR_INVALID_ARG;
   GUARD_BEGIN return h->w.finish();

@@ -267,7 +267,7 @@ __device__ __forceinline__ double blockSumK(const double (&v)[K], double* red, i
 // is published from registers (no store -> fence -> re-load of the freshly written cost fields).  `red`: >= 72 doubles.
 // nDefer > 0: the reprojection blocks also took the landmark half of the fused step; their step / state norm partials are
 // added to the (block-only) sums k_post_solve left in the record.
-__device__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, int nDefer = 0) {
+__device__ __forceinline__ void reduceCost(const DeviceProblem& p, int nA, int nB, double* red, int nDefer = 0) {
   const int t = threadIdx.x;
   constexpr int nD = (int)(sizeof(SolverScalars) / sizeof(double));
   static_assert(nD <= 64, "SolverScalars must fit one wave-wide store");
@@ -1380,7 +1380,7 @@ __device__ __forceinline__ int blockOff(const DeviceProblem& p, int kind, int sl
   return p.sbOff[slot];
 }
 
-__device__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorShared& sh) {
+__device__ __forceinline__ void evalFactorBlock(const DeviceProblem& p, int cand, int f, FactorShared& sh) {
   const int t = threadIdx.x;
   const DevFactor& fac = p.factors[f];
   FactorLin& lin = (cand ? p.linCand : p.linCur)[f];
@@ -1708,7 +1708,7 @@ int costSummedBy(const DeviceProblem& p) {
 // cost = 0.5 c0 + bp^T dchi + 0.5 dchi^T Ht dchi ;  grad (lin space) = bp + Ht dchi
 // Ceres multiplies the ambient Jacobian (J_min * lift(x_lin)) by PlusJacobian(x): for a pose block the
 // effective tangent map is M = blockdiag(I3, oplus(q_cur * q_lin^-1)[0:3,0:3]) (MarginalizationError.cpp:798-844).
-__device__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
+__device__ __forceinline__ void priorEvalBlock(const DeviceProblem& p, int cand, double* red) {
   const int t = threadIdx.x, m = p.priorM;
   double* priorDchi = cand ? p.priorDchiC : p.priorDchi;
   double* priorGrad = cand ? p.priorGradC : p.priorGrad;
@@ -1770,7 +1770,7 @@ void launchEvalPrior(const DeviceProblem& p, bool cand, hipStream_t s, bool sumC
 // in one launch, plus one block for the marginalisation prior (hasPrior); the block that finishes last sums the cost
 // (sumCost) and publishes the scalars.
 template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost, int hasPrior) {
+__device__ __forceinline__ void k_eval_all_body(const DeviceProblem& p, int cand, int nR, int sumCost, int hasPrior) {
   __shared__ FactorShared sh;
   const int F = (int)gridDim.x - nR - hasPrior;
   if ((int)blockIdx.x < F) {
@@ -1814,6 +1814,66 @@ __global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int
       if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
       TRACE(20);
     }
+  }
+}
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_all(DeviceProblem p, int cand, int nR, int sumCost, int hasPrior) { k_eval_all_body<WITH_EXT>(p, cand, nR, sumCost, hasPrior); }
+// The slot of this block's window.  The table is written by the host's copy before the launch and by nothing afterwards, so it is
+// read through the CONSTANT address space like the kernel arguments it replaces: every field stays a scalar load the compiler may
+// repeat wherever it likes.  Through a plain global pointer the loads behind the first barrier go through the vector memory path
+// into VGPRs (k_eval_all_batch: 407 registers and 976 bytes of scratch where k_eval_all has 348 and none).
+__device__ __forceinline__ const BatchSlot& batchSlot(const BatchSlot* slots) {
+  typedef const BatchSlot __attribute__((address_space(4))) * ConstantSlot;
+  return *(const BatchSlot*)(ConstantSlot)(slots + blockIdx.y);
+}
+// Batched form (blockIdx.y = the window of the batch, its problem from the slot table), as TWO launches: k_eval_all sizes every
+// block for the factor blocks' 131 KB of LDS (one workgroup per CU) and for the registers of the IMU chain; with B windows in the
+// grid the reprojection blocks are what fills the chip, so they get a kernel of their own (staging area only, registers of
+// evalReprojBlock alone) and the factor / prior blocks follow with the cost sum.  Same device functions, same partial slots,
+// same summation order as k_eval_all: a window's numbers do not change.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_reproj_batch(const BatchSlot* __restrict__ slots, int cand) {
+  extern __shared__ double smem[];
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchEval)) return;
+  const DeviceProblem& p = sl.p;
+  SVIN_ARGS(SA(p.poseC), SA(p.pose), SA(p.extC), SA(p.ext), SA(p.lm), SA(p.lmC), SA(p.cams), SA(p.obsUv), SA(p.obsW), SA(p.obsIdx),
+            SA(p.obsLm), SA(p.rCand), SA(p.JpCand), SA(p.JlCand), SA(p.partial), SA(p.scal), SA(p.vL), SA(p.yL), SA(p.lmPtr), SA(p.N),
+            SA(p.nPose), SA(p.nExt), SA(p.nCam));
+  const bool defer = cand && p.lmDeferred;
+  LmDefer df;
+  if (defer) {
+    df.on = 1;
+    df.cg = p.scal->spareA0; df.cn = p.scal->spareA1;
+    df.vL = p.vL; df.yL = p.yL; df.lmPtr = p.lmPtr; df.lmC = p.lmC;
+    df.stepPartial = p.partial + (size_t)PS_STEP * kMaxPartials;
+    df.xPartial = p.partial + (size_t)PS_XNORM * kMaxPartials;
+  }
+  evalReprojBlock<true, WITH_EXT>(blockIdx.x, smem + 48, smem, p.N, p.nPose, p.nExt, p.nCam, cand ? p.poseC : p.pose,
+                                  cand ? p.extC : p.ext, defer ? p.lm : (cand ? p.lmC : p.lm), p.cams, p.obsUv, p.obsW, p.obsIdx, p.obsLm,
+                                  cand ? p.rCand : p.rCur, cand ? p.JpCand : p.JpCur, cand ? p.JlCand : p.JlCur,
+                                  cand ? p.JeCand : p.JeCur, p.partial + (size_t)PS_COST_REPROJ * kMaxPartials, (size_t)p.N,
+                                  df, p.lmPrior);
+}
+// blocks [0, F): the small factors, block F (hasPrior): the marginalisation prior; the block that finishes last sums the cost
+__global__ __launch_bounds__(256) void k_eval_rest_batch(const BatchSlot* __restrict__ slots, int cand, int nR, int hasPrior) {
+  __shared__ FactorShared sh;
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchEval)) return;
+  const DeviceProblem& p = sl.p;
+  const int F = (int)gridDim.x - hasPrior;
+  if ((int)blockIdx.x < F) {
+    SVIN_ARGS(SA(p.factors), SA(p.imus), SA(p.linCand), SA(p.linCur), SA(p.poseC), SA(p.pose), SA(p.sbC), SA(p.sb), SA(p.extC), SA(p.ext),
+              SA(p.poseOff), SA(p.sbOff), SA(p.extOff), SA(p.partial), SA(p.imuT), SA(p.imuMeas));
+    evalFactorBlock(p, cand, blockIdx.x, sh);
+  } else {
+    priorEvalBlock(p, cand, reinterpret_cast<double*>(&sh));
+  }
+  __shared__ int lastFlag;
+  __shared__ double red4[72];
+  if (lastBlockDoneLight(&p.tickets[TK_EVAL], &lastFlag)) {   // (cost partials and costPrior are cstore()d; the reprojection partials: previous launch)
+    reduceCost(p, nR, F, red4, (cand && p.lmDeferred) ? nR : 0);
+    if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
   }
 }
 
@@ -2193,8 +2253,8 @@ __host__ __device__ constexpr int denseObsBatch(int rows) { return rows <= 128 ?
 // NW: waves per workgroup.  The landmark part always runs on the first 256 threads (16 lanes x 16 landmarks); with NW = 8 the
 // tiles are dealt over twice as many waves (clear, merge, products and slab stores take half as long per wave, and 10 tiles
 // per wave stay in registers where 20 spill).
-template <int MAXT, bool A_MFMA, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
+template <int MAXT, bool A_MFMA, int NW>
+__device__ __forceinline__ void k_schur_dense_body(const DeviceProblem& p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) {
   static_assert(A_MFMA || NW == 4, "the per-wave block copies of A exist for four waves");
   extern __shared__ double smem[];
   const int t = threadIdx.x, b = blockIdx.x;
@@ -2597,6 +2657,16 @@ __global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double
   }
 #endif
 }
+template <int MAXT, bool A_MFMA, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) { k_schur_dense_body<MAXT, A_MFMA, NW>(p, mu, initScale, nChunkBlocks, nFacBlocks); }
+// (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
+template <int MAXT, bool A_MFMA, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_schur_dense_batch(const BatchSlot* __restrict__ slots, int nChunkBlocks, int nFacBlocks) {
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchFull)) return;
+  k_schur_dense_body<MAXT, A_MFMA, NW>(sl.p, sl.mu, sl.initScale, nChunkBlocks, nFacBlocks);
+}
+
 
 // ---------------------------------------------------------------- Gram-matrix Schur complement for WIDE windows
 // dC > 254 rows do not fit one block's accumulator tiles, so the camera matrix is cut into panels of kPanelRows = 96
@@ -3384,7 +3454,7 @@ __global__ __launch_bounds__(256) void k_reduce_panel_slabs(DeviceProblem p) {
 // S += reduce(slabs) (block-upper data mirrored), vectors += reduce(slab vectors)
 // 16 entries x 16 slab-partitions per 256-thread block; fixed summation order -> deterministic
 constexpr int kSlabParts = 16;
-__global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
+__device__ __forceinline__ void k_reduce_slabs_body(const DeviceProblem& p) {
   __shared__ double part[256];
   SVIN_ARGS(SA(p.slabs), SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.nSlabs), SA(p.dC), SA(p.ldS));
   const int dC = p.dC;
@@ -3435,6 +3505,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_reduce_slabs(DeviceProblem p) { k_reduce_slabs_body(p); }
+// (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
+__global__ __launch_bounds__(256) void k_reduce_slabs_batch(const BatchSlot* __restrict__ slots) {
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchFull)) return;
+  k_reduce_slabs_body(sl.p);
+}
+
 // camera-column metric (Jacobi scaling fixed at iteration 0): returns the damping mu*htil for row i
 __device__ __forceinline__ double finalizeRow(const DeviceProblem& p, int i, double mu, int initScale) {
   double sc;
@@ -3507,25 +3585,38 @@ void launchZeroBuild(const DeviceProblem& p, hipStream_t s) {
 }
 // zeroFirst = false: the accumulators are already clear (pack() clears them, and k_post_solve clears them again
 // for the next linearisation of the trust-region loop)
+// the dense Gram-matrix form (k_schur_dense): variant, LDS size and DeviceProblem::aBlocks for a window's geometry
+struct DenseSchurPlan { int nTr; bool aMfma, aBlocks; size_t ldsBytes; };
+static DenseSchurPlan denseSchurPlan(const DeviceProblem& p) {
+  const int dC = p.dC;
+  DenseSchurPlan q;
+  q.nTr = (dC + 2 + 15) / 16;
+  const int rows = 16 * q.nTr;
+  q.aMfma = p.anyExtVariable || q.nTr > 8;
+  // A on the MFMA path needs a fill / barrier / clear round per batch of observations; when the blocks of A fit LDS
+  // next to G they are accumulated directly (LDS atomics) and merged into the accumulator tiles once per chunk
+  const int nPB = p.dCPose / 6, nEB = dC / 6 - nPB;
+  const size_t blocksExtra = (size_t)(dC / 6) * kPoseAcc + (size_t)nEB * nPB * 36;
+  const bool forceU = optOn(kOptSchurAMfma);
+  q.aBlocks = q.aMfma && !forceU && ((size_t)rows * kDenseLd + blocksExtra) * 8 <= 150 * 1024;
+  const size_t extra = q.aBlocks ? blocksExtra : (q.aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc);
+  q.ldsBytes = ((size_t)rows * kDenseLd + extra) * 8;
+  return q;
+}
+int schurDenseABlocks(const DeviceProblem& p) { return (p.L > 0 && p.N > 0 && p.dC > 0 && p.schurDense && denseSchurPlan(p).aBlocks) ? 1 : 0; }
 void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst) {
   const int dC = p.dC;
   if (zeroFirst) launchZeroBuild(p, s);
   const int nFac = p.F;   // this rank's factors
   const int nPri = priorAccBlocks(p);  // the prior rides along as extra blocks of the same launch
   if (p.L > 0 && p.N > 0 && dC > 0 && p.schurDense) {
-    const int nTr = (dC + 2 + 15) / 16, rows = 16 * nTr;
-    const bool aMfma = p.anyExtVariable || nTr > 8;
-    // A on the MFMA path needs a fill / barrier / clear round per batch of observations; when the blocks of A fit LDS
-    // next to G they are accumulated directly (LDS atomics) and merged into the accumulator tiles once per chunk
-    const int nPB = p.dCPose / 6, nEB = dC / 6 - nPB;
-    const size_t blocksExtra = (size_t)(dC / 6) * kPoseAcc + (size_t)nEB * nPB * 36;
-    const bool forceU = optOn(kOptSchurAMfma);
-    const bool aBlocks = aMfma && !forceU && ((size_t)rows * kDenseLd + blocksExtra) * 8 <= 150 * 1024;
-    const size_t extra = aBlocks ? blocksExtra : (aMfma ? (size_t)rows * (2 * denseObsBatch(rows) + 1) : (size_t)4 * (dC / 6) * kPoseAcc);
-    const size_t ldsBytes = ((size_t)rows * kDenseLd + extra) * 8;
+    const DenseSchurPlan plan = denseSchurPlan(p);
+    const int nTr = plan.nTr;
+    const bool aMfma = plan.aMfma;
+    const size_t ldsBytes = plan.ldsBytes;
     const dim3 grid(p.nSlabs + nFac + nPri);
     DeviceProblem pb = p;
-    pb.aBlocks = aBlocks ? 1 : 0;
+    pb.aBlocks = plan.aBlocks ? 1 : 0;
 #define LAUNCH(MAXT, E, NWV)                                                                                        \
   do {                                                                                                              \
     ensureDynamicLds((const void*)k_schur_dense<MAXT, E, NWV>, ldsBytes); \
@@ -3703,8 +3794,7 @@ constexpr int kBorderMP = 32, kBorderOffLinv = kBorderMP * kBorderLdV, kBorderOf
               kBorderOffG = kBorderOffQ + kBorderMP /* g1 - B^T q, 176 */, kBorderOffMask = kBorderOffG + kBorderLdV /* 16: tile column J of V is not zero */,
               kBorderScratchDoubles = kBorderOffMask + 16;
 template <int kBorder>
-__global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale,
-                                                                    int fuseFinalize, int border, const double* bscr) {
+__device__ __forceinline__ void k_chol_solve_lds_body(const DeviceProblem& p, int dpad, double mu, int initScale, int fuseFinalize, int border, const double* bscr) {
   extern __shared__ double smem[];
   SVIN_ARGS(SA(p.S), SA(p.gRed), SA(p.gFull), SA(p.hC), SA(p.scaleC), SA(p.htilC), SA(p.yC), SA(p.vC), SA(p.scal), SA(p.d), SA(p.ldS),
             SA(p.sPadded), SA(dpad), SA(mu), SA(initScale), SA(fuseFinalize));
@@ -4624,6 +4714,16 @@ __global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu
 #undef CHOL_STAMP
 #undef CHOL_STAMP_FINE
 }
+template <int kBorder>
+__global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds(DeviceProblem p, int dpad, double mu, int initScale, int fuseFinalize, int border, const double* bscr) { k_chol_solve_lds_body<kBorder>(p, dpad, mu, initScale, fuseFinalize, border, bscr); }
+// (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
+template <int kBorder>
+__global__ __launch_bounds__(kCholLdsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chol_solve_lds_batch(const BatchSlot* __restrict__ slots, int dpad, int fuseFinalize, int border, const double* bscr) {
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchFull)) return;
+  k_chol_solve_lds_body<kBorder>(sl.p, dpad, sl.mu, sl.initScale, fuseFinalize, border, bscr);
+}
+
 
 // ================================================================ K6': reduced systems beyond the LDS-resident solver
 // Blocked Cholesky over 64x64 blocks on many workgroups (d > 272, wide windows).  The right-hand side rides along as one
@@ -6570,7 +6670,7 @@ __device__ __forceinline__ void retractItem(const DeviceProblem& p, int i, doubl
 
 // stand-alone dogleg step + retraction (re-used linearisation after a rejected step, multi-GPU mode, wide windows);
 // the last block reduces the norms
-__global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) {
+__device__ __forceinline__ void k_step_retract_body(const DeviceProblem& p, double radius) {
   __shared__ double red[16 * 2];
   __shared__ int lastFlag;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -6593,6 +6693,14 @@ __global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double ra
   if (threadIdx.x == 1) p.scal->xNormSq = tot;
   if (threadIdx.x == 0) p.tickets[TK_STEP] = 0;
 }
+__global__ __launch_bounds__(256) void k_step_retract(DeviceProblem p, double radius) { k_step_retract_body(p, radius); }
+// (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
+__global__ __launch_bounds__(256) void k_step_retract_batch(const BatchSlot* __restrict__ slots) {
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchReuse)) return;
+  k_step_retract_body(sl.p, sl.radius);
+}
+
 
 // partial slots of the post-solve pass
 constexpr int kPostK = 9;  // A=|Jv|^2 B=|Jy|^2 C=Jv.Jy D=Jv.r E=Jy.r gHat gnHat gDotGn gradMax
@@ -6612,7 +6720,7 @@ __device__ constexpr int postSlotC(int k) {
 //  last block: camera part of the norms and the marginalisation prior (H-space);
 //  whichever block finishes last reduces all partials into SolverScalars group B.
 template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) {
+__device__ __forceinline__ void k_post_solve_body(const DeviceProblem& p, int nLmBlocks, int nFacBlocks, double fuseRadius) {
   __shared__ double red[16 * kPostK];
   __shared__ int lastFlag;
   const int t = threadIdx.x, b = blockIdx.x;
@@ -7018,6 +7126,16 @@ __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBloc
   }
   TRACE(7);
 }
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) { k_post_solve_body<WITH_EXT>(p, nLmBlocks, nFacBlocks, fuseRadius); }
+// (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256, 2) void k_post_solve_batch(const BatchSlot* __restrict__ slots, int nLmBlocks, int nFacBlocks) {
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchFull)) return;
+  k_post_solve_body<WITH_EXT>(sl.p, nLmBlocks, nFacBlocks, sl.radius);
+}
+
 
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius) {
   const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 1024) : 0;
@@ -7040,6 +7158,60 @@ void launchCost(const DeviceProblem& p, hipStream_t s) {
 void launchDoglegStep(const DeviceProblem& p, double radius, hipStream_t s) {
   const int nB = (p.nPose + p.nExt + p.nSb + p.L + 255) / 256;
   hipLaunchKernelGGL(k_step_retract, dim3(nB), dim3(256), 0, s, p, radius);
+}
+
+// ================================================================ batched rounds (kernels.hpp: BatchSlot)
+// The windows of a batch have the same launch geometry: every grid below is the one the launcher of the single window computes
+// from `geom`, with the window as blockIdx.y -- gridDim.x, which the kernels' last-block logic and partial sums read, is what it is
+// for the window on its own, and so is every reduction order: a window ends bit for bit where it ends alone.
+bool batchSupported(const DeviceProblem& p) {
+  if (!(p.L > 0 && p.N > 0 && p.dC > 0 && p.schurDense && p.d > 0)) return false;
+  if (!canFuseEvaluation(p) || optOn(kOptSplitEval) || optOn(kOptNoFuseStep) || optOn(kOptNoDeferLm)) return false;
+  if ((p.nPose + p.nExt + p.nSb + p.L) > 16384) return false;            // (the fused dogleg step of k_post_solve)
+  if (solverClass(p.d, p.sPadded != 0) != 0 || cholBorderRows(p.d, p.sPadded != 0) != 0) return false;   // LDS-resident solver, no border
+  if (priorAccBlocks(p) > 0 && !p.ownsCamera) return false;
+  return true;
+}
+void launchBatchRound(const BatchSlot* dSlots, const DeviceProblem& geom, int n, int stagesUnion, bool cand, hipStream_t s) {
+  const DeviceProblem& p = geom;
+  (void)hipGetLastError();
+  if (stagesUnion & kBatchFull) {
+    const DenseSchurPlan plan = denseSchurPlan(p);
+    const int nFac = p.F, nPri = priorAccBlocks(p);
+    const dim3 grid(p.nSlabs + nFac + nPri, n);
+#define LAUNCH(MAXT, E, NWV)                                                                                        \
+  do {                                                                                                              \
+    ensureDynamicLds((const void*)k_schur_dense_batch<MAXT, E, NWV>, plan.ldsBytes);                                \
+    hipLaunchKernelGGL((k_schur_dense_batch<MAXT, E, NWV>), grid, dim3(64 * NWV), plan.ldsBytes, s, dSlots, p.nSlabs, nFac); \
+  } while (0)
+    if (plan.nTr > 12) LAUNCH(17, true, 8);
+    else if (plan.nTr > 8) LAUNCH(10, true, 8);
+    else if (plan.aMfma) LAUNCH(9, true, 4);
+    else LAUNCH(9, false, 4);
+#undef LAUNCH
+    const int nRed = p.dC * p.dC + 3 * p.dC;
+    hipLaunchKernelGGL(k_reduce_slabs_batch, dim3((nRed + 15) / 16, n), dim3(256), 0, s, dSlots);
+    const int dpad = ((p.d + 15) / 16) * 16;
+    const size_t ldsChol = cholLdsBytes(dpad / 16);
+    ensureDynamicLds((const void*)k_chol_solve_lds_batch<0>, ldsChol);
+    hipLaunchKernelGGL(k_chol_solve_lds_batch<0>, dim3(1, n), dim3(kCholLdsThreads), ldsChol, s, dSlots, dpad, 1, 0, (const double*)nullptr);
+    const int nLm = min((p.L + 15) / 16, 1024);
+    const int nFacP = p.F > 0 ? min((p.F + 3) / 4, 1024) : 0;
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve_batch<true>, dim3(nLm + nFacP + 1, n), dim3(256), 0, s, dSlots, nLm, nFacP);
+    else hipLaunchKernelGGL(k_post_solve_batch<false>, dim3(nLm + nFacP + 1, n), dim3(256), 0, s, dSlots, nLm, nFacP);
+  }
+  if (stagesUnion & kBatchReuse) {
+    const int nB = (p.nPose + p.nExt + p.nSb + p.L + 255) / 256;
+    hipLaunchKernelGGL(k_step_retract_batch, dim3(nB, n), dim3(256), 0, s, dSlots);
+  }
+  if (stagesUnion & kBatchEval) {
+    const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
+    const size_t stage = (size_t)48 * 8 + (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_reproj_batch<true>, dim3(nR, n), dim3(256), stage, s, dSlots, cand ? 1 : 0);
+    else hipLaunchKernelGGL(k_eval_reproj_batch<false>, dim3(nR, n), dim3(256), stage, s, dSlots, cand ? 1 : 0);
+    hipLaunchKernelGGL(k_eval_rest_batch, dim3(p.F + pri, n), dim3(256), 0, s, dSlots, cand ? 1 : 0, nR, pri);
+  }
+  checkSolverLaunches();
 }
 
 // ================================================================ K9: landmark quality (Estimator.cpp:902-923)

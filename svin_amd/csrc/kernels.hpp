@@ -210,6 +210,24 @@ struct DeviceProblem {
                                              // the blocked solver eliminates them as a chain first (k_sb_factor ...)
 };
 
+// ---- batched solve (svin_ba_solve_prepared_batch: B independent windows of equal launch geometry through ONE launch sequence per
+// trust-region round, the window as blockIdx.y).  One slot per window, refilled by the host every round: the window's problem as
+// it stands (buffer sets swapped by its accepted steps, mailbox sequence number of this round's evaluation) and the scalars its
+// own trust region hands the kernels; `stages` says which launches of the round the window takes part in.
+enum : int { kBatchFull = 1,    // build + reduced solve + post-solve pass with the fused dogleg step (a fresh linearisation)
+             kBatchReuse = 2,   // k_step_retract only (a rejected step: smaller radius on the same Gauss-Newton / Cauchy pair)
+             kBatchEval = 4 };  // the candidate (or initial) evaluation
+struct BatchSlot {
+  DeviceProblem p;
+  double mu, radius;
+  int initScale, stages;
+};
+bool batchSupported(const DeviceProblem& p);   // the geometry the batched kernels cover (otherwise the window is solved on its own)
+// one round for the `n` windows of dSlots (device copy of the slot table); `geom` = any window of the batch (equal geometry),
+// `stagesUnion` = OR of the slots' stages, `cand` as for launchEvalAll
+void launchBatchRound(const BatchSlot* dSlots, const DeviceProblem& geom, int n, int stagesUnion, bool cand, hipStream_t s);
+int schurDenseABlocks(const DeviceProblem& p);   // DeviceProblem::aBlocks as launchAccumulateNormalEquations chooses it
+
 // ---- launch wrappers (kernels.hip).  `cand` selects candidate tables/buffers.
 void launchEvalReproj(const DeviceProblem& p, bool cand, bool robust, hipStream_t s);
 void launchEvalFactors(const DeviceProblem& p, bool cand, hipStream_t s, bool sumCost = false);

@@ -33,6 +33,8 @@ enum DebugOption : int {
   kOptNoSbElim,            // SVIN_NO_SB_ELIM: no speed / bias chain elimination
   kOptNoLdsBorder,         // SVIN_NO_LDS_BORDER: no border variants of the LDS-resident solver
   kOptBlkRounds,           // SVIN_BLK_ROUNDS=n: workgroups of k_schur_rows per place (two places per CU; read by pack(); default 2)
+  kOptBatchLanes,          // SVIN_BATCH_LANES=n: sub-batches of svin_ba_solve_prepared_batch on streams of their own (default 4)
+  kOptBatchTiming,         // SVIN_BATCH_TIMING: print the host's issue / collect times of a batched solve
   kOptCount
 };
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 
@@ -65,13 +66,14 @@ struct OptionTable {
         {kOptPgTiming, "SVIN_PG_TIMING"}, {kOptMargTiming, "SVIN_MARG_TIMING"}, {kOptMargKeepPre, "SVIN_MARG_KEEP_PRE"},
         {kOptMargSyncEnqueue, "SVIN_MARG_SYNC_ENQUEUE"}, {kOptMargEig, "SVIN_MARG_EIG"}, {kOptSchurAMfma, "SVIN_SCHUR_A_MFMA"},
         {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
-        {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}};
+        {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}, {kOptBatchLanes, "SVIN_BATCH_LANES"},
+        {kOptBatchTiming, "SVIN_BATCH_TIMING"}};
     static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
     for (const auto& n : kNames) {
       name[n.which] = n.env;
       const char* e = std::getenv(n.env);   // the library's ONE look at the environment for its switches
       int val = e ? 1 : 0;
-      if (e && n.which == kOptBlkRounds) val = std::atoi(e);
+      if (e && (n.which == kOptBlkRounds || n.which == kOptBatchLanes)) val = std::atoi(e);
       if (e && n.which == kOptMargEig) {
         const std::string w(e);
         val = w == "direct" ? 1 : (w == "jacobi" ? 3 : 2);   // any other value selects the Cholesky-preconditioned Jacobi solve alone
@@ -214,6 +216,7 @@ Window::~Window() {
   if (stageHost_) (void)hipHostFree(stageHost_);
   if (resStatus_) (void)hipHostFree(resStatus_);
   if (statesHost_) (void)hipHostFree(statesHost_);
+  if (batchSlotsHost_) (void)hipHostFree(batchSlotsHost_);
   if (lmSyncHost_) (void)hipHostFree(lmSyncHost_);
   if (imuPropHost_) (void)hipHostFree(imuPropHost_);
   if (mailbox_) (void)hipHostFree(mailbox_);
@@ -2290,12 +2293,7 @@ void Window::solve(size_t numIter, bool verbose) {
   summary_.initial_cost = sc.cost;
   double lastIterTime = 0;
   double stopVotes = 0.0;   // sharded mode: number of ranks whose clock asked to stop (identical on every rank)
-  auto swapSets = [&]() {
-    std::swap(p.pose, p.poseC); std::swap(p.ext, p.extC); std::swap(p.sb, p.sbC); std::swap(p.lm, p.lmC);
-    std::swap(p.rCur, p.rCand); std::swap(p.JpCur, p.JpCand); std::swap(p.JlCur, p.JlCand); std::swap(p.JeCur, p.JeCand);
-    std::swap(p.linCur, p.linCand);
-    std::swap(p.priorDchi, p.priorDchiC); std::swap(p.priorGrad, p.priorGradC); std::swap(p.priorM3, p.priorM3C);
-  };
+  auto swapSets = [&]() { swapStateSets(); };
   auto toTr = [&](const SolverScalars& r) {
     TrScalars t;
     t.cost = r.cost; t.stepNormSq = r.stepNormSq; t.xNormSq = r.xNormSq; t.gradMax = r.gradMax; t.failMax = r.failMax;
@@ -2392,6 +2390,220 @@ void Window::solve(size_t numIter, bool verbose) {
   summary_.num_successful_steps = tr.successful;
   summary_.total_time = nowSec() - tStart;
   distNative_ = false;
+}
+
+void Window::swapStateSets() {
+  DeviceProblem& p = prob_;
+  std::swap(p.pose, p.poseC); std::swap(p.ext, p.extC); std::swap(p.sb, p.sbC); std::swap(p.lm, p.lmC);
+  std::swap(p.rCur, p.rCand); std::swap(p.JpCur, p.JpCand); std::swap(p.JlCur, p.JlCand); std::swap(p.JeCur, p.JeCand);
+  std::swap(p.linCur, p.linCand);
+  std::swap(p.priorDchi, p.priorDchiC); std::swap(p.priorGrad, p.priorGradC); std::swap(p.priorM3, p.priorM3C);
+}
+
+// ------------------------------------------------------------------------------------------ batched solve
+// SURVEY 8(e)'s "independent replicas processing different windows" on ONE GPU: a 10-keyframe window keeps 1-3 % of the chip
+// busy (five launches of 10-30 us per iteration, the solver one workgroup), and eight handles on eight streams only reach
+// 1.6 x one handle -- launch rate and hardware queues.  Here the windows of a batch share the launches: per trust-region ROUND one
+// slot table goes to the device (every window's problem as it stands and the scalars of its own trust region, 816 bytes each)
+// and at most six launches follow with the window as blockIdx.y.  The host keeps one TrustRegionHost per window and takes each
+// window's decision from its own mailbox record exactly as solve() does; a window whose step was rejected takes the round's
+// k_step_retract launch instead of the build / solve / post-solve launches, a window that has terminated takes none.  No
+// speculative build (it hides a host latency the other windows of the round hide here).  The arithmetic of a window is the
+// arithmetic of solve(): same kernels bodies, same grids (gridDim.x), same reduction orders.
+namespace {
+struct BatchKey {
+  int v[16];
+  bool operator<(const BatchKey& o) const { return std::lexicographical_compare(v, v + 16, o.v, o.v + 16); }
+};
+BatchKey batchKeyOf(const DeviceProblem& p) {
+  // what the grids, the LDS sizes and the uniform kernel arguments of launchBatchRound are computed from (L and N themselves may
+  // differ: every kernel reads them from its window's problem)
+  return BatchKey{{p.d, p.dC, p.dCPose, (p.L + 15) / 16, (p.N + 255) / 256, p.F, p.nPose, p.nExt, p.nSb, (p.nPose + p.nExt + p.nSb + p.L + 255) / 256,
+                   p.nSlabs, p.priorM, p.anyExtVariable, p.ldS, p.sPadded, p.priorBlocks}};
+}
+}  // namespace
+
+int Window::solvePreparedBatch(Window* const* ws, int n, size_t numIter, bool verbose, int* nBatched) {
+  if (nBatched) *nBatched = 0;
+  if (n <= 0) return 1;
+  std::map<BatchKey, std::vector<Window*>> groups;
+  std::vector<Window*> alone;
+  for (int i = 0; i < n; ++i) {
+    Window* w = ws[i];
+    for (int j = 0; j < i; ++j)
+      if (ws[j] == w) throw std::invalid_argument("svin_ba_solve_prepared_batch: a handle appears twice");
+    w->maxIterationsOption_ = numIter;
+    const DeviceProblem& p = w->prob_;
+    const bool ok = w->world_ <= 1 && !w->rcclComm_ && w->device_ == ws[0]->device_ && w->mailbox_ && p.d + 3 * p.L > 0 && batchSupported(p);
+    if (ok) groups[batchKeyOf(p)].push_back(w);
+    else alone.push_back(w);
+  }
+  for (auto& kv : groups) {
+    if (kv.second.size() < 2) { alone.push_back(kv.second[0]); continue; }
+    solveBatchGroup(kv.second, numIter, verbose);
+    if (nBatched) *nBatched += (int)kv.second.size();
+  }
+  for (Window* w : alone) w->solvePrepared(numIter, verbose);
+  return 1;
+}
+
+// The streams of the lanes: created one after the other, once per device, so that they land on DIFFERENT hardware queues (the
+// runtime deals streams over its four queues in creation order; the windows' own streams -- every fourth handle on the same
+// queue -- would put all the lanes of a batch behind one another).  They live as long as the process.
+static hipStream_t laneStream(int device, int k) {
+  static std::mutex mu;
+  static std::map<int, std::vector<hipStream_t>> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  std::vector<hipStream_t>& v = pool[device];
+  while ((int)v.size() <= k) {
+    hipStream_t s = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    v.push_back(s);
+  }
+  return v[(size_t)k];
+}
+
+void Window::solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool verbose) {
+  const double tStart = nowSec();
+  const int B = (int)g.size();
+  HIP_OK(hipSetDevice(g[0]->device_));
+  for (Window* w : g) HIP_OK(hipStreamSynchronize(w->stream_));   // uploads / earlier work of every window: done before a shared stream reads them
+  // LANES: the windows are cut into up to kLanes sub-batches, each with the stream and the slot table of its first window.  The
+  // reduced solve (one workgroup per window, 30 us) and a re-preintegrating IMU factor (one workgroup, 50 us) are latency, not
+  // work: while one lane sits in them the launches of the other lanes fill the chip.  The host serves the lanes round robin --
+  // collect a lane's mailbox records, take its windows' decisions, issue its next round, go on to the next lane.
+  int nLanes = debugOption(kOptBatchLanes) > 0 ? debugOption(kOptBatchLanes) : 4;
+  nLanes = std::max(1, std::min(nLanes, B / 2));
+  struct Lane { int first = 0, count = 0; Window* lead = nullptr; hipStream_t s = nullptr; BatchSlot* hs = nullptr; bool cand = false, done = false; };
+  std::vector<Lane> lanes((size_t)nLanes);
+  for (int k = 0; k < nLanes; ++k) {
+    Lane& ln = lanes[(size_t)k];
+    ln.first = (int)((long long)B * k / nLanes);
+    ln.count = (int)((long long)B * (k + 1) / nLanes) - ln.first;
+    ln.lead = g[(size_t)ln.first];
+    ln.s = nLanes > 1 ? laneStream(g[0]->device_, k) : ln.lead->stream_;
+    ln.lead->batchSlotsDev_.reserve((size_t)ln.count);
+    if (ln.lead->batchSlotsHostCap_ < (size_t)ln.count) {   // pinned host copy of the lane's slot table (filled per round)
+      if (ln.lead->batchSlotsHost_) (void)hipHostFree(ln.lead->batchSlotsHost_);
+      ln.lead->batchSlotsHost_ = nullptr; ln.lead->batchSlotsHostCap_ = 0;
+      HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&ln.lead->batchSlotsHost_), sizeof(BatchSlot) * (size_t)ln.count, hipHostMallocDefault));
+      ln.lead->batchSlotsHostCap_ = (size_t)ln.count;
+    }
+    ln.hs = ln.lead->batchSlotsHost_;
+  }
+  struct State { TrustRegionHost tr; bool active = true; bool deferLm = false; double lastIterTime = 0, tIter = 0; };
+  std::vector<State> st((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    Window* w = g[i];
+    const DeviceProblem& p = w->prob_;
+    w->summary_.iterations = 0; w->summary_.num_successful_steps = 0; w->summary_.termination = 1;
+    w->distNative_ = false;
+    st[i].deferLm = p.L > 0 && p.N > 0;   // (batchSupported: fused step, fused evaluation)
+    st[i].tr.fTol = w->fTol_; st[i].tr.gTol = w->gTol_; st[i].tr.pTol = w->pTol_;
+    st[i].tr.maxIterations = (int)numIter;
+  }
+  // one round of a lane: the slots of its windows that take part -> device, the launches; false if no window takes part
+  auto issue = [&](Lane& ln, bool cand) -> bool {
+    int uni = 0;
+    for (int k = 0; k < ln.count; ++k) {
+      const int i = ln.first + k;
+      Window* w = g[i];
+      BatchSlot& sl = ln.hs[k];
+      sl.stages = 0;
+      if (!st[i].active) continue;
+      const TrustRegionHost& tr = st[i].tr;
+      DeviceProblem& p = w->prob_;
+      p.mailbox = w->mailboxDev_;
+      p.mailboxSeq = ++w->mailboxSeq_;
+      p.lmDeferred = (cand && st[i].deferLm && !tr.reuse) ? 1 : 0;
+      p.aBlocks = schurDenseABlocks(p);
+      sl.p = p;
+      p.lmDeferred = 0;
+      sl.mu = tr.mu; sl.radius = tr.radius; sl.initScale = tr.initScale ? 1 : 0;
+      sl.stages = !cand ? kBatchEval : (tr.reuse ? (kBatchReuse | kBatchEval) : (kBatchFull | kBatchEval));
+      uni |= sl.stages;
+    }
+    ln.cand = cand;
+    if (!uni) return false;
+    HIP_OK(hipMemcpyAsync(ln.lead->batchSlotsDev_.p, ln.hs, sizeof(BatchSlot) * (size_t)ln.count, hipMemcpyHostToDevice, ln.s));
+    launchBatchRound(ln.lead->batchSlotsDev_.p, ln.lead->prob_, ln.count, uni, cand, ln.s);
+    return true;
+  };
+  auto toTr = [](const SolverScalars& r) {
+    TrScalars t;
+    t.cost = r.cost; t.stepNormSq = r.stepNormSq; t.xNormSq = r.xNormSq; t.gradMax = r.gradMax; t.failMax = r.failMax;
+    t.jdSq = r.jdSq; t.jdDotR = r.jdDotR; t.doglegStepNorm = r.doglegStepNorm;
+    return t;
+  };
+  auto finishWindow = [&](int i) {
+    Window* w = g[i];
+    const TrustRegionHost& tr = st[i].tr;
+    st[i].active = false;
+    w->summary_.termination = tr.termination; w->summary_.final_cost = tr.x_cost; w->summary_.iterations = tr.iteration;
+    w->summary_.num_successful_steps = tr.successful; w->summary_.total_time = nowSec() - tStart;
+  };
+  // top of an iteration for window i (solve(): the time-limit callback, then TrustRegionHost::beginIteration)
+  auto begin = [&](int i) {
+    Window* w = g[i];
+    TrustRegionHost& tr = st[i].tr;
+    const bool stop = w->timeLimit_ >= 0.0 && tr.iteration >= w->minIterations_ && (nowSec() - tStart) + st[i].lastIterTime > w->timeLimit_;
+    if (!tr.beginIteration(stop)) { finishWindow(i); return; }
+    st[i].tIter = nowSec();
+  };
+  // the records of the lane's round in flight, and what each of its windows does with them
+  auto collect = [&](Lane& ln) {
+    for (int k = 0; k < ln.count; ++k) {
+      const int i = ln.first + k;
+      if (!ln.hs[k].stages) continue;
+      const SolverScalars sc = g[i]->readScalars();
+      TrustRegionHost& tr = st[i].tr;
+      if (!ln.cand) {   // the initial evaluation
+        tr.start(sc.cost);
+        g[i]->summary_.initial_cost = sc.cost;
+        begin(i);
+        continue;
+      }
+      const TrScalars t = toTr(sc);
+      if (t.failMax >= 4.0)
+        throw std::runtime_error("svin_ba: a device-side wait in the reduced-system solver timed out (cholFail " + std::to_string((int)t.failMax) +
+                                 "): synchronisation fault, not a numerical failure");
+      if (tr.retryFactorisation(t)) continue;   // the same iteration again, with more damping (next round: a fresh build)
+      const TrustRegionHost::Outcome o = tr.endIteration(t);
+      if (o == TrustRegionHost::kTerminated) { finishWindow(i); continue; }
+      if (o == TrustRegionHost::kAccepted) g[i]->swapStateSets();
+      if (verbose && o != TrustRegionHost::kInvalid)
+        std::printf("[svin_ba batch %d] it %d cost %.9e rel_dec %.3e radius %.3e step %.3e\n", i, tr.iteration, tr.x_cost, tr.relative_decrease,
+                    tr.radius, tr.last_step_norm);
+      st[i].lastIterTime = nowSec() - st[i].tIter;
+      begin(i);
+    }
+  };
+  const bool timing = optOn(kOptBatchTiming);
+  double tIssue = 0, tCollect = 0;
+  int nRounds = 0;
+  try {
+    for (Lane& ln : lanes) ln.done = !issue(ln, false);
+    for (bool any = true; any;) {
+      any = false;
+      for (Lane& ln : lanes) {
+        if (ln.done) continue;
+        const double t0 = timing ? nowSec() : 0.0;
+        collect(ln);
+        const double t1 = timing ? nowSec() : 0.0;
+        ln.done = !issue(ln, true);
+        if (timing) { tCollect += t1 - t0; tIssue += nowSec() - t1; ++nRounds; }
+        any = any || !ln.done;
+      }
+    }
+  } catch (...) {
+    for (Lane& ln : lanes) (void)hipStreamSynchronize(ln.s);   // nothing of this call is left in flight behind the error
+    throw;
+  }
+  for (Lane& ln : lanes) HIP_OK(hipStreamSynchronize(ln.s));
+  if (timing)
+    std::printf("[svin_ba batch] %d windows in %d lanes: %.1f us, %d lane rounds: collect %.1f us each (waiting included), issue %.1f us each\n", B, nLanes,
+                1e6 * (nowSec() - tStart), nRounds, 1e6 * tCollect / std::max(1, nRounds), 1e6 * tIssue / std::max(1, nRounds));
+  for (Window* w : g) w->summary_.solve_time = nowSec() - tStart;
 }
 
 int Window::prepare() {

@@ -234,6 +234,10 @@ class Window {
   int optimize(size_t numIter, bool verbose);
   int prepare();
   int solvePrepared(size_t numIter, bool verbose);
+  // B prepared windows through ONE launch sequence per trust-region round (the window as a grid dimension; kernels.hpp BatchSlot).
+  // Windows whose geometry the batched kernels do not cover, and groups of one, run solve() one after the other; *nBatched = the
+  // number of windows that ran in a batch.  Every window ends where solvePrepared() alone would leave it.
+  static int solvePreparedBatch(Window* const* ws, int n, size_t numIter, bool verbose, int* nBatched);
   int finish();
   void invalidatePreintegration() { for (auto& kv : factors_) if (kv.second.kind == F_IMU) kv.second.imu.redo = 1; }
   int setOptimizationTimeLimit(double timeLimit, int minIter);
@@ -348,6 +352,8 @@ class Window {
   void downloadStates();       // device tables -> host blocks / landmarks / imu states
   void evaluateAll(bool cand, hipStream_t s);
   void solve(size_t numIter, bool verbose);
+  static void solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool verbose);
+  void swapStateSets();   // an accepted step: the candidate sets become the current ones
   SolverScalars readScalars();
 
   // marginalisation (device algebra in marg.hip)
@@ -513,6 +519,10 @@ class Window {
   ScalarMailbox* mailboxDev_ = nullptr;   // its device-side address
   unsigned long long mailboxSeq_ = 0;
   int curSet_ = 0;
+  // batched solve (solvePreparedBatch): the slot table of the batch this window leads -- device copy and pinned host copy
+  DevBuf<BatchSlot> batchSlotsDev_;
+  BatchSlot* batchSlotsHost_ = nullptr;
+  size_t batchSlotsHostCap_ = 0;
 };
 
 std::string& lastError();

@@ -65,7 +65,7 @@ EXPORTS = [
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
     "svin_ba_set_keyframe", "svin_ba_timestamp", "svin_ba_state_count", "svin_ba_get_imu_preintegral",
     "svin_ba_set_imu_preintegral", "svin_ba_init_pose_from_imu", "svin_ba_imu_propagation_integrals",
-    "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl",
+    "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl", "svin_ba_solve_prepared_batch", "svin_ba_optimize_batch",
     "svin_ba_parameter_block_exists", "svin_ba_set_parameter_block_constant", "svin_ba_is_parameter_block_constant",
     "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
     "svin_host_imu_propagation", "svin_host_reprojection_error", "svin_host_homogeneous_point_error",
@@ -124,6 +124,8 @@ def load_library():
     sig("svin_ba_optimize", i32, vp, u64, u64, i32)
     sig("svin_ba_prepare", i32, vp)
     sig("svin_ba_solve_prepared", i32, vp, u64, i32)
+    sig("svin_ba_solve_prepared_batch", i32, C.POINTER(vp), i32, u64, i32, C.POINTER(i32))
+    sig("svin_ba_optimize_batch", i32, C.POINTER(vp), i32, u64, i32, C.POINTER(i32))
     sig("svin_ba_finish", i32, vp)
     sig("svin_ba_invalidate_preintegration", i32, vp)
     sig("svin_ba_set_optimization_time_limit", i32, vp, f64, i32)
@@ -223,6 +225,28 @@ def load_library():
     sig("svin_ba_get_all_landmark_observations", i32, vp, i32, pu64, C.POINTER(LandmarkInfo), pi32, i32, pu64, pu64, pu64, pu64, pi32)
     _LIB = L
     return L
+
+
+def _batch_call(fn_name, estimators, num_iter, verbose):
+    L = load_library()
+    n = len(estimators)
+    arr = (C.c_void_p * max(n, 1))(*[e.h for e in estimators])
+    nb = C.c_int32(0)
+    rc = getattr(L, fn_name)(arr, n, num_iter, 1 if verbose else 0, C.byref(nb))
+    if rc != 1:
+        raise RuntimeError("%s failed (%d): %s" % (fn_name, rc, L.svin_ba_last_error().decode()))
+    return int(nb.value)
+
+
+def solve_prepared_batch(estimators, num_iter, verbose=False):
+    """svin_ba_solve_prepared_batch: the trust-region iterations of several prepared windows (Estimator.prepare() on each) through
+    one launch sequence per round; returns the number of windows that ran in a batch (the others ran one after the other)"""
+    return _batch_call("svin_ba_solve_prepared_batch", estimators, num_iter, verbose)
+
+
+def optimize_batch(estimators, num_iter, verbose=False):
+    """svin_ba_optimize_batch: optimize() of several windows at once (prepare, batched solve, finish)"""
+    return _batch_call("svin_ba_optimize_batch", estimators, num_iter, verbose)
 
 
 def rccl_unique_id():
