@@ -2579,21 +2579,36 @@ void Window::solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool
     }
   };
   const bool timing = optOn(kOptBatchTiming);
-  double tIssue = 0, tCollect = 0;
+  double tIssue = 0, tCollect = 0, tWaitSum = 0;
   int nRounds = 0;
   try {
     for (Lane& ln : lanes) ln.done = !issue(ln, false);
-    for (bool any = true; any;) {
-      any = false;
-      for (Lane& ln : lanes) {
-        if (ln.done) continue;
-        const double t0 = timing ? nowSec() : 0.0;
-        collect(ln);
-        const double t1 = timing ? nowSec() : 0.0;
-        ln.done = !issue(ln, true);
-        if (timing) { tCollect += t1 - t0; tIssue += nowSec() - t1; ++nRounds; }
-        any = any || !ln.done;
+    // a lane is served as soon as the records of its round are there (the rounds of the lanes drift: rejected steps, windows
+    // that have terminated, a re-preintegration); a lane that stays silent for two seconds is collected anyway -- readScalars()
+    // then falls back to a synchronise and reports what it finds
+    auto ready = [&](const Lane& ln) {
+      for (int k = 0; k < ln.count; ++k)
+        if (ln.hs[k].stages && !g[ln.first + k]->scalarsReady()) return false;
+      return true;
+    };
+    for (;;) {
+      int open = 0;
+      Lane* pick = nullptr;
+      for (Lane& ln : lanes) open += ln.done ? 0 : 1;
+      if (!open) break;
+      const double tWait = nowSec();
+      for (unsigned long long spins = 0; !pick; ++spins) {
+        for (Lane& ln : lanes)
+          if (!ln.done && ready(ln)) { pick = &ln; break; }
+        if (!pick && (spins & 255) == 255 && nowSec() - tWait > 2.0)
+          for (Lane& ln : lanes)
+            if (!ln.done) { pick = &ln; break; }
       }
+      const double t0 = timing ? nowSec() : 0.0;
+      collect(*pick);
+      const double t1 = timing ? nowSec() : 0.0;
+      pick->done = !issue(*pick, true);
+      if (timing) { tCollect += t1 - t0; tWaitSum += t0 - tWait; tIssue += nowSec() - t1; ++nRounds; }
     }
   } catch (...) {
     for (Lane& ln : lanes) (void)hipStreamSynchronize(ln.s);   // nothing of this call is left in flight behind the error
@@ -2601,8 +2616,9 @@ void Window::solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool
   }
   for (Lane& ln : lanes) HIP_OK(hipStreamSynchronize(ln.s));
   if (timing)
-    std::printf("[svin_ba batch] %d windows in %d lanes: %.1f us, %d lane rounds: collect %.1f us each (waiting included), issue %.1f us each\n", B, nLanes,
-                1e6 * (nowSec() - tStart), nRounds, 1e6 * tCollect / std::max(1, nRounds), 1e6 * tIssue / std::max(1, nRounds));
+    std::printf("[svin_ba batch] %d windows in %d lanes: %.1f us, %d lane rounds: wait %.1f us, collect %.1f us, issue %.1f us each\n", B, nLanes,
+                1e6 * (nowSec() - tStart), nRounds, 1e6 * tWaitSum / std::max(1, nRounds), 1e6 * tCollect / std::max(1, nRounds),
+                1e6 * tIssue / std::max(1, nRounds));
   for (Window* w : g) w->summary_.solve_time = nowSec() - tStart;
 }
 

@@ -355,6 +355,8 @@ class Window {
   static void solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool verbose);
   void swapStateSets();   // an accepted step: the candidate sets become the current ones
   SolverScalars readScalars();
+  // the record of the last evaluation has reached the mailbox (no mailbox: true -- readScalars() synchronises)
+  bool scalarsReady() const { return !mailbox_ || *reinterpret_cast<const volatile unsigned long long*>(&mailbox_->seq) == mailboxSeq_; }
 
   // marginalisation (device algebra in marg.hip)
   friend class Marginalizer;
