@@ -242,6 +242,14 @@ int svin_ba_parameter_block_exists(svin_ba* h, uint64_t block_id);              
  * landmark is packed by the host and cannot marginalise a frame that sees it); unknown id: 0 */
 int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t block_id, int constant);
 int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t block_id);               /* ParameterBlock::fixed() */
+/* Map::resetParameterization (src/Map.cpp:513-543) with the values of Map::Parameterization (include/okvis/ceres/Map.hpp:97-105):
+ * 0 HomogeneousPoint (landmarks), 1 Pose6d, 2 Pose3d (orientation only: PoseManifold3d, src/PoseManifold.cpp:173-272),
+ * 3 Pose4d (position + yaw: :276-368), 4 Pose2d (roll / pitch: :372-466), 5 Trivial (speed / bias).  A pose or extrinsics block
+ * on a reduced manifold keeps its six rows in the reduced system; the rows of the held directions are struck out before the solve
+ * (same iterates as with the Jacobian columns removed).  1 = done, 0 = unknown block, SVIN_ERR_INVALID_ARG = a manifold the
+ * block's type cannot take.  svin_ba_linearize reports the 6-DoF system; a window holding such a block cannot marginalise. */
+int svin_ba_reset_parameterization(svin_ba* h, uint64_t block_id, int parameterization);
+int svin_ba_get_parameterization(svin_ba* h, uint64_t block_id);   /* the value above, SVIN_ERR_NOT_FOUND for an unknown block */
 /* Map::residuals(id) (src/Map.cpp:576-587): ids of every residual touching the block, in insertion order; returns the
  * count (may exceed cap), SVIN_ERR_NOT_FOUND for an unknown block */
 int svin_ba_residuals_of(svin_ba* h, uint64_t block_id, uint64_t* residual_ids, int cap);

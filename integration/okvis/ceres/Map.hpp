@@ -297,13 +297,11 @@ class Map {
   bool setParameterBlockConstant(uint64_t id) { need(); return svin_ba_set_parameter_block_constant(h_, id, 1) == 1; }  // :495-501
   bool setParameterBlockVariable(uint64_t id) { need(); return svin_ba_set_parameter_block_constant(h_, id, 0) == 1; }  // :504-510
   bool isParameterBlockConstant(uint64_t id) const { need(); return svin_ba_is_parameter_block_constant(h_, id) == 1; } // ParameterBlock::fixed()
-  /// Map::resetParameterization (Map.cpp:513-543).  The estimator only ever uses Pose6d for poses / extrinsics, the
-  /// homogeneous-point manifold for landmarks and none for speed/bias (Estimator.cpp:186-238, :417); the other pose
-  /// manifolds appear in commented-out code only (:801) and are not available on the device.
+  /// Map::resetParameterization (Map.cpp:513-543): Pose3d / Pose4d / Pose2d hold tangent directions of a pose or extrinsics
+  /// block on the device (svin_ba_reset_parameterization); a manifold the block's type cannot take is refused.
   bool resetParameterization(uint64_t id, int parameterization) const {
     need();
-    if (svin_ba_parameter_block_exists(h_, id) != 1) return false;
-    return parameterization == Pose6d || parameterization == HomogeneousPoint || parameterization == Trivial;
+    return svin_ba_reset_parameterization(h_, id, parameterization) == 1;
   }
   /// Map::parameterBlockPtr (Map.hpp:166-170): a snapshot of the block (values, id, fixed, time stamp / initialised flag)
   std::shared_ptr<okvis::ceres::ParameterBlock> parameterBlockPtr(uint64_t id) const {

@@ -111,6 +111,7 @@ def _bind(L):
     sig("orc_map_destroy", None, vp)
     sig("orc_map_add_param", i32, vp, u64, i32, pd)
     sig("orc_map_set_constant", i32, vp, u64, i32)
+    sig("orc_map_reset_parameterization", i32, vp, u64, i32)
     sig("orc_map_get_param", i32, vp, u64, pd)
     sig("orc_map_set_param", i32, vp, u64, pd)
     sig("orc_map_add_reproj", u64, vp, i32, pd, pd, pd, pd, i32, u64, u64, u64)
@@ -213,6 +214,10 @@ class OracleMap:
 
     def set_constant(self, pid, c=True):
         assert self.L.orc_map_set_constant(self.h, pid, 1 if c else 0)
+
+    def reset_parameterization(self, pid, manifold):
+        """Map::resetParameterization on a pose block: 6 / 3 / 4 / 2 = PoseManifold / 3d / 4d / 2d"""
+        return self.L.orc_map_reset_parameterization(self.h, pid, manifold) == 1
 
     def add_reproj(self, model, intr, dist, uv, info, loss, pose, lm, ext):
         intr, dist8, uv, info = arr(intr), np.zeros(8), arr(uv), arr(info).reshape(-1)

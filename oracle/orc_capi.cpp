@@ -259,6 +259,8 @@ int orc_map_add_param(void* m, uint64_t id, int type, const double* x) { return 
 int orc_map_set_constant(void* m, uint64_t id, int constant) {
   return (constant ? static_cast<Map*>(m)->setParameterBlockConstant(id) : static_cast<Map*>(m)->setParameterBlockVariable(id)) ? 1 : 0;
 }
+// Map::resetParameterization (Map.cpp:513-543) on a pose block: manifold = 6 (PoseManifold) / 3 / 4 / 2 (PoseManifold3d / 4d / 2d)
+int orc_map_reset_parameterization(void* m, uint64_t id, int manifold) { return static_cast<Map*>(m)->resetParameterization(id, manifold) ? 1 : 0; }
 int orc_map_get_param(void* m, uint64_t id, double* x) {
   Map* mp = static_cast<Map*>(m);
   if (!mp->parameterBlockExists(id)) return 0;

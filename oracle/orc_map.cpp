@@ -47,6 +47,13 @@ bool Map::removeResidualBlock(uint64_t resId) {  // Map.cpp:467-492
   residuals_.erase(it);
   return true;
 }
+bool Map::resetParameterization(uint64_t id, int manifold) {
+  auto it = params_.find(id);
+  if (it == params_.end()) return false;
+  if (it->second.type != BLOCK_POSE || !(manifold == 6 || manifold == 3 || manifold == 4 || manifold == 2)) return false;
+  it->second.manifold = manifold;
+  return true;
+}
 std::vector<uint64_t> Map::residuals(uint64_t paramId) const {
   auto it = param2res_.find(paramId);
   if (it == param2res_.end()) return {};
@@ -191,7 +198,7 @@ struct Problem {
         camIndex[b.id] = (int)cam.size();
         cam.push_back(&b);
         camOff.push_back(d);
-        d += b.mdim();
+        d += b.sdim();
       }
     }
     lmRes.resize(lm.size());
@@ -207,9 +214,9 @@ struct Problem {
       for (int j = 0; j < ri.nb; ++j) {
         ParamBlock& b = map.param(ri.rb->params[j]);
         ri.pb.push_back(&b);
-        ri.mdim.push_back(b.mdim());
+        ri.mdim.push_back(b.sdim());
         ri.joff.push_back(joff);
-        joff += (size_t)ri.m * b.mdim();
+        joff += (size_t)ri.m * b.sdim();
         if (b.fixed) { ri.kind.push_back(-1); ri.idx.push_back(-1); }
         else if (b.type == BLOCK_HPOINT) { ri.kind.push_back(1); ri.idx.push_back(lmIndex.at(b.id)); lmIdx = lmIndex.at(b.id); }
         else { ri.kind.push_back(0); ri.idx.push_back(camIndex.at(b.id)); }
@@ -252,15 +259,17 @@ struct Problem {
           if (ri.kind[j] < 0) continue;
           const ParamBlock& b = *ri.pb[j];
           double* out = &Jloc[ri.joff[j]];
-          const int dm = b.dim(), md = b.mdim();
+          const int dm = b.dim(), md = b.sdim();
           if (b.type == BLOCK_POSE) {
+            // (reduced manifolds: PlusJacobian is the 6-DoF one with the held columns left out, PoseManifold.cpp:223-236 / :325-334 / :420-433)
             double Jplus[42];
             manifoldPlusJacobian(BLOCK_POSE, b.x, Jplus);
             for (int a = 0; a < m; ++a)
-              for (int c = 0; c < 6; ++c) {
+              for (int c = 0; c < md; ++c) {
+                const int c6 = poseTangentIndex(b.manifold, c);
                 double s = 0;
-                for (int k = 0; k < 7; ++k) s += Jp[j][a * 7 + k] * Jplus[k * 6 + c];
-                out[a * 6 + c] = s;
+                for (int k = 0; k < 7; ++k) s += Jp[j][a * 7 + k] * Jplus[k * 6 + c6];
+                out[a * md + c] = s;
               }
           } else if (b.type == BLOCK_HPOINT) {
             for (int a = 0; a < m; ++a)
@@ -515,14 +524,14 @@ struct Problem {
       double Vibl[3];
       mat3_vec(Vi, bl, Vibl);
       for (int wa = w0; wa < w1; ++wa) {
-        const int ca = s.wCam[wa], ma = cam[ca]->mdim(), oa = camOff[ca];
+        const int ca = s.wCam[wa], ma = cam[ca]->sdim(), oa = camOff[ca];
         const double* Wa = &s.W[(size_t)wa * 27];
         double WVi[27];
         for (int a = 0; a < ma; ++a)
           for (int c = 0; c < 3; ++c) WVi[a * 3 + c] = Wa[a * 3] * Vi[c] + Wa[a * 3 + 1] * Vi[3 + c] + Wa[a * 3 + 2] * Vi[6 + c];
         for (int a = 0; a < ma; ++a) s.gred[oa + a] -= Wa[a * 3] * Vibl[0] + Wa[a * 3 + 1] * Vibl[1] + Wa[a * 3 + 2] * Vibl[2];
         for (int wb = w0; wb < w1; ++wb) {
-          const int cb = s.wCam[wb], mb = cam[cb]->mdim(), ob = camOff[cb];
+          const int cb = s.wCam[wb], mb = cam[cb]->sdim(), ob = camOff[cb];
           const double* Wb = &s.W[(size_t)wb * 27];
           for (int a = 0; a < ma; ++a)
             for (int c = 0; c < mb; ++c)
@@ -652,14 +661,14 @@ struct Problem {
         mat3_vec(Vi, bl, Vibl);
         const int nw = (int)wc.size();
         for (int wa = 0; wa < nw; ++wa) {
-          const int ca = wc[wa], ma = cam[ca]->mdim(), oa = camOff[ca];
+          const int ca = wc[wa], ma = cam[ca]->sdim(), oa = camOff[ca];
           const double* Wa = &W[(size_t)wa * 27];
           double WVi[27];
           for (int a = 0; a < ma; ++a)
             for (int c = 0; c < 3; ++c) WVi[a * 3 + c] = Wa[a * 3] * Vi[c] + Wa[a * 3 + 1] * Vi[3 + c] + Wa[a * 3 + 2] * Vi[6 + c];
           for (int a = 0; a < ma; ++a) dG[oa + a] -= Wa[a * 3] * Vibl[0] + Wa[a * 3 + 1] * Vibl[1] + Wa[a * 3 + 2] * Vibl[2];
           for (int wb = 0; wb < nw; ++wb) {
-            const int cb = wc[wb], mb = cam[cb]->mdim(), ob = camOff[cb];
+            const int cb = wc[wb], mb = cam[cb]->sdim(), ob = camOff[cb];
             const double* Wb = &W[(size_t)wb * 27];
             for (int a = 0; a < ma; ++a)
               for (int c = 0; c < mb; ++c)
@@ -714,7 +723,7 @@ struct Problem {
     for (int l = 0; l < (int)lm.size(); ++l) {
       double t[3] = {s.bl[3 * l], s.bl[3 * l + 1], s.bl[3 * l + 2]};
       for (int w = s.wStart[l]; w < s.wStart[l + 1]; ++w) {
-        const int c = s.wCam[w], mc = cam[c]->mdim(), oc = camOff[c];
+        const int c = s.wCam[w], mc = cam[c]->sdim(), oc = camOff[c];
         const double* W = &s.W[(size_t)w * 27];
         for (int a = 0; a < mc; ++a) { t[0] -= W[a * 3] * y[oc + a]; t[1] -= W[a * 3 + 1] * y[oc + a]; t[2] -= W[a * 3 + 2] * y[oc + a]; }
       }
@@ -738,6 +747,11 @@ struct Problem {
   void applyDelta(const std::vector<double>& delta) {
     for (size_t c = 0; c < cam.size(); ++c) {
       double xp[9];
+      if (cam[c]->type == BLOCK_POSE && cam[c]->manifold != 6) {
+        double d6[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < cam[c]->manifold; ++k) d6[poseTangentIndex(cam[c]->manifold, k)] = delta[camOff[c] + k];
+        manifoldPlus(BLOCK_POSE, cam[c]->x, d6, xp);
+      } else
       manifoldPlus(cam[c]->type, cam[c]->x, &delta[camOff[c]], xp);
       std::memcpy(cam[c]->x, xp, sizeof(double) * cam[c]->dim());
     }

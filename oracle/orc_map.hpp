@@ -23,7 +23,20 @@ struct ParamBlock {
   double x[9] = {0};
   int dim() const { return blockDim(type); }
   int mdim() const { return blockMinDim(type); }
+  // Map::resetParameterization (Map.cpp:513-543) on a pose block: 6 = PoseManifold, 3 / 4 / 2 = PoseManifold3d / 4d / 2d
+  // (PoseManifold.cpp:173-466).  Only the SOLVER sees it (Ceres takes the tangent size from the manifold); the error terms' own
+  // minimal Jacobians, getLhs and isJacobianCorrect keep six columns, as in the reference (ParameterBlock::minimalDimension()).
+  int manifold = 6;
+  int sdim() const { return type == BLOCK_POSE ? manifold : mdim(); }
 };
+// component of the 6-vector (dr, dalpha) that minimal coordinate c of a reduced pose manifold drives:
+// PoseManifold3d::Plus delta_[3..5] (PoseManifold.cpp:176-178), 4d: delta_[0..2], delta_[5] (:279-282), 2d: delta_[3..4] (:375-376)
+inline int poseTangentIndex(int manifold, int c) {
+  if (manifold == 3) return 3 + c;
+  if (manifold == 4) return c < 3 ? c : 5;
+  if (manifold == 2) return 3 + c;
+  return c;
+}
 
 struct ResidualBlock {
   uint64_t id = 0;
@@ -65,6 +78,7 @@ class Map {
   const ParamBlock& param(uint64_t id) const { return params_.at(id); }
   bool setParameterBlockConstant(uint64_t id) { if (!params_.count(id)) return false; params_[id].fixed = true; return true; }
   bool setParameterBlockVariable(uint64_t id) { if (!params_.count(id)) return false; params_[id].fixed = false; return true; }
+  bool resetParameterization(uint64_t id, int manifold);   // Map.cpp:513-543; manifold = 6 / 3 / 4 / 2 on a pose block
   uint64_t addResidualBlock(std::shared_ptr<ErrorTerm> err, int loss, const std::vector<uint64_t>& paramIds);
   bool removeResidualBlock(uint64_t resId);
   std::vector<uint64_t> residuals(uint64_t paramId) const;   // copy, insertion order

@@ -434,6 +434,10 @@ int svin_ba_parameter_block_exists(svin_ba* h, uint64_t id) try { return h ? (h-
 int svin_ba_set_parameter_block_constant(svin_ba* h, uint64_t id, int constant) try {
   return h ? h->w.setParameterBlockConstant(id, constant != 0) : SVIN_ERR_INVALID_ARG;
 } CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_reset_parameterization(svin_ba* h, uint64_t id, int parameterization) try {
+  return h ? h->w.resetParameterization(id, parameterization) : SVIN_ERR_INVALID_ARG;
+} CATCH_ALL(SVIN_ERR_DEVICE)
+int svin_ba_get_parameterization(svin_ba* h, uint64_t id) try { return h ? h->w.parameterization(id) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_is_parameter_block_constant(svin_ba* h, uint64_t id) try { return h ? h->w.isParameterBlockConstant(id) : SVIN_ERR_INVALID_ARG; } CATCH_ALL(SVIN_ERR_DEVICE)
 int svin_ba_residuals_of(svin_ba* h, uint64_t id, uint64_t* out, int cap) {
   if (!h || cap < 0 || (cap > 0 && !out)) return SVIN_ERR_INVALID_ARG;

@@ -1832,11 +1832,7 @@ __device__ __forceinline__ const BatchSlot& batchSlot(const BatchSlot* slots) {
 // evalReprojBlock alone) and the factor / prior blocks follow with the cost sum.  Same device functions, same partial slots,
 // same summation order as k_eval_all: a window's numbers do not change.
 template <bool WITH_EXT>
-__global__ __launch_bounds__(256) void k_eval_reproj_batch(const BatchSlot* __restrict__ slots, int cand) {
-  extern __shared__ double smem[];
-  const BatchSlot& sl = batchSlot(slots);
-  if (!(sl.stages & kBatchEval)) return;
-  const DeviceProblem& p = sl.p;
+__device__ __forceinline__ void evalReprojSplitBody(const DeviceProblem& p, int cand, double* smem) {
   SVIN_ARGS(SA(p.poseC), SA(p.pose), SA(p.extC), SA(p.ext), SA(p.lm), SA(p.lmC), SA(p.cams), SA(p.obsUv), SA(p.obsW), SA(p.obsIdx),
             SA(p.obsLm), SA(p.rCand), SA(p.JpCand), SA(p.JlCand), SA(p.partial), SA(p.scal), SA(p.vL), SA(p.yL), SA(p.lmPtr), SA(p.N),
             SA(p.nPose), SA(p.nExt), SA(p.nCam));
@@ -1856,11 +1852,7 @@ __global__ __launch_bounds__(256) void k_eval_reproj_batch(const BatchSlot* __re
                                   df, p.lmPrior);
 }
 // blocks [0, F): the small factors, block F (hasPrior): the marginalisation prior; the block that finishes last sums the cost
-__global__ __launch_bounds__(256) void k_eval_rest_batch(const BatchSlot* __restrict__ slots, int cand, int nR, int hasPrior) {
-  __shared__ FactorShared sh;
-  const BatchSlot& sl = batchSlot(slots);
-  if (!(sl.stages & kBatchEval)) return;
-  const DeviceProblem& p = sl.p;
+__device__ __forceinline__ void evalRestSplitBody(const DeviceProblem& p, int cand, int nR, int hasPrior, FactorShared& sh) {
   const int F = (int)gridDim.x - hasPrior;
   if ((int)blockIdx.x < F) {
     SVIN_ARGS(SA(p.factors), SA(p.imus), SA(p.linCand), SA(p.linCur), SA(p.poseC), SA(p.pose), SA(p.sbC), SA(p.sb), SA(p.extC), SA(p.ext),
@@ -1876,14 +1868,49 @@ __global__ __launch_bounds__(256) void k_eval_rest_batch(const BatchSlot* __rest
     if (threadIdx.x == 0) p.tickets[TK_EVAL] = 0;
   }
 }
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_reproj_batch(const BatchSlot* __restrict__ slots, int cand) {
+  extern __shared__ double smem[];
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchEval)) return;
+  evalReprojSplitBody<WITH_EXT>(sl.p, cand, smem);
+}
+__global__ __launch_bounds__(256) void k_eval_rest_batch(const BatchSlot* __restrict__ slots, int cand, int nR, int hasPrior) {
+  __shared__ FactorShared sh;
+  const BatchSlot& sl = batchSlot(slots);
+  if (!(sl.stages & kBatchEval)) return;
+  evalRestSplitBody(sl.p, cand, nR, hasPrior, sh);
+}
+// The same two launches for ONE window whose evaluation has more blocks than the chip has CUs (wide windows: 1 954 reprojection
+// blocks at 500 000 observations): in k_eval_all every block carries the factor blocks' LDS, one workgroup per CU.
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256) void k_eval_reproj_split(DeviceProblem p, int cand) {
+  extern __shared__ double smem[];
+  evalReprojSplitBody<WITH_EXT>(p, cand, smem);
+}
+__global__ __launch_bounds__(256) void k_eval_rest_split(DeviceProblem p, int cand, int nR, int hasPrior) {
+  __shared__ FactorShared sh;
+  evalRestSplitBody(p, cand, nR, hasPrior, sh);
+}
 
+constexpr int kEvalSplitBlocks = 512;   // more evaluation blocks than this: reprojection blocks in a launch of their own (launchEvalAll)
 // fused evaluation possible: factors and observations present, camera-owning rank, staging area fits
 bool canFuseEvaluation(const DeviceProblem& p) {
   const size_t stage = (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
   return p.F > 0 && p.N > 0 && stage <= sizeof(FactorShared) && (p.N + 255) / 256 + p.F <= kMaxPartials;
 }
+static size_t evalSplitStageBytes(const DeviceProblem& p) {
+  return (size_t)48 * 8 + (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
+}
 void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t s) {
   const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
+  if (sumCost && p.F + nR + pri > kEvalSplitBlocks && !optOn(kOptNoEvalSplit)) {
+    const size_t stage = evalSplitStageBytes(p);
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_reproj_split<true>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
+    else hipLaunchKernelGGL(k_eval_reproj_split<false>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
+    hipLaunchKernelGGL(k_eval_rest_split, dim3(p.F + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, pri);
+    return;
+  }
   if (p.anyExtVariable)
     hipLaunchKernelGGL(k_eval_all<true>, dim3(p.F + nR + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, sumCost ? 1 : 0, pri);
   else
@@ -6533,8 +6560,25 @@ static void checkSolverLaunches() {
   if (e != hipSuccess) throw std::runtime_error(std::string("reduced-system solver launch: ") + hipGetErrorString(e));
 }
 static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize);
+// Reduced pose manifolds (PoseManifold3d / 4d / 2d, PoseManifold.cpp:173-466; Map::resetParameterization, Map.cpp:513-543).  Their
+// Plus() is the 6-DoF one with some components of delta held at zero, so Ceres sees the 6-column local Jacobian with those columns
+// dropped.  Dropping columns of J drops the same rows and columns of J^T J and of every Schur complement built from it, and the
+// landmark blocks V_l do not contain pose columns at all -- so the kernels build the 6-DoF system as always and the locked rows are
+// struck out of the finished reduced system: row and column zero, unit diagonal, zero gradient, zero column norm (scale 1).  The
+// Gauss-Newton step and the gradient are then zero in the locked directions, which is all the dogleg step, the landmark
+// back-substitution (W^T x), the model-cost products (J d) and the retraction ever see of them.  One workgroup per locked row.
+__global__ __launch_bounds__(256) void k_lock_rows(DeviceProblem p) {
+  const int i = p.lockedRows[blockIdx.x];
+  const int d = p.d, ld = p.ldS ? p.ldS : d;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    p.S[(size_t)i * ld + j] = (j == i) ? 1.0 : 0.0;
+    if (j != i) p.S[(size_t)j * ld + i] = 0.0;
+  }
+  if (threadIdx.x == 0) { p.gRed[i] = 0.0; p.gFull[i] = 0.0; p.hC[i] = 0.0; }
+}
 void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   (void)hipGetLastError();   // (a polling hipEventQuery / hipStreamQuery of another library -- RCCL -- leaves hipErrorNotReady behind: not ours)
+  if (p.nLocked > 0) hipLaunchKernelGGL(k_lock_rows, dim3(p.nLocked), dim3(256), 0, s, p);
   launchSolveReducedUnchecked(p, s, mu, initScale, fuseFinalize);
   checkSolverLaunches();
 }
@@ -7128,6 +7172,9 @@ __device__ __forceinline__ void k_post_solve_body(const DeviceProblem& p, int nL
 }
 template <bool WITH_EXT>
 __global__ __launch_bounds__(256) void k_post_solve(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) { k_post_solve_body<WITH_EXT>(p, nLmBlocks, nFacBlocks, fuseRadius); }
+// (the same body held to 256 registers -- two workgroups per CU -- for grids of more blocks than the chip has CUs: wide windows)
+template <bool WITH_EXT>
+__global__ __launch_bounds__(256, 2) void k_post_solve_wide(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) { k_post_solve_body<WITH_EXT>(p, nLmBlocks, nFacBlocks, fuseRadius); }
 // (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
 template <bool WITH_EXT>
 __global__ __launch_bounds__(256, 2) void k_post_solve_batch(const BatchSlot* __restrict__ slots, int nLmBlocks, int nFacBlocks) {
@@ -7140,6 +7187,11 @@ __global__ __launch_bounds__(256, 2) void k_post_solve_batch(const BatchSlot* __
 void launchDoglegPrepare(const DeviceProblem& p, hipStream_t s, double fuseRadius) {
   const int nLm = (p.L > 0 && p.N > 0) ? min((p.L + 15) / 16, 1024) : 0;
   const int nFac = p.F > 0 ? min((p.F + 3) / 4, 1024) : 0;
+  if (nLm + nFac + 1 > kEvalSplitBlocks && !optOn(kOptNoEvalSplit)) {
+    if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve_wide<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
+    else hipLaunchKernelGGL(k_post_solve_wide<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
+    return;
+  }
   if (p.anyExtVariable) hipLaunchKernelGGL(k_post_solve<true>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
   else hipLaunchKernelGGL(k_post_solve<false>, dim3(nLm + nFac + 1), dim3(256), 0, s, p, nLm, nFac, fuseRadius);
 }
@@ -7170,6 +7222,7 @@ bool batchSupported(const DeviceProblem& p) {
   if ((p.nPose + p.nExt + p.nSb + p.L) > 16384) return false;            // (the fused dogleg step of k_post_solve)
   if (solverClass(p.d, p.sPadded != 0) != 0 || cholBorderRows(p.d, p.sPadded != 0) != 0) return false;   // LDS-resident solver, no border
   if (priorAccBlocks(p) > 0 && !p.ownsCamera) return false;
+  if (p.nLocked > 0) return false;   // (reduced pose manifolds: k_lock_rows has no batched form)
   return true;
 }
 void launchBatchRound(const BatchSlot* dSlots, const DeviceProblem& geom, int n, int stagesUnion, bool cand, hipStream_t s) {
@@ -7206,7 +7259,7 @@ void launchBatchRound(const BatchSlot* dSlots, const DeviceProblem& geom, int n,
   }
   if (stagesUnion & kBatchEval) {
     const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
-    const size_t stage = (size_t)48 * 8 + (size_t)(p.nPose + p.nExt) * 7 * 8 + (size_t)p.nCam * sizeof(CameraModel) + 64;
+    const size_t stage = evalSplitStageBytes(p);
     if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_reproj_batch<true>, dim3(nR, n), dim3(256), stage, s, dSlots, cand ? 1 : 0);
     else hipLaunchKernelGGL(k_eval_reproj_batch<false>, dim3(nR, n), dim3(256), stage, s, dSlots, cand ? 1 : 0);
     hipLaunchKernelGGL(k_eval_rest_batch, dim3(p.F + pri, n), dim3(256), 0, s, dSlots, cand ? 1 : 0, nR, pri);

@@ -208,6 +208,11 @@ struct DeviceProblem {
   int sbChain;                               // > 0: the rows dC .. d are sbChain variable speed / bias blocks (9 rows each) that
                                              // couple only with their neighbours in this order (IMU factors) and with the kept rows:
                                              // the blocked solver eliminates them as a chain first (k_sb_factor ...)
+  // poses / extrinsics on a reduced manifold (Map::Pose3d / Pose4d / Pose2d, PoseManifold.cpp:173-466): the rows of the reduced
+  // system that belong to their LOCKED tangent directions.  launchSolveReduced turns each into an identity row with a zero
+  // right-hand side first (k_lock_rows) -- the same system as with those Jacobian columns removed, the step stays zero there
+  const int* lockedRows;
+  int nLocked;
 };
 
 // ---- batched solve (svin_ba_solve_prepared_batch: B independent windows of equal launch geometry through ONE launch sequence per

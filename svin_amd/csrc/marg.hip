@@ -1239,6 +1239,12 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
     rit++;
     if (rit == states_.rend()) return 1;
   }
+  // A pose on a reduced manifold (Map::resetParameterization, a Map-level feature okvis::Estimator never uses: Estimator.cpp:801 is
+  // commented out): the prior's columns would have to be the 3 / 4 / 2 minimal ones (MarginalizationError.cpp:147-160 takes
+  // minimalDimension()).  Not built; refuse before anything is modified.
+  for (const auto& kv : blocks_)
+    if (kv.second.lock != 0)
+      throw std::runtime_error("applyMarginalizationStrategy: a pose block on a reduced manifold (Pose3d / Pose4d / Pose2d) is in the window");
   if (numLandmarkPriors_ > 0 || numFixedLandmarks_ > 0) {
     // Landmarks that carry a HomogeneousPointError stay out of the marginalisation: the reference's policy loop assumes
     // every residual of a landmark is a ReprojectionError (Estimator.cpp:689-698) and never meets one, because Estimator

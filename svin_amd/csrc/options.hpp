@@ -35,6 +35,8 @@ enum DebugOption : int {
   kOptBlkRounds,           // SVIN_BLK_ROUNDS=n: workgroups of k_schur_rows per place (two places per CU; read by pack(); default 2)
   kOptBatchLanes,          // SVIN_BATCH_LANES=n: sub-batches of svin_ba_solve_prepared_batch on streams of their own (default 4)
   kOptBatchTiming,         // SVIN_BATCH_TIMING: print the host's issue / collect times of a batched solve
+  kOptNoEvalSplit,         // SVIN_NO_EVAL_SPLIT: wide windows keep the one-launch evaluation (k_eval_all) and the one-workgroup-per-CU post-solve pass
+  kOptSlabChunks,          // SVIN_SLAB_CHUNKS=n: chunks of 16 landmarks per workgroup of k_schur_dense (read by pack())
   kOptCount
 };
 

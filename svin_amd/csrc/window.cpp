@@ -67,13 +67,14 @@ struct OptionTable {
         {kOptMargSyncEnqueue, "SVIN_MARG_SYNC_ENQUEUE"}, {kOptMargEig, "SVIN_MARG_EIG"}, {kOptSchurAMfma, "SVIN_SCHUR_A_MFMA"},
         {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
         {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}, {kOptBatchLanes, "SVIN_BATCH_LANES"},
-        {kOptBatchTiming, "SVIN_BATCH_TIMING"}};
+        {kOptBatchTiming, "SVIN_BATCH_TIMING"}, {kOptNoEvalSplit, "SVIN_NO_EVAL_SPLIT"},
+        {kOptSlabChunks, "SVIN_SLAB_CHUNKS"}};
     static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
     for (const auto& n : kNames) {
       name[n.which] = n.env;
       const char* e = std::getenv(n.env);   // the library's ONE look at the environment for its switches
       int val = e ? 1 : 0;
-      if (e && (n.which == kOptBlkRounds || n.which == kOptBatchLanes)) val = std::atoi(e);
+      if (e && (n.which == kOptBlkRounds || n.which == kOptBatchLanes || n.which == kOptSlabChunks)) val = std::atoi(e);
       if (e && n.which == kOptMargEig) {
         const std::string w(e);
         val = w == "direct" ? 1 : (w == "jacobi" ? 3 : 2);   // any other value selects the Cholesky-preconditioned Jacobi solve alone
@@ -1035,6 +1036,39 @@ int Window::setParameterBlockConstant(uint64_t id, bool constant) {
   b->fixed = constant;
   return 1;
 }
+// Map::resetParameterization (Map.cpp:513-543).  The reference removes the block and adds it again with the other manifold; here
+// the block keeps its place and only the set of held tangent directions changes.  Map::Parameterization (Map.hpp:97-105):
+// 0 HomogeneousPoint, 1 Pose6d, 2 Pose3d (orientation varies, position held: PoseManifold.cpp:173-178), 3 Pose4d (position + yaw,
+// :276-282), 4 Pose2d (roll / pitch, :372-376), 5 Trivial.  1 = done, 0 = unknown block (the reference's false), negative = a
+// manifold the block's type cannot take (the reference would hand Ceres a manifold of the wrong ambient size and abort).
+int Window::resetParameterization(uint64_t id, int parameterization) {
+  Block* b = findBlock(id);
+  if (!b) {
+    uint64_t hnd = 0;
+    if (!lmIndex_.find(id, &hnd)) return 0;
+    return parameterization == 0 ? 1 : -1 /* SVIN_ERR_INVALID_ARG */;
+  }
+  if (b->kind == B_SB) return parameterization == 5 ? 1 : -1 /* SVIN_ERR_INVALID_ARG */;
+  unsigned char lock;
+  switch (parameterization) {
+    case 1: lock = 0; break;
+    case 2: lock = 0x07; break;          // delta = (0, 0, 0, d0, d1, d2)
+    case 3: lock = 0x18; break;          // delta = (d0, d1, d2, 0, 0, d3)
+    case 4: lock = 0x27; break;          // delta = (0, 0, 0, d0, d1, 0)
+    default: return -1 /* SVIN_ERR_INVALID_ARG */;
+  }
+  b->lock = lock;
+  return 1;
+}
+int Window::parameterization(uint64_t id) const {
+  const Block* b = findBlock(id);
+  if (!b) {
+    uint64_t hnd = 0;
+    return lmIndex_.find(id, &hnd) ? 0 : -2 /* SVIN_ERR_NOT_FOUND */;
+  }
+  if (b->kind == B_SB) return 5;
+  return b->lock == 0 ? 1 : (b->lock == 0x07 ? 2 : (b->lock == 0x18 ? 3 : 4));
+}
 int Window::isParameterBlockConstant(uint64_t id) const {
   const Block* b = findBlock(id);
   if (!b) {
@@ -1487,6 +1521,13 @@ void Window::pack(bool solveFollows) {
     else { hExtOff[i] = d; redBlockIds_.push_back(b.id); redBlockOff_.push_back(d); d += 6; anyExtVar = true; }
   }
   const int dC = d;
+  // blocks on a reduced manifold: the reduced-system rows of their held tangent directions (kernels.hip k_lock_rows)
+  std::vector<int> hLocked;
+  for (size_t k = 0; k < redBlockIds_.size(); ++k) {
+    const Block& b = blocks_.at(redBlockIds_[k]);
+    for (int a = 0; a < 6; ++a)
+      if ((b.lock >> a) & 1) hLocked.push_back(redBlockOff_[k] + a);
+  }
   for (size_t i = 0; i < sbIds_.size(); ++i) {
     const Block& b = blocks_.at(sbIds_[i]);
     std::memcpy(&hSb[9 * i], b.x, 9 * sizeof(double));
@@ -1702,6 +1743,7 @@ void Window::pack(bool solveFollows) {
   dPoseC_.reserve(std::max<size_t>(hPose.size(), 1)); dExtC_.reserve(std::max<size_t>(hExt.size(), 1));
   dSbC_.reserve(std::max<size_t>(hSb.size(), 1)); dLmC_.reserve(std::max<size_t>((size_t)4 * L, 1));
   upload(dPoseOff_, hPoseOff, s); upload(dExtOff_, hExtOff, s); upload(dSbOff_, hSbOff, s);
+  if (!hLocked.empty()) upload(dLockedRows_, hLocked, s);
   upload(dCams_, cameras_, s);
   ResidentArgs ra;
   std::memset(&ra, 0, sizeof(ra));
@@ -1743,7 +1785,11 @@ void Window::pack(bool solveFollows) {
   // windows whose camera block fits 16 x 16 MFMA tiles (dC <= 254, e.g. 42 poses or 10 poses with per-frame extrinsics):
   // dense Gram-matrix Schur complement on MFMA
   const bool schurDense = dC > 0 && dC + 2 <= 256 && poseIds_.size() <= (size_t)kDensePoseCap && !optOn(kOptSchurPairwise);
-  if (schurDense) nSlabs = std::max(1, std::min(256, (L + 15) / 16));
+  if (schurDense) {
+    nSlabs = std::max(1, std::min(256, (L + 15) / 16));
+    // SVIN_SLAB_CHUNKS=n: n chunks of 16 landmarks per workgroup and private slab (default 1 up to 256 workgroups)
+    if (debugOption(kOptSlabChunks) > 1) nSlabs = std::max(1, std::min(nSlabs, ((L + 15) / 16 + debugOption(kOptSlabChunks) - 1) / debugOption(kOptSlabChunks)));
+  }
   else if (useLds) nSlabs = std::max(1, std::min(256, (L + 7) / 8));
   // dense Schur with the A part on MFMA (variable extrinsics, or more than 8 tile rows): within every chunk of 16
   // landmarks the observations are visited pose by pose, so that a batch only touches a few tile rows (counting sort)
@@ -2007,6 +2053,7 @@ void Window::pack(bool solveFollows) {
   p.pose = dPose_.p; p.ext = dExt_.p; p.sb = dSb_.p; p.lm = dLm_.p;
   p.obsOrder = orderObs ? dObsOrder_.p : nullptr;
   p.dCPose = dCPose;
+  p.lockedRows = hLocked.empty() ? nullptr : dLockedRows_.p; p.nLocked = (int)hLocked.size();
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;
@@ -2408,7 +2455,8 @@ void Window::swapStateSets() {
 // and at most six launches follow with the window as blockIdx.y.  The host keeps one TrustRegionHost per window and takes each
 // window's decision from its own mailbox record exactly as solve() does; a window whose step was rejected takes the round's
 // k_step_retract launch instead of the build / solve / post-solve launches, a window that has terminated takes none.  No
-// speculative build (it hides a host latency the other windows of the round hide here).  The arithmetic of a window is the
+// speculative build: measured (round 6, B = 16 in four lanes) 6.9 x one window with it against 7.4 x without -- the lanes keep the
+// chip busy, so the builds of steps that end up rejected are work added, not latency hidden.  The arithmetic of a window is the
 // arithmetic of solve(): same kernels bodies, same grids (gridDim.x), same reduction orders.
 namespace {
 struct BatchKey {

@@ -46,6 +46,7 @@ struct Block {
   uint64_t id = 0;
   int kind = B_POSE;  // B_POSE / B_EXT / B_SB
   bool fixed = false;
+  unsigned char lock = 0;           // pose / extrinsics blocks: bit k set = tangent direction k is held (Map::Pose3d / Pose4d / Pose2d)
   double x[9] = {0};
   std::vector<uint64_t> residuals;  // ids of the factors / the prior touching it (insertion order)
   int nObs = 0;                     // reprojection residuals touching it (they live in Landmark::obs only)
@@ -267,6 +268,8 @@ class Window {
   // speed/bias) and landmark ids.
   bool parameterBlockExists(uint64_t id) const { return blocks_.count(id) || lmIndex_.count(id); }   // Map.cpp:77-80
   int setParameterBlockConstant(uint64_t id, bool constant);     // Map.cpp:495-510
+  int resetParameterization(uint64_t id, int parameterization);  // Map.cpp:513-543 (values of Map::Parameterization, Map.hpp:97-105)
+  int parameterization(uint64_t id) const;
   int isParameterBlockConstant(uint64_t id) const;               // ParameterBlock::fixed()
   int residualsOf(uint64_t blockId, std::vector<uint64_t>& out) const;    // Map::residuals        Map.cpp:576-587
   int parametersOf(uint64_t resId, std::vector<uint64_t>& out) const;     // Map::parameters       Map.cpp:602-620
@@ -497,6 +500,7 @@ class Window {
 
   // device buffers
   DevBuf<double> dPose_, dExt_, dSb_, dLm_, dPoseC_, dExtC_, dSbC_, dLmC_;
+  DevBuf<int> dLockedRows_;
   DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_, dPanelWork_, dPanelChunks_, dPanelPairPtr_, dObsOrder_;
   DevBuf<int> dSlotPtr_, dSlotObsPtr_, dSlotObs_, dSlotLm_, dBlkBatch_, dBlkWaveTab_, dBlkRecSlot_;   // wide windows, block-pair Schur form: (landmark, pose) slots (kernels.hpp)
   DevBuf<unsigned short> dSlotBlk_;

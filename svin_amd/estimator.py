@@ -67,6 +67,7 @@ EXPORTS = [
     "svin_ba_set_imu_preintegral", "svin_ba_init_pose_from_imu", "svin_ba_imu_propagation_integrals",
     "svin_ba_rccl_unique_id", "svin_ba_set_distributed_rccl", "svin_ba_solve_prepared_batch", "svin_ba_optimize_batch",
     "svin_ba_parameter_block_exists", "svin_ba_set_parameter_block_constant", "svin_ba_is_parameter_block_constant",
+    "svin_ba_reset_parameterization", "svin_ba_get_parameterization",
     "svin_ba_residuals_of", "svin_ba_parameters_of", "svin_ba_get_landmark_observations",
     "svin_host_imu_propagation", "svin_host_reprojection_error", "svin_host_homogeneous_point_error",
     "svin_ba_add_homogeneous_point_error", "svin_ba_remove_homogeneous_point_error",
@@ -190,6 +191,8 @@ def load_library():
     sig("svin_ba_parameter_block_exists", i32, vp, u64)
     sig("svin_ba_set_parameter_block_constant", i32, vp, u64, i32)
     sig("svin_ba_is_parameter_block_constant", i32, vp, u64)
+    sig("svin_ba_reset_parameterization", i32, vp, u64, i32)
+    sig("svin_ba_get_parameterization", i32, vp, u64)
     sig("svin_ba_residuals_of", i32, vp, u64, pu64, i32)
     sig("svin_ba_parameters_of", i32, vp, u64, pu64, i32, pi32)
     sig("svin_ba_rccl_unique_id", i32, C.c_char_p)
@@ -611,6 +614,16 @@ class Estimator:
 
     def set_parameter_block_constant(self, bid, constant=True):
         return self._check(self.L.svin_ba_set_parameter_block_constant(self.h, bid, 1 if constant else 0), "set_parameter_block_constant") == 1
+
+    # Map::Parameterization (Map.hpp:97-105)
+    HOMOGENEOUS_POINT, POSE6D, POSE3D, POSE4D, POSE2D, TRIVIAL = range(6)
+
+    def reset_parameterization(self, bid, parameterization):
+        """Map::resetParameterization (Map.cpp:513-543): False for an unknown block, RuntimeError for a manifold the block cannot take"""
+        return self._check(self.L.svin_ba_reset_parameterization(self.h, bid, int(parameterization)), "reset_parameterization") == 1
+
+    def parameterization(self, bid):
+        return self._check(self.L.svin_ba_get_parameterization(self.h, bid), "get_parameterization")
 
     def is_parameter_block_constant(self, bid):
         return self._check(self.L.svin_ba_is_parameter_block_constant(self.h, bid), "is_parameter_block_constant") == 1

@@ -2,7 +2,7 @@
 // block through okvis::ceres::Map, solved on the GPU, the estimates are read back from the caller's parameter-block objects):
 //   part 1  okvis_ceres/test/TestHomogeneousPointError.cpp:57-99 -- 100 points, one HomogeneousPointError (variance 0.1)
 //           each, points disturbed, isJacobianCorrect per residual, solve, final_cost < 1e-10;
-//   part 2  okvis_ceres/test/TestMap.cpp:60-150: pose + constant extrinsics + N CONSTANT points ("no point optimization", :93) with
+//   part 2  okvis_ceres/test/TestMap.cpp:60-156 (the Pose2d re-solve of :146-156 included): pose + constant extrinsics + N CONSTANT points ("no point optimization", :93) with
 //           Cauchy-robustified ReprojectionError<equidistant pinhole>, some residuals / blocks removed again, 10 iterations,
 //           the pose must come back to the truth (quaternion 1e-2, translation 1e-1: the reference's thresholds).
 // Prints one line per part for tests/test_gpu_shim.py.
@@ -136,6 +136,28 @@ int main() {
     std::printf("map final_cost %.6e initial_cost %.6e jac_ok %d of %d removed_blocks %d removed_residuals %d d_rot %.3e d_trans %.3e iterations %d exists3 %d\n",
                 map.summary.final_cost, map.summary.initial_cost, jacOk, (int)N, removedBlocks, removedResiduals, dRot, dTr,
                 (int)map.summary.iterations.size() - 1, map.parameterBlockExists(3) ? 1 : 0);
+    // "also try out the resetting of parameterization" (TestMap.cpp:146-156): Pose2d, roll / pitch disturbed by 0.01, solve again.
+    // Beyond the reference's test (which only runs it): the position must not move at all and the cost must come back down.
+    if (!map.resetParameterization(pose->id(), okvis::ceres::Map::Pose2d)) return 10;
+    if (map.resetParameterization(777777, okvis::ceres::Map::Pose2d)) return 11;   // unknown block: false (Map.cpp:514)
+    const double cost6 = map.summary.final_cost;
+    double dq2[4] = {0.5 * 0.01 * rng.next(), 0.5 * 0.01 * rng.next(), 0.0, 1.0};   // oplus: q <- exp(dalpha) * q, dalpha = (a, b, 0)
+    n = std::sqrt(dq2[0] * dq2[0] + dq2[1] * dq2[1] + dq2[2] * dq2[2] + dq2[3] * dq2[3]);
+    for (double& v : dq2) v /= n;
+    double qStart[4];
+    quatMul(dq2, qe, qStart);
+    const double rStart[3] = {est.r()[0], est.r()[1], est.r()[2]};
+    pose->setEstimate(makeT(rStart, qStart));
+    map.solve();
+    const okvis::kinematics::Transformation est2 = pose->estimate();
+    const double dPos = std::fabs(est2.r()[0] - rStart[0]) + std::fabs(est2.r()[1] - rStart[1]) + std::fabs(est2.r()[2] - rStart[2]);
+    const double qe2[4] = {est2.q().x(), est2.q().y(), est2.q().z(), est2.q().w()};
+    const double qinv2[4] = {-qe2[0], -qe2[1], -qe2[2], qe2[3]};
+    double qd2[4];
+    quatMul(qWS, qinv2, qd2);
+    std::printf("map2d final_cost %.9e initial_cost %.9e cost6 %.9e d_pos %.3e d_rot %.3e iterations %d\n", map.summary.final_cost,
+                map.summary.initial_cost, cost6, dPos, 2.0 * std::sqrt(qd2[0] * qd2[0] + qd2[1] * qd2[1] + qd2[2] * qd2[2]),
+                (int)map.summary.iterations.size() - 1);
   }
   return 0;
 }

@@ -252,3 +252,53 @@ def test_imu_sonar_depth_errors_through_the_map_interface(gpu_lib):
         assert np.max(np.abs(est.get_parameter_block(SB[k]) - m.get_param(SB[k]))) < 1e-7
     # Map::removeResidualBlock on the IMU factor
     assert est.map_remove_residual_block(rid_imu) and not est.map_remove_residual_block(rid_imu)
+
+
+@pytest.mark.parametrize("manifold,param", [(3, 2), (4, 3), (2, 4)])
+def test_reduced_pose_manifolds_match_the_oracle_and_the_definition(gpu_lib, manifold, param):
+    """Map::resetParameterization (Map.cpp:513-543) with Pose3d / Pose4d / Pose2d (PoseManifold.cpp:173-466) on the device: the six
+    rows of the pose stay in the reduced system and k_lock_rows strikes out the held ones before the solve.  Same problem as
+    tests/test_oracle_manifolds.py: the device must end where the oracle's reduced-manifold solve ends, and pass the same
+    definition checks (stationary in the free directions only, held directions untouched)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import test_oracle_manifolds as tom
+    from svin_amd.estimator import Estimator
+    g = np.load(os.path.join(GOLD, "tiny_window.npz"))
+    T_start = tom.disturbed_start(g)
+    est = Estimator(0)
+    for c in range(2):
+        est.add_camera(syn.DIST_RADTAN, g["intr"], g["dist"], 752, 480, [0.0, 0.0, 0.0, 0.0])
+    info = 64.0 / float(g["size"]) ** 2 * np.eye(2)
+    assert est.map_add_parameter_block(1, est.BLOCK_POSE, g["T0"]) and est.set_parameter_block_constant(1)
+    assert est.map_add_parameter_block(2, est.BLOCK_POSE, T_start)
+    for c in range(2):
+        assert est.map_add_parameter_block(3 + c, est.BLOCK_POSE, g["T_SC"][c]) and est.set_parameter_block_constant(3 + c)
+    nL = len(g["lm_init"])
+    for l in range(nL):
+        assert est.map_add_parameter_block(10 + l, est.BLOCK_HOMOGENEOUS_POINT, np.r_[g["lm_init"][l], 1.0])
+        for f, pose in enumerate((1, 2)):
+            for c in range(2):
+                assert est.map_add_reprojection_error(pose, 10 + l, 3 + c, c, g["uv"][f, c, l], info) != 0
+    assert est.parameterization(2) == est.POSE6D
+    assert est.reset_parameterization(2, param) and est.parameterization(2) == param
+    assert not est.reset_parameterization(999, param)                       # unknown block: the reference's false
+    with pytest.raises(RuntimeError):
+        est.reset_parameterization(10, param)                              # a landmark cannot take a pose manifold
+    est.set_solver_options(1e-16, 1e-16, 1e-16)
+    est.optimize(500)
+    s = est.summary()
+    T1 = est.get_parameter_block(2)
+    lm = np.stack([est.get_parameter_block(10 + l)[:3] for l in range(nL)])
+    Tn = T_start / np.r_[1, 1, 1, [np.linalg.norm(T_start[3:])] * 4]
+    tom.check_solution(g, Tn, T1, lm, s["final_cost"], manifold)
+    m = tom.build_oracle(g, T_start, manifold)
+    so = m.solve(500)
+    To = m.get_param(2)
+    print("manifold", manifold, "gpu", s["final_cost"], s["iterations"], "oracle", so["final_cost"], so["iterations"])
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-9 * so["final_cost"]
+    assert np.linalg.norm(T1[:3] - To[:3]) < 1e-6 and quat_close(T1[3:], To[3:]) < 1e-6
+    # back to six degrees of freedom: the same handle goes on to the unrestricted minimum
+    assert est.reset_parameterization(2, est.POSE6D)
+    est.optimize(500)
+    assert est.summary()["final_cost"] < s["final_cost"] * (1 - 1e-6)

@@ -145,3 +145,8 @@ def test_reference_shaped_map_programs_run_on_the_gpu(gpu_lib, tmp_path):
     assert int(m["jac_ok"]) == 300 and int(m["removed_blocks"]) == 15 and int(m["removed_residuals"]) == 15 and int(m["exists3"]) == 0
     assert float(m["d_rot"]) < 1e-2 and float(m["d_trans"]) < 1e-1                                              # TestMap.cpp:140-144
     assert float(m["final_cost"]) < float(m["initial_cost"])
+    # TestMap.cpp:146-156: Pose2d (roll / pitch only) after a roll / pitch disturbance -- the position stays where it was, bit for bit,
+    # and the solve brings the cost back to the 6-DoF minimum's neighbourhood
+    m2 = kv(lines["map2d"])
+    assert float(m2["d_pos"]) == 0.0 and float(m2["final_cost"]) < float(m2["initial_cost"])
+    assert float(m2["final_cost"]) < float(m2["cost6"]) * (1 + 1e-3) and float(m2["d_rot"]) < 1e-2
