@@ -19,6 +19,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -142,6 +143,25 @@ extern "C" void svin_debug_trace(unsigned long long* out, int reset) {
 #define TRACE(k) ((void)0)
 #endif
 
+// side stream of a solver stream (one per device and stream, created on first use, kept for the life of the process) with the
+// events of the fork / join around what runs on it
+struct SideLane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
+#define HIP_LAUNCH_OK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+static SideLane& sideLaneOf(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideLane> pool;
+  int dev = 0;
+  HIP_LAUNCH_OK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  SideLane& l = pool[std::make_pair(dev, s)];
+  if (!l.side) {
+    HIP_LAUNCH_OK(hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking));
+    HIP_LAUNCH_OK(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+    HIP_LAUNCH_OK(hipEventCreateWithFlags(&l.mid, hipEventDisableTiming));
+    HIP_LAUNCH_OK(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+  }
+  return l;
+}
 // partial-sum slots in p.partial (each slot holds up to kMaxPartials doubles)
 constexpr int kMaxPartials = 4096;
 enum PartialSlot : int {
@@ -1906,6 +1926,8 @@ void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t 
   const int nR = (p.N + 255) / 256, pri = p.priorM > 0 ? 1 : 0;
   if (sumCost && p.F + nR + pri > kEvalSplitBlocks && !optOn(kOptNoEvalSplit)) {
     const size_t stage = evalSplitStageBytes(p);
+    // (measured, round 6: the factor blocks on the side stream beside the reprojection blocks, one cost ticket for both launches --
+    //  0.665 ms per iteration against 0.65 one after the other: both kernels slow down side by side by more than the overlap gains)
     if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_reproj_split<true>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
     else hipLaunchKernelGGL(k_eval_reproj_split<false>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
     hipLaunchKernelGGL(k_eval_rest_split, dim3(p.F + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, pri);
@@ -3631,6 +3653,8 @@ static DenseSchurPlan denseSchurPlan(const DeviceProblem& p) {
   return q;
 }
 int schurDenseABlocks(const DeviceProblem& p) { return (p.L > 0 && p.N > 0 && p.dC > 0 && p.schurDense && denseSchurPlan(p).aBlocks) ? 1 : 0; }
+static bool sbEarlyActive(const DeviceProblem& p);                                          // (behind the chain kernels, below)
+static void launchSbEarly(const DeviceProblem& p, hipStream_t side, double mu, bool initScale);
 void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool initScale, hipStream_t s, bool zeroFirst) {
   const int dC = p.dC;
   if (zeroFirst) launchZeroBuild(p, s);
@@ -3665,6 +3689,22 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     // Round 6: the block-pair form (k_blocks_slots + k_schur_rows) is the default; pack() decides (DeviceProblem::schurBlocks,
     // its slot tables) -- SVIN_PANELS_OLD=1 at pack() time keeps the round-4 / 5 tile form, whose work list holds fewer chunks per
     // workgroup.
+    // p.sideLane (one GPU, wide window; DeviceProblem): the small factors -- and behind them the factorisation and the forward
+    // substitution of the speed / bias chain, which read nothing the landmarks contribute to (S_ss, S_sk and g_s come from the IMU
+    // factors and the prior alone) -- run on a side stream beside the landmark elimination: 22 + 35 + 29 us off the iteration's
+    // critical path.  The pose blocks of S receive the factors' atomic adds AND the plain read-modify-writes of
+    // k_blocks_pose_reduce: the latter waits for the former (event `mid`).
+    SideLane* lane = nullptr;
+    const bool early = sbEarlyActive(p);
+    if (early) {
+      lane = &sideLaneOf(s);
+      HIP_LAUNCH_OK(hipEventRecord(lane->fork, s));
+      HIP_LAUNCH_OK(hipStreamWaitEvent(lane->side, lane->fork, 0));
+      hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, lane->side, p, nFac);
+      HIP_LAUNCH_OK(hipEventRecord(lane->mid, lane->side));
+      launchSbEarly(p, lane->side, mu, initScale);
+      HIP_LAUNCH_OK(hipEventRecord(lane->join, lane->side));
+    }
     if (p.schurBlocks) {
       constexpr int NW = kBlkWaves;
       const size_t ldsBlk = (size_t)std::max(2 * kBlkBatchRecs * kBlkStride, kBlkPanelPoses * kBlkPanelPoses * 36) * 8;   // (two record buffers / slab image)
@@ -3682,13 +3722,18 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_slots, dim3(nSlotBlocks), dim3(256), ldsLm, s, p, nCopies);
       ensureDynamicLds((const void*)k_schur_rows<NW>, ldsBlk);
       if (p.nPanelBlocks > 0) hipLaunchKernelGGL((k_schur_rows<NW>), dim3(p.nPanelBlocks), dim3(64 * NW), ldsBlk, s, p);
+      if (early) HIP_LAUNCH_OK(hipStreamWaitEvent(s, lane->mid, 0));
       if (nSlotBlocks > 0) hipLaunchKernelGGL(k_blocks_pose_reduce, dim3(dC / 6), dim3(1024), 0, s, p, nSlotBlocks);
     } else {
       hipLaunchKernelGGL(k_panels_landmarks, dim3((p.L + 15) / 16), dim3(256), 0, s, p, mu, initScale ? 1 : 0);
       ensureDynamicLds((const void*)k_schur_panels<2, false, true>, ldsBytes);
       hipLaunchKernelGGL((k_schur_panels<2, false, true>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
     }
-    if (nFac + nPri > 0) hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
+    if (early) {
+      HIP_LAUNCH_OK(hipStreamWaitEvent(s, lane->join, 0));   // (the chain's Y is there before anything of the solve; long since, in practice)
+    } else if (nFac + nPri > 0) {
+      hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
+    }
     hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 15) / 16, p.nPanelPairs), dim3(256), 0, s, p);
     return;
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
@@ -6582,16 +6627,34 @@ void launchSolveReduced(const DeviceProblem& p, hipStream_t s, double mu, bool i
   launchSolveReducedUnchecked(p, s, mu, initScale, fuseFinalize);
   checkSolverLaunches();
 }
-static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
-  SbElimArgs sb;
-  const int elim = planSbElimination(p, sb);
-  if (!elim) { launchSolveDense(p, s, mu, initScale, fuseFinalize, nullptr); return; }
+// factorisation and forward substitution of the speed / bias chain (the first two launches of the reduced solve with the chain
+// eliminated); fuseFinalize: the chain's rows get their metric and damping here
+static void launchSbChainFactor(const DeviceProblem& p, const SbElimArgs& sb, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
   const size_t ldsFactor = ((size_t)sb.n * 162 + (size_t)((sb.n + 1) / 2) * 243) * 8;
   ensureDynamicLds((const void*)k_sb_factor, ldsFactor);
   hipLaunchKernelGGL(k_sb_factor, dim3(1), dim3(kSbFactorThreads), ldsFactor, s, p, sb, mu, initScale ? 1 : 0, fuseFinalize ? 1 : 0);
   const size_t ldsFwd = ((size_t)sb.rowsY * kSbCols + (size_t)sb.n * kSbLdsRec) * 8;
   ensureDynamicLds((const void*)k_sb_forward, ldsFwd);
   hipLaunchKernelGGL(k_sb_forward, dim3(sb.ldY / kSbCols), dim3(256), ldsFwd, s, p, sb);
+}
+// ONE predicate for the build (which then launches the chain's kernels) and the solve (which then skips them)
+static bool sbEarlyActive(const DeviceProblem& p) {
+  if (!(p.sideLane != 0 && p.L > 0 && p.N > 0 && p.dC > 0 && !p.schurDense && p.schurPanels && p.schurBlocks && p.nLocked == 0)) return false;
+  if (p.F + priorAccBlocks(p) <= 0) return false;
+  SbElimArgs sb;
+  return planSbElimination(p, sb) != 0;
+}
+static void launchSbEarly(const DeviceProblem& p, hipStream_t side, double mu, bool initScale) {
+  SbElimArgs sb;
+  if (planSbElimination(p, sb)) launchSbChainFactor(p, sb, side, mu, initScale, /*fuseFinalize=*/true);
+}
+static void launchSolveReducedUnchecked(const DeviceProblem& p, hipStream_t s, double mu, bool initScale, bool fuseFinalize) {
+  SbElimArgs sb;
+  const int elim = planSbElimination(p, sb);
+  if (!elim) { launchSolveDense(p, s, mu, initScale, fuseFinalize, nullptr); return; }
+  // (p.sideLane: the build of this iteration has run them already, with this mu and initScale -- launchAccumulateNormalEquations)
+  if (p.sideLane != 0 && sbEarlyActive(p) && !fuseFinalize) throw std::logic_error("sbEarly without the fused finalisation");
+  if (!sbEarlyActive(p)) launchSbChainFactor(p, sb, s, mu, initScale, fuseFinalize);
   if (elim == 1) {
     launchSolveDense(p, s, mu, initScale, fuseFinalize, &sb);
   } else {

@@ -213,6 +213,12 @@ struct DeviceProblem {
   // right-hand side first (k_lock_rows) -- the same system as with those Jacobian columns removed, the step stays zero there
   const int* lockedRows;
   int nLocked;
+  // Set by Window::solve for the duration of a one-GPU solve: launches may fork onto the side stream of the solver's stream
+  // (kernels.hip sideLaneOf).  Wide windows: the build also launches the small factors and the speed / bias chain's factorisation
+  // and forward substitution (k_factors_only, k_sb_factor, k_sb_forward) there, beside the landmark elimination, whose results
+  // they do not read, and launchSolveReduced skips them -- build and solve of an iteration must then see the same mu / initScale,
+  // which is what the trust-region loop does anyway.
+  int sideLane;
 };
 
 // ---- batched solve (svin_ba_solve_prepared_batch: B independent windows of equal launch geometry through ONE launch sequence per

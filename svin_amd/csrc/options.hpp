@@ -37,6 +37,7 @@ enum DebugOption : int {
   kOptBatchTiming,         // SVIN_BATCH_TIMING: print the host's issue / collect times of a batched solve
   kOptNoEvalSplit,         // SVIN_NO_EVAL_SPLIT: wide windows keep the one-launch evaluation (k_eval_all) and the one-workgroup-per-CU post-solve pass
   kOptSlabChunks,          // SVIN_SLAB_CHUNKS=n: chunks of 16 landmarks per workgroup of k_schur_dense (read by pack())
+  kOptNoSbEarly,           // SVIN_NO_SB_EARLY: wide windows factorise the speed / bias chain inside the reduced solve, not beside the build
   kOptCount
 };
 

@@ -68,7 +68,7 @@ struct OptionTable {
         {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
         {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}, {kOptBatchLanes, "SVIN_BATCH_LANES"},
         {kOptBatchTiming, "SVIN_BATCH_TIMING"}, {kOptNoEvalSplit, "SVIN_NO_EVAL_SPLIT"},
-        {kOptSlabChunks, "SVIN_SLAB_CHUNKS"}};
+        {kOptSlabChunks, "SVIN_SLAB_CHUNKS"}, {kOptNoSbEarly, "SVIN_NO_SB_EARLY"}};
     static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
     for (const auto& n : kNames) {
       name[n.which] = n.env;
@@ -2321,6 +2321,11 @@ void Window::solve(size_t numIter, bool verbose) {
   // the stop vote (k_set_stop_vote) travels in the slots k_post_solve uses for the fused dogleg coefficients of the deferred
   // landmark step: the two never meet because a sharded solve takes neither the fused nor the deferred step
   if (dist && (fuseStep || deferLm)) throw std::logic_error("sharded solve with a fused step");
+  // one GPU: the builds of this solve also run the speed / bias chain's factorisation, beside the landmark elimination (kernels.hpp
+  // DeviceProblem::sideLane; every build below is followed by a solve with the same mu / initScale, or not used at all).  Sharded: the
+  // chain's blocks are complete only after the all-reduce.
+  struct SbEarlyGuard { DeviceProblem& q; ~SbEarlyGuard() { q.sideLane = 0; } } sbEarlyGuard{p};
+  p.sideLane = (!dist && !optOn(kOptNoSbEarly)) ? 1 : 0;
   evaluateAll(false, s);
   TrustRegionHost tr;   // every decision of the loop (trust_region.hpp: HIP-free, replayed on the CPU by the tests)
   // The first build depends on no decision (initial damping, metric fixed here): it is enqueued right behind the initial
