@@ -307,7 +307,7 @@ def window_record(name, spec, device, steps, warmup, iters):
             "solve": {"kernel": "k_chol_solve_lds" if d <= 176 else ("k_chol_solve_lds with border rows" if d <= 200 else "k_chol_solve_ll") if d <= 272 else ("k_sb_factor / _forward / _load / _back (speed / bias chain, cyclic reduction) + k_big_chol_chain + k_big_back on the kept rows"),
                       "launch_ms": so, "flops": chol_flops, "achieved": chol_flops / (so * 1e-3) / 1e12,
                       "frac": chol_flops / (so * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS},
-            "schur": {"kernel": "k_schur_dense" if spec.P <= 20 else "k_schur_panels", "launch_ms": bu, "flops": schur_flops,
+            "schur": {"kernel": "k_schur_dense" if spec.P <= 20 else "k_panels_landmarks + k_blocks_slots + k_schur_rows + k_blocks_pose_reduce (+ small factors, slab sum)", "launch_ms": bu, "flops": schur_flops,
                       "achieved": schur_flops / (bu * 1e-3) / 1e12, "frac": schur_flops / (bu * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS},
             "note": "algorithmic flops (Cholesky d^3/3 + two triangular solves; Schur complement sum_l 3 (6 n_l)^2) over the launch time: "
                     "both are latency-bound chains at these sizes (DESIGN.md 3), the fractions say how far from the matrix pipes' rate"}
@@ -316,15 +316,16 @@ def window_record(name, spec, device, steps, warmup, iters):
         rec["roofline"]["kernel"] = rec["roofline"]["solve"]["kernel"] if so >= bu else rec["roofline"]["schur"]["kernel"]
         rec["roofline"]["traffic"] = None
         if spec.P > 20:
-            # MFMA flops k_schur_panels executes (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) over the algorithmic count
-            # for THIS window: measured under the profiler (tools/run_r04_profiles.sh), quoted when it describes the same window
+            # MFMA flops k_schur_rows executes (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 x 512) over the algorithmic count
+            # for THIS window: measured under the profiler (tools/run_r06_profiles.sh), quoted when it describes the same window
             try:
-                with open(os.path.join(ROOT, "profiles", "r05_config4_mfma.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r06_config4_mfma.json")) as fh:
                     mf = json.load(fh)
                 if abs(mf["algorithmic_flops_per_launch"] - schur_flops) < 1e-6 * schur_flops:
                     rec["roofline"]["executed_over_algorithmic"] = mf["executed_over_algorithmic"]
                     rec["roofline"]["executed_mfma_flops_per_launch"] = mf["executed_mfma_flops_per_launch"]
-                    rec["roofline"]["executed_source"] = "profiles/r05_config4_mfma.json"
+                    rec["roofline"]["executed_kernel"] = mf.get("kernel")
+                    rec["roofline"]["executed_source"] = "profiles/r06_config4_mfma.json"
             except (OSError, KeyError, ValueError):
                 pass
     except Exception as ex:
@@ -870,7 +871,7 @@ def main():
         # cannot be read from inside this process, so the committed measurement is quoted when it describes the same
         # launch (same replica count and algorithmic bytes); otherwise null.
         traffic, traffic_from = None, None
-        for name in ("r05_k1_pmc.json", "r04_k1_pmc.json", "r02_k1_pmc.json", "r01_k1_pmc.json"):
+        for name in ("r06_k1_pmc.json", "r05_k1_pmc.json", "r04_k1_pmc.json", "r02_k1_pmc.json", "r01_k1_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh)
