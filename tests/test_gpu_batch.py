@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def states_of(est, fids, lids):
     T = np.stack([est.get_T_WS(f) for f in fids])
-    sb = np.stack([est.get_speed_and_bias(f) for f in fids])
+    sb = np.stack([v if v is not None else np.full(9, np.nan) for v in (est.get_speed_and_bias(f) for f in fids)])   # (old keyframes of a sliding window keep their pose only)
     lms = est.get_landmarks()
     lm = np.stack([np.r_[lms[l]["point"], lms[l]["quality"]] for l in lids])
     return T, sb, lm
@@ -96,3 +96,42 @@ def test_mixed_geometries_fall_into_groups_and_singles(gpu_lib):
     with pytest.raises(RuntimeError):
         estimator.optimize_batch([batch[0][0], batch[0][0]], 2)
     assert estimator.optimize_batch([], 3) == 0
+
+
+def test_batch_of_sliding_windows_with_marginalisation_priors(gpu_lib):
+    """windows in SVIn's operating mode: fed frame by frame, optimised and marginalised after every frame -- each carries a
+    marginalisation prior (the prior block of the batched evaluation, the prior's blocks of the batched build) and fixed-lag
+    structure.  Three handles per seed take the identical history; before the last optimisation two of them go into the batch
+    (partners of one geometry), the third is optimised alone: bit for bit."""
+    from svin_amd import estimator
+    from svin_amd.estimator import Estimator
+
+    def history(seed):
+        spec = syn.make_window(P=9, L=600, n_obs=6000, seed=seed, keyframe_every=2, frame_dt=0.3)
+        est = Estimator(0)
+
+        def on_frame(k, fid):
+            if k < spec.P - 1:
+                est.optimize(6)
+                est.apply_marginalization(3, 2)
+        fids, lids = syn.feed(est, spec, on_frame=on_frame)
+        est.wait_idle()
+        return est, est.frame_ids(), [l for l in lids if l in est.get_landmarks()]
+
+    seeds = [11, 12, 13]
+    alone = [history(sd) for sd in seeds]
+    batch = [history(sd) for sd in seeds for _ in range(2)]   # two handles per seed: every window has a partner of its geometry
+    for k, (b, fb, lb) in enumerate(batch):
+        a, fa, la = alone[k // 2]
+        assert a.marg() is not None and fa == fb and la == lb
+        for x, y in zip(states_of(a, fa, la), states_of(b, fb, lb)):
+            assert np.array_equal(x, y, equal_nan=True), "the histories of a seed differ before the batch"
+    for a, _, _ in alone:
+        a.optimize(8)
+    assert estimator.optimize_batch([b[0] for b in batch], 8) == len(batch)
+    for k, (b, fb, lb) in enumerate(batch):
+        a, fa, la = alone[k // 2]
+        sa, sb = a.summary(), b.summary()
+        assert (sa["iterations"], sa["successful"], sa["final_cost"]) == (sb["iterations"], sb["successful"], sb["final_cost"]), (k, sa, sb)
+        for x, y in zip(states_of(a, fa, la), states_of(b, fb, lb)):
+            assert np.array_equal(x, y, equal_nan=True), k
