@@ -1927,7 +1927,11 @@ void launchEvalAll(const DeviceProblem& p, bool cand, bool sumCost, hipStream_t 
   if (sumCost && p.F + nR + pri > kEvalSplitBlocks && !optOn(kOptNoEvalSplit)) {
     const size_t stage = evalSplitStageBytes(p);
     // (measured, round 6: the factor blocks on the side stream beside the reprojection blocks, one cost ticket for both launches --
-    //  0.665 ms per iteration against 0.65 one after the other: both kernels slow down side by side by more than the overlap gains)
+    //  0.665 ms per iteration against 0.65 one after the other: both kernels slow down side by side by more than the overlap gains.
+    //  Also measured: the factor blocks FIRST with an event behind them, so that the speculative build's side chain starts beside the
+    //  reprojection blocks instead of behind them -- the side chain then ends before the main one needs it, but the reprojection
+    //  launch takes 41 us instead of 27 next to it: 0.65 again.  A side stream of the highest priority changes nothing either: the
+    //  one workgroup of k_sb_factor / the few of k_sb_forward run 4-5 x slower next to k_schur_rows whatever the queue says.)
     if (p.anyExtVariable) hipLaunchKernelGGL(k_eval_reproj_split<true>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
     else hipLaunchKernelGGL(k_eval_reproj_split<false>, dim3(nR), dim3(256), stage, s, p, cand ? 1 : 0);
     hipLaunchKernelGGL(k_eval_rest_split, dim3(p.F + pri), dim3(256), 0, s, p, cand ? 1 : 0, nR, pri);
@@ -3110,12 +3114,27 @@ __global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopi
   // the four groups of a wave often do -- a copy per group)
   double* sMine = sA + (size_t)((t >> 4) & (nCopies - 1)) * nBlk * kBlkPoseLd;
   const size_t N = (size_t)p.N;
-  for (int j = 0; j < kBlkSlotsPerWorkgroup / 256; ++j) {
+  // the index chain of ALL the thread's slots first (observation range, pose block, landmark, first observation): three dependent
+  // global round trips once per workgroup instead of once per trip -- the kernel has ~1 workgroup per CU and was latency all the way
+  // (68 -> 57 us)
+  constexpr int kTrips = kBlkSlotsPerWorkgroup / 256;
+  int q0s[kTrips], q1s[kTrips], blks[kTrips], lms[kTrips], o0s[kTrips];
+#pragma unroll
+  for (int j = 0; j < kTrips; ++j) {
+    const int sl = blockIdx.x * kBlkSlotsPerWorkgroup + 256 * j + t;
+    const bool has = sl < p.nSlots;
+    q0s[j] = has ? p.slotObsPtr[sl] : 0; q1s[j] = has ? p.slotObsPtr[sl + 1] : 0;
+    blks[j] = has ? (int)p.slotBlk[sl] : 0; lms[j] = has ? p.slotLm[sl] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < kTrips; ++j) o0s[j] = q0s[j] < q1s[j] ? p.slotObs[q0s[j]] : 0;
+#pragma unroll
+  for (int j = 0; j < kTrips; ++j) {
     const int sl = blockIdx.x * kBlkSlotsPerWorkgroup + 256 * j + t;
     if (sl >= p.nSlots) break;
-    const int q0 = p.slotObsPtr[sl], q1 = p.slotObsPtr[sl + 1];
-    const int blk = (int)p.slotBlk[sl];
-    const double* f = p.lmFactor + 9 * (size_t)p.slotLm[sl];
+    const int q0 = q0s[j], q1 = q1s[j];
+    const int blk = blks[j];
+    const double* f = p.lmFactor + 9 * (size_t)lms[j];
     const double i00 = f[0], i10 = f[1], i11 = f[2], i20 = f[3], i21 = f[4], i22 = f[5], cv0 = f[6], cv1 = f[7], cv2 = f[8];
     double W[6][3], U[21], gF[6];
 #pragma unroll
@@ -3123,7 +3142,7 @@ __global__ __launch_bounds__(256) void k_blocks_slots(DeviceProblem p, int nCopi
 #pragma unroll
     for (int a = 0; a < 21; ++a) U[a] = 0.0;
     for (int q = q0; q < q1; ++q) {
-      const size_t o = (size_t)p.slotObs[q];
+      const size_t o = (size_t)(q == q0 ? o0s[j] : p.slotObs[q]);
       const double a0 = p.JlCur[o], a1 = p.JlCur[N + o], a2 = p.JlCur[2 * N + o];
       const double c0 = p.JlCur[3 * N + o], c1 = p.JlCur[4 * N + o], c2 = p.JlCur[5 * N + o];
       const double r0 = p.rCur[o], r1 = p.rCur[N + o];

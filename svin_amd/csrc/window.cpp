@@ -2314,10 +2314,12 @@ void Window::solve(size_t numIter, bool verbose) {
   // the post-solve pass can take the dogleg step itself when no all-reduce sits between them and one workgroup
   // retracts the whole window quickly enough
   const bool noFuseStep = optOn(kOptNoFuseStep);   // A/B switch for profiling
-  const bool fuseStep = !noFuseStep && !dist && (p.nPose + p.nExt + p.nSb + p.L) <= 16384;
   // fused step: the landmark half of the retraction rides in the candidate evaluation (k_eval_all), which reads every
-  // landmark anyway -- the serial tail of k_post_solve only moves the ~20 parameter blocks
-  const bool deferLm = fuseStep && canFuseEvaluation(p) && !optOn(kOptSplitEval) && !optOn(kOptNoDeferLm) && p.L > 0 && p.N > 0;
+  // landmark anyway -- the serial tail of k_post_solve only moves the ~20 parameter blocks.  With the landmarks deferred the
+  // fused step has no size limit (round 6: wide windows took a k_step_retract launch per iteration, 9 us, because of theirs)
+  const bool deferPossible = canFuseEvaluation(p) && !optOn(kOptSplitEval) && !optOn(kOptNoDeferLm) && p.L > 0 && p.N > 0;
+  const bool fuseStep = !noFuseStep && !dist && ((p.nPose + p.nExt + p.nSb + p.L) <= 16384 || deferPossible);
+  const bool deferLm = fuseStep && deferPossible;
   // the stop vote (k_set_stop_vote) travels in the slots k_post_solve uses for the fused dogleg coefficients of the deferred
   // landmark step: the two never meet because a sharded solve takes neither the fused nor the deferred step
   if (dist && (fuseStep || deferLm)) throw std::logic_error("sharded solve with a fused step");
