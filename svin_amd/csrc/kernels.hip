@@ -3446,8 +3446,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_schur_rows(DeviceProblem p) {
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    if (row0 < nPB && dValid) img[(row0 * nPB + k) * 36 + dOff] = acc0[k];
-    if (row1 < nPB && dValid) img[(row1 * nPB + k) * 36 + dOff] = acc1[k];
+    // (a heavy block row may have a second accumulator set on another wave -- Window::pack --: the image is zero, the adds of the
+    //  two sets commute)
+    if (row0 < nPB && dValid) atomicAdd(&img[(row0 * nPB + k) * 36 + dOff], acc0[k]);
+    if (row1 < nPB && dValid) atomicAdd(&img[(row1 * nPB + k) * 36 + dOff], acc1[k]);
   }
   __syncthreads();
   double* slab = p.slabs + (size_t)b * kPanelSlab;
@@ -3748,12 +3750,14 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
       ensureDynamicLds((const void*)k_schur_panels<2, false, true>, ldsBytes);
       hipLaunchKernelGGL((k_schur_panels<2, false, true>), dim3(p.nPanelBlocks), dim3(256), ldsBytes, s, p, mu, initScale ? 1 : 0, p.nPanelBlocks, nFac);
     }
-    if (early) {
-      HIP_LAUNCH_OK(hipStreamWaitEvent(s, lane->join, 0));   // (the chain's Y is there before anything of the solve; long since, in practice)
-    } else if (nFac + nPri > 0) {
-      hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
-    }
+    if (!early && nFac + nPri > 0) hipLaunchKernelGGL(k_factors_only, dim3(nFac + nPri), dim3(256), 0, s, p, nFac);
     hipLaunchKernelGGL(k_reduce_panel_slabs, dim3((kPanelSlab + 15) / 16, p.nPanelPairs), dim3(256), 0, s, p);
+    // The join comes LAST (the slab sum touches pose rows only, the chain's kernels read speed / bias rows only) but inside this
+    // function: once it returns, everything it enqueued is ordered on `s` (a later k_zero_build must not meet a chain still reading S).
+    // The chain is what the main stream waits for: k_sb_factor (145 KB of LDS) and k_sb_forward (161 KB per workgroup) need EMPTY CUs
+    // and get them only when k_schur_rows (two workgroups of 77 KB per CU, refilled from a queue of ~1 000) runs out -- they end with
+    // it however early they are launched, whatever the stream's or the waves' priority (both measured).
+    if (early) HIP_LAUNCH_OK(hipStreamWaitEvent(s, lane->join, 0));
     return;
   } else if (p.L > 0 && p.N > 0 && dC > 0) {
     const size_t accBytes = ((size_t)dC * dC + 3 * dC) * 8;

@@ -38,6 +38,7 @@ enum DebugOption : int {
   kOptNoEvalSplit,         // SVIN_NO_EVAL_SPLIT: wide windows keep the one-launch evaluation (k_eval_all) and the one-workgroup-per-CU post-solve pass
   kOptSlabChunks,          // SVIN_SLAB_CHUNKS=n: chunks of 16 landmarks per workgroup of k_schur_dense (read by pack())
   kOptNoSbEarly,           // SVIN_NO_SB_EARLY: wide windows factorise the speed / bias chain inside the reduced solve, not beside the build
+  kOptNoRowSplit,          // SVIN_NO_ROW_SPLIT: k_schur_rows work list with one accumulator set per block row (read by pack())
   kOptCount
 };
 

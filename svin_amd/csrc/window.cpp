@@ -68,7 +68,8 @@ struct OptionTable {
         {kOptPanelsOld, "SVIN_PANELS_OLD"}, {kOptNoLL, "SVIN_NO_LL"}, {kOptNoSbElim, "SVIN_NO_SB_ELIM"},
         {kOptNoLdsBorder, "SVIN_NO_LDS_BORDER"}, {kOptBlkRounds, "SVIN_BLK_ROUNDS"}, {kOptBatchLanes, "SVIN_BATCH_LANES"},
         {kOptBatchTiming, "SVIN_BATCH_TIMING"}, {kOptNoEvalSplit, "SVIN_NO_EVAL_SPLIT"},
-        {kOptSlabChunks, "SVIN_SLAB_CHUNKS"}, {kOptNoSbEarly, "SVIN_NO_SB_EARLY"}};
+        {kOptSlabChunks, "SVIN_SLAB_CHUNKS"}, {kOptNoSbEarly, "SVIN_NO_SB_EARLY"},
+        {kOptNoRowSplit, "SVIN_NO_ROW_SPLIT"}};
     static_assert(sizeof(kNames) / sizeof(kNames[0]) == kOptCount, "every option has its environment variable");
     for (const auto& n : kNames) {
       name[n.which] = n.env;
@@ -1896,6 +1897,7 @@ void Window::pack(bool solveFollows) {
       wordsPerWg = std::max<size_t>(kBlkMinWordsPerBlock, (total + places - 1) / places);
     }
     hPanelPairPtr.push_back(0);
+    size_t balWgMax = 0, balWgAll = 0, balAll = 0, balMax = 0;   // pair words of the busiest wave / of all waves: per workgroup, per batch (a barrier pair per batch)
     for (int I = 0; I < nPan; ++I)
       for (int J = 0; J <= I; ++J) {
         const std::vector<int>& li = lists[I * (I + 1) / 2 + J];
@@ -1904,24 +1906,55 @@ void Window::pack(bool solveFollows) {
         for (size_t k = 0; k < nEnt;) {
           size_t kEnd = k, wgWords = 0;
           while (kEnd < nEnt && wgWords < wordsPerWg) wgWords += entryWords(&li[4 * kEnd++], dg);
-          // the workgroup's sixteen block rows dealt to its eight waves, two each: heaviest first, to the wave with the least so far
+          // The workgroup's block rows dealt to the sixteen accumulator sets of its eight waves (two each).  Rows no landmark of the
+          // list touches get none; the sets that are left go to the heaviest rows as a SECOND set (the row's runs are then shared
+          // between two waves -- by the lighter wave of the moment, below -- and k_schur_rows adds both sets into the slab image:
+          // two terms, so the sum does not depend on their order).  Sets heaviest first, to the wave with the least so far.
+          // (round 6, measured on the bench window: one set per row and rows dealt by load left the busiest wave of a batch with
+          //  1.59 x the mean number of pair words and the busiest wave of a workgroup with 1.24 x; rows r, r + 8 to wave r: 1.71;
+          //  entries re-ordered round robin by the wave they load most: 1.57)
           long rowLoad[16] = {0};
           for (size_t e = k; e < kEnd; ++e) {
             const int fa = li[4 * e], nA = li[4 * e + 2] & 0xff, nB = li[4 * e + 2] >> 8;
             for (int ka = 0; ka < nA; ++ka) rowLoad[hSlotBlk[fa + ka] - 16 * I] += ((dg ? ka + 1 : nB) + 1) & ~1;
           }
-          int rowOrder[16], ownerWave[16], ownerSel[16], ownRows[kBlkWaves][2];
+          int nOwn[16] = {0}, ownerWave[16][2], ownerSel[16][2], ownRows[kBlkWaves][2];
           long waveLoad[kBlkWaves] = {0};
-          for (int r = 0; r < 16; ++r) rowOrder[r] = r;
-          std::stable_sort(rowOrder, rowOrder + 16, [&](int a, int b) { return rowLoad[a] > rowLoad[b]; });
           for (int wvv = 0; wvv < kBlkWaves; ++wvv) ownRows[wvv][0] = ownRows[wvv][1] = 255;
-          for (int kk = 0; kk < 16; ++kk) {
-            const int r = rowOrder[kk];
-            int best = -1;
-            for (int wvv = 0; wvv < kBlkWaves; ++wvv)
-              if (ownRows[wvv][1] == 255 && (best < 0 || waveLoad[wvv] < waveLoad[best])) best = wvv;
-            const int sel = ownRows[best][0] == 255 ? 0 : 1;
-            ownRows[best][sel] = r; ownerWave[r] = best; ownerSel[r] = sel; waveLoad[best] += rowLoad[r];
+          {
+            int mult[16], sets = 0;
+            for (int r = 0; r < 16; ++r) { mult[r] = rowLoad[r] > 0 ? 1 : 0; sets += mult[r]; }
+            const bool split = !optOn(kOptNoRowSplit);
+            while (split && sets < 2 * kBlkWaves) {
+              int best = -1;
+              for (int r = 0; r < 16; ++r)
+                if (mult[r] == 1 && rowLoad[r] >= 16 && (best < 0 || rowLoad[r] > rowLoad[best])) best = r;
+              if (best < 0) break;
+              mult[best] = 2; ++sets;
+            }
+            struct Unit { int row; long load; };
+            std::vector<Unit> units;
+            for (int r = 0; r < 16; ++r)
+              for (int c = 0; c < mult[r]; ++c) units.push_back(Unit{r, rowLoad[r] / mult[r]});
+            std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.load > b.load; });
+            for (const Unit& u : units) {
+              int best = -1;
+              for (int wvv = 0; wvv < kBlkWaves; ++wvv) {
+                if (ownRows[wvv][1] != 255) continue;
+                if (nOwn[u.row] == 1 && ownerWave[u.row][0] == wvv) continue;   // (the two sets of a row: two waves)
+                if (best < 0 || waveLoad[wvv] < waveLoad[best]) best = wvv;
+              }
+              if (best < 0) continue;   // (only the second set of a row can be left over: the row keeps its first)
+              const int sel = ownRows[best][0] == 255 ? 0 : 1;
+              ownRows[best][sel] = u.row;
+              ownerWave[u.row][nOwn[u.row]] = best; ownerSel[u.row][nOwn[u.row]] = sel; ++nOwn[u.row];
+              waveLoad[best] += u.load;
+            }
+          }
+          {
+            long mx = 0, sum = 0;
+            for (int wvv = 0; wvv < kBlkWaves; ++wvv) { mx = std::max(mx, waveLoad[wvv]); sum += waveLoad[wvv]; }
+            balWgMax += (size_t)mx; balWgAll += (size_t)sum;
           }
           int ownWords[4] = {0, 0, 0, 0};
           for (int wvv = 0; wvv < kBlkWaves; ++wvv)
@@ -1937,7 +1970,18 @@ void Window::pack(bool solveFollows) {
               const int need = nA + (dg ? 0 : nB);
               if (recs + need > kBlkBatchRecs - 1) break;
               int add[kBlkWaves] = {0};   // (every run of an A record is padded to an even number of words)
-              for (int ka = 0; ka < nA; ++ka) add[ownerWave[hSlotBlk[fa + ka] - 16 * I]] += ((dg ? ka + 1 : nB) + 1) & ~1;
+              int pick[64];               // which of its row's sets the run of slot ka goes to: the wave with fewer words in this batch
+              for (int ka = 0; ka < nA; ++ka) {
+                const int row = hSlotBlk[fa + ka] - 16 * I;
+                int c = 0;
+                if (nOwn[row] == 2) {
+                  const int w0 = ownerWave[row][0], w1 = ownerWave[row][1];
+                  const size_t l0 = words[w0][0].size() + words[w0][1].size() + (size_t)add[w0], l1 = words[w1][0].size() + words[w1][1].size() + (size_t)add[w1];
+                  c = l1 < l0 ? 1 : 0;
+                }
+                pick[ka] = c;
+                add[ownerWave[row][c]] += ((dg ? ka + 1 : nB) + 1) & ~1;
+              }
               bool fits = true;
               for (int wvv = 0; wvv < kBlkWaves; ++wvv) fits = fits && (int)(words[wvv][0].size() + words[wvv][1].size()) + add[wvv] <= kBlkBatchWords - 12;
               if (!fits) break;
@@ -1947,7 +1991,7 @@ void Window::pack(bool solveFollows) {
               recs += need;
               for (int ka = 0; ka < nA; ++ka) {
                 const int row = hSlotBlk[fa + ka] - 16 * I;
-                std::vector<uint32_t>& wl = words[ownerWave[row]][ownerSel[row]];
+                std::vector<uint32_t>& wl = words[ownerWave[row][pick[ka]]][ownerSel[row][pick[ka]]];
                 const int cnt = dg ? ka + 1 : nB;
                 int pb = 0;
                 for (int kb = 0; kb < cnt; ++kb) {
@@ -1960,6 +2004,11 @@ void Window::pack(bool solveFollows) {
             }
             if (recs == 0) throw std::logic_error("k_schur_rows work list: an entry does not fit a batch");
             hBatch.insert(hBatch.end(), {firstRec, recs});
+            {
+              size_t mx = 0;
+              for (int wvv = 0; wvv < kBlkWaves; ++wvv) { const size_t n = words[wvv][0].size() + words[wvv][1].size(); balAll += n; mx = std::max(mx, n); }
+              balMax += mx;
+            }
             for (int wvv = 0; wvv < kBlkWaves; ++wvv) {
               for (int sel = 0; sel < 2; ++sel)   // (a row's words in eights: padding words in twos -- both operands the zero record, two accumulators)
                 while (words[wvv][sel].size() % 8) {
@@ -1978,6 +2027,10 @@ void Window::pack(bool solveFollows) {
         }
         hPanelPairPtr.push_back(nPanelBlocks);
       }
+    if (optOn(kOptPackTiming))
+      std::printf("[svin_ba pack] k_schur_rows work list: %d workgroups, %zu batches, %zu pair words; the busiest wave of a batch has %.2f x the mean, of a workgroup %.2f x\n",
+                  nPanelBlocks, hBatch.size() / 2, balAll, balAll ? (double)kBlkWaves * (double)balMax / (double)balAll : 0.0,
+                  balWgAll ? (double)kBlkWaves * (double)balWgMax / (double)balWgAll : 0.0);
     hPairWords.resize(hPairWords.size() + 128, 0u);   // (a wave requests its words in 64s)
     hBatch.resize(hBatch.size() + 2 * 3, 0); hWaveTab.resize(hWaveTab.size() + (size_t)4 * kBlkWaves * 3, 0);   // (the kernel reads descriptors three batches ahead, unconditionally)
     upload(dBlkPairs_, hPairWords, s); upload(dBlkBatch_, hBatch, s); upload(dBlkWaveTab_, hWaveTab, s); upload(dBlkRecSlot_, hRecSlot, s);
