@@ -147,13 +147,26 @@ extern "C" void svin_debug_trace(unsigned long long* out, int reset) {
 // events of the fork / join around what runs on it
 struct SideLane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; };
 #define HIP_LAUNCH_OK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+static std::mutex g_sideLaneMutex;
+static std::map<std::pair<int, hipStream_t>, SideLane> g_sideLanes;
+// (called by the owner of `s` before it destroys the stream: the side stream has nothing in flight that `s` has not waited for)
+void releaseSideLane(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_sideLaneMutex);
+  for (auto it = g_sideLanes.begin(); it != g_sideLanes.end();) {
+    if (it->first.second != s) { ++it; continue; }
+    SideLane& l = it->second;
+    if (l.side) { (void)hipStreamSynchronize(l.side); (void)hipStreamDestroy(l.side); }
+    if (l.fork) (void)hipEventDestroy(l.fork);
+    if (l.mid) (void)hipEventDestroy(l.mid);
+    if (l.join) (void)hipEventDestroy(l.join);
+    it = g_sideLanes.erase(it);
+  }
+}
 static SideLane& sideLaneOf(hipStream_t s) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SideLane> pool;
   int dev = 0;
   HIP_LAUNCH_OK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
-  SideLane& l = pool[std::make_pair(dev, s)];
+  std::lock_guard<std::mutex> lock(g_sideLaneMutex);
+  SideLane& l = g_sideLanes[std::make_pair(dev, s)];
   if (!l.side) {
     HIP_LAUNCH_OK(hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking));
     HIP_LAUNCH_OK(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));

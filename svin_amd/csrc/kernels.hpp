@@ -233,6 +233,7 @@ struct BatchSlot {
   double mu, radius;
   int initScale, stages;
 };
+void releaseSideLane(hipStream_t s);   // frees the side stream / events kernels.hip keeps for solver stream `s` (before `s` is destroyed)
 bool batchSupported(const DeviceProblem& p);   // the geometry the batched kernels cover (otherwise the window is solved on its own)
 // one round for the `n` windows of dSlots (device copy of the slot table); `geom` = any window of the batch (equal geometry),
 // `stagesUnion` = OR of the slots' stages, `cand` as for launchEvalAll

@@ -225,7 +225,7 @@ Window::~Window() {
   if (evUploaded_) (void)hipEventDestroy(evUploaded_);
   if (evImuReady_) (void)hipEventDestroy(evImuReady_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream_) { releaseSideLane(stream_); (void)hipStreamDestroy(stream_); }
 }
 
 // ------------------------------------------------------------------------------------------ sensors
