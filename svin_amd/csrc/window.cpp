@@ -2520,14 +2520,14 @@ void Window::swapStateSets() {
 // arithmetic of solve(): same kernels bodies, same grids (gridDim.x), same reduction orders.
 namespace {
 struct BatchKey {
-  int v[16];
-  bool operator<(const BatchKey& o) const { return std::lexicographical_compare(v, v + 16, o.v, o.v + 16); }
+  int v[18];
+  bool operator<(const BatchKey& o) const { return std::lexicographical_compare(v, v + 18, o.v, o.v + 18); }
 };
 BatchKey batchKeyOf(const DeviceProblem& p) {
   // what the grids, the LDS sizes and the uniform kernel arguments of launchBatchRound are computed from (L and N themselves may
   // differ: every kernel reads them from its window's problem)
   return BatchKey{{p.d, p.dC, p.dCPose, (p.L + 15) / 16, (p.N + 255) / 256, p.F, p.nPose, p.nExt, p.nSb, (p.nPose + p.nExt + p.nSb + p.L + 255) / 256,
-                   p.nSlabs, p.priorM, p.anyExtVariable, p.ldS, p.sPadded, p.priorBlocks}};
+                   p.nSlabs, p.priorM, p.anyExtVariable, p.ldS, p.sPadded, p.priorBlocks, p.nCam /* (staging area of the evaluation) */, p.schurDense}};
 }
 }  // namespace
 
