@@ -303,6 +303,16 @@ uint64_t svin_ba_map_add_sonar_error(svin_ba* h, uint64_t pose_block, double ran
                                      const double* patch_xyz, int n_patch);
 /* DepthError(depth, information, first depth) on a pose block  src/DepthError.cpp:50-139 */
 uint64_t svin_ba_map_add_depth_error(svin_ba* h, uint64_t pose_block, double depth, double information, double first_depth);
+/* Map::addResidualBlock (src/Map.cpp:341-376) with a cost function the library has no kernel for: evaluated by the HOST.  The
+ * callback gets the n_blocks parameter blocks in the order given (pose / extrinsics: r(3), q(xyzw); speed / bias: 9) and writes
+ * residual_dim residuals and, per block, the residual_dim x (6 | 9) row-major Jacobian in MINIMAL coordinates (what
+ * ErrorInterface::EvaluateWithMinimalJacobians delivers: pose delta = (dr, dalpha), q <- exp(dalpha) * q); it returns non-zero on
+ * success (::ceres::CostFunction::Evaluate's bool).  Called from the thread that optimises, before every evaluation launch, with one
+ * stream synchronisation each time: a slow path for graphs third parties build through okvis::ceres::Map.  No loss function; no
+ * landmark blocks; residual_dim <= 15; at most 4 blocks and 30 minimal columns.  Such a window is neither batched nor
+ * marginalised nor sharded.  Returns the residual id, 0 if refused. */
+typedef int (*svin_cost_function)(void* user, const double* const* parameters, double* residuals, double** jacobians_minimal);
+uint64_t svin_ba_map_add_host_residual(svin_ba* h, const uint64_t* block_ids, int n_blocks, int residual_dim, svin_cost_function fn, void* user);
 /* ReprojectionError<geometry of camera cam_idx>(uv, information) under CauchyLoss(1) on (pose, landmark, extrinsics)
  * (ReprojectionErrorBase.hpp:50-54, Estimator.cpp:69).  information: 2 x 2 row-major, a positive multiple of the identity
  * (the device stores one weight per residual, as Estimator::addObservation's 64 / size^2 * I needs). */

@@ -5,7 +5,9 @@
 // (Map.hpp:341-347), `solve()`, and the graph queries.  The graph itself lives in libsvin_ba.so (the handle the owning
 // okvis::Estimator created); this class is a view onto it.  What does NOT survive, and why:
 //   * addResidualBlock with an ARBITRARY caller-supplied ::ceres::CostFunction (Map.cpp:341-376): a device solver cannot
-//     call virtual CPU cost functions.  What is there instead: addParameterBlock, and addResidualBlock for the error-term
+//     call virtual CPU cost functions.  Since round 6 any error term that implements ErrorInterface is accepted and evaluated by
+//     the host between the launches (a slow path, pose / speed-bias blocks, no loss); a bare ::ceres::CostFunction is not (there
+//     is no Ceres).  The fast path: addParameterBlock, and addResidualBlock for the error-term
 //     classes of this directory (PoseError, HomogeneousPointError, ReprojectionError<GEOMETRY> under CauchyLoss(1)) -- each
 //     maps onto a factor kind of the device solver (svin_ba_map_*), so that a program shaped like the reference's own tests
 //     (okvis_ceres/test/TestHomogeneousPointError.cpp:57-99, TestMap.cpp:60-150) builds its graph block by block, checks
@@ -207,12 +209,57 @@ class Map {
     return record(svin_ba_map_add_reprojection_error(h_, pose->id(), point->id(), extrinsics->id(), (uint64_t)it->second, uv, e->informationRowMajor()),
                   e, {pose, point, extrinsics});
   }
+  /// Map::addResidualBlock (Map.cpp:341-376) for ANY OTHER error term that implements ErrorInterface (the reference hands any
+  /// ::ceres::CostFunction to Ceres): the object is evaluated by the HOST before every evaluation launch of the solve
+  /// (svin_ba_map_add_host_residual: EvaluateWithMinimalJacobians at the current / candidate blocks, residual and minimal Jacobians to
+  /// the device).  Pose / extrinsics and speed / bias blocks only, no loss, residual dimension <= 15, at most four blocks; a slow
+  /// path by construction.  Returns NULL when the backend refuses the residual (Map.cpp:349-351).
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ERROR_T> e, ::ceres::LossFunction* loss,
+                                            std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> > blocks) {
+    need(); noLoss(loss);
+    if (blocks.empty() || blocks.size() > 4 || blocks.size() != e->parameterBlocks()) return nullptr;
+    std::unique_ptr<HostTerm> term(new HostTerm);
+    uint64_t ids[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      ids[i] = blocks[i]->id();
+      term->dims.push_back(blocks[i]->dimension());
+    }
+    term->m = e->residualDim();
+    term->eval = [e](double const* const* p, double* r, double** J, double** Jm) { return e->EvaluateWithMinimalJacobians(p, r, J, Jm); };
+    const uint64_t rid = svin_ba_map_add_host_residual(h_, ids, (int)blocks.size(), (int)term->m, &Map::hostTrampoline, term.get());
+    if (rid == 0) return nullptr;
+    hostTerms_[rid] = std::move(term);
+    return record(rid, e, std::move(blocks));
+  }
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ERROR_T> e, ::ceres::LossFunction* loss, std::shared_ptr<okvis::ceres::ParameterBlock> x0) {
+    return addResidualBlock(e, loss, std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> >{x0});
+  }
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ERROR_T> e, ::ceres::LossFunction* loss, std::shared_ptr<okvis::ceres::ParameterBlock> x0,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> x1) {
+    return addResidualBlock(e, loss, std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> >{x0, x1});
+  }
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ERROR_T> e, ::ceres::LossFunction* loss, std::shared_ptr<okvis::ceres::ParameterBlock> x0,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> x1, std::shared_ptr<okvis::ceres::ParameterBlock> x2) {
+    return addResidualBlock(e, loss, std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> >{x0, x1, x2});
+  }
+  template <class ERROR_T>
+  ::ceres::ResidualBlockId addResidualBlock(std::shared_ptr<ERROR_T> e, ::ceres::LossFunction* loss, std::shared_ptr<okvis::ceres::ParameterBlock> x0,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> x1, std::shared_ptr<okvis::ceres::ParameterBlock> x2,
+                                            std::shared_ptr<okvis::ceres::ParameterBlock> x3) {
+    return addResidualBlock(e, loss, std::vector<std::shared_ptr<okvis::ceres::ParameterBlock> >{x0, x1, x2, x3});
+  }
   /// Map::removeResidualBlock (Map.cpp:467-492), any residual of the graph
   bool removeResidualBlock(::ceres::ResidualBlockId residual) {
     need();
     const uint64_t rid = reinterpret_cast<uint64_t>(residual);
     built_.erase(rid);
-    return svin_ba_map_remove_residual_block(h_, rid) == 1;
+    const bool ok = svin_ba_map_remove_residual_block(h_, rid) == 1;
+    hostTerms_.erase(rid);   // (after the backend has forgotten the function pointer)
+    return ok;
   }
   /// Map::isJacobianCorrect (Map.cpp:153-252): central differences (delta 1e-8) through the blocks' plus() against the
   /// analytic minimal Jacobians of the error term, max |difference| / ||numeric|| <= relTol per block.  For residuals added
@@ -443,8 +490,25 @@ class Map {
     built_[rid] = std::move(b);
     return reinterpret_cast< ::ceres::ResidualBlockId>(rid);
   }
+  /// an error term the host evaluates for the backend (svin_cost_function's `user`)
+  struct HostTerm {
+    std::function<bool(double const* const*, double*, double**, double**)> eval;
+    size_t m;
+    std::vector<size_t> dims;   // ambient dimensions of the blocks (7 / 9)
+  };
+  static int hostTrampoline(void* user, const double* const* parameters, double* residuals, double** jacobiansMinimal) {
+    const HostTerm* t = static_cast<const HostTerm*>(user);
+    double ambient[4][15 * 9];   // the ambient Jacobians EvaluateWithMinimalJacobians also fills: not used by the backend
+    double* J[4] = {ambient[0], ambient[1], ambient[2], ambient[3]};
+    try {
+      return t->eval(parameters, residuals, J, jacobiansMinimal) ? 1 : 0;
+    } catch (...) {
+      return 0;
+    }
+  }
   svin_ba* h_;
   bool owned_;
+  std::map<uint64_t, std::unique_ptr<HostTerm> > hostTerms_;
   std::map<uint64_t, std::shared_ptr<okvis::ceres::ParameterBlock> > blocks_;   ///< blocks added through addParameterBlock
   std::unordered_map<uint64_t, Built> built_;
   std::map<const void*, int> cams_;                                             ///< camera geometry object -> backend camera index

@@ -684,6 +684,11 @@ uint64_t svin_ba_map_add_depth_error(svin_ba* h, uint64_t pose_block, double dep
   GUARD_BEGIN return h->w.mapAddDepthError(pose_block, depth, information, first_depth);
   GUARD_END(0)
 }
+uint64_t svin_ba_map_add_host_residual(svin_ba* h, const uint64_t* block_ids, int n_blocks, int residual_dim, svin_cost_function fn, void* user) {
+  if (!h) return 0;
+  GUARD_BEGIN return h->w.mapAddHostResidual(block_ids, n_blocks, residual_dim, fn, user);
+  GUARD_END(0)
+}
 uint64_t svin_ba_map_add_reprojection_error(svin_ba* h, uint64_t pose_block, uint64_t landmark, uint64_t extrinsics_block, uint64_t cam,
                                             const double uv[2], const double information[4]) {
   if (!h) return 0;

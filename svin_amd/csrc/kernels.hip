@@ -1431,6 +1431,17 @@ __device__ __forceinline__ void evalFactorBlock(const DeviceProblem& p, int cand
     if (b < fac.nblk) { tblOff = blockOff(p, fac.blkKind[b], fac.blkSlot[b]); tblDim = (fac.blkKind[b] == B_SB) ? 9 : 6; }
   }
 
+  if (fac.kind == F_HOST) {
+    // a caller-supplied cost function (Map::addResidualBlock with a ::ceres::CostFunction the library does not know, Map.cpp:341-376):
+    // the host has evaluated it at this point's parameter blocks and written r, J and the block table of `lin` before this launch
+    // (Window::evaluateHostFactors); what is left is the factor's share of the cost
+    if (t < 64) {
+      const double rv = (t < m && t < 16) ? lin.r[t] : 0.0;
+      const double c = rowSum16(rv * rv);
+      if (t == 0) cstore(p.partial + (size_t)PS_COST_FACTORS * kMaxPartials + f, 0.5 * c);
+    }
+    return;
+  }
   IMU_TICK(qe0);
   if (fac.kind == F_IMU) {
     DevImu& im = p.imus[fac.imuIndex];
@@ -7322,6 +7333,7 @@ bool batchSupported(const DeviceProblem& p) {
   if (solverClass(p.d, p.sPadded != 0) != 0 || cholBorderRows(p.d, p.sPadded != 0) != 0) return false;   // LDS-resident solver, no border
   if (priorAccBlocks(p) > 0 && !p.ownsCamera) return false;
   if (p.nLocked > 0) return false;   // (reduced pose manifolds: k_lock_rows has no batched form)
+  if (p.nHostFactors > 0) return false;
   return true;
 }
 void launchBatchRound(const BatchSlot* dSlots, const DeviceProblem& geom, int n, int stagesUnion, bool cand, hipStream_t s) {

@@ -46,7 +46,8 @@ struct DevImu {
   double sb_ref[9];
 };
 
-enum FactorKind : int { F_IMU = 0, F_POSE_PRIOR = 1, F_SB_PRIOR = 2, F_RELPOSE = 3, F_SONAR = 4, F_DEPTH = 5 };
+enum FactorKind : int { F_IMU = 0, F_POSE_PRIOR = 1, F_SB_PRIOR = 2, F_RELPOSE = 3, F_SONAR = 4, F_DEPTH = 5,
+                        F_HOST = 6 };   // residual and minimal Jacobians computed by a callback of the host (Window::evaluateHostFactors) before every evaluation launch
 enum BlockKind : int { B_POSE = 0, B_EXT = 1, B_SB = 2, B_LM = 3 };
 
 struct DevFactor {
@@ -213,6 +214,7 @@ struct DeviceProblem {
   // right-hand side first (k_lock_rows) -- the same system as with those Jacobian columns removed, the step stays zero there
   const int* lockedRows;
   int nLocked;
+  int nHostFactors;   // factors of kind F_HOST in `factors` (such a window is not batched: the host evaluates between the launches)
   // Set by Window::solve for the duration of a one-GPU solve: launches may fork onto the side stream of the solver's stream
   // (kernels.hip sideLaneOf).  Wide windows: the build also launches the small factors and the speed / bias chain's factorisation
   // and forward substitution (k_factors_only, k_sb_factor, k_sb_forward) there, beside the landmark elimination, whose results

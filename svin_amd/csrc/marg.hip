@@ -1242,6 +1242,9 @@ int Window::applyMarginalizationStrategy(size_t numKeyframes, size_t numImuFrame
   // A pose on a reduced manifold (Map::resetParameterization, a Map-level feature okvis::Estimator never uses: Estimator.cpp:801 is
   // commented out): the prior's columns would have to be the 3 / 4 / 2 minimal ones (MarginalizationError.cpp:147-160 takes
   // minimalDimension()).  Not built; refuse before anything is modified.
+  for (const auto& kv : factors_)
+    if (kv.second.kind == F_HOST)
+      throw std::runtime_error("applyMarginalizationStrategy: a residual evaluated by a host cost function is in the window (its linearisation is not available to the marginalisation kernels)");
   for (const auto& kv : blocks_)
     if (kv.second.lock != 0)
       throw std::runtime_error("applyMarginalizationStrategy: a pose block on a reduced manifold (Pose3d / Pose4d / Pose2d) is in the window");

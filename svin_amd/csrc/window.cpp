@@ -878,6 +878,67 @@ uint64_t Window::mapAddDepthError(uint64_t poseBlock, double depth, double infor
   f.sqrtInfo[0] = std::sqrt(information);
   return addFactor(std::move(f));
 }
+// Map::addResidualBlock with a cost function the library has no kernel for (Map.cpp:341-376; the reference hands ANY
+// ::ceres::CostFunction to Ceres).  The function is evaluated by the HOST: before every evaluation launch the blocks it names are
+// read back, the callback computes the residual and the Jacobians in MINIMAL coordinates (6 columns per pose / extrinsics block,
+// 9 per speed / bias block -- what ErrorInterface::EvaluateWithMinimalJacobians returns), and the record the device kernels
+// consume (FactorLin) is written for it.  A slow path by construction -- one stream synchronisation per evaluation -- for graphs
+// built through okvis::ceres::Map by third parties; no loss function, no landmark blocks (they are eliminated on the device
+// from reprojection residuals alone), residual dimension <= 15, at most 4 blocks / 30 minimal columns.
+uint64_t Window::mapAddHostResidual(const uint64_t* blockIds, int nBlocks, int residualDim, int (*fn)(void*, const double* const*, double*, double**),
+                                    void* user) {
+  if (!blockIds || !fn || nBlocks < 1 || nBlocks > 4 || residualDim < 1 || residualDim > 15) return 0;
+  int cols = 0;
+  for (int b = 0; b < nBlocks; ++b) {
+    const Block* blk = findBlock(blockIds[b]);
+    if (!blk) return 0;   // (unknown, or a landmark)
+    for (int c = 0; c < b; ++c)
+      if (blockIds[c] == blockIds[b]) return 0;
+    cols += blk->kind == B_SB ? 9 : 6;
+  }
+  if (cols > 30) return 0;
+  Factor f;
+  f.kind = F_HOST; f.nblk = nBlocks; f.m = residualDim;
+  for (int b = 0; b < nBlocks; ++b) f.blocks[b] = blockIds[b];
+  f.hostFn = fn; f.hostUser = user;
+  return addFactor(std::move(f));
+}
+void Window::evaluateHostFactors(bool cand, hipStream_t s) {
+  if (hostFactors_.empty()) return;
+  const DeviceProblem& p = prob_;
+  HIP_OK(hipStreamSynchronize(s));   // (the candidate blocks are the device's: k_post_solve / k_step_retract wrote them)
+  std::vector<double> hp((size_t)std::max(p.nPose, 1) * 7), he((size_t)std::max(p.nExt, 1) * 7), hs((size_t)std::max(p.nSb, 1) * 9);
+  if (p.nPose > 0) HIP_OK(hipMemcpy(hp.data(), cand ? p.poseC : p.pose, sizeof(double) * 7 * (size_t)p.nPose, hipMemcpyDeviceToHost));
+  if (p.nExt > 0) HIP_OK(hipMemcpy(he.data(), cand ? p.extC : p.ext, sizeof(double) * 7 * (size_t)p.nExt, hipMemcpyDeviceToHost));
+  if (p.nSb > 0) HIP_OK(hipMemcpy(hs.data(), cand ? p.sbC : p.sb, sizeof(double) * 9 * (size_t)p.nSb, hipMemcpyDeviceToHost));
+  FactorLin* dst = cand ? p.linCand : p.linCur;
+  for (const auto& hf : hostFactors_) {
+    const Factor& f = factors_.at(hf.second);
+    const double* params[4] = {nullptr, nullptr, nullptr, nullptr};
+    double jac[4][15 * 9];
+    double* jp[4] = {jac[0], jac[1], jac[2], jac[3]};
+    FactorLin L;
+    std::memset(&L, 0, sizeof(L));
+    L.m = f.m;
+    for (int b = 0; b < f.nblk; ++b) {
+      const Block& blk = blocks_.at(f.blocks[b]);
+      if (blk.kind == B_POSE) { const int sl = poseSlot_.at(blk.id); params[b] = &hp[(size_t)7 * sl]; L.off[b] = hPoseOffKeep_[(size_t)sl]; L.dim[b] = 6; }
+      else if (blk.kind == B_EXT) { const int sl = extSlot_.at(blk.id); params[b] = &he[(size_t)7 * sl]; L.off[b] = hExtOffKeep_[(size_t)sl]; L.dim[b] = 6; }
+      else { const int sl = sbSlot_.at(blk.id); params[b] = &hs[(size_t)9 * sl]; L.off[b] = hSbOffKeep_[(size_t)sl]; L.dim[b] = 9; }
+      L.ncols += L.dim[b];
+      std::memset(jac[b], 0, sizeof(jac[b]));
+    }
+    for (int b = f.nblk; b < 4; ++b) L.off[b] = -1;
+    if (!f.hostFn(f.hostUser, params, L.r, jp)) throw std::runtime_error("svin_ba: a host cost function (residual " + std::to_string(f.id) + ") reported a failure");
+    int col0 = 0;
+    for (int b = 0; b < f.nblk; ++b) {
+      for (int a = 0; a < f.m; ++a)
+        for (int c = 0; c < L.dim[b]; ++c) L.J[a * L.ncols + col0 + c] = jac[b][a * L.dim[b] + c];
+      col0 += L.dim[b];
+    }
+    HIP_OK(hipMemcpy(dst + hf.first, &L, sizeof(L), hipMemcpyHostToDevice));
+  }
+}
 // ReprojectionError<GEOMETRY>(geometry of camera `cam`, uv, information) with CauchyLoss(1) on (pose, landmark, extrinsics):
 // what Estimator::addObservation creates, with the blocks named by the caller.  The device kernels store ONE weight per
 // residual (Estimator only ever passes 64 / size^2 * I), so the information has to be a multiple of the identity.
@@ -1643,6 +1704,7 @@ void Window::pack(bool solveFollows) {
   const int L = resident ? (int)numLmObserved_ : (int)lmIds_.size(), N = resident ? (int)numObs_ : (int)hObsLm.size();
   // factors
   std::vector<DevFactor> hFac;
+  hostFactors_.clear();
   std::vector<DevImu> hImu;
   std::vector<uint32_t> hImuT;
   std::vector<double> hImuM;
@@ -1671,9 +1733,14 @@ void Window::pack(bool solveFollows) {
       hImuT.insert(hImuT.end(), f.imuT.begin(), f.imuT.end());
       hImuM.insert(hImuM.end(), f.imuMeas.begin(), f.imuMeas.end());
     }
+    if (f.kind == F_HOST) {
+      if (world_ > 1 || rcclComm_) throw std::runtime_error("svin_ba: host cost functions are not available in sharded mode");
+      hostFactors_.push_back(std::make_pair((int)hFac.size(), f.id));
+    }
     factorIds_.push_back(f.id);
     hFac.push_back(df);
   }
+  hPoseOffKeep_ = hPoseOff; hExtOffKeep_ = hExtOff; hSbOffKeep_ = hSbOff;
   if (phantom) {
     DevFactor df;
     std::memset(&df, 0, sizeof(df));
@@ -2107,6 +2174,7 @@ void Window::pack(bool solveFollows) {
   p.obsOrder = orderObs ? dObsOrder_.p : nullptr;
   p.dCPose = dCPose;
   p.lockedRows = hLocked.empty() ? nullptr : dLockedRows_.p; p.nLocked = (int)hLocked.size();
+  p.nHostFactors = (int)hostFactors_.size();
   p.poseC = dPoseC_.p; p.extC = dExtC_.p; p.sbC = dSbC_.p; p.lmC = dLmC_.p;
   p.poseOff = dPoseOff_.p; p.extOff = dExtOff_.p; p.sbOff = dSbOff_.p;
   p.cams = dCams_.p;
@@ -2298,6 +2366,7 @@ void Window::downloadStates() {
 }
 
 void Window::evaluateAll(bool cand, hipStream_t s) {
+  evaluateHostFactors(cand, s);
   prob_.mailbox = distNative_ ? nullptr : mailboxDev_;   // sharded: published after the all-reduce (launchPublishScalars)
   prob_.mailboxSeq = ++mailboxSeq_;
   const int who = costSummedBy(prob_);
@@ -2867,6 +2936,7 @@ int Window::evalFactors(int32_t* kind, int32_t* m, int32_t* ncols, double* r, do
   pack();
   const DeviceProblem& p = prob_;
   if (p.F == 0) return 0;
+  evaluateHostFactors(false, stream_);
   launchEvalFactors(p, false, stream_);
   std::vector<FactorLin> h(p.F);
   std::vector<DevImu> hImu(p.nImu);

@@ -104,6 +104,9 @@ struct Factor {
   std::vector<double> imuMeas;  // 6 per sample
   DevImu imu;                   // persistent pre-integration state (synced back after each solve)
   uint64_t dealKey = 0;         // creation number among the factors of this window (which rank owns it in sharded mode)
+  // F_HOST: the caller's cost function (svin_ba.h svin_cost_function) and its context
+  int (*hostFn)(void*, const double* const*, double*, double**) = nullptr;
+  void* hostUser = nullptr;
 };
 
 struct StateInfo { uint64_t id = 0; bool exists = false; };
@@ -226,6 +229,8 @@ class Window {
                           TimeStamp t1);                                                                         // ImuError.cpp:58-75
   uint64_t mapAddSonarError(uint64_t poseBlock, double range, double heading, double information, const double* patch, int nPatch);   // SonarError.cpp:57-183
   uint64_t mapAddDepthError(uint64_t poseBlock, double depth, double information, double firstDepth);             // DepthError.cpp:50-139
+  // a residual block whose cost function the HOST evaluates (Map::addResidualBlock with an arbitrary ::ceres::CostFunction, Map.cpp:341-376)
+  uint64_t mapAddHostResidual(const uint64_t* blockIds, int nBlocks, int residualDim, int (*fn)(void*, const double* const*, double*, double**), void* user);
   uint64_t mapAddReprojectionError(uint64_t poseBlock, uint64_t landmark, uint64_t extBlock, uint64_t cam, const double* uv,
                                    const double* information4);                                                 // ReprojectionError + CauchyLoss(1)
   int mapRemoveResidualBlock(uint64_t resId);
@@ -354,6 +359,7 @@ class Window {
   void pack(bool solveFollows = false);   // host graph -> device arrays (sets prob_); solveFollows: called by optimize()
   void downloadStates();       // device tables -> host blocks / landmarks / imu states
   void evaluateAll(bool cand, hipStream_t s);
+  void evaluateHostFactors(bool cand, hipStream_t s);   // F_HOST factors: callbacks at the current / candidate blocks, r and J into their FactorLin records
   void solve(size_t numIter, bool verbose);
   static void solveBatchGroup(const std::vector<Window*>& g, size_t numIter, bool verbose);
   void swapStateSets();   // an accepted step: the candidate sets become the current ones
@@ -501,6 +507,8 @@ class Window {
   // device buffers
   DevBuf<double> dPose_, dExt_, dSb_, dLm_, dPoseC_, dExtC_, dSbC_, dLmC_;
   DevBuf<int> dLockedRows_;
+  std::vector<std::pair<int, uint64_t>> hostFactors_;   // (index in the packed factor table, factor id) of the F_HOST factors
+  std::vector<int> hPoseOffKeep_, hExtOffKeep_, hSbOffKeep_;   // pack()'s block -> reduced-row tables (for the records of host factors)
   DevBuf<int> dPoseOff_, dExtOff_, dSbOff_, dLmPtr_, dObsLm_, dPanelWork_, dPanelChunks_, dPanelPairPtr_, dObsOrder_;
   DevBuf<int> dSlotPtr_, dSlotObsPtr_, dSlotObs_, dSlotLm_, dBlkBatch_, dBlkWaveTab_, dBlkRecSlot_;   // wide windows, block-pair Schur form: (landmark, pose) slots (kernels.hpp)
   DevBuf<unsigned short> dSlotBlk_;

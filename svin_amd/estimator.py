@@ -17,6 +17,7 @@ _LIB = None
 u64, u32, f64, i32 = C.c_uint64, C.c_uint32, C.c_double, C.c_int
 pd = C.POINTER(C.c_double)
 pu64 = C.POINTER(C.c_uint64)
+COST_FUNCTION = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(pd), pd, C.POINTER(pd))   # svin_cost_function (include/svin_ba.h)
 pi32 = C.POINTER(C.c_int32)
 
 
@@ -59,7 +60,7 @@ EXPORTS = [
     "svin_ba_get_prior", "svin_ba_describe_block", "svin_ba_bench_jacobian_eval", "svin_ba_bench_jacobian_eval_b2b", "svin_ba_set_pack_mode", "svin_ba_debug_csr", "svin_ba_residual_info",
     "svin_ba_map_add_parameter_block", "svin_ba_set_parameter_block", "svin_ba_map_remove_parameter_block", "svin_ba_map_add_pose_error",
     "svin_ba_map_add_speed_and_bias_error", "svin_ba_map_add_relative_pose_error", "svin_ba_map_add_reprojection_error",
-    "svin_ba_map_add_imu_error", "svin_ba_map_add_sonar_error", "svin_ba_map_add_depth_error",
+    "svin_ba_map_add_imu_error", "svin_ba_map_add_sonar_error", "svin_ba_map_add_depth_error", "svin_ba_map_add_host_residual",
     "svin_ba_map_remove_residual_block", "svin_ba_bench_kernel_times",
     "svin_ba_set_id_provider", "svin_ba_reserve_ids", "svin_ba_set_camera_geometry", "svin_ba_clear_cameras",
     "svin_ba_clear_imus", "svin_ba_is_landmark_initialized", "svin_ba_set_landmark_initialized", "svin_ba_get_landmarks",
@@ -181,6 +182,7 @@ def load_library():
     sig("svin_ba_map_add_imu_error", u64, vp, pu64, vp, i32, vp, u32, u32, u32, u32)
     sig("svin_ba_map_add_sonar_error", u64, vp, u64, f64, f64, f64, pd, i32)
     sig("svin_ba_map_add_depth_error", u64, vp, u64, f64, f64, f64)
+    sig("svin_ba_map_add_host_residual", u64, vp, pu64, i32, i32, COST_FUNCTION, vp)
     sig("svin_ba_map_add_reprojection_error", u64, vp, u64, u64, u64, u64, pd, pd)
     sig("svin_ba_map_remove_residual_block", i32, vp, u64)
     sig("svin_ba_debug_csr", i32, vp, pi32, pi32, pi32, pi32, C.POINTER(C.c_uint32), pd, pd, pd, pi32, pi32)
@@ -900,6 +902,39 @@ class Estimator:
 
     def map_add_depth_error(self, pose, depth, information, first_depth):
         return int(self.L.svin_ba_map_add_depth_error(self.h, pose, float(depth), float(information), float(first_depth)))
+
+    def map_add_host_residual(self, block_ids, block_dims, residual_dim, fn):
+        """svin_ba_map_add_host_residual: a residual block whose cost function Python evaluates.  fn(params) gets the blocks as a list
+        of numpy arrays (7 or 9 numbers each, in the order of block_ids) and returns (residuals, [J_0, J_1, ...]) with J_b of shape
+        residual_dim x (6 | 9) in minimal coordinates; block_dims = the 7 / 9 of each block (for unpacking the pointers)"""
+        dims = [int(d) for d in block_dims]
+        mins = [6 if d == 7 else 9 for d in dims]
+        m = int(residual_dim)
+
+        def trampoline(user, params, residuals, jacobians):
+            try:
+                ps = [np.ctypeslib.as_array(params[b], shape=(dims[b],)).copy() for b in range(len(dims))]
+                r, Js = fn(ps)
+                r = np.asarray(r, float).reshape(m)
+                for a in range(m):
+                    residuals[a] = r[a]
+                for b in range(len(dims)):
+                    J = np.asarray(Js[b], float).reshape(m, mins[b])
+                    out = np.ctypeslib.as_array(jacobians[b], shape=(m * mins[b],))
+                    out[:] = J.reshape(-1)
+                return 1
+            except Exception:   # (an exception must not cross the C boundary: reported as the cost function's failure)
+                import traceback
+                traceback.print_exc()
+                return 0
+        cb = COST_FUNCTION(trampoline)
+        ids = np.asarray(block_ids, np.uint64)
+        rid = int(self.L.svin_ba_map_add_host_residual(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(dims), m, cb, None))
+        if rid:
+            if not hasattr(self, "_host_callbacks"):
+                self._host_callbacks = {}
+            self._host_callbacks[rid] = cb   # (the library keeps the function pointer: the object must outlive the residual)
+        return rid
 
     def map_add_reprojection_error(self, pose, landmark, ext, cam, uv, information):
         u, i = _arr(uv), _arr(np.asarray(information, float).reshape(2, 2))

@@ -1,10 +1,11 @@
-// Two programs of the reference's test suite, re-created against integration/okvis/ceres/Map.hpp (the graph is built block by
+// Two programs of the reference's test suite (and a third-party error term), re-created against integration/okvis/ceres/Map.hpp (the graph is built block by
 // block through okvis::ceres::Map, solved on the GPU, the estimates are read back from the caller's parameter-block objects):
 //   part 1  okvis_ceres/test/TestHomogeneousPointError.cpp:57-99 -- 100 points, one HomogeneousPointError (variance 0.1)
 //           each, points disturbed, isJacobianCorrect per residual, solve, final_cost < 1e-10;
 //   part 2  okvis_ceres/test/TestMap.cpp:60-156 (the Pose2d re-solve of :146-156 included): pose + constant extrinsics + N CONSTANT points ("no point optimization", :93) with
 //           Cauchy-robustified ReprojectionError<equidistant pinhole>, some residuals / blocks removed again, 10 iterations,
 //           the pose must come back to the truth (quaternion 1e-2, translation 1e-1: the reference's thresholds).
+//   part 3  Map::addResidualBlock with an error term of the caller's own (ErrorInterface only: no kernel exists for it), evaluated by the host.
 // Prints one line per part for tests/test_gpu_shim.py.
 #include <okvis/MultiFrame.hpp>
 #include <okvis/ceres/Map.hpp>
@@ -33,6 +34,31 @@ void quatMul(const double a[4], const double b[4], double o[4]) {
   o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
   o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
 }
+// An error term the library has no kernel for (part 3): the distance between the positions of two poses held to a value.  Written
+// the way a third party writes one against okvis::ceres: ErrorInterface, analytic minimal Jacobians (the position part of a pose's
+// minimal coordinates is the position itself, PoseManifold.cpp:59-82).
+class DistanceError : public okvis::ceres::ErrorInterface {
+ public:
+  DistanceError(double distance, double weight) : d_(distance), w_(weight) {}
+  size_t residualDim() const override { return 1; }
+  size_t parameterBlocks() const override { return 2; }
+  size_t parameterBlockDim(size_t) const override { return 7; }
+  std::string typeInfo() const override { return "DistanceError"; }
+  bool EvaluateWithMinimalJacobians(double const* const* p, double* r, double** J, double** Jm) const override {
+    const double dx = p[1][0] - p[0][0], dy = p[1][1] - p[0][1], dz = p[1][2] - p[0][2];
+    const double n = std::sqrt(dx * dx + dy * dy + dz * dz);
+    r[0] = w_ * (n - d_);
+    const double g[3] = {w_ * dx / n, w_ * dy / n, w_ * dz / n};
+    for (int b = 0; b < 2; ++b) {
+      const double sgn = b == 0 ? -1.0 : 1.0;
+      if (J && J[b]) { for (int k = 0; k < 7; ++k) J[b][k] = k < 3 ? sgn * g[k] : 0.0; }
+      if (Jm && Jm[b]) { for (int k = 0; k < 6; ++k) Jm[b][k] = k < 3 ? sgn * g[k] : 0.0; }
+    }
+    return true;
+  }
+ private:
+  double d_, w_;
+};
 okvis::kinematics::Transformation makeT(const double r[3], const double q[4]) {
   return okvis::kinematics::Transformation(Eigen::Vector3d(r[0], r[1], r[2]), Eigen::Quaterniond(q[3], q[0], q[1], q[2]));
 }
@@ -158,6 +184,37 @@ int main() {
     std::printf("map2d final_cost %.9e initial_cost %.9e cost6 %.9e d_pos %.3e d_rot %.3e iterations %d\n", map.summary.final_cost,
                 map.summary.initial_cost, cost6, dPos, 2.0 * std::sqrt(qd2[0] * qd2[0] + qd2[1] * qd2[1] + qd2[2] * qd2[2]),
                 (int)map.summary.iterations.size() - 1);
+  }
+  {  // ---------------------------------------------------------------- part 3
+    // Map::addResidualBlock with an error term of the caller's own (Map.cpp:341-376 takes any cost function): two poses, a PoseError on
+    // each (the device's kernels), and a DistanceError between them that the HOST evaluates between the launches.  The priors want the
+    // poses 1 m apart, the distance term (weight 100 against information 1) wants 2 m: the solve must end near 2 m, and
+    // isJacobianCorrect must accept the term's Jacobians.
+    okvis::ceres::Map map;
+    const double q0[4] = {0, 0, 0, 1}, rA[3] = {0, 0, 0}, rB[3] = {1, 0.2, -0.1};
+    std::shared_ptr<okvis::ceres::PoseParameterBlock> A(new okvis::ceres::PoseParameterBlock(makeT(rA, q0), 1, okvis::Time(0, 0)));
+    std::shared_ptr<okvis::ceres::PoseParameterBlock> B(new okvis::ceres::PoseParameterBlock(makeT(rB, q0), 2, okvis::Time(0, 0)));
+    if (!map.addParameterBlock(A, okvis::ceres::Map::Pose6d) || !map.addParameterBlock(B, okvis::ceres::Map::Pose6d)) return 12;
+    Eigen::Matrix<double, 6, 6> info;   // (the stand-in Eigen of the test tree has no Identity())
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) info(a, b) = a == b ? 1.0 : 0.0;
+    std::shared_ptr<okvis::ceres::PoseError> pa(new okvis::ceres::PoseError(makeT(rA, q0), info)), pb(new okvis::ceres::PoseError(makeT(rB, q0), info));
+    if (!map.addResidualBlock(pa, NULL, A) || !map.addResidualBlock(pb, NULL, B)) return 13;
+    std::shared_ptr<DistanceError> dist(new DistanceError(2.0, 100.0));
+    ::ceres::ResidualBlockId id = map.addResidualBlock(dist, NULL, A, B);
+    if (!id) return 14;
+    const int jac = map.isJacobianCorrect(id) ? 1 : 0;
+    map.options.max_num_iterations = 20;
+    map.solve();
+    const okvis::kinematics::Transformation ea = A->estimate(), eb = B->estimate();
+    const double dd = std::sqrt((eb.r()[0] - ea.r()[0]) * (eb.r()[0] - ea.r()[0]) + (eb.r()[1] - ea.r()[1]) * (eb.r()[1] - ea.r()[1]) +
+                                (eb.r()[2] - ea.r()[2]) * (eb.r()[2] - ea.r()[2]));
+    const bool removed = map.removeResidualBlock(id);
+    map.solve();   // without the term the priors pull the poses back
+    const okvis::kinematics::Transformation fa = A->estimate(), fb = B->estimate();
+    const double d2 = std::sqrt((fb.r()[0] - fa.r()[0]) * (fb.r()[0] - fa.r()[0]) + (fb.r()[1] - fa.r()[1]) * (fb.r()[1] - fa.r()[1]) +
+                                (fb.r()[2] - fa.r()[2]) * (fb.r()[2] - fa.r()[2]));
+    std::printf("host jac_ok %d distance %.6f final_cost %.6e initial_cost %.6e removed %d distance_after_removal %.6f\n", jac, dd, map.summary.final_cost,
+                map.summary.initial_cost, removed ? 1 : 0, d2);
   }
   return 0;
 }

@@ -302,3 +302,88 @@ def test_reduced_pose_manifolds_match_the_oracle_and_the_definition(gpu_lib, man
     assert est.reset_parameterization(2, est.POSE6D)
     est.optimize(500)
     assert est.summary()["final_cost"] < s["final_cost"] * (1 - 1e-6)
+
+
+def test_host_cost_functions_match_the_builtin_error_terms(gpu_lib):
+    """Map::addResidualBlock with a cost function the library has no kernel for (Map.cpp:341-376; svin_ba_map_add_host_residual): the
+    host evaluates it before every evaluation launch.  Pinned against the library's own error terms: a PoseError and a
+    SpeedAndBiasError added (a) as the built-in factors and (b) as Python cost functions that return the same residuals and
+    minimal Jacobians (PoseError through its CPU twin svin_host_pose_error, SpeedAndBiasError from its definition,
+    SpeedAndBiasError.cpp:83-113) must give the same solve -- plus a cost function no kernel exists for (the distance between two
+    frames held to a value), checked by what it is supposed to achieve."""
+    from svin_amd import estimator
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=6, L=300, n_obs=3000, seed=21)
+
+    def build():
+        est = Estimator(0)
+        fids, lids = syn.feed(est, spec)
+        sb = {}
+        for bid in est.parameter_block_ids():
+            d = est.describe_block(bid)
+            if d is not None and d[1] == 2:
+                sb[d[0]] = bid
+        return est, fids, lids, sb
+
+    rng = np.random.default_rng(3)
+    a, fa, la, sba = build()
+    b, fb, lb, sbb = build()
+    assert fa == fb and sba == sbb
+    pose_meas = a.get_T_WS(fa[3]) + np.r_[0.05, -0.03, 0.02, 0, 0, 0, 0]
+    A6 = rng.standard_normal((6, 6))
+    pose_info = A6 @ A6.T + 50.0 * np.eye(6)
+    sb_meas = a.get_speed_and_bias(fa[2]) + 0.01 * rng.standard_normal(9)
+    A9 = rng.standard_normal((9, 9))
+    sb_info = A9 @ A9.T + 200.0 * np.eye(9)
+    assert a.map_add_pose_error(fa[3], pose_meas, pose_info) != 0
+    assert a.map_add_speed_and_bias_error(sba[fa[2]], sb_meas, sb_info) != 0
+    W9 = np.linalg.cholesky(sb_info).T          # e = meas - x, r = L^T e (SpeedAndBiasError.cpp:60-67, :95-103)
+    calls = {"pose": 0, "sb": 0}
+
+    def pose_cost(ps):
+        calls["pose"] += 1
+        r, Jm, _ = estimator.host_pose_error(pose_meas, pose_info, ps[0])
+        return r, [Jm]
+
+    def sb_cost(ps):
+        calls["sb"] += 1
+        return W9 @ (sb_meas - ps[0]), [-W9]
+
+    assert b.map_add_host_residual([fb[3]], [7], 6, pose_cost) != 0
+    rid_sb = b.map_add_host_residual([sbb[fb[2]]], [9], 9, sb_cost)
+    assert rid_sb != 0 and rid_sb in b.residuals_of(sbb[fb[2]])
+    # refused: an unknown block, a landmark, a block twice, too many residuals
+    assert b.map_add_host_residual([999999], [7], 6, pose_cost) == 0
+    assert b.map_add_host_residual([lb[0]], [7], 3, pose_cost) == 0
+    assert b.map_add_host_residual([fb[1], fb[1]], [7, 7], 3, pose_cost) == 0
+    assert b.map_add_host_residual([fb[1]], [7], 16, pose_cost) == 0
+    for e in (a, b):
+        e.set_solver_options(1e-14, 1e-14, 1e-14)
+        e.optimize(12)
+    sa, sb_ = a.summary(), b.summary()
+    print("built-in", sa["final_cost"], sa["iterations"], "host", sb_["final_cost"], sb_["iterations"], "callbacks", calls)
+    assert calls["pose"] >= sb_["iterations"] + 1 and calls["sb"] == calls["pose"]
+    assert sa["iterations"] == sb_["iterations"] and abs(sa["final_cost"] - sb_["final_cost"]) < 1e-10 * sa["final_cost"]
+    for f1, f2 in zip(fa, fb):
+        assert np.max(np.abs(a.get_T_WS(f1) - b.get_T_WS(f2))) < 1e-9
+        assert np.max(np.abs(a.get_speed_and_bias(f1) - b.get_speed_and_bias(f2))) < 1e-8
+    # a cost function of the caller's own: the distance between frames 1 and 4 held to 1.5 m (weight 1e3)
+    c, fc, _, _ = build()
+    target, w = 1.5, 1e3
+
+    def distance_cost(ps):
+        d = ps[1][:3] - ps[0][:3]
+        n = np.linalg.norm(d)
+        J0, J1 = np.zeros((1, 6)), np.zeros((1, 6))
+        J0[0, :3], J1[0, :3] = -w * d / n, w * d / n
+        return [w * (n - target)], [J0, J1]
+
+    before = np.linalg.norm(c.get_T_WS(fc[4])[:3] - c.get_T_WS(fc[1])[:3])
+    assert c.map_add_host_residual([fc[1], fc[4]], [7, 7], 1, distance_cost) != 0
+    c.optimize(15)
+    after = np.linalg.norm(c.get_T_WS(fc[4])[:3] - c.get_T_WS(fc[1])[:3])
+    print("distance between frames 1 and 4:", before, "->", after)
+    assert abs(before - target) > 0.05 and abs(after - target) < 5e-3
+    # such a window does not marginalise (the linearisation of a host residual is not available to the M1 kernels): a clean error
+    with pytest.raises(RuntimeError):
+        c.apply_marginalization(2, 2)

@@ -150,3 +150,8 @@ def test_reference_shaped_map_programs_run_on_the_gpu(gpu_lib, tmp_path):
     m2 = kv(lines["map2d"])
     assert float(m2["d_pos"]) == 0.0 and float(m2["final_cost"]) < float(m2["initial_cost"])
     assert float(m2["final_cost"]) < float(m2["cost6"]) * (1 + 1e-3) and float(m2["d_rot"]) < 1e-2
+    # part 3: an error term no kernel exists for, evaluated by the host between the launches (Map.cpp:341-376 accepts any cost function)
+    hs = kv(lines["host"])
+    assert int(hs["jac_ok"]) == 1 and int(hs["removed"]) == 1
+    assert abs(float(hs["distance"]) - 2.0) < 1e-3 and float(hs["final_cost"]) < float(hs["initial_cost"])
+    assert abs(float(hs["distance_after_removal"]) - np.sqrt(1 + 0.04 + 0.01)) < 1e-6
