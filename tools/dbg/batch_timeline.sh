@@ -1,4 +1,4 @@
-# round-6 scratch run: timeline of the batched solve (lanes given by $1, B = 16)
+# (gpurun helper) timeline of the batched solve (lanes given by $1, B = 16)
 mkdir -p gpurun_out/r06
 cd /tmp && export TMPDIR=/tmp
 for l in $1; do

@@ -1,4 +1,4 @@
-# round-6 scratch run: the wide window (config #4 shape) with / without the early speed-bias chain, tests of the wide paths, kernel table
+# (gpurun helper) the wide window (config #4 shape) with / without the early speed-bias chain, tests of the wide paths, kernel table
 mkdir -p gpurun_out/r06
 SVIN_WIDE_BENCH=1 python tools/widetime.py 2>&1 | grep "solve(5)"
 SVIN_NO_SB_EARLY=1 SVIN_WIDE_BENCH=1 python tools/widetime.py 2>&1 | grep "solve(5)"

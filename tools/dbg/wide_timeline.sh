@@ -1,4 +1,4 @@
-# round-6 scratch run: launch timeline of the wide window (both streams)
+# (gpurun helper) launch timeline of the wide window (both streams)
 mkdir -p gpurun_out/r06
 cd /tmp && export TMPDIR=/tmp
 SVIN_WIDE_BENCH=1 rocprofv3 --kernel-trace --stats -d /tmp/wt -o w -- python $GRAFT_REPO_ROOT/tools/widetime.py > /tmp/wt.log 2>&1
