@@ -3731,6 +3731,12 @@ void launchAccumulateNormalEquations(const DeviceProblem& p, double mu, bool ini
     // Round 4 (config #4, build of the normal equations 1.01 ms -> 0.67 ms, A/B in one gpurun call): two workgroups per CU instead
     // of one (0.79: 86 spilled registers with the next chunk's first observation prefetched, 0.73 without the prefetch and without
     // spills), per-landmark quantities from k_panels_landmarks instead of once per panel pair (0.67).
+    // (Measured for the DENSE form too, configs[2]: factors and chain on the side stream beside k_schur_dense<10, true, 8> -- 0.209 ms
+    //  per iteration against 0.191.  A launch's workgroups are dealt round robin over the eight XCDs; 250 chunk workgroups fill two
+    //  XCDs completely (32 CUs each, one workgroup of 512 threads x 256 registers per CU), and the side kernels' workgroups dealt
+    //  to those XCDs wait for the chunk kernel to end -- k_factors_only then ends 10 us AFTER k_schur_dense instead of inside it.
+    //  Concurrency across streams needs free room in EVERY XCD; the wide form below gains only what no longer sits between the
+    //  slab sum and the solve.)
     // Round 6: the block-pair form (k_blocks_slots + k_schur_rows) is the default; pack() decides (DeviceProblem::schurBlocks,
     // its slot tables) -- SVIN_PANELS_OLD=1 at pack() time keeps the round-4 / 5 tile form, whose work list holds fewer chunks per
     // workgroup.
