@@ -387,3 +387,58 @@ def test_host_cost_functions_match_the_builtin_error_terms(gpu_lib):
     # such a window does not marginalise (the linearisation of a host residual is not available to the M1 kernels): a clean error
     with pytest.raises(RuntimeError):
         c.apply_marginalization(2, 2)
+
+
+def test_reduced_manifold_on_an_extrinsics_block_and_host_residual_with_a_constant_block(gpu_lib):
+    """(a) Pose3d on a per-frame EXTRINSICS block of a stereo_rig_v2 window (variable extrinsics: the dense Schur form with extrinsics
+    rows, the border / chain solvers): its position must stay bit for bit while its orientation and everything else move, and a second
+    handle without the manifold must end elsewhere; (b) a host residual over a CONSTANT block and a variable one: the constant
+    block's Jacobian is ignored (off = -1 in the record), the variable block still feels the term."""
+    from svin_amd.estimator import Estimator
+    spec = syn.make_window(P=5, L=300, n_obs=3000, seed=17, rig="rig_v2")
+
+    def build():
+        est = Estimator(0)
+        fids, lids = syn.feed(est, spec)
+        ext = {}
+        for bid in est.parameter_block_ids():
+            d = est.describe_block(bid)
+            if d is not None and d[1] == 1:
+                ext[(d[0], d[2])] = bid
+        return est, fids, ext
+
+    a, fa, exa = build()
+    b, fb, exb = build()
+    key = (fa[2], 0)
+    bid = exa[key]
+    assert not a.is_parameter_block_constant(bid), "the rig must have variable extrinsics for this test"
+    T0 = a.get_parameter_block(bid).copy()
+    assert a.reset_parameterization(bid, a.POSE3D)
+    a.optimize(8)
+    b.optimize(8)
+    Ta, Tb = a.get_parameter_block(bid), b.get_parameter_block(exb[key])
+    print("extrinsics", T0, "->", Ta, "(6-DoF:", Tb, ")")
+    assert np.array_equal(Ta[:3], T0[:3]) and not np.array_equal(Ta[3:], T0[3:])
+    assert not np.array_equal(Tb[:3], T0[:3])
+    assert a.summary()["final_cost"] < a.summary()["initial_cost"]
+    # (b)
+    c, fc, _ = build()
+    assert c.set_parameter_block_constant(fc[0])
+    w, target = 1e3, 0.9
+    seen = []
+
+    def distance_cost(ps):
+        d = ps[1][:3] - ps[0][:3]
+        n = np.linalg.norm(d)
+        J0, J1 = np.zeros((1, 6)), np.zeros((1, 6))
+        J0[0, :3], J1[0, :3] = 1e6 * np.ones(3), w * d / n     # (the constant block's Jacobian: garbage on purpose)
+        seen.append(ps[0].copy())
+        return [w * (n - target)], [J0, J1]
+
+    P0 = c.get_T_WS(fc[0]).copy()
+    assert c.map_add_host_residual([fc[0], fc[2]], [7, 7], 1, distance_cost) != 0
+    c.optimize(15)
+    assert np.array_equal(c.get_T_WS(fc[0]), P0) and all(np.array_equal(s, seen[0]) for s in seen)
+    after = np.linalg.norm(c.get_T_WS(fc[2])[:3] - P0[:3])
+    print("distance to the constant frame:", after)
+    assert abs(after - target) < 5e-3
