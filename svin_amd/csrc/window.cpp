@@ -2585,7 +2585,9 @@ void Window::swapStateSets() {
 // window's decision from its own mailbox record exactly as solve() does; a window whose step was rejected takes the round's
 // k_step_retract launch instead of the build / solve / post-solve launches, a window that has terminated takes none.  No
 // speculative build: measured (round 6, B = 16 in four lanes) 6.9 x one window with it against 7.4 x without -- the lanes keep the
-// chip busy, so the builds of steps that end up rejected are work added, not latency hidden.  The arithmetic of a window is the
+// chip busy, so the builds of steps that end up rejected are work added, not latency hidden.  For the same reason issuing the initial
+// evaluation and the first round together (two slot tables, two mailbox records in flight; one host turnaround of eleven saved)
+// gains nothing: 6.8 x against 7.1 x at B = 16, 8.3 / 9.0 x at 32 / 64 either way -- measured, not kept.  The arithmetic of a window is the
 // arithmetic of solve(): same kernels bodies, same grids (gridDim.x), same reduction orders.
 namespace {
 struct BatchKey {
