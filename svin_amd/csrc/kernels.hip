@@ -26,6 +26,12 @@
 #include <unordered_map>
 #include "tile16.hpp"
 
+#ifndef SVIN_BATCH_OCC_SCHUR
+#define SVIN_BATCH_OCC_SCHUR 2   // waves per SIMD the batched Schur / post-solve forms are held to (register budget 512 / n)
+#endif
+#ifndef SVIN_BATCH_OCC_POST
+#define SVIN_BATCH_OCC_POST 2
+#endif
 namespace svin {
 
 // hipFuncSetAttribute once per kernel and size (it is a driver call: ~2 us on the host path of every launch otherwise)
@@ -2738,7 +2744,7 @@ template <int MAXT, bool A_MFMA, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void k_schur_dense(DeviceProblem p, double mu, int initScale, int nChunkBlocks, int nFacBlocks) { k_schur_dense_body<MAXT, A_MFMA, NW>(p, mu, initScale, nChunkBlocks, nFacBlocks); }
 // (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
 template <int MAXT, bool A_MFMA, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_schur_dense_batch(const BatchSlot* __restrict__ slots, int nChunkBlocks, int nFacBlocks) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? SVIN_BATCH_OCC_SCHUR : 1) void k_schur_dense_batch(const BatchSlot* __restrict__ slots, int nChunkBlocks, int nFacBlocks) {
   const BatchSlot& sl = batchSlot(slots);
   if (!(sl.stages & kBatchFull)) return;
   k_schur_dense_body<MAXT, A_MFMA, NW>(sl.p, sl.mu, sl.initScale, nChunkBlocks, nFacBlocks);
@@ -7293,7 +7299,7 @@ template <bool WITH_EXT>
 __global__ __launch_bounds__(256, 2) void k_post_solve_wide(DeviceProblem p, int nLmBlocks, int nFacBlocks, double fuseRadius) { k_post_solve_body<WITH_EXT>(p, nLmBlocks, nFacBlocks, fuseRadius); }
 // (batched form: blockIdx.y = the window of the batch, its problem and trust-region scalars from the slot table)
 template <bool WITH_EXT>
-__global__ __launch_bounds__(256, 2) void k_post_solve_batch(const BatchSlot* __restrict__ slots, int nLmBlocks, int nFacBlocks) {
+__global__ __launch_bounds__(256, SVIN_BATCH_OCC_POST) void k_post_solve_batch(const BatchSlot* __restrict__ slots, int nLmBlocks, int nFacBlocks) {
   const BatchSlot& sl = batchSlot(slots);
   if (!(sl.stages & kBatchFull)) return;
   k_post_solve_body<WITH_EXT>(sl.p, nLmBlocks, nFacBlocks, sl.radius);
