@@ -432,7 +432,7 @@ def sliding_window_record(device, with_oracle=True, rig="euroc"):
     return rec
 
 
-def batched_record(device, sizes=(16, 64), steps=12, warmup=3):
+def batched_record(device, sizes=(16, 32, 64), steps=12, warmup=3):
     """B independent configs[1] windows (their own seeds) through svin_ba_solve_prepared_batch: ONE launch sequence per trust-region
     round, the window as a grid dimension ("independent replicas processing different windows", on one GPU).  Per step
     every window starts from its own initial state, is packed and uploaded untimed (inputs resident in HBM), and the batch call is
@@ -609,6 +609,7 @@ def summary_of(out):
         "handles8_x": (round(out["concurrent"]["handles_8"]["aggregate"] / out["concurrent"]["handles_8"]["one_handle_alone"], 3)
                        if get("concurrent", "handles_8", "aggregate") and get("concurrent", "handles_8", "one_handle_alone") else None),
         "batched16_aggregate_its": get("batched", "B16", "aggregate"), "batched16_x": get("batched", "B16", "x_one_window"),
+        "batched32_aggregate_its": get("batched", "B32", "aggregate"), "batched32_x": get("batched", "B32", "x_one_window"),
         "batched64_aggregate_its": get("batched", "B64", "aggregate"), "batched64_x": get("batched", "B64", "x_one_window"),
         "k1_frac_b2b": get("roofline", "frac"), "k1_frac_survey_bytes": get("roofline", "frac_survey_bytes"),
         "k1_frac_4GB": get("roofline", "replicas_1024", "frac"),
