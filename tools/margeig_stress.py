@@ -1,5 +1,5 @@
 """Runs sliding windows (optimize + applyMarginalizationStrategy per frame) over several seeds and rigs with the default
-prior eigen-solver (Cholesky-preconditioned Jacobi) and with the plain one-sided Jacobi (SVIN_MARG_EIG=twophase / single),
+prior eigen-solver (Cholesky-preconditioned Jacobi) and with the plain one-sided Jacobi (SVIN_MARG_EIG=cholesky: the round-4 chain),
 and reports rank and pose agreement of the two."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -29,12 +29,12 @@ if __name__ == "__main__":
         for seed in range(1, 6):
             spec = syn.make_window(P=16, L=600, n_obs=6000, seed=seed, rig=rig, keyframe_every=2, frame_dt=0.25)
             ra, pa = run(spec, window, None)
-            rb, pb = run(spec, window, "twophase")
+            rb, pb = run(spec, window, "cholesky")
             d = float(np.max(np.abs(pa - pb)))
             worst = max(worst, d)
             same = ra == rb
             print("%-7s window %s seed %d: prior sizes %s rank sequences equal %s, max |pose difference| %.2e" %
                   (rig, window, seed, sorted(set(n for n, _ in ra)), same, d), flush=True)
             if not same:
-                print("   default:", ra, "\n   twophase:", rb)
+                print("   default:", ra, "\n   cholesky (round-4 Jacobi chain):", rb)
     print("worst pose difference", worst)
